@@ -1,0 +1,1389 @@
+/*
+ * impg_oracle.cpp -- CPU ORACLE: a plain restatement of the reference's
+ * interval-query + CIGAR-projection + transitive-closure + BED-merge path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see impg_oracle.h).  Every function cites the
+ * reference lines (pangenome/impg 0.5.0, paths relative to /root/reference)
+ * it follows.  The code is deliberately literal and slow: sequential loops,
+ * std::vector, no tricks.  Nothing here is shared with the HIP engine.
+ *
+ * Third-party arithmetic restated from its published algorithm (sources are
+ * not in the reference tree):
+ *   coitrees 0.4.0 (Cargo.lock:643-646) BasicCOITree  -> struct COITree below.
+ *     Only the *visit order* of query() matters to impg; it is restated as
+ *     "pre-order over the implicit midpoint BST, except subtrees laid out as
+ *     'simple' (<= 8 nodes, reached with childless=true in veb_order_recursion)
+ *     which are scanned in sorted order".  VISIT-ORDER PARITY UNPINNED: no
+ *     reference test observes it.
+ *   rayon par_sort_by_key  -> std::stable_sort (rayon's is documented stable).
+ *   rustc-hash FxHashMap iteration order decides impg's sequence ids
+ *     (main.rs:11519-11540); ids cross the boundary as data, here they are
+ *     assigned in first-seen order.
+ */
+#include "impg_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fcntl.h>
+#include <functional>
+#include <map>
+#include <string>
+#include <thread>
+#include <unistd.h>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+thread_local uint64_t g_nproj = 0;
+
+void set_err(const std::string &s) { g_err = s; }
+
+/* ------------------------------------------------------------------------ */
+/* CigarOp (impg.rs:75-140)                                                  */
+/* ------------------------------------------------------------------------ */
+bool cigar_new(int32_t len, char op, uint32_t *out) {
+  uint32_t val;
+  switch (op) { /* impg.rs:82-89 */
+  case '=': val = 0; break;
+  case 'X': val = 1; break;
+  case 'I': val = 2; break;
+  case 'D': val = 3; break;
+  case 'M': val = 4; break;
+  default: return false; /* panic!("Invalid CIGAR operation") */
+  }
+  *out = (val << 29) | (uint32_t)len; /* impg.rs:91 */
+  return true;
+}
+inline char cigar_op(uint32_t v) { /* impg.rs:95-105 */
+  switch (v >> 29) {
+  case 0: return '=';
+  case 1: return 'X';
+  case 2: return 'I';
+  case 3: return 'D';
+  case 4: return 'M';
+  default: return '?';
+  }
+}
+inline int32_t cigar_len(uint32_t v) { return (int32_t)(v & ((1u << 29) - 1)); } /* :107-109 */
+inline int32_t target_delta(uint32_t v) { /* impg.rs:115-121 */
+  char o = cigar_op(v);
+  return (o == '=' || o == 'X' || o == 'D' || o == 'M') ? cigar_len(v) : 0;
+}
+inline int32_t query_delta(uint32_t v, bool reverse) { /* impg.rs:123-135 */
+  char o = cigar_op(v);
+  if (o == '=' || o == 'X' || o == 'I' || o == 'M') return reverse ? -cigar_len(v) : cigar_len(v);
+  return 0;
+}
+inline uint32_t adjust_len(uint32_t v, int32_t delta) { /* impg.rs:137-139 */
+  return (v & (7u << 29)) | (uint32_t)(cigar_len(v) + delta);
+}
+
+/* parse_cigar_to_delta (impg.rs:2935-2950) */
+bool parse_cigar_to_delta(const char *s, size_t n, std::vector<uint32_t> &ops) {
+  ops.clear();
+  int32_t len = 0;
+  for (size_t i = 0; i < n; i++) {
+    unsigned char c = (unsigned char)s[i];
+    if (c >= '0' && c <= '9') {
+      len = len * 10 + (int32_t)(c - '0');
+    } else {
+      uint32_t v;
+      if (!cigar_new(len, (char)c, &v)) return false;
+      ops.push_back(v);
+      len = 0;
+    }
+  }
+  return true;
+}
+
+/* invert_cigar_ops_in_place (impg.rs:144-156) */
+void invert_cigar_ops_in_place(std::vector<uint32_t> &ops, bool strand_reverse) {
+  for (auto &op : ops) {
+    char o = cigar_op(op);
+    char n = o == 'I' ? 'D' : (o == 'D' ? 'I' : o);
+    uint32_t v = 0;
+    cigar_new(cigar_len(op), n, &v);
+    op = v;
+  }
+  if (strand_reverse) std::reverse(ops.begin(), ops.end());
+}
+
+/* project_target_range_through_alignment (impg.rs:2760-2898) */
+struct Projection {
+  int32_t q_start, q_end, t_start, t_end;
+  std::vector<uint32_t> cigar;
+};
+bool project_target_range_through_alignment(int32_t r0, int32_t r1, int32_t target_start,
+                                            int32_t target_end, int32_t query_start,
+                                            int32_t query_end, bool reverse,
+                                            const uint32_t *cigar_ops, size_t n_ops,
+                                            Projection &out) {
+  const int32_t dir = reverse ? -1 : 1;               /* :2777 */
+  int32_t query_pos = reverse ? query_end : query_start; /* :2778-2782 */
+  int32_t target_pos = target_start;
+  size_t first_op_idx = 0, last_op_idx = 0;
+  bool found_overlap = false;
+  int32_t projected_query_start = -1, projected_query_end = -1;
+  int32_t projected_target_start = -1, projected_target_end = -1;
+  int32_t first_op_offset = 0, last_op_remaining = 0;
+  const int32_t last_target_pos = std::min(target_end, r1); /* :2798 */
+
+  for (size_t curr_op_idx = 0; curr_op_idx < n_ops; curr_op_idx++) {
+    if (target_pos > last_target_pos) break; /* :2802 */
+    const uint32_t op = cigar_ops[curr_op_idx];
+    const int32_t td = target_delta(op), qd = query_delta(op, reverse);
+    if (td == 0) { /* :2807-2821 */
+      if (target_pos >= r0) {
+        if (!found_overlap) {
+          projected_query_start = query_pos;
+          projected_target_start = target_pos;
+          first_op_idx = curr_op_idx;
+          found_overlap = true;
+        }
+        projected_query_end = query_pos + qd;
+        projected_target_end = target_pos;
+        last_op_idx = curr_op_idx + 1;
+      }
+      query_pos += qd;
+    } else if (qd == 0) { /* :2822-2841 */
+      const int32_t overlap_start = std::max(target_pos, r0);
+      const int32_t overlap_end = std::min(target_pos + td, last_target_pos);
+      if (overlap_start < overlap_end) {
+        if (!found_overlap) {
+          projected_query_start = query_pos;
+          projected_target_start = overlap_start;
+          first_op_idx = curr_op_idx;
+          first_op_offset = overlap_start - target_pos;
+          found_overlap = true;
+        }
+        projected_query_end = query_pos;
+        projected_target_end = overlap_end;
+        last_op_idx = curr_op_idx + 1;
+        last_op_remaining = overlap_end - (target_pos + td);
+      }
+      target_pos += td;
+    } else { /* :2842-2867 */
+      const int32_t overlap_start = std::max(target_pos, r0);
+      const int32_t overlap_end = std::min(target_pos + td, r1);
+      if (overlap_start < overlap_end) {
+        const int32_t overlap_length = overlap_end - overlap_start;
+        const int32_t query_overlap_start = query_pos + (overlap_start - target_pos) * dir;
+        const int32_t query_overlap_end = query_overlap_start + overlap_length * dir;
+        if (!found_overlap) {
+          projected_query_start = query_overlap_start;
+          projected_target_start = overlap_start;
+          first_op_idx = curr_op_idx;
+          first_op_offset = overlap_start - target_pos;
+          found_overlap = true;
+        }
+        projected_query_end = query_overlap_end;
+        projected_target_end = overlap_end;
+        last_op_idx = curr_op_idx + 1;
+        last_op_remaining = overlap_end - (target_pos + td);
+      }
+      target_pos += td;
+      query_pos += qd;
+    }
+  }
+  if (found_overlap && projected_query_start != projected_query_end &&
+      projected_target_start != projected_target_end) { /* :2874-2877 */
+    out.cigar.assign(cigar_ops + first_op_idx, cigar_ops + last_op_idx);
+    if (first_op_offset > 0) out.cigar[0] = adjust_len(out.cigar[0], -first_op_offset);
+    if (last_op_remaining < 0) {
+      size_t k = last_op_idx - first_op_idx - 1;
+      out.cigar[k] = adjust_len(out.cigar[k], last_op_remaining);
+    }
+    out.q_start = projected_query_start;
+    out.q_end = projected_query_end;
+    out.t_start = projected_target_start;
+    out.t_end = projected_target_end;
+    return true;
+  }
+  return false;
+}
+
+/* calculate_gap_compressed_identity (impg.rs:2952-2973) */
+double gap_compressed_identity(const uint32_t *ops, size_t n) {
+  int32_t m = 0, mm = 0, ins = 0, del = 0;
+  for (size_t i = 0; i < n; i++) {
+    int32_t len = cigar_len(ops[i]);
+    switch (cigar_op(ops[i])) {
+    case 'M': case '=': m += len; break;
+    case 'X': mm += len; break;
+    case 'I': ins += 1; break;
+    case 'D': del += 1; break;
+    default: break;
+    }
+  }
+  int32_t total = m + mm + ins + del;
+  if (total == 0) return 0.0;
+  return (double)m / (double)total;
+}
+
+/* ------------------------------------------------------------------------ */
+/* SortedRanges (impg.rs:242-369)                                            */
+/* ------------------------------------------------------------------------ */
+struct SortedRanges {
+  std::vector<std::pair<int32_t, int32_t>> ranges;
+  int32_t sequence_length = 0;
+  int32_t min_distance = 0;
+
+  /* Rust binary_search_by_key(&start, |&(s,_)| s): Ok(pos)|Err(pos); starts are
+   * strictly increasing in a SortedRanges so both are the lower bound. */
+  size_t bsearch(int32_t start) const {
+    size_t lo = 0, hi = ranges.size();
+    while (lo < hi) {
+      size_t mid = lo + (hi - lo) / 2;
+      if (ranges[mid].first < start) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  }
+  void merge_forward_from(size_t start_idx) { /* :355-368 */
+    size_t write = start_idx, read = start_idx + 1;
+    while (read < ranges.size()) {
+      if (ranges[write].second >= ranges[read].first) {
+        ranges[write].second = std::max(ranges[write].second, ranges[read].second);
+      } else {
+        write += 1;
+        std::swap(ranges[write], ranges[read]);
+      }
+      read += 1;
+    }
+    ranges.resize(write + 1);
+  }
+  std::vector<std::pair<int32_t, int32_t>> insert(std::pair<int32_t, int32_t> new_range) { /* :270-353 */
+    int32_t start, end;
+    if (new_range.first <= new_range.second) { start = new_range.first; end = new_range.second; }
+    else { start = new_range.second; end = new_range.first; }
+    size_t i = bsearch(start);
+    if (i > 0 && std::abs(start - ranges[i - 1].second) < min_distance) { /* :284 */
+      start = ranges[i - 1].second;
+      i -= 1;
+    } else if (start < min_distance) {
+      start = 0;
+    }
+    if (i < ranges.size() && std::abs(ranges[i].first - end) < min_distance) { /* :292 */
+      end = ranges[i].first;
+    } else if (end > (sequence_length - min_distance)) {
+      end = sequence_length;
+    }
+    std::vector<std::pair<int32_t, int32_t>> non_overlapping;
+    int32_t current = start;
+    i = bsearch(start); /* :303 */
+    if (i > 0 && ranges[i - 1].second > start) i -= 1;
+    while (i < ranges.size() && current < end) { /* :314 */
+      int32_t range_start = ranges[i].first, range_end = ranges[i].second;
+      if (range_start > end) break;
+      if (current < range_start) non_overlapping.push_back({current, range_start});
+      current = std::max(current, range_end);
+      i += 1;
+    }
+    if (current < end) non_overlapping.push_back({current, end});
+    size_t pos = bsearch(start); /* :330 */
+    if (pos > 0 && ranges[pos - 1].second >= start) {
+      ranges[pos - 1].second = std::max(ranges[pos - 1].second, end);
+      merge_forward_from(pos - 1);
+    } else if (pos < ranges.size() && end >= ranges[pos].first) {
+      ranges[pos].first = std::min(start, ranges[pos].first);
+      ranges[pos].second = std::max(end, ranges[pos].second);
+      merge_forward_from(pos);
+    } else {
+      ranges.insert(ranges.begin() + pos, {start, end});
+    }
+    return non_overlapping;
+  }
+};
+
+/* ------------------------------------------------------------------------ */
+/* SequenceIndex (seqidx.rs:4-56)                                            */
+/* ------------------------------------------------------------------------ */
+struct SequenceIndex {
+  std::unordered_map<std::string, uint32_t> name_to_id;
+  std::vector<std::string> id_to_name;
+  std::vector<int64_t> id_to_len; /* -1 = None */
+  uint32_t get_or_insert_id(const std::string &name, int64_t length) { /* :22-34 */
+    auto it = name_to_id.find(name);
+    uint32_t id;
+    if (it == name_to_id.end()) {
+      id = (uint32_t)id_to_name.size();
+      name_to_id.emplace(name, id);
+      id_to_name.push_back(name);
+      id_to_len.push_back(-1);
+    } else id = it->second;
+    if (length >= 0 && id_to_len[id] < 0) id_to_len[id] = length; /* first length wins */
+    return id;
+  }
+};
+
+/* AlignmentRecord (alignment_record.rs:12-22) */
+struct AlignmentRecord {
+  uint32_t query_id;
+  uint64_t query_start, query_end;
+  uint32_t target_id;
+  uint64_t target_start, target_end;
+  uint64_t strand_and_data_offset;
+  uint64_t data_bytes;
+};
+const uint64_t STRAND_BIT = 0x8000000000000000ull;   /* impg.rs:178 */
+const uint64_t REVERSED_BIT = 0x4000000000000000ull; /* impg.rs:179 */
+
+/* QueryMetadata (impg.rs:164-174) */
+struct QueryMetadata {
+  uint32_t query_id;
+  int32_t target_start, target_end, query_start, query_end;
+  uint32_t alignment_file_index;
+  uint64_t strand_and_data_offset;
+  uint64_t data_bytes;
+  bool strand_reverse() const { return (strand_and_data_offset & STRAND_BIT) != 0; }
+  bool is_reversed() const { return (strand_and_data_offset & REVERSED_BIT) != 0; }
+  uint64_t data_offset() const { return strand_and_data_offset & ~(STRAND_BIT | REVERSED_BIT); }
+};
+struct IvNode {
+  int32_t first, last;
+  QueryMetadata metadata;
+};
+
+/* ------------------------------------------------------------------------ */
+/* coitrees 0.4.0 BasicCOITree, restated (see file header).                  */
+/* ------------------------------------------------------------------------ */
+const size_t SIMPLE_SUBTREE_CUTOFF = 8;
+struct COITree {
+  std::vector<IvNode> nodes;         /* sorted by `first`, ties in input order */
+  std::vector<int32_t> subtree_last; /* per sorted index: max last over its subtree */
+  std::vector<uint8_t> simple_root;  /* per sorted index: root of a 'simple' unit */
+
+  static size_t root_of(size_t s, size_t e) { return s + (e - s) / 2; } /* traverse_recursion */
+
+  int32_t traverse(size_t s, size_t e, uint32_t depth, uint32_t &max_depth) {
+    size_t r = root_of(s, e);
+    if (depth > max_depth) max_depth = depth;
+    int32_t sl = nodes[r].last;
+    if (r > s) sl = std::max(sl, traverse(s, r, depth + 1, max_depth));
+    if (r + 1 < e) sl = std::max(sl, traverse(r + 1, e, depth + 1, max_depth));
+    subtree_last[r] = sl;
+    return sl;
+  }
+  /* mark the complete subtrees rooted `levels` below [s,e)'s root */
+  void for_subtrees_at(size_t s, size_t e, uint32_t depth, uint32_t want, uint32_t max_depth) {
+    if (s >= e) return;
+    if (depth == want) { veb(s, e, want, max_depth); return; }
+    size_t r = root_of(s, e);
+    for_subtrees_at(s, r, depth + 1, want, max_depth);
+    for_subtrees_at(r + 1, e, depth + 1, want, max_depth);
+  }
+  /* veb_order_recursion restricted to the childless=true chain: only such
+   * units can become 'simple' (top parts recurse with childless=false). */
+  void veb(size_t s, size_t e, uint32_t min_depth, uint32_t max_depth) {
+    size_t n = e - s;
+    if (n <= SIMPLE_SUBTREE_CUTOFF) { simple_root[root_of(s, e)] = 1; return; }
+    uint32_t pivot_depth = min_depth + (max_depth - min_depth) / 2;
+    for_subtrees_at(s, e, min_depth, pivot_depth + 1, max_depth);
+  }
+  void build(std::vector<IvNode> &&input) {
+    nodes = std::move(input);
+    bool sorted = true;
+    for (size_t i = 1; i < nodes.size(); i++)
+      if (nodes[i].first < nodes[i - 1].first) { sorted = false; break; }
+    if (!sorted) /* LSD radix sort on `first` == stable sort by first */
+      std::stable_sort(nodes.begin(), nodes.end(),
+                       [](const IvNode &a, const IvNode &b) { return a.first < b.first; });
+    size_t n = nodes.size();
+    subtree_last.assign(n, 0);
+    simple_root.assign(n, 0);
+    if (n == 0) return;
+    uint32_t max_depth = 0;
+    traverse(0, n, 0, max_depth);
+    veb(0, n, 0, max_depth);
+  }
+  template <class F> void query_recursion(size_t s, size_t e, int32_t first, int32_t last, F &visit) const {
+    size_t r = root_of(s, e);
+    if (simple_root[r]) {
+      for (size_t i = s; i < e; i++) {
+        if (last < nodes[i].first) break;
+        if (first <= nodes[i].last) visit(nodes[i]);
+      }
+      return;
+    }
+    const IvNode &node = nodes[r];
+    if (node.first <= last && node.last >= first) visit(node);
+    if (r > s) {
+      size_t l = root_of(s, r);
+      if (subtree_last[l] >= first) query_recursion(s, r, first, last, visit);
+    }
+    if (r + 1 < e) {
+      size_t rr = root_of(r + 1, e);
+      if (node.first <= last && subtree_last[rr] >= first) query_recursion(r + 1, e, first, last, visit);
+    }
+  }
+  template <class F> void query(int32_t first, int32_t last, F visit) const {
+    if (!nodes.empty()) query_recursion(0, nodes.size(), first, last, visit);
+  }
+};
+
+/* ------------------------------------------------------------------------ */
+/* alignment files + index                                                   */
+/* ------------------------------------------------------------------------ */
+struct AlnFile {
+  std::string path;
+  int fd = -1;
+  const char *mem = nullptr;
+  std::string owned;
+  size_t mem_len = 0;
+  std::unordered_map<uint64_t, std::vector<uint32_t>> preparsed; /* by data_offset */
+};
+
+typedef std::unordered_map<uint32_t, COITree> TreeMap;
+
+struct AdjustedInterval { /* impg.rs:225 */
+  uint32_t q_id; int32_t q_first, q_last;
+  std::vector<uint32_t> cigar;
+  uint32_t t_id; int32_t t_first, t_last;
+};
+
+} // namespace
+
+struct oracle_index {
+  SequenceIndex seq_index;
+  std::vector<AlnFile> files;
+  TreeMap trees;                    /* Impg (single index over all files) */
+  std::vector<TreeMap> file_trees;  /* MultiImpg: one Impg per file */
+  bool preparse = false;
+  size_t n_records = 0;
+  ~oracle_index() { for (auto &f : files) if (f.fd >= 0) close(f.fd); }
+};
+
+namespace {
+
+/* Rust str::parse::<usize>(): optional '+', at least one digit, digits only. */
+bool parse_usize(const char *s, size_t n, uint64_t *out) {
+  size_t i = 0;
+  if (n > 0 && s[0] == '+') i = 1;
+  if (i >= n) return false;
+  uint64_t v = 0;
+  for (; i < n; i++) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    v = v * 10 + (uint64_t)(s[i] - '0');
+  }
+  *out = v;
+  return true;
+}
+bool parse_i32(const char *s, size_t n, int32_t *out) { /* str::parse::<i32>() */
+  size_t i = 0; bool neg = false;
+  if (n > 0 && (s[0] == '+' || s[0] == '-')) { neg = s[0] == '-'; i = 1; }
+  if (i >= n) return false;
+  int64_t v = 0;
+  for (; i < n; i++) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    v = v * 10 + (s[i] - '0');
+    if (v > 2147483648LL) return false;
+  }
+  if (neg) v = -v;
+  if (v > 2147483647LL || v < -2147483648LL) return false;
+  *out = (int32_t)v;
+  return true;
+}
+
+/* parse_paf_line (paf.rs:118-177) */
+bool parse_paf_line(const char *line, size_t len, uint64_t file_pos, SequenceIndex &seq_index,
+                    AlignmentRecord &rec) {
+  std::vector<std::pair<const char *, size_t>> fields;
+  size_t st = 0;
+  for (size_t i = 0; i <= len; i++)
+    if (i == len || line[i] == '\t') { fields.push_back({line + st, i - st}); st = i + 1; }
+  if (fields.size() < 12) { set_err("Not enough fields in PAF record"); return false; }
+  uint64_t qlen, qs, qe, tlen, ts, te;
+  if (!parse_usize(fields[1].first, fields[1].second, &qlen) ||
+      !parse_usize(fields[2].first, fields[2].second, &qs) ||
+      !parse_usize(fields[3].first, fields[3].second, &qe) ||
+      !parse_usize(fields[6].first, fields[6].second, &tlen) ||
+      !parse_usize(fields[7].first, fields[7].second, &ts) ||
+      !parse_usize(fields[8].first, fields[8].second, &te)) { set_err("Invalid field"); return false; }
+  if (fields[4].second == 0) { set_err("Expected '+' or '-' for strand"); return false; }
+  char sc = fields[4].first[0];
+  if (sc != '+' && sc != '-') { set_err("Invalid strand"); return false; }
+  std::string qname(fields[0].first, fields[0].second), tname(fields[5].first, fields[5].second);
+  uint32_t query_id = seq_index.get_or_insert_id(qname, (int64_t)qlen);
+  uint32_t target_id = seq_index.get_or_insert_id(tname, (int64_t)tlen);
+  uint64_t cigar_offset = file_pos, cigar_bytes = 0;
+  for (auto &f : fields) { /* :155-163 */
+    if (f.second >= 5 && memcmp(f.first, "cg:Z:", 5) == 0) {
+      cigar_offset += 5;
+      cigar_bytes = f.second - 5;
+      break;
+    } else cigar_offset += f.second + 1;
+  }
+  rec.query_id = query_id; rec.query_start = qs; rec.query_end = qe;
+  rec.target_id = target_id; rec.target_start = ts; rec.target_end = te;
+  rec.strand_and_data_offset = cigar_offset; rec.data_bytes = cigar_bytes;
+  if (sc == '-') rec.strand_and_data_offset |= STRAND_BIT; else rec.strand_and_data_offset &= ~STRAND_BIT;
+  return true;
+}
+
+/* parse_paf (paf.rs:179-194): BufRead::lines() strips "\n" and "\r\n";
+ * bytes_read += line.len() + 1 */
+bool parse_paf(const char *text, size_t len, SequenceIndex &seq_index, std::vector<AlignmentRecord> &records) {
+  uint64_t bytes_read = 0;
+  size_t pos = 0;
+  while (pos < len) {
+    size_t eol = pos;
+    while (eol < len && text[eol] != '\n') eol++;
+    size_t l = eol - pos;
+    if (l > 0 && text[pos + l - 1] == '\r') l--;
+    AlignmentRecord rec;
+    if (!parse_paf_line(text + pos, l, bytes_read, seq_index, rec)) return false;
+    records.push_back(rec);
+    bytes_read += l + 1;
+    pos = eol + 1;
+  }
+  return true;
+}
+
+/* from_multi_alignment_records entry construction (impg.rs:1553-1633) */
+void add_entries(const std::vector<AlignmentRecord> &records, uint32_t file_index, bool bidirectional,
+                 std::map<uint32_t, std::vector<IvNode>> &intervals) {
+  for (const auto &record : records) {
+    QueryMetadata fwd;
+    fwd.query_id = record.query_id;
+    fwd.target_start = (int32_t)record.target_start; fwd.target_end = (int32_t)record.target_end;
+    fwd.query_start = (int32_t)record.query_start; fwd.query_end = (int32_t)record.query_end;
+    fwd.alignment_file_index = file_index;
+    fwd.strand_and_data_offset = record.strand_and_data_offset;
+    fwd.data_bytes = record.data_bytes;
+    intervals[record.target_id].push_back({(int32_t)record.target_start, (int32_t)record.target_end, fwd});
+    if (bidirectional && record.query_id != record.target_id) { /* :1584 */
+      QueryMetadata rev;
+      rev.query_id = record.target_id;
+      rev.target_start = (int32_t)record.query_start; rev.target_end = (int32_t)record.query_end;
+      rev.query_start = (int32_t)record.target_start; rev.query_end = (int32_t)record.target_end;
+      rev.alignment_file_index = file_index;
+      rev.strand_and_data_offset = record.strand_and_data_offset | REVERSED_BIT;
+      rev.data_bytes = record.data_bytes;
+      intervals[record.query_id].push_back({(int32_t)record.query_start, (int32_t)record.query_end, rev});
+    }
+  }
+}
+void build_trees(std::map<uint32_t, std::vector<IvNode>> &intervals, TreeMap &trees) {
+  for (auto &kv : intervals) trees[kv.first].build(std::move(kv.second)); /* :1625-1633 */
+}
+
+bool read_cigar_bytes(const AlnFile &f, uint64_t offset, size_t n, std::vector<char> &buf) {
+  buf.resize(n);
+  if (f.mem) { /* memory-backed "file" */
+    if (offset + n > f.mem_len) { set_err("read past end"); return false; }
+    memcpy(buf.data(), f.mem + offset, n);
+    return true;
+  }
+  size_t got = 0; /* read_exact_at (impg.rs:2923) */
+  while (got < n) {
+    ssize_t r = pread(f.fd, buf.data() + got, n - got, (off_t)(offset + got));
+    if (r <= 0) { set_err("Failed to read CIGAR bytes from '" + f.path + "'"); return false; }
+    got += (size_t)r;
+  }
+  return true;
+}
+
+/* get_cigar_ops, PAF branch (impg.rs:495-551) */
+bool get_cigar_ops(const oracle_index &ix, const QueryMetadata &md, std::vector<uint32_t> &ops) {
+  const AlnFile &f = ix.files[md.alignment_file_index];
+  if (md.data_bytes == 0) {
+    set_err("The alignment file '" + f.path + "' does not contain CIGAR strings ('cg:Z' tag).");
+    return false;
+  }
+  if (ix.preparse) {
+    ops = f.preparsed.at(md.data_offset());
+  } else {
+    thread_local std::vector<char> buf; /* PAF_CIGAR_BUF (impg.rs:49) */
+    if (!read_cigar_bytes(f, md.data_offset(), md.data_bytes, buf)) return false;
+    if (!parse_cigar_to_delta(buf.data(), buf.size(), ops)) { set_err("Invalid CIGAR operation"); return false; }
+  }
+  if (md.is_reversed()) invert_cigar_ops_in_place(ops, md.strand_reverse()); /* :548-550 */
+  return true;
+}
+
+/* project_overlapping_interval, PAF branch (impg.rs:1260-1312).
+ * returns 1 Some, 0 None, -1 error */
+int project_overlapping_interval(const oracle_index &ix, const QueryMetadata &md, uint32_t target_id,
+                                 int32_t range_start, int32_t range_end, double min_identity,
+                                 AdjustedInterval &out) {
+  thread_local std::vector<uint32_t> cigar_ops;
+  if (!get_cigar_ops(ix, md, cigar_ops)) return -1;
+  Projection pr;
+  if (!project_target_range_through_alignment(range_start, range_end, md.target_start, md.target_end,
+                                              md.query_start, md.query_end, md.strand_reverse(),
+                                              cigar_ops.data(), cigar_ops.size(), pr))
+    return 0;
+  if (!std::isnan(min_identity)) { /* :1283-1287 */
+    if (gap_compressed_identity(pr.cigar.data(), pr.cigar.size()) < min_identity) return 0;
+  }
+  out.q_id = md.query_id; out.q_first = pr.q_start; out.q_last = pr.q_end;
+  out.t_id = target_id; out.t_first = pr.t_start; out.t_last = pr.t_end;
+  out.cigar = std::move(pr.cigar);
+  g_nproj++;
+  return 1;
+}
+
+AdjustedInterval make_self(uint32_t target_id, int32_t s, int32_t e, bool store_cigar) {
+  AdjustedInterval a;
+  a.q_id = target_id; a.q_first = s; a.q_last = e;
+  a.t_id = target_id; a.t_first = s; a.t_last = e;
+  if (store_cigar) { uint32_t v = 0; cigar_new(e - s, '=', &v); a.cigar.push_back(v); }
+  return a;
+}
+
+/* Impg::query (impg.rs:1852-1928) over one TreeMap */
+bool impg_query(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, int32_t range_start,
+                int32_t range_end, bool store_cigar, double min_identity,
+                std::vector<AdjustedInterval> &results) {
+  results.clear();
+  results.push_back(make_self(target_id, range_start, range_end, store_cigar));
+  auto it = trees.find(target_id);
+  bool ok = true;
+  if (it != trees.end()) {
+    it->second.query(range_start, range_end, [&](const IvNode &interval) {
+      if (!ok) return;
+      AdjustedInterval a;
+      int r = project_overlapping_interval(ix, interval.metadata, target_id, range_start, range_end,
+                                           min_identity, a);
+      if (r < 0) { ok = false; return; }
+      if (r == 1) {
+        if (!store_cigar) a.cigar.clear();
+        results.push_back(std::move(a));
+      }
+    });
+  }
+  return ok;
+}
+
+struct Hit { /* tuple of impg.rs:2384 */
+  uint32_t query_id; int32_t qs, qe; std::vector<uint32_t> cigar; int32_t ts, te; uint32_t cur_target;
+};
+
+/* lookup + clipped projection of one frontier range (impg.rs:2392-2460 / 2140-2206) */
+bool frontier_hits(const oracle_index &ix, const TreeMap &trees, uint32_t cur_id, int32_t cs, int32_t ce,
+                   bool store_cigar, double min_identity, std::vector<Hit> &local) {
+  auto it = trees.find(cur_id);
+  if (it == trees.end()) return true;
+  bool ok = true;
+  it->second.query(cs, ce, [&](const IvNode &interval) {
+    if (!ok) return;
+    int32_t overlap_start = std::max(cs, interval.first);
+    int32_t overlap_end = std::min(ce, interval.last);
+    if (overlap_start >= overlap_end) return; /* :2401 */
+    AdjustedInterval a;
+    int r = project_overlapping_interval(ix, interval.metadata, cur_id, overlap_start, overlap_end,
+                                         min_identity, a);
+    if (r < 0) { ok = false; return; }
+    if (r == 1) {
+      Hit h;
+      h.query_id = a.q_id; h.qs = a.q_first; h.qe = a.q_last;
+      if (store_cigar) h.cigar = std::move(a.cigar);
+      h.ts = a.t_first; h.te = a.t_last; h.cur_target = cur_id;
+      local.push_back(std::move(h));
+    }
+  });
+  return ok;
+}
+
+SortedRanges &visited_entry(const oracle_index &ix, std::unordered_map<uint32_t, SortedRanges> &visited,
+                            uint32_t id, bool masked_none) { /* impg.rs:2041-2055 */
+  auto it = visited.find(id);
+  if (it == visited.end()) {
+    SortedRanges sr;
+    sr.sequence_length = masked_none ? (int32_t)ix.seq_index.id_to_len[id] : 0;
+    sr.min_distance = 0;
+    it = visited.emplace(id, std::move(sr)).first;
+  }
+  return it->second;
+}
+
+/* the sequential per-hit update shared by BFS (:2482-2558) and DFS (:2218-2281).
+ * bfs_short_circuit: BFS checks the next range only if not already rejected (:2538). */
+template <class Push>
+void update_with_hit(const oracle_index &ix, std::unordered_map<uint32_t, SortedRanges> &visited,
+                     Hit &h, int32_t min_output_length, int32_t min_distance_between_ranges,
+                     int32_t min_transitive_len, bool bfs_short_circuit,
+                     std::vector<AdjustedInterval> &results, Push push_next) {
+  int32_t length = std::abs(h.qe - h.qs);
+  bool should_add_to_output = min_output_length >= 0 ? length >= min_output_length : true;
+  if (should_add_to_output) {
+    AdjustedInterval a;
+    a.q_id = h.query_id; a.q_first = h.qs; a.q_last = h.qe; a.cigar = h.cigar;
+    a.t_id = h.cur_target; a.t_first = h.ts; a.t_last = h.te;
+    results.push_back(std::move(a));
+  }
+  if (h.query_id != h.cur_target) {
+    SortedRanges &ranges = visited_entry(ix, visited, h.query_id, true);
+    bool should_add = true;
+    if (min_distance_between_ranges > 0) {
+      int32_t new_min = std::min(h.qs, h.qe), new_max = std::max(h.qs, h.qe);
+      size_t idx = ranges.bsearch(new_min);
+      if (idx > 0) {
+        int32_t prev_end = ranges.ranges[idx - 1].second;
+        if (std::abs(new_min - prev_end) < min_distance_between_ranges) should_add = false;
+      }
+      if ((!bfs_short_circuit || should_add) && idx < ranges.ranges.size()) {
+        int32_t next_start = ranges.ranges[idx].first;
+        if (std::abs(next_start - new_max) < min_distance_between_ranges) should_add = false;
+      }
+    }
+    if (should_add) {
+      auto new_ranges = ranges.insert({h.qs, h.qe});
+      for (auto &nr : new_ranges)
+        if (std::abs(nr.second - nr.first) >= min_transitive_len) push_next(h.query_id, nr.first, nr.second);
+    }
+  }
+}
+
+void parallel_for(size_t n, int threads, const std::function<void(size_t)> &f);
+
+/* Impg::query_transitive_bfs (impg.rs:2311-2597) */
+bool impg_bfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, int32_t range_start,
+              int32_t range_end, const oracle_params_t &p, int threads,
+              std::vector<AdjustedInterval> &results) {
+  std::unordered_map<uint32_t, SortedRanges> visited;
+  auto filtered = visited_entry(ix, visited, target_id, true).insert({range_start, range_end});
+  results.clear();
+  for (auto &f : filtered) results.push_back(make_self(target_id, f.first, f.second, p.store_cigar));
+  struct R { uint32_t id; int32_t s, e; };
+  std::vector<R> current;
+  for (auto &f : filtered)
+    if (std::abs(f.first - f.second) >= p.min_transitive_len) current.push_back({target_id, f.first, f.second});
+  uint32_t depth = 0;
+  while (!current.empty() && (p.max_depth == 0 || depth < p.max_depth)) {
+    std::vector<std::vector<Hit>> query_results(current.size());
+    std::atomic<bool> ok{true};
+    uint64_t nproj_before = g_nproj;
+    std::atomic<uint64_t> nproj_par{0};
+    auto body = [&](size_t i) {
+      uint64_t b = g_nproj; /* thread-local: worker's or ours */
+      if (!frontier_hits(ix, trees, current[i].id, current[i].s, current[i].e, p.store_cigar,
+                         p.min_identity, query_results[i])) ok = false;
+      nproj_par += g_nproj - b;
+    };
+    if (threads > 1 && current.size() > 1) parallel_for(current.size(), threads, body);
+    else for (size_t i = 0; i < current.size(); i++) body(i);
+    g_nproj = nproj_before + nproj_par;
+    if (!ok) return false;
+    std::vector<R> next;
+    for (auto &qr : query_results)
+      for (auto &h : qr)
+        update_with_hit(ix, visited, h, p.min_output_length, p.min_distance_between_ranges,
+                        p.min_transitive_len, true, results,
+                        [&](uint32_t id, int32_t s, int32_t e) { next.push_back({id, s, e}); });
+    depth += 1;
+    if (!next.empty()) { /* :2566-2584 */
+      std::stable_sort(next.begin(), next.end(), [](const R &a, const R &b) {
+        return a.id != b.id ? a.id < b.id : a.s < b.s;
+      });
+      size_t write = 0;
+      for (size_t read = 1; read < next.size(); read++) {
+        if (next[write].id == next[read].id && next[write].e >= next[read].s) {
+          next[write].e = std::max(next[write].e, next[read].e);
+        } else {
+          write += 1;
+          std::swap(next[write], next[read]);
+        }
+      }
+      next.resize(write + 1);
+    }
+    current = std::move(next);
+  }
+  return true;
+}
+
+/* Impg::query_transitive_dfs (impg.rs:2057-2309) */
+bool impg_dfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, int32_t range_start,
+              int32_t range_end, const oracle_params_t &p, std::vector<AdjustedInterval> &results) {
+  std::unordered_map<uint32_t, SortedRanges> visited;
+  auto filtered = visited_entry(ix, visited, target_id, true).insert({range_start, range_end});
+  results.clear();
+  struct S { uint32_t id; int32_t s, e; uint32_t depth; };
+  std::vector<S> stack;
+  for (auto &f : filtered) {
+    results.push_back(make_self(target_id, f.first, f.second, p.store_cigar));
+    if (std::abs(f.first - f.second) >= p.min_transitive_len) stack.push_back({target_id, f.first, f.second, 0});
+  }
+  while (!stack.empty()) {
+    S cur = stack.back();
+    stack.pop_back();
+    if (p.max_depth > 0 && cur.depth >= p.max_depth) continue; /* :2125 (skips the re-sort too) */
+    std::vector<Hit> hits;
+    if (!frontier_hits(ix, trees, cur.id, cur.s, cur.e, p.store_cigar, p.min_identity, hits)) return false;
+    for (auto &h : hits)
+      update_with_hit(ix, visited, h, p.min_output_length, p.min_distance_between_ranges,
+                      p.min_transitive_len, false, results,
+                      [&](uint32_t id, int32_t s, int32_t e) { stack.push_back({id, s, e, cur.depth + 1}); });
+    std::stable_sort(stack.begin(), stack.end(), [](const S &a, const S &b) { /* :2289 */
+      return a.id != b.id ? a.id < b.id : a.s < b.s;
+    });
+    size_t write = 0;
+    for (size_t read = 1; read < stack.size(); read++) {
+      if (stack[write].id == stack[read].id && stack[write].e >= stack[read].s) {
+        stack[write].e = std::max(stack[write].e, stack[read].e);
+      } else {
+        write += 1;
+        std::swap(stack[write], stack[read]);
+      }
+    }
+    if (!stack.empty()) stack.resize(write + 1); /* truncate(write+1) is a no-op on an empty Vec */
+  }
+  return true;
+}
+
+/* MultiImpg::query_all_indices (multi_impg.rs:495-595); ids are already unified */
+bool multi_query_all_indices(const oracle_index &ix, uint32_t target_id, int32_t range_start,
+                             int32_t range_end, bool store_cigar, double min_identity,
+                             std::vector<AdjustedInterval> &final_results) {
+  final_results.clear();
+  bool any_location = false;
+  bool seen_self = false;
+  for (const TreeMap &tm : ix.file_trees) {
+    if (tm.find(target_id) == tm.end()) continue;
+    any_location = true;
+    std::vector<AdjustedInterval> local;
+    if (!impg_query(ix, tm, target_id, range_start, range_end, store_cigar, min_identity, local)) return false;
+    for (auto &r : local) {
+      bool is_self = r.q_id == target_id && r.t_id == target_id && r.q_first == range_start && r.q_last == range_end;
+      if (is_self) {
+        if (!seen_self) { final_results.push_back(std::move(r)); seen_self = true; }
+      } else final_results.push_back(std::move(r));
+    }
+  }
+  if (!any_location) { final_results.push_back(make_self(target_id, range_start, range_end, store_cigar)); return true; }
+  if (!seen_self) final_results.insert(final_results.begin(), make_self(target_id, range_start, range_end, store_cigar));
+  if (final_results.size() > 1) { /* :582-592 */
+    AdjustedInterval self_interval = std::move(final_results[0]);
+    final_results.erase(final_results.begin());
+    std::stable_sort(final_results.begin(), final_results.end(), [](const AdjustedInterval &a, const AdjustedInterval &b) {
+      if (a.q_id != b.q_id) return a.q_id < b.q_id;
+      if (a.q_first != b.q_first) return a.q_first < b.q_first;
+      if (a.q_last != b.q_last) return a.q_last < b.q_last;
+      if (a.t_first != b.t_first) return a.t_first < b.t_first;
+      return a.t_last < b.t_last;
+    });
+    final_results.insert(final_results.begin(), std::move(self_interval));
+  }
+  return true;
+}
+
+/* MultiImpg::transitive_query_impl (multi_impg.rs:796-991) */
+bool multi_transitive(const oracle_index &ix, uint32_t target_id, int32_t range_start, int32_t range_end,
+                      const oracle_params_t &p, bool use_dfs, std::vector<AdjustedInterval> &results) {
+  std::unordered_map<uint32_t, SortedRanges> visited;
+  for (uint32_t id = 0; id < ix.seq_index.id_to_name.size(); id++) { /* :814-822 */
+    SortedRanges sr;
+    sr.sequence_length = (int32_t)std::max<int64_t>(ix.seq_index.id_to_len[id], 0);
+    visited.emplace(id, std::move(sr));
+  }
+  auto filtered = visited[target_id].insert({range_start, range_end});
+  results.clear();
+  struct S { uint32_t id; int32_t s, e; uint32_t depth; };
+  std::deque<S> stack;
+  for (auto &f : filtered) {
+    results.push_back(make_self(target_id, f.first, f.second, p.store_cigar));
+    if (std::abs(f.first - f.second) >= p.min_transitive_len) stack.push_back({target_id, f.first, f.second, 0});
+  }
+  while (!stack.empty()) {
+    S cur;
+    if (use_dfs) { cur = stack.back(); stack.pop_back(); } else { cur = stack.front(); stack.pop_front(); }
+    if (p.max_depth > 0 && cur.depth >= p.max_depth) continue;
+    std::vector<AdjustedInterval> step;
+    if (!multi_query_all_indices(ix, cur.id, cur.s, cur.e, p.store_cigar, p.min_identity, step)) return false;
+    for (auto &result : step) {
+      uint32_t query_id = result.q_id;
+      if (query_id == cur.id) continue; /* :883-885 */
+      int32_t aqs = std::min(result.q_first, result.q_last), aqe = std::max(result.q_first, result.q_last);
+      int32_t length = std::abs(result.q_last - result.q_first);
+      bool out = p.min_output_length >= 0 ? length >= p.min_output_length : true;
+      if (out) results.push_back(result);
+      SortedRanges &ranges = visited[query_id];
+      bool should_add = true;
+      if (p.min_distance_between_ranges > 0) {
+        size_t idx = ranges.bsearch(aqs);
+        if (idx > 0 && std::abs(aqs - ranges.ranges[idx - 1].second) < p.min_distance_between_ranges) should_add = false;
+        if (idx < ranges.ranges.size() && std::abs(ranges.ranges[idx].first - aqe) < p.min_distance_between_ranges) should_add = false;
+      }
+      if (should_add) {
+        auto nr = ranges.insert({aqs, aqe});
+        for (auto &r : nr)
+          if (std::abs(r.second - r.first) >= p.min_transitive_len) stack.push_back({query_id, r.first, r.second, cur.depth + 1});
+      }
+    }
+    std::stable_sort(stack.begin(), stack.end(), [](const S &a, const S &b) { /* :969-970 */
+      return a.id != b.id ? a.id < b.id : a.s < b.s;
+    });
+    size_t write = 0;
+    for (size_t read = 1; read < stack.size(); read++) {
+      if (stack[write].id == stack[read].id && stack[write].e >= stack[read].s) {
+        stack[write].e = std::max(stack[write].e, stack[read].e);
+      } else {
+        write += 1;
+        std::swap(stack[write], stack[read]);
+      }
+    }
+    if (!stack.empty()) stack.resize(write + 1);
+  }
+  return true;
+}
+
+/* dispatch as perform_query does (main.rs:11641-11699), without the retain */
+bool run_query(const oracle_index &ix, uint32_t target_id, int32_t s, int32_t e, const oracle_params_t &p,
+               int threads, std::vector<AdjustedInterval> &results) {
+  if (p.multi_impg) {
+    if (p.transitive) return multi_transitive(ix, target_id, s, e, p, p.dfs != 0, results);
+    return multi_query_all_indices(ix, target_id, s, e, p.store_cigar, p.min_identity, results);
+  }
+  if (p.transitive) {
+    if (p.dfs) return impg_dfs(ix, ix.trees, target_id, s, e, p, results);
+    return impg_bfs(ix, ix.trees, target_id, s, e, p, threads, results);
+  }
+  return impg_query(ix, ix.trees, target_id, s, e, p.store_cigar, p.min_identity, results);
+}
+
+/* ------------------------------------------------------------------------ */
+/* BED merge (main.rs:12858-13011, 12474-12560)                              */
+/* ------------------------------------------------------------------------ */
+size_t uf_find(std::vector<size_t> &parent, size_t x) {
+  while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+  return x;
+}
+void merge_adjusted_intervals_gap_2d(std::vector<oracle_interval_t> &results, int32_t merge_distance) {
+  if (results.size() <= 1 || merge_distance < 0) return;
+  const int64_t d = merge_distance;
+  std::map<std::tuple<uint32_t, uint32_t, bool>, std::vector<size_t>> groups;
+  for (size_t i = 0; i < results.size(); i++) {
+    bool strand_fwd = results[i].q_first <= results[i].q_last;
+    groups[{results[i].query_id, results[i].target_id, strand_fwd}].push_back(i);
+  }
+  size_t n = results.size();
+  std::vector<size_t> parent(n);
+  for (size_t i = 0; i < n; i++) parent[i] = i;
+  for (auto &kv : groups) {
+    bool strand_fwd = std::get<2>(kv.first);
+    std::vector<size_t> indices = kv.second;
+    std::stable_sort(indices.begin(), indices.end(), [&](size_t a, size_t b) {
+      int32_t ka = strand_fwd ? results[a].q_first : -results[a].q_first;
+      int32_t kb = strand_fwd ? results[b].q_first : -results[b].q_first;
+      return ka < kb;
+    });
+    for (size_t a_pos = 0; a_pos < indices.size(); a_pos++) {
+      size_t ia = indices[a_pos];
+      const auto &A = results[ia];
+      int64_t qa_start = strand_fwd ? A.q_first : A.q_last, qa_end = strand_fwd ? A.q_last : A.q_first;
+      int64_t ta_start = A.t_first, ta_end = A.t_last;
+      for (size_t b_pos = a_pos + 1; b_pos < indices.size(); b_pos++) {
+        size_t ib = indices[b_pos];
+        const auto &B = results[ib];
+        int64_t qb_start = strand_fwd ? B.q_first : B.q_last;
+        if (qb_start < qa_start) continue;
+        int64_t q_gap = qb_start - qa_end;
+        if (q_gap > d) break;
+        int64_t tb_start = B.t_first, tb_end = B.t_last;
+        int64_t t_gap; bool t_forward;
+        if (strand_fwd) { t_gap = tb_start - ta_end; t_forward = tb_start > ta_start; }
+        else { t_gap = ta_start - tb_end; t_forward = tb_end < ta_end; }
+        if (!t_forward || t_gap > d) continue;
+        size_t ra = uf_find(parent, ia), rb = uf_find(parent, ib);
+        if (ra != rb) parent[ra] = rb;
+      }
+    }
+  }
+  std::map<size_t, std::vector<size_t>> buckets;
+  for (size_t i = 0; i < n; i++) buckets[uf_find(parent, i)].push_back(i);
+  std::vector<oracle_interval_t> merged;
+  std::vector<bool> taken(n, false);
+  for (size_t i = 0; i < n; i++) {
+    if (taken[i]) continue;
+    size_t r = uf_find(parent, i);
+    auto it = buckets.find(r);
+    if (it == buckets.end()) continue;
+    std::vector<size_t> members = std::move(it->second);
+    buckets.erase(it);
+    for (size_t m : members) taken[m] = true;
+    bool strand_fwd = results[members[0]].q_first <= results[members[0]].q_last;
+    std::vector<size_t> ordered = members;
+    std::stable_sort(ordered.begin(), ordered.end(), [&](size_t a, size_t b) {
+      int32_t ka = strand_fwd ? results[a].q_first : -results[a].q_first;
+      int32_t kb = strand_fwd ? results[b].q_first : -results[b].q_first;
+      return ka < kb;
+    });
+    const auto &first = results[ordered[0]];
+    int32_t q_lo = first.q_first, q_hi = first.q_last, t_lo = first.t_first, t_hi = first.t_last;
+    for (size_t idx : ordered) {
+      const auto &x = results[idx];
+      if (strand_fwd) { q_lo = std::min(q_lo, x.q_first); q_hi = std::max(q_hi, x.q_last); }
+      else { q_lo = std::max(q_lo, x.q_first); q_hi = std::min(q_hi, x.q_last); }
+      t_lo = std::min(t_lo, x.t_first); t_hi = std::max(t_hi, x.t_last);
+    }
+    merged.push_back({first.query_id, q_lo, q_hi, first.target_id, t_lo, t_hi});
+  }
+  results = std::move(merged);
+}
+
+int32_t sat_sub(int32_t a, int32_t b) {
+  int64_t r = (int64_t)a - (int64_t)b;
+  if (r > 2147483647LL) return 2147483647;
+  if (r < -2147483648LL) return (int32_t)-2147483648LL;
+  return (int32_t)r;
+}
+void merge_query_adjusted_intervals(std::vector<oracle_interval_t> &results, int32_t merge_distance, bool merge_strands) {
+  if (!(results.size() > 1 && (merge_distance >= 0 || merge_strands))) return;
+  std::stable_sort(results.begin(), results.end(), [](const oracle_interval_t &a, const oracle_interval_t &b) {
+    bool af = a.q_first <= a.q_last, bf = b.q_first <= b.q_last;
+    int32_t as = af ? a.q_first : a.q_last, bs = bf ? b.q_first : b.q_last;
+    if (a.query_id != b.query_id) return a.query_id < b.query_id;
+    if (as != bs) return as < bs;
+    return (int)(!af) < (int)(!bf);
+  });
+  size_t write_idx = 0;
+  for (size_t read_idx = 1; read_idx < results.size(); read_idx++) {
+    const auto curr = results[write_idx];
+    const auto next = results[read_idx];
+    bool curr_is_forward = curr.q_first <= curr.q_last, next_is_forward = next.q_first <= next.q_last;
+    int32_t curr_start = curr_is_forward ? curr.q_first : curr.q_last, curr_end = curr_is_forward ? curr.q_last : curr.q_first;
+    int32_t next_start = next_is_forward ? next.q_first : next.q_last, next_end = next_is_forward ? next.q_last : next.q_first;
+    if (merge_distance < 0 || curr.query_id != next.query_id ||
+        (!merge_strands && curr_is_forward != next_is_forward) || next_start > curr_end + merge_distance) {
+      write_idx += 1;
+      if (write_idx != read_idx) std::swap(results[write_idx], results[read_idx]);
+    } else {
+      int32_t merged_start = std::min(curr_start, next_start), merged_end = std::max(curr_end, next_end);
+      bool merged_is_forward;
+      if (merge_strands && curr_is_forward != next_is_forward) {
+        int32_t curr_len = sat_sub(curr_end, curr_start), next_len = sat_sub(next_end, next_start);
+        merged_is_forward = next_len > curr_len ? next_is_forward : curr_is_forward;
+      } else merged_is_forward = curr_is_forward;
+      if (merged_is_forward) { results[write_idx].q_first = merged_start; results[write_idx].q_last = merged_end; }
+      else { results[write_idx].q_first = merged_end; results[write_idx].q_last = merged_start; }
+    }
+  }
+  results.resize(write_idx + 1);
+}
+
+void parallel_for(size_t n, int threads, const std::function<void(size_t)> &f) {
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  int T = std::max(1, std::min<int>(threads, (int)n));
+  for (int t = 0; t < T; t++)
+    th.emplace_back([&]() {
+      for (;;) {
+        size_t i = next.fetch_add(1);
+        if (i >= n) break;
+        f(i);
+      }
+    });
+  for (auto &t : th) t.join();
+}
+
+void append(char **buf, size_t *len, size_t *cap, const char *s, size_t n) {
+  if (*len + n + 1 > *cap) {
+    size_t nc = std::max<size_t>(*cap * 2, *len + n + 1024);
+    *buf = (char *)realloc(*buf, nc);
+    *cap = nc;
+  }
+  memcpy(*buf + *len, s, n);
+  *len += n;
+  (*buf)[*len] = 0;
+}
+
+oracle_index *finish_index(oracle_index *ix, std::vector<std::vector<AlignmentRecord>> &recs, bool bidirectional, bool preparse) {
+  std::map<uint32_t, std::vector<IvNode>> all;
+  ix->file_trees.resize(recs.size());
+  for (size_t f = 0; f < recs.size(); f++) {
+    add_entries(recs[f], (uint32_t)f, bidirectional, all);
+    std::map<uint32_t, std::vector<IvNode>> per;
+    add_entries(recs[f], (uint32_t)f, bidirectional, per);
+    build_trees(per, ix->file_trees[f]);
+    ix->n_records += recs[f].size();
+  }
+  build_trees(all, ix->trees);
+  ix->preparse = preparse;
+  if (preparse) {
+    for (size_t f = 0; f < recs.size(); f++) {
+      AlnFile &af = ix->files[f];
+      std::vector<char> buf;
+      for (auto &r : recs[f]) {
+        if (r.data_bytes == 0) continue;
+        uint64_t off = r.strand_and_data_offset & ~(STRAND_BIT | REVERSED_BIT);
+        if (!read_cigar_bytes(af, off, r.data_bytes, buf)) { delete ix; return nullptr; }
+        std::vector<uint32_t> ops;
+        if (!parse_cigar_to_delta(buf.data(), buf.size(), ops)) { set_err("Invalid CIGAR operation"); delete ix; return nullptr; }
+        af.preparsed.emplace(off, std::move(ops));
+      }
+    }
+  }
+  return ix;
+}
+
+} // namespace
+
+/* ======================================================================== */
+/* C interface                                                               */
+/* ======================================================================== */
+extern "C" {
+
+const char *oracle_last_error(void) { return g_err.c_str(); }
+uint64_t oracle_last_projection_count(void) { return g_nproj; }
+
+long oracle_parse_cigar(const char *cigar, size_t len, uint32_t *ops_out, size_t cap) {
+  std::vector<uint32_t> ops;
+  if (!parse_cigar_to_delta(cigar, len, ops)) return -1;
+  for (size_t i = 0; i < ops.size() && i < cap; i++) ops_out[i] = ops[i];
+  return (long)ops.size();
+}
+void oracle_invert_cigar(uint32_t *ops, size_t n, int strand_reverse) {
+  std::vector<uint32_t> v(ops, ops + n);
+  invert_cigar_ops_in_place(v, strand_reverse != 0);
+  std::copy(v.begin(), v.end(), ops);
+}
+int oracle_project(int32_t r0, int32_t r1, int32_t ts, int32_t te, int32_t qs, int32_t qe, int strand_reverse,
+                   const uint32_t *ops, size_t n_ops, int32_t *out4, uint32_t *slice_out, size_t *slice_len) {
+  Projection pr;
+  if (!project_target_range_through_alignment(r0, r1, ts, te, qs, qe, strand_reverse != 0, ops, n_ops, pr)) return 0;
+  out4[0] = pr.q_start; out4[1] = pr.q_end; out4[2] = pr.t_start; out4[3] = pr.t_end;
+  if (slice_out) std::copy(pr.cigar.begin(), pr.cigar.end(), slice_out);
+  if (slice_len) *slice_len = pr.cigar.size();
+  return 1;
+}
+double oracle_gap_compressed_identity(const uint32_t *ops, size_t n) { return gap_compressed_identity(ops, n); }
+
+struct oracle_sorted_ranges { SortedRanges sr; };
+oracle_sorted_ranges_t *oracle_sr_new(int32_t sequence_length, int32_t min_distance) {
+  auto *p = new oracle_sorted_ranges();
+  p->sr.sequence_length = sequence_length; p->sr.min_distance = min_distance;
+  return p;
+}
+void oracle_sr_free(oracle_sorted_ranges_t *p) { delete p; }
+long oracle_sr_insert(oracle_sorted_ranges_t *p, int32_t a, int32_t b, int32_t *pieces_out, size_t cap) {
+  auto v = p->sr.insert({a, b});
+  for (size_t i = 0; i < v.size() && i < cap; i++) { pieces_out[2 * i] = v[i].first; pieces_out[2 * i + 1] = v[i].second; }
+  return (long)v.size();
+}
+long oracle_sr_get(oracle_sorted_ranges_t *p, int32_t *out, size_t cap) {
+  for (size_t i = 0; i < p->sr.ranges.size() && i < cap; i++) { out[2 * i] = p->sr.ranges[i].first; out[2 * i + 1] = p->sr.ranges[i].second; }
+  return (long)p->sr.ranges.size();
+}
+
+oracle_index_t *oracle_index_from_paf(const char *const *paths, int n_paths, int bidirectional, int preparse) {
+  auto *ix = new oracle_index();
+  std::vector<std::vector<AlignmentRecord>> recs(n_paths);
+  for (int f = 0; f < n_paths; f++) {
+    AlnFile af;
+    af.path = paths[f];
+    af.fd = open(paths[f], O_RDONLY);
+    if (af.fd < 0) { set_err(std::string("Failed to open file '") + paths[f] + "'"); delete ix; return nullptr; }
+    off_t sz = lseek(af.fd, 0, SEEK_END);
+    std::string text((size_t)sz, '\0');
+    size_t got = 0;
+    while (got < (size_t)sz) {
+      ssize_t r = pread(af.fd, &text[got], (size_t)sz - got, (off_t)got);
+      if (r <= 0) break;
+      got += (size_t)r;
+    }
+    ix->files.push_back(std::move(af));
+    if (!parse_paf(text.data(), text.size(), ix->seq_index, recs[f])) { delete ix; return nullptr; }
+  }
+  return finish_index(ix, recs, bidirectional != 0, preparse != 0);
+}
+oracle_index_t *oracle_index_from_paf_text(const char *text, size_t len, int bidirectional, int preparse) {
+  auto *ix = new oracle_index();
+  AlnFile af;
+  af.path = "<memory>";
+  af.owned.assign(text, len);
+  ix->files.push_back(std::move(af));
+  ix->files[0].mem = ix->files[0].owned.data();
+  ix->files[0].mem_len = len;
+  std::vector<std::vector<AlignmentRecord>> recs(1);
+  if (!parse_paf(ix->files[0].mem, len, ix->seq_index, recs[0])) { delete ix; return nullptr; }
+  return finish_index(ix, recs, bidirectional != 0, preparse != 0);
+}
+void oracle_index_free(oracle_index_t *ix) { delete ix; }
+
+uint32_t oracle_num_seqs(const oracle_index_t *ix) { return (uint32_t)ix->seq_index.id_to_name.size(); }
+const char *oracle_seq_name(const oracle_index_t *ix, uint32_t id) {
+  return id < ix->seq_index.id_to_name.size() ? ix->seq_index.id_to_name[id].c_str() : nullptr;
+}
+int64_t oracle_seq_len(const oracle_index_t *ix, uint32_t id) {
+  return id < ix->seq_index.id_to_len.size() ? ix->seq_index.id_to_len[id] : -1;
+}
+int64_t oracle_seq_id(const oracle_index_t *ix, const char *name) {
+  auto it = ix->seq_index.name_to_id.find(name);
+  return it == ix->seq_index.name_to_id.end() ? -1 : (int64_t)it->second;
+}
+size_t oracle_num_records(const oracle_index_t *ix) { return ix->n_records; }
+size_t oracle_num_targets(const oracle_index_t *ix) { return ix->trees.size(); }
+size_t oracle_target_entries(const oracle_index_t *ix, uint32_t target_id, int32_t *out, size_t cap) {
+  auto it = ix->trees.find(target_id);
+  if (it == ix->trees.end()) return 0;
+  const auto &nodes = it->second.nodes;
+  for (size_t i = 0; i < nodes.size() && i < cap; i++) {
+    out[4 * i] = nodes[i].first; out[4 * i + 1] = nodes[i].last;
+    out[4 * i + 2] = (int32_t)nodes[i].metadata.query_id;
+    out[4 * i + 3] = (nodes[i].metadata.strand_reverse() ? 1 : 0) | (nodes[i].metadata.is_reversed() ? 2 : 0);
+  }
+  return nodes.size();
+}
+
+long oracle_query(const oracle_index_t *ix, uint32_t target_id, int32_t start, int32_t end, const oracle_params_t *p,
+                  oracle_interval_t *out, size_t cap) {
+  std::vector<AdjustedInterval> results;
+  g_nproj = 0;
+  if (!run_query(*ix, target_id, start, end, *p, 1, results)) return -1;
+  for (size_t i = 0; i < results.size() && i < cap; i++)
+    out[i] = {results[i].q_id, results[i].q_first, results[i].q_last, results[i].t_id, results[i].t_first, results[i].t_last};
+  return (long)results.size();
+}
+
+long oracle_bed_merge(oracle_interval_t *iv, size_t n, int32_t merge_distance, int merge_strands) {
+  std::vector<oracle_interval_t> v(iv, iv + n);
+  /* output_results_bed (main.rs:11858-11866): any_empty_cigar is true for BED
+   * because store_cigar=false (main.rs:7447) */
+  merge_adjusted_intervals_gap_2d(v, merge_distance);
+  merge_query_adjusted_intervals(v, merge_distance, merge_strands != 0);
+  std::copy(v.begin(), v.end(), iv);
+  return (long)v.size();
+}
+
+int oracle_query_bed(const oracle_index_t *ix, const char *target_name, int32_t start, int32_t end,
+                     const char *range_name, const oracle_params_t *p, int32_t merge_distance,
+                     char **buf, size_t *len, size_t *cap) {
+  /* validate_sequence_range (main.rs:10458-10520) */
+  auto it = ix->seq_index.name_to_id.find(target_name);
+  if (it == ix->seq_index.name_to_id.end()) { set_err(std::string("Sequence '") + target_name + "' not found in index"); return -2; }
+  uint32_t target_id = it->second;
+  int64_t seq_len = ix->seq_index.id_to_len[target_id];
+  if (start < 0 || end < 0 || start >= end || end > (int32_t)seq_len) { set_err("invalid range"); return -3; }
+  /* validate_range_min_length (main.rs:10387-10403) */
+  if (end - start < p->min_transitive_len) { set_err("Range is below minimum length"); return -4; }
+  /* perform_query (main.rs:11605-11707) */
+  std::vector<AdjustedInterval> results;
+  g_nproj = 0;
+  oracle_params_t q = *p;
+  q.store_cigar = 0; /* BED: main.rs:7447 */
+  if (!run_query(*ix, target_id, start, end, q, 1, results)) return -1;
+  std::vector<oracle_interval_t> v;
+  for (auto &r : results) v.push_back({r.q_id, r.q_first, r.q_last, r.t_id, r.t_first, r.t_last});
+  if (!p->transitive && p->min_output_length >= 0) { /* :11682-11688 retain */
+    std::vector<oracle_interval_t> kept;
+    for (auto &x : v) if (std::abs(x.q_last - x.q_first) >= p->min_output_length) kept.push_back(x);
+    v.swap(kept);
+  }
+  /* output_results_bed (main.rs:11849-11892), merge_strands_for_output("bed") = true */
+  merge_adjusted_intervals_gap_2d(v, merge_distance);
+  merge_query_adjusted_intervals(v, merge_distance, true);
+  for (auto &x : v) {
+    const std::string &qn = ix->seq_index.id_to_name[x.query_id];
+    int32_t first, last; char strand;
+    if (x.q_first <= x.q_last) { first = x.q_first; last = x.q_last; strand = '+'; }
+    else { first = x.q_last; last = x.q_first; strand = '-'; }
+    char line[64];
+    append(buf, len, cap, qn.data(), qn.size());
+    int n = snprintf(line, sizeof line, "\t%u\t%u\t", (uint32_t)first, (uint32_t)last);
+    append(buf, len, cap, line, (size_t)n);
+    append(buf, len, cap, range_name, strlen(range_name));
+    n = snprintf(line, sizeof line, "\t.\t%c\n", strand);
+    append(buf, len, cap, line, (size_t)n);
+  }
+  return 0;
+}
+
+/* parse_range (partition.rs:1765-1789) */
+static int parse_range_parts(const char *a, size_t an, const char *b, size_t bn, int32_t *s, int32_t *e) {
+  if (!parse_i32(a, an, s)) return -1;
+  if (!parse_i32(b, bn, e)) return -2;
+  if (*s >= *e) return -3;
+  return 0;
+}
+/* parse_target_range (partition.rs:1752-1763) */
+int oracle_parse_target_range(const char *str, char *name_out, size_t name_cap, int32_t *start, int32_t *end) {
+  const char *colon = strrchr(str, ':'); /* rsplitn(2, ':') */
+  if (!colon) return -1;
+  const char *range = colon + 1;
+  /* parts[0].split('-') must give exactly 2 parts */
+  size_t rl = strlen(range), ndash = 0, dpos = 0;
+  for (size_t i = 0; i < rl; i++) if (range[i] == '-') { ndash++; dpos = i; }
+  if (ndash != 1) return -2;
+  if (parse_range_parts(range, dpos, range + dpos + 1, rl - dpos - 1, start, end) != 0) return -3;
+  size_t nl = (size_t)(colon - str);
+  if (nl + 1 > name_cap) return -4;
+  memcpy(name_out, str, nl); name_out[nl] = 0;
+  return 0;
+}
+/* parse_bed_file (partition.rs:1719-1750).  names/rnames are '\n'-joined. */
+long oracle_parse_bed_text(const char *text, size_t len, char *names_out, size_t names_cap, int32_t *se_out,
+                           char *rnames_out, size_t rnames_cap, size_t cap) {
+  size_t pos = 0, count = 0, no = 0, ro = 0;
+  while (pos < len) {
+    size_t eol = pos;
+    while (eol < len && text[eol] != '\n') eol++;
+    size_t l = eol - pos;
+    if (l > 0 && text[pos + l - 1] == '\r') l--;
+    std::vector<std::pair<const char *, size_t>> parts;
+    size_t st = 0;
+    const char *line = text + pos;
+    for (size_t i = 0; i <= l; i++) if (i == l || line[i] == '\t') { parts.push_back({line + st, i - st}); st = i + 1; }
+    if (parts.size() < 3) return -1;
+    int32_t s, e;
+    if (parse_range_parts(parts[1].first, parts[1].second, parts[2].first, parts[2].second, &s, &e) != 0) return -2;
+    std::string name;
+    bool have = false;
+    if (parts.size() > 3) {
+      std::string t(parts[3].first, parts[3].second);
+      size_t a = 0, b = t.size();
+      while (a < b && isspace((unsigned char)t[a])) a++;
+      while (b > a && isspace((unsigned char)t[b - 1])) b--;
+      t = t.substr(a, b - a);
+      if (!t.empty() && t != ".") { name = t; have = true; }
+    }
+    std::string chrom(parts[0].first, parts[0].second);
+    if (!have) name = chrom + ":" + std::to_string(s) + "-" + std::to_string(e);
+    if (count < cap) {
+      if (no + chrom.size() + 1 > names_cap || ro + name.size() + 1 > rnames_cap) return -3;
+      memcpy(names_out + no, chrom.data(), chrom.size()); no += chrom.size(); names_out[no++] = '\n';
+      memcpy(rnames_out + ro, name.data(), name.size()); ro += name.size(); rnames_out[ro++] = '\n';
+      se_out[2 * count] = s; se_out[2 * count + 1] = e;
+    }
+    count++;
+    pos = eol + 1;
+  }
+  if (no < names_cap) names_out[no] = 0;
+  if (ro < rnames_cap) rnames_out[ro] = 0;
+  return (long)count;
+}
+
+int oracle_bench(const oracle_index_t *ix, const uint32_t *target_ids, const int32_t *starts, const int32_t *ends,
+                 size_t n, const oracle_params_t *p, int threads, int mode, uint64_t *n_projected,
+                 uint64_t *n_results, double *seconds) {
+  std::atomic<uint64_t> proj{0}, nres{0};
+  std::atomic<bool> ok{true};
+  auto t0 = std::chrono::steady_clock::now();
+  if (mode == 0) { /* main.rs:7435 serial over ranges; rayon inside the BFS level */
+    for (size_t i = 0; i < n; i++) {
+      std::vector<AdjustedInterval> results;
+      g_nproj = 0;
+      if (!run_query(*ix, target_ids[i], starts[i], ends[i], *p, threads, results)) { ok = false; break; }
+      proj += g_nproj; nres += results.size();
+    }
+  } else {
+    parallel_for(n, threads, [&](size_t i) {
+      std::vector<AdjustedInterval> results;
+      g_nproj = 0;
+      if (!run_query(*ix, target_ids[i], starts[i], ends[i], *p, 1, results)) ok = false;
+      proj += g_nproj; nres += results.size();
+    });
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  *n_projected = proj; *n_results = nres;
+  *seconds = std::chrono::duration<double>(t1 - t0).count();
+  return ok ? 0 : -1;
+}
+
+} // extern "C"

@@ -1,0 +1,308 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the impg_amd package.
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Interval(C.Structure):
+    _fields_ = [("query_id", C.c_uint32), ("q_first", C.c_int32), ("q_last", C.c_int32),
+                ("target_id", C.c_uint32), ("t_first", C.c_int32), ("t_last", C.c_int32)]
+
+
+INTERVAL_DTYPE = np.dtype([("query_id", "<u4"), ("q_first", "<i4"), ("q_last", "<i4"),
+                           ("target_id", "<u4"), ("t_first", "<i4"), ("t_last", "<i4")])
+
+
+class Params(C.Structure):
+    _fields_ = [("transitive", C.c_int32), ("dfs", C.c_int32), ("max_depth", C.c_uint32),
+                ("min_transitive_len", C.c_int32), ("min_distance_between_ranges", C.c_int32),
+                ("min_output_length", C.c_int32), ("min_identity", C.c_double),
+                ("store_cigar", C.c_int32), ("multi_impg", C.c_int32)]
+
+
+def make_params(transitive=False, dfs=False, max_depth=2, min_transitive_len=101,
+                min_distance_between_ranges=10, min_output_length=None, min_identity=None,
+                store_cigar=False, multi_impg=False):
+    """Defaults are the reference CLI's (main.rs:4259-4285)."""
+    return Params(int(transitive), int(dfs), max_depth, min_transitive_len,
+                  min_distance_between_ranges,
+                  -1 if min_output_length is None else min_output_length,
+                  math.nan if min_identity is None else float(min_identity),
+                  int(store_cigar), int(multi_impg))
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = [os.path.join(_HERE, f) for f in ("impg_oracle.cpp", "impg_oracle.h")]
+    if force or not os.path.exists(so) or any(
+            os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.oracle_last_error.restype = C.c_char_p
+        L.oracle_last_projection_count.restype = C.c_uint64
+        L.oracle_parse_cigar.restype = C.c_long
+        L.oracle_parse_cigar.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.oracle_invert_cigar.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        L.oracle_project.restype = C.c_int
+        L.oracle_project.argtypes = [C.c_int32] * 6 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                       C.c_void_p, C.POINTER(C.c_size_t)]
+        L.oracle_gap_compressed_identity.restype = C.c_double
+        L.oracle_gap_compressed_identity.argtypes = [C.c_void_p, C.c_size_t]
+        L.oracle_sr_new.restype = C.c_void_p
+        L.oracle_sr_new.argtypes = [C.c_int32, C.c_int32]
+        L.oracle_sr_free.argtypes = [C.c_void_p]
+        L.oracle_sr_insert.restype = C.c_long
+        L.oracle_sr_insert.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]
+        L.oracle_sr_get.restype = C.c_long
+        L.oracle_sr_get.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_index_from_paf.restype = C.c_void_p
+        L.oracle_index_from_paf.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int]
+        L.oracle_index_from_paf_text.restype = C.c_void_p
+        L.oracle_index_from_paf_text.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int]
+        L.oracle_index_free.argtypes = [C.c_void_p]
+        L.oracle_num_seqs.restype = C.c_uint32
+        L.oracle_num_seqs.argtypes = [C.c_void_p]
+        L.oracle_seq_name.restype = C.c_char_p
+        L.oracle_seq_name.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_seq_len.restype = C.c_int64
+        L.oracle_seq_len.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_seq_id.restype = C.c_int64
+        L.oracle_seq_id.argtypes = [C.c_void_p, C.c_char_p]
+        L.oracle_num_records.restype = C.c_size_t
+        L.oracle_num_records.argtypes = [C.c_void_p]
+        L.oracle_num_targets.restype = C.c_size_t
+        L.oracle_num_targets.argtypes = [C.c_void_p]
+        L.oracle_target_entries.restype = C.c_size_t
+        L.oracle_target_entries.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+        L.oracle_query.restype = C.c_long
+        L.oracle_query.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params),
+                                   C.c_void_p, C.c_size_t]
+        L.oracle_bed_merge.restype = C.c_long
+        L.oracle_bed_merge.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int]
+        L.oracle_query_bed.restype = C.c_int
+        L.oracle_query_bed.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p,
+                                       C.POINTER(Params), C.c_int32, C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.oracle_parse_target_range.restype = C.c_int
+        L.oracle_parse_target_range.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t,
+                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.oracle_parse_bed_text.restype = C.c_long
+        L.oracle_parse_bed_text.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p,
+                                            C.c_char_p, C.c_size_t, C.c_size_t]
+        L.oracle_bench.restype = C.c_int
+        L.oracle_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        _LIB = L
+    return _LIB
+
+
+OPS = "=XIDM"
+
+
+def op(length, ch):
+    """CigarOp::new (impg.rs:81-93)"""
+    return (OPS.index(ch) << 29) | length
+
+
+def ops_from_pairs(pairs):
+    return np.array([op(l, c) for l, c in pairs], dtype=np.uint32)
+
+
+def ops_to_pairs(arr):
+    return [(int(v) & ((1 << 29) - 1), OPS[int(v) >> 29]) for v in arr]
+
+
+def parse_cigar(s):
+    b = s.encode() if isinstance(s, str) else s
+    out = np.zeros(len(b) + 1, dtype=np.uint32)
+    n = lib().oracle_parse_cigar(b, len(b), out.ctypes.data, out.size)
+    if n < 0:
+        raise ValueError("Invalid CIGAR operation")
+    return out[:n].copy()
+
+
+def invert_cigar(ops, strand_reverse):
+    a = np.ascontiguousarray(ops, dtype=np.uint32).copy()
+    lib().oracle_invert_cigar(a.ctypes.data, a.size, int(strand_reverse))
+    return a
+
+
+def project(r, record, ops):
+    """project_target_range_through_alignment; record=(ts,te,qs,qe,reverse).
+    Returns None or (q_start,q_end,slice_ops,t_start,t_end)."""
+    a = np.ascontiguousarray(ops, dtype=np.uint32)
+    out4 = np.zeros(4, dtype=np.int32)
+    sl = np.zeros(max(a.size, 1), dtype=np.uint32)
+    n = C.c_size_t(0)
+    ok = lib().oracle_project(r[0], r[1], record[0], record[1], record[2], record[3], int(record[4]),
+                              a.ctypes.data, a.size, out4.ctypes.data, sl.ctypes.data, C.byref(n))
+    if not ok:
+        return None
+    return int(out4[0]), int(out4[1]), sl[:n.value].copy(), int(out4[2]), int(out4[3])
+
+
+def gap_compressed_identity(ops):
+    a = np.ascontiguousarray(ops, dtype=np.uint32)
+    return lib().oracle_gap_compressed_identity(a.ctypes.data, a.size)
+
+
+class SortedRanges:
+    def __init__(self, sequence_length, min_distance=0):
+        self._h = lib().oracle_sr_new(sequence_length, min_distance)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_sr_free(self._h)
+            self._h = None
+
+    def insert(self, a, b):
+        out = np.zeros(2 * 4096, dtype=np.int32)
+        n = lib().oracle_sr_insert(self._h, a, b, out.ctypes.data, 4096)
+        return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+    def ranges(self):
+        out = np.zeros(2 * 65536, dtype=np.int32)
+        n = lib().oracle_sr_get(self._h, out.ctypes.data, 65536)
+        return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+
+class OracleIndex:
+    """Impg (and MultiImpg) built from PAF text or files."""
+
+    def __init__(self, paf_text=None, paf_paths=None, bidirectional=True, preparse=False):
+        L = lib()
+        if paf_text is not None:
+            b = paf_text.encode() if isinstance(paf_text, str) else bytes(paf_text)
+            self._h = L.oracle_index_from_paf_text(b, len(b), int(bidirectional), int(preparse))
+        else:
+            arr = (C.c_char_p * len(paf_paths))(*[p.encode() for p in paf_paths])
+            self._h = L.oracle_index_from_paf(arr, len(paf_paths), int(bidirectional), int(preparse))
+        if not self._h:
+            raise RuntimeError(L.oracle_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_index_free(self._h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def num_seqs(self):
+        return lib().oracle_num_seqs(self._h)
+
+    def seq_name(self, i):
+        return lib().oracle_seq_name(self._h, i).decode()
+
+    def seq_len(self, i):
+        return lib().oracle_seq_len(self._h, i)
+
+    def seq_id(self, name):
+        r = lib().oracle_seq_id(self._h, name.encode())
+        return None if r < 0 else int(r)
+
+    def num_records(self):
+        return lib().oracle_num_records(self._h)
+
+    def num_targets(self):
+        return lib().oracle_num_targets(self._h)
+
+    def target_entries(self, target_id):
+        n = lib().oracle_target_entries(self._h, target_id, None, 0)
+        out = np.zeros((max(n, 1), 4), dtype=np.int32)
+        lib().oracle_target_entries(self._h, target_id, out.ctypes.data, n)
+        return out[:n]
+
+    def query(self, target_id, start, end, params=None, **kw):
+        """Results (numpy structured array) in reference emission order."""
+        p = params or make_params(**kw)
+        cap = 1 << 12
+        while True:
+            out = np.zeros(cap, dtype=INTERVAL_DTYPE)
+            n = lib().oracle_query(self._h, target_id, start, end, C.byref(p), out.ctypes.data, cap)
+            if n < 0:
+                raise RuntimeError(lib().oracle_last_error().decode())
+            if n <= cap:
+                return out[:n].copy()
+            cap = n
+
+    def last_projection_count(self):
+        return lib().oracle_last_projection_count()
+
+    def query_bed(self, target_name, start, end, range_name=None, merge_distance=0, params=None, **kw):
+        p = params or make_params(**kw)
+        if range_name is None:
+            range_name = "%s:%d-%d" % (target_name, start, end)
+        buf = C.c_void_p(None)
+        ln = C.c_size_t(0)
+        cap = C.c_size_t(0)
+        rc = lib().oracle_query_bed(self._h, target_name.encode(), start, end, range_name.encode(),
+                                    C.byref(p), merge_distance, C.byref(buf), C.byref(ln), C.byref(cap))
+        try:
+            if rc != 0:
+                raise RuntimeError(lib().oracle_last_error().decode())
+            return C.string_at(buf, ln.value).decode() if ln.value else ""
+        finally:
+            if buf.value:
+                C.CDLL(None).free(buf)
+
+    def bench(self, target_ids, starts, ends, params, threads=1, mode=0):
+        t = np.ascontiguousarray(target_ids, dtype=np.uint32)
+        s = np.ascontiguousarray(starts, dtype=np.int32)
+        e = np.ascontiguousarray(ends, dtype=np.int32)
+        npj = C.c_uint64(0)
+        nr = C.c_uint64(0)
+        sec = C.c_double(0)
+        rc = lib().oracle_bench(self._h, t.ctypes.data, s.ctypes.data, e.ctypes.data, t.size,
+                                C.byref(params), threads, mode, C.byref(npj), C.byref(nr), C.byref(sec))
+        if rc != 0:
+            raise RuntimeError(lib().oracle_last_error().decode())
+        return npj.value, nr.value, sec.value
+
+
+def bed_merge(intervals, merge_distance, merge_strands=True):
+    a = np.ascontiguousarray(intervals, dtype=INTERVAL_DTYPE).copy()
+    n = lib().oracle_bed_merge(a.ctypes.data, a.size, merge_distance, int(merge_strands))
+    return a[:n].copy()
+
+
+def parse_target_range(s):
+    name = C.create_string_buffer(4096)
+    a = C.c_int32(0)
+    b = C.c_int32(0)
+    rc = lib().oracle_parse_target_range(s.encode(), name, 4096, C.byref(a), C.byref(b))
+    if rc != 0:
+        raise ValueError("bad target range (%d)" % rc)
+    return name.value.decode(), a.value, b.value
+
+
+def parse_bed_text(text):
+    b = text.encode() if isinstance(text, str) else text
+    cap = b.count(b"\n") + 2
+    names = C.create_string_buffer(len(b) + 16)
+    rn = C.create_string_buffer(len(b) * 2 + 64 * cap)
+    se = np.zeros(2 * cap, dtype=np.int32)
+    n = lib().oracle_parse_bed_text(b, len(b), names, len(names), se.ctypes.data, rn, len(rn), cap)
+    if n < 0:
+        raise ValueError("Invalid BED file format (%d)" % n)
+    ns = names.value.decode().split("\n")[:n]
+    rs = rn.value.decode().split("\n")[:n]
+    return [(ns[i], int(se[2 * i]), int(se[2 * i + 1]), rs[i]) for i in range(n)]

@@ -1,0 +1,298 @@
+"""Pins the CPU oracle against every known-answer test the reference holds for
+the hot path.  Each case cites the reference test it
+restates (paths under /root/reference)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+F, R = False, True
+
+
+def P(pairs):
+    return o.ops_from_pairs(pairs)
+
+
+def check(result, expect):
+    qs, qe, sl, ts, te = result
+    assert (qs, qe, o.ops_to_pairs(sl), ts, te) == expect
+
+
+# src/impg.rs:2981-3001
+def test_project_forward():
+    ops = P([(100, "=")])
+    check(o.project((100, 200), (100, 200, 0, 100, F), ops), (0, 100, [(100, "=")], 100, 200))
+
+
+def test_project_reverse():
+    ops = P([(100, "=")])
+    check(o.project((100, 200), (100, 200, 0, 100, R), ops), (100, 0, [(100, "=")], 100, 200))
+
+
+BASE_OPS = [(10, "="), (5, "I"), (5, "D"), (50, "="), (50, "I"), (35, "=")]
+BASE = (0, 100, 50, 200, F)
+
+
+# src/impg.rs:3003-3055
+@pytest.mark.parametrize("rng,expect", [
+    ((0, 100), (50, 200, BASE_OPS, 0, 100)),
+    ((50, 55), (100, 105, [(5, "=")], 50, 55)),
+    ((50, 64), (100, 114, [(14, "=")], 50, 64)),
+    ((50, 65), (100, 165, [(15, "="), (50, "I")], 50, 65)),
+    ((50, 66), (100, 166, [(15, "="), (50, "I"), (1, "=")], 50, 66)),
+    ((70, 95), (170, 195, [(25, "=")], 70, 95)),
+])
+def test_project_base(rng, expect):
+    check(o.project(rng, BASE, P(BASE_OPS)), expect)
+
+
+# src/impg.rs:3029-3033: "We no longer output empty target ranges"
+def test_project_empty_target_range_not_emitted():
+    assert o.project((65, 65), BASE, P(BASE_OPS)) is None
+
+
+# src/impg.rs:3058-3083
+def test_forward_projection_simple():
+    check(o.project((100, 200), (100, 200, 100, 200, F), P([(100, "=")])),
+          (100, 200, [(100, "=")], 100, 200))
+
+
+def test_reverse_projection_simple():
+    check(o.project((100, 200), (100, 200, 100, 200, R), P([(100, "=")])),
+          (200, 100, [(100, "=")], 100, 200))
+
+
+# src/impg.rs:3086-3113
+def test_forward_projection_with_insertions():
+    ops = [(50, "="), (10, "I"), (50, "=")]
+    qs, qe, sl, _, _ = o.project((50, 150), (50, 150, 50, 160, F), P(ops))
+    assert (qs, qe, o.ops_to_pairs(sl)) == (50, 160, ops)
+
+
+def test_forward_projection_with_deletions():
+    ops = [(50, "="), (10, "D"), (40, "=")]
+    qs, qe, sl, _, _ = o.project((50, 150), (50, 150, 50, 140, F), P(ops))
+    assert (qs, qe, o.ops_to_pairs(sl)) == (50, 140, ops)
+
+
+# src/impg.rs:3116-3134
+def test_reverse_projection_with_mixed_operations():
+    ops = [(50, "="), (10, "D"), (10, "I"), (40, "=")]
+    qs, qe, sl, _, _ = o.project((150, 250), (100, 200, 200, 300, R), P(ops))
+    assert (qs, qe, o.ops_to_pairs(sl)) == (250, 200, [(10, "D"), (10, "I"), (40, "=")])
+
+
+# src/impg.rs:3137-3156
+def test_edge_case_projection():
+    ops = [(10, "="), (20, "D"), (8, "="), (1, "X"), (1, "="), (10, "I"), (10, "=")]
+    check(o.project((0, 10), (0, 50, 0, 40, F), P(ops)), (0, 10, [(10, "=")], 0, 10))
+
+
+# src/impg.rs:3158-3168
+def test_parse_cigar_to_delta_basic():
+    assert o.ops_to_pairs(o.parse_cigar("10=5I5D")) == [(10, "="), (5, "I"), (5, "D")]
+
+
+# src/impg.rs:3170-3174 (commented out in the reference: Q panics in CigarOp::new)
+def test_parse_cigar_invalid_op():
+    with pytest.raises(ValueError):
+        o.parse_cigar("10=5Q")
+
+
+# src/impg.rs:3200-3264
+def test_invert_cigar():
+    ops = P([(10, "="), (5, "I"), (3, "D"), (7, "X")])
+    assert o.ops_to_pairs(o.invert_cigar(ops, F)) == [(10, "="), (5, "D"), (3, "I"), (7, "X")]
+    ops = P([(10, "="), (5, "I"), (3, "D")])
+    assert o.ops_to_pairs(o.invert_cigar(ops, R)) == [(3, "I"), (5, "D"), (10, "=")]
+    assert len(o.invert_cigar(P([]), F)) == 0 and len(o.invert_cigar(P([]), R)) == 0
+    ops = P([(100, "="), (50, "X")])
+    assert o.ops_to_pairs(o.invert_cigar(ops, F)) == [(100, "="), (50, "X")]
+    assert o.ops_to_pairs(o.invert_cigar(ops, R)) == [(50, "X"), (100, "=")]
+
+
+# src/impg.rs:3176-3198 : strand_and_data_offset = 45, data_bytes = 3
+def test_parse_paf_offsets():
+    line = "seq1\t100\t10\t20\t+\tt1\t200\t30\t40\t10\t20\t255\tcg:Z:10M\n"
+    ix = o.OracleIndex(paf_text=line, preparse=True)
+    assert ix.num_seqs() == 2 and ix.seq_name(0) == "seq1" and ix.seq_name(1) == "t1"
+    assert ix.seq_len(0) == 100 and ix.seq_len(1) == 200
+    assert line[45:45 + 3] == "10M"
+    ent = ix.target_entries(1)  # keyed by t1: forward entry [30,40] query seq1
+    assert ent.tolist() == [[30, 40, 0, 0]]
+    ent = ix.target_entries(0)  # reversed entry keyed by seq1 [10,20]
+    assert ent.tolist() == [[10, 20, 1, 2]]
+    # the offset/len convention is exercised end-to-end: query t1:30-40 projects to seq1:10-20
+    r = ix.query(1, 30, 40)
+    assert r[1].tolist() == (0, 10, 20, 1, 30, 40)
+
+
+# src/paf.rs:365-392: no cg tag -> data_bytes = 0; a query then fails like the
+# reference's panic (impg.rs:506-511)
+def test_parse_paf_no_cigar():
+    line = "seq1\t100\t0\t100\t+\tseq2\t100\t0\t100\t60\t100\t255"
+    ix = o.OracleIndex(paf_text=line)
+    with pytest.raises(RuntimeError, match="does not contain CIGAR"):
+        ix.query(1, 0, 100)
+
+
+# src/paf.rs:400-415
+def test_parse_paf_invalid():
+    with pytest.raises(RuntimeError):
+        o.OracleIndex(paf_text="seq1\t100\t0\t100\t+\tseq2\t100\tz\t100\t60\t100\t255\tcg:Z:10M")
+    with pytest.raises(RuntimeError):  # < 12 fields
+        o.OracleIndex(paf_text="seq1\t100\t0\t100\t+\tseq2\t100\t0\t100\t60\t100")
+
+
+# ---------------------------------------------------------------------------
+# tests/test_transitive_integrity.rs scenarios (CLI: -d 0 --min-transitive-len 0)
+# ---------------------------------------------------------------------------
+def bed(ix, rng, **kw):
+    name, s, e = o.parse_target_range(rng)
+    kw.setdefault("min_transitive_len", 0)
+    out = ix.query_bed(name, s, e, merge_distance=0, **kw)
+    rows = []
+    for line in out.splitlines():
+        f = line.split("\t")
+        rows.append((f[0], int(f[1]), int(f[2]), f[3], f[4], f[5]))
+    return rows
+
+
+def paf(*lines):
+    return "\n".join(lines) + "\n"
+
+
+L100 = "\t100\t100\t60\tcg:Z:100="
+
+
+# :75 test_non_overlapping_regions_stay_separate
+def test_T1():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100,
+                                    "A\t1000\t500\t600\t+\tC\t1000\t0\t100" + L100))
+    names = {r[0] for r in bed(ix, "A:0-100", transitive=True)}
+    assert names == {"A", "B"}
+    names = {r[0] for r in bed(ix, "A:500-600", transitive=True)}
+    assert names == {"A", "C"}
+
+
+# :156 test_transitive_coordinate_accuracy (exactly 25/75 by Appendix A.4)
+def test_T2():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100,
+                                    "B\t1000\t0\t100\t+\tC\t1000\t0\t100" + L100))
+    rows = bed(ix, "A:25-75", transitive=True)
+    assert {r[0] for r in rows} == {"A", "B", "C"}
+    for name, s, e, rn, _, strand in rows:
+        assert 45 <= e - s <= 55
+        assert (s, e) == (25, 75) and rn == "A:25-75" and strand == "+"
+
+
+# :227 test_bidirectional_symmetry
+def test_T3():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t100\t+\tB\t1000\t200\t300" + L100))
+    rows = bed(ix, "A:0-100")
+    assert ("B", 200, 300, "A:0-100", ".", "+") in rows
+    rows = bed(ix, "B:200-300")
+    assert ("A", 0, 100, "B:200-300", ".", "+") in rows
+
+
+# :298 test_reverse_strand_coordinates (hand-derived row: B 50 100 -)
+def test_T4():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t100\t-\tB\t1000\t0\t100" + L100))
+    rows = bed(ix, "A:0-50")
+    b = [r for r in rows if r[0] == "B"]
+    assert b == [("B", 50, 100, "A:0-50", ".", "-")]
+
+
+# :349 test_distant_regions_no_collapse
+def test_T5():
+    ix = o.OracleIndex(paf_text=paf(
+        "A\t2000\t0\t100\t+\tB\t1000\t0\t100" + L100,
+        "A\t2000\t1000\t1100\t+\tC\t1000\t0\t100" + L100,
+        "B\t1000\t0\t100\t+\tD\t1000\t0\t100" + L100,
+        "C\t1000\t0\t100\t+\tD\t1000\t500\t600" + L100))
+    d = [r for r in bed(ix, "A:0-100", transitive=True, max_depth=3) if r[0] == "D"]
+    assert d and all(r[1] < 200 for r in d)
+    d = [r for r in bed(ix, "A:1000-1100", transitive=True, max_depth=3) if r[0] == "D"]
+    assert d and all(r[1] >= 400 for r in d)
+
+
+# :453 test_indel_coordinate_accuracy (hand-derived: B 0 50 / B 50 100)
+def test_T6():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t110\t+\tB\t1000\t0\t100\t100\t110\t60\tcg:Z:50=10I50="))
+    b = [r for r in bed(ix, "A:0-50") if r[0] == "B"]
+    assert b == [("B", 0, 50, "A:0-50", ".", "+")]
+    b = [r for r in bed(ix, "A:60-110") if r[0] == "B"]
+    assert b == [("B", 50, 100, "A:60-110", ".", "+")]
+
+
+# :536 test_multiple_alignments_stay_separate
+def test_T7():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100,
+                                    "A\t1000\t0\t100\t+\tB\t1000\t500\t600" + L100))
+    b = [r for r in bed(ix, "A:0-100") if r[0] == "B"]
+    assert len(b) == 2 and len({r[1] for r in b}) == 2
+
+
+# :649 test_empty_query_region
+def test_T9():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100))
+    rows = bed(ix, "A:500-600")
+    assert rows == [("A", 500, 600, "A:500-600", ".", "+")]
+
+
+# :689 test_transitive_depth_limit
+def test_T10():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100,
+                                    "B\t1000\t0\t100\t+\tC\t1000\t0\t100" + L100,
+                                    "C\t1000\t0\t100\t+\tD\t1000\t0\t100" + L100))
+    assert {r[0] for r in bed(ix, "A:0-100", transitive=True, max_depth=1)} == {"A", "B"}
+    assert {r[0] for r in bed(ix, "A:0-100", transitive=True, max_depth=2)} == {"A", "B", "C"}
+    # DFS and MultiImpg flavours agree on these fixtures
+    assert {r[0] for r in bed(ix, "A:0-100", transitive=True, dfs=True, max_depth=2)} == {"A", "B", "C"}
+    assert {r[0] for r in bed(ix, "A:0-100", transitive=True, multi_impg=True, max_depth=2)} == {"A", "B", "C"}
+
+
+# main.rs:10387-10403: ranges shorter than --min-transitive-len are rejected
+def test_min_length_validation():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100))
+    with pytest.raises(RuntimeError):
+        ix.query_bed("A", 0, 100, merge_distance=0)  # default min_transitive_len = 101
+    with pytest.raises(RuntimeError):  # perform_query: end > length (main.rs:11632)
+        ix.query_bed("A", 0, 2000, merge_distance=0)
+
+
+# partition.rs:1719-1789
+def test_parse_ranges():
+    assert o.parse_target_range("S288C#1#chrI:50000-100000") == ("S288C#1#chrI", 50000, 100000)
+    assert o.parse_target_range("a:b:1-2") == ("a:b", 1, 2)
+    with pytest.raises(ValueError):
+        o.parse_target_range("chr1:5-5")
+    rows = o.parse_bed_text("chr1\t10\t20\nchr2\t5\t9\tfoo\nchr3\t1\t2\t.\n")
+    assert rows == [("chr1", 10, 20, "chr1:10-20"), ("chr2", 5, 9, "foo"), ("chr3", 1, 2, "chr3:1-2")]
+    with pytest.raises(ValueError):
+        o.parse_bed_text("chr1\t10\n")
+
+
+# SortedRanges (impg.rs:242-369): behaviour derived from the code, incl. the A.6 example
+def test_sorted_ranges():
+    sr = o.SortedRanges(1000, 0)
+    assert sr.insert(100, 300) == [(100, 300)]
+    assert sr.insert(250, 320) == [(300, 320)]
+    assert sr.ranges() == [(100, 320)]
+    assert sr.insert(500, 400) == [(400, 500)]  # reversed input is normalised
+    assert sr.insert(0, 1200) == [(0, 100), (320, 400), (500, 1000)]  # clamp to sequence_length
+    assert sr.ranges() == [(0, 1000)]
+    sr = o.SortedRanges(1000, 0)
+    sr.insert(250, 320)
+    assert sr.insert(100, 300) == [(100, 250)]  # order dependence
+    sr = o.SortedRanges(1000, 0)
+    sr.insert(10, 20)
+    sr.insert(30, 40)
+    assert sr.insert(20, 30) == [(20, 30)]
+    assert sr.ranges() == [(10, 40)]
+
+
+def test_gap_compressed_identity():
+    assert o.gap_compressed_identity(P([(90, "="), (10, "X")])) == 0.9
+    assert o.gap_compressed_identity(P([(8, "="), (100, "I"), (7, "D"), (1, "M")])) == 9 / 11
+    assert o.gap_compressed_identity(P([])) == 0.0

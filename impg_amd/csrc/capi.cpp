@@ -1,0 +1,368 @@
+// extern "C" entry points of libimpg_gpu.so (include/impg_gpu.h).  Nothing
+// unwinds across this file: every body is wrapped and mapped to a status code.
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+#include <new>
+
+#include "engine.hpp"
+
+namespace impg {
+thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+void render_bed(const impg_gpu_results &res, const impg_gpu_index &ix, const char *const *range_names,
+                const impg_gpu_params_t &p, int32_t merge_distance, std::string &out);
+}  // namespace impg
+
+using namespace impg;
+
+impg_gpu_index::~impg_gpu_index() { delete engine; }
+
+#define IMPG_TRY try {
+#define IMPG_CATCH                                  \
+  }                                                 \
+  catch (const impg::Error &e) {                    \
+    impg::set_error(e.msg);                         \
+    return e.code;                                  \
+  }                                                 \
+  catch (const std::bad_alloc &) {                  \
+    impg::set_error("host out of memory");          \
+    return IMPG_E_OOM;                              \
+  }                                                 \
+  catch (const std::exception &e) {                 \
+    impg::set_error(std::string("internal: ") + e.what()); \
+    return IMPG_E_INVALID;                          \
+  }
+
+namespace {
+
+void require_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw Error{IMPG_E_HIP, "no HIP device available (libimpg_gpu has no CPU fallback)"};
+  if (device < 0 || device >= n) throw Error{IMPG_E_INVALID, "device ordinal out of range"};
+}
+
+std::unique_ptr<impg_gpu_index> make_index(const impg_gpu_record_t *records, size_t n_records, const uint32_t *ops,
+                                           size_t n_ops, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
+                                           int order_policy, int device, uint32_t shard, uint32_t n_shards,
+                                           HostSeqIndex *seq) {
+  if ((!records && n_records) || (!ops && n_ops) || (!seq_len && n_seq)) throw Error{IMPG_E_INVALID, "null input array"};
+  require_device(device);
+  auto ix = std::make_unique<impg_gpu_index>();
+  ix->device = device;
+  if (seq) ix->seq = std::move(*seq);
+  build_index(*ix, records, n_records, ops, n_ops, seq_len, n_seq, bidirectional != 0, order_policy, shard, n_shards);
+  ix->engine = new Engine(device);
+  ix->stream = ix->engine->stream;
+  return ix;
+}
+
+void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p,
+                      std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, impg_gpu_results &res) {
+  const bool transitive = p.transitive != 0;
+  res.ranges.assign(h_ranges, h_ranges + n);
+  std::vector<FrontierRec> self;
+  if (transitive) {
+    self.resize(n);
+    if (n) IMPG_HIP(hipMemcpy(self.data(), self_dev.p, (size_t)n * sizeof(FrontierRec), hipMemcpyDeviceToHost));
+  }
+  struct HostLevel {
+    std::vector<FrontierRec> fr;
+    std::vector<uint32_t> pair_range, qid;
+    std::vector<int32_t> qs, qe, ts, te;
+  };
+  std::vector<HostLevel> hl(levels.size());
+  for (size_t l = 0; l < levels.size(); l++) {
+    LevelBufs &L = *levels[l];
+    HostLevel &H = hl[l];
+    H.fr.resize(L.n_frontier);
+    if (L.n_frontier) IMPG_HIP(hipMemcpy(H.fr.data(), L.frontier.p, (size_t)L.n_frontier * sizeof(FrontierRec), hipMemcpyDeviceToHost));
+    size_t P = L.n_pairs;
+    H.pair_range.resize(P); H.qid.resize(P); H.qs.resize(P); H.qe.resize(P); H.ts.resize(P); H.te.resize(P);
+    if (P) {
+      IMPG_HIP(hipMemcpy(H.pair_range.data(), L.pair_range.p, P * 4, hipMemcpyDeviceToHost));
+      IMPG_HIP(hipMemcpy(H.qid.data(), L.qid.p, P * 4, hipMemcpyDeviceToHost));
+      IMPG_HIP(hipMemcpy(H.qs.data(), L.qs.p, P * 4, hipMemcpyDeviceToHost));
+      IMPG_HIP(hipMemcpy(H.qe.data(), L.qe.p, P * 4, hipMemcpyDeviceToHost));
+      IMPG_HIP(hipMemcpy(H.ts.data(), L.ts.p, P * 4, hipMemcpyDeviceToHost));
+      IMPG_HIP(hipMemcpy(H.te.data(), L.te.p, P * 4, hipMemcpyDeviceToHost));
+    }
+  }
+  auto emitted = [&](const HostLevel &H, size_t k) {
+    if (H.qid[k] == HIT_NONE) return false;
+    if (transitive && p.min_output_length >= 0 && std::abs((int64_t)H.qe[k] - H.qs[k]) < p.min_output_length) return false;
+    return true;  // impg.rs:2482-2504
+  };
+  // pass 1: counts
+  std::vector<uint64_t> cnt(n + 1, 0);
+  for (uint32_t q = 0; q < n; q++) {
+    if (!transitive) cnt[q] = 1;                                   // impg.rs:1864-1880
+    else cnt[q] = self[q].start < self[q].end ? 1 : 0;             // impg.rs:2345-2363
+  }
+  for (auto &H : hl)
+    for (size_t k = 0; k < H.qid.size(); k++)
+      if (emitted(H, k)) cnt[H.fr[H.pair_range[k]].qidx]++;
+  res.offsets.assign(n + 1, 0);
+  for (uint32_t q = 0; q < n; q++) res.offsets[q + 1] = res.offsets[q] + cnt[q];
+  res.intervals.resize(res.offsets[n]);
+  std::vector<uint64_t> cur(res.offsets.begin(), res.offsets.end() - 1);
+  for (uint32_t q = 0; q < n; q++) {
+    if (!transitive) {
+      const auto &r = h_ranges[q];
+      res.intervals[cur[q]++] = {r.target_id, r.start, r.end, r.target_id, r.start, r.end};
+    } else if (self[q].start < self[q].end) {
+      res.intervals[cur[q]++] = {self[q].target_id, self[q].start, self[q].end, self[q].target_id, self[q].start, self[q].end};
+    }
+  }
+  // pass 2: levels in order, slots in order == the reference's emission order
+  for (auto &H : hl)
+    for (size_t k = 0; k < H.qid.size(); k++)
+      if (emitted(H, k)) {
+        const FrontierRec &f = H.fr[H.pair_range[k]];
+        res.intervals[cur[f.qidx]++] = {H.qid[k], H.qs[k], H.qe[k], f.target_id, H.ts[k], H.te[k]};
+      }
+  res.projected = E.last_projected;
+}
+
+void check_ranges(const impg_gpu_range_t *ranges, size_t n) {
+  if (n >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 ranges in one batch"};
+  for (size_t i = 0; i < n; i++)
+    if (ranges[i].start >= ranges[i].end) throw Error{IMPG_E_INVALID, "query range must satisfy start < end"};
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *impg_gpu_last_error(void) { return impg::g_error.c_str(); }
+
+int impg_gpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int impg_gpu_index_create(const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops, size_t n_ops,
+                          const int64_t *seq_len, uint32_t n_seq, int bidirectional, int order_policy, int device,
+                          impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out) throw Error{IMPG_E_INVALID, "null out"};
+  *out = make_index(records, n_records, cigar_ops, n_ops, seq_len, n_seq, bidirectional, order_policy, device, 0, 1, nullptr).release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_create_sharded(const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops,
+                                  size_t n_ops, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
+                                  int order_policy, int device, uint32_t shard, uint32_t n_shards,
+                                  impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out) throw Error{IMPG_E_INVALID, "null out"};
+  *out = make_index(records, n_records, cigar_ops, n_ops, seq_len, n_seq, bidirectional, order_policy, device, shard, n_shards, nullptr).release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths, int bidirectional, int order_policy, int device,
+                                   impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out || !paths || n_paths <= 0) throw Error{IMPG_E_INVALID, "bad arguments"};
+  require_device(device);
+  ParsedPaf pp;
+  std::vector<std::string> ps(paths, paths + n_paths);
+  parse_paf_files(ps, pp);
+  std::vector<int64_t> lens = pp.seq.lens;
+  *out = make_index(pp.records.data(), pp.records.size(), pp.ops.data(), pp.ops.size(), lens.data(), (uint32_t)lens.size(),
+                    bidirectional, order_policy, device, 0, 1, &pp.seq).release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+void impg_gpu_index_destroy(impg_gpu_index_t *ix) { delete ix; }
+
+uint32_t impg_gpu_num_seqs(const impg_gpu_index_t *ix) { return (uint32_t)ix->seq.lens.size(); }
+const char *impg_gpu_seq_name(const impg_gpu_index_t *ix, uint32_t id) {
+  return id < ix->seq.names.size() ? ix->seq.names[id].c_str() : nullptr;
+}
+int64_t impg_gpu_seq_len(const impg_gpu_index_t *ix, uint32_t id) { return id < ix->seq.lens.size() ? ix->seq.lens[id] : -1; }
+int64_t impg_gpu_seq_id(const impg_gpu_index_t *ix, const char *name) {
+  auto it = ix->seq.name_to_id.find(name);
+  return it == ix->seq.name_to_id.end() ? -1 : (int64_t)it->second;
+}
+size_t impg_gpu_num_targets(const impg_gpu_index_t *ix) { return ix->n_targets; }
+size_t impg_gpu_target_ids(const impg_gpu_index_t *ix, uint32_t *out, size_t cap) {
+  size_t k = 0;
+  for (uint32_t s = 0; s + 1 < ix->h_tgt_off.size(); s++)
+    if (ix->h_tgt_off[s + 1] != ix->h_tgt_off[s]) {
+      if (out && k < cap) out[k] = s;
+      k++;
+    }
+  return k;
+}
+size_t impg_gpu_num_entries(const impg_gpu_index_t *ix) { return ix->n_entries; }
+size_t impg_gpu_num_records(const impg_gpu_index_t *ix) { return ix->n_records; }
+size_t impg_gpu_device_bytes(const impg_gpu_index_t *ix) { return ix->device_bytes; }
+
+int impg_gpu_visit_rank(uint32_t n, int order_policy, uint32_t *rank_out) {
+  IMPG_TRY
+  if (!rank_out && n) throw Error{IMPG_E_INVALID, "null argument"};
+  if (order_policy == IMPG_ORDER_COITREES) coitrees_visit_rank(n, rank_out);
+  else if (order_policy == IMPG_ORDER_SORTED) for (uint32_t i = 0; i < n; i++) rank_out[i] = i;
+  else throw Error{IMPG_E_INVALID, "bad order policy"};
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_query_batch(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
+                         impg_gpu_results_t **out) {
+  IMPG_TRY
+  if (!ix || !params || !out || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
+  check_ranges(ranges, n);
+  Engine &E = *ix->engine;
+  Engine::check_params(*params);
+  IMPG_HIP(hipSetDevice(ix->device));
+  auto res = std::make_unique<impg_gpu_results>();
+  E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
+  if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
+  std::vector<std::unique_ptr<LevelBufs>> levels;
+  DevBuf self_dev;
+  E.run(*ix, E.ranges_dev.as<impg_gpu_range_t>(), (uint32_t)n, *params, &levels, nullptr, nullptr, nullptr, &self_dev);
+  assemble_results(E, ranges, (uint32_t)n, *params, levels, self_dev, *res);
+  *out = res.release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_query(impg_gpu_index_t *ix, uint32_t target_id, int32_t start, int32_t end, const impg_gpu_params_t *params,
+                   impg_gpu_results_t **out) {
+  impg_gpu_range_t r{target_id, start, end};
+  return impg_gpu_query_batch(ix, &r, 1, params, out);
+}
+
+size_t impg_gpu_results_num_ranges(const impg_gpu_results_t *r) { return r->offsets.empty() ? 0 : r->offsets.size() - 1; }
+size_t impg_gpu_results_total(const impg_gpu_results_t *r) { return r->intervals.size(); }
+const uint64_t *impg_gpu_results_offsets(const impg_gpu_results_t *r) { return r->offsets.data(); }
+const impg_gpu_interval_t *impg_gpu_results_intervals(const impg_gpu_results_t *r) { return r->intervals.data(); }
+uint64_t impg_gpu_results_projected(const impg_gpu_results_t *r) { return r->projected; }
+void impg_gpu_results_free(impg_gpu_results_t *r) { delete r; }
+
+static int stats_impl(impg_gpu_index_t *ix, const impg_gpu_range_t *d_ranges, size_t n, const impg_gpu_params_t *params,
+                      uint64_t *per_range_count, uint64_t *per_range_checksum, impg_gpu_stats_t *stats) {
+  Engine &E = *ix->engine;
+  unsigned long long *dc = nullptr, *dk = nullptr;
+  if (per_range_count) {
+    E.stat_count.reserve(std::max<size_t>(n * 8, 256));
+    IMPG_HIP(hipMemsetAsync(E.stat_count.p, 0, n * 8, E.stream));
+    dc = E.stat_count.as<unsigned long long>();
+  }
+  if (per_range_checksum) {
+    E.stat_cksum.reserve(std::max<size_t>(n * 8, 256));
+    IMPG_HIP(hipMemsetAsync(E.stat_cksum.p, 0, n * 8, E.stream));
+    dk = E.stat_cksum.as<unsigned long long>();
+  }
+  E.run(*ix, d_ranges, (uint32_t)n, *params, nullptr, dc, dk, stats, nullptr);
+  if (per_range_count && n) IMPG_HIP(hipMemcpy(per_range_count, dc, n * 8, hipMemcpyDeviceToHost));
+  if (per_range_checksum && n) IMPG_HIP(hipMemcpy(per_range_checksum, dk, n * 8, hipMemcpyDeviceToHost));
+  return IMPG_OK;
+}
+
+int impg_gpu_query_batch_stats(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
+                               uint64_t *per_range_count, uint64_t *per_range_checksum, impg_gpu_stats_t *stats) {
+  IMPG_TRY
+  if (!ix || !params || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
+  check_ranges(ranges, n);
+  Engine &E = *ix->engine;
+  IMPG_HIP(hipSetDevice(ix->device));
+  E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
+  if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
+  return stats_impl(ix, E.ranges_dev.as<impg_gpu_range_t>(), n, params, per_range_count, per_range_checksum, stats);
+  IMPG_CATCH
+}
+
+int impg_gpu_query_batch_stats_dev(impg_gpu_index_t *ix, const impg_gpu_range_t *d_ranges, size_t n,
+                                   const impg_gpu_params_t *params, uint64_t *per_range_count,
+                                   uint64_t *per_range_checksum, impg_gpu_stats_t *stats) {
+  IMPG_TRY
+  if (!ix || !params || (!d_ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
+  if (n >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 ranges in one batch"};
+  IMPG_HIP(hipSetDevice(ix->device));
+  return stats_impl(ix, d_ranges, n, params, per_range_count, per_range_checksum, stats);
+  IMPG_CATCH
+}
+
+long impg_gpu_bed_merge(impg_gpu_interval_t *iv, size_t n, int32_t merge_distance, int merge_strands) {
+  try {
+    return (long)bed_merge(iv, n, merge_distance, merge_strands != 0);
+  } catch (...) {
+    impg::set_error("bed_merge failed");
+    return IMPG_E_OOM;
+  }
+}
+
+int impg_gpu_results_bed(const impg_gpu_results_t *res, const impg_gpu_index_t *ix, const char *const *range_names,
+                         const impg_gpu_params_t *params, int32_t merge_distance, char **text, size_t *len) {
+  IMPG_TRY
+  if (!res || !ix || !params || !text || !len) throw Error{IMPG_E_INVALID, "null argument"};
+  std::string s;
+  render_bed(*res, *ix, range_names, *params, merge_distance, s);
+  char *p = (char *)malloc(s.size() + 1);
+  if (!p) throw Error{IMPG_E_OOM, "host out of memory"};
+  memcpy(p, s.data(), s.size());
+  p[s.size()] = 0;
+  *text = p;
+  *len = s.size();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_stage_count(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
+                         uint32_t *d_counts, uint64_t *total) {
+  IMPG_TRY
+  if (!ix || (!d_frontier && n) || (!d_counts && n) || !total) throw Error{IMPG_E_INVALID, "null argument"};
+  if (n >= (1ull << 32) - 16) throw Error{IMPG_E_UNSUPPORTED, "frontier too large"};
+  Engine &E = *ix->engine;
+  IMPG_HIP(hipSetDevice(ix->device));
+  E.win.reserve(std::max<size_t>(n * 8, 256));
+  E.stage_off.reserve(std::max<size_t>(n * 4, 256));
+  launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, d_counts, E.win.as<uint2>(), E.stream);
+  *total = E.scan(d_counts, E.stage_off.as<uint32_t>(), (uint32_t)n);
+  IMPG_HIP(hipStreamSynchronize(E.stream));
+  E.stage_n = (uint32_t)n;
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
+                           const impg_gpu_params_t *params, impg_gpu_hit_t *d_hits, uint64_t total, uint64_t *accepted) {
+  IMPG_TRY
+  if (!ix || !params || (!d_frontier && n) || (!d_hits && total)) throw Error{IMPG_E_INVALID, "null argument"};
+  Engine &E = *ix->engine;
+  Engine::check_params(*params);
+  if (E.stage_n != n) throw Error{IMPG_E_INVALID, "stage_project must follow stage_count on the same frontier"};
+  if (total >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 pairs: split the frontier"};
+  IMPG_HIP(hipSetDevice(ix->device));
+  LevelBufs &L = E.level_scratch;
+  L.n_pairs = (uint32_t)total;
+  size_t b = std::max<size_t>(total * 4, 256);
+  L.pair_range.reserve(b); E.pair_entry.reserve(b);
+  L.qid.reserve(b); L.qs.reserve(b); L.qe.reserve(b); L.ts.reserve(b); L.te.reserve(b);
+  HitArrays h{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
+  IMPG_HIP(hipMemsetAsync(E.counters.p, 0, 64, E.stream));
+  launch_lookup_emit(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_off.as<uint32_t>(), E.win.as<uint2>(),
+                     L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), E.stream);
+  launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
+                 E.counters.as<unsigned long long>() + 1, (uint32_t *)(E.counters.as<uint64_t>() + 2), E.stream);
+  launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
+  IMPG_HIP(hipStreamSynchronize(E.stream));
+  uint64_t hc[3];
+  IMPG_HIP(hipMemcpy(hc, E.counters.p, 24, hipMemcpyDeviceToHost));
+  if (hc[2]) throw Error{IMPG_E_INVALID, "an alignment hit by the query has no CIGAR (missing cg:Z tag)"};
+  if (accepted) *accepted = hc[1];
+  E.stage_n = 0;
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Per-index execution state: stream, events, scratch buffers (engine.cpp).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace impg {
+
+struct LevelBufs {  // one BFS level: its frontier and its hit slots
+  DevBuf frontier, pair_range, qid, qs, qe, ts, te;
+  uint32_t n_frontier = 0, n_pairs = 0;
+};
+struct VisitedStore {  // device storage of one VisitedTable
+  DevBuf keys, off, len, ranges;
+  uint32_t n_groups = 0;
+};
+
+struct Engine {
+  hipStream_t stream = nullptr;
+  DevBuf counters;
+  uint64_t *h_counters = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_next = 0;
+  struct Timed { hipEvent_t a, b; int kind; };
+  std::vector<Timed> timed;
+  // scratch, grown on demand and reused across calls
+  DevBuf cnt, win, pair_off, pair_entry, scan_tmp, keys, skeys, vals, svals, sort_tmp, head, gid, gstart, glen, old_tab,
+      old_idx, cap, pcap, poff, pieces, n_pieces, foff, frontier_a, frontier_b, self_scratch, ranges_dev, stat_count,
+      stat_cksum, stage_off;
+  LevelBufs level_scratch;
+  std::vector<std::unique_ptr<VisitedStore>> tables;
+  uint64_t last_projected = 0;
+  uint32_t stage_n = 0;  // frontier size of the last stage_count call
+
+  explicit Engine(int device);
+  ~Engine();
+  hipEvent_t event();
+  uint64_t read_counter(int k);
+  uint64_t scan(const uint32_t *in, uint32_t *out, uint32_t n);
+  uint64_t expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
+                  impg_gpu_stats_t *st);
+  uint32_t update(const DeviceIndexView &v, const FrontierRec *fr, LevelBufs &L, uint32_t n_queries,
+                  const impg_gpu_params_t &p, DevBuf &next_frontier);
+  VisitedTables tables_view() const;
+  static void check_params(const impg_gpu_params_t &p);
+  void run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
+           std::vector<std::unique_ptr<LevelBufs>> *keep, unsigned long long *d_count, unsigned long long *d_cksum,
+           impg_gpu_stats_t *st, DevBuf *self_out);
+};
+
+void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops,
+                 size_t n_ops, const int64_t *seq_len, uint32_t n_seq, bool bidirectional, int order_policy,
+                 uint32_t shard, uint32_t n_shards);
+
+}  // namespace impg

@@ -1,0 +1,407 @@
+// Host-side ingest: PAF -> records + packed CIGAR ops, range parsers, and the
+// synthetic workload generators.  Mirrors the reference's parsers
+// (src/paf.rs:118-194, src/impg.rs:2935-2950, src/commands/partition.rs:1752-1789)
+// so that the same text yields the same records and sequence ids.
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "impg_internal.hpp"
+
+namespace impg {
+
+uint32_t HostSeqIndex::get_or_insert(const std::string &name, int64_t len) {
+  auto it = name_to_id.find(name);
+  if (it != name_to_id.end()) return it->second;  // first length seen wins (seqidx.rs:29-31)
+  uint32_t id = (uint32_t)names.size();
+  name_to_id.emplace(name, id);
+  names.push_back(name);
+  lens.push_back(len);
+  return id;
+}
+
+// "[0-9]+[=XIDM]" tokens; any non-digit byte closes an op (impg.rs:2940-2947).
+long parse_cigar(const char *s, size_t n, uint32_t *out, size_t cap) {
+  size_t k = 0;
+  uint32_t len = 0;
+  for (size_t i = 0; i < n; i++) {
+    unsigned c = (unsigned char)s[i];
+    unsigned d = c - '0';
+    if (d <= 9) {
+      len = len * 10 + d;
+      continue;
+    }
+    uint32_t code;
+    switch (c) {
+      case '=': code = 0; break;
+      case 'X': code = 1; break;
+      case 'I': code = 2; break;
+      case 'D': code = 3; break;
+      case 'M': code = 4; break;
+      default: return -1;
+    }
+    if (k < cap) out[k] = (code << 29) | (len & OP_LEN_MASK);
+    k++;
+    len = 0;
+  }
+  return (long)k;
+}
+
+namespace {
+
+struct Field {
+  const char *p;
+  size_t n;
+};
+
+// usize::from_str: optional '+', then digits only
+bool to_u64(Field f, uint64_t *v) {
+  size_t i = (f.n && f.p[0] == '+') ? 1 : 0;
+  if (i >= f.n) return false;
+  uint64_t x = 0;
+  for (; i < f.n; i++) {
+    unsigned d = (unsigned char)f.p[i] - '0';
+    if (d > 9) return false;
+    x = x * 10 + d;
+  }
+  *v = x;
+  return true;
+}
+
+struct ChunkOut {
+  std::vector<impg_gpu_record_t> records;  // ids are chunk-local
+  std::vector<uint32_t> ops;
+  std::vector<std::string> names;          // chunk-local id -> name, first-seen order
+  std::vector<int64_t> lens;
+  std::unordered_map<std::string, uint32_t> local;
+  std::string err;
+  size_t err_line = 0;
+  uint32_t id_of(Field name, int64_t len) {
+    std::string s(name.p, name.n);
+    auto it = local.find(s);
+    if (it != local.end()) return it->second;
+    uint32_t id = (uint32_t)names.size();
+    local.emplace(s, id);
+    names.push_back(std::move(s));
+    lens.push_back(len);
+    return id;
+  }
+};
+
+bool parse_line(const char *line, size_t len, ChunkOut &o) {
+  Field f[12];
+  size_t nf = 0, st = 0;
+  const char *cg = nullptr;
+  size_t cgn = 0;
+  for (size_t i = 0; i <= len; i++) {
+    if (i == len || line[i] == '\t') {
+      Field cur{line + st, i - st};
+      if (nf < 12) f[nf] = cur;
+      nf++;
+      // the reference scans every field, from the first, for the tag (paf.rs:155-163)
+      if (!cg && cur.n >= 5 && memcmp(cur.p, "cg:Z:", 5) == 0) {
+        cg = cur.p + 5;
+        cgn = cur.n - 5;
+      }
+      st = i + 1;
+    }
+  }
+  if (nf < 12) { o.err = "Not enough fields in PAF record"; return false; }
+  uint64_t qlen, qs, qe, tlen, ts, te;
+  if (!to_u64(f[1], &qlen) || !to_u64(f[2], &qs) || !to_u64(f[3], &qe) || !to_u64(f[6], &tlen) ||
+      !to_u64(f[7], &ts) || !to_u64(f[8], &te)) { o.err = "Invalid field"; return false; }
+  if (f[4].n == 0) { o.err = "Expected '+' or '-' for strand"; return false; }
+  char sc = f[4].p[0];
+  if (sc != '+' && sc != '-') { o.err = "Invalid strand"; return false; }
+  impg_gpu_record_t r;
+  r.query_id = o.id_of(f[0], (int64_t)qlen);   // query first, then target (paf.rs:149-150)
+  r.target_id = o.id_of(f[5], (int64_t)tlen);
+  r.query_start = (int32_t)qs; r.query_end = (int32_t)qe;
+  r.target_start = (int32_t)ts; r.target_end = (int32_t)te;
+  r.strand = sc == '-';
+  r.cigar_off = o.ops.size();
+  r.cigar_len = 0;
+  if (cg && cgn) {
+    size_t base = o.ops.size();
+    o.ops.resize(base + cgn);  // upper bound: one op per byte
+    long k = parse_cigar(cg, cgn, o.ops.data() + base, cgn);
+    if (k < 0) { o.err = "Invalid CIGAR operation"; return false; }
+    o.ops.resize(base + (size_t)k);
+    r.cigar_len = (uint32_t)k;
+  }
+  o.records.push_back(r);
+  return true;
+}
+
+void parse_chunk(const char *text, size_t begin, size_t end, ChunkOut &o) {
+  size_t pos = begin, line_no = 0;
+  while (pos < end) {
+    const char *nl = (const char *)memchr(text + pos, '\n', end - pos);
+    size_t eol = nl ? (size_t)(nl - text) : end;
+    size_t l = eol - pos;
+    if (l && text[pos + l - 1] == '\r') l--;  // BufRead::lines strips "\r\n"
+    if (!parse_line(text + pos, l, o)) { o.err_line = line_no; return; }
+    line_no++;
+    pos = eol + 1;
+  }
+}
+
+void merge_chunk(ChunkOut &c, ParsedPaf &out) {
+  std::vector<uint32_t> remap(c.names.size());
+  for (size_t i = 0; i < c.names.size(); i++) remap[i] = out.seq.get_or_insert(c.names[i], c.lens[i]);
+  uint64_t shift = out.ops.size();
+  out.ops.insert(out.ops.end(), c.ops.begin(), c.ops.end());
+  out.records.reserve(out.records.size() + c.records.size());
+  for (auto r : c.records) {
+    r.query_id = remap[r.query_id];
+    r.target_id = remap[r.target_id];
+    r.cigar_off += shift;
+    out.records.push_back(r);
+  }
+}
+
+}  // namespace
+
+void parse_paf_text(const char *text, size_t len, ParsedPaf &out) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, len / (4u << 20) + 1));
+  std::vector<size_t> cut(T + 1, len);
+  cut[0] = 0;
+  for (size_t t = 1; t < T; t++) {
+    size_t p = len / T * t;
+    const char *nl = (const char *)memchr(text + p, '\n', len - p);
+    cut[t] = nl ? (size_t)(nl - text) + 1 : len;
+  }
+  for (size_t t = 1; t <= T; t++) cut[t] = std::max(cut[t], cut[t - 1]);
+  std::vector<ChunkOut> chunks(T);
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < T; t++)
+    th.emplace_back([&, t]() { parse_chunk(text, cut[t], cut[t + 1], chunks[t]); });
+  for (auto &x : th) x.join();
+  for (size_t t = 0; t < T; t++)
+    if (!chunks[t].err.empty()) throw Error{IMPG_E_INVALID, "Failed to parse PAF: " + chunks[t].err};
+  for (size_t t = 0; t < T; t++) merge_chunk(chunks[t], out);
+}
+
+void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out) {
+  for (const auto &path : paths) {
+    if (path.size() > 3 && (path.compare(path.size() - 3, 3, ".gz") == 0 ||
+                            (path.size() > 4 && path.compare(path.size() - 4, 4, ".bgz") == 0)))
+      throw Error{IMPG_E_UNSUPPORTED, "BGZF-compressed PAF is not supported: " + path};
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw Error{IMPG_E_IO, "Failed to open file '" + path + "'"};
+    struct stat stt;
+    fstat(fd, &stt);
+    size_t sz = (size_t)stt.st_size;
+    if (sz == 0) { close(fd); continue; }
+    void *m = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) throw Error{IMPG_E_IO, "Failed to map file '" + path + "'"};
+    try {
+      parse_paf_text((const char *)m, sz, out);
+    } catch (...) {
+      munmap(m, sz);
+      throw;
+    }
+    munmap(m, sz);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// synthetic workload
+// ---------------------------------------------------------------------------
+namespace {
+struct SplitMix64 {
+  uint64_t s;
+  uint64_t next() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  uint64_t below(uint64_t n) { return next() % n; }
+};
+SplitMix64 rng_for(uint64_t seed, uint64_t i) {
+  SplitMix64 a{seed ^ ((i + 1) * 0xD1342543DE82EF95ull)};
+  return SplitMix64{a.next()};
+}
+
+struct SynthRecord {
+  uint32_t query, target, strand;
+  int32_t qs, qe, ts, te;
+  uint64_t matches, block;
+};
+// generates record i; appends 2*n_blocks ops
+SynthRecord synth_record(uint64_t seed, uint64_t i, uint32_t n_seq, int32_t L, int32_t span,
+                         uint32_t n_blocks, std::vector<uint32_t> &ops) {
+  SplitMix64 g = rng_for(seed, i);
+  SynthRecord r;
+  r.target = (uint32_t)g.below(n_seq);
+  r.query = (uint32_t)g.below(n_seq - 1);
+  if (r.query >= r.target) r.query++;
+  r.strand = (uint32_t)g.below(2);
+  std::vector<uint32_t> edit(n_blocks);
+  int64_t sumX = 0, sumD = 0, sumI = 0;
+  for (uint32_t b = 0; b < n_blocks; b++) {
+    uint64_t k = g.below(100);
+    if (k < 60) { edit[b] = (1u << 29) | 1; sumX += 1; }
+    else if (k < 80) { uint32_t l = 1 + (uint32_t)g.below(8); edit[b] = (2u << 29) | l; sumI += l; }
+    else { uint32_t l = 1 + (uint32_t)g.below(8); edit[b] = (3u << 29) | l; sumD += l; }
+  }
+  int64_t E = (int64_t)span - sumX - sumD;  // bases covered by '=' ops
+  int64_t rem = E - n_blocks;
+  std::vector<int64_t> cut(n_blocks + 1);
+  cut[0] = 0;
+  for (uint32_t b = 1; b < n_blocks; b++) cut[b] = (int64_t)g.below((uint64_t)rem + 1);
+  cut[n_blocks] = rem;
+  std::sort(cut.begin() + 1, cut.begin() + n_blocks);
+  for (uint32_t b = 0; b < n_blocks; b++) {
+    uint32_t l = (uint32_t)(cut[b + 1] - cut[b] + 1);
+    ops.push_back(l);  // code 0 '='
+    ops.push_back(edit[b]);
+  }
+  int64_t qspan = E + sumX + sumI;
+  r.ts = (int32_t)g.below((uint64_t)(L - span) + 1);
+  r.te = r.ts + span;
+  r.qs = (int32_t)g.below((uint64_t)(L - qspan) + 1);
+  r.qe = r.qs + (int32_t)qspan;
+  r.matches = (uint64_t)E;
+  r.block = (uint64_t)(E + sumX + sumI + sumD);
+  return r;
+}
+}  // namespace
+}  // namespace impg
+
+using namespace impg;
+
+extern "C" {
+
+int impg_synth_seq_name(uint32_t id, char *out, size_t cap) {
+  return snprintf(out, cap, "g%03u#%u#chr1", id / 4, id % 4 + 1);
+}
+
+int impg_synth_paf(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t seq_len, int32_t target_span,
+                   uint32_t n_blocks, impg_gpu_record_t *records, uint32_t *ops, size_t ops_cap,
+                   size_t *n_ops_out) {
+  if (n_seq < 2 || target_span <= 0 || seq_len < target_span + 8 * (int32_t)n_blocks ||
+      (int64_t)target_span < 10 * (int64_t)n_blocks) {
+    set_error("impg_synth_paf: bad shape");
+    return IMPG_E_INVALID;
+  }
+  size_t total = n_records * 2 * (size_t)n_blocks;
+  if (n_ops_out) *n_ops_out = total;
+  if (!ops || !records) return IMPG_OK;
+  if (ops_cap < total) { set_error("impg_synth_paf: ops buffer too small"); return IMPG_E_INVALID; }
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, n_records / 4096 + 1));
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < T; t++)
+    th.emplace_back([=]() {
+      std::vector<uint32_t> tmp;
+      for (size_t i = t; i < n_records; i += T) {
+        tmp.clear();
+        SynthRecord s = synth_record(seed, i, n_seq, seq_len, target_span, n_blocks, tmp);
+        memcpy(ops + i * 2 * (size_t)n_blocks, tmp.data(), tmp.size() * 4);
+        impg_gpu_record_t r;
+        r.query_id = s.query; r.target_id = s.target;
+        r.query_start = s.qs; r.query_end = s.qe; r.target_start = s.ts; r.target_end = s.te;
+        r.cigar_off = i * 2 * (uint64_t)n_blocks; r.cigar_len = 2 * n_blocks; r.strand = s.strand;
+        records[i] = r;
+      }
+    });
+  for (auto &x : th) x.join();
+  return IMPG_OK;
+}
+
+int impg_synth_paf_text(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t seq_len, int32_t target_span,
+                        uint32_t n_blocks, const char *path) {
+  if (n_seq < 2 || target_span <= 0 || seq_len < target_span + 8 * (int32_t)n_blocks ||
+      (int64_t)target_span < 10 * (int64_t)n_blocks) {
+    set_error("impg_synth_paf_text: bad shape");
+    return IMPG_E_INVALID;
+  }
+  FILE *fp = fopen(path, "wb");
+  if (!fp) { set_error(std::string("cannot create ") + path); return IMPG_E_IO; }
+  static const char OPC[] = "=XIDM";
+  std::vector<uint32_t> tmp;
+  std::string line;
+  char buf[160];
+  for (size_t i = 0; i < n_records; i++) {
+    tmp.clear();
+    SynthRecord s = synth_record(seed, i, n_seq, seq_len, target_span, n_blocks, tmp);
+    char qn[32], tn[32];
+    impg_synth_seq_name(s.query, qn, sizeof qn);
+    impg_synth_seq_name(s.target, tn, sizeof tn);
+    int n = snprintf(buf, sizeof buf, "%s\t%d\t%d\t%d\t%c\t%s\t%d\t%d\t%d\t%llu\t%llu\t255\tcg:Z:", qn, seq_len,
+                     s.qs, s.qe, s.strand ? '-' : '+', tn, seq_len, s.ts, s.te, (unsigned long long)s.matches,
+                     (unsigned long long)s.block);
+    line.assign(buf, (size_t)n);
+    for (uint32_t v : tmp) {
+      n = snprintf(buf, sizeof buf, "%u%c", v & OP_LEN_MASK, OPC[v >> 29]);
+      line.append(buf, (size_t)n);
+    }
+    line.push_back('\n');
+    if (fwrite(line.data(), 1, line.size(), fp) != line.size()) { fclose(fp); set_error("write failed"); return IMPG_E_IO; }
+  }
+  fclose(fp);
+  return IMPG_OK;
+}
+
+int impg_synth_bed(uint64_t seed, size_t n, uint32_t n_seq, int32_t seq_len, int32_t range_len,
+                   impg_gpu_range_t *out) {
+  if (range_len <= 0 || range_len > seq_len || n_seq == 0) { set_error("impg_synth_bed: bad shape"); return IMPG_E_INVALID; }
+  for (size_t i = 0; i < n; i++) {
+    SplitMix64 g = rng_for(seed, i);
+    out[i].target_id = (uint32_t)g.below(n_seq);
+    out[i].start = (int32_t)g.below((uint64_t)(seq_len - range_len) + 1);
+    out[i].end = out[i].start + range_len;
+  }
+  return IMPG_OK;
+}
+
+long impg_gpu_parse_cigar(const char *cigar, size_t len, uint32_t *ops_out, size_t cap) {
+  return parse_cigar(cigar, len, ops_out, cap);
+}
+
+// parse_target_range: split on the LAST ':', then "start-end" (partition.rs:1752-1789)
+int impg_gpu_parse_target_range(const char *s, char *name_out, size_t name_cap, int32_t *start, int32_t *end) {
+  const char *colon = strrchr(s, ':');
+  if (!colon) { set_error("Target range format should be `seq_name:start-end`"); return IMPG_E_INVALID; }
+  const char *r = colon + 1;
+  const char *dash = strchr(r, '-');
+  if (!dash || strchr(dash + 1, '-')) { set_error("Range format should be `start-end`"); return IMPG_E_INVALID; }
+  auto to_i32 = [](const char *p, size_t n, int32_t *v) {
+    size_t i = 0;
+    bool neg = false;
+    if (n && (p[0] == '+' || p[0] == '-')) { neg = p[0] == '-'; i = 1; }
+    if (i >= n) return false;
+    int64_t x = 0;
+    for (; i < n; i++) {
+      unsigned d = (unsigned char)p[i] - '0';
+      if (d > 9) return false;
+      x = x * 10 + d;
+      if (x > 2147483648ll) return false;
+    }
+    if (neg) x = -x;
+    if (x > 2147483647ll) return false;
+    *v = (int32_t)x;
+    return true;
+  };
+  if (!to_i32(r, (size_t)(dash - r), start)) { set_error("Invalid start value"); return IMPG_E_INVALID; }
+  if (!to_i32(dash + 1, strlen(dash + 1), end)) { set_error("Invalid end value"); return IMPG_E_INVALID; }
+  if (*start >= *end) { set_error("Start value must be less than end value"); return IMPG_E_INVALID; }
+  size_t nl = (size_t)(colon - s);
+  if (nl + 1 > name_cap) { set_error("name buffer too small"); return IMPG_E_INVALID; }
+  memcpy(name_out, s, nl);
+  name_out[nl] = 0;
+  return IMPG_OK;
+}
+
+}  // extern "C"

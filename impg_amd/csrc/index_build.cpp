@@ -1,0 +1,228 @@
+// Device index construction: replaces Impg::from_multi_alignment_records
+// (src/impg.rs:1535-1652), the per-target BasicCOITree::new (impg.rs:1630) and
+// ForestMap (src/forest_map.rs) with flat arrays in HBM:
+//   * entries of one target contiguous and ascending in target start (segment
+//     table tgt_off[] indexed by target id),
+//   * starts/ends/pmax/rank SoA for the wavefront search,
+//   * one op pool in 32-op (128-byte) tiles with a (target,query) prefix
+//     checkpoint per tile, shared by the forward and the reversed entry.
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
+
+#include "impg_internal.hpp"
+
+namespace impg {
+
+void DevBuf::reserve(size_t bytes) {
+  if (bytes <= cap) return;
+  release();
+  size_t want = std::max<size_t>(bytes, 256);
+  IMPG_HIP(hipMalloc(&p, want));
+  cap = want;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+// Visit rank of the sorted positions [0,n) under the restated coitrees 0.4
+// BasicCOITree::query order: pre-order over the implicit midpoint BST, except
+// that a complete subtree of <= 8 nodes rooted at a "unit root" depth is visited
+// in sorted order.  Unit-root depths follow the van Emde Boas split of
+// veb_order_recursion: d0 = 0, d' = d + (D - d)/2 + 1 with D = floor(log2 n).
+void coitrees_visit_rank(uint32_t n, uint32_t *rank) {
+  if (n == 0) return;
+  uint32_t D = 31 - __builtin_clz(n);
+  struct Fr { uint32_t s, e, d, cd; };
+  std::vector<Fr> st;
+  st.push_back({0, n, 0, 0});
+  uint32_t c = 0;
+  while (!st.empty()) {
+    Fr f = st.back();
+    st.pop_back();
+    if (f.s >= f.e) continue;
+    uint32_t size = f.e - f.s;
+    if (f.d == f.cd) {
+      if (size <= 8) {
+        for (uint32_t i = f.s; i < f.e; i++) rank[i] = c++;
+        continue;
+      }
+      f.cd = f.d + (D - f.d) / 2 + 1;
+    }
+    uint32_t r = f.s + size / 2;
+    rank[r] = c++;
+    st.push_back({r + 1, f.e, f.d + 1, f.cd});
+    st.push_back({f.s, r, f.d + 1, f.cd});
+  }
+}
+
+namespace {
+
+template <class T> void upload(DevBuf &b, const std::vector<T> &v, size_t &acc) {
+  b.reserve(std::max<size_t>(v.size() * sizeof(T), 256));
+  if (!v.empty()) IMPG_HIP(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  acc += v.size() * sizeof(T);
+}
+
+void parallel_chunks(size_t n, const std::function<void(size_t, size_t)> &f) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, n / 1024 + 1));
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < T; t++) th.emplace_back([&, t]() { f(n * t / T, n * (t + 1) / T); });
+  for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops,
+                 size_t n_ops, const int64_t *seq_len, uint32_t n_seq, bool bidirectional, int order_policy,
+                 uint32_t shard, uint32_t n_shards) {
+  if (n_shards == 0 || shard >= n_shards) throw Error{IMPG_E_INVALID, "bad shard"};
+  if (order_policy != IMPG_ORDER_COITREES && order_policy != IMPG_ORDER_SORTED)
+    throw Error{IMPG_E_INVALID, "bad order policy"};
+  if (n_records >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 records in one index"};
+  ix.n_records = n_records;
+  if (ix.seq.lens.empty()) ix.seq.lens.assign(seq_len, seq_len + n_seq);
+
+  // ---- validate, decide which records this shard needs -----------------------
+  auto owned = [&](uint32_t key) { return key % n_shards == shard; };
+  std::vector<uint8_t> need(n_records, 0);
+  std::vector<uint32_t> seg_count(n_seq + 1, 0);
+  for (size_t i = 0; i < n_records; i++) {
+    const auto &r = records[i];
+    if (r.query_id >= n_seq || r.target_id >= n_seq) throw Error{IMPG_E_INVALID, "record sequence id out of range"};
+    if (r.cigar_off + r.cigar_len > n_ops) throw Error{IMPG_E_INVALID, "record CIGAR outside the op pool"};
+    if (r.cigar_len > OP_LEN_MASK) throw Error{IMPG_E_UNSUPPORTED, "CIGAR longer than 2^29 ops"};
+    if (owned(r.target_id)) { need[i] = 1; seg_count[r.target_id]++; }
+    if (bidirectional && r.query_id != r.target_id && owned(r.query_id)) {  // impg.rs:1584
+      need[i] = 1;
+      seg_count[r.query_id]++;
+    }
+  }
+
+  // ---- op pool in 32-op tiles + per-tile prefix checkpoints -------------------
+  std::vector<uint32_t> tile_base(n_records, 0), cp_base(n_records, 0);
+  uint64_t n_tiles = 0, n_need = 0;
+  for (size_t i = 0; i < n_records; i++) {
+    if (!need[i]) continue;
+    tile_base[i] = (uint32_t)n_tiles;
+    cp_base[i] = (uint32_t)(n_tiles + n_need);
+    n_tiles += (records[i].cigar_len + TILE_OPS - 1) / TILE_OPS;
+    n_need++;
+    if (n_tiles + n_need >= (1ull << 32)) throw Error{IMPG_E_UNSUPPORTED, "op pool exceeds 2^32 tiles"};
+  }
+  std::vector<uint32_t> pool(n_tiles * TILE_OPS, OP_PAD);
+  std::vector<uint2> cp(n_tiles + n_need);
+  std::atomic<bool> bad_op{false};
+  parallel_chunks(n_records, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      if (!need[i]) continue;
+      const uint32_t *src = cigar_ops + records[i].cigar_off;
+      uint32_t n = records[i].cigar_len;
+      uint32_t *dst = pool.data() + (size_t)tile_base[i] * TILE_OPS;
+      uint2 *c = cp.data() + cp_base[i];
+      uint32_t st = 0, sq = 0;
+      for (uint32_t k = 0; k < n; k++) {
+        if (k % TILE_OPS == 0) c[k / TILE_OPS] = make_uint2(st, sq);
+        uint32_t v = src[k], code = v >> 29, len = v & OP_LEN_MASK;
+        if (code > 4) bad_op = true;  // CigarOp::new panics (impg.rs:88)
+        dst[k] = v;
+        if (code != 2) st += len;  // target_delta: all but 'I' (impg.rs:115-121)
+        if (code != 3) sq += len;  // |query_delta|: all but 'D' (impg.rs:123-135)
+      }
+      c[(n + TILE_OPS - 1) / TILE_OPS] = make_uint2(st, sq);  // record totals
+    }
+  });
+  if (bad_op) throw Error{IMPG_E_INVALID, "Invalid CIGAR operation"};
+
+  // ---- entries, grouped by key in input order (impg.rs:1559-1623) --------------
+  ix.h_tgt_off.assign(n_seq + 1, 0);
+  for (uint32_t s = 0; s < n_seq; s++) ix.h_tgt_off[s + 1] = ix.h_tgt_off[s] + seg_count[s];
+  size_t n_entries = ix.h_tgt_off[n_seq];
+  if (n_entries >= (1ull << 32) - 1) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 entries"};
+  std::vector<Entry> ent(n_entries);
+  {
+    std::vector<uint32_t> cur(ix.h_tgt_off.begin(), ix.h_tgt_off.end() - 1);
+    for (size_t i = 0; i < n_records; i++) {
+      const auto &r = records[i];
+      uint32_t fl = (r.cigar_len & OP_LEN_MASK) | (r.strand ? EF_STRAND : 0);
+      if (owned(r.target_id)) {
+        Entry e{r.target_start, r.target_end, r.query_start, r.query_end, r.query_id, tile_base[i], fl, cp_base[i]};
+        ent[cur[r.target_id]++] = e;
+      }
+      if (bidirectional && r.query_id != r.target_id && owned(r.query_id)) {
+        Entry e{r.query_start, r.query_end, r.target_start, r.target_end, r.target_id, tile_base[i],
+                fl | EF_REVERSED, cp_base[i]};
+        ent[cur[r.query_id]++] = e;
+      }
+    }
+  }
+  // per segment: stable sort by start (coitrees sorts by `first` only), then
+  // SoA columns, running max of end, visit rank
+  std::vector<int32_t> starts(n_entries), ends(n_entries), pmax(n_entries);
+  std::vector<uint32_t> rank(n_entries);
+  size_t n_targets = 0;
+  for (uint32_t s = 0; s < n_seq; s++) n_targets += seg_count[s] != 0;
+  {
+    std::atomic<uint32_t> next{0};
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, n_seq));
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; t++)
+      th.emplace_back([&]() {
+        for (;;) {
+          uint32_t s = next.fetch_add(1);
+          if (s >= n_seq) break;
+          uint32_t a = ix.h_tgt_off[s], b = ix.h_tgt_off[s + 1];
+          if (a == b) continue;
+          std::stable_sort(ent.begin() + a, ent.begin() + b, [](const Entry &x, const Entry &y) { return x.ts < y.ts; });
+          int32_t m = INT32_MIN;
+          for (uint32_t i = a; i < b; i++) {
+            starts[i] = ent[i].ts;
+            ends[i] = ent[i].te;
+            m = std::max(m, ent[i].te);
+            pmax[i] = m;
+          }
+          if (order_policy == IMPG_ORDER_COITREES) coitrees_visit_rank(b - a, rank.data() + a);
+          else for (uint32_t i = a; i < b; i++) rank[i] = i - a;
+        }
+      });
+    for (auto &x : th) x.join();
+  }
+
+  // ---- upload -------------------------------------------------------------------
+  IMPG_HIP(hipSetDevice(ix.device));
+  std::vector<int32_t> sl(n_seq);
+  for (uint32_t s = 0; s < n_seq; s++) sl[s] = (int32_t)std::min<int64_t>(std::max<int64_t>(seq_len[s], 0), INT32_MAX);
+  size_t acc = 0;
+  upload(ix.d_tgt_off, ix.h_tgt_off, acc);
+  upload(ix.d_starts, starts, acc);
+  upload(ix.d_ends, ends, acc);
+  upload(ix.d_pmax, pmax, acc);
+  upload(ix.d_rank, rank, acc);
+  upload(ix.d_entries, ent, acc);
+  upload(ix.d_ops, pool, acc);
+  upload(ix.d_cp, cp, acc);
+  upload(ix.d_seq_len, sl, acc);
+  ix.device_bytes = acc;
+  ix.n_entries = n_entries;
+  ix.n_tiles = n_tiles;
+  ix.n_targets = n_targets;
+  ix.view.tgt_off = ix.d_tgt_off.as<uint32_t>();
+  ix.view.starts = ix.d_starts.as<int32_t>();
+  ix.view.ends = ix.d_ends.as<int32_t>();
+  ix.view.pmax = ix.d_pmax.as<int32_t>();
+  ix.view.rank = ix.d_rank.as<uint32_t>();
+  ix.view.entries = ix.d_entries.as<Entry>();
+  ix.view.ops = ix.d_ops.as<uint32_t>();
+  ix.view.cp = ix.d_cp.as<uint2>();
+  ix.view.seq_len = ix.d_seq_len.as<int32_t>();
+  ix.view.n_seq = n_seq;
+  ix.view.n_entries = (uint32_t)n_entries;
+  ix.view.sorted_order = order_policy == IMPG_ORDER_SORTED;
+}
+
+}  // namespace impg

@@ -1,0 +1,905 @@
+// Hand-written HIP kernels for gfx950 (CDNA4, wave64).  Integer/HBM-bound work:
+// no MFMA.  See DESIGN.md section 5 for the per-kernel roofline accounting.
+//
+//   lookup_count / lookup_emit : replace coitrees BasicCOITree::query
+//        (call sites src/impg.rs:1897, :2142, :2393).  One wavefront per
+//        frontier range: 64-ary coalesced search of the per-target sorted
+//        start array and of the running-max-of-end array, then a coalesced
+//        scan of the candidate window with ballot compaction; hits are written
+//        in the reference's visit order (rank[]).
+//   project : replaces get_cigar_ops + project_target_range_through_alignment
+//        (src/impg.rs:495-551, :2760-2898).  One lane per (range, entry) pair.
+//        The CIGAR walk is cut down to the two 32-op tiles that hold the first
+//        and the last overlapping op, located through per-tile prefix
+//        checkpoints; reversed entries (REVERSED_BIT) read the same tiles with
+//        I<->D swapped and, on the reverse strand, back to front
+//        (invert_cigar_ops_in_place, src/impg.rs:144-156) -- no second copy.
+//   visited_update / frontier_* : the order-dependent sequential phase of
+//        query_transitive_bfs (src/impg.rs:2471-2584) with SortedRanges::insert
+//        (src/impg.rs:270-368), parallel over (query, sequence) groups.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "impg_internal.hpp"
+#include "kernels.hpp"
+
+namespace impg {
+
+// ---------------------------------------------------------------------------
+// wave helpers (wave = 64 lanes)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// First index in [lo,hi) whose value satisfies pred (monotone false..true), hi if
+// none.  All 64 lanes cooperate: 64 evenly spaced probes per round.
+template <class Pred>
+__device__ __forceinline__ uint32_t wave_search(const int32_t *__restrict__ arr, uint32_t lo, uint32_t hi, Pred pred) {
+  const unsigned lane = lane_id();
+  while (hi - lo > 64u) {
+    uint32_t step = (hi - lo + 63u) >> 6;
+    uint32_t idx = lo + (lane + 1u) * step - 1u;
+    bool p = idx < hi ? pred(arr[idx]) : true;
+    unsigned f = __ffsll((long long)__ballot(p)) - 1;  // lane 63 probes >= hi-1: always set
+    uint32_t nlo = lo + f * step;
+    uint32_t nhi = lo + (f + 1u) * step - 1u;
+    hi = nhi < hi ? nhi : hi;
+    lo = nlo;
+  }
+  uint32_t idx = lo + lane;
+  bool p = idx < hi ? pred(arr[idx]) : true;
+  unsigned f = __ffsll((long long)__ballot(p)) - 1;
+  uint32_t ans = lo + f;
+  return ans < hi ? ans : hi;
+}
+
+// candidate window of one frontier range inside its target's segment
+template <bool TRANSITIVE>
+__device__ __forceinline__ void range_window(const DeviceIndexView &v, const FrontierRec &f, uint32_t &lo, uint32_t &ub) {
+  lo = ub = 0;
+  if (f.target_id >= v.n_seq) return;
+  uint32_t a = v.tgt_off[f.target_id], b = v.tgt_off[f.target_id + 1];
+  if (a == b) return;
+  const int32_t qs = f.start, qe = f.end;
+  if (TRANSITIVE) {  // max(cs,first) < min(ce,last)   (impg.rs:2398-2403)
+    ub = wave_search(v.starts, a, b, [=](int32_t s) { return s >= qe; });
+    lo = wave_search(v.pmax, a, ub, [=](int32_t m) { return m > qs; });
+  } else {  // coitrees closed test: first <= q_last && last >= q_first
+    ub = wave_search(v.starts, a, b, [=](int32_t s) { return s > qe; });
+    lo = wave_search(v.pmax, a, ub, [=](int32_t m) { return m >= qs; });
+  }
+}
+template <bool TRANSITIVE>
+__device__ __forceinline__ bool overlaps(int32_t ts, int32_t te, int32_t qs, int32_t qe) {
+  if (TRANSITIVE) return max(qs, ts) < min(qe, te);
+  return ts <= qe && te >= qs;
+}
+
+// ---------------------------------------------------------------------------
+// K1a: count overlapping entries per frontier range (one wave per range)
+// ---------------------------------------------------------------------------
+template <bool TRANSITIVE>
+__global__ __launch_bounds__(256) void lookup_count_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
+                                                           uint32_t n, uint32_t *__restrict__ cnt,
+                                                           uint2 *__restrict__ win) {
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * 256u) >> 6;
+  const unsigned lane = lane_id();
+  for (uint32_t r = wave; r < n; r += nwaves) {
+    FrontierRec f = fr[r];
+    uint32_t lo, ub;
+    range_window<TRANSITIVE>(v, f, lo, ub);
+    uint32_t c = 0;
+    for (uint32_t base = lo; base < ub; base += 64u) {
+      uint32_t i = base + lane;
+      bool hit = false;
+      if (i < ub) hit = overlaps<TRANSITIVE>(v.starts[i], v.ends[i], f.start, f.end);
+      c += __popcll(__ballot(hit));
+    }
+    if (lane == 0) {
+      cnt[r] = c;
+      win[r] = make_uint2(lo, ub);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1b: emit (range, entry) pairs in visit order at pair_off[r]
+// ---------------------------------------------------------------------------
+template <bool TRANSITIVE>
+__global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
+                                                          uint32_t n, const uint32_t *__restrict__ pair_off,
+                                                          const uint2 *__restrict__ win,
+                                                          uint32_t *__restrict__ pair_range,
+                                                          uint32_t *__restrict__ pair_entry) {
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * 256u) >> 6;
+  const unsigned lane = lane_id();
+  for (uint32_t r = wave; r < n; r += nwaves) {
+    const uint2 w = win[r];
+    const uint32_t lo = w.x, ub = w.y;
+    if (lo >= ub) continue;
+    FrontierRec f = fr[r];
+    const uint32_t off = pair_off[r];
+    const uint32_t seg = v.tgt_off[f.target_id];
+    if (v.sorted_order) {  // visit order == segment order: plain stream compaction
+      uint32_t run = 0;
+      for (uint32_t base = lo; base < ub; base += 64u) {
+        uint32_t i = base + lane;
+        bool hit = i < ub && overlaps<TRANSITIVE>(v.starts[i], v.ends[i], f.start, f.end);
+        unsigned long long m = __ballot(hit);
+        if (hit) {
+          uint32_t pos = off + run + __popcll(m & lanemask_lt());
+          pair_range[pos] = r;
+          pair_entry[pos] = i;
+        }
+        run += __popcll(m);
+      }
+      continue;
+    }
+    // visit order = ascending rank[]: position of a hit = number of hits in the
+    // whole window with a smaller rank (ranks are distinct within a segment)
+    for (uint32_t base = lo; base < ub; base += 64u) {
+      uint32_t i = base + lane;
+      bool hit = i < ub && overlaps<TRANSITIVE>(v.starts[i], v.ends[i], f.start, f.end);
+      uint32_t rk = hit ? v.rank[i] : 0xFFFFFFFFu;
+      uint32_t pos = 0;
+      for (uint32_t b2 = lo; b2 < ub; b2 += 64u) {
+        uint32_t i2 = b2 + lane;
+        bool hit2;
+        uint32_t rk2;
+        if (b2 == base) { hit2 = hit; rk2 = rk; }  // common case: the window is one chunk
+        else {
+          hit2 = i2 < ub && overlaps<TRANSITIVE>(v.starts[i2], v.ends[i2], f.start, f.end);
+          rk2 = hit2 ? v.rank[i2] : 0xFFFFFFFFu;
+        }
+        unsigned long long m = __ballot(hit2);
+        while (m) {
+          int j = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          uint32_t rj = (uint32_t)__shfl((int)rk2, j);
+          pos += rj < rk;
+        }
+      }
+      if (hit) {
+        pair_range[off + pos] = r;
+        pair_entry[off + pos] = i;
+      }
+    }
+    (void)seg;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan of u32 (3 phases; offsets u32, grand total u64)
+// ---------------------------------------------------------------------------
+constexpr uint32_t SCAN_ITEMS = 8, SCAN_BLOCK = 256, SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = (uint32_t)__shfl_up((int)x, d);
+    if ((int)lane_id() >= d) x += y;
+  }
+  return x;
+}
+// block-wide exclusive scan of one value per thread (256 threads); returns the
+// exclusive prefix and, in *total, the block sum
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t *total) {
+  __shared__ uint32_t wsum[4];
+  uint32_t inc = wave_incl_scan(x);
+  unsigned w = threadIdx.x >> 6;
+  if (lane_id() == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (unsigned k = 0; k < w; k++) base += wsum[k];
+  *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  return base + inc - x;
+}
+
+__global__ __launch_bounds__(256) void scan_block_sums(const uint32_t *__restrict__ in, uint32_t n,
+                                                       unsigned long long *__restrict__ bsum) {
+  uint32_t base = blockIdx.x * SCAN_TILE;
+  uint32_t s = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_ITEMS; k++) {
+    uint32_t i = base + k * SCAN_BLOCK + threadIdx.x;
+    if (i < n) s += in[i];
+  }
+  uint32_t tot;
+  block_excl_scan(s, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+// single block: exclusive scan of the block sums in place, grand total to *total
+__global__ __launch_bounds__(256) void scan_of_sums(unsigned long long *bsum, uint32_t nb, unsigned long long *total) {
+  __shared__ unsigned long long carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += 256) {
+    uint32_t i = base + threadIdx.x;
+    unsigned long long x = i < nb ? bsum[i] : 0;
+    // 64-bit inclusive scan over the block through shared memory (small: nb/256 rounds)
+    __shared__ unsigned long long buf[256];
+    buf[threadIdx.x] = x;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      unsigned long long y = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += y;
+      __syncthreads();
+    }
+    unsigned long long carry = carry_s;
+    if (i < nb) bsum[i] = carry + buf[threadIdx.x] - x;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + buf[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry_s;
+}
+__global__ __launch_bounds__(256) void scan_apply(const uint32_t *__restrict__ in, uint32_t n,
+                                                  const unsigned long long *__restrict__ bsum,
+                                                  uint32_t *__restrict__ out) {
+  // thread t owns items [t*ITEMS, t*ITEMS+ITEMS) of the block tile
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t x[SCAN_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_ITEMS; k++) {
+    uint32_t i = base + k;
+    x[k] = i < n ? in[i] : 0;
+    s += x[k];
+  }
+  uint32_t tot;
+  uint32_t ex = block_excl_scan(s, &tot) + (uint32_t)bsum[blockIdx.x];
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_ITEMS; k++) {
+    uint32_t i = base + k;
+    if (i < n) out[i] = ex;
+    ex += x[k];
+  }
+}
+
+void launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, unsigned long long *d_bsum,
+                           unsigned long long *d_total, hipStream_t s) {
+  uint32_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb == 0) nb = 1;
+  // note: block sums are computed with a strided ownership, applied with a
+  // blocked ownership; both cover the same tile so the sums agree.
+  scan_block_sums<<<nb, SCAN_BLOCK, 0, s>>>(d_in, n, d_bsum);
+  scan_of_sums<<<1, 256, 0, s>>>(d_bsum, nb, d_total);
+  scan_apply<<<nb, SCAN_BLOCK, 0, s>>>(d_in, n, d_bsum, d_out);
+}
+size_t scan_scratch_bytes(uint32_t n) { return ((size_t)(n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(unsigned long long); }
+
+// ---------------------------------------------------------------------------
+// K2: projection, one lane per (range, entry) pair
+// ---------------------------------------------------------------------------
+struct TileScan {
+  bool found;
+  int32_t pqs, pts, pqe, pte;
+};
+
+// exact per-op step of project_target_range_through_alignment (impg.rs:2800-2869)
+// on the effective view of an entry.  T/Q are the running target/query position.
+__device__ __forceinline__ void op_step(uint32_t op, bool swp, int32_t dir, int32_t R0, int32_t R1, int32_t last_tp,
+                                        int32_t &T, int32_t &Q, bool &dead, TileScan &s) {
+  if (op == OP_PAD) return;
+  if (T > last_tp) dead = true;  // impg.rs:2802 (positions never decrease: once dead, always dead)
+  const uint32_t code = op >> 29;
+  const int32_t len = (int32_t)(op & OP_LEN_MASK);
+  int32_t td = code == 2u ? 0 : len;  // target_delta (impg.rs:115-121)
+  int32_t qa = code == 3u ? 0 : len;  // |query_delta| (impg.rs:123-135)
+  if (swp) { int32_t t = td; td = qa; qa = t; }  // I<->D for reversed entries (impg.rs:146-151)
+  const bool arm1 = td == 0;            // (0, query_delta)
+  const bool arm3 = !arm1 && qa != 0;   // (target_delta, query_delta)
+  const int32_t lim = (!arm1 && qa == 0) ? last_tp : R1;  // D clips to last_target_pos, match to range end
+  const int32_t os = max(T, R0);
+  const int32_t oe = min(T + td, lim);
+  const bool pass = !dead && (arm1 ? T >= R0 : os < oe);
+  if (pass) {
+    if (!s.found) {
+      s.found = true;
+      s.pqs = Q + (arm3 ? (os - T) * dir : 0);
+      s.pts = arm1 ? T : os;
+    }
+    const int32_t adv = arm1 ? qa : (arm3 ? oe - T : 0);
+    s.pqe = Q + adv * dir;
+    s.pte = arm1 ? T : oe;
+  }
+  T += td;
+  Q += qa * dir;
+}
+
+struct PairCtx {
+  int32_t ts, qbase, R0, R1, last_tp, dir;
+  bool swp, flip;
+  uint32_t m;            // number of tiles
+  uint32_t totT, totQ;   // record totals in the entry's (effective) axes
+  const uint2 *cp;       // checkpoints of the record, cp[0..m]
+  const uint32_t *ops;   // first tile of the record
+};
+__device__ __forceinline__ uint32_t cpT(const PairCtx &c, uint32_t j) { uint2 x = c.cp[j]; return c.swp ? x.y : x.x; }
+__device__ __forceinline__ uint32_t cpQ(const PairCtx &c, uint32_t j) { uint2 x = c.cp[j]; return c.swp ? x.x : x.y; }
+
+// running positions at the effective start of original tile j
+__device__ __forceinline__ void tile_start(const PairCtx &c, uint32_t j, int32_t &T, int32_t &Q) {
+  if (!c.flip) {
+    uint2 x = c.cp[j];
+    uint32_t t = c.swp ? x.y : x.x, q = c.swp ? x.x : x.y;
+    T = c.ts + (int32_t)t;
+    Q = c.qbase + (int32_t)q * c.dir;
+  } else {
+    uint2 x = c.cp[j + 1];
+    uint32_t t = c.swp ? x.y : x.x, q = c.swp ? x.x : x.y;
+    T = c.ts + (int32_t)(c.totT - t);
+    Q = c.qbase + (int32_t)(c.totQ - q) * c.dir;
+  }
+}
+
+// scan one tile held in registers, effective order
+__device__ __forceinline__ TileScan scan_tile_regs(const PairCtx &c, uint32_t j, const uint4 (&t)[8]) {
+  TileScan s;
+  s.found = false;
+  s.pqs = s.pts = s.pqe = s.pte = -1;
+  int32_t T, Q;
+  tile_start(c, j, T, Q);
+  bool dead = false;
+  uint32_t o[32];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { o[4 * k] = t[k].x; o[4 * k + 1] = t[k].y; o[4 * k + 2] = t[k].z; o[4 * k + 3] = t[k].w; }
+#pragma unroll
+  for (int u = 0; u < 32; u++) {
+    uint32_t op = c.flip ? o[31 - u] : o[u];
+    op_step(op, c.swp, c.dir, c.R0, c.R1, c.last_tp, T, Q, dead, s);
+  }
+  return s;
+}
+
+// literal walk over tiles A..B in effective order, one op at a time (rare path)
+__device__ __noinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32_t B) {
+  TileScan s;
+  s.found = false;
+  s.pqs = s.pts = s.pqe = s.pte = -1;
+  int32_t T, Q;
+  tile_start(c, A, T, Q);
+  bool dead = false;
+  const int stepj = c.flip ? -1 : 1;
+  for (int64_t j = A;; j += stepj) {
+    const uint32_t *tp = c.ops + (size_t)j * TILE_OPS;
+    for (int u = 0; u < 32 && !dead; u++) {
+      uint32_t op = tp[c.flip ? 31 - u : u];
+      op_step(op, c.swp, c.dir, c.R0, c.R1, c.last_tp, T, Q, dead, s);
+    }
+    if (dead || j == (int64_t)B) break;
+  }
+  return s;
+}
+
+__device__ __forceinline__ void load_tile(const uint32_t *p, uint4 (&t)[8]) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int k = 0; k < 8; k++) t[k] = q[k];
+}
+
+template <bool TRANSITIVE>
+__global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
+                                                      const uint32_t *__restrict__ pair_range,
+                                                      const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
+                                                      HitArrays h, unsigned long long *__restrict__ accepted,
+                                                      uint32_t *__restrict__ err_flag) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  bool ok = false;
+  TileScan res;
+  res.found = false;
+  res.pqs = res.pts = res.pqe = res.pte = -1;
+  uint32_t qid = HIT_NONE;
+  if (p < n_pairs) {
+    const uint32_t r = pair_range[p];
+    const FrontierRec f = fr[r];
+    const Entry en = v.entries[pair_entry[p]];
+    const uint32_t n = en.nops_flags & OP_LEN_MASK;
+    const bool rev = (en.nops_flags & EF_STRAND) != 0;
+    PairCtx c;
+    c.swp = (en.nops_flags & EF_REVERSED) != 0;
+    c.flip = c.swp && rev;
+    c.dir = rev ? -1 : 1;
+    c.ts = en.ts;
+    c.qbase = rev ? en.qe : en.qs;  // impg.rs:2778-2782
+    c.R0 = f.start;
+    c.R1 = f.end;
+    if (TRANSITIVE) {  // project the clipped overlap (impg.rs:2398-2400)
+      c.R0 = max(c.R0, en.ts);
+      c.R1 = min(c.R1, en.te);
+    }
+    c.last_tp = min(en.te, c.R1);  // impg.rs:2798
+    c.m = (n + TILE_OPS - 1) / TILE_OPS;
+    c.cp = v.cp + en.cp_base;
+    c.ops = v.ops + (size_t)en.tile_base * TILE_OPS;
+    if (n == 0) {
+      atomicOr(err_flag, 1u);  // record without cg:Z (the reference panics, impg.rs:506-511)
+    } else {
+      const uint2 tot = c.cp[c.m];
+      c.totT = c.swp ? tot.y : tot.x;
+      c.totQ = c.swp ? tot.x : tot.y;
+      // tile A holds the first op whose inclusive target prefix reaches R0; tile B
+      // the last op whose exclusive prefix is <= last_tp.  cpT is nondecreasing.
+      //   LB(x) = first i in [1,m] with cpT[i] >= x (m+1 if none)
+      //   UB(x) = first i in [0,m) with cpT[i] >  x (m if none)
+      const int32_t xa = c.flip ? (int32_t)c.totT + c.ts - c.R0 : c.R0 - c.ts;
+      const int32_t xb = c.flip ? (int32_t)c.totT + c.ts - c.last_tp : c.last_tp - c.ts;
+      const int32_t xlb = c.flip ? xb : xa, xub = c.flip ? xa : xb;
+      uint32_t lb, ubv;
+      {
+        uint32_t lo = 1, hi = c.m + 1;
+        while (lo < hi) {
+          uint32_t mid = (lo + hi) >> 1;
+          if ((int32_t)cpT(c, mid) >= xlb) hi = mid; else lo = mid + 1;
+        }
+        lb = lo;
+      }
+      {
+        uint32_t lo = 0, hi = c.m;
+        while (lo < hi) {
+          uint32_t mid = (lo + hi) >> 1;
+          if ((int32_t)cpT(c, mid) > xub) hi = mid; else lo = mid + 1;
+        }
+        ubv = lo;
+      }
+      const bool haveLB = lb <= c.m, haveUB = ubv >= 1;
+      if (haveLB && haveUB) {
+        const uint32_t jl = lb - 1, ju = ubv - 1;
+        const uint32_t A = c.flip ? ju : jl, B = c.flip ? jl : ju;
+        const bool ordered = c.flip ? A >= B : A <= B;
+        if (ordered) {
+          uint4 ta[8], tb[8];
+          load_tile(c.ops + (size_t)A * TILE_OPS, ta);
+          if (A != B) load_tile(c.ops + (size_t)B * TILE_OPS, tb);
+          TileScan sa = scan_tile_regs(c, A, ta);
+          if (A == B) {
+            res = sa;
+          } else {
+            TileScan sb = scan_tile_regs(c, B, tb);
+            if (sa.found && sb.found) {
+              res.found = true;
+              res.pqs = sa.pqs; res.pts = sa.pts;
+              res.pqe = sb.pqe; res.pte = sb.pte;
+            } else {
+              res = walk_tiles(c, A, B);
+            }
+          }
+        }
+      }
+      ok = res.found && res.pqs != res.pqe && res.pts != res.pte;  // impg.rs:2874-2877
+      if (ok) qid = en.query_id;
+    }
+    h.qid[p] = qid;
+    if (ok) {
+      h.qs[p] = res.pqs;
+      h.qe[p] = res.pqe;
+      h.ts[p] = res.pts;
+      h.te[p] = res.pte;
+    }
+  }
+  unsigned long long m = __ballot(ok);
+  if (lane_id() == 0 && m) atomicAdd(accepted, (unsigned long long)__popcll(m));
+}
+
+// ---------------------------------------------------------------------------
+// per-range statistics of one level's hits (verification / counting; not timed)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__restrict__ fr,
+                                                        const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
+                                                        HitArrays h, int32_t min_output_length,
+                                                        unsigned long long *__restrict__ count,
+                                                        unsigned long long *__restrict__ cksum) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n_pairs) return;
+  const uint32_t qid = h.qid[p];
+  if (qid == HIT_NONE) return;
+  const int32_t qs = h.qs[p], qe = h.qe[p];
+  if (min_output_length >= 0 && abs(qe - qs) < min_output_length) return;
+  const FrontierRec f = fr[pair_range[p]];
+  unsigned long long a = mix64(((unsigned long long)qid << 32) | (uint32_t)qs);
+  a = mix64(a ^ (((unsigned long long)(uint32_t)qe << 32) | f.target_id));
+  a = mix64(a ^ (((unsigned long long)(uint32_t)h.ts[p] << 32) | (uint32_t)h.te[p]));
+  if (count) atomicAdd(&count[f.qidx], 1ull);
+  if (cksum) atomicAdd(&cksum[f.qidx], a);
+}
+
+// ---------------------------------------------------------------------------
+// K3: visited-set update (impg.rs:2471-2560) and next frontier (impg.rs:2566-2584)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void update_keys_kernel(const FrontierRec *__restrict__ fr,
+                                                          const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
+                                                          HitArrays h, unsigned long long *__restrict__ keys,
+                                                          uint32_t *__restrict__ vals,
+                                                          unsigned long long *__restrict__ n_active) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  unsigned long long k = ~0ull;
+  if (p < n_pairs) {
+    const uint32_t qid = h.qid[p];
+    if (qid != HIT_NONE) {
+      const FrontierRec f = fr[pair_range[p]];
+      if (qid != f.target_id) k = ((unsigned long long)f.qidx << 32) | qid;  // impg.rs:2507
+    }
+    keys[p] = k;
+    vals[p] = p;
+  }
+  unsigned long long m = __ballot(k != ~0ull);
+  if (lane_id() == 0 && m) atomicAdd(n_active, (unsigned long long)__popcll(m));
+}
+
+// head flag of each run of equal keys (only keys != ~0 count)
+__global__ __launch_bounds__(256) void group_heads_kernel(const unsigned long long *__restrict__ skeys, uint32_t n,
+                                                          uint32_t *__restrict__ head) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = skeys[i];
+  head[i] = (k != ~0ull) && (i == 0 || skeys[i - 1] != k);
+}
+__global__ __launch_bounds__(256) void group_scatter_kernel(const unsigned long long *__restrict__ skeys, uint32_t n,
+                                                            const uint32_t *__restrict__ head,
+                                                            const uint32_t *__restrict__ gid,
+                                                            uint32_t *__restrict__ gstart,
+                                                            unsigned long long *__restrict__ gkey) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  if (head[i]) {
+    gstart[gid[i]] = i;
+    gkey[gid[i]] = skeys[i];
+  }
+}
+
+__device__ __forceinline__ uint32_t lower_bound_u64(const unsigned long long *a, uint32_t n, unsigned long long k) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// per group: run length, the group's current visited list (newest table that
+// holds the key), capacities for the new list and for the pieces
+__global__ __launch_bounds__(256) void group_prepare_kernel(VisitedTables vt, const unsigned long long *__restrict__ gkey,
+                                                            const uint32_t *__restrict__ gstart, uint32_t n_groups,
+                                                            uint32_t n_active, uint32_t *__restrict__ glen,
+                                                            uint32_t *__restrict__ old_tab, uint32_t *__restrict__ old_idx,
+                                                            uint32_t *__restrict__ cap, uint32_t *__restrict__ pcap) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint32_t st = gstart[g];
+  const uint32_t en = g + 1 < n_groups ? gstart[g + 1] : n_active;
+  const uint32_t len = en - st;
+  glen[g] = len;
+  const unsigned long long k = gkey[g];
+  uint32_t tab = 0xFFFFFFFFu, idx = 0, olen = 0;
+  for (int t = (int)vt.n_tables - 1; t >= 0; t--) {
+    const VisitedTable &T = vt.t[t];
+    uint32_t i = lower_bound_u64(T.keys, T.n_groups, k);
+    if (i < T.n_groups && T.keys[i] == k) {
+      tab = (uint32_t)t;
+      idx = i;
+      olen = T.len[i];
+      break;
+    }
+  }
+  old_tab[g] = tab;
+  old_idx[g] = idx;
+  cap[g] = olen + len;
+  pcap[g] = olen + 2u * len;
+}
+
+__device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n, int32_t s) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (a[mid].x < s) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// one thread per (query, sequence) group: replay the group's hits in emission
+// order against its visited list (SortedRanges::insert with min_distance = 0,
+// impg.rs:270-368), collect the new pieces
+__global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, const uint32_t *__restrict__ svals,
+                                                            HitArrays h, const int32_t *__restrict__ seq_len,
+                                                            const unsigned long long *__restrict__ gkey,
+                                                            const uint32_t *__restrict__ gstart,
+                                                            const uint32_t *__restrict__ glen,
+                                                            const uint32_t *__restrict__ old_tab,
+                                                            const uint32_t *__restrict__ old_idx,
+                                                            const uint32_t *__restrict__ noff,
+                                                            const uint32_t *__restrict__ poff, uint32_t n_groups,
+                                                            int32_t min_transitive_len, int32_t mdbr,
+                                                            int2 *__restrict__ new_ranges, uint32_t *__restrict__ new_len,
+                                                            int2 *__restrict__ pieces, uint32_t *__restrict__ n_pieces) {
+  const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+  if (g >= n_groups) return;
+  int2 *R = new_ranges + noff[g];
+  uint32_t len = 0;
+  if (old_tab[g] != 0xFFFFFFFFu) {
+    const VisitedTable &T = vt.t[old_tab[g]];
+    const int2 *src = T.ranges + T.off[old_idx[g]];
+    len = T.len[old_idx[g]];
+    for (uint32_t i = 0; i < len; i++) R[i] = src[i];
+  }
+  const int32_t sequence_length = seq_len[(uint32_t)(gkey[g] & 0xFFFFFFFFull)];  // visited_entry, impg.rs:2048-2053
+  int2 *P = pieces + poff[g];
+  uint32_t np = 0;
+  const uint32_t st = gstart[g], n = glen[g];
+  for (uint32_t t = 0; t < n; t++) {
+    const uint32_t p = svals[st + t];
+    const int32_t a = h.qs[p], b = h.qe[p];
+    int32_t start = min(a, b), end = max(a, b);
+    bool should_add = true;
+    if (mdbr > 0) {  // impg.rs:2513-2545
+      const uint32_t idx = lower_bound_start(R, len, start);
+      if (idx > 0 && abs(start - R[idx - 1].y) < mdbr) should_add = false;
+      if (should_add && idx < len && abs(R[idx].x - end) < mdbr) should_add = false;
+    }
+    if (!should_add) continue;
+    // ---- SortedRanges::insert, min_distance = 0 --------------------------------
+    if (start < 0) start = 0;                       // impg.rs:287-289
+    if (end > sequence_length) end = sequence_length;  // impg.rs:294-296
+    int32_t current = start;
+    uint32_t i = lower_bound_start(R, len, start);
+    if (i > 0 && R[i - 1].y > start) i -= 1;
+    while (i < len && current < end) {  // impg.rs:314-324
+      const int2 rg = R[i];
+      if (rg.x > end) break;
+      if (current < rg.x) {
+        if (abs(rg.x - current) >= min_transitive_len) P[np++] = make_int2(current, rg.x);
+      }
+      current = max(current, rg.y);
+      i += 1;
+    }
+    if (current < end) {
+      if (abs(end - current) >= min_transitive_len) P[np++] = make_int2(current, end);
+    }
+    const uint32_t pos = lower_bound_start(R, len, start);  // impg.rs:330-343
+    uint32_t mfrom;
+    if (pos > 0 && R[pos - 1].y >= start) {
+      R[pos - 1].y = max(R[pos - 1].y, end);
+      mfrom = pos - 1;
+    } else if (pos < len && end >= R[pos].x) {
+      R[pos].x = min(start, R[pos].x);
+      R[pos].y = max(end, R[pos].y);
+      mfrom = pos;
+    } else {
+      for (uint32_t k = len; k > pos; k--) R[k] = R[k - 1];
+      R[pos] = make_int2(start, end);
+      len += 1;
+      continue;
+    }
+    uint32_t write = mfrom, read = mfrom + 1;  // merge_forward_from, impg.rs:355-368
+    while (read < len) {
+      if (R[write].y >= R[read].x) {
+        R[write].y = max(R[write].y, R[read].y);
+      } else {
+        write += 1;
+        int2 tmp = R[write];
+        R[write] = R[read];
+        R[read] = tmp;
+      }
+      read += 1;
+    }
+    len = write + 1;
+  }
+  // next-depth ranges of this group: sort by start, merge overlapping/contiguous
+  // (impg.rs:2568-2584; ranges of different groups never share (query, id))
+  for (uint32_t i = 1; i < np; i++) {
+    int2 x = P[i];
+    uint32_t j = i;
+    while (j > 0 && P[j - 1].x > x.x) { P[j] = P[j - 1]; j--; }
+    P[j] = x;
+  }
+  uint32_t w = 0;
+  for (uint32_t r = 1; r < np; r++) {
+    if (P[w].y >= P[r].x) P[w].y = max(P[w].y, P[r].y);
+    else { w += 1; P[w] = P[r]; }
+  }
+  if (np) np = w + 1;
+  new_len[g] = len;
+  n_pieces[g] = np;
+}
+
+__global__ __launch_bounds__(256) void frontier_emit_kernel(const unsigned long long *__restrict__ gkey,
+                                                            const uint32_t *__restrict__ poff,
+                                                            const uint32_t *__restrict__ n_pieces,
+                                                            const uint32_t *__restrict__ foff, uint32_t n_groups,
+                                                            const int2 *__restrict__ pieces,
+                                                            FrontierRec *__restrict__ out) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= n_groups) return;
+  const unsigned long long k = gkey[g];
+  const uint32_t np = n_pieces[g];
+  const int2 *P = pieces + poff[g];
+  FrontierRec *o = out + foff[g];
+  for (uint32_t i = 0; i < np; i++) {
+    FrontierRec f;
+    f.target_id = (uint32_t)(k & 0xFFFFFFFFull);
+    f.start = P[i].x;
+    f.end = P[i].y;
+    f.qidx = (uint32_t)(k >> 32);
+    o[i] = f;
+  }
+}
+
+// level -1: every query's own range is visited on its target (impg.rs:2337-2340)
+__global__ __launch_bounds__(256) void visited_init_kernel(const impg_gpu_range_t *__restrict__ ranges, uint32_t n,
+                                                           const int32_t *__restrict__ seq_len, uint32_t n_seq,
+                                                           int32_t min_transitive_len, unsigned long long *__restrict__ keys,
+                                                           uint32_t *__restrict__ off, uint32_t *__restrict__ len,
+                                                           int2 *__restrict__ rng, FrontierRec *__restrict__ self_iv,
+                                                           uint32_t *__restrict__ in_frontier) {
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= n) return;
+  const impg_gpu_range_t r = ranges[q];
+  int32_t start = min(r.start, r.end), end = max(r.start, r.end);
+  const int32_t sl = r.target_id < n_seq ? seq_len[r.target_id] : 0x7FFFFFFF;
+  if (start < 0) start = 0;
+  if (end > sl) end = sl;
+  keys[q] = ((unsigned long long)q << 32) | r.target_id;
+  off[q] = q;
+  len[q] = 1;
+  rng[q] = make_int2(start, end);
+  FrontierRec f;
+  f.target_id = r.target_id;
+  f.start = start;
+  f.end = end;
+  f.qidx = q;
+  self_iv[q] = f;  // the filtered input range = the self interval (impg.rs:2345-2363)
+  in_frontier[q] = (start < end) && (abs(start - end) >= min_transitive_len);  // impg.rs:2369-2373
+}
+__global__ __launch_bounds__(256) void compact_frontier_kernel(const FrontierRec *__restrict__ in,
+                                                               const uint32_t *__restrict__ flag,
+                                                               const uint32_t *__restrict__ pos, uint32_t n,
+                                                               FrontierRec *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  if (flag[i]) out[pos[i]] = in[i];
+}
+__global__ __launch_bounds__(256) void ranges_to_frontier_kernel(const impg_gpu_range_t *__restrict__ ranges, uint32_t n,
+                                                                 FrontierRec *__restrict__ out) {
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= n) return;
+  FrontierRec f;
+  f.target_id = ranges[q].target_id;
+  f.start = ranges[q].start;
+  f.end = ranges[q].end;
+  f.qidx = q;
+  out[q] = f;
+}
+
+// AoS hits for the stage API
+__global__ __launch_bounds__(256) void hits_to_aos_kernel(const uint32_t *__restrict__ pair_range,
+                                                          const uint32_t *__restrict__ pair_off, uint32_t n_pairs,
+                                                          HitArrays h, impg_gpu_hit_t *__restrict__ out) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n_pairs) return;
+  impg_gpu_hit_t x;
+  x.fidx = pair_range[p];
+  x.query_id = h.qid[p];
+  const bool okk = x.query_id != HIT_NONE;
+  x.q_first = okk ? h.qs[p] : 0;
+  x.q_last = okk ? h.qe[p] : 0;
+  x.t_first = okk ? h.ts[p] : 0;
+  x.t_last = okk ? h.te[p] : 0;
+  x.order = p - pair_off[x.fidx];
+  x.pad = 0;
+  out[p] = x;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 waves per block, capped
+  uint32_t blocks = cdiv(n_items, 4);
+  const uint32_t cap = 256u * 32u;  // 32 blocks per CU worth of grid-stride
+  return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+}
+
+void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, uint32_t *cnt,
+                         uint2 *win, hipStream_t s) {
+  if (!n) return;
+  if (transitive) lookup_count_kernel<true><<<wave_grid(n), 256, 0, s>>>(v, fr, n, cnt, win);
+  else lookup_count_kernel<false><<<wave_grid(n), 256, 0, s>>>(v, fr, n, cnt, win);
+}
+void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
+                        const uint32_t *pair_off, const uint2 *win, uint32_t *pair_range, uint32_t *pair_entry,
+                        hipStream_t s) {
+  if (!n) return;
+  if (transitive) lookup_emit_kernel<true><<<wave_grid(n), 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry);
+  else lookup_emit_kernel<false><<<wave_grid(n), 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry);
+}
+void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
+                    const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
+                    unsigned long long *accepted, uint32_t *err_flag, hipStream_t s) {
+  if (!n_pairs) return;
+  if (transitive) project_kernel<true><<<cdiv(n_pairs, 256), 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag);
+  else project_kernel<false><<<cdiv(n_pairs, 256), 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag);
+}
+void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
+                      int32_t min_output_length, unsigned long long *count, unsigned long long *cksum, hipStream_t s) {
+  if (!n_pairs) return;
+  hit_stats_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, min_output_length, count, cksum);
+}
+void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
+                        unsigned long long *keys, uint32_t *vals, unsigned long long *n_active, hipStream_t s) {
+  if (!n_pairs) return;
+  update_keys_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, keys, vals, n_active);
+}
+size_t sort_pairs_scratch_bytes(uint32_t n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs<rocprim::default_config, const unsigned long long *, unsigned long long *,
+                                  const uint32_t *, uint32_t *>(nullptr, bytes, nullptr, nullptr, nullptr, nullptr, n, 0, 64,
+                                                                (hipStream_t)0);
+  return bytes;
+}
+void launch_sort_pairs(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
+                       const uint32_t *vin, uint32_t *vout, uint32_t n, unsigned end_bit, hipStream_t s) {
+  if (!n) return;
+  IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s));
+}
+void launch_group_heads(const unsigned long long *skeys, uint32_t n, uint32_t *head, hipStream_t s) {
+  if (!n) return;
+  group_heads_kernel<<<cdiv(n, 256), 256, 0, s>>>(skeys, n, head);
+}
+void launch_group_scatter(const unsigned long long *skeys, uint32_t n, const uint32_t *head, const uint32_t *gid,
+                          uint32_t *gstart, unsigned long long *gkey, hipStream_t s) {
+  if (!n) return;
+  group_scatter_kernel<<<cdiv(n, 256), 256, 0, s>>>(skeys, n, head, gid, gstart, gkey);
+}
+void launch_group_prepare(const VisitedTables &vt, const unsigned long long *gkey, const uint32_t *gstart,
+                          uint32_t n_groups, uint32_t n_active, uint32_t *glen, uint32_t *old_tab, uint32_t *old_idx,
+                          uint32_t *cap, uint32_t *pcap, hipStream_t s) {
+  if (!n_groups) return;
+  group_prepare_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(vt, gkey, gstart, n_groups, n_active, glen, old_tab, old_idx, cap, pcap);
+}
+void launch_visited_update(const VisitedTables &vt, const uint32_t *svals, HitArrays h, const int32_t *seq_len,
+                           const unsigned long long *gkey, const uint32_t *gstart, const uint32_t *glen,
+                           const uint32_t *old_tab, const uint32_t *old_idx, const uint32_t *noff, const uint32_t *poff,
+                           uint32_t n_groups, int32_t min_transitive_len, int32_t mdbr, int2 *new_ranges,
+                           uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, hipStream_t s) {
+  if (!n_groups) return;
+  visited_update_kernel<<<cdiv(n_groups, 64), 64, 0, s>>>(vt, svals, h, seq_len, gkey, gstart, glen, old_tab, old_idx, noff,
+                                                          poff, n_groups, min_transitive_len, mdbr, new_ranges, new_len,
+                                                          pieces, n_pieces);
+}
+void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
+                          const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s) {
+  if (!n_groups) return;
+  frontier_emit_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(gkey, poff, n_pieces, foff, n_groups, pieces, out);
+}
+void launch_visited_init(const impg_gpu_range_t *ranges, uint32_t n, const int32_t *seq_len, uint32_t n_seq,
+                         int32_t min_transitive_len, unsigned long long *keys, uint32_t *off, uint32_t *len, int2 *rng,
+                         FrontierRec *self_iv, uint32_t *in_frontier, hipStream_t s) {
+  if (!n) return;
+  visited_init_kernel<<<cdiv(n, 256), 256, 0, s>>>(ranges, n, seq_len, n_seq, min_transitive_len, keys, off, len, rng, self_iv, in_frontier);
+}
+void launch_compact_frontier(const FrontierRec *in, const uint32_t *flag, const uint32_t *pos, uint32_t n,
+                             FrontierRec *out, hipStream_t s) {
+  if (!n) return;
+  compact_frontier_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, flag, pos, n, out);
+}
+void launch_ranges_to_frontier(const impg_gpu_range_t *ranges, uint32_t n, FrontierRec *out, hipStream_t s) {
+  if (!n) return;
+  ranges_to_frontier_kernel<<<cdiv(n, 256), 256, 0, s>>>(ranges, n, out);
+}
+void launch_hits_to_aos(const uint32_t *pair_range, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
+                        impg_gpu_hit_t *out, hipStream_t s) {
+  if (!n_pairs) return;
+  hits_to_aos_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(pair_range, pair_off, n_pairs, h, out);
+}
+
+}  // namespace impg

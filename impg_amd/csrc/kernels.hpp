@@ -1,0 +1,72 @@
+// Kernel launch interface (kernels.hip) used by the host engine.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "impg_internal.hpp"
+
+namespace impg {
+
+typedef impg_gpu_frontier_t FrontierRec;  // {target_id, start, end, qidx}, 16 B
+
+// one level's hits, SoA, indexed by pair slot (slot order = frontier order x visit order)
+struct HitArrays {
+  uint32_t *qid;  // HIT_NONE = projection returned None
+  int32_t *qs, *qe, *ts, *te;
+};
+
+// visited sets: one table per BFS level; a key's newest table entry is complete
+struct VisitedTable {
+  const unsigned long long *keys;  // sorted unique (qidx << 32 | sequence id)
+  const uint32_t *off, *len;       // into ranges
+  const int2 *ranges;              // sorted disjoint (start,end) per key
+  uint32_t n_groups;
+};
+constexpr int MAX_VISITED_TABLES = 48;
+struct VisitedTables {
+  VisitedTable t[MAX_VISITED_TABLES];
+  uint32_t n_tables;
+};
+
+void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, uint32_t *cnt,
+                         uint2 *win, hipStream_t s);
+void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
+                        const uint32_t *pair_off, const uint2 *win, uint32_t *pair_range, uint32_t *pair_entry,
+                        hipStream_t s);
+void launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, unsigned long long *d_bsum,
+                           unsigned long long *d_total, hipStream_t s);
+size_t scan_scratch_bytes(uint32_t n);
+void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
+                    const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
+                    unsigned long long *accepted, uint32_t *err_flag, hipStream_t s);
+void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
+                      int32_t min_output_length, unsigned long long *count, unsigned long long *cksum, hipStream_t s);
+void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
+                        unsigned long long *keys, uint32_t *vals, unsigned long long *n_active, hipStream_t s);
+size_t sort_pairs_scratch_bytes(uint32_t n);
+void launch_sort_pairs(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
+                       const uint32_t *vin, uint32_t *vout, uint32_t n, unsigned end_bit, hipStream_t s);
+void launch_group_heads(const unsigned long long *skeys, uint32_t n, uint32_t *head, hipStream_t s);
+void launch_group_scatter(const unsigned long long *skeys, uint32_t n, const uint32_t *head, const uint32_t *gid,
+                          uint32_t *gstart, unsigned long long *gkey, hipStream_t s);
+void launch_group_prepare(const VisitedTables &vt, const unsigned long long *gkey, const uint32_t *gstart,
+                          uint32_t n_groups, uint32_t n_active, uint32_t *glen, uint32_t *old_tab, uint32_t *old_idx,
+                          uint32_t *cap, uint32_t *pcap, hipStream_t s);
+void launch_visited_update(const VisitedTables &vt, const uint32_t *svals, HitArrays h, const int32_t *seq_len,
+                           const unsigned long long *gkey, const uint32_t *gstart, const uint32_t *glen,
+                           const uint32_t *old_tab, const uint32_t *old_idx, const uint32_t *noff, const uint32_t *poff,
+                           uint32_t n_groups, int32_t min_transitive_len, int32_t mdbr, int2 *new_ranges,
+                           uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, hipStream_t s);
+void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
+                          const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s);
+void launch_visited_init(const impg_gpu_range_t *ranges, uint32_t n, const int32_t *seq_len, uint32_t n_seq,
+                         int32_t min_transitive_len, unsigned long long *keys, uint32_t *off, uint32_t *len, int2 *rng,
+                         FrontierRec *self_iv, uint32_t *in_frontier, hipStream_t s);
+void launch_compact_frontier(const FrontierRec *in, const uint32_t *flag, const uint32_t *pos, uint32_t n,
+                             FrontierRec *out, hipStream_t s);
+void launch_ranges_to_frontier(const impg_gpu_range_t *ranges, uint32_t n, FrontierRec *out, hipStream_t s);
+void launch_hits_to_aos(const uint32_t *pair_range, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
+                        impg_gpu_hit_t *out, hipStream_t s);
+
+}  // namespace impg

@@ -1,0 +1,266 @@
+"""Host-side mirror of the reference's index interface (trait ImpgIndex,
+src/impg_index.rs:21-121) over the C ABI.  Method names and argument meaning
+follow the trait; the batch_* methods are the fast path (one launch sequence for
+many ranges)."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import INTERVAL_DTYPE, RANGE_DTYPE, RECORD_DTYPE, Params, Stats, check, lib
+
+
+def make_params(transitive=False, dfs=False, max_depth=2, min_transitive_len=101, min_distance_between_ranges=10,
+                min_output_length=None, min_identity=None, store_cigar=False):
+    """CLI defaults of src/main.rs:4259-4285."""
+    return Params(int(transitive), int(dfs), max_depth, min_transitive_len, min_distance_between_ranges,
+                  -1 if min_output_length is None else min_output_length,
+                  math.nan if min_identity is None else float(min_identity), int(store_cigar), 0)
+
+
+class QueryResults:
+    """Vec<AdjustedInterval> per range, in the reference's emission order."""
+
+    def __init__(self, handle, owner):
+        self._h = handle
+        self._owner = owner
+        L = lib()
+        self.n_ranges = L.impg_gpu_results_num_ranges(handle)
+        total = L.impg_gpu_results_total(handle)
+        self.offsets = np.ctypeslib.as_array(C.cast(L.impg_gpu_results_offsets(handle), C.POINTER(C.c_uint64)),
+                                             shape=(self.n_ranges + 1,)).copy()
+        if total:
+            raw = np.ctypeslib.as_array(C.cast(L.impg_gpu_results_intervals(handle), C.POINTER(C.c_uint8)),
+                                        shape=(total * INTERVAL_DTYPE.itemsize,))
+            self.intervals = raw.view(INTERVAL_DTYPE).copy()
+        else:
+            self.intervals = np.zeros(0, dtype=INTERVAL_DTYPE)
+        self.projected = L.impg_gpu_results_projected(handle)
+
+    def __getitem__(self, i):
+        return self.intervals[self.offsets[i]:self.offsets[i + 1]]
+
+    def __len__(self):
+        return self.n_ranges
+
+    def bed(self, range_names=None, merge_distance=0, params=None):
+        """output_results_bed over every range (main.rs:11849-11892)."""
+        L = lib()
+        p = params or make_params()
+        arr = None
+        if range_names is not None:
+            arr = (C.c_char_p * len(range_names))(*[s.encode() for s in range_names])
+        text = C.c_void_p(None)
+        ln = C.c_size_t(0)
+        check(L.impg_gpu_results_bed(self._h, self._owner._h, arr, C.byref(p), merge_distance, C.byref(text), C.byref(ln)))
+        try:
+            return C.string_at(text, ln.value).decode()
+        finally:
+            _lib.free(text)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().impg_gpu_results_free(self._h)
+            self._h = None
+
+
+class GpuImpg:
+    """`impl ImpgIndex` backed by the HIP engine."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    # ---- construction (Impg::from_multi_alignment_records / load) ------------
+    @classmethod
+    def from_records(cls, records, ops, seq_len, bidirectional=True, order=_lib.ORDER_COITREES, device=0,
+                     shard=None, n_shards=None):
+        rec = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+        ops = np.ascontiguousarray(ops, dtype=np.uint32)
+        sl = np.ascontiguousarray(seq_len, dtype=np.int64)
+        h = C.c_void_p(None)
+        if shard is None:
+            check(lib().impg_gpu_index_create(rec.ctypes.data, rec.size, ops.ctypes.data, ops.size, sl.ctypes.data, sl.size,
+                                              int(bidirectional), order, device, C.byref(h)))
+        else:
+            check(lib().impg_gpu_index_create_sharded(rec.ctypes.data, rec.size, ops.ctypes.data, ops.size, sl.ctypes.data,
+                                                      sl.size, int(bidirectional), order, device, shard, n_shards,
+                                                      C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_paf(cls, paths, bidirectional=True, order=_lib.ORDER_COITREES, device=0):
+        if isinstance(paths, str):
+            paths = [paths]
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        h = C.c_void_p(None)
+        check(lib().impg_gpu_index_create_from_paf(arr, len(paths), int(bidirectional), order, device, C.byref(h)))
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().impg_gpu_index_destroy(self._h)
+            self._h = None
+
+    # ---- seq_index() / target_ids() / num_targets() ---------------------------
+    def num_seqs(self):
+        return lib().impg_gpu_num_seqs(self._h)
+
+    def seq_name(self, i):
+        s = lib().impg_gpu_seq_name(self._h, i)
+        return None if s is None else s.decode()
+
+    def seq_len(self, i):
+        return lib().impg_gpu_seq_len(self._h, i)
+
+    def seq_id(self, name):
+        r = lib().impg_gpu_seq_id(self._h, name.encode())
+        return None if r < 0 else int(r)
+
+    def num_targets(self):
+        return lib().impg_gpu_num_targets(self._h)
+
+    def target_ids(self):
+        n = lib().impg_gpu_target_ids(self._h, None, 0)
+        out = np.zeros(n, dtype=np.uint32)
+        lib().impg_gpu_target_ids(self._h, out.ctypes.data, n)
+        return out
+
+    def num_entries(self):
+        return lib().impg_gpu_num_entries(self._h)
+
+    def num_records(self):
+        return lib().impg_gpu_num_records(self._h)
+
+    def device_bytes(self):
+        return lib().impg_gpu_device_bytes(self._h)
+
+    # ---- queries ---------------------------------------------------------------
+    @staticmethod
+    def _ranges(ranges):
+        if isinstance(ranges, np.ndarray) and ranges.dtype == RANGE_DTYPE:
+            return np.ascontiguousarray(ranges)
+        a = np.zeros(len(ranges), dtype=RANGE_DTYPE)
+        for i, (t, s, e) in enumerate(ranges):
+            a[i] = (t, s, e)
+        return a
+
+    def query_batch(self, ranges, params=None, **kw):
+        p = params or make_params(**kw)
+        r = self._ranges(ranges)
+        h = C.c_void_p(None)
+        check(lib().impg_gpu_query_batch(self._h, r.ctypes.data, r.size, C.byref(p), C.byref(h)))
+        return QueryResults(h, self)
+
+    def query(self, target_id, range_start, range_end, store_cigar=False, min_gap_compressed_identity=None,
+              sequence_index=None, approximate_mode=False):
+        """ImpgIndex::query (impg_index.rs:26-35)."""
+        if approximate_mode:
+            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "approximate (tracepoint) mode is out of scope")
+        p = make_params(transitive=False, store_cigar=store_cigar, min_identity=min_gap_compressed_identity)
+        return self.query_batch([(target_id, range_start, range_end)], p)[0]
+
+    def query_transitive_bfs(self, target_id, range_start, range_end, masked_regions=None, max_depth=2,
+                             min_transitive_len=101, min_distance_between_ranges=10, min_output_length=None,
+                             store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
+                             approximate_mode=False, subset_filter=None):
+        """ImpgIndex::query_transitive_bfs (impg_index.rs:79-94)."""
+        if masked_regions is not None or subset_filter is not None or approximate_mode:
+            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "masked_regions / subset_filter / approximate_mode")
+        p = make_params(True, False, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
+                        min_gap_compressed_identity, store_cigar)
+        return self.query_batch([(target_id, range_start, range_end)], p)[0]
+
+    def query_transitive_dfs(self, target_id, range_start, range_end, masked_regions=None, max_depth=2,
+                             min_transitive_len=101, min_distance_between_ranges=10, min_output_length=None,
+                             store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
+                             approximate_mode=False, subset_filter=None):
+        """ImpgIndex::query_transitive_dfs (impg_index.rs:63-77)."""
+        if masked_regions is not None or subset_filter is not None or approximate_mode:
+            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "masked_regions / subset_filter / approximate_mode")
+        p = make_params(True, True, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
+                        min_gap_compressed_identity, store_cigar)
+        return self.query_batch([(target_id, range_start, range_end)], p)[0]
+
+    def query_batch_stats(self, ranges, params=None, counts=True, checksums=True, device_ptr=None, n=None, **kw):
+        """Throughput form: results stay in HBM; returns (Stats, counts, checksums)."""
+        p = params or make_params(**kw)
+        st = Stats()
+        if device_ptr is None:
+            r = self._ranges(ranges)
+            n = r.size
+        cnt = np.zeros(n, dtype=np.uint64) if counts else None
+        ck = np.zeros(n, dtype=np.uint64) if checksums else None
+        cp = cnt.ctypes.data if counts else None
+        kp = ck.ctypes.data if checksums else None
+        if device_ptr is None:
+            check(lib().impg_gpu_query_batch_stats(self._h, r.ctypes.data, n, C.byref(p), cp, kp, C.byref(st)))
+        else:
+            check(lib().impg_gpu_query_batch_stats_dev(self._h, device_ptr, n, C.byref(p), cp, kp, C.byref(st)))
+        return st, cnt, ck
+
+    # ---- stage API (device pointers; see impg_amd/sharded.py) --------------------
+    def stage_count(self, d_frontier_ptr, n, transitive, d_counts_ptr):
+        total = C.c_uint64(0)
+        check(lib().impg_gpu_stage_count(self._h, d_frontier_ptr, n, int(transitive), d_counts_ptr, C.byref(total)))
+        return total.value
+
+    def stage_project(self, d_frontier_ptr, n, transitive, params, d_hits_ptr, total):
+        acc = C.c_uint64(0)
+        check(lib().impg_gpu_stage_project(self._h, d_frontier_ptr, n, int(transitive), C.byref(params), d_hits_ptr, total,
+                                           C.byref(acc)))
+        return acc.value
+
+
+def bed_merge(intervals, merge_distance, merge_strands=True):
+    a = np.ascontiguousarray(intervals, dtype=INTERVAL_DTYPE).copy()
+    n = lib().impg_gpu_bed_merge(a.ctypes.data, a.size, merge_distance, int(merge_strands))
+    if n < 0:
+        check(int(n))
+    return a[:n].copy()
+
+
+def parse_cigar(s):
+    b = s.encode() if isinstance(s, str) else s
+    out = np.zeros(len(b) + 1, dtype=np.uint32)
+    n = lib().impg_gpu_parse_cigar(b, len(b), out.ctypes.data, out.size)
+    if n < 0:
+        raise ValueError("Invalid CIGAR operation")
+    return out[:n].copy()
+
+
+def parse_target_range(s):
+    name = C.create_string_buffer(4096)
+    a, b = C.c_int32(0), C.c_int32(0)
+    rc = lib().impg_gpu_parse_target_range(s.encode(), name, 4096, C.byref(a), C.byref(b))
+    if rc != 0:
+        raise ValueError(lib().impg_gpu_last_error().decode())
+    return name.value.decode(), a.value, b.value
+
+
+# ---- synthetic workloads --------------------------------
+def synth_paf(seed, n_records, n_seq=200, seq_len=5_000_000, target_span=10_000, n_blocks=100):
+    n_ops = C.c_size_t(0)
+    check(lib().impg_synth_paf(seed, n_records, n_seq, seq_len, target_span, n_blocks, None, None, 0, C.byref(n_ops)))
+    rec = np.zeros(n_records, dtype=RECORD_DTYPE)
+    ops = np.zeros(n_ops.value, dtype=np.uint32)
+    check(lib().impg_synth_paf(seed, n_records, n_seq, seq_len, target_span, n_blocks, rec.ctypes.data, ops.ctypes.data,
+                               ops.size, C.byref(n_ops)))
+    return rec, ops, np.full(n_seq, seq_len, dtype=np.int64)
+
+
+def synth_paf_text(path, seed, n_records, n_seq=200, seq_len=5_000_000, target_span=10_000, n_blocks=100):
+    check(lib().impg_synth_paf_text(seed, n_records, n_seq, seq_len, target_span, n_blocks, path.encode()))
+    return path
+
+
+def synth_seq_name(i):
+    b = C.create_string_buffer(64)
+    lib().impg_synth_seq_name(i, b, 64)
+    return b.value.decode()
+
+
+def synth_bed(seed, n, n_seq=200, seq_len=5_000_000, range_len=5_000):
+    out = np.zeros(n, dtype=RANGE_DTYPE)
+    check(lib().impg_synth_bed(seed, n, n_seq, seq_len, range_len, out.ctypes.data))
+    return out

@@ -1,0 +1,230 @@
+/*
+ * impg_gpu.h -- C ABI of the MI355X-native batch interval-query + CIGAR
+ * coordinate-projection engine (libimpg_gpu.so).
+ *
+ * This is the drop-in boundary for impg's hot path: a Rust
+ * `struct GpuImpg; impl ImpgIndex for GpuImpg` (reference
+ * src/impg_index.rs:21-121) is ~150 lines of glue over these entry points
+ * (binding sketch in INTEGRATION.md).  Plain pointers and sizes only; no C++
+ * or torch types; nothing unwinds across the boundary -- every call returns an
+ * int status (0 = ok, <0 = error) and impg_gpu_last_error() gives the message
+ * for the calling thread.  All coordinates are i32 and all sequence ids u32,
+ * exactly the reference's types (src/impg.rs:164-174, :225).
+ *
+ * The library requires a gfx950 GPU: there is no CPU fallback.  Index creation
+ * and queries fail with IMPG_E_HIP when no device is present.
+ */
+#ifndef IMPG_GPU_H
+#define IMPG_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMPG_OK 0
+#define IMPG_E_INVALID (-1)     /* bad argument / malformed input (the reference panics: impg.rs:88,:506) */
+#define IMPG_E_HIP (-2)         /* HIP runtime error / no device */
+#define IMPG_E_OOM (-3)
+#define IMPG_E_IO (-4)
+#define IMPG_E_UNSUPPORTED (-5) /* valid in the reference, not built yet */
+
+typedef struct impg_gpu_index impg_gpu_index_t;
+typedef struct impg_gpu_results impg_gpu_results_t;
+
+/* One alignment record as the reference parses it from PAF
+ * (AlignmentRecord, src/alignment_record.rs:12-22; parse_paf_line, src/paf.rs:118-177)
+ * with its CIGAR already tokenised into packed ops: op = code<<29 | len,
+ * codes '='0 'X'1 'I'2 'D'3 'M'4 -- identical to CigarOp (src/impg.rs:81-93). */
+typedef struct {
+  uint32_t query_id, target_id;
+  int32_t query_start, query_end;
+  int32_t target_start, target_end;
+  uint64_t cigar_off; /* first op of this record in the op pool */
+  uint32_t cigar_len; /* number of ops (0 = record has no cg:Z tag) */
+  uint32_t strand;    /* 0 '+', 1 '-' */
+} impg_gpu_record_t;
+
+/* A query range: (target_id, range_start, range_end) of ImpgIndex::query
+ * (src/impg_index.rs:26-35). */
+typedef struct {
+  uint32_t target_id;
+  int32_t start, end;
+} impg_gpu_range_t;
+
+/* AdjustedInterval without its CIGAR (src/impg.rs:225): query interval,
+ * target interval.  q_first > q_last encodes the reverse strand. */
+typedef struct {
+  uint32_t query_id;
+  int32_t q_first, q_last;
+  uint32_t target_id;
+  int32_t t_first, t_last;
+} impg_gpu_interval_t;
+
+/* Scalars of query / query_transitive_{bfs,dfs} (src/impg_index.rs:26-94) with
+ * the CLI defaults of src/main.rs:4259-4285. */
+typedef struct {
+  int32_t transitive;                  /* 0: Impg::query          (impg.rs:1852) */
+  int32_t dfs;                         /* 1: query_transitive_dfs (impg.rs:2057); 0: _bfs (impg.rs:2311) */
+  uint32_t max_depth;                  /* u16 in the reference; 0 = unlimited */
+  int32_t min_transitive_len;          /* default 101 */
+  int32_t min_distance_between_ranges; /* default 10 */
+  int32_t min_output_length;           /* < 0 = None */
+  double min_identity;                 /* NaN = None (min_gap_compressed_identity) */
+  int32_t store_cigar;                 /* BED output never needs it (main.rs:7447) */
+  int32_t reserved;
+} impg_gpu_params_t;
+
+/* Order in which overlapping entries of one target are visited; it fixes the
+ * emission order of hits (and, through the order-dependent visited-set update
+ * of impg.rs:2471-2560, the content of transitive results). */
+#define IMPG_ORDER_COITREES 0 /* coitrees 0.4 BasicCOITree::query order (restated) */
+#define IMPG_ORDER_SORTED 1   /* ascending target start, ties in input order */
+
+const char *impg_gpu_last_error(void);
+int impg_gpu_device_count(void);
+
+/* ---- index: replaces Impg::from_multi_alignment_records (impg.rs:1535-1652),
+ *      ForestMap (forest_map.rs:6-32) and the per-target coitrees ------------ */
+int impg_gpu_index_create(const impg_gpu_record_t *records, size_t n_records,
+                          const uint32_t *cigar_ops, size_t n_ops,
+                          const int64_t *seq_len, uint32_t n_seq,
+                          int bidirectional, int order_policy, int device,
+                          impg_gpu_index_t **out);
+/* Same, parsing PAF files on the host the way paf.rs:118-194 does; sequence ids
+ * are assigned in first-seen order over the files (query then target per line). */
+int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths,
+                                   int bidirectional, int order_policy,
+                                   int device, impg_gpu_index_t **out);
+/* Keep only the entries whose target satisfies target_id % n_shards == shard
+ * (multi-GPU sharding by target sequence; applied at create time). */
+int impg_gpu_index_create_sharded(const impg_gpu_record_t *records, size_t n_records,
+                                  const uint32_t *cigar_ops, size_t n_ops,
+                                  const int64_t *seq_len, uint32_t n_seq,
+                                  int bidirectional, int order_policy, int device,
+                                  uint32_t shard, uint32_t n_shards,
+                                  impg_gpu_index_t **out);
+void impg_gpu_index_destroy(impg_gpu_index_t *);
+
+/* seq_index() (seqidx.rs), target_ids(), num_targets() (impg_index.rs:105-113) */
+uint32_t impg_gpu_num_seqs(const impg_gpu_index_t *);
+const char *impg_gpu_seq_name(const impg_gpu_index_t *, uint32_t id); /* NULL if created without names */
+int64_t impg_gpu_seq_len(const impg_gpu_index_t *, uint32_t id);
+int64_t impg_gpu_seq_id(const impg_gpu_index_t *, const char *name);  /* -1 = unknown */
+size_t impg_gpu_num_targets(const impg_gpu_index_t *);
+size_t impg_gpu_target_ids(const impg_gpu_index_t *, uint32_t *out, size_t cap);
+size_t impg_gpu_num_entries(const impg_gpu_index_t *);
+size_t impg_gpu_num_records(const impg_gpu_index_t *);
+size_t impg_gpu_device_bytes(const impg_gpu_index_t *);
+
+/* Visit rank of the sorted positions 0..n-1 of an n-entry target under an order
+ * policy (what the index stores per entry); host-only, no GPU needed. */
+int impg_gpu_visit_rank(uint32_t n, int order_policy, uint32_t *rank_out);
+
+/* ---- queries ------------------------------------------------------------ */
+/* Batch form of ImpgIndex::query / query_transitive_bfs / _dfs: one independent
+ * query per range (each with its own visited set).  Results are grouped by
+ * range, in the reference's emission order, self interval(s) first.
+ * Unknown target or a target without alignments => self interval only
+ * (impg.rs:1896).  Requires start < end. */
+int impg_gpu_query_batch(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n,
+                         const impg_gpu_params_t *params, impg_gpu_results_t **out);
+/* Single range == batch of one; what a per-call `impl ImpgIndex` binds. */
+int impg_gpu_query(impg_gpu_index_t *, uint32_t target_id, int32_t start, int32_t end,
+                   const impg_gpu_params_t *params, impg_gpu_results_t **out);
+
+size_t impg_gpu_results_num_ranges(const impg_gpu_results_t *);
+size_t impg_gpu_results_total(const impg_gpu_results_t *);
+/* offsets[n_ranges+1] into intervals[]; both owned by the results object */
+const uint64_t *impg_gpu_results_offsets(const impg_gpu_results_t *);
+const impg_gpu_interval_t *impg_gpu_results_intervals(const impg_gpu_results_t *);
+/* number of Some(..) projections (self intervals excluded) = the work unit of BASELINE.md */
+uint64_t impg_gpu_results_projected(const impg_gpu_results_t *);
+void impg_gpu_results_free(impg_gpu_results_t *);
+
+/* Throughput form: same computation, results stay in HBM; returns per-range
+ * hit counts and an order-independent 64-bit checksum of each range's hits
+ * (either may be NULL), the number of projections, and per-stage times. */
+typedef struct {
+  uint64_t projected;      /* accepted projections */
+  uint64_t pairs;          /* (range, entry) candidate pairs examined */
+  uint64_t frontier_ranges;/* frontier ranges looked up over all levels */
+  uint32_t levels;
+  float ms_total;          /* HIP-event time of the whole call on the engine stream */
+  float ms_lookup, ms_project, ms_update; /* per-stage kernel time (HIP events) */
+  uint64_t project_launches;              /* launches of the projection kernel */
+} impg_gpu_stats_t;
+int impg_gpu_query_batch_stats(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n,
+                               const impg_gpu_params_t *params, uint64_t *per_range_count,
+                               uint64_t *per_range_checksum, impg_gpu_stats_t *stats);
+/* Same with the ranges already resident in HBM (device pointer). */
+int impg_gpu_query_batch_stats_dev(impg_gpu_index_t *, const impg_gpu_range_t *d_ranges, size_t n,
+                                   const impg_gpu_params_t *params, uint64_t *per_range_count,
+                                   uint64_t *per_range_checksum, impg_gpu_stats_t *stats);
+
+/* ---- BED: merge_adjusted_intervals_gap_2d + merge_query_adjusted_intervals +
+ *      output_results_bed (main.rs:12858-13011, :12474-12560, :11849-11892) ---- */
+/* In-place merge of one range's results as output_results_bed does for BED
+ * (all CIGARs empty).  Returns the new count. */
+long impg_gpu_bed_merge(impg_gpu_interval_t *iv, size_t n, int32_t merge_distance,
+                        int merge_strands);
+/* Render results as BED text.  range_names[i] is BED column 4 of range i.
+ * The non-transitive min_output_length retain of perform_query
+ * (main.rs:11682-11688) is applied here.  *text is malloc'ed; free() it. */
+int impg_gpu_results_bed(const impg_gpu_results_t *, const impg_gpu_index_t *,
+                         const char *const *range_names, const impg_gpu_params_t *params,
+                         int32_t merge_distance, char **text, size_t *len);
+
+/* ---- host-side ingest helpers (paf.rs, partition.rs parsers) -------------- */
+/* parse_cigar_to_delta (impg.rs:2935-2950): returns #ops or <0 */
+long impg_gpu_parse_cigar(const char *cigar, size_t len, uint32_t *ops_out, size_t cap);
+/* parse_target_range (partition.rs:1752-1763) */
+int impg_gpu_parse_target_range(const char *s, char *name_out, size_t name_cap,
+                                int32_t *start, int32_t *end);
+
+/* ---- stage API: one BFS hop split at its exchange points, for a host that
+ *      shards the index by target across GPUs.  All
+ *      pointers are DEVICE pointers owned by the caller unless noted. -------- */
+/* A frontier record: query range `qidx` (index into the caller's batch) wants
+ * [start,end) on target_id looked up.  16 B. */
+typedef struct {
+  uint32_t target_id;
+  int32_t start, end;
+  uint32_t qidx;
+} impg_gpu_frontier_t;
+/* A hit: projection of frontier record `fidx` through one alignment. 28 B SoA
+ * on device; this AoS form is what crosses ranks. */
+typedef struct {
+  uint32_t fidx;     /* index of the frontier record in the array passed in */
+  uint32_t query_id; /* 0xFFFFFFFF = projection returned None (slot unused) */
+  int32_t q_first, q_last, t_first, t_last;
+  uint32_t order;    /* visit position within the frontier record */
+  uint32_t pad;
+} impg_gpu_hit_t;
+/* lookup: writes counts[n] (overlapping entries of this shard per record) and
+ * returns their sum in *total. */
+int impg_gpu_stage_count(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n,
+                         int transitive, uint32_t *d_counts, uint64_t *total);
+/* project: fills d_hits[total] (slot order = frontier order x visit order). */
+int impg_gpu_stage_project(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n,
+                           int transitive, const impg_gpu_params_t *params,
+                           impg_gpu_hit_t *d_hits, uint64_t total, uint64_t *accepted);
+
+/* ---- synthetic workload generators (SplitMix64) ----- */
+/* Fills records / ops for `n_records` synthetic alignments (200-op CIGARs by
+ * default).  Call with ops == NULL to size: *n_ops_out receives the op count. */
+int impg_synth_paf(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t seq_len,
+                   int32_t target_span, uint32_t n_blocks, impg_gpu_record_t *records,
+                   uint32_t *ops, size_t ops_cap, size_t *n_ops_out);
+/* Writes the same alignments as PAF text (PanSN names gNNN#H#chr1). */
+int impg_synth_paf_text(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t seq_len,
+                        int32_t target_span, uint32_t n_blocks, const char *path);
+int impg_synth_seq_name(uint32_t id, char *out, size_t cap);
+int impg_synth_bed(uint64_t seed, size_t n, uint32_t n_seq, int32_t seq_len, int32_t range_len,
+                   impg_gpu_range_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,208 @@
+"""GPU parity: the HIP engine, called through the C ABI, against the CPU oracle
+on the same inputs.  Bit-exact (integer work): same intervals, same order."""
+import numpy as np
+import pytest
+
+import impg_amd
+from impg_amd import index as gi
+from oracle import oracle as o
+from tests.paf_gen import random_paf, random_ranges
+
+pytestmark = pytest.mark.gpu
+
+
+def both(tmp_path, text, order=impg_amd.ORDER_COITREES, bidirectional=True):
+    path = str(tmp_path / "t.paf")
+    with open(path, "w") as f:
+        f.write(text)
+    g = impg_amd.GpuImpg.from_paf(path, bidirectional=bidirectional, order=order)
+    c = o.OracleIndex(paf_paths=[path], bidirectional=bidirectional, preparse=True)
+    assert g.num_seqs() == c.num_seqs()
+    for i in range(g.num_seqs()):
+        assert g.seq_name(i) == c.seq_name(i) and g.seq_len(i) == c.seq_len(i)
+    return g, c
+
+
+def assert_same(g, c, ranges, **kw):
+    res = g.query_batch(ranges, impg_amd.make_params(**kw))
+    total = 0
+    for i, (t, s, e) in enumerate(ranges):
+        want = c.query(t, s, e, **kw)
+        got = res[i]
+        assert got.tolist() == want.tolist(), (i, (t, s, e), kw)
+        total += c.last_projection_count()
+    assert res.projected == total
+    return res
+
+
+# ---- the reference's own known-answer vectors, through the C ABI ---------------
+KATS = [  # (record ts,te,qs,qe,strand, cigar, range, expected (qs,qe,ts,te) or None)   impg.rs:2981-3156
+    ((100, 200, 0, 100, "+"), "100=", (100, 200), (0, 100, 100, 200)),
+    ((100, 200, 0, 100, "-"), "100=", (100, 200), (100, 0, 100, 200)),
+    ((0, 100, 50, 200, "+"), "10=5I5D50=50I35=", (0, 100), (50, 200, 0, 100)),
+    ((0, 100, 50, 200, "+"), "10=5I5D50=50I35=", (50, 55), (100, 105, 50, 55)),
+    ((0, 100, 50, 200, "+"), "10=5I5D50=50I35=", (50, 64), (100, 114, 50, 64)),
+    ((0, 100, 50, 200, "+"), "10=5I5D50=50I35=", (50, 65), (100, 165, 50, 65)),
+    ((0, 100, 50, 200, "+"), "10=5I5D50=50I35=", (50, 66), (100, 166, 50, 66)),
+    ((0, 100, 50, 200, "+"), "10=5I5D50=50I35=", (70, 95), (170, 195, 70, 95)),
+    ((100, 200, 100, 200, "+"), "100=", (100, 200), (100, 200, 100, 200)),
+    ((100, 200, 100, 200, "-"), "100=", (100, 200), (200, 100, 100, 200)),
+    ((50, 150, 50, 160, "+"), "50=10I50=", (50, 150), (50, 160, 50, 150)),
+    ((50, 150, 50, 140, "+"), "50=10D40=", (50, 150), (50, 140, 50, 150)),
+    ((100, 200, 200, 300, "-"), "50=10D10I40=", (150, 250), (250, 200, 150, 200)),
+    ((0, 50, 0, 40, "+"), "10=20D8=1X1=10I10=", (0, 10), (0, 10, 0, 10)),
+]
+
+
+@pytest.mark.parametrize("k", range(len(KATS)))
+def test_reference_kats(tmp_path, k):
+    (ts, te, qs, qe, strand), cg, rng, expect = KATS[k]
+    text = "Q\t1000\t%d\t%d\t%s\tT\t1000\t%d\t%d\t1\t1\t60\tcg:Z:%s\n" % (qs, qe, strand, ts, te, cg)
+    g, c = both(tmp_path, text, bidirectional=False)
+    tid = g.seq_id("T")
+    got = g.query(tid, rng[0], rng[1])
+    assert got[0].tolist() == (tid, rng[0], rng[1], tid, rng[0], rng[1])
+    assert got[1].tolist() == (g.seq_id("Q"), expect[0], expect[1], tid, expect[2], expect[3])
+    assert got.tolist() == c.query(tid, rng[0], rng[1]).tolist()
+
+
+def test_kat_65_65_not_emitted_and_touching(tmp_path):  # impg.rs:3029-3033
+    text = "Q\t1000\t50\t200\t+\tT\t1000\t0\t100\t1\t1\t60\tcg:Z:10=5I5D50=50I35=\n"
+    g, c = both(tmp_path, text, bidirectional=False)
+    tid = g.seq_id("T")
+    for rng in [(65, 66), (64, 65), (100, 120), (99, 100), (0, 1), (10, 15), (15, 16)]:
+        assert g.query(tid, *rng).tolist() == c.query(tid, *rng).tolist()
+
+
+# ---- tests/test_transitive_integrity.rs scenarios: BED bytes --------------------
+L100 = "\t100\t100\t60\tcg:Z:100="
+SCEN = [
+    (["A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100, "A\t1000\t500\t600\t+\tC\t1000\t0\t100" + L100],
+     ["A:0-100", "A:500-600"], dict(transitive=True)),
+    (["A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100, "B\t1000\t0\t100\t+\tC\t1000\t0\t100" + L100],
+     ["A:25-75"], dict(transitive=True)),
+    (["A\t1000\t0\t100\t+\tB\t1000\t200\t300" + L100], ["A:0-100", "B:200-300"], dict()),
+    (["A\t1000\t0\t100\t-\tB\t1000\t0\t100" + L100], ["A:0-50"], dict()),
+    (["A\t2000\t0\t100\t+\tB\t1000\t0\t100" + L100, "A\t2000\t1000\t1100\t+\tC\t1000\t0\t100" + L100,
+      "B\t1000\t0\t100\t+\tD\t1000\t0\t100" + L100, "C\t1000\t0\t100\t+\tD\t1000\t500\t600" + L100],
+     ["A:0-100", "A:1000-1100"], dict(transitive=True, max_depth=3)),
+    (["A\t1000\t0\t110\t+\tB\t1000\t0\t100\t100\t110\t60\tcg:Z:50=10I50="], ["A:0-50", "A:60-110"], dict()),
+    (["A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100, "A\t1000\t0\t100\t+\tB\t1000\t500\t600" + L100], ["A:0-100"], dict()),
+    (["A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100], ["A:500-600"], dict()),
+    (["A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100, "B\t1000\t0\t100\t+\tC\t1000\t0\t100" + L100,
+      "C\t1000\t0\t100\t+\tD\t1000\t0\t100" + L100], ["A:0-100"], dict(transitive=True, max_depth=1)),
+    (["A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100, "B\t1000\t0\t100\t+\tC\t1000\t0\t100" + L100,
+      "C\t1000\t0\t100\t+\tD\t1000\t0\t100" + L100], ["A:0-100"], dict(transitive=True, max_depth=2)),
+]
+
+
+@pytest.mark.parametrize("k", range(len(SCEN)))
+def test_cli_scenarios_bed_bytes(tmp_path, k):
+    lines, queries, kw = SCEN[k]
+    kw = dict(kw, min_transitive_len=0)
+    g, c = both(tmp_path, "\n".join(lines) + "\n")
+    p = impg_amd.make_params(**kw)
+    ranges, names = [], []
+    for q in queries:
+        name, s, e = gi.parse_target_range(q)
+        ranges.append((g.seq_id(name), s, e))
+        names.append(q)
+    res = g.query_batch(ranges, p)
+    got = res.bed(names, merge_distance=0, params=p)
+    want = "".join(c.query_bed(gi.parse_target_range(q)[0], *gi.parse_target_range(q)[1:], range_name=q,
+                               merge_distance=0, **kw) for q in queries)
+    assert got == want
+    assert got  # never empty: the self interval is always printed
+
+
+# ---- randomised parity -----------------------------------------------------------
+@pytest.mark.parametrize("seed,weird,incons", [(1, False, False), (2, True, False), (3, True, True), (4, False, True),
+                                               (5, True, True)])
+def test_random_query(tmp_path, seed, weird, incons):
+    text, names = random_paf(seed, 400, n_seq=5, seq_len=30000, weird=weird, inconsistent=incons, self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(seed + 100, 300, 5, 30000, max_len=4000)
+    assert_same(g, c, ranges)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_transitive(tmp_path, seed):
+    text, names = random_paf(seed, 300, n_seq=6, seq_len=20000, weird=(seed % 2 == 0), self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(seed + 7, 60, 6, 20000, max_len=3000, min_len=50)
+    for kw in [dict(transitive=True, max_depth=1, min_transitive_len=0, min_distance_between_ranges=0),
+               dict(transitive=True, max_depth=2),
+               dict(transitive=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=10),
+               dict(transitive=True, max_depth=4, min_transitive_len=101, min_distance_between_ranges=50, min_output_length=200),
+               dict(transitive=True, max_depth=0, min_transitive_len=300, min_distance_between_ranges=10)]:
+        assert_same(g, c, ranges, **kw)
+
+
+def test_dense_windows_many_hits(tmp_path):
+    """> 64 candidates per range: the multi-chunk ordering path of lookup_emit."""
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(700):
+        ts = int(rng.integers(0, 3000))
+        ln = int(rng.integers(200, 2500))
+        qs = int(rng.integers(0, 90000))
+        lines.append("Q%d\t100000\t%d\t%d\t%s\tT\t10000\t%d\t%d\t1\t1\t60\tcg:Z:%d=" %
+                     (i % 7, qs, qs + ln, "+-"[i % 2], ts, ts + ln, ln))
+    g, c = both(tmp_path, "\n".join(lines) + "\n")
+    tid = g.seq_id("T")
+    ranges = [(tid, 1000, 2000), (tid, 0, 10000), (tid, 2999, 3001), (tid, 5000, 5400)]
+    res = assert_same(g, c, ranges)
+    assert len(res[1]) > 600
+    assert_same(g, c, ranges, transitive=True, max_depth=2, min_transitive_len=50)
+
+
+def test_sorted_order_policy(tmp_path):
+    """IMPG_ORDER_SORTED: hits of a range come out in ascending target start."""
+    text, names = random_paf(21, 300, n_seq=3, seq_len=20000)
+    g, c = both(tmp_path, text, order=impg_amd.ORDER_SORTED)
+    ranges = random_ranges(3, 50, 3, 20000, max_len=5000)
+    res = g.query_batch(ranges, impg_amd.make_params())
+    for i, (t, s, e) in enumerate(ranges):
+        want = c.query(t, s, e)
+        got = res[i]
+        assert sorted(got.tolist()) == sorted(want.tolist())  # same set as the coitrees order
+        assert got[0].tolist() == want[0].tolist()
+
+
+def test_unknown_and_empty_targets(tmp_path):
+    g, c = both(tmp_path, "A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100 + "\nC\t500\t0\t50\t+\tC\t500\t100\t150\t1\t1\t60\tcg:Z:50=\n")
+    res = g.query_batch([(7, 0, 10), (0, 900, 950), (2, 0, 500)], impg_amd.make_params())
+    assert res[0].tolist() == [(7, 0, 10, 7, 0, 10)]          # unknown target: self only (impg.rs:1896)
+    assert res[1].tolist() == [(0, 900, 950, 0, 900, 950)]
+    assert res[2].tolist() == c.query(2, 0, 500).tolist()      # self-alignment: forward entry only (impg.rs:1584)
+    with pytest.raises(impg_amd.ImpgGpuError):
+        g.query_batch([(0, 10, 10)], impg_amd.make_params())
+
+
+def test_missing_cigar_is_an_error(tmp_path):
+    g, c = both(tmp_path, "A\t1000\t0\t100\t+\tB\t1000\t0\t100\t1\t1\t60\n")
+    assert g.query(0, 500, 600).tolist() == [(0, 500, 600, 0, 500, 600)]
+    with pytest.raises(impg_amd.ImpgGpuError, match="CIGAR"):  # the reference panics (impg.rs:506-511)
+        g.query(1, 0, 100)
+
+
+def test_synthetic_config_small(tmp_path):
+    """BASELINE configs 2/3 at reduced size: same generator, same flags."""
+    path = str(tmp_path / "s.paf")
+    shape = dict(n_seq=8, seq_len=400000, target_span=10000, n_blocks=100)
+    impg_amd.synth_paf_text(path, 42, 1500, **shape)
+    g = impg_amd.GpuImpg.from_paf(path)
+    c = o.OracleIndex(paf_paths=[path], preparse=True)
+    bed = impg_amd.synth_bed(7, 40, n_seq=8, seq_len=400000, range_len=5000)
+    ranges = [(g.seq_id(impg_amd.synth_seq_name(int(r["target_id"]))), int(r["start"]), int(r["end"])) for r in bed]
+    assert_same(g, c, ranges)
+    assert_same(g, c, ranges, transitive=True, max_depth=3)
+    p = impg_amd.make_params(transitive=True, max_depth=3)
+    res = g.query_batch(ranges, p)
+    got = res.bed(None, merge_distance=1000, params=p)
+    want = "".join(c.query_bed(g.seq_name(t), s, e, merge_distance=1000, transitive=True, max_depth=3) for t, s, e in ranges)
+    assert got == want
+    # stats form agrees with the full form
+    st, cnt, ck = g.query_batch_stats(ranges, p)
+    assert st.projected == res.projected
+    assert cnt.tolist() == [len(res[i]) - 1 for i in range(len(ranges))]

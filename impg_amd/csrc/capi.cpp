@@ -126,6 +126,25 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
   res.projected = E.last_projected;
 }
 
+// Runs fn(begin, end) over [0,n) in chunks; a chunk whose level outgrows the pair
+// budget (SplitBatch) is retried at half the size.  Queries are independent, so
+// any split by ranges gives identical results.
+template <class F> void for_chunks(Engine &E, size_t n, F fn) {
+  size_t chunk = E.chunk_ranges ? E.chunk_ranges : n;
+  if (chunk == 0) chunk = 1;
+  size_t b = 0;
+  while (b < n) {
+    size_t e = std::min(n, b + chunk);
+    try {
+      fn(b, e);
+      b = e;
+    } catch (const SplitBatch &) {
+      if (e - b <= 1) throw Error{IMPG_E_UNSUPPORTED, "a single range exceeds the pair budget"};
+      chunk = std::max<size_t>(1, (e - b) / 2);
+    }
+  }
+}
+
 void check_ranges(const impg_gpu_range_t *ranges, size_t n) {
   if (n >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 ranges in one batch"};
   for (size_t i = 0; i < n; i++)
@@ -205,6 +224,21 @@ size_t impg_gpu_num_entries(const impg_gpu_index_t *ix) { return ix->n_entries; 
 size_t impg_gpu_num_records(const impg_gpu_index_t *ix) { return ix->n_records; }
 size_t impg_gpu_device_bytes(const impg_gpu_index_t *ix) { return ix->device_bytes; }
 
+int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
+  IMPG_TRY
+  if (!ix || !key) throw Error{IMPG_E_INVALID, "null argument"};
+  std::string k(key);
+  if (k == "pair_budget") {
+    if (value < 1024 || value >= 0xFFFFFFF0ll) throw Error{IMPG_E_INVALID, "pair_budget out of range"};
+    ix->engine->pair_budget = (uint64_t)value;
+  } else if (k == "chunk_ranges") {
+    if (value < 0 || value >= (1ll << 31)) throw Error{IMPG_E_INVALID, "chunk_ranges out of range"};
+    ix->engine->chunk_ranges = (uint32_t)value;
+  } else throw Error{IMPG_E_INVALID, "unknown option " + k};
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
 int impg_gpu_visit_rank(uint32_t n, int order_policy, uint32_t *rank_out) {
   IMPG_TRY
   if (!rank_out && n) throw Error{IMPG_E_INVALID, "null argument"};
@@ -226,10 +260,19 @@ int impg_gpu_query_batch(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, s
   auto res = std::make_unique<impg_gpu_results>();
   E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
   if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
-  std::vector<std::unique_ptr<LevelBufs>> levels;
-  DevBuf self_dev;
-  E.run(*ix, E.ranges_dev.as<impg_gpu_range_t>(), (uint32_t)n, *params, &levels, nullptr, nullptr, nullptr, &self_dev);
-  assemble_results(E, ranges, (uint32_t)n, *params, levels, self_dev, *res);
+  res->offsets.assign(1, 0);
+  for_chunks(E, n, [&](size_t b, size_t e) {
+    std::vector<std::unique_ptr<LevelBufs>> levels;
+    DevBuf self_dev;
+    E.run(*ix, E.ranges_dev.as<impg_gpu_range_t>() + b, (uint32_t)(e - b), *params, &levels, nullptr, nullptr, nullptr, &self_dev);
+    impg_gpu_results part;
+    assemble_results(E, ranges + b, (uint32_t)(e - b), *params, levels, self_dev, part);
+    uint64_t base = res->intervals.size();
+    res->intervals.insert(res->intervals.end(), part.intervals.begin(), part.intervals.end());
+    for (size_t i = 1; i < part.offsets.size(); i++) res->offsets.push_back(base + part.offsets[i]);
+    res->projected += part.projected;
+  });
+  res->ranges.assign(ranges, ranges + n);
   *out = res.release();
   return IMPG_OK;
   IMPG_CATCH
@@ -262,7 +305,20 @@ static int stats_impl(impg_gpu_index_t *ix, const impg_gpu_range_t *d_ranges, si
     IMPG_HIP(hipMemsetAsync(E.stat_cksum.p, 0, n * 8, E.stream));
     dk = E.stat_cksum.as<unsigned long long>();
   }
-  E.run(*ix, d_ranges, (uint32_t)n, *params, nullptr, dc, dk, stats, nullptr);
+  impg_gpu_stats_t tot;
+  memset(&tot, 0, sizeof tot);
+  for_chunks(E, n, [&](size_t b, size_t e) {
+    impg_gpu_stats_t st;
+    // a split retry must not double-count the slice
+    if (dc) IMPG_HIP(hipMemsetAsync(dc + b, 0, (e - b) * 8, E.stream));
+    if (dk) IMPG_HIP(hipMemsetAsync(dk + b, 0, (e - b) * 8, E.stream));
+    E.run(*ix, d_ranges + b, (uint32_t)(e - b), *params, nullptr, dc ? dc + b : nullptr, dk ? dk + b : nullptr, &st, nullptr);
+    tot.projected += st.projected; tot.pairs += st.pairs; tot.frontier_ranges += st.frontier_ranges;
+    tot.levels = std::max(tot.levels, st.levels);
+    tot.ms_total += st.ms_total; tot.ms_lookup += st.ms_lookup; tot.ms_project += st.ms_project; tot.ms_update += st.ms_update;
+    tot.project_launches += st.project_launches;
+  });
+  if (stats) *stats = tot;
   if (per_range_count && n) IMPG_HIP(hipMemcpy(per_range_count, dc, n * 8, hipMemcpyDeviceToHost));
   if (per_range_checksum && n) IMPG_HIP(hipMemcpy(per_range_checksum, dk, n * 8, hipMemcpyDeviceToHost));
   return IMPG_OK;

@@ -73,7 +73,10 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   pair_off.reserve((size_t)n_fr * 4);
   launch_lookup_count(v, fr, n_fr, transitive, cnt.as<uint32_t>(), win.as<uint2>(), stream);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);
-  if (P >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 candidate pairs in one level: split the batch"};
+  if (P > pair_budget || P >= 0xFFFFFFF0ull) {
+    if (split_ok) throw SplitBatch{};
+    if (P >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 candidate pairs for a single range"};
+  }
   L.n_pairs = (uint32_t)P;
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
@@ -133,7 +136,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       uint64_t cap_total = scan(cap.as<uint32_t>(), vt->off.as<uint32_t>(), n_groups);
       uint64_t pcap_total = scan(pcap.as<uint32_t>(), poff.as<uint32_t>(), n_groups);
       if (cap_total >= 0xFFFFFFF0ull || pcap_total >= 0xFFFFFFF0ull)
-        throw Error{IMPG_E_UNSUPPORTED, "visited sets exceed 2^32 ranges: split the batch"};
+        { if (split_ok) throw SplitBatch{}; throw Error{IMPG_E_UNSUPPORTED, "visited sets exceed 2^32 ranges"}; }
       vt->ranges.reserve(std::max<size_t>(cap_total * 8, 256));
       vt->len.reserve((size_t)n_groups * 4);
       pieces.reserve(std::max<size_t>(pcap_total * 8, 256));
@@ -145,7 +148,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
                             p.min_distance_between_ranges, vt->ranges.as<int2>(), vt->len.as<uint32_t>(),
                             pieces.as<int2>(), n_pieces.as<uint32_t>(), stream);
       uint64_t nn = scan(n_pieces.as<uint32_t>(), foff.as<uint32_t>(), n_groups);
-      if (nn >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "frontier exceeds 2^32 ranges: split the batch"};
+      if (nn >= 0xFFFFFFF0ull) { if (split_ok) throw SplitBatch{}; throw Error{IMPG_E_UNSUPPORTED, "frontier exceeds 2^32 ranges"}; }
       n_next = (uint32_t)nn;
       next_frontier.reserve(std::max<size_t>((size_t)n_next * sizeof(FrontierRec), 256));
       launch_frontier_emit(vt->keys.as<unsigned long long>(), poff.as<uint32_t>(), n_pieces.as<uint32_t>(),
@@ -190,6 +193,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
                  unsigned long long *d_cksum, impg_gpu_stats_t *st, DevBuf *self_out) {
   check_params(p);
   IMPG_HIP(hipSetDevice(ix.device));
+  split_ok = n > 1;
   const DeviceIndexView &v = ix.view;
   ev_next = 0;
   timed.clear();

@@ -16,6 +16,8 @@ struct VisitedStore {  // device storage of one VisitedTable
   uint32_t n_groups = 0;
 };
 
+struct SplitBatch {};  // thrown when a level exceeds pair_budget: the caller halves the chunk
+
 struct Engine {
   hipStream_t stream = nullptr;
   DevBuf counters;
@@ -31,6 +33,9 @@ struct Engine {
   LevelBufs level_scratch;
   std::vector<std::unique_ptr<VisitedStore>> tables;
   uint64_t last_projected = 0;
+  uint64_t pair_budget = 1ull << 28;  // candidate pairs per level kept in HBM at once
+  uint32_t chunk_ranges = 0;          // ranges per chunk (0 = try the whole batch)
+  bool split_ok = false;
   uint32_t stage_n = 0;  // frontier size of the last stage_count call
 
   explicit Engine(int device);

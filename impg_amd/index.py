@@ -135,6 +135,9 @@ class GpuImpg:
     def device_bytes(self):
         return lib().impg_gpu_device_bytes(self._h)
 
+    def set_option(self, key, value):
+        check(lib().impg_gpu_set_option(self._h, key.encode(), int(value)))
+
     # ---- queries ---------------------------------------------------------------
     @staticmethod
     def _ranges(ranges):

@@ -118,6 +118,11 @@ size_t impg_gpu_num_entries(const impg_gpu_index_t *);
 size_t impg_gpu_num_records(const impg_gpu_index_t *);
 size_t impg_gpu_device_bytes(const impg_gpu_index_t *);
 
+/* Tunables: "pair_budget" (max candidate pairs held in HBM per level; a batch
+ * whose level exceeds it is split by ranges, queries being independent) and
+ * "chunk_ranges" (initial ranges per chunk, 0 = whole batch). */
+int impg_gpu_set_option(impg_gpu_index_t *, const char *key, int64_t value);
+
 /* Visit rank of the sorted positions 0..n-1 of an n-entry target under an order
  * policy (what the index stores per entry); host-only, no GPU needed. */
 int impg_gpu_visit_rank(uint32_t n, int order_policy, uint32_t *rank_out);

@@ -845,7 +845,11 @@ bool multi_query_all_indices(const oracle_index &ix, uint32_t target_id, int32_t
   final_results.clear();
   bool any_location = false;
   bool seen_self = false;
-  for (const TreeMap &tm : ix.file_trees) {
+  std::vector<const TreeMap *> subs;  /* one Impg per file; a single file shares the main trees */
+  if (ix.file_trees.empty()) subs.push_back(&ix.trees);
+  else for (const TreeMap &t : ix.file_trees) subs.push_back(&t);
+  for (const TreeMap *tmp : subs) {
+    const TreeMap &tm = *tmp;
     if (tm.find(target_id) == tm.end()) continue;
     any_location = true;
     std::vector<AdjustedInterval> local;
@@ -1096,12 +1100,14 @@ void append(char **buf, size_t *len, size_t *cap, const char *s, size_t n) {
 
 oracle_index *finish_index(oracle_index *ix, std::vector<std::vector<AlignmentRecord>> &recs, bool bidirectional, bool preparse) {
   std::map<uint32_t, std::vector<IvNode>> all;
-  ix->file_trees.resize(recs.size());
+  if (recs.size() > 1) ix->file_trees.resize(recs.size());
   for (size_t f = 0; f < recs.size(); f++) {
     add_entries(recs[f], (uint32_t)f, bidirectional, all);
-    std::map<uint32_t, std::vector<IvNode>> per;
-    add_entries(recs[f], (uint32_t)f, bidirectional, per);
-    build_trees(per, ix->file_trees[f]);
+    if (recs.size() > 1) {
+      std::map<uint32_t, std::vector<IvNode>> per;
+      add_entries(recs[f], (uint32_t)f, bidirectional, per);
+      build_trees(per, ix->file_trees[f]);
+    }
     ix->n_records += recs[f].size();
   }
   build_trees(all, ix->trees);

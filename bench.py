@@ -23,6 +23,13 @@ ALG_BYTES_PER_PROJECTION = 856  # 32 B entry + 4 B x 200
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+T_START = time.time()
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +65,7 @@ def main():
     n_seq, seq_len = 200, 5_000_000
     paf = args.paf or os.path.join(tempfile.gettempdir(), "impg_synth_%d_seed42.paf" % args.records)
     if rank == 0 and not os.path.exists(paf):
+        log("writing synthetic PAF %s" % paf)
         impg_amd.synth_paf_text(paf + ".tmp", 42, args.records, n_seq=n_seq, seq_len=seq_len)
         os.replace(paf + ".tmp", paf)
     if dist is not None:
@@ -65,6 +73,7 @@ def main():
     transitive = not args.no_transitive
     params = impg_amd.make_params(transitive=transitive, max_depth=args.max_depth)  # -x -m 3, defaults otherwise
 
+    log("building the device index")
     t_build = time.time()
     if world == 1:
         index = impg_amd.GpuImpg.from_paf(paf, device=local_rank)
@@ -97,13 +106,17 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    log("index ready (%.1f s, %.2f GB in HBM); warmup" % (t_build, index.device_bytes() / 1e9))
     for _ in range(args.warmup):
-        step()
+        st = step()
+        log("warmup step: %d projected, engine %.1f ms (lookup %.1f project %.1f update %.1f)" %
+            (st.projected, st.ms_total, st.ms_lookup, st.ms_project, st.ms_update))
     sync()
     t0 = time.perf_counter()
     stats = [step() for _ in range(args.steps)]
     sync()
     dt = time.perf_counter() - t0
+    log("timed region: %.3f s for %d steps" % (dt, args.steps))
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -178,9 +191,11 @@ def cpu_baseline(args, paf, ranges, transitive):
     (src/main.rs:7435, src/impg.rs:2384-2465, :495-551)."""
     from oracle import oracle as o
     cores = os.cpu_count() or 1
+    log("cpu baseline: building the oracle index")
     t0 = time.time()
     ix = o.OracleIndex(paf_paths=[paf], preparse=False)
     build_s = time.time() - t0
+    log("cpu baseline: oracle index built in %.1f s; timing the sample" % build_s)
     n = min(args.cpu_sample, len(ranges))
     p = o.make_params(transitive=transitive, max_depth=args.max_depth)
     sub = ranges[:n]

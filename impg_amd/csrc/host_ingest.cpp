@@ -330,27 +330,47 @@ int impg_synth_paf_text(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t
   FILE *fp = fopen(path, "wb");
   if (!fp) { set_error(std::string("cannot create ") + path); return IMPG_E_IO; }
   static const char OPC[] = "=XIDM";
-  std::vector<uint32_t> tmp;
-  std::string line;
-  char buf[160];
-  for (size_t i = 0; i < n_records; i++) {
-    tmp.clear();
-    SynthRecord s = synth_record(seed, i, n_seq, seq_len, target_span, n_blocks, tmp);
-    char qn[32], tn[32];
-    impg_synth_seq_name(s.query, qn, sizeof qn);
-    impg_synth_seq_name(s.target, tn, sizeof tn);
-    int n = snprintf(buf, sizeof buf, "%s\t%d\t%d\t%d\t%c\t%s\t%d\t%d\t%d\t%llu\t%llu\t255\tcg:Z:", qn, seq_len,
-                     s.qs, s.qe, s.strand ? '-' : '+', tn, seq_len, s.ts, s.te, (unsigned long long)s.matches,
-                     (unsigned long long)s.block);
-    line.assign(buf, (size_t)n);
-    for (uint32_t v : tmp) {
-      n = snprintf(buf, sizeof buf, "%u%c", v & OP_LEN_MASK, OPC[v >> 29]);
-      line.append(buf, (size_t)n);
-    }
-    line.push_back('\n');
-    if (fwrite(line.data(), 1, line.size(), fp) != line.size()) { fclose(fp); set_error("write failed"); return IMPG_E_IO; }
+  auto put_u = [](std::string &o, unsigned long long v) {
+    char b[24];
+    int n = 0;
+    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) o.push_back(b[--n]);
+  };
+  // records are formatted in parallel, block by block, and written in order
+  const size_t BLOCK = 4096;
+  unsigned hw = std::thread::hardware_concurrency();
+  const size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, 32));
+  bool ok = true;
+  for (size_t base = 0; base < n_records && ok; base += BLOCK * T) {
+    std::vector<std::string> bufs(T);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; t++)
+      th.emplace_back([&, t]() {
+        size_t lo = base + t * BLOCK, hi = std::min(n_records, lo + BLOCK);
+        std::string &line = bufs[t];
+        std::vector<uint32_t> tmp;
+        char qn[32], tn[32];
+        for (size_t i = lo; i < hi; i++) {
+          tmp.clear();
+          SynthRecord s = synth_record(seed, i, n_seq, seq_len, target_span, n_blocks, tmp);
+          impg_synth_seq_name(s.query, qn, sizeof qn);
+          impg_synth_seq_name(s.target, tn, sizeof tn);
+          line += qn; line.push_back('\t'); put_u(line, (unsigned)seq_len); line.push_back('\t');
+          put_u(line, (unsigned)s.qs); line.push_back('\t'); put_u(line, (unsigned)s.qe); line.push_back('\t');
+          line.push_back(s.strand ? '-' : '+'); line.push_back('\t');
+          line += tn; line.push_back('\t'); put_u(line, (unsigned)seq_len); line.push_back('\t');
+          put_u(line, (unsigned)s.ts); line.push_back('\t'); put_u(line, (unsigned)s.te); line.push_back('\t');
+          put_u(line, s.matches); line.push_back('\t'); put_u(line, s.block); line += "\t255\tcg:Z:";
+          for (uint32_t v : tmp) { put_u(line, v & OP_LEN_MASK); line.push_back(OPC[v >> 29]); }
+          line.push_back('\n');
+        }
+      });
+    for (auto &x : th) x.join();
+    for (size_t t = 0; t < T && ok; t++)
+      if (!bufs[t].empty() && fwrite(bufs[t].data(), 1, bufs[t].size(), fp) != bufs[t].size()) ok = false;
   }
-  fclose(fp);
+  if (fclose(fp) != 0) ok = false;
+  if (!ok) { set_error("write failed"); return IMPG_E_IO; }
   return IMPG_OK;
 }
 

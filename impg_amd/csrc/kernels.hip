@@ -42,7 +42,11 @@ __device__ __forceinline__ uint32_t wave_search(const int32_t *__restrict__ arr,
     uint32_t step = (hi - lo + 63u) >> 6;
     uint32_t idx = lo + (lane + 1u) * step - 1u;
     bool p = idx < hi ? pred(arr[idx]) : true;
-    unsigned f = __ffsll((long long)__ballot(p)) - 1;  // lane 63 probes >= hi-1: always set
+    unsigned long long mask = __ballot(p);
+    // no probe true: every lane probed inside [lo,hi) and lane 63 probed hi-1
+    // (64*step >= hi-lo), so nothing in the range satisfies pred
+    if (mask == 0ull) return hi;
+    unsigned f = __ffsll((long long)mask) - 1;
     uint32_t nlo = lo + f * step;
     uint32_t nhi = lo + (f + 1u) * step - 1u;
     hi = nhi < hi ? nhi : hi;

@@ -206,3 +206,22 @@ def test_synthetic_config_small(tmp_path):
     st, cnt, ck = g.query_batch_stats(ranges, p)
     assert st.projected == res.projected
     assert cnt.tolist() == [len(res[i]) - 1 for i in range(len(ranges))]
+
+
+@pytest.mark.parametrize("n", [64, 65, 128, 129, 4096, 4097, 10000])
+def test_large_segments_search_edges(tmp_path, n):
+    """Segments larger than one wave: multi-round 64-ary search, including
+    ranges before/after every entry (the 'no probe matches' round)."""
+    L = 20 * n + 1000
+    lines = ["q%d\t%d\t%d\t%d\t+\tT\t%d\t%d\t%d\t5\t5\t60\tcg:Z:12=" % (i % 3, L, 20 * i, 20 * i + 12, L, 20 * i + 100, 20 * i + 112)
+             for i in range(n)]
+    g, c = both(tmp_path, "\n".join(lines) + "\n", bidirectional=False)
+    tid = g.seq_id("T")
+    rng = np.random.default_rng(n)
+    ranges = [(tid, 0, 50), (tid, 0, 100), (tid, 0, 101), (tid, L - 50, L), (tid, 20 * n + 92, L), (tid, 20 * n + 91, L),
+              (tid, 0, L), (tid, 99, 101), (tid, 111, 113), (tid, 112, 120)]
+    for _ in range(40):
+        s = int(rng.integers(0, L - 400))
+        ranges.append((tid, s, s + int(rng.integers(1, 400))))
+    assert_same(g, c, ranges)
+    assert_same(g, c, ranges, transitive=True, max_depth=1, min_transitive_len=0)

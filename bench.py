@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--pair-budget", type=int, default=1 << 29)
     ap.add_argument("--cpu-sample", type=int, default=48, help="ranges timed on the CPU oracle (0 = skip)")
     ap.add_argument("--paf", default=None, help="reuse an existing synthetic PAF file")
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
 
     import numpy as np
@@ -54,8 +55,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
@@ -75,12 +79,13 @@ def main():
 
     log("building the device index")
     t_build = time.time()
-    if world == 1:
+    if dist is None:
         index = impg_amd.GpuImpg.from_paf(paf, device=local_rank)
         engine = None
     else:
         from impg_amd.sharded import ShardedImpg
         engine = ShardedImpg.from_paf(paf, rank, world, device=local_rank)
+        engine.chunk_ranges = args.chunk_ranges
         index = engine.local
     t_build = time.time() - t_build
     index.set_option("chunk_ranges", args.chunk_ranges)

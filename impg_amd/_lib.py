@@ -67,6 +67,8 @@ SYMBOLS = [
     ("impg_gpu_index_create_from_paf", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_create_sharded", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                                 C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    ("impg_gpu_index_create_from_paf_sharded", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int,
+                                                         C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("impg_gpu_index_destroy", None, [_P]),
     ("impg_gpu_num_seqs", C.c_uint32, [_P]),
     ("impg_gpu_seq_name", C.c_char_p, [_P, C.c_uint32]),
@@ -95,6 +97,10 @@ SYMBOLS = [
     ("impg_gpu_parse_target_range", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("impg_gpu_stage_count", C.c_int, [_P, _P, C.c_size_t, C.c_int, _P, C.POINTER(C.c_uint64)]),
     ("impg_gpu_stage_project", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(Params), _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("impg_gpu_stage_begin", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, C.POINTER(C.c_uint64), _P]),
+    ("impg_gpu_stage_update", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_uint64)]),
+    ("impg_gpu_stage_next_frontier", C.c_int, [_P, _P, C.c_size_t]),
+    ("impg_gpu_stage_timing", C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.c_int]),
     ("impg_synth_paf", C.c_int, [C.c_uint64, C.c_size_t, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, _P, _P, C.c_size_t,
                                  C.POINTER(C.c_size_t)]),
     ("impg_synth_paf_text", C.c_int, [C.c_uint64, C.c_size_t, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_char_p]),

@@ -199,6 +199,21 @@ int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths, int bi
   IMPG_CATCH
 }
 
+int impg_gpu_index_create_from_paf_sharded(const char *const *paths, int n_paths, int bidirectional, int order_policy,
+                                           int device, uint32_t shard, uint32_t n_shards, impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out || !paths || n_paths <= 0) throw Error{IMPG_E_INVALID, "bad arguments"};
+  require_device(device);
+  ParsedPaf pp;
+  std::vector<std::string> ps(paths, paths + n_paths);
+  parse_paf_files(ps, pp);
+  std::vector<int64_t> lens = pp.seq.lens;
+  *out = make_index(pp.records.data(), pp.records.size(), pp.ops.data(), pp.ops.size(), lens.data(), (uint32_t)lens.size(),
+                    bidirectional, order_policy, device, shard, n_shards, &pp.seq).release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
 void impg_gpu_index_destroy(impg_gpu_index_t *ix) { delete ix; }
 
 uint32_t impg_gpu_num_seqs(const impg_gpu_index_t *ix) { return (uint32_t)ix->seq.lens.size(); }
@@ -382,9 +397,14 @@ int impg_gpu_stage_count(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fron
   IMPG_HIP(hipSetDevice(ix->device));
   E.win.reserve(std::max<size_t>(n * 8, 256));
   E.stage_off.reserve(std::max<size_t>(n * 4, 256));
+  E.ev_next = 0;
+  hipEvent_t e0 = E.event(), e1 = E.event();
+  IMPG_HIP(hipEventRecord(e0, E.stream));
   launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, d_counts, E.win.as<uint2>(), E.stream);
   *total = E.scan(d_counts, E.stage_off.as<uint32_t>(), (uint32_t)n);
+  IMPG_HIP(hipEventRecord(e1, E.stream));
   IMPG_HIP(hipStreamSynchronize(E.stream));
+  { float ms = 0; IMPG_HIP(hipEventElapsedTime(&ms, e0, e1)); E.stage_ms[0] += ms; }
   E.stage_n = (uint32_t)n;
   return IMPG_OK;
   IMPG_CATCH
@@ -406,17 +426,96 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   L.qid.reserve(b); L.qs.reserve(b); L.qe.reserve(b); L.ts.reserve(b); L.te.reserve(b);
   HitArrays h{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
   IMPG_HIP(hipMemsetAsync(E.counters.p, 0, 64, E.stream));
+  E.ev_next = 0;
+  hipEvent_t e0 = E.event(), e1 = E.event(), e2 = E.event();
+  IMPG_HIP(hipEventRecord(e0, E.stream));
   launch_lookup_emit(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_off.as<uint32_t>(), E.win.as<uint2>(),
                      L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), E.stream);
+  IMPG_HIP(hipEventRecord(e1, E.stream));
   launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
                  E.counters.as<unsigned long long>() + 1, (uint32_t *)(E.counters.as<uint64_t>() + 2), E.stream);
+  IMPG_HIP(hipEventRecord(e2, E.stream));
   launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
   IMPG_HIP(hipStreamSynchronize(E.stream));
+  {
+    float ms = 0;
+    IMPG_HIP(hipEventElapsedTime(&ms, e0, e1)); E.stage_ms[0] += ms;
+    IMPG_HIP(hipEventElapsedTime(&ms, e1, e2)); E.stage_ms[1] += ms;
+    if (L.n_pairs) E.stage_launches += 1;
+  }
   uint64_t hc[3];
   IMPG_HIP(hipMemcpy(hc, E.counters.p, 24, hipMemcpyDeviceToHost));
   if (hc[2]) throw Error{IMPG_E_INVALID, "an alignment hit by the query has no CIGAR (missing cg:Z tag)"};
   if (accepted) *accepted = hc[1];
   E.stage_n = 0;
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_stage_begin(impg_gpu_index_t *ix, const impg_gpu_range_t *d_ranges, size_t n, const impg_gpu_params_t *params,
+                         impg_gpu_frontier_t *d_frontier_out, uint64_t *n_frontier, impg_gpu_frontier_t *d_self_out) {
+  IMPG_TRY
+  if (!ix || !params || !n_frontier || (n && (!d_ranges || !d_frontier_out || !d_self_out))) throw Error{IMPG_E_INVALID, "null argument"};
+  if (n >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 ranges in one batch"};
+  Engine &E = *ix->engine;
+  Engine::check_params(*params);
+  IMPG_HIP(hipSetDevice(ix->device));
+  uint32_t nf = 0;
+  if (n) {
+    nf = E.begin_transitive(ix->view, d_ranges, (uint32_t)n, *params, d_self_out, E.frontier_a);
+    if (nf) IMPG_HIP(hipMemcpyAsync(d_frontier_out, E.frontier_a.p, (size_t)nf * sizeof(FrontierRec), hipMemcpyDeviceToDevice, E.stream));
+  } else E.tables.clear();
+  IMPG_HIP(hipStreamSynchronize(E.stream));
+  E.stage_queries = (uint32_t)n;
+  E.stage_next_n = 0;
+  *n_frontier = nf;
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_stage_update(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
+                          const impg_gpu_hit_t *d_hits, size_t n_hits, const impg_gpu_params_t *params, uint64_t *n_next) {
+  IMPG_TRY
+  if (!ix || !params || !n_next || (n_hits && (!d_hits || !d_frontier))) throw Error{IMPG_E_INVALID, "null argument"};
+  if (n_hits >= 0xFFFFFFF0ull || n_frontier >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "too many hits in one update"};
+  Engine &E = *ix->engine;
+  IMPG_HIP(hipSetDevice(ix->device));
+  E.split_ok = false;
+  LevelBufs &L = E.level_scratch;
+  L.n_pairs = (uint32_t)n_hits;
+  size_t b = std::max<size_t>(n_hits * 4, 256);
+  L.pair_range.reserve(b); L.qid.reserve(b); L.qs.reserve(b); L.qe.reserve(b); L.ts.reserve(b); L.te.reserve(b);
+  HitArrays h{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
+  launch_aos_to_hits(d_hits, L.n_pairs, L.pair_range.as<uint32_t>(), h, E.stream);
+  E.ev_next = 0;
+  E.timed.clear();
+  E.stage_next_n = E.update(ix->view, d_frontier, L, std::max<uint32_t>(E.stage_queries, 1), *params, E.stage_next);
+  IMPG_HIP(hipStreamSynchronize(E.stream));
+  for (auto &te : E.timed) { float ms = 0; IMPG_HIP(hipEventElapsedTime(&ms, te.a, te.b)); E.stage_ms[2] += ms; }
+  *n_next = E.stage_next_n;
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_stage_next_frontier(impg_gpu_index_t *ix, impg_gpu_frontier_t *d_out, size_t cap) {
+  IMPG_TRY
+  if (!ix || (!d_out && cap)) throw Error{IMPG_E_INVALID, "null argument"};
+  Engine &E = *ix->engine;
+  if (cap < E.stage_next_n) throw Error{IMPG_E_INVALID, "output buffer too small"};
+  IMPG_HIP(hipSetDevice(ix->device));
+  if (E.stage_next_n) IMPG_HIP(hipMemcpyAsync(d_out, E.stage_next.p, (size_t)E.stage_next_n * sizeof(FrontierRec), hipMemcpyDeviceToDevice, E.stream));
+  IMPG_HIP(hipStreamSynchronize(E.stream));
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_stage_timing(impg_gpu_index_t *ix, float *ms3, uint64_t *launches, int reset) {
+  IMPG_TRY
+  if (!ix) throw Error{IMPG_E_INVALID, "null argument"};
+  Engine &E = *ix->engine;
+  if (ms3) for (int k = 0; k < 3; k++) ms3[k] = E.stage_ms[k];
+  if (launches) *launches = E.stage_launches;
+  if (reset) { E.stage_ms[0] = E.stage_ms[1] = E.stage_ms[2] = 0; E.stage_launches = 0; }
   return IMPG_OK;
   IMPG_CATCH
 }

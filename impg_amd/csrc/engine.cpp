@@ -178,6 +178,23 @@ VisitedTables Engine::tables_view() const {
   return t;
 }
 
+uint32_t Engine::begin_transitive(const DeviceIndexView &v, const impg_gpu_range_t *d_ranges, uint32_t n,
+                                  const impg_gpu_params_t &p, FrontierRec *d_self, DevBuf &frontier_out) {
+  tables.clear();
+  auto t = std::make_unique<VisitedStore>();
+  t->keys.reserve((size_t)n * 8); t->off.reserve((size_t)n * 4); t->len.reserve((size_t)n * 4);
+  t->ranges.reserve((size_t)n * 8);
+  t->n_groups = n;
+  head.reserve((size_t)n * 4); gid.reserve((size_t)n * 4);
+  launch_visited_init(d_ranges, n, v.seq_len, v.n_seq, p.min_transitive_len, t->keys.as<unsigned long long>(),
+                      t->off.as<uint32_t>(), t->len.as<uint32_t>(), t->ranges.as<int2>(), d_self, head.as<uint32_t>(), stream);
+  uint32_t n_fr = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), n);
+  frontier_out.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
+  launch_compact_frontier(d_self, head.as<uint32_t>(), gid.as<uint32_t>(), n, frontier_out.as<FrontierRec>(), stream);
+  tables.push_back(std::move(t));
+  return n_fr;
+}
+
 void Engine::check_params(const impg_gpu_params_t &p) {
   if (p.dfs && p.transitive) throw Error{IMPG_E_UNSUPPORTED, "query_transitive_dfs is not built yet"};
   if (!std::isnan(p.min_identity)) throw Error{IMPG_E_UNSUPPORTED, "min_gap_compressed_identity is not built yet"};
@@ -211,20 +228,9 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     launch_ranges_to_frontier(d_ranges, n, cur->as<FrontierRec>(), stream);
     n_fr = n;
   } else {
-    auto t = std::make_unique<VisitedStore>();
-    t->keys.reserve((size_t)n * 8); t->off.reserve((size_t)n * 4); t->len.reserve((size_t)n * 4);
-    t->ranges.reserve((size_t)n * 8);
-    t->n_groups = n;
     DevBuf &self = self_out ? *self_out : self_scratch;
     self.reserve(std::max<size_t>((size_t)n * sizeof(FrontierRec), 256));
-    head.reserve((size_t)n * 4); gid.reserve((size_t)n * 4);
-    launch_visited_init(d_ranges, n, v.seq_len, v.n_seq, p.min_transitive_len, t->keys.as<unsigned long long>(),
-                        t->off.as<uint32_t>(), t->len.as<uint32_t>(), t->ranges.as<int2>(), self.as<FrontierRec>(),
-                        head.as<uint32_t>(), stream);
-    n_fr = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), n);
-    cur->reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
-    launch_compact_frontier(self.as<FrontierRec>(), head.as<uint32_t>(), gid.as<uint32_t>(), n, cur->as<FrontierRec>(), stream);
-    tables.push_back(std::move(t));
+    n_fr = begin_transitive(v, d_ranges, n, p, self.as<FrontierRec>(), *cur);
   }
 
   uint32_t depth = 0;

@@ -49,6 +49,13 @@ struct Engine {
                   const impg_gpu_params_t &p, DevBuf &next_frontier);
   VisitedTables tables_view() const;
   static void check_params(const impg_gpu_params_t &p);
+  // level -1 of a transitive batch: visited table 0, self intervals, frontier 0
+  uint32_t begin_transitive(const DeviceIndexView &v, const impg_gpu_range_t *d_ranges, uint32_t n,
+                            const impg_gpu_params_t &p, FrontierRec *d_self, DevBuf &frontier_out);
+  float stage_ms[3] = {0, 0, 0};
+  uint64_t stage_launches = 0;
+  DevBuf stage_next;       // next frontier produced by the last stage_update
+  uint32_t stage_next_n = 0, stage_queries = 0;
   void run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
            std::vector<std::unique_ptr<LevelBufs>> *keep, unsigned long long *d_count, unsigned long long *d_cksum,
            impg_gpu_stats_t *st, DevBuf *self_out);

@@ -803,6 +803,19 @@ __global__ __launch_bounds__(256) void hits_to_aos_kernel(const uint32_t *__rest
   out[p] = x;
 }
 
+__global__ __launch_bounds__(256) void aos_to_hits_kernel(const impg_gpu_hit_t *__restrict__ in, uint32_t n,
+                                                          uint32_t *__restrict__ pair_range, HitArrays h) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n) return;
+  const impg_gpu_hit_t x = in[p];
+  pair_range[p] = x.fidx;
+  h.qid[p] = x.query_id;
+  h.qs[p] = x.q_first;
+  h.qe[p] = x.q_last;
+  h.ts[p] = x.t_first;
+  h.te[p] = x.t_last;
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -904,6 +917,11 @@ void launch_hits_to_aos(const uint32_t *pair_range, const uint32_t *pair_off, ui
                         impg_gpu_hit_t *out, hipStream_t s) {
   if (!n_pairs) return;
   hits_to_aos_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(pair_range, pair_off, n_pairs, h, out);
+}
+
+void launch_aos_to_hits(const impg_gpu_hit_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s) {
+  if (!n) return;
+  aos_to_hits_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, n, pair_range, h);
 }
 
 }  // namespace impg

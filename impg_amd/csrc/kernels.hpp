@@ -69,4 +69,6 @@ void launch_ranges_to_frontier(const impg_gpu_range_t *ranges, uint32_t n, Front
 void launch_hits_to_aos(const uint32_t *pair_range, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
                         impg_gpu_hit_t *out, hipStream_t s);
 
+void launch_aos_to_hits(const impg_gpu_hit_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s);
+
 }  // namespace impg

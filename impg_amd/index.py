@@ -89,12 +89,16 @@ class GpuImpg:
         return cls(h)
 
     @classmethod
-    def from_paf(cls, paths, bidirectional=True, order=_lib.ORDER_COITREES, device=0):
+    def from_paf(cls, paths, bidirectional=True, order=_lib.ORDER_COITREES, device=0, shard=None, n_shards=None):
         if isinstance(paths, str):
             paths = [paths]
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         h = C.c_void_p(None)
-        check(lib().impg_gpu_index_create_from_paf(arr, len(paths), int(bidirectional), order, device, C.byref(h)))
+        if shard is None:
+            check(lib().impg_gpu_index_create_from_paf(arr, len(paths), int(bidirectional), order, device, C.byref(h)))
+        else:
+            check(lib().impg_gpu_index_create_from_paf_sharded(arr, len(paths), int(bidirectional), order, device, shard,
+                                                               n_shards, C.byref(h)))
         return cls(h)
 
     def __del__(self):
@@ -213,6 +217,27 @@ class GpuImpg:
         check(lib().impg_gpu_stage_project(self._h, d_frontier_ptr, n, int(transitive), C.byref(params), d_hits_ptr, total,
                                            C.byref(acc)))
         return acc.value
+
+
+    def stage_begin(self, d_ranges_ptr, n, params, d_frontier_ptr, d_self_ptr):
+        nf = C.c_uint64(0)
+        check(lib().impg_gpu_stage_begin(self._h, d_ranges_ptr, n, C.byref(params), d_frontier_ptr, C.byref(nf), d_self_ptr))
+        return nf.value
+
+    def stage_update(self, d_frontier_ptr, n_frontier, d_hits_ptr, n_hits, params):
+        nn = C.c_uint64(0)
+        check(lib().impg_gpu_stage_update(self._h, d_frontier_ptr, n_frontier, d_hits_ptr, n_hits, C.byref(params), C.byref(nn)))
+        return nn.value
+
+    def stage_next_frontier(self, d_out_ptr, cap):
+        check(lib().impg_gpu_stage_next_frontier(self._h, d_out_ptr, cap))
+
+
+    def stage_timing(self, reset=True):
+        ms = (C.c_float * 3)()
+        n = C.c_uint64(0)
+        check(lib().impg_gpu_stage_timing(self._h, ms, C.byref(n), int(reset)))
+        return [ms[0], ms[1], ms[2]], n.value
 
 
 def bed_merge(intervals, merge_distance, merge_strands=True):

@@ -1,0 +1,234 @@
+"""Multi-GPU execution: one process per GPU, the alignment index sharded by
+target sequence (target_id % world == rank), queries resident on their HOME
+rank (the rank that submitted them), the frontier exchanged at every hop of the
+transitive closure (src/impg.rs:2376-2594) with torch.distributed (backend
+"nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).
+
+Per hop, in lock step on every rank:
+  1. home  : bucket its frontier by owner rank; all_gather of the bucket sizes,
+             all_to_all_single of the 16-byte records          (exchange #1)
+  2. owner : lookup + CIGAR projection of the records it received, on its shard
+  3. owner : hits go back to the record's home with all_to_all_single (#2);
+             skipped on the last level in counting mode
+  4. home  : hits re-ordered by frontier index (stable: hits of one record
+             arrive contiguous and in visit order), visited-set update, next
+             frontier (impg.rs:2471-2584)
+A frontier record lives on exactly one owner, so the reference's processing
+order (frontier order x visit order) is reproduced whatever the arrival order.
+
+`backend` is the per-rank engine: GpuBackend (stage API of libimpg_gpu.so) or,
+in CPU tests, a stand-in with the same four methods.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .index import GpuImpg
+
+FR_COLS = 4   # impg_gpu_frontier_t as int32[4]: target_id, start, end, qidx
+HIT_COLS = 8  # impg_gpu_hit_t as int32[8]: fidx, query_id, q_first, q_last, t_first, t_last, order, pad
+
+
+class GpuBackend:
+    """Stage API of the C ABI on torch CUDA tensors (device memory plumbing only)."""
+
+    def __init__(self, index, device):
+        self.index = index
+        self.device = torch.device("cuda", device)
+        self.slice_records = 1 << 22
+
+    def begin(self, ranges_t, n, params):
+        fr = torch.empty((max(n, 1), FR_COLS), dtype=torch.int32, device=self.device)
+        self_iv = torch.empty((max(n, 1), FR_COLS), dtype=torch.int32, device=self.device)
+        nf = self.index.stage_begin(ranges_t.data_ptr(), n, params, fr.data_ptr(), self_iv.data_ptr())
+        return fr[:nf], self_iv[:n]
+
+    def expand(self, frontier, transitive, params, want_hits=True):
+        """-> (hits int32[k,8] with fidx indexing `frontier`, accepted count)"""
+        n = frontier.shape[0]
+        outs, accepted, base = [], 0, 0
+        step = self.slice_records
+        while base < n:
+            m = min(step, n - base)
+            sub = frontier[base:base + m]
+            counts = torch.empty(m, dtype=torch.int32, device=self.device)
+            total = self.index.stage_count(sub.data_ptr(), m, transitive, counts.data_ptr())
+            if total > (1 << 29) and m > 1:  # keep one projection launch under the pair budget
+                step = max(1, m // 2)
+                continue
+            hits = torch.empty((max(total, 1), HIT_COLS), dtype=torch.int32, device=self.device)
+            accepted += self.index.stage_project(sub.data_ptr(), m, transitive, params, hits.data_ptr(), total)
+            if want_hits and total:
+                h = hits[:total]
+                h = h[h[:, 1] != -1]  # drop empty slots (query_id == 0xFFFFFFFF)
+                if base:
+                    h[:, 0] += base
+                outs.append(h)
+            base += m
+        if not want_hits or not outs:
+            return torch.empty((0, HIT_COLS), dtype=torch.int32, device=self.device), accepted
+        return (outs[0] if len(outs) == 1 else torch.cat(outs)), accepted
+
+    def update(self, frontier, hits, params):
+        nn = self.index.stage_update(frontier.data_ptr() if frontier.shape[0] else None, frontier.shape[0],
+                                     hits.data_ptr() if hits.shape[0] else None, hits.shape[0], params)
+        out = torch.empty((max(nn, 1), FR_COLS), dtype=torch.int32, device=self.device)
+        self.index.stage_next_frontier(out.data_ptr(), nn)
+        return out[:nn]
+
+
+class ShardStats:
+    def __init__(self):
+        self.projected = 0        # accepted projections computed on THIS rank's shard
+        self.frontier_ranges = 0
+        self.levels = 0
+        self.ms_lookup = self.ms_project = self.ms_update = self.ms_total = 0.0
+        self.pairs = 0
+        self.project_launches = 0
+
+
+class ShardedImpg:
+    def __init__(self, backend, rank, world, device=None, chunk_ranges=8192):
+        self.backend = backend
+        self.rank, self.world = rank, world
+        self.device = device if device is not None else torch.device("cpu")
+        self.chunk_ranges = chunk_ranges
+        self.local = getattr(backend, "index", None)
+
+    @classmethod
+    def from_paf(cls, paths, rank, world, device=0, **kw):
+        index = GpuImpg.from_paf(paths, device=device, shard=rank, n_shards=world, **kw)
+        return cls(GpuBackend(index, device), rank, world, torch.device("cuda", device))
+
+    # ---- collectives -------------------------------------------------------------
+    def _all_to_all_rows(self, rows, send_counts):
+        """rows grouped by destination rank (send_counts[d] rows each) -> rows
+        received, grouped by source rank, and the per-source counts."""
+        W = self.world
+        sc = torch.as_tensor(send_counts, dtype=torch.int64, device=self.device)
+        gathered = [torch.empty_like(sc) for _ in range(W)]
+        dist.all_gather(gathered, sc)  # every rank learns the full W x W count matrix
+        mat = torch.stack(gathered).cpu()
+        recv_counts = mat[:, self.rank].tolist()
+        out = torch.empty((int(sum(recv_counts)), rows.shape[1]), dtype=rows.dtype, device=self.device)
+        cols = rows.shape[1]
+        dist.all_to_all_single(out.view(-1), rows.contiguous().view(-1),
+                               output_split_sizes=[c * cols for c in recv_counts],
+                               input_split_sizes=[int(c) * cols for c in send_counts])
+        return out, recv_counts
+
+    def _any(self, flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item())
+
+    # ---- one hop --------------------------------------------------------------------
+    def _hop(self, front, transitive, params, need_hits):
+        W = self.world
+        owner = torch.remainder(front[:, 0].to(torch.int64) & 0xFFFFFFFF, W)
+        order = torch.argsort(owner, stable=True)
+        send = front[order].clone()
+        send[:, 3] = order.to(torch.int32)  # owners echo this back: the home frontier index
+        send_counts = torch.bincount(owner, minlength=W).tolist()
+        recv, recv_counts = self._all_to_all_rows(send, send_counts)
+        hits, accepted = self.backend.expand(recv, transitive, params, want_hits=need_hits)
+        if not need_hits:
+            return None, accepted, recv.shape[0]
+        # hits are ordered by fidx and `recv` is grouped by source rank, so hits are
+        # already grouped by the rank they must return to
+        bounds = torch.as_tensor(np.cumsum([0] + recv_counts), dtype=torch.int64, device=self.device)
+        fidx = hits[:, 0].to(torch.int64)
+        back_counts = (torch.searchsorted(fidx, bounds[1:], right=False) - torch.searchsorted(fidx, bounds[:-1], right=False)).tolist()
+        hits = hits.clone()
+        hits[:, 0] = recv[fidx, 3]
+        back, _ = self._all_to_all_rows(hits, back_counts)
+        perm = torch.argsort(back[:, 0].to(torch.int64), stable=True)
+        return back[perm].contiguous(), accepted, recv.shape[0]
+
+    # ---- batches ----------------------------------------------------------------------
+    def _run_chunk(self, ranges_t, n, params, collect):
+        """One chunk of this rank's queries, in lock step with the other ranks.
+        collect: None, or a list that receives (level, frontier, hits) at HOME."""
+        transitive = bool(params.transitive)
+        st = ShardStats()
+        if transitive:
+            front, self_iv = self.backend.begin(ranges_t, n, params)
+        else:
+            r = ranges_t.view(torch.int32).view(-1, 3)[:n]
+            front = torch.cat([r, torch.arange(n, dtype=torch.int32, device=r.device).view(-1, 1)], dim=1).contiguous()
+            self_iv = front
+        depth = 0
+        while True:
+            more = self._any(front.shape[0] > 0)
+            if not more or (transitive and params.max_depth > 0 and depth >= params.max_depth):
+                break
+            last = (not transitive) or (params.max_depth > 0 and depth + 1 >= params.max_depth)
+            need_hits = (collect is not None) or not last
+            hits, accepted, n_looked = self._hop(front, transitive, params, need_hits)
+            st.projected += accepted
+            st.frontier_ranges += n_looked
+            st.levels += 1
+            if collect is not None:
+                collect.append((depth, front, hits))
+            if last:
+                break
+            front = self.backend.update(front, hits, params)
+            depth += 1
+        return st, self_iv
+
+    def _chunks(self, n):
+        n_max = torch.tensor([n], dtype=torch.int64, device=self.device)
+        dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
+        n_chunks = max(1, -(-int(n_max.item()) // self.chunk_ranges))
+        for c in range(n_chunks):
+            b = min(n, c * self.chunk_ranges)
+            e = min(n, b + self.chunk_ranges)
+            yield b, e
+
+    def query_batch_stats(self, ranges_t, n, params):
+        """Counting mode (bench): results stay where they are computed."""
+        tot = ShardStats()
+        item = _lib.RANGE_DTYPE.itemsize
+        if self.local is not None:
+            self.local.stage_timing(reset=True)
+        for b, e in self._chunks(n):
+            st, _ = self._run_chunk(ranges_t[b * item:], e - b, params, None)
+            tot.projected += st.projected
+            tot.frontier_ranges += st.frontier_ranges
+            tot.levels = max(tot.levels, st.levels)
+        if self.local is not None:
+            ms, launches = self.local.stage_timing(reset=True)
+            tot.ms_lookup, tot.ms_project, tot.ms_update = ms
+            tot.ms_total = sum(ms)
+            tot.project_launches = launches
+        return tot
+
+    def query_batch(self, ranges, params):
+        """Full results for this rank's queries, in the reference's emission order:
+        list (per range) of numpy INTERVAL_DTYPE arrays."""
+        ranges = np.ascontiguousarray(ranges, dtype=_lib.RANGE_DTYPE)
+        n = ranges.size
+        ranges_t = torch.from_numpy(ranges.view(np.uint8).copy()).to(self.device)
+        item = _lib.RANGE_DTYPE.itemsize
+        transitive = bool(params.transitive)
+        out = [[] for _ in range(n)]
+        for b, e in self._chunks(n):
+            collect = []
+            _, self_iv = self._run_chunk(ranges_t[b * item:], e - b, params, collect)
+            sv = self_iv.cpu().numpy()
+            for q in range(e - b):
+                t, s, en = int(sv[q, 0]) & 0xFFFFFFFF, int(sv[q, 1]), int(sv[q, 2])
+                if (not transitive) or s < en:
+                    out[b + q].append((t, s, en, t, s, en))
+            for depth, front, hits in collect:
+                f = front.cpu().numpy()
+                h = hits.cpu().numpy()
+                for k in range(h.shape[0]):
+                    fi = int(h[k, 0])
+                    qs, qe = int(h[k, 2]), int(h[k, 3])
+                    if transitive and params.min_output_length >= 0 and abs(qe - qs) < params.min_output_length:
+                        continue
+                    out[b + int(f[fi, 3])].append((int(h[k, 1]) & 0xFFFFFFFF, qs, qe, int(f[fi, 0]) & 0xFFFFFFFF,
+                                                   int(h[k, 4]), int(h[k, 5])))
+        return [np.array(x, dtype=_lib.INTERVAL_DTYPE) for x in out]

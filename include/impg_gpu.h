@@ -105,6 +105,10 @@ int impg_gpu_index_create_sharded(const impg_gpu_record_t *records, size_t n_rec
                                   int bidirectional, int order_policy, int device,
                                   uint32_t shard, uint32_t n_shards,
                                   impg_gpu_index_t **out);
+int impg_gpu_index_create_from_paf_sharded(const char *const *paths, int n_paths,
+                                           int bidirectional, int order_policy, int device,
+                                           uint32_t shard, uint32_t n_shards,
+                                           impg_gpu_index_t **out);
 void impg_gpu_index_destroy(impg_gpu_index_t *);
 
 /* seq_index() (seqidx.rs), target_ids(), num_targets() (impg_index.rs:105-113) */
@@ -215,6 +219,25 @@ int impg_gpu_stage_count(impg_gpu_index_t *, const impg_gpu_frontier_t *d_fronti
 int impg_gpu_stage_project(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n,
                            int transitive, const impg_gpu_params_t *params,
                            impg_gpu_hit_t *d_hits, uint64_t total, uint64_t *accepted);
+
+/* Home-side steps of a sharded transitive batch (visited sets live where the
+ * query lives).  stage_begin resets the visited sets to the batch's own ranges
+ * (impg.rs:2337-2340), writes the self intervals (qidx = range index) to
+ * d_self_out[n] and the level-0 frontier to d_frontier_out (cap n).
+ * stage_update replays hits -- sorted by fidx, fidx indexing d_frontier, hits of
+ * one record in visit order -- against the visited sets (impg.rs:2471-2560) and
+ * builds the next frontier (impg.rs:2566-2584); stage_next_frontier copies it. */
+int impg_gpu_stage_begin(impg_gpu_index_t *, const impg_gpu_range_t *d_ranges, size_t n,
+                         const impg_gpu_params_t *params, impg_gpu_frontier_t *d_frontier_out,
+                         uint64_t *n_frontier, impg_gpu_frontier_t *d_self_out);
+int impg_gpu_stage_update(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
+                          const impg_gpu_hit_t *d_hits, size_t n_hits, const impg_gpu_params_t *params,
+                          uint64_t *n_next);
+int impg_gpu_stage_next_frontier(impg_gpu_index_t *, impg_gpu_frontier_t *d_out, size_t cap);
+/* HIP-event time accumulated by the stage calls since the last reset:
+ * ms[0] lookup (count+emit), ms[1] projection kernel, ms[2] visited update;
+ * launches = projection launches. */
+int impg_gpu_stage_timing(impg_gpu_index_t *, float *ms3, uint64_t *launches, int reset);
 
 /* ---- synthetic workload generators (SplitMix64) ----- */
 /* Fills records / ops for `n_records` synthetic alignments (200-op CIGARs by

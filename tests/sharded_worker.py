@@ -1,0 +1,60 @@
+"""Worker of the multi-rank tests: every rank shards the index by target,
+submits its own queries, and checks its results against the oracle."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import impg_amd  # noqa: E402
+from impg_amd.sharded import GpuBackend, ShardedImpg  # noqa: E402
+from oracle import oracle as o  # noqa: E402
+from tests.paf_gen import random_paf, random_ranges  # noqa: E402
+
+
+def main():
+    backend_name = sys.argv[1]  # "cpu" (gloo + oracle stand-in) or "gpu" (nccl + HIP engine)
+    paf_path = sys.argv[2]
+    dist.init_process_group("gloo" if backend_name == "cpu" else "nccl")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    c = o.OracleIndex(paf_paths=[paf_path], preparse=True)
+    n_seq = c.num_seqs()
+    if backend_name == "cpu":
+        from tests.cpu_backend import OracleBackend
+        eng = ShardedImpg(OracleBackend(c, rank, world), rank, world, torch.device("cpu"), chunk_ranges=7)
+    else:
+        torch.cuda.set_device(0)
+        g = impg_amd.GpuImpg.from_paf(paf_path, device=0, shard=rank, n_shards=world)
+        eng = ShardedImpg(GpuBackend(g, 0), rank, world, torch.device("cuda", 0), chunk_ranges=7)
+    seq_len = int(c.seq_len(0))
+    n_q = 18 + 5 * rank  # ranks own different numbers of queries
+    rl = random_ranges(100 + rank, n_q, n_seq, seq_len, max_len=3000, min_len=120)
+    ranges = np.array(rl, dtype=impg_amd.RANGE_DTYPE)
+    cases = [dict(), dict(transitive=True, max_depth=2), dict(transitive=True, max_depth=3, min_transitive_len=20),
+             dict(transitive=True, max_depth=0, min_transitive_len=200, min_output_length=150)]
+    for kw in cases:
+        p = impg_amd.make_params(**kw)
+        got = eng.query_batch(ranges, p)
+        total = 0
+        for i, (t, s, e) in enumerate(rl):
+            want = c.query(t, s, e, **kw)
+            assert got[i].tolist() == want.tolist(), (rank, i, kw)
+            total += c.last_projection_count()
+        rt = torch.from_numpy(ranges.view(np.uint8).copy()).to(eng.device)
+        st = eng.query_batch_stats(rt, n_q, p)
+        # projections are counted where they are computed: compare the global sums
+        tt = torch.tensor([st.projected, total], dtype=torch.int64, device=eng.device)
+        dist.all_reduce(tt)
+        assert int(tt[0]) == int(tt[1]), (rank, kw, tt.tolist())
+    dist.barrier()
+    if rank == 0:
+        print("sharded ok world=%d" % world)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

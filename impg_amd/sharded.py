@@ -38,7 +38,14 @@ class GpuBackend:
         self.device = torch.device("cuda", device)
         self.slice_records = 1 << 22
 
+    def _sync(self):
+        # the engine runs on its own non-blocking HIP stream: inputs produced by
+        # torch / RCCL on torch's stream must be complete before it reads them
+        # (the stage calls synchronise their own stream before returning)
+        torch.cuda.current_stream(self.device).synchronize()
+
     def begin(self, ranges_t, n, params):
+        self._sync()
         fr = torch.empty((max(n, 1), FR_COLS), dtype=torch.int32, device=self.device)
         self_iv = torch.empty((max(n, 1), FR_COLS), dtype=torch.int32, device=self.device)
         nf = self.index.stage_begin(ranges_t.data_ptr(), n, params, fr.data_ptr(), self_iv.data_ptr())
@@ -46,6 +53,7 @@ class GpuBackend:
 
     def expand(self, frontier, transitive, params, want_hits=True):
         """-> (hits int32[k,8] with fidx indexing `frontier`, accepted count)"""
+        self._sync()
         n = frontier.shape[0]
         outs, accepted, base = [], 0, 0
         step = self.slice_records
@@ -71,6 +79,7 @@ class GpuBackend:
         return (outs[0] if len(outs) == 1 else torch.cat(outs)), accepted
 
     def update(self, frontier, hits, params):
+        self._sync()
         nn = self.index.stage_update(frontier.data_ptr() if frontier.shape[0] else None, frontier.shape[0],
                                      hits.data_ptr() if hits.shape[0] else None, hits.shape[0], params)
         out = torch.empty((max(nn, 1), FR_COLS), dtype=torch.int32, device=self.device)

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libimpg_gpu.so")
+LIB_PATH = os.environ.get("IMPG_GPU_LIB") or os.path.join(_HERE, "libimpg_gpu.so")  # override: kernel experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 IMPG_OK = 0

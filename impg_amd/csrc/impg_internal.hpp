@@ -30,7 +30,11 @@ struct Error {
 // ---- packed CIGAR ops (CigarOp, impg.rs:75-140) ----------------------------
 constexpr uint32_t OP_LEN_MASK = (1u << 29) - 1;
 constexpr uint32_t OP_PAD = 0xFFFFFFFFu;  // tile padding, never a valid op (code 7)
-constexpr uint32_t TILE_OPS = 32;         // ops per tile = one 128-byte line
+#ifndef IMPG_TILE_OPS
+#define IMPG_TILE_OPS 32
+#endif
+constexpr uint32_t TILE_OPS = IMPG_TILE_OPS;  // ops per tile (32 = one 128-byte line)
+static_assert(TILE_OPS % 4 == 0 && TILE_OPS >= 8 && TILE_OPS <= 64, "tile size");
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 
 // ---- device index (HBM layout) ---------------------------------------------

@@ -344,19 +344,20 @@ __device__ __forceinline__ void tile_start(const PairCtx &c, uint32_t j, int32_t
 }
 
 // scan one tile held in registers, effective order
-__device__ __forceinline__ TileScan scan_tile_regs(const PairCtx &c, uint32_t j, const uint4 (&t)[8]) {
+constexpr int TILE_VEC = TILE_OPS / 4;
+__device__ __forceinline__ TileScan scan_tile_regs(const PairCtx &c, uint32_t j, const uint4 (&t)[TILE_VEC]) {
   TileScan s;
   s.found = false;
   s.pqs = s.pts = s.pqe = s.pte = -1;
   int32_t T, Q;
   tile_start(c, j, T, Q);
   bool dead = false;
-  uint32_t o[32];
+  uint32_t o[TILE_OPS];
 #pragma unroll
-  for (int k = 0; k < 8; k++) { o[4 * k] = t[k].x; o[4 * k + 1] = t[k].y; o[4 * k + 2] = t[k].z; o[4 * k + 3] = t[k].w; }
+  for (int k = 0; k < TILE_VEC; k++) { o[4 * k] = t[k].x; o[4 * k + 1] = t[k].y; o[4 * k + 2] = t[k].z; o[4 * k + 3] = t[k].w; }
 #pragma unroll
-  for (int u = 0; u < 32; u++) {
-    uint32_t op = c.flip ? o[31 - u] : o[u];
+  for (int u = 0; u < (int)TILE_OPS; u++) {
+    uint32_t op = c.flip ? o[TILE_OPS - 1 - u] : o[u];
     op_step(op, c.swp, c.dir, c.R0, c.R1, c.last_tp, T, Q, dead, s);
   }
   return s;
@@ -373,8 +374,8 @@ __device__ __noinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32
   const int stepj = c.flip ? -1 : 1;
   for (int64_t j = A;; j += stepj) {
     const uint32_t *tp = c.ops + (size_t)j * TILE_OPS;
-    for (int u = 0; u < 32 && !dead; u++) {
-      uint32_t op = tp[c.flip ? 31 - u : u];
+    for (int u = 0; u < (int)TILE_OPS && !dead; u++) {
+      uint32_t op = tp[c.flip ? (int)TILE_OPS - 1 - u : u];
       op_step(op, c.swp, c.dir, c.R0, c.R1, c.last_tp, T, Q, dead, s);
     }
     if (dead || j == (int64_t)B) break;
@@ -382,10 +383,10 @@ __device__ __noinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32
   return s;
 }
 
-__device__ __forceinline__ void load_tile(const uint32_t *p, uint4 (&t)[8]) {
+__device__ __forceinline__ void load_tile(const uint32_t *p, uint4 (&t)[TILE_VEC]) {
   const uint4 *q = reinterpret_cast<const uint4 *>(p);
 #pragma unroll
-  for (int k = 0; k < 8; k++) t[k] = q[k];
+  for (int k = 0; k < TILE_VEC; k++) t[k] = q[k];
 }
 
 template <bool TRANSITIVE>
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         const uint32_t A = c.flip ? ju : jl, B = c.flip ? jl : ju;
         const bool ordered = c.flip ? A >= B : A <= B;
         if (ordered) {
-          uint4 ta[8], tb[8];
+          uint4 ta[TILE_VEC], tb[TILE_VEC];
           load_tile(c.ops + (size_t)A * TILE_OPS, ta);
           if (A != B) load_tile(c.ops + (size_t)B * TILE_OPS, tb);
           TileScan sa = scan_tile_regs(c, A, ta);

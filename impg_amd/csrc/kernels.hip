@@ -283,84 +283,86 @@ size_t scan_scratch_bytes(uint32_t n) { return ((size_t)(n + SCAN_TILE - 1) / SC
 // ---------------------------------------------------------------------------
 struct TileScan {
   bool found;
-  int32_t pqs, pts, pqe, pte;
+  int32_t pqs, pts, pqe, pte;  // query values are direction-normalised (x dir) until the end
 };
-
-// exact per-op step of project_target_range_through_alignment (impg.rs:2800-2869)
-// on the effective view of an entry.  T/Q are the running target/query position.
-__device__ __forceinline__ void op_step(uint32_t op, bool swp, int32_t dir, int32_t R0, int32_t R1, int32_t last_tp,
-                                        int32_t &T, int32_t &Q, bool &dead, TileScan &s) {
-  if (op == OP_PAD) return;
-  if (T > last_tp) dead = true;  // impg.rs:2802 (positions never decrease: once dead, always dead)
-  const uint32_t code = op >> 29;
-  const int32_t len = (int32_t)(op & OP_LEN_MASK);
-  int32_t td = code == 2u ? 0 : len;  // target_delta (impg.rs:115-121)
-  int32_t qa = code == 3u ? 0 : len;  // |query_delta| (impg.rs:123-135)
-  if (swp) { int32_t t = td; td = qa; qa = t; }  // I<->D for reversed entries (impg.rs:146-151)
-  const bool arm1 = td == 0;            // (0, query_delta)
-  const bool arm3 = !arm1 && qa != 0;   // (target_delta, query_delta)
-  const int32_t lim = (!arm1 && qa == 0) ? last_tp : R1;  // D clips to last_target_pos, match to range end
-  const int32_t os = max(T, R0);
-  const int32_t oe = min(T + td, lim);
-  const bool pass = !dead && (arm1 ? T >= R0 : os < oe);
-  if (pass) {
-    if (!s.found) {
-      s.found = true;
-      s.pqs = Q + (arm3 ? (os - T) * dir : 0);
-      s.pts = arm1 ? T : os;
-    }
-    const int32_t adv = arm1 ? qa : (arm3 ? oe - T : 0);
-    s.pqe = Q + adv * dir;
-    s.pte = arm1 ? T : oe;
-  }
-  T += td;
-  Q += qa * dir;
-}
 
 struct PairCtx {
   int32_t ts, qbase, R0, R1, last_tp, dir;
   bool swp, flip;
+  uint32_t zt, zq;       // op code with zero target delta / zero query delta in the entry's view
   uint32_t m;            // number of tiles
   uint32_t totT, totQ;   // record totals in the entry's (effective) axes
   const uint2 *cp;       // checkpoints of the record, cp[0..m]
   const uint32_t *ops;   // first tile of the record
 };
-__device__ __forceinline__ uint32_t cpT(const PairCtx &c, uint32_t j) { uint2 x = c.cp[j]; return c.swp ? x.y : x.x; }
-__device__ __forceinline__ uint32_t cpQ(const PairCtx &c, uint32_t j) { uint2 x = c.cp[j]; return c.swp ? x.x : x.y; }
 
-// running positions at the effective start of original tile j
-__device__ __forceinline__ void tile_start(const PairCtx &c, uint32_t j, int32_t &T, int32_t &Q) {
-  if (!c.flip) {
-    uint2 x = c.cp[j];
-    uint32_t t = c.swp ? x.y : x.x, q = c.swp ? x.x : x.y;
-    T = c.ts + (int32_t)t;
-    Q = c.qbase + (int32_t)q * c.dir;
-  } else {
-    uint2 x = c.cp[j + 1];
-    uint32_t t = c.swp ? x.y : x.x, q = c.swp ? x.x : x.y;
-    T = c.ts + (int32_t)(c.totT - t);
-    Q = c.qbase + (int32_t)(c.totQ - q) * c.dir;
-  }
+// Exact per-op step of project_target_range_through_alignment (impg.rs:2800-2869)
+// on the effective view of an entry.  T = running target position, Qn = running
+// query position times dir (so it only ever grows).  Positions never decrease,
+// so "target_pos > last_target_pos => break" (impg.rs:2802) is a per-op test.
+//   arm 1 (target_delta == 0):  passes iff T >= R0;            first = (Q, T)       last = (Q+qd, T)
+//   arm 2 (query_delta == 0):   passes iff max(T,R0) < min(T+td,last_tp);  first = (Q, os)  last = (Q, oe)
+//   arm 3:                      passes iff max(T,R0) < min(T+td,R1);  first = (Q+(os-T), os)  last = (Q+(oe-T), oe)
+// When arm 1 passes, os == T and min(T, lim) == T, so "os"/"oe" serve all arms.
+__device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &T, int32_t &Qn, TileScan &s) {
+  const bool valid = op != OP_PAD;
+  const uint32_t code = op >> 29;
+  const int32_t len = valid ? (int32_t)(op & OP_LEN_MASK) : 0;
+  const int32_t td = code == c.zt ? 0 : len;  // target_delta (impg.rs:115-121), I<->D swapped for reversed entries
+  const int32_t qa = code == c.zq ? 0 : len;  // |query_delta| (impg.rs:123-135)
+  const bool arm1 = td == 0;
+  const bool qzero = qa == 0;
+  const int32_t lim = qzero ? c.last_tp : c.R1;  // a deletion clips to last_target_pos, a match to the range end
+  const int32_t os = max(T, c.R0);
+  const int32_t e = T + td;
+  const int32_t oe = min(e, lim);
+  const bool pass = valid && T <= c.last_tp && (arm1 ? T >= c.R0 : os < oe);
+  const int32_t fq = Qn + (qzero ? 0 : os - T);
+  const int32_t lq = Qn + ((arm1 || qzero) ? qa : oe - T);
+  const bool first = pass && !s.found;
+  s.pqs = first ? fq : s.pqs;
+  s.pts = first ? os : s.pts;
+  s.pqe = pass ? lq : s.pqe;
+  s.pte = pass ? oe : s.pte;
+  s.found = s.found || pass;
+  T = e;
+  Qn += qa;
 }
 
-// scan one tile held in registers, effective order
+__device__ __forceinline__ uint32_t cpT(const PairCtx &c, uint32_t j) { uint2 x = c.cp[j]; return c.swp ? x.y : x.x; }
+
+// running positions at the effective start of original tile j
+__device__ __forceinline__ void tile_start(const PairCtx &c, uint32_t j, int32_t &T, int32_t &Qn) {
+  const uint2 x = c.cp[c.flip ? j + 1 : j];
+  const uint32_t t = c.swp ? x.y : x.x, q = c.swp ? x.x : x.y;
+  T = c.ts + (int32_t)(c.flip ? c.totT - t : t);
+  Qn = (int32_t)(c.flip ? c.totQ - q : q);  // offset from qbase, in units of dir
+}
+
 constexpr int TILE_VEC = TILE_OPS / 4;
-__device__ __forceinline__ TileScan scan_tile_regs(const PairCtx &c, uint32_t j, const uint4 (&t)[TILE_VEC]) {
-  TileScan s;
-  s.found = false;
-  s.pqs = s.pts = s.pqe = s.pte = -1;
-  int32_t T, Q;
-  tile_start(c, j, T, Q);
-  bool dead = false;
-  uint32_t o[TILE_OPS];
-#pragma unroll
-  for (int k = 0; k < TILE_VEC; k++) { o[4 * k] = t[k].x; o[4 * k + 1] = t[k].y; o[4 * k + 2] = t[k].z; o[4 * k + 3] = t[k].w; }
-#pragma unroll
-  for (int u = 0; u < (int)TILE_OPS; u++) {
-    uint32_t op = c.flip ? o[TILE_OPS - 1 - u] : o[u];
-    op_step(op, c.swp, c.dir, c.R0, c.R1, c.last_tp, T, Q, dead, s);
+// Scan one tile in effective order, streaming it 16 bytes (4 ops) at a time with
+// the next vector in flight.  Reverse-strand reversed entries walk the tile back
+// to front: descending vector index and reversed components.  `first` is the
+// tile's first vector, already loaded by the caller so that both tiles' HBM
+// misses overlap.
+__device__ __forceinline__ void scan_tile(const PairCtx &c, uint32_t j, uint4 cur, TileScan &s) {
+  int32_t T, Qn;
+  tile_start(c, j, T, Qn);
+  const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)j * TILE_OPS);
+#pragma unroll 1
+  for (int k = 0; k < TILE_VEC; k++) {
+    uint4 nxt = cur;
+    if (k + 1 < TILE_VEC) nxt = q[c.flip ? TILE_VEC - 2 - k : k + 1];
+    op_step(c.flip ? cur.w : cur.x, c, T, Qn, s);
+    op_step(c.flip ? cur.z : cur.y, c, T, Qn, s);
+    op_step(c.flip ? cur.y : cur.z, c, T, Qn, s);
+    op_step(c.flip ? cur.x : cur.w, c, T, Qn, s);
+    cur = nxt;
   }
-  return s;
+}
+__device__ __forceinline__ uint4 tile_first_vec(const PairCtx &c, uint32_t j) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)j * TILE_OPS);
+  return q[c.flip ? TILE_VEC - 1 : 0];
 }
 
 // literal walk over tiles A..B in effective order, one op at a time (rare path)
@@ -368,25 +370,18 @@ __device__ __noinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32
   TileScan s;
   s.found = false;
   s.pqs = s.pts = s.pqe = s.pte = -1;
-  int32_t T, Q;
-  tile_start(c, A, T, Q);
-  bool dead = false;
+  int32_t T, Qn;
+  tile_start(c, A, T, Qn);
   const int stepj = c.flip ? -1 : 1;
   for (int64_t j = A;; j += stepj) {
     const uint32_t *tp = c.ops + (size_t)j * TILE_OPS;
-    for (int u = 0; u < (int)TILE_OPS && !dead; u++) {
+    for (int u = 0; u < (int)TILE_OPS && T <= c.last_tp; u++) {
       uint32_t op = tp[c.flip ? (int)TILE_OPS - 1 - u : u];
-      op_step(op, c.swp, c.dir, c.R0, c.R1, c.last_tp, T, Q, dead, s);
+      op_step(op, c, T, Qn, s);
     }
-    if (dead || j == (int64_t)B) break;
+    if (T > c.last_tp || j == (int64_t)B) break;
   }
   return s;
-}
-
-__device__ __forceinline__ void load_tile(const uint32_t *p, uint4 (&t)[TILE_VEC]) {
-  const uint4 *q = reinterpret_cast<const uint4 *>(p);
-#pragma unroll
-  for (int k = 0; k < TILE_VEC; k++) t[k] = q[k];
 }
 
 template <bool TRANSITIVE>
@@ -411,6 +406,8 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
     c.swp = (en.nops_flags & EF_REVERSED) != 0;
     c.flip = c.swp && rev;
     c.dir = rev ? -1 : 1;
+    c.zt = c.swp ? 3u : 2u;  // 'I' consumes no target; for a reversed entry 'D' does (impg.rs:146-151)
+    c.zq = c.swp ? 2u : 3u;
     c.ts = en.ts;
     c.qbase = rev ? en.qe : en.qs;  // impg.rs:2778-2782
     c.R0 = f.start;
@@ -459,14 +456,19 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         const uint32_t A = c.flip ? ju : jl, B = c.flip ? jl : ju;
         const bool ordered = c.flip ? A >= B : A <= B;
         if (ordered) {
-          uint4 ta[TILE_VEC], tb[TILE_VEC];
-          load_tile(c.ops + (size_t)A * TILE_OPS, ta);
-          if (A != B) load_tile(c.ops + (size_t)B * TILE_OPS, tb);
-          TileScan sa = scan_tile_regs(c, A, ta);
+          const uint4 va = tile_first_vec(c, A);
+          const uint4 vb = tile_first_vec(c, B);  // == va when A == B (same address: one miss)
+          TileScan sa;
+          sa.found = false;
+          sa.pqs = sa.pts = sa.pqe = sa.pte = -1;
+          scan_tile(c, A, va, sa);
           if (A == B) {
             res = sa;
           } else {
-            TileScan sb = scan_tile_regs(c, B, tb);
+            TileScan sb;
+            sb.found = false;
+            sb.pqs = sb.pts = sb.pqe = sb.pte = -1;
+            scan_tile(c, B, vb, sb);
             if (sa.found && sb.found) {
               res.found = true;
               res.pqs = sa.pqs; res.pts = sa.pts;
@@ -479,6 +481,9 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
       }
       ok = res.found && res.pqs != res.pqe && res.pts != res.pte;  // impg.rs:2874-2877
       if (ok) qid = en.query_id;
+      // back from direction-normalised offsets to query coordinates
+      res.pqs = c.qbase + (rev ? -res.pqs : res.pqs);
+      res.pqe = c.qbase + (rev ? -res.pqe : res.pqe);
     }
     h.qid[p] = qid;
     if (ok) {

@@ -426,6 +426,14 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
       const uint2 tot = c.cp[c.m];
       c.totT = c.swp ? tot.y : tot.x;
       c.totQ = c.swp ? tot.x : tot.y;
+      // Shortcuts that need no CIGAR bytes (exact):
+      //  * the range reaches back to the alignment start: op 0 is the first
+      //    overlapping op whatever its type, at (query offset 0, target ts);
+      //  * the range reaches the alignment end and the CIGAR is consistent with
+      //    the PAF coordinates: the final op is the last overlapping op, ending at
+      //    (query offset totQ, target te).
+      const bool start_cov = c.R0 <= c.ts && c.last_tp > c.ts;
+      const bool end_cov = c.R1 >= en.te && c.R0 < en.te && (int32_t)c.totT == en.te - c.ts;
       // tile A holds the first op whose inclusive target prefix reaches R0; tile B
       // the last op whose exclusive prefix is <= last_tp.  cpT is nondecreasing.
       //   LB(x) = first i in [1,m] with cpT[i] >= x (m+1 if none)
@@ -433,8 +441,11 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
       const int32_t xa = c.flip ? (int32_t)c.totT + c.ts - c.R0 : c.R0 - c.ts;
       const int32_t xb = c.flip ? (int32_t)c.totT + c.ts - c.last_tp : c.last_tp - c.ts;
       const int32_t xlb = c.flip ? xb : xa, xub = c.flip ? xa : xb;
-      uint32_t lb, ubv;
-      {
+      // the LB search serves A (forward) or B (flip); the UB search the other one
+      const bool need_lb = c.flip ? !end_cov : !start_cov;
+      const bool need_ub = c.flip ? !start_cov : !end_cov;
+      uint32_t lb = c.flip ? 1 : 1, ubv = c.flip ? c.m : c.m;  // covered ends: first / last effective tile
+      if (need_lb) {
         uint32_t lo = 1, hi = c.m + 1;
         while (lo < hi) {
           uint32_t mid = (lo + hi) >> 1;
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         }
         lb = lo;
       }
-      {
+      if (need_ub) {
         uint32_t lo = 0, hi = c.m;
         while (lo < hi) {
           uint32_t mid = (lo + hi) >> 1;
@@ -456,26 +467,37 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         const uint32_t A = c.flip ? ju : jl, B = c.flip ? jl : ju;
         const bool ordered = c.flip ? A >= B : A <= B;
         if (ordered) {
-          const uint4 va = tile_first_vec(c, A);
-          const uint4 vb = tile_first_vec(c, B);  // == va when A == B (same address: one miss)
-          TileScan sa;
-          sa.found = false;
+          uint4 va = make_uint4(OP_PAD, OP_PAD, OP_PAD, OP_PAD), vb = va;
+          if (!start_cov) va = tile_first_vec(c, A);
+          if (!end_cov && (start_cov || A != B)) vb = tile_first_vec(c, B);
+          TileScan sa, sb;
+          sa.found = sb.found = false;
           sa.pqs = sa.pts = sa.pqe = sa.pte = -1;
-          scan_tile(c, A, va, sa);
-          if (A == B) {
-            res = sa;
+          sb = sa;
+          if (start_cov) {
+            sa.found = true;
+            sa.pqs = 0;
+            sa.pts = c.ts;
           } else {
-            TileScan sb;
-            sb.found = false;
-            sb.pqs = sb.pts = sb.pqe = sb.pte = -1;
+            scan_tile(c, A, va, sa);
+          }
+          if (end_cov) {
+            sb.found = true;
+            sb.pqe = (int32_t)c.totQ;
+            sb.pte = en.te;
+          } else if (!start_cov && A == B) {
+            sb = sa;  // one tile holds both ends: its scan recorded the last overlapping op too
+          } else {
             scan_tile(c, B, vb, sb);
-            if (sa.found && sb.found) {
-              res.found = true;
-              res.pqs = sa.pqs; res.pts = sa.pts;
-              res.pqe = sb.pqe; res.pte = sb.pte;
-            } else {
-              res = walk_tiles(c, A, B);
-            }
+          }
+          if (sa.found && sb.found) {
+            res.found = true;
+            res.pqs = sa.pqs; res.pts = sa.pts;
+            res.pqe = sb.pqe; res.pte = sb.pte;
+          } else if (!start_cov && !end_cov && A == B) {
+            res.found = false;  // every overlapping op would lie in this tile
+          } else {
+            res = walk_tiles(c, A, B);
           }
         }
       }

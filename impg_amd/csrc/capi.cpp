@@ -426,6 +426,7 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   L.qid.reserve(b); L.qs.reserve(b); L.qe.reserve(b); L.ts.reserve(b); L.te.reserve(b);
   HitArrays h{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
   IMPG_HIP(hipMemsetAsync(E.counters.p, 0, 64, E.stream));
+  IMPG_HIP(hipMemsetAsync(E.acc_slots.p, 0, COUNT_BYTES, E.stream));
   E.ev_next = 0;
   hipEvent_t e0 = E.event(), e1 = E.event(), e2 = E.event();
   IMPG_HIP(hipEventRecord(e0, E.stream));
@@ -433,7 +434,7 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
                      L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), E.stream);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
-                 E.counters.as<unsigned long long>() + 1, (uint32_t *)(E.counters.as<uint64_t>() + 2), E.stream);
+                 E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), E.stream);
   IMPG_HIP(hipEventRecord(e2, E.stream));
   launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
   IMPG_HIP(hipStreamSynchronize(E.stream));
@@ -446,7 +447,7 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   uint64_t hc[3];
   IMPG_HIP(hipMemcpy(hc, E.counters.p, 24, hipMemcpyDeviceToHost));
   if (hc[2]) throw Error{IMPG_E_INVALID, "an alignment hit by the query has no CIGAR (missing cg:Z tag)"};
-  if (accepted) *accepted = hc[1];
+  if (accepted) *accepted = E.read_slots(E.acc_slots);
   E.stage_n = 0;
   return IMPG_OK;
   IMPG_CATCH

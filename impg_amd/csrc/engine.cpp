@@ -26,11 +26,15 @@ Engine::Engine(int device) {
   IMPG_HIP(hipSetDevice(device));
   IMPG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   counters.reserve(64);
+  acc_slots.reserve(COUNT_BYTES);
+  act_slots.reserve(COUNT_BYTES);
   IMPG_HIP(hipHostMalloc((void **)&h_counters, 64, hipHostMallocDefault));
+  IMPG_HIP(hipHostMalloc((void **)&h_slots, COUNT_BYTES, hipHostMallocDefault));
 }
 Engine::~Engine() {
   for (auto e : ev_pool) (void)hipEventDestroy(e);
   if (h_counters) (void)hipHostFree(h_counters);
+  if (h_slots) (void)hipHostFree(h_slots);
   if (stream) (void)hipStreamDestroy(stream);
 }
 hipEvent_t Engine::event() {
@@ -48,6 +52,14 @@ uint64_t Engine::read_counter(int k) {
   IMPG_HIP(hipMemcpyAsync(h_counters, counters.as<uint64_t>() + k, 8, hipMemcpyDeviceToHost, stream));
   IMPG_HIP(hipStreamSynchronize(stream));
   return h_counters[0];
+}
+
+uint64_t Engine::read_slots(DevBuf &b) {
+  IMPG_HIP(hipMemcpyAsync(h_slots, b.p, COUNT_BYTES, hipMemcpyDeviceToHost, stream));
+  IMPG_HIP(hipStreamSynchronize(stream));
+  uint64_t t = 0;
+  for (uint32_t k = 0; k < COUNT_SLOTS; k++) t += h_slots[k * COUNT_STRIDE];
+  return t;
 }
 
 uint64_t Engine::scan(const uint32_t *in, uint32_t *out, uint32_t n) {
@@ -85,7 +97,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   IMPG_HIP(hipEventRecord(e1, stream));
   HitArrays h = hit_arrays(L, L.n_pairs);
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
-                 counters.as<unsigned long long>() + 1, (uint32_t *)(counters.as<uint64_t>() + 2), stream);
+                 acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), stream);
   IMPG_HIP(hipEventRecord(e2, stream));
   timed.push_back({e0, e1, 0});
   timed.push_back({e1, e2, 1});
@@ -108,9 +120,9 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
   if (P) {
     keys.reserve((size_t)P * 8); skeys.reserve((size_t)P * 8);
     vals.reserve((size_t)P * 4); svals.reserve((size_t)P * 4);
-    IMPG_HIP(hipMemsetAsync(counters.as<uint64_t>() + 4, 0, 8, stream));
+    IMPG_HIP(hipMemsetAsync(act_slots.p, 0, COUNT_BYTES, stream));
     launch_update_keys(fr, L.pair_range.as<uint32_t>(), P, h, keys.as<unsigned long long>(), vals.as<uint32_t>(),
-                       counters.as<unsigned long long>() + 4, stream);
+                       act_slots.as<unsigned long long>(), stream);
     size_t tb = sort_pairs_scratch_bytes(P);
     sort_tmp.reserve(tb);
     launch_sort_pairs(sort_tmp.p, tb, keys.as<unsigned long long>(), skeys.as<unsigned long long>(), vals.as<uint32_t>(),
@@ -124,7 +136,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       gstart.reserve((size_t)n_groups * 4);
       launch_group_scatter(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), gid.as<uint32_t>(), gstart.as<uint32_t>(),
                            vt->keys.as<unsigned long long>(), stream);
-      const uint32_t n_active = (uint32_t)read_counter(4);  // hits that carry a (query, sequence) key
+      const uint32_t n_active = (uint32_t)read_slots(act_slots);  // hits that carry a (query, sequence) key
       glen.reserve((size_t)n_groups * 4); old_tab.reserve((size_t)n_groups * 4); old_idx.reserve((size_t)n_groups * 4);
       cap.reserve((size_t)n_groups * 4); pcap.reserve((size_t)n_groups * 4);
       VisitedTables tabs = tables_view();
@@ -216,6 +228,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   timed.clear();
   tables.clear();
   IMPG_HIP(hipMemsetAsync(counters.p, 0, 64, stream));
+  IMPG_HIP(hipMemsetAsync(acc_slots.p, 0, COUNT_BYTES, stream));
   hipEvent_t t0 = event(), t1 = event();
   IMPG_HIP(hipEventRecord(t0, stream));
   if (st) memset(st, 0, sizeof *st);
@@ -268,6 +281,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   uint64_t hc[3];
   IMPG_HIP(hipMemcpy(hc, counters.p, 24, hipMemcpyDeviceToHost));
   if (hc[2]) throw Error{IMPG_E_INVALID, "an alignment hit by the query has no CIGAR (missing cg:Z tag)"};
+  hc[1] = read_slots(acc_slots);
   if (st) {
     st->projected = hc[1];
     float ms = 0;

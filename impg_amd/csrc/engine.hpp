@@ -20,7 +20,10 @@ struct SplitBatch {};  // thrown when a level exceeds pair_budget: the caller ha
 
 struct Engine {
   hipStream_t stream = nullptr;
-  DevBuf counters;
+  DevBuf counters;          // 8 x u64: [2] error flag, [3] scan total
+  DevBuf acc_slots, act_slots;  // striped counters: accepted projections, keyed hits
+  uint64_t *h_slots = nullptr;
+  uint64_t read_slots(DevBuf &b);
   uint64_t *h_counters = nullptr;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;

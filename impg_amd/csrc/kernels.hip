@@ -515,8 +515,16 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
       h.te[p] = res.pte;
     }
   }
+  // accepted-projection count: one atomic per BLOCK, spread over COUNT_SLOTS
+  // cache lines (a single hot word caps the whole chip at ~90 atomics/us)
+  __shared__ uint32_t wcnt[4];
   unsigned long long m = __ballot(ok);
-  if (lane_id() == 0 && m) atomicAdd(accepted, (unsigned long long)__popcll(m));
+  if (lane_id() == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (tot) atomicAdd(&accepted[(blockIdx.x % COUNT_SLOTS) * COUNT_STRIDE], (unsigned long long)tot);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -565,8 +573,14 @@ __global__ __launch_bounds__(256) void update_keys_kernel(const FrontierRec *__r
     keys[p] = k;
     vals[p] = p;
   }
+  __shared__ uint32_t wcnt[4];
   unsigned long long m = __ballot(k != ~0ull);
-  if (lane_id() == 0 && m) atomicAdd(n_active, (unsigned long long)__popcll(m));
+  if (lane_id() == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (tot) atomicAdd(&n_active[(blockIdx.x % COUNT_SLOTS) * COUNT_STRIDE], (unsigned long long)tot);
+  }
 }
 
 // head flag of each run of equal keys (only keys != ~0 count)

@@ -24,6 +24,9 @@ struct VisitedTable {
   uint32_t n_groups;
 };
 constexpr int MAX_VISITED_TABLES = 48;
+// striped device counters: COUNT_SLOTS words, one per 128-byte line
+constexpr uint32_t COUNT_SLOTS = 64, COUNT_STRIDE = 16;
+constexpr size_t COUNT_BYTES = (size_t)COUNT_SLOTS * COUNT_STRIDE * 8;
 struct VisitedTables {
   VisitedTable t[MAX_VISITED_TABLES];
   uint32_t n_tables;

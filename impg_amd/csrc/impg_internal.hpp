@@ -30,35 +30,57 @@ struct Error {
 // ---- packed CIGAR ops (CigarOp, impg.rs:75-140) ----------------------------
 constexpr uint32_t OP_LEN_MASK = (1u << 29) - 1;
 constexpr uint32_t OP_PAD = 0xFFFFFFFFu;  // tile padding, never a valid op (code 7)
-#ifndef IMPG_TILE_OPS
-#define IMPG_TILE_OPS 32
-#endif
-constexpr uint32_t TILE_OPS = IMPG_TILE_OPS;  // ops per tile (32 = one 128-byte line)
-static_assert(TILE_OPS % 4 == 0 && TILE_OPS >= 8 && TILE_OPS <= 64, "tile size");
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 
+// One 128-byte line per tile: a 16-byte header {T0, Q0, sumT, sumQ} -- the sums of
+// target_delta / |query_delta| of the record's ops before the tile and inside it --
+// followed by 28 packed ops.  A tile is self-describing: the running positions at
+// either end follow from its own line.
+constexpr uint32_t TILE_WORDS = 32;
+constexpr uint32_t TILE_OPS = 28;
+constexpr uint32_t INLINE_TILES = 8;      // entries of records with <= 8 tiles carry their checkpoints inline
+
 // ---- device index (HBM layout) ---------------------------------------------
-// One 32-byte payload per index entry, stored in per-target start order.
+// One 64-byte payload per index entry, stored in per-target start order.
 struct alignas(16) Entry {
   int32_t ts, te, qs, qe;  // target_start/end, query_start/end of the ENTRY (already swapped for reversed entries)
   uint32_t query_id;
   uint32_t tile_base;      // first tile of the record's ops in the op pool
   uint32_t nops_flags;     // bits 0..28 n_ops, bit 30 = strand reverse, bit 31 = reversed entry (REVERSED_BIT)
-  uint32_t cp_base;        // first checkpoint of the record (= tile_base + record rank)
+  uint32_t totT;           // sum of target_delta over the record, in the entry's axes
+  uint32_t totQ;           // sum of |query_delta|
+  // target prefix at the start of effective tile k, k = 1..7 (effective = the
+  // order in which THIS entry walks the record); tiles > 8: tcp[0] = offset of
+  // the entry's m+1 prefixes in the external checkpoint array
+  uint32_t tcp[7];
 };
-static_assert(sizeof(Entry) == 32, "entry payload is 32 bytes");
+static_assert(sizeof(Entry) == 64, "entry payload is 64 bytes");
 constexpr uint32_t EF_STRAND = 1u << 30;
 constexpr uint32_t EF_REVERSED = 1u << 31;
 
+// per-target segment + its search levels (64-ary, B+tree style): level k holds
+// the last element of every 64-block of level k-1 (level 0 = the entry columns)
+constexpr int MAX_LEVELS = 4;
+struct SegDesc {
+  uint32_t a, n;                 // segment [a, a+n) of the entry arrays
+  uint32_t nlev;                 // number of sampled levels above the leaves
+  uint32_t off[MAX_LEVELS];      // offset of level k (1-based: off[k-1]) in the level arrays
+  uint32_t cnt[MAX_LEVELS];
+  uint32_t pad;
+};
+static_assert(sizeof(SegDesc) == 48, "segment descriptor");
+
 struct DeviceIndexView {  // passed by value to kernels
-  const uint32_t *tgt_off;   // [n_seq+1] per-target segment table (replaces ForestMap)
+  const SegDesc *seg;        // [n_seq] per-target segment table (replaces ForestMap)
   const int32_t *starts;     // [n_entries] t_start, ascending within a segment
   const int32_t *ends;       // [n_entries] t_end
   const int32_t *pmax;       // [n_entries] running max of t_end within the segment
+  const int32_t *starts_lvl; // sampled levels of starts / pmax (same offsets)
+  const int32_t *pmax_lvl;
   const uint32_t *rank;      // [n_entries] visit rank within the segment (order policy)
   const Entry *entries;      // [n_entries]
-  const uint32_t *ops;       // [n_tiles*32] packed ops, each record padded to whole tiles
-  const uint2 *cp;           // [n_tiles + n_records] per-tile prefix (sum target_delta, sum |query_delta|), +1 total per record
+  const uint32_t *ops;       // [n_tiles*32] tiles
+  const uint32_t *ext_cp;    // effective target prefixes of entries with > 8 tiles
   const int32_t *seq_len;    // [n_seq]
   uint32_t n_seq;
   uint32_t n_entries;
@@ -113,7 +135,7 @@ struct impg_gpu_index {
   impg::HostSeqIndex seq;
   size_t n_records = 0, n_entries = 0, n_tiles = 0, n_targets = 0;
   std::vector<uint32_t> h_tgt_off;
-  impg::DevBuf d_tgt_off, d_starts, d_ends, d_pmax, d_rank, d_entries, d_ops, d_cp, d_seq_len;
+  impg::DevBuf d_seg, d_starts, d_ends, d_pmax, d_starts_lvl, d_pmax_lvl, d_rank, d_entries, d_ops, d_ext_cp, d_seq_len;
   impg::DeviceIndexView view{};
   size_t device_bytes = 0;
   impg::Engine *engine = nullptr;  // scratch + streams (engine.cpp)

@@ -103,69 +103,161 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     }
   }
 
-  // ---- op pool in 32-op tiles + per-tile prefix checkpoints -------------------
-  std::vector<uint32_t> tile_base(n_records, 0), cp_base(n_records, 0);
-  uint64_t n_tiles = 0, n_need = 0;
+  // ---- op pool: 128-byte tiles {T0,Q0,sumT,sumQ | 28 ops} ------------------------
+  std::vector<uint32_t> tile_base(n_records, 0);
+  std::vector<uint32_t> rec_totT(n_records, 0), rec_totQ(n_records, 0);
+  uint64_t n_tiles = 0;
   for (size_t i = 0; i < n_records; i++) {
     if (!need[i]) continue;
     tile_base[i] = (uint32_t)n_tiles;
-    cp_base[i] = (uint32_t)(n_tiles + n_need);
     n_tiles += (records[i].cigar_len + TILE_OPS - 1) / TILE_OPS;
-    n_need++;
-    if (n_tiles + n_need >= (1ull << 32)) throw Error{IMPG_E_UNSUPPORTED, "op pool exceeds 2^32 tiles"};
+    if (n_tiles >= (1ull << 32) - 2) throw Error{IMPG_E_UNSUPPORTED, "op pool exceeds 2^32 tiles"};
   }
-  std::vector<uint32_t> pool(n_tiles * TILE_OPS, OP_PAD);
-  std::vector<uint2> cp(n_tiles + n_need);
+  std::vector<uint32_t> pool(n_tiles * TILE_WORDS, OP_PAD);
   std::atomic<bool> bad_op{false};
   parallel_chunks(n_records, [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; i++) {
       if (!need[i]) continue;
       const uint32_t *src = cigar_ops + records[i].cigar_off;
-      uint32_t n = records[i].cigar_len;
-      uint32_t *dst = pool.data() + (size_t)tile_base[i] * TILE_OPS;
-      uint2 *c = cp.data() + cp_base[i];
+      const uint32_t n = records[i].cigar_len;
       uint32_t st = 0, sq = 0;
-      for (uint32_t k = 0; k < n; k++) {
-        if (k % TILE_OPS == 0) c[k / TILE_OPS] = make_uint2(st, sq);
-        uint32_t v = src[k], code = v >> 29, len = v & OP_LEN_MASK;
-        if (code > 4) bad_op = true;  // CigarOp::new panics (impg.rs:88)
-        dst[k] = v;
-        if (code != 2) st += len;  // target_delta: all but 'I' (impg.rs:115-121)
-        if (code != 3) sq += len;  // |query_delta|: all but 'D' (impg.rs:123-135)
+      for (uint32_t k0 = 0; k0 < n; k0 += TILE_OPS) {
+        uint32_t *line = pool.data() + ((size_t)tile_base[i] + k0 / TILE_OPS) * TILE_WORDS;
+        uint32_t t0 = st, q0 = sq;
+        for (uint32_t k = k0; k < std::min(n, k0 + TILE_OPS); k++) {
+          uint32_t v = src[k], code = v >> 29, len = v & OP_LEN_MASK;
+          if (code > 4) bad_op = true;  // CigarOp::new panics (impg.rs:88)
+          line[4 + (k - k0)] = v;
+          if (code != 2) st += len;  // target_delta: all but 'I' (impg.rs:115-121)
+          if (code != 3) sq += len;  // |query_delta|: all but 'D' (impg.rs:123-135)
+        }
+        line[0] = t0; line[1] = q0; line[2] = st - t0; line[3] = sq - q0;
       }
-      c[(n + TILE_OPS - 1) / TILE_OPS] = make_uint2(st, sq);  // record totals
+      rec_totT[i] = st;
+      rec_totQ[i] = sq;
     }
   });
   if (bad_op) throw Error{IMPG_E_INVALID, "Invalid CIGAR operation"};
 
   // ---- entries, grouped by key in input order (impg.rs:1559-1623) --------------
-  ix.h_tgt_off.assign(n_seq + 1, 0);
-  for (uint32_t s = 0; s < n_seq; s++) ix.h_tgt_off[s + 1] = ix.h_tgt_off[s] + seg_count[s];
-  size_t n_entries = ix.h_tgt_off[n_seq];
+  std::vector<uint32_t> tgt_off(n_seq + 1, 0);
+  for (uint32_t s = 0; s < n_seq; s++) tgt_off[s + 1] = tgt_off[s] + seg_count[s];
+  ix.h_tgt_off = tgt_off;
+  size_t n_entries = tgt_off[n_seq];
   if (n_entries >= (1ull << 32) - 1) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 entries"};
   std::vector<Entry> ent(n_entries);
+  std::vector<uint32_t> ent_rec(n_entries);  // record of each entry (for the checkpoints below)
   {
-    std::vector<uint32_t> cur(ix.h_tgt_off.begin(), ix.h_tgt_off.end() - 1);
+    std::vector<uint32_t> cur(tgt_off.begin(), tgt_off.end() - 1);
     for (size_t i = 0; i < n_records; i++) {
       const auto &r = records[i];
       uint32_t fl = (r.cigar_len & OP_LEN_MASK) | (r.strand ? EF_STRAND : 0);
       if (owned(r.target_id)) {
-        Entry e{r.target_start, r.target_end, r.query_start, r.query_end, r.query_id, tile_base[i], fl, cp_base[i]};
+        Entry e{};
+        e.ts = r.target_start; e.te = r.target_end; e.qs = r.query_start; e.qe = r.query_end;
+        e.query_id = r.query_id; e.tile_base = tile_base[i]; e.nops_flags = fl;
+        e.totT = rec_totT[i]; e.totQ = rec_totQ[i];
+        ent_rec[cur[r.target_id]] = (uint32_t)i;
         ent[cur[r.target_id]++] = e;
       }
       if (bidirectional && r.query_id != r.target_id && owned(r.query_id)) {
-        Entry e{r.query_start, r.query_end, r.target_start, r.target_end, r.target_id, tile_base[i],
-                fl | EF_REVERSED, cp_base[i]};
+        Entry e{};
+        e.ts = r.query_start; e.te = r.query_end; e.qs = r.target_start; e.qe = r.target_end;
+        e.query_id = r.target_id; e.tile_base = tile_base[i]; e.nops_flags = fl | EF_REVERSED;
+        e.totT = rec_totQ[i]; e.totQ = rec_totT[i];  // axes swapped (impg.rs:1585-1590)
+        ent_rec[cur[r.query_id]] = (uint32_t)i;
         ent[cur[r.query_id]++] = e;
       }
     }
   }
-  // per segment: stable sort by start (coitrees sorts by `first` only), then
-  // SoA columns, running max of end, visit rank
+  // per segment: stable sort by start (coitrees sorts by `first` only)
+  {
+    std::vector<uint32_t> perm(n_entries);
+    for (size_t i = 0; i < n_entries; i++) perm[i] = (uint32_t)i;
+    std::atomic<uint32_t> next{0};
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, n_seq));
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; t++)
+      th.emplace_back([&]() {
+        for (;;) {
+          uint32_t s = next.fetch_add(1);
+          if (s >= n_seq) break;
+          std::stable_sort(perm.begin() + tgt_off[s], perm.begin() + tgt_off[s + 1],
+                           [&](uint32_t x, uint32_t y) { return ent[x].ts < ent[y].ts; });
+        }
+      });
+    for (auto &x : th) x.join();
+    std::vector<Entry> e2(n_entries);
+    std::vector<uint32_t> r2(n_entries);
+    parallel_chunks(n_entries, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; i++) { e2[i] = ent[perm[i]]; r2[i] = ent_rec[perm[i]]; }
+    });
+    ent.swap(e2);
+    ent_rec.swap(r2);
+  }
+  // effective-order target checkpoints of every entry: prefix at the start of
+  // effective tile k.  Forward walk: the tile's own T0 (or Q0 for a reversed
+  // entry); back-to-front walk (reversed entry on the reverse strand): total
+  // minus the prefix at the END of the mirrored tile.
+  std::vector<uint32_t> ext_cp;
+  {
+    std::vector<uint64_t> ext_off(n_entries + 1, 0);
+    for (size_t i = 0; i < n_entries; i++) {
+      uint32_t n = ent[i].nops_flags & OP_LEN_MASK, m = (n + TILE_OPS - 1) / TILE_OPS;
+      ext_off[i + 1] = ext_off[i] + (m > INLINE_TILES ? m + 1 : 0);
+    }
+    if (ext_off[n_entries] >= (1ull << 32)) throw Error{IMPG_E_UNSUPPORTED, "external checkpoint array exceeds 2^32"};
+    ext_cp.assign(ext_off[n_entries], 0);
+    parallel_chunks(n_entries, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; i++) {
+        Entry &e = ent[i];
+        const uint32_t n = e.nops_flags & OP_LEN_MASK, m = (n + TILE_OPS - 1) / TILE_OPS;
+        const bool swp = (e.nops_flags & EF_REVERSED) != 0, flip = swp && (e.nops_flags & EF_STRAND);
+        const uint32_t *base = pool.data() + (size_t)e.tile_base * TILE_WORDS;
+        auto pre = [&](uint32_t k) -> uint32_t {  // effective target prefix at the start of effective tile k (k <= m)
+          if (k == 0) return 0;
+          if (k >= m) return e.totT;
+          if (!flip) return base[(size_t)k * TILE_WORDS + (swp ? 1 : 0)];
+          const uint32_t *line = base + (size_t)(m - k) * TILE_WORDS;  // effective tile k-1 is original tile m-k
+          return e.totT - line[swp ? 1 : 0];
+        };
+        if (m <= INLINE_TILES) {
+          for (uint32_t k = 1; k < m; k++) e.tcp[k - 1] = pre(k);
+        } else {
+          e.tcp[0] = (uint32_t)ext_off[i];
+          for (uint32_t k = 0; k <= m; k++) ext_cp[ext_off[i] + k] = pre(k);
+        }
+      }
+    });
+  }
+  // SoA columns, running max of end, visit rank, search levels
   std::vector<int32_t> starts(n_entries), ends(n_entries), pmax(n_entries);
   std::vector<uint32_t> rank(n_entries);
+  std::vector<SegDesc> seg(n_seq);
+  std::vector<int32_t> starts_lvl, pmax_lvl;
   size_t n_targets = 0;
-  for (uint32_t s = 0; s < n_seq; s++) n_targets += seg_count[s] != 0;
+  for (uint32_t s = 0; s < n_seq; s++) {
+    n_targets += seg_count[s] != 0;
+    SegDesc d{};
+    d.a = tgt_off[s];
+    d.n = tgt_off[s + 1] - tgt_off[s];
+    uint32_t cnt = d.n, lev = 0;
+    uint64_t off = starts_lvl.size();
+    while (cnt > 64) {
+      if (lev == MAX_LEVELS) throw Error{IMPG_E_UNSUPPORTED, "more than 64^5 entries on one target"};
+      cnt = (cnt + 63) / 64;
+      d.off[lev] = (uint32_t)off;
+      d.cnt[lev] = cnt;
+      off += cnt;
+      lev++;
+    }
+    d.nlev = lev;
+    if (off >= (1ull << 32)) throw Error{IMPG_E_UNSUPPORTED, "search levels exceed 2^32"};
+    starts_lvl.resize(off);
+    pmax_lvl.resize(off);
+    seg[s] = d;
+  }
   {
     std::atomic<uint32_t> next{0};
     unsigned hw = std::thread::hardware_concurrency();
@@ -176,9 +268,9 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
         for (;;) {
           uint32_t s = next.fetch_add(1);
           if (s >= n_seq) break;
-          uint32_t a = ix.h_tgt_off[s], b = ix.h_tgt_off[s + 1];
+          const SegDesc &d = seg[s];
+          uint32_t a = d.a, b = d.a + d.n;
           if (a == b) continue;
-          std::stable_sort(ent.begin() + a, ent.begin() + b, [](const Entry &x, const Entry &y) { return x.ts < y.ts; });
           int32_t m = INT32_MIN;
           for (uint32_t i = a; i < b; i++) {
             starts[i] = ent[i].ts;
@@ -188,6 +280,18 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
           }
           if (order_policy == IMPG_ORDER_COITREES) coitrees_visit_rank(b - a, rank.data() + a);
           else for (uint32_t i = a; i < b; i++) rank[i] = i - a;
+          // level k = last element of every 64-block of level k-1
+          const int32_t *ps = starts.data() + a, *pp = pmax.data() + a;
+          uint32_t pn = d.n;
+          for (uint32_t k = 0; k < d.nlev; k++) {
+            int32_t *ls = starts_lvl.data() + d.off[k], *lp = pmax_lvl.data() + d.off[k];
+            for (uint32_t j = 0; j < d.cnt[k]; j++) {
+              uint32_t last = std::min(pn, 64 * (j + 1)) - 1;
+              ls[j] = ps[last];
+              lp[j] = pp[last];
+            }
+            ps = ls; pp = lp; pn = d.cnt[k];
+          }
         }
       });
     for (auto &x : th) x.join();
@@ -198,27 +302,31 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   std::vector<int32_t> sl(n_seq);
   for (uint32_t s = 0; s < n_seq; s++) sl[s] = (int32_t)std::min<int64_t>(std::max<int64_t>(seq_len[s], 0), INT32_MAX);
   size_t acc = 0;
-  upload(ix.d_tgt_off, ix.h_tgt_off, acc);
+  upload(ix.d_seg, seg, acc);
   upload(ix.d_starts, starts, acc);
   upload(ix.d_ends, ends, acc);
   upload(ix.d_pmax, pmax, acc);
+  upload(ix.d_starts_lvl, starts_lvl, acc);
+  upload(ix.d_pmax_lvl, pmax_lvl, acc);
   upload(ix.d_rank, rank, acc);
   upload(ix.d_entries, ent, acc);
   upload(ix.d_ops, pool, acc);
-  upload(ix.d_cp, cp, acc);
+  upload(ix.d_ext_cp, ext_cp, acc);
   upload(ix.d_seq_len, sl, acc);
   ix.device_bytes = acc;
   ix.n_entries = n_entries;
   ix.n_tiles = n_tiles;
   ix.n_targets = n_targets;
-  ix.view.tgt_off = ix.d_tgt_off.as<uint32_t>();
+  ix.view.seg = ix.d_seg.as<SegDesc>();
   ix.view.starts = ix.d_starts.as<int32_t>();
   ix.view.ends = ix.d_ends.as<int32_t>();
   ix.view.pmax = ix.d_pmax.as<int32_t>();
+  ix.view.starts_lvl = ix.d_starts_lvl.as<int32_t>();
+  ix.view.pmax_lvl = ix.d_pmax_lvl.as<int32_t>();
   ix.view.rank = ix.d_rank.as<uint32_t>();
   ix.view.entries = ix.d_entries.as<Entry>();
   ix.view.ops = ix.d_ops.as<uint32_t>();
-  ix.view.cp = ix.d_cp.as<uint2>();
+  ix.view.ext_cp = ix.d_ext_cp.as<uint32_t>();
   ix.view.seq_len = ix.d_seq_len.as<int32_t>();
   ix.view.n_seq = n_seq;
   ix.view.n_entries = (uint32_t)n_entries;

@@ -33,47 +33,50 @@ namespace impg {
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-// First index in [lo,hi) whose value satisfies pred (monotone false..true), hi if
-// none.  All 64 lanes cooperate: 64 evenly spaced probes per round.
+// First position in a segment whose value satisfies pred (monotone false..true),
+// d.n if none.  64-ary descent over the sampled levels: every level is ONE
+// coalesced read of (up to) 64 consecutive values -- level k holds the last
+// element of each 64-block of level k-1, so a block has a true element iff its
+// sample is true.  lvl = sampled levels, leaf = the full column.
 template <class Pred>
-__device__ __forceinline__ uint32_t wave_search(const int32_t *__restrict__ arr, uint32_t lo, uint32_t hi, Pred pred) {
+__device__ __forceinline__ uint32_t seg_search(const SegDesc &d, const int32_t *__restrict__ lvl,
+                                               const int32_t *__restrict__ leaf, Pred pred) {
   const unsigned lane = lane_id();
-  while (hi - lo > 64u) {
-    uint32_t step = (hi - lo + 63u) >> 6;
-    uint32_t idx = lo + (lane + 1u) * step - 1u;
-    bool p = idx < hi ? pred(arr[idx]) : true;
-    unsigned long long mask = __ballot(p);
-    // no probe true: every lane probed inside [lo,hi) and lane 63 probed hi-1
-    // (64*step >= hi-lo), so nothing in the range satisfies pred
-    if (mask == 0ull) return hi;
-    unsigned f = __ffsll((long long)mask) - 1;
-    uint32_t nlo = lo + f * step;
-    uint32_t nhi = lo + (f + 1u) * step - 1u;
-    hi = nhi < hi ? nhi : hi;
-    lo = nlo;
+  uint32_t blk = 0;
+  for (int k = (int)d.nlev - 1; k >= 0; k--) {
+    const uint32_t base = 64u * blk, cnt = d.cnt[k];
+    const uint32_t i = base + lane;
+    const bool p = i < cnt ? pred(lvl[d.off[k] + i]) : true;
+    const unsigned f = __ffsll((long long)__ballot(p)) - 1;  // lanes past the end are set: f < 64
+    if (base + f >= cnt) return d.n;  // no sample true: nothing below is
+    blk = base + f;
   }
-  uint32_t idx = lo + lane;
-  bool p = idx < hi ? pred(arr[idx]) : true;
-  unsigned f = __ffsll((long long)__ballot(p)) - 1;
-  uint32_t ans = lo + f;
-  return ans < hi ? ans : hi;
+  const uint32_t base = 64u * blk;
+  const uint32_t i = base + lane;
+  const bool p = i < d.n ? pred(leaf[d.a + i]) : true;
+  const unsigned f = __ffsll((long long)__ballot(p)) - 1;
+  const uint32_t ans = base + f;
+  return ans < d.n ? ans : d.n;
 }
 
-// candidate window of one frontier range inside its target's segment
+// candidate window of one frontier range inside its target's segment (absolute indices)
 template <bool TRANSITIVE>
 __device__ __forceinline__ void range_window(const DeviceIndexView &v, const FrontierRec &f, uint32_t &lo, uint32_t &ub) {
   lo = ub = 0;
   if (f.target_id >= v.n_seq) return;
-  uint32_t a = v.tgt_off[f.target_id], b = v.tgt_off[f.target_id + 1];
-  if (a == b) return;
+  const SegDesc d = v.seg[f.target_id];
+  if (d.n == 0) return;
   const int32_t qs = f.start, qe = f.end;
+  uint32_t u, l;
   if (TRANSITIVE) {  // max(cs,first) < min(ce,last)   (impg.rs:2398-2403)
-    ub = wave_search(v.starts, a, b, [=](int32_t s) { return s >= qe; });
-    lo = wave_search(v.pmax, a, ub, [=](int32_t m) { return m > qs; });
+    u = seg_search(d, v.starts_lvl, v.starts, [=](int32_t s) { return s >= qe; });
+    l = seg_search(d, v.pmax_lvl, v.pmax, [=](int32_t m) { return m > qs; });
   } else {  // coitrees closed test: first <= q_last && last >= q_first
-    ub = wave_search(v.starts, a, b, [=](int32_t s) { return s > qe; });
-    lo = wave_search(v.pmax, a, ub, [=](int32_t m) { return m >= qs; });
+    u = seg_search(d, v.starts_lvl, v.starts, [=](int32_t s) { return s > qe; });
+    l = seg_search(d, v.pmax_lvl, v.pmax, [=](int32_t m) { return m >= qs; });
   }
+  ub = d.a + u;
+  lo = d.a + (l < u ? l : u);
 }
 template <bool TRANSITIVE>
 __device__ __forceinline__ bool overlaps(int32_t ts, int32_t te, int32_t qs, int32_t qe) {
@@ -127,7 +130,6 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
     if (lo >= ub) continue;
     FrontierRec f = fr[r];
     const uint32_t off = pair_off[r];
-    const uint32_t seg = v.tgt_off[f.target_id];
     if (v.sorted_order) {  // visit order == segment order: plain stream compaction
       uint32_t run = 0;
       for (uint32_t base = lo; base < ub; base += 64u) {
@@ -172,7 +174,6 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
         pair_entry[off + pos] = i;
       }
     }
-    (void)seg;
   }
 }
 
@@ -283,27 +284,27 @@ size_t scan_scratch_bytes(uint32_t n) { return ((size_t)(n + SCAN_TILE - 1) / SC
 // ---------------------------------------------------------------------------
 struct TileScan {
   bool found;
-  int32_t pqs, pts, pqe, pte;  // query values are direction-normalised (x dir) until the end
+  int32_t pqs, pts, pqe, pte;  // query values are direction-normalised offsets from qbase until the end
 };
 
 struct PairCtx {
-  int32_t ts, qbase, R0, R1, last_tp, dir;
+  int32_t ts, R0, R1, last_tp;
   bool swp, flip;
   uint32_t zt, zq;       // op code with zero target delta / zero query delta in the entry's view
   uint32_t m;            // number of tiles
   uint32_t totT, totQ;   // record totals in the entry's (effective) axes
-  const uint2 *cp;       // checkpoints of the record, cp[0..m]
-  const uint32_t *ops;   // first tile of the record
+  const uint32_t *ops;   // first tile line of the record
 };
 
 // Exact per-op step of project_target_range_through_alignment (impg.rs:2800-2869)
 // on the effective view of an entry.  T = running target position, Qn = running
-// query position times dir (so it only ever grows).  Positions never decrease,
-// so "target_pos > last_target_pos => break" (impg.rs:2802) is a per-op test.
-//   arm 1 (target_delta == 0):  passes iff T >= R0;            first = (Q, T)       last = (Q+qd, T)
-//   arm 2 (query_delta == 0):   passes iff max(T,R0) < min(T+td,last_tp);  first = (Q, os)  last = (Q, oe)
-//   arm 3:                      passes iff max(T,R0) < min(T+td,R1);  first = (Q+(os-T), os)  last = (Q+(oe-T), oe)
-// When arm 1 passes, os == T and min(T, lim) == T, so "os"/"oe" serve all arms.
+// query offset from the entry's query base in units of dir (so it only grows).
+// Positions never decrease, so "target_pos > last_target_pos => break"
+// (impg.rs:2802) is a per-op test.
+//   arm 1 (target_delta == 0):  passes iff T >= R0;                          first (Q, T)       last (Q+qd, T)
+//   arm 2 (query_delta == 0):   passes iff max(T,R0) < min(T+td,last_tp);    first (Q, os)      last (Q, oe)
+//   arm 3:                      passes iff max(T,R0) < min(T+td,R1);         first (Q+os-T, os) last (Q+oe-T, oe)
+// When arm 1 passes, os == T and min(T, lim) == T, so os / oe serve all arms.
 __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &T, int32_t &Qn, TileScan &s) {
   const bool valid = op != OP_PAD;
   const uint32_t code = op >> 29;
@@ -329,30 +330,27 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
   Qn += qa;
 }
 
-__device__ __forceinline__ uint32_t cpT(const PairCtx &c, uint32_t j) { uint2 x = c.cp[j]; return c.swp ? x.y : x.x; }
-
-// running positions at the effective start of original tile j
-__device__ __forceinline__ void tile_start(const PairCtx &c, uint32_t j, int32_t &T, int32_t &Qn) {
-  const uint2 x = c.cp[c.flip ? j + 1 : j];
-  const uint32_t t = c.swp ? x.y : x.x, q = c.swp ? x.x : x.y;
-  T = c.ts + (int32_t)(c.flip ? c.totT - t : t);
-  Qn = (int32_t)(c.flip ? c.totQ - q : q);  // offset from qbase, in units of dir
+// running positions at the effective start of original tile j, from the tile's own header
+__device__ __forceinline__ void tile_start(const PairCtx &c, const uint4 hdr, int32_t &T, int32_t &Qn) {
+  const uint32_t t0 = c.swp ? hdr.y : hdr.x, q0 = c.swp ? hdr.x : hdr.y;
+  const uint32_t st = c.swp ? hdr.w : hdr.z, sq = c.swp ? hdr.z : hdr.w;
+  T = c.ts + (int32_t)(c.flip ? c.totT - (t0 + st) : t0);
+  Qn = (int32_t)(c.flip ? c.totQ - (q0 + sq) : q0);
 }
 
-constexpr int TILE_VEC = TILE_OPS / 4;
-// Scan one tile in effective order, streaming it 16 bytes (4 ops) at a time with
-// the next vector in flight.  Reverse-strand reversed entries walk the tile back
-// to front: descending vector index and reversed components.  `first` is the
-// tile's first vector, already loaded by the caller so that both tiles' HBM
-// misses overlap.
-__device__ __forceinline__ void scan_tile(const PairCtx &c, uint32_t j, uint4 cur, TileScan &s) {
+constexpr int TILE_DVEC = TILE_OPS / 4;  // 7 data vectors after the header vector
+// Scan one tile in effective order, streaming its line 16 bytes (4 ops) at a time
+// with the next vector in flight.  Reverse-strand reversed entries walk the tile
+// back to front: descending vector index and reversed components.
+__device__ __forceinline__ void scan_tile(const PairCtx &c, uint32_t j, const uint4 hdr, TileScan &s) {
   int32_t T, Qn;
-  tile_start(c, j, T, Qn);
-  const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)j * TILE_OPS);
+  tile_start(c, hdr, T, Qn);
+  const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)j * TILE_WORDS);
+  uint4 cur = q[c.flip ? TILE_DVEC : 1];
 #pragma unroll 1
-  for (int k = 0; k < TILE_VEC; k++) {
+  for (int k = 0; k < TILE_DVEC; k++) {
     uint4 nxt = cur;
-    if (k + 1 < TILE_VEC) nxt = q[c.flip ? TILE_VEC - 2 - k : k + 1];
+    if (k + 1 < TILE_DVEC) nxt = q[c.flip ? TILE_DVEC - 1 - k : k + 2];
     op_step(c.flip ? cur.w : cur.x, c, T, Qn, s);
     op_step(c.flip ? cur.z : cur.y, c, T, Qn, s);
     op_step(c.flip ? cur.y : cur.z, c, T, Qn, s);
@@ -360,9 +358,8 @@ __device__ __forceinline__ void scan_tile(const PairCtx &c, uint32_t j, uint4 cu
     cur = nxt;
   }
 }
-__device__ __forceinline__ uint4 tile_first_vec(const PairCtx &c, uint32_t j) {
-  const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)j * TILE_OPS);
-  return q[c.flip ? TILE_VEC - 1 : 0];
+__device__ __forceinline__ uint4 tile_header(const PairCtx &c, uint32_t j) {
+  return *reinterpret_cast<const uint4 *>(c.ops + (size_t)j * TILE_WORDS);
 }
 
 // literal walk over tiles A..B in effective order, one op at a time (rare path)
@@ -371,10 +368,10 @@ __device__ __noinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32
   s.found = false;
   s.pqs = s.pts = s.pqe = s.pte = -1;
   int32_t T, Qn;
-  tile_start(c, A, T, Qn);
+  tile_start(c, tile_header(c, A), T, Qn);
   const int stepj = c.flip ? -1 : 1;
   for (int64_t j = A;; j += stepj) {
-    const uint32_t *tp = c.ops + (size_t)j * TILE_OPS;
+    const uint32_t *tp = c.ops + (size_t)j * TILE_WORDS + 4;
     for (int u = 0; u < (int)TILE_OPS && T <= c.last_tp; u++) {
       uint32_t op = tp[c.flip ? (int)TILE_OPS - 1 - u : u];
       op_step(op, c, T, Qn, s);
@@ -399,33 +396,34 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
   if (p < n_pairs) {
     const uint32_t r = pair_range[p];
     const FrontierRec f = fr[r];
-    const Entry en = v.entries[pair_entry[p]];
-    const uint32_t n = en.nops_flags & OP_LEN_MASK;
-    const bool rev = (en.nops_flags & EF_STRAND) != 0;
+    // the 64-byte entry: coordinates, record totals and its inline checkpoints
+    const uint4 *ep = reinterpret_cast<const uint4 *>(v.entries + pair_entry[p]);
+    const uint4 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
+    const int32_t en_ts = (int32_t)e0.x, en_te = (int32_t)e0.y, en_qs = (int32_t)e0.z, en_qe = (int32_t)e0.w;
+    const uint32_t nops_flags = e1.z;
+    const uint32_t n = nops_flags & OP_LEN_MASK;
+    const bool rev = (nops_flags & EF_STRAND) != 0;
     PairCtx c;
-    c.swp = (en.nops_flags & EF_REVERSED) != 0;
+    c.swp = (nops_flags & EF_REVERSED) != 0;
     c.flip = c.swp && rev;
-    c.dir = rev ? -1 : 1;
     c.zt = c.swp ? 3u : 2u;  // 'I' consumes no target; for a reversed entry 'D' does (impg.rs:146-151)
     c.zq = c.swp ? 2u : 3u;
-    c.ts = en.ts;
-    c.qbase = rev ? en.qe : en.qs;  // impg.rs:2778-2782
+    c.ts = en_ts;
+    const int32_t qbase = rev ? en_qe : en_qs;  // impg.rs:2778-2782
     c.R0 = f.start;
     c.R1 = f.end;
     if (TRANSITIVE) {  // project the clipped overlap (impg.rs:2398-2400)
-      c.R0 = max(c.R0, en.ts);
-      c.R1 = min(c.R1, en.te);
+      c.R0 = max(c.R0, en_ts);
+      c.R1 = min(c.R1, en_te);
     }
-    c.last_tp = min(en.te, c.R1);  // impg.rs:2798
+    c.last_tp = min(en_te, c.R1);  // impg.rs:2798
     c.m = (n + TILE_OPS - 1) / TILE_OPS;
-    c.cp = v.cp + en.cp_base;
-    c.ops = v.ops + (size_t)en.tile_base * TILE_OPS;
+    c.totT = e1.w;
+    c.totQ = e2.x;
+    c.ops = v.ops + (size_t)e1.y * TILE_WORDS;
     if (n == 0) {
       atomicOr(err_flag, 1u);  // record without cg:Z (the reference panics, impg.rs:506-511)
     } else {
-      const uint2 tot = c.cp[c.m];
-      c.totT = c.swp ? tot.y : tot.x;
-      c.totQ = c.swp ? tot.x : tot.y;
       // Shortcuts that need no CIGAR bytes (exact):
       //  * the range reaches back to the alignment start: op 0 is the first
       //    overlapping op whatever its type, at (query offset 0, target ts);
@@ -433,79 +431,77 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
       //    the PAF coordinates: the final op is the last overlapping op, ending at
       //    (query offset totQ, target te).
       const bool start_cov = c.R0 <= c.ts && c.last_tp > c.ts;
-      const bool end_cov = c.R1 >= en.te && c.R0 < en.te && (int32_t)c.totT == en.te - c.ts;
-      // tile A holds the first op whose inclusive target prefix reaches R0; tile B
-      // the last op whose exclusive prefix is <= last_tp.  cpT is nondecreasing.
-      //   LB(x) = first i in [1,m] with cpT[i] >= x (m+1 if none)
-      //   UB(x) = first i in [0,m) with cpT[i] >  x (m if none)
-      const int32_t xa = c.flip ? (int32_t)c.totT + c.ts - c.R0 : c.R0 - c.ts;
-      const int32_t xb = c.flip ? (int32_t)c.totT + c.ts - c.last_tp : c.last_tp - c.ts;
-      const int32_t xlb = c.flip ? xb : xa, xub = c.flip ? xa : xb;
-      // the LB search serves A (forward) or B (flip); the UB search the other one
-      const bool need_lb = c.flip ? !end_cov : !start_cov;
-      const bool need_ub = c.flip ? !start_cov : !end_cov;
-      uint32_t lb = c.flip ? 1 : 1, ubv = c.flip ? c.m : c.m;  // covered ends: first / last effective tile
-      if (need_lb) {
+      const bool end_cov = c.R1 >= en_te && c.R0 < en_te && (int32_t)c.totT == en_te - c.ts;
+      // Effective tile k (k-th tile in this entry's walking order) starts at target
+      // prefix P[k]: P[0] = 0, P[m] = totT, P[1..m-1] inline (m <= 8) or external.
+      //   A = first k with P[k+1] >= R0 - ts        (holds the first op that can overlap)
+      //   B = last  k with P[k]   <= last_tp - ts   (holds the last live op)
+      const int32_t xa = c.R0 - c.ts, xb = c.last_tp - c.ts;
+      uint32_t cA = 0, cB = 0;  // cA = #{i in [1,m] : P[i] < xa}, cB = #{i in [0,m) : P[i] <= xb}
+      if (c.m <= INLINE_TILES) {
+        const uint32_t P[INLINE_TILES + 1] = {0u, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w, 0u};
+#pragma unroll
+        for (uint32_t i = 0; i <= INLINE_TILES; i++) {
+          const int32_t pv = (int32_t)(i == c.m ? c.totT : P[i]);
+          if (i >= 1) cA += (i <= c.m && pv < xa) ? 1u : 0u;
+          if (i < INLINE_TILES) cB += (i < c.m && pv <= xb) ? 1u : 0u;
+        }
+      } else {
+        const uint32_t *P = v.ext_cp + e2.y;  // P[0..m]
         uint32_t lo = 1, hi = c.m + 1;
-        while (lo < hi) {
+        while (lo < hi) {  // first i in [1,m] with P[i] >= xa
           uint32_t mid = (lo + hi) >> 1;
-          if ((int32_t)cpT(c, mid) >= xlb) hi = mid; else lo = mid + 1;
+          if ((int32_t)P[mid] >= xa) hi = mid; else lo = mid + 1;
         }
-        lb = lo;
-      }
-      if (need_ub) {
-        uint32_t lo = 0, hi = c.m;
-        while (lo < hi) {
+        cA = lo - 1;
+        lo = 0; hi = c.m;
+        while (lo < hi) {  // first i in [0,m) with P[i] > xb
           uint32_t mid = (lo + hi) >> 1;
-          if ((int32_t)cpT(c, mid) > xub) hi = mid; else lo = mid + 1;
+          if ((int32_t)P[mid] > xb) hi = mid; else lo = mid + 1;
         }
-        ubv = lo;
+        cB = lo;
       }
-      const bool haveLB = lb <= c.m, haveUB = ubv >= 1;
-      if (haveLB && haveUB) {
-        const uint32_t jl = lb - 1, ju = ubv - 1;
-        const uint32_t A = c.flip ? ju : jl, B = c.flip ? jl : ju;
-        const bool ordered = c.flip ? A >= B : A <= B;
-        if (ordered) {
-          uint4 va = make_uint4(OP_PAD, OP_PAD, OP_PAD, OP_PAD), vb = va;
-          if (!start_cov) va = tile_first_vec(c, A);
-          if (!end_cov && (start_cov || A != B)) vb = tile_first_vec(c, B);
-          TileScan sa, sb;
-          sa.found = sb.found = false;
-          sa.pqs = sa.pts = sa.pqe = sa.pte = -1;
-          sb = sa;
-          if (start_cov) {
-            sa.found = true;
-            sa.pqs = 0;
-            sa.pts = c.ts;
-          } else {
-            scan_tile(c, A, va, sa);
-          }
-          if (end_cov) {
-            sb.found = true;
-            sb.pqe = (int32_t)c.totQ;
-            sb.pte = en.te;
-          } else if (!start_cov && A == B) {
-            sb = sa;  // one tile holds both ends: its scan recorded the last overlapping op too
-          } else {
-            scan_tile(c, B, vb, sb);
-          }
-          if (sa.found && sb.found) {
-            res.found = true;
-            res.pqs = sa.pqs; res.pts = sa.pts;
-            res.pqe = sb.pqe; res.pte = sb.pte;
-          } else if (!start_cov && !end_cov && A == B) {
-            res.found = false;  // every overlapping op would lie in this tile
-          } else {
-            res = walk_tiles(c, A, B);
-          }
+      if (cA < c.m && cB >= 1 && cA <= cB - 1) {
+        const uint32_t kA = cA, kB = cB - 1;                       // effective tile indices
+        const uint32_t A = c.flip ? c.m - 1 - kA : kA, B = c.flip ? c.m - 1 - kB : kB;  // original tile indices
+        uint4 ha = make_uint4(0, 0, 0, 0), hb = ha;
+        if (!start_cov) ha = tile_header(c, A);
+        if (!end_cov && (start_cov || A != B)) hb = tile_header(c, B);  // both lines in flight before any scan
+        TileScan sa, sb;
+        sa.found = false;
+        sa.pqs = sa.pts = sa.pqe = sa.pte = -1;
+        sb = sa;
+        if (start_cov) {
+          sa.found = true;
+          sa.pqs = 0;
+          sa.pts = c.ts;
+        } else {
+          scan_tile(c, A, ha, sa);
+        }
+        if (end_cov) {
+          sb.found = true;
+          sb.pqe = (int32_t)c.totQ;
+          sb.pte = en_te;
+        } else if (!start_cov && A == B) {
+          sb = sa;  // one tile holds both ends: its scan recorded the last overlapping op too
+        } else {
+          scan_tile(c, B, hb, sb);
+        }
+        if (sa.found && sb.found) {
+          res.found = true;
+          res.pqs = sa.pqs; res.pts = sa.pts;
+          res.pqe = sb.pqe; res.pte = sb.pte;
+        } else if (!start_cov && !end_cov && A == B) {
+          res.found = false;  // every overlapping op would lie in this tile
+        } else {
+          res = walk_tiles(c, A, B);
         }
       }
       ok = res.found && res.pqs != res.pqe && res.pts != res.pte;  // impg.rs:2874-2877
-      if (ok) qid = en.query_id;
+      if (ok) qid = e1.x;
       // back from direction-normalised offsets to query coordinates
-      res.pqs = c.qbase + (rev ? -res.pqs : res.pqs);
-      res.pqe = c.qbase + (rev ? -res.pqe : res.pqe);
+      res.pqs = qbase + (rev ? -res.pqs : res.pqs);
+      res.pqe = qbase + (rev ? -res.pqe : res.pqe);
     }
     h.qid[p] = qid;
     if (ok) {

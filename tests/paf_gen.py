@@ -29,7 +29,9 @@ def random_paf(seed, n_records, n_seq=6, seq_len=20000, max_ops=150, weird=False
     names = ["s%d" % i for i in range(n_seq)]
     lines = []
     for _ in range(n_records):
-        n_ops = int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 96, int(rng.integers(1, max_ops + 1))]))
+        n_ops = int(rng.choice([1, 2, 3, 27, 28, 29, 31, 32, 33, 55, 56, 57, 63, 64, 65, 96, 223, 224, 225,
+                                int(rng.integers(1, max_ops + 1)), int(rng.integers(1, max_ops + 1))]))
+        n_ops = min(n_ops, max(max_ops, 3))
         ops = random_cigar(rng, n_ops, weird)
         td, qd = spans(ops)
         if td == 0 or qd == 0:

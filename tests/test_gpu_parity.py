@@ -225,3 +225,14 @@ def test_large_segments_search_edges(tmp_path, n):
         ranges.append((tid, s, s + int(rng.integers(1, 400))))
     assert_same(g, c, ranges)
     assert_same(g, c, ranges, transitive=True, max_depth=1, min_transitive_len=0)
+
+
+@pytest.mark.parametrize("seed,weird", [(31, False), (32, True), (33, True)])
+def test_long_cigars_external_checkpoints(tmp_path, seed, weird):
+    """Records with more than 8 tiles (> 224 ops): checkpoints live in the external array."""
+    text, names = random_paf(seed, 160, n_seq=4, seq_len=400000, max_ops=3000, weird=weird, inconsistent=(seed == 33),
+                             self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(seed, 150, 4, 400000, max_len=30000, min_len=1)
+    assert_same(g, c, ranges)
+    assert_same(g, c, ranges[:40], transitive=True, max_depth=2, min_transitive_len=50)

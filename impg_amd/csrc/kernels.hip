@@ -33,30 +33,40 @@ namespace impg {
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-// First position in a segment whose value satisfies pred (monotone false..true),
-// d.n if none.  64-ary descent over the sampled levels: every level is ONE
-// coalesced read of (up to) 64 consecutive values -- level k holds the last
-// element of each 64-block of level k-1, so a block has a true element iff its
-// sample is true.  lvl = sampled levels, leaf = the full column.
-template <class Pred>
-__device__ __forceinline__ uint32_t seg_search(const SegDesc &d, const int32_t *__restrict__ lvl,
-                                               const int32_t *__restrict__ leaf, Pred pred) {
+// Two searches at once over the same segment: first position whose start
+// satisfies ps and first position whose running-max satisfies pp (both monotone
+// false..true), d.n if none.  64-ary descent over the sampled levels: every level
+// is ONE coalesced read of up to 64 consecutive values per column -- level k
+// holds the last element of each 64-block of level k-1, so a block has a true
+// element iff its sample is true.  The two descents are independent, so their
+// loads are issued together (half the dependent round trips).
+template <class PredS, class PredP>
+__device__ __forceinline__ void seg_search2(const DeviceIndexView &v, const SegDesc &d, PredS ps, PredP pp,
+                                            uint32_t &rs, uint32_t &rp) {
   const unsigned lane = lane_id();
-  uint32_t blk = 0;
+  uint32_t bs = 0, bp = 0;
+  bool ds = false, dp = false;  // decided "none"
   for (int k = (int)d.nlev - 1; k >= 0; k--) {
-    const uint32_t base = 64u * blk, cnt = d.cnt[k];
-    const uint32_t i = base + lane;
-    const bool p = i < cnt ? pred(lvl[d.off[k] + i]) : true;
-    const unsigned f = __ffsll((long long)__ballot(p)) - 1;  // lanes past the end are set: f < 64
-    if (base + f >= cnt) return d.n;  // no sample true: nothing below is
-    blk = base + f;
+    const uint32_t cnt = d.cnt[k], off = d.off[k];
+    const uint32_t is = 64u * bs + lane, ip = 64u * bp + lane;
+    const int32_t vs = is < cnt ? v.starts_lvl[off + is] : 0;
+    const int32_t vp = ip < cnt ? v.pmax_lvl[off + ip] : 0;
+    const bool qs_ = is < cnt ? ps(vs) : true, qp_ = ip < cnt ? pp(vp) : true;
+    const unsigned fs = __ffsll((long long)__ballot(qs_)) - 1;  // lanes past the end are set: f < 64
+    const unsigned fp = __ffsll((long long)__ballot(qp_)) - 1;
+    if (64u * bs + fs >= cnt) ds = true;  // no sample true: nothing below is
+    if (64u * bp + fp >= cnt) dp = true;
+    bs = ds ? 0 : 64u * bs + fs;
+    bp = dp ? 0 : 64u * bp + fp;
   }
-  const uint32_t base = 64u * blk;
-  const uint32_t i = base + lane;
-  const bool p = i < d.n ? pred(leaf[d.a + i]) : true;
-  const unsigned f = __ffsll((long long)__ballot(p)) - 1;
-  const uint32_t ans = base + f;
-  return ans < d.n ? ans : d.n;
+  const uint32_t is = 64u * bs + lane, ip = 64u * bp + lane;
+  const int32_t vs = is < d.n ? v.starts[d.a + is] : 0;
+  const int32_t vp = ip < d.n ? v.pmax[d.a + ip] : 0;
+  const bool qs_ = is < d.n ? ps(vs) : true, qp_ = ip < d.n ? pp(vp) : true;
+  const uint32_t as = 64u * bs + (__ffsll((long long)__ballot(qs_)) - 1);
+  const uint32_t ap = 64u * bp + (__ffsll((long long)__ballot(qp_)) - 1);
+  rs = (ds || as >= d.n) ? d.n : as;
+  rp = (dp || ap >= d.n) ? d.n : ap;
 }
 
 // candidate window of one frontier range inside its target's segment (absolute indices)
@@ -68,13 +78,10 @@ __device__ __forceinline__ void range_window(const DeviceIndexView &v, const Fro
   if (d.n == 0) return;
   const int32_t qs = f.start, qe = f.end;
   uint32_t u, l;
-  if (TRANSITIVE) {  // max(cs,first) < min(ce,last)   (impg.rs:2398-2403)
-    u = seg_search(d, v.starts_lvl, v.starts, [=](int32_t s) { return s >= qe; });
-    l = seg_search(d, v.pmax_lvl, v.pmax, [=](int32_t m) { return m > qs; });
-  } else {  // coitrees closed test: first <= q_last && last >= q_first
-    u = seg_search(d, v.starts_lvl, v.starts, [=](int32_t s) { return s > qe; });
-    l = seg_search(d, v.pmax_lvl, v.pmax, [=](int32_t m) { return m >= qs; });
-  }
+  if (TRANSITIVE)  // max(cs,first) < min(ce,last)   (impg.rs:2398-2403)
+    seg_search2(v, d, [=](int32_t s) { return s >= qe; }, [=](int32_t m) { return m > qs; }, u, l);
+  else  // coitrees closed test: first <= q_last && last >= q_first
+    seg_search2(v, d, [=](int32_t s) { return s > qe; }, [=](int32_t m) { return m >= qs; }, u, l);
   ub = d.a + u;
   lo = d.a + (l < u ? l : u);
 }

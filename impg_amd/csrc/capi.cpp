@@ -434,7 +434,7 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
                      L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), E.stream);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
-                 E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), E.stream);
+                 E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), params->min_identity, E.stream);
   IMPG_HIP(hipEventRecord(e2, E.stream));
   launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
   IMPG_HIP(hipStreamSynchronize(E.stream));

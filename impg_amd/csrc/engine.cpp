@@ -97,7 +97,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   IMPG_HIP(hipEventRecord(e1, stream));
   HitArrays h = hit_arrays(L, L.n_pairs);
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
-                 acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), stream);
+                 acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity, stream);
   IMPG_HIP(hipEventRecord(e2, stream));
   timed.push_back({e0, e1, 0});
   timed.push_back({e1, e2, 1});
@@ -209,7 +209,6 @@ uint32_t Engine::begin_transitive(const DeviceIndexView &v, const impg_gpu_range
 
 void Engine::check_params(const impg_gpu_params_t &p) {
   if (p.dfs && p.transitive) throw Error{IMPG_E_UNSUPPORTED, "query_transitive_dfs is not built yet"};
-  if (!std::isnan(p.min_identity)) throw Error{IMPG_E_UNSUPPORTED, "min_gap_compressed_identity is not built yet"};
   if (p.store_cigar) throw Error{IMPG_E_UNSUPPORTED, "store_cigar (BEDPE/PAF output) is not built yet"};
   if (p.transitive && p.max_depth > 65535) throw Error{IMPG_E_INVALID, "max_depth is a u16 in the reference"};
 }
@@ -223,6 +222,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   check_params(p);
   IMPG_HIP(hipSetDevice(ix.device));
   split_ok = n > 1;
+  min_identity = p.min_identity;
   const DeviceIndexView &v = ix.view;
   ev_next = 0;
   timed.clear();

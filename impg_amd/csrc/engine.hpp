@@ -39,6 +39,7 @@ struct Engine {
   uint64_t pair_budget = 1ull << 28;  // candidate pairs per level kept in HBM at once
   uint32_t chunk_ranges = 0;          // ranges per chunk (0 = try the whole batch)
   bool split_ok = false;
+  double min_identity = __builtin_nan("");  // of the batch / stage call in flight
   uint32_t stage_n = 0;  // frontier size of the last stage_count call
 
   explicit Engine(int device);

@@ -81,6 +81,7 @@ struct DeviceIndexView {  // passed by value to kernels
   const Entry *entries;      // [n_entries]
   const uint32_t *ops;       // [n_tiles*32] tiles
   const uint32_t *ext_cp;    // effective target prefixes of entries with > 8 tiles
+  const uint4 *idp;          // [n_tiles] matched bases, mismatched bases, gap ops of the record before each tile
   const int32_t *seq_len;    // [n_seq]
   uint32_t n_seq;
   uint32_t n_entries;
@@ -135,7 +136,7 @@ struct impg_gpu_index {
   impg::HostSeqIndex seq;
   size_t n_records = 0, n_entries = 0, n_tiles = 0, n_targets = 0;
   std::vector<uint32_t> h_tgt_off;
-  impg::DevBuf d_seg, d_starts, d_ends, d_pmax, d_starts_lvl, d_pmax_lvl, d_rank, d_entries, d_ops, d_ext_cp, d_seq_len;
+  impg::DevBuf d_seg, d_starts, d_ends, d_pmax, d_starts_lvl, d_pmax_lvl, d_rank, d_entries, d_ops, d_ext_cp, d_idp, d_seq_len;
   impg::DeviceIndexView view{};
   size_t device_bytes = 0;
   impg::Engine *engine = nullptr;  // scratch + streams (engine.cpp)

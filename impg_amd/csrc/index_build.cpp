@@ -114,15 +114,17 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     if (n_tiles >= (1ull << 32) - 2) throw Error{IMPG_E_UNSUPPORTED, "op pool exceeds 2^32 tiles"};
   }
   std::vector<uint32_t> pool(n_tiles * TILE_WORDS, OP_PAD);
+  std::vector<uint4> idp(n_tiles);  // per tile: matched / mismatched bases and gap ops before it (identity filter)
   std::atomic<bool> bad_op{false};
   parallel_chunks(n_records, [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; i++) {
       if (!need[i]) continue;
       const uint32_t *src = cigar_ops + records[i].cigar_off;
       const uint32_t n = records[i].cigar_len;
-      uint32_t st = 0, sq = 0;
+      uint32_t st = 0, sq = 0, sm = 0, sx = 0, sg = 0;
       for (uint32_t k0 = 0; k0 < n; k0 += TILE_OPS) {
         uint32_t *line = pool.data() + ((size_t)tile_base[i] + k0 / TILE_OPS) * TILE_WORDS;
+        idp[(size_t)tile_base[i] + k0 / TILE_OPS] = make_uint4(sm, sx, sg, 0);
         uint32_t t0 = st, q0 = sq;
         for (uint32_t k = k0; k < std::min(n, k0 + TILE_OPS); k++) {
           uint32_t v = src[k], code = v >> 29, len = v & OP_LEN_MASK;
@@ -130,6 +132,9 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
           line[4 + (k - k0)] = v;
           if (code != 2) st += len;  // target_delta: all but 'I' (impg.rs:115-121)
           if (code != 3) sq += len;  // |query_delta|: all but 'D' (impg.rs:123-135)
+          if (code == 0 || code == 4) sm += len;       // 'M' counted as match (impg.rs:2959)
+          else if (code == 1) sx += len;
+          else sg += 1;                                 // gap-compressed: one per 'I' / 'D' op
         }
         line[0] = t0; line[1] = q0; line[2] = st - t0; line[3] = sq - q0;
       }
@@ -312,6 +317,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   upload(ix.d_entries, ent, acc);
   upload(ix.d_ops, pool, acc);
   upload(ix.d_ext_cp, ext_cp, acc);
+  upload(ix.d_idp, idp, acc);
   upload(ix.d_seq_len, sl, acc);
   ix.device_bytes = acc;
   ix.n_entries = n_entries;
@@ -327,6 +333,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   ix.view.entries = ix.d_entries.as<Entry>();
   ix.view.ops = ix.d_ops.as<uint32_t>();
   ix.view.ext_cp = ix.d_ext_cp.as<uint32_t>();
+  ix.view.idp = ix.d_idp.as<uint4>();
   ix.view.seq_len = ix.d_seq_len.as<int32_t>();
   ix.view.n_seq = n_seq;
   ix.view.n_entries = (uint32_t)n_entries;

@@ -293,6 +293,17 @@ struct TileScan {
   bool found;
   int32_t pqs, pts, pqe, pte;  // query values are direction-normalised offsets from qbase until the end
 };
+// extra state for min_gap_compressed_identity (impg.rs:2952-2973): running sums of
+// matched bases ('=' and 'M'), mismatched bases ('X') and gap OPS ('I'/'D') in
+// walking order, snapshots at the first / last overlapping op, and what the
+// slice adjustment (impg.rs:2879-2886) takes off those two ops.
+struct IdentScan {
+  uint32_t rm, rx, rg;        // running (inclusive of the ops walked so far)
+  uint32_t fm, fx, fg;        // running sums just BEFORE the first overlapping op
+  uint32_t lm, lx, lg;        // running sums just AFTER the last overlapping op
+  int32_t first_adj_m, first_adj_x;  // first_op_offset if the first op is a match / mismatch op
+  int32_t last_adj_m, last_adj_x;    // last_op_remaining (<= 0) if the last op is a match / mismatch op
+};
 
 struct PairCtx {
   int32_t ts, R0, R1, last_tp;
@@ -312,7 +323,8 @@ struct PairCtx {
 //   arm 2 (query_delta == 0):   passes iff max(T,R0) < min(T+td,last_tp);    first (Q, os)      last (Q, oe)
 //   arm 3:                      passes iff max(T,R0) < min(T+td,R1);         first (Q+os-T, os) last (Q+oe-T, oe)
 // When arm 1 passes, os == T and min(T, lim) == T, so os / oe serve all arms.
-__device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &T, int32_t &Qn, TileScan &s) {
+template <bool IDENT>
+__device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &T, int32_t &Qn, TileScan &s, IdentScan &id) {
   const bool valid = op != OP_PAD;
   const uint32_t code = op >> 29;
   const int32_t len = valid ? (int32_t)(op & OP_LEN_MASK) : 0;
@@ -328,6 +340,25 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
   const int32_t fq = Qn + (qzero ? 0 : os - T);
   const int32_t lq = Qn + ((arm1 || qzero) ? qa : oe - T);
   const bool first = pass && !s.found;
+  if (IDENT) {
+    const bool is_m = valid && (code == 0u || code == 4u), is_x = valid && code == 1u;
+    const bool is_g = valid && (code == 2u || code == 3u);
+    if (first) {
+      id.fm = id.rm; id.fx = id.rx; id.fg = id.rg;
+      const int32_t off = arm1 ? 0 : os - T;  // first_op_offset (impg.rs:2832, :2856)
+      id.first_adj_m = is_m ? off : 0;
+      id.first_adj_x = is_x ? off : 0;
+    }
+    id.rm += is_m ? (uint32_t)len : 0u;
+    id.rx += is_x ? (uint32_t)len : 0u;
+    id.rg += is_g ? 1u : 0u;
+    if (pass) {
+      id.lm = id.rm; id.lx = id.rx; id.lg = id.rg;
+      const int32_t rem = arm1 ? 0 : oe - e;  // last_op_remaining (impg.rs:2838, :2862); an arm-1 last op is a gap op
+      id.last_adj_m = is_m ? rem : 0;
+      id.last_adj_x = is_x ? rem : 0;
+    }
+  }
   s.pqs = first ? fq : s.pqs;
   s.pts = first ? os : s.pts;
   s.pqe = pass ? lq : s.pqe;
@@ -349,7 +380,8 @@ constexpr int TILE_DVEC = TILE_OPS / 4;  // 7 data vectors after the header vect
 // Scan one tile in effective order, streaming its line 16 bytes (4 ops) at a time
 // with the next vector in flight.  Reverse-strand reversed entries walk the tile
 // back to front: descending vector index and reversed components.
-__device__ __forceinline__ void scan_tile(const PairCtx &c, uint32_t j, const uint4 hdr, TileScan &s) {
+template <bool IDENT>
+__device__ __forceinline__ void scan_tile(const PairCtx &c, uint32_t j, const uint4 hdr, TileScan &s, IdentScan &id) {
   int32_t T, Qn;
   tile_start(c, hdr, T, Qn);
   const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)j * TILE_WORDS);
@@ -358,22 +390,28 @@ __device__ __forceinline__ void scan_tile(const PairCtx &c, uint32_t j, const ui
   for (int k = 0; k < TILE_DVEC; k++) {
     uint4 nxt = cur;
     if (k + 1 < TILE_DVEC) nxt = q[c.flip ? TILE_DVEC - 1 - k : k + 2];
-    op_step(c.flip ? cur.w : cur.x, c, T, Qn, s);
-    op_step(c.flip ? cur.z : cur.y, c, T, Qn, s);
-    op_step(c.flip ? cur.y : cur.z, c, T, Qn, s);
-    op_step(c.flip ? cur.x : cur.w, c, T, Qn, s);
+    op_step<IDENT>(c.flip ? cur.w : cur.x, c, T, Qn, s, id);
+    op_step<IDENT>(c.flip ? cur.z : cur.y, c, T, Qn, s, id);
+    op_step<IDENT>(c.flip ? cur.y : cur.z, c, T, Qn, s, id);
+    op_step<IDENT>(c.flip ? cur.x : cur.w, c, T, Qn, s, id);
     cur = nxt;
   }
 }
 __device__ __forceinline__ uint4 tile_header(const PairCtx &c, uint32_t j) {
   return *reinterpret_cast<const uint4 *>(c.ops + (size_t)j * TILE_WORDS);
 }
+__device__ __forceinline__ void ident_reset(IdentScan &id) {
+  id.rm = id.rx = id.rg = id.fm = id.fx = id.fg = id.lm = id.lx = id.lg = 0;
+  id.first_adj_m = id.first_adj_x = id.last_adj_m = id.last_adj_x = 0;
+}
 
 // literal walk over tiles A..B in effective order, one op at a time (rare path)
-__device__ __noinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32_t B) {
+template <bool IDENT>
+__device__ __noinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32_t B, IdentScan &id) {
   TileScan s;
   s.found = false;
   s.pqs = s.pts = s.pqe = s.pte = -1;
+  ident_reset(id);
   int32_t T, Qn;
   tile_start(c, tile_header(c, A), T, Qn);
   const int stepj = c.flip ? -1 : 1;
@@ -381,19 +419,21 @@ __device__ __noinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32
     const uint32_t *tp = c.ops + (size_t)j * TILE_WORDS + 4;
     for (int u = 0; u < (int)TILE_OPS && T <= c.last_tp; u++) {
       uint32_t op = tp[c.flip ? (int)TILE_OPS - 1 - u : u];
-      op_step(op, c, T, Qn, s);
+      op_step<IDENT>(op, c, T, Qn, s, id);
     }
     if (T > c.last_tp || j == (int64_t)B) break;
   }
   return s;
 }
 
-template <bool TRANSITIVE>
+// IDENT: also evaluate calculate_gap_compressed_identity on the projected CIGAR
+// slice (impg.rs:1283-1287, :2952-2973) and drop hits below min_identity.
+template <bool TRANSITIVE, bool IDENT>
 __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
                                                       const uint32_t *__restrict__ pair_range,
                                                       const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
-                                                      uint32_t *__restrict__ err_flag) {
+                                                      uint32_t *__restrict__ err_flag, double min_identity) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   bool ok = false;
   TileScan res;
@@ -437,8 +477,9 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
       //  * the range reaches the alignment end and the CIGAR is consistent with
       //    the PAF coordinates: the final op is the last overlapping op, ending at
       //    (query offset totQ, target te).
-      const bool start_cov = c.R0 <= c.ts && c.last_tp > c.ts;
-      const bool end_cov = c.R1 >= en_te && c.R0 < en_te && (int32_t)c.totT == en_te - c.ts;
+      // (The identity filter needs the slice's op counts, so it always reads the tiles.)
+      const bool start_cov = !IDENT && c.R0 <= c.ts && c.last_tp > c.ts;
+      const bool end_cov = !IDENT && c.R1 >= en_te && c.R0 < en_te && (int32_t)c.totT == en_te - c.ts;
       // Effective tile k (k-th tile in this entry's walking order) starts at target
       // prefix P[k]: P[0] = 0, P[m] = totT, P[1..m-1] inline (m <= 8) or external.
       //   A = first k with P[k+1] >= R0 - ts        (holds the first op that can overlap)
@@ -478,12 +519,16 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         sa.found = false;
         sa.pqs = sa.pts = sa.pqe = sa.pte = -1;
         sb = sa;
+        IdentScan ia, ib;
+        ident_reset(ia);
+        ident_reset(ib);
+        bool walked = false;
         if (start_cov) {
           sa.found = true;
           sa.pqs = 0;
           sa.pts = c.ts;
         } else {
-          scan_tile(c, A, ha, sa);
+          scan_tile<IDENT>(c, A, ha, sa, ia);
         }
         if (end_cov) {
           sb.found = true;
@@ -491,8 +536,9 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
           sb.pte = en_te;
         } else if (!start_cov && A == B) {
           sb = sa;  // one tile holds both ends: its scan recorded the last overlapping op too
+          ib = ia;
         } else {
-          scan_tile(c, B, hb, sb);
+          scan_tile<IDENT>(c, B, hb, sb, ib);
         }
         if (sa.found && sb.found) {
           res.found = true;
@@ -501,7 +547,38 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         } else if (!start_cov && !end_cov && A == B) {
           res.found = false;  // every overlapping op would lie in this tile
         } else {
-          res = walk_tiles(c, A, B);
+          res = walk_tiles<IDENT>(c, A, B, ia);
+          walked = true;
+        }
+        if (IDENT && res.found) {
+          // op counts of the slice [first op, last op] in ORIGINAL op order:
+          //   forward walk : prefix(B) + lastB  -  (prefix(A) + firstA)
+          //   backward walk: (prefix(A) + total(A) - firstA) - (prefix(B) + total(B) - lastB)
+          // where prefix(j) = matched / mismatched bases and gap ops before tile j (idp[])
+          // and firstA / lastB are the walking-order running sums snapshotted by op_step.
+          int64_t M, X, G;
+          if (walked || A == B) {  // one continuous walk: plain difference of its running sums
+            const IdentScan &w = ia;
+            M = (int64_t)w.lm - w.fm; X = (int64_t)w.lx - w.fx; G = (int64_t)w.lg - w.fg;
+            M += -(int64_t)w.first_adj_m + w.last_adj_m;
+            X += -(int64_t)w.first_adj_x + w.last_adj_x;
+          } else {
+            const uint4 pa = v.idp[e1.y + A], pb = v.idp[e1.y + B];
+            if (!c.flip) {
+              M = ((int64_t)pb.x + ib.lm) - ((int64_t)pa.x + ia.fm);
+              X = ((int64_t)pb.y + ib.lx) - ((int64_t)pa.y + ia.fx);
+              G = ((int64_t)pb.z + ib.lg) - ((int64_t)pa.z + ia.fg);
+            } else {
+              M = ((int64_t)pa.x + ia.rm - ia.fm) - ((int64_t)pb.x + ib.rm - ib.lm);
+              X = ((int64_t)pa.y + ia.rx - ia.fx) - ((int64_t)pb.y + ib.rx - ib.lx);
+              G = ((int64_t)pa.z + ia.rg - ia.fg) - ((int64_t)pb.z + ib.rg - ib.lg);
+            }
+            M += -(int64_t)ia.first_adj_m + ib.last_adj_m;
+            X += -(int64_t)ia.first_adj_x + ib.last_adj_x;
+          }
+          const int64_t total = M + X + G;  // impg.rs:2967
+          const double ident = total == 0 ? 0.0 : (double)M / (double)total;
+          if (ident < min_identity) res.found = false;  // impg.rs:1284-1286
         }
       }
       ok = res.found && res.pqs != res.pqe && res.pts != res.pte;  // impg.rs:2874-2877
@@ -886,10 +963,14 @@ void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_
 }
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
-                    unsigned long long *accepted, uint32_t *err_flag, hipStream_t s) {
+                    unsigned long long *accepted, uint32_t *err_flag, double min_identity, hipStream_t s) {
   if (!n_pairs) return;
-  if (transitive) project_kernel<true><<<cdiv(n_pairs, 256), 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag);
-  else project_kernel<false><<<cdiv(n_pairs, 256), 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag);
+  const bool ident = min_identity == min_identity;  // NaN = no filter
+  const uint32_t g = cdiv(n_pairs, 256);
+  if (transitive && ident) project_kernel<true, true><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, min_identity);
+  else if (transitive) project_kernel<true, false><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, 0.0);
+  else if (ident) project_kernel<false, true><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, min_identity);
+  else project_kernel<false, false><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, 0.0);
 }
 void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
                       int32_t min_output_length, unsigned long long *count, unsigned long long *cksum, hipStream_t s) {

@@ -42,7 +42,7 @@ void launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, un
 size_t scan_scratch_bytes(uint32_t n);
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
-                    unsigned long long *accepted, uint32_t *err_flag, hipStream_t s);
+                    unsigned long long *accepted, uint32_t *err_flag, double min_identity, hipStream_t s);
 void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
                       int32_t min_output_length, unsigned long long *count, unsigned long long *cksum, hipStream_t s);
 void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,

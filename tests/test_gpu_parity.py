@@ -236,3 +236,20 @@ def test_long_cigars_external_checkpoints(tmp_path, seed, weird):
     ranges = random_ranges(seed, 150, 4, 400000, max_len=30000, min_len=1)
     assert_same(g, c, ranges)
     assert_same(g, c, ranges[:40], transitive=True, max_depth=2, min_transitive_len=50)
+
+
+@pytest.mark.parametrize("seed,weird,max_ops", [(41, False, 150), (42, True, 150), (43, False, 1200)])
+def test_min_gap_compressed_identity(tmp_path, seed, weird, max_ops):
+    """--min-result-identity: calculate_gap_compressed_identity on the projected slice (impg.rs:1283-1287)."""
+    text, names = random_paf(seed, 300, n_seq=5, seq_len=120000 if max_ops > 200 else 30000, max_ops=max_ops, weird=weird,
+                             self_aln=True)
+    g, c = both(tmp_path, text)
+    sl = 120000 if max_ops > 200 else 30000
+    ranges = random_ranges(seed, 200, 5, sl, max_len=6000)
+    kept = []
+    for thr in [0.0, 0.35, 0.5, 0.62, 0.8, 0.999, 1.0]:
+        res = assert_same(g, c, ranges, min_identity=thr)
+        kept.append(res.projected)
+    assert kept[0] > kept[-1] and sorted(kept, reverse=True) == kept  # the filter bites, monotonically
+    for thr in [0.4, 0.7]:
+        assert_same(g, c, ranges[:50], transitive=True, max_depth=3, min_transitive_len=30, min_identity=thr)

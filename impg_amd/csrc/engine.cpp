@@ -166,9 +166,8 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       launch_frontier_emit(vt->keys.as<unsigned long long>(), poff.as<uint32_t>(), n_pieces.as<uint32_t>(),
                            foff.as<uint32_t>(), n_groups, pieces.as<int2>(), next_frontier.as<FrontierRec>(), stream);
       vt->n_groups = n_groups;
-      if (tables.size() + 1 >= (size_t)MAX_VISITED_TABLES)
-        throw Error{IMPG_E_UNSUPPORTED, "transitive depth exceeds the visited-table limit"};
       tables.push_back(std::move(vt));
+      if (tables.size() + 2 >= (size_t)MAX_VISITED_TABLES) compact_tables();
     }
   }
   IMPG_HIP(hipEventRecord(e1, stream));
@@ -208,7 +207,6 @@ uint32_t Engine::begin_transitive(const DeviceIndexView &v, const impg_gpu_range
 }
 
 void Engine::check_params(const impg_gpu_params_t &p) {
-  if (p.dfs && p.transitive) throw Error{IMPG_E_UNSUPPORTED, "query_transitive_dfs is not built yet"};
   if (p.store_cigar) throw Error{IMPG_E_UNSUPPORTED, "store_cigar (BEDPE/PAF output) is not built yet"};
   if (p.transitive && p.max_depth > 65535) throw Error{IMPG_E_INVALID, "max_depth is a u16 in the reference"};
 }
@@ -233,6 +231,11 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   IMPG_HIP(hipEventRecord(t0, stream));
   if (st) memset(st, 0, sizeof *st);
   const bool transitive = p.transitive != 0;
+  if (transitive && p.dfs) {
+    ev_next = 0;
+    run_dfs(ix, d_ranges, n, p, keep, d_count, d_cksum, st, self_out);
+    return;
+  }
 
   DevBuf *cur = &frontier_a, *nxt = &frontier_b;
   uint32_t n_fr = 0;
@@ -276,6 +279,10 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     n_fr = n_next;
     depth += 1;
   }
+  finish_run(st, t0, t1);
+}
+
+void Engine::finish_run(impg_gpu_stats_t *st, hipEvent_t t0, hipEvent_t t1) {
   IMPG_HIP(hipEventRecord(t1, stream));
   IMPG_HIP(hipStreamSynchronize(stream));
   uint64_t hc[3];
@@ -295,6 +302,159 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     }
   }
   last_projected = hc[1];
+}
+
+// Fold every visited table into one: for each key the newest table's list wins
+// (it is complete).  Keeps long transitive walks (DFS rounds, unlimited depth)
+// within MAX_VISITED_TABLES.
+void Engine::compact_tables() {
+  if (tables.size() < 2) return;
+  uint64_t G = 0;
+  for (auto &t : tables) G += t->n_groups;
+  if (G >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "visited tables exceed 2^32 groups"};
+  const uint32_t g = (uint32_t)G;
+  VisitedTables tv = tables_view();
+  d_ckey.reserve((size_t)g * 8); d_ckey2.reserve((size_t)g * 8); d_src.reserve((size_t)g * 8); d_src2.reserve((size_t)g * 8);
+  uint32_t off = 0;
+  for (size_t t = 0; t < tables.size(); t++) {  // oldest first: a stable sort leaves the newest last within a key
+    launch_compact_fill(tables[t]->keys.as<unsigned long long>(), tables[t]->n_groups, (uint32_t)t,
+                        d_ckey.as<unsigned long long>() + off, d_src.as<unsigned long long>() + off, stream);
+    off += tables[t]->n_groups;
+  }
+  size_t tb = sort_u64v_scratch_bytes(g);
+  sort_tmp.reserve(tb);
+  launch_sort_u64v(sort_tmp.p, tb, d_ckey.as<unsigned long long>(), d_ckey2.as<unsigned long long>(),
+                   d_src.as<unsigned long long>(), d_src2.as<unsigned long long>(), g, stream);
+  d_flag2.reserve((size_t)g * 4); d_pos2.reserve((size_t)g * 4);
+  launch_compact_last(d_ckey2.as<unsigned long long>(), g, d_flag2.as<uint32_t>(), stream);
+  const uint32_t g2 = (uint32_t)scan(d_flag2.as<uint32_t>(), d_pos2.as<uint32_t>(), g);
+  auto nt = std::make_unique<VisitedStore>();
+  nt->keys.reserve((size_t)g2 * 8); nt->off.reserve((size_t)g2 * 4); nt->len.reserve((size_t)g2 * 4);
+  launch_compact_select(tv, d_ckey2.as<unsigned long long>(), d_src2.as<unsigned long long>(), g, d_flag2.as<uint32_t>(),
+                        d_pos2.as<uint32_t>(), nt->keys.as<unsigned long long>(), d_src.as<unsigned long long>(),
+                        nt->len.as<uint32_t>(), stream);
+  const uint64_t total = scan(nt->len.as<uint32_t>(), nt->off.as<uint32_t>(), g2);
+  if (total >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "visited sets exceed 2^32 ranges"};
+  nt->ranges.reserve(std::max<size_t>(total * 8, 256));
+  launch_compact_copy(tv, d_src.as<unsigned long long>(), nt->off.as<uint32_t>(), nt->len.as<uint32_t>(), g2,
+                      nt->ranges.as<int2>(), stream);
+  nt->n_groups = g2;
+  IMPG_HIP(hipStreamSynchronize(stream));  // the old tables are read by the copy above
+  tables.clear();
+  tables.push_back(std::move(nt));
+}
+
+// query_transitive_dfs (impg.rs:2057-2309) for a whole batch, in rounds: every
+// query pops the top of its own stack, the popped ranges are expanded together,
+// the visited update runs for all of them, and the stacks are re-sorted and merged
+// (impg.rs:2289-2304).  A query's pops happen in the reference's order; queries
+// are independent, so interleaving them changes nothing.
+void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
+                     std::vector<std::unique_ptr<LevelBufs>> *keep, unsigned long long *d_count, unsigned long long *d_cksum,
+                     impg_gpu_stats_t *st, DevBuf *self_out) {
+  const DeviceIndexView &v = ix.view;
+  hipEvent_t t0 = event(), t1 = event();
+  IMPG_HIP(hipEventRecord(t0, stream));
+  DevBuf &self = self_out ? *self_out : self_scratch;
+  self.reserve(std::max<size_t>((size_t)n * sizeof(FrontierRec), 256));
+  uint32_t n_stack = begin_transitive(v, d_ranges, n, p, self.as<FrontierRec>(), frontier_a);
+  auto res4 = [&](DevBuf &k, DevBuf &s, DevBuf &e, DevBuf &d, size_t m) {
+    k.reserve(std::max<size_t>(m * 8, 256)); s.reserve(std::max<size_t>(m * 4, 256));
+    e.reserve(std::max<size_t>(m * 4, 256)); d.reserve(std::max<size_t>(m * 4, 256));
+  };
+  res4(dk_a, ds_a, de_a, dd_a, n_stack);
+  d_popdepth.reserve(std::max<size_t>((size_t)n * 4, 256));
+  launch_frontier_to_stack(frontier_a.as<FrontierRec>(), n_stack, nullptr, false, dk_a.as<unsigned long long>(),
+                           ds_a.as<int32_t>(), de_a.as<int32_t>(), dd_a.as<uint32_t>(), stream);
+  // current stack in the *_a buffers, sorted by (qidx, sequence, start)
+  while (n_stack > 0) {
+    // ---- pop the top of every query's stack -----------------------------------
+    head.reserve((size_t)n_stack * 4); gid.reserve((size_t)n_stack * 4);
+    d_flag2.reserve((size_t)n_stack * 4); d_pos2.reserve((size_t)n_stack * 4);
+    launch_dfs_pop_flags(dk_a.as<unsigned long long>(), dd_a.as<uint32_t>(), n_stack, p.max_depth, head.as<uint32_t>(),
+                         d_flag2.as<uint32_t>(), d_popdepth.as<uint32_t>(), stream);
+    const uint32_t n_fr = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), n_stack);
+    const uint32_t n_keep = (uint32_t)scan(d_flag2.as<uint32_t>(), d_pos2.as<uint32_t>(), n_stack);
+    frontier_b.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
+    uint32_t n_pieces = 0;
+    // remaining stack goes to the *_b buffers; the new pieces are appended behind it
+    std::unique_ptr<LevelBufs> own;
+    LevelBufs *L = &level_scratch;
+    if (keep) { own = std::make_unique<LevelBufs>(); L = own.get(); }
+    res4(dk_b, ds_b, de_b, dd_b, (size_t)n_keep + 1);
+    launch_dfs_pop_scatter(dk_a.as<unsigned long long>(), ds_a.as<int32_t>(), de_a.as<int32_t>(), dd_a.as<uint32_t>(), n_stack,
+                           head.as<uint32_t>(), gid.as<uint32_t>(), d_flag2.as<uint32_t>(), d_pos2.as<uint32_t>(),
+                           frontier_b.as<FrontierRec>(), dk_b.as<unsigned long long>(), ds_b.as<int32_t>(), de_b.as<int32_t>(),
+                           dd_b.as<uint32_t>(), stream);
+    if (n_fr) {
+      expand(v, frontier_b.as<FrontierRec>(), n_fr, true, *L, st);
+      L->n_frontier = n_fr;
+      if (d_count || d_cksum) {
+        HitArrays h{L->qid.as<uint32_t>(), L->qs.as<int32_t>(), L->qe.as<int32_t>(), L->ts.as<int32_t>(), L->te.as<int32_t>()};
+        launch_hit_stats(frontier_b.as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h, p.min_output_length,
+                         d_count, d_cksum, stream);
+      }
+      if (st) st->levels += 1;
+      n_pieces = update(v, frontier_b.as<FrontierRec>(), *L, n, p, frontier_a);  // pieces, sorted by (qidx, seq, start)
+      if (keep) {
+        L->frontier.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
+        IMPG_HIP(hipMemcpyAsync(L->frontier.p, frontier_b.p, (size_t)n_fr * sizeof(FrontierRec), hipMemcpyDeviceToDevice, stream));
+        keep->push_back(std::move(own));
+      }
+    }
+    const uint32_t m = n_keep + n_pieces;
+    if (m == 0) break;
+    if (n_pieces == 0) {  // nothing pushed: the remaining stack is still sorted and merged
+      dk_a.swap(dk_b); ds_a.swap(ds_b); de_a.swap(de_b); dd_a.swap(dd_b);
+      n_stack = n_keep;
+      continue;
+    }
+    if (m >= 0xFFFFFFF0u) throw Error{IMPG_E_UNSUPPORTED, "DFS stacks exceed 2^32 records"};
+    // *_b buffers may have been sized for n_keep only: grow while keeping the kept part
+    {
+      DevBuf nk, ns, ne, nd;
+      res4(nk, ns, ne, nd, m);
+      if (n_keep) {
+        IMPG_HIP(hipMemcpyAsync(nk.p, dk_b.p, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, stream));
+        IMPG_HIP(hipMemcpyAsync(ns.p, ds_b.p, (size_t)n_keep * 4, hipMemcpyDeviceToDevice, stream));
+        IMPG_HIP(hipMemcpyAsync(ne.p, de_b.p, (size_t)n_keep * 4, hipMemcpyDeviceToDevice, stream));
+        IMPG_HIP(hipMemcpyAsync(nd.p, dd_b.p, (size_t)n_keep * 4, hipMemcpyDeviceToDevice, stream));
+      }
+      launch_frontier_to_stack(frontier_a.as<FrontierRec>(), n_pieces, d_popdepth.as<uint32_t>(), true,
+                               nk.as<unsigned long long>() + n_keep, ns.as<int32_t>() + n_keep, ne.as<int32_t>() + n_keep,
+                               nd.as<uint32_t>() + n_keep, stream);
+      IMPG_HIP(hipStreamSynchronize(stream));
+      dk_b.swap(nk); ds_b.swap(ns); de_b.swap(ne); dd_b.swap(nd);
+    }
+    // ---- stack.sort_by_key((id, start)) for every query at once: LSD, two stable radix sorts
+    d_perm.reserve((size_t)m * 4); d_perm2.reserve((size_t)m * 4); d_k32.reserve((size_t)m * 4); d_k32b.reserve((size_t)m * 4);
+    launch_iota(d_perm.as<uint32_t>(), m, stream);
+    size_t tb = std::max(sort_u32_scratch_bytes(m), sort_pairs_scratch_bytes(m));
+    sort_tmp.reserve(tb);
+    launch_sort_u32(sort_tmp.p, tb, reinterpret_cast<const uint32_t *>(ds_b.as<int32_t>()), d_k32b.as<uint32_t>(),
+                    d_perm.as<uint32_t>(), d_perm2.as<uint32_t>(), m, stream);
+    d_ckey.reserve((size_t)m * 8); d_ckey2.reserve((size_t)m * 8);
+    launch_gather_u64(dk_b.as<unsigned long long>(), d_perm2.as<uint32_t>(), m, d_ckey.as<unsigned long long>(), stream);
+    launch_sort_pairs(sort_tmp.p, tb, d_ckey.as<unsigned long long>(), d_ckey2.as<unsigned long long>(), d_perm2.as<uint32_t>(),
+                      d_perm.as<uint32_t>(), m, 64, stream);
+    // ---- merge overlapping / contiguous neighbours of the same (query, sequence)
+    head.reserve((size_t)m * 4); gid.reserve((size_t)m * 4);
+    launch_run_heads(d_ckey2.as<unsigned long long>(), m, head.as<uint32_t>(), stream);
+    const uint32_t n_groups = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), m);
+    gstart.reserve((size_t)n_groups * 4); cap.reserve((size_t)n_groups * 4); foff.reserve((size_t)n_groups * 4);
+    launch_run_starts(head.as<uint32_t>(), gid.as<uint32_t>(), m, gstart.as<uint32_t>(), stream);
+    DevBuf &sm = d_k32, &em = d_k32b, &dm = d_pos2;  // merged records, still at their run's offset
+    sm.reserve((size_t)m * 4); em.reserve((size_t)m * 4); dm.reserve((size_t)m * 4);
+    launch_dfs_merge(gstart.as<uint32_t>(), n_groups, m, d_perm.as<uint32_t>(), ds_b.as<int32_t>(), de_b.as<int32_t>(),
+                     dd_b.as<uint32_t>(), sm.as<int32_t>(), em.as<int32_t>(), dm.as<uint32_t>(), cap.as<uint32_t>(), stream);
+    const uint32_t n_new = (uint32_t)scan(cap.as<uint32_t>(), foff.as<uint32_t>(), n_groups);
+    res4(dk_a, ds_a, de_a, dd_a, n_new);
+    launch_dfs_compact(gstart.as<uint32_t>(), cap.as<uint32_t>(), foff.as<uint32_t>(), n_groups, d_ckey2.as<unsigned long long>(),
+                       sm.as<int32_t>(), em.as<int32_t>(), dm.as<uint32_t>(), dk_a.as<unsigned long long>(), ds_a.as<int32_t>(),
+                       de_a.as<int32_t>(), dd_a.as<uint32_t>(), stream);
+    n_stack = n_new;
+  }
+  finish_run(st, t0, t1);
 }
 
 }  // namespace impg

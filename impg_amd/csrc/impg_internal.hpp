@@ -101,6 +101,7 @@ struct DevBuf {
   size_t cap = 0;
   void reserve(size_t bytes);  // contents are NOT preserved on growth
   void release();
+  void swap(DevBuf &o) { void *tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; }
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
   ~DevBuf() { release(); }
   DevBuf() = default;

@@ -925,6 +925,189 @@ __global__ __launch_bounds__(256) void hits_to_aos_kernel(const uint32_t *__rest
   out[p] = x;
 }
 
+// ---------------------------------------------------------------------------
+// DFS (query_transitive_dfs, impg.rs:2057-2309): every query keeps a stack of
+// (sequence, start, end, depth) sorted by (sequence, start); one round pops the
+// last element of every query's stack.  Stacks of all queries live in one flat
+// array sorted by (qidx, sequence, start).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frontier_to_stack_kernel(const FrontierRec *__restrict__ fr, uint32_t n,
+                                                                const uint32_t *__restrict__ pop_depth, int use_depth,
+                                                                unsigned long long *__restrict__ key,
+                                                                int32_t *__restrict__ st, int32_t *__restrict__ en,
+                                                                uint32_t *__restrict__ depth) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const FrontierRec f = fr[i];
+  key[i] = ((unsigned long long)f.qidx << 32) | f.target_id;
+  st[i] = f.start;
+  en[i] = f.end;
+  depth[i] = use_depth ? pop_depth[f.qidx] + 1u : 0u;  // impg.rs:2277 pushes current_depth + 1
+}
+// the last record of a query's segment is its stack top (impg.rs:2117-2122)
+__global__ __launch_bounds__(256) void dfs_pop_flags_kernel(const unsigned long long *__restrict__ key,
+                                                            const uint32_t *__restrict__ depth, uint32_t n,
+                                                            uint32_t max_depth, uint32_t *__restrict__ fr_flag,
+                                                            uint32_t *__restrict__ keep_flag,
+                                                            uint32_t *__restrict__ pop_depth) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t q = (uint32_t)(key[i] >> 32);
+  const bool last = (i + 1 == n) || ((uint32_t)(key[i + 1] >> 32) != q);
+  const uint32_t d = depth[i];
+  keep_flag[i] = last ? 0u : 1u;
+  fr_flag[i] = (last && !(max_depth > 0 && d >= max_depth)) ? 1u : 0u;  // impg.rs:2125: too deep -> popped, not explored
+  if (last) pop_depth[q] = d;
+}
+__global__ __launch_bounds__(256) void dfs_pop_scatter_kernel(const unsigned long long *__restrict__ key,
+                                                              const int32_t *__restrict__ st, const int32_t *__restrict__ en,
+                                                              const uint32_t *__restrict__ depth, uint32_t n,
+                                                              const uint32_t *__restrict__ fr_flag,
+                                                              const uint32_t *__restrict__ fr_pos,
+                                                              const uint32_t *__restrict__ keep_flag,
+                                                              const uint32_t *__restrict__ keep_pos,
+                                                              FrontierRec *__restrict__ fr_out,
+                                                              unsigned long long *__restrict__ key_out,
+                                                              int32_t *__restrict__ st_out, int32_t *__restrict__ en_out,
+                                                              uint32_t *__restrict__ depth_out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  if (fr_flag[i]) {
+    FrontierRec f;
+    f.target_id = (uint32_t)(key[i] & 0xFFFFFFFFull);
+    f.start = st[i];
+    f.end = en[i];
+    f.qidx = (uint32_t)(key[i] >> 32);
+    fr_out[fr_pos[i]] = f;
+  }
+  if (keep_flag[i]) {
+    const uint32_t p = keep_pos[i];
+    key_out[p] = key[i];
+    st_out[p] = st[i];
+    en_out[p] = en[i];
+    depth_out[p] = depth[i];
+  }
+}
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t *__restrict__ v, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+__global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
+                                                         uint32_t n, uint32_t *__restrict__ dst) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ __launch_bounds__(256) void gather_u64_kernel(const unsigned long long *__restrict__ src,
+                                                         const uint32_t *__restrict__ idx, uint32_t n,
+                                                         unsigned long long *__restrict__ dst) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+// head of each run of equal keys (all keys real)
+__global__ __launch_bounds__(256) void run_heads_kernel(const unsigned long long *__restrict__ skeys, uint32_t n,
+                                                        uint32_t *__restrict__ head) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  head[i] = (i == 0 || skeys[i - 1] != skeys[i]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void run_starts_kernel(const uint32_t *__restrict__ head, const uint32_t *__restrict__ gid,
+                                                         uint32_t n, uint32_t *__restrict__ gstart) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n && head[i]) gstart[gid[i]] = i;
+}
+// stack merge sweep (impg.rs:2291-2304) inside one (query, sequence) run, records
+// gathered through perm[]; merged records are written at the run's own offset
+__global__ __launch_bounds__(64) void dfs_merge_kernel(const uint32_t *__restrict__ gstart, uint32_t n_groups, uint32_t n,
+                                                       const uint32_t *__restrict__ perm,
+                                                       const int32_t *__restrict__ st, const int32_t *__restrict__ en,
+                                                       const uint32_t *__restrict__ depth,
+                                                       int32_t *__restrict__ st_m, int32_t *__restrict__ en_m,
+                                                       uint32_t *__restrict__ depth_m, uint32_t *__restrict__ cnt) {
+  const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint32_t a = gstart[g], b = g + 1 < n_groups ? gstart[g + 1] : n;
+  uint32_t w = a;
+  uint32_t p0 = perm[a];
+  int32_t ws = st[p0], we = en[p0];
+  uint32_t wd = depth[p0];
+  for (uint32_t r = a + 1; r < b; r++) {
+    const uint32_t pr = perm[r];
+    const int32_t rs = st[pr], re = en[pr];
+    if (we >= rs) {
+      we = max(we, re);  // merged element keeps the first one's depth
+    } else {
+      st_m[w] = ws; en_m[w] = we; depth_m[w] = wd;
+      w++;
+      ws = rs; we = re; wd = depth[pr];
+    }
+  }
+  st_m[w] = ws; en_m[w] = we; depth_m[w] = wd;
+  cnt[g] = w - a + 1;
+}
+__global__ __launch_bounds__(256) void dfs_compact_kernel(const uint32_t *__restrict__ gstart,
+                                                          const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ off,
+                                                          uint32_t n_groups, const unsigned long long *__restrict__ skeys,
+                                                          const int32_t *__restrict__ st_m, const int32_t *__restrict__ en_m,
+                                                          const uint32_t *__restrict__ depth_m,
+                                                          unsigned long long *__restrict__ key_out,
+                                                          int32_t *__restrict__ st_out, int32_t *__restrict__ en_out,
+                                                          uint32_t *__restrict__ depth_out) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint32_t a = gstart[g], c = cnt[g], o = off[g];
+  const unsigned long long k = skeys[a];
+  for (uint32_t i = 0; i < c; i++) {
+    key_out[o + i] = k;
+    st_out[o + i] = st_m[a + i];
+    en_out[o + i] = en_m[a + i];
+    depth_out[o + i] = depth_m[a + i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// visited-table compaction: fold all tables into one (newest entry of a key wins)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compact_fill_kernel(const unsigned long long *__restrict__ keys, uint32_t n,
+                                                           uint32_t table, unsigned long long *__restrict__ key_out,
+                                                           unsigned long long *__restrict__ src_out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  key_out[i] = keys[i];
+  src_out[i] = ((unsigned long long)table << 32) | i;
+}
+__global__ __launch_bounds__(256) void compact_last_kernel(const unsigned long long *__restrict__ skeys, uint32_t n,
+                                                           uint32_t *__restrict__ flag) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (i + 1 == n || skeys[i + 1] != skeys[i]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void compact_select_kernel(VisitedTables vt, const unsigned long long *__restrict__ skeys,
+                                                             const unsigned long long *__restrict__ ssrc, uint32_t n,
+                                                             const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
+                                                             unsigned long long *__restrict__ key_out,
+                                                             unsigned long long *__restrict__ src_out,
+                                                             uint32_t *__restrict__ len_out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const uint32_t p = pos[i];
+  const unsigned long long s = ssrc[i];
+  key_out[p] = skeys[i];
+  src_out[p] = s;
+  len_out[p] = vt.t[(uint32_t)(s >> 32)].len[(uint32_t)(s & 0xFFFFFFFFull)];
+}
+__global__ __launch_bounds__(256) void compact_copy_kernel(VisitedTables vt, const unsigned long long *__restrict__ src,
+                                                           const uint32_t *__restrict__ off, const uint32_t *__restrict__ len,
+                                                           uint32_t n, int2 *__restrict__ ranges_out) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= n) return;
+  const unsigned long long s = src[g];
+  const VisitedTable &T = vt.t[(uint32_t)(s >> 32)];
+  const int2 *in = T.ranges + T.off[(uint32_t)(s & 0xFFFFFFFFull)];
+  int2 *out = ranges_out + off[g];
+  const uint32_t l = len[g];
+  for (uint32_t i = 0; i < l; i++) out[i] = in[i];
+}
+
 __global__ __launch_bounds__(256) void aos_to_hits_kernel(const impg_gpu_hit_t *__restrict__ in, uint32_t n,
                                                           uint32_t *__restrict__ pair_range, HitArrays h) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -1045,6 +1228,87 @@ void launch_hits_to_aos(const uint32_t *pair_range, const uint32_t *pair_off, ui
   hits_to_aos_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(pair_range, pair_off, n_pairs, h, out);
 }
 
+void launch_frontier_to_stack(const FrontierRec *fr, uint32_t n, const uint32_t *pop_depth, bool use_depth,
+                              unsigned long long *key, int32_t *st, int32_t *en, uint32_t *depth, hipStream_t s) {
+  if (!n) return;
+  frontier_to_stack_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, n, pop_depth, use_depth ? 1 : 0, key, st, en, depth);
+}
+void launch_dfs_pop_flags(const unsigned long long *key, const uint32_t *depth, uint32_t n, uint32_t max_depth,
+                          uint32_t *fr_flag, uint32_t *keep_flag, uint32_t *pop_depth, hipStream_t s) {
+  if (!n) return;
+  dfs_pop_flags_kernel<<<cdiv(n, 256), 256, 0, s>>>(key, depth, n, max_depth, fr_flag, keep_flag, pop_depth);
+}
+void launch_dfs_pop_scatter(const unsigned long long *key, const int32_t *st, const int32_t *en, const uint32_t *depth,
+                            uint32_t n, const uint32_t *fr_flag, const uint32_t *fr_pos, const uint32_t *keep_flag,
+                            const uint32_t *keep_pos, FrontierRec *fr_out, unsigned long long *key_out, int32_t *st_out,
+                            int32_t *en_out, uint32_t *depth_out, hipStream_t s) {
+  if (!n) return;
+  dfs_pop_scatter_kernel<<<cdiv(n, 256), 256, 0, s>>>(key, st, en, depth, n, fr_flag, fr_pos, keep_flag, keep_pos, fr_out,
+                                                     key_out, st_out, en_out, depth_out);
+}
+void launch_iota(uint32_t *v, uint32_t n, hipStream_t s) { if (n) iota_kernel<<<cdiv(n, 256), 256, 0, s>>>(v, n); }
+void launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t *dst, hipStream_t s) {
+  if (n) gather_u32_kernel<<<cdiv(n, 256), 256, 0, s>>>(src, idx, n, dst);
+}
+void launch_gather_u64(const unsigned long long *src, const uint32_t *idx, uint32_t n, unsigned long long *dst, hipStream_t s) {
+  if (n) gather_u64_kernel<<<cdiv(n, 256), 256, 0, s>>>(src, idx, n, dst);
+}
+void launch_run_heads(const unsigned long long *skeys, uint32_t n, uint32_t *head, hipStream_t s) {
+  if (n) run_heads_kernel<<<cdiv(n, 256), 256, 0, s>>>(skeys, n, head);
+}
+void launch_run_starts(const uint32_t *head, const uint32_t *gid, uint32_t n, uint32_t *gstart, hipStream_t s) {
+  if (n) run_starts_kernel<<<cdiv(n, 256), 256, 0, s>>>(head, gid, n, gstart);
+}
+void launch_dfs_merge(const uint32_t *gstart, uint32_t n_groups, uint32_t n, const uint32_t *perm, const int32_t *st,
+                      const int32_t *en, const uint32_t *depth, int32_t *st_m, int32_t *en_m, uint32_t *depth_m,
+                      uint32_t *cnt, hipStream_t s) {
+  if (n_groups) dfs_merge_kernel<<<cdiv(n_groups, 64), 64, 0, s>>>(gstart, n_groups, n, perm, st, en, depth, st_m, en_m, depth_m, cnt);
+}
+void launch_dfs_compact(const uint32_t *gstart, const uint32_t *cnt, const uint32_t *off, uint32_t n_groups,
+                        const unsigned long long *skeys, const int32_t *st_m, const int32_t *en_m, const uint32_t *depth_m,
+                        unsigned long long *key_out, int32_t *st_out, int32_t *en_out, uint32_t *depth_out, hipStream_t s) {
+  if (n_groups) dfs_compact_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(gstart, cnt, off, n_groups, skeys, st_m, en_m, depth_m,
+                                                                       key_out, st_out, en_out, depth_out);
+}
+size_t sort_u32_scratch_bytes(uint32_t n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *>(
+      nullptr, bytes, nullptr, nullptr, nullptr, nullptr, n, 0, 32, (hipStream_t)0);
+  return bytes;
+}
+void launch_sort_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                     uint32_t n, hipStream_t s) {
+  if (!n) return;
+  IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, 32, s));
+}
+size_t sort_u64v_scratch_bytes(uint32_t n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs<rocprim::default_config, const unsigned long long *, unsigned long long *,
+                                  const unsigned long long *, unsigned long long *>(nullptr, bytes, nullptr, nullptr, nullptr,
+                                                                                    nullptr, n, 0, 64, (hipStream_t)0);
+  return bytes;
+}
+void launch_sort_u64v(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
+                      const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s) {
+  if (!n) return;
+  IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, 64, s));
+}
+void launch_compact_fill(const unsigned long long *keys, uint32_t n, uint32_t table, unsigned long long *key_out,
+                         unsigned long long *src_out, hipStream_t s) {
+  if (n) compact_fill_kernel<<<cdiv(n, 256), 256, 0, s>>>(keys, n, table, key_out, src_out);
+}
+void launch_compact_last(const unsigned long long *skeys, uint32_t n, uint32_t *flag, hipStream_t s) {
+  if (n) compact_last_kernel<<<cdiv(n, 256), 256, 0, s>>>(skeys, n, flag);
+}
+void launch_compact_select(const VisitedTables &vt, const unsigned long long *skeys, const unsigned long long *ssrc, uint32_t n,
+                           const uint32_t *flag, const uint32_t *pos, unsigned long long *key_out,
+                           unsigned long long *src_out, uint32_t *len_out, hipStream_t s) {
+  if (n) compact_select_kernel<<<cdiv(n, 256), 256, 0, s>>>(vt, skeys, ssrc, n, flag, pos, key_out, src_out, len_out);
+}
+void launch_compact_copy(const VisitedTables &vt, const unsigned long long *src, const uint32_t *off, const uint32_t *len,
+                         uint32_t n, int2 *ranges_out, hipStream_t s) {
+  if (n) compact_copy_kernel<<<cdiv(n, 256), 256, 0, s>>>(vt, src, off, len, n, ranges_out);
+}
 void launch_aos_to_hits(const impg_gpu_hit_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s) {
   if (!n) return;
   aos_to_hits_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, n, pair_range, h);

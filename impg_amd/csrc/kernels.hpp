@@ -72,6 +72,39 @@ void launch_ranges_to_frontier(const impg_gpu_range_t *ranges, uint32_t n, Front
 void launch_hits_to_aos(const uint32_t *pair_range, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
                         impg_gpu_hit_t *out, hipStream_t s);
 
+void launch_frontier_to_stack(const FrontierRec *fr, uint32_t n, const uint32_t *pop_depth, bool use_depth,
+                              unsigned long long *key, int32_t *st, int32_t *en, uint32_t *depth, hipStream_t s);
+void launch_dfs_pop_flags(const unsigned long long *key, const uint32_t *depth, uint32_t n, uint32_t max_depth,
+                          uint32_t *fr_flag, uint32_t *keep_flag, uint32_t *pop_depth, hipStream_t s);
+void launch_dfs_pop_scatter(const unsigned long long *key, const int32_t *st, const int32_t *en, const uint32_t *depth,
+                            uint32_t n, const uint32_t *fr_flag, const uint32_t *fr_pos, const uint32_t *keep_flag,
+                            const uint32_t *keep_pos, FrontierRec *fr_out, unsigned long long *key_out, int32_t *st_out,
+                            int32_t *en_out, uint32_t *depth_out, hipStream_t s);
+void launch_iota(uint32_t *v, uint32_t n, hipStream_t s);
+void launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t *dst, hipStream_t s);
+void launch_gather_u64(const unsigned long long *src, const uint32_t *idx, uint32_t n, unsigned long long *dst, hipStream_t s);
+void launch_run_heads(const unsigned long long *skeys, uint32_t n, uint32_t *head, hipStream_t s);
+void launch_run_starts(const uint32_t *head, const uint32_t *gid, uint32_t n, uint32_t *gstart, hipStream_t s);
+void launch_dfs_merge(const uint32_t *gstart, uint32_t n_groups, uint32_t n, const uint32_t *perm, const int32_t *st,
+                      const int32_t *en, const uint32_t *depth, int32_t *st_m, int32_t *en_m, uint32_t *depth_m,
+                      uint32_t *cnt, hipStream_t s);
+void launch_dfs_compact(const uint32_t *gstart, const uint32_t *cnt, const uint32_t *off, uint32_t n_groups,
+                        const unsigned long long *skeys, const int32_t *st_m, const int32_t *en_m, const uint32_t *depth_m,
+                        unsigned long long *key_out, int32_t *st_out, int32_t *en_out, uint32_t *depth_out, hipStream_t s);
+size_t sort_u32_scratch_bytes(uint32_t n);
+void launch_sort_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                     uint32_t n, hipStream_t s);
+size_t sort_u64v_scratch_bytes(uint32_t n);
+void launch_sort_u64v(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
+                      const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s);
+void launch_compact_fill(const unsigned long long *keys, uint32_t n, uint32_t table, unsigned long long *key_out,
+                         unsigned long long *src_out, hipStream_t s);
+void launch_compact_last(const unsigned long long *skeys, uint32_t n, uint32_t *flag, hipStream_t s);
+void launch_compact_select(const VisitedTables &vt, const unsigned long long *skeys, const unsigned long long *ssrc, uint32_t n,
+                           const uint32_t *flag, const uint32_t *pos, unsigned long long *key_out,
+                           unsigned long long *src_out, uint32_t *len_out, hipStream_t s);
+void launch_compact_copy(const VisitedTables &vt, const unsigned long long *src, const uint32_t *off, const uint32_t *len,
+                         uint32_t n, int2 *ranges_out, hipStream_t s);
 void launch_aos_to_hits(const impg_gpu_hit_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s);
 
 }  // namespace impg

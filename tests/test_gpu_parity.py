@@ -253,3 +253,31 @@ def test_min_gap_compressed_identity(tmp_path, seed, weird, max_ops):
     assert kept[0] > kept[-1] and sorted(kept, reverse=True) == kept  # the filter bites, monotonically
     for thr in [0.4, 0.7]:
         assert_same(g, c, ranges[:50], transitive=True, max_depth=3, min_transitive_len=30, min_identity=thr)
+
+
+@pytest.mark.parametrize("seed", [51, 52, 53])
+def test_transitive_dfs(tmp_path, seed):
+    """query_transitive_dfs (impg.rs:2057-2309): one stack pop per query per round."""
+    text, names = random_paf(seed, 300, n_seq=6, seq_len=20000, weird=(seed % 2 == 0), self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(seed + 7, 50, 6, 20000, max_len=3000, min_len=50)
+    for kw in [dict(transitive=True, dfs=True, max_depth=1, min_transitive_len=0, min_distance_between_ranges=0),
+               dict(transitive=True, dfs=True, max_depth=2),
+               dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=10),
+               dict(transitive=True, dfs=True, max_depth=4, min_transitive_len=101, min_distance_between_ranges=50,
+                    min_output_length=200),
+               dict(transitive=True, dfs=True, max_depth=0, min_transitive_len=300, min_distance_between_ranges=10)]:
+        assert_same(g, c, ranges, **kw)
+
+
+def test_deep_bfs_compacts_visited_tables(tmp_path):
+    """A chain of 70 sequences: unlimited depth walks 69 levels, more than the
+    visited-table limit, so the tables are folded on the way."""
+    n = 70
+    lines = ["S%d\t1000\t0\t500\t+\tS%d\t1000\t0\t500\t500\t500\t60\tcg:Z:500=" % (i, i + 1) for i in range(n - 1)]
+    g, c = both(tmp_path, "\n".join(lines) + "\n")
+    ranges = [(g.seq_id("S0"), 100, 400), (g.seq_id("S35"), 0, 500), (g.seq_id("S69"), 200, 450)]
+    for kw in [dict(transitive=True, max_depth=0), dict(transitive=True, dfs=True, max_depth=0),
+               dict(transitive=True, max_depth=60), dict(transitive=True, dfs=True, max_depth=65)]:
+        res = assert_same(g, c, ranges, **kw)
+    assert len(res[0]) >= 60

@@ -1,0 +1,204 @@
+// impg-gpu: the `impg query` command line (reference src/main.rs:4259-4381,
+// :6513-7520) over libimpg_gpu.so, for the BED output path.  Same flags, same
+// defaults, same validation order, same bytes on stdout; every BED row of a
+// `-b` file goes to the GPU in ONE batch instead of the reference's serial loop
+// (main.rs:7435).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/impg_gpu.h"
+
+namespace {
+
+[[noreturn]] void die(const std::string &msg, int code = 1) {
+  fprintf(stderr, "Error: %s\n", msg.c_str());
+  exit(code);
+}
+
+// clap's "-d" accepts metric suffixes (50k, 1m): main.rs parse of merge distance
+bool parse_metric(const char *s, long long *out) {
+  char *end = nullptr;
+  double v = strtod(s, &end);
+  if (end == s) return false;
+  long long mul = 1;
+  if (*end == 'k' || *end == 'K') { mul = 1000; end++; }
+  else if (*end == 'm' || *end == 'M') { mul = 1000000; end++; }
+  else if (*end == 'g' || *end == 'G') { mul = 1000000000; end++; }
+  if (*end) return false;
+  *out = (long long)llround(v * (double)mul);
+  return true;
+}
+
+struct Target {
+  std::string seq, name;
+  int32_t start, end;
+};
+
+bool parse_i32(const std::string &s, int32_t *v) {
+  if (s.empty()) return false;
+  size_t i = (s[0] == '+' || s[0] == '-') ? 1 : 0;
+  if (i >= s.size()) return false;
+  long long x = 0;
+  for (; i < s.size(); i++) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    x = x * 10 + (s[i] - '0');
+    if (x > 2147483648ll) return false;
+  }
+  if (s[0] == '-') x = -x;
+  if (x > 2147483647ll) return false;
+  *v = (int32_t)x;
+  return true;
+}
+
+// parse_bed_file (src/commands/partition.rs:1719-1750)
+std::vector<Target> parse_bed_file(const std::string &path) {
+  std::ifstream in(path);
+  if (!in) die("No such file or directory: " + path);
+  std::vector<Target> out;
+  std::string line;
+  while (std::getline(in, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    std::vector<std::string> parts;
+    size_t st = 0;
+    for (size_t i = 0; i <= line.size(); i++)
+      if (i == line.size() || line[i] == '\t') { parts.push_back(line.substr(st, i - st)); st = i + 1; }
+    if (parts.size() < 3) die("Invalid BED file format");
+    Target t;
+    if (!parse_i32(parts[1], &t.start)) die("Invalid start value");
+    if (!parse_i32(parts[2], &t.end)) die("Invalid end value");
+    if (t.start >= t.end) die("Start value must be less than end value");
+    t.seq = parts[0];
+    std::string nm;
+    if (parts.size() > 3) {
+      nm = parts[3];
+      size_t a = nm.find_first_not_of(" \t\r\n\v\f"), b = nm.find_last_not_of(" \t\r\n\v\f");
+      nm = a == std::string::npos ? "" : nm.substr(a, b - a + 1);
+    }
+    if (nm.empty() || nm == ".") nm = t.seq + ":" + std::to_string(t.start) + "-" + std::to_string(t.end);
+    t.name = nm;
+    out.push_back(t);
+  }
+  return out;
+}
+
+void usage() {
+  fprintf(stderr,
+          "impg-gpu query -a <paf>... (-r seq:start-end | -b <bed>) (-d <bp> | --no-merge) [-x] [-m N]\n"
+          "               [--transitive-dfs] [--min-transitive-len N] [--min-distance-between-ranges N]\n"
+          "               [-l N] [--min-result-identity F] [-o auto|bed] [--unidirectional] [--order coitrees|sorted]\n"
+          "               [--device N]\n");
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc < 2 || strcmp(argv[1], "query") != 0) {
+    usage();
+    return 2;
+  }
+  std::vector<std::string> pafs;
+  std::string range, bed, ofmt = "auto";
+  bool have_d = false, no_merge = false, transitive = false, dfs = false, unidirectional = false;
+  long long merge_d = 0;
+  long max_depth = 2, min_tl = -1, mdbr = 10, min_out = -1;
+  double min_ident = NAN;
+  int device = 0, order = IMPG_ORDER_COITREES;
+  for (int i = 2; i < argc; i++) {
+    std::string a = argv[i];
+    auto need = [&](const char *f) -> const char * {
+      if (i + 1 >= argc) die(std::string("a value is required for '") + f + "'", 2);
+      return argv[++i];
+    };
+    if (a == "-a" || a == "--alignment-files") {
+      pafs.push_back(need("-a"));
+      while (i + 1 < argc && argv[i + 1][0] != '-') pafs.push_back(argv[++i]);
+    } else if (a == "-r" || a == "--target-range") range = need("-r");
+    else if (a == "-b" || a == "--target-bed") bed = need("-b");
+    else if (a == "-d" || a == "--merge-distance") {
+      if (!parse_metric(need("-d"), &merge_d) || merge_d < 0 || merge_d > 2147483647ll) die("invalid value for '-d'", 2);
+      have_d = true;
+    } else if (a == "--no-merge") no_merge = true;
+    else if (a == "-x" || a == "--transitive") transitive = true;
+    else if (a == "--transitive-dfs") dfs = true;
+    else if (a == "-m" || a == "--max-depth") max_depth = atol(need("-m"));
+    else if (a == "--min-transitive-len") min_tl = atol(need(a.c_str()));
+    else if (a == "--min-distance-between-ranges") mdbr = atol(need(a.c_str()));
+    else if (a == "-l" || a == "--min-output-length") min_out = atol(need("-l"));
+    else if (a == "--min-result-identity") min_ident = atof(need(a.c_str()));
+    else if (a == "-o" || a == "--output-format") ofmt = need("-o");
+    else if (a == "--unidirectional") unidirectional = true;
+    else if (a == "--device") device = atoi(need(a.c_str()));
+    else if (a == "--order") { std::string o = need("--order"); order = o == "sorted" ? IMPG_ORDER_SORTED : IMPG_ORDER_COITREES; }
+    else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbose" || a == "-i" || a == "--index") need(a.c_str());  // accepted, unused
+    else if (a == "-h" || a == "--help") { usage(); return 0; }
+    else die("unexpected argument '" + a + "'", 2);
+  }
+  if (pafs.empty()) die("the following required arguments were not provided: --alignment-files", 2);
+  if (range.empty() == bed.empty()) die("exactly one of --target-range and --target-bed is required", 2);
+  if (!have_d && !no_merge)  // MERGE_DISTANCE_REQUIRED_TEXT (main.rs:4288-4315)
+    die("-d/--merge-distance is required. For `impg query`, pass `-d <bp>`. Use `--no-merge` to explicitly disable merging.");
+  const int32_t merge_distance = no_merge ? -1 : (int32_t)merge_d;
+  if (max_depth < 0 || max_depth > 65535) die("invalid value for '--max-depth'", 2);
+  // -o auto: bed for -r, bedpe for -b (main.rs:7365-7373); only BED is built
+  std::string fmt = ofmt == "auto" ? (bed.empty() ? "bed" : "bedpe") : ofmt;
+  if (fmt != "bed") die("output format '" + fmt + "' is not built in impg-gpu yet (use -o bed)");
+
+  std::vector<const char *> pp;
+  for (auto &p : pafs) pp.push_back(p.c_str());
+  impg_gpu_index_t *ix = nullptr;
+  if (impg_gpu_index_create_from_paf(pp.data(), (int)pp.size(), unidirectional ? 0 : 1, order, device, &ix) != IMPG_OK)
+    die(impg_gpu_last_error());
+
+  std::vector<Target> targets;
+  if (!range.empty()) {
+    char name[4096];
+    int32_t s, e;
+    if (impg_gpu_parse_target_range(range.c_str(), name, sizeof name, &s, &e) != IMPG_OK) die(impg_gpu_last_error());
+    targets.push_back({name, std::string(name) + ":" + std::to_string(s) + "-" + std::to_string(e), s, e});
+  } else {
+    targets = parse_bed_file(bed);
+  }
+  const int32_t eff_min_tl = min_tl < 0 ? 101 : (int32_t)min_tl;  // effective_min_transitive_len (main.rs:4283)
+  std::vector<impg_gpu_range_t> ranges;
+  std::vector<const char *> names;
+  for (auto &t : targets) {
+    // validate_sequence_range (main.rs:10458-10520), validate_range_min_length (:10387-10403), perform_query bound (:11632)
+    long long id = impg_gpu_seq_id(ix, t.seq.c_str());
+    if (id < 0) die("Sequence '" + t.seq + "' not found in index");
+    long long len = impg_gpu_seq_len(ix, (uint32_t)id);
+    if (t.start < 0) die("Start position " + std::to_string(t.start) + " cannot be negative");
+    if (t.end < 0) die("End position " + std::to_string(t.end) + " cannot be negative");
+    if (t.start >= t.end) die("Start position must be less than end position");
+    if (t.end > len) die("End position " + std::to_string(t.end) + " exceeds sequence length " + std::to_string(len));
+    if (t.end - t.start < eff_min_tl)
+      die("Range '" + t.name + "' (" + std::to_string(t.end - t.start) + " bp) is below minimum of " +
+          std::to_string(eff_min_tl) + " bp. Lower --min-transitive-len or use a longer range");
+    ranges.push_back({(uint32_t)id, t.start, t.end});
+    names.push_back(t.name.c_str());
+  }
+  impg_gpu_params_t p;
+  memset(&p, 0, sizeof p);
+  p.transitive = transitive || dfs;  // --transitive-dfs implies a transitive query
+  p.dfs = dfs;
+  p.max_depth = (uint32_t)max_depth;
+  p.min_transitive_len = eff_min_tl;
+  p.min_distance_between_ranges = (int32_t)mdbr;
+  p.min_output_length = min_out < 0 ? -1 : (int32_t)min_out;
+  p.min_identity = min_ident;
+  p.store_cigar = 0;  // BED (main.rs:7447)
+  impg_gpu_results_t *res = nullptr;
+  if (impg_gpu_query_batch(ix, ranges.data(), ranges.size(), &p, &res) != IMPG_OK) die(impg_gpu_last_error());
+  char *text = nullptr;
+  size_t len = 0;
+  if (impg_gpu_results_bed(res, ix, names.data(), &p, merge_distance, &text, &len) != IMPG_OK) die(impg_gpu_last_error());
+  fwrite(text, 1, len, stdout);
+  free(text);
+  impg_gpu_results_free(res);
+  impg_gpu_index_destroy(ix);
+  return 0;
+}

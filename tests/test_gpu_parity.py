@@ -281,3 +281,38 @@ def test_deep_bfs_compacts_visited_tables(tmp_path):
                dict(transitive=True, max_depth=60), dict(transitive=True, dfs=True, max_depth=65)]:
         res = assert_same(g, c, ranges, **kw)
     assert len(res[0]) >= 60
+
+
+def test_cli_bed_bytes(tmp_path):
+    """`impg-gpu query` prints the bytes the reference's `impg query -o bed` would (oracle restatement)."""
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(impg_amd.__file__), "impg-gpu")
+    text, names = random_paf(61, 300, n_seq=5, seq_len=30000, self_aln=True)
+    paf = str(tmp_path / "c.paf")
+    with open(paf, "w") as f:
+        f.write(text)
+    c = o.OracleIndex(paf_paths=[paf], preparse=True)
+    rl = random_ranges(9, 25, 5, 30000, max_len=4000, min_len=150)
+    bed = str(tmp_path / "q.bed")
+    with open(bed, "w") as f:
+        for i, (t, s, e) in enumerate(rl):
+            f.write("%s\t%d\t%d%s\n" % (c.seq_name(t), s, e, "" if i % 3 == 0 else ("\tname%d" % i if i % 3 == 1 else "\t.")))
+    rnames = [("%s:%d-%d" % (c.seq_name(t), s, e)) if i % 3 != 1 else "name%d" % i for i, (t, s, e) in enumerate(rl)]
+    cases = [(["-d", "1000"], dict(), 1000), (["-d", "0", "-x", "-m", "3"], dict(transitive=True, max_depth=3), 0),
+             (["--no-merge", "-x"], dict(transitive=True), -1),
+             (["-d", "5k", "--transitive-dfs", "-m", "2", "-l", "300"], dict(transitive=True, dfs=True, max_depth=2, min_output_length=300), 5000),
+             (["-d", "10", "--min-result-identity", "0.6", "-l", "500"], dict(min_identity=0.6, min_output_length=500), 10)]
+    for flags, kw, d in cases:
+        r = subprocess.run([cli, "query", "-a", paf, "-b", bed, "-o", "bed"] + flags, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        want = "".join(c.query_bed(c.seq_name(t), s, e, range_name=rnames[i], merge_distance=d, **kw) for i, (t, s, e) in enumerate(rl))
+        assert r.stdout == want, flags
+    # -r form and the validation errors of main.rs:10387-10520
+    t, s, e = rl[0]
+    r = subprocess.run([cli, "query", "-a", paf, "-r", "%s:%d-%d" % (c.seq_name(t), s, e), "-d", "100"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == c.query_bed(c.seq_name(t), s, e, merge_distance=100)
+    for bad in (["-r", "nope:1-500", "-d", "0"], ["-r", "%s:0-50" % c.seq_name(0), "-d", "0"], ["-r", "%s:0-500" % c.seq_name(0)],
+                ["-r", "%s:0-99999999" % c.seq_name(0), "-d", "0"], ["-b", bed, "-d", "0"]):
+        r = subprocess.run([cli, "query", "-a", paf] + bad, capture_output=True, text=True)
+        assert r.returncode != 0 and r.stdout == "" and r.stderr.startswith("Error:")

@@ -128,3 +128,17 @@ def test_bed_merge_matches_oracle(seed):
             got = gi.bed_merge(iv, d, ms)
             want = o.bed_merge(iv.astype(o.INTERVAL_DTYPE), d, ms)
             assert got.tolist() == want.tolist(), (d, ms)
+
+
+def test_cli_fails_loudly_without_gpu(tmp_path):
+    import subprocess
+    if impg_amd.lib().impg_gpu_device_count() > 0:
+        pytest.skip("GPU present")
+    cli = os.path.join(ROOT, "impg_amd", "impg-gpu")
+    paf = tmp_path / "t.paf"
+    paf.write_text("A\t1000\t0\t100\t+\tB\t1000\t0\t100\t100\t100\t60\tcg:Z:100=\n")
+    r = subprocess.run([cli, "query", "-a", str(paf), "-r", "A:0-100", "-d", "0", "--min-transitive-len", "0"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and r.stdout == "" and "no HIP device" in r.stderr
+    r = subprocess.run([cli, "query", "-a", str(paf), "-r", "A:0-100"], capture_output=True, text=True)
+    assert r.returncode != 0 and "merge-distance is required" in r.stderr

@@ -405,9 +405,11 @@ __device__ __forceinline__ void ident_reset(IdentScan &id) {
   id.first_adj_m = id.first_adj_x = id.last_adj_m = id.last_adj_x = 0;
 }
 
-// literal walk over tiles A..B in effective order, one op at a time (rare path)
+// literal walk over tiles A..B in effective order, one op at a time (rare path).
+// Inlined on purpose: as a call it forced the whole PairCtx through scratch
+// memory for EVERY pair (48 B/lane of extra HBM writes), not only the rare ones.
 template <bool IDENT>
-__device__ __noinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32_t B, IdentScan &id) {
+__device__ __forceinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32_t B, IdentScan &id) {
   TileScan s;
   s.found = false;
   s.pqs = s.pts = s.pqe = s.pte = -1;

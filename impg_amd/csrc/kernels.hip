@@ -516,7 +516,13 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         const uint32_t A = c.flip ? c.m - 1 - kA : kA, B = c.flip ? c.m - 1 - kB : kB;  // original tile indices
         uint4 ha = make_uint4(0, 0, 0, 0), hb = ha;
         if (!start_cov) ha = tile_header(c, A);
+#ifdef IMPG_PREFETCH_B
         if (!end_cov && (start_cov || A != B)) hb = tile_header(c, B);  // both lines in flight before any scan
+#else
+        // tile B's line is requested only when its scan starts: fetched earlier it is
+        // often evicted from L2 again before the scan of A is over (measured refetch)
+        if (!end_cov && start_cov) hb = tile_header(c, B);
+#endif
         TileScan sa, sb;
         sa.found = false;
         sa.pqs = sa.pts = sa.pqe = sa.pte = -1;
@@ -540,6 +546,9 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
           sb = sa;  // one tile holds both ends: its scan recorded the last overlapping op too
           ib = ia;
         } else {
+#ifndef IMPG_PREFETCH_B
+          if (!start_cov) hb = tile_header(c, B);
+#endif
           scan_tile<IDENT>(c, B, hb, sb, ib);
         }
         if (sa.found && sb.found) {

@@ -32,12 +32,15 @@ constexpr uint32_t OP_LEN_MASK = (1u << 29) - 1;
 constexpr uint32_t OP_PAD = 0xFFFFFFFFu;  // tile padding, never a valid op (code 7)
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 
-// One 128-byte line per tile: a 16-byte header {T0, Q0, sumT, sumQ} -- the sums of
-// target_delta / |query_delta| of the record's ops before the tile and inside it --
-// followed by 28 packed ops.  A tile is self-describing: the running positions at
-// either end follow from its own line.
+// One 128-byte line per tile: a 24-byte header {T0, Q0, sumT, sumQ, Tm, Qm} -- the
+// sums of target_delta / |query_delta| of the record's ops before the tile, inside
+// it, and before its op 10 -- followed by 26 packed ops.  A tile is
+// self-describing (running positions at either end and at the split follow from
+// its own line) and splits into two sub-tiles on 16-byte boundaries: ops 0..9
+// (words 6..15) and ops 10..25 (words 16..31); a scan walks one sub-tile.
 constexpr uint32_t TILE_WORDS = 32;
-constexpr uint32_t TILE_OPS = 28;
+constexpr uint32_t TILE_OPS = 26;
+constexpr uint32_t TILE_LOW_OPS = 10;
 constexpr uint32_t INLINE_TILES = 8;      // entries of records with <= 8 tiles carry their checkpoints inline
 
 // ---- device index (HBM layout) ---------------------------------------------
@@ -81,7 +84,7 @@ struct DeviceIndexView {  // passed by value to kernels
   const Entry *entries;      // [n_entries]
   const uint32_t *ops;       // [n_tiles*32] tiles
   const uint32_t *ext_cp;    // effective target prefixes of entries with > 8 tiles
-  const uint4 *idp;          // [n_tiles] matched bases, mismatched bases, gap ops of the record before each tile
+  const uint4 *idp;          // [2*n_tiles] matched bases, mismatched bases, gap ops of the record before each sub-tile
   const int32_t *seq_len;    // [n_seq]
   uint32_t n_seq;
   uint32_t n_entries;

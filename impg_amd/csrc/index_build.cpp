@@ -114,7 +114,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     if (n_tiles >= (1ull << 32) - 2) throw Error{IMPG_E_UNSUPPORTED, "op pool exceeds 2^32 tiles"};
   }
   std::vector<uint32_t> pool(n_tiles * TILE_WORDS, OP_PAD);
-  std::vector<uint4> idp(n_tiles);  // per tile: matched / mismatched bases and gap ops before it (identity filter)
+  std::vector<uint4> idp(2 * n_tiles);  // per sub-tile: matched / mismatched bases and gap ops before it (identity filter)
   std::atomic<bool> bad_op{false};
   parallel_chunks(n_records, [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; i++) {
@@ -123,18 +123,29 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
       const uint32_t n = records[i].cigar_len;
       uint32_t st = 0, sq = 0, sm = 0, sx = 0, sg = 0;
       for (uint32_t k0 = 0; k0 < n; k0 += TILE_OPS) {
-        uint32_t *line = pool.data() + ((size_t)tile_base[i] + k0 / TILE_OPS) * TILE_WORDS;
-        idp[(size_t)tile_base[i] + k0 / TILE_OPS] = make_uint4(sm, sx, sg, 0);
+        const size_t tile = (size_t)tile_base[i] + k0 / TILE_OPS;
+        uint32_t *line = pool.data() + tile * TILE_WORDS;
+        idp[2 * tile] = make_uint4(sm, sx, sg, 0);
         uint32_t t0 = st, q0 = sq;
+        bool mid_set = false;
         for (uint32_t k = k0; k < std::min(n, k0 + TILE_OPS); k++) {
+          if (k - k0 == TILE_LOW_OPS) {  // prefix before the upper sub-tile
+            line[4] = st; line[5] = sq;
+            idp[2 * tile + 1] = make_uint4(sm, sx, sg, 0);
+            mid_set = true;
+          }
           uint32_t v = src[k], code = v >> 29, len = v & OP_LEN_MASK;
           if (code > 4) bad_op = true;  // CigarOp::new panics (impg.rs:88)
-          line[4 + (k - k0)] = v;
+          line[6 + (k - k0)] = v;
           if (code != 2) st += len;  // target_delta: all but 'I' (impg.rs:115-121)
           if (code != 3) sq += len;  // |query_delta|: all but 'D' (impg.rs:123-135)
           if (code == 0 || code == 4) sm += len;       // 'M' counted as match (impg.rs:2959)
           else if (code == 1) sx += len;
           else sg += 1;                                 // gap-compressed: one per 'I' / 'D' op
+        }
+        if (!mid_set) {  // <= 10 ops: the upper sub-tile is empty and starts at the tile's end
+          line[4] = st; line[5] = sq;
+          idp[2 * tile + 1] = make_uint4(sm, sx, sg, 0);
         }
         line[0] = t0; line[1] = q0; line[2] = st - t0; line[3] = sq - q0;
       }

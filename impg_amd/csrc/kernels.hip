@@ -368,28 +368,62 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
   Qn += qa;
 }
 
-// running positions at the effective start of original tile j, from the tile's own header
-__device__ __forceinline__ void tile_start(const PairCtx &c, const uint4 hdr, int32_t &T, int32_t &Qn) {
-  const uint32_t t0 = c.swp ? hdr.y : hdr.x, q0 = c.swp ? hdr.x : hdr.y;
-  const uint32_t st = c.swp ? hdr.w : hdr.z, sq = c.swp ? hdr.z : hdr.w;
-  T = c.ts + (int32_t)(c.flip ? c.totT - (t0 + st) : t0);
-  Qn = (int32_t)(c.flip ? c.totQ - (q0 + sq) : q0);
+// A sub-tile: original tile j, half h (0 = ops 0..9, 1 = ops 10..25).
+struct SubTile {
+  uint32_t j, h;
+};
+__device__ __forceinline__ bool same_sub(const SubTile &a, const SubTile &b) { return a.j == b.j && a.h == b.h; }
+
+struct TileHdr {  // the line header, in the ENTRY's axes
+  uint32_t t0, q0, st, sq, tm, qm;
+};
+__device__ __forceinline__ TileHdr tile_header(const PairCtx &c, uint32_t j) {
+  const uint32_t *line = c.ops + (size_t)j * TILE_WORDS;
+  const uint4 a = *reinterpret_cast<const uint4 *>(line);
+  const uint2 b = *reinterpret_cast<const uint2 *>(line + 4);
+  TileHdr h;
+  h.t0 = c.swp ? a.y : a.x; h.q0 = c.swp ? a.x : a.y;
+  h.st = c.swp ? a.w : a.z; h.sq = c.swp ? a.z : a.w;
+  h.tm = c.swp ? b.y : b.x; h.qm = c.swp ? b.x : b.y;
+  return h;
+}
+// target position at which the tile's SECOND effective sub-tile starts
+__device__ __forceinline__ int32_t tile_mid_T(const PairCtx &c, const TileHdr &h) {
+  return c.ts + (int32_t)(c.flip ? c.totT - h.tm : h.tm);
+}
+// running positions at the effective start of sub-tile (j, half)
+__device__ __forceinline__ void sub_start(const PairCtx &c, const TileHdr &h, uint32_t half, int32_t &T, int32_t &Qn) {
+  uint32_t t, q;
+  if (!c.flip) { t = half ? h.tm : h.t0; q = half ? h.qm : h.q0; }
+  else { t = c.totT - (half ? h.t0 + h.st : h.tm); q = c.totQ - (half ? h.q0 + h.sq : h.qm); }
+  T = c.ts + (int32_t)t;
+  Qn = (int32_t)q;
 }
 
-constexpr int TILE_DVEC = TILE_OPS / 4;  // 7 data vectors after the header vector
-// Scan one tile in effective order, streaming its line 16 bytes (4 ops) at a time
-// with the next vector in flight.  Reverse-strand reversed entries walk the tile
-// back to front: descending vector index and reversed components.
+// Scan one sub-tile in effective order, 16 bytes (4 ops) at a time with the next
+// vector in flight.  Lanes of a wave scan different halves, so the loop is the
+// same for both: 4 vector slots; the lower half fills 3 of them (its first vector
+// also carries two header words, masked to padding).  Reverse-strand reversed
+// entries walk back to front: descending vector index, reversed components.
 template <bool IDENT>
-__device__ __forceinline__ void scan_tile(const PairCtx &c, uint32_t j, const uint4 hdr, TileScan &s, IdentScan &id) {
+__device__ __forceinline__ void scan_sub(const PairCtx &c, const SubTile &t, const TileHdr &hdr, TileScan &s, IdentScan &id) {
   int32_t T, Qn;
-  tile_start(c, hdr, T, Qn);
-  const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)j * TILE_WORDS);
-  uint4 cur = q[c.flip ? TILE_DVEC : 1];
+  sub_start(c, hdr, t.h, T, Qn);
+  const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)t.j * TILE_WORDS);
+  // vector index of slot `it`: upper half 4..7, lower half 1..3 (+ one empty slot)
+  const int base = t.h ? (c.flip ? 7 : 4) : (c.flip ? 3 : 1);
+  const int step = c.flip ? -1 : 1;
+  const int nvec = t.h ? 4 : 3;
+  uint4 cur = q[base];
+  if (base == 1) cur.x = cur.y = OP_PAD;  // words 4,5 are header
 #pragma unroll 1
-  for (int k = 0; k < TILE_DVEC; k++) {
-    uint4 nxt = cur;
-    if (k + 1 < TILE_DVEC) nxt = q[c.flip ? TILE_DVEC - 1 - k : k + 2];
+  for (int it = 0; it < 4; it++) {
+    const int ni = base + (it + 1) * step;
+    uint4 nxt = make_uint4(OP_PAD, OP_PAD, OP_PAD, OP_PAD);
+    if (it + 1 < nvec) {
+      nxt = q[ni];
+      if (ni == 1) nxt.x = nxt.y = OP_PAD;
+    }
     op_step<IDENT>(c.flip ? cur.w : cur.x, c, T, Qn, s, id);
     op_step<IDENT>(c.flip ? cur.z : cur.y, c, T, Qn, s, id);
     op_step<IDENT>(c.flip ? cur.y : cur.z, c, T, Qn, s, id);
@@ -397,15 +431,12 @@ __device__ __forceinline__ void scan_tile(const PairCtx &c, uint32_t j, const ui
     cur = nxt;
   }
 }
-__device__ __forceinline__ uint4 tile_header(const PairCtx &c, uint32_t j) {
-  return *reinterpret_cast<const uint4 *>(c.ops + (size_t)j * TILE_WORDS);
-}
 __device__ __forceinline__ void ident_reset(IdentScan &id) {
   id.rm = id.rx = id.rg = id.fm = id.fx = id.fg = id.lm = id.lx = id.lg = 0;
   id.first_adj_m = id.first_adj_x = id.last_adj_m = id.last_adj_x = 0;
 }
 
-// literal walk over tiles A..B in effective order, one op at a time (rare path).
+// literal walk over whole tiles A..B in effective order, one op at a time (rare path).
 // Inlined on purpose: as a call it forced the whole PairCtx through scratch
 // memory for EVERY pair (48 B/lane of extra HBM writes), not only the rare ones.
 template <bool IDENT>
@@ -415,10 +446,10 @@ __device__ __forceinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uin
   s.pqs = s.pts = s.pqe = s.pte = -1;
   ident_reset(id);
   int32_t T, Qn;
-  tile_start(c, tile_header(c, A), T, Qn);
+  sub_start(c, tile_header(c, A), c.flip ? 1u : 0u, T, Qn);  // the tile's first sub-tile in walking order
   const int stepj = c.flip ? -1 : 1;
   for (int64_t j = A;; j += stepj) {
-    const uint32_t *tp = c.ops + (size_t)j * TILE_WORDS + 4;
+    const uint32_t *tp = c.ops + (size_t)j * TILE_WORDS + 6;
     for (int u = 0; u < (int)TILE_OPS && T <= c.last_tp; u++) {
       uint32_t op = tp[c.flip ? (int)TILE_OPS - 1 - u : u];
       op_step<IDENT>(op, c, T, Qn, s, id);
@@ -514,15 +545,9 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
       if (cA < c.m && cB >= 1 && cA <= cB - 1) {
         const uint32_t kA = cA, kB = cB - 1;                       // effective tile indices
         const uint32_t A = c.flip ? c.m - 1 - kA : kA, B = c.flip ? c.m - 1 - kB : kB;  // original tile indices
-        uint4 ha = make_uint4(0, 0, 0, 0), hb = ha;
-        if (!start_cov) ha = tile_header(c, A);
-#ifdef IMPG_PREFETCH_B
-        if (!end_cov && (start_cov || A != B)) hb = tile_header(c, B);  // both lines in flight before any scan
-#else
-        // tile B's line is requested only when its scan starts: fetched earlier it is
-        // often evicted from L2 again before the scan of A is over (measured refetch)
-        if (!end_cov && start_cov) hb = tile_header(c, B);
-#endif
+        // refine to sub-tiles with the tiles' own headers: the first overlapping op
+        // is in A's first effective half iff that half's end prefix reaches R0; the
+        // last live op is in B's second effective half iff that half starts <= last_tp
         TileScan sa, sb;
         sa.found = false;
         sa.pqs = sa.pts = sa.pqe = sa.pte = -1;
@@ -531,50 +556,68 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         ident_reset(ia);
         ident_reset(ib);
         bool walked = false;
+        SubTile subA{A, 0}, subB{B, 0};
+        TileHdr ha, hb;
+        if (!start_cov) {
+          ha = tile_header(c, A);
+          const uint32_t cntA = min(TILE_OPS, n - A * TILE_OPS);
+          const bool upperA = cntA > TILE_LOW_OPS;  // the upper sub-tile holds ops
+          const bool first_half = (c.flip ? upperA : true) && tile_mid_T(c, ha) >= c.R0;
+          const uint32_t he = first_half ? 0u : 1u;        // effective half
+          subA.h = c.flip ? 1u - he : he;                  // original half
+          if (!c.flip && he == 1u && !upperA) subA.h = 0u; // (cannot happen: the tile end prefix >= R0)
+        }
         if (start_cov) {
           sa.found = true;
           sa.pqs = 0;
           sa.pts = c.ts;
         } else {
-          scan_tile<IDENT>(c, A, ha, sa, ia);
+          scan_sub<IDENT>(c, subA, ha, sa, ia);
+        }
+        bool same = false;
+        if (!end_cov) {
+          hb = (!start_cov && A == B) ? ha : tile_header(c, B);  // requested only now (see IMPG note on refetch)
+          const uint32_t cntB = min(TILE_OPS, n - B * TILE_OPS);
+          const bool upperB = cntB > TILE_LOW_OPS;
+          const bool second_half = (c.flip ? true : upperB) && tile_mid_T(c, hb) <= c.last_tp;
+          const uint32_t he = second_half ? 1u : 0u;
+          subB.h = c.flip ? 1u - he : he;
+          same = !start_cov && same_sub(subA, subB);
         }
         if (end_cov) {
           sb.found = true;
           sb.pqe = (int32_t)c.totQ;
           sb.pte = en_te;
-        } else if (!start_cov && A == B) {
-          sb = sa;  // one tile holds both ends: its scan recorded the last overlapping op too
+        } else if (same) {
+          sb = sa;  // one sub-tile holds both ends: its scan recorded the last overlapping op too
           ib = ia;
         } else {
-#ifndef IMPG_PREFETCH_B
-          if (!start_cov) hb = tile_header(c, B);
-#endif
-          scan_tile<IDENT>(c, B, hb, sb, ib);
+          scan_sub<IDENT>(c, subB, hb, sb, ib);
         }
         if (sa.found && sb.found) {
           res.found = true;
           res.pqs = sa.pqs; res.pts = sa.pts;
           res.pqe = sb.pqe; res.pte = sb.pte;
-        } else if (!start_cov && !end_cov && A == B) {
-          res.found = false;  // every overlapping op would lie in this tile
+        } else if (!start_cov && !end_cov && same) {
+          res.found = false;  // every overlapping op would lie in this sub-tile
         } else {
           res = walk_tiles<IDENT>(c, A, B, ia);
           walked = true;
         }
         if (IDENT && res.found) {
           // op counts of the slice [first op, last op] in ORIGINAL op order:
-          //   forward walk : prefix(B) + lastB  -  (prefix(A) + firstA)
-          //   backward walk: (prefix(A) + total(A) - firstA) - (prefix(B) + total(B) - lastB)
-          // where prefix(j) = matched / mismatched bases and gap ops before tile j (idp[])
+          //   forward walk : prefix(subB) + lastB  -  (prefix(subA) + firstA)
+          //   backward walk: (prefix(subA) + total(subA) - firstA) - (prefix(subB) + total(subB) - lastB)
+          // where prefix(s) = matched / mismatched bases and gap ops before sub-tile s (idp[])
           // and firstA / lastB are the walking-order running sums snapshotted by op_step.
           int64_t M, X, G;
-          if (walked || A == B) {  // one continuous walk: plain difference of its running sums
+          if (walked || same) {  // one continuous walk: plain difference of its running sums
             const IdentScan &w = ia;
             M = (int64_t)w.lm - w.fm; X = (int64_t)w.lx - w.fx; G = (int64_t)w.lg - w.fg;
             M += -(int64_t)w.first_adj_m + w.last_adj_m;
             X += -(int64_t)w.first_adj_x + w.last_adj_x;
           } else {
-            const uint4 pa = v.idp[e1.y + A], pb = v.idp[e1.y + B];
+            const uint4 pa = v.idp[2 * ((size_t)e1.y + subA.j) + subA.h], pb = v.idp[2 * ((size_t)e1.y + subB.j) + subB.h];
             if (!c.flip) {
               M = ((int64_t)pb.x + ib.lm) - ((int64_t)pa.x + ia.fm);
               X = ((int64_t)pb.y + ib.lx) - ((int64_t)pa.y + ia.fx);

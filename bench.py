@@ -141,6 +141,14 @@ def main():
     ms_project = sum(s.ms_project for s in stats)
     launches = sum(s.project_launches for s in stats)
     ach = (sum(s.projected for s in stats) * ALG_BYTES_PER_PROJECTION) / (ms_project * 1e-3) / 1e9 if ms_project > 0 else 0.0
+    # HBM bytes per projection measured with rocprofv3 PMC passes of this same command
+    # (scripts/profile_r1.sh -> profiles/r1_v2_traffic.json; FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_v2_traffic.json")
+    if os.path.exists(tpath) and launches:
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = tj["hbm_bytes_per_pair"] * (sum(s.pairs for s in stats) or sum(s.projected for s in stats)) / launches
     out = {
         "metric": "projected ranges/sec, 1M-PAF 100k-BED -x depth 3; CPU coitrees baseline",
         "value": projected_total / dt,
@@ -175,7 +183,10 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "project_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_note": "bytes per launch = rocprofv3 (FETCH_SIZE x2 [gfx950] + WRITE_SIZE) per pair, from "
+                            "profiles/r1_v2_traffic.json, x pairs per launch of this run",
+            "achieved_traffic_GBs": (traffic / (ms_project / launches * 1e-3) / 1e9) if (traffic and ms_project) else None,
             "algorithmic_bytes_per_projection": ALG_BYTES_PER_PROJECTION,
             "launches": launches,
             "avg_launch_ms": ms_project / launches if launches else None,

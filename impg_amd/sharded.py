@@ -104,6 +104,9 @@ class ShardedImpg:
         self.device = device if device is not None else torch.device("cpu")
         self.chunk_ranges = chunk_ranges
         self.local = getattr(backend, "index", None)
+        # collectives run on the compute device (RCCL) unless the process group is
+        # gloo, which moves host memory: then tensors hop through the CPU
+        self.comm_device = self.device if dist.get_backend() != "gloo" else torch.device("cpu")
 
     @classmethod
     def from_paf(cls, paths, rank, world, device=0, **kw):
@@ -115,20 +118,20 @@ class ShardedImpg:
         """rows grouped by destination rank (send_counts[d] rows each) -> rows
         received, grouped by source rank, and the per-source counts."""
         W = self.world
-        sc = torch.as_tensor(send_counts, dtype=torch.int64, device=self.device)
+        sc = torch.as_tensor(send_counts, dtype=torch.int64, device=self.comm_device)
         gathered = [torch.empty_like(sc) for _ in range(W)]
         dist.all_gather(gathered, sc)  # every rank learns the full W x W count matrix
         mat = torch.stack(gathered).cpu()
         recv_counts = mat[:, self.rank].tolist()
-        out = torch.empty((int(sum(recv_counts)), rows.shape[1]), dtype=rows.dtype, device=self.device)
+        out = torch.empty((int(sum(recv_counts)), rows.shape[1]), dtype=rows.dtype, device=self.comm_device)
         cols = rows.shape[1]
-        dist.all_to_all_single(out.view(-1), rows.contiguous().view(-1),
+        dist.all_to_all_single(out.view(-1), rows.contiguous().to(self.comm_device).view(-1),
                                output_split_sizes=[c * cols for c in recv_counts],
                                input_split_sizes=[int(c) * cols for c in send_counts])
-        return out, recv_counts
+        return out.to(self.device), recv_counts
 
     def _any(self, flag):
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return bool(t.item())
 
@@ -187,7 +190,7 @@ class ShardedImpg:
         return st, self_iv
 
     def _chunks(self, n):
-        n_max = torch.tensor([n], dtype=torch.int64, device=self.device)
+        n_max = torch.tensor([n], dtype=torch.int64, device=self.comm_device)
         dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
         n_chunks = max(1, -(-int(n_max.item()) // self.chunk_ranges))
         for c in range(n_chunks):

@@ -17,9 +17,11 @@ from tests.paf_gen import random_paf, random_ranges  # noqa: E402
 
 
 def main():
-    backend_name = sys.argv[1]  # "cpu" (gloo + oracle stand-in) or "gpu" (nccl + HIP engine)
+    # "cpu": gloo + oracle stand-in; "gpu": nccl (RCCL) + HIP engine; "gpu-gloo": HIP engine on
+    # every rank (ranks share the one GPU of the test box), collectives through host memory
+    backend_name = sys.argv[1]
     paf_path = sys.argv[2]
-    dist.init_process_group("gloo" if backend_name == "cpu" else "nccl")
+    dist.init_process_group("nccl" if backend_name == "gpu" else "gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     c = o.OracleIndex(paf_paths=[paf_path], preparse=True)
     n_seq = c.num_seqs()
@@ -47,7 +49,7 @@ def main():
         rt = torch.from_numpy(ranges.view(np.uint8).copy()).to(eng.device)
         st = eng.query_batch_stats(rt, n_q, p)
         # projections are counted where they are computed: compare the global sums
-        tt = torch.tensor([st.projected, total], dtype=torch.int64, device=eng.device)
+        tt = torch.tensor([st.projected, total], dtype=torch.int64, device=eng.comm_device)
         dist.all_reduce(tt)
         assert int(tt[0]) == int(tt[1]), (rank, kw, tt.tolist())
     dist.barrier()

@@ -33,3 +33,11 @@ def test_sharded_gloo(tmp_path, world):
 def test_sharded_gpu_world1(tmp_path):
     """The same orchestration on the HIP stage API with RCCL (one rank: the GPU box has one GPU)."""
     run_world(tmp_path, 1, "gpu", 29650)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gpu_multirank_over_gloo(tmp_path, world):
+    """Several ranks, each with its own shard of the index on the (single) GPU and the
+    real stage API; only the transport differs from the RCCL run (host memory)."""
+    run_world(tmp_path, world, "gpu-gloo", 29660 + world)

@@ -71,7 +71,7 @@ struct SegDesc {
   uint32_t cnt[MAX_LEVELS];
   uint32_t pad;
 };
-static_assert(sizeof(SegDesc) == 48, "segment descriptor");
+static_assert(sizeof(SegDesc) == 48 && MAX_LEVELS == 4, "segment descriptor (kernels read it as three 16-byte vectors)");
 
 struct DeviceIndexView {  // passed by value to kernels
   const SegDesc *seg;        // [n_seq] per-target segment table (replaces ForestMap)

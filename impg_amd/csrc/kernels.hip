@@ -33,57 +33,89 @@ namespace impg {
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-// Two searches at once over the same segment: first position whose start
-// satisfies ps and first position whose running-max satisfies pp (both monotone
-// false..true), d.n if none.  64-ary descent over the sampled levels: every level
-// is ONE coalesced read of up to 64 consecutive values per column -- level k
-// holds the last element of each 64-block of level k-1, so a block has a true
-// element iff its sample is true.  The two descents are independent, so their
-// loads are issued together (half the dependent round trips).
-template <class PredS, class PredP>
-__device__ __forceinline__ void seg_search2(const DeviceIndexView &v, const SegDesc &d, PredS ps, PredP pp,
-                                            uint32_t &rs, uint32_t &rp) {
+// Candidate windows of K frontier ranges at once (absolute indices).  The K
+// descents are independent; unrolled together their loads overlap, which is what
+// these latency-bound kernels need (K x the requests in flight per wave).
+template <bool TRANSITIVE, int K>
+__device__ __forceinline__ void range_windows(const DeviceIndexView &v, const FrontierRec (&f)[K], const bool (&act)[K],
+                                              uint32_t (&lo)[K], uint32_t (&ub)[K]) {
   const unsigned lane = lane_id();
-  uint32_t bs = 0, bp = 0;
-  bool ds = false, dp = false;  // decided "none"
-  for (int k = (int)d.nlev - 1; k >= 0; k--) {
-    const uint32_t cnt = d.cnt[k], off = d.off[k];
-    const uint32_t is = 64u * bs + lane, ip = 64u * bp + lane;
-    const int32_t vs = is < cnt ? v.starts_lvl[off + is] : 0;
-    const int32_t vp = ip < cnt ? v.pmax_lvl[off + ip] : 0;
-    const bool qs_ = is < cnt ? ps(vs) : true, qp_ = ip < cnt ? pp(vp) : true;
-    const unsigned fs = __ffsll((long long)__ballot(qs_)) - 1;  // lanes past the end are set: f < 64
-    const unsigned fp = __ffsll((long long)__ballot(qp_)) - 1;
-    if (64u * bs + fs >= cnt) ds = true;  // no sample true: nothing below is
-    if (64u * bp + fp >= cnt) dp = true;
-    bs = ds ? 0 : 64u * bs + fs;
-    bp = dp ? 0 : 64u * bp + fp;
+  // per-range segment descriptor in plain scalars (one array per field, indexed by
+  // the unrolled k only): anything indexed by the run-time level would be demoted
+  // to scratch memory
+  uint32_t da[K], dn[K], dl[K], o0[K], o1[K], o2[K], o3[K], c0[K], c1[K], c2[K], c3[K];
+  uint32_t bs[K], bp[K];
+  bool ds[K], dp[K], live[K];
+  int maxlev = 0;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    lo[k] = ub[k] = 0;
+    live[k] = act[k] && f[k].target_id < v.n_seq;
+    const uint4 *sp = reinterpret_cast<const uint4 *>(v.seg + (live[k] ? f[k].target_id : 0));
+    uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0, s2 = s0;
+    if (live[k]) { s0 = sp[0]; s1 = sp[1]; s2 = sp[2]; }
+    da[k] = s0.x; dn[k] = s0.y; dl[k] = s0.z;
+    o0[k] = s0.w; o1[k] = s1.x; o2[k] = s1.y; o3[k] = s1.z;
+    c0[k] = s1.w; c1[k] = s2.x; c2[k] = s2.y; c3[k] = s2.z;
+    live[k] = live[k] && dn[k] != 0;
+    if (!live[k]) dl[k] = 0;
+    bs[k] = bp[k] = 0;
+    ds[k] = dp[k] = false;
+    maxlev = max(maxlev, (int)dl[k]);
   }
-  const uint32_t is = 64u * bs + lane, ip = 64u * bp + lane;
-  const int32_t vs = is < d.n ? v.starts[d.a + is] : 0;
-  const int32_t vp = ip < d.n ? v.pmax[d.a + ip] : 0;
-  const bool qs_ = is < d.n ? ps(vs) : true, qp_ = ip < d.n ? pp(vp) : true;
-  const uint32_t as = 64u * bs + (__ffsll((long long)__ballot(qs_)) - 1);
-  const uint32_t ap = 64u * bp + (__ffsll((long long)__ballot(qp_)) - 1);
-  rs = (ds || as >= d.n) ? d.n : as;
-  rp = (dp || ap >= d.n) ? d.n : ap;
-}
-
-// candidate window of one frontier range inside its target's segment (absolute indices)
-template <bool TRANSITIVE>
-__device__ __forceinline__ void range_window(const DeviceIndexView &v, const FrontierRec &f, uint32_t &lo, uint32_t &ub) {
-  lo = ub = 0;
-  if (f.target_id >= v.n_seq) return;
-  const SegDesc d = v.seg[f.target_id];
-  if (d.n == 0) return;
-  const int32_t qs = f.start, qe = f.end;
-  uint32_t u, l;
-  if (TRANSITIVE)  // max(cs,first) < min(ce,last)   (impg.rs:2398-2403)
-    seg_search2(v, d, [=](int32_t s) { return s >= qe; }, [=](int32_t m) { return m > qs; }, u, l);
-  else  // coitrees closed test: first <= q_last && last >= q_first
-    seg_search2(v, d, [=](int32_t s) { return s > qe; }, [=](int32_t m) { return m >= qs; }, u, l);
-  ub = d.a + u;
-  lo = d.a + (l < u ? l : u);
+  for (int lev = maxlev - 1; lev >= 0; lev--) {
+    int32_t vs[K], vp[K];
+    bool in_s[K], in_p[K], on[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {  // issue every load of this level first
+      on[k] = lev < (int)dl[k];
+      const uint32_t cntl = lev == 0 ? c0[k] : lev == 1 ? c1[k] : lev == 2 ? c2[k] : c3[k];
+      const uint32_t offl = lev == 0 ? o0[k] : lev == 1 ? o1[k] : lev == 2 ? o2[k] : o3[k];
+      const uint32_t cnt = on[k] ? cntl : 0, off = on[k] ? offl : 0;
+      const uint32_t is = 64u * bs[k] + lane, ip = 64u * bp[k] + lane;
+      in_s[k] = is < cnt;
+      in_p[k] = ip < cnt;
+      vs[k] = in_s[k] ? v.starts_lvl[off + is] : 0;
+      vp[k] = in_p[k] ? v.pmax_lvl[off + ip] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      if (!on[k]) continue;
+      const uint32_t cnt = lev == 0 ? c0[k] : lev == 1 ? c1[k] : lev == 2 ? c2[k] : c3[k];
+      const int32_t qs = f[k].start, qe = f[k].end;
+      const bool ts_ = in_s[k] ? (TRANSITIVE ? vs[k] >= qe : vs[k] > qe) : true;
+      const bool tp_ = in_p[k] ? (TRANSITIVE ? vp[k] > qs : vp[k] >= qs) : true;
+      const unsigned fs = __ffsll((long long)__ballot(ts_)) - 1;  // lanes past the end are set: f < 64
+      const unsigned fp = __ffsll((long long)__ballot(tp_)) - 1;
+      if (64u * bs[k] + fs >= cnt) ds[k] = true;  // no sample true: nothing below is
+      if (64u * bp[k] + fp >= cnt) dp[k] = true;
+      bs[k] = ds[k] ? 0 : 64u * bs[k] + fs;
+      bp[k] = dp[k] ? 0 : 64u * bp[k] + fp;
+    }
+  }
+  int32_t vs[K], vp[K];
+  bool in_s[K], in_p[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const uint32_t is = 64u * bs[k] + lane, ip = 64u * bp[k] + lane;
+    in_s[k] = live[k] && is < dn[k];
+    in_p[k] = live[k] && ip < dn[k];
+    vs[k] = in_s[k] ? v.starts[da[k] + is] : 0;
+    vp[k] = in_p[k] ? v.pmax[da[k] + ip] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    if (!live[k]) continue;
+    const int32_t qs = f[k].start, qe = f[k].end;
+    const bool ts_ = in_s[k] ? (TRANSITIVE ? vs[k] >= qe : vs[k] > qe) : true;
+    const bool tp_ = in_p[k] ? (TRANSITIVE ? vp[k] > qs : vp[k] >= qs) : true;
+    const uint32_t as = 64u * bs[k] + (__ffsll((long long)__ballot(ts_)) - 1);
+    const uint32_t ap = 64u * bp[k] + (__ffsll((long long)__ballot(tp_)) - 1);
+    const uint32_t u = (ds[k] || as >= dn[k]) ? dn[k] : as;
+    const uint32_t l = (dp[k] || ap >= dn[k]) ? dn[k] : ap;
+    ub[k] = da[k] + u;
+    lo[k] = da[k] + (l < u ? l : u);
+  }
 }
 template <bool TRANSITIVE>
 __device__ __forceinline__ bool overlaps(int32_t ts, int32_t te, int32_t qs, int32_t qe) {
@@ -98,23 +130,46 @@ template <bool TRANSITIVE>
 __global__ __launch_bounds__(256) void lookup_count_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
                                                            uint32_t n, uint32_t *__restrict__ cnt,
                                                            uint2 *__restrict__ win) {
+  constexpr int K = 4;  // ranges in flight per wave
   const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * 256u) >> 6;
   const unsigned lane = lane_id();
-  for (uint32_t r = wave; r < n; r += nwaves) {
-    FrontierRec f = fr[r];
-    uint32_t lo, ub;
-    range_window<TRANSITIVE>(v, f, lo, ub);
-    uint32_t c = 0;
-    for (uint32_t base = lo; base < ub; base += 64u) {
-      uint32_t i = base + lane;
-      bool hit = false;
-      if (i < ub) hit = overlaps<TRANSITIVE>(v.starts[i], v.ends[i], f.start, f.end);
-      c += __popcll(__ballot(hit));
+  for (uint32_t r0 = wave * K; r0 < n; r0 += nwaves * K) {
+    FrontierRec f[K];
+    bool act[K];
+    uint32_t lo[K], ub[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      act[k] = r0 + k < n;
+      if (act[k]) f[k] = fr[r0 + k];
+      else { f[k].target_id = 0xFFFFFFFFu; f[k].start = f[k].end = 0; f[k].qidx = 0; }
     }
-    if (lane == 0) {
-      cnt[r] = c;
-      win[r] = make_uint2(lo, ub);
+    range_windows<TRANSITIVE, K>(v, f, act, lo, ub);
+    // windows: first chunk of every range loaded together, rare further chunks one by one
+    int32_t ws[K], we[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint32_t i = lo[k] + lane;
+      const bool in = i < ub[k];
+      ws[k] = in ? v.starts[i] : 0;
+      we[k] = in ? v.ends[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      if (!act[k]) continue;
+      const uint32_t i = lo[k] + lane;
+      bool hit = i < ub[k] && overlaps<TRANSITIVE>(ws[k], we[k], f[k].start, f[k].end);
+      uint32_t c = __popcll(__ballot(hit));
+      for (uint32_t base = lo[k] + 64u; base < ub[k]; base += 64u) {
+        const uint32_t i2 = base + lane;
+        bool h2 = false;
+        if (i2 < ub[k]) h2 = overlaps<TRANSITIVE>(v.starts[i2], v.ends[i2], f[k].start, f[k].end);
+        c += __popcll(__ballot(h2));
+      }
+      if (lane == 0) {
+        cnt[r0 + k] = c;
+        win[r0 + k] = make_uint2(lo[k], ub[k]);
+      }
     }
   }
 }
@@ -169,10 +224,10 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
           rk2 = hit2 ? v.rank[i2] : 0xFFFFFFFFu;
         }
         unsigned long long m = __ballot(hit2);
-        while (m) {
-          int j = __ffsll((long long)m) - 1;
+        while (m) {  // m is wave-uniform: the lane index can live in an SGPR (v_readlane, no LDS round trip)
+          const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
           m &= m - 1;
-          uint32_t rj = (uint32_t)__shfl((int)rk2, j);
+          const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)rk2, j);
           pos += rj < rk;
         }
       }

@@ -395,12 +395,12 @@ int impg_gpu_stage_count(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fron
   if (n >= (1ull << 32) - 16) throw Error{IMPG_E_UNSUPPORTED, "frontier too large"};
   Engine &E = *ix->engine;
   IMPG_HIP(hipSetDevice(ix->device));
-  E.win.reserve(std::max<size_t>(n * 8, 256));
+  E.win.reserve(std::max<size_t>(n * 16, 256));
   E.stage_off.reserve(std::max<size_t>(n * 4, 256));
   E.ev_next = 0;
   hipEvent_t e0 = E.event(), e1 = E.event();
   IMPG_HIP(hipEventRecord(e0, E.stream));
-  launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, d_counts, E.win.as<uint2>(), E.stream);
+  launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, d_counts, E.win.as<uint4>(), E.stream);
   *total = E.scan(d_counts, E.stage_off.as<uint32_t>(), (uint32_t)n);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   IMPG_HIP(hipStreamSynchronize(E.stream));
@@ -430,7 +430,7 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   E.ev_next = 0;
   hipEvent_t e0 = E.event(), e1 = E.event(), e2 = E.event();
   IMPG_HIP(hipEventRecord(e0, E.stream));
-  launch_lookup_emit(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_off.as<uint32_t>(), E.win.as<uint2>(),
+  launch_lookup_emit(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_off.as<uint32_t>(), E.win.as<uint4>(),
                      L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), E.stream);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,

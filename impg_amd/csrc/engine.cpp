@@ -81,9 +81,9 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   hipEvent_t e0 = event(), e1 = event(), e2 = event();
   IMPG_HIP(hipEventRecord(e0, stream));
   cnt.reserve((size_t)n_fr * 4);
-  win.reserve((size_t)n_fr * 8);
+  win.reserve((size_t)n_fr * 16);
   pair_off.reserve((size_t)n_fr * 4);
-  launch_lookup_count(v, fr, n_fr, transitive, cnt.as<uint32_t>(), win.as<uint2>(), stream);
+  launch_lookup_count(v, fr, n_fr, transitive, cnt.as<uint32_t>(), win.as<uint4>(), stream);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);
   if (P > pair_budget || P >= 0xFFFFFFF0ull) {
     if (split_ok) throw SplitBatch{};
@@ -92,7 +92,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   L.n_pairs = (uint32_t)P;
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
-  launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint2>(), L.pair_range.as<uint32_t>(),
+  launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                      pair_entry.as<uint32_t>(), stream);
   IMPG_HIP(hipEventRecord(e1, stream));
   HitArrays h = hit_arrays(L, L.n_pairs);

@@ -77,6 +77,7 @@ struct DeviceIndexView {  // passed by value to kernels
   const SegDesc *seg;        // [n_seq] per-target segment table (replaces ForestMap)
   const int32_t *starts;     // [n_entries] t_start, ascending within a segment
   const int32_t *ends;       // [n_entries] t_end
+  const int32_t *ends_t;     // [n_entries] t_end, INT_MIN where first >= last (such an entry never overlaps a clipped range)
   const int32_t *pmax;       // [n_entries] running max of t_end within the segment
   const int32_t *starts_lvl; // sampled levels of starts / pmax (same offsets)
   const int32_t *pmax_lvl;
@@ -140,7 +141,7 @@ struct impg_gpu_index {
   impg::HostSeqIndex seq;
   size_t n_records = 0, n_entries = 0, n_tiles = 0, n_targets = 0;
   std::vector<uint32_t> h_tgt_off;
-  impg::DevBuf d_seg, d_starts, d_ends, d_pmax, d_starts_lvl, d_pmax_lvl, d_rank, d_entries, d_ops, d_ext_cp, d_idp, d_seq_len;
+  impg::DevBuf d_seg, d_starts, d_ends, d_ends_t, d_pmax, d_starts_lvl, d_pmax_lvl, d_rank, d_entries, d_ops, d_ext_cp, d_idp, d_seq_len;
   impg::DeviceIndexView view{};
   size_t device_bytes = 0;
   impg::Engine *engine = nullptr;  // scratch + streams (engine.cpp)

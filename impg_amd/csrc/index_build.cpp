@@ -248,7 +248,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     });
   }
   // SoA columns, running max of end, visit rank, search levels
-  std::vector<int32_t> starts(n_entries), ends(n_entries), pmax(n_entries);
+  std::vector<int32_t> starts(n_entries), ends(n_entries), ends_t(n_entries), pmax(n_entries);
   std::vector<uint32_t> rank(n_entries);
   std::vector<SegDesc> seg(n_seq);
   std::vector<int32_t> starts_lvl, pmax_lvl;
@@ -291,6 +291,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
           for (uint32_t i = a; i < b; i++) {
             starts[i] = ent[i].ts;
             ends[i] = ent[i].te;
+            ends_t[i] = ent[i].ts < ent[i].te ? ent[i].te : INT32_MIN;
             m = std::max(m, ent[i].te);
             pmax[i] = m;
           }
@@ -321,6 +322,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   upload(ix.d_seg, seg, acc);
   upload(ix.d_starts, starts, acc);
   upload(ix.d_ends, ends, acc);
+  upload(ix.d_ends_t, ends_t, acc);
   upload(ix.d_pmax, pmax, acc);
   upload(ix.d_starts_lvl, starts_lvl, acc);
   upload(ix.d_pmax_lvl, pmax_lvl, acc);
@@ -337,6 +339,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   ix.view.seg = ix.d_seg.as<SegDesc>();
   ix.view.starts = ix.d_starts.as<int32_t>();
   ix.view.ends = ix.d_ends.as<int32_t>();
+  ix.view.ends_t = ix.d_ends_t.as<int32_t>();
   ix.view.pmax = ix.d_pmax.as<int32_t>();
   ix.view.starts_lvl = ix.d_starts_lvl.as<int32_t>();
   ix.view.pmax_lvl = ix.d_pmax_lvl.as<int32_t>();

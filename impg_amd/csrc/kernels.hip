@@ -117,11 +117,16 @@ __device__ __forceinline__ void range_windows(const DeviceIndexView &v, const Fr
     lo[k] = da[k] + (l < u ? l : u);
   }
 }
+// Inside a window every entry already starts before the range end (ub), so the
+// overlap test needs the end column only.  Transitive levels use ends_t, where an
+// entry with first >= last holds INT_MIN: max(cs,first) < min(ce,last)
+// (impg.rs:2398-2403) can never hold for it.
 template <bool TRANSITIVE>
-__device__ __forceinline__ bool overlaps(int32_t ts, int32_t te, int32_t qs, int32_t qe) {
-  if (TRANSITIVE) return max(qs, ts) < min(qe, te);
-  return ts <= qe && te >= qs;
+__device__ __forceinline__ bool window_hit(int32_t te, int32_t qs) {
+  return TRANSITIVE ? te > qs : te >= qs;
 }
+template <bool TRANSITIVE>
+__device__ __forceinline__ const int32_t *end_col(const DeviceIndexView &v) { return TRANSITIVE ? v.ends_t : v.ends; }
 
 // ---------------------------------------------------------------------------
 // K1a: count overlapping entries per frontier range (one wave per range)
@@ -129,8 +134,11 @@ __device__ __forceinline__ bool overlaps(int32_t ts, int32_t te, int32_t qs, int
 template <bool TRANSITIVE>
 __global__ __launch_bounds__(256) void lookup_count_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
                                                            uint32_t n, uint32_t *__restrict__ cnt,
-                                                           uint2 *__restrict__ win) {
-  constexpr int K = 4;  // ranges in flight per wave
+                                                           uint4 *__restrict__ win) {
+#ifndef IMPG_COUNT_K
+#define IMPG_COUNT_K 2
+#endif
+  constexpr int K = IMPG_COUNT_K;  // ranges in flight per wave
   const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * 256u) >> 6;
   const unsigned lane = lane_id();
@@ -146,29 +154,28 @@ __global__ __launch_bounds__(256) void lookup_count_kernel(DeviceIndexView v, co
     }
     range_windows<TRANSITIVE, K>(v, f, act, lo, ub);
     // windows: first chunk of every range loaded together, rare further chunks one by one
-    int32_t ws[K], we[K];
+    const int32_t *ecol = end_col<TRANSITIVE>(v);
+    int32_t we[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const uint32_t i = lo[k] + lane;
-      const bool in = i < ub[k];
-      ws[k] = in ? v.starts[i] : 0;
-      we[k] = in ? v.ends[i] : 0;
+      we[k] = i < ub[k] ? ecol[i] : 0;
     }
 #pragma unroll
     for (int k = 0; k < K; k++) {
       if (!act[k]) continue;
       const uint32_t i = lo[k] + lane;
-      bool hit = i < ub[k] && overlaps<TRANSITIVE>(ws[k], we[k], f[k].start, f[k].end);
-      uint32_t c = __popcll(__ballot(hit));
+      const bool hit = i < ub[k] && window_hit<TRANSITIVE>(we[k], f[k].start);
+      const unsigned long long m0 = __ballot(hit);
+      uint32_t c = __popcll(m0);
       for (uint32_t base = lo[k] + 64u; base < ub[k]; base += 64u) {
         const uint32_t i2 = base + lane;
-        bool h2 = false;
-        if (i2 < ub[k]) h2 = overlaps<TRANSITIVE>(v.starts[i2], v.ends[i2], f[k].start, f[k].end);
+        const bool h2 = i2 < ub[k] && window_hit<TRANSITIVE>(ecol[i2], f[k].start);
         c += __popcll(__ballot(h2));
       }
       if (lane == 0) {
         cnt[r0 + k] = c;
-        win[r0 + k] = make_uint2(lo[k], ub[k]);
+        win[r0 + k] = make_uint4(lo[k], ub[k], (uint32_t)m0, (uint32_t)(m0 >> 32));  // + hit mask of the first chunk
       }
     }
   }
@@ -180,23 +187,53 @@ __global__ __launch_bounds__(256) void lookup_count_kernel(DeviceIndexView v, co
 template <bool TRANSITIVE>
 __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
                                                           uint32_t n, const uint32_t *__restrict__ pair_off,
-                                                          const uint2 *__restrict__ win,
+                                                          const uint4 *__restrict__ win,
                                                           uint32_t *__restrict__ pair_range,
                                                           uint32_t *__restrict__ pair_entry) {
   const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * 256u) >> 6;
   const unsigned lane = lane_id();
+  const int32_t *ecol = end_col<TRANSITIVE>(v);
   for (uint32_t r = wave; r < n; r += nwaves) {
-    const uint2 w = win[r];
+    const uint4 w = win[r];
     const uint32_t lo = w.x, ub = w.y;
     if (lo >= ub) continue;
-    FrontierRec f = fr[r];
     const uint32_t off = pair_off[r];
-    if (v.sorted_order) {  // visit order == segment order: plain stream compaction
+    const unsigned long long m0 = ((unsigned long long)w.w << 32) | w.z;  // hits of the first chunk, from the count pass
+    if (ub - lo <= 64u) {
+      // the whole window is one chunk (the common case): no column is re-read
+      const bool hit = (m0 >> lane) & 1ull;
+      if (v.sorted_order) {  // visit order == segment order: plain stream compaction
+        if (hit) {
+          const uint32_t pos = off + __popcll(m0 & lanemask_lt());
+          pair_range[pos] = r;
+          pair_entry[pos] = lo + lane;
+        }
+        continue;
+      }
+      // visit order = ascending rank[]: position = number of hits with a smaller rank
+      const uint32_t rk = hit ? v.rank[lo + lane] : 0xFFFFFFFFu;
+      uint32_t pos = 0;
+      unsigned long long m = m0;
+      while (m) {  // m is wave-uniform: the lane index lives in an SGPR (v_readlane, no LDS round trip)
+        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+        m &= m - 1;
+        const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)rk, j);
+        pos += rj < rk;
+      }
+      if (hit) {
+        pair_range[off + pos] = r;
+        pair_entry[off + pos] = lo + lane;
+      }
+      continue;
+    }
+    // ---- windows wider than one wave (dense targets): chunked -----------------------
+    const int32_t qs = fr[r].start;
+    if (v.sorted_order) {
       uint32_t run = 0;
       for (uint32_t base = lo; base < ub; base += 64u) {
         uint32_t i = base + lane;
-        bool hit = i < ub && overlaps<TRANSITIVE>(v.starts[i], v.ends[i], f.start, f.end);
+        bool hit = i < ub && window_hit<TRANSITIVE>(ecol[i], qs);
         unsigned long long m = __ballot(hit);
         if (hit) {
           uint32_t pos = off + run + __popcll(m & lanemask_lt());
@@ -207,24 +244,22 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
       }
       continue;
     }
-    // visit order = ascending rank[]: position of a hit = number of hits in the
-    // whole window with a smaller rank (ranks are distinct within a segment)
     for (uint32_t base = lo; base < ub; base += 64u) {
       uint32_t i = base + lane;
-      bool hit = i < ub && overlaps<TRANSITIVE>(v.starts[i], v.ends[i], f.start, f.end);
+      bool hit = i < ub && window_hit<TRANSITIVE>(ecol[i], qs);
       uint32_t rk = hit ? v.rank[i] : 0xFFFFFFFFu;
       uint32_t pos = 0;
       for (uint32_t b2 = lo; b2 < ub; b2 += 64u) {
         uint32_t i2 = b2 + lane;
         bool hit2;
         uint32_t rk2;
-        if (b2 == base) { hit2 = hit; rk2 = rk; }  // common case: the window is one chunk
+        if (b2 == base) { hit2 = hit; rk2 = rk; }
         else {
-          hit2 = i2 < ub && overlaps<TRANSITIVE>(v.starts[i2], v.ends[i2], f.start, f.end);
+          hit2 = i2 < ub && window_hit<TRANSITIVE>(ecol[i2], qs);
           rk2 = hit2 ? v.rank[i2] : 0xFFFFFFFFu;
         }
         unsigned long long m = __ballot(hit2);
-        while (m) {  // m is wave-uniform: the lane index can live in an SGPR (v_readlane, no LDS round trip)
+        while (m) {
           const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
           m &= m - 1;
           const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)rk2, j);
@@ -1241,13 +1276,13 @@ static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 wa
 }
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, uint32_t *cnt,
-                         uint2 *win, hipStream_t s) {
+                         uint4 *win, hipStream_t s) {
   if (!n) return;
   if (transitive) lookup_count_kernel<true><<<wave_grid(n), 256, 0, s>>>(v, fr, n, cnt, win);
   else lookup_count_kernel<false><<<wave_grid(n), 256, 0, s>>>(v, fr, n, cnt, win);
 }
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
-                        const uint32_t *pair_off, const uint2 *win, uint32_t *pair_range, uint32_t *pair_entry,
+                        const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
                         hipStream_t s) {
   if (!n) return;
   if (transitive) lookup_emit_kernel<true><<<wave_grid(n), 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry);

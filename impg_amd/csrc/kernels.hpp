@@ -33,9 +33,9 @@ struct VisitedTables {
 };
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, uint32_t *cnt,
-                         uint2 *win, hipStream_t s);
+                         uint4 *win, hipStream_t s);
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
-                        const uint32_t *pair_off, const uint2 *win, uint32_t *pair_range, uint32_t *pair_entry,
+                        const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
                         hipStream_t s);
 void launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, unsigned long long *d_bsum,
                            unsigned long long *d_total, hipStream_t s);

@@ -142,15 +142,23 @@ __global__ __launch_bounds__(256) void lookup_count_kernel(DeviceIndexView v, co
   const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * 256u) >> 6;
   const unsigned lane = lane_id();
+  FrontierRec fnext[K];  // software pipeline: the next iteration's frontier records are already in flight
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    fnext[k].target_id = 0xFFFFFFFFu; fnext[k].start = fnext[k].end = 0; fnext[k].qidx = 0;
+    if (wave * K + k < n) fnext[k] = fr[wave * K + k];
+  }
   for (uint32_t r0 = wave * K; r0 < n; r0 += nwaves * K) {
     FrontierRec f[K];
     bool act[K];
     uint32_t lo[K], ub[K];
+    const uint32_t rn = r0 + nwaves * K;
 #pragma unroll
     for (int k = 0; k < K; k++) {
       act[k] = r0 + k < n;
-      if (act[k]) f[k] = fr[r0 + k];
-      else { f[k].target_id = 0xFFFFFFFFu; f[k].start = f[k].end = 0; f[k].qidx = 0; }
+      f[k] = fnext[k];
+      fnext[k].target_id = 0xFFFFFFFFu; fnext[k].start = fnext[k].end = 0; fnext[k].qidx = 0;
+      if (rn + k < n) fnext[k] = fr[rn + k];
     }
     range_windows<TRANSITIVE, K>(v, f, act, lo, ub);
     // windows: first chunk of every range loaded together, rare further chunks one by one
@@ -194,18 +202,29 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
   const uint32_t nwaves = (gridDim.x * 256u) >> 6;
   const unsigned lane = lane_id();
   const int32_t *ecol = end_col<TRANSITIVE>(v);
+  // software pipeline: the next range's window record and slot offset are
+  // requested before the current range is processed, so a range costs one
+  // dependent round trip (its rank column), not three
+  uint4 w = make_uint4(0, 0, 0, 0);
+  uint32_t off = 0;
+  if (wave < n) { w = win[wave]; off = pair_off[wave]; }
   for (uint32_t r = wave; r < n; r += nwaves) {
-    const uint4 w = win[r];
+    const uint32_t rn = r + nwaves;
+    uint4 wn = make_uint4(0, 0, 0, 0);
+    uint32_t offn = 0;
+    if (rn < n) { wn = win[rn]; offn = pair_off[rn]; }
     const uint32_t lo = w.x, ub = w.y;
-    if (lo >= ub) continue;
-    const uint32_t off = pair_off[r];
     const unsigned long long m0 = ((unsigned long long)w.w << 32) | w.z;  // hits of the first chunk, from the count pass
+    const uint32_t off_r = off;
+    w = wn;
+    off = offn;
+    if (lo >= ub) continue;
     if (ub - lo <= 64u) {
       // the whole window is one chunk (the common case): no column is re-read
       const bool hit = (m0 >> lane) & 1ull;
       if (v.sorted_order) {  // visit order == segment order: plain stream compaction
         if (hit) {
-          const uint32_t pos = off + __popcll(m0 & lanemask_lt());
+          const uint32_t pos = off_r + __popcll(m0 & lanemask_lt());
           pair_range[pos] = r;
           pair_entry[pos] = lo + lane;
         }
@@ -222,11 +241,12 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
         pos += rj < rk;
       }
       if (hit) {
-        pair_range[off + pos] = r;
-        pair_entry[off + pos] = lo + lane;
+        pair_range[off_r + pos] = r;
+        pair_entry[off_r + pos] = lo + lane;
       }
       continue;
     }
+    const uint32_t off = off_r;  // (shadows the pipelined register inside the rare path)
     // ---- windows wider than one wave (dense targets): chunked -----------------------
     const int32_t qs = fr[r].start;
     if (v.sorted_order) {

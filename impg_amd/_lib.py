@@ -88,6 +88,8 @@ SYMBOLS = [
     ("impg_gpu_results_offsets", _P, [_P]),
     ("impg_gpu_results_intervals", _P, [_P]),
     ("impg_gpu_results_projected", C.c_uint64, [_P]),
+    ("impg_gpu_results_cigar_offsets", _P, [_P]),
+    ("impg_gpu_results_cigar_ops", _P, [_P]),
     ("impg_gpu_results_free", None, [_P]),
     ("impg_gpu_query_batch_stats", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, _P, C.POINTER(Stats)]),
     ("impg_gpu_query_batch_stats_dev", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, _P, C.POINTER(Stats)]),

@@ -72,6 +72,7 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
     std::vector<FrontierRec> fr;
     std::vector<uint32_t> pair_range, qid;
     std::vector<int32_t> qs, qe, ts, te;
+    std::vector<uint32_t> sl_pos, sl_n, pool;
   };
   std::vector<HostLevel> hl(levels.size());
   for (size_t l = 0; l < levels.size(); l++) {
@@ -88,6 +89,12 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
       IMPG_HIP(hipMemcpy(H.qe.data(), L.qe.p, P * 4, hipMemcpyDeviceToHost));
       IMPG_HIP(hipMemcpy(H.ts.data(), L.ts.p, P * 4, hipMemcpyDeviceToHost));
       IMPG_HIP(hipMemcpy(H.te.data(), L.te.p, P * 4, hipMemcpyDeviceToHost));
+      if (p.store_cigar) {
+        H.sl_pos.resize(P); H.sl_n.resize(P); H.pool.resize(L.slice_total);
+        IMPG_HIP(hipMemcpy(H.sl_pos.data(), L.slice_pos.p, P * 4, hipMemcpyDeviceToHost));
+        IMPG_HIP(hipMemcpy(H.sl_n.data(), L.sl_n.p, P * 4, hipMemcpyDeviceToHost));
+        if (L.slice_total) IMPG_HIP(hipMemcpy(H.pool.data(), L.slice_pool.p, L.slice_total * 4, hipMemcpyDeviceToHost));
+      }
     }
   }
   auto emitted = [&](const HostLevel &H, size_t k) {
@@ -107,12 +114,18 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
   res.offsets.assign(n + 1, 0);
   for (uint32_t q = 0; q < n; q++) res.offsets[q + 1] = res.offsets[q] + cnt[q];
   res.intervals.resize(res.offsets[n]);
+  res.has_cigar = p.store_cigar != 0;
+  // with store_cigar every interval carries an op list; collected per interval first
+  std::vector<std::vector<uint32_t>> cg;
+  if (res.has_cigar) cg.resize(res.intervals.size());
   std::vector<uint64_t> cur(res.offsets.begin(), res.offsets.end() - 1);
   for (uint32_t q = 0; q < n; q++) {
     if (!transitive) {
       const auto &r = h_ranges[q];
+      if (res.has_cigar) cg[cur[q]] = {(uint32_t)(r.end - r.start)};  // vec![CigarOp::new(range_end - range_start, '=')] (impg.rs:1870-1872)
       res.intervals[cur[q]++] = {r.target_id, r.start, r.end, r.target_id, r.start, r.end};
     } else if (self[q].start < self[q].end) {
+      if (res.has_cigar) cg[cur[q]] = {(uint32_t)(self[q].end - self[q].start)};  // impg.rs:2352-2354
       res.intervals[cur[q]++] = {self[q].target_id, self[q].start, self[q].end, self[q].target_id, self[q].start, self[q].end};
     }
   }
@@ -121,8 +134,16 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
     for (size_t k = 0; k < H.qid.size(); k++)
       if (emitted(H, k)) {
         const FrontierRec &f = H.fr[H.pair_range[k]];
+        if (res.has_cigar) cg[cur[f.qidx]].assign(H.pool.begin() + H.sl_pos[k], H.pool.begin() + H.sl_pos[k] + H.sl_n[k]);
         res.intervals[cur[f.qidx]++] = {H.qid[k], H.qs[k], H.qe[k], f.target_id, H.ts[k], H.te[k]};
       }
+  if (res.has_cigar) {
+    res.cigar_off.assign(1, 0);
+    for (auto &c : cg) {
+      res.cigar_ops.insert(res.cigar_ops.end(), c.begin(), c.end());
+      res.cigar_off.push_back(res.cigar_ops.size());
+    }
+  }
   res.projected = E.last_projected;
 }
 
@@ -285,6 +306,13 @@ int impg_gpu_query_batch(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, s
     uint64_t base = res->intervals.size();
     res->intervals.insert(res->intervals.end(), part.intervals.begin(), part.intervals.end());
     for (size_t i = 1; i < part.offsets.size(); i++) res->offsets.push_back(base + part.offsets[i]);
+    if (part.has_cigar) {
+      res->has_cigar = true;
+      if (res->cigar_off.empty()) res->cigar_off.assign(1, 0);
+      uint64_t cb = res->cigar_ops.size();
+      res->cigar_ops.insert(res->cigar_ops.end(), part.cigar_ops.begin(), part.cigar_ops.end());
+      for (size_t i = 1; i < part.cigar_off.size(); i++) res->cigar_off.push_back(cb + part.cigar_off[i]);
+    }
     res->projected += part.projected;
   });
   res->ranges.assign(ranges, ranges + n);
@@ -304,6 +332,8 @@ size_t impg_gpu_results_total(const impg_gpu_results_t *r) { return r->intervals
 const uint64_t *impg_gpu_results_offsets(const impg_gpu_results_t *r) { return r->offsets.data(); }
 const impg_gpu_interval_t *impg_gpu_results_intervals(const impg_gpu_results_t *r) { return r->intervals.data(); }
 uint64_t impg_gpu_results_projected(const impg_gpu_results_t *r) { return r->projected; }
+const uint64_t *impg_gpu_results_cigar_offsets(const impg_gpu_results_t *r) { return r->has_cigar ? r->cigar_off.data() : nullptr; }
+const uint32_t *impg_gpu_results_cigar_ops(const impg_gpu_results_t *r) { return r->has_cigar ? r->cigar_ops.data() : nullptr; }
 void impg_gpu_results_free(impg_gpu_results_t *r) { delete r; }
 
 static int stats_impl(impg_gpu_index_t *ix, const impg_gpu_range_t *d_ranges, size_t n, const impg_gpu_params_t *params,
@@ -417,6 +447,7 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   Engine &E = *ix->engine;
   Engine::check_params(*params);
   if (E.stage_n != n) throw Error{IMPG_E_INVALID, "stage_project must follow stage_count on the same frontier"};
+  if (params->store_cigar) throw Error{IMPG_E_UNSUPPORTED, "store_cigar is not available through the stage API"};
   if (total >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 pairs: split the frontier"};
   IMPG_HIP(hipSetDevice(ix->device));
   LevelBufs &L = E.level_scratch;
@@ -434,7 +465,8 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
                      L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), E.stream);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
-                 E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), params->min_identity, E.stream);
+                 E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), params->min_identity, nullptr,
+                 E.stream);
   IMPG_HIP(hipEventRecord(e2, E.stream));
   launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
   IMPG_HIP(hipStreamSynchronize(E.stream));

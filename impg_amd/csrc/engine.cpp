@@ -96,9 +96,30 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
                      pair_entry.as<uint32_t>(), stream);
   IMPG_HIP(hipEventRecord(e1, stream));
   HitArrays h = hit_arrays(L, L.n_pairs);
+  SliceArrays sl{nullptr, nullptr, nullptr, nullptr};
+  if (store_cigar) {
+    size_t b = std::max<size_t>((size_t)L.n_pairs * 4, 256);
+    L.sl_a.reserve(b); L.sl_n.reserve(b); L.sl_off.reserve(b); L.sl_rem.reserve(b);
+    sl = SliceArrays{L.sl_a.as<uint32_t>(), L.sl_n.as<uint32_t>(), L.sl_off.as<int32_t>(), L.sl_rem.as<int32_t>()};
+  }
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
-                 acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity, stream);
+                 acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity,
+                 store_cigar ? &sl : nullptr, stream);
   IMPG_HIP(hipEventRecord(e2, stream));
+  if (store_cigar && L.n_pairs) {  // materialise the slices while pair_entry is still this level's
+    cnt.reserve((size_t)L.n_pairs * 4);
+    L.slice_pos.reserve((size_t)L.n_pairs * 4);
+    launch_slice_counts(h, sl, L.n_pairs, cnt.as<uint32_t>(), stream);
+    L.slice_total = scan(cnt.as<uint32_t>(), L.slice_pos.as<uint32_t>(), L.n_pairs);
+    if (L.slice_total >= 0xFFFFFFF0ull) {
+      if (split_ok) throw SplitBatch{};
+      throw Error{IMPG_E_UNSUPPORTED, "CIGAR slices of one level exceed 2^32 ops"};
+    }
+    L.slice_pool.reserve(std::max<size_t>(L.slice_total * 4, 256));
+    launch_slice_write(v, pair_entry.as<uint32_t>(), h, sl, L.n_pairs, L.slice_pos.as<uint32_t>(), L.slice_pool.as<uint32_t>(), stream);
+  } else {
+    L.slice_total = 0;
+  }
   timed.push_back({e0, e1, 0});
   timed.push_back({e1, e2, 1});
   if (st) {
@@ -207,7 +228,6 @@ uint32_t Engine::begin_transitive(const DeviceIndexView &v, const impg_gpu_range
 }
 
 void Engine::check_params(const impg_gpu_params_t &p) {
-  if (p.store_cigar) throw Error{IMPG_E_UNSUPPORTED, "store_cigar (BEDPE/PAF output) is not built yet"};
   if (p.transitive && p.max_depth > 65535) throw Error{IMPG_E_INVALID, "max_depth is a u16 in the reference"};
 }
 
@@ -221,6 +241,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   IMPG_HIP(hipSetDevice(ix.device));
   split_ok = n > 1;
   min_identity = p.min_identity;
+  store_cigar = p.store_cigar != 0 && keep != nullptr;  // slices are only materialised for full results
   const DeviceIndexView &v = ix.view;
   ev_next = 0;
   timed.clear();

@@ -9,6 +9,9 @@ namespace impg {
 
 struct LevelBufs {  // one BFS level: its frontier and its hit slots
   DevBuf frontier, pair_range, qid, qs, qe, ts, te;
+  // store_cigar: slice descriptors per slot, then the materialised slices
+  DevBuf sl_a, sl_n, sl_off, sl_rem, slice_pos, slice_pool;
+  uint64_t slice_total = 0;
   uint32_t n_frontier = 0, n_pairs = 0;
 };
 struct VisitedStore {  // device storage of one VisitedTable
@@ -40,6 +43,7 @@ struct Engine {
   uint32_t chunk_ranges = 0;          // ranges per chunk (0 = try the whole batch)
   bool split_ok = false;
   double min_identity = __builtin_nan("");  // of the batch / stage call in flight
+  bool store_cigar = false;
   uint32_t stage_n = 0;  // frontier size of the last stage_count call
 
   explicit Engine(int device);

@@ -152,5 +152,8 @@ struct impg_gpu_results {
   std::vector<uint64_t> offsets;
   std::vector<impg_gpu_interval_t> intervals;
   std::vector<impg_gpu_range_t> ranges;
+  bool has_cigar = false;
+  std::vector<uint64_t> cigar_off;  // [intervals+1] when has_cigar
+  std::vector<uint32_t> cigar_ops;
   uint64_t projected = 0;
 };

@@ -422,7 +422,12 @@ struct IdentScan {
   uint32_t lm, lx, lg;        // running sums just AFTER the last overlapping op
   int32_t first_adj_m, first_adj_x;  // first_op_offset if the first op is a match / mismatch op
   int32_t last_adj_m, last_adj_x;    // last_op_remaining (<= 0) if the last op is a match / mismatch op
+  // store_cigar (impg.rs:2878-2886): original indices of the first / last overlapping
+  // op and the two length adjustments exactly as the reference carries them
+  uint32_t first_oi, last_oi;
+  int32_t first_off, last_rem;
 };
+constexpr int MODE_IDENT = 1, MODE_CIGAR = 2;
 
 struct PairCtx {
   int32_t ts, R0, R1, last_tp;
@@ -442,8 +447,10 @@ struct PairCtx {
 //   arm 2 (query_delta == 0):   passes iff max(T,R0) < min(T+td,last_tp);    first (Q, os)      last (Q, oe)
 //   arm 3:                      passes iff max(T,R0) < min(T+td,R1);         first (Q+os-T, os) last (Q+oe-T, oe)
 // When arm 1 passes, os == T and min(T, lim) == T, so os / oe serve all arms.
-template <bool IDENT>
-__device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &T, int32_t &Qn, TileScan &s, IdentScan &id) {
+template <int MODE>
+__device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &T, int32_t &Qn, TileScan &s, IdentScan &id,
+                                        uint32_t oi = 0) {
+  constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   const bool valid = op != OP_PAD;
   const uint32_t code = op >> 29;
   const int32_t len = valid ? (int32_t)(op & OP_LEN_MASK) : 0;
@@ -476,6 +483,16 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
       const int32_t rem = arm1 ? 0 : oe - e;  // last_op_remaining (impg.rs:2838, :2862); an arm-1 last op is a gap op
       id.last_adj_m = is_m ? rem : 0;
       id.last_adj_x = is_x ? rem : 0;
+    }
+  }
+  if (MODE & MODE_CIGAR) {
+    if (first) {
+      id.first_oi = oi;
+      id.first_off = arm1 ? 0 : os - T;  // only the deletion / match arms set it (impg.rs:2832, :2856)
+    }
+    if (pass) {
+      id.last_oi = oi;
+      if (!arm1) id.last_rem = oe - e;   // an insertion leaves the previous value in place (impg.rs:2807-2821)
     }
   }
   s.pqs = first ? fq : s.pqs;
@@ -524,7 +541,7 @@ __device__ __forceinline__ void sub_start(const PairCtx &c, const TileHdr &h, ui
 // same for both: 4 vector slots; the lower half fills 3 of them (its first vector
 // also carries two header words, masked to padding).  Reverse-strand reversed
 // entries walk back to front: descending vector index, reversed components.
-template <bool IDENT>
+template <int MODE>
 __device__ __forceinline__ void scan_sub(const PairCtx &c, const SubTile &t, const TileHdr &hdr, TileScan &s, IdentScan &id) {
   int32_t T, Qn;
   sub_start(c, hdr, t.h, T, Qn);
@@ -543,22 +560,24 @@ __device__ __forceinline__ void scan_sub(const PairCtx &c, const SubTile &t, con
       nxt = q[ni];
       if (ni == 1) nxt.x = nxt.y = OP_PAD;
     }
-    op_step<IDENT>(c.flip ? cur.w : cur.x, c, T, Qn, s, id);
-    op_step<IDENT>(c.flip ? cur.z : cur.y, c, T, Qn, s, id);
-    op_step<IDENT>(c.flip ? cur.y : cur.z, c, T, Qn, s, id);
-    op_step<IDENT>(c.flip ? cur.x : cur.w, c, T, Qn, s, id);
+    op_step<MODE>(c.flip ? cur.w : cur.x, c, T, Qn, s, id);
+    op_step<MODE>(c.flip ? cur.z : cur.y, c, T, Qn, s, id);
+    op_step<MODE>(c.flip ? cur.y : cur.z, c, T, Qn, s, id);
+    op_step<MODE>(c.flip ? cur.x : cur.w, c, T, Qn, s, id);
     cur = nxt;
   }
 }
 __device__ __forceinline__ void ident_reset(IdentScan &id) {
   id.rm = id.rx = id.rg = id.fm = id.fx = id.fg = id.lm = id.lx = id.lg = 0;
   id.first_adj_m = id.first_adj_x = id.last_adj_m = id.last_adj_x = 0;
+  id.first_oi = id.last_oi = 0;
+  id.first_off = id.last_rem = 0;
 }
 
 // literal walk over whole tiles A..B in effective order, one op at a time (rare path).
 // Inlined on purpose: as a call it forced the whole PairCtx through scratch
 // memory for EVERY pair (48 B/lane of extra HBM writes), not only the rare ones.
-template <bool IDENT>
+template <int MODE>
 __device__ __forceinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32_t B, IdentScan &id) {
   TileScan s;
   s.found = false;
@@ -570,8 +589,8 @@ __device__ __forceinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uin
   for (int64_t j = A;; j += stepj) {
     const uint32_t *tp = c.ops + (size_t)j * TILE_WORDS + 6;
     for (int u = 0; u < (int)TILE_OPS && T <= c.last_tp; u++) {
-      uint32_t op = tp[c.flip ? (int)TILE_OPS - 1 - u : u];
-      op_step<IDENT>(op, c, T, Qn, s, id);
+      const int w = c.flip ? (int)TILE_OPS - 1 - u : u;
+      op_step<MODE>(tp[w], c, T, Qn, s, id, (uint32_t)j * TILE_OPS + (uint32_t)w);
     }
     if (T > c.last_tp || j == (int64_t)B) break;
   }
@@ -580,12 +599,18 @@ __device__ __forceinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uin
 
 // IDENT: also evaluate calculate_gap_compressed_identity on the projected CIGAR
 // slice (impg.rs:1283-1287, :2952-2973) and drop hits below min_identity.
-template <bool TRANSITIVE, bool IDENT>
+// MODE & MODE_CIGAR: also record which ops form the projected CIGAR slice
+// (store_cigar); such launches walk tiles A..B literally -- BEDPE/PAF output is
+// not the throughput path.
+template <bool TRANSITIVE, int MODE>
 __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
                                                       const uint32_t *__restrict__ pair_range,
                                                       const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
-                                                      uint32_t *__restrict__ err_flag, double min_identity) {
+                                                      uint32_t *__restrict__ err_flag, double min_identity,
+                                                      SliceArrays sl) {
+  constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
+  constexpr bool CIGAR = (MODE & MODE_CIGAR) != 0;
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   bool ok = false;
   TileScan res;
@@ -630,8 +655,8 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
       //    the PAF coordinates: the final op is the last overlapping op, ending at
       //    (query offset totQ, target te).
       // (The identity filter needs the slice's op counts, so it always reads the tiles.)
-      const bool start_cov = !IDENT && c.R0 <= c.ts && c.last_tp > c.ts;
-      const bool end_cov = !IDENT && c.R1 >= en_te && c.R0 < en_te && (int32_t)c.totT == en_te - c.ts;
+      const bool start_cov = MODE == 0 && c.R0 <= c.ts && c.last_tp > c.ts;
+      const bool end_cov = MODE == 0 && c.R1 >= en_te && c.R0 < en_te && (int32_t)c.totT == en_te - c.ts;
       // Effective tile k (k-th tile in this entry's walking order) starts at target
       // prefix P[k]: P[0] = 0, P[m] = totT, P[1..m-1] inline (m <= 8) or external.
       //   A = first k with P[k+1] >= R0 - ts        (holds the first op that can overlap)
@@ -674,9 +699,13 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         IdentScan ia, ib;
         ident_reset(ia);
         ident_reset(ib);
-        bool walked = false;
+        bool walked = false, same = false;
         SubTile subA{A, 0}, subB{B, 0};
         TileHdr ha, hb;
+        if (CIGAR) {
+          res = walk_tiles<MODE>(c, A, B, ia);
+          walked = true;
+        } else {
         if (!start_cov) {
           ha = tile_header(c, A);
           const uint32_t cntA = min(TILE_OPS, n - A * TILE_OPS);
@@ -691,9 +720,8 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
           sa.pqs = 0;
           sa.pts = c.ts;
         } else {
-          scan_sub<IDENT>(c, subA, ha, sa, ia);
+          scan_sub<MODE>(c, subA, ha, sa, ia);
         }
-        bool same = false;
         if (!end_cov) {
           hb = (!start_cov && A == B) ? ha : tile_header(c, B);  // requested only now (see IMPG note on refetch)
           const uint32_t cntB = min(TILE_OPS, n - B * TILE_OPS);
@@ -711,7 +739,7 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
           sb = sa;  // one sub-tile holds both ends: its scan recorded the last overlapping op too
           ib = ia;
         } else {
-          scan_sub<IDENT>(c, subB, hb, sb, ib);
+          scan_sub<MODE>(c, subB, hb, sb, ib);
         }
         if (sa.found && sb.found) {
           res.found = true;
@@ -720,8 +748,15 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         } else if (!start_cov && !end_cov && same) {
           res.found = false;  // every overlapping op would lie in this sub-tile
         } else {
-          res = walk_tiles<IDENT>(c, A, B, ia);
+          res = walk_tiles<MODE>(c, A, B, ia);
           walked = true;
+        }
+        }
+        if (CIGAR) {
+          sl.a[p] = ia.first_oi;
+          sl.n[p] = (ia.first_oi > ia.last_oi ? ia.first_oi - ia.last_oi : ia.last_oi - ia.first_oi) + 1u;
+          sl.off[p] = ia.first_off;
+          sl.rem[p] = ia.last_rem;
         }
         if (IDENT && res.found) {
           // op counts of the slice [first op, last op] in ORIGINAL op order:
@@ -778,6 +813,41 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
     uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     if (tot) atomicAdd(&accepted[(blockIdx.x % COUNT_SLOTS) * COUNT_STRIDE], (unsigned long long)tot);
   }
+}
+
+// ---------------------------------------------------------------------------
+// store_cigar: materialise the projected CIGAR slices (impg.rs:2878-2886)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slice_counts_kernel(HitArrays h, SliceArrays sl, uint32_t n_pairs,
+                                                           uint32_t *__restrict__ cnt) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n_pairs) return;
+  cnt[p] = h.qid[p] == HIT_NONE ? 0u : sl.n[p];
+}
+__global__ __launch_bounds__(64) void slice_write_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry,
+                                                         HitArrays h, SliceArrays sl, uint32_t n_pairs,
+                                                         const uint32_t *__restrict__ off, uint32_t *__restrict__ out) {
+  const uint32_t p = blockIdx.x * 64u + threadIdx.x;
+  if (p >= n_pairs || h.qid[p] == HIT_NONE) return;
+  const Entry &en = v.entries[pair_entry[p]];
+  const bool swp = (en.nops_flags & EF_REVERSED) != 0, flip = swp && (en.nops_flags & EF_STRAND);
+  const uint32_t *rec = v.ops + (size_t)en.tile_base * TILE_WORDS;
+  const uint32_t n = sl.n[p], a = sl.a[p];
+  uint32_t *o = out + off[p];
+  for (uint32_t t = 0; t < n; t++) {
+    const uint32_t oi = flip ? a - t : a + t;  // reverse-strand reversed entries list their ops back to front
+    uint32_t op = rec[(size_t)(oi / TILE_OPS) * TILE_WORDS + 6 + oi % TILE_OPS];
+    if (swp) {  // invert_cigar_ops_in_place: I <-> D (impg.rs:146-151)
+      const uint32_t code = op >> 29;
+      if (code == 2u) op = (3u << 29) | (op & OP_LEN_MASK);
+      else if (code == 3u) op = (2u << 29) | (op & OP_LEN_MASK);
+    }
+    o[t] = op;
+  }
+  // adjust_len (impg.rs:137-139), same arithmetic: val = (val & (7 << 29)) | ((len + delta) as u32)
+  const int32_t fo = sl.off[p], lr = sl.rem[p];
+  if (fo > 0) o[0] = (o[0] & (7u << 29)) | (uint32_t)((int32_t)(o[0] & OP_LEN_MASK) - fo);
+  if (lr < 0) o[n - 1] = (o[n - 1] & (7u << 29)) | (uint32_t)((int32_t)(o[n - 1] & OP_LEN_MASK) + lr);
 }
 
 // ---------------------------------------------------------------------------
@@ -1319,14 +1389,29 @@ void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_
 }
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
-                    unsigned long long *accepted, uint32_t *err_flag, double min_identity, hipStream_t s) {
+                    unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
+                    hipStream_t s) {
   if (!n_pairs) return;
   const bool ident = min_identity == min_identity;  // NaN = no filter
   const uint32_t g = cdiv(n_pairs, 256);
-  if (transitive && ident) project_kernel<true, true><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, min_identity);
-  else if (transitive) project_kernel<true, false><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, 0.0);
-  else if (ident) project_kernel<false, true><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, min_identity);
-  else project_kernel<false, false><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, 0.0);
+  const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};
+  const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0);
+#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl)
+  if (transitive) {
+    switch (mode) { case 0: IMPG_LAUNCH(true, 0); break; case 1: IMPG_LAUNCH(true, 1); break;
+                    case 2: IMPG_LAUNCH(true, 2); break; default: IMPG_LAUNCH(true, 3); }
+  } else {
+    switch (mode) { case 0: IMPG_LAUNCH(false, 0); break; case 1: IMPG_LAUNCH(false, 1); break;
+                    case 2: IMPG_LAUNCH(false, 2); break; default: IMPG_LAUNCH(false, 3); }
+  }
+#undef IMPG_LAUNCH
+}
+void launch_slice_counts(HitArrays h, SliceArrays sl, uint32_t n_pairs, uint32_t *cnt, hipStream_t s) {
+  if (n_pairs) slice_counts_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(h, sl, n_pairs, cnt);
+}
+void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, HitArrays h, SliceArrays sl, uint32_t n_pairs,
+                        const uint32_t *off, uint32_t *out, hipStream_t s) {
+  if (n_pairs) slice_write_kernel<<<cdiv(n_pairs, 64), 64, 0, s>>>(v, pair_entry, h, sl, n_pairs, off, out);
 }
 void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
                       int32_t min_output_length, unsigned long long *count, unsigned long long *cksum, hipStream_t s) {

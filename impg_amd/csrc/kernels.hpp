@@ -16,6 +16,14 @@ struct HitArrays {
   int32_t *qs, *qe, *ts, *te;
 };
 
+// store_cigar: which ops of the record form each slot's projected slice
+struct SliceArrays {
+  uint32_t *a;   // original index of the slice's first op in walking order
+  uint32_t *n;   // number of ops
+  int32_t *off;  // first_op_offset
+  int32_t *rem;  // last_op_remaining
+};
+
 // visited sets: one table per BFS level; a key's newest table entry is complete
 struct VisitedTable {
   const unsigned long long *keys;  // sorted unique (qidx << 32 | sequence id)
@@ -42,7 +50,11 @@ void launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, un
 size_t scan_scratch_bytes(uint32_t n);
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
-                    unsigned long long *accepted, uint32_t *err_flag, double min_identity, hipStream_t s);
+                    unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
+                    hipStream_t s);
+void launch_slice_counts(HitArrays h, SliceArrays sl, uint32_t n_pairs, uint32_t *cnt, hipStream_t s);
+void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, HitArrays h, SliceArrays sl, uint32_t n_pairs,
+                        const uint32_t *off, uint32_t *out, hipStream_t s);
 void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
                       int32_t min_output_length, unsigned long long *count, unsigned long long *cksum, hipStream_t s);
 void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,

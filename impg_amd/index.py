@@ -37,9 +37,21 @@ class QueryResults:
         else:
             self.intervals = np.zeros(0, dtype=INTERVAL_DTYPE)
         self.projected = L.impg_gpu_results_projected(handle)
+        self.cigar_off = self.cigar_ops = None
+        cop = L.impg_gpu_results_cigar_offsets(handle)
+        if cop:
+            self.cigar_off = np.ctypeslib.as_array(C.cast(cop, C.POINTER(C.c_uint64)), shape=(total + 1,)).copy()
+            nops = int(self.cigar_off[-1])
+            self.cigar_ops = (np.ctypeslib.as_array(C.cast(L.impg_gpu_results_cigar_ops(handle), C.POINTER(C.c_uint32)),
+                                                    shape=(nops,)).copy() if nops else np.zeros(0, dtype=np.uint32))
 
     def __getitem__(self, i):
         return self.intervals[self.offsets[i]:self.offsets[i + 1]]
+
+    def cigars(self, i):
+        """Vec<CigarOp> (packed u32 ops) of every interval of range i; needs store_cigar."""
+        a, b = int(self.offsets[i]), int(self.offsets[i + 1])
+        return [self.cigar_ops[int(self.cigar_off[k]):int(self.cigar_off[k + 1])] for k in range(a, b)]
 
     def __len__(self):
         return self.n_ranges

@@ -148,6 +148,11 @@ size_t impg_gpu_results_total(const impg_gpu_results_t *);
 /* offsets[n_ranges+1] into intervals[]; both owned by the results object */
 const uint64_t *impg_gpu_results_offsets(const impg_gpu_results_t *);
 const impg_gpu_interval_t *impg_gpu_results_intervals(const impg_gpu_results_t *);
+/* store_cigar: the Vec<CigarOp> of every interval (impg.rs:1870-1872, :2878-2886),
+ * packed ops at cigar_ops[cigar_offsets[i] .. cigar_offsets[i+1]); NULL when the
+ * query ran with store_cigar = 0 */
+const uint64_t *impg_gpu_results_cigar_offsets(const impg_gpu_results_t *);
+const uint32_t *impg_gpu_results_cigar_ops(const impg_gpu_results_t *);
 /* number of Some(..) projections (self intervals excluded) = the work unit of BASELINE.md */
 uint64_t impg_gpu_results_projected(const impg_gpu_results_t *);
 void impg_gpu_results_free(impg_gpu_results_t *);

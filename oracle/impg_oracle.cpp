@@ -1248,6 +1248,30 @@ long oracle_query(const oracle_index_t *ix, uint32_t target_id, int32_t start, i
   return (long)results.size();
 }
 
+long oracle_query_cigar(const oracle_index_t *ix, uint32_t target_id, int32_t start, int32_t end, const oracle_params_t *p,
+                        oracle_interval_t *out, size_t cap, uint64_t *cigar_off, uint32_t *cigar_ops, size_t ops_cap,
+                        uint64_t *n_ops) {
+  std::vector<AdjustedInterval> results;
+  g_nproj = 0;
+  oracle_params_t q = *p;
+  q.store_cigar = 1;
+  if (!run_query(*ix, target_id, start, end, q, 1, results)) return -1;
+  uint64_t k = 0;
+  for (size_t i = 0; i < results.size(); i++) {
+    if (i < cap) {
+      out[i] = {results[i].q_id, results[i].q_first, results[i].q_last, results[i].t_id, results[i].t_first, results[i].t_last};
+      cigar_off[i] = k;
+    }
+    for (uint32_t v : results[i].cigar) {
+      if (i < cap && k < ops_cap) cigar_ops[k] = v;
+      k++;
+    }
+    if (i < cap) cigar_off[i + 1] = k;
+  }
+  *n_ops = k;
+  return (long)results.size();
+}
+
 long oracle_bed_merge(oracle_interval_t *iv, size_t n, int32_t merge_distance, int merge_strands) {
   std::vector<oracle_interval_t> v(iv, iv + n);
   /* output_results_bed (main.rs:11858-11866): any_empty_cigar is true for BED

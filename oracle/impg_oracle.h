@@ -110,6 +110,13 @@ long oracle_query(const oracle_index_t *, uint32_t target_id, int32_t start,
                   int32_t end, const oracle_params_t *p, oracle_interval_t *out,
                   size_t cap);
 
+/* Same with store_cigar: cigar_off[cap+1], cigar_ops[ops_cap] receive the
+ * Vec<CigarOp> of every result (CSR); *n_ops = total ops (may exceed ops_cap). */
+long oracle_query_cigar(const oracle_index_t *, uint32_t target_id, int32_t start,
+                        int32_t end, const oracle_params_t *p, oracle_interval_t *out,
+                        size_t cap, uint64_t *cigar_off, uint32_t *cigar_ops,
+                        size_t ops_cap, uint64_t *n_ops);
+
 /* number of Some(..) projections performed by the last oracle_query on this
  * thread (the work unit of BASELINE.md section 3). */
 uint64_t oracle_last_projection_count(void);

@@ -93,6 +93,9 @@ def lib():
         L.oracle_query.restype = C.c_long
         L.oracle_query.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params),
                                    C.c_void_p, C.c_size_t]
+        L.oracle_query_cigar.restype = C.c_long
+        L.oracle_query_cigar.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p,
+                                         C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         L.oracle_bed_merge.restype = C.c_long
         L.oracle_bed_merge.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int]
         L.oracle_query_bed.restype = C.c_int
@@ -243,6 +246,23 @@ class OracleIndex:
             if n <= cap:
                 return out[:n].copy()
             cap = n
+
+    def query_cigar(self, target_id, start, end, params=None, **kw):
+        """(results, [ops array per result]) with store_cigar."""
+        p = params or make_params(**kw)
+        cap, ops_cap = 1 << 12, 1 << 18
+        while True:
+            out = np.zeros(cap, dtype=INTERVAL_DTYPE)
+            off = np.zeros(cap + 1, dtype=np.uint64)
+            ops = np.zeros(ops_cap, dtype=np.uint32)
+            nops = C.c_uint64(0)
+            n = lib().oracle_query_cigar(self._h, target_id, start, end, C.byref(p), out.ctypes.data, cap,
+                                         off.ctypes.data, ops.ctypes.data, ops_cap, C.byref(nops))
+            if n < 0:
+                raise RuntimeError(lib().oracle_last_error().decode())
+            if n <= cap and nops.value <= ops_cap:
+                return out[:n].copy(), [ops[int(off[i]):int(off[i + 1])].copy() for i in range(n)]
+            cap, ops_cap = max(cap, n), max(ops_cap, int(nops.value))
 
     def last_projection_count(self):
         return lib().oracle_last_projection_count()

@@ -316,3 +316,34 @@ def test_cli_bed_bytes(tmp_path):
                 ["-r", "%s:0-99999999" % c.seq_name(0), "-d", "0"], ["-b", bed, "-d", "0"]):
         r = subprocess.run([cli, "query", "-a", paf] + bad, capture_output=True, text=True)
         assert r.returncode != 0 and r.stdout == "" and r.stderr.startswith("Error:")
+
+
+@pytest.mark.parametrize("seed,weird,incons,max_ops", [(71, False, False, 150), (72, True, False, 150), (73, True, True, 150),
+                                                        (74, False, False, 1500)])
+def test_store_cigar_slices(tmp_path, seed, weird, incons, max_ops):
+    """store_cigar = true: every interval's Vec<CigarOp> (sliced, first/last op trimmed, inverted for
+    reversed entries -- impg.rs:2878-2886, :144-156) equals the oracle's, op for op."""
+    sl = 200000 if max_ops > 200 else 30000
+    text, names = random_paf(seed, 250, n_seq=5, seq_len=sl, max_ops=max_ops, weird=weird, inconsistent=incons, self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(seed, 120, 5, sl, max_len=8000)
+    for kw in [dict(), dict(transitive=True, max_depth=2, min_transitive_len=40), dict(min_identity=0.5),
+               dict(transitive=True, dfs=True, max_depth=2, min_transitive_len=40)]:
+        rs = ranges if not kw.get("transitive") else ranges[:40]
+        res = g.query_batch(rs, impg_amd.make_params(store_cigar=True, **kw))
+        for i, (t, s, e) in enumerate(rs):
+            want, wcg = c.query_cigar(t, s, e, **kw)
+            assert res[i].tolist() == want.tolist(), (i, kw)
+            got = res.cigars(i)
+            assert len(got) == len(wcg)
+            for k in range(len(wcg)):
+                assert got[k].tolist() == wcg[k].tolist(), (i, k, kw)
+    # the reference's own slice vectors (impg.rs:3016-3053) come out of the same path
+    text = "Q\t1000\t50\t200\t+\tT\t1000\t0\t100\t1\t1\t60\tcg:Z:10=5I5D50=50I35=\n"
+    g, c = both(tmp_path, text, bidirectional=False)
+    tid = g.seq_id("T")
+    r = g.query_batch([(tid, 50, 65), (tid, 50, 66), (tid, 0, 100)], impg_amd.make_params(store_cigar=True))
+    assert o.ops_to_pairs(r.cigars(0)[1]) == [(15, "="), (50, "I")]
+    assert o.ops_to_pairs(r.cigars(1)[1]) == [(15, "="), (50, "I"), (1, "=")]
+    assert o.ops_to_pairs(r.cigars(2)[1]) == [(10, "="), (5, "I"), (5, "D"), (50, "="), (50, "I"), (35, "=")]
+    assert o.ops_to_pairs(r.cigars(2)[0]) == [(100, "=")]  # the self interval's own CIGAR (impg.rs:1870-1872)

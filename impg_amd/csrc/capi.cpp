@@ -97,8 +97,10 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
       }
     }
   }
+  const bool skip_same = transitive && p.multi_impg;  // multi_impg.rs:883-885
   auto emitted = [&](const HostLevel &H, size_t k) {
     if (H.qid[k] == HIT_NONE) return false;
+    if (skip_same && H.qid[k] == H.fr[H.pair_range[k]].target_id) return false;
     if (transitive && p.min_output_length >= 0 && std::abs((int64_t)H.qe[k] - H.qs[k]) < p.min_output_length) return false;
     return true;  // impg.rs:2482-2504
   };
@@ -448,6 +450,7 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   Engine::check_params(*params);
   if (E.stage_n != n) throw Error{IMPG_E_INVALID, "stage_project must follow stage_count on the same frontier"};
   if (params->store_cigar) throw Error{IMPG_E_UNSUPPORTED, "store_cigar is not available through the stage API"};
+  if (params->multi_impg) throw Error{IMPG_E_UNSUPPORTED, "MultiImpg semantics are not available through the stage API"};
   if (total >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 pairs: split the frontier"};
   IMPG_HIP(hipSetDevice(ix->device));
   LevelBufs &L = E.level_scratch;

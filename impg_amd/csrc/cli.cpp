@@ -89,7 +89,7 @@ std::vector<Target> parse_bed_file(const std::string &path) {
 void usage() {
   fprintf(stderr,
           "impg-gpu query -a <paf>... (-r seq:start-end | -b <bed>) (-d <bp> | --no-merge) [-x] [-m N]\n"
-          "               [--transitive-dfs] [--min-transitive-len N] [--min-distance-between-ranges N]\n"
+          "               [--transitive-dfs] [--multi-impg] [--min-transitive-len N] [--min-distance-between-ranges N]\n"
           "               [-l N] [--min-result-identity F] [-o auto|bed] [--unidirectional] [--order coitrees|sorted]\n"
           "               [--device N]\n");
 }
@@ -103,7 +103,7 @@ int main(int argc, char **argv) {
   }
   std::vector<std::string> pafs;
   std::string range, bed, ofmt = "auto";
-  bool have_d = false, no_merge = false, transitive = false, dfs = false, unidirectional = false;
+  bool have_d = false, no_merge = false, transitive = false, dfs = false, unidirectional = false, multi = false;
   long long merge_d = 0;
   long max_depth = 2, min_tl = -1, mdbr = 10, min_out = -1;
   double min_ident = NAN;
@@ -125,6 +125,7 @@ int main(int argc, char **argv) {
     } else if (a == "--no-merge") no_merge = true;
     else if (a == "-x" || a == "--transitive") transitive = true;
     else if (a == "--transitive-dfs") dfs = true;
+    else if (a == "--multi-impg") multi = true;  // per-file indices (the reference's MultiImpg, src/multi_impg.rs)
     else if (a == "-m" || a == "--max-depth") max_depth = atol(need("-m"));
     else if (a == "--min-transitive-len") min_tl = atol(need(a.c_str()));
     else if (a == "--min-distance-between-ranges") mdbr = atol(need(a.c_str()));
@@ -185,6 +186,7 @@ int main(int argc, char **argv) {
   memset(&p, 0, sizeof p);
   p.transitive = transitive || dfs;  // --transitive-dfs implies a transitive query
   p.dfs = dfs;
+  p.multi_impg = multi;
   p.max_depth = (uint32_t)max_depth;
   p.min_transitive_len = eff_min_tl;
   p.min_distance_between_ranges = (int32_t)mdbr;

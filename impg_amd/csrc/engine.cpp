@@ -83,6 +83,8 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   cnt.reserve((size_t)n_fr * 4);
   win.reserve((size_t)n_fr * 16);
   pair_off.reserve((size_t)n_fr * 4);
+  // MultiImpg steps are Impg::query calls (multi_impg.rs:520-530): closed overlap test, unclipped range
+  if (multi) transitive = false;
   launch_lookup_count(v, fr, n_fr, transitive, cnt.as<uint32_t>(), win.as<uint4>(), stream);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);
   if (P > pair_budget || P >= 0xFFFFFFF0ull) {
@@ -105,6 +107,24 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
                  acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity,
                  store_cigar ? &sl : nullptr, stream);
+  if (multi && L.n_pairs) {
+    // sort every range's hits by (query_id, q.first, q.last, t.first, t.last) (multi_impg.rs:582-592)
+    const size_t b = std::max<size_t>((size_t)L.n_pairs * 4, 256);
+    m_dest.reserve(b); m_qid.reserve(b); m_qs.reserve(b); m_qe.reserve(b); m_ts.reserve(b); m_te.reserve(b); m_pe.reserve(b);
+    launch_sort5(fr, n_fr, pair_off.as<uint32_t>(), L.n_pairs, h, m_dest.as<uint32_t>(), stream);
+    HitArrays h2{m_qid.as<uint32_t>(), m_qs.as<int32_t>(), m_qe.as<int32_t>(), m_ts.as<int32_t>(), m_te.as<int32_t>()};
+    SliceArrays sl2{nullptr, nullptr, nullptr, nullptr};
+    if (store_cigar) {
+      m_sa.reserve(b); m_sn.reserve(b); m_so.reserve(b); m_sr.reserve(b);
+      sl2 = SliceArrays{m_sa.as<uint32_t>(), m_sn.as<uint32_t>(), m_so.as<int32_t>(), m_sr.as<int32_t>()};
+    }
+    launch_permute_slots(m_dest.as<uint32_t>(), L.n_pairs, h, h2, pair_entry.as<uint32_t>(), m_pe.as<uint32_t>(), sl, sl2, stream);
+    L.qid.swap(m_qid); L.qs.swap(m_qs); L.qe.swap(m_qe); L.ts.swap(m_ts); L.te.swap(m_te);
+    pair_entry.swap(m_pe);
+    if (store_cigar) { L.sl_a.swap(m_sa); L.sl_n.swap(m_sn); L.sl_off.swap(m_so); L.sl_rem.swap(m_sr); }
+    h = h2;
+    sl = sl2;
+  }
   IMPG_HIP(hipEventRecord(e2, stream));
   if (store_cigar && L.n_pairs) {  // materialise the slices while pair_entry is still this level's
     cnt.reserve((size_t)L.n_pairs * 4);
@@ -242,6 +262,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   split_ok = n > 1;
   min_identity = p.min_identity;
   store_cigar = p.store_cigar != 0 && keep != nullptr;  // slices are only materialised for full results
+  multi = p.multi_impg != 0;
   const DeviceIndexView &v = ix.view;
   ev_next = 0;
   timed.clear();
@@ -252,7 +273,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   IMPG_HIP(hipEventRecord(t0, stream));
   if (st) memset(st, 0, sizeof *st);
   const bool transitive = p.transitive != 0;
-  if (transitive && p.dfs) {
+  if (transitive && (p.dfs || multi)) {  // one worklist pop at a time per query
     ev_next = 0;
     run_dfs(ix, d_ranges, n, p, keep, d_count, d_cksum, st, self_out);
     return;
@@ -283,7 +304,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     if (d_count || d_cksum) {
       HitArrays h{L->qid.as<uint32_t>(), L->qs.as<int32_t>(), L->qe.as<int32_t>(), L->ts.as<int32_t>(), L->te.as<int32_t>()};
       launch_hit_stats(cur->as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h,
-                       transitive ? p.min_output_length : -1, d_count, d_cksum, stream);
+                       transitive ? p.min_output_length : -1, false, d_count, d_cksum, stream);
     }
     if (st) st->levels += 1;
     const bool last = !transitive || (p.max_depth > 0 && depth + 1 >= p.max_depth);
@@ -392,7 +413,7 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
     // ---- pop the top of every query's stack -----------------------------------
     head.reserve((size_t)n_stack * 4); gid.reserve((size_t)n_stack * 4);
     d_flag2.reserve((size_t)n_stack * 4); d_pos2.reserve((size_t)n_stack * 4);
-    launch_dfs_pop_flags(dk_a.as<unsigned long long>(), dd_a.as<uint32_t>(), n_stack, p.max_depth, head.as<uint32_t>(),
+    launch_dfs_pop_flags(dk_a.as<unsigned long long>(), dd_a.as<uint32_t>(), n_stack, p.max_depth, multi && !p.dfs, head.as<uint32_t>(),
                          d_flag2.as<uint32_t>(), d_popdepth.as<uint32_t>(), stream);
     const uint32_t n_fr = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), n_stack);
     const uint32_t n_keep = (uint32_t)scan(d_flag2.as<uint32_t>(), d_pos2.as<uint32_t>(), n_stack);
@@ -413,7 +434,7 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
       if (d_count || d_cksum) {
         HitArrays h{L->qid.as<uint32_t>(), L->qs.as<int32_t>(), L->qe.as<int32_t>(), L->ts.as<int32_t>(), L->te.as<int32_t>()};
         launch_hit_stats(frontier_b.as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h, p.min_output_length,
-                         d_count, d_cksum, stream);
+                         multi, d_count, d_cksum, stream);
       }
       if (st) st->levels += 1;
       n_pieces = update(v, frontier_b.as<FrontierRec>(), *L, n, p, frontier_a);  // pieces, sorted by (qidx, seq, start)

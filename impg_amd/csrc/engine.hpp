@@ -44,6 +44,8 @@ struct Engine {
   bool split_ok = false;
   double min_identity = __builtin_nan("");  // of the batch / stage call in flight
   bool store_cigar = false;
+  bool multi = false;       // MultiImpg semantics for the batch in flight (params.multi_impg)
+  DevBuf m_dest, m_qid, m_qs, m_qe, m_ts, m_te, m_pe, m_sa, m_sn, m_so, m_sr;  // 5-key sort: destination + double buffers
   uint32_t stage_n = 0;  // frontier size of the last stage_count call
 
   explicit Engine(int device);

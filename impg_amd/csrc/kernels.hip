@@ -860,7 +860,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 }
 __global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__restrict__ fr,
                                                         const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
-                                                        HitArrays h, int32_t min_output_length,
+                                                        HitArrays h, int32_t min_output_length, int skip_same_target,
                                                         unsigned long long *__restrict__ count,
                                                         unsigned long long *__restrict__ cksum) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -870,6 +870,7 @@ __global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__res
   const int32_t qs = h.qs[p], qe = h.qe[p];
   if (min_output_length >= 0 && abs(qe - qs) < min_output_length) return;
   const FrontierRec f = fr[pair_range[p]];
+  if (skip_same_target && qid == f.target_id) return;  // multi_impg.rs:883-885
   unsigned long long a = mix64(((unsigned long long)qid << 32) | (uint32_t)qs);
   a = mix64(a ^ (((unsigned long long)(uint32_t)qe << 32) | f.target_id));
   a = mix64(a ^ (((unsigned long long)(uint32_t)h.ts[p] << 32) | (uint32_t)h.te[p]));
@@ -1169,6 +1170,78 @@ __global__ __launch_bounds__(256) void hits_to_aos_kernel(const uint32_t *__rest
 }
 
 // ---------------------------------------------------------------------------
+// MultiImpg::query_all_indices (multi_impg.rs:556-592): the hits of one step are
+// merged over the per-file indices, hits equal to the self interval are dropped,
+// and the rest is sorted by (query_id, q.first, q.last, t.first, t.last).  Merging
+// then sorting makes the per-file split irrelevant: sort every range's slot run.
+// One wave per range; dest = number of slots that sort before (ties by slot).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool key5_less(uint32_t aq, int32_t a1, int32_t a2, int32_t a3, int32_t a4, uint32_t ai,
+                                          uint32_t bq, int32_t b1, int32_t b2, int32_t b3, int32_t b4, uint32_t bi) {
+  if (aq != bq) return aq < bq;
+  if (a1 != b1) return a1 < b1;
+  if (a2 != b2) return a2 < b2;
+  if (a3 != b3) return a3 < b3;
+  if (a4 != b4) return a4 < b4;
+  return ai < bi;
+}
+__global__ __launch_bounds__(256) void sort5_kernel(const FrontierRec *__restrict__ fr, uint32_t n,
+                                                    const uint32_t *__restrict__ pair_off, uint32_t n_pairs,
+                                                    HitArrays h, uint32_t *__restrict__ dest) {
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * 256u) >> 6;
+  const unsigned lane = lane_id();
+  for (uint32_t r = wave; r < n; r += nwaves) {
+    const uint32_t a = pair_off[r], b = r + 1 < n ? pair_off[r + 1] : n_pairs;
+    const FrontierRec f = fr[r];
+    for (uint32_t base = a; base < b; base += 64u) {
+      const uint32_t i = base + lane;
+      uint32_t q = HIT_NONE;
+      int32_t k1 = 0, k2 = 0, k3 = 0, k4 = 0;
+      if (i < b) {
+        q = h.qid[i];
+        if (q != HIT_NONE) {
+          k1 = h.qs[i]; k2 = h.qe[i]; k3 = h.ts[i]; k4 = h.te[i];
+          // is_self (multi_impg.rs:558-562): equal to the step's own interval -> dropped
+          if (q == f.target_id && k1 == f.start && k2 == f.end) { q = HIT_NONE; h.qid[i] = HIT_NONE; k1 = k2 = k3 = k4 = 0; }
+        }
+      }
+      uint32_t pos = 0;
+      for (uint32_t b2 = a; b2 < b; b2 += 64u) {
+        const uint32_t i2 = b2 + lane;
+        uint32_t q2 = HIT_NONE;
+        int32_t j1 = 0, j2 = 0, j3 = 0, j4 = 0;
+        if (i2 < b) {
+          q2 = h.qid[i2];
+          if (q2 != HIT_NONE) {
+            j1 = h.qs[i2]; j2 = h.qe[i2]; j3 = h.ts[i2]; j4 = h.te[i2];
+            if (q2 == f.target_id && j1 == f.start && j2 == f.end) { q2 = HIT_NONE; j1 = j2 = j3 = j4 = 0; }
+          }
+        }
+        const uint32_t cntl = min(64u, b - b2);
+        for (uint32_t t = 0; t < cntl; t++) {
+          const uint32_t oq = (uint32_t)__shfl((int)q2, (int)t);
+          const int32_t o1 = __shfl(j1, (int)t), o2 = __shfl(j2, (int)t), o3 = __shfl(j3, (int)t), o4 = __shfl(j4, (int)t);
+          pos += key5_less(oq, o1, o2, o3, o4, b2 + t, q, k1, k2, k3, k4, i) ? 1u : 0u;
+        }
+      }
+      if (i < b) dest[i] = a + pos;  // empty slots (0xFFFFFFFF) sort last
+    }
+  }
+}
+// out[dest[p]] = in[p] for every per-slot column
+__global__ __launch_bounds__(256) void permute_slots_kernel(const uint32_t *__restrict__ dest, uint32_t n_pairs, HitArrays in,
+                                                            HitArrays out, const uint32_t *__restrict__ pe_in,
+                                                            uint32_t *__restrict__ pe_out, SliceArrays sin, SliceArrays sout) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n_pairs) return;
+  const uint32_t d = dest[p];
+  out.qid[d] = in.qid[p]; out.qs[d] = in.qs[p]; out.qe[d] = in.qe[p]; out.ts[d] = in.ts[p]; out.te[d] = in.te[p];
+  pe_out[d] = pe_in[p];
+  if (sin.a) { sout.a[d] = sin.a[p]; sout.n[d] = sin.n[p]; sout.off[d] = sin.off[p]; sout.rem[d] = sin.rem[p]; }
+}
+
+// ---------------------------------------------------------------------------
 // DFS (query_transitive_dfs, impg.rs:2057-2309): every query keeps a stack of
 // (sequence, start, end, depth) sorted by (sequence, start); one round pops the
 // last element of every query's stack.  Stacks of all queries live in one flat
@@ -1190,13 +1263,16 @@ __global__ __launch_bounds__(256) void frontier_to_stack_kernel(const FrontierRe
 // the last record of a query's segment is its stack top (impg.rs:2117-2122)
 __global__ __launch_bounds__(256) void dfs_pop_flags_kernel(const unsigned long long *__restrict__ key,
                                                             const uint32_t *__restrict__ depth, uint32_t n,
-                                                            uint32_t max_depth, uint32_t *__restrict__ fr_flag,
+                                                            uint32_t max_depth, int pop_front,
+                                                            uint32_t *__restrict__ fr_flag,
                                                             uint32_t *__restrict__ keep_flag,
                                                             uint32_t *__restrict__ pop_depth) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const uint32_t q = (uint32_t)(key[i] >> 32);
-  const bool last = (i + 1 == n) || ((uint32_t)(key[i + 1] >> 32) != q);
+  // stack top = last record of the query's run; MultiImpg's FIFO worklist pops the first (multi_impg.rs:849-854)
+  const bool last = pop_front ? (i == 0 || (uint32_t)(key[i - 1] >> 32) != q)
+                              : ((i + 1 == n) || ((uint32_t)(key[i + 1] >> 32) != q));
   const uint32_t d = depth[i];
   keep_flag[i] = last ? 0u : 1u;
   fr_flag[i] = (last && !(max_depth > 0 && d >= max_depth)) ? 1u : 0u;  // impg.rs:2125: too deep -> popped, not explored
@@ -1414,9 +1490,11 @@ void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, Hi
   if (n_pairs) slice_write_kernel<<<cdiv(n_pairs, 64), 64, 0, s>>>(v, pair_entry, h, sl, n_pairs, off, out);
 }
 void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
-                      int32_t min_output_length, unsigned long long *count, unsigned long long *cksum, hipStream_t s) {
+                      int32_t min_output_length, bool skip_same_target, unsigned long long *count, unsigned long long *cksum,
+                      hipStream_t s) {
   if (!n_pairs) return;
-  hit_stats_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, min_output_length, count, cksum);
+  hit_stats_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, min_output_length, skip_same_target ? 1 : 0,
+                                                     count, cksum);
 }
 void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
                         unsigned long long *keys, uint32_t *vals, unsigned long long *n_active, hipStream_t s) {
@@ -1492,9 +1570,17 @@ void launch_frontier_to_stack(const FrontierRec *fr, uint32_t n, const uint32_t 
   frontier_to_stack_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, n, pop_depth, use_depth ? 1 : 0, key, st, en, depth);
 }
 void launch_dfs_pop_flags(const unsigned long long *key, const uint32_t *depth, uint32_t n, uint32_t max_depth,
-                          uint32_t *fr_flag, uint32_t *keep_flag, uint32_t *pop_depth, hipStream_t s) {
+                          bool pop_front, uint32_t *fr_flag, uint32_t *keep_flag, uint32_t *pop_depth, hipStream_t s) {
   if (!n) return;
-  dfs_pop_flags_kernel<<<cdiv(n, 256), 256, 0, s>>>(key, depth, n, max_depth, fr_flag, keep_flag, pop_depth);
+  dfs_pop_flags_kernel<<<cdiv(n, 256), 256, 0, s>>>(key, depth, n, max_depth, pop_front ? 1 : 0, fr_flag, keep_flag, pop_depth);
+}
+void launch_sort5(const FrontierRec *fr, uint32_t n, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h, uint32_t *dest,
+                  hipStream_t s) {
+  if (n && n_pairs) sort5_kernel<<<wave_grid(n), 256, 0, s>>>(fr, n, pair_off, n_pairs, h, dest);
+}
+void launch_permute_slots(const uint32_t *dest, uint32_t n_pairs, HitArrays in, HitArrays out, const uint32_t *pe_in,
+                          uint32_t *pe_out, SliceArrays sin, SliceArrays sout, hipStream_t s) {
+  if (n_pairs) permute_slots_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(dest, n_pairs, in, out, pe_in, pe_out, sin, sout);
 }
 void launch_dfs_pop_scatter(const unsigned long long *key, const int32_t *st, const int32_t *en, const uint32_t *depth,
                             uint32_t n, const uint32_t *fr_flag, const uint32_t *fr_pos, const uint32_t *keep_flag,

@@ -56,7 +56,12 @@ void launch_slice_counts(HitArrays h, SliceArrays sl, uint32_t n_pairs, uint32_t
 void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, HitArrays h, SliceArrays sl, uint32_t n_pairs,
                         const uint32_t *off, uint32_t *out, hipStream_t s);
 void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
-                      int32_t min_output_length, unsigned long long *count, unsigned long long *cksum, hipStream_t s);
+                      int32_t min_output_length, bool skip_same_target, unsigned long long *count, unsigned long long *cksum,
+                      hipStream_t s);
+void launch_sort5(const FrontierRec *fr, uint32_t n, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h, uint32_t *dest,
+                  hipStream_t s);
+void launch_permute_slots(const uint32_t *dest, uint32_t n_pairs, HitArrays in, HitArrays out, const uint32_t *pe_in,
+                          uint32_t *pe_out, SliceArrays sin, SliceArrays sout, hipStream_t s);
 void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
                         unsigned long long *keys, uint32_t *vals, unsigned long long *n_active, hipStream_t s);
 size_t sort_pairs_scratch_bytes(uint32_t n);
@@ -87,7 +92,7 @@ void launch_hits_to_aos(const uint32_t *pair_range, const uint32_t *pair_off, ui
 void launch_frontier_to_stack(const FrontierRec *fr, uint32_t n, const uint32_t *pop_depth, bool use_depth,
                               unsigned long long *key, int32_t *st, int32_t *en, uint32_t *depth, hipStream_t s);
 void launch_dfs_pop_flags(const unsigned long long *key, const uint32_t *depth, uint32_t n, uint32_t max_depth,
-                          uint32_t *fr_flag, uint32_t *keep_flag, uint32_t *pop_depth, hipStream_t s);
+                          bool pop_front, uint32_t *fr_flag, uint32_t *keep_flag, uint32_t *pop_depth, hipStream_t s);
 void launch_dfs_pop_scatter(const unsigned long long *key, const int32_t *st, const int32_t *en, const uint32_t *depth,
                             uint32_t n, const uint32_t *fr_flag, const uint32_t *fr_pos, const uint32_t *keep_flag,
                             const uint32_t *keep_pos, FrontierRec *fr_out, unsigned long long *key_out, int32_t *st_out,

@@ -73,7 +73,9 @@ typedef struct {
   int32_t min_output_length;           /* < 0 = None */
   double min_identity;                 /* NaN = None (min_gap_compressed_identity) */
   int32_t store_cigar;                 /* BED output never needs it (main.rs:7447) */
-  int32_t reserved;
+  int32_t multi_impg;                  /* 1: MultiImpg semantics (src/multi_impg.rs:495-595, :796-991): every step's hits
+                                          sorted by (query_id, q.first, q.last, t.first, t.last), one worklist pop at a
+                                          time (front = BFS, back = DFS), unclipped ranges, same-sequence hits skipped */
 } impg_gpu_params_t;
 
 /* Order in which overlapping entries of one target are visited; it fixes the

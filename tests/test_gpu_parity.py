@@ -347,3 +347,63 @@ def test_store_cigar_slices(tmp_path, seed, weird, incons, max_ops):
     assert o.ops_to_pairs(r.cigars(1)[1]) == [(15, "="), (50, "I"), (1, "=")]
     assert o.ops_to_pairs(r.cigars(2)[1]) == [(10, "="), (5, "I"), (5, "D"), (50, "="), (50, "I"), (35, "=")]
     assert o.ops_to_pairs(r.cigars(2)[0]) == [(100, "=")]  # the self interval's own CIGAR (impg.rs:1870-1872)
+
+
+def both_files(tmp_path, texts, bidirectional=True):
+    paths = []
+    for i, t in enumerate(texts):
+        paths.append(str(tmp_path / ("f%d.paf" % i)))
+        with open(paths[-1], "w") as f:
+            f.write(t)
+    g = impg_amd.GpuImpg.from_paf(paths, bidirectional=bidirectional)
+    c = o.OracleIndex(paf_paths=paths, bidirectional=bidirectional, preparse=True)
+    assert g.num_seqs() == c.num_seqs()
+    return g, c
+
+
+@pytest.mark.parametrize("seed,n_files", [(81, 1), (82, 3), (83, 4)])
+def test_multi_impg_semantics(tmp_path, seed, n_files):
+    """params.multi_impg: MultiImpg::query / query_transitive_{bfs,dfs} over per-file indices
+    (multi_impg.rs:495-595, :796-991): hits of one step merged over the files and sorted by five
+    keys, one worklist pop at a time (front or back), unclipped ranges, same-sequence hits skipped."""
+    texts = []
+    for k in range(n_files):  # same sequence universe in every file, different alignments
+        t, names = random_paf(seed * 10 + k, 120, n_seq=6, seq_len=20000, weird=(k % 2 == 1), self_aln=True)
+        texts.append(t)
+    g, c = both_files(tmp_path, texts)
+    ranges = random_ranges(seed + 3, 60, g.num_seqs(), 20000, max_len=3000, min_len=50)
+    for kw in [dict(),
+               dict(min_identity=0.6),
+               dict(transitive=True, max_depth=1, min_transitive_len=0, min_distance_between_ranges=0),
+               dict(transitive=True, max_depth=2),
+               dict(transitive=True, dfs=True, max_depth=2),
+               dict(transitive=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=10),
+               dict(transitive=True, dfs=True, max_depth=4, min_transitive_len=101, min_distance_between_ranges=50,
+                    min_output_length=200),
+               dict(transitive=True, max_depth=0, min_transitive_len=300, min_distance_between_ranges=10)]:
+        assert_same(g, c, ranges, multi_impg=True, **kw)
+    # store_cigar rides along with the permutation of the sorted hits
+    kw = dict(transitive=True, max_depth=2, min_transitive_len=40, multi_impg=True)
+    res = g.query_batch(ranges[:20], impg_amd.make_params(store_cigar=True, **kw))
+    for i, (t, s, e) in enumerate(ranges[:20]):
+        want, wcg = c.query_cigar(t, s, e, **kw)
+        assert res[i].tolist() == want.tolist()
+        got = res.cigars(i)
+        assert [x.tolist() for x in got] == [x.tolist() for x in wcg]
+
+
+def test_multi_impg_dense_step(tmp_path):
+    """> 64 hits in one step: the multi-chunk path of the five-key sort, with duplicates
+    of the self interval and exact ties."""
+    lines = []
+    for i in range(150):
+        q = "Q%d" % (i % 7)
+        lines.append("%s\t5000\t%d\t%d\t%s\tT\t5000\t%d\t%d\t10\t10\t60\tcg:Z:%d=" %
+                     (q, 100 + (i % 5), 600 + (i % 5), "+-"[i % 2], 1000 + (i % 3), 1500 + (i % 3), 500))
+    lines.append("T\t5000\t1000\t1500\t+\tT\t5000\t1000\t1500\t10\t10\t60\tcg:Z:500=")  # maps a range onto itself
+    g, c = both_files(tmp_path, ["\n".join(lines[:80]) + "\n", "\n".join(lines[80:]) + "\n"])
+    t = g.seq_id("T")
+    ranges = [(t, 1000, 1500), (t, 900, 1600), (t, 1200, 1300), (g.seq_id("Q1"), 0, 1000)]
+    for kw in [dict(), dict(transitive=True, max_depth=2, min_transitive_len=10),
+               dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=10, min_distance_between_ranges=0)]:
+        assert_same(g, c, ranges, multi_impg=True, **kw)

@@ -272,6 +272,9 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
   } else if (k == "chunk_ranges") {
     if (value < 0 || value >= (1ll << 31)) throw Error{IMPG_E_INVALID, "chunk_ranges out of range"};
     ix->engine->chunk_ranges = (uint32_t)value;
+  } else if (k == "locality_min") {  // frontier size from which the projection runs in window order (0 = never)
+    if (value < 0 || value >= (1ll << 31)) throw Error{IMPG_E_INVALID, "locality_min out of range"};
+    ix->engine->locality_min = (uint32_t)value;
   } else throw Error{IMPG_E_INVALID, "unknown option " + k};
   return IMPG_OK;
   IMPG_CATCH
@@ -465,11 +468,11 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   hipEvent_t e0 = E.event(), e1 = E.event(), e2 = E.event();
   IMPG_HIP(hipEventRecord(e0, E.stream));
   launch_lookup_emit(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_off.as<uint32_t>(), E.win.as<uint4>(),
-                     L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), E.stream);
+                     L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), nullptr, nullptr, E.stream);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
                  E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), params->min_identity, nullptr,
-                 E.stream);
+                 nullptr, E.stream);
   IMPG_HIP(hipEventRecord(e2, E.stream));
   launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
   IMPG_HIP(hipStreamSynchronize(E.stream));

@@ -94,8 +94,32 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   L.n_pairs = (uint32_t)P;
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
+  // Projection order: the slots stay in the reference's order, but the projection
+  // kernel walks them range by range in the order of the ranges' windows in the
+  // entry array, so that lanes and workgroups in flight together gather
+  // neighbouring entries and CIGAR tiles (L2 hits instead of HBM lines).
+  const uint32_t *d_slot_of = nullptr, *d_offp = nullptr;
+  if (locality_min && n_fr >= locality_min && P) {
+    const size_t nb = (size_t)n_fr * 4;
+    lo_key.reserve(nb); lo_key2.reserve(nb); lo_idx.reserve(nb); lo_perm.reserve(nb); lo_cnt.reserve(nb); lo_off.reserve(nb);
+    lo_offp.reserve(nb);
+    slot_of.reserve(std::max<size_t>(P * 4, 256));
+    launch_window_keys(win.as<uint4>(), n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream);
+    const size_t tb = sort_u32_scratch_bytes(n_fr);
+    sort_tmp.reserve(tb);
+    // 16-entry granularity is plenty; keys are positions in the entry array
+    const unsigned loc_bit = 4;
+    const unsigned hi_bit = std::max(5u, bits_for((uint32_t)std::min<size_t>(v.n_entries, 0xFFFFFFFFull)));
+    launch_sort_u32(sort_tmp.p, tb, lo_key.as<uint32_t>(), lo_key2.as<uint32_t>(), lo_idx.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr,
+                    stream, std::min(loc_bit, hi_bit - 1), hi_bit);
+    launch_gather_u32(cnt.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr, lo_cnt.as<uint32_t>(), stream);
+    scan(lo_cnt.as<uint32_t>(), lo_off.as<uint32_t>(), n_fr);
+    launch_scatter_u32(lo_off.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr, lo_offp.as<uint32_t>(), stream);
+    d_slot_of = slot_of.as<uint32_t>();
+    d_offp = lo_offp.as<uint32_t>();
+  }
   launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
-                     pair_entry.as<uint32_t>(), stream);
+                     pair_entry.as<uint32_t>(), d_offp, const_cast<uint32_t *>(d_slot_of), stream);
   IMPG_HIP(hipEventRecord(e1, stream));
   HitArrays h = hit_arrays(L, L.n_pairs);
   SliceArrays sl{nullptr, nullptr, nullptr, nullptr};
@@ -106,7 +130,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   }
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
                  acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity,
-                 store_cigar ? &sl : nullptr, stream);
+                 store_cigar ? &sl : nullptr, d_slot_of, stream);
   if (multi && L.n_pairs) {
     // sort every range's hits by (query_id, q.first, q.last, t.first, t.last) (multi_impg.rs:582-592)
     const size_t b = std::max<size_t>((size_t)L.n_pairs * 4, 256);

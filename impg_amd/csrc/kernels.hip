@@ -197,36 +197,45 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
                                                           uint32_t n, const uint32_t *__restrict__ pair_off,
                                                           const uint4 *__restrict__ win,
                                                           uint32_t *__restrict__ pair_range,
-                                                          uint32_t *__restrict__ pair_entry) {
+                                                          uint32_t *__restrict__ pair_entry,
+                                                          const uint32_t *__restrict__ offp,
+                                                          uint32_t *__restrict__ slot_of) {
   const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * 256u) >> 6;
   const unsigned lane = lane_id();
   const int32_t *ecol = end_col<TRANSITIVE>(v);
+  // slot_of (optional): the same slots listed in PROJECTION order -- ranges sorted by
+  // their window position in the entry array -- so that neighbouring lanes of the
+  // projection kernel gather neighbouring entries and tiles (offp[r] = first
+  // position of range r in that order).  Slot order itself never changes.
   // software pipeline: the next range's window record and slot offset are
   // requested before the current range is processed, so a range costs one
   // dependent round trip (its rank column), not three
   uint4 w = make_uint4(0, 0, 0, 0);
-  uint32_t off = 0;
-  if (wave < n) { w = win[wave]; off = pair_off[wave]; }
+  uint32_t off = 0, po = 0;
+  if (wave < n) { w = win[wave]; off = pair_off[wave]; if (slot_of) po = offp[wave]; }
   for (uint32_t r = wave; r < n; r += nwaves) {
     const uint32_t rn = r + nwaves;
     uint4 wn = make_uint4(0, 0, 0, 0);
-    uint32_t offn = 0;
-    if (rn < n) { wn = win[rn]; offn = pair_off[rn]; }
+    uint32_t offn = 0, pon = 0;
+    if (rn < n) { wn = win[rn]; offn = pair_off[rn]; if (slot_of) pon = offp[rn]; }
     const uint32_t lo = w.x, ub = w.y;
     const unsigned long long m0 = ((unsigned long long)w.w << 32) | w.z;  // hits of the first chunk, from the count pass
-    const uint32_t off_r = off;
+    const uint32_t off_r = off, po_r = po;
     w = wn;
     off = offn;
+    po = pon;
     if (lo >= ub) continue;
     if (ub - lo <= 64u) {
       // the whole window is one chunk (the common case): no column is re-read
       const bool hit = (m0 >> lane) & 1ull;
       if (v.sorted_order) {  // visit order == segment order: plain stream compaction
         if (hit) {
-          const uint32_t pos = off_r + __popcll(m0 & lanemask_lt());
+          const uint32_t k = __popcll(m0 & lanemask_lt());
+          const uint32_t pos = off_r + k;
           pair_range[pos] = r;
           pair_entry[pos] = lo + lane;
+          if (slot_of) slot_of[po_r + k] = pos;
         }
         continue;
       }
@@ -252,6 +261,7 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
       if (lane < (unsigned)__popcll(m0)) {  // lane i now holds the i-th hit in visit order: coalesced stores
         pair_range[off_r + lane] = r;
         pair_entry[off_r + lane] = lo + who;
+        if (slot_of) slot_of[po_r + lane] = off_r + lane;
       }
       continue;
     }
@@ -265,9 +275,11 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
         bool hit = i < ub && window_hit<TRANSITIVE>(ecol[i], qs);
         unsigned long long m = __ballot(hit);
         if (hit) {
-          uint32_t pos = off + run + __popcll(m & lanemask_lt());
+          uint32_t k = run + __popcll(m & lanemask_lt());
+          uint32_t pos = off + k;
           pair_range[pos] = r;
           pair_entry[pos] = i;
+          if (slot_of) slot_of[po_r + k] = pos;
         }
         run += __popcll(m);
       }
@@ -298,9 +310,24 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
       if (hit) {
         pair_range[off + pos] = r;
         pair_entry[off + pos] = i;
+        if (slot_of) slot_of[po_r + pos] = off + pos;
       }
     }
   }
+}
+
+// projection order: ranges sorted by the position of their window in the entry array
+__global__ __launch_bounds__(256) void window_keys_kernel(const uint4 *__restrict__ win, uint32_t n, uint32_t *__restrict__ key,
+                                                          uint32_t *__restrict__ idx) {
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= n) return;
+  key[r] = win[r].x;
+  idx[r] = r;
+}
+__global__ __launch_bounds__(256) void scatter_u32_kernel(const uint32_t *__restrict__ in, const uint32_t *__restrict__ perm,
+                                                          uint32_t n, uint32_t *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) out[perm[i]] = in[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -608,16 +635,22 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
                                                       const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
                                                       uint32_t *__restrict__ err_flag, double min_identity,
-                                                      SliceArrays sl) {
+                                                      SliceArrays sl, const uint32_t *__restrict__ slot_of, int xcd_map) {
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   constexpr bool CIGAR = (MODE & MODE_CIGAR) != 0;
-  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give
+  // every XCD one contiguous eighth of the (locality-ordered) pair list instead of
+  // every eighth block of it.  The grid is a multiple of 8 blocks.
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t lblock = xcd_map ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t pp = lblock * 256u + threadIdx.x;
   bool ok = false;
   TileScan res;
   res.found = false;
   res.pqs = res.pts = res.pqe = res.pte = -1;
   uint32_t qid = HIT_NONE;
-  if (p < n_pairs) {
+  if (pp < n_pairs) {
+    const uint32_t p = slot_of ? slot_of[pp] : pp;
     const uint32_t r = pair_range[p];
     const FrontierRec f = fr[r];
     // the 64-byte entry: coordinates, record totals and its inline checkpoints
@@ -1458,21 +1491,28 @@ void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32
 }
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
-                        hipStream_t s) {
+                        const uint32_t *offp, uint32_t *slot_of, hipStream_t s) {
   if (!n) return;
-  if (transitive) lookup_emit_kernel<true><<<wave_grid(n), 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry);
-  else lookup_emit_kernel<false><<<wave_grid(n), 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry);
+  if (transitive) lookup_emit_kernel<true><<<wave_grid(n), 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, slot_of);
+  else lookup_emit_kernel<false><<<wave_grid(n), 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, slot_of);
+}
+void launch_window_keys(const uint4 *win, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s) {
+  if (n) window_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(win, n, key, idx);
+}
+void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, uint32_t *out, hipStream_t s) {
+  if (n) scatter_u32_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, perm, n, out);
 }
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
-                    hipStream_t s) {
+                    const uint32_t *slot_of, hipStream_t s) {
   if (!n_pairs) return;
   const bool ident = min_identity == min_identity;  // NaN = no filter
-  const uint32_t g = cdiv(n_pairs, 256);
+  const uint32_t g = (cdiv(n_pairs, 256) + 7u) & ~7u;  // a multiple of the 8 XCDs (see the block mapping in the kernel)
+  const int xcd_map = 1;
   const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};
   const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0);
-#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl)
+#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, slot_of, xcd_map)
   if (transitive) {
     switch (mode) { case 0: IMPG_LAUNCH(true, 0); break; case 1: IMPG_LAUNCH(true, 1); break;
                     case 2: IMPG_LAUNCH(true, 2); break; default: IMPG_LAUNCH(true, 3); }
@@ -1621,9 +1661,9 @@ size_t sort_u32_scratch_bytes(uint32_t n) {
   return bytes;
 }
 void launch_sort_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
-                     uint32_t n, hipStream_t s) {
+                     uint32_t n, hipStream_t s, unsigned begin_bit, unsigned end_bit) {
   if (!n) return;
-  IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, 32, s));
+  IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s));
 }
 size_t sort_u64v_scratch_bytes(uint32_t n) {
   size_t bytes = 0;

@@ -44,14 +44,16 @@ void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32
                          uint4 *win, hipStream_t s);
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
-                        hipStream_t s);
+                        const uint32_t *offp, uint32_t *slot_of, hipStream_t s);
+void launch_window_keys(const uint4 *win, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s);
+void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, uint32_t *out, hipStream_t s);
 void launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, unsigned long long *d_bsum,
                            unsigned long long *d_total, hipStream_t s);
 size_t scan_scratch_bytes(uint32_t n);
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
-                    hipStream_t s);
+                    const uint32_t *slot_of, hipStream_t s);
 void launch_slice_counts(HitArrays h, SliceArrays sl, uint32_t n_pairs, uint32_t *cnt, hipStream_t s);
 void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, HitArrays h, SliceArrays sl, uint32_t n_pairs,
                         const uint32_t *off, uint32_t *out, hipStream_t s);
@@ -110,7 +112,7 @@ void launch_dfs_compact(const uint32_t *gstart, const uint32_t *cnt, const uint3
                         unsigned long long *key_out, int32_t *st_out, int32_t *en_out, uint32_t *depth_out, hipStream_t s);
 size_t sort_u32_scratch_bytes(uint32_t n);
 void launch_sort_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
-                     uint32_t n, hipStream_t s);
+                     uint32_t n, hipStream_t s, unsigned begin_bit = 0, unsigned end_bit = 32);
 size_t sort_u64v_scratch_bytes(uint32_t n);
 void launch_sort_u64v(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
                       const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s);

@@ -126,7 +126,10 @@ size_t impg_gpu_device_bytes(const impg_gpu_index_t *);
 
 /* Tunables: "pair_budget" (max candidate pairs held in HBM per level; a batch
  * whose level exceeds it is split by ranges, queries being independent) and
- * "chunk_ranges" (initial ranges per chunk, 0 = whole batch). */
+ * "chunk_ranges" (initial ranges per chunk, 0 = whole batch), "locality_min"
+ * (frontier size from which the projection kernel walks the hit slots in the order
+ * of the ranges' windows in the entry array -- a cache-locality order; results
+ * are identical either way; 0 = never). */
 int impg_gpu_set_option(impg_gpu_index_t *, const char *key, int64_t value);
 
 /* Visit rank of the sorted positions 0..n-1 of an n-entry target under an order

@@ -32,15 +32,30 @@ constexpr uint32_t OP_LEN_MASK = (1u << 29) - 1;
 constexpr uint32_t OP_PAD = 0xFFFFFFFFu;  // tile padding, never a valid op (code 7)
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 
-// One 128-byte line per tile: a 24-byte header {T0, Q0, sumT, sumQ, Tm, Qm} -- the
-// sums of target_delta / |query_delta| of the record's ops before the tile, inside
-// it, and before its op 10 -- followed by 26 packed ops.  A tile is
-// self-describing (running positions at either end and at the split follow from
-// its own line) and splits into two sub-tiles on 16-byte boundaries: ops 0..9
-// (words 6..15) and ops 10..25 (words 16..31); a scan walks one sub-tile.
+// One 128-byte line per tile: a 24-byte header followed by 26 packed ops (words 6..31).
+//   w0 T0, w1 Q0          sums of target_delta / |query_delta| of the record's ops before the tile
+//   w2 dT1 | dT2 << 16    the same sums, relative to T0, before the tile's ops 6, 14, 22
+//   w3 dT3 | dT4 << 16    ... and after its last op (dT4 = the tile's own target sum)
+//   w4 dQ1 | dQ2 << 16, w5 dQ3 | dQ4 << 16
+// A tile is self-describing (running positions at either end and at three inner
+// splits follow from its own line) and splits into four sub-tiles on 16-byte
+// boundaries: ops 0..5 (words 6..11), 6..13 (12..19), 14..21 (20..27), 22..25
+// (28..31); a scan walks one sub-tile, at most two 16-byte vectors.  A tile whose
+// target or query sum does not fit 16 bits ("wide") stores 0xFFFF in all eight
+// fields and is walked literally; its end position is the next tile's T0/Q0.
 constexpr uint32_t TILE_WORDS = 32;
 constexpr uint32_t TILE_OPS = 26;
-constexpr uint32_t TILE_LOW_OPS = 10;
+constexpr uint32_t TILE_SUBS = 4;
+constexpr uint32_t TILE_WIDE = 0xFFFFu;
+#if defined(__HIPCC__)
+#define IMPG_HD __host__ __device__
+#else
+#define IMPG_HD
+#endif
+IMPG_HD constexpr uint32_t sub_first_op(uint32_t s) { return s == 0 ? 0u : s == 1 ? 6u : s == 2 ? 14u : s == 3 ? 22u : 26u; }
+IMPG_HD constexpr uint32_t subs_with_ops(uint32_t n_ops_in_tile) {  // sub-tiles of a tile that hold at least one op
+  return n_ops_in_tile > 22u ? 4u : n_ops_in_tile > 14u ? 3u : n_ops_in_tile > 6u ? 2u : 1u;
+}
 constexpr uint32_t INLINE_TILES = 8;      // entries of records with <= 8 tiles carry their checkpoints inline
 
 // ---- device index (HBM layout) ---------------------------------------------
@@ -85,7 +100,7 @@ struct DeviceIndexView {  // passed by value to kernels
   const Entry *entries;      // [n_entries]
   const uint32_t *ops;       // [n_tiles*32] tiles
   const uint32_t *ext_cp;    // effective target prefixes of entries with > 8 tiles
-  const uint4 *idp;          // [2*n_tiles] matched bases, mismatched bases, gap ops of the record before each sub-tile
+  const uint4 *idp;          // [4*n_tiles] matched bases, mismatched bases, gap ops of the record before each sub-tile
   const int32_t *seq_len;    // [n_seq]
   uint32_t n_seq;
   uint32_t n_entries;

@@ -103,7 +103,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     }
   }
 
-  // ---- op pool: 128-byte tiles {T0,Q0,sumT,sumQ | 28 ops} ------------------------
+  // ---- op pool: 128-byte tiles {T0,Q0, 8 x u16 inner sums | 26 ops} (impg_internal.hpp) ----
   std::vector<uint32_t> tile_base(n_records, 0);
   std::vector<uint32_t> rec_totT(n_records, 0), rec_totQ(n_records, 0);
   uint64_t n_tiles = 0;
@@ -114,7 +114,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     if (n_tiles >= (1ull << 32) - 2) throw Error{IMPG_E_UNSUPPORTED, "op pool exceeds 2^32 tiles"};
   }
   std::vector<uint32_t> pool(n_tiles * TILE_WORDS, OP_PAD);
-  std::vector<uint4> idp(2 * n_tiles);  // per sub-tile: matched / mismatched bases and gap ops before it (identity filter)
+  std::vector<uint4> idp(TILE_SUBS * n_tiles);  // per sub-tile: matched / mismatched bases and gap ops before it (identity filter)
   std::atomic<bool> bad_op{false};
   parallel_chunks(n_records, [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; i++) {
@@ -125,29 +125,34 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
       for (uint32_t k0 = 0; k0 < n; k0 += TILE_OPS) {
         const size_t tile = (size_t)tile_base[i] + k0 / TILE_OPS;
         uint32_t *line = pool.data() + tile * TILE_WORDS;
-        idp[2 * tile] = make_uint4(sm, sx, sg, 0);
-        uint32_t t0 = st, q0 = sq;
-        bool mid_set = false;
-        for (uint32_t k = k0; k < std::min(n, k0 + TILE_OPS); k++) {
-          if (k - k0 == TILE_LOW_OPS) {  // prefix before the upper sub-tile
-            line[4] = st; line[5] = sq;
-            idp[2 * tile + 1] = make_uint4(sm, sx, sg, 0);
-            mid_set = true;
-          }
-          uint32_t v = src[k], code = v >> 29, len = v & OP_LEN_MASK;
+        const uint32_t t0 = st, q0 = sq;
+        uint32_t dt[TILE_SUBS + 1], dq[TILE_SUBS + 1];  // sums before sub-tile s (s = 4: after the tile)
+        uint32_t sub = 0;
+        const uint32_t cnt = std::min(n - k0, TILE_OPS);
+        auto boundary = [&]() {
+          dt[sub] = st - t0; dq[sub] = sq - q0;
+          if (sub < TILE_SUBS) idp[TILE_SUBS * tile + sub] = make_uint4(sm, sx, sg, 0);
+          sub++;
+        };
+        for (uint32_t u = 0; u < cnt; u++) {
+          if (u == sub_first_op(sub)) boundary();
+          const uint32_t v = src[k0 + u], code = v >> 29, len = v & OP_LEN_MASK;
           if (code > 4) bad_op = true;  // CigarOp::new panics (impg.rs:88)
-          line[6 + (k - k0)] = v;
+          line[6 + u] = v;
           if (code != 2) st += len;  // target_delta: all but 'I' (impg.rs:115-121)
           if (code != 3) sq += len;  // |query_delta|: all but 'D' (impg.rs:123-135)
           if (code == 0 || code == 4) sm += len;       // 'M' counted as match (impg.rs:2959)
           else if (code == 1) sx += len;
           else sg += 1;                                 // gap-compressed: one per 'I' / 'D' op
         }
-        if (!mid_set) {  // <= 10 ops: the upper sub-tile is empty and starts at the tile's end
-          line[4] = st; line[5] = sq;
-          idp[2 * tile + 1] = make_uint4(sm, sx, sg, 0);
+        while (sub <= TILE_SUBS) boundary();  // sub-tiles without ops start (and end) at the tile's end
+        line[0] = t0; line[1] = q0;
+        if (dt[TILE_SUBS] >= TILE_WIDE || dq[TILE_SUBS] >= TILE_WIDE) {
+          line[2] = line[3] = line[4] = line[5] = 0xFFFFFFFFu;  // wide tile: no inner splits
+        } else {
+          line[2] = dt[1] | dt[2] << 16; line[3] = dt[3] | dt[4] << 16;
+          line[4] = dq[1] | dq[2] << 16; line[5] = dq[3] | dq[4] << 16;
         }
-        line[0] = t0; line[1] = q0; line[2] = st - t0; line[3] = sq - q0;
       }
       rec_totT[i] = st;
       rec_totQ[i] = sq;

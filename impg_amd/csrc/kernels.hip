@@ -531,14 +531,16 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
   Qn += qa;
 }
 
-// A sub-tile: original tile j, half h (0 = ops 0..9, 1 = ops 10..25).
+// A sub-tile: original tile j, sub-tile h (0..3, impg_internal.hpp).
 struct SubTile {
   uint32_t j, h;
 };
 __device__ __forceinline__ bool same_sub(const SubTile &a, const SubTile &b) { return a.j == b.j && a.h == b.h; }
 
-struct TileHdr {  // the line header, in the ENTRY's axes
-  uint32_t t0, q0, st, sq, tm, qm;
+struct TileHdr {  // the line header, in the ENTRY's axes: sums before the tile, then (relative to those) before its
+  uint32_t t0, q0;                                   // sub-tiles 1..3 and after its last op
+  uint32_t bt1, bt2, bt3, bt4, bq1, bq2, bq3, bq4;
+  bool wide;                                         // no inner sums (a sum overflows 16 bits): walk literally
 };
 __device__ __forceinline__ TileHdr tile_header(const PairCtx &c, uint32_t j) {
   const uint32_t *line = c.ops + (size_t)j * TILE_WORDS;
@@ -546,52 +548,94 @@ __device__ __forceinline__ TileHdr tile_header(const PairCtx &c, uint32_t j) {
   const uint2 b = *reinterpret_cast<const uint2 *>(line + 4);
   TileHdr h;
   h.t0 = c.swp ? a.y : a.x; h.q0 = c.swp ? a.x : a.y;
-  h.st = c.swp ? a.w : a.z; h.sq = c.swp ? a.z : a.w;
-  h.tm = c.swp ? b.y : b.x; h.qm = c.swp ? b.x : b.y;
+  const uint32_t t12 = c.swp ? b.x : a.z, t34 = c.swp ? b.y : a.w;
+  const uint32_t q12 = c.swp ? a.z : b.x, q34 = c.swp ? a.w : b.y;
+  h.bt1 = t12 & 0xFFFFu; h.bt2 = t12 >> 16; h.bt3 = t34 & 0xFFFFu; h.bt4 = t34 >> 16;
+  h.bq1 = q12 & 0xFFFFu; h.bq2 = q12 >> 16; h.bq3 = q34 & 0xFFFFu; h.bq4 = q34 >> 16;
+  h.wide = (a.w >> 16) == TILE_WIDE;
   return h;
 }
-// target position at which the tile's SECOND effective sub-tile starts
-__device__ __forceinline__ int32_t tile_mid_T(const PairCtx &c, const TileHdr &h) {
-  return c.ts + (int32_t)(c.flip ? c.totT - h.tm : h.tm);
+// sums before original sub-tile s of the tile (s = 4: after the tile), relative to its start
+__device__ __forceinline__ uint32_t sub_bt(const TileHdr &h, uint32_t s) {
+  return s == 0 ? 0u : s == 1 ? h.bt1 : s == 2 ? h.bt2 : s == 3 ? h.bt3 : h.bt4;
 }
-// running positions at the effective start of sub-tile (j, half)
-__device__ __forceinline__ void sub_start(const PairCtx &c, const TileHdr &h, uint32_t half, int32_t &T, int32_t &Qn) {
+__device__ __forceinline__ uint32_t sub_bq(const TileHdr &h, uint32_t s) {
+  return s == 0 ? 0u : s == 1 ? h.bq1 : s == 2 ? h.bq2 : s == 3 ? h.bq3 : h.bq4;
+}
+// running positions where the walk ENTERS original sub-tile s: its start for a
+// forward walk, its end (mirrored) for a back-to-front walk.  Not for wide tiles.
+__device__ __forceinline__ void sub_start(const PairCtx &c, const TileHdr &h, uint32_t s, int32_t &T, int32_t &Qn) {
   uint32_t t, q;
-  if (!c.flip) { t = half ? h.tm : h.t0; q = half ? h.qm : h.q0; }
-  else { t = c.totT - (half ? h.t0 + h.st : h.tm); q = c.totQ - (half ? h.q0 + h.sq : h.qm); }
+  if (!c.flip) { t = h.t0 + sub_bt(h, s); q = h.q0 + sub_bq(h, s); }
+  else { t = c.totT - (h.t0 + sub_bt(h, s + 1)); q = c.totQ - (h.q0 + sub_bq(h, s + 1)); }
   T = c.ts + (int32_t)t;
   Qn = (int32_t)q;
 }
+// running positions where the walk enters TILE j (any tile, wide or not)
+__device__ __forceinline__ void tile_start(const PairCtx &c, uint32_t j, int32_t &T, int32_t &Qn) {
+  const TileHdr h = tile_header(c, j);
+  if (!c.flip) { T = c.ts + (int32_t)h.t0; Qn = (int32_t)h.q0; return; }
+  uint32_t et, eq;  // sums after the tile
+  if (!h.wide) { et = h.t0 + h.bt4; eq = h.q0 + h.bq4; }
+  else if (j + 1 < c.m) { const TileHdr n = tile_header(c, j + 1); et = n.t0; eq = n.q0; }
+  else { et = c.totT; eq = c.totQ; }
+  T = c.ts + (int32_t)(c.totT - et);
+  Qn = (int32_t)(c.totQ - eq);
+}
 
-// Scan one sub-tile in effective order, 16 bytes (4 ops) at a time with the next
-// vector in flight.  Lanes of a wave scan different halves, so the loop is the
-// same for both: 4 vector slots; the lower half fills 3 of them (its first vector
-// also carries two header words, masked to padding).  Reverse-strand reversed
-// entries walk back to front: descending vector index, reversed components.
-template <int MODE>
-__device__ __forceinline__ void scan_sub(const PairCtx &c, const SubTile &t, const TileHdr &hdr, TileScan &s, IdentScan &id) {
+// A position of the walk: effective tile k / effective sub-tile he (both counted in
+// the entry's walking order) and the running sums at which the walk enters it.
+struct Cursor {
+  uint32_t k, he;
   int32_t T, Qn;
-  sub_start(c, hdr, t.h, T, Qn);
-  const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)t.j * TILE_WORDS);
-  // vector index of slot `it`: upper half 4..7, lower half 1..3 (+ one empty slot)
-  const int base = t.h ? (c.flip ? 7 : 4) : (c.flip ? 3 : 1);
-  const int step = c.flip ? -1 : 1;
-  const int nvec = t.h ? 4 : 3;
-  uint4 cur = q[base];
-  if (base == 1) cur.x = cur.y = OP_PAD;  // words 4,5 are header
-#pragma unroll 1
-  for (int it = 0; it < 4; it++) {
-    const int ni = base + (it + 1) * step;
-    uint4 nxt = make_uint4(OP_PAD, OP_PAD, OP_PAD, OP_PAD);
-    if (it + 1 < nvec) {
-      nxt = q[ni];
-      if (ni == 1) nxt.x = nxt.y = OP_PAD;
-    }
-    op_step<MODE>(c.flip ? cur.w : cur.x, c, T, Qn, s, id);
-    op_step<MODE>(c.flip ? cur.z : cur.y, c, T, Qn, s, id);
-    op_step<MODE>(c.flip ? cur.y : cur.z, c, T, Qn, s, id);
-    op_step<MODE>(c.flip ? cur.x : cur.w, c, T, Qn, s, id);
-    cur = nxt;
+};
+__device__ __forceinline__ uint32_t orig_tile(const PairCtx &c, uint32_t k) { return c.flip ? c.m - 1u - k : k; }
+__device__ __forceinline__ uint32_t orig_sub(const PairCtx &c, uint32_t he) { return c.flip ? 3u - he : he; }
+__device__ __forceinline__ uint32_t tile_subs(uint32_t n_ops, uint32_t j) { return subs_with_ops(min(TILE_OPS, n_ops - j * TILE_OPS)); }
+
+// Scan the cursor's sub-tile in walking order: its one or two 16-byte vectors are
+// requested together, then eight op slots are replayed (sub-tile 0 shares its
+// first vector with two header words and sub-tile 3 has a single vector: those
+// slots are padding).  Reverse-strand reversed entries walk back to front.  The
+// cursor's sums end up at the sub-tile's far end, which is where the next one starts.
+template <int MODE>
+__device__ __forceinline__ void scan_cur(const PairCtx &c, Cursor &cur, TileScan &s, IdentScan &id) {
+  const uint32_t h = orig_sub(c, cur.he);
+  const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)orig_tile(c, cur.k) * TILE_WORDS);
+  const uint32_t v0 = 1u + 2u * h;
+  uint4 a = q[v0];
+  uint4 b = make_uint4(OP_PAD, OP_PAD, OP_PAD, OP_PAD);
+  if (h != 3u) b = q[v0 + 1u];
+  if (h == 0u) a.x = a.y = OP_PAD;  // words 4, 5 are header
+  const uint4 f = c.flip ? b : a, g = c.flip ? a : b;
+  op_step<MODE>(c.flip ? f.w : f.x, c, cur.T, cur.Qn, s, id);
+  op_step<MODE>(c.flip ? f.z : f.y, c, cur.T, cur.Qn, s, id);
+  op_step<MODE>(c.flip ? f.y : f.z, c, cur.T, cur.Qn, s, id);
+  op_step<MODE>(c.flip ? f.x : f.w, c, cur.T, cur.Qn, s, id);
+  op_step<MODE>(c.flip ? g.w : g.x, c, cur.T, cur.Qn, s, id);
+  op_step<MODE>(c.flip ? g.z : g.y, c, cur.T, cur.Qn, s, id);
+  op_step<MODE>(c.flip ? g.y : g.z, c, cur.T, cur.Qn, s, id);
+  op_step<MODE>(c.flip ? g.x : g.w, c, cur.T, cur.Qn, s, id);
+}
+// next sub-tile that holds ops, in walking order; false at the end of the record
+__device__ __forceinline__ bool advance(const PairCtx &c, uint32_t n_ops, Cursor &cur) {
+  // forward: the sub-tiles without ops are the last ones of the last tile; backward: they were skipped on entry
+  const uint32_t lim = c.flip ? TILE_SUBS : tile_subs(n_ops, cur.k);
+  if (cur.he + 1u < lim) { cur.he += 1u; return true; }
+  if (cur.k + 1u >= c.m) return false;
+  cur.k += 1u;   // every tile but the record's last is full
+  cur.he = 0u;
+  return true;
+}
+// Put the cursor on effective sub-tile `he` of effective tile k (header h).
+__device__ __forceinline__ void place(const PairCtx &c, uint32_t n_ops, const TileHdr &h, uint32_t k, uint32_t he, Cursor &cur) {
+  cur.k = k;
+  if (h.wide) {  // no inner sums: enter at the tile's first sub-tile with ops
+    cur.he = c.flip ? TILE_SUBS - tile_subs(n_ops, orig_tile(c, k)) : 0u;
+    tile_start(c, orig_tile(c, k), cur.T, cur.Qn);
+  } else {
+    cur.he = he;
+    sub_start(c, h, orig_sub(c, he), cur.T, cur.Qn);
   }
 }
 __device__ __forceinline__ void ident_reset(IdentScan &id) {
@@ -611,7 +655,7 @@ __device__ __forceinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uin
   s.pqs = s.pts = s.pqe = s.pte = -1;
   ident_reset(id);
   int32_t T, Qn;
-  sub_start(c, tile_header(c, A), c.flip ? 1u : 0u, T, Qn);  // the tile's first sub-tile in walking order
+  tile_start(c, A, T, Qn);
   const int stepj = c.flip ? -1 : 1;
   for (int64_t j = A;; j += stepj) {
     const uint32_t *tp = c.ops + (size_t)j * TILE_WORDS + 6;
@@ -695,14 +739,14 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
       //   A = first k with P[k+1] >= R0 - ts        (holds the first op that can overlap)
       //   B = last  k with P[k]   <= last_tp - ts   (holds the last live op)
       const int32_t xa = c.R0 - c.ts, xb = c.last_tp - c.ts;
-      uint32_t cA = 0, cB = 0;  // cA = #{i in [1,m] : P[i] < xa}, cB = #{i in [0,m) : P[i] <= xb}
+      uint32_t cA = 0, cB = 0;  // cA = #{i in [1,m] : P[i] < xa}, cB = #{i in [0,m) : P[i] < xb}
       if (c.m <= INLINE_TILES) {
         const uint32_t P[INLINE_TILES + 1] = {0u, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w, 0u};
 #pragma unroll
         for (uint32_t i = 0; i <= INLINE_TILES; i++) {
           const int32_t pv = (int32_t)(i == c.m ? c.totT : P[i]);
           if (i >= 1) cA += (i <= c.m && pv < xa) ? 1u : 0u;
-          if (i < INLINE_TILES) cB += (i < c.m && pv <= xb) ? 1u : 0u;
+          if (i < INLINE_TILES) cB += (i < c.m && pv < xb) ? 1u : 0u;
         }
       } else {
         const uint32_t *P = v.ext_cp + e2.y;  // P[0..m]
@@ -713,18 +757,23 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         }
         cA = lo - 1;
         lo = 0; hi = c.m;
-        while (lo < hi) {  // first i in [0,m) with P[i] > xb
+        while (lo < hi) {  // first i in [0,m) with P[i] >= xb
           uint32_t mid = (lo + hi) >> 1;
-          if ((int32_t)P[mid] > xb) hi = mid; else lo = mid + 1;
+          if ((int32_t)P[mid] >= xb) hi = mid; else lo = mid + 1;
         }
         cB = lo;
       }
-      if (cA < c.m && cB >= 1 && cA <= cB - 1) {
-        const uint32_t kA = cA, kB = cB - 1;                       // effective tile indices
-        const uint32_t A = c.flip ? c.m - 1 - kA : kA, B = c.flip ? c.m - 1 - kB : kB;  // original tile indices
-        // refine to sub-tiles with the tiles' own headers: the first overlapping op
-        // is in A's first effective half iff that half's end prefix reaches R0; the
-        // last live op is in B's second effective half iff that half starts <= last_tp
+      if (cA < c.m) {
+        // Two short literal walks instead of one long one (exact):
+        //  A. from the first sub-tile whose END sum reaches R0 (every op before it ends
+        //     before R0 and cannot overlap) until the first overlapping op shows up --
+        //     normally in that very sub-tile -- or the ops start past last_target_pos;
+        //  B. from the last sub-tile that starts BEFORE last_target_pos until the ops
+        //     start past it; it records the last overlapping op.  If that sub-tile is
+        //     not beyond the one walk A stopped in, walk A simply carries on.
+        // Everything between the two walks lies between the first and the last
+        // overlapping op and cannot change the answer.
+        const uint32_t kA = cA, kB = max(cB, 1u) - 1u;  // effective tile indices
         TileScan sa, sb;
         sa.found = false;
         sa.pqs = sa.pts = sa.pqe = sa.pte = -1;
@@ -732,59 +781,96 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         IdentScan ia, ib;
         ident_reset(ia);
         ident_reset(ib);
-        bool walked = false, same = false;
-        SubTile subA{A, 0}, subB{B, 0};
-        TileHdr ha, hb;
+        bool walked = false, joined = false, need_walk = false;
+        uint32_t ipa = 0, ipb = 0;  // idp[] rows the two walks count from
         if (CIGAR) {
-          res = walk_tiles<MODE>(c, A, B, ia);
+          res = walk_tiles<MODE>(c, orig_tile(c, kA), c.flip ? 0u : c.m - 1u, ia);
           walked = true;
         } else {
-        if (!start_cov) {
-          ha = tile_header(c, A);
-          const uint32_t cntA = min(TILE_OPS, n - A * TILE_OPS);
-          const bool upperA = cntA > TILE_LOW_OPS;  // the upper sub-tile holds ops
-          const bool first_half = (c.flip ? upperA : true) && tile_mid_T(c, ha) >= c.R0;
-          const uint32_t he = first_half ? 0u : 1u;        // effective half
-          subA.h = c.flip ? 1u - he : he;                  // original half
-          if (!c.flip && he == 1u && !upperA) subA.h = 0u; // (cannot happen: the tile end prefix >= R0)
-        }
+        Cursor cur;
+        cur.k = 0xFFFFFFFFu; cur.he = 0; cur.T = 0; cur.Qn = 0;
+        TileHdr hd;          // header of effective tile hk
+        uint32_t hk = 0xFFFFFFFFu;
         if (start_cov) {
           sa.found = true;
           sa.pqs = 0;
           sa.pts = c.ts;
         } else {
-          scan_sub<MODE>(c, subA, ha, sa, ia);
+          hd = tile_header(c, orig_tile(c, kA));
+          hk = kA;
+          const uint32_t nsub = tile_subs(n, orig_tile(c, kA));
+          uint32_t he;
+          if (!c.flip) {
+            const int32_t y = xa - (int32_t)hd.t0;
+            he = ((int32_t)hd.bt1 < y ? 1u : 0u) + ((int32_t)hd.bt2 < y ? 1u : 0u) + ((int32_t)hd.bt3 < y ? 1u : 0u);
+            he = min(he, nsub - 1u);
+          } else {
+            const int32_t z = (int32_t)(c.totT - hd.t0) - xa;
+            he = ((int32_t)hd.bt3 > z ? 1u : 0u) + ((int32_t)hd.bt2 > z ? 1u : 0u) + ((int32_t)hd.bt1 > z ? 1u : 0u);
+            he = max(he, TILE_SUBS - nsub);  // the sub-tiles without ops come first in a back-to-front walk
+          }
+          place(c, n, hd, kA, he, cur);
+          const uint32_t ipa0 = TILE_SUBS * (e1.y + orig_tile(c, cur.k)) + orig_sub(c, cur.he);
+          for (;;) {
+            scan_cur<MODE>(c, cur, sa, ia);
+            if (sa.found || cur.T > c.last_tp) break;
+            if (!advance(c, n, cur)) break;
+          }
+          ipa = c.flip ? TILE_SUBS * (e1.y + orig_tile(c, cur.k)) + orig_sub(c, cur.he) : ipa0;
         }
-        if (!end_cov) {
-          hb = (!start_cov && A == B) ? ha : tile_header(c, B);  // requested only now (see IMPG note on refetch)
-          const uint32_t cntB = min(TILE_OPS, n - B * TILE_OPS);
-          const bool upperB = cntB > TILE_LOW_OPS;
-          const bool second_half = (c.flip ? true : upperB) && tile_mid_T(c, hb) <= c.last_tp;
-          const uint32_t he = second_half ? 1u : 0u;
-          subB.h = c.flip ? 1u - he : he;
-          same = !start_cov && same_sub(subA, subB);
-        }
-        if (end_cov) {
+        if (sa.found && end_cov) {
           sb.found = true;
           sb.pqe = (int32_t)c.totQ;
           sb.pte = en_te;
-        } else if (same) {
-          sb = sa;  // one sub-tile holds both ends: its scan recorded the last overlapping op too
-          ib = ia;
-        } else {
-          scan_sub<MODE>(c, subB, hb, sb, ib);
+        } else if (sa.found) {
+          if (hk != kB) {
+            hd = tile_header(c, orig_tile(c, kB));  // requested only now: earlier it was evicted before use
+            hk = kB;
+          }
+          const uint32_t nsub = tile_subs(n, orig_tile(c, kB));
+          uint32_t he;
+          if (!c.flip) {
+            const int32_t y = xb - (int32_t)hd.t0;
+            he = ((int32_t)hd.bt1 < y ? 1u : 0u) + ((int32_t)hd.bt2 < y ? 1u : 0u) + ((int32_t)hd.bt3 < y ? 1u : 0u);
+            he = min(he, nsub - 1u);
+          } else {
+            const int32_t z = (int32_t)(c.totT - hd.t0) - xb;
+            he = ((int32_t)hd.bt3 > z ? 1u : 0u) + ((int32_t)hd.bt2 > z ? 1u : 0u) + ((int32_t)hd.bt1 > z ? 1u : 0u);
+            he = max(he, TILE_SUBS - nsub);
+          }
+          if (hd.wide) he = c.flip ? TILE_SUBS - nsub : 0u;
+          joined = !start_cov && (kB < cur.k || (kB == cur.k && he <= cur.he));
+          bool go;
+          if (joined) {  // walk A stands in or past that sub-tile: it carries on and keeps recording
+            sb = sa;
+            ib = ia;
+            go = cur.T <= c.last_tp && advance(c, n, cur);
+          } else {
+            place(c, n, hd, kB, he, cur);
+            ipb = TILE_SUBS * (e1.y + orig_tile(c, cur.k)) + orig_sub(c, cur.he);
+            go = true;
+          }
+          while (go) {
+            scan_cur<MODE>(c, cur, sb, ib);
+            go = cur.T <= c.last_tp && advance(c, n, cur);
+          }
+          if (c.flip) ipb = TILE_SUBS * (e1.y + orig_tile(c, cur.k)) + orig_sub(c, cur.he);
+          need_walk = !sb.found;  // (cannot happen for a consistent CIGAR; stay exact anyway)
         }
-        if (sa.found && sb.found) {
+        if (need_walk) {
+          res = walk_tiles<MODE>(c, orig_tile(c, kA), c.flip ? 0u : c.m - 1u, ia);
+          walked = true;
+        } else if (sa.found && sb.found) {
           res.found = true;
           res.pqs = sa.pqs; res.pts = sa.pts;
           res.pqe = sb.pqe; res.pte = sb.pte;
-        } else if (!start_cov && !end_cov && same) {
-          res.found = false;  // every overlapping op would lie in this sub-tile
         } else {
-          res = walk_tiles<MODE>(c, A, B, ia);
-          walked = true;
+          res.found = false;
         }
         }
+#ifdef IMPG_DEBUG_WALK
+        if (walked) atomicAdd(&accepted[(blockIdx.x % COUNT_SLOTS) * COUNT_STRIDE], 1ull << 40);
+#endif
         if (CIGAR) {
           sl.a[p] = ia.first_oi;
           sl.n[p] = (ia.first_oi > ia.last_oi ? ia.first_oi - ia.last_oi : ia.last_oi - ia.first_oi) + 1u;
@@ -793,18 +879,18 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         }
         if (IDENT && res.found) {
           // op counts of the slice [first op, last op] in ORIGINAL op order:
-          //   forward walk : prefix(subB) + lastB  -  (prefix(subA) + firstA)
-          //   backward walk: (prefix(subA) + total(subA) - firstA) - (prefix(subB) + total(subB) - lastB)
+          //   forward walks : prefix(B's first sub-tile) + lastB  -  (prefix(A's first sub-tile) + firstA)
+          //   backward walks: (prefix(A's last sub-tile) + total(A walk) - firstA) - (prefix(B's last sub-tile) + total(B walk) - lastB)
           // where prefix(s) = matched / mismatched bases and gap ops before sub-tile s (idp[])
           // and firstA / lastB are the walking-order running sums snapshotted by op_step.
           int64_t M, X, G;
-          if (walked || same) {  // one continuous walk: plain difference of its running sums
-            const IdentScan &w = ia;
+          if (walked || joined) {  // one continuous walk: plain difference of its running sums
+            const IdentScan &w = walked ? ia : ib;
             M = (int64_t)w.lm - w.fm; X = (int64_t)w.lx - w.fx; G = (int64_t)w.lg - w.fg;
             M += -(int64_t)w.first_adj_m + w.last_adj_m;
             X += -(int64_t)w.first_adj_x + w.last_adj_x;
           } else {
-            const uint4 pa = v.idp[2 * ((size_t)e1.y + subA.j) + subA.h], pb = v.idp[2 * ((size_t)e1.y + subB.j) + subB.h];
+            const uint4 pa = v.idp[ipa], pb = v.idp[ipb];
             if (!c.flip) {
               M = ((int64_t)pb.x + ib.lm) - ((int64_t)pa.x + ia.fm);
               X = ((int64_t)pb.y + ib.lx) - ((int64_t)pa.y + ia.fx);

@@ -435,7 +435,10 @@ int impg_gpu_stage_count(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fron
   E.ev_next = 0;
   hipEvent_t e0 = E.event(), e1 = E.event();
   IMPG_HIP(hipEventRecord(e0, E.stream));
-  launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, d_counts, E.win.as<uint4>(), E.stream);
+  E.wide_n.reserve(256);
+  E.wide_list.reserve(std::max<size_t>(n * 4, 256));
+  launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, d_counts, E.win.as<uint4>(), E.wide_n.as<uint32_t>(),
+                      E.wide_list.as<uint32_t>(), E.stream);
   *total = E.scan(d_counts, E.stage_off.as<uint32_t>(), (uint32_t)n);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   IMPG_HIP(hipStreamSynchronize(E.stream));
@@ -468,7 +471,8 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   hipEvent_t e0 = E.event(), e1 = E.event(), e2 = E.event();
   IMPG_HIP(hipEventRecord(e0, E.stream));
   launch_lookup_emit(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_off.as<uint32_t>(), E.win.as<uint4>(),
-                     L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), nullptr, nullptr, E.stream);
+                     L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), nullptr, nullptr, E.wide_n.as<uint32_t>(),
+                     E.wide_list.as<uint32_t>(), E.stream);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
                  E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), params->min_identity, nullptr,

@@ -85,7 +85,9 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   pair_off.reserve((size_t)n_fr * 4);
   // MultiImpg steps are Impg::query calls (multi_impg.rs:520-530): closed overlap test, unclipped range
   if (multi) transitive = false;
-  launch_lookup_count(v, fr, n_fr, transitive, cnt.as<uint32_t>(), win.as<uint4>(), stream);
+  wide_n.reserve(256);
+  wide_list.reserve(std::max<size_t>((size_t)n_fr * 4, 256));
+  launch_lookup_count(v, fr, n_fr, transitive, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);
   if (P > pair_budget || P >= 0xFFFFFFF0ull) {
     if (split_ok) throw SplitBatch{};
@@ -119,7 +121,8 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
     d_offp = lo_offp.as<uint32_t>();
   }
   launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
-                     pair_entry.as<uint32_t>(), d_offp, const_cast<uint32_t *>(d_slot_of), stream);
+                     pair_entry.as<uint32_t>(), d_offp, const_cast<uint32_t *>(d_slot_of), wide_n.as<uint32_t>(),
+                     wide_list.as<uint32_t>(), stream);
   IMPG_HIP(hipEventRecord(e1, stream));
   HitArrays h = hit_arrays(L, L.n_pairs);
   SliceArrays sl{nullptr, nullptr, nullptr, nullptr};

@@ -47,6 +47,7 @@ struct Engine {
   bool multi = false;       // MultiImpg semantics for the batch in flight (params.multi_impg)
   DevBuf m_dest, m_qid, m_qs, m_qe, m_ts, m_te, m_pe, m_sa, m_sn, m_so, m_sr;  // 5-key sort: destination + double buffers
   // projection order (locality): ranges sorted by window position, their slots listed in that order
+  DevBuf wide_n, wide_list;  // ranges whose window is wider than the lane-per-range emit pass takes
   DevBuf lo_key, lo_key2, lo_idx, lo_perm, lo_cnt, lo_off, lo_offp, slot_of;
   uint32_t locality_min = 4096;  // frontier ranges below which the reordering is not worth its launches (0 = never reorder)
   uint32_t stage_n = 0;  // frontier size of the last stage_count call

@@ -62,7 +62,7 @@ void coitrees_visit_rank(uint32_t n, uint32_t *rank) {
 namespace {
 
 template <class T> void upload(DevBuf &b, const std::vector<T> &v, size_t &acc) {
-  b.reserve(std::max<size_t>(v.size() * sizeof(T), 256));
+  b.reserve(std::max<size_t>(v.size() * sizeof(T) + 64, 256));  // + slack: kernels read whole 16-byte vectors
   if (!v.empty()) IMPG_HIP(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   acc += v.size() * sizeof(T);
 }

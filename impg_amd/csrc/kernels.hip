@@ -33,90 +33,6 @@ namespace impg {
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-// Candidate windows of K frontier ranges at once (absolute indices).  The K
-// descents are independent; unrolled together their loads overlap, which is what
-// these latency-bound kernels need (K x the requests in flight per wave).
-template <bool TRANSITIVE, int K>
-__device__ __forceinline__ void range_windows(const DeviceIndexView &v, const FrontierRec (&f)[K], const bool (&act)[K],
-                                              uint32_t (&lo)[K], uint32_t (&ub)[K]) {
-  const unsigned lane = lane_id();
-  // per-range segment descriptor in plain scalars (one array per field, indexed by
-  // the unrolled k only): anything indexed by the run-time level would be demoted
-  // to scratch memory
-  uint32_t da[K], dn[K], dl[K], o0[K], o1[K], o2[K], o3[K], c0[K], c1[K], c2[K], c3[K];
-  uint32_t bs[K], bp[K];
-  bool ds[K], dp[K], live[K];
-  int maxlev = 0;
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    lo[k] = ub[k] = 0;
-    live[k] = act[k] && f[k].target_id < v.n_seq;
-    const uint4 *sp = reinterpret_cast<const uint4 *>(v.seg + (live[k] ? f[k].target_id : 0));
-    uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0, s2 = s0;
-    if (live[k]) { s0 = sp[0]; s1 = sp[1]; s2 = sp[2]; }
-    da[k] = s0.x; dn[k] = s0.y; dl[k] = s0.z;
-    o0[k] = s0.w; o1[k] = s1.x; o2[k] = s1.y; o3[k] = s1.z;
-    c0[k] = s1.w; c1[k] = s2.x; c2[k] = s2.y; c3[k] = s2.z;
-    live[k] = live[k] && dn[k] != 0;
-    if (!live[k]) dl[k] = 0;
-    bs[k] = bp[k] = 0;
-    ds[k] = dp[k] = false;
-    maxlev = max(maxlev, (int)dl[k]);
-  }
-  for (int lev = maxlev - 1; lev >= 0; lev--) {
-    int32_t vs[K], vp[K];
-    bool in_s[K], in_p[K], on[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) {  // issue every load of this level first
-      on[k] = lev < (int)dl[k];
-      const uint32_t cntl = lev == 0 ? c0[k] : lev == 1 ? c1[k] : lev == 2 ? c2[k] : c3[k];
-      const uint32_t offl = lev == 0 ? o0[k] : lev == 1 ? o1[k] : lev == 2 ? o2[k] : o3[k];
-      const uint32_t cnt = on[k] ? cntl : 0, off = on[k] ? offl : 0;
-      const uint32_t is = 64u * bs[k] + lane, ip = 64u * bp[k] + lane;
-      in_s[k] = is < cnt;
-      in_p[k] = ip < cnt;
-      vs[k] = in_s[k] ? v.starts_lvl[off + is] : 0;
-      vp[k] = in_p[k] ? v.pmax_lvl[off + ip] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      if (!on[k]) continue;
-      const uint32_t cnt = lev == 0 ? c0[k] : lev == 1 ? c1[k] : lev == 2 ? c2[k] : c3[k];
-      const int32_t qs = f[k].start, qe = f[k].end;
-      const bool ts_ = in_s[k] ? (TRANSITIVE ? vs[k] >= qe : vs[k] > qe) : true;
-      const bool tp_ = in_p[k] ? (TRANSITIVE ? vp[k] > qs : vp[k] >= qs) : true;
-      const unsigned fs = __ffsll((long long)__ballot(ts_)) - 1;  // lanes past the end are set: f < 64
-      const unsigned fp = __ffsll((long long)__ballot(tp_)) - 1;
-      if (64u * bs[k] + fs >= cnt) ds[k] = true;  // no sample true: nothing below is
-      if (64u * bp[k] + fp >= cnt) dp[k] = true;
-      bs[k] = ds[k] ? 0 : 64u * bs[k] + fs;
-      bp[k] = dp[k] ? 0 : 64u * bp[k] + fp;
-    }
-  }
-  int32_t vs[K], vp[K];
-  bool in_s[K], in_p[K];
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    const uint32_t is = 64u * bs[k] + lane, ip = 64u * bp[k] + lane;
-    in_s[k] = live[k] && is < dn[k];
-    in_p[k] = live[k] && ip < dn[k];
-    vs[k] = in_s[k] ? v.starts[da[k] + is] : 0;
-    vp[k] = in_p[k] ? v.pmax[da[k] + ip] : 0;
-  }
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    if (!live[k]) continue;
-    const int32_t qs = f[k].start, qe = f[k].end;
-    const bool ts_ = in_s[k] ? (TRANSITIVE ? vs[k] >= qe : vs[k] > qe) : true;
-    const bool tp_ = in_p[k] ? (TRANSITIVE ? vp[k] > qs : vp[k] >= qs) : true;
-    const uint32_t as = 64u * bs[k] + (__ffsll((long long)__ballot(ts_)) - 1);
-    const uint32_t ap = 64u * bp[k] + (__ffsll((long long)__ballot(tp_)) - 1);
-    const uint32_t u = (ds[k] || as >= dn[k]) ? dn[k] : as;
-    const uint32_t l = (dp[k] || ap >= dn[k]) ? dn[k] : ap;
-    ub[k] = da[k] + u;
-    lo[k] = da[k] + (l < u ? l : u);
-  }
-}
 // Inside a window every entry already starts before the range end (ub), so the
 // overlap test needs the end column only.  Transitive levels use ends_t, where an
 // entry with first >= last holds INT_MIN: max(cs,first) < min(ce,last)
@@ -129,64 +45,92 @@ template <bool TRANSITIVE>
 __device__ __forceinline__ const int32_t *end_col(const DeviceIndexView &v) { return TRANSITIVE ? v.ends_t : v.ends; }
 
 // ---------------------------------------------------------------------------
-// K1a: count overlapping entries per frontier range (one wave per range)
+// K1a: count overlapping entries per frontier range, one LANE per range.  (The first
+// cut, one wave per range descending 64-ary sampled levels with ballots, spent ~200
+// VALU instructions per range and was VALU-bound; a lane running its own two searches
+// and walking its own window costs ~15, and the gathers it issues instead are what
+// the memory pipeline is good at -- rocprofv3)
+//   ub = first entry of the segment with start >= range end   (> for the closed test)
+//   lo = first entry whose running max of ends > range start  (>= ...)
+//   hits = entries of [lo, ub) whose end passes the same test; the mask of the
+//   first 64 goes to the emit pass with the window.
 // ---------------------------------------------------------------------------
+// Two lower-bound searches side by side -- first s in [l1,h1) with S[s] >= qe (> for
+// the closed test), first p in [l2,h2) with P[p] > qs (>=) -- 4-ary: three probes per
+// search and round are in flight together.
 template <bool TRANSITIVE>
-__global__ __launch_bounds__(256) void lookup_count_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
-                                                           uint32_t n, uint32_t *__restrict__ cnt,
-                                                           uint4 *__restrict__ win) {
-#ifndef IMPG_COUNT_K
-#define IMPG_COUNT_K 2
-#endif
-  constexpr int K = IMPG_COUNT_K;  // ranges in flight per wave
-  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * 256u) >> 6;
-  const unsigned lane = lane_id();
-  FrontierRec fnext[K];  // software pipeline: the next iteration's frontier records are already in flight
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    fnext[k].target_id = 0xFFFFFFFFu; fnext[k].start = fnext[k].end = 0; fnext[k].qidx = 0;
-    if (wave * K + k < n) fnext[k] = fr[wave * K + k];
-  }
-  for (uint32_t r0 = wave * K; r0 < n; r0 += nwaves * K) {
-    FrontierRec f[K];
-    bool act[K];
-    uint32_t lo[K], ub[K];
-    const uint32_t rn = r0 + nwaves * K;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      act[k] = r0 + k < n;
-      f[k] = fnext[k];
-      fnext[k].target_id = 0xFFFFFFFFu; fnext[k].start = fnext[k].end = 0; fnext[k].qidx = 0;
-      if (rn + k < n) fnext[k] = fr[rn + k];
+__device__ __forceinline__ void dual_search4(const int32_t *__restrict__ S, uint32_t &l1, uint32_t &h1,
+                                             const int32_t *__restrict__ P, uint32_t &l2, uint32_t &h2, int32_t qs, int32_t qe) {
+  while (l1 < h1 || l2 < h2) {
+    const uint32_t w1 = h1 - l1, w2 = h2 - l2;
+    const uint32_t a1 = l1 + (w1 >> 2), b1 = l1 + (w1 >> 1), c1 = l1 + (w1 >> 1) + (w1 >> 2);
+    const uint32_t a2 = l2 + (w2 >> 2), b2 = l2 + (w2 >> 1), c2 = l2 + (w2 >> 1) + (w2 >> 2);
+    const bool g1 = w1 != 0, g2 = w2 != 0;   // (a <= b <= c < h whenever w != 0)
+    const int32_t sa = g1 ? S[a1] : 0, sb = g1 ? S[b1] : 0, sc = g1 ? S[c1] : 0;
+    const int32_t pa = g2 ? P[a2] : 0, pb = g2 ? P[b2] : 0, pc = g2 ? P[c2] : 0;
+    if (g1) {
+      const bool ta = TRANSITIVE ? sa >= qe : sa > qe, tb = TRANSITIVE ? sb >= qe : sb > qe, tc = TRANSITIVE ? sc >= qe : sc > qe;
+      // the predicate is monotone: pick the quarter that holds the first true
+      if (ta) h1 = a1; else if (tb) { l1 = a1 + 1u; h1 = b1; } else if (tc) { l1 = b1 + 1u; h1 = c1; } else l1 = c1 + 1u;
     }
-    range_windows<TRANSITIVE, K>(v, f, act, lo, ub);
-    // windows: first chunk of every range loaded together, rare further chunks one by one
-    const int32_t *ecol = end_col<TRANSITIVE>(v);
-    int32_t we[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      const uint32_t i = lo[k] + lane;
-      we[k] = i < ub[k] ? ecol[i] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      if (!act[k]) continue;
-      const uint32_t i = lo[k] + lane;
-      const bool hit = i < ub[k] && window_hit<TRANSITIVE>(we[k], f[k].start);
-      const unsigned long long m0 = __ballot(hit);
-      uint32_t c = __popcll(m0);
-      for (uint32_t base = lo[k] + 64u; base < ub[k]; base += 64u) {
-        const uint32_t i2 = base + lane;
-        const bool h2 = i2 < ub[k] && window_hit<TRANSITIVE>(ecol[i2], f[k].start);
-        c += __popcll(__ballot(h2));
-      }
-      if (lane == 0) {
-        cnt[r0 + k] = c;
-        win[r0 + k] = make_uint4(lo[k], ub[k], (uint32_t)m0, (uint32_t)(m0 >> 32));  // + hit mask of the first chunk
-      }
+    if (g2) {
+      const bool ta = TRANSITIVE ? pa > qs : pa >= qs, tb = TRANSITIVE ? pb > qs : pb >= qs, tc = TRANSITIVE ? pc > qs : pc >= qs;
+      if (ta) h2 = a2; else if (tb) { l2 = a2 + 1u; h2 = b2; } else if (tc) { l2 = b2 + 1u; h2 = c2; } else l2 = c2 + 1u;
     }
   }
+}
+
+template <bool TRANSITIVE>
+__global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
+                                                                uint32_t n, uint32_t *__restrict__ cnt,
+                                                                uint4 *__restrict__ win, uint32_t *__restrict__ wide_n,
+                                                                uint32_t *__restrict__ wide_list) {
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= n) return;
+  const FrontierRec f = fr[r];
+  uint32_t a = 0, sn = 0, off0 = 0, cnt0 = 0;
+  if (f.target_id < v.n_seq) {
+    const uint4 *dp = reinterpret_cast<const uint4 *>(v.seg + f.target_id);
+    const uint4 d0 = dp[0], d1 = dp[1];  // {a, n, nlev, off[0]}, {off[1..3], cnt[0]}
+    a = d0.x;
+    sn = d0.y;
+    if (d0.z) { off0 = d0.w; cnt0 = d1.w; }
+  }
+  const int32_t qs = f.start, qe = f.end;
+  // first over the segment's samples (the last element of every 64-entry block: a
+  // small array that stays in L2), then inside the one block that holds the answer
+  uint32_t l1 = 0, h1 = sn, l2 = 0, h2 = sn;
+  if (cnt0) {
+    uint32_t b1 = 0, e1 = cnt0, b2 = 0, e2 = cnt0;
+    dual_search4<TRANSITIVE>(v.starts_lvl + off0, b1, e1, v.pmax_lvl + off0, b2, e2, qs, qe);
+    // b = first block whose last element passes; none: the answer is n
+    l1 = b1 < cnt0 ? 64u * b1 : sn; h1 = b1 < cnt0 ? min(l1 + 63u, sn) : sn;  // (that last element itself passes)
+    l2 = b2 < cnt0 ? 64u * b2 : sn; h2 = b2 < cnt0 ? min(l2 + 63u, sn) : sn;
+  }
+  dual_search4<TRANSITIVE>(v.starts + a, l1, h1, v.pmax + a, l2, h2, qs, qe);
+  const uint32_t ub = a + l1, lo = a + min(l2, l1);
+  // the window, eight entries (two aligned 16-byte vectors) per round
+  const int32_t *ecol = end_col<TRANSITIVE>(v);
+  uint32_t c = 0;
+  unsigned long long mask = 0;
+  for (uint32_t b = lo & ~3u; b < ub; b += 8u) {
+    const int4 e0 = *reinterpret_cast<const int4 *>(ecol + b);
+    int4 e1 = make_int4(0, 0, 0, 0);
+    if (b + 4u < ub) e1 = *reinterpret_cast<const int4 *>(ecol + b + 4u);
+    const int32_t ev[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint32_t i = b + k;
+      const bool hit = i >= lo && i < ub && window_hit<TRANSITIVE>(ev[k], qs);
+      c += hit ? 1u : 0u;
+      const uint32_t bit = i - lo;  // (only meaningful for a hit)
+      if (hit && bit < 64u) mask |= 1ull << bit;
+    }
+  }
+  cnt[r] = c;
+  win[r] = make_uint4(lo, ub, (uint32_t)mask, (uint32_t)(mask >> 32));
+  // windows too wide for the lane-per-range emit pass (dense targets) are listed for the wave-per-range one
+  if (wide_list && lo < ub && ub - (lo & ~3u) > 64u) wide_list[atomicAdd(wide_n, 1u)] = r;
 }
 
 // ---------------------------------------------------------------------------
@@ -199,7 +143,11 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
                                                           uint32_t *__restrict__ pair_range,
                                                           uint32_t *__restrict__ pair_entry,
                                                           const uint32_t *__restrict__ offp,
-                                                          uint32_t *__restrict__ slot_of) {
+                                                          uint32_t *__restrict__ slot_of,
+                                                          const uint32_t *__restrict__ list,
+                                                          const uint32_t *__restrict__ list_n) {
+  // list (optional): process only these ranges -- the ones whose window is wider than
+  // lookup_emit_lane_kernel takes, collected by the count pass
   const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * 256u) >> 6;
   const unsigned lane = lane_id();
@@ -211,14 +159,22 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
   // software pipeline: the next range's window record and slot offset are
   // requested before the current range is processed, so a range costs one
   // dependent round trip (its rank column), not three
+  const uint32_t n_items = list ? min(*list_n, n) : n;
   uint4 w = make_uint4(0, 0, 0, 0);
-  uint32_t off = 0, po = 0;
-  if (wave < n) { w = win[wave]; off = pair_off[wave]; if (slot_of) po = offp[wave]; }
-  for (uint32_t r = wave; r < n; r += nwaves) {
-    const uint32_t rn = r + nwaves;
+  uint32_t off = 0, po = 0, rcur = 0;
+  if (wave < n_items) {
+    rcur = list ? list[wave] : wave;
+    w = win[rcur]; off = pair_off[rcur]; if (slot_of) po = offp[rcur];
+  }
+  for (uint32_t it = wave; it < n_items; it += nwaves) {
+    const uint32_t r = rcur;
+    const uint32_t itn = it + nwaves;
     uint4 wn = make_uint4(0, 0, 0, 0);
     uint32_t offn = 0, pon = 0;
-    if (rn < n) { wn = win[rn]; offn = pair_off[rn]; if (slot_of) pon = offp[rn]; }
+    if (itn < n_items) {
+      rcur = list ? list[itn] : itn;
+      wn = win[rcur]; offn = pair_off[rcur]; if (slot_of) pon = offp[rcur];
+    }
     const uint32_t lo = w.x, ub = w.y;
     const unsigned long long m0 = ((unsigned long long)w.w << 32) | w.z;  // hits of the first chunk, from the count pass
     const uint32_t off_r = off, po_r = po;
@@ -328,6 +284,100 @@ __global__ __launch_bounds__(256) void scatter_u32_kernel(const uint32_t *__rest
                                                           uint32_t n, uint32_t *__restrict__ out) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < n) out[perm[i]] = in[i];
+}
+
+// ---------------------------------------------------------------------------
+// K1b': the same for windows of at most 64 entries (counted from the 16-byte
+// boundary below lo), one LANE per range.  The wave-per-range kernel above spends
+// ~300 instructions per range on a 21-stage cross-lane bitonic sort for ~26 hits;
+// here a lane keeps its window's 64 keys (rank << 6 | position, all-ones for a
+// non-hit) in registers, sorts them with a fully unrolled network (min/max pairs,
+// static register indices, ~20 instructions per range), and the wave stages the
+// sorted runs in LDS so that the stores stay coalesced.  Needs ranks < 2^26.
+// ---------------------------------------------------------------------------
+constexpr uint32_t EMIT_LDS_SLOTS = 64u * 64u;  // a lane emits at most 64 pairs
+template <bool TRANSITIVE>
+__global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v, uint32_t n,
+                                                              const uint32_t *__restrict__ pair_off,
+                                                              const uint4 *__restrict__ win,
+                                                              uint32_t *__restrict__ pair_range,
+                                                              uint32_t *__restrict__ pair_entry,
+                                                              const uint32_t *__restrict__ offp,
+                                                              uint32_t *__restrict__ slot_of) {
+  __shared__ uint16_t stage[EMIT_LDS_SLOTS];
+  const unsigned lane = threadIdx.x;
+  const uint32_t r0 = blockIdx.x * 64u, r = r0 + lane;
+  uint32_t lo = 0, ub = 0, off = 0, po = 0;
+  unsigned long long mask = 0;
+  if (r < n) {
+    const uint4 w = win[r];
+    lo = w.x; ub = w.y;
+    mask = ((unsigned long long)w.w << 32) | w.z;
+    off = pair_off[r];
+    if (slot_of) po = offp[r];
+  }
+  const uint32_t b = lo & ~3u;
+  const bool mine = lo < ub && ub - b <= 64u;  // wider windows belong to the wave-per-range kernel
+  if (!mine) { ub = b; mask = 0; }
+  uint32_t key[64];
+#pragma unroll
+  for (uint32_t q = 0; q < 16; q++) {
+    uint4 rk = make_uint4(0, 0, 0, 0);
+    if (b + 4u * q < ub) rk = *reinterpret_cast<const uint4 *>(v.rank + b + 4u * q);
+    const uint32_t rv[4] = {rk.x, rk.y, rk.z, rk.w};
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++) {
+      const uint32_t i = 4u * q + t, pos = b + i;
+      const bool hit = pos >= lo && pos < ub && ((mask >> ((pos - lo) & 63u)) & 1ull);
+      key[i] = hit ? (rv[t] << 6) | i : 0xFFFFFFFFu;
+    }
+  }
+  // bitonic network over the 64 registers, ascending (ranks of hits are distinct)
+#pragma unroll
+  for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (uint32_t i = 0; i < 64; i++) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const uint32_t x = key[i], y = key[l];
+          const uint32_t mn = min(x, y), mx = max(x, y);
+          key[i] = (i & k) == 0 ? mn : mx;
+          key[l] = (i & k) == 0 ? mx : mn;
+        }
+      }
+    }
+  }
+  const uint32_t c = (uint32_t)__popcll(mask);
+  // LDS offsets of the lanes' runs: exclusive scan of c over the wave
+  uint32_t inc = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)inc, d);
+    if ((int)lane >= d) inc += y;
+  }
+  const uint32_t loff = inc - c;
+  const uint32_t total = (uint32_t)__shfl((int)inc, 63);
+#pragma unroll
+  for (uint32_t k = 0; k < 64; k++) {
+    if (__ballot(k < c) == 0ull) break;
+    if (k < c) stage[loff + k] = (uint16_t)((lane << 6) | (key[k] & 63u));
+  }
+  __syncthreads();
+  for (uint32_t tb = 0; tb < total; tb += 64u) {  // every lane takes part in the cross-lane reads
+    const uint32_t t = tb + lane;
+    const bool live = t < total;
+    const uint32_t sv = live ? stage[t] : 0u, ln = sv >> 6, rel = sv & 63u;
+    const uint32_t lb = (uint32_t)__shfl((int)b, (int)ln), lof = (uint32_t)__shfl((int)off, (int)ln);
+    const uint32_t llo = (uint32_t)__shfl((int)loff, (int)ln), lpo = (uint32_t)__shfl((int)po, (int)ln);
+    if (live) {
+      const uint32_t slot = lof + (t - llo);
+      pair_range[slot] = r0 + ln;
+      pair_entry[slot] = lb + rel;
+      if (slot_of) slot_of[lpo + (t - llo)] = slot;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1563,6 +1613,8 @@ __global__ __launch_bounds__(256) void aos_to_hits_kernel(const impg_gpu_hit_t *
 // launchers
 // ---------------------------------------------------------------------------
 static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+// windows of <= 64 entries are emitted lane-per-range (needs ranks < 2^26 for the packed sort key)
+static inline bool emit_by_lanes(const DeviceIndexView &v) { return v.n_entries < (1u << 26); }
 static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 waves per block, capped
   uint32_t blocks = cdiv(n_items, 4);
   const uint32_t cap = 256u * 32u;  // 32 blocks per CU worth of grid-stride
@@ -1570,17 +1622,30 @@ static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 wa
 }
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, uint32_t *cnt,
-                         uint4 *win, hipStream_t s) {
+                         uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s) {
   if (!n) return;
-  if (transitive) lookup_count_kernel<true><<<wave_grid(n), 256, 0, s>>>(v, fr, n, cnt, win);
-  else lookup_count_kernel<false><<<wave_grid(n), 256, 0, s>>>(v, fr, n, cnt, win);
+  const bool lanes = emit_by_lanes(v);
+  if (lanes) IMPG_HIP(hipMemsetAsync(wide_n, 0, 4, s));
+  if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, cnt, win, wide_n, lanes ? wide_list : nullptr);
+  else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, cnt, win, wide_n, lanes ? wide_list : nullptr);
 }
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
-                        const uint32_t *offp, uint32_t *slot_of, hipStream_t s) {
+                        const uint32_t *offp, uint32_t *slot_of, const uint32_t *wide_n, const uint32_t *wide_list,
+                        hipStream_t s) {
   if (!n) return;
-  if (transitive) lookup_emit_kernel<true><<<wave_grid(n), 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, slot_of);
-  else lookup_emit_kernel<false><<<wave_grid(n), 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, slot_of);
+  // windows of <= 64 entries: lane per range; the rest (dense targets), or everything if a rank could
+  // overflow the packed sort key: wave per range
+  const bool lanes = emit_by_lanes(v);
+  if (lanes) {
+    if (transitive) lookup_emit_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, offp, slot_of);
+    else lookup_emit_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, offp, slot_of);
+  }
+  // the listed wide windows only (a small grid: the list is normally short or empty), or everything
+  const uint32_t g = lanes ? std::min(wave_grid(n), 256u) : wave_grid(n);
+  const uint32_t *ln = lanes ? wide_n : nullptr, *ll = lanes ? wide_list : nullptr;
+  if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, slot_of, ll, ln);
+  else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, slot_of, ll, ln);
 }
 void launch_window_keys(const uint4 *win, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s) {
   if (n) window_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(win, n, key, idx);

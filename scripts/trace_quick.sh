@@ -7,7 +7,7 @@ IMPG_GPU_LIB=${LIB:+$REPO/impg_amd/$LIB} timeout 300 rocprofv3 --kernel-trace -d
 python3 $REPO/scripts/rocpd_summary.py $OUT/t/t_results.db $OUT/t
 python3 - <<PY
 import csv
-for r in list(csv.DictReader(open("$OUT/t_kernel_stats.csv")))[:7]:
+for r in list(csv.DictReader(open("$OUT/t_kernel_stats.csv")))[:16]:
     print("%-40s calls=%s total_ms=%.2f avg_ms=%.3f max_ms=%.3f pct=%s" % (r["Name"][9:49], r["Calls"], int(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e6, int(r["MaxNs"])/1e6, r["Percentage"]))
 PY
 rm -rf $OUT/t

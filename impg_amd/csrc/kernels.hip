@@ -487,6 +487,7 @@ size_t scan_scratch_bytes(uint32_t n) { return ((size_t)(n + SCAN_TILE - 1) / SC
 // ---------------------------------------------------------------------------
 struct TileScan {
   bool found;
+  bool any;  // an op passed since the caller last cleared it
   int32_t pqs, pts, pqe, pte;  // query values are direction-normalised offsets from qbase until the end
 };
 // extra state for min_gap_compressed_identity (impg.rs:2952-2973): running sums of
@@ -577,6 +578,7 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
   s.pqe = pass ? lq : s.pqe;
   s.pte = pass ? oe : s.pte;
   s.found = s.found || pass;
+  s.any = s.any || pass;
   T = e;
   Qn += qa;
 }
@@ -701,7 +703,7 @@ __device__ __forceinline__ void ident_reset(IdentScan &id) {
 template <int MODE>
 __device__ __forceinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uint32_t B, IdentScan &id) {
   TileScan s;
-  s.found = false;
+  s.found = s.any = false;
   s.pqs = s.pts = s.pqe = s.pte = -1;
   ident_reset(id);
   int32_t T, Qn;
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
   const uint32_t pp = lblock * 256u + threadIdx.x;
   bool ok = false;
   TileScan res;
-  res.found = false;
+  res.found = res.any = false;
   res.pqs = res.pts = res.pqe = res.pte = -1;
   uint32_t qid = HIT_NONE;
   if (pp < n_pairs) {
@@ -824,10 +826,9 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         // Everything between the two walks lies between the first and the last
         // overlapping op and cannot change the answer.
         const uint32_t kA = cA, kB = max(cB, 1u) - 1u;  // effective tile indices
-        TileScan sa, sb;
-        sa.found = false;
+        TileScan sa;  // one record for both walks: the first overlapping op is set once, the last keeps moving
+        sa.found = sa.any = false;
         sa.pqs = sa.pts = sa.pqe = sa.pte = -1;
-        sb = sa;
         IdentScan ia, ib;
         ident_reset(ia);
         ident_reset(ib);
@@ -839,15 +840,12 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         } else {
         Cursor cur;
         cur.k = 0xFFFFFFFFu; cur.he = 0; cur.T = 0; cur.Qn = 0;
-        TileHdr hd;          // header of effective tile hk
-        uint32_t hk = 0xFFFFFFFFu;
         if (start_cov) {
           sa.found = true;
           sa.pqs = 0;
           sa.pts = c.ts;
         } else {
-          hd = tile_header(c, orig_tile(c, kA));
-          hk = kA;
+          const TileHdr hd = tile_header(c, orig_tile(c, kA));
           const uint32_t nsub = tile_subs(n, orig_tile(c, kA));
           uint32_t he;
           if (!c.flip) {
@@ -869,14 +867,12 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
           ipa = c.flip ? TILE_SUBS * (e1.y + orig_tile(c, cur.k)) + orig_sub(c, cur.he) : ipa0;
         }
         if (sa.found && end_cov) {
-          sb.found = true;
-          sb.pqe = (int32_t)c.totQ;
-          sb.pte = en_te;
+          sa.pqe = (int32_t)c.totQ;
+          sa.pte = en_te;
         } else if (sa.found) {
-          if (hk != kB) {
-            hd = tile_header(c, orig_tile(c, kB));  // requested only now: earlier it was evicted before use
-            hk = kB;
-          }
+          // requested only now: asked for earlier, the line was evicted before use; when walk A
+          // read the same tile it is an L1 hit, and not keeping A's header alive saves registers
+          const TileHdr hd = tile_header(c, orig_tile(c, kB));
           const uint32_t nsub = tile_subs(n, orig_tile(c, kB));
           uint32_t he;
           if (!c.flip) {
@@ -892,30 +888,26 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
           joined = !start_cov && (kB < cur.k || (kB == cur.k && he <= cur.he));
           bool go;
           if (joined) {  // walk A stands in or past that sub-tile: it carries on and keeps recording
-            sb = sa;
             ib = ia;
             go = cur.T <= c.last_tp && advance(c, n, cur);
           } else {
             place(c, n, hd, kB, he, cur);
             ipb = TILE_SUBS * (e1.y + orig_tile(c, cur.k)) + orig_sub(c, cur.he);
             go = true;
+            sa.any = false;
           }
           while (go) {
-            scan_cur<MODE>(c, cur, sb, ib);
+            scan_cur<MODE>(c, cur, sa, ib);
             go = cur.T <= c.last_tp && advance(c, n, cur);
           }
           if (c.flip) ipb = TILE_SUBS * (e1.y + orig_tile(c, cur.k)) + orig_sub(c, cur.he);
-          need_walk = !sb.found;  // (cannot happen for a consistent CIGAR; stay exact anyway)
+          need_walk = !joined && !sa.any;  // walk B saw no overlapping op (cannot happen for a consistent CIGAR; stay exact)
         }
         if (need_walk) {
           res = walk_tiles<MODE>(c, orig_tile(c, kA), c.flip ? 0u : c.m - 1u, ia);
           walked = true;
-        } else if (sa.found && sb.found) {
-          res.found = true;
-          res.pqs = sa.pqs; res.pts = sa.pts;
-          res.pqe = sb.pqe; res.pte = sb.pte;
         } else {
-          res.found = false;
+          res = sa;
         }
         }
 #ifdef IMPG_DEBUG_WALK

@@ -10,6 +10,7 @@ resident in HBM.  Prints ONE JSON line (rank 0).  See DESIGN.md section 7.
 """
 import argparse
 import json
+import glob
 import os
 import sys
 import tempfile
@@ -144,7 +145,8 @@ def main():
     # HBM bytes per projection measured with rocprofv3 PMC passes of this same command
     # (scripts/profile_r1.sh -> profiles/r1_v2_traffic.json; FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_v2_traffic.json")
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))  # newest build last
+    tpath = tfiles[-1] if tfiles else ""
     if os.path.exists(tpath) and launches:
         with open(tpath) as f:
             tj = json.load(f)
@@ -185,7 +187,7 @@ def main():
             "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_note": "bytes per launch = rocprofv3 (FETCH_SIZE x2 [gfx950] + WRITE_SIZE) per pair, from "
-                            "profiles/r1_v2_traffic.json, x pairs per launch of this run",
+                            "profiles/%s, x pairs per launch of this run" % os.path.basename(tpath),
             "achieved_traffic_GBs": (traffic / (ms_project / launches * 1e-3) / 1e9) if (traffic and ms_project) else None,
             "algorithmic_bytes_per_projection": ALG_BYTES_PER_PROJECTION,
             "launches": launches,

@@ -437,9 +437,11 @@ int impg_gpu_stage_count(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fron
   IMPG_HIP(hipEventRecord(e0, E.stream));
   E.wide_n.reserve(256);
   E.wide_list.reserve(std::max<size_t>(n * 4, 256));
-  launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, d_counts, E.win.as<uint4>(), E.wide_n.as<uint32_t>(),
-                      E.wide_list.as<uint32_t>(), E.stream);
-  *total = E.scan(d_counts, E.stage_off.as<uint32_t>(), (uint32_t)n);
+  E.cnt.reserve(std::max<size_t>(n * 4, 256));  // kept for the projection order of stage_project
+  launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.cnt.as<uint32_t>(), E.win.as<uint4>(),
+                      E.wide_n.as<uint32_t>(), E.wide_list.as<uint32_t>(), E.stream);
+  if (n) IMPG_HIP(hipMemcpyAsync(d_counts, E.cnt.p, n * 4, hipMemcpyDeviceToDevice, E.stream));
+  *total = E.scan(E.cnt.as<uint32_t>(), E.stage_off.as<uint32_t>(), (uint32_t)n);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   IMPG_HIP(hipStreamSynchronize(E.stream));
   { float ms = 0; IMPG_HIP(hipEventElapsedTime(&ms, e0, e1)); E.stage_ms[0] += ms; }
@@ -451,7 +453,7 @@ int impg_gpu_stage_count(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fron
 int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
                            const impg_gpu_params_t *params, impg_gpu_hit_t *d_hits, uint64_t total, uint64_t *accepted) {
   IMPG_TRY
-  if (!ix || !params || (!d_frontier && n) || (!d_hits && total)) throw Error{IMPG_E_INVALID, "null argument"};
+  if (!ix || !params || (!d_frontier && n)) throw Error{IMPG_E_INVALID, "null argument"};  // d_hits may be null: count only
   Engine &E = *ix->engine;
   Engine::check_params(*params);
   if (E.stage_n != n) throw Error{IMPG_E_INVALID, "stage_project must follow stage_count on the same frontier"};
@@ -470,15 +472,17 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   E.ev_next = 0;
   hipEvent_t e0 = E.event(), e1 = E.event(), e2 = E.event();
   IMPG_HIP(hipEventRecord(e0, E.stream));
+  const uint32_t *d_offp = nullptr, *d_slot_of = nullptr;
+  E.projection_order(ix->view, (uint32_t)n, E.cnt.as<uint32_t>(), total, d_offp, d_slot_of);
   launch_lookup_emit(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_off.as<uint32_t>(), E.win.as<uint4>(),
-                     L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), nullptr, nullptr, E.wide_n.as<uint32_t>(),
-                     E.wide_list.as<uint32_t>(), E.stream);
+                     L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), d_offp, const_cast<uint32_t *>(d_slot_of),
+                     E.wide_n.as<uint32_t>(), E.wide_list.as<uint32_t>(), E.stream);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
                  E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), params->min_identity, nullptr,
-                 nullptr, E.stream);
+                 d_slot_of, E.stream);
   IMPG_HIP(hipEventRecord(e2, E.stream));
-  launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
+  if (d_hits) launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
   IMPG_HIP(hipStreamSynchronize(E.stream));
   {
     float ms = 0;
@@ -491,6 +495,37 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   if (hc[2]) throw Error{IMPG_E_INVALID, "an alignment hit by the query has no CIGAR (missing cg:Z tag)"};
   if (accepted) *accepted = E.read_slots(E.acc_slots);
   E.stage_n = 0;
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_stage_route(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, uint32_t world,
+                         impg_gpu_frontier_t *d_out, uint64_t *counts) {
+  IMPG_TRY
+  if (!ix || !counts || (n && (!d_frontier || !d_out))) throw Error{IMPG_E_INVALID, "null argument"};
+  if (world == 0 || world > ROUTE_WORLD_MAX) throw Error{IMPG_E_INVALID, "world size out of range"};
+  if (n >= (1ull << 32) - 16) throw Error{IMPG_E_UNSUPPORTED, "frontier too large"};
+  Engine &E = *ix->engine;
+  IMPG_HIP(hipSetDevice(ix->device));
+  for (uint32_t k = 0; k < world; k++) counts[k] = 0;
+  if (!n) return IMPG_OK;
+  const size_t nb = std::max<size_t>(n * 4, 256);
+  E.lo_key.reserve(nb); E.lo_key2.reserve(nb); E.lo_idx.reserve(nb); E.lo_perm.reserve(nb);
+  E.stat_count.reserve((size_t)world * 8);
+  IMPG_HIP(hipMemsetAsync(E.stat_count.p, 0, (size_t)world * 8, E.stream));
+  launch_route_keys(d_frontier, (uint32_t)n, world, E.lo_key.as<uint32_t>(), E.lo_idx.as<uint32_t>(),
+                    E.stat_count.as<unsigned long long>(), E.stream);
+  unsigned bits = 1;
+  while ((1u << bits) < world) bits++;
+  const size_t tb = sort_u32_scratch_bytes((uint32_t)n);
+  E.sort_tmp.reserve(tb);
+  launch_sort_u32(E.sort_tmp.p, tb, E.lo_key.as<uint32_t>(), E.lo_key2.as<uint32_t>(), E.lo_idx.as<uint32_t>(),
+                  E.lo_perm.as<uint32_t>(), (uint32_t)n, E.stream, 0, bits);  // stable: original order within an owner
+  launch_route_gather(d_frontier, E.lo_perm.as<uint32_t>(), (uint32_t)n, d_out, E.stream);
+  IMPG_HIP(hipStreamSynchronize(E.stream));
+  std::vector<unsigned long long> h(world);
+  IMPG_HIP(hipMemcpy(h.data(), E.stat_count.p, (size_t)world * 8, hipMemcpyDeviceToHost));
+  for (uint32_t k = 0; k < world; k++) counts[k] = h[k];
   return IMPG_OK;
   IMPG_CATCH
 }

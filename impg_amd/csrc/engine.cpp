@@ -75,6 +75,34 @@ static HitArrays hit_arrays(LevelBufs &L, uint32_t n_pairs) {
   return HitArrays{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
 }
 
+// Projection order: the slots stay in the reference's order, but the projection
+// kernel walks them range by range in the order of the ranges' windows in the
+// entry array, so that lanes and workgroups in flight together gather
+// neighbouring entries and CIGAR tiles (L2 hits instead of HBM lines).  Needs
+// win[] (count pass) and the per-range counts; leaves offp[r] (first position of
+// range r in that order) and room for slot_of[P], or nulls when not worth it.
+void Engine::projection_order(const DeviceIndexView &v, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
+                              const uint32_t *&d_slot_of) {
+  d_offp = d_slot_of = nullptr;
+  if (!locality_min || n_fr < locality_min || !P) return;
+  const size_t nb = (size_t)n_fr * 4;
+  lo_key.reserve(nb); lo_key2.reserve(nb); lo_idx.reserve(nb); lo_perm.reserve(nb); lo_cnt.reserve(nb); lo_off.reserve(nb);
+  lo_offp.reserve(nb);
+  slot_of.reserve(std::max<size_t>(P * 4, 256));
+  launch_window_keys(win.as<uint4>(), n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream);
+  const size_t tb = sort_u32_scratch_bytes(n_fr);
+  sort_tmp.reserve(tb);
+  // 16-entry granularity is plenty; keys are positions in the entry array
+  const unsigned hi_bit = std::max(5u, bits_for((uint32_t)std::min<size_t>(v.n_entries, 0xFFFFFFFFull)));
+  launch_sort_u32(sort_tmp.p, tb, lo_key.as<uint32_t>(), lo_key2.as<uint32_t>(), lo_idx.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr,
+                  stream, 4, hi_bit);
+  launch_gather_u32(d_cnt, lo_perm.as<uint32_t>(), n_fr, lo_cnt.as<uint32_t>(), stream);
+  scan(lo_cnt.as<uint32_t>(), lo_off.as<uint32_t>(), n_fr);
+  launch_scatter_u32(lo_off.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr, lo_offp.as<uint32_t>(), stream);
+  d_slot_of = slot_of.as<uint32_t>();
+  d_offp = lo_offp.as<uint32_t>();
+}
+
 // lookup + projection of one frontier; fills L (pair_range, hit arrays), returns #pairs
 uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
                         impg_gpu_stats_t *st) {
@@ -96,30 +124,8 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   L.n_pairs = (uint32_t)P;
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
-  // Projection order: the slots stay in the reference's order, but the projection
-  // kernel walks them range by range in the order of the ranges' windows in the
-  // entry array, so that lanes and workgroups in flight together gather
-  // neighbouring entries and CIGAR tiles (L2 hits instead of HBM lines).
   const uint32_t *d_slot_of = nullptr, *d_offp = nullptr;
-  if (locality_min && n_fr >= locality_min && P) {
-    const size_t nb = (size_t)n_fr * 4;
-    lo_key.reserve(nb); lo_key2.reserve(nb); lo_idx.reserve(nb); lo_perm.reserve(nb); lo_cnt.reserve(nb); lo_off.reserve(nb);
-    lo_offp.reserve(nb);
-    slot_of.reserve(std::max<size_t>(P * 4, 256));
-    launch_window_keys(win.as<uint4>(), n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream);
-    const size_t tb = sort_u32_scratch_bytes(n_fr);
-    sort_tmp.reserve(tb);
-    // 16-entry granularity is plenty; keys are positions in the entry array
-    const unsigned loc_bit = 4;
-    const unsigned hi_bit = std::max(5u, bits_for((uint32_t)std::min<size_t>(v.n_entries, 0xFFFFFFFFull)));
-    launch_sort_u32(sort_tmp.p, tb, lo_key.as<uint32_t>(), lo_key2.as<uint32_t>(), lo_idx.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr,
-                    stream, std::min(loc_bit, hi_bit - 1), hi_bit);
-    launch_gather_u32(cnt.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr, lo_cnt.as<uint32_t>(), stream);
-    scan(lo_cnt.as<uint32_t>(), lo_off.as<uint32_t>(), n_fr);
-    launch_scatter_u32(lo_off.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr, lo_offp.as<uint32_t>(), stream);
-    d_slot_of = slot_of.as<uint32_t>();
-    d_offp = lo_offp.as<uint32_t>();
-  }
+  projection_order(v, n_fr, cnt.as<uint32_t>(), P, d_offp, d_slot_of);
   launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                      pair_entry.as<uint32_t>(), d_offp, const_cast<uint32_t *>(d_slot_of), wide_n.as<uint32_t>(),
                      wide_list.as<uint32_t>(), stream);

@@ -57,6 +57,8 @@ struct Engine {
   hipEvent_t event();
   uint64_t read_counter(int k);
   uint64_t scan(const uint32_t *in, uint32_t *out, uint32_t n);
+  void projection_order(const DeviceIndexView &v, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
+                        const uint32_t *&d_slot_of);
   uint64_t expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
                   impg_gpu_stats_t *st);
   uint32_t update(const DeviceIndexView &v, const FrontierRec *fr, LevelBufs &L, uint32_t n_queries,

@@ -272,6 +272,37 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
   }
 }
 
+// ---------------------------------------------------------------------------
+// multi-GPU routing: owner rank of a frontier record = target_id % world
+// ---------------------------------------------------------------------------
+constexpr uint32_t ROUTE_MAX_WORLD = 1024;
+__global__ __launch_bounds__(256) void route_keys_kernel(const FrontierRec *__restrict__ fr, uint32_t n, uint32_t world,
+                                                         uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
+                                                         unsigned long long *__restrict__ hist) {
+  __shared__ uint32_t h[ROUTE_MAX_WORLD];
+  for (uint32_t k = threadIdx.x; k < world; k += 256u) h[k] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) {
+    const uint32_t o = fr[i].target_id % world;
+    key[i] = o;
+    idx[i] = i;
+    atomicAdd(&h[o], 1u);
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < world; k += 256u)
+    if (h[k]) atomicAdd(&hist[k], (unsigned long long)h[k]);
+}
+__global__ __launch_bounds__(256) void route_gather_kernel(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ perm,
+                                                           uint32_t n, FrontierRec *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t src = perm[i];
+  FrontierRec f = fr[src];
+  f.qidx = src;  // the home index the owner echoes back
+  out[i] = f;
+}
+
 // projection order: ranges sorted by the position of their window in the entry array
 __global__ __launch_bounds__(256) void window_keys_kernel(const uint4 *__restrict__ win, uint32_t n, uint32_t *__restrict__ key,
                                                           uint32_t *__restrict__ idx) {
@@ -1638,6 +1669,13 @@ void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   const uint32_t *ln = lanes ? wide_n : nullptr, *ll = lanes ? wide_list : nullptr;
   if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, slot_of, ll, ln);
   else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, slot_of, ll, ln);
+}
+void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, uint32_t *key, uint32_t *idx, unsigned long long *hist,
+                       hipStream_t s) {
+  if (n) route_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, n, world, key, idx, hist);
+}
+void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s) {
+  if (n) route_gather_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, perm, n, out);
 }
 void launch_window_keys(const uint4 *win, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s) {
   if (n) window_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(win, n, key, idx);

@@ -231,6 +231,11 @@ class GpuImpg:
         return acc.value
 
 
+    def stage_route(self, d_frontier_ptr, n, world, d_out_ptr):
+        counts = (C.c_uint64 * world)()
+        check(lib().impg_gpu_stage_route(self._h, d_frontier_ptr, n, world, d_out_ptr, counts))
+        return list(counts)
+
     def stage_begin(self, d_ranges_ptr, n, params, d_frontier_ptr, d_self_ptr):
         nf = C.c_uint64(0)
         check(lib().impg_gpu_stage_begin(self._h, d_ranges_ptr, n, C.byref(params), d_frontier_ptr, C.byref(nf), d_self_ptr))

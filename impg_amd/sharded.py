@@ -36,7 +36,8 @@ class GpuBackend:
     def __init__(self, index, device):
         self.index = index
         self.device = torch.device("cuda", device)
-        self.slice_records = 1 << 22
+        self.slice_records = 1 << 26   # frontier records per stage call
+        self.pair_budget = 1 << 30     # candidate pairs per projection launch (36 B of slots each)
 
     def _sync(self):
         # the engine runs on its own non-blocking HIP stream: inputs produced by
@@ -51,8 +52,18 @@ class GpuBackend:
         nf = self.index.stage_begin(ranges_t.data_ptr(), n, params, fr.data_ptr(), self_iv.data_ptr())
         return fr[:nf], self_iv[:n]
 
+    def route(self, frontier, world):
+        """Stable partition by owner rank (target_id % world): (records grouped by owner with qidx :=
+        their index in `frontier`, counts per owner).  Native: one 1..10-bit radix sort."""
+        self._sync()
+        n = frontier.shape[0]
+        out = torch.empty((max(n, 1), FR_COLS), dtype=torch.int32, device=self.device)
+        counts = self.index.stage_route(frontier.data_ptr() if n else None, n, world, out.data_ptr())
+        return out[:n], [int(c) for c in counts]
+
     def expand(self, frontier, transitive, params, want_hits=True):
-        """-> (hits int32[k,8] with fidx indexing `frontier`, accepted count)"""
+        """-> (hits int32[k,8] with fidx indexing `frontier`, accepted count).  Slots whose projection
+        returned None (query_id == -1) stay in the list: they are rare and every consumer skips them."""
         self._sync()
         n = frontier.shape[0]
         outs, accepted, base = [], 0, 0
@@ -62,17 +73,19 @@ class GpuBackend:
             sub = frontier[base:base + m]
             counts = torch.empty(m, dtype=torch.int32, device=self.device)
             total = self.index.stage_count(sub.data_ptr(), m, transitive, counts.data_ptr())
-            if total > (1 << 29) and m > 1:  # keep one projection launch under the pair budget
+            if total > self.pair_budget and m > 1:  # keep one projection launch under the pair budget
                 step = max(1, m // 2)
                 continue
-            hits = torch.empty((max(total, 1), HIT_COLS), dtype=torch.int32, device=self.device)
-            accepted += self.index.stage_project(sub.data_ptr(), m, transitive, params, hits.data_ptr(), total)
-            if want_hits and total:
-                h = hits[:total]
-                h = h[h[:, 1] != -1]  # drop empty slots (query_id == 0xFFFFFFFF)
-                if base:
-                    h[:, 0] += base
-                outs.append(h)
+            if want_hits:
+                hits = torch.empty((max(total, 1), HIT_COLS), dtype=torch.int32, device=self.device)
+                accepted += self.index.stage_project(sub.data_ptr(), m, transitive, params, hits.data_ptr(), total)
+                if total:
+                    h = hits[:total]
+                    if base:
+                        h[:, 0] += base
+                    outs.append(h)
+            else:  # counting only: the hits stay in the engine's slot arrays
+                accepted += self.index.stage_project(sub.data_ptr(), m, transitive, params, None, total)
             base += m
         if not want_hits or not outs:
             return torch.empty((0, HIT_COLS), dtype=torch.int32, device=self.device), accepted
@@ -114,6 +127,11 @@ class ShardedImpg:
         return cls(GpuBackend(index, device), rank, world, torch.device("cuda", device))
 
     # ---- collectives -------------------------------------------------------------
+    # bytes one rank sends or receives in ONE all_to_all_single call.  Larger exchanges are cut into
+    # rounds: on this stack (RCCL 2.26 / ROCm 7.0) a message past 1 GiB came back with half of its rows
+    # wrong (scripts/dbg_a2a.py), and bounded rounds also bound the staging memory.
+    A2A_ROUND_BYTES = 512 << 20
+
     def _all_to_all_rows(self, rows, send_counts):
         """rows grouped by destination rank (send_counts[d] rows each) -> rows
         received, grouped by source rank, and the per-source counts."""
@@ -123,11 +141,36 @@ class ShardedImpg:
         dist.all_gather(gathered, sc)  # every rank learns the full W x W count matrix
         mat = torch.stack(gathered).cpu()
         recv_counts = mat[:, self.rank].tolist()
-        out = torch.empty((int(sum(recv_counts)), rows.shape[1]), dtype=rows.dtype, device=self.comm_device)
         cols = rows.shape[1]
-        dist.all_to_all_single(out.view(-1), rows.contiguous().to(self.comm_device).view(-1),
-                               output_split_sizes=[c * cols for c in recv_counts],
-                               input_split_sizes=[int(c) * cols for c in send_counts])
+        out = torch.empty((int(sum(recv_counts)), cols), dtype=rows.dtype, device=self.comm_device)
+        rows = rows.contiguous().to(self.comm_device)
+        # every rank derives the same number of rounds from the same matrix
+        busiest = int(max(mat.sum(dim=1).max(), mat.sum(dim=0).max()))
+        K = max(1, -(-busiest * cols * rows.element_size() // self.A2A_ROUND_BYTES))
+        if K == 1:
+            dist.all_to_all_single(out.view(-1), rows.view(-1),
+                                   output_split_sizes=[c * cols for c in recv_counts],
+                                   input_split_sizes=[int(c) * cols for c in send_counts])
+            return out.to(self.device), recv_counts
+        soff = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
+        roff = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+        cut = lambda c, k: (int(c) * k) // K  # round k moves rows [cut(c,k), cut(c,k+1)) of every (source, destination) block
+        for k in range(K):
+            ins = [(int(soff[d]) + cut(send_counts[d], k), int(soff[d]) + cut(send_counts[d], k + 1)) for d in range(W)]
+            outs = [(int(roff[s]) + cut(recv_counts[s], k), int(roff[s]) + cut(recv_counts[s], k + 1)) for s in range(W)]
+            if W == 1:  # one block each way: the slices are already contiguous
+                src, dst = rows[ins[0][0]:ins[0][1]], out[outs[0][0]:outs[0][1]]
+            else:
+                src = torch.cat([rows[a:b] for a, b in ins])
+                dst = torch.empty((sum(b - a for a, b in outs), cols), dtype=rows.dtype, device=self.comm_device)
+            dist.all_to_all_single(dst.view(-1), src.view(-1),
+                                   output_split_sizes=[(b - a) * cols for a, b in outs],
+                                   input_split_sizes=[(b - a) * cols for a, b in ins])
+            if W > 1:
+                pos = 0
+                for a, b in outs:
+                    out[a:b] = dst[pos:pos + (b - a)]
+                    pos += b - a
         return out.to(self.device), recv_counts
 
     def _any(self, flag):
@@ -135,14 +178,20 @@ class ShardedImpg:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return bool(t.item())
 
-    # ---- one hop --------------------------------------------------------------------
-    def _hop(self, front, transitive, params, need_hits):
-        W = self.world
+    def _route(self, front):
+        if hasattr(self.backend, "route"):
+            return self.backend.route(front, self.world)
+        W = self.world  # generic (CPU stand-in backends)
         owner = torch.remainder(front[:, 0].to(torch.int64) & 0xFFFFFFFF, W)
         order = torch.argsort(owner, stable=True)
         send = front[order].clone()
-        send[:, 3] = order.to(torch.int32)  # owners echo this back: the home frontier index
-        send_counts = torch.bincount(owner, minlength=W).tolist()
+        send[:, 3] = order.to(torch.int32)
+        return send, torch.bincount(owner, minlength=W).tolist()
+
+    # ---- one hop --------------------------------------------------------------------
+    def _hop(self, front, transitive, params, need_hits):
+        W = self.world
+        send, send_counts = self._route(front)  # grouped by owner; column 3 = the home frontier index, echoed back
         recv, recv_counts = self._all_to_all_rows(send, send_counts)
         hits, accepted = self.backend.expand(recv, transitive, params, want_hits=need_hits)
         if not need_hits:
@@ -152,9 +201,10 @@ class ShardedImpg:
         bounds = torch.as_tensor(np.cumsum([0] + recv_counts), dtype=torch.int64, device=self.device)
         fidx = hits[:, 0].to(torch.int64)
         back_counts = (torch.searchsorted(fidx, bounds[1:], right=False) - torch.searchsorted(fidx, bounds[:-1], right=False)).tolist()
-        hits = hits.clone()
-        hits[:, 0] = recv[fidx, 3]
+        hits[:, 0] = recv[fidx, 3]  # (the hit list is ours: relabel in place)
         back, _ = self._all_to_all_rows(hits, back_counts)
+        if W == 1:
+            return back, accepted, recv.shape[0]  # one source: already in home frontier order
         perm = torch.argsort(back[:, 0].to(torch.int64), stable=True)
         return back[perm].contiguous(), accepted, recv.shape[0]
 
@@ -237,6 +287,8 @@ class ShardedImpg:
                 f = front.cpu().numpy()
                 h = hits.cpu().numpy()
                 for k in range(h.shape[0]):
+                    if int(h[k, 1]) == -1:
+                        continue  # projection returned None
                     fi = int(h[k, 0])
                     qs, qe = int(h[k, 2]), int(h[k, 3])
                     if transitive and params.min_output_length >= 0 and abs(qe - qs) < params.min_output_length:

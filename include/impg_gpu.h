@@ -225,10 +225,18 @@ typedef struct {
  * returns their sum in *total. */
 int impg_gpu_stage_count(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n,
                          int transitive, uint32_t *d_counts, uint64_t *total);
-/* project: fills d_hits[total] (slot order = frontier order x visit order). */
+/* project: fills d_hits[total] (slot order = frontier order x visit order); d_hits may be
+ * NULL when only *accepted is wanted (the last level of a counting run). */
 int impg_gpu_stage_project(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n,
                            int transitive, const impg_gpu_params_t *params,
                            impg_gpu_hit_t *d_hits, uint64_t total, uint64_t *accepted);
+
+/* route: stable partition of a frontier by owner rank (target_id % world).  d_out[n]
+ * receives the records grouped by owner, in their original order within a group,
+ * with qidx replaced by the record's index in d_frontier (the home index an owner
+ * echoes back in impg_gpu_hit_t.fidx); counts[world] (HOST) receives the group sizes. */
+int impg_gpu_stage_route(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n, uint32_t world,
+                         impg_gpu_frontier_t *d_out, uint64_t *counts);
 
 /* Home-side steps of a sharded transitive batch (visited sets live where the
  * query lives).  stage_begin resets the visited sets to the batch's own ranges

@@ -38,7 +38,9 @@ def main():
     ranges = np.array(rl, dtype=impg_amd.RANGE_DTYPE)
     cases = [dict(), dict(transitive=True, max_depth=2), dict(transitive=True, max_depth=3, min_transitive_len=20),
              dict(transitive=True, max_depth=0, min_transitive_len=200, min_output_length=150)]
-    for kw in cases:
+    for ci, kw in enumerate(cases):
+        # odd cases: exchanges cut into many small rounds (the > 512 MB path of _all_to_all_rows)
+        eng.A2A_ROUND_BYTES = (512 << 20) if ci % 2 == 0 else 200
         p = impg_amd.make_params(**kw)
         got = eng.query_batch(ranges, p)
         total = 0

@@ -10,6 +10,8 @@
 namespace impg {
 thread_local std::string g_error;
 void set_error(const std::string &msg) { g_error = msg; }
+void render_paf(const impg_gpu_results &res, const impg_gpu_index &ix, const char *const *range_names,
+                const impg_gpu_params_t &p, int32_t merge_distance, bool bedpe, std::string &out);
 void render_bed(const impg_gpu_results &res, const impg_gpu_index &ix, const char *const *range_names,
                 const impg_gpu_params_t &p, int32_t merge_distance, std::string &out);
 }  // namespace impg
@@ -413,6 +415,23 @@ int impg_gpu_results_bed(const impg_gpu_results_t *res, const impg_gpu_index_t *
   if (!res || !ix || !params || !text || !len) throw Error{IMPG_E_INVALID, "null argument"};
   std::string s;
   render_bed(*res, *ix, range_names, *params, merge_distance, s);
+  char *p = (char *)malloc(s.size() + 1);
+  if (!p) throw Error{IMPG_E_OOM, "host out of memory"};
+  memcpy(p, s.data(), s.size());
+  p[s.size()] = 0;
+  *text = p;
+  *len = s.size();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_results_paf(const impg_gpu_results_t *res, const impg_gpu_index_t *ix, const char *const *range_names,
+                         const impg_gpu_params_t *params, int32_t merge_distance, int format, char **text, size_t *len) {
+  IMPG_TRY
+  if (!res || !ix || !params || !text || !len) throw Error{IMPG_E_INVALID, "null argument"};
+  if (format != IMPG_OUT_PAF && format != IMPG_OUT_BEDPE) throw Error{IMPG_E_INVALID, "unknown output format"};
+  std::string s;
+  render_paf(*res, *ix, range_names, *params, merge_distance, format == IMPG_OUT_BEDPE, s);
   char *p = (char *)malloc(s.size() + 1);
   if (!p) throw Error{IMPG_E_OOM, "host out of memory"};
   memcpy(p, s.data(), s.size());

@@ -90,7 +90,7 @@ void usage() {
   fprintf(stderr,
           "impg-gpu query -a <paf>... (-r seq:start-end | -b <bed>) (-d <bp> | --no-merge) [-x] [-m N]\n"
           "               [--transitive-dfs] [--multi-impg] [--min-transitive-len N] [--min-distance-between-ranges N]\n"
-          "               [-l N] [--min-result-identity F] [-o auto|bed] [--unidirectional] [--order coitrees|sorted]\n"
+          "               [-l N] [--min-result-identity F] [-o auto|bed|bedpe|paf] [--unidirectional] [--order coitrees|sorted]\n"
           "               [--device N]\n");
 }
 
@@ -145,9 +145,10 @@ int main(int argc, char **argv) {
     die("-d/--merge-distance is required. For `impg query`, pass `-d <bp>`. Use `--no-merge` to explicitly disable merging.");
   const int32_t merge_distance = no_merge ? -1 : (int32_t)merge_d;
   if (max_depth < 0 || max_depth > 65535) die("invalid value for '--max-depth'", 2);
-  // -o auto: bed for -r, bedpe for -b (main.rs:7365-7373); only BED is built
+  // -o auto: bed for -r, bedpe for -b (main.rs:7365-7373)
   std::string fmt = ofmt == "auto" ? (bed.empty() ? "bed" : "bedpe") : ofmt;
-  if (fmt != "bed") die("output format '" + fmt + "' is not built in impg-gpu yet (use -o bed)");
+  if (fmt != "bed" && fmt != "bedpe" && fmt != "paf")
+    die("output format '" + fmt + "' is not built in impg-gpu (bed, bedpe, paf)");
 
   std::vector<const char *> pp;
   for (auto &p : pafs) pp.push_back(p.c_str());
@@ -192,12 +193,15 @@ int main(int argc, char **argv) {
   p.min_distance_between_ranges = (int32_t)mdbr;
   p.min_output_length = min_out < 0 ? -1 : (int32_t)min_out;
   p.min_identity = min_ident;
-  p.store_cigar = 0;  // BED (main.rs:7447)
+  p.store_cigar = fmt != "bed";  // CIGARs for PAF / BEDPE only (main.rs:7447)
   impg_gpu_results_t *res = nullptr;
   if (impg_gpu_query_batch(ix, ranges.data(), ranges.size(), &p, &res) != IMPG_OK) die(impg_gpu_last_error());
   char *text = nullptr;
   size_t len = 0;
-  if (impg_gpu_results_bed(res, ix, names.data(), &p, merge_distance, &text, &len) != IMPG_OK) die(impg_gpu_last_error());
+  const int rc = fmt == "bed" ? impg_gpu_results_bed(res, ix, names.data(), &p, merge_distance, &text, &len)
+                              : impg_gpu_results_paf(res, ix, names.data(), &p, merge_distance,
+                                                     fmt == "paf" ? IMPG_OUT_PAF : IMPG_OUT_BEDPE, &text, &len);
+  if (rc != IMPG_OK) die(impg_gpu_last_error());
   fwrite(text, 1, len, stdout);
   free(text);
   impg_gpu_results_free(res);

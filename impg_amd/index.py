@@ -71,6 +71,23 @@ class QueryResults:
         finally:
             _lib.free(text)
 
+    def paf(self, range_names=None, merge_distance=0, params=None, fmt="paf"):
+        """output_results_paf / output_results_bedpe over every range (main.rs:11894-12103); the batch
+        must have been queried with store_cigar = True."""
+        L = lib()
+        p = params or make_params(store_cigar=True)
+        arr = None
+        if range_names is not None:
+            arr = (C.c_char_p * len(range_names))(*[s.encode() for s in range_names])
+        text = C.c_void_p(None)
+        ln = C.c_size_t(0)
+        check(L.impg_gpu_results_paf(self._h, self._owner._h, arr, C.byref(p), merge_distance, {"paf": 0, "bedpe": 1}[fmt],
+                                     C.byref(text), C.byref(ln)))
+        try:
+            return C.string_at(text, ln.value).decode()
+        finally:
+            _lib.free(text)
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().impg_gpu_results_free(self._h)

@@ -195,6 +195,17 @@ int impg_gpu_results_bed(const impg_gpu_results_t *, const impg_gpu_index_t *,
                          const char *const *range_names, const impg_gpu_params_t *params,
                          int32_t merge_distance, char **text, size_t *len);
 
+/* ---- PAF / BEDPE: results.remove(0) + merge_adjusted_intervals (CIGAR-faithful
+ *      merge: contiguity, identical overlap, gaps <= -d) + output_results_paf /
+ *      output_results_bedpe with gi:f / bi:f (main.rs:7472-7496, :11894-12103,
+ *      :12563-12845, :13014-13180).  The results must come from a query with
+ *      store_cigar = 1.  *text is malloc'ed; free() it. ------------------------ */
+#define IMPG_OUT_PAF 0
+#define IMPG_OUT_BEDPE 1
+int impg_gpu_results_paf(const impg_gpu_results_t *, const impg_gpu_index_t *,
+                         const char *const *range_names, const impg_gpu_params_t *params,
+                         int32_t merge_distance, int format, char **text, size_t *len);
+
 /* ---- host-side ingest helpers (paf.rs, partition.rs parsers) -------------- */
 /* parse_cigar_to_delta (impg.rs:2935-2950): returns #ops or <0 */
 long impg_gpu_parse_cigar(const char *cigar, size_t len, uint32_t *ops_out, size_t cap);

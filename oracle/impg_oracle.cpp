@@ -32,6 +32,7 @@
 #include <deque>
 #include <fcntl.h>
 #include <functional>
+#include <limits>
 #include <map>
 #include <string>
 #include <thread>
@@ -1270,6 +1271,283 @@ long oracle_query_cigar(const oracle_index_t *ix, uint32_t target_id, int32_t st
   }
   *n_ops = k;
   return (long)results.size();
+}
+
+/* ------------------------------------------------------------------------ */
+/* PAF / BEDPE output (main.rs:11894-12103, :12563-12845, :13014-13180)       */
+/* ------------------------------------------------------------------------ */
+namespace {
+inline uint32_t cigar_make(int32_t len, char op) { /* CigarOp::new (impg.rs:80-93) on a known-valid op letter */
+  uint32_t v = 0;
+  cigar_new(len, op, &v);
+  return v;
+}
+/* merge_consecutive_cigar_ops (main.rs:13014-13035) */
+void merge_consecutive_cigar_ops(std::vector<uint32_t> &cigar) {
+  if (cigar.size() <= 1) return;
+  size_t write_idx = 0;
+  for (size_t read_idx = 1; read_idx < cigar.size(); read_idx++) {
+    if (cigar_op(cigar[write_idx]) == cigar_op(cigar[read_idx])) {
+      int32_t combined = cigar_len(cigar[write_idx]) + cigar_len(cigar[read_idx]);
+      cigar[write_idx] = cigar_make(combined, cigar_op(cigar[write_idx]));
+    } else {
+      write_idx += 1;
+      if (write_idx != read_idx) cigar[write_idx] = cigar[read_idx];
+    }
+  }
+  cigar.resize(write_idx + 1);
+}
+/* extract_cigar_suffix (main.rs:13054-13090) */
+std::vector<uint32_t> extract_cigar_suffix(const std::vector<uint32_t> &cigar, int32_t query_len, bool forward) {
+  std::vector<uint32_t> result;
+  int32_t remaining_query = query_len;
+  for (size_t k = cigar.size(); k-- > 0;) {
+    uint32_t op = cigar[k];
+    if (remaining_query <= 0) break;
+    int32_t qd = std::abs(query_delta(op, !forward));
+    if (qd <= remaining_query) {
+      result.push_back(op);
+      remaining_query -= qd;
+    } else if (qd > 0) {
+      volatile float scale = (float)remaining_query / (float)qd;
+      volatile float scaled = (float)cigar_len(op) * scale;
+      result.push_back(cigar_make((int32_t)scaled, cigar_op(op)));
+      remaining_query = 0;
+    }
+  }
+  std::reverse(result.begin(), result.end());
+  return result;
+}
+/* extract_cigar_prefix (main.rs:13092-13125) */
+std::vector<uint32_t> extract_cigar_prefix(const std::vector<uint32_t> &cigar, int32_t query_len, bool forward) {
+  std::vector<uint32_t> result;
+  int32_t remaining_query = query_len;
+  for (uint32_t op : cigar) {
+    if (remaining_query <= 0) break;
+    int32_t qd = std::abs(query_delta(op, !forward));
+    if (qd <= remaining_query) {
+      result.push_back(op);
+      remaining_query -= qd;
+    } else if (qd > 0) {
+      volatile float scale = (float)remaining_query / (float)qd;
+      volatile float scaled = (float)cigar_len(op) * scale;
+      result.push_back(cigar_make((int32_t)scaled, cigar_op(op)));
+      remaining_query = 0;
+    }
+  }
+  return result;
+}
+/* check_cigar_overlap_match (main.rs:13037-13052) */
+bool check_cigar_overlap_match(const std::vector<uint32_t> &cur, const std::vector<uint32_t> &next, int32_t qlen, bool fwd) {
+  return extract_cigar_suffix(cur, qlen, fwd) == extract_cigar_prefix(next, qlen, fwd);
+}
+/* trim_cigar_prefix (main.rs:13127-13180) */
+std::vector<uint32_t> trim_cigar_prefix(const std::vector<uint32_t> &cigar, int32_t query_len, int32_t target_len) {
+  std::vector<uint32_t> result;
+  int32_t query_consumed = 0, target_consumed = 0;
+  size_t start_idx = 0;
+  for (size_t idx = 0; idx < cigar.size(); idx++) {
+    uint32_t op = cigar[idx];
+    int32_t q_delta = std::abs(query_delta(op, false)), t_delta = target_delta(op);
+    if (query_consumed + q_delta > query_len || target_consumed + t_delta > target_len) {
+      int32_t query_remaining = query_len - query_consumed, target_remaining = target_len - target_consumed;
+      volatile float skip_ratio;
+      if (q_delta > 0 && t_delta > 0) {
+        volatile float a = (float)query_remaining / (float)q_delta, b = (float)target_remaining / (float)t_delta;
+        skip_ratio = a < b ? a : b; /* f32::min (no NaNs here) */
+      } else if (q_delta > 0) skip_ratio = (float)query_remaining / (float)q_delta;
+      else if (t_delta > 0) skip_ratio = (float)target_remaining / (float)t_delta;
+      else skip_ratio = 0.0f;
+      volatile float sk = (float)cigar_len(op) * skip_ratio;
+      int32_t skip_len = (int32_t)sk;
+      if (skip_len < cigar_len(op)) result.push_back(cigar_make(cigar_len(op) - skip_len, cigar_op(op)));
+      start_idx = idx + 1;
+      break;
+    }
+    query_consumed += q_delta;
+    target_consumed += t_delta;
+    if (query_consumed >= query_len && target_consumed >= target_len) {
+      start_idx = idx + 1;
+      break;
+    }
+  }
+  result.insert(result.end(), cigar.begin() + (long)start_idx, cigar.end());
+  return result;
+}
+/* merge_adjusted_intervals (main.rs:12563-12845) */
+bool merge_adjusted_intervals(std::vector<AdjustedInterval> &results, int32_t merge_distance) {
+  if (!(results.size() > 1 && merge_distance >= 0)) return true;
+  std::stable_sort(results.begin(), results.end(), [](const AdjustedInterval &a, const AdjustedInterval &b) {
+    bool af = a.q_first < a.q_last, bf = b.q_first < b.q_last; /* strict here (:12567) */
+    auto ka = std::make_tuple(a.q_id, af, af ? a.q_first : a.q_last, a.t_id, a.t_first);
+    auto kb = std::make_tuple(b.q_id, bf, bf ? b.q_first : b.q_last, b.t_id, b.t_first);
+    return ka < kb;
+  });
+  std::vector<AdjustedInterval> merged;
+  AdjustedInterval cur = std::move(results[0]);
+  for (size_t i = 1; i < results.size(); i++) {
+    AdjustedInterval next = std::move(results[i]);
+    bool query_forward = cur.q_first <= cur.q_last, next_query_forward = next.q_first <= next.q_last;
+    bool target_forward = cur.t_first <= cur.t_last, next_target_forward = next.t_first <= next.t_last;
+    if (!target_forward || !next_target_forward) { set_err("Target intervals should always be in forward!"); return false; }
+    if (cur.q_id != next.q_id || cur.t_id != next.t_id || query_forward != next_query_forward) {
+      merged.push_back(std::move(cur));
+      cur = std::move(next);
+      continue;
+    }
+    bool q_contig, t_contig, q_overlap, t_overlap;
+    if (query_forward) {
+      q_contig = cur.q_last == next.q_first; t_contig = cur.t_last == next.t_first;
+      q_overlap = cur.q_last > next.q_first; t_overlap = cur.t_last > next.t_first;
+    } else {
+      q_contig = cur.q_first == next.q_last; t_contig = cur.t_first == next.t_last;
+      q_overlap = cur.q_first > next.q_last; t_overlap = cur.t_first < next.t_last;
+    }
+    if (q_contig && t_contig) {
+      if (query_forward) {
+        cur.q_last = next.q_last; cur.t_last = next.t_last;
+        cur.cigar.insert(cur.cigar.end(), next.cigar.begin(), next.cigar.end());
+      } else {
+        cur.q_first = next.q_first; cur.t_first = next.t_first;
+        std::vector<uint32_t> nc(next.cigar);
+        nc.insert(nc.end(), cur.cigar.begin(), cur.cigar.end());
+        cur.cigar.swap(nc);
+      }
+      merge_consecutive_cigar_ops(cur.cigar);
+      continue;
+    }
+    if (q_overlap && t_overlap) {
+      int32_t qol, tol;
+      if (query_forward) { qol = next.q_first - cur.q_last; tol = next.t_first - cur.t_last; }
+      else { qol = next.q_last - cur.q_first; tol = cur.t_first - next.t_last; }
+      if (qol > 0 && tol > 0) {
+        if (check_cigar_overlap_match(cur.cigar, next.cigar, qol, query_forward)) {
+          std::vector<uint32_t> trimmed = trim_cigar_prefix(next.cigar, qol, tol);
+          if (query_forward) {
+            cur.q_last = next.q_last; cur.t_last = next.t_last;
+            cur.cigar.insert(cur.cigar.end(), trimmed.begin(), trimmed.end());
+          } else {
+            cur.q_first = next.q_first; cur.t_first = next.t_first;
+            trimmed.insert(trimmed.end(), cur.cigar.begin(), cur.cigar.end());
+            cur.cigar.swap(trimmed);
+          }
+          continue;
+        }
+      }
+    }
+    if (!q_overlap && !t_overlap) {
+      int32_t query_gap, target_gap;
+      if (query_forward) { query_gap = next.q_first - cur.q_last; target_gap = next.t_first - cur.t_last; }
+      else { query_gap = cur.q_first - next.q_last; target_gap = cur.t_first - next.t_last; }
+      if (query_gap >= 0 && target_gap >= 0 && (query_gap > 0 || target_gap > 0) && query_gap <= merge_distance &&
+          target_gap <= merge_distance) {
+        std::vector<uint32_t> gap;
+        if (query_gap > 0) gap.push_back(cigar_make(query_gap, 'I'));
+        if (target_gap > 0) gap.push_back(cigar_make(target_gap, 'D'));
+        if (query_forward) {
+          cur.q_last = next.q_last; cur.t_last = next.t_last;
+          cur.cigar.insert(cur.cigar.end(), gap.begin(), gap.end());
+          cur.cigar.insert(cur.cigar.end(), next.cigar.begin(), next.cigar.end());
+        } else {
+          cur.q_first = next.q_first; cur.t_first = next.t_first;
+          std::vector<uint32_t> nc(next.cigar);
+          nc.insert(nc.end(), gap.begin(), gap.end());
+          nc.insert(nc.end(), cur.cigar.begin(), cur.cigar.end());
+          cur.cigar.swap(nc);
+        }
+        merge_consecutive_cigar_ops(cur.cigar);
+        continue;
+      }
+    }
+    merged.push_back(std::move(cur));
+    cur = std::move(next);
+  }
+  merged.push_back(std::move(cur));
+  results = std::move(merged);
+  return true;
+}
+/* format!("{x:.6}").trim_end_matches('0').trim_end_matches('.') for an f32 (main.rs:11960-11967) */
+std::string fmt_f32_trim(float x) {
+  char b[64];
+  if (x != x) return "NaN";
+  if (x == std::numeric_limits<float>::infinity()) return "inf";
+  if (x == -std::numeric_limits<float>::infinity()) return "-inf";
+  snprintf(b, sizeof b, "%.6f", (double)x);
+  std::string s(b);
+  while (!s.empty() && s.back() == '0') s.pop_back();
+  while (!s.empty() && s.back() == '.') s.pop_back();
+  return s;
+}
+} // namespace
+
+/* perform_query + results.remove(0) + output_results_paf / output_results_bedpe
+ * (main.rs:7472-7496, :11894-12103).  format: 0 = PAF, 1 = BEDPE. */
+int oracle_query_paf(const oracle_index_t *ix, const char *target_name, int32_t start, int32_t end,
+                     const char *range_name, const oracle_params_t *p, int32_t merge_distance, int format,
+                     char **buf, size_t *len, size_t *cap) {
+  auto it = ix->seq_index.name_to_id.find(target_name);
+  if (it == ix->seq_index.name_to_id.end()) { set_err(std::string("Sequence '") + target_name + "' not found in index"); return -2; }
+  uint32_t target_id = it->second;
+  int64_t seq_len = ix->seq_index.id_to_len[target_id];
+  if (start < 0 || end < 0 || start >= end || end > (int32_t)seq_len) { set_err("invalid range"); return -3; }
+  if (end - start < p->min_transitive_len) { set_err("Range is below minimum length"); return -4; }
+  std::vector<AdjustedInterval> results;
+  g_nproj = 0;
+  oracle_params_t q = *p;
+  q.store_cigar = 1; /* main.rs:7447 */
+  if (!run_query(*ix, target_id, start, end, q, 1, results)) return -1;
+  if (!p->transitive && p->min_output_length >= 0) { /* :11682-11688 retain */
+    std::vector<AdjustedInterval> kept;
+    for (auto &x : results) if (std::abs(x.q_last - x.q_first) >= p->min_output_length) kept.push_back(std::move(x));
+    results.swap(kept);
+  }
+  if (results.empty()) { set_err("removal index (is 0) should be < len (is 0)"); return -5; } /* Vec::remove(0) panics */
+  results.erase(results.begin());
+  if (format == 1) { /* output_results_bedpe: a row without CIGAR would switch to the gap-2d merge (:11905-11910) */
+    bool any_empty = false;
+    for (auto &r : results) any_empty = any_empty || r.cigar.empty();
+    if (any_empty) { set_err("empty CIGAR in a BEDPE row (syng output) is outside the restated path"); return -6; }
+  }
+  if (!merge_adjusted_intervals(results, merge_distance)) return -7;
+  for (auto &r : results) {
+    const std::string &qn = ix->seq_index.id_to_name[r.q_id], &tn = ix->seq_index.id_to_name[r.t_id];
+    int32_t first, last; char strand;
+    if (r.q_first <= r.q_last) { first = r.q_first; last = r.q_last; strand = '+'; }
+    else { first = r.q_last; last = r.q_first; strand = '-'; }
+    int32_t matches = 0, mismatches = 0, insertions = 0, inserted_bp = 0, deletions = 0, deleted_bp = 0, block_len = 0;
+    for (uint32_t op : r.cigar) {
+      int32_t l = cigar_len(op);
+      switch (cigar_op(op)) {
+      case 'M': case '=': matches += l; block_len += l; break;
+      case 'X': mismatches += l; block_len += l; break;
+      case 'I': insertions += 1; inserted_bp += l; block_len += l; break;
+      case 'D': deletions += 1; deleted_bp += l; block_len += l; break;
+      default: break;
+      }
+    }
+    volatile float gi = (float)matches / (float)(matches + mismatches + insertions + deletions);
+    int32_t edit_distance = mismatches + inserted_bp + deleted_bp;
+    volatile float bi = (float)matches / (float)(matches + edit_distance);
+    std::string gi_s = fmt_f32_trim(gi), bi_s = fmt_f32_trim(bi);
+    std::string line;
+    char num[64];
+    if (format == 1) {
+      line += qn; snprintf(num, sizeof num, "\t%u\t%u\t", (uint32_t)first, (uint32_t)last); line += num;
+      line += tn; snprintf(num, sizeof num, "\t%u\t%u\t", (uint32_t)r.t_first, (uint32_t)r.t_last); line += num;
+      line += range_name; line += "\t0\t"; line += strand; line += "\t+\tgi:f:"; line += gi_s; line += "\tbi:f:"; line += bi_s;
+      line += "\n";
+    } else {
+      line += qn; snprintf(num, sizeof num, "\t%llu\t%u\t%u\t%c\t", (unsigned long long)ix->seq_index.id_to_len[r.q_id],
+                           (uint32_t)first, (uint32_t)last, strand); line += num;
+      line += tn; snprintf(num, sizeof num, "\t%llu\t%u\t%u\t%d\t%d\t255\tgi:f:", (unsigned long long)ix->seq_index.id_to_len[r.t_id],
+                           (uint32_t)r.t_first, (uint32_t)r.t_last, matches, block_len); line += num;
+      line += gi_s; line += "\tbi:f:"; line += bi_s; line += "\tcg:Z:";
+      for (uint32_t op : r.cigar) { snprintf(num, sizeof num, "%d%c", cigar_len(op), cigar_op(op)); line += num; }
+      line += "\tan:Z:"; line += range_name; line += "\n";
+    }
+    append(buf, len, cap, line.data(), line.size());
+  }
+  return 0;
 }
 
 long oracle_bed_merge(oracle_interval_t *iv, size_t n, int32_t merge_distance, int merge_strands) {

@@ -135,6 +135,15 @@ int oracle_query_bed(const oracle_index_t *, const char *target_name,
                      const oracle_params_t *p, int32_t merge_distance,
                      char **buf, size_t *len, size_t *cap);
 
+/* perform_query (store_cigar = true), results.remove(0), then output_results_paf
+ * (format 0) or output_results_bedpe (format 1): merge_adjusted_intervals with
+ * its CIGAR concatenation / f32-scaled trims, gi:f / bi:f formatting
+ * (main.rs:7472-7496, :11894-12103, :12563-12845, :13014-13180). */
+int oracle_query_paf(const oracle_index_t *, const char *target_name, int32_t start,
+                     int32_t end, const char *range_name, const oracle_params_t *p,
+                     int32_t merge_distance, int format, char **buf, size_t *len,
+                     size_t *cap);
+
 /* parse_bed_file / parse_target_range (partition.rs:1719-1789) */
 long oracle_parse_bed_text(const char *text, size_t len, char *names_out,
                            size_t names_cap, int32_t *start_end_out,

@@ -98,6 +98,10 @@ def lib():
                                          C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         L.oracle_bed_merge.restype = C.c_long
         L.oracle_bed_merge.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int]
+        L.oracle_query_paf.restype = C.c_int
+        L.oracle_query_paf.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p,
+                                       C.POINTER(Params), C.c_int32, C.c_int, C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.oracle_query_bed.restype = C.c_int
         L.oracle_query_bed.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p,
                                        C.POINTER(Params), C.c_int32, C.POINTER(C.c_void_p),
@@ -276,6 +280,24 @@ class OracleIndex:
         cap = C.c_size_t(0)
         rc = lib().oracle_query_bed(self._h, target_name.encode(), start, end, range_name.encode(),
                                     C.byref(p), merge_distance, C.byref(buf), C.byref(ln), C.byref(cap))
+        try:
+            if rc != 0:
+                raise RuntimeError(lib().oracle_last_error().decode())
+            return C.string_at(buf, ln.value).decode() if ln.value else ""
+        finally:
+            if buf.value:
+                C.CDLL(None).free(buf)
+
+    def query_paf(self, target_name, start, end, range_name=None, merge_distance=0, fmt="paf", params=None, **kw):
+        """`impg query -o paf|bedpe` text for one target range."""
+        p = params or make_params(**kw)
+        if range_name is None:
+            range_name = "%s:%d-%d" % (target_name, start, end)
+        buf = C.c_void_p(None)
+        ln = C.c_size_t(0)
+        cap = C.c_size_t(0)
+        rc = lib().oracle_query_paf(self._h, target_name.encode(), start, end, range_name.encode(), C.byref(p),
+                                    merge_distance, {"paf": 0, "bedpe": 1}[fmt], C.byref(buf), C.byref(ln), C.byref(cap))
         try:
             if rc != 0:
                 raise RuntimeError(lib().oracle_last_error().decode())

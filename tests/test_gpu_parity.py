@@ -313,9 +313,17 @@ def test_cli_bed_bytes(tmp_path):
     r = subprocess.run([cli, "query", "-a", paf, "-r", "%s:%d-%d" % (c.seq_name(t), s, e), "-d", "100"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout == c.query_bed(c.seq_name(t), s, e, merge_distance=100)
     for bad in (["-r", "nope:1-500", "-d", "0"], ["-r", "%s:0-50" % c.seq_name(0), "-d", "0"], ["-r", "%s:0-500" % c.seq_name(0)],
-                ["-r", "%s:0-99999999" % c.seq_name(0), "-d", "0"], ["-b", bed, "-d", "0"]):
+                ["-r", "%s:0-99999999" % c.seq_name(0), "-d", "0"], ["-b", bed, "-d", "0", "-o", "gfa"]):
         r = subprocess.run([cli, "query", "-a", paf] + bad, capture_output=True, text=True)
         assert r.returncode != 0 and r.stdout == "" and r.stderr.startswith("Error:")
+    # -o auto is BEDPE for a BED of targets (main.rs:7365-7373); -o paf
+    for fmt_flags, fmt in ([], "bedpe"), (["-o", "paf"], "paf"), (["-o", "bedpe", "-x", "-m", "2"], "bedpe"):
+        kw = dict(transitive=True, max_depth=2) if "-x" in fmt_flags else dict()
+        r = subprocess.run([cli, "query", "-a", paf, "-b", bed, "-d", "50"] + fmt_flags, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        want = "".join(c.query_paf(c.seq_name(t), s, e, range_name=rnames[i], merge_distance=50, fmt=fmt, **kw)
+                       for i, (t, s, e) in enumerate(rl))
+        assert r.stdout == want, fmt_flags
 
 
 @pytest.mark.parametrize("seed,weird,incons,max_ops", [(71, False, False, 150), (72, True, False, 150), (73, True, True, 150),
@@ -428,3 +436,57 @@ def test_stage_route_is_a_stable_partition_by_owner(tmp_path):
             want[:, 3] = order.to(torch.int32)
             assert bool((out == want).all()), (n, world)
             assert counts == torch.bincount(owner, minlength=world).tolist()
+
+
+@pytest.mark.parametrize("seed,weird,incons,max_ops", [(91, False, False, 60), (92, True, False, 60), (93, True, True, 200),
+                                                        (94, False, False, 12)])
+def test_paf_and_bedpe_bytes(tmp_path, seed, weird, incons, max_ops):
+    """`-o paf` / `-o bedpe`: merge_adjusted_intervals (CIGAR concatenation, gap filling, f32-scaled trims)
+    and the gi:f / bi:f columns, byte for byte against the oracle's restatement (main.rs:11894-12103,
+    :12563-12845, :13014-13180)."""
+    sl = 30000
+    text, names = random_paf(seed, 300, n_seq=5, seq_len=sl, max_ops=max_ops, weird=weird, inconsistent=incons, self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(seed, 60, 5, sl, max_len=6000, min_len=150)
+    rnames = ["r%d" % i for i in range(len(ranges))]
+    for kw in [dict(), dict(transitive=True, max_depth=2), dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=50),
+               dict(min_identity=0.7), dict(min_output_length=300)]:
+        p = impg_amd.make_params(store_cigar=True, **kw)
+        res = g.query_batch(ranges, p)
+
+        def oracle_text(i, d, fmt):
+            t, s, e = ranges[i]
+            return c.query_paf(g.seq_name(t), s, e, range_name=rnames[i], merge_distance=d, fmt=fmt, **kw)
+
+        # a range whose every row is filtered away makes the reference panic in results.remove(0): both sides raise
+        dead = set()
+        for i in range(len(ranges)):
+            try:
+                oracle_text(i, 0, "paf")
+            except RuntimeError:
+                dead.add(i)
+                one = g.query_batch([ranges[i]], p)
+                with pytest.raises(impg_amd.ImpgGpuError):
+                    one.paf([rnames[i]], merge_distance=0, params=p)
+        live = [i for i in range(len(ranges)) if i not in dead]
+        if dead:
+            res = g.query_batch([ranges[i] for i in live], p)
+        for d in (-1, 0, 25, 1000):
+            for fmt in ("paf", "bedpe"):
+                got = res.paf([rnames[i] for i in live], merge_distance=d, params=p, fmt=fmt)
+                want = "".join(oracle_text(i, d, fmt) for i in live)
+                assert got == want, (kw, d, fmt)
+    # chained tandem copies: contiguous rows that merge_adjusted_intervals joins
+    lines = ["Q\t4000\t%d\t%d\t+\tT\t4000\t%d\t%d\t1\t1\t60\tcg:Z:%d=" % (100 * k, 100 * k + 100, 500 + 100 * k, 600 + 100 * k, 100)
+             for k in range(8)]
+    lines += ["R\t4000\t%d\t%d\t-\tT\t4000\t%d\t%d\t1\t1\t60\tcg:Z:40=3I57=" % (3000 - 110 * k, 3100 - 110 * k, 500 + 100 * k, 600 + 100 * k)
+              for k in range(6)]
+    g, c = both(tmp_path, "\n".join(lines) + "\n", bidirectional=False)
+    t = g.seq_id("T")
+    p = impg_amd.make_params(store_cigar=True)
+    res = g.query_batch([(t, 400, 1500)], p)
+    for d in (0, 5, 20):
+        for fmt in ("paf", "bedpe"):
+            got = res.paf(["x"], merge_distance=d, params=p, fmt=fmt)
+            assert got == c.query_paf("T", 400, 1500, range_name="x", merge_distance=d, fmt=fmt)
+    assert res.paf(["x"], merge_distance=0, params=p).count("\n") < res.paf(["x"], merge_distance=-1, params=p).count("\n")

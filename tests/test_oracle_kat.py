@@ -296,3 +296,33 @@ def test_gap_compressed_identity():
     assert o.gap_compressed_identity(P([(90, "="), (10, "X")])) == 0.9
     assert o.gap_compressed_identity(P([(8, "="), (100, "I"), (7, "D"), (1, "M")])) == 9 / 11
     assert o.gap_compressed_identity(P([])) == 0.0
+
+
+def test_paf_and_bedpe_rows_by_hand(tmp_path):
+    """output_results_paf / _bedpe (main.rs:11894-12103) on rows small enough to check by hand."""
+    text = ("Q\t1000\t50\t200\t+\tT\t1000\t0\t100\t1\t1\t60\tcg:Z:10=5I5D50=50I35=\n"
+            "Q2\t500\t0\t100\t-\tT\t1000\t20\t120\t1\t1\t60\tcg:Z:40=2X58=\n")
+    p = tmp_path / "k.paf"
+    p.write_text(text)
+    ix = o.OracleIndex(paf_paths=[str(p)], preparse=True)
+    # T:10-90 through Q: the slice starts with the insertion sitting on T=10 (query 60) and ends 25 bases
+    # into the last '=' (query 190): 75 matches, 2 insertions (55 bp), 1 deletion (5 bp), block 135
+    # gi = 75/78, bi = 75/135;  through Q2 (reverse strand): 40= 2X 28= of T:20-90 -> 68 matches, block 70
+    want = ("Q\t1000\t60\t190\t+\tT\t1000\t10\t90\t75\t135\t255\tgi:f:0.961538\tbi:f:0.555556\tcg:Z:5I5D50=50I25=\tan:Z:T:10-90\n"
+            "Q2\t500\t30\t100\t-\tT\t1000\t20\t90\t68\t70\t255\tgi:f:0.971429\tbi:f:0.971429\tcg:Z:40=2X28=\tan:Z:T:10-90\n")
+    assert ix.query_paf("T", 10, 90, merge_distance=0, min_transitive_len=10) == want
+    assert ix.query_paf("T", 10, 90, merge_distance=0, fmt="bedpe", min_transitive_len=10) == (
+        "Q\t60\t190\tT\t10\t90\tT:10-90\t0\t+\t+\tgi:f:0.961538\tbi:f:0.555556\n"
+        "Q2\t30\t100\tT\t20\t90\tT:10-90\t0\t-\t+\tgi:f:0.971429\tbi:f:0.971429\n")
+    # two abutting alignments are joined and their CIGAR runs fused (main.rs:12640-12676);
+    # a 7-base gap on both axes is bridged with 7I7D when -d allows it (:12757-12828)
+    text = ("A\t900\t0\t100\t+\tT\t900\t100\t200\t1\t1\t60\tcg:Z:100=\n"
+            "A\t900\t100\t160\t+\tT\t900\t200\t260\t1\t1\t60\tcg:Z:30=1X29=\n"
+            "A\t900\t167\t200\t+\tT\t900\t267\t300\t1\t1\t60\tcg:Z:33=\n")
+    p.write_text(text)
+    ix = o.OracleIndex(paf_paths=[str(p)], bidirectional=False, preparse=True)
+    rows = ix.query_paf("T", 100, 300, merge_distance=0, min_transitive_len=10).splitlines()
+    assert [r.split("\t")[2:4] + [r.split("\t")[14]] for r in rows] == [["0", "160", "cg:Z:130=1X29="], ["167", "200", "cg:Z:33="]]
+    rows = ix.query_paf("T", 100, 300, merge_distance=10, min_transitive_len=10).splitlines()
+    assert [r.split("\t")[2:4] + [r.split("\t")[14]] for r in rows] == [["0", "200", "cg:Z:130=1X29=7I7D33="]]
+    assert len(ix.query_paf("T", 100, 300, merge_distance=-1, min_transitive_len=10).splitlines()) == 3

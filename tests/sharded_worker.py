@@ -32,6 +32,20 @@ def main():
         torch.cuda.set_device(0)
         g = impg_amd.GpuImpg.from_paf(paf_path, device=0, shard=rank, n_shards=world)
         eng = ShardedImpg(GpuBackend(g, 0), rank, world, torch.device("cuda", 0), chunk_ranges=7)
+        # impg_gpu_stage_route: stable partition by target_id % W, qidx := home index, counts per owner
+        gen = torch.Generator(device="cpu").manual_seed(3 + rank)
+        for n in (1, 777, 300_000):
+            for W in (1, 2, 3, 8):
+                fr = torch.randint(0, 1000, (n, 4), dtype=torch.int32, generator=gen).cuda()
+                out = torch.empty_like(fr)
+                torch.cuda.synchronize()
+                counts = g.stage_route(fr.data_ptr(), n, W, out.data_ptr())
+                owner = torch.remainder(fr[:, 0].to(torch.int64), W)
+                order = torch.argsort(owner, stable=True)
+                want = fr[order].clone()
+                want[:, 3] = order.to(torch.int32)
+                assert bool((out == want).all()), (n, W)
+                assert [int(x) for x in counts] == torch.bincount(owner, minlength=W).tolist()
     seq_len = int(c.seq_len(0))
     n_q = 18 + 5 * rank  # ranks own different numbers of queries
     rl = random_ranges(100 + rank, n_q, n_seq, seq_len, max_len=3000, min_len=120)

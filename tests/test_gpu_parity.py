@@ -417,27 +417,6 @@ def test_multi_impg_dense_step(tmp_path):
         assert_same(g, c, ranges, multi_impg=True, **kw)
 
 
-def test_stage_route_is_a_stable_partition_by_owner(tmp_path):
-    """impg_gpu_stage_route (multi-GPU frontier routing): records grouped by target_id % world, original
-    order kept inside a group, qidx replaced by the record's home index, counts per owner."""
-    import torch
-    text, _ = random_paf(5, 40, n_seq=4, seq_len=5000)
-    g, _c = both(tmp_path, text)
-    gen = torch.Generator(device="cpu").manual_seed(3)
-    for n in (1, 777, 300_000):
-        for world in (1, 2, 3, 8):
-            fr = torch.randint(0, 1000, (n, 4), dtype=torch.int32, generator=gen).cuda()
-            out = torch.empty_like(fr)
-            torch.cuda.synchronize()
-            counts = g.stage_route(fr.data_ptr(), n, world, out.data_ptr())
-            owner = torch.remainder(fr[:, 0].to(torch.int64), world)
-            order = torch.argsort(owner, stable=True)
-            want = fr[order].clone()
-            want[:, 3] = order.to(torch.int32)
-            assert bool((out == want).all()), (n, world)
-            assert counts == torch.bincount(owner, minlength=world).tolist()
-
-
 @pytest.mark.parametrize("seed,weird,incons,max_ops", [(91, False, False, 60), (92, True, False, 60), (93, True, True, 200),
                                                         (94, False, False, 12)])
 def test_paf_and_bedpe_bytes(tmp_path, seed, weird, incons, max_ops):

@@ -31,6 +31,16 @@ def log(msg):
     print("[bench %7.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
 
 
+def flush_c_stdio():
+    """Flush libc's stdio buffers (libraries such as RCCL print through them; when stdout is a pipe their
+    text would otherwise appear at process exit, after the JSON line)."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +56,11 @@ def main():
     ap.add_argument("--paf", default=None, help="reuse an existing synthetic PAF file")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
+
+    # stdout carries exactly one line, the result: anything a library prints to fd 1 (RCCL's version
+    # banner does) is sent to stderr instead
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -75,6 +90,7 @@ def main():
         os.replace(paf + ".tmp", paf)
     if dist is not None:
         dist.barrier()
+        flush_c_stdio()  # (the communicator exists now: its banner, if any, goes out first)
     transitive = not args.no_transitive
     params = impg_amd.make_params(transitive=transitive, max_depth=args.max_depth)  # -x -m 3, defaults otherwise
 
@@ -136,6 +152,7 @@ def main():
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
+        flush_c_stdio()
         return
 
     proj_per_step = sum(s.projected for s in stats) / max(1, args.steps)
@@ -196,9 +213,11 @@ def main():
         },
     }
     out["cpu_baseline"] = cpu_baseline(args, paf, ranges, transitive) if (world == 1 and args.cpu_sample > 0) else None
-    print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    flush_c_stdio()
+    result_out.write(json.dumps(out) + "\n")
+    result_out.flush()
 
 
 def cpu_baseline(args, paf, ranges, transitive):

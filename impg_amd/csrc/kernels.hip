@@ -833,18 +833,18 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         }
       } else {
         const uint32_t *P = v.ext_cp + e2.y;  // P[0..m]
-        uint32_t lo = 1, hi = c.m + 1;
-        while (lo < hi) {  // first i in [1,m] with P[i] >= xa
-          uint32_t mid = (lo + hi) >> 1;
-          if ((int32_t)P[mid] >= xa) hi = mid; else lo = mid + 1;
+        // two binary searches side by side (their probes overlap): first i in [1,m] with P[i] >= xa,
+        // first i in [0,m) with P[i] >= xb
+        uint32_t la = 1, ha = c.m + 1, lb = 0, hb = c.m;
+        while (la < ha || lb < hb) {
+          const uint32_t ma = (la + ha) >> 1, mb = (lb + hb) >> 1;
+          const bool ga = la < ha, gb = lb < hb;
+          const int32_t pa = ga ? (int32_t)P[ma] : 0, pb = gb ? (int32_t)P[mb] : 0;
+          if (ga) { if (pa >= xa) ha = ma; else la = ma + 1; }
+          if (gb) { if (pb >= xb) hb = mb; else lb = mb + 1; }
         }
-        cA = lo - 1;
-        lo = 0; hi = c.m;
-        while (lo < hi) {  // first i in [0,m) with P[i] >= xb
-          uint32_t mid = (lo + hi) >> 1;
-          if ((int32_t)P[mid] >= xb) hi = mid; else lo = mid + 1;
-        }
-        cB = lo;
+        cA = la - 1;
+        cB = lb;
       }
       if (cA < c.m) {
         // Two short literal walks instead of one long one (exact):

@@ -469,3 +469,31 @@ def test_paf_and_bedpe_bytes(tmp_path, seed, weird, incons, max_ops):
             got = res.paf(["x"], merge_distance=d, params=p, fmt=fmt)
             assert got == c.query_paf("T", 400, 1500, range_name="x", merge_distance=d, fmt=fmt)
     assert res.paf(["x"], merge_distance=0, params=p).count("\n") < res.paf(["x"], merge_distance=-1, params=p).count("\n")
+
+
+def test_projection_order_is_invisible(tmp_path):
+    """locality_min = 1 forces the window-order projection (slot_of indirection, XCD block mapping, lane
+    and wave emit passes writing it) on small batches: results must not change in any position."""
+    text, names = random_paf(131, 400, n_seq=6, seq_len=20000, weird=True, self_aln=True)
+    g, c = both(tmp_path, text)
+    g.set_option("locality_min", 1)
+    ranges = random_ranges(17, 80, 6, 20000, max_len=4000, min_len=50)
+    for kw in [dict(), dict(transitive=True, max_depth=3, min_transitive_len=20), dict(transitive=True, dfs=True, max_depth=2),
+               dict(min_identity=0.6), dict(transitive=True, max_depth=2, multi_impg=True)]:
+        assert_same(g, c, ranges, **kw)
+    res = g.query_batch(ranges[:30], impg_amd.make_params(store_cigar=True, transitive=True, max_depth=2))
+    for i, (t, s, e) in enumerate(ranges[:30]):
+        want, wcg = c.query_cigar(t, s, e, transitive=True, max_depth=2)
+        assert res[i].tolist() == want.tolist()
+        assert [x.tolist() for x in res.cigars(i)] == [x.tolist() for x in wcg]
+    # dense target: windows wider than 64 entries go through the wave-per-range emit pass
+    lines = []
+    for i in range(300):
+        lines.append("Q%d\t9000\t%d\t%d\t%s\tT\t9000\t%d\t%d\t10\t10\t60\tcg:Z:%d=" %
+                     (i % 11, 100 + i, 1100 + i, "+-"[i % 2], 2000 + (i * 7) % 900, 3000 + (i * 7) % 900, 1000))
+    g, c = both(tmp_path, "\n".join(lines) + "\n")
+    g.set_option("locality_min", 1)
+    t = g.seq_id("T")
+    dense = [(t, 2500, 2600), (t, 2000, 4000), (t, 2890, 2910), (g.seq_id("Q3"), 0, 2000)]
+    for kw in [dict(), dict(transitive=True, max_depth=2, min_transitive_len=10)]:
+        assert_same(g, c, dense, **kw)

@@ -457,7 +457,8 @@ int impg_gpu_stage_count(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fron
   E.wide_n.reserve(256);
   E.wide_list.reserve(std::max<size_t>(n * 4, 256));
   E.cnt.reserve(std::max<size_t>(n * 4, 256));  // kept for the projection order of stage_project
-  launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.cnt.as<uint32_t>(), E.win.as<uint4>(),
+  E.stage_perm = E.lookup_order(ix->view, d_frontier, (uint32_t)n);  // kept for stage_project
+  launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_perm, E.cnt.as<uint32_t>(), E.win.as<uint4>(),
                       E.wide_n.as<uint32_t>(), E.wide_list.as<uint32_t>(), E.stream);
   if (n) IMPG_HIP(hipMemcpyAsync(d_counts, E.cnt.p, n * 4, hipMemcpyDeviceToDevice, E.stream));
   *total = E.scan(E.cnt.as<uint32_t>(), E.stage_off.as<uint32_t>(), (uint32_t)n);
@@ -492,10 +493,10 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   hipEvent_t e0 = E.event(), e1 = E.event(), e2 = E.event();
   IMPG_HIP(hipEventRecord(e0, E.stream));
   const uint32_t *d_offp = nullptr, *d_slot_of = nullptr;
-  E.projection_order(ix->view, (uint32_t)n, E.cnt.as<uint32_t>(), total, d_offp, d_slot_of);
+  E.projection_offsets(E.stage_perm, (uint32_t)n, E.cnt.as<uint32_t>(), total, d_offp, d_slot_of);
   launch_lookup_emit(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_off.as<uint32_t>(), E.win.as<uint4>(),
-                     L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), d_offp, const_cast<uint32_t *>(d_slot_of),
-                     E.wide_n.as<uint32_t>(), E.wide_list.as<uint32_t>(), E.stream);
+                     L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), d_slot_of ? E.stage_perm : nullptr, d_offp,
+                     const_cast<uint32_t *>(d_slot_of), E.wide_n.as<uint32_t>(), E.wide_list.as<uint32_t>(), E.stream);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
                  E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), params->min_identity, nullptr,

@@ -75,30 +75,35 @@ static HitArrays hit_arrays(LevelBufs &L, uint32_t n_pairs) {
   return HitArrays{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
 }
 
-// Projection order: the slots stay in the reference's order, but the projection
-// kernel walks them range by range in the order of the ranges' windows in the
-// entry array, so that lanes and workgroups in flight together gather
-// neighbouring entries and CIGAR tiles (L2 hits instead of HBM lines).  Needs
-// win[] (count pass) and the per-range counts; leaves offp[r] (first position of
-// range r in that order) and room for slot_of[P], or nulls when not worth it.
-void Engine::projection_order(const DeviceIndexView &v, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
-                              const uint32_t *&d_slot_of) {
-  d_offp = d_slot_of = nullptr;
-  if (!locality_min || n_fr < locality_min || !P) return;
+// Lookup / projection order: the slots stay in the reference's order, but the count,
+// emit and projection kernels take the ranges in the order of their (estimated)
+// windows in the entry array, so that lanes and workgroups in flight together
+// search the same blocks and gather neighbouring entries and CIGAR tiles (L1/L2
+// hits instead of HBM lines).  Returns the permutation, or null when not worth it.
+const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr) {
+  if (!locality_min || n_fr < locality_min) return nullptr;
   const size_t nb = (size_t)n_fr * 4;
-  lo_key.reserve(nb); lo_key2.reserve(nb); lo_idx.reserve(nb); lo_perm.reserve(nb); lo_cnt.reserve(nb); lo_off.reserve(nb);
-  lo_offp.reserve(nb);
-  slot_of.reserve(std::max<size_t>(P * 4, 256));
-  launch_window_keys(win.as<uint4>(), n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream);
+  lo_key.reserve(nb); lo_key2.reserve(nb); lo_idx.reserve(nb); lo_perm.reserve(nb);
+  launch_order_keys(v, fr, n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream);
   const size_t tb = sort_u32_scratch_bytes(n_fr);
   sort_tmp.reserve(tb);
   // 16-entry granularity is plenty; keys are positions in the entry array
   const unsigned hi_bit = std::max(5u, bits_for((uint32_t)std::min<size_t>(v.n_entries, 0xFFFFFFFFull)));
   launch_sort_u32(sort_tmp.p, tb, lo_key.as<uint32_t>(), lo_key2.as<uint32_t>(), lo_idx.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr,
                   stream, 4, hi_bit);
-  launch_gather_u32(d_cnt, lo_perm.as<uint32_t>(), n_fr, lo_cnt.as<uint32_t>(), stream);
+  return lo_perm.as<uint32_t>();
+}
+// After the count pass: offp[r] = first place of range r's pairs in that order, and room for slot_of[P].
+void Engine::projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
+                                const uint32_t *&d_slot_of) {
+  d_offp = d_slot_of = nullptr;
+  if (!d_perm || !P) return;
+  const size_t nb = (size_t)n_fr * 4;
+  lo_cnt.reserve(nb); lo_off.reserve(nb); lo_offp.reserve(nb);
+  slot_of.reserve(std::max<size_t>(P * 4, 256));
+  launch_gather_u32(d_cnt, d_perm, n_fr, lo_cnt.as<uint32_t>(), stream);
   scan(lo_cnt.as<uint32_t>(), lo_off.as<uint32_t>(), n_fr);
-  launch_scatter_u32(lo_off.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr, lo_offp.as<uint32_t>(), stream);
+  launch_scatter_u32(lo_off.as<uint32_t>(), d_perm, n_fr, lo_offp.as<uint32_t>(), stream);
   d_slot_of = slot_of.as<uint32_t>();
   d_offp = lo_offp.as<uint32_t>();
 }
@@ -115,7 +120,9 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   if (multi) transitive = false;
   wide_n.reserve(256);
   wide_list.reserve(std::max<size_t>((size_t)n_fr * 4, 256));
-  launch_lookup_count(v, fr, n_fr, transitive, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
+  const uint32_t *d_perm = lookup_order(v, fr, n_fr);
+  launch_lookup_count(v, fr, n_fr, transitive, d_perm, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(),
+                      wide_list.as<uint32_t>(), stream);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);
   if (P > pair_budget || P >= 0xFFFFFFF0ull) {
     if (split_ok) throw SplitBatch{};
@@ -125,10 +132,10 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
   const uint32_t *d_slot_of = nullptr, *d_offp = nullptr;
-  projection_order(v, n_fr, cnt.as<uint32_t>(), P, d_offp, d_slot_of);
+  projection_offsets(d_perm, n_fr, cnt.as<uint32_t>(), P, d_offp, d_slot_of);
   launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
-                     pair_entry.as<uint32_t>(), d_offp, const_cast<uint32_t *>(d_slot_of), wide_n.as<uint32_t>(),
-                     wide_list.as<uint32_t>(), stream);
+                     pair_entry.as<uint32_t>(), d_slot_of ? d_perm : nullptr, d_offp, const_cast<uint32_t *>(d_slot_of),
+                     wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
   IMPG_HIP(hipEventRecord(e1, stream));
   HitArrays h = hit_arrays(L, L.n_pairs);
   SliceArrays sl{nullptr, nullptr, nullptr, nullptr};

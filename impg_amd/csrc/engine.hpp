@@ -50,6 +50,7 @@ struct Engine {
   DevBuf wide_n, wide_list;  // ranges whose window is wider than the lane-per-range emit pass takes
   DevBuf lo_key, lo_key2, lo_idx, lo_perm, lo_cnt, lo_off, lo_offp, slot_of;
   uint32_t locality_min = 4096;  // frontier ranges below which the reordering is not worth its launches (0 = never reorder)
+  const uint32_t *stage_perm = nullptr;  // lookup order of the last stage_count call
   uint32_t stage_n = 0;  // frontier size of the last stage_count call
 
   explicit Engine(int device);
@@ -57,8 +58,11 @@ struct Engine {
   hipEvent_t event();
   uint64_t read_counter(int k);
   uint64_t scan(const uint32_t *in, uint32_t *out, uint32_t n);
-  void projection_order(const DeviceIndexView &v, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
-                        const uint32_t *&d_slot_of);
+  // lookup / projection order (locality): lookup_order() before the count pass gives the permutation (null
+  // when not worth it); projection_offsets() after the scan gives every range's first place in slot_of
+  const uint32_t *lookup_order(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr);
+  void projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
+                          const uint32_t *&d_slot_of);
   uint64_t expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
                   impg_gpu_stats_t *st);
   uint32_t update(const DeviceIndexView &v, const FrontierRec *fr, LevelBufs &L, uint32_t n_queries,

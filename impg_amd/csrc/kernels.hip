@@ -82,11 +82,15 @@ __device__ __forceinline__ void dual_search4(const int32_t *__restrict__ S, uint
 
 template <bool TRANSITIVE>
 __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
-                                                                uint32_t n, uint32_t *__restrict__ cnt,
+                                                                uint32_t n, const uint32_t *__restrict__ perm,
+                                                                uint32_t *__restrict__ cnt,
                                                                 uint4 *__restrict__ win, uint32_t *__restrict__ wide_n,
                                                                 uint32_t *__restrict__ wide_list) {
-  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-  if (r >= n) return;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  // perm (optional): neighbouring lanes take ranges that are neighbours in the entry array, so
+  // their searches and windows share cache lines; results still land at the range's own index
+  const uint32_t r = perm ? perm[i] : i;
   const FrontierRec f = fr[r];
   uint32_t a = 0, sn = 0, off0 = 0, cnt0 = 0;
   if (f.target_id < v.n_seq) {
@@ -303,12 +307,23 @@ __global__ __launch_bounds__(256) void route_gather_kernel(const FrontierRec *__
   out[i] = f;
 }
 
-// projection order: ranges sorted by the position of their window in the entry array
-__global__ __launch_bounds__(256) void window_keys_kernel(const uint4 *__restrict__ win, uint32_t n, uint32_t *__restrict__ key,
-                                                          uint32_t *__restrict__ idx) {
+// Lookup / projection order: ranges sorted by where their window will be in the entry array,
+// estimated before any search from the record alone: segment start + start / sequence length x
+// segment size (alignments spread evenly enough for a LOCALITY key; exactness is not needed).
+__global__ __launch_bounds__(256) void order_keys_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr, uint32_t n,
+                                                         uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   if (r >= n) return;
-  key[r] = win[r].x;
+  const FrontierRec f = fr[r];
+  uint32_t k = 0;
+  if (f.target_id < v.n_seq) {
+    const uint2 d = *reinterpret_cast<const uint2 *>(v.seg + f.target_id);  // {a, n}
+    const int32_t len = v.seq_len[f.target_id];
+    const uint64_t st = (uint64_t)(uint32_t)max(f.start, 0);
+    const uint64_t rel = len > 0 ? st * d.y / (uint64_t)(uint32_t)len : 0ull;
+    k = d.x + (uint32_t)min(rel, (uint64_t)(d.y ? d.y - 1u : 0u));
+  }
+  key[r] = k;
   idx[r] = r;
 }
 __global__ __launch_bounds__(256) void scatter_u32_kernel(const uint32_t *__restrict__ in, const uint32_t *__restrict__ perm,
@@ -333,14 +348,17 @@ __global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v,
                                                               const uint4 *__restrict__ win,
                                                               uint32_t *__restrict__ pair_range,
                                                               uint32_t *__restrict__ pair_entry,
+                                                              const uint32_t *__restrict__ perm,
                                                               const uint32_t *__restrict__ offp,
                                                               uint32_t *__restrict__ slot_of) {
   __shared__ uint16_t stage[EMIT_LDS_SLOTS];
   const unsigned lane = threadIdx.x;
-  const uint32_t r0 = blockIdx.x * 64u, r = r0 + lane;
-  uint32_t lo = 0, ub = 0, off = 0, po = 0;
+  const uint32_t i = blockIdx.x * 64u + lane;
+  uint32_t r = 0, lo = 0, ub = 0, off = 0, po = 0;
   unsigned long long mask = 0;
-  if (r < n) {
+  if (i < n) {
+    r = perm ? perm[i] : i;  // (with the lookup order a wave's 64 ranges are neighbours in the entry array
+                             //  and in slot_of, where offp[] are then consecutive)
     const uint4 w = win[r];
     lo = w.x; ub = w.y;
     mask = ((unsigned long long)w.w << 32) | w.z;
@@ -402,9 +420,10 @@ __global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v,
     const uint32_t sv = live ? stage[t] : 0u, ln = sv >> 6, rel = sv & 63u;
     const uint32_t lb = (uint32_t)__shfl((int)b, (int)ln), lof = (uint32_t)__shfl((int)off, (int)ln);
     const uint32_t llo = (uint32_t)__shfl((int)loff, (int)ln), lpo = (uint32_t)__shfl((int)po, (int)ln);
+    const uint32_t lr = (uint32_t)__shfl((int)r, (int)ln);
     if (live) {
       const uint32_t slot = lof + (t - llo);
-      pair_range[slot] = r0 + ln;
+      pair_range[slot] = lr;
       pair_entry[slot] = lb + rel;
       if (slot_of) slot_of[lpo + (t - llo)] = slot;
     }
@@ -1644,25 +1663,25 @@ static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 wa
   return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 }
 
-void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, uint32_t *cnt,
-                         uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s) {
+void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
+                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s) {
   if (!n) return;
   const bool lanes = emit_by_lanes(v);
   if (lanes) IMPG_HIP(hipMemsetAsync(wide_n, 0, 4, s));
-  if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, cnt, win, wide_n, lanes ? wide_list : nullptr);
-  else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, cnt, win, wide_n, lanes ? wide_list : nullptr);
+  if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr);
+  else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr);
 }
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
-                        const uint32_t *offp, uint32_t *slot_of, const uint32_t *wide_n, const uint32_t *wide_list,
-                        hipStream_t s) {
+                        const uint32_t *perm, const uint32_t *offp, uint32_t *slot_of, const uint32_t *wide_n,
+                        const uint32_t *wide_list, hipStream_t s) {
   if (!n) return;
   // windows of <= 64 entries: lane per range; the rest (dense targets), or everything if a rank could
   // overflow the packed sort key: wave per range
   const bool lanes = emit_by_lanes(v);
   if (lanes) {
-    if (transitive) lookup_emit_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, offp, slot_of);
-    else lookup_emit_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, offp, slot_of);
+    if (transitive) lookup_emit_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, slot_of);
+    else lookup_emit_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, slot_of);
   }
   // the listed wide windows only (a small grid: the list is normally short or empty), or everything
   const uint32_t g = lanes ? std::min(wave_grid(n), 256u) : wave_grid(n);
@@ -1677,8 +1696,8 @@ void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, uint32
 void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s) {
   if (n) route_gather_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, perm, n, out);
 }
-void launch_window_keys(const uint4 *win, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s) {
-  if (n) window_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(win, n, key, idx);
+void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s) {
+  if (n) order_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, key, idx);
 }
 void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, uint32_t *out, hipStream_t s) {
   if (n) scatter_u32_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, perm, n, out);

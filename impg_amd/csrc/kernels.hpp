@@ -40,17 +40,17 @@ struct VisitedTables {
   uint32_t n_tables;
 };
 
-void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, uint32_t *cnt,
-                         uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s);
+void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
+                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s);
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
-                        const uint32_t *offp, uint32_t *slot_of, const uint32_t *wide_n, const uint32_t *wide_list,
-                        hipStream_t s);
+                        const uint32_t *perm, const uint32_t *offp, uint32_t *slot_of, const uint32_t *wide_n,
+                        const uint32_t *wide_list, hipStream_t s);
 constexpr uint32_t ROUTE_WORLD_MAX = 1024;
 void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, uint32_t *key, uint32_t *idx, unsigned long long *hist,
                        hipStream_t s);
 void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s);
-void launch_window_keys(const uint4 *win, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s);
+void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s);
 void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, uint32_t *out, hipStream_t s);
 void launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, unsigned long long *d_bsum,
                            unsigned long long *d_total, hipStream_t s);

@@ -87,10 +87,10 @@ const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec
   launch_order_keys(v, fr, n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream);
   const size_t tb = sort_u32_scratch_bytes(n_fr);
   sort_tmp.reserve(tb);
-  // 16-entry granularity is plenty; keys are positions in the entry array
-  const unsigned hi_bit = std::max(5u, bits_for((uint32_t)std::min<size_t>(v.n_entries, 0xFFFFFFFFull)));
+  // keys are positions in the entry array: only the bits below n_entries are sorted
+  const unsigned hi_bit = std::max(1u, bits_for((uint32_t)std::min<size_t>(v.n_entries, 0xFFFFFFFFull)));
   launch_sort_u32(sort_tmp.p, tb, lo_key.as<uint32_t>(), lo_key2.as<uint32_t>(), lo_idx.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr,
-                  stream, 4, hi_bit);
+                  stream, 0, hi_bit);
   return lo_perm.as<uint32_t>();
 }
 // After the count pass: offp[r] = first place of range r's pairs in that order, and room for slot_of[P].

@@ -492,15 +492,16 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   E.ev_next = 0;
   hipEvent_t e0 = E.event(), e1 = E.event(), e2 = E.event();
   IMPG_HIP(hipEventRecord(e0, E.stream));
-  const uint32_t *d_offp = nullptr, *d_slot_of = nullptr;
-  E.projection_offsets(E.stage_perm, (uint32_t)n, E.cnt.as<uint32_t>(), total, d_offp, d_slot_of);
+  const uint32_t *d_offp = nullptr;
+  ProjList pl;
+  E.projection_offsets(E.stage_perm, (uint32_t)n, E.cnt.as<uint32_t>(), total, d_offp, pl);
   launch_lookup_emit(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_off.as<uint32_t>(), E.win.as<uint4>(),
-                     L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), d_slot_of ? E.stage_perm : nullptr, d_offp,
-                     const_cast<uint32_t *>(d_slot_of), E.wide_n.as<uint32_t>(), E.wide_list.as<uint32_t>(), E.stream);
+                     L.pair_range.as<uint32_t>(), pl.slot ? nullptr : E.pair_entry.as<uint32_t>(), pl.slot ? E.stage_perm : nullptr,
+                     d_offp, pl, E.wide_n.as<uint32_t>(), E.wide_list.as<uint32_t>(), E.stream);
   IMPG_HIP(hipEventRecord(e1, E.stream));
   launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
                  E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), params->min_identity, nullptr,
-                 d_slot_of, E.stream);
+                 pl, E.stream);
   IMPG_HIP(hipEventRecord(e2, E.stream));
   if (d_hits) launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
   IMPG_HIP(hipStreamSynchronize(E.stream));

@@ -95,16 +95,18 @@ const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec
 }
 // After the count pass: offp[r] = first place of range r's pairs in that order, and room for slot_of[P].
 void Engine::projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
-                                const uint32_t *&d_slot_of) {
-  d_offp = d_slot_of = nullptr;
+                                ProjList &pl) {
+  d_offp = nullptr;
+  pl = ProjList{nullptr, nullptr, nullptr};
   if (!d_perm || !P) return;
   const size_t nb = (size_t)n_fr * 4;
   lo_cnt.reserve(nb); lo_off.reserve(nb); lo_offp.reserve(nb);
-  slot_of.reserve(std::max<size_t>(P * 4, 256));
+  const size_t pb = std::max<size_t>(P * 4, 256);
+  slot_of.reserve(pb); proj_range.reserve(pb); proj_entry.reserve(pb);
   launch_gather_u32(d_cnt, d_perm, n_fr, lo_cnt.as<uint32_t>(), stream);
   scan(lo_cnt.as<uint32_t>(), lo_off.as<uint32_t>(), n_fr);
   launch_scatter_u32(lo_off.as<uint32_t>(), d_perm, n_fr, lo_offp.as<uint32_t>(), stream);
-  d_slot_of = slot_of.as<uint32_t>();
+  pl = ProjList{slot_of.as<uint32_t>(), proj_range.as<uint32_t>(), proj_entry.as<uint32_t>()};
   d_offp = lo_offp.as<uint32_t>();
 }
 
@@ -131,10 +133,13 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   L.n_pairs = (uint32_t)P;
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
-  const uint32_t *d_slot_of = nullptr, *d_offp = nullptr;
-  projection_offsets(d_perm, n_fr, cnt.as<uint32_t>(), P, d_offp, d_slot_of);
+  const uint32_t *d_offp = nullptr;
+  ProjList pl;
+  projection_offsets(d_perm, n_fr, cnt.as<uint32_t>(), P, d_offp, pl);
+  // the slot-order entry list is only read by the slice materialisation and the five-key sort
+  const bool entry_slots = store_cigar || multi || !pl.slot;
   launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
-                     pair_entry.as<uint32_t>(), d_slot_of ? d_perm : nullptr, d_offp, const_cast<uint32_t *>(d_slot_of),
+                     entry_slots ? pair_entry.as<uint32_t>() : nullptr, pl.slot ? d_perm : nullptr, d_offp, pl,
                      wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
   IMPG_HIP(hipEventRecord(e1, stream));
   HitArrays h = hit_arrays(L, L.n_pairs);
@@ -146,7 +151,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   }
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
                  acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity,
-                 store_cigar ? &sl : nullptr, d_slot_of, stream);
+                 store_cigar ? &sl : nullptr, pl, stream);
   if (multi && L.n_pairs) {
     // sort every range's hits by (query_id, q.first, q.last, t.first, t.last) (multi_impg.rs:582-592)
     const size_t b = std::max<size_t>((size_t)L.n_pairs * 4, 256);

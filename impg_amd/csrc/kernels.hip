@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
                                                           uint32_t *__restrict__ pair_range,
                                                           uint32_t *__restrict__ pair_entry,
                                                           const uint32_t *__restrict__ offp,
-                                                          uint32_t *__restrict__ slot_of,
+                                                          ProjList pl,
                                                           const uint32_t *__restrict__ list,
                                                           const uint32_t *__restrict__ list_n) {
   // list (optional): process only these ranges -- the ones whose window is wider than
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
   const uint32_t nwaves = (gridDim.x * 256u) >> 6;
   const unsigned lane = lane_id();
   const int32_t *ecol = end_col<TRANSITIVE>(v);
-  // slot_of (optional): the same slots listed in PROJECTION order -- ranges sorted by
+  uint32_t *const slot_of = pl.slot;
+  // pl (optional): the same pairs listed in PROJECTION order -- ranges sorted by
   // their window position in the entry array -- so that neighbouring lanes of the
   // projection kernel gather neighbouring entries and tiles (offp[r] = first
   // position of range r in that order).  Slot order itself never changes.
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
           const uint32_t k = __popcll(m0 & lanemask_lt());
           const uint32_t pos = off_r + k;
           pair_range[pos] = r;
-          pair_entry[pos] = lo + lane;
-          if (slot_of) slot_of[po_r + k] = pos;
+          if (pair_entry) pair_entry[pos] = lo + lane;
+          if (slot_of) { slot_of[po_r + k] = pos; pl.range[po_r + k] = r; pl.entry[po_r + k] = lo + lane; }
         }
         continue;
       }
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
       }
       if (lane < (unsigned)__popcll(m0)) {  // lane i now holds the i-th hit in visit order: coalesced stores
         pair_range[off_r + lane] = r;
-        pair_entry[off_r + lane] = lo + who;
-        if (slot_of) slot_of[po_r + lane] = off_r + lane;
+        if (pair_entry) pair_entry[off_r + lane] = lo + who;
+        if (slot_of) { slot_of[po_r + lane] = off_r + lane; pl.range[po_r + lane] = r; pl.entry[po_r + lane] = lo + who; }
       }
       continue;
     }
@@ -238,8 +239,8 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
           uint32_t k = run + __popcll(m & lanemask_lt());
           uint32_t pos = off + k;
           pair_range[pos] = r;
-          pair_entry[pos] = i;
-          if (slot_of) slot_of[po_r + k] = pos;
+          if (pair_entry) pair_entry[pos] = i;
+          if (slot_of) { slot_of[po_r + k] = pos; pl.range[po_r + k] = r; pl.entry[po_r + k] = i; }
         }
         run += __popcll(m);
       }
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
       }
       if (hit) {
         pair_range[off + pos] = r;
-        pair_entry[off + pos] = i;
-        if (slot_of) slot_of[po_r + pos] = off + pos;
+        if (pair_entry) pair_entry[off + pos] = i;
+        if (slot_of) { slot_of[po_r + pos] = off + pos; pl.range[po_r + pos] = r; pl.entry[po_r + pos] = i; }
       }
     }
   }
@@ -350,7 +351,8 @@ __global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v,
                                                               uint32_t *__restrict__ pair_entry,
                                                               const uint32_t *__restrict__ perm,
                                                               const uint32_t *__restrict__ offp,
-                                                              uint32_t *__restrict__ slot_of) {
+                                                              ProjList pl) {
+  uint32_t *const slot_of = pl.slot;
   __shared__ uint16_t stage[EMIT_LDS_SLOTS];
   const unsigned lane = threadIdx.x;
   const uint32_t i = blockIdx.x * 64u + lane;
@@ -424,8 +426,13 @@ __global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v,
     if (live) {
       const uint32_t slot = lof + (t - llo);
       pair_range[slot] = lr;
-      pair_entry[slot] = lb + rel;
-      if (slot_of) slot_of[lpo + (t - llo)] = slot;
+      if (pair_entry) pair_entry[slot] = lb + rel;
+      if (slot_of) {  // (consecutive t are consecutive places when the lanes follow the lookup order: coalesced)
+        const uint32_t place = lpo + (t - llo);
+        slot_of[place] = slot;
+        pl.range[place] = lr;
+        pl.entry[place] = lb + rel;
+      }
     }
   }
 }
@@ -781,7 +788,7 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
                                                       const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
                                                       uint32_t *__restrict__ err_flag, double min_identity,
-                                                      SliceArrays sl, const uint32_t *__restrict__ slot_of, int xcd_map) {
+                                                      SliceArrays sl, ProjList pl, int xcd_map) {
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   constexpr bool CIGAR = (MODE & MODE_CIGAR) != 0;
   // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give
@@ -796,11 +803,12 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
   res.pqs = res.pts = res.pqe = res.pte = -1;
   uint32_t qid = HIT_NONE;
   if (pp < n_pairs) {
-    const uint32_t p = slot_of ? slot_of[pp] : pp;
-    const uint32_t r = pair_range[p];
+    const uint32_t p = pl.slot ? pl.slot[pp] : pp;
+    // (in projection order the pair's range and entry are listed next to its slot: three coalesced reads)
+    const uint32_t r = pl.slot ? pl.range[pp] : pair_range[p];
     const FrontierRec f = fr[r];
     // the 64-byte entry: coordinates, record totals and its inline checkpoints
-    const uint4 *ep = reinterpret_cast<const uint4 *>(v.entries + pair_entry[p]);
+    const uint4 *ep = reinterpret_cast<const uint4 *>(v.entries + (pl.slot ? pl.entry[pp] : pair_entry[p]));
     const uint4 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
     const int32_t en_ts = (int32_t)e0.x, en_te = (int32_t)e0.y, en_qs = (int32_t)e0.z, en_qe = (int32_t)e0.w;
     const uint32_t nops_flags = e1.z;
@@ -1673,21 +1681,21 @@ void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32
 }
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
-                        const uint32_t *perm, const uint32_t *offp, uint32_t *slot_of, const uint32_t *wide_n,
+                        const uint32_t *perm, const uint32_t *offp, ProjList pl, const uint32_t *wide_n,
                         const uint32_t *wide_list, hipStream_t s) {
   if (!n) return;
   // windows of <= 64 entries: lane per range; the rest (dense targets), or everything if a rank could
   // overflow the packed sort key: wave per range
   const bool lanes = emit_by_lanes(v);
   if (lanes) {
-    if (transitive) lookup_emit_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, slot_of);
-    else lookup_emit_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, slot_of);
+    if (transitive) lookup_emit_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, pl);
+    else lookup_emit_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, pl);
   }
   // the listed wide windows only (a small grid: the list is normally short or empty), or everything
   const uint32_t g = lanes ? std::min(wave_grid(n), 256u) : wave_grid(n);
   const uint32_t *ln = lanes ? wide_n : nullptr, *ll = lanes ? wide_list : nullptr;
-  if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, slot_of, ll, ln);
-  else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, slot_of, ll, ln);
+  if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln);
+  else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln);
 }
 void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, uint32_t *key, uint32_t *idx, unsigned long long *hist,
                        hipStream_t s) {
@@ -1705,14 +1713,14 @@ void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, ui
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
-                    const uint32_t *slot_of, hipStream_t s) {
+                    ProjList pl, hipStream_t s) {
   if (!n_pairs) return;
   const bool ident = min_identity == min_identity;  // NaN = no filter
   const uint32_t g = (cdiv(n_pairs, 256) + 7u) & ~7u;  // a multiple of the 8 XCDs (see the block mapping in the kernel)
   const int xcd_map = 1;
   const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};
   const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0);
-#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, slot_of, xcd_map)
+#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map)
   if (transitive) {
     switch (mode) { case 0: IMPG_LAUNCH(true, 0); break; case 1: IMPG_LAUNCH(true, 1); break;
                     case 2: IMPG_LAUNCH(true, 2); break; default: IMPG_LAUNCH(true, 3); }

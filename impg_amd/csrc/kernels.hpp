@@ -42,9 +42,14 @@ struct VisitedTables {
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
                          uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s);
+// The pairs listed in projection order (optional: slot == nullptr means the projection runs in slot order):
+// place -> the pair's slot, its frontier range and its entry.
+struct ProjList {
+  uint32_t *slot, *range, *entry;
+};
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
-                        const uint32_t *perm, const uint32_t *offp, uint32_t *slot_of, const uint32_t *wide_n,
+                        const uint32_t *perm, const uint32_t *offp, ProjList pl, const uint32_t *wide_n,
                         const uint32_t *wide_list, hipStream_t s);
 constexpr uint32_t ROUTE_WORLD_MAX = 1024;
 void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, uint32_t *key, uint32_t *idx, unsigned long long *hist,
@@ -58,7 +63,7 @@ size_t scan_scratch_bytes(uint32_t n);
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
-                    const uint32_t *slot_of, hipStream_t s);
+                    ProjList pl, hipStream_t s);
 void launch_slice_counts(HitArrays h, SliceArrays sl, uint32_t n_pairs, uint32_t *cnt, hipStream_t s);
 void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, HitArrays h, SliceArrays sl, uint32_t n_pairs,
                         const uint32_t *off, uint32_t *out, hipStream_t s);

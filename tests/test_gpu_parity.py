@@ -497,3 +497,16 @@ def test_projection_order_is_invisible(tmp_path):
     dense = [(t, 2500, 2600), (t, 2000, 4000), (t, 2890, 2910), (g.seq_id("Q3"), 0, 2000)]
     for kw in [dict(), dict(transitive=True, max_depth=2, min_transitive_len=10)]:
         assert_same(g, c, dense, **kw)
+
+
+def test_many_small_targets(tmp_path):
+    """Hundreds of sequences with a handful of alignments each (tiny segments, most without a sampled level,
+    some empty), lookup order on: key arithmetic, segment tables and the (query, sequence) keys at another scale."""
+    text, names = random_paf(151, 1500, n_seq=400, seq_len=3000, self_aln=True)
+    g, c = both(tmp_path, text)
+    g.set_option("locality_min", 1)
+    ranges = random_ranges(23, 300, g.num_seqs(), 3000, max_len=1500, min_len=30)
+    for kw in [dict(), dict(transitive=True, max_depth=3, min_transitive_len=10, min_distance_between_ranges=0),
+               dict(transitive=True, dfs=True, max_depth=2, min_transitive_len=10),
+               dict(transitive=True, max_depth=0, min_transitive_len=400)]:
+        assert_same(g, c, ranges, **kw)

@@ -582,7 +582,10 @@ struct PairCtx {
 //   arm 2 (query_delta == 0):   passes iff max(T,R0) < min(T+td,last_tp);    first (Q, os)      last (Q, oe)
 //   arm 3:                      passes iff max(T,R0) < min(T+td,R1);         first (Q+os-T, os) last (Q+oe-T, oe)
 // When arm 1 passes, os == T and min(T, lim) == T, so os / oe serve all arms.
-template <int MODE>
+// PART: 0 = record both ends; 1 = only look for the FIRST overlapping op (walk A of the plain projection);
+// 2 = only keep the LAST one (walk B).  A walk that needs one end skips a fifth of the arithmetic.
+constexpr int PART_BOTH = 0, PART_FIRST = 1, PART_LAST = 2;
+template <int MODE, int PART = PART_BOTH>
 __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &T, int32_t &Qn, TileScan &s, IdentScan &id,
                                         uint32_t oi = 0) {
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
@@ -597,10 +600,10 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
   const int32_t os = max(T, c.R0);
   const int32_t e = T + td;
   const int32_t oe = min(e, lim);
-  const bool pass = valid && T <= c.last_tp && (arm1 ? T >= c.R0 : os < oe);
-  const int32_t fq = Qn + (qzero ? 0 : os - T);
-  const int32_t lq = Qn + ((arm1 || qzero) ? qa : oe - T);
-  const bool first = pass && !s.found;
+  // (bitwise on purpose: with && / ?: the compiler branches around each comparison -- three
+  //  exec-mask save/restore sequences per op; both comparisons are cheaper than one branch)
+  const bool pass = valid & (T <= c.last_tp) & ((arm1 & (T >= c.R0)) | (!arm1 & (os < oe)));
+  const bool first = PART != PART_LAST && (pass & !s.found);
   if (IDENT) {
     const bool is_m = valid && (code == 0u || code == 4u), is_x = valid && code == 1u;
     const bool is_g = valid && (code == 2u || code == 3u);
@@ -630,12 +633,18 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
       if (!arm1) id.last_rem = oe - e;   // an insertion leaves the previous value in place (impg.rs:2807-2821)
     }
   }
-  s.pqs = first ? fq : s.pqs;
-  s.pts = first ? os : s.pts;
-  s.pqe = pass ? lq : s.pqe;
-  s.pte = pass ? oe : s.pte;
-  s.found = s.found || pass;
-  s.any = s.any || pass;
+  if (PART != PART_LAST) {
+    const int32_t fq = Qn + (qzero ? 0 : os - T);
+    s.pqs = first ? fq : s.pqs;
+    s.pts = first ? os : s.pts;
+    s.found = s.found | pass;
+  }
+  if (PART != PART_FIRST) {
+    const int32_t lq = Qn + ((arm1 || qzero) ? qa : oe - T);
+    s.pqe = pass ? lq : s.pqe;
+    s.pte = pass ? oe : s.pte;
+    s.any = s.any | pass;
+  }
   T = e;
   Qn += qa;
 }
@@ -707,7 +716,7 @@ __device__ __forceinline__ uint32_t tile_subs(uint32_t n_ops, uint32_t j) { retu
 // first vector with two header words and sub-tile 3 has a single vector: those
 // slots are padding).  Reverse-strand reversed entries walk back to front.  The
 // cursor's sums end up at the sub-tile's far end, which is where the next one starts.
-template <int MODE>
+template <int MODE, int PART = PART_BOTH>
 __device__ __forceinline__ void scan_cur(const PairCtx &c, Cursor &cur, TileScan &s, IdentScan &id) {
   const uint32_t h = orig_sub(c, cur.he);
   const uint4 *q = reinterpret_cast<const uint4 *>(c.ops + (size_t)orig_tile(c, cur.k) * TILE_WORDS);
@@ -717,14 +726,14 @@ __device__ __forceinline__ void scan_cur(const PairCtx &c, Cursor &cur, TileScan
   if (h != 3u) b = q[v0 + 1u];
   if (h == 0u) a.x = a.y = OP_PAD;  // words 4, 5 are header
   const uint4 f = c.flip ? b : a, g = c.flip ? a : b;
-  op_step<MODE>(c.flip ? f.w : f.x, c, cur.T, cur.Qn, s, id);
-  op_step<MODE>(c.flip ? f.z : f.y, c, cur.T, cur.Qn, s, id);
-  op_step<MODE>(c.flip ? f.y : f.z, c, cur.T, cur.Qn, s, id);
-  op_step<MODE>(c.flip ? f.x : f.w, c, cur.T, cur.Qn, s, id);
-  op_step<MODE>(c.flip ? g.w : g.x, c, cur.T, cur.Qn, s, id);
-  op_step<MODE>(c.flip ? g.z : g.y, c, cur.T, cur.Qn, s, id);
-  op_step<MODE>(c.flip ? g.y : g.z, c, cur.T, cur.Qn, s, id);
-  op_step<MODE>(c.flip ? g.x : g.w, c, cur.T, cur.Qn, s, id);
+  op_step<MODE, PART>(c.flip ? f.w : f.x, c, cur.T, cur.Qn, s, id);
+  op_step<MODE, PART>(c.flip ? f.z : f.y, c, cur.T, cur.Qn, s, id);
+  op_step<MODE, PART>(c.flip ? f.y : f.z, c, cur.T, cur.Qn, s, id);
+  op_step<MODE, PART>(c.flip ? f.x : f.w, c, cur.T, cur.Qn, s, id);
+  op_step<MODE, PART>(c.flip ? g.w : g.x, c, cur.T, cur.Qn, s, id);
+  op_step<MODE, PART>(c.flip ? g.z : g.y, c, cur.T, cur.Qn, s, id);
+  op_step<MODE, PART>(c.flip ? g.y : g.z, c, cur.T, cur.Qn, s, id);
+  op_step<MODE, PART>(c.flip ? g.x : g.w, c, cur.T, cur.Qn, s, id);
 }
 // next sub-tile that holds ops, in walking order; false at the end of the record
 __device__ __forceinline__ bool advance(const PairCtx &c, uint32_t n_ops, Cursor &cur) {
@@ -891,6 +900,7 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         ident_reset(ia);
         ident_reset(ib);
         bool walked = false, joined = false, need_walk = false;
+        constexpr int PA = MODE == 0 ? PART_FIRST : PART_BOTH, PB = MODE == 0 ? PART_LAST : PART_BOTH;
         uint32_t ipa = 0, ipb = 0;  // idp[] rows the two walks count from
         if (CIGAR) {
           res = walk_tiles<MODE>(c, orig_tile(c, kA), c.flip ? 0u : c.m - 1u, ia);
@@ -918,7 +928,7 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
           place(c, n, hd, kA, he, cur);
           const uint32_t ipa0 = TILE_SUBS * (e1.y + orig_tile(c, cur.k)) + orig_sub(c, cur.he);
           for (;;) {
-            scan_cur<MODE>(c, cur, sa, ia);
+            scan_cur<MODE, PA>(c, cur, sa, ia);
             if (sa.found || cur.T > c.last_tp) break;
             if (!advance(c, n, cur)) break;
           }
@@ -945,7 +955,15 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
           if (hd.wide) he = c.flip ? TILE_SUBS - nsub : 0u;
           joined = !start_cov && (kB < cur.k || (kB == cur.k && he <= cur.he));
           bool go;
-          if (joined) {  // walk A stands in or past that sub-tile: it carries on and keeps recording
+          if (joined && MODE == 0) {
+            // walk A stands in or past that sub-tile but only looked for the first op: walk B starts over
+            // at the sub-tile walk A stopped in (whose scan it repeats, now keeping the last op)
+            const uint32_t ka = cur.k, ha = cur.he;
+            if (ka == kB) place(c, n, hd, ka, ha, cur);
+            else place(c, n, tile_header(c, orig_tile(c, ka)), ka, ha, cur);
+            go = true;
+            sa.any = false;
+          } else if (joined) {  // (identity filter) walk A carries on and keeps recording
             ib = ia;
             go = cur.T <= c.last_tp && advance(c, n, cur);
           } else {
@@ -955,11 +973,11 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
             sa.any = false;
           }
           while (go) {
-            scan_cur<MODE>(c, cur, sa, ib);
+            scan_cur<MODE, PB>(c, cur, sa, ib);
             go = cur.T <= c.last_tp && advance(c, n, cur);
           }
           if (c.flip) ipb = TILE_SUBS * (e1.y + orig_tile(c, cur.k)) + orig_sub(c, cur.he);
-          need_walk = !joined && !sa.any;  // walk B saw no overlapping op (cannot happen for a consistent CIGAR; stay exact)
+          need_walk = (MODE == 0 || !joined) && !sa.any;  // walk B saw no overlapping op (cannot happen for a consistent CIGAR; stay exact)
         }
         if (need_walk) {
           res = walk_tiles<MODE>(c, orig_tile(c, kA), c.flip ? 0u : c.m - 1u, ia);

@@ -244,7 +244,9 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
           return e.totT - line[swp ? 1 : 0];
         };
         if (m <= INLINE_TILES) {
-          for (uint32_t k = 1; k < m; k++) e.tcp[k - 1] = pre(k);
+          // P[1..m-1], then P[m] = the record total, then INT_MAX: the kernel counts "P[i] < x" over all
+          // seven slots without asking how many are real (P[8], when m = 8, is the entry's totT field)
+          for (uint32_t k = 1; k <= 7; k++) e.tcp[k - 1] = k < m ? pre(k) : k == m ? e.totT : 0x7FFFFFFFu;
         } else {
           e.tcp[0] = (uint32_t)ext_off[i];
           for (uint32_t k = 0; k <= m; k++) ext_cp[ext_off[i] + k] = pre(k);

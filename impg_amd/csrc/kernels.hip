@@ -860,13 +860,16 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
       const int32_t xa = c.R0 - c.ts, xb = c.last_tp - c.ts;
       uint32_t cA = 0, cB = 0;  // cA = #{i in [1,m] : P[i] < xa}, cB = #{i in [0,m) : P[i] < xb}
       if (c.m <= INLINE_TILES) {
-        const uint32_t P[INLINE_TILES + 1] = {0u, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w, 0u};
+        // the seven inline slots hold P[1..m-1], P[m] = totT, then INT_MAX (index_build.cpp); P[8] is totT when m = 8
+        const int32_t P[8] = {(int32_t)e2.y, (int32_t)e2.z, (int32_t)e2.w, (int32_t)e3.x, (int32_t)e3.y, (int32_t)e3.z, (int32_t)e3.w,
+                              c.m == INLINE_TILES ? (int32_t)c.totT : 0x7FFFFFFF};
+        cB = 0 < xb ? 1u : 0u;
 #pragma unroll
-        for (uint32_t i = 0; i <= INLINE_TILES; i++) {
-          const int32_t pv = (int32_t)(i == c.m ? c.totT : P[i]);
-          if (i >= 1) cA += (i <= c.m && pv < xa) ? 1u : 0u;
-          if (i < INLINE_TILES) cB += (i < c.m && pv < xb) ? 1u : 0u;
+        for (uint32_t i = 0; i < 8; i++) {
+          cA += P[i] < xa ? 1u : 0u;
+          cB += P[i] < xb ? 1u : 0u;
         }
+        cB = min(cB, c.m);  // (P[m] itself is not a tile start: only an inconsistent CIGAR has totT < xb)
       } else {
         const uint32_t *P = v.ext_cp + e2.y;  // P[0..m]
         // two binary searches side by side (their probes overlap): first i in [1,m] with P[i] >= xa,

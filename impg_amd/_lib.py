@@ -100,6 +100,8 @@ SYMBOLS = [
     ("impg_gpu_parse_target_range", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("impg_gpu_stage_count", C.c_int, [_P, _P, C.c_size_t, C.c_int, _P, C.POINTER(C.c_uint64)]),
     ("impg_gpu_stage_project", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(Params), _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("impg_gpu_stage_project16", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(Params), _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("impg_gpu_stage_update16", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_uint64)]),
     ("impg_gpu_stage_route", C.c_int, [_P, _P, C.c_size_t, C.c_uint32, _P, C.POINTER(C.c_uint64)]),
     ("impg_gpu_stage_begin", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, C.POINTER(C.c_uint64), _P]),
     ("impg_gpu_stage_update", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_uint64)]),

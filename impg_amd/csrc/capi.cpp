@@ -470,8 +470,11 @@ int impg_gpu_stage_count(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fron
   IMPG_CATCH
 }
 
-int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
-                           const impg_gpu_params_t *params, impg_gpu_hit_t *d_hits, uint64_t total, uint64_t *accepted) {
+namespace {
+// shared by impg_gpu_stage_project (32-byte hits) and impg_gpu_stage_project16 (16-byte hits)
+int stage_project_impl(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
+                       const impg_gpu_params_t *params, impg_gpu_hit_t *d_hits, impg_gpu_hit16_t *d_hits16, uint64_t total,
+                       uint64_t *accepted) {
   IMPG_TRY
   if (!ix || !params || (!d_frontier && n)) throw Error{IMPG_E_INVALID, "null argument"};  // d_hits may be null: count only
   Engine &E = *ix->engine;
@@ -504,6 +507,7 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
                  pl, E.stream);
   IMPG_HIP(hipEventRecord(e2, E.stream));
   if (d_hits) launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
+  if (d_hits16) launch_hits_to_aos16(L.pair_range.as<uint32_t>(), L.n_pairs, h, d_hits16, E.stream);
   IMPG_HIP(hipStreamSynchronize(E.stream));
   {
     float ms = 0;
@@ -518,6 +522,16 @@ int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fr
   E.stage_n = 0;
   return IMPG_OK;
   IMPG_CATCH
+}
+}  // namespace
+
+int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
+                           const impg_gpu_params_t *params, impg_gpu_hit_t *d_hits, uint64_t total, uint64_t *accepted) {
+  return stage_project_impl(ix, d_frontier, n, transitive, params, d_hits, nullptr, total, accepted);
+}
+int impg_gpu_stage_project16(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
+                             const impg_gpu_params_t *params, impg_gpu_hit16_t *d_hits, uint64_t total, uint64_t *accepted) {
+  return stage_project_impl(ix, d_frontier, n, transitive, params, nullptr, d_hits, total, accepted);
 }
 
 int impg_gpu_stage_route(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, uint32_t world,
@@ -572,10 +586,11 @@ int impg_gpu_stage_begin(impg_gpu_index_t *ix, const impg_gpu_range_t *d_ranges,
   IMPG_CATCH
 }
 
-int impg_gpu_stage_update(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
-                          const impg_gpu_hit_t *d_hits, size_t n_hits, const impg_gpu_params_t *params, uint64_t *n_next) {
+namespace {
+int stage_update_impl(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n_frontier, const impg_gpu_hit_t *d_hits,
+                      const impg_gpu_hit16_t *d_hits16, size_t n_hits, const impg_gpu_params_t *params, uint64_t *n_next) {
   IMPG_TRY
-  if (!ix || !params || !n_next || (n_hits && (!d_hits || !d_frontier))) throw Error{IMPG_E_INVALID, "null argument"};
+  if (!ix || !params || !n_next || (n_hits && ((!d_hits && !d_hits16) || !d_frontier))) throw Error{IMPG_E_INVALID, "null argument"};
   if (n_hits >= 0xFFFFFFF0ull || n_frontier >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "too many hits in one update"};
   Engine &E = *ix->engine;
   IMPG_HIP(hipSetDevice(ix->device));
@@ -585,7 +600,8 @@ int impg_gpu_stage_update(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fro
   size_t b = std::max<size_t>(n_hits * 4, 256);
   L.pair_range.reserve(b); L.qid.reserve(b); L.qs.reserve(b); L.qe.reserve(b); L.ts.reserve(b); L.te.reserve(b);
   HitArrays h{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
-  launch_aos_to_hits(d_hits, L.n_pairs, L.pair_range.as<uint32_t>(), h, E.stream);
+  if (d_hits16) launch_aos16_to_hits(d_hits16, L.n_pairs, L.pair_range.as<uint32_t>(), h, E.stream);  // (target columns unused by the update)
+  else launch_aos_to_hits(d_hits, L.n_pairs, L.pair_range.as<uint32_t>(), h, E.stream);
   E.ev_next = 0;
   E.timed.clear();
   E.stage_next_n = E.update(ix->view, d_frontier, L, std::max<uint32_t>(E.stage_queries, 1), *params, E.stage_next);
@@ -594,6 +610,16 @@ int impg_gpu_stage_update(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fro
   *n_next = E.stage_next_n;
   return IMPG_OK;
   IMPG_CATCH
+}
+}  // namespace
+
+int impg_gpu_stage_update(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
+                          const impg_gpu_hit_t *d_hits, size_t n_hits, const impg_gpu_params_t *params, uint64_t *n_next) {
+  return stage_update_impl(ix, d_frontier, n_frontier, d_hits, nullptr, n_hits, params, n_next);
+}
+int impg_gpu_stage_update16(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
+                            const impg_gpu_hit16_t *d_hits, size_t n_hits, const impg_gpu_params_t *params, uint64_t *n_next) {
+  return stage_update_impl(ix, d_frontier, n_frontier, nullptr, d_hits, n_hits, params, n_next);
 }
 
 int impg_gpu_stage_next_frontier(impg_gpu_index_t *ix, impg_gpu_frontier_t *d_out, size_t cap) {

@@ -1409,6 +1409,29 @@ __global__ __launch_bounds__(256) void hits_to_aos_kernel(const uint32_t *__rest
   out[p] = x;
 }
 
+__global__ __launch_bounds__(256) void hits_to_aos16_kernel(const uint32_t *__restrict__ pair_range, uint32_t n_pairs, HitArrays h,
+                                                            impg_gpu_hit16_t *__restrict__ out) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n_pairs) return;
+  impg_gpu_hit16_t x;
+  x.fidx = pair_range[p];
+  x.query_id = h.qid[p];
+  const bool okk = x.query_id != HIT_NONE;
+  x.q_first = okk ? h.qs[p] : 0;
+  x.q_last = okk ? h.qe[p] : 0;
+  out[p] = x;
+}
+__global__ __launch_bounds__(256) void aos16_to_hits_kernel(const impg_gpu_hit16_t *__restrict__ in, uint32_t n,
+                                                            uint32_t *__restrict__ pair_range, HitArrays h) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n) return;
+  const impg_gpu_hit16_t x = in[p];
+  pair_range[p] = x.fidx;
+  h.qid[p] = x.query_id;
+  h.qs[p] = x.q_first;
+  h.qe[p] = x.q_last;
+}
+
 // ---------------------------------------------------------------------------
 // MultiImpg::query_all_indices (multi_impg.rs:556-592): the hits of one step are
 // merged over the per-file indices, hits equal to the self interval are dropped,
@@ -1921,6 +1944,12 @@ void launch_compact_select(const VisitedTables &vt, const unsigned long long *sk
 void launch_compact_copy(const VisitedTables &vt, const unsigned long long *src, const uint32_t *off, const uint32_t *len,
                          uint32_t n, int2 *ranges_out, hipStream_t s) {
   if (n) compact_copy_kernel<<<cdiv(n, 256), 256, 0, s>>>(vt, src, off, len, n, ranges_out);
+}
+void launch_hits_to_aos16(const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, impg_gpu_hit16_t *out, hipStream_t s) {
+  if (n_pairs) hits_to_aos16_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(pair_range, n_pairs, h, out);
+}
+void launch_aos16_to_hits(const impg_gpu_hit16_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s) {
+  if (n) aos16_to_hits_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, n, pair_range, h);
 }
 void launch_aos_to_hits(const impg_gpu_hit_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s) {
   if (!n) return;

@@ -135,5 +135,7 @@ void launch_compact_select(const VisitedTables &vt, const unsigned long long *sk
 void launch_compact_copy(const VisitedTables &vt, const unsigned long long *src, const uint32_t *off, const uint32_t *len,
                          uint32_t n, int2 *ranges_out, hipStream_t s);
 void launch_aos_to_hits(const impg_gpu_hit_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s);
+void launch_hits_to_aos16(const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, impg_gpu_hit16_t *out, hipStream_t s);
+void launch_aos16_to_hits(const impg_gpu_hit16_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s);
 
 }  // namespace impg

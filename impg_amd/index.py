@@ -241,10 +241,11 @@ class GpuImpg:
         check(lib().impg_gpu_stage_count(self._h, d_frontier_ptr, n, int(transitive), d_counts_ptr, C.byref(total)))
         return total.value
 
-    def stage_project(self, d_frontier_ptr, n, transitive, params, d_hits_ptr, total):
+    def stage_project(self, d_frontier_ptr, n, transitive, params, d_hits_ptr, total, compact=False):
+        """compact: 16-byte hit records {fidx, query_id, q_first, q_last} instead of the 32-byte ones"""
         acc = C.c_uint64(0)
-        check(lib().impg_gpu_stage_project(self._h, d_frontier_ptr, n, int(transitive), C.byref(params), d_hits_ptr, total,
-                                           C.byref(acc)))
+        f = lib().impg_gpu_stage_project16 if compact else lib().impg_gpu_stage_project
+        check(f(self._h, d_frontier_ptr, n, int(transitive), C.byref(params), d_hits_ptr, total, C.byref(acc)))
         return acc.value
 
 
@@ -258,9 +259,10 @@ class GpuImpg:
         check(lib().impg_gpu_stage_begin(self._h, d_ranges_ptr, n, C.byref(params), d_frontier_ptr, C.byref(nf), d_self_ptr))
         return nf.value
 
-    def stage_update(self, d_frontier_ptr, n_frontier, d_hits_ptr, n_hits, params):
+    def stage_update(self, d_frontier_ptr, n_frontier, d_hits_ptr, n_hits, params, compact=False):
         nn = C.c_uint64(0)
-        check(lib().impg_gpu_stage_update(self._h, d_frontier_ptr, n_frontier, d_hits_ptr, n_hits, C.byref(params), C.byref(nn)))
+        f = lib().impg_gpu_stage_update16 if compact else lib().impg_gpu_stage_update
+        check(f(self._h, d_frontier_ptr, n_frontier, d_hits_ptr, n_hits, C.byref(params), C.byref(nn)))
         return nn.value
 
     def stage_next_frontier(self, d_out_ptr, cap):

@@ -28,6 +28,7 @@ from .index import GpuImpg
 
 FR_COLS = 4   # impg_gpu_frontier_t as int32[4]: target_id, start, end, qidx
 HIT_COLS = 8  # impg_gpu_hit_t as int32[8]: fidx, query_id, q_first, q_last, t_first, t_last, order, pad
+HIT16_COLS = 4  # impg_gpu_hit16_t: the first four of them -- all the visited-set update reads
 
 
 class GpuBackend:
@@ -61,9 +62,11 @@ class GpuBackend:
         counts = self.index.stage_route(frontier.data_ptr() if n else None, n, world, out.data_ptr())
         return out[:n], [int(c) for c in counts]
 
-    def expand(self, frontier, transitive, params, want_hits=True):
+    def expand(self, frontier, transitive, params, want_hits=True, compact=False):
         """-> (hits int32[k,8] with fidx indexing `frontier`, accepted count).  Slots whose projection
-        returned None (query_id == -1) stay in the list: they are rare and every consumer skips them."""
+        returned None (query_id == -1) stay in the list: they are rare and every consumer skips them.
+        compact: int32[k,4] records (no target columns): enough for the visited-set update, half the bytes."""
+        cols = HIT16_COLS if compact else HIT_COLS
         self._sync()
         n = frontier.shape[0]
         outs, accepted, base = [], 0, 0
@@ -77,8 +80,8 @@ class GpuBackend:
                 step = max(1, m // 2)
                 continue
             if want_hits:
-                hits = torch.empty((max(total, 1), HIT_COLS), dtype=torch.int32, device=self.device)
-                accepted += self.index.stage_project(sub.data_ptr(), m, transitive, params, hits.data_ptr(), total)
+                hits = torch.empty((max(total, 1), cols), dtype=torch.int32, device=self.device)
+                accepted += self.index.stage_project(sub.data_ptr(), m, transitive, params, hits.data_ptr(), total, compact=compact)
                 if total:
                     h = hits[:total]
                     if base:
@@ -88,13 +91,14 @@ class GpuBackend:
                 accepted += self.index.stage_project(sub.data_ptr(), m, transitive, params, None, total)
             base += m
         if not want_hits or not outs:
-            return torch.empty((0, HIT_COLS), dtype=torch.int32, device=self.device), accepted
+            return torch.empty((0, cols), dtype=torch.int32, device=self.device), accepted
         return (outs[0] if len(outs) == 1 else torch.cat(outs)), accepted
 
     def update(self, frontier, hits, params):
         self._sync()
         nn = self.index.stage_update(frontier.data_ptr() if frontier.shape[0] else None, frontier.shape[0],
-                                     hits.data_ptr() if hits.shape[0] else None, hits.shape[0], params)
+                                     hits.data_ptr() if hits.shape[0] else None, hits.shape[0], params,
+                                     compact=hits.shape[1] == HIT16_COLS)
         out = torch.empty((max(nn, 1), FR_COLS), dtype=torch.int32, device=self.device)
         self.index.stage_next_frontier(out.data_ptr(), nn)
         return out[:nn]
@@ -189,11 +193,11 @@ class ShardedImpg:
         return send, torch.bincount(owner, minlength=W).tolist()
 
     # ---- one hop --------------------------------------------------------------------
-    def _hop(self, front, transitive, params, need_hits):
+    def _hop(self, front, transitive, params, need_hits, compact=False):
         W = self.world
         send, send_counts = self._route(front)  # grouped by owner; column 3 = the home frontier index, echoed back
         recv, recv_counts = self._all_to_all_rows(send, send_counts)
-        hits, accepted = self.backend.expand(recv, transitive, params, want_hits=need_hits)
+        hits, accepted = self.backend.expand(recv, transitive, params, want_hits=need_hits, compact=compact)
         if not need_hits:
             return None, accepted, recv.shape[0]
         # hits are ordered by fidx and `recv` is grouped by source rank, so hits are
@@ -227,7 +231,8 @@ class ShardedImpg:
                 break
             last = (not transitive) or (params.max_depth > 0 and depth + 1 >= params.max_depth)
             need_hits = (collect is not None) or not last
-            hits, accepted, n_looked = self._hop(front, transitive, params, need_hits)
+            # nobody reads result rows at home in a counting run: the owners send back 16-byte records
+            hits, accepted, n_looked = self._hop(front, transitive, params, need_hits, compact=collect is None)
             st.projected += accepted
             st.frontier_ranges += n_looked
             st.levels += 1

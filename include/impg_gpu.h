@@ -242,6 +242,18 @@ int impg_gpu_stage_project(impg_gpu_index_t *, const impg_gpu_frontier_t *d_fron
                            int transitive, const impg_gpu_params_t *params,
                            impg_gpu_hit_t *d_hits, uint64_t total, uint64_t *accepted);
 
+/* The same pair of calls on 16-byte hit records {fidx, query_id, q_first, q_last}: all the visited-set
+ * update reads.  For runs that only need the closure's frontier and counts (no result rows at home),
+ * it halves the bytes the owners send back. */
+typedef struct {
+  uint32_t fidx;
+  uint32_t query_id; /* 0xFFFFFFFF = projection returned None */
+  int32_t q_first, q_last;
+} impg_gpu_hit16_t;
+int impg_gpu_stage_project16(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n,
+                             int transitive, const impg_gpu_params_t *params,
+                             impg_gpu_hit16_t *d_hits, uint64_t total, uint64_t *accepted);
+
 /* route: stable partition of a frontier by owner rank (target_id % world).  d_out[n]
  * receives the records grouped by owner, in their original order within a group,
  * with qidx replaced by the record's index in d_frontier (the home index an owner
@@ -262,6 +274,9 @@ int impg_gpu_stage_begin(impg_gpu_index_t *, const impg_gpu_range_t *d_ranges, s
 int impg_gpu_stage_update(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
                           const impg_gpu_hit_t *d_hits, size_t n_hits, const impg_gpu_params_t *params,
                           uint64_t *n_next);
+int impg_gpu_stage_update16(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
+                            const impg_gpu_hit16_t *d_hits, size_t n_hits, const impg_gpu_params_t *params,
+                            uint64_t *n_next);
 int impg_gpu_stage_next_frontier(impg_gpu_index_t *, impg_gpu_frontier_t *d_out, size_t cap);
 /* HIP-event time accumulated by the stage calls since the last reset:
  * ms[0] lookup (count+emit), ms[1] projection kernel, ms[2] visited update;

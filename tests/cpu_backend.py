@@ -28,7 +28,7 @@ class OracleBackend:
                 front.append((t, ps, pe, q))
         return (torch.tensor(front, dtype=torch.int32).view(-1, 4), torch.tensor(self_iv, dtype=torch.int32).view(-1, 4))
 
-    def expand(self, frontier, transitive, params, want_hits=True):
+    def expand(self, frontier, transitive, params, want_hits=True, compact=False):
         rows, accepted = [], 0
         f = frontier.numpy()
         for i in range(f.shape[0]):
@@ -42,6 +42,8 @@ class OracleBackend:
                 rows.append((i, int(x["query_id"]), int(x["q_first"]), int(x["q_last"]), int(x["t_first"]), int(x["t_last"]), k, 0))
             accepted += len(res) - 1
         h = torch.tensor(rows, dtype=torch.int32).view(-1, 8)
+        if compact:
+            h = h[:, :4].contiguous()
         return (h if want_hits else h[:0]), accepted
 
     def update(self, frontier, hits, params):

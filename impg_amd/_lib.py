@@ -64,6 +64,8 @@ SYMBOLS = [
     ("impg_gpu_last_error", C.c_char_p, []),
     ("impg_gpu_device_count", C.c_int, []),
     ("impg_gpu_index_create", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("impg_gpu_index_create_files", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, _P, C.c_uint32, C.c_int, C.c_int,
+                                              C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("impg_gpu_index_create_from_paf", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_create_sharded", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                                 C.c_uint32, C.c_uint32, C.POINTER(_P)]),

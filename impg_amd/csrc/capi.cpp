@@ -49,12 +49,18 @@ void require_device(int device) {
 std::unique_ptr<impg_gpu_index> make_index(const impg_gpu_record_t *records, size_t n_records, const uint32_t *ops,
                                            size_t n_ops, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
                                            int order_policy, int device, uint32_t shard, uint32_t n_shards,
-                                           HostSeqIndex *seq) {
+                                           HostSeqIndex *seq, const std::vector<uint64_t> *file_first = nullptr) {
   if ((!records && n_records) || (!ops && n_ops) || (!seq_len && n_seq)) throw Error{IMPG_E_INVALID, "null input array"};
   require_device(device);
   auto ix = std::make_unique<impg_gpu_index>();
   ix->device = device;
   if (seq) ix->seq = std::move(*seq);
+  if (file_first) {
+    if (file_first->size() < 2 || file_first->front() != 0 || file_first->back() != n_records ||
+        !std::is_sorted(file_first->begin(), file_first->end()))
+      throw Error{IMPG_E_INVALID, "file boundaries must start at 0, end at n_records and be ascending"};
+    ix->file_first = *file_first;
+  }
   build_index(*ix, records, n_records, ops, n_ops, seq_len, n_seq, bidirectional != 0, order_policy, shard, n_shards);
   ix->engine = new Engine(device);
   ix->stream = ix->engine->stream;
@@ -209,6 +215,20 @@ int impg_gpu_index_create_sharded(const impg_gpu_record_t *records, size_t n_rec
   IMPG_CATCH
 }
 
+int impg_gpu_index_create_files(const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops, size_t n_ops,
+                                const int64_t *seq_len, uint32_t n_seq, const uint64_t *file_first_record, uint32_t n_files,
+                                int bidirectional, int order_policy, int device, uint32_t shard, uint32_t n_shards,
+                                impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out || !file_first_record || n_files == 0) throw Error{IMPG_E_INVALID, "bad arguments"};
+  std::vector<uint64_t> ff(file_first_record, file_first_record + n_files);
+  ff.push_back(n_records);
+  *out = make_index(records, n_records, cigar_ops, n_ops, seq_len, n_seq, bidirectional, order_policy, device, shard, n_shards, nullptr,
+                    &ff).release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
 int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths, int bidirectional, int order_policy, int device,
                                    impg_gpu_index_t **out) {
   IMPG_TRY
@@ -219,7 +239,7 @@ int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths, int bi
   parse_paf_files(ps, pp);
   std::vector<int64_t> lens = pp.seq.lens;
   *out = make_index(pp.records.data(), pp.records.size(), pp.ops.data(), pp.ops.size(), lens.data(), (uint32_t)lens.size(),
-                    bidirectional, order_policy, device, 0, 1, &pp.seq).release();
+                    bidirectional, order_policy, device, 0, 1, &pp.seq, &pp.file_first).release();
   return IMPG_OK;
   IMPG_CATCH
 }
@@ -234,7 +254,7 @@ int impg_gpu_index_create_from_paf_sharded(const char *const *paths, int n_paths
   parse_paf_files(ps, pp);
   std::vector<int64_t> lens = pp.seq.lens;
   *out = make_index(pp.records.data(), pp.records.size(), pp.ops.data(), pp.ops.size(), lens.data(), (uint32_t)lens.size(),
-                    bidirectional, order_policy, device, shard, n_shards, &pp.seq).release();
+                    bidirectional, order_policy, device, shard, n_shards, &pp.seq, &pp.file_first).release();
   return IMPG_OK;
   IMPG_CATCH
 }

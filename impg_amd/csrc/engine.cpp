@@ -156,7 +156,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
     // sort every range's hits by (query_id, q.first, q.last, t.first, t.last) (multi_impg.rs:582-592)
     const size_t b = std::max<size_t>((size_t)L.n_pairs * 4, 256);
     m_dest.reserve(b); m_qid.reserve(b); m_qs.reserve(b); m_qe.reserve(b); m_ts.reserve(b); m_te.reserve(b); m_pe.reserve(b);
-    launch_sort5(fr, n_fr, pair_off.as<uint32_t>(), L.n_pairs, h, m_dest.as<uint32_t>(), stream);
+    launch_sort5(fr, n_fr, pair_off.as<uint32_t>(), L.n_pairs, h, pair_entry.as<uint32_t>(), v.mrank, m_dest.as<uint32_t>(), stream);
     HitArrays h2{m_qid.as<uint32_t>(), m_qs.as<int32_t>(), m_qe.as<int32_t>(), m_ts.as<int32_t>(), m_te.as<int32_t>()};
     SliceArrays sl2{nullptr, nullptr, nullptr, nullptr};
     if (store_cigar) {

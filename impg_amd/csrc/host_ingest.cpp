@@ -191,7 +191,9 @@ void parse_paf_text(const char *text, size_t len, ParsedPaf &out) {
 }
 
 void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out) {
+  out.file_first.clear();
   for (const auto &path : paths) {
+    out.file_first.push_back(out.records.size());
     if (path.size() > 3 && (path.compare(path.size() - 3, 3, ".gz") == 0 ||
                             (path.size() > 4 && path.compare(path.size() - 4, 4, ".bgz") == 0)))
       throw Error{IMPG_E_UNSUPPORTED, "BGZF-compressed PAF is not supported: " + path};
@@ -212,6 +214,7 @@ void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out) {
     }
     munmap(m, sz);
   }
+  out.file_first.push_back(out.records.size());
 }
 
 // ---------------------------------------------------------------------------

@@ -97,6 +97,7 @@ struct DeviceIndexView {  // passed by value to kernels
   const int32_t *starts_lvl; // sampled levels of starts / pmax (same offsets)
   const int32_t *pmax_lvl;
   const uint32_t *rank;      // [n_entries] visit rank within the segment (order policy)
+  const uint32_t *mrank;     // [n_entries] MultiImpg tie order: (alignment file, visit rank in THAT file's tree); == rank for one file
   const Entry *entries;      // [n_entries]
   const uint32_t *ops;       // [n_tiles*32] tiles
   const uint32_t *ext_cp;    // effective target prefixes of entries with > 8 tiles
@@ -133,6 +134,7 @@ struct ParsedPaf {
   HostSeqIndex seq;
   std::vector<impg_gpu_record_t> records;
   std::vector<uint32_t> ops;
+  std::vector<uint64_t> file_first;  // first record of every input file, then the record count
 };
 // parse_paf + parse_cigar_to_delta over whole files (paf.rs:118-194, impg.rs:2935-2950)
 void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out);
@@ -156,7 +158,8 @@ struct impg_gpu_index {
   impg::HostSeqIndex seq;
   size_t n_records = 0, n_entries = 0, n_tiles = 0, n_targets = 0;
   std::vector<uint32_t> h_tgt_off;
-  impg::DevBuf d_seg, d_starts, d_ends, d_ends_t, d_pmax, d_starts_lvl, d_pmax_lvl, d_rank, d_entries, d_ops, d_ext_cp, d_idp, d_seq_len;
+  std::vector<uint64_t> file_first;  // first record of every alignment file (+ the record count); empty = one file
+  impg::DevBuf d_seg, d_starts, d_ends, d_ends_t, d_pmax, d_starts_lvl, d_pmax_lvl, d_rank, d_mrank, d_entries, d_ops, d_ext_cp, d_idp, d_seq_len;
   impg::DeviceIndexView view{};
   size_t device_bytes = 0;
   impg::Engine *engine = nullptr;  // scratch + streams (engine.cpp)

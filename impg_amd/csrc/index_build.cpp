@@ -321,6 +321,52 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     for (auto &x : th) x.join();
   }
 
+  // ---- MultiImpg tie order (multi_impg.rs:556-592): the hits of a step are concatenated file by file, each
+  // file's in ITS tree's visit order, then sorted stably by five keys -- so hits that agree on all five keep
+  // (file, visit rank in that file's tree).  mrank = position of the entry in that order within its segment.
+  std::vector<uint32_t> mrank;
+  const bool multi_file = ix.file_first.size() > 2;
+  if (multi_file) {
+    mrank.resize(n_entries);
+    auto file_of = [&](uint32_t rec) {
+      return (uint32_t)(std::upper_bound(ix.file_first.begin(), ix.file_first.end(), (uint64_t)rec) - ix.file_first.begin() - 1);
+    };
+    std::atomic<uint32_t> next{0};
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, n_seq));
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; t++)
+      th.emplace_back([&]() {
+        std::vector<std::pair<uint64_t, uint32_t>> key;  // ((file, rank in the file's tree), entry)
+        std::vector<uint32_t> members, vr;
+        for (;;) {
+          uint32_t s = next.fetch_add(1);
+          if (s >= n_seq) break;
+          const uint32_t a = tgt_off[s], b = tgt_off[s + 1];
+          if (a == b) continue;
+          // entries a..b are in start order (stable), which restricted to one file is that file's own node order
+          std::vector<std::pair<uint32_t, uint32_t>> by_file;  // (file, entry), stable in entry order
+          by_file.reserve(b - a);
+          for (uint32_t i = a; i < b; i++) by_file.push_back({file_of(ent_rec[i]), i});
+          std::stable_sort(by_file.begin(), by_file.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+          key.clear();
+          for (size_t u = 0; u < by_file.size();) {
+            size_t w = u;
+            while (w < by_file.size() && by_file[w].first == by_file[u].first) w++;
+            const uint32_t nf = (uint32_t)(w - u);
+            vr.resize(nf);
+            if (order_policy == IMPG_ORDER_COITREES) coitrees_visit_rank(nf, vr.data());
+            else for (uint32_t k = 0; k < nf; k++) vr[k] = k;
+            for (uint32_t k = 0; k < nf; k++) key.push_back({((uint64_t)by_file[u].first << 32) | vr[k], by_file[u + k].second});
+            u = w;
+          }
+          std::sort(key.begin(), key.end());
+          for (uint32_t k = 0; k < key.size(); k++) mrank[key[k].second] = k;
+        }
+      });
+    for (auto &x : th) x.join();
+  }
+
   // ---- upload -------------------------------------------------------------------
   IMPG_HIP(hipSetDevice(ix.device));
   std::vector<int32_t> sl(n_seq);
@@ -334,6 +380,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   upload(ix.d_starts_lvl, starts_lvl, acc);
   upload(ix.d_pmax_lvl, pmax_lvl, acc);
   upload(ix.d_rank, rank, acc);
+  if (multi_file) upload(ix.d_mrank, mrank, acc);
   upload(ix.d_entries, ent, acc);
   upload(ix.d_ops, pool, acc);
   upload(ix.d_ext_cp, ext_cp, acc);
@@ -351,6 +398,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   ix.view.starts_lvl = ix.d_starts_lvl.as<int32_t>();
   ix.view.pmax_lvl = ix.d_pmax_lvl.as<int32_t>();
   ix.view.rank = ix.d_rank.as<uint32_t>();
+  ix.view.mrank = multi_file ? ix.d_mrank.as<uint32_t>() : ix.d_rank.as<uint32_t>();
   ix.view.entries = ix.d_entries.as<Entry>();
   ix.view.ops = ix.d_ops.as<uint32_t>();
   ix.view.ext_cp = ix.d_ext_cp.as<uint32_t>();

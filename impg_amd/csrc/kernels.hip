@@ -1439,18 +1439,22 @@ __global__ __launch_bounds__(256) void aos16_to_hits_kernel(const impg_gpu_hit16
 // then sorting makes the per-file split irrelevant: sort every range's slot run.
 // One wave per range; dest = number of slots that sort before (ties by slot).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ bool key5_less(uint32_t aq, int32_t a1, int32_t a2, int32_t a3, int32_t a4, uint32_t ai,
-                                          uint32_t bq, int32_t b1, int32_t b2, int32_t b3, int32_t b4, uint32_t bi) {
+// ties on all five keys keep the reference's concatenation order: alignment file by alignment file, each in
+// its own tree's visit order (am / bm = the entries' mrank); the slot index only separates empty slots
+__device__ __forceinline__ bool key5_less(uint32_t aq, int32_t a1, int32_t a2, int32_t a3, int32_t a4, uint32_t am, uint32_t ai,
+                                          uint32_t bq, int32_t b1, int32_t b2, int32_t b3, int32_t b4, uint32_t bm, uint32_t bi) {
   if (aq != bq) return aq < bq;
   if (a1 != b1) return a1 < b1;
   if (a2 != b2) return a2 < b2;
   if (a3 != b3) return a3 < b3;
   if (a4 != b4) return a4 < b4;
+  if (am != bm) return am < bm;
   return ai < bi;
 }
 __global__ __launch_bounds__(256) void sort5_kernel(const FrontierRec *__restrict__ fr, uint32_t n,
                                                     const uint32_t *__restrict__ pair_off, uint32_t n_pairs,
-                                                    HitArrays h, uint32_t *__restrict__ dest) {
+                                                    HitArrays h, const uint32_t *__restrict__ pair_entry,
+                                                    const uint32_t *__restrict__ mrank, uint32_t *__restrict__ dest) {
   const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * 256u) >> 6;
   const unsigned lane = lane_id();
@@ -1459,33 +1463,36 @@ __global__ __launch_bounds__(256) void sort5_kernel(const FrontierRec *__restric
     const FrontierRec f = fr[r];
     for (uint32_t base = a; base < b; base += 64u) {
       const uint32_t i = base + lane;
-      uint32_t q = HIT_NONE;
+      uint32_t q = HIT_NONE, km = 0;
       int32_t k1 = 0, k2 = 0, k3 = 0, k4 = 0;
       if (i < b) {
         q = h.qid[i];
         if (q != HIT_NONE) {
           k1 = h.qs[i]; k2 = h.qe[i]; k3 = h.ts[i]; k4 = h.te[i];
+          km = mrank[pair_entry[i]];
           // is_self (multi_impg.rs:558-562): equal to the step's own interval -> dropped
-          if (q == f.target_id && k1 == f.start && k2 == f.end) { q = HIT_NONE; h.qid[i] = HIT_NONE; k1 = k2 = k3 = k4 = 0; }
+          if (q == f.target_id && k1 == f.start && k2 == f.end) { q = HIT_NONE; h.qid[i] = HIT_NONE; k1 = k2 = k3 = k4 = 0; km = 0; }
         }
       }
       uint32_t pos = 0;
       for (uint32_t b2 = a; b2 < b; b2 += 64u) {
         const uint32_t i2 = b2 + lane;
-        uint32_t q2 = HIT_NONE;
+        uint32_t q2 = HIT_NONE, jm = 0;
         int32_t j1 = 0, j2 = 0, j3 = 0, j4 = 0;
         if (i2 < b) {
           q2 = h.qid[i2];
           if (q2 != HIT_NONE) {
             j1 = h.qs[i2]; j2 = h.qe[i2]; j3 = h.ts[i2]; j4 = h.te[i2];
-            if (q2 == f.target_id && j1 == f.start && j2 == f.end) { q2 = HIT_NONE; j1 = j2 = j3 = j4 = 0; }
+            jm = mrank[pair_entry[i2]];
+            if (q2 == f.target_id && j1 == f.start && j2 == f.end) { q2 = HIT_NONE; j1 = j2 = j3 = j4 = 0; jm = 0; }
           }
         }
         const uint32_t cntl = min(64u, b - b2);
         for (uint32_t t = 0; t < cntl; t++) {
           const uint32_t oq = (uint32_t)__shfl((int)q2, (int)t);
           const int32_t o1 = __shfl(j1, (int)t), o2 = __shfl(j2, (int)t), o3 = __shfl(j3, (int)t), o4 = __shfl(j4, (int)t);
-          pos += key5_less(oq, o1, o2, o3, o4, b2 + t, q, k1, k2, k3, k4, i) ? 1u : 0u;
+          const uint32_t om = (uint32_t)__shfl((int)jm, (int)t);
+          pos += key5_less(oq, o1, o2, o3, o4, om, b2 + t, q, k1, k2, k3, k4, km, i) ? 1u : 0u;
         }
       }
       if (i < b) dest[i] = a + pos;  // empty slots (0xFFFFFFFF) sort last
@@ -1866,9 +1873,9 @@ void launch_dfs_pop_flags(const unsigned long long *key, const uint32_t *depth, 
   if (!n) return;
   dfs_pop_flags_kernel<<<cdiv(n, 256), 256, 0, s>>>(key, depth, n, max_depth, pop_front ? 1 : 0, fr_flag, keep_flag, pop_depth);
 }
-void launch_sort5(const FrontierRec *fr, uint32_t n, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h, uint32_t *dest,
-                  hipStream_t s) {
-  if (n && n_pairs) sort5_kernel<<<wave_grid(n), 256, 0, s>>>(fr, n, pair_off, n_pairs, h, dest);
+void launch_sort5(const FrontierRec *fr, uint32_t n, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
+                  const uint32_t *pair_entry, const uint32_t *mrank, uint32_t *dest, hipStream_t s) {
+  if (n && n_pairs) sort5_kernel<<<wave_grid(n), 256, 0, s>>>(fr, n, pair_off, n_pairs, h, pair_entry, mrank, dest);
 }
 void launch_permute_slots(const uint32_t *dest, uint32_t n_pairs, HitArrays in, HitArrays out, const uint32_t *pe_in,
                           uint32_t *pe_out, SliceArrays sin, SliceArrays sout, hipStream_t s) {

@@ -70,8 +70,8 @@ void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, Hi
 void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
                       int32_t min_output_length, bool skip_same_target, unsigned long long *count, unsigned long long *cksum,
                       hipStream_t s);
-void launch_sort5(const FrontierRec *fr, uint32_t n, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h, uint32_t *dest,
-                  hipStream_t s);
+void launch_sort5(const FrontierRec *fr, uint32_t n, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
+                  const uint32_t *pair_entry, const uint32_t *mrank, uint32_t *dest, hipStream_t s);
 void launch_permute_slots(const uint32_t *dest, uint32_t n_pairs, HitArrays in, HitArrays out, const uint32_t *pe_in,
                           uint32_t *pe_out, SliceArrays sin, SliceArrays sout, hipStream_t s);
 void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,

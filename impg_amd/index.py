@@ -103,11 +103,19 @@ class GpuImpg:
     # ---- construction (Impg::from_multi_alignment_records / load) ------------
     @classmethod
     def from_records(cls, records, ops, seq_len, bidirectional=True, order=_lib.ORDER_COITREES, device=0,
-                     shard=None, n_shards=None):
+                     shard=None, n_shards=None, file_first=None):
+        """file_first: first record of every alignment file (records_by_file of the reference); only the
+        MultiImpg tie order observes it"""
         rec = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
         ops = np.ascontiguousarray(ops, dtype=np.uint32)
         sl = np.ascontiguousarray(seq_len, dtype=np.int64)
         h = C.c_void_p(None)
+        if file_first is not None:
+            ff = np.ascontiguousarray(file_first, dtype=np.uint64)
+            check(lib().impg_gpu_index_create_files(rec.ctypes.data, rec.size, ops.ctypes.data, ops.size, sl.ctypes.data, sl.size,
+                                                    ff.ctypes.data, ff.size, int(bidirectional), order, device,
+                                                    0 if shard is None else shard, 1 if n_shards is None else n_shards, C.byref(h)))
+            return cls(h)
         if shard is None:
             check(lib().impg_gpu_index_create(rec.ctypes.data, rec.size, ops.ctypes.data, ops.size, sl.ctypes.data, sl.size,
                                               int(bidirectional), order, device, C.byref(h)))

@@ -94,6 +94,17 @@ int impg_gpu_index_create(const impg_gpu_record_t *records, size_t n_records,
                           const int64_t *seq_len, uint32_t n_seq,
                           int bidirectional, int order_policy, int device,
                           impg_gpu_index_t **out);
+/* The same from records of several alignment files: records[file_first_record[f] .. file_first_record[f+1])
+ * (the last file ends at n_records) came from file f, as in `records_by_file` of
+ * Impg::from_multi_alignment_records (impg.rs:1535).  Only MultiImpg semantics observe the split, and only
+ * in the order of hits that agree on all five sort keys (multi_impg.rs:556-592): they stay file by file,
+ * each in its own tree's visit order.  impg_gpu_index_create treats all records as one file. */
+int impg_gpu_index_create_files(const impg_gpu_record_t *records, size_t n_records,
+                                const uint32_t *cigar_ops, size_t n_ops, const int64_t *seq_len,
+                                uint32_t n_seq, const uint64_t *file_first_record, uint32_t n_files,
+                                int bidirectional, int order_policy, int device, uint32_t shard,
+                                uint32_t n_shards, impg_gpu_index_t **out);
+
 /* Same, parsing PAF files on the host the way paf.rs:118-194 does; sequence ids
  * are assigned in first-seen order over the files (query then target per line). */
 int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths,

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Differential soak test on the GPU box: random PAFs, random ranges, random parameters; the HIP engine
+(through the C ABI) against the CPU oracle, row for row -- results, CIGARs, projection counts, BED / PAF /
+BEDPE text.  usage: fuzz_parity.py <seconds> [first_seed]"""
+import os, sys, time, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import impg_amd
+from oracle import oracle as o
+from tests.paf_gen import random_paf, random_ranges
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+t_end = time.time() + budget
+n_cases = n_rows = 0
+tmp = tempfile.mkdtemp()
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    n_seq = int(rng.integers(2, 14))
+    seq_len = int(rng.choice([2500, 8000, 30000, 120000]))
+    max_ops = int(rng.choice([6, 30, 150, 700]))
+    n_rec = int(rng.integers(20, 700))
+    weird, incons, self_aln = bool(rng.random() < 0.4), bool(rng.random() < 0.3), bool(rng.random() < 0.6)
+    n_files = int(rng.choice([1, 1, 2, 3]))
+    paths = []
+    for k in range(n_files):
+        text, _ = random_paf(seed * 7 + k, max(5, n_rec // n_files), n_seq=n_seq, seq_len=seq_len, max_ops=max_ops, weird=weird,
+                             inconsistent=incons, self_aln=self_aln)
+        p = os.path.join(tmp, "f%d_%d.paf" % (seed, k))
+        open(p, "w").write(text)
+        paths.append(p)
+    bidir = bool(rng.random() < 0.8)
+    order = impg_amd.ORDER_COITREES if rng.random() < 0.8 else impg_amd.ORDER_SORTED
+    g = impg_amd.GpuImpg.from_paf(paths, bidirectional=bidir, order=order)
+    if order == impg_amd.ORDER_SORTED:
+        for p in paths:
+            os.remove(p)
+        seed += 1
+        continue  # (the oracle only restates the coitrees order; the sorted policy has its own test)
+    c = o.OracleIndex(paf_paths=paths, bidirectional=bidir, preparse=True)
+    g.set_option("locality_min", int(rng.choice([0, 1, 4096])))
+    if rng.random() < 0.3:
+        g.set_option("chunk_ranges", int(rng.integers(1, 40)))
+    ranges = random_ranges(seed + 1, int(rng.integers(5, 120)), g.num_seqs(), seq_len, max_len=int(min(rng.choice([300, 3000, seq_len // 2]), seq_len - 1)),
+                           min_len=int(rng.choice([1, 50, 150])))
+    ranges = [(t, s, e) for (t, s, e) in ranges if e > s] or [(0, 0, min(seq_len, 500))]
+    kw = {}
+    if rng.random() < 0.7:
+        kw.update(transitive=True, max_depth=int(rng.choice([0, 1, 2, 3, 5])), min_transitive_len=int(rng.choice([0, 10, 101, 500])),
+                  min_distance_between_ranges=int(rng.choice([0, 10, 200])))
+        if rng.random() < 0.3:
+            kw["dfs"] = True
+        if kw["max_depth"] == 0 and kw["min_transitive_len"] < 101:
+            kw["max_depth"] = 3  # keep unlimited-depth cases from exploding
+    if rng.random() < 0.3:
+        kw["min_output_length"] = int(rng.choice([0, 100, 1000]))
+    if rng.random() < 0.3:
+        kw["min_identity"] = float(rng.choice([0.3, 0.7, 0.95]))
+    if rng.random() < 0.25:
+        kw["multi_impg"] = True
+    cigar = bool(rng.random() < 0.5)
+    params = impg_amd.make_params(store_cigar=cigar, **kw)
+    res = g.query_batch(ranges, params)
+    total = 0
+    for i, (t, s, e) in enumerate(ranges):
+        if cigar:
+            want, wcg = c.query_cigar(t, s, e, **kw)
+            got_cg = res.cigars(i)
+            assert [x.tolist() for x in got_cg] == [x.tolist() for x in wcg], ("cigar", seed, i, kw)
+        else:
+            want = c.query(t, s, e, **kw)
+        assert res[i].tolist() == want.tolist(), ("rows", seed, i, (t, s, e), kw)
+        total += c.last_projection_count()
+        n_rows += len(want)
+    assert res.projected == total, ("projected", seed, kw)
+    # text outputs on the ranges long enough for perform_query's validation
+    mtl = kw.get("min_transitive_len", 101)
+    ok = [i for i, (t, s, e) in enumerate(ranges) if e - s >= mtl]
+    if ok and not kw.get("multi_impg"):
+        sub = [ranges[i] for i in ok]
+        d = int(rng.choice([-1, 0, 30, 1000]))
+        names = ["n%d" % i for i in ok]
+        if cigar:
+            r2 = g.query_batch(sub, params)
+            for fmt in ("paf", "bedpe"):
+                try:
+                    want = "".join(c.query_paf(g.seq_name(t), s, e, range_name=names[k], merge_distance=d, fmt=fmt, **kw)
+                                   for k, (t, s, e) in enumerate(sub))
+                except RuntimeError:
+                    continue  # a range with no row to drop: the reference panics
+                assert r2.paf(names, merge_distance=d, params=params, fmt=fmt) == want, (fmt, seed, d, kw)
+        else:
+            r2 = g.query_batch(sub, params)
+            want = "".join(c.query_bed(g.seq_name(t), s, e, range_name=names[k], merge_distance=d, **kw) for k, (t, s, e) in enumerate(sub))
+            assert r2.bed(names, merge_distance=d, params=params) == want, ("bed", seed, d, kw)
+    n_cases += 1
+    for p in paths:
+        os.remove(p)
+    seed += 1
+print("fuzz ok: %d cases, %d result rows compared, seeds up to %d" % (n_cases, n_rows, seed - 1))

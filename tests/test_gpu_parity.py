@@ -510,3 +510,24 @@ def test_many_small_targets(tmp_path):
                dict(transitive=True, dfs=True, max_depth=2, min_transitive_len=10),
                dict(transitive=True, max_depth=0, min_transitive_len=400)]:
         assert_same(g, c, ranges, **kw)
+
+
+def test_multi_impg_ties_keep_file_order(tmp_path):
+    """Hits that agree on all five MultiImpg sort keys but carry different CIGARs (the same alignment
+    coordinates in two files): the stable sort of multi_impg.rs:582-592 keeps them file by file, each in its own
+    tree's visit order -- found by scripts/fuzz_parity.py."""
+    def rec(q, qs, qe, t, ts, te, cg):
+        return "%s\t5000\t%d\t%d\t+\t%s\t5000\t%d\t%d\t1\t1\t60\tcg:Z:%s" % (q, qs, qe, t, ts, te, cg)
+    f0 = [rec("A", 100, 200, "T", 1000, 1100, "100="), rec("B", 0, 50, "T", 1020, 1070, "50="),
+          rec("A", 100, 200, "T", 1000, 1100, "40=1X59="), rec("C", 10, 110, "T", 900, 1000, "100=")]
+    f1 = [rec("A", 100, 200, "T", 1000, 1100, "10=2X88="), rec("A", 100, 200, "T", 1000, 1100, "99=1X"),
+          rec("D", 5, 105, "T", 1050, 1150, "100=")] + [rec("E%d" % k, 0, 30, "T", 1000 + k, 1030 + k, "30=") for k in range(12)]
+    g, c = both_files(tmp_path, ["\n".join(f0) + "\n", "\n".join(f1) + "\n"])
+    t = g.seq_id("T")
+    ranges = [(t, 1000, 1100), (t, 950, 1200), (t, 1040, 1060)]
+    for kw in [dict(multi_impg=True), dict(multi_impg=True, transitive=True, max_depth=2, min_transitive_len=10)]:
+        res = g.query_batch(ranges, impg_amd.make_params(store_cigar=True, **kw))
+        for i, (tt, s, e) in enumerate(ranges):
+            want, wcg = c.query_cigar(tt, s, e, **kw)
+            assert res[i].tolist() == want.tolist()
+            assert [x.tolist() for x in res.cigars(i)] == [x.tolist() for x in wcg], (i, kw)

@@ -42,6 +42,8 @@ while time.time() < t_end:
     g.set_option("locality_min", int(rng.choice([0, 1, 4096])))
     if rng.random() < 0.3:
         g.set_option("chunk_ranges", int(rng.integers(1, 40)))
+    if rng.random() < 0.2:
+        g.set_option("pair_budget", int(rng.choice([1024, 5000, 100000])))  # levels that outgrow it split the chunk
     ranges = random_ranges(seed + 1, int(rng.integers(5, 120)), g.num_seqs(), seq_len, max_len=int(min(rng.choice([300, 3000, seq_len // 2]), seq_len - 1)),
                            min_len=int(rng.choice([1, 50, 150])))
     ranges = [(t, s, e) for (t, s, e) in ranges if e > s] or [(0, 0, min(seq_len, 500))]

@@ -90,7 +90,10 @@ class QueryResults:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().impg_gpu_results_free(self._h)
+            try:
+                lib().impg_gpu_results_free(self._h)
+            except Exception:
+                pass
             self._h = None
 
 
@@ -140,7 +143,10 @@ class GpuImpg:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().impg_gpu_index_destroy(self._h)
+            try:
+                lib().impg_gpu_index_destroy(self._h)
+            except Exception:  # interpreter shutdown: the binding module may already be torn down
+                pass
             self._h = None
 
     # ---- seq_index() / target_ids() / num_targets() ---------------------------

@@ -176,7 +176,10 @@ class SortedRanges:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().oracle_sr_free(self._h)
+            try:
+                lib().oracle_sr_free(self._h)
+            except Exception:  # interpreter shutdown
+                pass
             self._h = None
 
     def insert(self, a, b):
@@ -206,7 +209,10 @@ class OracleIndex:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().oracle_index_free(self._h)
+            try:
+                lib().oracle_index_free(self._h)
+            except Exception:  # interpreter shutdown
+                pass
             self._h = None
 
     @property

@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--no-transitive", action="store_true")
     ap.add_argument("--chunk-ranges", type=int, default=50000)
     ap.add_argument("--pair-budget", type=int, default=1 << 30)
-    ap.add_argument("--cpu-sample", type=int, default=48, help="ranges timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="ranges timed on the CPU oracle, ~15 s of CPU work (0 = skip)")
     ap.add_argument("--paf", default=None, help="reuse an existing synthetic PAF file")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()

@@ -649,12 +649,6 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
   Qn += qa;
 }
 
-// A sub-tile: original tile j, sub-tile h (0..3, impg_internal.hpp).
-struct SubTile {
-  uint32_t j, h;
-};
-__device__ __forceinline__ bool same_sub(const SubTile &a, const SubTile &b) { return a.j == b.j && a.h == b.h; }
-
 struct TileHdr {  // the line header, in the ENTRY's axes: sums before the tile, then (relative to those) before its
   uint32_t t0, q0;                                   // sub-tiles 1..3 and after its last op
   uint32_t bt1, bt2, bt3, bt4, bq1, bq2, bq3, bq4;

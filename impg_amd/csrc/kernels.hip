@@ -866,15 +866,23 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
         cB = min(cB, c.m);  // (P[m] itself is not a tile start: only an inconsistent CIGAR has totT < xb)
       } else {
         const uint32_t *P = v.ext_cp + e2.y;  // P[0..m]
-        // two binary searches side by side (their probes overlap): first i in [1,m] with P[i] >= xa,
-        // first i in [0,m) with P[i] >= xb
+        // two lower-bound searches side by side, 4-ary (three probes each per round, all in flight together:
+        // half the dependent rounds of a binary search): first i in [1,m] with P[i] >= xa, first i in [0,m)
+        // with P[i] >= xb
         uint32_t la = 1, ha = c.m + 1, lb = 0, hb = c.m;
         while (la < ha || lb < hb) {
-          const uint32_t ma = (la + ha) >> 1, mb = (lb + hb) >> 1;
-          const bool ga = la < ha, gb = lb < hb;
-          const int32_t pa = ga ? (int32_t)P[ma] : 0, pb = gb ? (int32_t)P[mb] : 0;
-          if (ga) { if (pa >= xa) ha = ma; else la = ma + 1; }
-          if (gb) { if (pb >= xb) hb = mb; else lb = mb + 1; }
+          const uint32_t wa = ha - la, wb = hb - lb;
+          const uint32_t a1 = la + (wa >> 2), a2 = la + (wa >> 1), a3 = la + (wa >> 1) + (wa >> 2);
+          const uint32_t b1 = lb + (wb >> 2), b2 = lb + (wb >> 1), b3 = lb + (wb >> 1) + (wb >> 2);
+          const bool ga = wa != 0, gb = wb != 0;
+          const int32_t pa1 = ga ? (int32_t)P[a1] : 0, pa2 = ga ? (int32_t)P[a2] : 0, pa3 = ga ? (int32_t)P[a3] : 0;
+          const int32_t pb1 = gb ? (int32_t)P[b1] : 0, pb2 = gb ? (int32_t)P[b2] : 0, pb3 = gb ? (int32_t)P[b3] : 0;
+          if (ga) {
+            if (pa1 >= xa) ha = a1; else if (pa2 >= xa) { la = a1 + 1; ha = a2; } else if (pa3 >= xa) { la = a2 + 1; ha = a3; } else la = a3 + 1;
+          }
+          if (gb) {
+            if (pb1 >= xb) hb = b1; else if (pb2 >= xb) { lb = b1 + 1; hb = b2; } else if (pb3 >= xb) { lb = b2 + 1; hb = b3; } else lb = b3 + 1;
+          }
         }
         cA = la - 1;
         cB = lb;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential soak test on the GPU box: random PAFs, random ranges, random parameters; the HIP engine
 (through the C ABI) against the CPU oracle, row for row -- results, CIGARs, projection counts, BED / PAF /
-BEDPE text.  usage: fuzz_parity.py <seconds> [first_seed]"""
+BEDPE text.  usage: fuzz_parity.py <seconds> [first_seed] [big]     (big: thousands of records on few
+sequences -- dense windows, the wave-per-range emit pass, frontiers past the lookup-order threshold)"""
 import os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +13,7 @@ from tests.paf_gen import random_paf, random_ranges
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+BIG = len(sys.argv) > 3
 t_end = time.time() + budget
 n_cases = n_rows = 0
 tmp = tempfile.mkdtemp()
@@ -21,6 +23,9 @@ while time.time() < t_end:
     seq_len = int(rng.choice([2500, 8000, 30000, 120000]))
     max_ops = int(rng.choice([6, 30, 150, 700]))
     n_rec = int(rng.integers(20, 700))
+    if BIG:
+        n_seq, n_rec, seq_len = int(rng.integers(2, 6)), int(rng.integers(1500, 7000)), int(rng.choice([8000, 30000]))
+        max_ops = int(rng.choice([6, 30, 150]))
     weird, incons, self_aln = bool(rng.random() < 0.4), bool(rng.random() < 0.3), bool(rng.random() < 0.6)
     n_files = int(rng.choice([1, 1, 2, 3]))
     paths = []
@@ -44,12 +49,12 @@ while time.time() < t_end:
         g.set_option("chunk_ranges", int(rng.integers(1, 40)))
     if rng.random() < 0.2:
         g.set_option("pair_budget", int(rng.choice([1024, 5000, 100000])))  # levels that outgrow it split the chunk
-    ranges = random_ranges(seed + 1, int(rng.integers(5, 120)), g.num_seqs(), seq_len, max_len=int(min(rng.choice([300, 3000, seq_len // 2]), seq_len - 1)),
+    ranges = random_ranges(seed + 1, int(rng.integers(100, 600)) if BIG else int(rng.integers(5, 120)), g.num_seqs(), seq_len, max_len=int(min(rng.choice([300, 3000, seq_len // 2]), seq_len - 1)),
                            min_len=int(rng.choice([1, 50, 150])))
     ranges = [(t, s, e) for (t, s, e) in ranges if e > s] or [(0, 0, min(seq_len, 500))]
     kw = {}
     if rng.random() < 0.7:
-        kw.update(transitive=True, max_depth=int(rng.choice([0, 1, 2, 3, 5])), min_transitive_len=int(rng.choice([0, 10, 101, 500])),
+        kw.update(transitive=True, max_depth=int(rng.choice([1, 2]) if BIG else rng.choice([0, 1, 2, 3, 5])), min_transitive_len=int(rng.choice([0, 10, 101, 500])),
                   min_distance_between_ranges=int(rng.choice([0, 10, 200])))
         if rng.random() < 0.3:
             kw["dfs"] = True

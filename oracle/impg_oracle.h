@@ -11,7 +11,10 @@
  * reference itself cannot be compiled here (no Rust toolchain), and the
  * traversal order of the third-party crate coitrees 0.4.0 (not vendored in the
  * reference tree) is restated from its published algorithm: "visit-order
- * parity unpinned" (DESIGN.md section 3).
+ * parity unpinned" (DESIGN.md section 3).  The PAF / BEDPE writers
+ * (oracle_query_paf: merge_adjusted_intervals and its CIGAR helpers) have no
+ * reference test at all: that restatement is pinned by hand-checked rows only
+ * (tests/test_oracle_kat.py::test_paf_and_bedpe_rows_by_hand).
  */
 #ifndef IMPG_ORACLE_H
 #define IMPG_ORACLE_H

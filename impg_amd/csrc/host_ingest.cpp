@@ -10,6 +10,7 @@
 
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <zlib.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -195,8 +196,30 @@ void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out) {
   for (const auto &path : paths) {
     out.file_first.push_back(out.records.size());
     if (path.size() > 3 && (path.compare(path.size() - 3, 3, ".gz") == 0 ||
-                            (path.size() > 4 && path.compare(path.size() - 4, 4, ".bgz") == 0)))
-      throw Error{IMPG_E_UNSUPPORTED, "BGZF-compressed PAF is not supported: " + path};
+                            (path.size() > 4 && path.compare(path.size() - 4, 4, ".bgz") == 0))) {
+      // gzip / BGZF (a BGZF file is a series of gzip members: zlib reads it as one stream).  The reference keeps
+      // such files compressed and seeks into them per hit (.gzi index, impg.rs:2903-2933); here the CIGARs
+      // are tokenised once at ingest, so a sequential decompression is all that is needed.
+      gzFile gz = gzopen(path.c_str(), "rb");
+      if (!gz) throw Error{IMPG_E_IO, "Failed to open file '" + path + "'"};
+      gzbuffer(gz, 1 << 20);
+      std::string text;
+      std::vector<char> buf(1 << 22);
+      for (;;) {
+        int n = gzread(gz, buf.data(), (unsigned)buf.size());
+        if (n < 0) {
+          int err = 0;
+          std::string msg = gzerror(gz, &err);
+          gzclose(gz);
+          throw Error{IMPG_E_IO, "Failed to decompress '" + path + "': " + msg};
+        }
+        if (n == 0) break;
+        text.append(buf.data(), (size_t)n);
+      }
+      gzclose(gz);
+      if (!text.empty()) parse_paf_text(text.data(), text.size(), out);
+      continue;
+    }
     int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw Error{IMPG_E_IO, "Failed to open file '" + path + "'"};
     struct stat stt;

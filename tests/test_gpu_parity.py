@@ -531,3 +531,27 @@ def test_multi_impg_ties_keep_file_order(tmp_path):
             want, wcg = c.query_cigar(tt, s, e, **kw)
             assert res[i].tolist() == want.tolist()
             assert [x.tolist() for x in res.cigars(i)] == [x.tolist() for x in wcg], (i, kw)
+
+
+def test_gzip_and_bgzf_paf_ingest(tmp_path):
+    """.paf.gz (one gzip stream) and BGZF-style input (a series of gzip members): the same index as from the text."""
+    import gzip
+    text, names = random_paf(171, 300, n_seq=5, seq_len=20000, self_aln=True)
+    g, c = both(tmp_path, text)
+    gz = str(tmp_path / "t.paf.gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(text.encode())
+    bgz = str(tmp_path / "t.paf.bgz")
+    raw = text.encode()
+    with open(bgz, "wb") as f:  # members cut at arbitrary byte positions, then the empty EOF member
+        for a in range(0, len(raw), 7001):
+            f.write(gzip.compress(raw[a:a + 7001]))
+        f.write(gzip.compress(b""))
+    ranges = random_ranges(5, 60, 5, 20000, max_len=3000, min_len=50)
+    want = g.query_batch(ranges, impg_amd.make_params(transitive=True, max_depth=2))
+    for path in (gz, bgz):
+        g2 = impg_amd.GpuImpg.from_paf(path)
+        assert g2.num_seqs() == g.num_seqs() and [g2.seq_name(i) for i in range(g.num_seqs())] == [g.seq_name(i) for i in range(g.num_seqs())]
+        got = g2.query_batch(ranges, impg_amd.make_params(transitive=True, max_depth=2))
+        assert all(got[i].tolist() == want[i].tolist() for i in range(len(ranges)))
+    assert_same(g, c, ranges[:20], transitive=True, max_depth=2)

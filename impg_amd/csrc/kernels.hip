@@ -382,6 +382,7 @@ __global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v,
       const bool hit = pos >= lo && pos < ub && ((mask >> ((pos - lo) & 63u)) & 1ull);
       key[i] = hit ? (rv[t] << 6) | i : 0xFFFFFFFFu;
     }
+    if ((q & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);  // four rank vectors in flight at a time, not sixteen
   }
   // bitonic network over the 64 registers, ascending (ranks of hits are distinct)
 #pragma unroll
@@ -392,8 +393,13 @@ __global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v,
       for (uint32_t i = 0; i < 64; i++) {
         const uint32_t l = i ^ j;
         if (l > i) {
-          const uint32_t x = key[i], y = key[l];
-          const uint32_t mn = min(x, y), mx = max(x, y);
+          // one compare-exchange = v_min_u32 + v_max_u32.  Written as a volatile asm pair so that the 672
+          // exchanges stay in program order: left to itself the scheduler interleaves a whole stage and keeps
+          // its 64 inputs and 64 outputs live together (140 VGPRs, 3 waves per SIMD).
+          // (the minimum replaces its first input in place; the maximum takes the one new register, and the
+          //  second input's register is free again)
+          uint32_t mn = key[i], mx;
+          asm volatile("v_max_u32 %1, %0, %2\n\tv_min_u32 %0, %0, %2" : "+v"(mn), "=&v"(mx) : "v"(key[l]));
           key[i] = (i & k) == 0 ? mn : mx;
           key[l] = (i & k) == 0 ? mx : mn;
         }

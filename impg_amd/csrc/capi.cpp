@@ -79,7 +79,7 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
   struct HostLevel {
     std::vector<FrontierRec> fr;
     std::vector<uint32_t> pair_range, qid;
-    std::vector<int32_t> qs, qe, ts, te;
+    std::vector<int4> c;  // {q_first, q_last, t_first, t_last}
     std::vector<uint32_t> sl_pos, sl_n, pool;
   };
   std::vector<HostLevel> hl(levels.size());
@@ -89,14 +89,11 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
     H.fr.resize(L.n_frontier);
     if (L.n_frontier) IMPG_HIP(hipMemcpy(H.fr.data(), L.frontier.p, (size_t)L.n_frontier * sizeof(FrontierRec), hipMemcpyDeviceToHost));
     size_t P = L.n_pairs;
-    H.pair_range.resize(P); H.qid.resize(P); H.qs.resize(P); H.qe.resize(P); H.ts.resize(P); H.te.resize(P);
+    H.pair_range.resize(P); H.qid.resize(P); H.c.resize(P);
     if (P) {
       IMPG_HIP(hipMemcpy(H.pair_range.data(), L.pair_range.p, P * 4, hipMemcpyDeviceToHost));
       IMPG_HIP(hipMemcpy(H.qid.data(), L.qid.p, P * 4, hipMemcpyDeviceToHost));
-      IMPG_HIP(hipMemcpy(H.qs.data(), L.qs.p, P * 4, hipMemcpyDeviceToHost));
-      IMPG_HIP(hipMemcpy(H.qe.data(), L.qe.p, P * 4, hipMemcpyDeviceToHost));
-      IMPG_HIP(hipMemcpy(H.ts.data(), L.ts.p, P * 4, hipMemcpyDeviceToHost));
-      IMPG_HIP(hipMemcpy(H.te.data(), L.te.p, P * 4, hipMemcpyDeviceToHost));
+      IMPG_HIP(hipMemcpy(H.c.data(), L.coords.p, P * 16, hipMemcpyDeviceToHost));
       if (p.store_cigar) {
         H.sl_pos.resize(P); H.sl_n.resize(P); H.pool.resize(L.slice_total);
         IMPG_HIP(hipMemcpy(H.sl_pos.data(), L.slice_pos.p, P * 4, hipMemcpyDeviceToHost));
@@ -109,7 +106,7 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
   auto emitted = [&](const HostLevel &H, size_t k) {
     if (H.qid[k] == HIT_NONE) return false;
     if (skip_same && H.qid[k] == H.fr[H.pair_range[k]].target_id) return false;
-    if (transitive && p.min_output_length >= 0 && std::abs((int64_t)H.qe[k] - H.qs[k]) < p.min_output_length) return false;
+    if (transitive && p.min_output_length >= 0 && std::abs((int64_t)H.c[k].y - H.c[k].x) < p.min_output_length) return false;
     return true;  // impg.rs:2482-2504
   };
   // pass 1: counts
@@ -145,7 +142,7 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
       if (emitted(H, k)) {
         const FrontierRec &f = H.fr[H.pair_range[k]];
         if (res.has_cigar) cg[cur[f.qidx]].assign(H.pool.begin() + H.sl_pos[k], H.pool.begin() + H.sl_pos[k] + H.sl_n[k]);
-        res.intervals[cur[f.qidx]++] = {H.qid[k], H.qs[k], H.qe[k], f.target_id, H.ts[k], H.te[k]};
+        res.intervals[cur[f.qidx]++] = {H.qid[k], H.c[k].x, H.c[k].y, f.target_id, H.c[k].z, H.c[k].w};
       }
   if (res.has_cigar) {
     res.cigar_off.assign(1, 0);
@@ -508,8 +505,8 @@ int stage_project_impl(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_fronti
   L.n_pairs = (uint32_t)total;
   size_t b = std::max<size_t>(total * 4, 256);
   L.pair_range.reserve(b); E.pair_entry.reserve(b);
-  L.qid.reserve(b); L.qs.reserve(b); L.qe.reserve(b); L.ts.reserve(b); L.te.reserve(b);
-  HitArrays h{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
+  L.qid.reserve(b); L.coords.reserve(4 * b);
+  HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
   IMPG_HIP(hipMemsetAsync(E.counters.p, 0, 64, E.stream));
   IMPG_HIP(hipMemsetAsync(E.acc_slots.p, 0, COUNT_BYTES, E.stream));
   E.ev_next = 0;
@@ -618,8 +615,8 @@ int stage_update_impl(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontie
   LevelBufs &L = E.level_scratch;
   L.n_pairs = (uint32_t)n_hits;
   size_t b = std::max<size_t>(n_hits * 4, 256);
-  L.pair_range.reserve(b); L.qid.reserve(b); L.qs.reserve(b); L.qe.reserve(b); L.ts.reserve(b); L.te.reserve(b);
-  HitArrays h{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
+  L.pair_range.reserve(b); L.qid.reserve(b); L.coords.reserve(4 * b);
+  HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
   if (d_hits16) launch_aos16_to_hits(d_hits16, L.n_pairs, L.pair_range.as<uint32_t>(), h, E.stream);  // (target columns unused by the update)
   else launch_aos_to_hits(d_hits, L.n_pairs, L.pair_range.as<uint32_t>(), h, E.stream);
   E.ev_next = 0;

@@ -71,8 +71,8 @@ uint64_t Engine::scan(const uint32_t *in, uint32_t *out, uint32_t n) {
 
 static HitArrays hit_arrays(LevelBufs &L, uint32_t n_pairs) {
   size_t b = std::max<size_t>((size_t)n_pairs * 4, 256);
-  L.qid.reserve(b); L.qs.reserve(b); L.qe.reserve(b); L.ts.reserve(b); L.te.reserve(b);
-  return HitArrays{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
+  L.qid.reserve(b); L.coords.reserve(4 * b);
+  return HitArrays{L.qid.as<uint32_t>(), L.coords.as<int4>()};
 }
 
 // Lookup / projection order: the slots stay in the reference's order, but the count,
@@ -155,16 +155,16 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   if (multi && L.n_pairs) {
     // sort every range's hits by (query_id, q.first, q.last, t.first, t.last) (multi_impg.rs:582-592)
     const size_t b = std::max<size_t>((size_t)L.n_pairs * 4, 256);
-    m_dest.reserve(b); m_qid.reserve(b); m_qs.reserve(b); m_qe.reserve(b); m_ts.reserve(b); m_te.reserve(b); m_pe.reserve(b);
+    m_dest.reserve(b); m_qid.reserve(b); m_coords.reserve(4 * b); m_pe.reserve(b);
     launch_sort5(fr, n_fr, pair_off.as<uint32_t>(), L.n_pairs, h, pair_entry.as<uint32_t>(), v.mrank, m_dest.as<uint32_t>(), stream);
-    HitArrays h2{m_qid.as<uint32_t>(), m_qs.as<int32_t>(), m_qe.as<int32_t>(), m_ts.as<int32_t>(), m_te.as<int32_t>()};
+    HitArrays h2{m_qid.as<uint32_t>(), m_coords.as<int4>()};
     SliceArrays sl2{nullptr, nullptr, nullptr, nullptr};
     if (store_cigar) {
       m_sa.reserve(b); m_sn.reserve(b); m_so.reserve(b); m_sr.reserve(b);
       sl2 = SliceArrays{m_sa.as<uint32_t>(), m_sn.as<uint32_t>(), m_so.as<int32_t>(), m_sr.as<int32_t>()};
     }
     launch_permute_slots(m_dest.as<uint32_t>(), L.n_pairs, h, h2, pair_entry.as<uint32_t>(), m_pe.as<uint32_t>(), sl, sl2, stream);
-    L.qid.swap(m_qid); L.qs.swap(m_qs); L.qe.swap(m_qe); L.ts.swap(m_ts); L.te.swap(m_te);
+    L.qid.swap(m_qid); L.coords.swap(m_coords);
     pair_entry.swap(m_pe);
     if (store_cigar) { L.sl_a.swap(m_sa); L.sl_n.swap(m_sn); L.sl_off.swap(m_so); L.sl_rem.swap(m_sr); }
     h = h2;
@@ -202,7 +202,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
   IMPG_HIP(hipEventRecord(e0, stream));
   const uint32_t P = L.n_pairs;
   uint32_t n_next = 0;
-  HitArrays h{L.qid.as<uint32_t>(), L.qs.as<int32_t>(), L.qe.as<int32_t>(), L.ts.as<int32_t>(), L.te.as<int32_t>()};
+  HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
   if (P) {
     keys.reserve((size_t)P * 8); skeys.reserve((size_t)P * 8);
     vals.reserve((size_t)P * 4); svals.reserve((size_t)P * 4);
@@ -347,7 +347,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     expand(v, cur->as<FrontierRec>(), n_fr, transitive, *L, st);
     L->n_frontier = n_fr;
     if (d_count || d_cksum) {
-      HitArrays h{L->qid.as<uint32_t>(), L->qs.as<int32_t>(), L->qe.as<int32_t>(), L->ts.as<int32_t>(), L->te.as<int32_t>()};
+      HitArrays h{L->qid.as<uint32_t>(), L->coords.as<int4>()};
       launch_hit_stats(cur->as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h,
                        transitive ? p.min_output_length : -1, false, d_count, d_cksum, stream);
     }
@@ -477,7 +477,7 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
       expand(v, frontier_b.as<FrontierRec>(), n_fr, true, *L, st);
       L->n_frontier = n_fr;
       if (d_count || d_cksum) {
-        HitArrays h{L->qid.as<uint32_t>(), L->qs.as<int32_t>(), L->qe.as<int32_t>(), L->ts.as<int32_t>(), L->te.as<int32_t>()};
+        HitArrays h{L->qid.as<uint32_t>(), L->coords.as<int4>()};
         launch_hit_stats(frontier_b.as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h, p.min_output_length,
                          multi, d_count, d_cksum, stream);
       }

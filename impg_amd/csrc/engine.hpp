@@ -8,7 +8,7 @@
 namespace impg {
 
 struct LevelBufs {  // one BFS level: its frontier and its hit slots
-  DevBuf frontier, pair_range, qid, qs, qe, ts, te;
+  DevBuf frontier, pair_range, qid, coords;  // coords: {q_first, q_last, t_first, t_last} per slot (16 B)
   // store_cigar: slice descriptors per slot, then the materialised slices
   DevBuf sl_a, sl_n, sl_off, sl_rem, slice_pos, slice_pool;
   uint64_t slice_total = 0;
@@ -45,7 +45,7 @@ struct Engine {
   double min_identity = __builtin_nan("");  // of the batch / stage call in flight
   bool store_cigar = false;
   bool multi = false;       // MultiImpg semantics for the batch in flight (params.multi_impg)
-  DevBuf m_dest, m_qid, m_qs, m_qe, m_ts, m_te, m_pe, m_sa, m_sn, m_so, m_sr;  // 5-key sort: destination + double buffers
+  DevBuf m_dest, m_qid, m_coords, m_pe, m_sa, m_sn, m_so, m_sr;  // 5-key sort: destination + double buffers
   // projection order (locality): ranges sorted by window position, their slots listed in that order
   DevBuf wide_n, wide_list;  // ranges whose window is wider than the lane-per-range emit pass takes
   DevBuf lo_key, lo_key2, lo_idx, lo_perm, lo_cnt, lo_off, lo_offp, slot_of;

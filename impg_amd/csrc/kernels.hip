@@ -1045,10 +1045,7 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
     }
     h.qid[p] = qid;
     if (ok) {
-      h.qs[p] = res.pqs;
-      h.qe[p] = res.pqe;
-      h.ts[p] = res.pts;
-      h.te[p] = res.pte;
+      h.c[p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
     }
   }
   // accepted-projection count: one atomic per BLOCK, spread over COUNT_SLOTS
@@ -1115,13 +1112,14 @@ __global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__res
   if (p >= n_pairs) return;
   const uint32_t qid = h.qid[p];
   if (qid == HIT_NONE) return;
-  const int32_t qs = h.qs[p], qe = h.qe[p];
+  const int4 hc = h.c[p];
+  const int32_t qs = hc.x, qe = hc.y;
   if (min_output_length >= 0 && abs(qe - qs) < min_output_length) return;
   const FrontierRec f = fr[pair_range[p]];
   if (skip_same_target && qid == f.target_id) return;  // multi_impg.rs:883-885
   unsigned long long a = mix64(((unsigned long long)qid << 32) | (uint32_t)qs);
   a = mix64(a ^ (((unsigned long long)(uint32_t)qe << 32) | f.target_id));
-  a = mix64(a ^ (((unsigned long long)(uint32_t)h.ts[p] << 32) | (uint32_t)h.te[p]));
+  a = mix64(a ^ (((unsigned long long)(uint32_t)hc.z << 32) | (uint32_t)hc.w));
   if (count) atomicAdd(&count[f.qidx], 1ull);
   if (cksum) atomicAdd(&cksum[f.qidx], a);
 }
@@ -1256,7 +1254,8 @@ __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, co
   const uint32_t st = gstart[g], n = glen[g];
   for (uint32_t t = 0; t < n; t++) {
     const uint32_t p = svals[st + t];
-    const int32_t a = h.qs[p], b = h.qe[p];
+    const int4 hc = h.c[p];
+    const int32_t a = hc.x, b = hc.y;
     int32_t start = min(a, b), end = max(a, b);
     bool should_add = true;
     if (mdbr > 0) {  // impg.rs:2513-2545
@@ -1408,10 +1407,11 @@ __global__ __launch_bounds__(256) void hits_to_aos_kernel(const uint32_t *__rest
   x.fidx = pair_range[p];
   x.query_id = h.qid[p];
   const bool okk = x.query_id != HIT_NONE;
-  x.q_first = okk ? h.qs[p] : 0;
-  x.q_last = okk ? h.qe[p] : 0;
-  x.t_first = okk ? h.ts[p] : 0;
-  x.t_last = okk ? h.te[p] : 0;
+  const int4 hc = okk ? h.c[p] : make_int4(0, 0, 0, 0);
+  x.q_first = hc.x;
+  x.q_last = hc.y;
+  x.t_first = hc.z;
+  x.t_last = hc.w;
   x.order = p - pair_off[x.fidx];
   x.pad = 0;
   out[p] = x;
@@ -1425,8 +1425,9 @@ __global__ __launch_bounds__(256) void hits_to_aos16_kernel(const uint32_t *__re
   x.fidx = pair_range[p];
   x.query_id = h.qid[p];
   const bool okk = x.query_id != HIT_NONE;
-  x.q_first = okk ? h.qs[p] : 0;
-  x.q_last = okk ? h.qe[p] : 0;
+  const int4 hc = okk ? h.c[p] : make_int4(0, 0, 0, 0);
+  x.q_first = hc.x;
+  x.q_last = hc.y;
   out[p] = x;
 }
 __global__ __launch_bounds__(256) void aos16_to_hits_kernel(const impg_gpu_hit16_t *__restrict__ in, uint32_t n,
@@ -1436,8 +1437,7 @@ __global__ __launch_bounds__(256) void aos16_to_hits_kernel(const impg_gpu_hit16
   const impg_gpu_hit16_t x = in[p];
   pair_range[p] = x.fidx;
   h.qid[p] = x.query_id;
-  h.qs[p] = x.q_first;
-  h.qe[p] = x.q_last;
+  h.c[p] = make_int4(x.q_first, x.q_last, 0, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1476,7 +1476,8 @@ __global__ __launch_bounds__(256) void sort5_kernel(const FrontierRec *__restric
       if (i < b) {
         q = h.qid[i];
         if (q != HIT_NONE) {
-          k1 = h.qs[i]; k2 = h.qe[i]; k3 = h.ts[i]; k4 = h.te[i];
+          const int4 hc = h.c[i];
+          k1 = hc.x; k2 = hc.y; k3 = hc.z; k4 = hc.w;
           km = mrank[pair_entry[i]];
           // is_self (multi_impg.rs:558-562): equal to the step's own interval -> dropped
           if (q == f.target_id && k1 == f.start && k2 == f.end) { q = HIT_NONE; h.qid[i] = HIT_NONE; k1 = k2 = k3 = k4 = 0; km = 0; }
@@ -1490,7 +1491,8 @@ __global__ __launch_bounds__(256) void sort5_kernel(const FrontierRec *__restric
         if (i2 < b) {
           q2 = h.qid[i2];
           if (q2 != HIT_NONE) {
-            j1 = h.qs[i2]; j2 = h.qe[i2]; j3 = h.ts[i2]; j4 = h.te[i2];
+            const int4 hc = h.c[i2];
+            j1 = hc.x; j2 = hc.y; j3 = hc.z; j4 = hc.w;
             jm = mrank[pair_entry[i2]];
             if (q2 == f.target_id && j1 == f.start && j2 == f.end) { q2 = HIT_NONE; j1 = j2 = j3 = j4 = 0; jm = 0; }
           }
@@ -1514,7 +1516,7 @@ __global__ __launch_bounds__(256) void permute_slots_kernel(const uint32_t *__re
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   if (p >= n_pairs) return;
   const uint32_t d = dest[p];
-  out.qid[d] = in.qid[p]; out.qs[d] = in.qs[p]; out.qe[d] = in.qe[p]; out.ts[d] = in.ts[p]; out.te[d] = in.te[p];
+  out.qid[d] = in.qid[p]; out.c[d] = in.c[p];
   pe_out[d] = pe_in[p];
   if (sin.a) { sout.a[d] = sin.a[p]; sout.n[d] = sin.n[p]; sout.off[d] = sin.off[p]; sout.rem[d] = sin.rem[p]; }
 }
@@ -1712,10 +1714,7 @@ __global__ __launch_bounds__(256) void aos_to_hits_kernel(const impg_gpu_hit_t *
   const impg_gpu_hit_t x = in[p];
   pair_range[p] = x.fidx;
   h.qid[p] = x.query_id;
-  h.qs[p] = x.q_first;
-  h.qe[p] = x.q_last;
-  h.ts[p] = x.t_first;
-  h.te[p] = x.t_last;
+  h.c[p] = make_int4(x.q_first, x.q_last, x.t_first, x.t_last);
 }
 
 // ---------------------------------------------------------------------------

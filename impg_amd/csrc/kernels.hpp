@@ -11,9 +11,9 @@ namespace impg {
 typedef impg_gpu_frontier_t FrontierRec;  // {target_id, start, end, qidx}, 16 B
 
 // one level's hits, SoA, indexed by pair slot (slot order = frontier order x visit order)
-struct HitArrays {
-  uint32_t *qid;  // HIT_NONE = projection returned None
-  int32_t *qs, *qe, *ts, *te;
+struct HitArrays {  // one level's hit slots: the query id (0xFFFFFFFF = no hit) and {q_first, q_last, t_first, t_last}
+  uint32_t *qid;
+  int4 *c;          // one 16-byte store / load per slot instead of four scattered 4-byte ones
 };
 
 // store_cigar: which ops of the record form each slot's projected slice

@@ -205,14 +205,14 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
   HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
   if (P) {
     keys.reserve((size_t)P * 8); skeys.reserve((size_t)P * 8);
-    vals.reserve((size_t)P * 4); svals.reserve((size_t)P * 4);
+    vals.reserve((size_t)P * 8); svals.reserve((size_t)P * 8);
     IMPG_HIP(hipMemsetAsync(act_slots.p, 0, COUNT_BYTES, stream));
-    launch_update_keys(fr, L.pair_range.as<uint32_t>(), P, h, keys.as<unsigned long long>(), vals.as<uint32_t>(),
+    launch_update_keys(fr, L.pair_range.as<uint32_t>(), P, h, keys.as<unsigned long long>(), vals.as<unsigned long long>(),
                        act_slots.as<unsigned long long>(), stream);
-    size_t tb = sort_pairs_scratch_bytes(P);
+    size_t tb = sort_u64v_scratch_bytes(P);
     sort_tmp.reserve(tb);
-    launch_sort_pairs(sort_tmp.p, tb, keys.as<unsigned long long>(), skeys.as<unsigned long long>(), vals.as<uint32_t>(),
-                      svals.as<uint32_t>(), P, 32 + std::max(1u, bits_for(n_queries)), stream);
+    launch_sort_u64v(sort_tmp.p, tb, keys.as<unsigned long long>(), skeys.as<unsigned long long>(), vals.as<unsigned long long>(),
+                     svals.as<unsigned long long>(), P, stream, 32 + std::max(1u, bits_for(n_queries)));
     head.reserve((size_t)P * 4); gid.reserve((size_t)P * 4);
     launch_group_heads(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), stream);
     uint32_t n_groups = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), P);
@@ -240,7 +240,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       pieces.reserve(std::max<size_t>(pcap_total * 8, 256));
       n_pieces.reserve((size_t)n_groups * 4);
       foff.reserve((size_t)n_groups * 4);
-      launch_visited_update(tabs, svals.as<uint32_t>(), h, v.seq_len, vt->keys.as<unsigned long long>(),
+      launch_visited_update(tabs, svals.as<unsigned long long>(), v.seq_len, vt->keys.as<unsigned long long>(),
                             gstart.as<uint32_t>(), glen.as<uint32_t>(), old_tab.as<uint32_t>(), old_idx.as<uint32_t>(),
                             vt->off.as<uint32_t>(), poff.as<uint32_t>(), n_groups, p.min_transitive_len,
                             p.min_distance_between_ranges, vt->ranges.as<int2>(), vt->len.as<uint32_t>(),

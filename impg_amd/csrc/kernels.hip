@@ -1130,18 +1130,26 @@ __global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__res
 __global__ __launch_bounds__(256) void update_keys_kernel(const FrontierRec *__restrict__ fr,
                                                           const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
                                                           HitArrays h, unsigned long long *__restrict__ keys,
-                                                          uint32_t *__restrict__ vals,
+                                                          unsigned long long *__restrict__ vals,
                                                           unsigned long long *__restrict__ n_active) {
+  // the sort's payload is the hit's normalised query interval itself (start << 32 | end), all the update
+  // reads of a hit: carried as a slot index, every group paid a random 16-byte gather for it (60 % of
+  // visited_update).  A stable sort keeps equal keys in slot order = the reference's processing order.
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   unsigned long long k = ~0ull;
   if (p < n_pairs) {
     const uint32_t qid = h.qid[p];
+    unsigned long long v = 0;
     if (qid != HIT_NONE) {
       const FrontierRec f = fr[pair_range[p]];
-      if (qid != f.target_id) k = ((unsigned long long)f.qidx << 32) | qid;  // impg.rs:2507
+      if (qid != f.target_id) {  // impg.rs:2507
+        k = ((unsigned long long)f.qidx << 32) | qid;
+        const int4 hc = h.c[p];
+        v = ((unsigned long long)(uint32_t)min(hc.x, hc.y) << 32) | (uint32_t)max(hc.x, hc.y);
+      }
     }
     keys[p] = k;
-    vals[p] = p;
+    vals[p] = v;
   }
   __shared__ uint32_t wcnt[4];
   unsigned long long m = __ballot(k != ~0ull);
@@ -1226,8 +1234,8 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
 // one thread per (query, sequence) group: replay the group's hits in emission
 // order against its visited list (SortedRanges::insert with min_distance = 0,
 // impg.rs:270-368), collect the new pieces
-__global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, const uint32_t *__restrict__ svals,
-                                                            HitArrays h, const int32_t *__restrict__ seq_len,
+__global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, const unsigned long long *__restrict__ svals,
+                                                            const int32_t *__restrict__ seq_len,
                                                             const unsigned long long *__restrict__ gkey,
                                                             const uint32_t *__restrict__ gstart,
                                                             const uint32_t *__restrict__ glen,
@@ -1253,10 +1261,8 @@ __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, co
   uint32_t np = 0;
   const uint32_t st = gstart[g], n = glen[g];
   for (uint32_t t = 0; t < n; t++) {
-    const uint32_t p = svals[st + t];
-    const int4 hc = h.c[p];
-    const int32_t a = hc.x, b = hc.y;
-    int32_t start = min(a, b), end = max(a, b);
+    const unsigned long long iv = svals[st + t];  // (min, max) of the hit's query interval, packed by update_keys
+    int32_t start = (int32_t)(uint32_t)(iv >> 32), end = (int32_t)(uint32_t)iv;
     bool should_add = true;
     if (mdbr > 0) {  // impg.rs:2513-2545
       const uint32_t idx = lower_bound_start(R, len, start);
@@ -1803,7 +1809,7 @@ void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_
                                                      count, cksum);
 }
 void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
-                        unsigned long long *keys, uint32_t *vals, unsigned long long *n_active, hipStream_t s) {
+                        unsigned long long *keys, unsigned long long *vals, unsigned long long *n_active, hipStream_t s) {
   if (!n_pairs) return;
   update_keys_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, keys, vals, n_active);
 }
@@ -1834,13 +1840,13 @@ void launch_group_prepare(const VisitedTables &vt, const unsigned long long *gke
   if (!n_groups) return;
   group_prepare_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(vt, gkey, gstart, n_groups, n_active, glen, old_tab, old_idx, cap, pcap);
 }
-void launch_visited_update(const VisitedTables &vt, const uint32_t *svals, HitArrays h, const int32_t *seq_len,
+void launch_visited_update(const VisitedTables &vt, const unsigned long long *svals, const int32_t *seq_len,
                            const unsigned long long *gkey, const uint32_t *gstart, const uint32_t *glen,
                            const uint32_t *old_tab, const uint32_t *old_idx, const uint32_t *noff, const uint32_t *poff,
                            uint32_t n_groups, int32_t min_transitive_len, int32_t mdbr, int2 *new_ranges,
                            uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, hipStream_t s) {
   if (!n_groups) return;
-  visited_update_kernel<<<cdiv(n_groups, 64), 64, 0, s>>>(vt, svals, h, seq_len, gkey, gstart, glen, old_tab, old_idx, noff,
+  visited_update_kernel<<<cdiv(n_groups, 64), 64, 0, s>>>(vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff,
                                                           poff, n_groups, min_transitive_len, mdbr, new_ranges, new_len,
                                                           pieces, n_pieces);
 }
@@ -1939,9 +1945,9 @@ size_t sort_u64v_scratch_bytes(uint32_t n) {
   return bytes;
 }
 void launch_sort_u64v(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
-                      const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s) {
+                      const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s, unsigned end_bit) {
   if (!n) return;
-  IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, 64, s));
+  IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s));
 }
 void launch_compact_fill(const unsigned long long *keys, uint32_t n, uint32_t table, unsigned long long *key_out,
                          unsigned long long *src_out, hipStream_t s) {

@@ -75,7 +75,7 @@ void launch_sort5(const FrontierRec *fr, uint32_t n, const uint32_t *pair_off, u
 void launch_permute_slots(const uint32_t *dest, uint32_t n_pairs, HitArrays in, HitArrays out, const uint32_t *pe_in,
                           uint32_t *pe_out, SliceArrays sin, SliceArrays sout, hipStream_t s);
 void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
-                        unsigned long long *keys, uint32_t *vals, unsigned long long *n_active, hipStream_t s);
+                        unsigned long long *keys, unsigned long long *vals, unsigned long long *n_active, hipStream_t s);
 size_t sort_pairs_scratch_bytes(uint32_t n);
 void launch_sort_pairs(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
                        const uint32_t *vin, uint32_t *vout, uint32_t n, unsigned end_bit, hipStream_t s);
@@ -85,7 +85,7 @@ void launch_group_scatter(const unsigned long long *skeys, uint32_t n, const uin
 void launch_group_prepare(const VisitedTables &vt, const unsigned long long *gkey, const uint32_t *gstart,
                           uint32_t n_groups, uint32_t n_active, uint32_t *glen, uint32_t *old_tab, uint32_t *old_idx,
                           uint32_t *cap, uint32_t *pcap, hipStream_t s);
-void launch_visited_update(const VisitedTables &vt, const uint32_t *svals, HitArrays h, const int32_t *seq_len,
+void launch_visited_update(const VisitedTables &vt, const unsigned long long *svals, const int32_t *seq_len,
                            const unsigned long long *gkey, const uint32_t *gstart, const uint32_t *glen,
                            const uint32_t *old_tab, const uint32_t *old_idx, const uint32_t *noff, const uint32_t *poff,
                            uint32_t n_groups, int32_t min_transitive_len, int32_t mdbr, int2 *new_ranges,
@@ -125,7 +125,7 @@ void launch_sort_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t 
                      uint32_t n, hipStream_t s, unsigned begin_bit = 0, unsigned end_bit = 32);
 size_t sort_u64v_scratch_bytes(uint32_t n);
 void launch_sort_u64v(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
-                      const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s);
+                      const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s, unsigned end_bit = 64);
 void launch_compact_fill(const unsigned long long *keys, uint32_t n, uint32_t table, unsigned long long *key_out,
                          unsigned long long *src_out, hipStream_t s);
 void launch_compact_last(const unsigned long long *skeys, uint32_t n, uint32_t *flag, hipStream_t s);

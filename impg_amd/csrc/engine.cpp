@@ -211,8 +211,16 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
                        act_slots.as<unsigned long long>(), stream);
     size_t tb = sort_u64v_scratch_bytes(P);
     sort_tmp.reserve(tb);
+    // key = qidx << 32 | sequence id (all ones for a hit without a key): the bits between the sequence id and
+    // the query index are zero, so two stable sorts -- the sequence-id bits, then the query bits plus the one
+    // above them that only the all-ones keys have -- order the keys in 4 radix passes instead of 6
+    const unsigned sbits = std::max(1u, bits_for(v.n_seq)), qbits = std::max(1u, bits_for(n_queries));
     launch_sort_u64v(sort_tmp.p, tb, keys.as<unsigned long long>(), skeys.as<unsigned long long>(), vals.as<unsigned long long>(),
-                     svals.as<unsigned long long>(), P, stream, 32 + std::max(1u, bits_for(n_queries)));
+                     svals.as<unsigned long long>(), P, stream, sbits, 0);
+    launch_sort_u64v(sort_tmp.p, tb, skeys.as<unsigned long long>(), keys.as<unsigned long long>(), svals.as<unsigned long long>(),
+                     vals.as<unsigned long long>(), P, stream, std::min(64u, 32 + qbits + 1), 32);
+    keys.swap(skeys);
+    vals.swap(svals);
     head.reserve((size_t)P * 4); gid.reserve((size_t)P * 4);
     launch_group_heads(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), stream);
     uint32_t n_groups = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), P);

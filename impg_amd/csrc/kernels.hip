@@ -1945,9 +1945,10 @@ size_t sort_u64v_scratch_bytes(uint32_t n) {
   return bytes;
 }
 void launch_sort_u64v(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
-                      const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s, unsigned end_bit) {
+                      const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s, unsigned end_bit,
+                      unsigned begin_bit) {
   if (!n) return;
-  IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s));
+  IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s));
 }
 void launch_compact_fill(const unsigned long long *keys, uint32_t n, uint32_t table, unsigned long long *key_out,
                          unsigned long long *src_out, hipStream_t s) {

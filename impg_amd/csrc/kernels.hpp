@@ -125,7 +125,8 @@ void launch_sort_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t 
                      uint32_t n, hipStream_t s, unsigned begin_bit = 0, unsigned end_bit = 32);
 size_t sort_u64v_scratch_bytes(uint32_t n);
 void launch_sort_u64v(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
-                      const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s, unsigned end_bit = 64);
+                      const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s, unsigned end_bit = 64,
+                      unsigned begin_bit = 0);
 void launch_compact_fill(const unsigned long long *keys, uint32_t n, uint32_t table, unsigned long long *key_out,
                          unsigned long long *src_out, hipStream_t s);
 void launch_compact_last(const unsigned long long *skeys, uint32_t n, uint32_t *flag, hipStream_t s);

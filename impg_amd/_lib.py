@@ -58,6 +58,11 @@ def build(force=False):
     return LIB_PATH
 
 
+class Mask(C.Structure):  # impg_gpu_mask_t
+    _fields_ = [("n_seqs", C.c_uint32), ("seq_id", C.c_void_p), ("sequence_length", C.c_void_p),
+                ("range_off", C.c_void_p), ("ranges", C.c_void_p)]
+
+
 # every symbol include/impg_gpu.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = [
@@ -84,6 +89,7 @@ SYMBOLS = [
     ("impg_gpu_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("impg_gpu_visit_rank", C.c_int, [C.c_uint32, C.c_int, _P]),
     ("impg_gpu_query_batch", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), C.POINTER(_P)]),
+    ("impg_gpu_query_batch_masked", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, C.POINTER(_P)]),
     ("impg_gpu_query", C.c_int, [_P, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params), C.POINTER(_P)]),
     ("impg_gpu_results_num_ranges", C.c_size_t, [_P]),
     ("impg_gpu_results_total", C.c_size_t, [_P]),

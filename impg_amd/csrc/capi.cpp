@@ -71,10 +71,19 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
                       std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, impg_gpu_results &res) {
   const bool transitive = p.transitive != 0;
   res.ranges.assign(h_ranges, h_ranges + n);
+  // self intervals: one per query (empty ones dropped below), or under masked_regions the pieces the mask left
   std::vector<FrontierRec> self;
-  if (transitive) {
+  std::vector<uint32_t> self_off;
+  if (transitive && E.masked) {
+    self.resize(E.n_self);
+    self_off.assign(n + 1, (uint32_t)E.n_self);
+    if (n) IMPG_HIP(hipMemcpy(self_off.data(), E.self_off.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (E.n_self) IMPG_HIP(hipMemcpy(self.data(), self_dev.p, (size_t)E.n_self * sizeof(FrontierRec), hipMemcpyDeviceToHost));
+  } else if (transitive) {
     self.resize(n);
     if (n) IMPG_HIP(hipMemcpy(self.data(), self_dev.p, (size_t)n * sizeof(FrontierRec), hipMemcpyDeviceToHost));
+    self_off.resize(n + 1);
+    for (uint32_t q = 0; q <= n; q++) self_off[q] = q;
   }
   struct HostLevel {
     std::vector<FrontierRec> fr;
@@ -113,7 +122,7 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
   std::vector<uint64_t> cnt(n + 1, 0);
   for (uint32_t q = 0; q < n; q++) {
     if (!transitive) cnt[q] = 1;                                   // impg.rs:1864-1880
-    else cnt[q] = self[q].start < self[q].end ? 1 : 0;             // impg.rs:2345-2363
+    else for (uint32_t k = self_off[q]; k < self_off[q + 1]; k++) cnt[q] += self[k].start < self[k].end ? 1 : 0;  // impg.rs:2345-2363
   }
   for (auto &H : hl)
     for (size_t k = 0; k < H.qid.size(); k++)
@@ -131,9 +140,11 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
       const auto &r = h_ranges[q];
       if (res.has_cigar) cg[cur[q]] = {(uint32_t)(r.end - r.start)};  // vec![CigarOp::new(range_end - range_start, '=')] (impg.rs:1870-1872)
       res.intervals[cur[q]++] = {r.target_id, r.start, r.end, r.target_id, r.start, r.end};
-    } else if (self[q].start < self[q].end) {
-      if (res.has_cigar) cg[cur[q]] = {(uint32_t)(self[q].end - self[q].start)};  // impg.rs:2352-2354
-      res.intervals[cur[q]++] = {self[q].target_id, self[q].start, self[q].end, self[q].target_id, self[q].start, self[q].end};
+    } else for (uint32_t k = self_off[q]; k < self_off[q + 1]; k++) {
+      const FrontierRec &f = self[k];
+      if (f.start >= f.end) continue;
+      if (res.has_cigar) cg[cur[q]] = {(uint32_t)(f.end - f.start)};  // impg.rs:2352-2354
+      res.intervals[cur[q]++] = {f.target_id, f.start, f.end, f.target_id, f.start, f.end};
     }
   }
   // pass 2: levels in order, slots in order == the reference's emission order
@@ -309,14 +320,68 @@ int impg_gpu_visit_rank(uint32_t n, int order_policy, uint32_t *rank_out) {
   IMPG_CATCH
 }
 
+namespace {
+// masked_regions -> the engine's device tables; cleared again when the call ends
+struct MaskScope {
+  Engine &E;
+  MaskScope(Engine &e, const impg_gpu_index &ix, const impg_gpu_mask_t *m, const impg_gpu_params_t &p) : E(e) {
+    if (!m) return;
+    if (!p.transitive) throw Error{IMPG_E_INVALID, "masked_regions belong to the transitive queries"};
+    const uint32_t n_seq = ix.view.n_seq;
+    if (m->n_seqs && (!m->seq_id || !m->sequence_length || !m->range_off)) throw Error{IMPG_E_INVALID, "null mask array"};
+    const uint64_t total = m->n_seqs ? m->range_off[m->n_seqs] : 0;
+    if (total >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "mask exceeds 2^32 ranges"};
+    if (total && !m->ranges) throw Error{IMPG_E_INVALID, "null mask array"};
+    std::vector<uint32_t> off(n_seq + 1, 0);
+    // a sequence absent from the map: Impg starts its set with length 0 (visited_entry, impg.rs:2048-2053), MultiImpg
+    // with the real length (multi_impg.rs:919-922) except for the query's own target (entry().or_default(), :827-830)
+    std::vector<int32_t> init_len(n_seq, 0), touch_len(n_seq, 0);
+    if (p.multi_impg) for (uint32_t s = 0; s < n_seq; s++) touch_len[s] = (int32_t)std::min<int64_t>(std::max<int64_t>(ix.seq.lens[s], 0), INT32_MAX);
+    for (uint32_t i = 0; i < m->n_seqs; i++) {
+      const uint32_t s = m->seq_id[i];
+      if (s >= n_seq) throw Error{IMPG_E_INVALID, "mask names an unknown sequence id"};
+      if (i && s <= m->seq_id[i - 1]) throw Error{IMPG_E_INVALID, "mask sequence ids must be strictly ascending"};
+      if (m->range_off[i + 1] < m->range_off[i]) throw Error{IMPG_E_INVALID, "mask offsets must not decrease"};
+      off[s + 1] = (uint32_t)(m->range_off[i + 1] - m->range_off[i]);
+      init_len[s] = touch_len[s] = m->sequence_length[i];
+      for (uint64_t k = m->range_off[i]; k < m->range_off[i + 1]; k++) {
+        const int32_t a = m->ranges[2 * k], b = m->ranges[2 * k + 1];
+        if (a > b || (k > m->range_off[i] && a <= m->ranges[2 * k - 1]))  // SortedRanges invariant (impg.rs:330-368)
+          throw Error{IMPG_E_INVALID, "mask ranges must be sorted, disjoint and non-touching"};
+      }
+    }
+    for (uint32_t s = 0; s < n_seq; s++) off[s + 1] += off[s];
+    // m->ranges is already in sequence-id order
+    E.mask_off.reserve((size_t)(n_seq + 1) * 4);
+    E.mask_ranges.reserve(std::max<size_t>(total * 8, 256));
+    E.mask_init_len.reserve(std::max<size_t>((size_t)n_seq * 4, 256));
+    E.mask_touch_len.reserve(std::max<size_t>((size_t)n_seq * 4, 256));
+    IMPG_HIP(hipMemcpy(E.mask_off.p, off.data(), (size_t)(n_seq + 1) * 4, hipMemcpyHostToDevice));
+    if (total) IMPG_HIP(hipMemcpy(E.mask_ranges.p, m->ranges, total * 8, hipMemcpyHostToDevice));
+    if (n_seq) {
+      IMPG_HIP(hipMemcpy(E.mask_init_len.p, init_len.data(), (size_t)n_seq * 4, hipMemcpyHostToDevice));
+      IMPG_HIP(hipMemcpy(E.mask_touch_len.p, touch_len.data(), (size_t)n_seq * 4, hipMemcpyHostToDevice));
+    }
+    E.masked = true;
+  }
+  ~MaskScope() { E.masked = false; }
+};
+}  // namespace
+
 int impg_gpu_query_batch(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
                          impg_gpu_results_t **out) {
+  return impg_gpu_query_batch_masked(ix, ranges, n, params, nullptr, out);
+}
+
+int impg_gpu_query_batch_masked(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n,
+                                const impg_gpu_params_t *params, const impg_gpu_mask_t *mask, impg_gpu_results_t **out) {
   IMPG_TRY
   if (!ix || !params || !out || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
   check_ranges(ranges, n);
   Engine &E = *ix->engine;
   Engine::check_params(*params);
   IMPG_HIP(hipSetDevice(ix->device));
+  MaskScope mask_scope(E, *ix, mask, *params);
   auto res = std::make_unique<impg_gpu_results>();
   E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
   if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));

@@ -248,7 +248,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       pieces.reserve(std::max<size_t>(pcap_total * 8, 256));
       n_pieces.reserve((size_t)n_groups * 4);
       foff.reserve((size_t)n_groups * 4);
-      launch_visited_update(tabs, svals.as<unsigned long long>(), v.seq_len, vt->keys.as<unsigned long long>(),
+      launch_visited_update(tabs, svals.as<unsigned long long>(), masked ? mask_touch_len.as<int32_t>() : v.seq_len, vt->keys.as<unsigned long long>(),
                             gstart.as<uint32_t>(), glen.as<uint32_t>(), old_tab.as<uint32_t>(), old_idx.as<uint32_t>(),
                             vt->off.as<uint32_t>(), poff.as<uint32_t>(), n_groups, p.min_transitive_len,
                             p.min_distance_between_ranges, vt->ranges.as<int2>(), vt->len.as<uint32_t>(),
@@ -280,6 +280,10 @@ VisitedTables Engine::tables_view() const {
     t.t[i].ranges = tables[i]->ranges.as<int2>();
     t.t[i].n_groups = tables[i]->n_groups;
   }
+  if (masked) {
+    t.mask_off = mask_off.as<uint32_t>();
+    t.mask_ranges = mask_ranges.as<int2>();
+  }
   return t;
 }
 
@@ -296,6 +300,37 @@ uint32_t Engine::begin_transitive(const DeviceIndexView &v, const impg_gpu_range
   uint32_t n_fr = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), n);
   frontier_out.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
   launch_compact_frontier(d_self, head.as<uint32_t>(), gid.as<uint32_t>(), n, frontier_out.as<FrontierRec>(), stream);
+  tables.push_back(std::move(t));
+  return n_fr;
+}
+
+// level -1 under masked_regions: table 0 holds every query's (query, target) list = its target's mask list with
+// the input range inserted; `self` receives the pieces (CSR in self_off / n_self), the long ones open the frontier
+uint32_t Engine::begin_transitive_masked(const DeviceIndexView &v, const impg_gpu_range_t *d_ranges, uint32_t n,
+                                         const impg_gpu_params_t &p, DevBuf &self, DevBuf &frontier_out) {
+  tables.clear();
+  auto t = std::make_unique<VisitedStore>();
+  t->keys.reserve((size_t)n * 8); t->off.reserve((size_t)n * 4 + 4); t->len.reserve((size_t)n * 4);
+  t->n_groups = n;
+  cap.reserve((size_t)n * 4);
+  launch_mask_caps(d_ranges, n, mask_off.as<uint32_t>(), v.n_seq, cap.as<uint32_t>(), stream);
+  const uint64_t total = scan(cap.as<uint32_t>(), t->off.as<uint32_t>(), n);
+  if (total >= 0xFFFFFFF0ull) { if (split_ok) throw SplitBatch{}; throw Error{IMPG_E_UNSUPPORTED, "visited sets exceed 2^32 ranges"}; }
+  t->ranges.reserve(std::max<size_t>(total * 8, 256));
+  pieces.reserve(std::max<size_t>(total * 8, 256));
+  n_pieces.reserve((size_t)n * 4); head.reserve((size_t)n * 4); gid.reserve((size_t)n * 4);
+  self_off.reserve((size_t)n * 4 + 4);
+  launch_visited_init_masked(d_ranges, n, mask_init_len.as<int32_t>(), v.n_seq, mask_off.as<uint32_t>(), mask_ranges.as<int2>(),
+                             p.min_transitive_len, t->off.as<uint32_t>(), t->keys.as<unsigned long long>(),
+                             t->len.as<uint32_t>(), t->ranges.as<int2>(), pieces.as<int2>(), n_pieces.as<uint32_t>(),
+                             head.as<uint32_t>(), stream);
+  n_self = scan(n_pieces.as<uint32_t>(), self_off.as<uint32_t>(), n);
+  const uint32_t n_fr = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), n);
+  self.reserve(std::max<size_t>((size_t)n_self * sizeof(FrontierRec), 256));
+  frontier_out.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
+  launch_masked_self_emit(d_ranges, n, t->off.as<uint32_t>(), n_pieces.as<uint32_t>(), self_off.as<uint32_t>(),
+                          gid.as<uint32_t>(), p.min_transitive_len, pieces.as<int2>(), self.as<FrontierRec>(),
+                          frontier_out.as<FrontierRec>(), stream);
   tables.push_back(std::move(t));
   return n_fr;
 }
@@ -341,7 +376,8 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   } else {
     DevBuf &self = self_out ? *self_out : self_scratch;
     self.reserve(std::max<size_t>((size_t)n * sizeof(FrontierRec), 256));
-    n_fr = begin_transitive(v, d_ranges, n, p, self.as<FrontierRec>(), *cur);
+    n_fr = masked ? begin_transitive_masked(v, d_ranges, n, p, self, *cur)
+                  : begin_transitive(v, d_ranges, n, p, self.as<FrontierRec>(), *cur);
   }
 
   uint32_t depth = 0;
@@ -452,7 +488,8 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
   IMPG_HIP(hipEventRecord(t0, stream));
   DevBuf &self = self_out ? *self_out : self_scratch;
   self.reserve(std::max<size_t>((size_t)n * sizeof(FrontierRec), 256));
-  uint32_t n_stack = begin_transitive(v, d_ranges, n, p, self.as<FrontierRec>(), frontier_a);
+  uint32_t n_stack = masked ? begin_transitive_masked(v, d_ranges, n, p, self, frontier_a)
+                            : begin_transitive(v, d_ranges, n, p, self.as<FrontierRec>(), frontier_a);
   auto res4 = [&](DevBuf &k, DevBuf &s, DevBuf &e, DevBuf &d, size_t m) {
     k.reserve(std::max<size_t>(m * 8, 256)); s.reserve(std::max<size_t>(m * 4, 256));
     e.reserve(std::max<size_t>(m * 4, 256)); d.reserve(std::max<size_t>(m * 4, 256));

@@ -81,6 +81,14 @@ struct Engine {
   // level -1 of a transitive batch: visited table 0, self intervals, frontier 0
   uint32_t begin_transitive(const DeviceIndexView &v, const impg_gpu_range_t *d_ranges, uint32_t n,
                             const impg_gpu_params_t &p, FrontierRec *d_self, DevBuf &frontier_out);
+  // masked_regions of the batch in flight (capi sets these around Engine::run): CSR over the sequence ids, the
+  // sequence length a set starts with at level -1 / on first touch (visited_entry, impg.rs:2041-2055)
+  bool masked = false;
+  DevBuf mask_off, mask_ranges, mask_init_len, mask_touch_len;
+  DevBuf self_off;        // masked batches: query q's self intervals are self[self_off[q] .. self_off[q+1])
+  uint64_t n_self = 0;
+  uint32_t begin_transitive_masked(const DeviceIndexView &v, const impg_gpu_range_t *d_ranges, uint32_t n,
+                                   const impg_gpu_params_t &p, DevBuf &self, DevBuf &frontier_out);
   float stage_ms[3] = {0, 0, 0};
   uint64_t stage_launches = 0;
   DevBuf stage_next;       // next frontier produced by the last stage_update

@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(256) void group_prepare_kernel(VisitedTables vt, co
   const uint32_t len = en - st;
   glen[g] = len;
   const unsigned long long k = gkey[g];
-  uint32_t tab = 0xFFFFFFFFu, idx = 0, olen = 0;
+  uint32_t tab = VISITED_NONE, idx = 0, olen = 0;
   for (int t = (int)vt.n_tables - 1; t >= 0; t--) {
     const VisitedTable &T = vt.t[t];
     uint32_t i = lower_bound_u64(T.keys, T.n_groups, k);
@@ -1215,6 +1215,11 @@ __global__ __launch_bounds__(256) void group_prepare_kernel(VisitedTables vt, co
       olen = T.len[i];
       break;
     }
+  }
+  if (tab == VISITED_NONE && vt.mask_off) {  // first touch under a mask: the clone of the mask's list (impg.rs:2077-2078)
+    const uint32_t seq = (uint32_t)(k & 0xFFFFFFFFull);
+    olen = vt.mask_off[seq + 1] - vt.mask_off[seq];
+    if (olen) { tab = VISITED_MASK; idx = seq; }
   }
   old_tab[g] = tab;
   old_idx[g] = idx;
@@ -1250,7 +1255,11 @@ __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, co
   if (g >= n_groups) return;
   int2 *R = new_ranges + noff[g];
   uint32_t len = 0;
-  if (old_tab[g] != 0xFFFFFFFFu) {
+  if (old_tab[g] == VISITED_MASK) {
+    const uint32_t a = vt.mask_off[old_idx[g]];
+    len = vt.mask_off[old_idx[g] + 1] - a;
+    for (uint32_t i = 0; i < len; i++) R[i] = vt.mask_ranges[a + i];
+  } else if (old_tab[g] != VISITED_NONE) {
     const VisitedTable &T = vt.t[old_tab[g]];
     const int2 *src = T.ranges + T.off[old_idx[g]];
     len = T.len[old_idx[g]];
@@ -1354,6 +1363,120 @@ __global__ __launch_bounds__(256) void frontier_emit_kernel(const unsigned long 
     f.end = P[i].y;
     f.qidx = (uint32_t)(k >> 32);
     o[i] = f;
+  }
+}
+
+// level -1 under masked_regions (impg.rs:2077-2112, :2331-2373): the input range goes through
+// SortedRanges::insert (min_distance 0) on a copy of its target's mask list; every piece is a self interval,
+// the pieces of at least min_transitive_len open the frontier.
+__global__ __launch_bounds__(256) void mask_caps_kernel(const impg_gpu_range_t *__restrict__ ranges, uint32_t n,
+                                                        const uint32_t *__restrict__ mask_off, uint32_t n_seq,
+                                                        uint32_t *__restrict__ cap) {
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= n) return;
+  const uint32_t t = ranges[q].target_id;
+  cap[q] = (t < n_seq ? mask_off[t + 1] - mask_off[t] : 0u) + 1u;
+}
+__global__ __launch_bounds__(64) void visited_init_masked_kernel(const impg_gpu_range_t *__restrict__ ranges, uint32_t n,
+                                                                 const int32_t *__restrict__ init_len, uint32_t n_seq,
+                                                                 const uint32_t *__restrict__ mask_off,
+                                                                 const int2 *__restrict__ mask_ranges,
+                                                                 int32_t min_transitive_len, const uint32_t *__restrict__ loff,
+                                                                 unsigned long long *__restrict__ keys,
+                                                                 uint32_t *__restrict__ len_out, int2 *__restrict__ rng,
+                                                                 int2 *__restrict__ pieces, uint32_t *__restrict__ n_self,
+                                                                 uint32_t *__restrict__ n_front) {
+  const uint32_t q = blockIdx.x * 64u + threadIdx.x;
+  if (q >= n) return;
+  const impg_gpu_range_t r = ranges[q];
+  int32_t start = min(r.start, r.end), end = max(r.start, r.end);
+  const bool known = r.target_id < n_seq;
+  const int32_t sequence_length = known ? init_len[r.target_id] : 0;  // absent from the map: length 0 (impg.rs:2048-2053)
+  int2 *R = rng + loff[q];
+  int2 *P = pieces + loff[q];
+  uint32_t len = 0;
+  if (known) {
+    const uint32_t a = mask_off[r.target_id];
+    len = mask_off[r.target_id + 1] - a;
+    for (uint32_t i = 0; i < len; i++) R[i] = mask_ranges[a + i];
+  }
+  if (start < 0) start = 0;                          // impg.rs:287-289
+  if (end > sequence_length) end = sequence_length;  // impg.rs:294-296
+  uint32_t np = 0, nf = 0;
+  int32_t current = start;
+  uint32_t i = lower_bound_start(R, len, start);
+  if (i > 0 && R[i - 1].y > start) i -= 1;
+  while (i < len && current < end) {  // impg.rs:314-324
+    const int2 rg = R[i];
+    if (rg.x > end) break;
+    if (current < rg.x) {
+      P[np++] = make_int2(current, rg.x);
+      nf += abs(rg.x - current) >= min_transitive_len;
+    }
+    current = max(current, rg.y);
+    i += 1;
+  }
+  if (current < end) {
+    P[np++] = make_int2(current, end);
+    nf += abs(end - current) >= min_transitive_len;
+  }
+  const uint32_t pos = lower_bound_start(R, len, start);  // impg.rs:330-343
+  bool merge = true;
+  uint32_t mfrom = 0;
+  if (pos > 0 && R[pos - 1].y >= start) {
+    R[pos - 1].y = max(R[pos - 1].y, end);
+    mfrom = pos - 1;
+  } else if (pos < len && end >= R[pos].x) {
+    R[pos].x = min(start, R[pos].x);
+    R[pos].y = max(end, R[pos].y);
+    mfrom = pos;
+  } else {
+    for (uint32_t k = len; k > pos; k--) R[k] = R[k - 1];
+    R[pos] = make_int2(start, end);
+    len += 1;
+    merge = false;
+  }
+  if (merge) {  // merge_forward_from, impg.rs:355-368
+    uint32_t write = mfrom, read = mfrom + 1;
+    while (read < len) {
+      if (R[write].y >= R[read].x) {
+        R[write].y = max(R[write].y, R[read].y);
+      } else {
+        write += 1;
+        int2 tmp = R[write];
+        R[write] = R[read];
+        R[read] = tmp;
+      }
+      read += 1;
+    }
+    len = write + 1;
+  }
+  keys[q] = ((unsigned long long)q << 32) | r.target_id;
+  len_out[q] = len;
+  n_self[q] = np;
+  n_front[q] = nf;
+}
+__global__ __launch_bounds__(256) void masked_self_emit_kernel(const impg_gpu_range_t *__restrict__ ranges, uint32_t n,
+                                                               const uint32_t *__restrict__ loff,
+                                                               const uint32_t *__restrict__ n_self,
+                                                               const uint32_t *__restrict__ self_off,
+                                                               const uint32_t *__restrict__ front_off,
+                                                               int32_t min_transitive_len, const int2 *__restrict__ pieces,
+                                                               FrontierRec *__restrict__ self_out,
+                                                               FrontierRec *__restrict__ frontier_out) {
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= n) return;
+  const int2 *P = pieces + loff[q];
+  const uint32_t np = n_self[q];
+  uint32_t so = self_off[q], fo = front_off[q];
+  for (uint32_t i = 0; i < np; i++) {
+    FrontierRec f;
+    f.target_id = ranges[q].target_id;
+    f.start = P[i].x;
+    f.end = P[i].y;
+    f.qidx = q;
+    self_out[so++] = f;                                                   // impg.rs:2345-2363
+    if (abs(P[i].x - P[i].y) >= min_transitive_len) frontier_out[fo++] = f;  // impg.rs:2369-2373
   }
 }
 
@@ -1854,6 +1977,23 @@ void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, 
                           const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s) {
   if (!n_groups) return;
   frontier_emit_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(gkey, poff, n_pieces, foff, n_groups, pieces, out);
+}
+void launch_mask_caps(const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *mask_off, uint32_t n_seq, uint32_t *cap,
+                      hipStream_t s) {
+  if (n) mask_caps_kernel<<<cdiv(n, 256), 256, 0, s>>>(ranges, n, mask_off, n_seq, cap);
+}
+void launch_visited_init_masked(const impg_gpu_range_t *ranges, uint32_t n, const int32_t *init_len, uint32_t n_seq,
+                                const uint32_t *mask_off, const int2 *mask_ranges, int32_t min_transitive_len,
+                                const uint32_t *loff, unsigned long long *keys, uint32_t *len, int2 *rng, int2 *pieces,
+                                uint32_t *n_self, uint32_t *n_front, hipStream_t s) {
+  if (n) visited_init_masked_kernel<<<cdiv(n, 64), 64, 0, s>>>(ranges, n, init_len, n_seq, mask_off, mask_ranges,
+                                                                min_transitive_len, loff, keys, len, rng, pieces, n_self, n_front);
+}
+void launch_masked_self_emit(const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *loff, const uint32_t *n_self,
+                             const uint32_t *self_off, const uint32_t *front_off, int32_t min_transitive_len,
+                             const int2 *pieces, FrontierRec *self_out, FrontierRec *frontier_out, hipStream_t s) {
+  if (n) masked_self_emit_kernel<<<cdiv(n, 256), 256, 0, s>>>(ranges, n, loff, n_self, self_off, front_off, min_transitive_len,
+                                                              pieces, self_out, frontier_out);
 }
 void launch_visited_init(const impg_gpu_range_t *ranges, uint32_t n, const int32_t *seq_len, uint32_t n_seq,
                          int32_t min_transitive_len, unsigned long long *keys, uint32_t *off, uint32_t *len, int2 *rng,

@@ -38,7 +38,12 @@ constexpr size_t COUNT_BYTES = (size_t)COUNT_SLOTS * COUNT_STRIDE * 8;
 struct VisitedTables {
   VisitedTable t[MAX_VISITED_TABLES];
   uint32_t n_tables;
+  // masked_regions (impg.rs:2077-2081): the lists a (query, sequence) key starts from while no table holds it,
+  // shared by every query of the batch; CSR over the sequence ids.  Null without a mask.
+  const uint32_t *mask_off;
+  const int2 *mask_ranges;
 };
+constexpr uint32_t VISITED_NONE = 0xFFFFFFFFu, VISITED_MASK = 0xFFFFFFFEu;  // old_tab values that name no table
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
                          uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s);
@@ -92,6 +97,17 @@ void launch_visited_update(const VisitedTables &vt, const unsigned long long *sv
                            uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, hipStream_t s);
 void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
                           const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s);
+// level -1 under a mask: the input range is inserted into a copy of its target's mask list (impg.rs:2084-2086);
+// cap[q] = that list's length + 1 bounds both the new list and the pieces
+void launch_mask_caps(const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *mask_off, uint32_t n_seq, uint32_t *cap,
+                      hipStream_t s);
+void launch_visited_init_masked(const impg_gpu_range_t *ranges, uint32_t n, const int32_t *init_len, uint32_t n_seq,
+                                const uint32_t *mask_off, const int2 *mask_ranges, int32_t min_transitive_len,
+                                const uint32_t *loff, unsigned long long *keys, uint32_t *len, int2 *rng, int2 *pieces,
+                                uint32_t *n_self, uint32_t *n_front, hipStream_t s);
+void launch_masked_self_emit(const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *loff, const uint32_t *n_self,
+                             const uint32_t *self_off, const uint32_t *front_off, int32_t min_transitive_len,
+                             const int2 *pieces, FrontierRec *self_out, FrontierRec *frontier_out, hipStream_t s);
 void launch_visited_init(const impg_gpu_range_t *ranges, uint32_t n, const int32_t *seq_len, uint32_t n_seq,
                          int32_t min_transitive_len, unsigned long long *keys, uint32_t *off, uint32_t *len, int2 *rng,
                          FrontierRec *self_iv, uint32_t *in_frontier, hipStream_t s);

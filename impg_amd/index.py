@@ -195,11 +195,33 @@ class GpuImpg:
             a[i] = (t, s, e)
         return a
 
-    def query_batch(self, ranges, params=None, **kw):
+    @staticmethod
+    def _mask(masked_regions):
+        """{sequence id: (sequence_length, [(start, end), ...])} -> (impg_gpu_mask_t, arrays kept alive)."""
+        ids = sorted(masked_regions)
+        seq = np.array(ids, dtype=np.uint32)
+        slen = np.array([masked_regions[i][0] for i in ids], dtype=np.int32)
+        off = np.zeros(len(ids) + 1, dtype=np.uint64)
+        flat = []
+        for k, i in enumerate(ids):
+            flat.extend(masked_regions[i][1])
+            off[k + 1] = len(flat)
+        rng = np.ascontiguousarray(np.array(flat, dtype=np.int32).reshape(-1, 2))
+        m = _lib.Mask(len(ids), seq.ctypes.data, slen.ctypes.data, off.ctypes.data, rng.ctypes.data)
+        return m, (seq, slen, off, rng)
+
+    def query_batch(self, ranges, params=None, masked_regions=None, **kw):
+        """masked_regions: one map for the whole batch (impg_gpu_query_batch_masked); every range starts
+        from its own clone of it, as the reference's per-range calls do (impg.rs:2077-2081)."""
         p = params or make_params(**kw)
         r = self._ranges(ranges)
         h = C.c_void_p(None)
-        check(lib().impg_gpu_query_batch(self._h, r.ctypes.data, r.size, C.byref(p), C.byref(h)))
+        if masked_regions is not None:
+            m, keep = self._mask(masked_regions)
+            check(lib().impg_gpu_query_batch_masked(self._h, r.ctypes.data, r.size, C.byref(p), C.byref(m), C.byref(h)))
+            del keep
+        else:
+            check(lib().impg_gpu_query_batch(self._h, r.ctypes.data, r.size, C.byref(p), C.byref(h)))
         return QueryResults(h, self)
 
     def query(self, target_id, range_start, range_end, store_cigar=False, min_gap_compressed_identity=None,
@@ -215,22 +237,22 @@ class GpuImpg:
                              store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
                              approximate_mode=False, subset_filter=None):
         """ImpgIndex::query_transitive_bfs (impg_index.rs:79-94)."""
-        if masked_regions is not None or subset_filter is not None or approximate_mode:
-            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "masked_regions / subset_filter / approximate_mode")
+        if subset_filter is not None or approximate_mode:
+            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "subset_filter / approximate_mode")
         p = make_params(True, False, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
                         min_gap_compressed_identity, store_cigar)
-        return self.query_batch([(target_id, range_start, range_end)], p)[0]
+        return self.query_batch([(target_id, range_start, range_end)], p, masked_regions=masked_regions)[0]
 
     def query_transitive_dfs(self, target_id, range_start, range_end, masked_regions=None, max_depth=2,
                              min_transitive_len=101, min_distance_between_ranges=10, min_output_length=None,
                              store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
                              approximate_mode=False, subset_filter=None):
         """ImpgIndex::query_transitive_dfs (impg_index.rs:63-77)."""
-        if masked_regions is not None or subset_filter is not None or approximate_mode:
-            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "masked_regions / subset_filter / approximate_mode")
+        if subset_filter is not None or approximate_mode:
+            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "subset_filter / approximate_mode")
         p = make_params(True, True, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
                         min_gap_compressed_identity, store_cigar)
-        return self.query_batch([(target_id, range_start, range_end)], p)[0]
+        return self.query_batch([(target_id, range_start, range_end)], p, masked_regions=masked_regions)[0]
 
     def query_batch_stats(self, ranges, params=None, counts=True, checksums=True, device_ptr=None, n=None, **kw):
         """Throughput form: results stay in HBM; returns (Stats, counts, checksums)."""

@@ -156,6 +156,28 @@ int impg_gpu_visit_rank(uint32_t n, int order_policy, uint32_t *rank_out);
 int impg_gpu_query_batch(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n,
                          const impg_gpu_params_t *params, impg_gpu_results_t **out);
 /* Single range == batch of one; what a per-call `impl ImpgIndex` binds. */
+/* masked_regions: Option<&FxHashMap<u32, SortedRanges>> of query_transitive_bfs / query_transitive_dfs
+ * (impg.rs:2062, :2316; multi_impg.rs:692, :727, :801), as partition.rs:250-256, :364, :380 passes it.
+ * One map for the whole batch: every range starts from its own clone of it (impg.rs:2077-2081), so a
+ * batch under one mask equals the reference's per-range calls with the same map.  The map is given as
+ * n_seqs entries in strictly ascending sequence-id order: SortedRanges.sequence_length, and
+ * ranges[2*range_off[i] .. 2*range_off[i+1]) as (start, end) pairs, sorted, disjoint and non-touching
+ * (the SortedRanges invariant).  Every SortedRanges has min_distance 0, as partition builds them.
+ * A sequence absent from the map follows the reference: Impg gives it a set of length 0 (visited_entry,
+ * impg.rs:2048-2053: its hits are reported but never expanded), MultiImpg its real length, except the
+ * range's own target (entry().or_default(), multi_impg.rs:827-830: no result at all).
+ * A range can now have several self intervals, or none; they lead its results in ascending order.
+ * mask == NULL is impg_gpu_query_batch.  Only the transitive queries take a mask (IMPG_E_INVALID). */
+typedef struct {
+  uint32_t n_seqs;
+  const uint32_t *seq_id;          /* [n_seqs] */
+  const int32_t *sequence_length;  /* [n_seqs] */
+  const uint64_t *range_off;       /* [n_seqs + 1] */
+  const int32_t *ranges;           /* [2 * range_off[n_seqs]] */
+} impg_gpu_mask_t;
+int impg_gpu_query_batch_masked(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n,
+                                const impg_gpu_params_t *params, const impg_gpu_mask_t *mask,
+                                impg_gpu_results_t **out);
 int impg_gpu_query(impg_gpu_index_t *, uint32_t target_id, int32_t start, int32_t end,
                    const impg_gpu_params_t *params, impg_gpu_results_t **out);
 

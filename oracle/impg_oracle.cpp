@@ -693,6 +693,9 @@ bool frontier_hits(const oracle_index &ix, const TreeMap &trees, uint32_t cur_id
   return ok;
 }
 
+/* masked_regions: Option<&FxHashMap<u32, SortedRanges>> (impg.rs:2062, :2316; multi_impg.rs:801) */
+typedef std::unordered_map<uint32_t, SortedRanges> MaskMap;
+
 SortedRanges &visited_entry(const oracle_index &ix, std::unordered_map<uint32_t, SortedRanges> &visited,
                             uint32_t id, bool masked_none) { /* impg.rs:2041-2055 */
   auto it = visited.find(id);
@@ -710,7 +713,7 @@ SortedRanges &visited_entry(const oracle_index &ix, std::unordered_map<uint32_t,
 template <class Push>
 void update_with_hit(const oracle_index &ix, std::unordered_map<uint32_t, SortedRanges> &visited,
                      Hit &h, int32_t min_output_length, int32_t min_distance_between_ranges,
-                     int32_t min_transitive_len, bool bfs_short_circuit,
+                     int32_t min_transitive_len, bool bfs_short_circuit, bool masked_none,
                      std::vector<AdjustedInterval> &results, Push push_next) {
   int32_t length = std::abs(h.qe - h.qs);
   bool should_add_to_output = min_output_length >= 0 ? length >= min_output_length : true;
@@ -721,7 +724,7 @@ void update_with_hit(const oracle_index &ix, std::unordered_map<uint32_t, Sorted
     results.push_back(std::move(a));
   }
   if (h.query_id != h.cur_target) {
-    SortedRanges &ranges = visited_entry(ix, visited, h.query_id, true);
+    SortedRanges &ranges = visited_entry(ix, visited, h.query_id, masked_none);
     bool should_add = true;
     if (min_distance_between_ranges > 0) {
       int32_t new_min = std::min(h.qs, h.qe), new_max = std::max(h.qs, h.qe);
@@ -747,10 +750,12 @@ void parallel_for(size_t n, int threads, const std::function<void(size_t)> &f);
 
 /* Impg::query_transitive_bfs (impg.rs:2311-2597) */
 bool impg_bfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, int32_t range_start,
-              int32_t range_end, const oracle_params_t &p, int threads,
+              int32_t range_end, const oracle_params_t &p, int threads, const MaskMap *mask,
               std::vector<AdjustedInterval> &results) {
+  const bool masked_none = mask == nullptr; /* :2330-2335 */
   std::unordered_map<uint32_t, SortedRanges> visited;
-  auto filtered = visited_entry(ix, visited, target_id, true).insert({range_start, range_end});
+  if (mask) visited = *mask;
+  auto filtered = visited_entry(ix, visited, target_id, masked_none).insert({range_start, range_end});
   results.clear();
   for (auto &f : filtered) results.push_back(make_self(target_id, f.first, f.second, p.store_cigar));
   struct R { uint32_t id; int32_t s, e; };
@@ -777,7 +782,7 @@ bool impg_bfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, 
     for (auto &qr : query_results)
       for (auto &h : qr)
         update_with_hit(ix, visited, h, p.min_output_length, p.min_distance_between_ranges,
-                        p.min_transitive_len, true, results,
+                        p.min_transitive_len, true, masked_none, results,
                         [&](uint32_t id, int32_t s, int32_t e) { next.push_back({id, s, e}); });
     depth += 1;
     if (!next.empty()) { /* :2566-2584 */
@@ -802,9 +807,12 @@ bool impg_bfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, 
 
 /* Impg::query_transitive_dfs (impg.rs:2057-2309) */
 bool impg_dfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, int32_t range_start,
-              int32_t range_end, const oracle_params_t &p, std::vector<AdjustedInterval> &results) {
+              int32_t range_end, const oracle_params_t &p, const MaskMap *mask,
+              std::vector<AdjustedInterval> &results) {
+  const bool masked_none = mask == nullptr; /* :2076-2081 */
   std::unordered_map<uint32_t, SortedRanges> visited;
-  auto filtered = visited_entry(ix, visited, target_id, true).insert({range_start, range_end});
+  if (mask) visited = *mask;
+  auto filtered = visited_entry(ix, visited, target_id, masked_none).insert({range_start, range_end});
   results.clear();
   struct S { uint32_t id; int32_t s, e; uint32_t depth; };
   std::vector<S> stack;
@@ -820,7 +828,7 @@ bool impg_dfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, 
     if (!frontier_hits(ix, trees, cur.id, cur.s, cur.e, p.store_cigar, p.min_identity, hits)) return false;
     for (auto &h : hits)
       update_with_hit(ix, visited, h, p.min_output_length, p.min_distance_between_ranges,
-                      p.min_transitive_len, false, results,
+                      p.min_transitive_len, false, masked_none, results,
                       [&](uint32_t id, int32_t s, int32_t e) { stack.push_back({id, s, e, cur.depth + 1}); });
     std::stable_sort(stack.begin(), stack.end(), [](const S &a, const S &b) { /* :2289 */
       return a.id != b.id ? a.id < b.id : a.s < b.s;
@@ -881,14 +889,16 @@ bool multi_query_all_indices(const oracle_index &ix, uint32_t target_id, int32_t
 
 /* MultiImpg::transitive_query_impl (multi_impg.rs:796-991) */
 bool multi_transitive(const oracle_index &ix, uint32_t target_id, int32_t range_start, int32_t range_end,
-                      const oracle_params_t &p, bool use_dfs, std::vector<AdjustedInterval> &results) {
+                      const oracle_params_t &p, bool use_dfs, const MaskMap *mask,
+                      std::vector<AdjustedInterval> &results) {
   std::unordered_map<uint32_t, SortedRanges> visited;
-  for (uint32_t id = 0; id < ix.seq_index.id_to_name.size(); id++) { /* :814-822 */
+  if (mask) visited = *mask; /* :814-815 */
+  else for (uint32_t id = 0; id < ix.seq_index.id_to_name.size(); id++) { /* :817-822 */
     SortedRanges sr;
     sr.sequence_length = (int32_t)std::max<int64_t>(ix.seq_index.id_to_len[id], 0);
     visited.emplace(id, std::move(sr));
   }
-  auto filtered = visited[target_id].insert({range_start, range_end});
+  auto filtered = visited[target_id].insert({range_start, range_end}); /* :827-830 entry().or_default(): length 0 */
   results.clear();
   struct S { uint32_t id; int32_t s, e; uint32_t depth; };
   std::deque<S> stack;
@@ -909,7 +919,13 @@ bool multi_transitive(const oracle_index &ix, uint32_t target_id, int32_t range_
       int32_t length = std::abs(result.q_last - result.q_first);
       bool out = p.min_output_length >= 0 ? length >= p.min_output_length : true;
       if (out) results.push_back(result);
-      SortedRanges &ranges = visited[query_id];
+      auto vit = visited.find(query_id); /* :919-922 or_insert_with(real length) */
+      if (vit == visited.end()) {
+        SortedRanges sr;
+        sr.sequence_length = (int32_t)std::max<int64_t>(ix.seq_index.id_to_len[query_id], 0);
+        vit = visited.emplace(query_id, std::move(sr)).first;
+      }
+      SortedRanges &ranges = vit->second;
       bool should_add = true;
       if (p.min_distance_between_ranges > 0) {
         size_t idx = ranges.bsearch(aqs);
@@ -941,14 +957,14 @@ bool multi_transitive(const oracle_index &ix, uint32_t target_id, int32_t range_
 
 /* dispatch as perform_query does (main.rs:11641-11699), without the retain */
 bool run_query(const oracle_index &ix, uint32_t target_id, int32_t s, int32_t e, const oracle_params_t &p,
-               int threads, std::vector<AdjustedInterval> &results) {
+               int threads, std::vector<AdjustedInterval> &results, const MaskMap *mask = nullptr) {
   if (p.multi_impg) {
-    if (p.transitive) return multi_transitive(ix, target_id, s, e, p, p.dfs != 0, results);
+    if (p.transitive) return multi_transitive(ix, target_id, s, e, p, p.dfs != 0, mask, results);
     return multi_query_all_indices(ix, target_id, s, e, p.store_cigar, p.min_identity, results);
   }
   if (p.transitive) {
-    if (p.dfs) return impg_dfs(ix, ix.trees, target_id, s, e, p, results);
-    return impg_bfs(ix, ix.trees, target_id, s, e, p, threads, results);
+    if (p.dfs) return impg_dfs(ix, ix.trees, target_id, s, e, p, mask, results);
+    return impg_bfs(ix, ix.trees, target_id, s, e, p, threads, mask, results);
   }
   return impg_query(ix, ix.trees, target_id, s, e, p.store_cigar, p.min_identity, results);
 }
@@ -1244,6 +1260,26 @@ long oracle_query(const oracle_index_t *ix, uint32_t target_id, int32_t start, i
   std::vector<AdjustedInterval> results;
   g_nproj = 0;
   if (!run_query(*ix, target_id, start, end, *p, 1, results)) return -1;
+  for (size_t i = 0; i < results.size() && i < cap; i++)
+    out[i] = {results[i].q_id, results[i].q_first, results[i].q_last, results[i].t_id, results[i].t_first, results[i].t_last};
+  return (long)results.size();
+}
+
+long oracle_query_masked(const oracle_index_t *ix, uint32_t target_id, int32_t start, int32_t end, const oracle_params_t *p,
+                         uint32_t n_mask, const uint32_t *mask_seq, const int32_t *mask_seq_len, const uint64_t *mask_off,
+                         const int32_t *mask_ranges, oracle_interval_t *out, size_t cap) {
+  MaskMap mask;
+  for (uint32_t i = 0; i < n_mask; i++) {
+    SortedRanges sr;
+    sr.sequence_length = mask_seq_len[i];
+    sr.min_distance = 0; /* partition.rs:250-256 builds its masks with min_distance 0 */
+    for (uint64_t k = mask_off[i]; k < mask_off[i + 1]; k++) sr.ranges.push_back({mask_ranges[2 * k], mask_ranges[2 * k + 1]});
+    mask.emplace(mask_seq[i], std::move(sr));
+  }
+  std::vector<AdjustedInterval> results;
+  g_nproj = 0;
+  if (!p->transitive) return -2; /* only the transitive queries take masked_regions */
+  if (!run_query(*ix, target_id, start, end, *p, 1, results, &mask)) return -1;
   for (size_t i = 0; i < results.size() && i < cap; i++)
     out[i] = {results[i].q_id, results[i].q_first, results[i].q_last, results[i].t_id, results[i].t_first, results[i].t_last};
   return (long)results.size();

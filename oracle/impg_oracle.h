@@ -113,6 +113,16 @@ long oracle_query(const oracle_index_t *, uint32_t target_id, int32_t start,
                   int32_t end, const oracle_params_t *p, oracle_interval_t *out,
                   size_t cap);
 
+/* query_transitive_{bfs,dfs} with masked_regions = Some(map) (impg.rs:2062-2081,
+ * :2316-2335; multi_impg.rs:801-830): the map as n_mask entries (sequence id,
+ * SortedRanges.sequence_length, ranges[mask_off[i]..mask_off[i+1]) as start,end
+ * pairs, sorted and disjoint); every SortedRanges has min_distance 0 as
+ * partition.rs:250-256 builds them.  Returns -2 for a non-transitive params. */
+long oracle_query_masked(const oracle_index_t *, uint32_t target_id, int32_t start, int32_t end,
+                         const oracle_params_t *p, uint32_t n_mask, const uint32_t *mask_seq,
+                         const int32_t *mask_seq_len, const uint64_t *mask_off,
+                         const int32_t *mask_ranges, oracle_interval_t *out, size_t cap);
+
 /* Same with store_cigar: cigar_off[cap+1], cigar_ops[ops_cap] receive the
  * Vec<CigarOp> of every result (CSR); *n_ops = total ops (may exceed ops_cap). */
 long oracle_query_cigar(const oracle_index_t *, uint32_t target_id, int32_t start,

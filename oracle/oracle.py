@@ -93,6 +93,9 @@ def lib():
         L.oracle_query.restype = C.c_long
         L.oracle_query.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params),
                                    C.c_void_p, C.c_size_t]
+        L.oracle_query_masked.restype = C.c_long
+        L.oracle_query_masked.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_query_cigar.restype = C.c_long
         L.oracle_query_cigar.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p,
                                          C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
@@ -193,6 +196,21 @@ class SortedRanges:
         return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
 
 
+def pack_mask(masked_regions):
+    """{seq id: (sequence_length, [(start, end), ...])} -> the four flat arrays of the C interfaces
+    (ids ascending, u64 CSR offsets, int32 start/end pairs)."""
+    ids = sorted(masked_regions)
+    mseq = np.array(ids, dtype=np.uint32)
+    mlen = np.array([masked_regions[i][0] for i in ids], dtype=np.int32)
+    moff = np.zeros(len(ids) + 1, dtype=np.uint64)
+    flat = []
+    for k, i in enumerate(ids):
+        flat.extend(masked_regions[i][1])
+        moff[k + 1] = len(flat)
+    mrng = np.array(flat, dtype=np.int32).reshape(-1, 2) if flat else np.zeros((0, 2), dtype=np.int32)
+    return mseq, mlen, moff, np.ascontiguousarray(mrng)
+
+
 class OracleIndex:
     """Impg (and MultiImpg) built from PAF text or files."""
 
@@ -244,13 +262,21 @@ class OracleIndex:
         lib().oracle_target_entries(self._h, target_id, out.ctypes.data, n)
         return out[:n]
 
-    def query(self, target_id, start, end, params=None, **kw):
-        """Results (numpy structured array) in reference emission order."""
+    def query(self, target_id, start, end, params=None, masked_regions=None, **kw):
+        """Results (numpy structured array) in reference emission order.
+        masked_regions: {sequence id: (sequence_length, [(start, end), ...])} -- the
+        Option<&FxHashMap<u32, SortedRanges>> of query_transitive_{bfs,dfs}."""
         p = params or make_params(**kw)
         cap = 1 << 12
+        if masked_regions is not None:
+            mseq, mlen, moff, mrng = pack_mask(masked_regions)
         while True:
             out = np.zeros(cap, dtype=INTERVAL_DTYPE)
-            n = lib().oracle_query(self._h, target_id, start, end, C.byref(p), out.ctypes.data, cap)
+            if masked_regions is not None:
+                n = lib().oracle_query_masked(self._h, target_id, start, end, C.byref(p), len(mseq), mseq.ctypes.data,
+                                              mlen.ctypes.data, moff.ctypes.data, mrng.ctypes.data, out.ctypes.data, cap)
+            else:
+                n = lib().oracle_query(self._h, target_id, start, end, C.byref(p), out.ctypes.data, cap)
             if n < 0:
                 raise RuntimeError(lib().oracle_last_error().decode())
             if n <= cap:

@@ -23,11 +23,11 @@ def both(tmp_path, text, order=impg_amd.ORDER_COITREES, bidirectional=True):
     return g, c
 
 
-def assert_same(g, c, ranges, **kw):
-    res = g.query_batch(ranges, impg_amd.make_params(**kw))
+def assert_same(g, c, ranges, masked_regions=None, **kw):
+    res = g.query_batch(ranges, impg_amd.make_params(**kw), masked_regions=masked_regions)
     total = 0
     for i, (t, s, e) in enumerate(ranges):
-        want = c.query(t, s, e, **kw)
+        want = c.query(t, s, e, masked_regions=masked_regions, **kw)
         got = res[i]
         assert got.tolist() == want.tolist(), (i, (t, s, e), kw)
         total += c.last_projection_count()
@@ -555,3 +555,88 @@ def test_gzip_and_bgzf_paf_ingest(tmp_path):
         got = g2.query_batch(ranges, impg_amd.make_params(transitive=True, max_depth=2))
         assert all(got[i].tolist() == want[i].tolist() for i in range(len(ranges)))
     assert_same(g, c, ranges[:20], transitive=True, max_depth=2)
+
+
+def random_mask(seed, n_seq, seq_len, present=0.8, max_ranges=12, odd_lengths=False):
+    """{seq id: (sequence_length, sorted disjoint non-touching ranges)} -- a masked_regions map."""
+    rng = np.random.default_rng(seed)
+    mask = {}
+    for sid in range(n_seq):
+        if rng.random() > present:
+            continue
+        k = int(rng.integers(0, max_ranges + 1))
+        cuts = np.unique(rng.integers(0, seq_len, size=2 * k))
+        cuts = cuts[: 2 * (len(cuts) // 2)]
+        rs = [(int(cuts[2 * i]), int(cuts[2 * i + 1])) for i in range(len(cuts) // 2)]
+        length = seq_len
+        if odd_lengths and rng.random() < 0.3:  # a SortedRanges may carry any sequence_length
+            length = int(rng.integers(seq_len // 2, seq_len + 1000))
+        mask[sid] = (length, rs)
+    return mask
+
+
+@pytest.mark.parametrize("seed,present,odd", [(101, 1.0, False), (102, 0.7, False), (103, 0.9, True), (104, 0.3, True)])
+def test_masked_regions(tmp_path, seed, present, odd):
+    """query_transitive_{bfs,dfs} with masked_regions = Some(map) (impg.rs:2077-2112, :2331-2373;
+    partition.rs:364, :380): one map for the batch, every range starting from its own clone.  Several
+    self intervals (or none) per range, visited sets seeded from the map, the length-0 sets of
+    sequences the map does not hold."""
+    text, names = random_paf(seed, 300, n_seq=6, seq_len=20000, weird=(seed % 2 == 0), self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(seed + 7, 80, 6, 20000, max_len=4000, min_len=50)
+    for m_seed in (1, 2):
+        mask = random_mask(seed * 10 + m_seed, 6, 20000, present=present, odd_lengths=odd)
+        for kw in [dict(transitive=True, max_depth=1, min_transitive_len=0, min_distance_between_ranges=0),
+                   dict(transitive=True, max_depth=2),
+                   dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=10),
+                   dict(transitive=True, max_depth=4, min_transitive_len=101, min_distance_between_ranges=50,
+                        min_output_length=200),
+                   dict(transitive=True, dfs=True, max_depth=0, min_transitive_len=300, min_distance_between_ranges=10),
+                   dict(transitive=True, max_depth=0, min_transitive_len=50, min_distance_between_ranges=0)]:
+            assert_same(g, c, ranges, masked_regions=mask, **kw)
+    # the empty map and the all-covering map
+    assert_same(g, c, ranges, masked_regions={}, transitive=True, max_depth=2)
+    assert_same(g, c, ranges, masked_regions={i: (20000, [(0, 20000)]) for i in range(6)}, transitive=True, max_depth=2)
+    # store_cigar: every self piece carries its own N= (impg.rs:2352-2354)
+    mask = random_mask(seed, 6, 20000, present=1.0)
+    kw = dict(transitive=True, max_depth=2, min_transitive_len=40)
+    res = g.query_batch(ranges[:20], impg_amd.make_params(store_cigar=True, **kw), masked_regions=mask)
+    plain = g.query_batch(ranges[:20], impg_amd.make_params(**kw), masked_regions=mask)
+    n_self = 0
+    for i, (t, s0, e0) in enumerate(ranges[:20]):
+        assert res[i].tolist() == plain[i].tolist()
+        want, wcg = c.query(t, s0, e0, masked_regions=mask, **kw), None
+        assert res[i].tolist() == want.tolist()
+        for k, row in enumerate(res[i].tolist()):  # the leading self pieces
+            if not (row[0] == row[3] == t and row[1:3] == row[4:6]):
+                break
+            assert res.cigars(i)[k].tolist() == o.ops_from_pairs([(row[2] - row[1], "=")]).tolist()
+            n_self += 1
+    assert n_self > 0
+    # only the transitive queries take a mask
+    with pytest.raises(impg_amd.ImpgGpuError):
+        g.query_batch(ranges[:2], impg_amd.make_params(transitive=False), masked_regions=mask)
+    # the trait-shaped calls
+    t, s, e = ranges[0]
+    got = g.query_transitive_bfs(t, s, e, masked_regions=mask, max_depth=3)
+    assert got.tolist() == c.query(t, s, e, masked_regions=mask, transitive=True, max_depth=3).tolist()
+    got = g.query_transitive_dfs(t, s, e, masked_regions=mask, max_depth=3)
+    assert got.tolist() == c.query(t, s, e, masked_regions=mask, transitive=True, dfs=True, max_depth=3).tolist()
+
+
+@pytest.mark.parametrize("seed", [111, 112])
+def test_masked_regions_multi_impg(tmp_path, seed):
+    """MultiImpg with masked_regions (multi_impg.rs:814-830, :919-922): sequences absent from the map keep
+    their real length, except the range's own target."""
+    texts = []
+    for k in range(3):
+        t, names = random_paf(seed * 10 + k, 120, n_seq=6, seq_len=20000, weird=(k % 2 == 1), self_aln=True)
+        texts.append(t)
+    g, c = both_files(tmp_path, texts)
+    ranges = random_ranges(seed + 3, 60, g.num_seqs(), 20000, max_len=3000, min_len=50)
+    for m_seed, present in ((1, 1.0), (2, 0.6)):
+        mask = random_mask(seed * 10 + m_seed, g.num_seqs(), 20000, present=present, odd_lengths=True)
+        for kw in [dict(transitive=True, max_depth=2),
+                   dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=10),
+                   dict(transitive=True, max_depth=0, min_transitive_len=300, min_distance_between_ranges=10)]:
+            assert_same(g, c, ranges, masked_regions=mask, multi_impg=True, **kw)

@@ -326,3 +326,48 @@ def test_paf_and_bedpe_rows_by_hand(tmp_path):
     rows = ix.query_paf("T", 100, 300, merge_distance=10, min_transitive_len=10).splitlines()
     assert [r.split("\t")[2:4] + [r.split("\t")[14]] for r in rows] == [["0", "200", "cg:Z:130=1X29=7I7D33="]]
     assert len(ix.query_paf("T", 100, 300, merge_distance=-1, min_transitive_len=10).splitlines()) == 3
+
+
+# masked_regions (impg.rs:2062-2090, :2316-2344, :2041-2055; multi_impg.rs:814-830, :919-922): no reference test
+# holds a masked query, so the expected tuples are derived by hand from the cited code on the T2 chain
+# A(0-100) = B(0-100) = C(0-100) (ids A=0, B=1, C=2; every alignment is 100=, so projections are 1:1).
+def _tuples(res):
+    return sorted((int(r["query_id"]), int(r["q_first"]), int(r["q_last"]), int(r["target_id"]), int(r["t_first"]),
+                   int(r["t_last"])) for r in res)
+
+
+def test_masked_regions_by_hand():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100,
+                                    "B\t1000\t0\t100\t+\tC\t1000\t0\t100" + L100))
+    full = {0: (1000, [(40, 60)]), 1: (1000, []), 2: (1000, [])}
+    # the input range is split by the mask into 25-40 and 60-75; both pieces walk A -> B -> {A, C} -> B
+    expect = sorted([(0, 25, 40, 0, 25, 40), (0, 60, 75, 0, 60, 75),
+                     (1, 25, 40, 0, 25, 40), (1, 60, 75, 0, 60, 75),
+                     (0, 25, 40, 1, 25, 40), (2, 25, 40, 1, 25, 40), (0, 60, 75, 1, 60, 75), (2, 60, 75, 1, 60, 75),
+                     (1, 25, 40, 2, 25, 40), (1, 60, 75, 2, 60, 75)])
+    for dfs in (False, True):
+        res = ix.query(0, 25, 75, transitive=True, dfs=dfs, min_transitive_len=0, max_depth=0, masked_regions=full)
+        assert _tuples(res) == expect
+        # the self intervals come first, in ascending order
+        assert [tuple(int(x) for x in r) for r in res[:2]] == [(0, 25, 40, 0, 25, 40), (0, 60, 75, 0, 60, 75)]
+        # a sequence absent from the map gets a SortedRanges of length 0 (visited_entry, masked_none = false):
+        # every insert there clamps its end to 0, so B is reported but never expanded
+        res = ix.query(0, 25, 75, transitive=True, dfs=dfs, min_transitive_len=0, max_depth=0, masked_regions={0: (1000, [])})
+        assert _tuples(res) == [(0, 25, 75, 0, 25, 75), (1, 25, 75, 0, 25, 75)]
+        # a fully masked input range yields no self interval and no result at all
+        res = ix.query(0, 25, 75, transitive=True, dfs=dfs, min_transitive_len=0, max_depth=0, masked_regions={0: (1000, [(0, 100)])})
+        assert len(res) == 0
+        # the pieces below min_transitive_len are reported but not expanded
+        res = ix.query(0, 25, 75, transitive=True, dfs=dfs, min_transitive_len=16, max_depth=0, masked_regions=full)
+        assert _tuples(res) == [(0, 25, 40, 0, 25, 40), (0, 60, 75, 0, 60, 75)]
+        # MultiImpg: a sequence absent from the map keeps its real length (multi_impg.rs:919-922) ...
+        res = ix.query(0, 25, 75, transitive=True, dfs=dfs, min_transitive_len=0, max_depth=0, multi_impg=True,
+                       masked_regions={0: (1000, [])})
+        assert _tuples(res) == sorted([(0, 25, 75, 0, 25, 75), (1, 25, 75, 0, 25, 75), (0, 25, 75, 1, 25, 75),
+                                       (2, 25, 75, 1, 25, 75), (1, 25, 75, 2, 25, 75)])
+        # ... except the query's own target, which is entry().or_default() = length 0 (multi_impg.rs:827-830)
+        res = ix.query(0, 25, 75, transitive=True, dfs=dfs, min_transitive_len=0, max_depth=0, multi_impg=True,
+                       masked_regions={1: (1000, [])})
+        assert len(res) == 0
+    with pytest.raises(RuntimeError):
+        ix.query(0, 25, 75, transitive=False, masked_regions=full)

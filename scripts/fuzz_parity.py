@@ -67,8 +67,17 @@ while time.time() < t_end:
     if rng.random() < 0.25:
         kw["multi_impg"] = True
     cigar = bool(rng.random() < 0.5)
+    mask = None
+    if kw.get("transitive") and rng.random() < 0.35:  # masked_regions: one map for the batch
+        mask = {}
+        for sid in range(g.num_seqs()):
+            if rng.random() < 0.8:
+                cuts = np.unique(rng.integers(0, seq_len, size=2 * int(rng.integers(0, 10))))
+                rs = [(int(cuts[2 * i]), int(cuts[2 * i + 1])) for i in range(len(cuts) // 2)]
+                mask[sid] = (int(seq_len if rng.random() < 0.8 else rng.integers(1, seq_len + 500)), rs)
+        cigar = False  # (the oracle's masked entry point returns rows only)
     params = impg_amd.make_params(store_cigar=cigar, **kw)
-    res = g.query_batch(ranges, params)
+    res = g.query_batch(ranges, params, masked_regions=mask)
     total = 0
     for i, (t, s, e) in enumerate(ranges):
         if cigar:
@@ -76,15 +85,15 @@ while time.time() < t_end:
             got_cg = res.cigars(i)
             assert [x.tolist() for x in got_cg] == [x.tolist() for x in wcg], ("cigar", seed, i, kw)
         else:
-            want = c.query(t, s, e, **kw)
-        assert res[i].tolist() == want.tolist(), ("rows", seed, i, (t, s, e), kw)
+            want = c.query(t, s, e, masked_regions=mask, **kw)
+        assert res[i].tolist() == want.tolist(), ("rows", seed, i, (t, s, e), kw, mask)
         total += c.last_projection_count()
         n_rows += len(want)
     assert res.projected == total, ("projected", seed, kw)
     # text outputs on the ranges long enough for perform_query's validation
     mtl = kw.get("min_transitive_len", 101)
     ok = [i for i, (t, s, e) in enumerate(ranges) if e - s >= mtl]
-    if ok and not kw.get("multi_impg"):
+    if ok and not kw.get("multi_impg") and mask is None:
         sub = [ranges[i] for i in ok]
         d = int(rng.choice([-1, 0, 30, 1000]))
         names = ["n%d" % i for i in ok]

@@ -110,6 +110,7 @@ SYMBOLS = [
     ("impg_gpu_stage_project", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(Params), _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("impg_gpu_stage_project16", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(Params), _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("impg_gpu_stage_update16", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_uint64)]),
+    ("impg_gpu_stage_reorder", C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.c_size_t, _P]),
     ("impg_gpu_stage_route", C.c_int, [_P, _P, C.c_size_t, C.c_uint32, _P, C.POINTER(C.c_uint64)]),
     ("impg_gpu_stage_begin", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, C.POINTER(C.c_uint64), _P]),
     ("impg_gpu_stage_update", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_uint64)]),

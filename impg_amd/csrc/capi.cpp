@@ -616,6 +616,33 @@ int impg_gpu_stage_project16(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_
   return stage_project_impl(ix, d_frontier, n, transitive, params, nullptr, d_hits, total, accepted);
 }
 
+int impg_gpu_stage_reorder(impg_gpu_index_t *ix, const void *d_hits, size_t n, uint32_t words_per_hit, size_t n_frontier,
+                           void *d_out) {
+  IMPG_TRY
+  if (!ix || (n && (!d_hits || !d_out))) throw Error{IMPG_E_INVALID, "null argument"};
+  if (words_per_hit != 4 && words_per_hit != 8) throw Error{IMPG_E_INVALID, "hit records are 4 or 8 words"};
+  if (n >= (1ull << 32) - 16 || n_frontier >= (1ull << 32) - 16) throw Error{IMPG_E_UNSUPPORTED, "too many records"};
+  if (!n) return IMPG_OK;
+  Engine &E = *ix->engine;
+  IMPG_HIP(hipSetDevice(ix->device));
+  const size_t fb = std::max<size_t>(n_frontier * 4, 256);
+  E.lo_key.reserve(fb); E.lo_cnt.reserve(fb); E.lo_off.reserve(fb);
+  IMPG_HIP(hipMemsetAsync(E.lo_cnt.p, 0, fb, E.stream));
+  IMPG_HIP(hipMemsetAsync(E.counters.as<unsigned long long>() + 4, 0, 8, E.stream));
+  uint32_t *err = reinterpret_cast<uint32_t *>(E.counters.as<unsigned long long>() + 4);
+  launch_reorder_runs(static_cast<const uint32_t *>(d_hits), (uint32_t)n, words_per_hit, (uint32_t)n_frontier,
+                      E.lo_key.as<uint32_t>(), E.lo_cnt.as<uint32_t>(), err, E.stream);
+  const uint64_t total = E.scan(E.lo_cnt.as<uint32_t>(), E.lo_off.as<uint32_t>(), (uint32_t)n_frontier);
+  uint32_t bad = 0;
+  IMPG_HIP(hipMemcpy(&bad, err, 4, hipMemcpyDeviceToHost));
+  if (bad || total != n) throw Error{IMPG_E_INVALID, "hit records name a frontier index twice or out of range"};
+  launch_reorder_scatter(d_hits, (uint32_t)n, words_per_hit, (uint32_t)n_frontier, E.lo_key.as<uint32_t>(),
+                         E.lo_off.as<uint32_t>(), d_out, E.stream);
+  IMPG_HIP(hipStreamSynchronize(E.stream));
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
 int impg_gpu_stage_route(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, uint32_t world,
                          impg_gpu_frontier_t *d_out, uint64_t *counts) {
   IMPG_TRY

@@ -308,6 +308,41 @@ __global__ __launch_bounds__(256) void route_gather_kernel(const FrontierRec *__
   out[i] = f;
 }
 
+// Home side of a hop: hit records arrive grouped by owner rank, every owner's block in ascending fidx (the index
+// of the frontier record at home).  A frontier record lives on exactly one owner, so the runs of equal fidx never
+// interleave and the stable order by fidx is a counting pass over the frontier indices, not a sort:
+// run bounds -> lengths -> exclusive scan -> every record lands at off[fidx] + its place in its run.
+__global__ __launch_bounds__(256) void reorder_runs_kernel(const uint32_t *__restrict__ hits, uint32_t n, uint32_t words,
+                                                           uint32_t n_front, uint32_t *__restrict__ run_start,
+                                                           uint32_t *__restrict__ run_len, uint32_t *__restrict__ err) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t f = hits[(size_t)i * words];
+  if (f >= n_front) { *err = 1; return; }
+  if (i == 0 || hits[(size_t)(i - 1) * words] != f) {
+    run_start[f] = i;
+    uint32_t e = i + 1;  // runs are a few dozen records (one frontier range's hits): the head walks its own run
+    while (e < n && hits[(size_t)e * words] == f) e++;
+    run_len[f] = e - i;
+  }
+}
+template <int WORDS>
+__global__ __launch_bounds__(256) void reorder_scatter_kernel(const uint4 *__restrict__ hits, uint32_t n, uint32_t n_front,
+                                                              const uint32_t *__restrict__ run_start,
+                                                              const uint32_t *__restrict__ off, uint4 *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  constexpr int Q = WORDS / 4;
+  uint4 r[Q];
+#pragma unroll
+  for (int k = 0; k < Q; k++) r[k] = hits[(size_t)i * Q + k];
+  const uint32_t f = r[0].x;
+  if (f >= n_front) return;
+  const size_t d = (size_t)off[f] + (i - run_start[f]);
+#pragma unroll
+  for (int k = 0; k < Q; k++) out[d * Q + k] = r[k];
+}
+
 // Lookup / projection order: ranges sorted by where their window will be in the entry array,
 // estimated before any search from the record alone: segment start + start / sequence length x
 // segment size (alignments spread evenly enough for a LOCALITY key; exactness is not needed).
@@ -1890,6 +1925,16 @@ void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, uint32
 }
 void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s) {
   if (n) route_gather_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, perm, n, out);
+}
+void launch_reorder_runs(const uint32_t *hits, uint32_t n, uint32_t words, uint32_t n_front, uint32_t *run_start,
+                         uint32_t *run_len, uint32_t *err, hipStream_t s) {
+  if (n) reorder_runs_kernel<<<cdiv(n, 256), 256, 0, s>>>(hits, n, words, n_front, run_start, run_len, err);
+}
+void launch_reorder_scatter(const void *hits, uint32_t n, uint32_t words, uint32_t n_front, const uint32_t *run_start,
+                            const uint32_t *off, void *out, hipStream_t s) {
+  if (!n) return;
+  if (words == 4) reorder_scatter_kernel<4><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)hits, n, n_front, run_start, off, (uint4 *)out);
+  else reorder_scatter_kernel<8><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)hits, n, n_front, run_start, off, (uint4 *)out);
 }
 void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s) {
   if (n) order_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, key, idx);

@@ -285,6 +285,9 @@ class GpuImpg:
         return acc.value
 
 
+    def stage_reorder(self, d_hits_ptr, n, words_per_hit, n_frontier, d_out_ptr):
+        check(lib().impg_gpu_stage_reorder(self._h, d_hits_ptr, n, words_per_hit, n_frontier, d_out_ptr))
+
     def stage_route(self, d_frontier_ptr, n, world, d_out_ptr):
         counts = (C.c_uint64 * world)()
         check(lib().impg_gpu_stage_route(self._h, d_frontier_ptr, n, world, d_out_ptr, counts))

@@ -62,6 +62,18 @@ class GpuBackend:
         counts = self.index.stage_route(frontier.data_ptr() if n else None, n, world, out.data_ptr())
         return out[:n], [int(c) for c in counts]
 
+    def reorder(self, hits, n_frontier):
+        """Hits that came home grouped by owner (each block ascending in fidx) -> ascending fidx, stable.
+        Native: a counting pass over the frontier indices (impg_gpu_stage_reorder), not a sort."""
+        self._sync()
+        n = hits.shape[0]
+        if n == 0:
+            return hits
+        hits = hits.contiguous()
+        out = torch.empty_like(hits)
+        self.index.stage_reorder(hits.data_ptr(), n, hits.shape[1], n_frontier, out.data_ptr())
+        return out
+
     def expand(self, frontier, transitive, params, want_hits=True, compact=False):
         """-> (hits int32[k,8] with fidx indexing `frontier`, accepted count).  Slots whose projection
         returned None (query_id == -1) stay in the list: they are rare and every consumer skips them.
@@ -121,6 +133,7 @@ class ShardedImpg:
         self.device = device if device is not None else torch.device("cpu")
         self.chunk_ranges = chunk_ranges
         self.local = getattr(backend, "index", None)
+        self.always_reorder = False  # tests: run the home-side reorder even with one rank
         # collectives run on the compute device (RCCL) unless the process group is
         # gloo, which moves host memory: then tensors hop through the CPU
         self.comm_device = self.device if dist.get_backend() != "gloo" else torch.device("cpu")
@@ -207,9 +220,11 @@ class ShardedImpg:
         back_counts = (torch.searchsorted(fidx, bounds[1:], right=False) - torch.searchsorted(fidx, bounds[:-1], right=False)).tolist()
         hits[:, 0] = recv[fidx, 3]  # (the hit list is ours: relabel in place)
         back, _ = self._all_to_all_rows(hits, back_counts)
-        if W == 1:
+        if W == 1 and not self.always_reorder:
             return back, accepted, recv.shape[0]  # one source: already in home frontier order
-        perm = torch.argsort(back[:, 0].to(torch.int64), stable=True)
+        if hasattr(self.backend, "reorder"):
+            return self.backend.reorder(back, front.shape[0]), accepted, recv.shape[0]
+        perm = torch.argsort(back[:, 0].to(torch.int64), stable=True)  # generic (CPU stand-in backends)
         return back[perm].contiguous(), accepted, recv.shape[0]
 
     # ---- batches ----------------------------------------------------------------------

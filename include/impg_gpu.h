@@ -287,6 +287,15 @@ int impg_gpu_stage_project16(impg_gpu_index_t *, const impg_gpu_frontier_t *d_fr
                              int transitive, const impg_gpu_params_t *params,
                              impg_gpu_hit16_t *d_hits, uint64_t total, uint64_t *accepted);
 
+/* reorder: the home side of a hop.  d_hits[n] (impg_gpu_hit_t: words_per_hit = 8, or impg_gpu_hit16_t: 4;
+ * fidx = index into the home frontier of n_frontier records) arrived grouped by owner rank, every
+ * owner's block in ascending fidx.  d_out receives them in ascending fidx, order within one fidx kept
+ * (what a stable sort by fidx gives): a frontier record lives on exactly one owner, so records of one
+ * fidx are already contiguous and a counting pass replaces the sort.  IMPG_E_INVALID if a fidx is out
+ * of range or shows up in two separate runs. */
+int impg_gpu_stage_reorder(impg_gpu_index_t *, const void *d_hits, size_t n, uint32_t words_per_hit,
+                           size_t n_frontier, void *d_out);
+
 /* route: stable partition of a frontier by owner rank (target_id % world).  d_out[n]
  * receives the records grouped by owner, in their original order within a group,
  * with qidx replaced by the record's index in d_frontier (the home index an owner

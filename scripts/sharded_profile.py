@@ -16,6 +16,13 @@ eng = sharded.ShardedImpg.from_paf(paf, 0, 1, device=0)
 eng.chunk_ranges = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 if os.environ.get("IMPG_SLICE"): eng.backend.slice_records = int(os.environ["IMPG_SLICE"])
 if os.environ.get("IMPG_NO_LOC"): eng.local.set_option("locality_min", 0)
+if os.environ.get("IMPG_REORDER"):  # take the home-side reorder even with one rank: "native" or "argsort"
+    eng.always_reorder = True
+    if os.environ["IMPG_REORDER"] == "argsort":
+        def _argsort(hits, n_front):
+            perm = torch.argsort(hits[:, 0].to(torch.int64), stable=True)
+            return hits[perm].contiguous()
+        eng.backend.reorder = _argsort
 T = collections.defaultdict(float)
 def timed(obj, name, label=None):
     f = getattr(obj, name)
@@ -26,7 +33,7 @@ def timed(obj, name, label=None):
         return r
     setattr(obj, name, w)
 timed(eng, "_all_to_all_rows"); timed(eng, "_any"); timed(eng.backend, "expand"); timed(eng.backend, "update"); timed(eng.backend, "begin")
-timed(eng, "_hop")
+timed(eng, "_hop"); timed(eng.backend, "reorder")
 bed = impg_amd.synth_bed(7, 100000)
 ids = np.array([eng.local.seq_id(impg_amd.synth_seq_name(i)) for i in range(200)], dtype=np.uint32)
 r = np.zeros(len(bed), dtype=impg_amd.RANGE_DTYPE)

@@ -46,6 +46,30 @@ def main():
                 want[:, 3] = order.to(torch.int32)
                 assert bool((out == want).all()), (n, W)
                 assert [int(x) for x in counts] == torch.bincount(owner, minlength=W).tolist()
+        # impg_gpu_stage_reorder: blocks (one per owner) of ascending fidx runs -> the stable order by fidx
+        for cols in (4, 8):
+            for n_front, W in ((1, 1), (50, 3), (200_000, 8)):
+                owner = torch.randint(0, W, (n_front,), generator=gen)
+                reps = torch.randint(0, 40, (n_front,), generator=gen)
+                reps[torch.rand(n_front, generator=gen) < 0.01] = 3000  # a few long runs
+                blocks = []
+                for w in range(W):
+                    idx = torch.nonzero(owner == w).flatten()
+                    blocks.append(torch.repeat_interleave(idx, reps[idx]))
+                fidx = torch.cat(blocks).to(torch.int32)
+                hits = torch.randint(-5, 1 << 30, (fidx.numel(), cols), dtype=torch.int32, generator=gen)
+                hits[:, 0] = fidx
+                hits = hits.cuda()
+                want = hits[torch.argsort(hits[:, 0].to(torch.int64), stable=True)]
+                got = eng.backend.reorder(hits, n_front)
+                assert got.shape == want.shape and bool((got == want).all()), (cols, n_front, W)
+        bad = torch.tensor([[0, 1, 2, 3], [1, 1, 2, 3], [0, 1, 2, 3]], dtype=torch.int32).cuda()  # fidx 0 in two runs
+        try:
+            eng.backend.reorder(bad, 2)
+            raise AssertionError("a split run must be rejected")
+        except impg_amd.ImpgGpuError:
+            pass
+        eng.always_reorder = True  # one rank still takes the home-side reorder below
     seq_len = int(c.seq_len(0))
     n_q = 18 + 5 * rank  # ranks own different numbers of queries
     rl = random_ranges(100 + rank, n_q, n_seq, seq_len, max_len=3000, min_len=120)

@@ -225,7 +225,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
     launch_group_heads(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), stream);
     uint32_t n_groups = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), P);
     if (n_groups) {
-      auto vt = std::make_unique<VisitedStore>();
+      auto vt = std::make_unique<VisitedStore>(&table_pool);
       vt->keys.reserve((size_t)n_groups * 8);
       gstart.reserve((size_t)n_groups * 4);
       launch_group_scatter(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), gid.as<uint32_t>(), gstart.as<uint32_t>(),
@@ -290,7 +290,7 @@ VisitedTables Engine::tables_view() const {
 uint32_t Engine::begin_transitive(const DeviceIndexView &v, const impg_gpu_range_t *d_ranges, uint32_t n,
                                   const impg_gpu_params_t &p, FrontierRec *d_self, DevBuf &frontier_out) {
   tables.clear();
-  auto t = std::make_unique<VisitedStore>();
+  auto t = std::make_unique<VisitedStore>(&table_pool);
   t->keys.reserve((size_t)n * 8); t->off.reserve((size_t)n * 4); t->len.reserve((size_t)n * 4);
   t->ranges.reserve((size_t)n * 8);
   t->n_groups = n;
@@ -309,7 +309,7 @@ uint32_t Engine::begin_transitive(const DeviceIndexView &v, const impg_gpu_range
 uint32_t Engine::begin_transitive_masked(const DeviceIndexView &v, const impg_gpu_range_t *d_ranges, uint32_t n,
                                          const impg_gpu_params_t &p, DevBuf &self, DevBuf &frontier_out) {
   tables.clear();
-  auto t = std::make_unique<VisitedStore>();
+  auto t = std::make_unique<VisitedStore>(&table_pool);
   t->keys.reserve((size_t)n * 8); t->off.reserve((size_t)n * 4 + 4); t->len.reserve((size_t)n * 4);
   t->n_groups = n;
   cap.reserve((size_t)n * 4);
@@ -459,7 +459,7 @@ void Engine::compact_tables() {
   d_flag2.reserve((size_t)g * 4); d_pos2.reserve((size_t)g * 4);
   launch_compact_last(d_ckey2.as<unsigned long long>(), g, d_flag2.as<uint32_t>(), stream);
   const uint32_t g2 = (uint32_t)scan(d_flag2.as<uint32_t>(), d_pos2.as<uint32_t>(), g);
-  auto nt = std::make_unique<VisitedStore>();
+  auto nt = std::make_unique<VisitedStore>(&table_pool);
   nt->keys.reserve((size_t)g2 * 8); nt->off.reserve((size_t)g2 * 4); nt->len.reserve((size_t)g2 * 4);
   launch_compact_select(tv, d_ckey2.as<unsigned long long>(), d_src2.as<unsigned long long>(), g, d_flag2.as<uint32_t>(),
                         d_pos2.as<uint32_t>(), nt->keys.as<unsigned long long>(), d_src.as<unsigned long long>(),

@@ -17,6 +17,7 @@ struct LevelBufs {  // one BFS level: its frontier and its hit slots
 struct VisitedStore {  // device storage of one VisitedTable
   DevBuf keys, off, len, ranges;
   uint32_t n_groups = 0;
+  explicit VisitedStore(BufPool *pool) { keys.pool = off.pool = len.pool = ranges.pool = pool; }
 };
 
 struct SplitBatch {};  // thrown when a level exceeds pair_budget: the caller halves the chunk
@@ -37,6 +38,7 @@ struct Engine {
       old_idx, cap, pcap, poff, pieces, n_pieces, foff, frontier_a, frontier_b, self_scratch, ranges_dev, stat_count,
       stat_cksum, stage_off;
   LevelBufs level_scratch;
+  BufPool table_pool;  // declared before `tables`: the tables hand their blocks back when they die
   std::vector<std::unique_ptr<VisitedStore>> tables;
   uint64_t last_projected = 0;
   uint64_t pair_budget = 1ull << 28;  // candidate pairs per level kept in HBM at once

@@ -115,13 +115,31 @@ struct HostSeqIndex {  // SequenceIndex (seqidx.rs)
   uint32_t get_or_insert(const std::string &name, int64_t len);
 };
 
+// ---- recycled device allocations ------------------------------------------------
+// The per-level visited tables are new buffers at every BFS level of every chunk; hipMalloc / hipFree cost
+// 0.1-1 ms each and hipFree synchronises the device, so their blocks go back to a free list instead.
+struct BufPool {
+  struct Blk { void *p; size_t cap; };
+  std::vector<Blk> free_;
+  size_t held = 0;                                  // bytes on the free list
+  static constexpr size_t MAX_HELD = 16ull << 30;   // beyond this the largest blocks are really freed
+  void *take(size_t bytes, size_t &cap_out);
+  void give(void *p, size_t cap);
+  ~BufPool();
+};
+
 // ---- simple growable device buffer ------------------------------------------
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  BufPool *pool = nullptr;     // set: blocks come from / go back to the pool
   void reserve(size_t bytes);  // contents are NOT preserved on growth
   void release();
-  void swap(DevBuf &o) { void *tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; }
+  void swap(DevBuf &o) {
+    void *tp = p; p = o.p; o.p = tp;
+    size_t tc = cap; cap = o.cap; o.cap = tc;
+    BufPool *tq = pool; pool = o.pool; o.pool = tq;
+  }
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
   ~DevBuf() { release(); }
   DevBuf() = default;

@@ -19,13 +19,64 @@ void DevBuf::reserve(size_t bytes) {
   if (bytes <= cap) return;
   release();
   size_t want = std::max<size_t>(bytes, 256);
+  if (pool) {
+    p = pool->take(want, cap);
+    return;
+  }
   IMPG_HIP(hipMalloc(&p, want));
   cap = want;
 }
 void DevBuf::release() {
-  if (p) (void)hipFree(p);
+  if (p) {
+    if (pool) pool->give(p, cap);
+    else (void)hipFree(p);
+  }
   p = nullptr;
   cap = 0;
+}
+
+void *BufPool::take(size_t bytes, size_t &cap_out) {
+  // best fit among the blocks that are not wastefully large for the request
+  const size_t limit = std::max<size_t>(4 * bytes, 1u << 20);
+  size_t best = free_.size();
+  for (size_t i = 0; i < free_.size(); i++)
+    if (free_[i].cap >= bytes && free_[i].cap <= limit && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
+  if (best != free_.size()) {
+    Blk b = free_[best];
+    free_[best] = free_.back();
+    free_.pop_back();
+    held -= b.cap;
+    cap_out = b.cap;
+    return b.p;
+  }
+  // a quarter of slack: the same level of the next chunk is about, not exactly, this size
+  size_t want = (bytes + bytes / 4 + 255) & ~(size_t)255;
+  void *p = nullptr;
+  if (hipMalloc(&p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    for (Blk &b : free_) (void)hipFree(b.p);  // out of memory: drop the free list and ask for the exact size
+    free_.clear();
+    held = 0;
+    want = bytes;
+    IMPG_HIP(hipMalloc(&p, want));
+  }
+  cap_out = want;
+  return p;
+}
+void BufPool::give(void *p, size_t cap) {
+  free_.push_back({p, cap});
+  held += cap;
+  while (held > MAX_HELD && !free_.empty()) {
+    size_t big = 0;
+    for (size_t i = 1; i < free_.size(); i++) if (free_[i].cap > free_[big].cap) big = i;
+    (void)hipFree(free_[big].p);
+    held -= free_[big].cap;
+    free_[big] = free_.back();
+    free_.pop_back();
+  }
+}
+BufPool::~BufPool() {
+  for (Blk &b : free_) (void)hipFree(b.p);
 }
 
 // Visit rank of the sorted positions [0,n) under the restated coitrees 0.4

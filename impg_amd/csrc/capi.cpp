@@ -267,6 +267,28 @@ int impg_gpu_index_create_from_paf_sharded(const char *const *paths, int n_paths
   IMPG_CATCH
 }
 
+int impg_gpu_index_save(const impg_gpu_index_t *ix, const char *path) {
+  IMPG_TRY
+  if (!ix || !path) throw Error{IMPG_E_INVALID, "null argument"};
+  save_index(*ix, path);
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_load(const char *path, int device, impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!path || !out) throw Error{IMPG_E_INVALID, "null argument"};
+  require_device(device);
+  auto ix = std::make_unique<impg_gpu_index>();
+  ix->device = device;
+  load_index(*ix, path);
+  ix->engine = new Engine(device);
+  ix->stream = ix->engine->stream;
+  *out = ix.release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
 void impg_gpu_index_destroy(impg_gpu_index_t *ix) { delete ix; }
 
 uint32_t impg_gpu_num_seqs(const impg_gpu_index_t *ix) { return (uint32_t)ix->seq.lens.size(); }

@@ -88,7 +88,8 @@ std::vector<Target> parse_bed_file(const std::string &path) {
 
 void usage() {
   fprintf(stderr,
-          "impg-gpu query -a <paf>... (-r seq:start-end | -b <bed>) (-d <bp> | --no-merge) [-x] [-m N]\n"
+          "impg-gpu index -a <paf>... -i <file> [--unidirectional] [--order coitrees|sorted] [--device N]\n"
+          "impg-gpu query (-a <paf>... | -i <file>) (-r seq:start-end | -b <bed>) (-d <bp> | --no-merge) [-x] [-m N]\n"
           "               [--transitive-dfs] [--multi-impg] [--min-transitive-len N] [--min-distance-between-ranges N]\n"
           "               [-l N] [--min-result-identity F] [-o auto|bed|bedpe|paf] [--unidirectional] [--order coitrees|sorted]\n"
           "               [--device N]\n");
@@ -97,10 +98,12 @@ void usage() {
 }  // namespace
 
 int main(int argc, char **argv) {
-  if (argc < 2 || strcmp(argv[1], "query") != 0) {
+  if (argc < 2 || (strcmp(argv[1], "query") != 0 && strcmp(argv[1], "index") != 0)) {
     usage();
     return 2;
   }
+  const bool index_only = strcmp(argv[1], "index") == 0;
+  std::string index_file;  // -i: a saved index (impg_gpu_index_save), read if it exists, else written after the build
   std::vector<std::string> pafs;
   std::string range, bed, ofmt = "auto";
   bool have_d = false, no_merge = false, transitive = false, dfs = false, unidirectional = false, multi = false;
@@ -135,11 +138,25 @@ int main(int argc, char **argv) {
     else if (a == "--unidirectional") unidirectional = true;
     else if (a == "--device") device = atoi(need(a.c_str()));
     else if (a == "--order") { std::string o = need("--order"); order = o == "sorted" ? IMPG_ORDER_SORTED : IMPG_ORDER_COITREES; }
-    else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbose" || a == "-i" || a == "--index") need(a.c_str());  // accepted, unused
+    else if (a == "-i" || a == "--index") index_file = need("-i");
+    else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbose") need(a.c_str());  // accepted, unused
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else die("unexpected argument '" + a + "'", 2);
   }
-  if (pafs.empty()) die("the following required arguments were not provided: --alignment-files", 2);
+  auto file_exists = [](const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; };
+  if (index_only) {  // `impg index` (main.rs:11321-11386): build once, keep the result
+    if (pafs.empty() || index_file.empty()) die("impg-gpu index needs --alignment-files and --index", 2);
+    std::vector<const char *> pp;
+    for (auto &p : pafs) pp.push_back(p.c_str());
+    impg_gpu_index_t *ix = nullptr;
+    if (impg_gpu_index_create_from_paf(pp.data(), (int)pp.size(), unidirectional ? 0 : 1, order, device, &ix) != IMPG_OK)
+      die(impg_gpu_last_error());
+    if (impg_gpu_index_save(ix, index_file.c_str()) != IMPG_OK) die(impg_gpu_last_error());
+    impg_gpu_index_destroy(ix);
+    return 0;
+  }
+  const bool load_saved = !index_file.empty() && file_exists(index_file);
+  if (pafs.empty() && !load_saved) die("the following required arguments were not provided: --alignment-files", 2);
   if (range.empty() == bed.empty()) die("exactly one of --target-range and --target-bed is required", 2);
   if (!have_d && !no_merge)  // MERGE_DISTANCE_REQUIRED_TEXT (main.rs:4288-4315)
     die("-d/--merge-distance is required. For `impg query`, pass `-d <bp>`. Use `--no-merge` to explicitly disable merging.");
@@ -153,8 +170,13 @@ int main(int argc, char **argv) {
   std::vector<const char *> pp;
   for (auto &p : pafs) pp.push_back(p.c_str());
   impg_gpu_index_t *ix = nullptr;
-  if (impg_gpu_index_create_from_paf(pp.data(), (int)pp.size(), unidirectional ? 0 : 1, order, device, &ix) != IMPG_OK)
-    die(impg_gpu_last_error());
+  if (load_saved) {
+    if (impg_gpu_index_load(index_file.c_str(), device, &ix) != IMPG_OK) die(impg_gpu_last_error());
+  } else {
+    if (impg_gpu_index_create_from_paf(pp.data(), (int)pp.size(), unidirectional ? 0 : 1, order, device, &ix) != IMPG_OK)
+      die(impg_gpu_last_error());
+    if (!index_file.empty() && impg_gpu_index_save(ix, index_file.c_str()) != IMPG_OK) die(impg_gpu_last_error());
+  }
 
   std::vector<Target> targets;
   if (!range.empty()) {

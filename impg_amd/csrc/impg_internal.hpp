@@ -162,6 +162,10 @@ long parse_cigar(const char *s, size_t n, uint32_t *out, size_t cap);
 // visit rank of each sorted position of an n-entry segment (order policy)
 void coitrees_visit_rank(uint32_t n, uint32_t *rank_out);
 
+// ---- saved device index (index_io.cpp) ------------------------------------------
+void save_index(const impg_gpu_index &ix, const char *path);
+void load_index(impg_gpu_index &ix, const char *path);  // ix.device set; fills everything but the engine
+
 // ---- BED (bed.cpp) -----------------------------------------------------------
 size_t bed_merge(impg_gpu_interval_t *iv, size_t n, int32_t merge_distance, bool merge_strands);
 
@@ -179,6 +183,12 @@ struct impg_gpu_index {
   std::vector<uint64_t> file_first;  // first record of every alignment file (+ the record count); empty = one file
   impg::DevBuf d_seg, d_starts, d_ends, d_ends_t, d_pmax, d_starts_lvl, d_pmax_lvl, d_rank, d_mrank, d_entries, d_ops, d_ext_cp, d_idp, d_seq_len;
   impg::DeviceIndexView view{};
+  // the device arrays in a fixed order with their content sizes (index_io.cpp writes / reads them back)
+  static constexpr int N_BLOBS = 14;
+  impg::DevBuf *blob(int k);
+  size_t blob_bytes[N_BLOBS] = {};
+  bool multi_file = false;
+  void bind_view(uint32_t n_seq, uint32_t sorted_order);  // view pointers from the device arrays
   size_t device_bytes = 0;
   impg::Engine *engine = nullptr;  // scratch + streams (engine.cpp)
   ~impg_gpu_index();

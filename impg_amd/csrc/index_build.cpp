@@ -112,9 +112,11 @@ void coitrees_visit_rank(uint32_t n, uint32_t *rank) {
 
 namespace {
 
-template <class T> void upload(DevBuf &b, const std::vector<T> &v, size_t &acc) {
+template <class T> void upload(impg_gpu_index &ix, int k, const std::vector<T> &v, size_t &acc) {
+  DevBuf &b = *ix.blob(k);
   b.reserve(std::max<size_t>(v.size() * sizeof(T) + 64, 256));  // + slack: kernels read whole 16-byte vectors
   if (!v.empty()) IMPG_HIP(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  ix.blob_bytes[k] = v.size() * sizeof(T);
   acc += v.size() * sizeof(T);
 }
 
@@ -423,41 +425,52 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   std::vector<int32_t> sl(n_seq);
   for (uint32_t s = 0; s < n_seq; s++) sl[s] = (int32_t)std::min<int64_t>(std::max<int64_t>(seq_len[s], 0), INT32_MAX);
   size_t acc = 0;
-  upload(ix.d_seg, seg, acc);
-  upload(ix.d_starts, starts, acc);
-  upload(ix.d_ends, ends, acc);
-  upload(ix.d_ends_t, ends_t, acc);
-  upload(ix.d_pmax, pmax, acc);
-  upload(ix.d_starts_lvl, starts_lvl, acc);
-  upload(ix.d_pmax_lvl, pmax_lvl, acc);
-  upload(ix.d_rank, rank, acc);
-  if (multi_file) upload(ix.d_mrank, mrank, acc);
-  upload(ix.d_entries, ent, acc);
-  upload(ix.d_ops, pool, acc);
-  upload(ix.d_ext_cp, ext_cp, acc);
-  upload(ix.d_idp, idp, acc);
-  upload(ix.d_seq_len, sl, acc);
+  upload(ix, 0, seg, acc);
+  upload(ix, 1, starts, acc);
+  upload(ix, 2, ends, acc);
+  upload(ix, 3, ends_t, acc);
+  upload(ix, 4, pmax, acc);
+  upload(ix, 5, starts_lvl, acc);
+  upload(ix, 6, pmax_lvl, acc);
+  upload(ix, 7, rank, acc);
+  if (multi_file) upload(ix, 8, mrank, acc);
+  upload(ix, 9, ent, acc);
+  upload(ix, 10, pool, acc);
+  upload(ix, 11, ext_cp, acc);
+  upload(ix, 12, idp, acc);
+  upload(ix, 13, sl, acc);
   ix.device_bytes = acc;
   ix.n_entries = n_entries;
   ix.n_tiles = n_tiles;
   ix.n_targets = n_targets;
-  ix.view.seg = ix.d_seg.as<SegDesc>();
-  ix.view.starts = ix.d_starts.as<int32_t>();
-  ix.view.ends = ix.d_ends.as<int32_t>();
-  ix.view.ends_t = ix.d_ends_t.as<int32_t>();
-  ix.view.pmax = ix.d_pmax.as<int32_t>();
-  ix.view.starts_lvl = ix.d_starts_lvl.as<int32_t>();
-  ix.view.pmax_lvl = ix.d_pmax_lvl.as<int32_t>();
-  ix.view.rank = ix.d_rank.as<uint32_t>();
-  ix.view.mrank = multi_file ? ix.d_mrank.as<uint32_t>() : ix.d_rank.as<uint32_t>();
-  ix.view.entries = ix.d_entries.as<Entry>();
-  ix.view.ops = ix.d_ops.as<uint32_t>();
-  ix.view.ext_cp = ix.d_ext_cp.as<uint32_t>();
-  ix.view.idp = ix.d_idp.as<uint4>();
-  ix.view.seq_len = ix.d_seq_len.as<int32_t>();
-  ix.view.n_seq = n_seq;
-  ix.view.n_entries = (uint32_t)n_entries;
-  ix.view.sorted_order = order_policy == IMPG_ORDER_SORTED;
+  ix.multi_file = multi_file;
+  ix.bind_view(n_seq, order_policy == IMPG_ORDER_SORTED);
 }
 
 }  // namespace impg
+
+impg::DevBuf *impg_gpu_index::blob(int k) {
+  impg::DevBuf *const b[N_BLOBS] = {&d_seg, &d_starts, &d_ends, &d_ends_t, &d_pmax, &d_starts_lvl, &d_pmax_lvl,
+                                    &d_rank, &d_mrank, &d_entries, &d_ops, &d_ext_cp, &d_idp, &d_seq_len};
+  return b[k];
+}
+void impg_gpu_index::bind_view(uint32_t n_seq, uint32_t sorted_order) {
+  using namespace impg;
+  view.seg = d_seg.as<SegDesc>();
+  view.starts = d_starts.as<int32_t>();
+  view.ends = d_ends.as<int32_t>();
+  view.ends_t = d_ends_t.as<int32_t>();
+  view.pmax = d_pmax.as<int32_t>();
+  view.starts_lvl = d_starts_lvl.as<int32_t>();
+  view.pmax_lvl = d_pmax_lvl.as<int32_t>();
+  view.rank = d_rank.as<uint32_t>();
+  view.mrank = multi_file ? d_mrank.as<uint32_t>() : d_rank.as<uint32_t>();
+  view.entries = d_entries.as<Entry>();
+  view.ops = d_ops.as<uint32_t>();
+  view.ext_cp = d_ext_cp.as<uint32_t>();
+  view.idp = d_idp.as<uint4>();
+  view.seq_len = d_seq_len.as<int32_t>();
+  view.n_seq = n_seq;
+  view.n_entries = (uint32_t)n_entries;
+  view.sorted_order = sorted_order;
+}

@@ -1,0 +1,131 @@
+// A built index written to / read from one file: the device arrays exactly as they sit in HBM
+// plus the host-side sequence table.  The reference keeps its index in a `.impg` file for the same reason
+// (impg.rs:1655-1721 / :1787-1850): parsing and tokenising the alignments is the expensive part of start-up and is
+// done once.  The reference's file stores byte offsets into the PAF and re-reads the CIGAR text on demand; this one
+// stores the tokenised, tiled ops themselves, so a load is one read + one host-to-device copy per array and the PAF
+// is not needed again.  The two formats are not interchangeable.
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+
+#include "impg_internal.hpp"
+
+namespace impg {
+namespace {
+
+constexpr char MAGIC[8] = {'I', 'M', 'P', 'G', 'H', 'B', 'M', '1'};
+constexpr uint32_t VERSION = 1;
+
+struct Header {  // fixed-size, little-endian (gfx950 hosts are x86-64)
+  char magic[8];
+  uint32_t version, tile_words, tile_ops, tile_subs, entry_bytes, n_seq, sorted_order, multi_file;
+  uint64_t n_records, n_entries, n_tiles, n_targets, n_names, n_file_first, n_tgt_off;
+  uint64_t blob_bytes[impg_gpu_index::N_BLOBS];
+};
+
+struct File {
+  FILE *f = nullptr;
+  std::string path;
+  File(const char *p, const char *mode) : path(p) {
+    f = fopen(p, mode);
+    if (!f) throw Error{IMPG_E_IO, "cannot open " + path + ": " + strerror(errno)};
+  }
+  ~File() { if (f) fclose(f); }
+  void write(const void *p, size_t n) {
+    if (n && fwrite(p, 1, n, f) != n) throw Error{IMPG_E_IO, "short write to " + path};
+  }
+  void read(void *p, size_t n) {
+    if (n && fread(p, 1, n, f) != n) throw Error{IMPG_E_IO, path + " is truncated"};
+  }
+};
+
+}  // namespace
+
+void save_index(const impg_gpu_index &cix, const char *path) {
+  impg_gpu_index &ix = const_cast<impg_gpu_index &>(cix);  // (blob() is not const; nothing is modified)
+  IMPG_HIP(hipSetDevice(ix.device));
+  Header h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, MAGIC, 8);
+  h.version = VERSION;
+  h.tile_words = TILE_WORDS; h.tile_ops = TILE_OPS; h.tile_subs = TILE_SUBS; h.entry_bytes = sizeof(Entry);
+  h.n_seq = ix.view.n_seq; h.sorted_order = ix.view.sorted_order; h.multi_file = ix.multi_file ? 1 : 0;
+  h.n_records = ix.n_records; h.n_entries = ix.n_entries; h.n_tiles = ix.n_tiles; h.n_targets = ix.n_targets;
+  h.n_names = ix.seq.names.size(); h.n_file_first = ix.file_first.size(); h.n_tgt_off = ix.h_tgt_off.size();
+  for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) h.blob_bytes[k] = ix.blob_bytes[k];
+  File out(path, "wb");
+  out.write(&h, sizeof h);
+  out.write(ix.seq.lens.data(), ix.seq.lens.size() * sizeof(int64_t));
+  for (const std::string &nm : ix.seq.names) {
+    const uint32_t n = (uint32_t)nm.size();
+    out.write(&n, 4);
+    out.write(nm.data(), n);
+  }
+  out.write(ix.file_first.data(), ix.file_first.size() * sizeof(uint64_t));
+  out.write(ix.h_tgt_off.data(), ix.h_tgt_off.size() * sizeof(uint32_t));
+  std::vector<char> buf;
+  for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) {
+    const size_t n = ix.blob_bytes[k];
+    buf.resize(n);
+    if (n) IMPG_HIP(hipMemcpy(buf.data(), ix.blob(k)->p, n, hipMemcpyDeviceToHost));
+    out.write(buf.data(), n);
+  }
+  const uint64_t tail = 0x454E44474D50ull ^ h.n_entries;  // an end mark: a file cut short is caught even if sizes line up
+  out.write(&tail, 8);
+  if (fflush(out.f) != 0) throw Error{IMPG_E_IO, "cannot flush " + out.path};
+}
+
+void load_index(impg_gpu_index &ix, const char *path) {
+  File in(path, "rb");
+  Header h;
+  in.read(&h, sizeof h);
+  if (memcmp(h.magic, MAGIC, 8) != 0) throw Error{IMPG_E_INVALID, in.path + " is not a saved impg-gpu index"};
+  if (h.version != VERSION || h.tile_words != TILE_WORDS || h.tile_ops != TILE_OPS || h.tile_subs != TILE_SUBS ||
+      h.entry_bytes != sizeof(Entry))
+    throw Error{IMPG_E_UNSUPPORTED, in.path + " was written by a build with a different index layout: rebuild it"};
+  if (h.n_names != 0 && h.n_names != h.n_seq) throw Error{IMPG_E_INVALID, in.path + ": inconsistent sequence table"};
+  IMPG_HIP(hipSetDevice(ix.device));
+  ix.n_records = h.n_records; ix.n_entries = h.n_entries; ix.n_tiles = h.n_tiles; ix.n_targets = h.n_targets;
+  ix.multi_file = h.multi_file != 0;
+  ix.seq.lens.resize(h.n_seq);
+  in.read(ix.seq.lens.data(), (size_t)h.n_seq * sizeof(int64_t));
+  ix.seq.names.clear();
+  ix.seq.name_to_id.clear();
+  for (uint64_t i = 0; i < h.n_names; i++) {
+    uint32_t n = 0;
+    in.read(&n, 4);
+    if (n > (1u << 20)) throw Error{IMPG_E_INVALID, in.path + ": unreasonable sequence name length"};
+    std::string nm(n, '\0');
+    in.read(nm.data(), n);
+    ix.seq.name_to_id.emplace(nm, (uint32_t)i);
+    ix.seq.names.push_back(std::move(nm));
+  }
+  if (h.n_file_first > h.n_records + 2 || h.n_tgt_off > (uint64_t)h.n_seq + 1) throw Error{IMPG_E_INVALID, in.path + ": bad table sizes"};
+  ix.file_first.resize(h.n_file_first);
+  in.read(ix.file_first.data(), h.n_file_first * sizeof(uint64_t));
+  ix.h_tgt_off.resize(h.n_tgt_off);
+  in.read(ix.h_tgt_off.data(), h.n_tgt_off * sizeof(uint32_t));
+  std::vector<char> buf;
+  size_t acc = 0;
+  for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) {
+    const size_t n = h.blob_bytes[k];
+    if (n > (1ull << 40)) throw Error{IMPG_E_INVALID, in.path + ": unreasonable array size"};
+    buf.resize(n);
+    in.read(buf.data(), n);
+    DevBuf &b = *ix.blob(k);
+    if (n || k != 8) b.reserve(std::max<size_t>(n + 64, 256));  // (array 8, mrank, only exists for several files)
+    if (n) IMPG_HIP(hipMemcpy(b.p, buf.data(), n, hipMemcpyHostToDevice));
+    ix.blob_bytes[k] = n;
+    acc += n;
+  }
+  uint64_t tail = 0;
+  in.read(&tail, 8);
+  if (tail != (0x454E44474D50ull ^ h.n_entries)) throw Error{IMPG_E_INVALID, in.path + " is damaged (end mark)"};
+  if (ix.blob_bytes[9] != h.n_entries * sizeof(Entry) || ix.blob_bytes[13] != (size_t)h.n_seq * 4 ||
+      ix.blob_bytes[10] != h.n_tiles * TILE_WORDS * 4)
+    throw Error{IMPG_E_INVALID, in.path + ": array sizes do not match the header"};
+  ix.device_bytes = acc;
+  ix.bind_view(h.n_seq, h.sorted_order);
+}
+
+}  // namespace impg

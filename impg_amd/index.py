@@ -2,6 +2,7 @@
 src/impg_index.rs:21-121) over the C ABI.  Method names and argument meaning
 follow the trait; the batch_* methods are the fast path (one launch sequence for
 many ranges)."""
+import os
 import ctypes as C
 import math
 
@@ -126,6 +127,17 @@ class GpuImpg:
             check(lib().impg_gpu_index_create_sharded(rec.ctypes.data, rec.size, ops.ctypes.data, ops.size, sl.ctypes.data,
                                                       sl.size, int(bidirectional), order, device, shard, n_shards,
                                                       C.byref(h)))
+        return cls(h)
+
+    def save(self, path):
+        """impg_gpu_index_save: the built index (device arrays + sequence table) as one file."""
+        check(lib().impg_gpu_index_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path, device=0):
+        """impg_gpu_index_load: what `save` wrote, back in HBM without touching the alignment files."""
+        h = C.c_void_p(None)
+        check(lib().impg_gpu_index_load(os.fsencode(path), device, C.byref(h)))
         return cls(h)
 
     @classmethod

@@ -122,6 +122,15 @@ int impg_gpu_index_create_from_paf_sharded(const char *const *paths, int n_paths
                                            int bidirectional, int order_policy, int device,
                                            uint32_t shard, uint32_t n_shards,
                                            impg_gpu_index_t **out);
+/* A built index as one file: the role of the reference's `.impg` file (writer impg.rs:1655-1721, reader
+ * :1787-1850; `impg index` / the implicit index cache of `impg query`, main.rs:11321-11386): pay for
+ * parsing and tokenising once.  The file holds the device arrays as they sit in HBM plus the sequence
+ * table (so the alignment files are not needed again, unlike with `.impg`, which stores byte offsets into
+ * them); it is this library's own layout ("IMPGHBM1"), tied to the build's tile constants, and NOT the
+ * reference's IMPGIDX2 format.  A sharded index saves / loads its shard.  load: IMPG_E_INVALID for a
+ * foreign or damaged file, IMPG_E_UNSUPPORTED for a layout version this build does not read. */
+int impg_gpu_index_save(const impg_gpu_index_t *, const char *path);
+int impg_gpu_index_load(const char *path, int device, impg_gpu_index_t **out);
 void impg_gpu_index_destroy(impg_gpu_index_t *);
 
 /* seq_index() (seqidx.rs), target_ids(), num_targets() (impg_index.rs:105-113) */

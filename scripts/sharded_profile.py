@@ -33,7 +33,7 @@ def timed(obj, name, label=None):
         return r
     setattr(obj, name, w)
 timed(eng, "_all_to_all_rows"); timed(eng, "_any"); timed(eng.backend, "expand"); timed(eng.backend, "update"); timed(eng.backend, "begin")
-timed(eng, "_hop"); timed(eng.backend, "reorder")
+timed(eng, "_hop"); timed(eng.backend, "reorder"); timed(eng.backend, "route")
 bed = impg_amd.synth_bed(7, 100000)
 ids = np.array([eng.local.seq_id(impg_amd.synth_seq_name(i)) for i in range(200)], dtype=np.uint32)
 r = np.zeros(len(bed), dtype=impg_amd.RANGE_DTYPE)

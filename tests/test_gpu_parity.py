@@ -640,3 +640,56 @@ def test_masked_regions_multi_impg(tmp_path, seed):
                    dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=10),
                    dict(transitive=True, max_depth=0, min_transitive_len=300, min_distance_between_ranges=10)]:
             assert_same(g, c, ranges, masked_regions=mask, multi_impg=True, **kw)
+
+
+@pytest.mark.parametrize("n_files", [1, 3])
+def test_saved_index_round_trip(tmp_path, n_files):
+    """impg_gpu_index_save / _load (the role of the reference's .impg file, impg.rs:1655-1850): a loaded index answers
+    every kind of query exactly like the one that was built from the alignments, names and lengths included; the
+    CLI builds it with `index` and reads it back with `query -i` without the alignment files."""
+    import os
+    import subprocess
+    texts = [random_paf(700 + k, 150, n_seq=6, seq_len=20000, weird=(k == 1), self_aln=True, max_ops=300)[0] for k in range(n_files)]
+    g, c = both_files(tmp_path, texts)
+    saved = str(tmp_path / "index.impghbm")
+    g.save(saved)
+    h = impg_amd.GpuImpg.load(saved)
+    assert h.num_seqs() == g.num_seqs() and h.num_entries() == g.num_entries() and h.num_records() == g.num_records()
+    assert h.num_targets() == g.num_targets() and h.target_ids().tolist() == g.target_ids().tolist()
+    assert h.device_bytes() == g.device_bytes()
+    for i in range(g.num_seqs()):
+        assert h.seq_name(i) == g.seq_name(i) and h.seq_len(i) == g.seq_len(i) and h.seq_id(g.seq_name(i)) == i
+    ranges = random_ranges(5, 50, g.num_seqs(), 20000, max_len=3000, min_len=50)
+    for kw in [dict(), dict(min_identity=0.7), dict(transitive=True, max_depth=3, min_transitive_len=20),
+               dict(transitive=True, dfs=True, max_depth=2), dict(transitive=True, max_depth=2, multi_impg=True)]:
+        assert_same(h, c, ranges, **kw)
+    kw = dict(transitive=True, max_depth=2, min_transitive_len=40)
+    a = g.query_batch(ranges[:10], impg_amd.make_params(store_cigar=True, **kw))
+    b = h.query_batch(ranges[:10], impg_amd.make_params(store_cigar=True, **kw))
+    for i in range(10):
+        assert a[i].tolist() == b[i].tolist() and [x.tolist() for x in a.cigars(i)] == [x.tolist() for x in b.cigars(i)]
+    # a second save of the loaded index is the same file
+    again = str(tmp_path / "again.impghbm")
+    h.save(again)
+    assert open(saved, "rb").read() == open(again, "rb").read()
+    # damaged / foreign files are refused
+    blob = open(saved, "rb").read()
+    for bad in (blob[:len(blob) // 2], b"IMPGIDX2" + blob[8:], blob[:-8] + bytes(8)):
+        p = str(tmp_path / "bad.bin")
+        open(p, "wb").write(bad)
+        with pytest.raises(impg_amd.ImpgGpuError):
+            impg_amd.GpuImpg.load(p)
+    # CLI: index once, query from the saved file alone
+    cli = os.path.join(os.path.dirname(impg_amd.__file__), "impg-gpu")
+    pafs = [str(tmp_path / ("f%d.paf" % k)) for k in range(n_files)]
+    for p, t in zip(pafs, texts):
+        open(p, "w").write(t)
+    cli_saved = str(tmp_path / "cli.impghbm")
+    r = subprocess.run([cli, "index", "-a"] + pafs + ["-i", cli_saved], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    t, s, e = next(x for x in ranges if x[2] - x[1] >= 150)
+    rng = "%s:%d-%d" % (c.seq_name(t), s, e)
+    r1 = subprocess.run([cli, "query", "-i", cli_saved, "-r", rng, "-d", "100", "-x"], capture_output=True, text=True)
+    r2 = subprocess.run([cli, "query", "-a"] + pafs + ["-r", rng, "-d", "100", "-x"], capture_output=True, text=True)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
+    assert r1.stdout == r2.stdout == c.query_bed(c.seq_name(t), s, e, merge_distance=100, transitive=True)

@@ -397,6 +397,12 @@ int impg_gpu_query_batch(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, s
 
 int impg_gpu_query_batch_masked(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n,
                                 const impg_gpu_params_t *params, const impg_gpu_mask_t *mask, impg_gpu_results_t **out) {
+  return impg_gpu_query_batch_filtered(ix, ranges, n, params, mask, nullptr, out);
+}
+
+int impg_gpu_query_batch_filtered(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n,
+                                  const impg_gpu_params_t *params, const impg_gpu_mask_t *mask, const uint8_t *subset_keep,
+                                  impg_gpu_results_t **out) {
   IMPG_TRY
   if (!ix || !params || !out || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
   check_ranges(ranges, n);
@@ -404,6 +410,16 @@ int impg_gpu_query_batch_masked(impg_gpu_index_t *ix, const impg_gpu_range_t *ra
   Engine::check_params(*params);
   IMPG_HIP(hipSetDevice(ix->device));
   MaskScope mask_scope(E, *ix, mask, *params);
+  struct SubsetScope {
+    Engine &E;
+    ~SubsetScope() { E.subset_on = false; }
+  } subset_scope{E};
+  if (subset_keep) {
+    const size_t ns = ix->view.n_seq;
+    E.subset_keep.reserve(std::max<size_t>(ns, 256));
+    if (ns) IMPG_HIP(hipMemcpy(E.subset_keep.p, subset_keep, ns, hipMemcpyHostToDevice));
+    E.subset_on = true;
+  }
   auto res = std::make_unique<impg_gpu_results>();
   E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
   if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));

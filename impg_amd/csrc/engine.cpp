@@ -152,6 +152,8 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
                  acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity,
                  store_cigar ? &sl : nullptr, pl, stream);
+  if (subset_on)
+    launch_subset_filter(fr, L.pair_range.as<uint32_t>(), L.n_pairs, h.qid, subset_keep.as<uint8_t>(), cur_ranges, stream);
   if (multi && L.n_pairs) {
     // sort every range's hits by (query_id, q.first, q.last, t.first, t.last) (multi_impg.rs:582-592)
     const size_t b = std::max<size_t>((size_t)L.n_pairs * 4, 256);
@@ -352,6 +354,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   store_cigar = p.store_cigar != 0 && keep != nullptr;  // slices are only materialised for full results
   multi = p.multi_impg != 0;
   const DeviceIndexView &v = ix.view;
+  cur_ranges = d_ranges;
   ev_next = 0;
   timed.clear();
   tables.clear();

@@ -85,6 +85,11 @@ struct Engine {
                             const impg_gpu_params_t &p, FrontierRec *d_self, DevBuf &frontier_out);
   // masked_regions of the batch in flight (capi sets these around Engine::run): CSR over the sequence ids, the
   // sequence length a set starts with at level -1 / on first touch (visited_entry, impg.rs:2041-2055)
+  // subset filter of the batch in flight: keep[sequence id] on the device (null = none), and the batch's ranges
+  // (a hit on the query's own target always stays)
+  DevBuf subset_keep;
+  bool subset_on = false;
+  const impg_gpu_range_t *cur_ranges = nullptr;
   bool masked = false;
   DevBuf mask_off, mask_ranges, mask_init_len, mask_touch_len;
   DevBuf self_off;        // masked batches: query q's self intervals are self[self_off[q] .. self_off[q+1])

@@ -1401,6 +1401,21 @@ __global__ __launch_bounds__(256) void frontier_emit_kernel(const unsigned long 
   }
 }
 
+// subset filter (impg.rs:2176-2185, :2430-2439; multi_impg.rs:888-896; main.rs:11693-11696): a hit survives iff its
+// query sequence is the query's own target or the caller's keep[] says its name matches.  A dropped hit becomes a
+// slot without a projection, which every later pass already skips.
+__global__ __launch_bounds__(256) void subset_filter_kernel(const FrontierRec *__restrict__ fr,
+                                                            const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
+                                                            uint32_t *__restrict__ qid, const uint8_t *__restrict__ keep,
+                                                            const impg_gpu_range_t *__restrict__ ranges) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n_pairs) return;
+  const uint32_t q = qid[p];
+  if (q == HIT_NONE) return;
+  if (keep[q]) return;
+  if (q != ranges[fr[pair_range[p]].qidx].target_id) qid[p] = HIT_NONE;
+}
+
 // level -1 under masked_regions (impg.rs:2077-2112, :2331-2373): the input range goes through
 // SortedRanges::insert (min_distance 0) on a copy of its target's mask list; every piece is a self interval,
 // the pieces of at least min_transitive_len open the frontier.
@@ -2022,6 +2037,10 @@ void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, 
                           const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s) {
   if (!n_groups) return;
   frontier_emit_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(gkey, poff, n_pieces, foff, n_groups, pieces, out);
+}
+void launch_subset_filter(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *qid,
+                          const uint8_t *keep, const impg_gpu_range_t *ranges, hipStream_t s) {
+  if (n_pairs) subset_filter_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, qid, keep, ranges);
 }
 void launch_mask_caps(const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *mask_off, uint32_t n_seq, uint32_t *cap,
                       hipStream_t s) {

@@ -102,6 +102,8 @@ void launch_visited_update(const VisitedTables &vt, const unsigned long long *sv
                            uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, hipStream_t s);
 void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
                           const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s);
+void launch_subset_filter(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *qid,
+                          const uint8_t *keep, const impg_gpu_range_t *ranges, hipStream_t s);
 // level -1 under a mask: the input range is inserted into a copy of its target's mask list (impg.rs:2084-2086);
 // cap[q] = that list's length + 1 bounds both the new list and the pieces
 void launch_mask_caps(const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *mask_off, uint32_t n_seq, uint32_t *cap,

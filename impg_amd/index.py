@@ -222,13 +222,22 @@ class GpuImpg:
         m = _lib.Mask(len(ids), seq.ctypes.data, slen.ctypes.data, off.ctypes.data, rng.ctypes.data)
         return m, (seq, slen, off, rng)
 
-    def query_batch(self, ranges, params=None, masked_regions=None, **kw):
+    def query_batch(self, ranges, params=None, masked_regions=None, subset_keep=None, **kw):
         """masked_regions: one map for the whole batch (impg_gpu_query_batch_masked); every range starts
-        from its own clone of it, as the reference's per-range calls do (impg.rs:2077-2081)."""
+        from its own clone of it, as the reference's per-range calls do (impg.rs:2077-2081).
+        subset_keep: uint8[num_seqs], the host's SubsetFilter::matches verdict per sequence id."""
         p = params or make_params(**kw)
         r = self._ranges(ranges)
         h = C.c_void_p(None)
-        if masked_regions is not None:
+        if subset_keep is not None:
+            keep = np.ascontiguousarray(subset_keep, dtype=np.uint8)
+            if keep.size != self.num_seqs():
+                raise _lib.ImpgGpuError(_lib.IMPG_E_INVALID, "subset_keep needs one entry per sequence")
+            m, keepalive = self._mask(masked_regions) if masked_regions is not None else (None, None)
+            check(lib().impg_gpu_query_batch_filtered(self._h, r.ctypes.data, r.size, C.byref(p),
+                                                      C.byref(m) if m is not None else None, keep.ctypes.data, C.byref(h)))
+            del keepalive
+        elif masked_regions is not None:
             m, keep = self._mask(masked_regions)
             check(lib().impg_gpu_query_batch_masked(self._h, r.ctypes.data, r.size, C.byref(p), C.byref(m), C.byref(h)))
             del keep
@@ -249,22 +258,24 @@ class GpuImpg:
                              store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
                              approximate_mode=False, subset_filter=None):
         """ImpgIndex::query_transitive_bfs (impg_index.rs:79-94)."""
-        if subset_filter is not None or approximate_mode:
-            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "subset_filter / approximate_mode")
+        if approximate_mode:
+            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "approximate_mode")
         p = make_params(True, False, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
                         min_gap_compressed_identity, store_cigar)
-        return self.query_batch([(target_id, range_start, range_end)], p, masked_regions=masked_regions)[0]
+        return self.query_batch([(target_id, range_start, range_end)], p, masked_regions=masked_regions,
+                                subset_keep=subset_filter)[0]
 
     def query_transitive_dfs(self, target_id, range_start, range_end, masked_regions=None, max_depth=2,
                              min_transitive_len=101, min_distance_between_ranges=10, min_output_length=None,
                              store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
                              approximate_mode=False, subset_filter=None):
         """ImpgIndex::query_transitive_dfs (impg_index.rs:63-77)."""
-        if subset_filter is not None or approximate_mode:
-            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "subset_filter / approximate_mode")
+        if approximate_mode:
+            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "approximate_mode")
         p = make_params(True, True, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
                         min_gap_compressed_identity, store_cigar)
-        return self.query_batch([(target_id, range_start, range_end)], p, masked_regions=masked_regions)[0]
+        return self.query_batch([(target_id, range_start, range_end)], p, masked_regions=masked_regions,
+                                subset_keep=subset_filter)[0]
 
     def query_batch_stats(self, ranges, params=None, counts=True, checksums=True, device_ptr=None, n=None, **kw):
         """Throughput form: results stay in HBM; returns (Stats, counts, checksums)."""

@@ -187,6 +187,16 @@ typedef struct {
 int impg_gpu_query_batch_masked(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n,
                                 const impg_gpu_params_t *params, const impg_gpu_mask_t *mask,
                                 impg_gpu_results_t **out);
+/* subset_filter: Option<&SubsetFilter> of the three trait methods (`--subset-sequence-list`).  The name
+ * matching (SubsetFilter::matches, subset_filter.rs:23-60: exact / coordinate-stripped / sample / haplotype
+ * keys) is host string work and stays with the host: it hands over its verdict per sequence id,
+ * subset_keep[num_seqs], non-zero = matches.  A hit is kept iff its query sequence is the range's own
+ * target or subset_keep says so -- while exploring for the transitive queries (impg.rs:2176-2185,
+ * :2430-2439; multi_impg.rs:888-896: a dropped hit is neither reported nor expanded), after the query
+ * otherwise (perform_query, main.rs:11693-11696).  mask and subset_keep may each be NULL. */
+int impg_gpu_query_batch_filtered(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n,
+                                  const impg_gpu_params_t *params, const impg_gpu_mask_t *mask,
+                                  const uint8_t *subset_keep, impg_gpu_results_t **out);
 int impg_gpu_query(impg_gpu_index_t *, uint32_t target_id, int32_t start, int32_t end,
                    const impg_gpu_params_t *params, impg_gpu_results_t **out);
 

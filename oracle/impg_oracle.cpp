@@ -669,7 +669,8 @@ struct Hit { /* tuple of impg.rs:2384 */
 
 /* lookup + clipped projection of one frontier range (impg.rs:2392-2460 / 2140-2206) */
 bool frontier_hits(const oracle_index &ix, const TreeMap &trees, uint32_t cur_id, int32_t cs, int32_t ce,
-                   bool store_cigar, double min_identity, std::vector<Hit> &local) {
+                   bool store_cigar, double min_identity, std::vector<Hit> &local,
+                   const uint8_t *subset_keep = nullptr, uint32_t root_target = 0) {
   auto it = trees.find(cur_id);
   if (it == trees.end()) return true;
   bool ok = true;
@@ -682,6 +683,9 @@ bool frontier_hits(const oracle_index &ix, const TreeMap &trees, uint32_t cur_id
     int r = project_overlapping_interval(ix, interval.metadata, cur_id, overlap_start, overlap_end,
                                          min_identity, a);
     if (r < 0) { ok = false; return; }
+    /* subset filter: keep if it is the (original) target or its name matches (impg.rs:2176-2185, :2430-2439);
+     * the name matching itself (subset_filter.rs:23-60) stays with the caller: keep[id] is its verdict */
+    if (r == 1 && subset_keep && !(a.q_id == root_target || subset_keep[a.q_id])) r = 0;
     if (r == 1) {
       Hit h;
       h.query_id = a.q_id; h.qs = a.q_first; h.qe = a.q_last;
@@ -751,7 +755,7 @@ void parallel_for(size_t n, int threads, const std::function<void(size_t)> &f);
 /* Impg::query_transitive_bfs (impg.rs:2311-2597) */
 bool impg_bfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, int32_t range_start,
               int32_t range_end, const oracle_params_t &p, int threads, const MaskMap *mask,
-              std::vector<AdjustedInterval> &results) {
+              std::vector<AdjustedInterval> &results, const uint8_t *subset_keep = nullptr) {
   const bool masked_none = mask == nullptr; /* :2330-2335 */
   std::unordered_map<uint32_t, SortedRanges> visited;
   if (mask) visited = *mask;
@@ -771,7 +775,7 @@ bool impg_bfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, 
     auto body = [&](size_t i) {
       uint64_t b = g_nproj; /* thread-local: worker's or ours */
       if (!frontier_hits(ix, trees, current[i].id, current[i].s, current[i].e, p.store_cigar,
-                         p.min_identity, query_results[i])) ok = false;
+                         p.min_identity, query_results[i], subset_keep, target_id)) ok = false;
       nproj_par += g_nproj - b;
     };
     if (threads > 1 && current.size() > 1) parallel_for(current.size(), threads, body);
@@ -808,7 +812,7 @@ bool impg_bfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, 
 /* Impg::query_transitive_dfs (impg.rs:2057-2309) */
 bool impg_dfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, int32_t range_start,
               int32_t range_end, const oracle_params_t &p, const MaskMap *mask,
-              std::vector<AdjustedInterval> &results) {
+              std::vector<AdjustedInterval> &results, const uint8_t *subset_keep = nullptr) {
   const bool masked_none = mask == nullptr; /* :2076-2081 */
   std::unordered_map<uint32_t, SortedRanges> visited;
   if (mask) visited = *mask;
@@ -825,7 +829,7 @@ bool impg_dfs(const oracle_index &ix, const TreeMap &trees, uint32_t target_id, 
     stack.pop_back();
     if (p.max_depth > 0 && cur.depth >= p.max_depth) continue; /* :2125 (skips the re-sort too) */
     std::vector<Hit> hits;
-    if (!frontier_hits(ix, trees, cur.id, cur.s, cur.e, p.store_cigar, p.min_identity, hits)) return false;
+    if (!frontier_hits(ix, trees, cur.id, cur.s, cur.e, p.store_cigar, p.min_identity, hits, subset_keep, target_id)) return false;
     for (auto &h : hits)
       update_with_hit(ix, visited, h, p.min_output_length, p.min_distance_between_ranges,
                       p.min_transitive_len, false, masked_none, results,
@@ -890,7 +894,7 @@ bool multi_query_all_indices(const oracle_index &ix, uint32_t target_id, int32_t
 /* MultiImpg::transitive_query_impl (multi_impg.rs:796-991) */
 bool multi_transitive(const oracle_index &ix, uint32_t target_id, int32_t range_start, int32_t range_end,
                       const oracle_params_t &p, bool use_dfs, const MaskMap *mask,
-                      std::vector<AdjustedInterval> &results) {
+                      std::vector<AdjustedInterval> &results, const uint8_t *subset_keep = nullptr) {
   std::unordered_map<uint32_t, SortedRanges> visited;
   if (mask) visited = *mask; /* :814-815 */
   else for (uint32_t id = 0; id < ix.seq_index.id_to_name.size(); id++) { /* :817-822 */
@@ -915,6 +919,7 @@ bool multi_transitive(const oracle_index &ix, uint32_t target_id, int32_t range_
     for (auto &result : step) {
       uint32_t query_id = result.q_id;
       if (query_id == cur.id) continue; /* :883-885 */
+      if (subset_keep && query_id != target_id && !subset_keep[query_id]) continue; /* :888-896 */
       int32_t aqs = std::min(result.q_first, result.q_last), aqe = std::max(result.q_first, result.q_last);
       int32_t length = std::abs(result.q_last - result.q_first);
       bool out = p.min_output_length >= 0 ? length >= p.min_output_length : true;
@@ -957,16 +962,25 @@ bool multi_transitive(const oracle_index &ix, uint32_t target_id, int32_t range_
 
 /* dispatch as perform_query does (main.rs:11641-11699), without the retain */
 bool run_query(const oracle_index &ix, uint32_t target_id, int32_t s, int32_t e, const oracle_params_t &p,
-               int threads, std::vector<AdjustedInterval> &results, const MaskMap *mask = nullptr) {
-  if (p.multi_impg) {
-    if (p.transitive) return multi_transitive(ix, target_id, s, e, p, p.dfs != 0, mask, results);
-    return multi_query_all_indices(ix, target_id, s, e, p.store_cigar, p.min_identity, results);
-  }
+               int threads, std::vector<AdjustedInterval> &results, const MaskMap *mask = nullptr,
+               const uint8_t *subset_keep = nullptr) {
   if (p.transitive) {
-    if (p.dfs) return impg_dfs(ix, ix.trees, target_id, s, e, p, mask, results);
-    return impg_bfs(ix, ix.trees, target_id, s, e, p, threads, mask, results);
+    if (p.multi_impg) return multi_transitive(ix, target_id, s, e, p, p.dfs != 0, mask, results, subset_keep);
+    if (p.dfs) return impg_dfs(ix, ix.trees, target_id, s, e, p, mask, results, subset_keep);
+    return impg_bfs(ix, ix.trees, target_id, s, e, p, threads, mask, results, subset_keep);
   }
-  return impg_query(ix, ix.trees, target_id, s, e, p.store_cigar, p.min_identity, results);
+  bool ok = p.multi_impg ? multi_query_all_indices(ix, target_id, s, e, p.store_cigar, p.min_identity, results)
+                         : impg_query(ix, ix.trees, target_id, s, e, p.store_cigar, p.min_identity, results);
+  if (ok && subset_keep) { /* non-transitive: filtered after the query (main.rs:11693-11696, subset_filter.rs:84-100) */
+    size_t w = 0;
+    for (size_t i = 0; i < results.size(); i++)
+      if (results[i].q_id == target_id || subset_keep[results[i].q_id]) {
+        if (w != i) results[w] = std::move(results[i]);
+        w++;
+      }
+    results.resize(w);
+  }
+  return ok;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1268,7 +1282,15 @@ long oracle_query(const oracle_index_t *ix, uint32_t target_id, int32_t start, i
 long oracle_query_masked(const oracle_index_t *ix, uint32_t target_id, int32_t start, int32_t end, const oracle_params_t *p,
                          uint32_t n_mask, const uint32_t *mask_seq, const int32_t *mask_seq_len, const uint64_t *mask_off,
                          const int32_t *mask_ranges, oracle_interval_t *out, size_t cap) {
+  return oracle_query_filtered(ix, target_id, start, end, p, 1, n_mask, mask_seq, mask_seq_len, mask_off, mask_ranges, nullptr, out, cap);
+}
+
+long oracle_query_filtered(const oracle_index_t *ix, uint32_t target_id, int32_t start, int32_t end, const oracle_params_t *p,
+                           int has_mask, uint32_t n_mask, const uint32_t *mask_seq, const int32_t *mask_seq_len,
+                           const uint64_t *mask_off, const int32_t *mask_ranges, const uint8_t *subset_keep,
+                           oracle_interval_t *out, size_t cap) {
   MaskMap mask;
+  if (!has_mask) n_mask = 0;
   for (uint32_t i = 0; i < n_mask; i++) {
     SortedRanges sr;
     sr.sequence_length = mask_seq_len[i];
@@ -1278,8 +1300,8 @@ long oracle_query_masked(const oracle_index_t *ix, uint32_t target_id, int32_t s
   }
   std::vector<AdjustedInterval> results;
   g_nproj = 0;
-  if (!p->transitive) return -2; /* only the transitive queries take masked_regions */
-  if (!run_query(*ix, target_id, start, end, *p, 1, results, &mask)) return -1;
+  if (has_mask && !p->transitive) return -2; /* only the transitive queries take masked_regions */
+  if (!run_query(*ix, target_id, start, end, *p, 1, results, has_mask ? &mask : nullptr, subset_keep)) return -1;
   for (size_t i = 0; i < results.size() && i < cap; i++)
     out[i] = {results[i].q_id, results[i].q_first, results[i].q_last, results[i].t_id, results[i].t_first, results[i].t_last};
   return (long)results.size();

@@ -123,6 +123,16 @@ long oracle_query_masked(const oracle_index_t *, uint32_t target_id, int32_t sta
                          const int32_t *mask_seq_len, const uint64_t *mask_off,
                          const int32_t *mask_ranges, oracle_interval_t *out, size_t cap);
 
+/* The same with an optional mask (has_mask) and an optional subset filter: subset_keep[id] != 0 where
+ * SubsetFilter::matches(name of id) holds (subset_filter.rs:23-60; the string matching stays with the
+ * caller).  A hit is kept iff its query id is the query's own target or subset_keep says so: during the
+ * exploration for the transitive queries (impg.rs:2176-2185, :2430-2439; multi_impg.rs:888-896), after the
+ * query otherwise (main.rs:11693-11696). */
+long oracle_query_filtered(const oracle_index_t *, uint32_t target_id, int32_t start, int32_t end,
+                           const oracle_params_t *p, int has_mask, uint32_t n_mask, const uint32_t *mask_seq,
+                           const int32_t *mask_seq_len, const uint64_t *mask_off, const int32_t *mask_ranges,
+                           const uint8_t *subset_keep, oracle_interval_t *out, size_t cap);
+
 /* Same with store_cigar: cigar_off[cap+1], cigar_ops[ops_cap] receive the
  * Vec<CigarOp> of every result (CSR); *n_ops = total ops (may exceed ops_cap). */
 long oracle_query_cigar(const oracle_index_t *, uint32_t target_id, int32_t start,

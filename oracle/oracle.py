@@ -96,6 +96,9 @@ def lib():
         L.oracle_query_masked.restype = C.c_long
         L.oracle_query_masked.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_uint32,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_query_filtered.restype = C.c_long
+        L.oracle_query_filtered.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_int, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_query_cigar.restype = C.c_long
         L.oracle_query_cigar.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p,
                                          C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
@@ -262,7 +265,7 @@ class OracleIndex:
         lib().oracle_target_entries(self._h, target_id, out.ctypes.data, n)
         return out[:n]
 
-    def query(self, target_id, start, end, params=None, masked_regions=None, **kw):
+    def query(self, target_id, start, end, params=None, masked_regions=None, subset_keep=None, **kw):
         """Results (numpy structured array) in reference emission order.
         masked_regions: {sequence id: (sequence_length, [(start, end), ...])} -- the
         Option<&FxHashMap<u32, SortedRanges>> of query_transitive_{bfs,dfs}."""
@@ -270,9 +273,20 @@ class OracleIndex:
         cap = 1 << 12
         if masked_regions is not None:
             mseq, mlen, moff, mrng = pack_mask(masked_regions)
+        if subset_keep is not None:  # subset filter: keep[id] = SubsetFilter::matches(name of id), decided by the caller
+            keep = np.ascontiguousarray(subset_keep, dtype=np.uint8)
+            assert keep.size == self.num_seqs()
         while True:
             out = np.zeros(cap, dtype=INTERVAL_DTYPE)
-            if masked_regions is not None:
+            if subset_keep is not None:
+                if masked_regions is not None:
+                    n = lib().oracle_query_filtered(self._h, target_id, start, end, C.byref(p), 1, len(mseq), mseq.ctypes.data,
+                                                    mlen.ctypes.data, moff.ctypes.data, mrng.ctypes.data, keep.ctypes.data,
+                                                    out.ctypes.data, cap)
+                else:
+                    n = lib().oracle_query_filtered(self._h, target_id, start, end, C.byref(p), 0, 0, None, None, None, None,
+                                                    keep.ctypes.data, out.ctypes.data, cap)
+            elif masked_regions is not None:
                 n = lib().oracle_query_masked(self._h, target_id, start, end, C.byref(p), len(mseq), mseq.ctypes.data,
                                               mlen.ctypes.data, moff.ctypes.data, mrng.ctypes.data, out.ctypes.data, cap)
             else:

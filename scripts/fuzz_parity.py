@@ -76,8 +76,12 @@ while time.time() < t_end:
                 rs = [(int(cuts[2 * i]), int(cuts[2 * i + 1])) for i in range(len(cuts) // 2)]
                 mask[sid] = (int(seq_len if rng.random() < 0.8 else rng.integers(1, seq_len + 500)), rs)
         cigar = False  # (the oracle's masked entry point returns rows only)
+    keep = None
+    if rng.random() < 0.25:  # subset filter: the host's per-sequence verdict
+        keep = (rng.random(g.num_seqs()) < rng.choice([0.2, 0.6, 0.9])).astype(np.uint8)
+        cigar = False
     params = impg_amd.make_params(store_cigar=cigar, **kw)
-    res = g.query_batch(ranges, params, masked_regions=mask)
+    res = g.query_batch(ranges, params, masked_regions=mask, subset_keep=keep)
     total = 0
     for i, (t, s, e) in enumerate(ranges):
         if cigar:
@@ -85,7 +89,7 @@ while time.time() < t_end:
             got_cg = res.cigars(i)
             assert [x.tolist() for x in got_cg] == [x.tolist() for x in wcg], ("cigar", seed, i, kw)
         else:
-            want = c.query(t, s, e, masked_regions=mask, **kw)
+            want = c.query(t, s, e, masked_regions=mask, subset_keep=keep, **kw)
         assert res[i].tolist() == want.tolist(), ("rows", seed, i, (t, s, e), kw, mask)
         total += c.last_projection_count()
         n_rows += len(want)
@@ -93,7 +97,7 @@ while time.time() < t_end:
     # text outputs on the ranges long enough for perform_query's validation
     mtl = kw.get("min_transitive_len", 101)
     ok = [i for i, (t, s, e) in enumerate(ranges) if e - s >= mtl]
-    if ok and not kw.get("multi_impg") and mask is None:
+    if ok and not kw.get("multi_impg") and mask is None and keep is None:
         sub = [ranges[i] for i in ok]
         d = int(rng.choice([-1, 0, 30, 1000]))
         names = ["n%d" % i for i in ok]

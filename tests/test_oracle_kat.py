@@ -371,3 +371,23 @@ def test_masked_regions_by_hand():
         assert len(res) == 0
     with pytest.raises(RuntimeError):
         ix.query(0, 25, 75, transitive=False, masked_regions=full)
+
+
+# subset filter (impg.rs:2176-2185, :2430-2439; multi_impg.rs:888-896; main.rs:11693-11696): hand-derived on the same
+# chain A = B = C.  keep[id] is SubsetFilter::matches(name) as decided by the caller.
+def test_subset_filter_by_hand():
+    ix = o.OracleIndex(paf_text=paf("A\t1000\t0\t100\t+\tB\t1000\t0\t100" + L100,
+                                    "B\t1000\t0\t100\t+\tC\t1000\t0\t100" + L100))
+    A, B, C_ = (0, 25, 75, 0, 25, 75), (1, 25, 75, 0, 25, 75), (2, 25, 75, 1, 25, 75)
+    for flavour in (dict(), dict(dfs=True), dict(multi_impg=True), dict(multi_impg=True, dfs=True)):
+        kw = dict(transitive=True, max_depth=0, min_transitive_len=0, **flavour)
+        # only C matches: B is dropped where it is found, so the walk never gets to C
+        assert _tuples(ix.query(0, 25, 75, subset_keep=[0, 0, 1], **kw)) == [A]
+        # only B matches: from B, A is kept (it is the query's own target), C is dropped
+        assert _tuples(ix.query(0, 25, 75, subset_keep=[0, 1, 0], **kw)) == sorted([A, B, (0, 25, 75, 1, 25, 75)])
+        # everything matches: the unfiltered result
+        assert _tuples(ix.query(0, 25, 75, subset_keep=[1, 1, 1], **kw)) == _tuples(ix.query(0, 25, 75, **kw))
+    # non-transitive: filtered after the query; the self interval stays
+    for flavour in (dict(), dict(multi_impg=True)):
+        assert _tuples(ix.query(1, 25, 75, subset_keep=[0, 0, 1], **flavour)) == sorted([(1, 25, 75, 1, 25, 75), C_])
+        assert _tuples(ix.query(1, 25, 75, subset_keep=[0, 0, 0], **flavour)) == [(1, 25, 75, 1, 25, 75)]

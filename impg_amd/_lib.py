@@ -93,6 +93,7 @@ SYMBOLS = [
     ("impg_gpu_query_batch", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), C.POINTER(_P)]),
     ("impg_gpu_query_batch_masked", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, C.POINTER(_P)]),
     ("impg_gpu_query_batch_filtered", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, _P, C.POINTER(_P)]),
+    ("impg_gpu_subset_keep", C.c_int, [C.c_char_p, C.c_size_t, _P, C.c_size_t, _P, C.POINTER(C.c_size_t)]),
     ("impg_gpu_query", C.c_int, [_P, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params), C.POINTER(_P)]),
     ("impg_gpu_results_num_ranges", C.c_size_t, [_P]),
     ("impg_gpu_results_total", C.c_size_t, [_P]),

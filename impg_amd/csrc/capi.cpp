@@ -267,6 +267,16 @@ int impg_gpu_index_create_from_paf_sharded(const char *const *paths, int n_paths
   IMPG_CATCH
 }
 
+int impg_gpu_subset_keep(const char *list_text, size_t len, const char *const *names, size_t n, uint8_t *keep_out,
+                         size_t *n_entries) {
+  IMPG_TRY
+  if ((!list_text && len) || (n && (!names || !keep_out))) throw Error{IMPG_E_INVALID, "null argument"};
+  const size_t e = subset_select(list_text, len, names, n, keep_out);
+  if (n_entries) *n_entries = e;
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
 int impg_gpu_index_save(const impg_gpu_index_t *ix, const char *path) {
   IMPG_TRY
   if (!ix || !path) throw Error{IMPG_E_INVALID, "null argument"};

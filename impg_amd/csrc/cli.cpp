@@ -91,7 +91,7 @@ void usage() {
           "impg-gpu index -a <paf>... -i <file> [--unidirectional] [--order coitrees|sorted] [--device N]\n"
           "impg-gpu query (-a <paf>... | -i <file>) (-r seq:start-end | -b <bed>) (-d <bp> | --no-merge) [-x] [-m N]\n"
           "               [--transitive-dfs] [--multi-impg] [--min-transitive-len N] [--min-distance-between-ranges N]\n"
-          "               [-l N] [--min-result-identity F] [-o auto|bed|bedpe|paf] [--unidirectional] [--order coitrees|sorted]\n"
+          "               [-l N] [--min-result-identity F] [--subset-sequence-list FILE] [-o auto|bed|bedpe|paf] [--unidirectional] [--order coitrees|sorted]\n"
           "               [--device N]\n");
 }
 
@@ -110,6 +110,7 @@ int main(int argc, char **argv) {
   long long merge_d = 0;
   long max_depth = 2, min_tl = -1, mdbr = 10, min_out = -1;
   double min_ident = NAN;
+  std::string subset_list;  // --subset-sequence-list: a file of sequence names (main.rs:4357, :11709-11720)
   int device = 0, order = IMPG_ORDER_COITREES;
   for (int i = 2; i < argc; i++) {
     std::string a = argv[i];
@@ -134,6 +135,7 @@ int main(int argc, char **argv) {
     else if (a == "--min-distance-between-ranges") mdbr = atol(need(a.c_str()));
     else if (a == "-l" || a == "--min-output-length") min_out = atol(need("-l"));
     else if (a == "--min-result-identity") min_ident = atof(need(a.c_str()));
+    else if (a == "--subset-sequence-list") subset_list = need(a.c_str());
     else if (a == "-o" || a == "--output-format") ofmt = need("-o");
     else if (a == "--unidirectional") unidirectional = true;
     else if (a == "--device") device = atoi(need(a.c_str()));
@@ -217,7 +219,25 @@ int main(int argc, char **argv) {
   p.min_identity = min_ident;
   p.store_cigar = fmt != "bed";  // CIGARs for PAF / BEDPE only (main.rs:7447)
   impg_gpu_results_t *res = nullptr;
-  if (impg_gpu_query_batch(ix, ranges.data(), ranges.size(), &p, &res) != IMPG_OK) die(impg_gpu_last_error());
+  std::vector<uint8_t> keep;
+  if (!subset_list.empty()) {  // load_subset_filter (subset_filter.rs:63-82) + one matches() per sequence
+    FILE *f = fopen(subset_list.c_str(), "rb");
+    if (!f) die("Failed to read subset sequence list '" + subset_list + "'");
+    std::string text;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
+    fclose(f);
+    const uint32_t ns = impg_gpu_num_seqs(ix);
+    std::vector<const char *> nm(ns);
+    for (uint32_t i = 0; i < ns; i++) nm[i] = impg_gpu_seq_name(ix, i);
+    keep.resize(ns);
+    size_t entries = 0;
+    if (impg_gpu_subset_keep(text.data(), text.size(), nm.data(), ns, keep.data(), &entries) != IMPG_OK) die(impg_gpu_last_error());
+    if (entries == 0) die("Subset sequence list '" + subset_list + "' did not contain any sequence names");
+  }
+  if (impg_gpu_query_batch_filtered(ix, ranges.data(), ranges.size(), &p, nullptr, keep.empty() ? nullptr : keep.data(), &res) != IMPG_OK)
+    die(impg_gpu_last_error());
   char *text = nullptr;
   size_t len = 0;
   const int rc = fmt == "bed" ? impg_gpu_results_bed(res, ix, names.data(), &p, merge_distance, &text, &len)

@@ -166,6 +166,9 @@ void coitrees_visit_rank(uint32_t n, uint32_t *rank_out);
 void save_index(const impg_gpu_index &ix, const char *path);
 void load_index(impg_gpu_index &ix, const char *path);  // ix.device set; fills everything but the engine
 
+// ---- subset lists (subset.cpp): keep[i] = the list selects names[i]; returns the number of list entries
+size_t subset_select(const char *text, size_t len, const char *const *names, size_t n, uint8_t *keep);
+
 // ---- BED (bed.cpp) -----------------------------------------------------------
 size_t bed_merge(impg_gpu_interval_t *iv, size_t n, int32_t merge_distance, bool merge_strands);
 

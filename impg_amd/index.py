@@ -338,6 +338,16 @@ class GpuImpg:
         return [ms[0], ms[1], ms[2]], n.value
 
 
+def subset_keep(list_text, names):
+    """impg_gpu_subset_keep: (uint8 verdict per name, number of list entries) for a --subset-sequence-list text."""
+    data = list_text.encode() if isinstance(list_text, str) else bytes(list_text)
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    keep = np.zeros(len(names), dtype=np.uint8)
+    n_entries = C.c_size_t(0)
+    check(lib().impg_gpu_subset_keep(data, len(data), arr, len(names), keep.ctypes.data, C.byref(n_entries)))
+    return keep, int(n_entries.value)
+
+
 def bed_merge(intervals, merge_distance, merge_strands=True):
     a = np.ascontiguousarray(intervals, dtype=INTERVAL_DTYPE).copy()
     n = lib().impg_gpu_bed_merge(a.ctypes.data, a.size, merge_distance, int(merge_strands))

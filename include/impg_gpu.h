@@ -197,6 +197,13 @@ int impg_gpu_query_batch_masked(impg_gpu_index_t *, const impg_gpu_range_t *rang
 int impg_gpu_query_batch_filtered(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n,
                                   const impg_gpu_params_t *params, const impg_gpu_mask_t *mask,
                                   const uint8_t *subset_keep, impg_gpu_results_t **out);
+/* The name matching for hosts that do not bring their own SubsetFilter: list_text is the content of a
+ * `--subset-sequence-list` file (one name per line, '#' comments; parse_subset_filter, subset_filter.rs:117-141);
+ * keep_out[i] = SubsetFilter::matches(names[i]) (:23-60: exact, without ":start-end", or by the
+ * sample / sample+haplotype key of "S_hapN…" and "S#N#…" names, :143-176).  *n_entries = SubsetFilter::entry_count
+ * (the reference refuses a list with 0 entries, :76-81).  Host-only: needs no device. */
+int impg_gpu_subset_keep(const char *list_text, size_t len, const char *const *names, size_t n, uint8_t *keep_out,
+                         size_t *n_entries);
 int impg_gpu_query(impg_gpu_index_t *, uint32_t target_id, int32_t start, int32_t end,
                    const impg_gpu_params_t *params, impg_gpu_results_t **out);
 

@@ -34,6 +34,7 @@
 #include <functional>
 #include <limits>
 #include <map>
+#include <set>
 #include <string>
 #include <thread>
 #include <unistd.h>
@@ -1305,6 +1306,87 @@ long oracle_query_filtered(const oracle_index_t *ix, uint32_t target_id, int32_t
   for (size_t i = 0; i < results.size() && i < cap; i++)
     out[i] = {results[i].q_id, results[i].q_first, results[i].q_last, results[i].t_id, results[i].t_first, results[i].t_last};
   return (long)results.size();
+}
+
+/* ------------------------------------------------------------------------ */
+/* SubsetFilter (subset_filter.rs:8-60, :117-176), transcribed                */
+/* ------------------------------------------------------------------------ */
+namespace {
+struct SubsetFilter {
+  std::set<std::string> exact, normalized, sample_ids;
+  std::set<std::pair<std::string, std::string>> sample_haps;
+};
+std::string rust_trim(const std::string &s) { /* ASCII subset of str::trim */
+  size_t a = 0, b = s.size();
+  auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; };
+  while (a < b && ws(s[a])) a++;
+  while (b > a && ws(s[b - 1])) b--;
+  return s.substr(a, b - a);
+}
+/* extract_sample_and_hap (:143-176): returns false for None; hap empty = None */
+bool extract_sample_and_hap(const std::string &name, std::string &sample, std::string &hap) {
+  hap.clear();
+  size_t idx = name.find("_hap");
+  if (idx != std::string::npos) {
+    sample = name.substr(0, idx);
+    for (size_t i = idx + 4; i < name.size() && isdigit((unsigned char)name[i]); i++) hap.push_back(name[i]);
+    return true;
+  }
+  size_t h = name.find('#');
+  if (h != std::string::npos) { /* split_once('#') */
+    sample = name.substr(0, h);
+    std::string rest = name.substr(h + 1);
+    std::string hap_fragment = rest.substr(0, rest.find('#'));
+    for (char c : hap_fragment) { if (!isdigit((unsigned char)c)) break; hap.push_back(c); }
+    return true;
+  }
+  if (name.find(':') == std::string::npos && !rust_trim(name).empty()) { sample = name; return true; }
+  return false;
+}
+SubsetFilter parse_subset_filter(const std::string &contents) { /* :117-141 */
+  SubsetFilter f;
+  size_t p = 0;
+  while (p <= contents.size()) {
+    size_t e = contents.find('\n', p);
+    if (e == std::string::npos) e = contents.size();
+    std::string line = contents.substr(p, e - p);
+    p = e + 1;
+    std::string trimmed = rust_trim(line);
+    if (trimmed.empty() || trimmed[0] == '#') { if (e == contents.size()) break; continue; }
+    f.exact.insert(trimmed);
+    std::string no_coords = trimmed.substr(0, trimmed.find(':'));
+    f.normalized.insert(no_coords);
+    std::string sample, hap;
+    if (extract_sample_and_hap(no_coords, sample, hap)) {
+      if (!hap.empty()) f.sample_haps.insert({sample, hap});
+      else f.sample_ids.insert(sample);
+    }
+    if (e == contents.size()) break;
+  }
+  return f;
+}
+bool matches_sample_keys(const SubsetFilter &f, const std::string &seq_name) { /* :45-59 */
+  std::string sample, hap;
+  if (extract_sample_and_hap(seq_name, sample, hap)) {
+    if (!hap.empty() && f.sample_haps.count({sample, hap})) return true;
+    if (f.sample_ids.count(sample)) return true;
+  }
+  return false;
+}
+bool subset_matches(const SubsetFilter &f, const std::string &seq_name) { /* :23-43 */
+  if (f.exact.count(seq_name)) return true;
+  std::string no_coords = seq_name.substr(0, seq_name.find(':'));
+  if (seq_name != no_coords && f.exact.count(no_coords)) return true;
+  if (f.normalized.count(no_coords)) return true;
+  if (matches_sample_keys(f, no_coords)) return true;
+  return matches_sample_keys(f, seq_name);
+}
+} // namespace
+
+long oracle_subset_matches(const char *list_text, const char *const *names, size_t n, uint8_t *out) {
+  SubsetFilter f = parse_subset_filter(list_text);
+  for (size_t i = 0; i < n; i++) out[i] = subset_matches(f, names[i]) ? 1 : 0;
+  return (long)f.exact.size(); /* entry_count (:19-21) */
 }
 
 long oracle_query_cigar(const oracle_index_t *ix, uint32_t target_id, int32_t start, int32_t end, const oracle_params_t *p,

@@ -133,6 +133,10 @@ long oracle_query_filtered(const oracle_index_t *, uint32_t target_id, int32_t s
                            const int32_t *mask_seq_len, const uint64_t *mask_off, const int32_t *mask_ranges,
                            const uint8_t *subset_keep, oracle_interval_t *out, size_t cap);
 
+/* SubsetFilter: parse_subset_filter(list_text) then matches(names[i]) -> out[i]; returns entry_count
+ * (subset_filter.rs:19-60, :117-176). */
+long oracle_subset_matches(const char *list_text, const char *const *names, size_t n, uint8_t *out);
+
 /* Same with store_cigar: cigar_off[cap+1], cigar_ops[ops_cap] receive the
  * Vec<CigarOp> of every result (CSR); *n_ops = total ops (may exceed ops_cap). */
 long oracle_query_cigar(const oracle_index_t *, uint32_t target_id, int32_t start,

@@ -199,6 +199,17 @@ class SortedRanges:
         return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
 
 
+def subset_matches(list_text, names):
+    """(uint8 verdict per name, entry_count) of the reference's SubsetFilter for a list file's text."""
+    L = lib()
+    L.oracle_subset_matches.restype = C.c_long
+    L.oracle_subset_matches.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    out = np.zeros(len(names), dtype=np.uint8)
+    n = L.oracle_subset_matches(list_text.encode(), arr, len(names), out.ctypes.data)
+    return out, int(n)
+
+
 def pack_mask(masked_regions):
     """{seq id: (sequence_length, [(start, end), ...])} -> the four flat arrays of the C interfaces
     (ids ascending, u64 CSR offsets, int32 start/end pairs)."""

@@ -734,3 +734,37 @@ def test_subset_filter(tmp_path, seed):
     t, s0, e0 = ranges[0]
     got = g.query_transitive_bfs(t, s0, e0, subset_filter=keep, max_depth=3)
     assert got.tolist() == c.query(t, s0, e0, subset_keep=keep, transitive=True, max_depth=3).tolist()
+
+
+def test_cli_subset_sequence_list(tmp_path):
+    """`impg-gpu query --subset-sequence-list`: the list is read and matched on the host (impg_gpu_subset_keep), the
+    verdicts filter on the device; same bytes as the library calls, and the reference's two error messages."""
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(impg_amd.__file__), "impg-gpu")
+    text, names = random_paf(131, 250, n_seq=8, seq_len=20000, self_aln=True)
+    g, c = both(tmp_path, text)
+    paf = str(tmp_path / "t.paf")
+    all_names = [g.seq_name(i) for i in range(g.num_seqs())]
+    lst = str(tmp_path / "subset.txt")
+    with open(lst, "w") as f:
+        f.write("# kept\n%s\n  %s:5-10\t\n\n%s\n" % (all_names[1], all_names[3], all_names[6]))
+    keep, entries = impg_amd.subset_keep(open(lst).read(), all_names)
+    assert entries == 3 and keep.tolist() == [1 if i in (1, 3, 6) else 0 for i in range(len(all_names))]
+    t, s, e = next(x for x in random_ranges(4, 40, 8, 20000, max_len=3000, min_len=200))
+    rng = "%s:%d-%d" % (g.seq_name(t), s, e)
+    for flags, kw in ((["-x", "-m", "3"], dict(transitive=True, max_depth=3)), ([], dict())):
+        r = subprocess.run([cli, "query", "-a", paf, "-r", rng, "-d", "50", "--subset-sequence-list", lst] + flags,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        p = impg_amd.make_params(**kw)
+        want = g.query_batch([(t, s, e)], p, subset_keep=keep).bed([rng], merge_distance=50, params=p)
+        assert r.stdout == want
+        assert g.query_batch([(t, s, e)], p, subset_keep=keep)[0].tolist() == c.query(t, s, e, subset_keep=keep, **kw).tolist()
+        full = subprocess.run([cli, "query", "-a", paf, "-r", rng, "-d", "50"] + flags, capture_output=True, text=True)
+        assert full.stdout != r.stdout  # (the list does change the answer)
+    empty = str(tmp_path / "empty.txt")
+    open(empty, "w").write("# nothing\n\n")
+    for bad in (empty, str(tmp_path / "missing.txt")):
+        r = subprocess.run([cli, "query", "-a", paf, "-r", rng, "-d", "50", "--subset-sequence-list", bad], capture_output=True, text=True)
+        assert r.returncode != 0 and r.stdout == "" and r.stderr.startswith("Error:")

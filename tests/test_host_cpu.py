@@ -142,3 +142,37 @@ def test_cli_fails_loudly_without_gpu(tmp_path):
     assert r.returncode != 0 and r.stdout == "" and "no HIP device" in r.stderr
     r = subprocess.run([cli, "query", "-a", str(paf), "-r", "A:0-100"], capture_output=True, text=True)
     assert r.returncode != 0 and "merge-distance is required" in r.stderr
+
+
+def test_subset_keep_reference_kat_and_differential():
+    """impg_gpu_subset_keep (host-only string logic): the reference's own vectors (subset_filter.rs:181-199), then
+    random lists / names against the oracle's transcription."""
+    import numpy as np
+    import impg_amd
+    from oracle import oracle as o
+    from tests.test_oracle_kat import SUBSET_KAT, SUBSET_LIST
+    got, entries = impg_amd.subset_keep(SUBSET_LIST, [n for n, _ in SUBSET_KAT])
+    assert got.tolist() == [w for _, w in SUBSET_KAT] and entries == 5
+    rng = np.random.default_rng(5)
+    parts = ["HG001", "HG002", "NA12", "chr1", "chr2", "s", "x_y", ""]
+
+    def name():
+        k = rng.integers(0, 7)
+        a, b = parts[rng.integers(0, len(parts))], parts[rng.integers(0, len(parts))]
+        d = str(rng.integers(0, 3)) if rng.random() < 0.7 else ""
+        base = [a, a + "#" + d + "#" + b, a + "#" + d, a + "_hap" + d + "_v1", a + "_hap" + d, a + "#" + b, a + "##" + b][k]
+        if rng.random() < 0.3:
+            base += ":%d-%d" % (rng.integers(0, 50), rng.integers(50, 99))
+        return base
+
+    for _ in range(300):
+        lines = []
+        for _ in range(int(rng.integers(0, 6))):
+            x = name()
+            x = [x, "  " + x + "\t", "# " + x, x + "\r", ""][rng.integers(0, 5)]
+            lines.append(x)
+        text = "\n".join(lines) + ("\n" if rng.random() < 0.5 else "")
+        names = [name() for _ in range(12)] + [" ", ":", "#", "_hap"]
+        want, we = o.subset_matches(text, names)
+        got, ge = impg_amd.subset_keep(text, names)
+        assert got.tolist() == want.tolist() and ge == we, (text, names)

@@ -391,3 +391,16 @@ def test_subset_filter_by_hand():
     for flavour in (dict(), dict(multi_impg=True)):
         assert _tuples(ix.query(1, 25, 75, subset_keep=[0, 0, 1], **flavour)) == sorted([(1, 25, 75, 1, 25, 75), C_])
         assert _tuples(ix.query(1, 25, 75, subset_keep=[0, 0, 0], **flavour)) == [(1, 25, 75, 1, 25, 75)]
+
+
+# src/subset_filter.rs:181-199 test_subset_filter_matches_variants
+SUBSET_LIST = "# comment\nchr1\nchr2\n\nchr1\t\n  chr3  \nHG00097_hap1_hprc_r2_v1.0.1\nHG00098#2#chr5\n"
+SUBSET_KAT = [("chr1", 1), ("chr1:10-20", 1), ("chr3", 1), ("HG00097#1#chr7", 1), ("HG00097#1", 1),
+              ("HG00098#2#chr5", 1), ("HG00098#1#chr5", 0)]
+
+
+def test_subset_filter_matches_variants():
+    names = [n for n, _ in SUBSET_KAT]
+    got, entries = o.subset_matches(SUBSET_LIST, names)
+    assert got.tolist() == [w for _, w in SUBSET_KAT]
+    assert entries == 5  # chr1 (twice, once with a trailing tab), chr2, chr3 and the two sample names

@@ -1273,7 +1273,94 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
 
 // one thread per (query, sequence) group: replay the group's hits in emission
 // order against its visited list (SortedRanges::insert with min_distance = 0,
-// impg.rs:270-368), collect the new pieces
+// impg.rs:270-368), collect the new pieces.
+// The list is searched three times and shifted once per hit, every step a dependent access: lists of at most
+// VU_LDS_CAP ranges (nearly all of them) are kept in LDS while they are worked on (lane-interleaved, so the 64
+// lists of a wave never share a bank) and written out once at the end; longer ones are worked on in place.
+constexpr uint32_t VU_LDS_CAP = 16;
+struct ListInPlace {  // the group's slice of the new table
+  int2 *p;
+  __device__ __forceinline__ int32_t &x(uint32_t i) const { return p[i].x; }
+  __device__ __forceinline__ int32_t &y(uint32_t i) const { return p[i].y; }
+};
+struct ListInLds {  // element i of this lane's list at [i * 64 + lane]
+  int32_t *bx, *by;
+  __device__ __forceinline__ int32_t &x(uint32_t i) const { return bx[i * 64u]; }
+  __device__ __forceinline__ int32_t &y(uint32_t i) const { return by[i * 64u]; }
+};
+template <class L> __device__ __forceinline__ uint32_t list_lower_bound(const L &R, uint32_t n, int32_t s) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (R.x(mid) < s) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// replays hits [st, st+n) against the list R (len entries on entry); returns the new length, appends pieces to P
+template <class L>
+__device__ __forceinline__ uint32_t replay_hits(const L &R, uint32_t len, const unsigned long long *__restrict__ svals,
+                                                uint32_t st, uint32_t n, int32_t sequence_length,
+                                                int32_t min_transitive_len, int32_t mdbr, int2 *__restrict__ P, uint32_t &np) {
+  for (uint32_t t = 0; t < n; t++) {
+    const unsigned long long iv = svals[st + t];  // (min, max) of the hit's query interval, packed by update_keys
+    int32_t start = (int32_t)(uint32_t)(iv >> 32), end = (int32_t)(uint32_t)iv;
+    bool should_add = true;
+    if (mdbr > 0) {  // impg.rs:2513-2545
+      const uint32_t idx = list_lower_bound(R, len, start);
+      if (idx > 0 && abs(start - R.y(idx - 1)) < mdbr) should_add = false;
+      if (should_add && idx < len && abs(R.x(idx) - end) < mdbr) should_add = false;
+    }
+    if (!should_add) continue;
+    // ---- SortedRanges::insert, min_distance = 0 --------------------------------
+    if (start < 0) start = 0;                       // impg.rs:287-289
+    if (end > sequence_length) end = sequence_length;  // impg.rs:294-296
+    int32_t current = start;
+    const uint32_t pos = list_lower_bound(R, len, start);  // (the same lower bound serves :303 and :330)
+    uint32_t i = pos;
+    if (i > 0 && R.y(i - 1) > start) i -= 1;
+    while (i < len && current < end) {  // impg.rs:314-324
+      const int32_t rx = R.x(i), ry = R.y(i);
+      if (rx > end) break;
+      if (current < rx) {
+        if (abs(rx - current) >= min_transitive_len) P[np++] = make_int2(current, rx);
+      }
+      current = max(current, ry);
+      i += 1;
+    }
+    if (current < end) {
+      if (abs(end - current) >= min_transitive_len) P[np++] = make_int2(current, end);
+    }
+    uint32_t mfrom;  // impg.rs:330-343
+    if (pos > 0 && R.y(pos - 1) >= start) {
+      R.y(pos - 1) = max(R.y(pos - 1), end);
+      mfrom = pos - 1;
+    } else if (pos < len && end >= R.x(pos)) {
+      R.x(pos) = min(start, R.x(pos));
+      R.y(pos) = max(end, R.y(pos));
+      mfrom = pos;
+    } else {
+      for (uint32_t k = len; k > pos; k--) { R.x(k) = R.x(k - 1); R.y(k) = R.y(k - 1); }
+      R.x(pos) = start;
+      R.y(pos) = end;
+      len += 1;
+      continue;
+    }
+    uint32_t write = mfrom, read = mfrom + 1;  // merge_forward_from, impg.rs:355-368
+    while (read < len) {
+      if (R.y(write) >= R.x(read)) {
+        R.y(write) = max(R.y(write), R.y(read));
+      } else {
+        write += 1;
+        const int32_t tx = R.x(write), ty = R.y(write);
+        R.x(write) = R.x(read); R.y(write) = R.y(read);
+        R.x(read) = tx; R.y(read) = ty;
+      }
+      read += 1;
+    }
+    len = write + 1;
+  }
+  return len;
+}
 __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, const unsigned long long *__restrict__ svals,
                                                             const int32_t *__restrict__ seq_len,
                                                             const unsigned long long *__restrict__ gkey,
@@ -1286,80 +1373,34 @@ __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, co
                                                             int32_t min_transitive_len, int32_t mdbr,
                                                             int2 *__restrict__ new_ranges, uint32_t *__restrict__ new_len,
                                                             int2 *__restrict__ pieces, uint32_t *__restrict__ n_pieces) {
+  __shared__ int32_t lds_x[VU_LDS_CAP * 64], lds_y[VU_LDS_CAP * 64];
   const uint32_t g = blockIdx.x * 64u + threadIdx.x;
   if (g >= n_groups) return;
   int2 *R = new_ranges + noff[g];
+  // the group's current list: the newest table that holds the key, else the mask's list of the sequence
+  const int2 *src = nullptr;
   uint32_t len = 0;
   if (old_tab[g] == VISITED_MASK) {
     const uint32_t a = vt.mask_off[old_idx[g]];
     len = vt.mask_off[old_idx[g] + 1] - a;
-    for (uint32_t i = 0; i < len; i++) R[i] = vt.mask_ranges[a + i];
+    src = vt.mask_ranges + a;
   } else if (old_tab[g] != VISITED_NONE) {
     const VisitedTable &T = vt.t[old_tab[g]];
-    const int2 *src = T.ranges + T.off[old_idx[g]];
+    src = T.ranges + T.off[old_idx[g]];
     len = T.len[old_idx[g]];
-    for (uint32_t i = 0; i < len; i++) R[i] = src[i];
   }
   const int32_t sequence_length = seq_len[(uint32_t)(gkey[g] & 0xFFFFFFFFull)];  // visited_entry, impg.rs:2048-2053
   int2 *P = pieces + poff[g];
   uint32_t np = 0;
   const uint32_t st = gstart[g], n = glen[g];
-  for (uint32_t t = 0; t < n; t++) {
-    const unsigned long long iv = svals[st + t];  // (min, max) of the hit's query interval, packed by update_keys
-    int32_t start = (int32_t)(uint32_t)(iv >> 32), end = (int32_t)(uint32_t)iv;
-    bool should_add = true;
-    if (mdbr > 0) {  // impg.rs:2513-2545
-      const uint32_t idx = lower_bound_start(R, len, start);
-      if (idx > 0 && abs(start - R[idx - 1].y) < mdbr) should_add = false;
-      if (should_add && idx < len && abs(R[idx].x - end) < mdbr) should_add = false;
-    }
-    if (!should_add) continue;
-    // ---- SortedRanges::insert, min_distance = 0 --------------------------------
-    if (start < 0) start = 0;                       // impg.rs:287-289
-    if (end > sequence_length) end = sequence_length;  // impg.rs:294-296
-    int32_t current = start;
-    uint32_t i = lower_bound_start(R, len, start);
-    if (i > 0 && R[i - 1].y > start) i -= 1;
-    while (i < len && current < end) {  // impg.rs:314-324
-      const int2 rg = R[i];
-      if (rg.x > end) break;
-      if (current < rg.x) {
-        if (abs(rg.x - current) >= min_transitive_len) P[np++] = make_int2(current, rg.x);
-      }
-      current = max(current, rg.y);
-      i += 1;
-    }
-    if (current < end) {
-      if (abs(end - current) >= min_transitive_len) P[np++] = make_int2(current, end);
-    }
-    const uint32_t pos = lower_bound_start(R, len, start);  // impg.rs:330-343
-    uint32_t mfrom;
-    if (pos > 0 && R[pos - 1].y >= start) {
-      R[pos - 1].y = max(R[pos - 1].y, end);
-      mfrom = pos - 1;
-    } else if (pos < len && end >= R[pos].x) {
-      R[pos].x = min(start, R[pos].x);
-      R[pos].y = max(end, R[pos].y);
-      mfrom = pos;
-    } else {
-      for (uint32_t k = len; k > pos; k--) R[k] = R[k - 1];
-      R[pos] = make_int2(start, end);
-      len += 1;
-      continue;
-    }
-    uint32_t write = mfrom, read = mfrom + 1;  // merge_forward_from, impg.rs:355-368
-    while (read < len) {
-      if (R[write].y >= R[read].x) {
-        R[write].y = max(R[write].y, R[read].y);
-      } else {
-        write += 1;
-        int2 tmp = R[write];
-        R[write] = R[read];
-        R[read] = tmp;
-      }
-      read += 1;
-    }
-    len = write + 1;
+  if (len + n <= VU_LDS_CAP) {  // (len + n bounds the list at every step)
+    const ListInLds A{lds_x + threadIdx.x, lds_y + threadIdx.x};
+    for (uint32_t i = 0; i < len; i++) { const int2 r = src[i]; A.x(i) = r.x; A.y(i) = r.y; }
+    len = replay_hits(A, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np);
+    for (uint32_t i = 0; i < len; i++) R[i] = make_int2(A.x(i), A.y(i));
+  } else {
+    for (uint32_t i = 0; i < len; i++) R[i] = src[i];
+    len = replay_hits(ListInPlace{R}, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np);
   }
   // next-depth ranges of this group: sort by start, merge overlapping/contiguous
   // (impg.rs:2568-2584; ranges of different groups never share (query, id))

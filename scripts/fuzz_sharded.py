@@ -10,6 +10,8 @@ if "RANK" not in os.environ:
     secs = sys.argv[1] if len(sys.argv) > 1 else "60"
     world = sys.argv[2] if len(sys.argv) > 2 else "2"
     seed = sys.argv[3] if len(sys.argv) > 3 else "5000"
+    if not 1 <= int(world) <= 8:
+        sys.exit("world must be 1..8 (usage: fuzz_sharded.py <seconds> [world] [first_seed])")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", world, "--master-addr",
                         "127.0.0.1", "--master-port", "29701", os.path.abspath(__file__), secs, world, seed], cwd=ROOT)
     sys.exit(r.returncode)

@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--chunk-ranges", type=int, default=50000)
     ap.add_argument("--pair-budget", type=int, default=1 << 30)
     ap.add_argument("--cpu-sample", type=int, default=1000, help="ranges timed on the CPU oracle, ~15 s of CPU work (0 = skip)")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=VALUE",
+                    help="impg_gpu_set_option before the run (timing comparisons, e.g. locality_min=0)")
     ap.add_argument("--paf", default=None, help="reuse an existing synthetic PAF file")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
@@ -107,6 +109,9 @@ def main():
     t_build = time.time() - t_build
     index.set_option("chunk_ranges", args.chunk_ranges)
     index.set_option("pair_budget", args.pair_budget)
+    for kv in args.engine_option:
+        k, v = kv.split("=", 1)
+        index.set_option(k, int(v))
 
     # each rank is home to its own `--ranges` queries (weak scaling): seed 7 + rank
     bed = impg_amd.synth_bed(7 + rank, args.ranges, n_seq=n_seq, seq_len=seq_len, range_len=5000)

@@ -308,6 +308,12 @@ def test_cli_bed_bytes(tmp_path):
         assert r.returncode == 0, r.stderr
         want = "".join(c.query_bed(c.seq_name(t), s, e, range_name=rnames[i], merge_distance=d, **kw) for i, (t, s, e) in enumerate(rl))
         assert r.stdout == want, flags
+    # parse_merge_distance vectors (main.rs:13701-13707): metric suffixes, fractions
+    t, s, e = rl[0]
+    one = ["-r", "%s:%d-%d" % (c.seq_name(t), s, e)]
+    for spelled, d in (("50000", 50000), ("50k", 50000), ("1m", 1000000), ("1M", 1000000), ("1.5k", 1500)):
+        r = subprocess.run([cli, "query", "-a", paf] + one + ["-d", spelled], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout == c.query_bed(c.seq_name(t), s, e, merge_distance=d), spelled
     # -r form and the validation errors of main.rs:10387-10520
     t, s, e = rl[0]
     r = subprocess.run([cli, "query", "-a", paf, "-r", "%s:%d-%d" % (c.seq_name(t), s, e), "-d", "100"], capture_output=True, text=True)

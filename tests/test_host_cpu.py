@@ -176,3 +176,14 @@ def test_subset_keep_reference_kat_and_differential():
         want, we = o.subset_matches(text, names)
         got, ge = impg_amd.subset_keep(text, names)
         assert got.tolist() == want.tolist() and ge == we, (text, names)
+
+
+def test_cli_merge_distance_vectors_rejected_before_any_device_work():
+    """parse_merge_distance (main.rs:47-55; vectors main.rs:13709-13714): "10kb" and "3g" are errors, and so is a
+    query without -d / --no-merge (main.rs:13401-13416).  The CLI refuses them while parsing its arguments."""
+    import os, subprocess
+    import impg_amd
+    cli = os.path.join(os.path.dirname(impg_amd.__file__), "impg-gpu")
+    for bad in (["-d", "10kb"], ["-d", "3g"], ["-d", "-5"], ["-d", "abc"]):
+        r = subprocess.run([cli, "query", "-a", "x.paf", "-r", "s:1-200"] + bad, capture_output=True, text=True)
+        assert r.returncode != 0 and r.stdout == "" and r.stderr.startswith("Error:"), bad

@@ -35,7 +35,7 @@ class Params(C.Structure):
     _fields_ = [("transitive", C.c_int32), ("dfs", C.c_int32), ("max_depth", C.c_uint32),
                 ("min_transitive_len", C.c_int32), ("min_distance_between_ranges", C.c_int32),
                 ("min_output_length", C.c_int32), ("min_identity", C.c_double),
-                ("store_cigar", C.c_int32), ("multi_impg", C.c_int32)]
+                ("store_cigar", C.c_int32), ("multi_impg", C.c_int32), ("original_sequence_coordinates", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -93,6 +93,7 @@ SYMBOLS = [
     ("impg_gpu_query_batch", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), C.POINTER(_P)]),
     ("impg_gpu_query_batch_masked", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, C.POINTER(_P)]),
     ("impg_gpu_query_batch_filtered", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, _P, C.POINTER(_P)]),
+    ("impg_gpu_parse_subsequence", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]),
     ("impg_gpu_subset_keep", C.c_int, [C.c_char_p, C.c_size_t, _P, C.c_size_t, _P, C.POINTER(C.c_size_t)]),
     ("impg_gpu_query", C.c_int, [_P, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(Params), C.POINTER(_P)]),
     ("impg_gpu_results_num_ranges", C.c_size_t, [_P]),

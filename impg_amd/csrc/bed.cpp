@@ -168,10 +168,11 @@ void render_bed(const impg_gpu_results &res, const impg_gpu_index &ix, const cha
       std::string fallback;
       const char *rn = range_names ? range_names[i] : nullptr;
       for (const auto &x : v) {
-        if (x.query_id < ix.seq.names.size()) s += ix.seq.names[x.query_id];
+        uint32_t shift = 0;  // --original-sequence-coordinates (main.rs:11876-11883)
+        if (x.query_id < ix.seq.names.size()) shift = put_original_name(s, ix.seq.names[x.query_id], p.original_sequence_coordinates != 0);
         else s += std::to_string(x.query_id);
-        int n = snprintf(buf, sizeof buf, "\t%u\t%u\t", (uint32_t)std::min(x.q_first, x.q_last),
-                         (uint32_t)std::max(x.q_first, x.q_last));
+        int n = snprintf(buf, sizeof buf, "\t%u\t%u\t", (uint32_t)std::min(x.q_first, x.q_last) + shift,
+                         (uint32_t)std::max(x.q_first, x.q_last) + shift);
         s.append(buf, (size_t)n);
         if (rn) s += rn;
         else {  // "{chrom}:{start}-{end}" (partition.rs:1741, :1762)

@@ -267,6 +267,21 @@ int impg_gpu_index_create_from_paf_sharded(const char *const *paths, int n_paths
   IMPG_CATCH
 }
 
+int impg_gpu_parse_subsequence(const char *seq_name, char *base_out, size_t base_cap, int32_t *start_offset) {
+  IMPG_TRY
+  if (!seq_name || !base_out || !start_offset) throw Error{IMPG_E_INVALID, "null argument"};
+  size_t base_len = 0;
+  uint32_t off = 0;
+  const std::string name(seq_name);
+  if (!subsequence_origin(name, base_len, off)) return 0;
+  if (base_len + 1 > base_cap) throw Error{IMPG_E_INVALID, "name buffer too small"};
+  memcpy(base_out, name.data(), base_len);
+  base_out[base_len] = '\0';
+  *start_offset = (int32_t)off;
+  return 1;
+  IMPG_CATCH
+}
+
 int impg_gpu_subset_keep(const char *list_text, size_t len, const char *const *names, size_t n, uint8_t *keep_out,
                          size_t *n_entries) {
   IMPG_TRY

@@ -91,7 +91,8 @@ void usage() {
           "impg-gpu index -a <paf>... -i <file> [--unidirectional] [--order coitrees|sorted] [--device N]\n"
           "impg-gpu query (-a <paf>... | -i <file>) (-r seq:start-end | -b <bed>) (-d <bp> | --no-merge) [-x] [-m N]\n"
           "               [--transitive-dfs] [--multi-impg] [--min-transitive-len N] [--min-distance-between-ranges N]\n"
-          "               [-l N] [--min-result-identity F] [--subset-sequence-list FILE] [-o auto|bed|bedpe|paf] [--unidirectional] [--order coitrees|sorted]\n"
+          "               [-l N] [--min-result-identity F] [--subset-sequence-list FILE] [--original-sequence-coordinates]\n"
+          "               [-o auto|bed|bedpe|paf] [--unidirectional] [--order coitrees|sorted]\n"
           "               [--device N]\n");
 }
 
@@ -110,6 +111,7 @@ int main(int argc, char **argv) {
   long long merge_d = 0;
   long max_depth = 2, min_tl = -1, mdbr = 10, min_out = -1;
   double min_ident = NAN;
+  bool original_coords = false;  // main.rs:4370
   std::string subset_list;  // --subset-sequence-list: a file of sequence names (main.rs:4357, :11709-11720)
   int device = 0, order = IMPG_ORDER_COITREES;
   for (int i = 2; i < argc; i++) {
@@ -136,6 +138,7 @@ int main(int argc, char **argv) {
     else if (a == "-l" || a == "--min-output-length") min_out = atol(need("-l"));
     else if (a == "--min-result-identity") min_ident = atof(need(a.c_str()));
     else if (a == "--subset-sequence-list") subset_list = need(a.c_str());
+    else if (a == "--original-sequence-coordinates") original_coords = true;
     else if (a == "-o" || a == "--output-format") ofmt = need("-o");
     else if (a == "--unidirectional") unidirectional = true;
     else if (a == "--device") device = atoi(need(a.c_str()));
@@ -218,6 +221,7 @@ int main(int argc, char **argv) {
   p.min_output_length = min_out < 0 ? -1 : (int32_t)min_out;
   p.min_identity = min_ident;
   p.store_cigar = fmt != "bed";  // CIGARs for PAF / BEDPE only (main.rs:7447)
+  p.original_sequence_coordinates = original_coords;
   impg_gpu_results_t *res = nullptr;
   std::vector<uint8_t> keep;
   if (!subset_list.empty()) {  // load_subset_filter (subset_filter.rs:63-82) + one matches() per sequence

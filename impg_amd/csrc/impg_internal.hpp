@@ -169,6 +169,38 @@ void load_index(impg_gpu_index &ix, const char *path);  // ix.device set; fills 
 // ---- subset lists (subset.cpp): keep[i] = the list selects names[i]; returns the number of list entries
 size_t subset_select(const char *text, size_t len, const char *const *names, size_t n, uint8_t *keep);
 
+// ---- "base:START-END" sequence names (--original-sequence-coordinates; main.rs:4642-4678) ---------------------
+// length of the base name and START if `name` ends in ":<i32>-...", else false
+inline bool subsequence_origin(const std::string &name, size_t &base_len, uint32_t &offset) {
+  const size_t colon = name.rfind(':');
+  if (colon == std::string::npos) return false;
+  const size_t dash = name.find('-', colon + 1);
+  if (dash == std::string::npos) return false;
+  size_t i = colon + 1;
+  if (i < dash && name[i] == '+') i++;  // (a '-' cannot lead: the first dash ends the number)
+  if (i >= dash) return false;
+  uint64_t v = 0;
+  for (; i < dash; i++) {
+    if (name[i] < '0' || name[i] > '9') return false;
+    v = v * 10 + (uint64_t)(name[i] - '0');
+    if (v > 2147483647ull) return false;
+  }
+  base_len = colon;
+  offset = (uint32_t)v;
+  return true;
+}
+// appends the printed name and returns the offset to add to its coordinates
+inline uint32_t put_original_name(std::string &s, const std::string &name, bool original) {
+  size_t base_len = 0;
+  uint32_t off = 0;
+  if (original && subsequence_origin(name, base_len, off)) {
+    s.append(name, 0, base_len);
+    return off;
+  }
+  s += name;
+  return 0;
+}
+
 // ---- BED (bed.cpp) -----------------------------------------------------------
 size_t bed_merge(impg_gpu_interval_t *iv, size_t n, int32_t merge_distance, bool merge_strands);
 

@@ -267,19 +267,31 @@ void render_paf(const impg_gpu_results &res, const impg_gpu_index &ix, const cha
           }
           volatile float mf = (float)m, g_den = (float)(m + x + ni + nd), b_den = (float)(m + (x + ibp + dbp));
           volatile float gi = mf / g_den, bi = mf / b_den;
+          // --original-sequence-coordinates (main.rs:11925-11938, :12014-12046): "base:START-END" names print as
+          // "base" with START added; PAF lengths are then 0 (no sequence files to ask)
+          const bool orig = p.original_sequence_coordinates != 0;
+          auto put_shifted_name = [&](uint32_t id) -> uint32_t {
+            if (id < ix.seq.names.size()) return put_original_name(s, ix.seq.names[id], orig);
+            put_name(s, ix, id);
+            return 0u;
+          };
           if (bedpe) {
-            put_name(s, ix, r.iv.query_id); s += '\t'; put_u(s, first); s += '\t'; put_u(s, last); s += '\t';
-            put_name(s, ix, r.iv.target_id); s += '\t'; put_u(s, (uint32_t)r.iv.t_first); s += '\t'; put_u(s, (uint32_t)r.iv.t_last);
+            const uint32_t qo = put_shifted_name(r.iv.query_id);
+            s += '\t'; put_u(s, (uint32_t)first + qo); s += '\t'; put_u(s, (uint32_t)last + qo); s += '\t';
+            const uint32_t to = put_shifted_name(r.iv.target_id);
+            s += '\t'; put_u(s, (uint32_t)r.iv.t_first + to); s += '\t'; put_u(s, (uint32_t)r.iv.t_last + to);
             s += '\t'; s += rname; s += "\t0\t"; s += f ? '+' : '-'; s += "\t+\tgi:f:"; put_f32(s, gi); s += "\tbi:f:"; put_f32(s, bi);
             s += '\n';
           } else {
             auto seq_len = [&](uint32_t id) -> unsigned long long {
               return id < ix.seq.lens.size() ? (unsigned long long)ix.seq.lens[id] : 0ull;
             };
-            put_name(s, ix, r.iv.query_id); s += '\t'; put_u(s, seq_len(r.iv.query_id)); s += '\t'; put_u(s, first); s += '\t';
-            put_u(s, last); s += '\t'; s += f ? '+' : '-'; s += '\t';
-            put_name(s, ix, r.iv.target_id); s += '\t'; put_u(s, seq_len(r.iv.target_id)); s += '\t'; put_u(s, (uint32_t)r.iv.t_first);
-            s += '\t'; put_u(s, (uint32_t)r.iv.t_last); s += '\t'; s += std::to_string(m); s += '\t'; s += std::to_string(bl);
+            const uint32_t qo = put_shifted_name(r.iv.query_id);
+            s += '\t'; put_u(s, orig ? 0ull : seq_len(r.iv.query_id)); s += '\t'; put_u(s, (uint32_t)first + qo); s += '\t';
+            put_u(s, (uint32_t)last + qo); s += '\t'; s += f ? '+' : '-'; s += '\t';
+            const uint32_t to = put_shifted_name(r.iv.target_id);
+            s += '\t'; put_u(s, orig ? 0ull : seq_len(r.iv.target_id)); s += '\t'; put_u(s, (uint32_t)r.iv.t_first + to);
+            s += '\t'; put_u(s, (uint32_t)r.iv.t_last + to); s += '\t'; s += std::to_string(m); s += '\t'; s += std::to_string(bl);
             s += "\t255\tgi:f:"; put_f32(s, gi); s += "\tbi:f:"; put_f32(s, bi); s += "\tcg:Z:";
             char b[24];
             for (uint32_t op : r.cigar) {

@@ -13,11 +13,13 @@ from ._lib import INTERVAL_DTYPE, RANGE_DTYPE, RECORD_DTYPE, Params, Stats, chec
 
 
 def make_params(transitive=False, dfs=False, max_depth=2, min_transitive_len=101, min_distance_between_ranges=10,
-                min_output_length=None, min_identity=None, store_cigar=False, multi_impg=False):
+                min_output_length=None, min_identity=None, store_cigar=False, multi_impg=False,
+                original_sequence_coordinates=False):
     """CLI defaults of src/main.rs:4259-4285."""
     return Params(int(transitive), int(dfs), max_depth, min_transitive_len, min_distance_between_ranges,
                   -1 if min_output_length is None else min_output_length,
-                  math.nan if min_identity is None else float(min_identity), int(store_cigar), int(multi_impg))
+                  math.nan if min_identity is None else float(min_identity), int(store_cigar), int(multi_impg),
+                  int(original_sequence_coordinates))
 
 
 class QueryResults:
@@ -336,6 +338,16 @@ class GpuImpg:
         n = C.c_uint64(0)
         check(lib().impg_gpu_stage_timing(self._h, ms, C.byref(n), int(reset)))
         return [ms[0], ms[1], ms[2]], n.value
+
+
+def parse_subsequence(name):
+    """impg_gpu_parse_subsequence: (base, start offset) of a "base:START-END" name, or None."""
+    buf = C.create_string_buffer(len(name.encode()) + 2)
+    off = C.c_int32(0)
+    r = lib().impg_gpu_parse_subsequence(name.encode(), buf, len(buf), C.byref(off))
+    if r < 0:
+        check(r)
+    return (buf.value.decode(), int(off.value)) if r == 1 else None
 
 
 def subset_keep(list_text, names):

@@ -76,6 +76,11 @@ typedef struct {
   int32_t multi_impg;                  /* 1: MultiImpg semantics (src/multi_impg.rs:495-595, :796-991): every step's hits
                                           sorted by (query_id, q.first, q.last, t.first, t.last), one worklist pop at a
                                           time (front = BFS, back = DFS), unclipped ranges, same-sequence hits skipped */
+  int32_t original_sequence_coordinates; /* text writers only (--original-sequence-coordinates, main.rs:4370): a sequence
+                                          named "base:START-END" is printed as "base" with START added to its
+                                          coordinates (transform_coordinates_to_original, main.rs:4642-4678); PAF
+                                          sequence lengths are then 0, as the reference prints them when it has no
+                                          sequence files to ask (get_original_sequence_length, main.rs:4681-4704) */
 } impg_gpu_params_t;
 
 /* Order in which overlapping entries of one target are visited; it fixes the
@@ -269,6 +274,9 @@ int impg_gpu_results_paf(const impg_gpu_results_t *, const impg_gpu_index_t *,
 /* parse_cigar_to_delta (impg.rs:2935-2950): returns #ops or <0 */
 long impg_gpu_parse_cigar(const char *cigar, size_t len, uint32_t *ops_out, size_t cap);
 /* parse_target_range (partition.rs:1752-1763) */
+/* parse_subsequence_coordinates (main.rs:4642-4659): "base:START-END" -> 1, base name and START;
+ * 0 when the name carries no parsable coordinates.  Host-only. */
+int impg_gpu_parse_subsequence(const char *seq_name, char *base_out, size_t base_cap, int32_t *start_offset);
 int impg_gpu_parse_target_range(const char *s, char *name_out, size_t name_cap,
                                 int32_t *start, int32_t *end);
 

@@ -1622,6 +1622,47 @@ std::string fmt_f32_trim(float x) {
 
 /* perform_query + results.remove(0) + output_results_paf / output_results_bedpe
  * (main.rs:7472-7496, :11894-12103).  format: 0 = PAF, 1 = BEDPE. */
+/* parse_subsequence_coordinates (main.rs:4642-4659) and transform_coordinates_to_original (:4662-4678) */
+static bool parse_subsequence_coordinates(const std::string &seq_name, std::string &base_name, int32_t &start_offset) {
+  size_t colon_pos = seq_name.rfind(':');
+  if (colon_pos == std::string::npos) return false;
+  std::string range_part = seq_name.substr(colon_pos + 1);
+  size_t dash_pos = range_part.find('-');
+  if (dash_pos == std::string::npos) return false;
+  std::string start_str = range_part.substr(0, dash_pos);
+  /* str::parse::<i32>: optional sign, at least one digit, no overflow */
+  size_t i = 0;
+  bool neg = false;
+  if (i < start_str.size() && (start_str[i] == '+' || start_str[i] == '-')) { neg = start_str[i] == '-'; i++; }
+  if (i >= start_str.size()) return false;
+  int64_t v = 0;
+  for (; i < start_str.size(); i++) {
+    if (start_str[i] < '0' || start_str[i] > '9') return false;
+    v = v * 10 + (start_str[i] - '0');
+    if (v > 2147483648ll) return false;
+  }
+  if (neg) v = -v;
+  if (v > 2147483647ll || v < -2147483648ll) return false;
+  base_name = seq_name.substr(0, colon_pos);
+  start_offset = (int32_t)v;
+  return true;
+}
+static void transform_coordinates_to_original(const std::string &seq_name, uint32_t start, uint32_t end, bool original_coordinates,
+                                              std::string &name_out, uint32_t &start_out, uint32_t &end_out) {
+  std::string base; int32_t offset = 0;
+  if (original_coordinates && parse_subsequence_coordinates(seq_name, base, offset)) {
+    name_out = base; start_out = start + (uint32_t)offset; end_out = end + (uint32_t)offset;
+  } else { name_out = seq_name; start_out = start; end_out = end; }
+}
+long oracle_parse_subsequence(const char *seq_name, char *base_out, size_t cap, int32_t *offset) {
+  std::string base; int32_t off = 0;
+  if (!parse_subsequence_coordinates(seq_name, base, off)) return 0;
+  if (base.size() + 1 > cap) return -1;
+  memcpy(base_out, base.c_str(), base.size() + 1);
+  *offset = off;
+  return 1;
+}
+
 int oracle_query_paf(const oracle_index_t *ix, const char *target_name, int32_t start, int32_t end,
                      const char *range_name, const oracle_params_t *p, int32_t merge_distance, int format,
                      char **buf, size_t *len, size_t *cap) {
@@ -1671,16 +1712,22 @@ int oracle_query_paf(const oracle_index_t *ix, const char *target_name, int32_t 
     std::string gi_s = fmt_f32_trim(gi), bi_s = fmt_f32_trim(bi);
     std::string line;
     char num[64];
+    const bool orig = p->original_sequence_coordinates != 0;
+    std::string tqn, ttn; uint32_t tf, tl, ttf, ttl; /* :11925-11938, :12014-12027 */
+    transform_coordinates_to_original(qn, (uint32_t)first, (uint32_t)last, orig, tqn, tf, tl);
+    transform_coordinates_to_original(tn, (uint32_t)r.t_first, (uint32_t)r.t_last, orig, ttn, ttf, ttl);
+    /* :12030-12046: with original coordinates the lengths come from the sequence files; none are given here,
+     * which the reference answers with a warning and 0 (get_original_sequence_length, :4681-4704) */
+    unsigned long long qlen = orig ? 0ull : (unsigned long long)ix->seq_index.id_to_len[r.q_id];
+    unsigned long long tlen = orig ? 0ull : (unsigned long long)ix->seq_index.id_to_len[r.t_id];
     if (format == 1) {
-      line += qn; snprintf(num, sizeof num, "\t%u\t%u\t", (uint32_t)first, (uint32_t)last); line += num;
-      line += tn; snprintf(num, sizeof num, "\t%u\t%u\t", (uint32_t)r.t_first, (uint32_t)r.t_last); line += num;
+      line += tqn; snprintf(num, sizeof num, "\t%u\t%u\t", tf, tl); line += num;
+      line += ttn; snprintf(num, sizeof num, "\t%u\t%u\t", ttf, ttl); line += num;
       line += range_name; line += "\t0\t"; line += strand; line += "\t+\tgi:f:"; line += gi_s; line += "\tbi:f:"; line += bi_s;
       line += "\n";
     } else {
-      line += qn; snprintf(num, sizeof num, "\t%llu\t%u\t%u\t%c\t", (unsigned long long)ix->seq_index.id_to_len[r.q_id],
-                           (uint32_t)first, (uint32_t)last, strand); line += num;
-      line += tn; snprintf(num, sizeof num, "\t%llu\t%u\t%u\t%d\t%d\t255\tgi:f:", (unsigned long long)ix->seq_index.id_to_len[r.t_id],
-                           (uint32_t)r.t_first, (uint32_t)r.t_last, matches, block_len); line += num;
+      line += tqn; snprintf(num, sizeof num, "\t%llu\t%u\t%u\t%c\t", qlen, tf, tl, strand); line += num;
+      line += ttn; snprintf(num, sizeof num, "\t%llu\t%u\t%u\t%d\t%d\t255\tgi:f:", tlen, ttf, ttl, matches, block_len); line += num;
       line += gi_s; line += "\tbi:f:"; line += bi_s; line += "\tcg:Z:";
       for (uint32_t op : r.cigar) { snprintf(num, sizeof num, "%d%c", cigar_len(op), cigar_op(op)); line += num; }
       line += "\tan:Z:"; line += range_name; line += "\n";
@@ -1733,8 +1780,10 @@ int oracle_query_bed(const oracle_index_t *ix, const char *target_name, int32_t 
     if (x.q_first <= x.q_last) { first = x.q_first; last = x.q_last; strand = '+'; }
     else { first = x.q_last; last = x.q_first; strand = '-'; }
     char line[64];
-    append(buf, len, cap, qn.data(), qn.size());
-    int n = snprintf(line, sizeof line, "\t%u\t%u\t", (uint32_t)first, (uint32_t)last);
+    std::string tqn; uint32_t tf, tl; /* :11876-11883 */
+    transform_coordinates_to_original(qn, (uint32_t)first, (uint32_t)last, p->original_sequence_coordinates != 0, tqn, tf, tl);
+    append(buf, len, cap, tqn.data(), tqn.size());
+    int n = snprintf(line, sizeof line, "\t%u\t%u\t", tf, tl);
     append(buf, len, cap, line, (size_t)n);
     append(buf, len, cap, range_name, strlen(range_name));
     n = snprintf(line, sizeof line, "\t.\t%c\n", strand);

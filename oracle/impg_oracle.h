@@ -46,6 +46,7 @@ typedef struct {
   double min_identity;       /* NaN = None */
   int32_t store_cigar;
   int32_t multi_impg;        /* 1 = MultiImpg semantics (multi_impg.rs) */
+  int32_t original_sequence_coordinates; /* text writers only: --original-sequence-coordinates (main.rs:4370) */
 } oracle_params_t;
 
 /* ---- leaf functions (known-answer tested) ------------------------------ */
@@ -136,6 +137,10 @@ long oracle_query_filtered(const oracle_index_t *, uint32_t target_id, int32_t s
 /* SubsetFilter: parse_subset_filter(list_text) then matches(names[i]) -> out[i]; returns entry_count
  * (subset_filter.rs:19-60, :117-176). */
 long oracle_subset_matches(const char *list_text, const char *const *names, size_t n, uint8_t *out);
+
+/* parse_subsequence_coordinates (main.rs:4642-4659): 1 and (base name, start offset) for "base:START-END",
+ * 0 when the name carries no parsable coordinates, -1 if base_out is too small. */
+long oracle_parse_subsequence(const char *seq_name, char *base_out, size_t cap, int32_t *offset);
 
 /* Same with store_cigar: cigar_off[cap+1], cigar_ops[ops_cap] receive the
  * Vec<CigarOp> of every result (CSR); *n_ops = total ops (may exceed ops_cap). */

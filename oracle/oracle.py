@@ -27,18 +27,29 @@ class Params(C.Structure):
     _fields_ = [("transitive", C.c_int32), ("dfs", C.c_int32), ("max_depth", C.c_uint32),
                 ("min_transitive_len", C.c_int32), ("min_distance_between_ranges", C.c_int32),
                 ("min_output_length", C.c_int32), ("min_identity", C.c_double),
-                ("store_cigar", C.c_int32), ("multi_impg", C.c_int32)]
+                ("store_cigar", C.c_int32), ("multi_impg", C.c_int32), ("original_sequence_coordinates", C.c_int32)]
 
 
 def make_params(transitive=False, dfs=False, max_depth=2, min_transitive_len=101,
                 min_distance_between_ranges=10, min_output_length=None, min_identity=None,
-                store_cigar=False, multi_impg=False):
+                store_cigar=False, multi_impg=False, original_sequence_coordinates=False):
     """Defaults are the reference CLI's (main.rs:4259-4285)."""
     return Params(int(transitive), int(dfs), max_depth, min_transitive_len,
                   min_distance_between_ranges,
                   -1 if min_output_length is None else min_output_length,
                   math.nan if min_identity is None else float(min_identity),
-                  int(store_cigar), int(multi_impg))
+                  int(store_cigar), int(multi_impg), int(original_sequence_coordinates))
+
+
+def parse_subsequence(name):
+    """parse_subsequence_coordinates (main.rs:4642-4659): (base, offset) or None."""
+    L = lib()
+    L.oracle_parse_subsequence.restype = C.c_long
+    L.oracle_parse_subsequence.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]
+    buf = C.create_string_buffer(len(name.encode()) + 2)
+    off = C.c_int32(0)
+    r = L.oracle_parse_subsequence(name.encode(), buf, len(buf), C.byref(off))
+    return (buf.value.decode(), int(off.value)) if r == 1 else None
 
 
 def build(force=False):

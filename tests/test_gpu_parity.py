@@ -783,3 +783,50 @@ def test_cli_subset_sequence_list(tmp_path):
     for bad in (empty, str(tmp_path / "missing.txt")):
         r = subprocess.run([cli, "query", "-a", paf, "-r", rng, "-d", "50", "--subset-sequence-list", bad], capture_output=True, text=True)
         assert r.returncode != 0 and r.stdout == "" and r.stderr.startswith("Error:")
+
+
+def test_original_sequence_coordinates(tmp_path):
+    """--original-sequence-coordinates (main.rs:4370, :4642-4678): sequences named "base:START-END" are printed as
+    "base" with START added to their coordinates in BED / BEDPE / PAF; PAF lengths become 0 without sequence files."""
+    import os
+    import subprocess
+    text, names = random_paf(141, 200, n_seq=6, seq_len=20000, self_aln=True)
+    # rename: s0 -> chrA:1000-21000, s1 -> sample#1#chrB:5-20005, s2 -> chrC:notanumber-5, the rest keep their names
+    ren = {"s0": "chrA:1000-21000", "s1": "sample#1#chrB:5-20005", "s2": "chrC:oops-5"}
+    lines = []
+    for ln in text.splitlines():
+        f = ln.split("\t")
+        f[0], f[5] = ren.get(f[0], f[0]), ren.get(f[5], f[5])
+        lines.append("\t".join(f))
+    g, c = both(tmp_path, "\n".join(lines) + "\n")
+    ranges = [(t, s, e) for (t, s, e) in random_ranges(9, 30, 6, 20000, max_len=3000, min_len=150)]
+    rnames = ["r%d" % i for i in range(len(ranges))]
+    kw = dict(transitive=True, max_depth=2, min_transitive_len=40)
+    for orig in (True, False):
+        p = impg_amd.make_params(original_sequence_coordinates=orig, **kw)
+        want = "".join(c.query_bed(c.seq_name(t), s, e, range_name=rnames[i], merge_distance=20, original_sequence_coordinates=orig, **kw)
+                       for i, (t, s, e) in enumerate(ranges))
+        got = g.query_batch(ranges, p).bed(rnames, merge_distance=20, params=p)
+        assert got == want
+        pc = impg_amd.make_params(store_cigar=True, original_sequence_coordinates=orig, **kw)
+        res = g.query_batch(ranges, pc)
+        for fmt in ("paf", "bedpe"):
+            want = "".join(c.query_paf(c.seq_name(t), s, e, range_name=rnames[i], merge_distance=20, fmt=fmt,
+                                       original_sequence_coordinates=orig, **kw) for i, (t, s, e) in enumerate(ranges))
+            assert res.paf(rnames, merge_distance=20, params=pc, fmt=fmt) == want
+            if orig:
+                assert "chrA\t" in want and "chrA:1000-21000\t" not in want.replace("an:Z:", "")
+    # the CLI flag
+    cli = os.path.join(os.path.dirname(impg_amd.__file__), "impg-gpu")
+    paf = str(tmp_path / "t.paf")
+    t, s, e = ranges[0]
+    rng = "%s:%d-%d" % (c.seq_name(t), s, e)
+    for fmt in ("bed", "paf"):
+        r = subprocess.run([cli, "query", "-a", paf, "-r", rng, "-d", "20", "-x", "--min-transitive-len", "40", "-o", fmt,
+                            "--original-sequence-coordinates"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        if fmt == "bed":
+            want = c.query_bed(c.seq_name(t), s, e, merge_distance=20, original_sequence_coordinates=True, **kw)
+        else:
+            want = c.query_paf(c.seq_name(t), s, e, merge_distance=20, fmt="paf", original_sequence_coordinates=True, **kw)
+        assert r.stdout == want

@@ -187,3 +187,15 @@ def test_cli_merge_distance_vectors_rejected_before_any_device_work():
     for bad in (["-d", "10kb"], ["-d", "3g"], ["-d", "-5"], ["-d", "abc"]):
         r = subprocess.run([cli, "query", "-a", "x.paf", "-r", "s:1-200"] + bad, capture_output=True, text=True)
         assert r.returncode != 0 and r.stdout == "" and r.stderr.startswith("Error:"), bad
+
+
+def test_parse_subsequence_reference_kat():
+    """impg_gpu_parse_subsequence against the reference's vectors (main.rs:13330-13346) and the oracle on odd names."""
+    import impg_amd
+    from oracle import oracle as o
+    from tests.test_oracle_kat import SUBSEQ_KAT
+    for name, want in SUBSEQ_KAT:
+        assert impg_amd.parse_subsequence(name) == want
+    for name in ["a:1-2", "a:b:10-20", "a:+7-9", "a:-7-9", "a:7", "a:-", ":5-6", "a:2147483647-1", "a:2147483648-1", "a:00012-3",
+                 "a:1-2:x", "a:1-2:3-4", "a: 1-2", "a:1 -2", "", ":", "-", "a#1#c:5-", "a:5-5-5"]:
+        assert impg_amd.parse_subsequence(name) == o.parse_subsequence(name), name

@@ -404,3 +404,13 @@ def test_subset_filter_matches_variants():
     got, entries = o.subset_matches(SUBSET_LIST, names)
     assert got.tolist() == [w for _, w in SUBSET_KAT]
     assert entries == 5  # chr1 (twice, once with a trailing tab), chr2, chr3 and the two sample names
+
+
+# src/main.rs:13330-13346 test_parse_subsequence_coordinates
+SUBSEQ_KAT = [("HG002#1#chr1:5116130-6116563", ("HG002#1#chr1", 5116130)), ("GRCh38#0#chr1:5477602-6474357", ("GRCh38#0#chr1", 5477602)),
+              ("chr1", None), ("chr1:invalid", None)]
+
+
+def test_parse_subsequence_coordinates():
+    for name, want in SUBSEQ_KAT:
+        assert o.parse_subsequence(name) == want

@@ -103,6 +103,7 @@ SYMBOLS = [
     ("impg_gpu_results_projected", C.c_uint64, [_P]),
     ("impg_gpu_results_cigar_offsets", _P, [_P]),
     ("impg_gpu_results_cigar_ops", _P, [_P]),
+    ("impg_gpu_results_timing", None, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("impg_gpu_results_free", None, [_P]),
     ("impg_gpu_query_batch_stats", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, _P, C.POINTER(Stats)]),
     ("impg_gpu_query_batch_stats_dev", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, _P, C.POINTER(Stats)]),

@@ -4,6 +4,7 @@
 // output_results_bed (src/main.rs:11849-11892).  Independent of the oracle.
 #include <algorithm>
 #include <atomic>
+#include <cstring>
 #include <numeric>
 #include <thread>
 
@@ -142,9 +143,9 @@ size_t bed_merge(impg_gpu_interval_t *iv, size_t n, int32_t merge_distance, bool
 }
 
 void render_bed(const impg_gpu_results &res, const impg_gpu_index &ix, const char *const *range_names,
-                const impg_gpu_params_t &p, int32_t merge_distance, std::string &out) {
+                const impg_gpu_params_t &p, int32_t merge_distance, std::vector<std::string> &parts) {
   const size_t nr = res.offsets.size() - 1;
-  std::vector<std::string> parts(nr);
+  parts.assign(nr, std::string());
   std::atomic<size_t> next{0};
   unsigned hw = std::thread::hardware_concurrency();
   size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, nr / 16 + 1));
@@ -191,11 +192,36 @@ void render_bed(const impg_gpu_results &res, const impg_gpu_index &ix, const cha
   std::vector<std::thread> th;
   for (size_t t = 0; t < T; t++) th.emplace_back(work);
   for (auto &t : th) t.join();
-  size_t total = 0;
-  for (auto &s : parts) total += s.size();
-  out.clear();
-  out.reserve(total);
-  for (auto &s : parts) out += s;
+}
+
+// The ranges' texts -> one malloc'ed, NUL-terminated buffer.  Gigabytes for a transitive batch: the destination is
+// written (and its pages first touched) by many threads, each copying a contiguous run of parts.
+char *join_parts(std::vector<std::string> &parts, size_t *len) {
+  std::vector<size_t> off(parts.size() + 1, 0);
+  for (size_t i = 0; i < parts.size(); i++) off[i + 1] = off[i] + parts[i].size();
+  const size_t total = off.back();
+  char *p = (char *)malloc(total + 1);
+  if (!p) throw Error{IMPG_E_OOM, "host out of memory"};
+  unsigned hw = std::thread::hardware_concurrency();
+  const size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, total / (8u << 20) + 1));
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= parts.size()) break;
+      if (!parts[i].empty()) memcpy(p + off[i], parts[i].data(), parts[i].size());
+      std::string().swap(parts[i]);  // give the part's memory back as we go
+    }
+  };
+  if (T == 1) work();
+  else {
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; t++) th.emplace_back(work);
+    for (auto &t : th) t.join();
+  }
+  p[total] = 0;
+  *len = total;
+  return p;
 }
 
 }  // namespace impg

@@ -1,5 +1,9 @@
 // extern "C" entry points of libimpg_gpu.so (include/impg_gpu.h).  Nothing
 // unwinds across this file: every body is wrapped and mapped to a status code.
+#include <atomic>
+#include <functional>
+#include <thread>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <memory>
@@ -11,9 +15,10 @@ namespace impg {
 thread_local std::string g_error;
 void set_error(const std::string &msg) { g_error = msg; }
 void render_paf(const impg_gpu_results &res, const impg_gpu_index &ix, const char *const *range_names,
-                const impg_gpu_params_t &p, int32_t merge_distance, bool bedpe, std::string &out);
+                const impg_gpu_params_t &p, int32_t merge_distance, bool bedpe, std::vector<std::string> &parts);
 void render_bed(const impg_gpu_results &res, const impg_gpu_index &ix, const char *const *range_names,
-                const impg_gpu_params_t &p, int32_t merge_distance, std::string &out);
+                const impg_gpu_params_t &p, int32_t merge_distance, std::vector<std::string> &parts);
+char *join_parts(std::vector<std::string> &parts, size_t *len);  // bed.cpp
 }  // namespace impg
 
 using namespace impg;
@@ -118,15 +123,62 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
     if (transitive && p.min_output_length >= 0 && std::abs((int64_t)H.c[k].y - H.c[k].x) < p.min_output_length) return false;
     return true;  // impg.rs:2482-2504
   };
-  // pass 1: counts
-  std::vector<uint64_t> cnt(n + 1, 0);
-  for (uint32_t q = 0; q < n; q++) {
-    if (!transitive) cnt[q] = 1;                                   // impg.rs:1864-1880
-    else for (uint32_t k = self_off[q]; k < self_off[q + 1]; k++) cnt[q] += self[k].start < self[k].end ? 1 : 0;  // impg.rs:2345-2363
+  // A level's hits come in frontier order and every frontier is sorted by query, so the hits of one range are one
+  // contiguous run per level: seg[l][q] = first slot of range q in level l.  With that the ranges are independent and
+  // the assembly runs over them in parallel (a transitive batch is hundreds of millions of rows).  A level whose
+  // frontier is not in query order (never produced by this engine) falls back to the serial passes below.
+  const size_t nl = hl.size();
+  std::vector<std::vector<uint64_t>> seg(nl);
+  bool by_range = true;
+  unsigned hw = std::thread::hardware_concurrency();
+  const size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, 64));
+  size_t total_hits = 0;
+  for (auto &H : hl) total_hits += H.qid.size();
+  auto parallel = [&](size_t count, const std::function<void(size_t, size_t)> &f) {
+    if (total_hits < (1u << 18) || count < 2 * T || T == 1) { f(0, count); return; }  // small batches: not worth the threads
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; t++) th.emplace_back([&, t]() { f(count * t / T, count * (t + 1) / T); });
+    for (auto &x : th) x.join();
+  };
+  for (size_t l = 0; l < nl && by_range; l++) {
+    const HostLevel &H = hl[l];
+    const size_t P = H.qid.size();
+    seg[l].assign((size_t)n + 1, P);
+    std::atomic<bool> ok{true};
+    auto qof = [&](size_t k) { return H.fr[H.pair_range[k]].qidx; };
+    parallel(P, [&](size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; k++) {
+        const uint32_t q = qof(k);
+        const int64_t prev = k ? (int64_t)qof(k - 1) : -1;
+        if (q >= n || (int64_t)q < prev) { ok = false; return; }
+        for (int64_t x = prev + 1; x <= (int64_t)q; x++) seg[l][(size_t)x] = k;  // ranges without hits share the next start
+      }
+    });
+    by_range = ok.load();
   }
-  for (auto &H : hl)
-    for (size_t k = 0; k < H.qid.size(); k++)
-      if (emitted(H, k)) cnt[H.fr[H.pair_range[k]].qidx]++;
+  std::vector<uint64_t> cnt(n + 1, 0);
+  auto self_rows = [&](uint32_t q) -> uint64_t {
+    if (!transitive) return 1;                                   // impg.rs:1864-1880
+    uint64_t c = 0;
+    for (uint32_t k = self_off[q]; k < self_off[q + 1]; k++) c += self[k].start < self[k].end ? 1 : 0;  // impg.rs:2345-2363
+    return c;
+  };
+  // pass 1: counts
+  if (by_range) {
+    parallel(n, [&](size_t lo, size_t hi) {
+      for (size_t q = lo; q < hi; q++) {
+        uint64_t c = self_rows((uint32_t)q);
+        for (size_t l = 0; l < nl; l++)
+          for (uint64_t k = seg[l][q]; k < seg[l][q + 1]; k++) c += emitted(hl[l], k) ? 1 : 0;
+        cnt[q] = c;
+      }
+    });
+  } else {
+    for (uint32_t q = 0; q < n; q++) cnt[q] = self_rows(q);
+    for (auto &H : hl)
+      for (size_t k = 0; k < H.qid.size(); k++)
+        if (emitted(H, k)) cnt[H.fr[H.pair_range[k]].qidx]++;
+  }
   res.offsets.assign(n + 1, 0);
   for (uint32_t q = 0; q < n; q++) res.offsets[q + 1] = res.offsets[q] + cnt[q];
   res.intervals.resize(res.offsets[n]);
@@ -135,7 +187,7 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
   std::vector<std::vector<uint32_t>> cg;
   if (res.has_cigar) cg.resize(res.intervals.size());
   std::vector<uint64_t> cur(res.offsets.begin(), res.offsets.end() - 1);
-  for (uint32_t q = 0; q < n; q++) {
+  auto put_self = [&](uint32_t q) {
     if (!transitive) {
       const auto &r = h_ranges[q];
       if (res.has_cigar) cg[cur[q]] = {(uint32_t)(r.end - r.start)};  // vec![CigarOp::new(range_end - range_start, '=')] (impg.rs:1870-1872)
@@ -146,15 +198,28 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
       if (res.has_cigar) cg[cur[q]] = {(uint32_t)(f.end - f.start)};  // impg.rs:2352-2354
       res.intervals[cur[q]++] = {f.target_id, f.start, f.end, f.target_id, f.start, f.end};
     }
-  }
-  // pass 2: levels in order, slots in order == the reference's emission order
-  for (auto &H : hl)
-    for (size_t k = 0; k < H.qid.size(); k++)
-      if (emitted(H, k)) {
-        const FrontierRec &f = H.fr[H.pair_range[k]];
-        if (res.has_cigar) cg[cur[f.qidx]].assign(H.pool.begin() + H.sl_pos[k], H.pool.begin() + H.sl_pos[k] + H.sl_n[k]);
-        res.intervals[cur[f.qidx]++] = {H.qid[k], H.c[k].x, H.c[k].y, f.target_id, H.c[k].z, H.c[k].w};
+  };
+  auto put_hit = [&](const HostLevel &H, size_t k) {
+    const FrontierRec &f = H.fr[H.pair_range[k]];
+    if (res.has_cigar) cg[cur[f.qidx]].assign(H.pool.begin() + H.sl_pos[k], H.pool.begin() + H.sl_pos[k] + H.sl_n[k]);
+    res.intervals[cur[f.qidx]++] = {H.qid[k], H.c[k].x, H.c[k].y, f.target_id, H.c[k].z, H.c[k].w};
+  };
+  // pass 2: per range the self interval(s), then levels in order, slots in order == the reference's emission order
+  if (by_range) {
+    parallel(n, [&](size_t lo, size_t hi) {
+      for (size_t q = lo; q < hi; q++) {
+        put_self((uint32_t)q);
+        for (size_t l = 0; l < nl; l++)
+          for (uint64_t k = seg[l][q]; k < seg[l][q + 1]; k++)
+            if (emitted(hl[l], k)) put_hit(hl[l], k);
       }
+    });
+  } else {
+    for (uint32_t q = 0; q < n; q++) put_self(q);
+    for (auto &H : hl)
+      for (size_t k = 0; k < H.qid.size(); k++)
+        if (emitted(H, k)) put_hit(H, k);
+  }
   if (res.has_cigar) {
     res.cigar_off.assign(1, 0);
     for (auto &c : cg) {
@@ -452,12 +517,21 @@ int impg_gpu_query_batch_filtered(impg_gpu_index_t *ix, const impg_gpu_range_t *
   for_chunks(E, n, [&](size_t b, size_t e) {
     std::vector<std::unique_ptr<LevelBufs>> levels;
     DevBuf self_dev;
+    const auto c0 = std::chrono::steady_clock::now();
     E.run(*ix, E.ranges_dev.as<impg_gpu_range_t>() + b, (uint32_t)(e - b), *params, &levels, nullptr, nullptr, nullptr, &self_dev);
+    const auto c1 = std::chrono::steady_clock::now();
     impg_gpu_results part;
     assemble_results(E, ranges + b, (uint32_t)(e - b), *params, levels, self_dev, part);
+    res->run_s += std::chrono::duration<double>(c1 - c0).count();
+    res->assemble_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - c1).count();
     uint64_t base = res->intervals.size();
-    res->intervals.insert(res->intervals.end(), part.intervals.begin(), part.intervals.end());
-    for (size_t i = 1; i < part.offsets.size(); i++) res->offsets.push_back(base + part.offsets[i]);
+    if (base == 0 && res->offsets.size() == 1) {  // the first (usually the only) chunk: take its arrays, no copy
+      res->intervals.swap(part.intervals);
+      res->offsets.swap(part.offsets);
+    } else {
+      res->intervals.insert(res->intervals.end(), part.intervals.begin(), part.intervals.end());
+      for (size_t i = 1; i < part.offsets.size(); i++) res->offsets.push_back(base + part.offsets[i]);
+    }
     if (part.has_cigar) {
       res->has_cigar = true;
       if (res->cigar_off.empty()) res->cigar_off.assign(1, 0);
@@ -486,6 +560,10 @@ const impg_gpu_interval_t *impg_gpu_results_intervals(const impg_gpu_results_t *
 uint64_t impg_gpu_results_projected(const impg_gpu_results_t *r) { return r->projected; }
 const uint64_t *impg_gpu_results_cigar_offsets(const impg_gpu_results_t *r) { return r->has_cigar ? r->cigar_off.data() : nullptr; }
 const uint32_t *impg_gpu_results_cigar_ops(const impg_gpu_results_t *r) { return r->has_cigar ? r->cigar_ops.data() : nullptr; }
+void impg_gpu_results_timing(const impg_gpu_results_t *r, double *engine_s, double *assemble_s) {
+  if (engine_s) *engine_s = r ? r->run_s : 0;
+  if (assemble_s) *assemble_s = r ? r->assemble_s : 0;
+}
 void impg_gpu_results_free(impg_gpu_results_t *r) { delete r; }
 
 static int stats_impl(impg_gpu_index_t *ix, const impg_gpu_range_t *d_ranges, size_t n, const impg_gpu_params_t *params,
@@ -558,14 +636,9 @@ int impg_gpu_results_bed(const impg_gpu_results_t *res, const impg_gpu_index_t *
                          const impg_gpu_params_t *params, int32_t merge_distance, char **text, size_t *len) {
   IMPG_TRY
   if (!res || !ix || !params || !text || !len) throw Error{IMPG_E_INVALID, "null argument"};
-  std::string s;
-  render_bed(*res, *ix, range_names, *params, merge_distance, s);
-  char *p = (char *)malloc(s.size() + 1);
-  if (!p) throw Error{IMPG_E_OOM, "host out of memory"};
-  memcpy(p, s.data(), s.size());
-  p[s.size()] = 0;
-  *text = p;
-  *len = s.size();
+  std::vector<std::string> parts;
+  render_bed(*res, *ix, range_names, *params, merge_distance, parts);
+  *text = join_parts(parts, len);
   return IMPG_OK;
   IMPG_CATCH
 }
@@ -575,14 +648,9 @@ int impg_gpu_results_paf(const impg_gpu_results_t *res, const impg_gpu_index_t *
   IMPG_TRY
   if (!res || !ix || !params || !text || !len) throw Error{IMPG_E_INVALID, "null argument"};
   if (format != IMPG_OUT_PAF && format != IMPG_OUT_BEDPE) throw Error{IMPG_E_INVALID, "unknown output format"};
-  std::string s;
-  render_paf(*res, *ix, range_names, *params, merge_distance, format == IMPG_OUT_BEDPE, s);
-  char *p = (char *)malloc(s.size() + 1);
-  if (!p) throw Error{IMPG_E_OOM, "host out of memory"};
-  memcpy(p, s.data(), s.size());
-  p[s.size()] = 0;
-  *text = p;
-  *len = s.size();
+  std::vector<std::string> parts;
+  render_paf(*res, *ix, range_names, *params, merge_distance, format == IMPG_OUT_BEDPE, parts);
+  *text = join_parts(parts, len);
   return IMPG_OK;
   IMPG_CATCH
 }

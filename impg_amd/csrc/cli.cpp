@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <string>
@@ -111,6 +112,7 @@ int main(int argc, char **argv) {
   long long merge_d = 0;
   long max_depth = 2, min_tl = -1, mdbr = 10, min_out = -1;
   double min_ident = NAN;
+  int verbose = 0;
   bool original_coords = false;  // main.rs:4370
   std::string subset_list;  // --subset-sequence-list: a file of sequence names (main.rs:4357, :11709-11720)
   int device = 0, order = IMPG_ORDER_COITREES;
@@ -144,7 +146,8 @@ int main(int argc, char **argv) {
     else if (a == "--device") device = atoi(need(a.c_str()));
     else if (a == "--order") { std::string o = need("--order"); order = o == "sorted" ? IMPG_ORDER_SORTED : IMPG_ORDER_COITREES; }
     else if (a == "-i" || a == "--index") index_file = need("-i");
-    else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbose") need(a.c_str());  // accepted, unused
+    else if (a == "-v" || a == "--verbose") verbose = atoi(need(a.c_str()));  // >= 1: phase timings on stderr
+    else if (a == "-t" || a == "--threads") need(a.c_str());  // accepted, unused
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else die("unexpected argument '" + a + "'", 2);
   }
@@ -240,15 +243,26 @@ int main(int argc, char **argv) {
     if (impg_gpu_subset_keep(text.data(), text.size(), nm.data(), ns, keep.data(), &entries) != IMPG_OK) die(impg_gpu_last_error());
     if (entries == 0) die("Subset sequence list '" + subset_list + "' did not contain any sequence names");
   }
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   if (impg_gpu_query_batch_filtered(ix, ranges.data(), ranges.size(), &p, nullptr, keep.empty() ? nullptr : keep.data(), &res) != IMPG_OK)
     die(impg_gpu_last_error());
+  const double t1 = now();
   char *text = nullptr;
   size_t len = 0;
   const int rc = fmt == "bed" ? impg_gpu_results_bed(res, ix, names.data(), &p, merge_distance, &text, &len)
                               : impg_gpu_results_paf(res, ix, names.data(), &p, merge_distance,
                                                      fmt == "paf" ? IMPG_OUT_PAF : IMPG_OUT_BEDPE, &text, &len);
   if (rc != IMPG_OK) die(impg_gpu_last_error());
+  const double t2 = now();
   fwrite(text, 1, len, stdout);
+  fflush(stdout);
+  if (verbose >= 1) {
+    double eng = 0, asm_s = 0;
+    impg_gpu_results_timing(res, &eng, &asm_s);
+    fprintf(stderr, "[impg-gpu] query %.2f s (engine %.2f, result assembly %.2f), merge + text %.2f s, write %.2f s, %zu intervals, %zu bytes\n",
+            t1 - t0, eng, asm_s, t2 - t1, now() - t2, impg_gpu_results_total(res), len);
+  }
   free(text);
   impg_gpu_results_free(res);
   impg_gpu_index_destroy(ix);

@@ -237,4 +237,5 @@ struct impg_gpu_results {
   std::vector<uint64_t> cigar_off;  // [intervals+1] when has_cigar
   std::vector<uint32_t> cigar_ops;
   uint64_t projected = 0;
+  double run_s = 0, assemble_s = 0;  // wall time in the engine (GPU) and in the host-side result assembly
 };

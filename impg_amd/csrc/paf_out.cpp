@@ -213,10 +213,10 @@ void put_u(std::string &s, unsigned long long v) {
 }  // namespace
 
 void render_paf(const impg_gpu_results &res, const impg_gpu_index &ix, const char *const *range_names,
-                const impg_gpu_params_t &p, int32_t merge_distance, bool bedpe, std::string &out) {
+                const impg_gpu_params_t &p, int32_t merge_distance, bool bedpe, std::vector<std::string> &parts) {
   if (!res.has_cigar) throw Error{IMPG_E_INVALID, "PAF / BEDPE output needs results queried with store_cigar = 1"};
   const size_t nr = res.offsets.size() - 1;
-  std::vector<std::string> parts(nr);
+  parts.assign(nr, std::string());
   std::atomic<size_t> next{0};
   std::atomic<int> failed{0};
   std::string fail_msg;
@@ -312,11 +312,6 @@ void render_paf(const impg_gpu_results &res, const impg_gpu_index &ix, const cha
   for (size_t t = 0; t < T; t++) th.emplace_back(work);
   for (auto &t : th) t.join();
   if (failed.load()) throw Error{failed.load(), fail_msg};
-  size_t total = 0;
-  for (auto &s : parts) total += s.size();
-  out.clear();
-  out.reserve(total);
-  for (auto &s : parts) out += s;
 }
 
 }  // namespace impg

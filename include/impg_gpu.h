@@ -224,6 +224,9 @@ const uint64_t *impg_gpu_results_cigar_offsets(const impg_gpu_results_t *);
 const uint32_t *impg_gpu_results_cigar_ops(const impg_gpu_results_t *);
 /* number of Some(..) projections (self intervals excluded) = the work unit of BASELINE.md */
 uint64_t impg_gpu_results_projected(const impg_gpu_results_t *);
+/* wall seconds the call spent in the engine (lookup / projection / update on the GPU) and in copying the hit
+ * slots back and assembling them into per-range result lists on the host */
+void impg_gpu_results_timing(const impg_gpu_results_t *, double *engine_s, double *assemble_s);
 void impg_gpu_results_free(impg_gpu_results_t *);
 
 /* Throughput form: same computation, results stay in HBM; returns per-range

@@ -830,3 +830,28 @@ def test_original_sequence_coordinates(tmp_path):
         else:
             want = c.query_paf(c.seq_name(t), s, e, merge_distance=20, fmt="paf", original_sequence_coordinates=True, **kw)
         assert r.stdout == want
+
+
+def test_parallel_result_assembly(tmp_path):
+    """Large batches assemble their result lists range-parallel on the host (runs of one range per level); small
+    chunks take the serial passes.  Same rows and CIGARs either way, and the oracle agrees on a sample."""
+    text, names = random_paf(151, 3000, n_seq=4, seq_len=30000, self_aln=True, max_ops=40)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(17, 1500, 4, 30000, max_len=4000, min_len=120)
+    for kw in (dict(transitive=True, max_depth=2, min_transitive_len=50), dict(transitive=True, dfs=True, max_depth=2),
+               dict(), dict(transitive=True, max_depth=2, multi_impg=True)):
+        p = impg_amd.make_params(store_cigar=True, **kw)
+        g.set_option("chunk_ranges", 0)
+        big = g.query_batch(ranges, p)
+        assert len(big.intervals) > (1 << 18) or not kw.get("transitive")
+        g.set_option("chunk_ranges", 40)
+        small = g.query_batch(ranges, p)
+        g.set_option("chunk_ranges", 0)
+        assert big.offsets.tolist() == small.offsets.tolist()
+        assert (big.intervals == small.intervals).all()
+        for i in range(0, len(ranges), 97):
+            t, s, e = ranges[i]
+            want, wcg = c.query_cigar(t, s, e, **kw)
+            assert big[i].tolist() == want.tolist()
+            assert [x.tolist() for x in big.cigars(i)] == [x.tolist() for x in wcg]
+            assert [x.tolist() for x in small.cigars(i)] == [x.tolist() for x in wcg]

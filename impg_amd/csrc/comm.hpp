@@ -1,0 +1,118 @@
+// Rank-to-rank transport of the sharded engine (sharded.cpp): what one hop of the
+// transitive closure needs from the fabric -- an all-gather of a few host words
+// (bucket sizes, liveness) and an all-to-all-v of device buffers (frontier
+// records out, hit records back).  Four implementations behind one interface:
+//   SelfComm   one rank: copies
+//   LocalComm  the ranks are threads of this process, one per GPU (impg_gpu_index_create_multi):
+//              every rank PULLS its blocks from its peers' send buffers with hipMemcpyPeerAsync -- direct
+//              xGMI reads, no staging, no library in between
+//   RcclComm   one process per GPU (the torch.distributed.run layout): ncclSend / ncclRecv groups on the
+//              engine's stream; librccl is opened at run time (dlopen), so the library loads without it
+//   HostComm   the host brings the transport (MPI, gloo, ...) as two callbacks over host memory; blocks are
+//              staged through pinned buffers.  Also what the multi-rank tests on a one-GPU box use.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "impg_internal.hpp"
+
+namespace impg {
+
+struct Comm {
+  int rank = 0, world = 1;
+  virtual ~Comm() {}
+  // all[r * k + i] = value i of rank r
+  virtual void allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) = 0;
+  // Block d of d_send (send_off[d], send_bytes[d]) goes to rank d; block s of d_recv comes from rank s.
+  // Device memory both sides; ordered after the work already queued on `s`; complete on return.
+  virtual void alltoallv(const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
+                         const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) = 0;
+  virtual void barrier() = 0;
+  virtual const char *kind() const = 0;
+};
+
+struct SelfComm : Comm {
+  void allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) override;
+  void alltoallv(const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
+                 const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) override;
+  void barrier() override {}
+  const char *kind() const override { return "self"; }
+};
+
+// ---- threads of one process ----------------------------------------------------
+struct LocalFabric {  // shared by the `world` LocalComm objects of one lane
+  int world;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  bool broken = false;  // a rank failed: everybody waiting is released with an error
+  struct Slot {
+    const uint64_t *vals = nullptr;
+    const void *send = nullptr;
+    const uint64_t *send_off = nullptr, *send_bytes = nullptr;
+    int device = 0;
+  };
+  std::vector<Slot> slots;
+  explicit LocalFabric(int w) : world(w), slots(w) {}
+  void wait_all();  // sense-reversing barrier; throws if the fabric broke
+  void poison();
+};
+struct LocalComm : Comm {
+  std::shared_ptr<LocalFabric> fab;
+  int device;
+  LocalComm(std::shared_ptr<LocalFabric> f, int rank_, int device_) : fab(std::move(f)), device(device_) {
+    rank = rank_;
+    world = fab->world;
+  }
+  void allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) override;
+  void alltoallv(const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
+                 const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) override;
+  void barrier() override { fab->wait_all(); }
+  const char *kind() const override { return "local"; }
+};
+
+// ---- RCCL ------------------------------------------------------------------------
+constexpr size_t RCCL_UNIQUE_ID_BYTES = 128;  // ncclUniqueId
+void rccl_unique_id(uint8_t *id128);          // rank 0 makes it; the host carries it to the other ranks
+struct RcclComm : Comm {
+  void *comm = nullptr;  // ncclComm_t
+  int device;
+  DevBuf d_vals;
+  uint64_t *h_vals = nullptr;  // pinned
+  size_t h_cap = 0;
+  RcclComm(const uint8_t *id128, int rank_, int world_, int device_);
+  ~RcclComm() override;
+  void allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) override;
+  void alltoallv(const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
+                 const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) override;
+  void barrier() override;
+  const char *kind() const override { return "rccl"; }
+};
+
+// ---- host-provided transport --------------------------------------------------------
+struct HostComm : Comm {
+  impg_gpu_host_transport_t t;
+  char *h_send = nullptr, *h_recv = nullptr;  // pinned staging
+  size_t send_cap = 0, recv_cap = 0;
+  HostComm(const impg_gpu_host_transport_t &tr, int rank_, int world_);
+  ~HostComm() override;
+  void allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) override;
+  void alltoallv(const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
+                 const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) override;
+  void barrier() override;
+  const char *kind() const override { return "host"; }
+};
+
+}  // namespace impg
+
+// the opaque handle of include/impg_gpu.h: one communicator per lane (chunks in flight)
+struct impg_gpu_comm {
+  int rank = 0, world = 1, device = 0;
+  std::vector<std::unique_ptr<impg::Comm>> lanes;
+};

@@ -278,10 +278,11 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
 }
 
 // ---------------------------------------------------------------------------
-// multi-GPU routing: owner rank of a frontier record = target_id % world
+// multi-GPU routing: owner rank of a frontier record = owner[target_id] (shard map), else target_id % world
 // ---------------------------------------------------------------------------
 constexpr uint32_t ROUTE_MAX_WORLD = 1024;
 __global__ __launch_bounds__(256) void route_keys_kernel(const FrontierRec *__restrict__ fr, uint32_t n, uint32_t world,
+                                                         const uint32_t *__restrict__ owner, uint32_t n_seq,
                                                          uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
                                                          unsigned long long *__restrict__ hist) {
   __shared__ uint32_t h[ROUTE_MAX_WORLD];
@@ -289,7 +290,10 @@ __global__ __launch_bounds__(256) void route_keys_kernel(const FrontierRec *__re
   __syncthreads();
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < n) {
-    const uint32_t o = fr[i].target_id % world;
+    // owner table of the shard map (targets bin-packed by entry count); a sequence id the index does not know
+    // has no alignments anywhere: any rank may answer "no hits"
+    const uint32_t t = fr[i].target_id;
+    const uint32_t o = (owner && t < n_seq) ? owner[t] : t % world;
     key[i] = o;
     idx[i] = i;
     atomicAdd(&h[o], 1u);
@@ -1938,6 +1942,54 @@ __global__ __launch_bounds__(256) void aos_to_hits_kernel(const impg_gpu_hit_t *
 }
 
 // ---------------------------------------------------------------------------
+// Hits between ranks (sharded.cpp).  An owner packs the slots of its expansion into AoS records addressed to the
+// record's HOME: word 0 = the home's frontier index (the qidx the routed record carried), then query id and the
+// query interval -- all the visited-set update reads (4 words) -- and, for runs that keep result rows or sort
+// them (MultiImpg), the target interval and the entry's MultiImpg tie rank (8 words).  Home puts the blocks that
+// arrive per owner back into frontier order (a frontier record has one owner: runs never interleave) and
+// unpacks them into the slot arrays a local expansion would have filled.
+// ---------------------------------------------------------------------------
+template <int WORDS>
+__global__ __launch_bounds__(256) void hits_pack_kernel(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ pair_range,
+                                                        uint32_t n_pairs, HitArrays h, const uint32_t *__restrict__ pair_entry,
+                                                        const uint32_t *__restrict__ mrank, uint4 *__restrict__ out) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n_pairs) return;
+  const uint32_t q = h.qid[p];
+  const int4 hc = q != HIT_NONE ? h.c[p] : make_int4(0, 0, 0, 0);
+  const uint32_t home = fr[pair_range[p]].qidx;
+  if (WORDS == 4) {
+    out[p] = make_uint4(home, q, (uint32_t)hc.x, (uint32_t)hc.y);
+  } else {
+    out[2 * (size_t)p] = make_uint4(home, q, (uint32_t)hc.x, (uint32_t)hc.y);
+    out[2 * (size_t)p + 1] = make_uint4((uint32_t)hc.z, (uint32_t)hc.w, (pair_entry && mrank) ? mrank[pair_entry[p]] : 0u, 0u);
+  }
+}
+// run_start == nullptr: the records are already in frontier order (one owner)
+template <int WORDS>
+__global__ __launch_bounds__(256) void hits_unpack_kernel(const uint4 *__restrict__ in, uint32_t n, uint32_t n_front,
+                                                          const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ off,
+                                                          uint32_t *__restrict__ pair_range, HitArrays h,
+                                                          uint32_t *__restrict__ mslot) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  constexpr int Q = WORDS / 4;
+  const uint4 a = in[(size_t)i * Q];
+  const uint32_t f = a.x;
+  if (f >= n_front) return;
+  const size_t d = run_start ? (size_t)off[f] + (i - run_start[f]) : i;
+  pair_range[d] = f;
+  h.qid[d] = a.y;
+  if (WORDS == 4) {
+    h.c[d] = make_int4((int32_t)a.z, (int32_t)a.w, 0, 0);
+  } else {
+    const uint4 b = in[(size_t)i * Q + 1];
+    h.c[d] = make_int4((int32_t)a.z, (int32_t)a.w, (int32_t)b.x, (int32_t)b.y);
+    if (mslot) mslot[d] = b.z;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -1975,9 +2027,9 @@ void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln);
   else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln);
 }
-void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, uint32_t *key, uint32_t *idx, unsigned long long *hist,
-                       hipStream_t s) {
-  if (n) route_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, n, world, key, idx, hist);
+void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, const uint32_t *owner, uint32_t n_seq, uint32_t *key,
+                       uint32_t *idx, unsigned long long *hist, hipStream_t s) {
+  if (n) route_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, n, world, owner, n_seq, key, idx, hist);
 }
 void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s) {
   if (n) route_gather_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, perm, n, out);
@@ -2216,6 +2268,18 @@ void launch_hits_to_aos16(const uint32_t *pair_range, uint32_t n_pairs, HitArray
 }
 void launch_aos16_to_hits(const impg_gpu_hit16_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s) {
   if (n) aos16_to_hits_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, n, pair_range, h);
+}
+void launch_hits_pack(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, const uint32_t *pair_entry,
+                      const uint32_t *mrank, uint32_t words, void *out, hipStream_t s) {
+  if (!n_pairs) return;
+  if (words == 4) hits_pack_kernel<4><<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, pair_entry, mrank, (uint4 *)out);
+  else hits_pack_kernel<8><<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, pair_entry, mrank, (uint4 *)out);
+}
+void launch_hits_unpack(const void *in, uint32_t n, uint32_t words, uint32_t n_front, const uint32_t *run_start, const uint32_t *off,
+                        uint32_t *pair_range, HitArrays h, uint32_t *mslot, hipStream_t s) {
+  if (!n) return;
+  if (words == 4) hits_unpack_kernel<4><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, n_front, run_start, off, pair_range, h, mslot);
+  else hits_unpack_kernel<8><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, n_front, run_start, off, pair_range, h, mslot);
 }
 void launch_aos_to_hits(const impg_gpu_hit_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s) {
   if (!n) return;

@@ -57,8 +57,13 @@ void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_
                         const uint32_t *perm, const uint32_t *offp, ProjList pl, const uint32_t *wide_n,
                         const uint32_t *wide_list, hipStream_t s);
 constexpr uint32_t ROUTE_WORLD_MAX = 1024;
-void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, uint32_t *key, uint32_t *idx, unsigned long long *hist,
-                       hipStream_t s);
+void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, const uint32_t *owner, uint32_t n_seq, uint32_t *key,
+                       uint32_t *idx, unsigned long long *hist, hipStream_t s);
+// hits between ranks: pack at the owner (word 0 = the home's frontier index), reorder + unpack at home
+void launch_hits_pack(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, const uint32_t *pair_entry,
+                      const uint32_t *mrank, uint32_t words, void *out, hipStream_t s);
+void launch_hits_unpack(const void *in, uint32_t n, uint32_t words, uint32_t n_front, const uint32_t *run_start, const uint32_t *off,
+                        uint32_t *pair_range, HitArrays h, uint32_t *mslot, hipStream_t s);
 void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s);
 // stable order of hit records (words u32 each, fidx first) by fidx when equal fidx are already contiguous
 void launch_reorder_runs(const uint32_t *hits, uint32_t n, uint32_t words, uint32_t n_front, uint32_t *run_start,

@@ -25,18 +25,21 @@ def make_params(transitive=False, dfs=False, max_depth=2, min_transitive_len=101
 class QueryResults:
     """Vec<AdjustedInterval> per range, in the reference's emission order."""
 
-    def __init__(self, handle, owner):
+    def __init__(self, handle, owner, copy=True):
+        """copy=False: the arrays are views of the library's buffers (valid while this object lives); a
+        transitive batch is hundreds of millions of rows, not worth duplicating."""
         self._h = handle
         self._owner = owner
         L = lib()
         self.n_ranges = L.impg_gpu_results_num_ranges(handle)
         total = L.impg_gpu_results_total(handle)
+        self.total = total
         self.offsets = np.ctypeslib.as_array(C.cast(L.impg_gpu_results_offsets(handle), C.POINTER(C.c_uint64)),
                                              shape=(self.n_ranges + 1,)).copy()
         if total:
             raw = np.ctypeslib.as_array(C.cast(L.impg_gpu_results_intervals(handle), C.POINTER(C.c_uint8)),
                                         shape=(total * INTERVAL_DTYPE.itemsize,))
-            self.intervals = raw.view(INTERVAL_DTYPE).copy()
+            self.intervals = raw.view(INTERVAL_DTYPE).copy() if copy else raw.view(INTERVAL_DTYPE)
         else:
             self.intervals = np.zeros(0, dtype=INTERVAL_DTYPE)
         self.projected = L.impg_gpu_results_projected(handle)
@@ -50,6 +53,12 @@ class QueryResults:
 
     def __getitem__(self, i):
         return self.intervals[self.offsets[i]:self.offsets[i + 1]]
+
+    def timing(self):
+        """(seconds in the engine, seconds copying back + assembling) of the call (impg_gpu_results_timing)."""
+        a, b = C.c_double(0), C.c_double(0)
+        lib().impg_gpu_results_timing(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def cigars(self, i):
         """Vec<CigarOp> (packed u32 ops) of every interval of range i; needs store_cigar."""
@@ -224,7 +233,7 @@ class GpuImpg:
         m = _lib.Mask(len(ids), seq.ctypes.data, slen.ctypes.data, off.ctypes.data, rng.ctypes.data)
         return m, (seq, slen, off, rng)
 
-    def query_batch(self, ranges, params=None, masked_regions=None, subset_keep=None, **kw):
+    def query_batch(self, ranges, params=None, masked_regions=None, subset_keep=None, copy=True, **kw):
         """masked_regions: one map for the whole batch (impg_gpu_query_batch_masked); every range starts
         from its own clone of it, as the reference's per-range calls do (impg.rs:2077-2081).
         subset_keep: uint8[num_seqs], the host's SubsetFilter::matches verdict per sequence id."""
@@ -245,7 +254,7 @@ class GpuImpg:
             del keep
         else:
             check(lib().impg_gpu_query_batch(self._h, r.ctypes.data, r.size, C.byref(p), C.byref(h)))
-        return QueryResults(h, self)
+        return QueryResults(h, self, copy=copy)
 
     def query(self, target_id, range_start, range_end, store_cigar=False, min_gap_compressed_identity=None,
               sequence_index=None, approximate_mode=False):

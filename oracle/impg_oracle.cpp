@@ -24,6 +24,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1104,19 +1106,70 @@ void merge_query_adjusted_intervals(std::vector<oracle_interval_t> &results, int
   results.resize(write_idx + 1);
 }
 
-void parallel_for(size_t n, int threads, const std::function<void(size_t)> &f) {
+/* rayon keeps one pool of workers for the process (the reference's par_iter calls, impg.rs:2384-2465, reuse
+ * it); spawning std::threads per BFS level would time thread creation, not the algorithm.  One job at a time
+ * (callers never nest): the caller publishes it, takes part itself, and waits for the workers that joined. */
+struct WorkerPool {
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> workers;
+  const std::function<void(size_t)> *job = nullptr;
+  size_t job_n = 0, grain = 1;
   std::atomic<size_t> next{0};
-  std::vector<std::thread> th;
-  int T = std::max(1, std::min<int>(threads, (int)n));
-  for (int t = 0; t < T; t++)
-    th.emplace_back([&]() {
-      for (;;) {
-        size_t i = next.fetch_add(1);
-        if (i >= n) break;
-        f(i);
-      }
-    });
-  for (auto &t : th) t.join();
+  uint64_t epoch = 0;
+  int want = 0, joined = 0, active = 0;
+  bool stop = false;
+  void drain() {
+    for (;;) {
+      size_t b = next.fetch_add(grain);
+      if (b >= job_n) break;
+      size_t e = std::min(job_n, b + grain);
+      for (size_t i = b; i < e; i++) (*job)(i);
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv_work.wait(lk, [&] { return stop || (epoch != seen && joined < want); });
+      if (stop) return;
+      seen = epoch;
+      joined++; active++;
+      lk.unlock();
+      drain();
+      lk.lock();
+      if (--active == 0) cv_done.notify_all();
+    }
+  }
+  void run(size_t n, int threads, const std::function<void(size_t)> &f) {
+    std::unique_lock<std::mutex> lk(m);
+    while ((int)workers.size() < threads - 1) workers.emplace_back([this] { worker(); });
+    job = &f; job_n = n; next = 0;
+    grain = std::max<size_t>(1, n / ((size_t)threads * 8));
+    want = threads - 1; joined = 0; active = 0;
+    epoch++;
+    lk.unlock();
+    cv_work.notify_all();
+    drain();
+    lk.lock();
+    want = joined;  /* late workers stay asleep: the job is exhausted */
+    cv_done.wait(lk, [&] { return active == 0; });
+    job = nullptr;
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv_work.notify_all();
+    for (auto &t : workers) t.join();
+  }
+};
+WorkerPool &pool() { static WorkerPool p; return p; }
+std::mutex g_pool_user;
+
+void parallel_for(size_t n, int threads, const std::function<void(size_t)> &f) {
+  int T = std::max(1, std::min<int>(threads, (int)std::min<size_t>(n, 1u << 20)));
+  if (T == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+  std::lock_guard<std::mutex> user(g_pool_user);
+  pool().run(n, T, f);
 }
 
 void append(char **buf, size_t *len, size_t *cap, const char *s, size_t n) {

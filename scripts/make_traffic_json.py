@@ -20,7 +20,7 @@ pairs = bench["pairs_per_step_rank0"] * passes
 rd128 = vals.get("TCC_EA0_RDREQ_128B_sum", 0.0)
 res = {
     "kernel": "project_kernel",
-    "command": "bench.py --ranges 16384 --steps 2 --warmup 1 --cpu-sample 0 (scripts/profile_r1.sh, separate --pmc passes)",
+    "command": "bench.py " + " ".join(bench.get("argv", ["--ranges 16384 --steps 2 --warmup 1 --cpu-sample 0"])) + " (scripts/profile_r*.sh, separate --pmc passes)",
     "dispatches": disp,
     "pairs": pairs,
     "FETCH_SIZE_KB_sum": vals.get("FETCH_SIZE"),

@@ -57,6 +57,7 @@ def main():
                     help="impg_gpu_set_option before the run (timing comparisons, e.g. locality_min=0)")
     ap.add_argument("--paf", default=None, help="reuse an existing synthetic PAF file")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even with one rank")
+    ap.add_argument("--lanes", type=int, default=2, help="sharded index: chunks of the batch in flight at once per rank")
     ap.add_argument("--no-extras", action="store_true", help="skip the full-results measurement (profiling runs)")
     args = ap.parse_args()
 
@@ -108,14 +109,14 @@ def main():
 
     log("building the device index")
     t_build = time.time()
+    comm = None
     if dist is None:
         index = impg_amd.GpuImpg.from_paf(paf, device=local_rank)
-        engine = None
     else:
-        from impg_amd.sharded import ShardedImpg
-        engine = ShardedImpg.from_paf(paf, rank, world, device=local_rank)
-        engine.chunk_ranges = args.chunk_ranges
-        index = engine.local
+        # this rank's shard of the index (targets bin-packed over the ranks); torch.distributed only carries the
+        # RCCL ids to the ranks -- every collective of a query runs inside libimpg_gpu.so
+        comm = impg_amd.Comm.rccl(rank, world, local_rank, lanes=args.lanes)
+        index = impg_amd.GpuImpg.from_paf(paf, device=local_rank, comm=comm)
     t_build = time.time() - t_build
     index.set_option("chunk_ranges", args.chunk_ranges)
     index.set_option("pair_budget", args.pair_budget)
@@ -131,12 +132,10 @@ def main():
     ranges["start"], ranges["end"] = bed["start"], bed["end"]
     d_ranges = torch.from_numpy(ranges.view(np.uint8)).to(dev)  # resident in HBM before the timed region
 
-    def step():
-        if engine is None:
-            st, _, _ = index.query_batch_stats(None, params, counts=False, checksums=False,
-                                               device_ptr=d_ranges.data_ptr(), n=args.ranges)
-            return st
-        return engine.query_batch_stats(d_ranges, args.ranges, params)
+    def step():  # (a collective call when the index is sharded: every rank brings its own ranges)
+        st, _, _ = index.query_batch_stats(None, params, counts=False, checksums=False,
+                                           device_ptr=d_ranges.data_ptr(), n=args.ranges)
+        return st
 
     def sync():
         torch.cuda.synchronize()
@@ -146,8 +145,8 @@ def main():
     log("index ready (%.1f s, %.2f GB in HBM); warmup" % (t_build, index.device_bytes() / 1e9))
     for _ in range(args.warmup):
         st = step()
-        log("warmup step: %d projected, engine %.1f ms (lookup %.1f project %.1f update %.1f)" %
-            (st.projected, st.ms_total, st.ms_lookup, st.ms_project, st.ms_update))
+        log("warmup step: %d projected, engine %.1f ms (lookup %.1f project %.1f update %.1f exchange %.1f)" %
+            (st.projected, st.ms_total, st.ms_lookup, st.ms_project, st.ms_update, st.ms_exchange))
     sync()
     t0 = time.perf_counter()
     stats = [step() for _ in range(args.steps)]
@@ -166,6 +165,8 @@ def main():
 
     if rank != 0:
         if dist is not None:
+            del index
+            comm.close()
             dist.destroy_process_group()
         flush_c_stdio()
         return
@@ -202,7 +203,8 @@ def main():
                         (args.records, args.ranges, ("-x -m %d" % args.max_depth) if transitive else "no transitive"),
             "records": args.records, "ranges_per_gpu": args.ranges, "max_depth": args.max_depth if transitive else 0,
             "min_transitive_len": 101, "min_distance_between_ranges": 10,
-            "parallelism": "1 process/GPU, index sharded by target sequence" if world > 1 else "single GPU",
+            "parallelism": ("1 process/GPU, index sharded by target sequence (bin-packed), frontier all-to-all-v over RCCL, "
+                            "%d chunks in flight per rank" % args.lanes) if dist is not None else "single GPU",
             "chunk_ranges": args.chunk_ranges, "pair_budget": args.pair_budget,
         },
         "projected_per_step_rank0": proj_per_step,
@@ -211,6 +213,7 @@ def main():
         "stage_ms_per_step_rank0": {"lookup": sum(s.ms_lookup for s in stats) / max(1, args.steps),
                                     "project": ms_project / max(1, args.steps),
                                     "update": sum(s.ms_update for s in stats) / max(1, args.steps),
+                                    "exchange_wall": sum(s.ms_exchange for s in stats) / max(1, args.steps),
                                     "engine_total": sum(s.ms_total for s in stats) / max(1, args.steps)},
         "argv": sys.argv[1:],
         "index_build_s": t_build,
@@ -221,6 +224,8 @@ def main():
         out["full_results"] = full_results_leg(index, ranges, params)
     out["cpu_baseline"] = cpu_baseline(args, paf, ranges, transitive) if (world == 1 and args.cpu_sample > 0) else None
     if dist is not None:
+        del index
+        comm.close()
         dist.destroy_process_group()
     flush_c_stdio()
     result_out.write(json.dumps(out) + "\n")

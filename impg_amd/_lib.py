@@ -25,10 +25,17 @@ RECORD_DTYPE = np.dtype([("query_id", "<u4"), ("target_id", "<u4"), ("query_star
 RANGE_DTYPE = np.dtype([("target_id", "<u4"), ("start", "<i4"), ("end", "<i4")])
 INTERVAL_DTYPE = np.dtype([("query_id", "<u4"), ("q_first", "<i4"), ("q_last", "<i4"),
                            ("target_id", "<u4"), ("t_first", "<i4"), ("t_last", "<i4")])
-FRONTIER_DTYPE = np.dtype([("target_id", "<u4"), ("start", "<i4"), ("end", "<i4"), ("qidx", "<u4")])
-HIT_DTYPE = np.dtype([("fidx", "<u4"), ("query_id", "<u4"), ("q_first", "<i4"), ("q_last", "<i4"),
-                      ("t_first", "<i4"), ("t_last", "<i4"), ("order", "<u4"), ("pad", "<u4")])
-assert RECORD_DTYPE.itemsize == 40 and RANGE_DTYPE.itemsize == 12 and HIT_DTYPE.itemsize == 32
+assert RECORD_DTYPE.itemsize == 40 and RANGE_DTYPE.itemsize == 12
+COMM_ID_BYTES = 128
+
+
+ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint64))
+ALLTOALLV_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p,
+                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+
+
+class HostTransport(C.Structure):  # impg_gpu_host_transport_t
+    _fields_ = [("ctx", C.c_void_p), ("allgather_u64", ALLGATHER_CB), ("alltoallv", ALLTOALLV_CB)]
 
 
 class Params(C.Structure):
@@ -41,7 +48,8 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("projected", C.c_uint64), ("pairs", C.c_uint64), ("frontier_ranges", C.c_uint64),
                 ("levels", C.c_uint32), ("ms_total", C.c_float), ("ms_lookup", C.c_float),
-                ("ms_project", C.c_float), ("ms_update", C.c_float), ("project_launches", C.c_uint64)]
+                ("ms_project", C.c_float), ("ms_update", C.c_float), ("project_launches", C.c_uint64),
+                ("ms_exchange", C.c_float)]
 
 
 class ImpgGpuError(RuntimeError):
@@ -70,12 +78,8 @@ SYMBOLS = [
     ("impg_gpu_device_count", C.c_int, []),
     ("impg_gpu_index_create", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_create_files", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, _P, C.c_uint32, C.c_int, C.c_int,
-                                              C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+                                              C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_create_from_paf", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
-    ("impg_gpu_index_create_sharded", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, C.c_int, C.c_int, C.c_int,
-                                                C.c_uint32, C.c_uint32, C.POINTER(_P)]),
-    ("impg_gpu_index_create_from_paf_sharded", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int,
-                                                         C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("impg_gpu_index_save", C.c_int, [_P, C.c_char_p]),
     ("impg_gpu_index_load", C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_destroy", None, [_P]),
@@ -112,16 +116,21 @@ SYMBOLS = [
     ("impg_gpu_results_paf", C.c_int, [_P, _P, _P, C.POINTER(Params), C.c_int32, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("impg_gpu_parse_cigar", C.c_long, [C.c_char_p, C.c_size_t, _P, C.c_size_t]),
     ("impg_gpu_parse_target_range", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    ("impg_gpu_stage_count", C.c_int, [_P, _P, C.c_size_t, C.c_int, _P, C.POINTER(C.c_uint64)]),
-    ("impg_gpu_stage_project", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(Params), _P, C.c_uint64, C.POINTER(C.c_uint64)]),
-    ("impg_gpu_stage_project16", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(Params), _P, C.c_uint64, C.POINTER(C.c_uint64)]),
-    ("impg_gpu_stage_update16", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_uint64)]),
-    ("impg_gpu_stage_reorder", C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.c_size_t, _P]),
-    ("impg_gpu_stage_route", C.c_int, [_P, _P, C.c_size_t, C.c_uint32, _P, C.POINTER(C.c_uint64)]),
-    ("impg_gpu_stage_begin", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, C.POINTER(C.c_uint64), _P]),
-    ("impg_gpu_stage_update", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_uint64)]),
-    ("impg_gpu_stage_next_frontier", C.c_int, [_P, _P, C.c_size_t]),
-    ("impg_gpu_stage_timing", C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.c_int]),
+    ("impg_gpu_comm_unique_id", C.c_int, [_P, C.c_int]),
+    ("impg_gpu_comm_create_rccl", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("impg_gpu_comm_create_host", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("impg_gpu_comm_destroy", None, [_P]),
+    ("impg_gpu_comm_info", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
+    ("impg_gpu_comm_check", C.c_int, [_P, C.c_int]),
+    ("impg_gpu_index_create_rank", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, _P, C.c_uint32, C.c_int, C.c_int,
+                                             C.c_int, _P, C.POINTER(_P)]),
+    ("impg_gpu_index_create_from_paf_rank", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    ("impg_gpu_index_create_multi", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, _P, C.c_uint32, C.c_int, C.c_int,
+                                              _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("impg_gpu_index_create_from_paf_multi", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                                       C.POINTER(_P)]),
+    ("impg_gpu_shard_assign", C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    ("impg_gpu_index_shard_info", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _P, C.c_size_t]),
     ("impg_synth_paf", C.c_int, [C.c_uint64, C.c_size_t, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, _P, _P, C.c_size_t,
                                  C.POINTER(C.c_size_t)]),
     ("impg_synth_paf_text", C.c_int, [C.c_uint64, C.c_size_t, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_char_p]),

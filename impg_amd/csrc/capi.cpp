@@ -23,7 +23,35 @@ char *join_parts(std::vector<std::string> &parts, size_t *len);  // bed.cpp
 
 using namespace impg;
 
-impg_gpu_index::~impg_gpu_index() { delete engine; }
+
+namespace impg {
+// One engine = one stream + one set of scratch buffers + the visited sets of the batch in flight.  Calls on one
+// handle from several host threads (the trait is Send + Sync: rayon workers share the index) each take their
+// own engine: up to max_engines run side by side, further callers wait for one to come back.
+EngineLease::EngineLease(impg_gpu_index &ix_) : ix(ix_) {
+  std::unique_lock<std::mutex> lk(ix.eng_m);
+  for (;;) {
+    if (!ix.eng_free.empty()) { e = ix.eng_free.back(); ix.eng_free.pop_back(); break; }
+    if ((int)ix.engines.size() < ix.max_engines) {
+      ix.engines.emplace_back(new Engine(ix.device));
+      e = ix.engines.back().get();
+      break;
+    }
+    ix.eng_cv.wait(lk);
+  }
+  e->pair_budget = ix.opt_pair_budget;
+  e->chunk_ranges = ix.opt_chunk_ranges;
+  e->locality_min = ix.opt_locality_min;
+}
+EngineLease::~EngineLease() {
+  e->remote = nullptr;
+  e->masked = false;
+  e->subset_on = false;
+  std::lock_guard<std::mutex> lk(ix.eng_m);
+  ix.eng_free.push_back(e);
+  ix.eng_cv.notify_one();
+}
+}  // namespace impg
 
 #define IMPG_TRY try {
 #define IMPG_CATCH                                  \
@@ -41,7 +69,7 @@ impg_gpu_index::~impg_gpu_index() { delete engine; }
     return IMPG_E_INVALID;                          \
   }
 
-namespace {
+namespace impg {
 
 void require_device(int device) {
   int n = 0;
@@ -54,24 +82,27 @@ void require_device(int device) {
 std::unique_ptr<impg_gpu_index> make_index(const impg_gpu_record_t *records, size_t n_records, const uint32_t *ops,
                                            size_t n_ops, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
                                            int order_policy, int device, uint32_t shard, uint32_t n_shards,
-                                           HostSeqIndex *seq, const std::vector<uint64_t> *file_first = nullptr) {
+                                           const HostSeqIndex *seq, const std::vector<uint64_t> *file_first,
+                                           const uint32_t *owner) {
   if ((!records && n_records) || (!ops && n_ops) || (!seq_len && n_seq)) throw Error{IMPG_E_INVALID, "null input array"};
   require_device(device);
   auto ix = std::make_unique<impg_gpu_index>();
   ix->device = device;
-  if (seq) ix->seq = std::move(*seq);
+  if (seq) ix->seq = *seq;
   if (file_first) {
     if (file_first->size() < 2 || file_first->front() != 0 || file_first->back() != n_records ||
         !std::is_sorted(file_first->begin(), file_first->end()))
       throw Error{IMPG_E_INVALID, "file boundaries must start at 0, end at n_records and be ascending"};
     ix->file_first = *file_first;
   }
-  build_index(*ix, records, n_records, ops, n_ops, seq_len, n_seq, bidirectional != 0, order_policy, shard, n_shards);
-  ix->engine = new Engine(device);
-  ix->stream = ix->engine->stream;
+  build_index(*ix, records, n_records, ops, n_ops, seq_len, n_seq, bidirectional != 0, order_policy, shard, n_shards, owner);
+  { EngineLease warm(*ix); }  // the first engine exists before the first query (stream + counters)
   return ix;
 }
 
+}  // namespace impg
+
+namespace impg {
 void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p,
                       std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, impg_gpu_results &res) {
   const bool transitive = p.transitive != 0;
@@ -230,6 +261,9 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
   res.projected = E.last_projected;
 }
 
+}  // namespace impg
+
+namespace {
 // Runs fn(begin, end) over [0,n) in chunks; a chunk whose level outgrows the pair
 // budget (SplitBatch) is retried at half the size.  Queries are independent, so
 // any split by ranges gives identical results.
@@ -249,13 +283,37 @@ template <class F> void for_chunks(Engine &E, size_t n, F fn) {
   }
 }
 
+}  // namespace
+
+namespace impg {
 void check_ranges(const impg_gpu_range_t *ranges, size_t n) {
   if (n >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 ranges in one batch"};
   for (size_t i = 0; i < n; i++)
     if (ranges[i].start >= ranges[i].end) throw Error{IMPG_E_INVALID, "query range must satisfy start < end"};
 }
-
-}  // namespace
+void append_results(impg_gpu_results &res, impg_gpu_results &part) {
+  if (res.offsets.empty()) res.offsets.assign(1, 0);
+  const uint64_t base = res.intervals.size();
+  if (base == 0 && res.offsets.size() == 1) {  // the first (often the only) part: take its arrays, no copy
+    res.intervals.swap(part.intervals);
+    res.offsets.swap(part.offsets);
+    if (res.offsets.empty()) res.offsets.assign(1, 0);
+  } else {
+    res.intervals.insert(res.intervals.end(), part.intervals.begin(), part.intervals.end());
+    for (size_t i = 1; i < part.offsets.size(); i++) res.offsets.push_back(base + part.offsets[i]);
+  }
+  if (part.has_cigar) {
+    res.has_cigar = true;
+    if (res.cigar_off.empty()) res.cigar_off.assign(1, 0);
+    const uint64_t cb = res.cigar_ops.size();
+    res.cigar_ops.insert(res.cigar_ops.end(), part.cigar_ops.begin(), part.cigar_ops.end());
+    for (size_t i = 1; i < part.cigar_off.size(); i++) res.cigar_off.push_back(cb + part.cigar_off[i]);
+  }
+  res.projected += part.projected;
+  res.run_s += part.run_s;
+  res.assemble_s += part.assemble_s;
+}
+}  // namespace impg
 
 extern "C" {
 
@@ -272,32 +330,21 @@ int impg_gpu_index_create(const impg_gpu_record_t *records, size_t n_records, co
                           impg_gpu_index_t **out) {
   IMPG_TRY
   if (!out) throw Error{IMPG_E_INVALID, "null out"};
-  *out = make_index(records, n_records, cigar_ops, n_ops, seq_len, n_seq, bidirectional, order_policy, device, 0, 1, nullptr).release();
-  return IMPG_OK;
-  IMPG_CATCH
-}
-
-int impg_gpu_index_create_sharded(const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops,
-                                  size_t n_ops, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
-                                  int order_policy, int device, uint32_t shard, uint32_t n_shards,
-                                  impg_gpu_index_t **out) {
-  IMPG_TRY
-  if (!out) throw Error{IMPG_E_INVALID, "null out"};
-  *out = make_index(records, n_records, cigar_ops, n_ops, seq_len, n_seq, bidirectional, order_policy, device, shard, n_shards, nullptr).release();
+  *out = make_index(records, n_records, cigar_ops, n_ops, seq_len, n_seq, bidirectional, order_policy, device, 0, 1, nullptr,
+                    nullptr, nullptr).release();
   return IMPG_OK;
   IMPG_CATCH
 }
 
 int impg_gpu_index_create_files(const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops, size_t n_ops,
                                 const int64_t *seq_len, uint32_t n_seq, const uint64_t *file_first_record, uint32_t n_files,
-                                int bidirectional, int order_policy, int device, uint32_t shard, uint32_t n_shards,
-                                impg_gpu_index_t **out) {
+                                int bidirectional, int order_policy, int device, impg_gpu_index_t **out) {
   IMPG_TRY
   if (!out || !file_first_record || n_files == 0) throw Error{IMPG_E_INVALID, "bad arguments"};
   std::vector<uint64_t> ff(file_first_record, file_first_record + n_files);
   ff.push_back(n_records);
-  *out = make_index(records, n_records, cigar_ops, n_ops, seq_len, n_seq, bidirectional, order_policy, device, shard, n_shards, nullptr,
-                    &ff).release();
+  *out = make_index(records, n_records, cigar_ops, n_ops, seq_len, n_seq, bidirectional, order_policy, device, 0, 1, nullptr,
+                    &ff, nullptr).release();
   return IMPG_OK;
   IMPG_CATCH
 }
@@ -312,22 +359,7 @@ int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths, int bi
   parse_paf_files(ps, pp);
   std::vector<int64_t> lens = pp.seq.lens;
   *out = make_index(pp.records.data(), pp.records.size(), pp.ops.data(), pp.ops.size(), lens.data(), (uint32_t)lens.size(),
-                    bidirectional, order_policy, device, 0, 1, &pp.seq, &pp.file_first).release();
-  return IMPG_OK;
-  IMPG_CATCH
-}
-
-int impg_gpu_index_create_from_paf_sharded(const char *const *paths, int n_paths, int bidirectional, int order_policy,
-                                           int device, uint32_t shard, uint32_t n_shards, impg_gpu_index_t **out) {
-  IMPG_TRY
-  if (!out || !paths || n_paths <= 0) throw Error{IMPG_E_INVALID, "bad arguments"};
-  require_device(device);
-  ParsedPaf pp;
-  std::vector<std::string> ps(paths, paths + n_paths);
-  parse_paf_files(ps, pp);
-  std::vector<int64_t> lens = pp.seq.lens;
-  *out = make_index(pp.records.data(), pp.records.size(), pp.ops.data(), pp.ops.size(), lens.data(), (uint32_t)lens.size(),
-                    bidirectional, order_policy, device, shard, n_shards, &pp.seq, &pp.file_first).release();
+                    bidirectional, order_policy, device, 0, 1, &pp.seq, &pp.file_first, nullptr).release();
   return IMPG_OK;
   IMPG_CATCH
 }
@@ -360,6 +392,7 @@ int impg_gpu_subset_keep(const char *list_text, size_t len, const char *const *n
 int impg_gpu_index_save(const impg_gpu_index_t *ix, const char *path) {
   IMPG_TRY
   if (!ix || !path) throw Error{IMPG_E_INVALID, "null argument"};
+  if (ix->shard || ix->cluster) throw Error{IMPG_E_UNSUPPORTED, "an index sharded over GPUs is not saved: save the plain index and shard it at load"};
   save_index(*ix, path);
   return IMPG_OK;
   IMPG_CATCH
@@ -372,8 +405,7 @@ int impg_gpu_index_load(const char *path, int device, impg_gpu_index_t **out) {
   auto ix = std::make_unique<impg_gpu_index>();
   ix->device = device;
   load_index(*ix, path);
-  ix->engine = new Engine(device);
-  ix->stream = ix->engine->stream;
+  { EngineLease warm(*ix); }
   *out = ix.release();
   return IMPG_OK;
   IMPG_CATCH
@@ -410,13 +442,13 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
   std::string k(key);
   if (k == "pair_budget") {
     if (value < 1024 || value >= 0xFFFFFFF0ll) throw Error{IMPG_E_INVALID, "pair_budget out of range"};
-    ix->engine->pair_budget = (uint64_t)value;
+    ix->opt_pair_budget = (uint64_t)value;
   } else if (k == "chunk_ranges") {
     if (value < 0 || value >= (1ll << 31)) throw Error{IMPG_E_INVALID, "chunk_ranges out of range"};
-    ix->engine->chunk_ranges = (uint32_t)value;
+    ix->opt_chunk_ranges = (uint32_t)value;
   } else if (k == "locality_min") {  // frontier size from which the projection runs in window order (0 = never)
     if (value < 0 || value >= (1ll << 31)) throw Error{IMPG_E_INVALID, "locality_min out of range"};
-    ix->engine->locality_min = (uint32_t)value;
+    ix->opt_locality_min = (uint32_t)value;
   } else throw Error{IMPG_E_INVALID, "unknown option " + k};
   return IMPG_OK;
   IMPG_CATCH
@@ -432,11 +464,11 @@ int impg_gpu_visit_rank(uint32_t n, int order_policy, uint32_t *rank_out) {
   IMPG_CATCH
 }
 
-namespace {
-// masked_regions -> the engine's device tables; cleared again when the call ends
-struct MaskScope {
-  Engine &E;
-  MaskScope(Engine &e, const impg_gpu_index &ix, const impg_gpu_mask_t *m, const impg_gpu_params_t &p) : E(e) {
+}  // extern "C"
+namespace impg {
+// masked_regions -> the engine's device tables (EngineLease clears the flag when the call ends)
+void apply_mask(Engine &E, const impg_gpu_index &ix, const impg_gpu_mask_t *m, const impg_gpu_params_t &p) {
+  {
     if (!m) return;
     if (!p.transitive) throw Error{IMPG_E_INVALID, "masked_regions belong to the transitive queries"};
     const uint32_t n_seq = ix.view.n_seq;
@@ -476,9 +508,16 @@ struct MaskScope {
     }
     E.masked = true;
   }
-  ~MaskScope() { E.masked = false; }
-};
-}  // namespace
+}
+void apply_subset(Engine &E, const impg_gpu_index &ix, const uint8_t *subset_keep) {
+  if (!subset_keep) return;
+  const size_t ns = ix.view.n_seq;
+  E.subset_keep.reserve(std::max<size_t>(ns, 256));
+  if (ns) IMPG_HIP(hipMemcpy(E.subset_keep.p, subset_keep, ns, hipMemcpyHostToDevice));
+  E.subset_on = true;
+}
+}  // namespace impg
+extern "C" {
 
 int impg_gpu_query_batch(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
                          impg_gpu_results_t **out) {
@@ -496,20 +535,13 @@ int impg_gpu_query_batch_filtered(impg_gpu_index_t *ix, const impg_gpu_range_t *
   IMPG_TRY
   if (!ix || !params || !out || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
   check_ranges(ranges, n);
-  Engine &E = *ix->engine;
   Engine::check_params(*params);
+  if (ix->shard || ix->cluster) return sharded_query_batch(*ix, ranges, n, *params, mask, subset_keep, out);
   IMPG_HIP(hipSetDevice(ix->device));
-  MaskScope mask_scope(E, *ix, mask, *params);
-  struct SubsetScope {
-    Engine &E;
-    ~SubsetScope() { E.subset_on = false; }
-  } subset_scope{E};
-  if (subset_keep) {
-    const size_t ns = ix->view.n_seq;
-    E.subset_keep.reserve(std::max<size_t>(ns, 256));
-    if (ns) IMPG_HIP(hipMemcpy(E.subset_keep.p, subset_keep, ns, hipMemcpyHostToDevice));
-    E.subset_on = true;
-  }
+  EngineLease lease(*ix);
+  Engine &E = *lease;
+  apply_mask(E, *ix, mask, *params);
+  apply_subset(E, *ix, subset_keep);
   auto res = std::make_unique<impg_gpu_results>();
   E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
   if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
@@ -522,24 +554,9 @@ int impg_gpu_query_batch_filtered(impg_gpu_index_t *ix, const impg_gpu_range_t *
     const auto c1 = std::chrono::steady_clock::now();
     impg_gpu_results part;
     assemble_results(E, ranges + b, (uint32_t)(e - b), *params, levels, self_dev, part);
-    res->run_s += std::chrono::duration<double>(c1 - c0).count();
-    res->assemble_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - c1).count();
-    uint64_t base = res->intervals.size();
-    if (base == 0 && res->offsets.size() == 1) {  // the first (usually the only) chunk: take its arrays, no copy
-      res->intervals.swap(part.intervals);
-      res->offsets.swap(part.offsets);
-    } else {
-      res->intervals.insert(res->intervals.end(), part.intervals.begin(), part.intervals.end());
-      for (size_t i = 1; i < part.offsets.size(); i++) res->offsets.push_back(base + part.offsets[i]);
-    }
-    if (part.has_cigar) {
-      res->has_cigar = true;
-      if (res->cigar_off.empty()) res->cigar_off.assign(1, 0);
-      uint64_t cb = res->cigar_ops.size();
-      res->cigar_ops.insert(res->cigar_ops.end(), part.cigar_ops.begin(), part.cigar_ops.end());
-      for (size_t i = 1; i < part.cigar_off.size(); i++) res->cigar_off.push_back(cb + part.cigar_off[i]);
-    }
-    res->projected += part.projected;
+    part.run_s = std::chrono::duration<double>(c1 - c0).count();
+    part.assemble_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - c1).count();
+    append_results(*res, part);
   });
   res->ranges.assign(ranges, ranges + n);
   *out = res.release();
@@ -566,9 +583,8 @@ void impg_gpu_results_timing(const impg_gpu_results_t *r, double *engine_s, doub
 }
 void impg_gpu_results_free(impg_gpu_results_t *r) { delete r; }
 
-static int stats_impl(impg_gpu_index_t *ix, const impg_gpu_range_t *d_ranges, size_t n, const impg_gpu_params_t *params,
+static int stats_impl(impg_gpu_index_t *ix, Engine &E, const impg_gpu_range_t *d_ranges, size_t n, const impg_gpu_params_t *params,
                       uint64_t *per_range_count, uint64_t *per_range_checksum, impg_gpu_stats_t *stats) {
-  Engine &E = *ix->engine;
   unsigned long long *dc = nullptr, *dk = nullptr;
   if (per_range_count) {
     E.stat_count.reserve(std::max<size_t>(n * 8, 256));
@@ -604,11 +620,14 @@ int impg_gpu_query_batch_stats(impg_gpu_index_t *ix, const impg_gpu_range_t *ran
   IMPG_TRY
   if (!ix || !params || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
   check_ranges(ranges, n);
-  Engine &E = *ix->engine;
+  Engine::check_params(*params);
+  if (ix->shard || ix->cluster) return sharded_query_stats(*ix, ranges, false, n, *params, per_range_count, per_range_checksum, stats);
   IMPG_HIP(hipSetDevice(ix->device));
+  EngineLease lease(*ix);
+  Engine &E = *lease;
   E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
   if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
-  return stats_impl(ix, E.ranges_dev.as<impg_gpu_range_t>(), n, params, per_range_count, per_range_checksum, stats);
+  return stats_impl(ix, E, E.ranges_dev.as<impg_gpu_range_t>(), n, params, per_range_count, per_range_checksum, stats);
   IMPG_CATCH
 }
 
@@ -618,8 +637,12 @@ int impg_gpu_query_batch_stats_dev(impg_gpu_index_t *ix, const impg_gpu_range_t 
   IMPG_TRY
   if (!ix || !params || (!d_ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
   if (n >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 ranges in one batch"};
+  Engine::check_params(*params);
+  if (ix->cluster) throw Error{IMPG_E_INVALID, "device-resident ranges belong to one GPU: a multi-GPU handle takes host ranges"};
+  if (ix->shard) return sharded_query_stats(*ix, d_ranges, true, n, *params, per_range_count, per_range_checksum, stats);
   IMPG_HIP(hipSetDevice(ix->device));
-  return stats_impl(ix, d_ranges, n, params, per_range_count, per_range_checksum, stats);
+  EngineLease lease(*ix);
+  return stats_impl(ix, *lease, d_ranges, n, params, per_range_count, per_range_checksum, stats);
   IMPG_CATCH
 }
 
@@ -651,236 +674,6 @@ int impg_gpu_results_paf(const impg_gpu_results_t *res, const impg_gpu_index_t *
   std::vector<std::string> parts;
   render_paf(*res, *ix, range_names, *params, merge_distance, format == IMPG_OUT_BEDPE, parts);
   *text = join_parts(parts, len);
-  return IMPG_OK;
-  IMPG_CATCH
-}
-
-int impg_gpu_stage_count(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
-                         uint32_t *d_counts, uint64_t *total) {
-  IMPG_TRY
-  if (!ix || (!d_frontier && n) || (!d_counts && n) || !total) throw Error{IMPG_E_INVALID, "null argument"};
-  if (n >= (1ull << 32) - 16) throw Error{IMPG_E_UNSUPPORTED, "frontier too large"};
-  Engine &E = *ix->engine;
-  IMPG_HIP(hipSetDevice(ix->device));
-  E.win.reserve(std::max<size_t>(n * 16, 256));
-  E.stage_off.reserve(std::max<size_t>(n * 4, 256));
-  E.ev_next = 0;
-  hipEvent_t e0 = E.event(), e1 = E.event();
-  IMPG_HIP(hipEventRecord(e0, E.stream));
-  E.wide_n.reserve(256);
-  E.wide_list.reserve(std::max<size_t>(n * 4, 256));
-  E.cnt.reserve(std::max<size_t>(n * 4, 256));  // kept for the projection order of stage_project
-  E.stage_perm = E.lookup_order(ix->view, d_frontier, (uint32_t)n);  // kept for stage_project
-  launch_lookup_count(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_perm, E.cnt.as<uint32_t>(), E.win.as<uint4>(),
-                      E.wide_n.as<uint32_t>(), E.wide_list.as<uint32_t>(), E.stream);
-  if (n) IMPG_HIP(hipMemcpyAsync(d_counts, E.cnt.p, n * 4, hipMemcpyDeviceToDevice, E.stream));
-  *total = E.scan(E.cnt.as<uint32_t>(), E.stage_off.as<uint32_t>(), (uint32_t)n);
-  IMPG_HIP(hipEventRecord(e1, E.stream));
-  IMPG_HIP(hipStreamSynchronize(E.stream));
-  { float ms = 0; IMPG_HIP(hipEventElapsedTime(&ms, e0, e1)); E.stage_ms[0] += ms; }
-  E.stage_n = (uint32_t)n;
-  return IMPG_OK;
-  IMPG_CATCH
-}
-
-namespace {
-// shared by impg_gpu_stage_project (32-byte hits) and impg_gpu_stage_project16 (16-byte hits)
-int stage_project_impl(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
-                       const impg_gpu_params_t *params, impg_gpu_hit_t *d_hits, impg_gpu_hit16_t *d_hits16, uint64_t total,
-                       uint64_t *accepted) {
-  IMPG_TRY
-  if (!ix || !params || (!d_frontier && n)) throw Error{IMPG_E_INVALID, "null argument"};  // d_hits may be null: count only
-  Engine &E = *ix->engine;
-  Engine::check_params(*params);
-  if (E.stage_n != n) throw Error{IMPG_E_INVALID, "stage_project must follow stage_count on the same frontier"};
-  if (params->store_cigar) throw Error{IMPG_E_UNSUPPORTED, "store_cigar is not available through the stage API"};
-  if (params->multi_impg) throw Error{IMPG_E_UNSUPPORTED, "MultiImpg semantics are not available through the stage API"};
-  if (total >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 pairs: split the frontier"};
-  IMPG_HIP(hipSetDevice(ix->device));
-  LevelBufs &L = E.level_scratch;
-  L.n_pairs = (uint32_t)total;
-  size_t b = std::max<size_t>(total * 4, 256);
-  L.pair_range.reserve(b); E.pair_entry.reserve(b);
-  L.qid.reserve(b); L.coords.reserve(4 * b);
-  HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
-  IMPG_HIP(hipMemsetAsync(E.counters.p, 0, 64, E.stream));
-  IMPG_HIP(hipMemsetAsync(E.acc_slots.p, 0, COUNT_BYTES, E.stream));
-  E.ev_next = 0;
-  hipEvent_t e0 = E.event(), e1 = E.event(), e2 = E.event();
-  IMPG_HIP(hipEventRecord(e0, E.stream));
-  const uint32_t *d_offp = nullptr;
-  ProjList pl;
-  E.projection_offsets(E.stage_perm, (uint32_t)n, E.cnt.as<uint32_t>(), total, d_offp, pl);
-  launch_lookup_emit(ix->view, d_frontier, (uint32_t)n, transitive != 0, E.stage_off.as<uint32_t>(), E.win.as<uint4>(),
-                     L.pair_range.as<uint32_t>(), pl.slot ? nullptr : E.pair_entry.as<uint32_t>(), pl.slot ? E.stage_perm : nullptr,
-                     d_offp, pl, E.wide_n.as<uint32_t>(), E.wide_list.as<uint32_t>(), E.stream);
-  IMPG_HIP(hipEventRecord(e1, E.stream));
-  launch_project(ix->view, d_frontier, L.pair_range.as<uint32_t>(), E.pair_entry.as<uint32_t>(), L.n_pairs, transitive != 0, h,
-                 E.acc_slots.as<unsigned long long>(), (uint32_t *)(E.counters.as<uint64_t>() + 2), params->min_identity, nullptr,
-                 pl, E.stream);
-  IMPG_HIP(hipEventRecord(e2, E.stream));
-  if (d_hits) launch_hits_to_aos(L.pair_range.as<uint32_t>(), E.stage_off.as<uint32_t>(), L.n_pairs, h, d_hits, E.stream);
-  if (d_hits16) launch_hits_to_aos16(L.pair_range.as<uint32_t>(), L.n_pairs, h, d_hits16, E.stream);
-  IMPG_HIP(hipStreamSynchronize(E.stream));
-  {
-    float ms = 0;
-    IMPG_HIP(hipEventElapsedTime(&ms, e0, e1)); E.stage_ms[0] += ms;
-    IMPG_HIP(hipEventElapsedTime(&ms, e1, e2)); E.stage_ms[1] += ms;
-    if (L.n_pairs) E.stage_launches += 1;
-  }
-  uint64_t hc[3];
-  IMPG_HIP(hipMemcpy(hc, E.counters.p, 24, hipMemcpyDeviceToHost));
-  if (hc[2]) throw Error{IMPG_E_INVALID, "an alignment hit by the query has no CIGAR (missing cg:Z tag)"};
-  if (accepted) *accepted = E.read_slots(E.acc_slots);
-  E.stage_n = 0;
-  return IMPG_OK;
-  IMPG_CATCH
-}
-}  // namespace
-
-int impg_gpu_stage_project(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
-                           const impg_gpu_params_t *params, impg_gpu_hit_t *d_hits, uint64_t total, uint64_t *accepted) {
-  return stage_project_impl(ix, d_frontier, n, transitive, params, d_hits, nullptr, total, accepted);
-}
-int impg_gpu_stage_project16(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, int transitive,
-                             const impg_gpu_params_t *params, impg_gpu_hit16_t *d_hits, uint64_t total, uint64_t *accepted) {
-  return stage_project_impl(ix, d_frontier, n, transitive, params, nullptr, d_hits, total, accepted);
-}
-
-int impg_gpu_stage_reorder(impg_gpu_index_t *ix, const void *d_hits, size_t n, uint32_t words_per_hit, size_t n_frontier,
-                           void *d_out) {
-  IMPG_TRY
-  if (!ix || (n && (!d_hits || !d_out))) throw Error{IMPG_E_INVALID, "null argument"};
-  if (words_per_hit != 4 && words_per_hit != 8) throw Error{IMPG_E_INVALID, "hit records are 4 or 8 words"};
-  if (n >= (1ull << 32) - 16 || n_frontier >= (1ull << 32) - 16) throw Error{IMPG_E_UNSUPPORTED, "too many records"};
-  if (!n) return IMPG_OK;
-  Engine &E = *ix->engine;
-  IMPG_HIP(hipSetDevice(ix->device));
-  const size_t fb = std::max<size_t>(n_frontier * 4, 256);
-  E.lo_key.reserve(fb); E.lo_cnt.reserve(fb); E.lo_off.reserve(fb);
-  IMPG_HIP(hipMemsetAsync(E.lo_cnt.p, 0, fb, E.stream));
-  IMPG_HIP(hipMemsetAsync(E.counters.as<unsigned long long>() + 4, 0, 8, E.stream));
-  uint32_t *err = reinterpret_cast<uint32_t *>(E.counters.as<unsigned long long>() + 4);
-  launch_reorder_runs(static_cast<const uint32_t *>(d_hits), (uint32_t)n, words_per_hit, (uint32_t)n_frontier,
-                      E.lo_key.as<uint32_t>(), E.lo_cnt.as<uint32_t>(), err, E.stream);
-  const uint64_t total = E.scan(E.lo_cnt.as<uint32_t>(), E.lo_off.as<uint32_t>(), (uint32_t)n_frontier);
-  uint32_t bad = 0;
-  IMPG_HIP(hipMemcpy(&bad, err, 4, hipMemcpyDeviceToHost));
-  if (bad || total != n) throw Error{IMPG_E_INVALID, "hit records name a frontier index twice or out of range"};
-  launch_reorder_scatter(d_hits, (uint32_t)n, words_per_hit, (uint32_t)n_frontier, E.lo_key.as<uint32_t>(),
-                         E.lo_off.as<uint32_t>(), d_out, E.stream);
-  IMPG_HIP(hipStreamSynchronize(E.stream));
-  return IMPG_OK;
-  IMPG_CATCH
-}
-
-int impg_gpu_stage_route(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n, uint32_t world,
-                         impg_gpu_frontier_t *d_out, uint64_t *counts) {
-  IMPG_TRY
-  if (!ix || !counts || (n && (!d_frontier || !d_out))) throw Error{IMPG_E_INVALID, "null argument"};
-  if (world == 0 || world > ROUTE_WORLD_MAX) throw Error{IMPG_E_INVALID, "world size out of range"};
-  if (n >= (1ull << 32) - 16) throw Error{IMPG_E_UNSUPPORTED, "frontier too large"};
-  Engine &E = *ix->engine;
-  IMPG_HIP(hipSetDevice(ix->device));
-  for (uint32_t k = 0; k < world; k++) counts[k] = 0;
-  if (!n) return IMPG_OK;
-  const size_t nb = std::max<size_t>(n * 4, 256);
-  E.lo_key.reserve(nb); E.lo_key2.reserve(nb); E.lo_idx.reserve(nb); E.lo_perm.reserve(nb);
-  E.stat_count.reserve((size_t)world * 8);
-  IMPG_HIP(hipMemsetAsync(E.stat_count.p, 0, (size_t)world * 8, E.stream));
-  launch_route_keys(d_frontier, (uint32_t)n, world, E.lo_key.as<uint32_t>(), E.lo_idx.as<uint32_t>(),
-                    E.stat_count.as<unsigned long long>(), E.stream);
-  unsigned bits = 1;
-  while ((1u << bits) < world) bits++;
-  const size_t tb = sort_u32_scratch_bytes((uint32_t)n);
-  E.sort_tmp.reserve(tb);
-  launch_sort_u32(E.sort_tmp.p, tb, E.lo_key.as<uint32_t>(), E.lo_key2.as<uint32_t>(), E.lo_idx.as<uint32_t>(),
-                  E.lo_perm.as<uint32_t>(), (uint32_t)n, E.stream, 0, bits);  // stable: original order within an owner
-  launch_route_gather(d_frontier, E.lo_perm.as<uint32_t>(), (uint32_t)n, d_out, E.stream);
-  IMPG_HIP(hipStreamSynchronize(E.stream));
-  std::vector<unsigned long long> h(world);
-  IMPG_HIP(hipMemcpy(h.data(), E.stat_count.p, (size_t)world * 8, hipMemcpyDeviceToHost));
-  for (uint32_t k = 0; k < world; k++) counts[k] = h[k];
-  return IMPG_OK;
-  IMPG_CATCH
-}
-
-int impg_gpu_stage_begin(impg_gpu_index_t *ix, const impg_gpu_range_t *d_ranges, size_t n, const impg_gpu_params_t *params,
-                         impg_gpu_frontier_t *d_frontier_out, uint64_t *n_frontier, impg_gpu_frontier_t *d_self_out) {
-  IMPG_TRY
-  if (!ix || !params || !n_frontier || (n && (!d_ranges || !d_frontier_out || !d_self_out))) throw Error{IMPG_E_INVALID, "null argument"};
-  if (n >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 ranges in one batch"};
-  Engine &E = *ix->engine;
-  Engine::check_params(*params);
-  IMPG_HIP(hipSetDevice(ix->device));
-  uint32_t nf = 0;
-  if (n) {
-    nf = E.begin_transitive(ix->view, d_ranges, (uint32_t)n, *params, d_self_out, E.frontier_a);
-    if (nf) IMPG_HIP(hipMemcpyAsync(d_frontier_out, E.frontier_a.p, (size_t)nf * sizeof(FrontierRec), hipMemcpyDeviceToDevice, E.stream));
-  } else E.tables.clear();
-  IMPG_HIP(hipStreamSynchronize(E.stream));
-  E.stage_queries = (uint32_t)n;
-  E.stage_next_n = 0;
-  *n_frontier = nf;
-  return IMPG_OK;
-  IMPG_CATCH
-}
-
-namespace {
-int stage_update_impl(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n_frontier, const impg_gpu_hit_t *d_hits,
-                      const impg_gpu_hit16_t *d_hits16, size_t n_hits, const impg_gpu_params_t *params, uint64_t *n_next) {
-  IMPG_TRY
-  if (!ix || !params || !n_next || (n_hits && ((!d_hits && !d_hits16) || !d_frontier))) throw Error{IMPG_E_INVALID, "null argument"};
-  if (n_hits >= 0xFFFFFFF0ull || n_frontier >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "too many hits in one update"};
-  Engine &E = *ix->engine;
-  IMPG_HIP(hipSetDevice(ix->device));
-  E.split_ok = false;
-  LevelBufs &L = E.level_scratch;
-  L.n_pairs = (uint32_t)n_hits;
-  size_t b = std::max<size_t>(n_hits * 4, 256);
-  L.pair_range.reserve(b); L.qid.reserve(b); L.coords.reserve(4 * b);
-  HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
-  if (d_hits16) launch_aos16_to_hits(d_hits16, L.n_pairs, L.pair_range.as<uint32_t>(), h, E.stream);  // (target columns unused by the update)
-  else launch_aos_to_hits(d_hits, L.n_pairs, L.pair_range.as<uint32_t>(), h, E.stream);
-  E.ev_next = 0;
-  E.timed.clear();
-  E.stage_next_n = E.update(ix->view, d_frontier, L, std::max<uint32_t>(E.stage_queries, 1), *params, E.stage_next);
-  IMPG_HIP(hipStreamSynchronize(E.stream));
-  for (auto &te : E.timed) { float ms = 0; IMPG_HIP(hipEventElapsedTime(&ms, te.a, te.b)); E.stage_ms[2] += ms; }
-  *n_next = E.stage_next_n;
-  return IMPG_OK;
-  IMPG_CATCH
-}
-}  // namespace
-
-int impg_gpu_stage_update(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
-                          const impg_gpu_hit_t *d_hits, size_t n_hits, const impg_gpu_params_t *params, uint64_t *n_next) {
-  return stage_update_impl(ix, d_frontier, n_frontier, d_hits, nullptr, n_hits, params, n_next);
-}
-int impg_gpu_stage_update16(impg_gpu_index_t *ix, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
-                            const impg_gpu_hit16_t *d_hits, size_t n_hits, const impg_gpu_params_t *params, uint64_t *n_next) {
-  return stage_update_impl(ix, d_frontier, n_frontier, nullptr, d_hits, n_hits, params, n_next);
-}
-
-int impg_gpu_stage_next_frontier(impg_gpu_index_t *ix, impg_gpu_frontier_t *d_out, size_t cap) {
-  IMPG_TRY
-  if (!ix || (!d_out && cap)) throw Error{IMPG_E_INVALID, "null argument"};
-  Engine &E = *ix->engine;
-  if (cap < E.stage_next_n) throw Error{IMPG_E_INVALID, "output buffer too small"};
-  IMPG_HIP(hipSetDevice(ix->device));
-  if (E.stage_next_n) IMPG_HIP(hipMemcpyAsync(d_out, E.stage_next.p, (size_t)E.stage_next_n * sizeof(FrontierRec), hipMemcpyDeviceToDevice, E.stream));
-  IMPG_HIP(hipStreamSynchronize(E.stream));
-  return IMPG_OK;
-  IMPG_CATCH
-}
-
-int impg_gpu_stage_timing(impg_gpu_index_t *ix, float *ms3, uint64_t *launches, int reset) {
-  IMPG_TRY
-  if (!ix) throw Error{IMPG_E_INVALID, "null argument"};
-  Engine &E = *ix->engine;
-  if (ms3) for (int k = 0; k < 3; k++) ms3[k] = E.stage_ms[k];
-  if (launches) *launches = E.stage_launches;
-  if (reset) { E.stage_ms[0] = E.stage_ms[1] = E.stage_ms[2] = 0; E.stage_launches = 0; }
   return IMPG_OK;
   IMPG_CATCH
 }

@@ -124,10 +124,12 @@ RcclComm::RcclComm(const uint8_t *id128, int rank_, int world_, int device_) : d
   Uid uid;
   memcpy(uid.b, id128, 128);
   nccl_check(rccl().CommInitRank(&comm, world, uid, rank), "ncclCommInitRank");
+  IMPG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
 }
 RcclComm::~RcclComm() {
   if (comm) (void)rccl().CommDestroy(comm);
   if (h_vals) (void)hipHostFree(h_vals);
+  if (cs) (void)hipStreamDestroy(cs);
 }
 void RcclComm::allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) {
   IMPG_HIP(hipSetDevice(device));
@@ -138,8 +140,7 @@ void RcclComm::allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) {
     IMPG_HIP(hipHostMalloc((void **)&h_vals, h_cap, hipHostMallocDefault));
   }
   d_vals.reserve(std::max<size_t>(need, 4096));
-  // the default stream of this thread is not used by anything else here: a private ordering domain
-  hipStream_t s = nullptr;
+  hipStream_t s = cs;
   memcpy(h_vals, mine, k * 8);
   uint64_t *d_mine = d_vals.as<uint64_t>(), *d_all = d_mine + k;
   IMPG_HIP(hipMemcpyAsync(d_mine, h_vals, k * 8, hipMemcpyHostToDevice, s));
@@ -202,7 +203,7 @@ void HostComm::alltoallv(const void *d_send, const uint64_t *send_off, const uin
   uint64_t st = 0, rt = 0;
   for (int p = 0; p < world; p++) { so[p] = st; st += send_bytes[p]; ro[p] = rt; rt += recv_bytes[p]; }
   auto grow = [](char *&p, size_t &cap, size_t need) {
-    if (need <= cap) return;
+    if (need <= cap && p) return;  // (never null: the callback gets real buffers even for an empty exchange)
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = std::max<size_t>(need + need / 4, 1 << 16);

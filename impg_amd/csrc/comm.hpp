@@ -33,6 +33,8 @@ struct Comm {
   virtual void alltoallv(const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
                          const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) = 0;
   virtual void barrier() = 0;
+  virtual void abort() {}  // this rank failed: release peers that wait for it, where the transport can
+  virtual void reset() {}  // before a new batch, with no rank inside the transport: forget an earlier abort
   virtual const char *kind() const = 0;
 };
 
@@ -62,6 +64,11 @@ struct LocalFabric {  // shared by the `world` LocalComm objects of one lane
   explicit LocalFabric(int w) : world(w), slots(w) {}
   void wait_all();  // sense-reversing barrier; throws if the fabric broke
   void poison();
+  void reset() {
+    std::lock_guard<std::mutex> lk(m);
+    broken = false;
+    arrived = 0;
+  }
 };
 struct LocalComm : Comm {
   std::shared_ptr<LocalFabric> fab;
@@ -74,6 +81,8 @@ struct LocalComm : Comm {
   void alltoallv(const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
                  const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) override;
   void barrier() override { fab->wait_all(); }
+  void abort() override { fab->poison(); }
+  void reset() override { fab->reset(); }
   const char *kind() const override { return "local"; }
 };
 
@@ -86,6 +95,7 @@ struct RcclComm : Comm {
   DevBuf d_vals;
   uint64_t *h_vals = nullptr;  // pinned
   size_t h_cap = 0;
+  hipStream_t cs = nullptr;  // the small all-gathers run on their own stream
   RcclComm(const uint8_t *id128, int rank_, int world_, int device_);
   ~RcclComm() override;
   void allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) override;

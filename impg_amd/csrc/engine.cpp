@@ -112,7 +112,7 @@ void Engine::projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uin
 
 // lookup + projection of one frontier; fills L (pair_range, hit arrays), returns #pairs
 uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
-                        impg_gpu_stats_t *st) {
+                        impg_gpu_stats_t *st, bool raw) {
   hipEvent_t e0 = event(), e1 = event(), e2 = event();
   IMPG_HIP(hipEventRecord(e0, stream));
   cnt.reserve((size_t)n_fr * 4);
@@ -152,25 +152,10 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
                  acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity,
                  store_cigar ? &sl : nullptr, pl, stream);
-  if (subset_on)
-    launch_subset_filter(fr, L.pair_range.as<uint32_t>(), L.n_pairs, h.qid, subset_keep.as<uint8_t>(), cur_ranges, stream);
-  if (multi && L.n_pairs) {
-    // sort every range's hits by (query_id, q.first, q.last, t.first, t.last) (multi_impg.rs:582-592)
-    const size_t b = std::max<size_t>((size_t)L.n_pairs * 4, 256);
-    m_dest.reserve(b); m_qid.reserve(b); m_coords.reserve(4 * b); m_pe.reserve(b);
-    launch_sort5(fr, n_fr, pair_off.as<uint32_t>(), L.n_pairs, h, pair_entry.as<uint32_t>(), v.mrank, m_dest.as<uint32_t>(), stream);
-    HitArrays h2{m_qid.as<uint32_t>(), m_coords.as<int4>()};
-    SliceArrays sl2{nullptr, nullptr, nullptr, nullptr};
-    if (store_cigar) {
-      m_sa.reserve(b); m_sn.reserve(b); m_so.reserve(b); m_sr.reserve(b);
-      sl2 = SliceArrays{m_sa.as<uint32_t>(), m_sn.as<uint32_t>(), m_so.as<int32_t>(), m_sr.as<int32_t>()};
-    }
-    launch_permute_slots(m_dest.as<uint32_t>(), L.n_pairs, h, h2, pair_entry.as<uint32_t>(), m_pe.as<uint32_t>(), sl, sl2, stream);
-    L.qid.swap(m_qid); L.coords.swap(m_coords);
-    pair_entry.swap(m_pe);
-    if (store_cigar) { L.sl_a.swap(m_sa); L.sl_n.swap(m_sn); L.sl_off.swap(m_so); L.sl_rem.swap(m_sr); }
-    h = h2;
-    sl = sl2;
+  if (!raw) {
+    post_expand(fr, n_fr, L, pair_off.as<uint32_t>(), pair_entry.as<uint32_t>(), v.mrank, sl);
+    h = HitArrays{L.qid.as<uint32_t>(), L.coords.as<int4>()};
+    if (store_cigar) sl = SliceArrays{L.sl_a.as<uint32_t>(), L.sl_n.as<uint32_t>(), L.sl_off.as<int32_t>(), L.sl_rem.as<int32_t>()};
   }
   IMPG_HIP(hipEventRecord(e2, stream));
   if (store_cigar && L.n_pairs) {  // materialise the slices while pair_entry is still this level's
@@ -195,6 +180,40 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
     if (P) st->project_launches += 1;
   }
   return P;
+}
+
+// What a level's slots go through between the projection and their readers: the subset filter (a hit whose query
+// sequence is neither the range's own target nor kept becomes an empty slot) and, under MultiImpg semantics, the
+// five-key sort of every frontier record's slot run (multi_impg.rs:582-592).  tie_idx is permuted with the slots
+// (it is pair_entry on one GPU: the slice materialisation reads it afterwards).
+void Engine::post_expand(const FrontierRec *fr, uint32_t n_fr, LevelBufs &L, const uint32_t *d_pair_off, uint32_t *tie_idx,
+                         const uint32_t *tie_rank, SliceArrays sl) {
+  HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
+  if (subset_on)
+    launch_subset_filter(fr, L.pair_range.as<uint32_t>(), L.n_pairs, h.qid, subset_keep.as<uint8_t>(), cur_ranges, stream);
+  if (multi && L.n_pairs) {
+    const size_t b = std::max<size_t>((size_t)L.n_pairs * 4, 256);
+    m_dest.reserve(b); m_qid.reserve(b); m_coords.reserve(4 * b); m_pe.reserve(b);
+    launch_sort5(fr, n_fr, d_pair_off, L.n_pairs, h, tie_idx, tie_rank, m_dest.as<uint32_t>(), stream);
+    HitArrays h2{m_qid.as<uint32_t>(), m_coords.as<int4>()};
+    SliceArrays sl2{nullptr, nullptr, nullptr, nullptr};
+    if (sl.a) {
+      m_sa.reserve(b); m_sn.reserve(b); m_so.reserve(b); m_sr.reserve(b);
+      sl2 = SliceArrays{m_sa.as<uint32_t>(), m_sn.as<uint32_t>(), m_so.as<int32_t>(), m_sr.as<int32_t>()};
+    }
+    launch_permute_slots(m_dest.as<uint32_t>(), L.n_pairs, h, h2, tie_idx, m_pe.as<uint32_t>(), sl, sl2, stream);
+    L.qid.swap(m_qid); L.coords.swap(m_coords);
+    if (tie_idx == pair_entry.as<uint32_t>()) pair_entry.swap(m_pe);
+    if (sl.a) { L.sl_a.swap(m_sa); L.sl_n.swap(m_sn); L.sl_off.swap(m_so); L.sl_rem.swap(m_sr); }
+  }
+}
+
+HopResult Engine::hop(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
+                      impg_gpu_stats_t *st, bool need_hits, bool need_rows, bool alive) {
+  if (remote) return remote->hop(*this, v, fr, n_fr, transitive, L, st, need_hits, need_rows, alive);
+  if (!alive) { L.n_pairs = 0; return HopResult{0, true}; }
+  if (!n_fr) { L.n_pairs = 0; return HopResult{0, false}; }
+  return HopResult{expand(v, fr, n_fr, transitive, L, st), false};
 }
 
 // visited update + next frontier (impg.rs:2471-2584).  Returns the next frontier size.
@@ -349,7 +368,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
                  unsigned long long *d_cksum, impg_gpu_stats_t *st, DevBuf *self_out) {
   check_params(p);
   IMPG_HIP(hipSetDevice(ix.device));
-  split_ok = n > 1;
+  split_ok = n > 1 && !remote;  // (ranks of a sharded batch stay in lock step: no re-splitting)
   min_identity = p.min_identity;
   store_cigar = p.store_cigar != 0 && keep != nullptr;  // slices are only materialised for full results
   multi = p.multi_impg != 0;
@@ -372,8 +391,9 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
 
   DevBuf *cur = &frontier_a, *nxt = &frontier_b;
   uint32_t n_fr = 0;
-  if (!transitive) {
-    cur->reserve(std::max<size_t>((size_t)n * sizeof(FrontierRec), 256));
+  cur->reserve(std::max<size_t>((size_t)n * sizeof(FrontierRec), 256));
+  if (!n) {  // (a rank of a sharded batch that has no ranges of its own still takes part in every hop)
+  } else if (!transitive) {
     launch_ranges_to_frontier(d_ranges, n, cur->as<FrontierRec>(), stream);
     n_fr = n;
   } else {
@@ -384,31 +404,37 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   }
 
   uint32_t depth = 0;
-  while (n_fr > 0 && (!transitive || p.max_depth == 0 || depth < p.max_depth)) {
+  for (;;) {
+    const bool alive = n_fr > 0 && (!transitive || p.max_depth == 0 || depth < p.max_depth);
+    const bool last = !transitive || (p.max_depth > 0 && depth + 1 >= p.max_depth);
     std::unique_ptr<LevelBufs> own;
     LevelBufs *L = &level_scratch;
     if (keep) {
       own = std::make_unique<LevelBufs>();
       L = own.get();
     }
-    expand(v, cur->as<FrontierRec>(), n_fr, transitive, *L, st);
-    L->n_frontier = n_fr;
-    if (d_count || d_cksum) {
-      HitArrays h{L->qid.as<uint32_t>(), L->coords.as<int4>()};
-      launch_hit_stats(cur->as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h,
-                       transitive ? p.min_output_length : -1, false, d_count, d_cksum, stream);
-    }
-    if (st) st->levels += 1;
-    const bool last = !transitive || (p.max_depth > 0 && depth + 1 >= p.max_depth);
+    const bool want_stats = d_count || d_cksum;
+    const HopResult hr = hop(v, cur->as<FrontierRec>(), alive ? n_fr : 0, transitive, *L, st, keep || want_stats || !last,
+                             keep || d_cksum, alive);
+    if (hr.all_dead) break;
     uint32_t n_next = 0;
-    if (!last) n_next = update(v, cur->as<FrontierRec>(), *L, n, p, *nxt);
-    if (keep) {
-      // the level keeps its own copy of the frontier (qidx / target per pair)
-      L->frontier.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
-      IMPG_HIP(hipMemcpyAsync(L->frontier.p, cur->p, (size_t)n_fr * sizeof(FrontierRec), hipMemcpyDeviceToDevice, stream));
-      keep->push_back(std::move(own));
+    if (alive) {
+      L->n_frontier = n_fr;
+      if (want_stats) {
+        HitArrays h{L->qid.as<uint32_t>(), L->coords.as<int4>()};
+        launch_hit_stats(cur->as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h,
+                         transitive ? p.min_output_length : -1, false, d_count, d_cksum, stream);
+      }
+      if (st) st->levels += 1;
+      if (!last) n_next = update(v, cur->as<FrontierRec>(), *L, n, p, *nxt);
+      if (keep) {
+        // the level keeps its own copy of the frontier (qidx / target per pair)
+        L->frontier.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
+        IMPG_HIP(hipMemcpyAsync(L->frontier.p, cur->p, (size_t)n_fr * sizeof(FrontierRec), hipMemcpyDeviceToDevice, stream));
+        keep->push_back(std::move(own));
+      }
     }
-    if (last) break;
+    if (last) break;  // (the depth is the same on every rank)
     std::swap(cur, nxt);
     n_fr = n_next;
     depth += 1;
@@ -491,8 +517,9 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
   IMPG_HIP(hipEventRecord(t0, stream));
   DevBuf &self = self_out ? *self_out : self_scratch;
   self.reserve(std::max<size_t>((size_t)n * sizeof(FrontierRec), 256));
-  uint32_t n_stack = masked ? begin_transitive_masked(v, d_ranges, n, p, self, frontier_a)
-                            : begin_transitive(v, d_ranges, n, p, self.as<FrontierRec>(), frontier_a);
+  uint32_t n_stack = 0;
+  if (n) n_stack = masked ? begin_transitive_masked(v, d_ranges, n, p, self, frontier_a)
+                          : begin_transitive(v, d_ranges, n, p, self.as<FrontierRec>(), frontier_a);
   auto res4 = [&](DevBuf &k, DevBuf &s, DevBuf &e, DevBuf &d, size_t m) {
     k.reserve(std::max<size_t>(m * 8, 256)); s.reserve(std::max<size_t>(m * 4, 256));
     e.reserve(std::max<size_t>(m * 4, 256)); d.reserve(std::max<size_t>(m * 4, 256));
@@ -502,27 +529,36 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
   launch_frontier_to_stack(frontier_a.as<FrontierRec>(), n_stack, nullptr, false, dk_a.as<unsigned long long>(),
                            ds_a.as<int32_t>(), de_a.as<int32_t>(), dd_a.as<uint32_t>(), stream);
   // current stack in the *_a buffers, sorted by (qidx, sequence, start)
-  while (n_stack > 0) {
+  for (;;) {
+    const bool alive = n_stack > 0;
     // ---- pop the top of every query's stack -----------------------------------
-    head.reserve((size_t)n_stack * 4); gid.reserve((size_t)n_stack * 4);
-    d_flag2.reserve((size_t)n_stack * 4); d_pos2.reserve((size_t)n_stack * 4);
-    launch_dfs_pop_flags(dk_a.as<unsigned long long>(), dd_a.as<uint32_t>(), n_stack, p.max_depth, multi && !p.dfs, head.as<uint32_t>(),
-                         d_flag2.as<uint32_t>(), d_popdepth.as<uint32_t>(), stream);
-    const uint32_t n_fr = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), n_stack);
-    const uint32_t n_keep = (uint32_t)scan(d_flag2.as<uint32_t>(), d_pos2.as<uint32_t>(), n_stack);
-    frontier_b.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
+    uint32_t n_fr = 0, n_keep = 0;
+    frontier_b.reserve(256);
+    if (alive) {
+      head.reserve((size_t)n_stack * 4); gid.reserve((size_t)n_stack * 4);
+      d_flag2.reserve((size_t)n_stack * 4); d_pos2.reserve((size_t)n_stack * 4);
+      launch_dfs_pop_flags(dk_a.as<unsigned long long>(), dd_a.as<uint32_t>(), n_stack, p.max_depth, multi && !p.dfs, head.as<uint32_t>(),
+                           d_flag2.as<uint32_t>(), d_popdepth.as<uint32_t>(), stream);
+      n_fr = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), n_stack);
+      n_keep = (uint32_t)scan(d_flag2.as<uint32_t>(), d_pos2.as<uint32_t>(), n_stack);
+      frontier_b.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
+    }
     uint32_t n_pieces = 0;
     // remaining stack goes to the *_b buffers; the new pieces are appended behind it
     std::unique_ptr<LevelBufs> own;
     LevelBufs *L = &level_scratch;
     if (keep) { own = std::make_unique<LevelBufs>(); L = own.get(); }
-    res4(dk_b, ds_b, de_b, dd_b, (size_t)n_keep + 1);
-    launch_dfs_pop_scatter(dk_a.as<unsigned long long>(), ds_a.as<int32_t>(), de_a.as<int32_t>(), dd_a.as<uint32_t>(), n_stack,
-                           head.as<uint32_t>(), gid.as<uint32_t>(), d_flag2.as<uint32_t>(), d_pos2.as<uint32_t>(),
-                           frontier_b.as<FrontierRec>(), dk_b.as<unsigned long long>(), ds_b.as<int32_t>(), de_b.as<int32_t>(),
-                           dd_b.as<uint32_t>(), stream);
+    if (alive) {
+      res4(dk_b, ds_b, de_b, dd_b, (size_t)n_keep + 1);
+      launch_dfs_pop_scatter(dk_a.as<unsigned long long>(), ds_a.as<int32_t>(), de_a.as<int32_t>(), dd_a.as<uint32_t>(), n_stack,
+                             head.as<uint32_t>(), gid.as<uint32_t>(), d_flag2.as<uint32_t>(), d_pos2.as<uint32_t>(),
+                             frontier_b.as<FrontierRec>(), dk_b.as<unsigned long long>(), ds_b.as<int32_t>(), de_b.as<int32_t>(),
+                             dd_b.as<uint32_t>(), stream);
+    }
+    const HopResult hr = hop(v, frontier_b.as<FrontierRec>(), n_fr, true, *L, st, true, keep || d_cksum, alive);
+    if (hr.all_dead) break;
+    if (!alive) continue;
     if (n_fr) {
-      expand(v, frontier_b.as<FrontierRec>(), n_fr, true, *L, st);
       L->n_frontier = n_fr;
       if (d_count || d_cksum) {
         HitArrays h{L->qid.as<uint32_t>(), L->coords.as<int4>()};
@@ -538,7 +574,7 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
       }
     }
     const uint32_t m = n_keep + n_pieces;
-    if (m == 0) break;
+    if (m == 0) { n_stack = 0; continue; }  // (one more hop call tells the other ranks, or ends the walk)
     if (n_pieces == 0) {  // nothing pushed: the remaining stack is still sorted and merged
       dk_a.swap(dk_b); ds_a.swap(ds_b); de_a.swap(de_b); dd_a.swap(dd_b);
       n_stack = n_keep;

@@ -22,6 +22,24 @@ struct VisitedStore {  // device storage of one VisitedTable
 
 struct SplitBatch {};  // thrown when a level exceeds pair_budget: the caller halves the chunk
 
+// Where a frontier is expanded.  On one GPU the engine looks its records up in its own index (Engine::expand).
+// With the index sharded over ranks (sharded.cpp) the records travel to the ranks that own their targets and
+// the hits come home; the slot arrays of `L` end up exactly as a local expansion would have left them (frontier
+// order x visit order), so everything downstream -- visited update, DFS stacks, masks, result assembly -- is
+// shared.  A hop is collective: every rank takes part in every hop, with an empty frontier once it has nothing
+// left (`alive` = this rank still has work pending); all_dead = no rank has, the walk is over everywhere.
+struct HopResult {
+  uint64_t pairs;
+  bool all_dead;
+};
+struct Engine;
+struct Expander {
+  virtual ~Expander() {}
+  // need_hits: somebody at home reads the slots (update, counts, rows); need_rows: including the target columns
+  virtual HopResult hop(Engine &home, const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive,
+                        LevelBufs &L, impg_gpu_stats_t *st, bool need_hits, bool need_rows, bool alive) = 0;
+};
+
 struct Engine {
   hipStream_t stream = nullptr;
   DevBuf counters;          // 8 x u64: [2] error flag, [3] scan total
@@ -66,8 +84,16 @@ struct Engine {
   void projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
                           ProjList &pl);
   DevBuf proj_range, proj_entry;  // the pairs' ranges / entries in projection order (next to slot_of)
+  // raw: the owner side of a sharded hop -- slots as projected; the subset filter and the MultiImpg sort run at home
   uint64_t expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
-                  impg_gpu_stats_t *st);
+                  impg_gpu_stats_t *st, bool raw = false);
+  // subset filter + MultiImpg five-key sort of a level's slots (pair_off: first slot of every frontier record;
+  // tie_rank[tie_idx[slot]] = the MultiImpg tie order of the slot's entry)
+  void post_expand(const FrontierRec *fr, uint32_t n_fr, LevelBufs &L, const uint32_t *d_pair_off, uint32_t *tie_idx,
+                   const uint32_t *tie_rank, SliceArrays sl);
+  Expander *remote = nullptr;  // set: frontiers are expanded on the owning shards
+  HopResult hop(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
+                impg_gpu_stats_t *st, bool need_hits, bool need_rows, bool alive);
   uint32_t update(const DeviceIndexView &v, const FrontierRec *fr, LevelBufs &L, uint32_t n_queries,
                   const impg_gpu_params_t &p, DevBuf &next_frontier);
   VisitedTables tables_view() const;
@@ -105,8 +131,44 @@ struct Engine {
            impg_gpu_stats_t *st, DevBuf *self_out);
 };
 
+// owner: null = one shard holds everything; else owner[target id] = the shard that holds the target's entries
 void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops,
                  size_t n_ops, const int64_t *seq_len, uint32_t n_seq, bool bidirectional, int order_policy,
-                 uint32_t shard, uint32_t n_shards);
+                 uint32_t shard, uint32_t n_shards, const uint32_t *owner);
+
+struct EngineLease {  // an engine of the index for the duration of one call (capi.cpp)
+  impg_gpu_index &ix;
+  Engine *e = nullptr;
+  explicit EngineLease(impg_gpu_index &ix);
+  ~EngineLease();
+  EngineLease(const EngineLease &) = delete;
+  Engine &operator*() { return *e; }
+  Engine *operator->() { return e; }
+};
+
+// ---- shared by capi.cpp and sharded.cpp --------------------------------------------------------------
+void require_device(int device);
+std::unique_ptr<impg_gpu_index> make_index(const impg_gpu_record_t *records, size_t n_records, const uint32_t *ops,
+                                           size_t n_ops, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
+                                           int order_policy, int device, uint32_t shard, uint32_t n_shards,
+                                           const HostSeqIndex *seq, const std::vector<uint64_t> *file_first,
+                                           const uint32_t *owner);
+void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p,
+                      std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, impg_gpu_results &res);
+void append_results(impg_gpu_results &res, impg_gpu_results &part);  // part's rows behind res's (chunks, ranks)
+void check_ranges(const impg_gpu_range_t *ranges, size_t n);
+// masked_regions / subset filter of a batch -> an engine's device tables (cleared when the engine's lease ends)
+void apply_mask(Engine &E, const impg_gpu_index &ix, const impg_gpu_mask_t *m, const impg_gpu_params_t &p);
+void apply_subset(Engine &E, const impg_gpu_index &ix, const uint8_t *subset_keep);
+// entry points of sharded.cpp behind the public query calls
+int sharded_query_batch(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t &p,
+                        const impg_gpu_mask_t *mask, const uint8_t *subset_keep, impg_gpu_results **out);
+int sharded_query_stats(impg_gpu_index &ix, const impg_gpu_range_t *ranges, bool on_device, size_t n,
+                        const impg_gpu_params_t &p, uint64_t *per_range_count, uint64_t *per_range_checksum,
+                        impg_gpu_stats_t *stats);
+// targets bin-packed onto shards by entry count: heaviest first onto the least loaded shard
+void shard_assign(const uint64_t *entries_per_target, uint32_t n_seq, uint32_t n_shards, uint32_t *owner);
+void count_entries_per_target(const impg_gpu_record_t *records, size_t n_records, uint32_t n_seq, bool bidirectional,
+                              std::vector<uint64_t> &cnt);
 
 }  // namespace impg

@@ -3,8 +3,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -204,7 +207,9 @@ inline uint32_t put_original_name(std::string &s, const std::string &name, bool 
 // ---- BED (bed.cpp) -----------------------------------------------------------
 size_t bed_merge(impg_gpu_interval_t *iv, size_t n, int32_t merge_distance, bool merge_strands);
 
-struct Engine;  // engine.hpp
+struct Engine;    // engine.hpp
+struct ShardCtx;  // sharded.cpp: this rank's part of an index sharded over GPUs
+struct Cluster;   // sharded.cpp: the ranks of an index sharded over the GPUs of this process
 
 }  // namespace impg
 
@@ -225,7 +230,17 @@ struct impg_gpu_index {
   bool multi_file = false;
   void bind_view(uint32_t n_seq, uint32_t sorted_order);  // view pointers from the device arrays
   size_t device_bytes = 0;
-  impg::Engine *engine = nullptr;  // scratch + streams (engine.cpp)
+  // engines (engine.cpp: stream + scratch + the visited sets of one batch in flight), handed out by EngineLease
+  std::vector<std::unique_ptr<impg::Engine>> engines;
+  std::vector<impg::Engine *> eng_free;
+  std::mutex eng_m;
+  std::condition_variable eng_cv;
+  int max_engines = 4;
+  uint64_t opt_pair_budget = 1ull << 28;  // impg_gpu_set_option values, applied to an engine when it is leased
+  uint32_t opt_chunk_ranges = 0, opt_locality_min = 4096;
+  impg::ShardCtx *shard = nullptr;    // set: this index is one rank's shard; queries are collective calls
+  impg::Cluster *cluster = nullptr;   // set: this handle fronts n_dev shards in this process (no arrays of its own)
+  impg_gpu_index();
   ~impg_gpu_index();
 };
 

@@ -132,7 +132,7 @@ void parallel_chunks(size_t n, const std::function<void(size_t, size_t)> &f) {
 
 void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops,
                  size_t n_ops, const int64_t *seq_len, uint32_t n_seq, bool bidirectional, int order_policy,
-                 uint32_t shard, uint32_t n_shards) {
+                 uint32_t shard, uint32_t n_shards, const uint32_t *owner) {
   if (n_shards == 0 || shard >= n_shards) throw Error{IMPG_E_INVALID, "bad shard"};
   if (order_policy != IMPG_ORDER_COITREES && order_policy != IMPG_ORDER_SORTED)
     throw Error{IMPG_E_INVALID, "bad order policy"};
@@ -141,7 +141,8 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   if (ix.seq.lens.empty()) ix.seq.lens.assign(seq_len, seq_len + n_seq);
 
   // ---- validate, decide which records this shard needs -----------------------
-  auto owned = [&](uint32_t key) { return key % n_shards == shard; };
+  if (n_shards > 1 && !owner) throw Error{IMPG_E_INVALID, "a sharded index needs its shard map"};
+  auto owned = [&](uint32_t key) { return n_shards == 1 || owner[key] == shard; };
   std::vector<uint8_t> need(n_records, 0);
   std::vector<uint32_t> seg_count(n_seq + 1, 0);
   for (size_t i = 0; i < n_records; i++) {

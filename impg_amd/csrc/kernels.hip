@@ -330,23 +330,6 @@ __global__ __launch_bounds__(256) void reorder_runs_kernel(const uint32_t *__res
     run_len[f] = e - i;
   }
 }
-template <int WORDS>
-__global__ __launch_bounds__(256) void reorder_scatter_kernel(const uint4 *__restrict__ hits, uint32_t n, uint32_t n_front,
-                                                              const uint32_t *__restrict__ run_start,
-                                                              const uint32_t *__restrict__ off, uint4 *__restrict__ out) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  constexpr int Q = WORDS / 4;
-  uint4 r[Q];
-#pragma unroll
-  for (int k = 0; k < Q; k++) r[k] = hits[(size_t)i * Q + k];
-  const uint32_t f = r[0].x;
-  if (f >= n_front) return;
-  const size_t d = (size_t)off[f] + (i - run_start[f]);
-#pragma unroll
-  for (int k = 0; k < Q; k++) out[d * Q + k] = r[k];
-}
-
 // Lookup / projection order: ranges sorted by where their window will be in the entry array,
 // estimated before any search from the record alone: segment start + start / sequence length x
 // segment size (alignments spread evenly enough for a LOCALITY key; exactness is not needed).
@@ -1621,49 +1604,6 @@ __global__ __launch_bounds__(256) void ranges_to_frontier_kernel(const impg_gpu_
   out[q] = f;
 }
 
-// AoS hits for the stage API
-__global__ __launch_bounds__(256) void hits_to_aos_kernel(const uint32_t *__restrict__ pair_range,
-                                                          const uint32_t *__restrict__ pair_off, uint32_t n_pairs,
-                                                          HitArrays h, impg_gpu_hit_t *__restrict__ out) {
-  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= n_pairs) return;
-  impg_gpu_hit_t x;
-  x.fidx = pair_range[p];
-  x.query_id = h.qid[p];
-  const bool okk = x.query_id != HIT_NONE;
-  const int4 hc = okk ? h.c[p] : make_int4(0, 0, 0, 0);
-  x.q_first = hc.x;
-  x.q_last = hc.y;
-  x.t_first = hc.z;
-  x.t_last = hc.w;
-  x.order = p - pair_off[x.fidx];
-  x.pad = 0;
-  out[p] = x;
-}
-
-__global__ __launch_bounds__(256) void hits_to_aos16_kernel(const uint32_t *__restrict__ pair_range, uint32_t n_pairs, HitArrays h,
-                                                            impg_gpu_hit16_t *__restrict__ out) {
-  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= n_pairs) return;
-  impg_gpu_hit16_t x;
-  x.fidx = pair_range[p];
-  x.query_id = h.qid[p];
-  const bool okk = x.query_id != HIT_NONE;
-  const int4 hc = okk ? h.c[p] : make_int4(0, 0, 0, 0);
-  x.q_first = hc.x;
-  x.q_last = hc.y;
-  out[p] = x;
-}
-__global__ __launch_bounds__(256) void aos16_to_hits_kernel(const impg_gpu_hit16_t *__restrict__ in, uint32_t n,
-                                                            uint32_t *__restrict__ pair_range, HitArrays h) {
-  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= n) return;
-  const impg_gpu_hit16_t x = in[p];
-  pair_range[p] = x.fidx;
-  h.qid[p] = x.query_id;
-  h.c[p] = make_int4(x.q_first, x.q_last, 0, 0);
-}
-
 // ---------------------------------------------------------------------------
 // MultiImpg::query_all_indices (multi_impg.rs:556-592): the hits of one step are
 // merged over the per-file indices, hits equal to the self interval are dropped,
@@ -1931,16 +1871,6 @@ __global__ __launch_bounds__(256) void compact_copy_kernel(VisitedTables vt, con
   for (uint32_t i = 0; i < l; i++) out[i] = in[i];
 }
 
-__global__ __launch_bounds__(256) void aos_to_hits_kernel(const impg_gpu_hit_t *__restrict__ in, uint32_t n,
-                                                          uint32_t *__restrict__ pair_range, HitArrays h) {
-  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= n) return;
-  const impg_gpu_hit_t x = in[p];
-  pair_range[p] = x.fidx;
-  h.qid[p] = x.query_id;
-  h.c[p] = make_int4(x.q_first, x.q_last, x.t_first, x.t_last);
-}
-
 // ---------------------------------------------------------------------------
 // Hits between ranks (sharded.cpp).  An owner packs the slots of its expansion into AoS records addressed to the
 // record's HOME: word 0 = the home's frontier index (the qidx the routed record carried), then query id and the
@@ -2037,12 +1967,6 @@ void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n
 void launch_reorder_runs(const uint32_t *hits, uint32_t n, uint32_t words, uint32_t n_front, uint32_t *run_start,
                          uint32_t *run_len, uint32_t *err, hipStream_t s) {
   if (n) reorder_runs_kernel<<<cdiv(n, 256), 256, 0, s>>>(hits, n, words, n_front, run_start, run_len, err);
-}
-void launch_reorder_scatter(const void *hits, uint32_t n, uint32_t words, uint32_t n_front, const uint32_t *run_start,
-                            const uint32_t *off, void *out, hipStream_t s) {
-  if (!n) return;
-  if (words == 4) reorder_scatter_kernel<4><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)hits, n, n_front, run_start, off, (uint4 *)out);
-  else reorder_scatter_kernel<8><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)hits, n, n_front, run_start, off, (uint4 *)out);
 }
 void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s) {
   if (n) order_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, key, idx);
@@ -2167,12 +2091,6 @@ void launch_ranges_to_frontier(const impg_gpu_range_t *ranges, uint32_t n, Front
   if (!n) return;
   ranges_to_frontier_kernel<<<cdiv(n, 256), 256, 0, s>>>(ranges, n, out);
 }
-void launch_hits_to_aos(const uint32_t *pair_range, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
-                        impg_gpu_hit_t *out, hipStream_t s) {
-  if (!n_pairs) return;
-  hits_to_aos_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(pair_range, pair_off, n_pairs, h, out);
-}
-
 void launch_frontier_to_stack(const FrontierRec *fr, uint32_t n, const uint32_t *pop_depth, bool use_depth,
                               unsigned long long *key, int32_t *st, int32_t *en, uint32_t *depth, hipStream_t s) {
   if (!n) return;
@@ -2263,12 +2181,6 @@ void launch_compact_copy(const VisitedTables &vt, const unsigned long long *src,
                          uint32_t n, int2 *ranges_out, hipStream_t s) {
   if (n) compact_copy_kernel<<<cdiv(n, 256), 256, 0, s>>>(vt, src, off, len, n, ranges_out);
 }
-void launch_hits_to_aos16(const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, impg_gpu_hit16_t *out, hipStream_t s) {
-  if (n_pairs) hits_to_aos16_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(pair_range, n_pairs, h, out);
-}
-void launch_aos16_to_hits(const impg_gpu_hit16_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s) {
-  if (n) aos16_to_hits_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, n, pair_range, h);
-}
 void launch_hits_pack(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, const uint32_t *pair_entry,
                       const uint32_t *mrank, uint32_t words, void *out, hipStream_t s) {
   if (!n_pairs) return;
@@ -2281,9 +2193,4 @@ void launch_hits_unpack(const void *in, uint32_t n, uint32_t words, uint32_t n_f
   if (words == 4) hits_unpack_kernel<4><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, n_front, run_start, off, pair_range, h, mslot);
   else hits_unpack_kernel<8><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, n_front, run_start, off, pair_range, h, mslot);
 }
-void launch_aos_to_hits(const impg_gpu_hit_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s) {
-  if (!n) return;
-  aos_to_hits_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, n, pair_range, h);
-}
-
 }  // namespace impg

@@ -8,7 +8,13 @@
 
 namespace impg {
 
-typedef impg_gpu_frontier_t FrontierRec;  // {target_id, start, end, qidx}, 16 B
+// A frontier record: query `qidx` of the batch wants [start, end) of target_id looked up.  16 B; also what travels
+// between ranks of a sharded index (qidx then carries the record's index in its home frontier).
+struct FrontierRec {
+  uint32_t target_id;
+  int32_t start, end;
+  uint32_t qidx;
+};
 
 // one level's hits, SoA, indexed by pair slot (slot order = frontier order x visit order)
 struct HitArrays {  // one level's hit slots: the query id (0xFFFFFFFF = no hit) and {q_first, q_last, t_first, t_last}
@@ -68,8 +74,6 @@ void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n
 // stable order of hit records (words u32 each, fidx first) by fidx when equal fidx are already contiguous
 void launch_reorder_runs(const uint32_t *hits, uint32_t n, uint32_t words, uint32_t n_front, uint32_t *run_start,
                          uint32_t *run_len, uint32_t *err, hipStream_t s);
-void launch_reorder_scatter(const void *hits, uint32_t n, uint32_t words, uint32_t n_front, const uint32_t *run_start,
-                            const uint32_t *off, void *out, hipStream_t s);
 void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s);
 void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, uint32_t *out, hipStream_t s);
 void launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, unsigned long long *d_bsum,
@@ -126,8 +130,6 @@ void launch_visited_init(const impg_gpu_range_t *ranges, uint32_t n, const int32
 void launch_compact_frontier(const FrontierRec *in, const uint32_t *flag, const uint32_t *pos, uint32_t n,
                              FrontierRec *out, hipStream_t s);
 void launch_ranges_to_frontier(const impg_gpu_range_t *ranges, uint32_t n, FrontierRec *out, hipStream_t s);
-void launch_hits_to_aos(const uint32_t *pair_range, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
-                        impg_gpu_hit_t *out, hipStream_t s);
 
 void launch_frontier_to_stack(const FrontierRec *fr, uint32_t n, const uint32_t *pop_depth, bool use_depth,
                               unsigned long long *key, int32_t *st, int32_t *en, uint32_t *depth, hipStream_t s);
@@ -163,8 +165,5 @@ void launch_compact_select(const VisitedTables &vt, const unsigned long long *sk
                            unsigned long long *src_out, uint32_t *len_out, hipStream_t s);
 void launch_compact_copy(const VisitedTables &vt, const unsigned long long *src, const uint32_t *off, const uint32_t *len,
                          uint32_t n, int2 *ranges_out, hipStream_t s);
-void launch_aos_to_hits(const impg_gpu_hit_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s);
-void launch_hits_to_aos16(const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, impg_gpu_hit16_t *out, hipStream_t s);
-void launch_aos16_to_hits(const impg_gpu_hit16_t *in, uint32_t n, uint32_t *pair_range, HitArrays h, hipStream_t s);
 
 }  // namespace impg

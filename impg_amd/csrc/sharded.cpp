@@ -1,0 +1,793 @@
+// The index sharded over GPUs: entries live with the rank that owns their target
+// sequence (targets bin-packed by entry count), every query lives with its HOME rank (the rank that
+// submitted it: visited sets, DFS stacks, result order), and each hop of the walk sends the frontier
+// records to the owners of their targets and brings the hits home:
+//
+//   home   route: stable partition of the frontier by owner (one short radix sort); the record's home
+//          index rides along in place of qidx
+//          all-gather of the bucket sizes (+ one liveness word per rank: termination costs no extra round)
+//          all-to-all-v of 16-byte frontier records
+//   owner  lookup + projection of what arrived, on its shard, in slices under the pair budget
+//          (Engine::expand, the same kernels as on one GPU); slots packed into 16- or 32-byte records
+//          addressed to the record's home
+//          all-gather of the per-home counts, all-to-all-v of the hit records
+//   home   blocks arrive per owner, each ascending in the home index; a frontier record has exactly one
+//          owner, so a counting pass puts them back in frontier order x visit order; unpacked into the
+//          slot arrays a local expansion would have filled -- from there the single-GPU code runs unchanged
+//          (visited update, DFS / MultiImpg worklists, masks, subset filter, result assembly)
+//
+// The transport is a Comm (comm.hpp): threads + peer copies inside one process, RCCL between processes, or
+// host callbacks.  Several chunks of a batch are in flight at once, one per LANE (engine + communicator +
+// host thread): while one lane waits for an exchange the others keep the GPU busy.
+// The north-star text says "allgatherv of the frontier"; all-to-all-v moves 1/world of that volume over the
+// point-to-point xGMI links, and is what is built (the all-gather carries the counts).
+#include <algorithm>
+#include <chrono>
+#include <exception>
+#include <numeric>
+#include <thread>
+
+#include "comm.hpp"
+#include "engine.hpp"
+
+namespace impg {
+
+// ---- shard map ------------------------------------------------------------------------------
+void count_entries_per_target(const impg_gpu_record_t *records, size_t n_records, uint32_t n_seq, bool bidirectional,
+                              std::vector<uint64_t> &cnt) {
+  cnt.assign(n_seq, 0);
+  for (size_t i = 0; i < n_records; i++) {
+    const auto &r = records[i];
+    if (r.query_id >= n_seq || r.target_id >= n_seq) throw Error{IMPG_E_INVALID, "record sequence id out of range"};
+    cnt[r.target_id]++;
+    if (bidirectional && r.query_id != r.target_id) cnt[r.query_id]++;  // the reversed entry (impg.rs:1584)
+  }
+}
+void shard_assign(const uint64_t *c, uint32_t n_seq, uint32_t n_shards, uint32_t *owner) {
+  if (n_shards == 0) throw Error{IMPG_E_INVALID, "no shards"};
+  std::vector<uint32_t> order(n_seq);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c[a] > c[b]; });
+  std::vector<uint64_t> load(n_shards, 0);
+  for (uint32_t t : order) {
+    if (c[t] == 0) { owner[t] = t % n_shards; continue; }  // no entries anywhere: any rank answers "no hits"
+    uint32_t best = 0;
+    for (uint32_t k = 1; k < n_shards; k++)
+      if (load[k] < load[best]) best = k;
+    owner[t] = best;
+    load[best] += c[t];
+  }
+}
+
+// ---- one hop ---------------------------------------------------------------------------------
+struct ShardedExpander : Expander {
+  Comm *comm = nullptr;
+  const uint32_t *d_owner = nullptr;
+  uint32_t n_seq = 0;
+  DevBuf send_fr, recv_fr, hits_out, hits_in, mslot, iota, route_hist;
+  LevelBufs owner_L;
+  uint32_t *h_vals = nullptr;  // pinned: slot offsets at block boundaries
+  size_t h_cap = 0;
+  double exchange_s = 0;  // wall time inside the transport, accumulated
+  uint64_t bytes_out = 0;
+
+  ~ShardedExpander() override {
+    if (h_vals) (void)hipHostFree(h_vals);
+  }
+
+  void route(Engine &E, const FrontierRec *fr, uint32_t n, uint64_t *counts) {
+    const uint32_t W = (uint32_t)comm->world;
+    hipStream_t s = E.stream;
+    const size_t nb = std::max<size_t>((size_t)n * 4, 256);
+    E.lo_key.reserve(nb); E.lo_key2.reserve(nb); E.lo_idx.reserve(nb); E.lo_perm.reserve(nb);
+    route_hist.reserve(std::max<size_t>((size_t)W * 8, 256));
+    IMPG_HIP(hipMemsetAsync(route_hist.p, 0, (size_t)W * 8, s));
+    launch_route_keys(fr, n, W, d_owner, n_seq, E.lo_key.as<uint32_t>(), E.lo_idx.as<uint32_t>(),
+                      route_hist.as<unsigned long long>(), s);
+    if (W > 1) {
+      unsigned bits = 1;
+      while ((1u << bits) < W) bits++;
+      const size_t tb = sort_u32_scratch_bytes(n);
+      E.sort_tmp.reserve(tb);
+      launch_sort_u32(E.sort_tmp.p, tb, E.lo_key.as<uint32_t>(), E.lo_key2.as<uint32_t>(), E.lo_idx.as<uint32_t>(),
+                      E.lo_perm.as<uint32_t>(), n, s, 0, bits);  // stable: frontier order within an owner
+      launch_route_gather(fr, E.lo_perm.as<uint32_t>(), n, send_fr.as<FrontierRec>(), s);
+    } else {
+      launch_route_gather(fr, E.lo_idx.as<uint32_t>(), n, send_fr.as<FrontierRec>(), s);
+    }
+    std::vector<unsigned long long> h(W);
+    IMPG_HIP(hipMemcpyAsync(h.data(), route_hist.p, (size_t)W * 8, hipMemcpyDeviceToHost, s));
+    IMPG_HIP(hipStreamSynchronize(s));
+    for (uint32_t k = 0; k < W; k++) counts[k] = h[k];
+  }
+
+  template <class F> void timed_comm(F f) {
+    const auto t0 = std::chrono::steady_clock::now();
+    f();
+    exchange_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+
+  HopResult hop(Engine &E, const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
+                impg_gpu_stats_t *st, bool need_hits, bool need_rows, bool alive) override {
+    if (E.store_cigar)
+      throw Error{IMPG_E_UNSUPPORTED, "store_cigar is not available on an index sharded over GPUs (CIGAR slices stay with their owner)"};
+    const int W = comm->world, me = comm->rank;
+    hipStream_t s = E.stream;
+    const size_t K = (size_t)W + 1;
+    std::vector<uint64_t> mine(K, 0), mat(K * W);
+    L.n_pairs = 0;
+    // ---- home: the frontier bucketed by owner; sizes and liveness to everybody
+    send_fr.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
+    if (n_fr) route(E, fr, n_fr, mine.data());
+    mine[W] = alive ? 1 : 0;
+    timed_comm([&] { comm->allgather_u64(mine.data(), K, mat.data()); });
+    bool any = false;
+    for (int r = 0; r < W; r++) any = any || mat[(size_t)r * K + W] != 0;
+    if (!any) return HopResult{0, true};
+    // ---- frontier records to the owners of their targets
+    std::vector<uint64_t> so(W), sb(W), ro(W), rb(W), rstart(W + 1);
+    uint64_t acc = 0, n_recv = 0;
+    for (int d = 0; d < W; d++) { so[d] = acc * sizeof(FrontierRec); sb[d] = mine[d] * sizeof(FrontierRec); acc += mine[d]; }
+    for (int r = 0; r < W; r++) {
+      const uint64_t c = mat[(size_t)r * K + me];
+      rstart[r] = n_recv; ro[r] = n_recv * sizeof(FrontierRec); rb[r] = c * sizeof(FrontierRec);
+      n_recv += c;
+    }
+    rstart[W] = n_recv;
+    if (n_recv >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 frontier records for one shard in one hop"};
+    recv_fr.reserve(std::max<size_t>(n_recv * sizeof(FrontierRec), 256));
+    timed_comm([&] { comm->alltoallv(send_fr.p, so.data(), sb.data(), recv_fr.p, ro.data(), rb.data(), s); });
+    bytes_out += acc * sizeof(FrontierRec);
+    // ---- owner: expand what arrived, in slices under the pair budget
+    const uint32_t words = (need_rows || E.multi) ? 8u : 4u;
+    std::vector<uint64_t> back(W, 0);
+    struct Piece { std::unique_ptr<DevBuf> buf; uint64_t n; };
+    std::vector<Piece> pieces;
+    uint64_t total_pairs = 0, total_hits = 0;
+    const bool saved_split = E.split_ok;
+    if ((size_t)(W + 1) * 4 > h_cap) {
+      if (h_vals) (void)hipHostFree(h_vals);
+      h_cap = std::max<size_t>((size_t)(W + 1) * 4, 4096);
+      IMPG_HIP(hipHostMalloc((void **)&h_vals, h_cap, hipHostMallocDefault));
+    }
+    uint64_t a = 0, step = std::max<uint64_t>(n_recv, 1);
+    while (a < n_recv) {
+      const uint64_t m = std::min(step, n_recv - a);
+      E.split_ok = m > 1;
+      uint64_t P = 0;
+      const FrontierRec *sub = recv_fr.as<FrontierRec>() + a;
+      try {
+        P = E.expand(v, sub, (uint32_t)m, transitive, owner_L, st, /*raw=*/true);
+      } catch (const SplitBatch &) {
+        step = std::max<uint64_t>(1, m / 2);
+        continue;
+      }
+      total_pairs += P;
+      if (need_hits && P) {
+        // slots per home rank: the records of one home are one contiguous run of `sub`
+        std::vector<std::pair<int, std::pair<uint64_t, uint64_t>>> runs;  // (home, [lo, hi) relative to a)
+        size_t nread = 0;
+        for (int r = 0; r < W; r++) {
+          const uint64_t lo = std::max(a, rstart[r]), hi = std::min(a + m, rstart[r + 1]);
+          if (lo >= hi) continue;
+          runs.push_back({r, {lo - a, hi - a}});
+          IMPG_HIP(hipMemcpyAsync(h_vals + nread, E.pair_off.as<uint32_t>() + (lo - a), 4, hipMemcpyDeviceToHost, s));
+          nread++;
+        }
+        Piece pc{std::make_unique<DevBuf>(), P};
+        pc.buf->reserve(std::max<size_t>(P * words * 4, 256));
+        HitArrays h{owner_L.qid.as<uint32_t>(), owner_L.coords.as<int4>()};
+        launch_hits_pack(sub, owner_L.pair_range.as<uint32_t>(), (uint32_t)P, h, E.multi ? E.pair_entry.as<uint32_t>() : nullptr,
+                         E.multi ? v.mrank : nullptr, words, pc.buf->p, s);
+        IMPG_HIP(hipStreamSynchronize(s));
+        for (size_t k = 0; k < runs.size(); k++) {
+          const uint64_t first = h_vals[k], end = k + 1 < runs.size() ? h_vals[k + 1] : P;
+          back[runs[k].first] += end - first;
+        }
+        total_hits += P;
+        pieces.push_back(std::move(pc));
+      }
+      a += m;
+    }
+    E.split_ok = saved_split;
+    if (!need_hits) return HopResult{total_pairs, false};
+    if (total_hits >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 hits leave one shard in one hop"};
+    const void *out_ptr = nullptr;
+    if (pieces.size() == 1) {
+      out_ptr = pieces[0].buf->p;
+    } else {
+      hits_out.reserve(std::max<size_t>(total_hits * words * 4, 256));
+      uint64_t pos = 0;
+      for (auto &pc : pieces) {
+        IMPG_HIP(hipMemcpyAsync((char *)hits_out.p + pos * words * 4, pc.buf->p, pc.n * words * 4, hipMemcpyDeviceToDevice, s));
+        pos += pc.n;
+      }
+      out_ptr = hits_out.p;
+    }
+    // ---- hits go home
+    std::vector<uint64_t> mat2((size_t)W * W);
+    timed_comm([&] { comm->allgather_u64(back.data(), W, mat2.data()); });
+    uint64_t n_home = 0;
+    acc = 0;
+    const uint64_t rec = (uint64_t)words * 4;
+    for (int d = 0; d < W; d++) { so[d] = acc * rec; sb[d] = back[d] * rec; acc += back[d]; }
+    for (int o = 0; o < W; o++) {
+      const uint64_t c = mat2[(size_t)o * W + me];
+      ro[o] = n_home * rec; rb[o] = c * rec;
+      n_home += c;
+    }
+    if (n_home >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 hits come home in one hop: use smaller chunks (chunk_ranges)"};
+    hits_in.reserve(std::max<size_t>(n_home * rec, 256));
+    timed_comm([&] { comm->alltoallv(out_ptr, so.data(), sb.data(), hits_in.p, ro.data(), rb.data(), s); });
+    bytes_out += acc * rec;
+    pieces.clear();
+    // ---- home: back into frontier order x visit order, into the slot arrays
+    L.n_pairs = (uint32_t)n_home;
+    const size_t b = std::max<size_t>((size_t)n_home * 4, 256);
+    L.pair_range.reserve(b); L.qid.reserve(b); L.coords.reserve(4 * b);
+    HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
+    const bool need_order = W > 1 || E.multi;
+    if (E.multi) mslot.reserve(b);
+    if (n_home) {
+      if (need_order) {
+        const size_t fb = std::max<size_t>((size_t)n_fr * 4, 256);
+        E.lo_key.reserve(fb); E.lo_cnt.reserve(fb); E.lo_off.reserve(fb);
+        IMPG_HIP(hipMemsetAsync(E.lo_cnt.p, 0, fb, s));
+        IMPG_HIP(hipMemsetAsync(E.counters.as<unsigned long long>() + 4, 0, 8, s));
+        uint32_t *err = reinterpret_cast<uint32_t *>(E.counters.as<unsigned long long>() + 4);
+        launch_reorder_runs(hits_in.as<uint32_t>(), (uint32_t)n_home, words, n_fr, E.lo_key.as<uint32_t>(), E.lo_cnt.as<uint32_t>(), err, s);
+        const uint64_t total = E.scan(E.lo_cnt.as<uint32_t>(), E.lo_off.as<uint32_t>(), n_fr);
+        uint32_t bad = 0;
+        IMPG_HIP(hipMemcpy(&bad, err, 4, hipMemcpyDeviceToHost));
+        if (bad || total != n_home) throw Error{IMPG_E_INVALID, "hits came home for a frontier record twice or out of range"};
+        launch_hits_unpack(hits_in.p, (uint32_t)n_home, words, n_fr, E.lo_key.as<uint32_t>(), E.lo_off.as<uint32_t>(),
+                           L.pair_range.as<uint32_t>(), h, E.multi ? mslot.as<uint32_t>() : nullptr, s);
+      } else {
+        launch_hits_unpack(hits_in.p, (uint32_t)n_home, words, n_fr, nullptr, nullptr, L.pair_range.as<uint32_t>(), h, nullptr, s);
+      }
+      if (E.multi) {
+        iota.reserve(b);
+        launch_iota(iota.as<uint32_t>(), (uint32_t)n_home, s);
+      }
+      E.post_expand(fr, n_fr, L, E.lo_off.as<uint32_t>(), iota.as<uint32_t>(), mslot.as<uint32_t>(),
+                    SliceArrays{nullptr, nullptr, nullptr, nullptr});
+    }
+    return HopResult{total_pairs, false};
+  }
+};
+
+struct ShardCtx {
+  impg_gpu_comm *comm = nullptr;  // borrowed (the host's, or the cluster's)
+  std::vector<uint32_t> owner;
+  DevBuf d_owner;
+  std::vector<std::unique_ptr<ShardedExpander>> lanes;
+};
+struct Cluster {
+  std::vector<std::unique_ptr<impg_gpu_comm>> comms;   // declared first: destroyed last
+  std::vector<std::unique_ptr<impg_gpu_index>> ranks;
+};
+
+}  // namespace impg
+
+impg_gpu_index::impg_gpu_index() {}
+impg_gpu_index::~impg_gpu_index() {
+  delete cluster;
+  delete shard;
+}
+
+namespace impg {
+namespace {
+
+void attach_shard(impg_gpu_index &ix, impg_gpu_comm *comm, const std::vector<uint32_t> &owner) {
+  auto S = std::make_unique<ShardCtx>();
+  S->comm = comm;
+  S->owner = owner;
+  IMPG_HIP(hipSetDevice(ix.device));
+  S->d_owner.reserve(std::max<size_t>(owner.size() * 4, 256));
+  if (!owner.empty()) IMPG_HIP(hipMemcpy(S->d_owner.p, owner.data(), owner.size() * 4, hipMemcpyHostToDevice));
+  for (size_t l = 0; l < comm->lanes.size(); l++) {
+    auto x = std::make_unique<ShardedExpander>();
+    x->comm = comm->lanes[l].get();
+    x->d_owner = S->d_owner.as<uint32_t>();
+    x->n_seq = (uint32_t)owner.size();
+    S->lanes.push_back(std::move(x));
+  }
+  ix.max_engines = std::max<int>(ix.max_engines, (int)comm->lanes.size());
+  ix.shard = S.release();
+}
+
+struct LaneWork {  // what one lane accumulates
+  impg_gpu_stats_t st;
+  std::exception_ptr err;
+};
+
+// Runs body(lane, engine, chunk_begin, chunk_end) for every chunk of this rank's ranges, chunks dealt to the
+// lanes round-robin; every rank runs the same number of chunks (ranks with fewer ranges run empty ones).
+template <class F> void run_lanes(impg_gpu_index &ix, size_t n, F body) {
+  ShardCtx &S = *ix.shard;
+  const size_t chunk = ix.opt_chunk_ranges ? ix.opt_chunk_ranges : std::max<size_t>(n, 1);
+  uint64_t my_chunks = std::max<uint64_t>(1, (n + chunk - 1) / chunk);
+  std::vector<uint64_t> all(S.comm->world);
+  S.comm->lanes[0]->allgather_u64(&my_chunks, 1, all.data());
+  const uint64_t n_chunks = *std::max_element(all.begin(), all.end());
+  const size_t n_lanes = std::min<uint64_t>(S.comm->lanes.size(), n_chunks);
+  std::vector<std::exception_ptr> errs(n_lanes);
+  auto lane_main = [&](size_t l) {
+    try {
+      IMPG_HIP(hipSetDevice(ix.device));
+      EngineLease lease(ix);
+      Engine &E = *lease;
+      E.remote = S.lanes[l].get();
+      for (uint64_t c = l; c < n_chunks; c += n_lanes) {
+        const size_t b = std::min<size_t>(n, c * chunk), e = std::min<size_t>(n, b + chunk);
+        body(l, E, b, e);
+      }
+    } catch (...) {
+      errs[l] = std::current_exception();
+      for (auto &c : S.comm->lanes) c->abort();  // peers waiting for this rank are released with an error
+    }
+  };
+  if (n_lanes == 1) lane_main(0);
+  else {
+    std::vector<std::thread> th;
+    for (size_t l = 0; l < n_lanes; l++) th.emplace_back(lane_main, l);
+    for (auto &t : th) t.join();
+  }
+  for (auto &e : errs)
+    if (e) std::rethrow_exception(e);
+}
+
+void add_stats(impg_gpu_stats_t &tot, const impg_gpu_stats_t &st) {
+  tot.projected += st.projected; tot.pairs += st.pairs; tot.frontier_ranges += st.frontier_ranges;
+  tot.levels = std::max(tot.levels, st.levels);
+  tot.ms_total += st.ms_total; tot.ms_lookup += st.ms_lookup; tot.ms_project += st.ms_project; tot.ms_update += st.ms_update;
+  tot.project_launches += st.project_launches;
+  tot.ms_exchange += st.ms_exchange;
+}
+
+// one rank's part of a collective counting batch
+void rank_stats(impg_gpu_index &ix, const impg_gpu_range_t *ranges, bool on_device, size_t n, const impg_gpu_params_t &p,
+                uint64_t *per_range_count, uint64_t *per_range_checksum, impg_gpu_stats_t *stats) {
+  IMPG_HIP(hipSetDevice(ix.device));
+  DevBuf d_ranges, d_cnt, d_ck;
+  const impg_gpu_range_t *dr = ranges;
+  if (!on_device) {
+    check_ranges(ranges, n);
+    d_ranges.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
+    if (n) IMPG_HIP(hipMemcpy(d_ranges.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice));
+    dr = d_ranges.as<impg_gpu_range_t>();
+  }
+  unsigned long long *dc = nullptr, *dk = nullptr;
+  if (per_range_count) {
+    d_cnt.reserve(std::max<size_t>(n * 8, 256));
+    IMPG_HIP(hipMemset(d_cnt.p, 0, std::max<size_t>(n * 8, 8)));
+    dc = d_cnt.as<unsigned long long>();
+  }
+  if (per_range_checksum) {
+    d_ck.reserve(std::max<size_t>(n * 8, 256));
+    IMPG_HIP(hipMemset(d_ck.p, 0, std::max<size_t>(n * 8, 8)));
+    dk = d_ck.as<unsigned long long>();
+  }
+  ShardCtx &S = *ix.shard;
+  std::vector<impg_gpu_stats_t> per_lane(S.comm->lanes.size());
+  for (auto &x : per_lane) memset(&x, 0, sizeof x);
+  for (auto &x : S.lanes) x->exchange_s = 0;
+  run_lanes(ix, n, [&](size_t l, Engine &E, size_t b, size_t e) {
+    impg_gpu_stats_t st;
+    E.run(ix, dr + b, (uint32_t)(e - b), p, nullptr, dc ? dc + b : nullptr, dk ? dk + b : nullptr, &st, nullptr);
+    add_stats(per_lane[l], st);
+  });
+  impg_gpu_stats_t tot;
+  memset(&tot, 0, sizeof tot);
+  for (size_t l = 0; l < per_lane.size(); l++) {
+    per_lane[l].ms_exchange = (float)(S.lanes[l]->exchange_s * 1e3);
+    add_stats(tot, per_lane[l]);
+  }
+  if (stats) *stats = tot;
+  if (per_range_count && n) IMPG_HIP(hipMemcpy(per_range_count, dc, n * 8, hipMemcpyDeviceToHost));
+  if (per_range_checksum && n) IMPG_HIP(hipMemcpy(per_range_checksum, dk, n * 8, hipMemcpyDeviceToHost));
+}
+
+// one rank's part of a collective full-results batch
+void rank_query(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t &p,
+                const impg_gpu_mask_t *mask, const uint8_t *subset_keep, impg_gpu_results &res) {
+  IMPG_HIP(hipSetDevice(ix.device));
+  check_ranges(ranges, n);
+  DevBuf d_ranges;
+  d_ranges.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
+  if (n) IMPG_HIP(hipMemcpy(d_ranges.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice));
+  const size_t chunk = ix.opt_chunk_ranges ? ix.opt_chunk_ranges : std::max<size_t>(n, 1);
+  std::vector<std::unique_ptr<impg_gpu_results>> parts((n + chunk - 1) / chunk + 1);
+  std::vector<Engine *> prepared;
+  std::mutex pm;
+  run_lanes(ix, n, [&](size_t, Engine &E, size_t b, size_t e) {
+    {
+      std::lock_guard<std::mutex> lk(pm);
+      if (std::find(prepared.begin(), prepared.end(), &E) == prepared.end()) {
+        apply_mask(E, ix, mask, p);  // every lane's engine carries the batch's mask / filter
+        apply_subset(E, ix, subset_keep);
+        prepared.push_back(&E);
+      }
+    }
+    std::vector<std::unique_ptr<LevelBufs>> levels;
+    DevBuf self_dev;
+    const auto c0 = std::chrono::steady_clock::now();
+    E.run(ix, d_ranges.as<impg_gpu_range_t>() + b, (uint32_t)(e - b), p, &levels, nullptr, nullptr, nullptr, &self_dev);
+    const auto c1 = std::chrono::steady_clock::now();
+    if (e == b) return;  // an empty chunk: this rank only took part in the hops
+    auto part = std::make_unique<impg_gpu_results>();
+    assemble_results(E, ranges + b, (uint32_t)(e - b), p, levels, self_dev, *part);
+    part->run_s = std::chrono::duration<double>(c1 - c0).count();
+    part->assemble_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - c1).count();
+    parts[b / chunk] = std::move(part);
+  });
+  res.offsets.assign(1, 0);
+  for (auto &pt : parts)
+    if (pt) append_results(res, *pt);
+  res.ranges.assign(ranges, ranges + n);
+}
+
+// ranges of a multi-GPU handle are dealt to the ranks in contiguous blocks (results concatenate in order)
+void split_blocks(size_t n, size_t W, std::vector<size_t> &cut) {
+  cut.resize(W + 1);
+  for (size_t r = 0; r <= W; r++) cut[r] = n * r / W;
+}
+
+template <class F> void on_every_rank(Cluster &C, F f) {
+  const size_t W = C.ranks.size();
+  std::vector<std::exception_ptr> errs(W);
+  std::vector<std::thread> th;
+  for (auto &cm : C.comms)
+    for (auto &l : cm->lanes) l->reset();  // (a batch that failed left the fabric poisoned)
+  for (size_t r = 0; r < W; r++)
+    th.emplace_back([&, r] {
+      try {
+        f(r);
+      } catch (...) {
+        errs[r] = std::current_exception();
+        for (auto &c : C.comms[r]->lanes) c->abort();
+      }
+    });
+  for (auto &t : th) t.join();
+  // report the first real failure, not the "a peer rank failed" echoes it caused
+  std::exception_ptr first;
+  for (auto &e : errs) {
+    if (!e) continue;
+    try { std::rethrow_exception(e); }
+    catch (const Error &er) { if (er.msg != "a peer rank failed") { first = e; break; } if (!first) first = e; }
+    catch (...) { first = e; break; }
+  }
+  if (first) std::rethrow_exception(first);
+}
+
+}  // namespace
+
+int sharded_query_stats(impg_gpu_index &ix, const impg_gpu_range_t *ranges, bool on_device, size_t n,
+                        const impg_gpu_params_t &p, uint64_t *per_range_count, uint64_t *per_range_checksum,
+                        impg_gpu_stats_t *stats) {
+  if (!ix.cluster) {
+    rank_stats(ix, ranges, on_device, n, p, per_range_count, per_range_checksum, stats);
+    return IMPG_OK;
+  }
+  Cluster &C = *ix.cluster;
+  check_ranges(ranges, n);
+  const size_t W = C.ranks.size();
+  std::vector<size_t> cut;
+  split_blocks(n, W, cut);
+  std::vector<impg_gpu_stats_t> sts(W);
+  for (auto &r : C.ranks) { r->opt_chunk_ranges = ix.opt_chunk_ranges; r->opt_pair_budget = ix.opt_pair_budget; r->opt_locality_min = ix.opt_locality_min; }
+  on_every_rank(C, [&](size_t r) {
+    rank_stats(*C.ranks[r], ranges + cut[r], false, cut[r + 1] - cut[r], p, per_range_count ? per_range_count + cut[r] : nullptr,
+               per_range_checksum ? per_range_checksum + cut[r] : nullptr, &sts[r]);
+  });
+  if (stats) {
+    memset(stats, 0, sizeof *stats);
+    for (auto &s : sts) {  // work adds up; the ranks ran side by side, so time is the slowest rank's
+      stats->projected += s.projected; stats->pairs += s.pairs; stats->frontier_ranges += s.frontier_ranges;
+      stats->project_launches += s.project_launches;
+      stats->levels = std::max(stats->levels, s.levels);
+      stats->ms_total = std::max(stats->ms_total, s.ms_total); stats->ms_lookup = std::max(stats->ms_lookup, s.ms_lookup);
+      stats->ms_project = std::max(stats->ms_project, s.ms_project); stats->ms_update = std::max(stats->ms_update, s.ms_update);
+      stats->ms_exchange = std::max(stats->ms_exchange, s.ms_exchange);
+    }
+  }
+  return IMPG_OK;
+}
+
+int sharded_query_batch(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t &p,
+                        const impg_gpu_mask_t *mask, const uint8_t *subset_keep, impg_gpu_results **out) {
+  if (mask && !p.transitive) throw Error{IMPG_E_INVALID, "masked_regions belong to the transitive queries"};
+  auto res = std::make_unique<impg_gpu_results>();
+  if (!ix.cluster) {
+    rank_query(ix, ranges, n, p, mask, subset_keep, *res);
+    *out = res.release();
+    return IMPG_OK;
+  }
+  Cluster &C = *ix.cluster;
+  const size_t W = C.ranks.size();
+  std::vector<size_t> cut;
+  split_blocks(n, W, cut);
+  std::vector<impg_gpu_results> parts(W);
+  for (auto &r : C.ranks) { r->opt_chunk_ranges = ix.opt_chunk_ranges; r->opt_pair_budget = ix.opt_pair_budget; r->opt_locality_min = ix.opt_locality_min; }
+  on_every_rank(C, [&](size_t r) { rank_query(*C.ranks[r], ranges + cut[r], cut[r + 1] - cut[r], p, mask, subset_keep, parts[r]); });
+  res->offsets.assign(1, 0);
+  double run_s = 0, asm_s = 0;
+  for (auto &pt : parts) {
+    run_s = std::max(run_s, pt.run_s); asm_s = std::max(asm_s, pt.assemble_s);
+    append_results(*res, pt);
+  }
+  res->run_s = run_s; res->assemble_s = asm_s;
+  res->ranges.assign(ranges, ranges + n);
+  *out = res.release();
+  return IMPG_OK;
+}
+
+}  // namespace impg
+
+using namespace impg;
+
+#define IMPG_TRY try {
+#define IMPG_CATCH                                          \
+  }                                                         \
+  catch (const impg::Error &e) {                            \
+    impg::set_error(e.msg);                                 \
+    return e.code;                                          \
+  }                                                         \
+  catch (const std::bad_alloc &) {                          \
+    impg::set_error("host out of memory");                  \
+    return IMPG_E_OOM;                                      \
+  }                                                         \
+  catch (const std::exception &e) {                         \
+    impg::set_error(std::string("internal: ") + e.what());  \
+    return IMPG_E_INVALID;                                  \
+  }
+
+namespace {
+std::unique_ptr<impg_gpu_index> make_rank_index(const impg_gpu_record_t *records, size_t n_records, const uint32_t *ops, size_t n_ops,
+                                                const int64_t *seq_len, uint32_t n_seq, const std::vector<uint64_t> *file_first,
+                                                int bidirectional, int order_policy, int device, impg_gpu_comm *comm,
+                                                const HostSeqIndex *seq, const std::vector<uint32_t> &owner) {
+  auto ix = make_index(records, n_records, ops, n_ops, seq_len, n_seq, bidirectional, order_policy, device, (uint32_t)comm->rank,
+                       (uint32_t)comm->world, seq, file_first, owner.data());
+  attach_shard(*ix, comm, owner);
+  return ix;
+}
+std::vector<uint32_t> owner_map(const impg_gpu_record_t *records, size_t n_records, uint32_t n_seq, int bidirectional, int world) {
+  if ((!records && n_records)) throw Error{IMPG_E_INVALID, "null input array"};
+  std::vector<uint64_t> cnt;
+  count_entries_per_target(records, n_records, n_seq, bidirectional != 0, cnt);
+  std::vector<uint32_t> owner(n_seq);
+  shard_assign(cnt.data(), n_seq, (uint32_t)world, owner.data());
+  return owner;
+}
+void check_comm(const impg_gpu_comm *comm) {
+  if (!comm || comm->lanes.empty()) throw Error{IMPG_E_INVALID, "null communicator"};
+  if (comm->world < 1 || comm->world > (int)ROUTE_WORLD_MAX) throw Error{IMPG_E_INVALID, "world size out of range"};
+}
+
+std::unique_ptr<impg_gpu_index> make_cluster(const impg_gpu_record_t *records, size_t n_records, const uint32_t *ops, size_t n_ops,
+                                             const int64_t *seq_len, uint32_t n_seq, const std::vector<uint64_t> *file_first,
+                                             int bidirectional, int order_policy, const int *devices, int n_dev, int lanes,
+                                             const HostSeqIndex *seq) {
+  if (!devices || n_dev < 1 || n_dev > (int)ROUTE_WORLD_MAX) throw Error{IMPG_E_INVALID, "bad device list"};
+  if (lanes < 1 || lanes > 8) throw Error{IMPG_E_INVALID, "lanes must be 1..8"};
+  for (int r = 0; r < n_dev; r++) require_device(devices[r]);
+  const std::vector<uint32_t> owner = owner_map(records, n_records, n_seq, bidirectional, n_dev);
+  auto C = std::make_unique<Cluster>();
+  std::vector<std::shared_ptr<LocalFabric>> fabs;
+  for (int l = 0; l < lanes; l++) fabs.push_back(std::make_shared<LocalFabric>(n_dev));
+  for (int r = 0; r < n_dev; r++) {
+    auto cm = std::make_unique<impg_gpu_comm>();
+    cm->rank = r; cm->world = n_dev; cm->device = devices[r];
+    for (int l = 0; l < lanes; l++) cm->lanes.emplace_back(new LocalComm(fabs[l], r, devices[r]));
+    C->comms.push_back(std::move(cm));
+  }
+  // direct loads over xGMI between the shards' devices
+  for (int a = 0; a < n_dev; a++)
+    for (int b = 0; b < n_dev; b++) {
+      if (devices[a] == devices[b]) continue;
+      IMPG_HIP(hipSetDevice(devices[a]));
+      int can = 0;
+      (void)hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
+      if (can) {
+        hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      }
+    }
+  C->ranks.resize(n_dev);
+  std::vector<std::exception_ptr> errs(n_dev);
+  std::vector<std::thread> th;
+  for (int r = 0; r < n_dev; r++)
+    th.emplace_back([&, r] {
+      try {
+        C->ranks[r] = make_rank_index(records, n_records, ops, n_ops, seq_len, n_seq, file_first, bidirectional, order_policy,
+                                      devices[r], C->comms[r].get(), seq, owner);
+      } catch (...) { errs[r] = std::current_exception(); }
+    });
+  for (auto &t : th) t.join();
+  for (auto &e : errs)
+    if (e) std::rethrow_exception(e);
+  auto front = std::make_unique<impg_gpu_index>();
+  front->device = devices[0];
+  if (seq) front->seq = *seq;
+  else front->seq.lens.assign(seq_len, seq_len + n_seq);
+  front->n_records = n_records;
+  std::vector<uint64_t> cnt;
+  count_entries_per_target(records, n_records, n_seq, bidirectional != 0, cnt);
+  front->h_tgt_off.assign(n_seq + 1, 0);
+  for (uint32_t t = 0; t < n_seq; t++) {
+    front->h_tgt_off[t + 1] = (uint32_t)std::min<uint64_t>(front->h_tgt_off[t] + cnt[t], 0xFFFFFFFFull);
+    if (cnt[t]) front->n_targets++;
+    front->n_entries += cnt[t];
+  }
+  for (auto &r : C->ranks) front->device_bytes += r->device_bytes;
+  front->view.n_seq = n_seq;
+  front->cluster = C.release();
+  return front;
+}
+}  // namespace
+
+extern "C" {
+
+int impg_gpu_shard_assign(const uint64_t *entries_per_target, uint32_t n_seq, uint32_t n_shards, uint32_t *owner_out) {
+  IMPG_TRY
+  if ((n_seq && (!entries_per_target || !owner_out))) throw Error{IMPG_E_INVALID, "null argument"};
+  shard_assign(entries_per_target, n_seq, n_shards, owner_out);
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_comm_unique_id(uint8_t *ids, int lanes) {
+  IMPG_TRY
+  if (!ids || lanes < 1 || lanes > 8) throw Error{IMPG_E_INVALID, "bad arguments"};
+  for (int l = 0; l < lanes; l++) rccl_unique_id(ids + (size_t)l * IMPG_COMM_ID_BYTES);
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_comm_create_rccl(const uint8_t *ids, int lanes, int rank, int world, int device, impg_gpu_comm_t **out) {
+  IMPG_TRY
+  if (!ids || !out || lanes < 1 || lanes > 8 || world < 1 || rank < 0 || rank >= world) throw Error{IMPG_E_INVALID, "bad arguments"};
+  require_device(device);
+  auto cm = std::make_unique<impg_gpu_comm>();
+  cm->rank = rank; cm->world = world; cm->device = device;
+  for (int l = 0; l < lanes; l++) cm->lanes.emplace_back(new RcclComm(ids + (size_t)l * IMPG_COMM_ID_BYTES, rank, world, device));
+  *out = cm.release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_comm_create_host(const impg_gpu_host_transport_t *transports, int lanes, int rank, int world, int device,
+                              impg_gpu_comm_t **out) {
+  IMPG_TRY
+  if (!transports || !out || lanes < 1 || lanes > 8 || world < 1 || rank < 0 || rank >= world) throw Error{IMPG_E_INVALID, "bad arguments"};
+  auto cm = std::make_unique<impg_gpu_comm>();
+  cm->rank = rank; cm->world = world; cm->device = device;
+  for (int l = 0; l < lanes; l++) cm->lanes.emplace_back(new HostComm(transports[l], rank, world));
+  *out = cm.release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+void impg_gpu_comm_destroy(impg_gpu_comm_t *c) { delete c; }
+
+int impg_gpu_comm_info(const impg_gpu_comm_t *c, int *rank, int *world, int *lanes, const char **kind) {
+  IMPG_TRY
+  check_comm(c);
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  if (lanes) *lanes = (int)c->lanes.size();
+  if (kind) *kind = c->lanes[0]->kind();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_comm_check(impg_gpu_comm_t *c, int lane) {
+  IMPG_TRY
+  check_comm(c);
+  if (lane < 0 || lane >= (int)c->lanes.size()) throw Error{IMPG_E_INVALID, "no such lane"};
+  Comm &cm = *c->lanes[lane];
+  const int W = cm.world, me = cm.rank;
+  // all-gather: rank r contributes (r+1)*1000 + i
+  const size_t K = 3;
+  std::vector<uint64_t> mine(K), all(K * W);
+  for (size_t i = 0; i < K; i++) mine[i] = (uint64_t)(me + 1) * 1000 + i;
+  cm.allgather_u64(mine.data(), K, all.data());
+  for (int r = 0; r < W; r++)
+    for (size_t i = 0; i < K; i++)
+      if (all[(size_t)r * K + i] != (uint64_t)(r + 1) * 1000 + i) throw Error{IMPG_E_IO, "transport check: all-gather returned wrong values"};
+  HostComm *hc = dynamic_cast<HostComm *>(&cm);
+  if (!hc) return IMPG_OK;  // device transports are exercised by the queries themselves
+  // all-to-all-v over host memory, ragged: rank s sends (s + 2 d + 1) words to rank d, word j = s<<20 | d<<10 | j
+  std::vector<uint64_t> so(W), sb(W), ro(W), rb(W);
+  uint64_t st = 0, rt = 0;
+  for (int d = 0; d < W; d++) { so[d] = st; sb[d] = (uint64_t)(me + 2 * d + 1) * 4; st += sb[d]; }
+  for (int s2 = 0; s2 < W; s2++) { ro[s2] = rt; rb[s2] = (uint64_t)(s2 + 2 * me + 1) * 4; rt += rb[s2]; }
+  std::vector<uint32_t> snd(st / 4 + 1), rcv(rt / 4 + 1, 0xFFFFFFFFu);
+  for (int d = 0; d < W; d++)
+    for (uint64_t j = 0; j < sb[d] / 4; j++) snd[so[d] / 4 + j] = (uint32_t)me << 20 | (uint32_t)d << 10 | (uint32_t)j;
+  if (hc->t.alltoallv(hc->t.ctx, snd.data(), so.data(), sb.data(), rcv.data(), ro.data(), rb.data()) != 0)
+    throw Error{IMPG_E_IO, "transport check: alltoallv callback failed"};
+  for (int s2 = 0; s2 < W; s2++)
+    for (uint64_t j = 0; j < rb[s2] / 4; j++)
+      if (rcv[ro[s2] / 4 + j] != ((uint32_t)s2 << 20 | (uint32_t)me << 10 | (uint32_t)j))
+        throw Error{IMPG_E_IO, "transport check: all-to-all-v delivered wrong bytes"};
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_create_rank(const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops, size_t n_ops,
+                               const int64_t *seq_len, uint32_t n_seq, const uint64_t *file_first_record, uint32_t n_files,
+                               int bidirectional, int order_policy, int device, impg_gpu_comm_t *comm, impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out) throw Error{IMPG_E_INVALID, "null out"};
+  check_comm(comm);
+  std::vector<uint64_t> ff;
+  if (file_first_record && n_files) { ff.assign(file_first_record, file_first_record + n_files); ff.push_back(n_records); }
+  const std::vector<uint32_t> owner = owner_map(records, n_records, n_seq, bidirectional, comm->world);
+  *out = make_rank_index(records, n_records, cigar_ops, n_ops, seq_len, n_seq, ff.empty() ? nullptr : &ff, bidirectional, order_policy,
+                         device, comm, nullptr, owner).release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_create_from_paf_rank(const char *const *paths, int n_paths, int bidirectional, int order_policy, int device,
+                                        impg_gpu_comm_t *comm, impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out || !paths || n_paths <= 0) throw Error{IMPG_E_INVALID, "bad arguments"};
+  check_comm(comm);
+  require_device(device);
+  ParsedPaf pp;
+  std::vector<std::string> ps(paths, paths + n_paths);
+  parse_paf_files(ps, pp);
+  std::vector<int64_t> lens = pp.seq.lens;
+  const std::vector<uint32_t> owner = owner_map(pp.records.data(), pp.records.size(), (uint32_t)lens.size(), bidirectional, comm->world);
+  *out = make_rank_index(pp.records.data(), pp.records.size(), pp.ops.data(), pp.ops.size(), lens.data(), (uint32_t)lens.size(),
+                         &pp.file_first, bidirectional, order_policy, device, comm, &pp.seq, owner).release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_create_multi(const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops, size_t n_ops,
+                                const int64_t *seq_len, uint32_t n_seq, const uint64_t *file_first_record, uint32_t n_files,
+                                int bidirectional, int order_policy, const int *devices, int n_dev, int lanes,
+                                impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out || (!seq_len && n_seq)) throw Error{IMPG_E_INVALID, "null argument"};
+  std::vector<uint64_t> ff;
+  if (file_first_record && n_files) { ff.assign(file_first_record, file_first_record + n_files); ff.push_back(n_records); }
+  *out = make_cluster(records, n_records, cigar_ops, n_ops, seq_len, n_seq, ff.empty() ? nullptr : &ff, bidirectional, order_policy,
+                      devices, n_dev, lanes, nullptr).release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_create_from_paf_multi(const char *const *paths, int n_paths, int bidirectional, int order_policy,
+                                         const int *devices, int n_dev, int lanes, impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out || !paths || n_paths <= 0) throw Error{IMPG_E_INVALID, "bad arguments"};
+  ParsedPaf pp;
+  std::vector<std::string> ps(paths, paths + n_paths);
+  parse_paf_files(ps, pp);
+  std::vector<int64_t> lens = pp.seq.lens;
+  *out = make_cluster(pp.records.data(), pp.records.size(), pp.ops.data(), pp.ops.size(), lens.data(), (uint32_t)lens.size(),
+                      &pp.file_first, bidirectional, order_policy, devices, n_dev, lanes, &pp.seq).release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_shard_info(const impg_gpu_index_t *ix, int *rank, int *world, int *lanes, uint32_t *owner_out, size_t cap) {
+  IMPG_TRY
+  if (!ix) throw Error{IMPG_E_INVALID, "null argument"};
+  const ShardCtx *S = ix->shard ? ix->shard : (ix->cluster && !ix->cluster->ranks.empty() ? ix->cluster->ranks[0]->shard : nullptr);
+  if (rank) *rank = ix->shard ? S->comm->rank : (ix->cluster ? -1 : 0);
+  if (world) *world = S ? S->comm->world : 1;
+  if (lanes) *lanes = S ? (int)S->comm->lanes.size() : 1;
+  if (owner_out && S)
+    for (size_t t = 0; t < S->owner.size() && t < cap; t++) owner_out[t] = S->owner[t];
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+}  // extern "C"

@@ -118,27 +118,34 @@ class GpuImpg:
     # ---- construction (Impg::from_multi_alignment_records / load) ------------
     @classmethod
     def from_records(cls, records, ops, seq_len, bidirectional=True, order=_lib.ORDER_COITREES, device=0,
-                     shard=None, n_shards=None, file_first=None):
+                     file_first=None, devices=None, lanes=2, comm=None):
         """file_first: first record of every alignment file (records_by_file of the reference); only the
-        MultiImpg tie order observes it"""
+        MultiImpg tie order observes it.
+        devices=[...]: ONE handle over several GPUs of this process (impg_gpu_index_create_multi).
+        comm=Comm: this rank's shard of an index sharded one process per GPU (impg_gpu_index_create_rank);
+        queries on it are collective calls."""
         rec = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
         ops = np.ascontiguousarray(ops, dtype=np.uint32)
         sl = np.ascontiguousarray(seq_len, dtype=np.int64)
         h = C.c_void_p(None)
-        if file_first is not None:
-            ff = np.ascontiguousarray(file_first, dtype=np.uint64)
+        ff = None if file_first is None else np.ascontiguousarray(file_first, dtype=np.uint64)
+        ffp, ffn = (None, 0) if ff is None else (ff.ctypes.data, ff.size)
+        if devices is not None:
+            dv = np.ascontiguousarray(devices, dtype=np.int32)
+            check(lib().impg_gpu_index_create_multi(rec.ctypes.data, rec.size, ops.ctypes.data, ops.size, sl.ctypes.data, sl.size,
+                                                    ffp, ffn, int(bidirectional), order, dv.ctypes.data, dv.size, lanes, C.byref(h)))
+        elif comm is not None:
+            check(lib().impg_gpu_index_create_rank(rec.ctypes.data, rec.size, ops.ctypes.data, ops.size, sl.ctypes.data, sl.size,
+                                                   ffp, ffn, int(bidirectional), order, device, comm._h, C.byref(h)))
+        elif ff is not None:
             check(lib().impg_gpu_index_create_files(rec.ctypes.data, rec.size, ops.ctypes.data, ops.size, sl.ctypes.data, sl.size,
-                                                    ff.ctypes.data, ff.size, int(bidirectional), order, device,
-                                                    0 if shard is None else shard, 1 if n_shards is None else n_shards, C.byref(h)))
-            return cls(h)
-        if shard is None:
+                                                    ffp, ffn, int(bidirectional), order, device, C.byref(h)))
+        else:
             check(lib().impg_gpu_index_create(rec.ctypes.data, rec.size, ops.ctypes.data, ops.size, sl.ctypes.data, sl.size,
                                               int(bidirectional), order, device, C.byref(h)))
-        else:
-            check(lib().impg_gpu_index_create_sharded(rec.ctypes.data, rec.size, ops.ctypes.data, ops.size, sl.ctypes.data,
-                                                      sl.size, int(bidirectional), order, device, shard, n_shards,
-                                                      C.byref(h)))
-        return cls(h)
+        ix = cls(h)
+        ix._comm = comm  # the communicator outlives the index
+        return ix
 
     def save(self, path):
         """impg_gpu_index_save: the built index (device arrays + sequence table) as one file."""
@@ -152,17 +159,23 @@ class GpuImpg:
         return cls(h)
 
     @classmethod
-    def from_paf(cls, paths, bidirectional=True, order=_lib.ORDER_COITREES, device=0, shard=None, n_shards=None):
+    def from_paf(cls, paths, bidirectional=True, order=_lib.ORDER_COITREES, device=0, devices=None, lanes=2, comm=None):
+        """devices / comm: as in from_records (impg_gpu_index_create_from_paf_multi / _rank)."""
         if isinstance(paths, str):
             paths = [paths]
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         h = C.c_void_p(None)
-        if shard is None:
-            check(lib().impg_gpu_index_create_from_paf(arr, len(paths), int(bidirectional), order, device, C.byref(h)))
+        if devices is not None:
+            dv = np.ascontiguousarray(devices, dtype=np.int32)
+            check(lib().impg_gpu_index_create_from_paf_multi(arr, len(paths), int(bidirectional), order, dv.ctypes.data, dv.size,
+                                                             lanes, C.byref(h)))
+        elif comm is not None:
+            check(lib().impg_gpu_index_create_from_paf_rank(arr, len(paths), int(bidirectional), order, device, comm._h, C.byref(h)))
         else:
-            check(lib().impg_gpu_index_create_from_paf_sharded(arr, len(paths), int(bidirectional), order, device, shard,
-                                                               n_shards, C.byref(h)))
-        return cls(h)
+            check(lib().impg_gpu_index_create_from_paf(arr, len(paths), int(bidirectional), order, device, C.byref(h)))
+        ix = cls(h)
+        ix._comm = comm
+        return ix
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -305,48 +318,114 @@ class GpuImpg:
             check(lib().impg_gpu_query_batch_stats_dev(self._h, device_ptr, n, C.byref(p), cp, kp, C.byref(st)))
         return st, cnt, ck
 
-    # ---- stage API (device pointers; see impg_amd/sharded.py) --------------------
-    def stage_count(self, d_frontier_ptr, n, transitive, d_counts_ptr):
-        total = C.c_uint64(0)
-        check(lib().impg_gpu_stage_count(self._h, d_frontier_ptr, n, int(transitive), d_counts_ptr, C.byref(total)))
-        return total.value
-
-    def stage_project(self, d_frontier_ptr, n, transitive, params, d_hits_ptr, total, compact=False):
-        """compact: 16-byte hit records {fidx, query_id, q_first, q_last} instead of the 32-byte ones"""
-        acc = C.c_uint64(0)
-        f = lib().impg_gpu_stage_project16 if compact else lib().impg_gpu_stage_project
-        check(f(self._h, d_frontier_ptr, n, int(transitive), C.byref(params), d_hits_ptr, total, C.byref(acc)))
-        return acc.value
+    def shard_info(self):
+        """(rank, world, lanes, owner[num_seqs]) of a sharded index; rank -1 = a multi-GPU handle; (0, 1, 1, None) = plain."""
+        r, w, l = C.c_int(0), C.c_int(1), C.c_int(1)
+        owner = np.zeros(self.num_seqs(), dtype=np.uint32)
+        check(lib().impg_gpu_index_shard_info(self._h, C.byref(r), C.byref(w), C.byref(l), owner.ctypes.data, owner.size))
+        return r.value, w.value, l.value, (owner if w.value > 1 or r.value != 0 else None)
 
 
-    def stage_reorder(self, d_hits_ptr, n, words_per_hit, n_frontier, d_out_ptr):
-        check(lib().impg_gpu_stage_reorder(self._h, d_hits_ptr, n, words_per_hit, n_frontier, d_out_ptr))
-
-    def stage_route(self, d_frontier_ptr, n, world, d_out_ptr):
-        counts = (C.c_uint64 * world)()
-        check(lib().impg_gpu_stage_route(self._h, d_frontier_ptr, n, world, d_out_ptr, counts))
-        return list(counts)
-
-    def stage_begin(self, d_ranges_ptr, n, params, d_frontier_ptr, d_self_ptr):
-        nf = C.c_uint64(0)
-        check(lib().impg_gpu_stage_begin(self._h, d_ranges_ptr, n, C.byref(params), d_frontier_ptr, C.byref(nf), d_self_ptr))
-        return nf.value
-
-    def stage_update(self, d_frontier_ptr, n_frontier, d_hits_ptr, n_hits, params, compact=False):
-        nn = C.c_uint64(0)
-        f = lib().impg_gpu_stage_update16 if compact else lib().impg_gpu_stage_update
-        check(f(self._h, d_frontier_ptr, n_frontier, d_hits_ptr, n_hits, C.byref(params), C.byref(nn)))
-        return nn.value
-
-    def stage_next_frontier(self, d_out_ptr, cap):
-        check(lib().impg_gpu_stage_next_frontier(self._h, d_out_ptr, cap))
+def shard_assign(entries_per_target, n_shards):
+    """impg_gpu_shard_assign: owner shard of every target (greedy bin-packing by entry count); host-only."""
+    c = np.ascontiguousarray(entries_per_target, dtype=np.uint64)
+    out = np.zeros(c.size, dtype=np.uint32)
+    check(lib().impg_gpu_shard_assign(c.ctypes.data, c.size, n_shards, out.ctypes.data))
+    return out
 
 
-    def stage_timing(self, reset=True):
-        ms = (C.c_float * 3)()
-        n = C.c_uint64(0)
-        check(lib().impg_gpu_stage_timing(self._h, ms, C.byref(n), int(reset)))
-        return [ms[0], ms[1], ms[2]], n.value
+class Comm:
+    """impg_gpu_comm_t: the transport between the ranks of an index sharded one process per GPU."""
+
+    def __init__(self, handle, rank, world, lanes, keep=None):
+        self._h, self.rank, self.world, self.lanes = handle, rank, world, lanes
+        self._keep = keep
+
+    @classmethod
+    def rccl(cls, rank, world, device, lanes=2, group=None):
+        """RCCL communicators (one per lane).  Rank 0 makes the unique ids; torch.distributed (already
+        initialised by the launcher) carries them to the other ranks -- plumbing only: every collective of
+        a query runs inside libimpg_gpu.so."""
+        import torch.distributed as dist
+        ids = np.zeros(lanes * _lib.COMM_ID_BYTES, dtype=np.uint8)
+        if rank == 0:
+            check(lib().impg_gpu_comm_unique_id(ids.ctypes.data, lanes))
+        box = [ids.tobytes()]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        ids = np.frombuffer(box[0], dtype=np.uint8).copy()
+        h = C.c_void_p(None)
+        check(lib().impg_gpu_comm_create_rccl(ids.ctypes.data, lanes, rank, world, device, C.byref(h)))
+        return cls(h, rank, world, lanes)
+
+    @classmethod
+    def host(cls, rank, world, device, groups):
+        """The host's own transport (impg_gpu_comm_create_host): one torch.distributed group per lane, moving
+        HOST memory (gloo).  What the multi-rank tests use on a box whose ranks share one GPU."""
+        import torch
+        import torch.distributed as dist
+        lanes = len(groups)
+        arr = (_lib.HostTransport * lanes)()
+        keep = []
+
+        def make(group):
+            def allgather(ctx, mine, k, out):
+                try:
+                    t = torch.from_numpy(np.ctypeslib.as_array(mine, shape=(k,)).astype(np.int64))
+                    parts = [torch.empty_like(t) for _ in range(world)]
+                    dist.all_gather(parts, t, group=group)
+                    dst = np.ctypeslib.as_array(out, shape=(world * k,))
+                    for r in range(world):
+                        dst[r * k:(r + 1) * k] = parts[r].numpy().astype(np.uint64)
+                    return 0
+                except Exception as e:  # noqa: BLE001 -- nothing may unwind into C
+                    print("host transport allgather failed:", e, flush=True)
+                    return 1
+
+            def alltoallv(ctx, send, soff, sbytes, recv, roff, rbytes):
+                try:
+                    so = [int(soff[d]) for d in range(world)]
+                    sb = [int(sbytes[d]) for d in range(world)]
+                    ro = [int(roff[d]) for d in range(world)]
+                    rb = [int(rbytes[d]) for d in range(world)]
+                    st, rt = sum(sb), sum(rb)
+                    src = (torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(st,)).copy())
+                           if st else torch.empty(0, dtype=torch.uint8))
+                    dst = torch.empty(rt, dtype=torch.uint8)
+                    assert so == list(np.cumsum([0] + sb[:-1])) and ro == list(np.cumsum([0] + rb[:-1]))
+                    dist.all_to_all_single(dst, src, output_split_sizes=rb, input_split_sizes=sb, group=group)
+                    if rt:
+                        np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(rt,))[:] = dst.numpy()
+                    return 0
+                except Exception as e:  # noqa: BLE001
+                    print("host transport alltoallv failed:", e, flush=True)
+                    return 1
+            return _lib.ALLGATHER_CB(allgather), _lib.ALLTOALLV_CB(alltoallv)
+
+        for l, g in enumerate(groups):
+            ag, aa = make(g)
+            keep += [ag, aa]
+            arr[l].ctx = None
+            arr[l].allgather_u64 = ag
+            arr[l].alltoallv = aa
+        h = C.c_void_p(None)
+        check(lib().impg_gpu_comm_create_host(arr, lanes, rank, world, device, C.byref(h)))
+        return cls(h, rank, world, lanes, keep=(arr, keep))
+
+    def check(self):
+        """impg_gpu_comm_check on every lane (collective)."""
+        for l in range(self.lanes):
+            check(lib().impg_gpu_comm_check(self._h, l))
+
+    def kind(self):
+        k = C.c_char_p(None)
+        check(lib().impg_gpu_comm_info(self._h, None, None, None, C.byref(k)))
+        return k.value.decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().impg_gpu_comm_destroy(self._h)
+            self._h = None
 
 
 def parse_subsequence(name):

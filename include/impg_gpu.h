@@ -107,32 +107,19 @@ int impg_gpu_index_create(const impg_gpu_record_t *records, size_t n_records,
 int impg_gpu_index_create_files(const impg_gpu_record_t *records, size_t n_records,
                                 const uint32_t *cigar_ops, size_t n_ops, const int64_t *seq_len,
                                 uint32_t n_seq, const uint64_t *file_first_record, uint32_t n_files,
-                                int bidirectional, int order_policy, int device, uint32_t shard,
-                                uint32_t n_shards, impg_gpu_index_t **out);
+                                int bidirectional, int order_policy, int device, impg_gpu_index_t **out);
 
 /* Same, parsing PAF files on the host the way paf.rs:118-194 does; sequence ids
  * are assigned in first-seen order over the files (query then target per line). */
 int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths,
                                    int bidirectional, int order_policy,
                                    int device, impg_gpu_index_t **out);
-/* Keep only the entries whose target satisfies target_id % n_shards == shard
- * (multi-GPU sharding by target sequence; applied at create time). */
-int impg_gpu_index_create_sharded(const impg_gpu_record_t *records, size_t n_records,
-                                  const uint32_t *cigar_ops, size_t n_ops,
-                                  const int64_t *seq_len, uint32_t n_seq,
-                                  int bidirectional, int order_policy, int device,
-                                  uint32_t shard, uint32_t n_shards,
-                                  impg_gpu_index_t **out);
-int impg_gpu_index_create_from_paf_sharded(const char *const *paths, int n_paths,
-                                           int bidirectional, int order_policy, int device,
-                                           uint32_t shard, uint32_t n_shards,
-                                           impg_gpu_index_t **out);
 /* A built index as one file: the role of the reference's `.impg` file (writer impg.rs:1655-1721, reader
  * :1787-1850; `impg index` / the implicit index cache of `impg query`, main.rs:11321-11386): pay for
  * parsing and tokenising once.  The file holds the device arrays as they sit in HBM plus the sequence
  * table (so the alignment files are not needed again, unlike with `.impg`, which stores byte offsets into
  * them); it is this library's own layout ("IMPGHBM1"), tied to the build's tile constants, and NOT the
- * reference's IMPGIDX2 format.  A sharded index saves / loads its shard.  load: IMPG_E_INVALID for a
+ * reference's IMPGIDX2 format.  Not for a sharded index.  load: IMPG_E_INVALID for a
  * foreign or damaged file, IMPG_E_UNSUPPORTED for a layout version this build does not read. */
 int impg_gpu_index_save(const impg_gpu_index_t *, const char *path);
 int impg_gpu_index_load(const char *path, int device, impg_gpu_index_t **out);
@@ -240,11 +227,12 @@ typedef struct {
   float ms_total;          /* HIP-event time of the whole call on the engine stream */
   float ms_lookup, ms_project, ms_update; /* per-stage kernel time (HIP events) */
   uint64_t project_launches;              /* launches of the projection kernel */
+  float ms_exchange;                      /* sharded index: wall time inside the transport (all-gathers + all-to-all-v) */
 } impg_gpu_stats_t;
 int impg_gpu_query_batch_stats(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n,
                                const impg_gpu_params_t *params, uint64_t *per_range_count,
                                uint64_t *per_range_checksum, impg_gpu_stats_t *stats);
-/* Same with the ranges already resident in HBM (device pointer). */
+/* Same with the ranges already resident in HBM (device pointer; not for a multi handle, whose ranges span GPUs). */
 int impg_gpu_query_batch_stats_dev(impg_gpu_index_t *, const impg_gpu_range_t *d_ranges, size_t n,
                                    const impg_gpu_params_t *params, uint64_t *per_range_count,
                                    uint64_t *per_range_checksum, impg_gpu_stats_t *stats);
@@ -283,84 +271,73 @@ int impg_gpu_parse_subsequence(const char *seq_name, char *base_out, size_t base
 int impg_gpu_parse_target_range(const char *s, char *name_out, size_t name_cap,
                                 int32_t *start, int32_t *end);
 
-/* ---- stage API: one BFS hop split at its exchange points, for a host that
- *      shards the index by target across GPUs.  All
- *      pointers are DEVICE pointers owned by the caller unless noted. -------- */
-/* A frontier record: query range `qidx` (index into the caller's batch) wants
- * [start,end) on target_id looked up.  16 B. */
+/* ---- multi-GPU: the index sharded by target sequence over the GPUs of one node ---------
+ * Entries live with the rank that owns their target (targets bin-packed by entry count, heaviest first onto the
+ * least loaded shard: impg_gpu_shard_assign); a record's ops are stored with its forward entry's owner and with its
+ * reversed entry's owner.  Every query lives with its HOME rank -- visited sets, worklists and result order, the
+ * sequential state of impg.rs:2471-2560 -- and each hop of the walk sends the frontier records to the owners of
+ * their targets (all-to-all-v of 16-byte records) and brings the hits home (16- or 32-byte records), where they are
+ * put back into frontier order x visit order before the visited-set update.  The whole loop runs inside this
+ * library; the reference has no counterpart (its MultiImpg, multi_impg.rs:495-595, queries per-file indices
+ * serially on one host).  Two ways to bring the ranks up:
+ *
+ *  (1) one process, n_dev GPUs: impg_gpu_index_create_multi / _from_paf_multi return ONE handle.  Every query
+ *      entry point above works on it unchanged -- a Rust `impl ImpgIndex` gets the whole node for free.  The ranks
+ *      are host threads; exchanges are direct peer copies over xGMI (hipMemcpyPeerAsync).  The batch's ranges are
+ *      dealt to the ranks in contiguous blocks; results come back in the caller's order.
+ *  (2) one process per GPU (torch.distributed.run / mpirun layout): every rank makes a communicator
+ *      (impg_gpu_comm_create_rccl: RCCL send/recv groups over xGMI; rank 0 makes the ids with
+ *      impg_gpu_comm_unique_id and the launcher carries them to the others -- or impg_gpu_comm_create_host: the
+ *      host's own transport as two callbacks), builds its shard (impg_gpu_index_create_rank / _from_paf_rank),
+ *      and then the query entry points are COLLECTIVE: every rank calls the same function with the same params
+ *      and ITS OWN ranges (possibly none) and gets the results of its own ranges.
+ *
+ * `lanes` chunks of a batch ("chunk_ranges") are in flight at once, each on its own engine, stream, host thread
+ * and communicator, so one lane's exchange overlaps the other lanes' kernels.
+ * Not offered on a sharded index: store_cigar (IMPG_E_UNSUPPORTED), impg_gpu_index_save.  projected / pairs /
+ * stage times of a rank (2) count the work done ON THAT RANK's shard; a multi handle (1) reports the sum of
+ * the work and the slowest rank's times. */
+typedef struct impg_gpu_comm impg_gpu_comm_t;
+#define IMPG_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+/* ids[lanes * IMPG_COMM_ID_BYTES]: one RCCL unique id per lane, made on one rank */
+int impg_gpu_comm_unique_id(uint8_t *ids, int lanes);
+int impg_gpu_comm_create_rccl(const uint8_t *ids, int lanes, int rank, int world, int device, impg_gpu_comm_t **out);
+/* The host's transport.  Both callbacks move HOST memory and return 0 on success; they are called from the lane's
+ * own thread (one transport per lane: collectives of different lanes must not share an ordering domain).
+ *   allgather_u64: all[r * k + i] = value i of rank r.
+ *   alltoallv: bytes [send_off[d], +send_bytes[d]) of `send` go to rank d; bytes from rank s land at recv_off[s]. */
 typedef struct {
-  uint32_t target_id;
-  int32_t start, end;
-  uint32_t qidx;
-} impg_gpu_frontier_t;
-/* A hit: projection of frontier record `fidx` through one alignment. 28 B SoA
- * on device; this AoS form is what crosses ranks. */
-typedef struct {
-  uint32_t fidx;     /* index of the frontier record in the array passed in */
-  uint32_t query_id; /* 0xFFFFFFFF = projection returned None (slot unused) */
-  int32_t q_first, q_last, t_first, t_last;
-  uint32_t order;    /* visit position within the frontier record */
-  uint32_t pad;
-} impg_gpu_hit_t;
-/* lookup: writes counts[n] (overlapping entries of this shard per record) and
- * returns their sum in *total. */
-int impg_gpu_stage_count(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n,
-                         int transitive, uint32_t *d_counts, uint64_t *total);
-/* project: fills d_hits[total] (slot order = frontier order x visit order); d_hits may be
- * NULL when only *accepted is wanted (the last level of a counting run). */
-int impg_gpu_stage_project(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n,
-                           int transitive, const impg_gpu_params_t *params,
-                           impg_gpu_hit_t *d_hits, uint64_t total, uint64_t *accepted);
-
-/* The same pair of calls on 16-byte hit records {fidx, query_id, q_first, q_last}: all the visited-set
- * update reads.  For runs that only need the closure's frontier and counts (no result rows at home),
- * it halves the bytes the owners send back. */
-typedef struct {
-  uint32_t fidx;
-  uint32_t query_id; /* 0xFFFFFFFF = projection returned None */
-  int32_t q_first, q_last;
-} impg_gpu_hit16_t;
-int impg_gpu_stage_project16(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n,
-                             int transitive, const impg_gpu_params_t *params,
-                             impg_gpu_hit16_t *d_hits, uint64_t total, uint64_t *accepted);
-
-/* reorder: the home side of a hop.  d_hits[n] (impg_gpu_hit_t: words_per_hit = 8, or impg_gpu_hit16_t: 4;
- * fidx = index into the home frontier of n_frontier records) arrived grouped by owner rank, every
- * owner's block in ascending fidx.  d_out receives them in ascending fidx, order within one fidx kept
- * (what a stable sort by fidx gives): a frontier record lives on exactly one owner, so records of one
- * fidx are already contiguous and a counting pass replaces the sort.  IMPG_E_INVALID if a fidx is out
- * of range or shows up in two separate runs. */
-int impg_gpu_stage_reorder(impg_gpu_index_t *, const void *d_hits, size_t n, uint32_t words_per_hit,
-                           size_t n_frontier, void *d_out);
-
-/* route: stable partition of a frontier by owner rank (target_id % world).  d_out[n]
- * receives the records grouped by owner, in their original order within a group,
- * with qidx replaced by the record's index in d_frontier (the home index an owner
- * echoes back in impg_gpu_hit_t.fidx); counts[world] (HOST) receives the group sizes. */
-int impg_gpu_stage_route(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n, uint32_t world,
-                         impg_gpu_frontier_t *d_out, uint64_t *counts);
-
-/* Home-side steps of a sharded transitive batch (visited sets live where the
- * query lives).  stage_begin resets the visited sets to the batch's own ranges
- * (impg.rs:2337-2340), writes the self intervals (qidx = range index) to
- * d_self_out[n] and the level-0 frontier to d_frontier_out (cap n).
- * stage_update replays hits -- sorted by fidx, fidx indexing d_frontier, hits of
- * one record in visit order -- against the visited sets (impg.rs:2471-2560) and
- * builds the next frontier (impg.rs:2566-2584); stage_next_frontier copies it. */
-int impg_gpu_stage_begin(impg_gpu_index_t *, const impg_gpu_range_t *d_ranges, size_t n,
-                         const impg_gpu_params_t *params, impg_gpu_frontier_t *d_frontier_out,
-                         uint64_t *n_frontier, impg_gpu_frontier_t *d_self_out);
-int impg_gpu_stage_update(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
-                          const impg_gpu_hit_t *d_hits, size_t n_hits, const impg_gpu_params_t *params,
-                          uint64_t *n_next);
-int impg_gpu_stage_update16(impg_gpu_index_t *, const impg_gpu_frontier_t *d_frontier, size_t n_frontier,
-                            const impg_gpu_hit16_t *d_hits, size_t n_hits, const impg_gpu_params_t *params,
-                            uint64_t *n_next);
-int impg_gpu_stage_next_frontier(impg_gpu_index_t *, impg_gpu_frontier_t *d_out, size_t cap);
-/* HIP-event time accumulated by the stage calls since the last reset:
- * ms[0] lookup (count+emit), ms[1] projection kernel, ms[2] visited update;
- * launches = projection launches. */
-int impg_gpu_stage_timing(impg_gpu_index_t *, float *ms3, uint64_t *launches, int reset);
+  void *ctx;
+  int (*allgather_u64)(void *ctx, const uint64_t *mine, size_t k, uint64_t *all);
+  int (*alltoallv)(void *ctx, const void *send, const uint64_t *send_off, const uint64_t *send_bytes, void *recv,
+                   const uint64_t *recv_off, const uint64_t *recv_bytes);
+} impg_gpu_host_transport_t;
+int impg_gpu_comm_create_host(const impg_gpu_host_transport_t *transports /* [lanes] */, int lanes, int rank, int world,
+                              int device, impg_gpu_comm_t **out);
+void impg_gpu_comm_destroy(impg_gpu_comm_t *); /* after the indexes that use it */
+int impg_gpu_comm_info(const impg_gpu_comm_t *, int *rank, int *world, int *lanes, const char **kind /* "rccl", "host", ... */);
+/* Collective self-check of one lane's transport before any index is built on it: an all-gather of known words and,
+ * for a host transport, a ragged all-to-all-v of a known pattern over host memory (needs no GPU).
+ * IMPG_E_IO if anything arrives wrong. */
+int impg_gpu_comm_check(impg_gpu_comm_t *, int lane);
+/* (2): this rank's shard.  Every rank passes the SAME records (each keeps what its targets need). */
+int impg_gpu_index_create_rank(const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops, size_t n_ops,
+                               const int64_t *seq_len, uint32_t n_seq, const uint64_t *file_first_record /* may be NULL */,
+                               uint32_t n_files, int bidirectional, int order_policy, int device, impg_gpu_comm_t *comm,
+                               impg_gpu_index_t **out);
+int impg_gpu_index_create_from_paf_rank(const char *const *paths, int n_paths, int bidirectional, int order_policy,
+                                        int device, impg_gpu_comm_t *comm, impg_gpu_index_t **out);
+/* (1): one handle over n_dev GPUs of this process (a device may be listed more than once: its shards share it). */
+int impg_gpu_index_create_multi(const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops, size_t n_ops,
+                                const int64_t *seq_len, uint32_t n_seq, const uint64_t *file_first_record /* may be NULL */,
+                                uint32_t n_files, int bidirectional, int order_policy, const int *devices, int n_dev,
+                                int lanes, impg_gpu_index_t **out);
+int impg_gpu_index_create_from_paf_multi(const char *const *paths, int n_paths, int bidirectional, int order_policy,
+                                         const int *devices, int n_dev, int lanes, impg_gpu_index_t **out);
+/* The shard map: owner_out[t] = shard of target t given its entry count (host-only, deterministic). */
+int impg_gpu_shard_assign(const uint64_t *entries_per_target, uint32_t n_seq, uint32_t n_shards, uint32_t *owner_out);
+/* rank (-1 for a multi handle), world, lanes and the shard map of an index (1 / 0 for a plain one) */
+int impg_gpu_index_shard_info(const impg_gpu_index_t *, int *rank, int *world, int *lanes, uint32_t *owner_out, size_t cap);
 
 /* ---- synthetic workload generators (SplitMix64) ----- */
 /* Fills records / ops for `n_records` synthetic alignments (200-op CIGARs by

@@ -1,0 +1,98 @@
+"""Worker of the multi-rank tests (one process per rank, launched by torch.distributed.run).
+
+  comm-check <transport>   CPU: the host transport (gloo callbacks) passes impg_gpu_comm_check on every lane
+  query <transport> <paf>  GPU: every rank builds its shard, submits its own queries (collective calls) and
+                           checks its results against the oracle; transport = host (gloo, ranks share GPU 0)
+                           or rccl (one GPU per rank)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import impg_amd  # noqa: E402
+
+
+def make_comm(transport, rank, world, lanes, device):
+    if transport == "rccl":
+        return impg_amd.Comm.rccl(rank, world, device, lanes=lanes)
+    groups = [dist.new_group(list(range(world)), backend="gloo") for _ in range(lanes)]
+    return impg_amd.Comm.host(rank, world, device, groups)
+
+
+def main():
+    mode, transport = sys.argv[1], sys.argv[2]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lanes = int(os.environ.get("IMPG_TEST_LANES", "2"))
+    if mode == "comm-check":
+        comm = make_comm(transport, rank, world, lanes, 0)
+        assert comm.kind() == "host"
+        comm.check()
+        dist.barrier()
+        if rank == 0:
+            print("comm ok world=%d lanes=%d" % (world, lanes))
+        comm.close()
+        dist.destroy_process_group()
+        return
+
+    from oracle import oracle as o
+    from tests.paf_gen import random_ranges
+    paf_path = sys.argv[3]
+    device = int(os.environ.get("LOCAL_RANK", "0")) if transport == "rccl" else 0
+    comm = make_comm(transport, rank, world, lanes, device)
+    comm.check()
+    c = o.OracleIndex(paf_paths=[paf_path], preparse=True)
+    g = impg_amd.GpuImpg.from_paf(paf_path, device=device, comm=comm)
+    r, w, l, owner = g.shard_info()
+    assert (r, w, l) == (rank, world, lanes)
+    g.set_option("chunk_ranges", 7)
+    n_seq, seq_len = c.num_seqs(), int(c.seq_len(0))
+    n_q = 0 if (rank == 1 and world == 3) else 18 + 5 * rank  # ranks own different numbers of queries; one owns none
+    rl = random_ranges(100 + rank, n_q, n_seq, seq_len, max_len=3000, min_len=120)
+    mask = {0: (seq_len, [(100, 2000), (5000, 9000)]), 2: (seq_len, [(0, 700)])}
+    keep = np.array([1, 0, 1, 1, 0, 1, 1][:n_seq] + [1] * max(0, n_seq - 7), dtype=np.uint8)
+    cases = [dict(), dict(transitive=True, max_depth=2), dict(transitive=True, max_depth=3, min_transitive_len=20),
+             dict(transitive=True, max_depth=0, min_transitive_len=200, min_output_length=150),
+             dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=50),
+             dict(transitive=True, max_depth=2, multi_impg=True), dict(transitive=True, dfs=True, max_depth=2, multi_impg=True),
+             dict(min_identity=0.8), dict(transitive=True, max_depth=2, masked=True), dict(transitive=True, max_depth=2, subset=True)]
+    for kw in cases:
+        kw = dict(kw)
+        m = mask if kw.pop("masked", False) else None
+        sk = keep if kw.pop("subset", False) else None
+        p = impg_amd.make_params(**kw)
+        got = g.query_batch(rl, p, masked_regions=m, subset_keep=sk)
+        total = 0
+        for i, (t, s, e) in enumerate(rl):
+            want = c.query(t, s, e, masked_regions=m, subset_keep=sk, **kw)
+            assert got[i].tolist() == want.tolist(), (rank, i, kw)
+            total += c.last_projection_count()
+        if m is None and sk is None:
+            st, cnt, ck = g.query_batch_stats(rl, p)
+            tt = torch.tensor([st.projected, total], dtype=torch.int64)
+            dist.all_reduce(tt)  # projections are counted where they are computed: compare the global sums
+            assert int(tt[0]) == int(tt[1]), (rank, kw, tt.tolist())
+            n_self = 1  # (no mask: one self interval per range)
+            for i in range(len(rl)):
+                assert int(cnt[i]) == len(got[i]) - n_self, (rank, i, kw)
+    try:
+        g.query_batch(rl, impg_amd.make_params(store_cigar=True))
+        raise AssertionError("store_cigar on a sharded index must be refused")
+    except impg_amd.ImpgGpuError as e:
+        assert e.code == impg_amd.IMPG_E_UNSUPPORTED
+    dist.barrier()
+    if rank == 0:
+        print("multi ok world=%d lanes=%d transport=%s" % (world, lanes, transport))
+    del g
+    comm.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

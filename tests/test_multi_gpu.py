@@ -1,0 +1,135 @@
+"""The index sharded over GPUs, on the GPU box (one MI355X: the shards of a multi handle share device 0, the
+ranks of the process-per-rank runs share it too; only the transport differs from an 8-GPU node).
+Everything goes through the C ABI; results are compared with the oracle row for row."""
+import threading
+
+import numpy as np
+import pytest
+
+import impg_amd
+from oracle import oracle as o
+from tests.paf_gen import random_paf, random_ranges
+from tests.test_multi_cpu import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+def write_paf(tmp_path, seed=77, n=260, **kw):
+    text, _ = random_paf(seed, n, n_seq=7, seq_len=20000, self_aln=True, **kw)
+    path = str(tmp_path / "w.paf")
+    with open(path, "w") as f:
+        f.write(text)
+    return path
+
+
+CASES = [dict(), dict(transitive=True, max_depth=2), dict(transitive=True, max_depth=3, min_transitive_len=20),
+         dict(transitive=True, max_depth=0, min_transitive_len=200, min_output_length=150),
+         dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=50),
+         dict(transitive=True, max_depth=2, multi_impg=True), dict(transitive=True, dfs=True, max_depth=2, multi_impg=True),
+         dict(min_identity=0.8), dict(transitive=True, max_depth=2, min_identity=0.6)]
+
+
+@pytest.mark.parametrize("world,lanes", [(1, 1), (2, 1), (3, 2), (5, 3), (8, 2)])
+def test_multi_handle_matches_oracle(tmp_path, world, lanes):
+    path = write_paf(tmp_path)
+    c = o.OracleIndex(paf_paths=[path], preparse=True)
+    g = impg_amd.GpuImpg.from_paf(path, devices=[0] * world, lanes=lanes)
+    single = impg_amd.GpuImpg.from_paf(path)
+    assert g.num_seqs() == c.num_seqs() and g.num_entries() == single.num_entries()
+    assert g.num_targets() == single.num_targets() and g.target_ids().tolist() == single.target_ids().tolist()
+    r, w, l, owner = g.shard_info()
+    assert (r, w, l) == (-1, world, lanes) and (world == 1 or owner.max() < world)
+    g.set_option("chunk_ranges", 7)  # many chunks: every lane is used, ranks run different numbers of real chunks
+    rl = random_ranges(100, 53, c.num_seqs(), 20000, max_len=3000, min_len=120)
+    seq_len = int(c.seq_len(0))
+    mask = {0: (seq_len, [(100, 2000), (5000, 9000)]), 2: (seq_len, [(0, 700)])}
+    keep = np.array([1, 0, 1, 1, 0, 1, 1], dtype=np.uint8)
+    for kw in CASES:
+        p = impg_amd.make_params(**kw)
+        got = g.query_batch(rl, p)
+        total = 0
+        for i, (t, s, e) in enumerate(rl):
+            assert got[i].tolist() == c.query(t, s, e, **kw).tolist(), (i, kw)
+            total += c.last_projection_count()
+        assert got.projected == total
+        st, cnt, ck = g.query_batch_stats(rl, p)
+        st1, cnt1, ck1 = single.query_batch_stats(rl, p)
+        assert st.projected == st1.projected == total and cnt.tolist() == cnt1.tolist() and ck.tolist() == ck1.tolist()
+    for kw in (dict(transitive=True, max_depth=2), dict(transitive=True, dfs=True, max_depth=2, multi_impg=True)):
+        got = g.query_batch(rl, impg_amd.make_params(**kw), masked_regions=mask)
+        for i, (t, s, e) in enumerate(rl):
+            assert got[i].tolist() == c.query(t, s, e, masked_regions=mask, **kw).tolist(), (i, kw, "mask")
+        got = g.query_batch(rl, impg_amd.make_params(**kw), subset_keep=keep)
+        for i, (t, s, e) in enumerate(rl):
+            assert got[i].tolist() == c.query(t, s, e, subset_keep=keep, **kw).tolist(), (i, kw, "subset")
+    with pytest.raises(impg_amd.ImpgGpuError) as ei:
+        g.query_batch(rl, impg_amd.make_params(store_cigar=True))
+    assert ei.value.code == impg_amd.IMPG_E_UNSUPPORTED
+    # ... and the handle still works after the refused call
+    assert g.query_batch(rl[:3], impg_amd.make_params())[0].tolist() == c.query(*rl[0]).tolist()
+    # an empty batch, a batch smaller than the world
+    assert len(g.query_batch([], impg_amd.make_params(transitive=True))) == 0
+    got = g.query_batch(rl[:2], impg_amd.make_params(transitive=True, max_depth=2))
+    assert [got[i].tolist() for i in range(2)] == [c.query(*rl[i], transitive=True, max_depth=2).tolist() for i in range(2)]
+
+
+def test_multi_handle_pair_budget_slices(tmp_path):
+    """Owners expand what arrives in slices under the pair budget; results do not change."""
+    path = write_paf(tmp_path, seed=5, n=400)
+    c = o.OracleIndex(paf_paths=[path], preparse=True)
+    g = impg_amd.GpuImpg.from_paf(path, devices=[0, 0, 0], lanes=2)
+    g.set_option("pair_budget", 1024)
+    rl = random_ranges(9, 300, c.num_seqs(), 20000, max_len=6000, min_len=500)
+    kw = dict(transitive=True, max_depth=3, min_transitive_len=30)
+    got = g.query_batch(rl, impg_amd.make_params(**kw))
+    for i, (t, s, e) in enumerate(rl):
+        assert got[i].tolist() == c.query(t, s, e, **kw).tolist(), i
+
+
+@pytest.mark.parametrize("world,lanes", [(2, 2), (3, 1)])
+def test_rank_processes_host_transport(tmp_path, world, lanes):
+    """One process per rank (the torch.distributed.run layout); collectives through the host transport
+    (gloo), every rank's shard on GPU 0."""
+    path = write_paf(tmp_path)
+    out = run_ranks(world, ["query", "host", path], 29720 + world, lanes=lanes, timeout=900)
+    assert "multi ok world=%d lanes=%d transport=host" % (world, lanes) in out
+
+
+def test_rank_process_rccl_world1(tmp_path):
+    """The RCCL transport (ncclSend / ncclRecv groups, dlopen'ed librccl) with the one rank a one-GPU box allows."""
+    path = write_paf(tmp_path)
+    out = run_ranks(1, ["query", "rccl", path], 29730, lanes=2, timeout=900)
+    assert "multi ok world=1 lanes=2 transport=rccl" in out
+
+
+def test_concurrent_calls_on_one_handle(tmp_path):
+    """The trait is Send + Sync (rayon workers share the index, multi_impg.rs:518-530): calls on one handle
+    from several host threads each take their own engine and give the answers a serial caller gets."""
+    path = write_paf(tmp_path, n=400)
+    g = impg_amd.GpuImpg.from_paf(path)
+    rl = random_ranges(3, 240, g.num_seqs(), 20000, max_len=3000, min_len=120)
+    kws = [dict(), dict(transitive=True, max_depth=3, min_transitive_len=20), dict(transitive=True, dfs=True, max_depth=2),
+           dict(transitive=True, max_depth=2, multi_impg=True)]
+    want = {}
+    for k, kw in enumerate(kws):
+        res = g.query_batch(rl, impg_amd.make_params(**kw))
+        want[k] = [res[i].tolist() for i in range(len(rl))]
+    errs = []
+
+    def worker(tid):
+        try:
+            for rep in range(6):
+                k = (tid + rep) % len(kws)
+                lo = (tid * 17 + rep * 31) % 200
+                res = g.query_batch(rl[lo:lo + 40], impg_amd.make_params(**kws[k]))
+                for i in range(40):
+                    assert res[i].tolist() == want[k][lo + i], (tid, rep, k, i)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[:3]

@@ -50,7 +50,8 @@ def main():
     ap.add_argument("--ranges", type=int, default=100_000, help="query ranges per GPU")
     ap.add_argument("--max-depth", type=int, default=3)
     ap.add_argument("--no-transitive", action="store_true")
-    ap.add_argument("--chunk-ranges", type=int, default=50000)
+    ap.add_argument("--chunk-ranges", type=int, default=None,
+                    help="ranges per chunk (default 50000 on one GPU; 25000 per rank on a sharded index: two chunks per lane)")
     ap.add_argument("--pair-budget", type=int, default=1 << 30)
     ap.add_argument("--cpu-sample", type=int, default=1000, help="ranges timed on the CPU oracle, ~15 s of CPU work (0 = skip)")
     ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=VALUE",
@@ -79,6 +80,8 @@ def main():
     import torch
 
     import impg_amd
+    if args.chunk_ranges is None:
+        args.chunk_ranges = 25000 if (args.gpus > 1 or args.force_sharded) else 50000
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -42,7 +42,8 @@ class Params(C.Structure):
     _fields_ = [("transitive", C.c_int32), ("dfs", C.c_int32), ("max_depth", C.c_uint32),
                 ("min_transitive_len", C.c_int32), ("min_distance_between_ranges", C.c_int32),
                 ("min_output_length", C.c_int32), ("min_identity", C.c_double),
-                ("store_cigar", C.c_int32), ("multi_impg", C.c_int32), ("original_sequence_coordinates", C.c_int32)]
+                ("store_cigar", C.c_int32), ("multi_impg", C.c_int32), ("original_sequence_coordinates", C.c_int32),
+                ("consider_strandness", C.c_int32)]
 
 
 class Stats(C.Structure):

@@ -164,7 +164,7 @@ void render_bed(const impg_gpu_results &res, const impg_gpu_index &ix, const cha
                 v.end());
       }
       gap_2d(v, merge_distance);
-      merge_query_axis(v, merge_distance, true);  // merge_strands_for_output("bed") (main.rs:4395-4409)
+      merge_query_axis(v, merge_distance, !p.consider_strandness);  // merge_strands_for_output("bed") (main.rs:4395-4409)
       std::string &s = parts[i];
       std::string fallback;
       const char *rn = range_names ? range_names[i] : nullptr;

@@ -3,6 +3,7 @@
 // defaults, same validation order, same bytes on stdout; every BED row of a
 // `-b` file goes to the GPU in ONE batch instead of the reference's serial loop
 // (main.rs:7435).
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -93,7 +94,7 @@ void usage() {
           "impg-gpu query (-a <paf>... | -i <file>) (-r seq:start-end | -b <bed>) (-d <bp> | --no-merge) [-x] [-m N]\n"
           "               [--transitive-dfs] [--multi-impg] [--min-transitive-len N] [--min-distance-between-ranges N]\n"
           "               [-l N] [--min-result-identity F] [--subset-sequence-list FILE] [--original-sequence-coordinates]\n"
-          "               [-o auto|bed|bedpe|paf] [--unidirectional] [--order coitrees|sorted]\n"
+          "               [--consider-strandness] [-o auto|bed|bedpe|paf] [--unidirectional] [--order coitrees|sorted]\n"
           "               [--device N]\n");
 }
 
@@ -116,6 +117,22 @@ int main(int argc, char **argv) {
   bool original_coords = false;  // main.rs:4370
   std::string subset_list;  // --subset-sequence-list: a file of sequence names (main.rs:4357, :11709-11720)
   int device = 0, order = IMPG_ORDER_COITREES;
+  // numeric options are parsed whole or refused, as clap does for the reference (a typo must not become 0 = "unlimited")
+  auto num = [](const std::string &flag, const char *v, long lo, long hi) -> long {
+    char *end = nullptr;
+    errno = 0;
+    const long x = strtol(v, &end, 10);
+    if (errno || end == v || *end != '\0' || x < lo || x > hi) die("invalid value '" + std::string(v) + "' for '" + flag + "'", 2);
+    return x;
+  };
+  auto real = [](const std::string &flag, const char *v) -> double {
+    char *end = nullptr;
+    errno = 0;
+    const double x = strtod(v, &end);
+    if (errno || end == v || *end != '\0' || !(x == x)) die("invalid value '" + std::string(v) + "' for '" + flag + "'", 2);
+    return x;
+  };
+  bool consider_strandness = false;  // main.rs:4380
   for (int i = 2; i < argc; i++) {
     std::string a = argv[i];
     auto need = [&](const char *f) -> const char * {
@@ -134,19 +151,24 @@ int main(int argc, char **argv) {
     else if (a == "-x" || a == "--transitive") transitive = true;
     else if (a == "--transitive-dfs") dfs = true;
     else if (a == "--multi-impg") multi = true;  // per-file indices (the reference's MultiImpg, src/multi_impg.rs)
-    else if (a == "-m" || a == "--max-depth") max_depth = atol(need("-m"));
-    else if (a == "--min-transitive-len") min_tl = atol(need(a.c_str()));
-    else if (a == "--min-distance-between-ranges") mdbr = atol(need(a.c_str()));
-    else if (a == "-l" || a == "--min-output-length") min_out = atol(need("-l"));
-    else if (a == "--min-result-identity") min_ident = atof(need(a.c_str()));
+    else if (a == "-m" || a == "--max-depth") max_depth = num(a, need("-m"), 0, 65535);           // u16 (main.rs:4263)
+    else if (a == "--min-transitive-len") min_tl = num(a, need(a.c_str()), 0, 2147483647);
+    else if (a == "--min-distance-between-ranges") mdbr = num(a, need(a.c_str()), 0, 2147483647);
+    else if (a == "-l" || a == "--min-output-length") min_out = num(a, need("-l"), 0, 2147483647);
+    else if (a == "--min-result-identity") min_ident = real(a, need(a.c_str()));
+    else if (a == "--consider-strandness") consider_strandness = true;
     else if (a == "--subset-sequence-list") subset_list = need(a.c_str());
     else if (a == "--original-sequence-coordinates") original_coords = true;
     else if (a == "-o" || a == "--output-format") ofmt = need("-o");
     else if (a == "--unidirectional") unidirectional = true;
-    else if (a == "--device") device = atoi(need(a.c_str()));
-    else if (a == "--order") { std::string o = need("--order"); order = o == "sorted" ? IMPG_ORDER_SORTED : IMPG_ORDER_COITREES; }
+    else if (a == "--device") device = (int)num(a, need(a.c_str()), 0, 1023);
+    else if (a == "--order") {
+      std::string o = need("--order");
+      if (o != "sorted" && o != "coitrees") die("invalid value '" + o + "' for '--order'", 2);
+      order = o == "sorted" ? IMPG_ORDER_SORTED : IMPG_ORDER_COITREES;
+    }
     else if (a == "-i" || a == "--index") index_file = need("-i");
-    else if (a == "-v" || a == "--verbose") verbose = atoi(need(a.c_str()));  // >= 1: phase timings on stderr
+    else if (a == "-v" || a == "--verbose") verbose = (int)num(a, need(a.c_str()), 0, 9);  // >= 1: phase timings on stderr
     else if (a == "-t" || a == "--threads") need(a.c_str());  // accepted, unused
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else die("unexpected argument '" + a + "'", 2);
@@ -169,7 +191,6 @@ int main(int argc, char **argv) {
   if (!have_d && !no_merge)  // MERGE_DISTANCE_REQUIRED_TEXT (main.rs:4288-4315)
     die("-d/--merge-distance is required. For `impg query`, pass `-d <bp>`. Use `--no-merge` to explicitly disable merging.");
   const int32_t merge_distance = no_merge ? -1 : (int32_t)merge_d;
-  if (max_depth < 0 || max_depth > 65535) die("invalid value for '--max-depth'", 2);
   // -o auto: bed for -r, bedpe for -b (main.rs:7365-7373)
   std::string fmt = ofmt == "auto" ? (bed.empty() ? "bed" : "bedpe") : ofmt;
   if (fmt != "bed" && fmt != "bedpe" && fmt != "paf")
@@ -178,9 +199,13 @@ int main(int argc, char **argv) {
   std::vector<const char *> pp;
   for (auto &p : pafs) pp.push_back(p.c_str());
   impg_gpu_index_t *ix = nullptr;
+  bool loaded = false;
   if (load_saved) {
-    if (impg_gpu_index_load(index_file.c_str(), device, &ix) != IMPG_OK) die(impg_gpu_last_error());
-  } else {
+    if (impg_gpu_index_load(index_file.c_str(), device, &ix) == IMPG_OK) loaded = true;
+    else if (pafs.empty()) die(impg_gpu_last_error());
+    else fprintf(stderr, "[impg-gpu] %s: %s -- rebuilding it from the alignment files\n", index_file.c_str(), impg_gpu_last_error());
+  }
+  if (!loaded) {
     if (impg_gpu_index_create_from_paf(pp.data(), (int)pp.size(), unidirectional ? 0 : 1, order, device, &ix) != IMPG_OK)
       die(impg_gpu_last_error());
     if (!index_file.empty() && impg_gpu_index_save(ix, index_file.c_str()) != IMPG_OK) die(impg_gpu_last_error());
@@ -190,8 +215,15 @@ int main(int argc, char **argv) {
   if (!range.empty()) {
     char name[4096];
     int32_t s, e;
-    if (impg_gpu_parse_target_range(range.c_str(), name, sizeof name, &s, &e) != IMPG_OK) die(impg_gpu_last_error());
-    targets.push_back({name, std::string(name) + ":" + std::to_string(s) + "-" + std::to_string(e), s, e});
+    if (range.find(':') == std::string::npos) {  // no interval: the whole sequence [0, len) (main.rs:7290-7310)
+      const long long id = impg_gpu_seq_id(ix, range.c_str());
+      if (id < 0) die("Sequence '" + range + "' not found in index");
+      const long long len = impg_gpu_seq_len(ix, (uint32_t)id);
+      targets.push_back({range, range + ":0-" + std::to_string(len), 0, (int32_t)len});
+    } else {
+      if (impg_gpu_parse_target_range(range.c_str(), name, sizeof name, &s, &e) != IMPG_OK) die(impg_gpu_last_error());
+      targets.push_back({name, std::string(name) + ":" + std::to_string(s) + "-" + std::to_string(e), s, e});
+    }
   } else {
     targets = parse_bed_file(bed);
   }
@@ -225,6 +257,7 @@ int main(int argc, char **argv) {
   p.min_identity = min_ident;
   p.store_cigar = fmt != "bed";  // CIGARs for PAF / BEDPE only (main.rs:7447)
   p.original_sequence_coordinates = original_coords;
+  p.consider_strandness = consider_strandness;
   impg_gpu_results_t *res = nullptr;
   std::vector<uint8_t> keep;
   if (!subset_list.empty()) {  // load_subset_filter (subset_filter.rs:63-82) + one matches() per sequence

@@ -4,6 +4,8 @@
 // done once.  The reference's file stores byte offsets into the PAF and re-reads the CIGAR text on demand; this one
 // stores the tokenised, tiled ops themselves, so a load is one read + one host-to-device copy per array and the PAF
 // is not needed again.  The two formats are not interchangeable.
+#include <unistd.h>
+
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
@@ -14,7 +16,7 @@ namespace impg {
 namespace {
 
 constexpr char MAGIC[8] = {'I', 'M', 'P', 'G', 'H', 'B', 'M', '1'};
-constexpr uint32_t VERSION = 1;
+constexpr uint32_t VERSION = 2;  // 2: checksum of the arrays behind the end mark
 
 struct Header {  // fixed-size, little-endian (gfx950 hosts are x86-64)
   char magic[8];
@@ -39,6 +41,19 @@ struct File {
   }
 };
 
+uint64_t fnv64(uint64_t h, const void *p, size_t n) {  // FNV-1a over 8-byte words (+ the tail bytes): damage inside an array is caught
+  const unsigned char *b = static_cast<const unsigned char *>(p);
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, b + i, 8);
+    h = (h ^ w) * 0x100000001B3ull;
+  }
+  for (; i < n; i++) h = (h ^ b[i]) * 0x100000001B3ull;
+  return h;
+}
+constexpr uint64_t FNV_SEED = 0xCBF29CE484222325ull;
+
 }  // namespace
 
 void save_index(const impg_gpu_index &cix, const char *path) {
@@ -53,7 +68,15 @@ void save_index(const impg_gpu_index &cix, const char *path) {
   h.n_records = ix.n_records; h.n_entries = ix.n_entries; h.n_tiles = ix.n_tiles; h.n_targets = ix.n_targets;
   h.n_names = ix.seq.names.size(); h.n_file_first = ix.file_first.size(); h.n_tgt_off = ix.h_tgt_off.size();
   for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) h.blob_bytes[k] = ix.blob_bytes[k];
-  File out(path, "wb");
+  // written next to the target and renamed over it: an interrupted save never leaves a truncated cache behind
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
+  struct Unlink {
+    const std::string &p;
+    bool keep = false;
+    ~Unlink() { if (!keep) (void)unlink(p.c_str()); }
+  } guard{tmp};
+  File out(tmp.c_str(), "wb");
+  uint64_t sum = FNV_SEED;
   out.write(&h, sizeof h);
   out.write(ix.seq.lens.data(), ix.seq.lens.size() * sizeof(int64_t));
   for (const std::string &nm : ix.seq.names) {
@@ -68,11 +91,17 @@ void save_index(const impg_gpu_index &cix, const char *path) {
     const size_t n = ix.blob_bytes[k];
     buf.resize(n);
     if (n) IMPG_HIP(hipMemcpy(buf.data(), ix.blob(k)->p, n, hipMemcpyDeviceToHost));
+    sum = fnv64(sum, buf.data(), n);
     out.write(buf.data(), n);
   }
   const uint64_t tail = 0x454E44474D50ull ^ h.n_entries;  // an end mark: a file cut short is caught even if sizes line up
   out.write(&tail, 8);
-  if (fflush(out.f) != 0) throw Error{IMPG_E_IO, "cannot flush " + out.path};
+  out.write(&sum, 8);
+  if (fflush(out.f) != 0 || fsync(fileno(out.f)) != 0) throw Error{IMPG_E_IO, "cannot flush " + out.path};
+  fclose(out.f);
+  out.f = nullptr;
+  if (rename(tmp.c_str(), path) != 0) throw Error{IMPG_E_IO, std::string("cannot rename onto ") + path + ": " + strerror(errno)};
+  guard.keep = true;
 }
 
 void load_index(impg_gpu_index &ix, const char *path) {
@@ -84,6 +113,25 @@ void load_index(impg_gpu_index &ix, const char *path) {
       h.entry_bytes != sizeof(Entry))
     throw Error{IMPG_E_UNSUPPORTED, in.path + " was written by a build with a different index layout: rebuild it"};
   if (h.n_names != 0 && h.n_names != h.n_seq) throw Error{IMPG_E_INVALID, in.path + ": inconsistent sequence table"};
+  // every array's size follows from the counts in the header: check them all before anything is allocated or uploaded
+  {
+    if (fseek(in.f, 0, SEEK_END) != 0) throw Error{IMPG_E_IO, "cannot seek in " + in.path};
+    const uint64_t file_bytes = (uint64_t)ftell(in.f);
+    if (fseek(in.f, (long)sizeof h, SEEK_SET) != 0) throw Error{IMPG_E_IO, "cannot seek in " + in.path};
+    const uint64_t E = h.n_entries, T = h.n_tiles, S = h.n_seq;
+    if (S > 0x7FFFFFFFull || E >= 0xFFFFFFF0ull || T >= 0xFFFFFFF0ull || S * 8 > file_bytes)
+      throw Error{IMPG_E_INVALID, in.path + ": counts out of range"};
+    const uint64_t want[impg_gpu_index::N_BLOBS] = {S * sizeof(SegDesc), E * 4, E * 4, E * 4, E * 4, h.blob_bytes[5], h.blob_bytes[5],
+                                                    E * 4, h.multi_file ? E * 4 : 0, E * sizeof(Entry), T * TILE_WORDS * 4,
+                                                    h.blob_bytes[11], T * TILE_SUBS * 16, S * 4};
+    uint64_t total = 0;
+    for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) {
+      if (h.blob_bytes[k] != want[k] || (h.blob_bytes[k] & 3)) throw Error{IMPG_E_INVALID, in.path + ": array sizes do not match the header"};
+      total += h.blob_bytes[k];
+    }
+    if (total > file_bytes) throw Error{IMPG_E_INVALID, in.path + " is truncated"};
+    if (h.n_tgt_off != 0 && h.n_tgt_off != S + 1) throw Error{IMPG_E_INVALID, in.path + ": bad table sizes"};
+  }
   IMPG_HIP(hipSetDevice(ix.device));
   ix.n_records = h.n_records; ix.n_entries = h.n_entries; ix.n_tiles = h.n_tiles; ix.n_targets = h.n_targets;
   ix.multi_file = h.multi_file != 0;
@@ -105,13 +153,28 @@ void load_index(impg_gpu_index &ix, const char *path) {
   in.read(ix.file_first.data(), h.n_file_first * sizeof(uint64_t));
   ix.h_tgt_off.resize(h.n_tgt_off);
   in.read(ix.h_tgt_off.data(), h.n_tgt_off * sizeof(uint32_t));
+  for (size_t i = 0; i < ix.h_tgt_off.size(); i++)
+    if ((i && ix.h_tgt_off[i] < ix.h_tgt_off[i - 1]) || ix.h_tgt_off[i] > h.n_entries || (i == 0 && ix.h_tgt_off[0] != 0))
+      throw Error{IMPG_E_INVALID, in.path + ": target offsets are not ascending within the entry count"};
+  if (!ix.h_tgt_off.empty() && ix.h_tgt_off.back() != h.n_entries) throw Error{IMPG_E_INVALID, in.path + ": target offsets do not end at the entry count"};
   std::vector<char> buf;
   size_t acc = 0;
+  uint64_t sum = FNV_SEED;
   for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) {
     const size_t n = h.blob_bytes[k];
     if (n > (1ull << 40)) throw Error{IMPG_E_INVALID, in.path + ": unreasonable array size"};
     buf.resize(n);
     in.read(buf.data(), n);
+    sum = fnv64(sum, buf.data(), n);
+    if (k == 0) {  // the segment table addresses every other array: it must stay inside them
+      const SegDesc *sg = reinterpret_cast<const SegDesc *>(buf.data());
+      const uint64_t lvl_words = h.blob_bytes[5] / 4;
+      for (uint32_t t = 0; t < h.n_seq; t++) {
+        bool ok = (uint64_t)sg[t].a + sg[t].n <= h.n_entries && sg[t].nlev <= (uint32_t)MAX_LEVELS;
+        for (uint32_t l = 0; ok && l < sg[t].nlev; l++) ok = (uint64_t)sg[t].off[l] + sg[t].cnt[l] <= lvl_words;
+        if (!ok) throw Error{IMPG_E_INVALID, in.path + ": a segment points outside the arrays"};
+      }
+    }
     DevBuf &b = *ix.blob(k);
     if (n || k != 8) b.reserve(std::max<size_t>(n + 64, 256));  // (array 8, mrank, only exists for several files)
     if (n) IMPG_HIP(hipMemcpy(b.p, buf.data(), n, hipMemcpyHostToDevice));
@@ -121,9 +184,9 @@ void load_index(impg_gpu_index &ix, const char *path) {
   uint64_t tail = 0;
   in.read(&tail, 8);
   if (tail != (0x454E44474D50ull ^ h.n_entries)) throw Error{IMPG_E_INVALID, in.path + " is damaged (end mark)"};
-  if (ix.blob_bytes[9] != h.n_entries * sizeof(Entry) || ix.blob_bytes[13] != (size_t)h.n_seq * 4 ||
-      ix.blob_bytes[10] != h.n_tiles * TILE_WORDS * 4)
-    throw Error{IMPG_E_INVALID, in.path + ": array sizes do not match the header"};
+  uint64_t want_sum = 0;
+  in.read(&want_sum, 8);
+  if (want_sum != sum) throw Error{IMPG_E_INVALID, in.path + " is damaged (checksum of the arrays)"};
   ix.device_bytes = acc;
   ix.bind_view(h.n_seq, h.sorted_order);
 }

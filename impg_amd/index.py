@@ -14,12 +14,12 @@ from ._lib import INTERVAL_DTYPE, RANGE_DTYPE, RECORD_DTYPE, Params, Stats, chec
 
 def make_params(transitive=False, dfs=False, max_depth=2, min_transitive_len=101, min_distance_between_ranges=10,
                 min_output_length=None, min_identity=None, store_cigar=False, multi_impg=False,
-                original_sequence_coordinates=False):
+                original_sequence_coordinates=False, consider_strandness=False):
     """CLI defaults of src/main.rs:4259-4285."""
     return Params(int(transitive), int(dfs), max_depth, min_transitive_len, min_distance_between_ranges,
                   -1 if min_output_length is None else min_output_length,
                   math.nan if min_identity is None else float(min_identity), int(store_cigar), int(multi_impg),
-                  int(original_sequence_coordinates))
+                  int(original_sequence_coordinates), int(consider_strandness))
 
 
 class QueryResults:

@@ -81,6 +81,8 @@ typedef struct {
                                           coordinates (transform_coordinates_to_original, main.rs:4642-4678); PAF
                                           sequence lengths are then 0, as the reference prints them when it has no
                                           sequence files to ask (get_original_sequence_length, main.rs:4681-4704) */
+  int32_t consider_strandness;         /* BED writer only (--consider-strandness, main.rs:4380): 1 keeps the two strands
+                                          apart in the query-axis merge (merge_strands_for_output, main.rs:4395-4409) */
 } impg_gpu_params_t;
 
 /* Order in which overlapping entries of one target are visited; it fixes the

@@ -45,6 +45,7 @@
 
 namespace {
 
+std::atomic<int> g_sorted_visits{0}; /* oracle_set_sorted_visits */
 thread_local std::string g_err;
 thread_local uint64_t g_nproj = 0;
 
@@ -428,7 +429,16 @@ struct COITree {
     }
   }
   template <class F> void query(int32_t first, int32_t last, F visit) const {
-    if (!nodes.empty()) query_recursion(0, nodes.size(), first, last, visit);
+    if (nodes.empty()) return;
+    if (g_sorted_visits) { /* NOT the reference: the engine's IMPG_ORDER_SORTED policy (ascending start, ties in
+                              input order), so that both order policies have an exact checker */
+      for (const IvNode &nd : nodes) {
+        if (last < nd.first) break;
+        if (first <= nd.last) visit(nd);
+      }
+      return;
+    }
+    query_recursion(0, nodes.size(), first, last, visit);
   }
 };
 
@@ -1222,6 +1232,7 @@ oracle_index *finish_index(oracle_index *ix, std::vector<std::vector<AlignmentRe
 extern "C" {
 
 const char *oracle_last_error(void) { return g_err.c_str(); }
+void oracle_set_sorted_visits(int on) { g_sorted_visits = on ? 1 : 0; }
 uint64_t oracle_last_projection_count(void) { return g_nproj; }
 
 long oracle_parse_cigar(const char *cigar, size_t len, uint32_t *ops_out, size_t cap) {
@@ -1800,6 +1811,15 @@ long oracle_bed_merge(oracle_interval_t *iv, size_t n, int32_t merge_distance, i
   return (long)v.size();
 }
 
+/* merge_query_adjusted_intervals alone (main.rs:12474-12560): what the reference's own test
+ * test_syng_gfa_intervals_are_merged_before_graph_build (main.rs:13655-13698) drives */
+long oracle_merge_query(oracle_interval_t *iv, size_t n, int32_t merge_distance, int merge_strands) {
+  std::vector<oracle_interval_t> v(iv, iv + n);
+  merge_query_adjusted_intervals(v, merge_distance, merge_strands != 0);
+  std::copy(v.begin(), v.end(), iv);
+  return (long)v.size();
+}
+
 int oracle_query_bed(const oracle_index_t *ix, const char *target_name, int32_t start, int32_t end,
                      const char *range_name, const oracle_params_t *p, int32_t merge_distance,
                      char **buf, size_t *len, size_t *cap) {
@@ -1826,7 +1846,7 @@ int oracle_query_bed(const oracle_index_t *ix, const char *target_name, int32_t 
   }
   /* output_results_bed (main.rs:11849-11892), merge_strands_for_output("bed") = true */
   merge_adjusted_intervals_gap_2d(v, merge_distance);
-  merge_query_adjusted_intervals(v, merge_distance, true);
+  merge_query_adjusted_intervals(v, merge_distance, !p->consider_strandness); /* merge_strands_for_output("bed"), main.rs:4395-4409 */
   for (auto &x : v) {
     const std::string &qn = ix->seq_index.id_to_name[x.query_id];
     int32_t first, last; char strand;

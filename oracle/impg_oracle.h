@@ -47,6 +47,7 @@ typedef struct {
   int32_t store_cigar;
   int32_t multi_impg;        /* 1 = MultiImpg semantics (multi_impg.rs) */
   int32_t original_sequence_coordinates; /* text writers only: --original-sequence-coordinates (main.rs:4370) */
+  int32_t consider_strandness;           /* BED writer only: --consider-strandness (main.rs:4380, :4395-4409) */
 } oracle_params_t;
 
 /* ---- leaf functions (known-answer tested) ------------------------------ */
@@ -149,6 +150,11 @@ long oracle_query_cigar(const oracle_index_t *, uint32_t target_id, int32_t star
                         size_t cap, uint64_t *cigar_off, uint32_t *cigar_ops,
                         size_t ops_cap, uint64_t *n_ops);
 
+/* Process-wide switch, off by default: overlapping entries of a target are visited in ascending start (ties in
+ * input order) instead of the coitrees order.  This is NOT reference behaviour; it is the checker of the engine's
+ * IMPG_ORDER_SORTED policy and lets tests measure what the visit order can change. */
+void oracle_set_sorted_visits(int on);
+
 /* number of Some(..) projections performed by the last oracle_query on this
  * thread (the work unit of BASELINE.md section 3). */
 uint64_t oracle_last_projection_count(void);
@@ -159,6 +165,9 @@ uint64_t oracle_last_projection_count(void);
  * Returns the new count. */
 long oracle_bed_merge(oracle_interval_t *iv, size_t n, int32_t merge_distance,
                       int merge_strands);
+/* merge_query_adjusted_intervals alone (main.rs:12474-12560) */
+long oracle_merge_query(oracle_interval_t *iv, size_t n, int32_t merge_distance,
+                        int merge_strands);
 
 /* perform_query + output_results_bed for one target range; appends BED text to
  * a malloc'ed buffer (*buf,*len,*cap grow).  Returns 0 or <0. */

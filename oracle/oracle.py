@@ -27,18 +27,21 @@ class Params(C.Structure):
     _fields_ = [("transitive", C.c_int32), ("dfs", C.c_int32), ("max_depth", C.c_uint32),
                 ("min_transitive_len", C.c_int32), ("min_distance_between_ranges", C.c_int32),
                 ("min_output_length", C.c_int32), ("min_identity", C.c_double),
-                ("store_cigar", C.c_int32), ("multi_impg", C.c_int32), ("original_sequence_coordinates", C.c_int32)]
+                ("store_cigar", C.c_int32), ("multi_impg", C.c_int32), ("original_sequence_coordinates", C.c_int32),
+                ("consider_strandness", C.c_int32)]
 
 
 def make_params(transitive=False, dfs=False, max_depth=2, min_transitive_len=101,
                 min_distance_between_ranges=10, min_output_length=None, min_identity=None,
-                store_cigar=False, multi_impg=False, original_sequence_coordinates=False):
+                store_cigar=False, multi_impg=False, original_sequence_coordinates=False,
+                consider_strandness=False):
     """Defaults are the reference CLI's (main.rs:4259-4285)."""
     return Params(int(transitive), int(dfs), max_depth, min_transitive_len,
                   min_distance_between_ranges,
                   -1 if min_output_length is None else min_output_length,
                   math.nan if min_identity is None else float(min_identity),
-                  int(store_cigar), int(multi_impg), int(original_sequence_coordinates))
+                  int(store_cigar), int(multi_impg), int(original_sequence_coordinates),
+                  int(consider_strandness))
 
 
 def parse_subsequence(name):
@@ -386,6 +389,20 @@ class OracleIndex:
         if rc != 0:
             raise RuntimeError(lib().oracle_last_error().decode())
         return npj.value, nr.value, sec.value
+
+
+def set_sorted_visits(on):
+    """oracle_set_sorted_visits: process-wide; the checker of the engine's IMPG_ORDER_SORTED policy."""
+    lib().oracle_set_sorted_visits(int(bool(on)))
+
+
+def merge_query(intervals, merge_distance, merge_strands=True):
+    a = np.ascontiguousarray(intervals, dtype=INTERVAL_DTYPE).copy()
+    f = lib().oracle_merge_query
+    f.restype = C.c_long
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int]
+    n = f(a.ctypes.data, a.size, merge_distance, int(merge_strands))
+    return a[:n].copy()
 
 
 def bed_merge(intervals, merge_distance, merge_strands=True):

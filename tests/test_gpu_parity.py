@@ -852,3 +852,64 @@ def test_parallel_result_assembly(tmp_path):
             assert big[i].tolist() == want.tolist()
             assert [x.tolist() for x in big.cigars(i)] == [x.tolist() for x in wcg]
             assert [x.tolist() for x in small.cigars(i)] == [x.tolist() for x in wcg]
+
+
+@pytest.mark.parametrize("order", [impg_amd.ORDER_COITREES, impg_amd.ORDER_SORTED])
+def test_adversarial_visit_order_equal_starts(tmp_path, order):
+    """Targets with 9..64 (and a few larger) entries, most of them sharing their start: the visit order is then
+    decided by the tie rule (input order) and by the order policy alone.  The transitive results depend on it
+    through the order-dependent visited-set update (impg.rs:2471-2560); both policies have an exact checker
+    (the oracle's coitrees restatement / its sorted-visits switch)."""
+    rng = np.random.default_rng(99)
+    lines, sizes = [], list(range(9, 65)) + [65, 100, 129, 500]
+    for k, n in enumerate(sizes):
+        tname = "T%d" % k
+        starts = rng.choice([100, 100, 100, 400, 400, 900], size=n)
+        for i in range(n):
+            ts = int(starts[i])
+            ln = int(rng.integers(150, 1200))
+            qs = int(rng.integers(0, 50000))
+            q = "T%d" % int(rng.integers(0, len(sizes)))
+            if q == tname:
+                q = "T%d" % ((k + 1) % len(sizes))
+            lines.append("%s\t60000\t%d\t%d\t%s\t%s\t60000\t%d\t%d\t1\t1\t60\tcg:Z:%d=" %
+                         (q, qs, qs + ln, "+-"[i % 2], tname, ts, ts + ln, ln))
+    o.set_sorted_visits(order == impg_amd.ORDER_SORTED)
+    try:
+        g, c = both(tmp_path, "\n".join(lines) + "\n", order=order, bidirectional=False)
+        ranges = []
+        for k in range(len(sizes)):
+            tid = g.seq_id("T%d" % k)
+            ranges += [(tid, 0, 2000), (tid, 350, 450), (tid, 90, 110)]
+        assert_same(g, c, ranges)
+        assert_same(g, c, ranges, transitive=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=50)
+        assert_same(g, c, ranges, transitive=True, dfs=True, max_depth=2, min_transitive_len=20)
+        g2, c2 = both(tmp_path, "\n".join(lines) + "\n", order=order, bidirectional=True)
+        assert_same(g2, c2, ranges[:60], transitive=True, max_depth=2, min_transitive_len=50, min_distance_between_ranges=200)
+    finally:
+        o.set_sorted_visits(False)
+
+
+def test_cli_whole_sequence_strandness_and_stale_cache(tmp_path):
+    """`-r name` without an interval is the whole sequence (main.rs:7290-7310); --consider-strandness keeps the
+    strands apart in the BED merge (main.rs:4395-4409); a damaged -i cache is rebuilt from -a instead of
+    failing every later run."""
+    import os, subprocess
+    text, names = random_paf(61, 200, n_seq=4, seq_len=20000)
+    paf = str(tmp_path / "c.paf")
+    open(paf, "w").write(text)
+    cli = os.path.join(os.path.dirname(impg_amd.__file__), "impg-gpu")
+    c = o.OracleIndex(paf_paths=[paf], preparse=True)
+    for extra, kw in (([], dict()), (["--consider-strandness"], dict(consider_strandness=True)),
+                      (["-x", "-m", "2", "--consider-strandness"], dict(transitive=True, max_depth=2, consider_strandness=True))):
+        r = subprocess.run([cli, "query", "-a", paf, "-r", "s1", "-d", "50", "-o", "bed"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == c.query_bed("s1", 0, 20000, "s1:0-20000", 50, o.make_params(**kw)), extra
+    cache = str(tmp_path / "cache.idx")
+    open(cache, "wb").write(b"IMPGHBM1" + bytes(100))  # a truncated / foreign cache file
+    r = subprocess.run([cli, "query", "-a", paf, "-i", cache, "-r", "s2:100-5000", "-d", "0", "-o", "bed"], capture_output=True, text=True)
+    assert r.returncode == 0 and "rebuilding" in r.stderr
+    assert r.stdout == c.query_bed("s2", 100, 5000, "s2:100-5000", 0, o.make_params())
+    r2 = subprocess.run([cli, "query", "-i", cache, "-r", "s2:100-5000", "-d", "0", "-o", "bed"], capture_output=True, text=True)
+    assert r2.returncode == 0 and r2.stdout == r.stdout and "rebuilding" not in r2.stderr  # the rewritten cache loads
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]

@@ -187,6 +187,12 @@ def test_cli_merge_distance_vectors_rejected_before_any_device_work():
     for bad in (["-d", "10kb"], ["-d", "3g"], ["-d", "-5"], ["-d", "abc"]):
         r = subprocess.run([cli, "query", "-a", "x.paf", "-r", "s:1-200"] + bad, capture_output=True, text=True)
         assert r.returncode != 0 and r.stdout == "" and r.stderr.startswith("Error:"), bad
+    # numeric options are parsed whole or refused (clap does the same for the reference): a typo must not become
+    # 0, which for -m means "unlimited depth"
+    for bad in (["-m", "x"], ["-m", "3x"], ["-m", "70000"], ["--min-transitive-len", "foo"], ["-l", "1e3"],
+                ["--min-result-identity", "high"], ["--min-distance-between-ranges", "-1"], ["--order", "random"]):
+        r = subprocess.run([cli, "query", "-a", "x.paf", "-r", "s:1-200", "-d", "0"] + bad, capture_output=True, text=True)
+        assert r.returncode == 2 and r.stdout == "" and "invalid value" in r.stderr, (bad, r.stderr)
 
 
 def test_parse_subsequence_reference_kat():

@@ -414,3 +414,23 @@ SUBSEQ_KAT = [("HG002#1#chr1:5116130-6116563", ("HG002#1#chr1", 5116130)), ("GRC
 def test_parse_subsequence_coordinates():
     for name, want in SUBSEQ_KAT:
         assert o.parse_subsequence(name) == want
+
+
+def test_merge_query_reference_vector():
+    """test_syng_gfa_intervals_are_merged_before_graph_build (main.rs:13655-13698): two forward query intervals
+    [10,100) and [150,220) on one sequence, both against target [0,300); merge_query_adjusted_intervals with
+    distance 100 gives one [10,220], with distance 10 leaves two."""
+    iv = np.zeros(2, dtype=o.INTERVAL_DTYPE)
+    iv["query_id"] = 1
+    iv["q_first"], iv["q_last"] = [10, 150], [100, 220]
+    iv["target_id"], iv["t_first"], iv["t_last"] = 0, 0, 300
+    merged = o.merge_query(iv, 100, True)
+    assert len(merged) == 1 and (int(merged[0]["q_first"]), int(merged[0]["q_last"])) == (10, 220)
+    assert len(o.merge_query(iv, 10, True)) == 2
+    # the same through the engine's host-side merge (BED path: gap_2d chain, then the query-axis sweep)
+    import impg_amd
+    for d in (100, 10):
+        got = impg_amd.index.bed_merge(iv.astype(impg_amd.INTERVAL_DTYPE), d, True)
+        want = o.bed_merge(iv, d, True)
+        assert got.tolist() == want.tolist()
+    assert len(impg_amd.index.bed_merge(iv.astype(impg_amd.INTERVAL_DTYPE), 100, True)) == 1

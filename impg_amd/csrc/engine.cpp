@@ -269,11 +269,13 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       pieces.reserve(std::max<size_t>(pcap_total * 8, 256));
       n_pieces.reserve((size_t)n_groups * 4);
       foff.reserve((size_t)n_groups * 4);
+      big_list.reserve((size_t)n_groups * 4);
       launch_visited_update(tabs, svals.as<unsigned long long>(), masked ? mask_touch_len.as<int32_t>() : v.seq_len, vt->keys.as<unsigned long long>(),
                             gstart.as<uint32_t>(), glen.as<uint32_t>(), old_tab.as<uint32_t>(), old_idx.as<uint32_t>(),
                             vt->off.as<uint32_t>(), poff.as<uint32_t>(), n_groups, p.min_transitive_len,
                             p.min_distance_between_ranges, vt->ranges.as<int2>(), vt->len.as<uint32_t>(),
-                            pieces.as<int2>(), n_pieces.as<uint32_t>(), stream);
+                            pieces.as<int2>(), n_pieces.as<uint32_t>(), cap.as<uint32_t>(), big_list.as<uint32_t>(),
+                            (uint32_t *)(counters.as<uint64_t>() + 5), stream);
       uint64_t nn = scan(n_pieces.as<uint32_t>(), foff.as<uint32_t>(), n_groups);
       if (nn >= 0xFFFFFFF0ull) { if (split_ok) throw SplitBatch{}; throw Error{IMPG_E_UNSUPPORTED, "frontier exceeds 2^32 ranges"}; }
       n_next = (uint32_t)nn;

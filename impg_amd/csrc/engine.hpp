@@ -52,6 +52,7 @@ struct Engine {
   struct Timed { hipEvent_t a, b; int kind; };
   std::vector<Timed> timed;
   // scratch, grown on demand and reused across calls
+  DevBuf big_list;  // groups of a level whose visited list gets a whole wave
   DevBuf cnt, win, pair_off, pair_entry, scan_tmp, keys, skeys, vals, svals, sort_tmp, head, gid, gstart, glen, old_tab,
       old_idx, cap, pcap, poff, pieces, n_pieces, foff, frontier_a, frontier_b, self_scratch, ranges_dev, stat_count,
       stat_cksum, stage_off;

@@ -109,6 +109,7 @@ struct DeviceIndexView {  // passed by value to kernels
   uint32_t n_seq;
   uint32_t n_entries;
   uint32_t sorted_order;     // 1 = rank is the identity (IMPG_ORDER_SORTED)
+  uint32_t max_seg;          // entries of the largest segment: visit ranks stay below it
 };
 
 struct HostSeqIndex {  // SequenceIndex (seqidx.rs)

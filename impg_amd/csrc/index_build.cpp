@@ -474,4 +474,7 @@ void impg_gpu_index::bind_view(uint32_t n_seq, uint32_t sorted_order) {
   view.n_seq = n_seq;
   view.n_entries = (uint32_t)n_entries;
   view.sorted_order = sorted_order;
+  view.max_seg = 0;
+  for (size_t t = 0; t + 1 < h_tgt_off.size(); t++) view.max_seg = std::max(view.max_seg, h_tgt_off[t + 1] - h_tgt_off[t]);
+  if (h_tgt_off.empty()) view.max_seg = (uint32_t)n_entries;
 }

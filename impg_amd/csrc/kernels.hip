@@ -1125,25 +1125,68 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
+// Slots are in frontier order and every frontier is sorted by query, so the slots of one query are one run:
+// a whole wave, usually a whole block, adds to the same two words.  The wave sums first (a tiling batch at
+// depth 5 has 10^7 hits per query: one atomic per hit on one address ran at ~90 atomics/us, 95 % of the batch).
 __global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__restrict__ fr,
                                                         const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
                                                         HitArrays h, int32_t min_output_length, int skip_same_target,
                                                         unsigned long long *__restrict__ count,
                                                         unsigned long long *__restrict__ cksum) {
+  __shared__ uint32_t s_q[4];
+  __shared__ unsigned long long s_c[4], s_k[4];
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= n_pairs) return;
-  const uint32_t qid = h.qid[p];
-  if (qid == HIT_NONE) return;
-  const int4 hc = h.c[p];
-  const int32_t qs = hc.x, qe = hc.y;
-  if (min_output_length >= 0 && abs(qe - qs) < min_output_length) return;
-  const FrontierRec f = fr[pair_range[p]];
-  if (skip_same_target && qid == f.target_id) return;  // multi_impg.rs:883-885
-  unsigned long long a = mix64(((unsigned long long)qid << 32) | (uint32_t)qs);
-  a = mix64(a ^ (((unsigned long long)(uint32_t)qe << 32) | f.target_id));
-  a = mix64(a ^ (((unsigned long long)(uint32_t)hc.z << 32) | (uint32_t)hc.w));
-  if (count) atomicAdd(&count[f.qidx], 1ull);
-  if (cksum) atomicAdd(&cksum[f.qidx], a);
+  uint32_t qx = 0xFFFFFFFFu;
+  unsigned long long c = 0, a = 0;
+  if (p < n_pairs) {
+    const FrontierRec f = fr[pair_range[p]];
+    qx = f.qidx;
+    const uint32_t qid = h.qid[p];
+    if (qid != HIT_NONE) {
+      const int4 hc = h.c[p];
+      const int32_t qs = hc.x, qe = hc.y;
+      const bool drop = (min_output_length >= 0 && abs(qe - qs) < min_output_length) ||
+                        (skip_same_target && qid == f.target_id);  // multi_impg.rs:883-885
+      if (!drop) {
+        a = mix64(((unsigned long long)qid << 32) | (uint32_t)qs);
+        a = mix64(a ^ (((unsigned long long)(uint32_t)qe << 32) | f.target_id));
+        a = mix64(a ^ (((unsigned long long)(uint32_t)hc.z << 32) | (uint32_t)hc.w));
+        c = 1;
+      }
+    }
+  }
+  // one query for the whole wave? (lanes past the end carry 0xFFFFFFFF and nothing to add: they go along)
+  const unsigned long long live = __ballot(qx != 0xFFFFFFFFu);
+  const uint32_t q0 = live ? (uint32_t)__shfl((int)qx, __ffsll((long long)live) - 1) : 0xFFFFFFFFu;
+  const bool uniform = __all(qx == q0 || qx == 0xFFFFFFFFu);
+  if (!uniform) {
+    if (c) {
+      if (count) atomicAdd(&count[qx], 1ull);
+      if (cksum) atomicAdd(&cksum[qx], a);
+    }
+    if (lane_id() == 0) s_q[threadIdx.x >> 6] = 0xFFFFFFFFu;
+  } else {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      c += (unsigned long long)__shfl_xor((long long)c, o);
+      a += (unsigned long long)__shfl_xor((long long)a, o);
+    }
+    if (lane_id() == 0) { s_q[threadIdx.x >> 6] = q0; s_c[threadIdx.x >> 6] = c; s_k[threadIdx.x >> 6] = a; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // the block's (up to four) wave sums, merged where they name the same query
+    for (int w = 0; w < 4; w++) {
+      const uint32_t q = s_q[w];
+      if (q == 0xFFFFFFFFu) continue;
+      unsigned long long cc = s_c[w], kk = s_k[w];
+      for (int w2 = w + 1; w2 < 4; w2++)
+        if (s_q[w2] == q) { cc += s_c[w2]; kk += s_k[w2]; s_q[w2] = 0xFFFFFFFFu; }
+      if (cc) {
+        if (count) atomicAdd(&count[q], cc);
+        if (cksum) atomicAdd(&cksum[q], kk);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1265,6 +1308,8 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
 // VU_LDS_CAP ranges (nearly all of them) are kept in LDS while they are worked on (lane-interleaved, so the 64
 // lists of a wave never share a bank) and written out once at the end; longer ones are worked on in place.
 constexpr uint32_t VU_LDS_CAP = 16;
+// groups whose list can outgrow this get a whole wave (visited_update_wave_kernel below)
+constexpr uint32_t VW_MIN = 64, VW_LIST_CAP = 2048, VW_PIECE_CAP = 4096;
 struct ListInPlace {  // the group's slice of the new table
   int2 *p;
   __device__ __forceinline__ int32_t &x(uint32_t i) const { return p[i].x; }
@@ -1380,6 +1425,7 @@ __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, co
   int2 *P = pieces + poff[g];
   uint32_t np = 0;
   const uint32_t st = gstart[g], n = glen[g];
+  if (len + n > VW_MIN) return;  // a wave of visited_update_wave_kernel takes this group
   if (len + n <= VU_LDS_CAP) {  // (len + n bounds the list at every step)
     const ListInLds A{lds_x + threadIdx.x, lds_y + threadIdx.x};
     for (uint32_t i = 0; i < len; i++) { const int2 r = src[i]; A.x(i) = r.x; A.y(i) = r.y; }
@@ -1405,6 +1451,236 @@ __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, co
   if (np) np = w + 1;
   new_len[g] = len;
   n_pieces[g] = np;
+}
+
+// ---------------------------------------------------------------------------
+// The same replay for groups with long lists or many hits (deep closures: at depth 5 of a window tiling a group
+// replays thousands of hits against lists of hundreds of ranges): one WAVE per group.  The replay stays
+// sequential hit by hit -- the reference's order dependence -- and every lane runs the same scalar logic on the
+// same list words (LDS broadcasts); what a single lane did in O(list) per hit is spread over the 64 lanes: the
+// lower bounds (64-ary narrowing with ballots), the shift that makes room for an insertion, the shift that
+// closes the gap after a merge, and the final sort of the group's pieces (a bitonic network, O(n log^2 n / 64)
+// where the lane kernel's insertion sort was O(n^2)).  List and pieces live in LDS while they fit
+// (VW_LIST_CAP / VW_PIECE_CAP), else the same code runs on the group's slices in global memory.
+// ---------------------------------------------------------------------------
+struct ListSoA {  // x[i], y[i] in two LDS arrays
+  int32_t *px, *py;
+  __device__ __forceinline__ int32_t &x(uint32_t i) const { return px[i]; }
+  __device__ __forceinline__ int32_t &y(uint32_t i) const { return py[i]; }
+};
+template <class L> __device__ __forceinline__ uint32_t wave_lower_bound(const L &R, uint32_t n, int32_t s) {
+  uint32_t lo = 0, hi = n;  // everything before lo is < s, everything from hi on is >= s
+  const uint32_t lane = lane_id();
+  while (hi - lo > 64u) {
+    const uint32_t step = (hi - lo + 63u) >> 6;
+    const uint32_t idx = lo + (lane + 1u) * step - 1u;  // last element of this lane's block
+    const bool lt = idx < hi && R.x(idx) < s;
+    const uint32_t c = (uint32_t)__popcll(__ballot(lt));   // the blocks that lie wholly below s are a prefix
+    const uint32_t nlo = lo + c * step;
+    hi = min(hi, nlo + step);
+    lo = nlo;
+  }
+  const uint32_t idx = lo + lane;
+  return lo + (uint32_t)__popcll(__ballot(idx < hi && R.x(idx) < s));
+}
+template <class L> __device__ __forceinline__ void wave_shift_up(const L &R, uint32_t pos, uint32_t len) {  // [pos, len) -> [pos+1, len+1)
+  const uint32_t lane = lane_id();
+  for (uint32_t top = len; top > pos;) {
+    const uint32_t base = top > pos + 64u ? top - 64u : pos;
+    const uint32_t i = base + lane;
+    const bool on = i < top;
+    int32_t vx = 0, vy = 0;
+    if (on) { vx = R.x(i); vy = R.y(i); }
+    __syncthreads();  // (one wave per block: orders the reads of a chunk before its writes for the compiler)
+    if (on) { R.x(i + 1) = vx; R.y(i + 1) = vy; }
+    __syncthreads();
+    top = base;
+  }
+}
+template <class L> __device__ __forceinline__ void wave_shift_down(const L &R, uint32_t from, uint32_t len, uint32_t k) {  // [from, len) -> [from-k, len-k)
+  const uint32_t lane = lane_id();
+  for (uint32_t base = from; base < len; base += 64u) {
+    const uint32_t i = base + lane;
+    const bool on = i < len;
+    int32_t vx = 0, vy = 0;
+    if (on) { vx = R.x(i); vy = R.y(i); }
+    __syncthreads();
+    if (on) { R.x(i - k) = vx; R.y(i - k) = vy; }
+    __syncthreads();
+  }
+}
+// ascending sort of p[0..n) by .x: a bitonic network in its all-ascending form (first step of every merge pairs i
+// with its mirror image in the block), so an index past n behaves as +infinity without being stored
+__device__ __forceinline__ void wave_sort_pieces(int2 *p, uint32_t n) {
+  if (n < 2) return;
+  const uint32_t lane = lane_id();
+  uint32_t n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  for (uint32_t k = 2; k <= n2; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = lane; i < n; i += 64u) {
+        const uint32_t l = (j == (k >> 1)) ? (i ^ (k - 1u)) : (i ^ j);
+        if (l > i && l < n) {
+          const int2 a = p[i], b = p[l];
+          if (a.x > b.x) { p[i] = b; p[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+template <class L>
+__device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, const unsigned long long *__restrict__ svals,
+                                                     uint32_t st, uint32_t n, int32_t sequence_length,
+                                                     int32_t min_transitive_len, int32_t mdbr, int2 *P, uint32_t &np) {
+  const bool writer = lane_id() == 0;
+  for (uint32_t t = 0; t < n; t++) {
+    const unsigned long long iv = svals[st + t];
+    int32_t start = (int32_t)(uint32_t)(iv >> 32), end = (int32_t)(uint32_t)iv;
+    uint32_t pos = wave_lower_bound(R, len, start);
+    if (mdbr > 0) {  // impg.rs:2513-2545
+      bool should_add = true;
+      if (pos > 0 && abs(start - R.y(pos - 1)) < mdbr) should_add = false;
+      if (should_add && pos < len && abs(R.x(pos) - end) < mdbr) should_add = false;
+      if (!should_add) continue;
+    }
+    if (start < 0) { start = 0; pos = wave_lower_bound(R, len, start); }  // impg.rs:287-289 (never taken on real coordinates)
+    if (end > sequence_length) end = sequence_length;                      // impg.rs:294-296
+    int32_t current = start;
+    uint32_t i = pos;
+    if (i > 0 && R.y(i - 1) > start) i -= 1;
+    while (i < len && current < end) {  // impg.rs:314-324
+      const int32_t rx = R.x(i), ry = R.y(i);
+      if (rx > end) break;
+      if (current < rx && abs(rx - current) >= min_transitive_len) {
+        if (writer) P[np] = make_int2(current, rx);
+        np++;
+      }
+      current = max(current, ry);
+      i += 1;
+    }
+    if (current < end && abs(end - current) >= min_transitive_len) {
+      if (writer) P[np] = make_int2(current, end);
+      np++;
+    }
+    uint32_t mfrom;  // impg.rs:330-343
+    if (pos > 0 && R.y(pos - 1) >= start) {
+      const int32_t ny = max(R.y(pos - 1), end);
+      __syncthreads();
+      if (writer) R.y(pos - 1) = ny;
+      mfrom = pos - 1;
+    } else if (pos < len && end >= R.x(pos)) {
+      const int32_t nx = min(start, R.x(pos)), ny = max(end, R.y(pos));
+      __syncthreads();
+      if (writer) { R.x(pos) = nx; R.y(pos) = ny; }
+      mfrom = pos;
+    } else {
+      wave_shift_up(R, pos, len);
+      if (writer) { R.x(pos) = start; R.y(pos) = end; }
+      __syncthreads();
+      len += 1;
+      continue;
+    }
+    __syncthreads();
+    // merge_forward_from (impg.rs:355-368): the list is sorted and its ranges neither overlap nor touch, so the
+    // ranges the grown one swallows are one run right behind it; the rest moves down by the run's length
+    uint32_t read = mfrom + 1;
+    int32_t wy = R.y(mfrom);
+    while (read < len && wy >= R.x(read)) { wy = max(wy, R.y(read)); read += 1; }
+    const uint32_t k = read - (mfrom + 1);
+    if (k) {
+      __syncthreads();
+      if (writer) R.y(mfrom) = wy;
+      __syncthreads();
+      wave_shift_down(R, read, len, k);
+      len -= k;
+    }
+  }
+  return len;
+}
+__global__ __launch_bounds__(64) void visited_update_wave_kernel(VisitedTables vt, const unsigned long long *__restrict__ svals,
+                                                                 const int32_t *__restrict__ seq_len,
+                                                                 const unsigned long long *__restrict__ gkey,
+                                                                 const uint32_t *__restrict__ gstart,
+                                                                 const uint32_t *__restrict__ glen,
+                                                                 const uint32_t *__restrict__ old_tab,
+                                                                 const uint32_t *__restrict__ old_idx,
+                                                                 const uint32_t *__restrict__ noff,
+                                                                 const uint32_t *__restrict__ poff,
+                                                                 const uint32_t *__restrict__ big_list,
+                                                                 const uint32_t *__restrict__ n_big, int32_t min_transitive_len,
+                                                                 int32_t mdbr, int2 *__restrict__ new_ranges,
+                                                                 uint32_t *__restrict__ new_len, int2 *__restrict__ pieces,
+                                                                 uint32_t *__restrict__ n_pieces) {
+  __shared__ int32_t lx[VW_LIST_CAP], ly[VW_LIST_CAP];
+  __shared__ int2 lp[VW_PIECE_CAP];
+  const uint32_t lane = lane_id();
+  const uint32_t nb = *n_big;
+  for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    const uint32_t g = big_list[b];
+    int2 *R = new_ranges + noff[g];
+    const int2 *src = nullptr;
+    uint32_t len = 0;
+    if (old_tab[g] == VISITED_MASK) {
+      const uint32_t a = vt.mask_off[old_idx[g]];
+      len = vt.mask_off[old_idx[g] + 1] - a;
+      src = vt.mask_ranges + a;
+    } else if (old_tab[g] != VISITED_NONE) {
+      const VisitedTable &T = vt.t[old_tab[g]];
+      src = T.ranges + T.off[old_idx[g]];
+      len = T.len[old_idx[g]];
+    }
+    const int32_t sequence_length = seq_len[(uint32_t)(gkey[g] & 0xFFFFFFFFull)];
+    const uint32_t st = gstart[g], n = glen[g];
+    const bool list_lds = len + n <= VW_LIST_CAP, piece_lds = len + 2u * n <= VW_PIECE_CAP;  // (the capacities group_prepare sized)
+    int2 *P = piece_lds ? lp : pieces + poff[g];
+    uint32_t np = 0;
+    __syncthreads();  // (the previous group's LDS contents are dead)
+    if (list_lds) {
+      for (uint32_t i = lane; i < len; i += 64u) { const int2 r = src[i]; lx[i] = r.x; ly[i] = r.y; }
+      __syncthreads();
+      len = replay_hits_wave(ListSoA{lx, ly}, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np);
+      __syncthreads();
+      for (uint32_t i = lane; i < len; i += 64u) R[i] = make_int2(lx[i], ly[i]);
+    } else {
+      for (uint32_t i = lane; i < len; i += 64u) R[i] = src[i];
+      __syncthreads();
+      len = replay_hits_wave(ListInPlace{R}, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np);
+    }
+    __syncthreads();
+    // next-depth ranges of the group: sorted by start, overlapping / contiguous ones merged (impg.rs:2568-2584)
+    wave_sort_pieces(P, np);
+    uint32_t w = 0;
+    if (np) {
+      int32_t cx = P[0].x, cy = P[0].y;
+      int2 *out = pieces + poff[g];
+      for (uint32_t r = 1; r < np; r++) {
+        const int2 q = P[r];
+        if (cy >= q.x) cy = max(cy, q.y);
+        else {  // (in place when P is the global slice: w < r, the slot rewritten was read in an earlier iteration)
+          if (lane == 0) out[w] = make_int2(cx, cy);
+          w += 1;
+          cx = q.x; cy = q.y;
+        }
+      }
+      __syncthreads();
+      if (lane == 0) out[w] = make_int2(cx, cy);
+      w += 1;
+    }
+    if (lane == 0) { new_len[g] = len; n_pieces[g] = w; }
+  }
+}
+// groups the lane kernel leaves to the wave kernel, in any order
+__global__ __launch_bounds__(256) void big_groups_kernel(const uint32_t *__restrict__ cap, uint32_t n_groups,
+                                                         uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  const bool big = g < n_groups && cap[g] > VW_MIN;  // cap = old length + hits of the level (group_prepare)
+  const unsigned long long m = __ballot(big);
+  if (!m) return;
+  uint32_t base = 0;
+  if (lane_id() == 0) base = atomicAdd(n_big, (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, 0);
+  if (big) big_list[base + (uint32_t)__popcll(m & lanemask_lt())] = g;
 }
 
 __global__ __launch_bounds__(256) void frontier_emit_kernel(const unsigned long long *__restrict__ gkey,
@@ -1923,8 +2199,9 @@ __global__ __launch_bounds__(256) void hits_unpack_kernel(const uint4 *__restric
 // launchers
 // ---------------------------------------------------------------------------
 static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
-// windows of <= 64 entries are emitted lane-per-range (needs ranks < 2^26 for the packed sort key)
-static inline bool emit_by_lanes(const DeviceIndexView &v) { return v.n_entries < (1u << 26); }
+// windows of <= 64 entries are emitted lane-per-range (needs ranks < 2^26 for the packed sort key: a rank is a
+// position within its target's segment, so the largest segment decides, not the index)
+static inline bool emit_by_lanes(const DeviceIndexView &v) { return v.max_seg < (1u << 26); }
 static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 waves per block, capped
   uint32_t blocks = cdiv(n_items, 4);
   const uint32_t cap = 256u * 32u;  // 32 blocks per CU worth of grid-stride
@@ -2044,11 +2321,18 @@ void launch_visited_update(const VisitedTables &vt, const unsigned long long *sv
                            const unsigned long long *gkey, const uint32_t *gstart, const uint32_t *glen,
                            const uint32_t *old_tab, const uint32_t *old_idx, const uint32_t *noff, const uint32_t *poff,
                            uint32_t n_groups, int32_t min_transitive_len, int32_t mdbr, int2 *new_ranges,
-                           uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, hipStream_t s) {
+                           uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, const uint32_t *cap, uint32_t *big_list,
+                           uint32_t *n_big, hipStream_t s) {
   if (!n_groups) return;
+  (void)hipMemsetAsync(n_big, 0, 4, s);
+  big_groups_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(cap, n_groups, big_list, n_big);
   visited_update_kernel<<<cdiv(n_groups, 64), 64, 0, s>>>(vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff,
                                                           poff, n_groups, min_transitive_len, mdbr, new_ranges, new_len,
                                                           pieces, n_pieces);
+  // one wave per big group, grid-strided over however many there are (the count stays on the device)
+  const uint32_t blocks = std::min<uint32_t>(n_groups, 256u * 12u);
+  visited_update_wave_kernel<<<blocks, 64, 0, s>>>(vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list,
+                                                   n_big, min_transitive_len, mdbr, new_ranges, new_len, pieces, n_pieces);
 }
 void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
                           const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s) {

@@ -913,3 +913,28 @@ def test_cli_whole_sequence_strandness_and_stale_cache(tmp_path):
     r2 = subprocess.run([cli, "query", "-i", cache, "-r", "s2:100-5000", "-d", "0", "-o", "bed"], capture_output=True, text=True)
     assert r2.returncode == 0 and r2.stdout == r.stdout and "rebuilding" not in r2.stderr  # the rewritten cache loads
     assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+
+
+@pytest.mark.parametrize("seed,n_aln,mdbr", [(1, 900, 10), (2, 4000, 0), (3, 2500, 120)])
+def test_visited_update_big_groups(tmp_path, seed, n_aln, mdbr):
+    """(query, sequence) groups with hundreds to thousands of hits per level and visited lists of hundreds of
+    ranges: the wave-per-group update (lists and pieces in LDS up to their caps, in global memory beyond), against
+    the oracle's literal replay.  Few sequences, many short alignments, small min_transitive_len, depth 4."""
+    rng = np.random.default_rng(seed)
+    L = 400_000
+    names = ["A", "B", "C"]
+    lines = []
+    for _ in range(n_aln):
+        t, q = rng.choice(3, size=2, replace=False)
+        ln = int(rng.integers(30, 400))
+        ts, qs = int(rng.integers(0, L - ln)), int(rng.integers(0, L - ln))
+        lines.append("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t60\tcg:Z:%d=" %
+                     (names[q], L, qs, qs + ln, "+-"[int(rng.integers(0, 2))], names[t], L, ts, ts + ln, ln, ln, ln))
+    g, c = both(tmp_path, "\n".join(lines) + "\n")
+    ranges = [(g.seq_id("A"), 0, L), (g.seq_id("B"), 1000, L - 1000), (g.seq_id("C"), 0, L // 2), (g.seq_id("A"), 50_000, 90_000)]
+    kw = dict(transitive=True, max_depth=4, min_transitive_len=5, min_distance_between_ranges=mdbr)
+    res = assert_same(g, c, ranges, **kw)
+    assert len(res[0]) > n_aln  # every alignment is reached, most of them several times
+    assert_same(g, c, ranges, transitive=True, dfs=True, max_depth=3, min_transitive_len=5, min_distance_between_ranges=mdbr)
+    masked = {int(g.seq_id("B")): (L, [(k * 3000, k * 3000 + 900) for k in range(100)])}  # a mask list of 100 ranges: a big group from its first touch
+    assert_same(g, c, ranges[:2], masked_regions=masked, **kw)

@@ -8,6 +8,8 @@
 // max_depth): its only outputs, the visited sets and the next frontier, are
 // never read again (impg.rs:2376 ends the loop).
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 
 #include "engine.hpp"
@@ -258,6 +260,27 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       launch_group_prepare(tabs, vt->keys.as<unsigned long long>(), gstart.as<uint32_t>(), n_groups, n_active,
                            glen.as<uint32_t>(), old_tab.as<uint32_t>(), old_idx.as<uint32_t>(), cap.as<uint32_t>(),
                            pcap.as<uint32_t>(), stream);
+      if (getenv("IMPG_DEBUG_GROUPS")) {  // histogram of group sizes (tuning aid)
+        std::vector<uint32_t> hc(n_groups), hp(n_groups), hl(n_groups);
+        IMPG_HIP(hipStreamSynchronize(stream));
+        IMPG_HIP(hipMemcpy(hc.data(), cap.p, (size_t)n_groups * 4, hipMemcpyDeviceToHost));
+        IMPG_HIP(hipMemcpy(hp.data(), pcap.p, (size_t)n_groups * 4, hipMemcpyDeviceToHost));
+        IMPG_HIP(hipMemcpy(hl.data(), glen.p, (size_t)n_groups * 4, hipMemcpyDeviceToHost));
+        uint64_t b[8] = {0}, hits[8] = {0};
+        const uint32_t edge[8] = {16, 64, 512, 1024, 2048, 4096, 16384, 0xFFFFFFFFu};
+        uint32_t mx = 0, mxl = 0;
+        for (uint32_t g2 = 0; g2 < n_groups; g2++) {
+          int k = 0;
+          while (hc[g2] > edge[k]) k++;
+          b[k]++; hits[k] += hl[g2];
+          mx = std::max(mx, hc[g2]); mxl = std::max(mxl, hl[g2]);
+        }
+        fprintf(stderr, "[groups] n=%u P=%u maxcap=%u maxhits=%u | cap<=16:%llu(%llu) 64:%llu(%llu) 512:%llu(%llu) 1k:%llu(%llu) 2k:%llu(%llu) 4k:%llu(%llu) 16k:%llu(%llu) more:%llu(%llu)\n",
+                n_groups, P, mx, mxl, (unsigned long long)b[0], (unsigned long long)hits[0], (unsigned long long)b[1], (unsigned long long)hits[1],
+                (unsigned long long)b[2], (unsigned long long)hits[2], (unsigned long long)b[3], (unsigned long long)hits[3],
+                (unsigned long long)b[4], (unsigned long long)hits[4], (unsigned long long)b[5], (unsigned long long)hits[5],
+                (unsigned long long)b[6], (unsigned long long)hits[6], (unsigned long long)b[7], (unsigned long long)hits[7]);
+      }
       vt->off.reserve((size_t)n_groups * 4);
       poff.reserve((size_t)n_groups * 4);
       uint64_t cap_total = scan(cap.as<uint32_t>(), vt->off.as<uint32_t>(), n_groups);
@@ -274,7 +297,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
                             gstart.as<uint32_t>(), glen.as<uint32_t>(), old_tab.as<uint32_t>(), old_idx.as<uint32_t>(),
                             vt->off.as<uint32_t>(), poff.as<uint32_t>(), n_groups, p.min_transitive_len,
                             p.min_distance_between_ranges, vt->ranges.as<int2>(), vt->len.as<uint32_t>(),
-                            pieces.as<int2>(), n_pieces.as<uint32_t>(), cap.as<uint32_t>(), big_list.as<uint32_t>(),
+                            pieces.as<int2>(), n_pieces.as<uint32_t>(), cap.as<uint32_t>(), pcap.as<uint32_t>(), big_list.as<uint32_t>(),
                             (uint32_t *)(counters.as<uint64_t>() + 5), stream);
       uint64_t nn = scan(n_pieces.as<uint32_t>(), foff.as<uint32_t>(), n_groups);
       if (nn >= 0xFFFFFFF0ull) { if (split_ok) throw SplitBatch{}; throw Error{IMPG_E_UNSUPPORTED, "frontier exceeds 2^32 ranges"}; }

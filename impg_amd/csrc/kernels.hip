@@ -1309,7 +1309,8 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
 // lists of a wave never share a bank) and written out once at the end; longer ones are worked on in place.
 constexpr uint32_t VU_LDS_CAP = 16;
 // groups whose list can outgrow this get a whole wave (visited_update_wave_kernel below)
-constexpr uint32_t VW_MIN = 64, VW_LIST_CAP = 2048, VW_PIECE_CAP = 4096;
+// two sizes of LDS working set (8 KB: 20 waves per CU; 32 KB: 5): groups with few hits and a short list take the small one
+constexpr uint32_t VW_MIN = 64, VW_CAP_SMALL = 1024, VW_CAP_LARGE = 4096, VW_SMALL_HITS = 400;
 struct ListInPlace {  // the group's slice of the new table
   int2 *p;
   __device__ __forceinline__ int32_t &x(uint32_t i) const { return p[i].x; }
@@ -1463,11 +1464,16 @@ __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, co
 // where the lane kernel's insertion sort was O(n^2)).  List and pieces live in LDS while they fit
 // (VW_LIST_CAP / VW_PIECE_CAP), else the same code runs on the group's slices in global memory.
 // ---------------------------------------------------------------------------
+// Lanes of the one wave read words other lanes wrote a few instructions earlier.  For a list in LDS the hardware
+// keeps one wave's ds_ instructions in program order, so the only thing to stop is the compiler moving them
+// (wave_barrier emits no instruction); a list worked on in global memory gets the real barrier (waitcnt + s_barrier).
+template <class L> __device__ __forceinline__ void order_point(const L &) { __syncthreads(); }
 struct ListSoA {  // x[i], y[i] in two LDS arrays
   int32_t *px, *py;
   __device__ __forceinline__ int32_t &x(uint32_t i) const { return px[i]; }
   __device__ __forceinline__ int32_t &y(uint32_t i) const { return py[i]; }
 };
+template <> __device__ __forceinline__ void order_point<ListSoA>(const ListSoA &) { __builtin_amdgcn_wave_barrier(); }
 template <class L> __device__ __forceinline__ uint32_t wave_lower_bound(const L &R, uint32_t n, int32_t s) {
   uint32_t lo = 0, hi = n;  // everything before lo is < s, everything from hi on is >= s
   const uint32_t lane = lane_id();
@@ -1491,9 +1497,9 @@ template <class L> __device__ __forceinline__ void wave_shift_up(const L &R, uin
     const bool on = i < top;
     int32_t vx = 0, vy = 0;
     if (on) { vx = R.x(i); vy = R.y(i); }
-    __syncthreads();  // (one wave per block: orders the reads of a chunk before its writes for the compiler)
+    order_point(R);
     if (on) { R.x(i + 1) = vx; R.y(i + 1) = vy; }
-    __syncthreads();
+    order_point(R);
     top = base;
   }
 }
@@ -1504,9 +1510,9 @@ template <class L> __device__ __forceinline__ void wave_shift_down(const L &R, u
     const bool on = i < len;
     int32_t vx = 0, vy = 0;
     if (on) { vx = R.x(i); vy = R.y(i); }
-    __syncthreads();
+    order_point(R);
     if (on) { R.x(i - k) = vx; R.y(i - k) = vy; }
-    __syncthreads();
+    order_point(R);
   }
 }
 // ascending sort of p[0..n) by .x: a bitonic network in its all-ascending form (first step of every merge pairs i
@@ -1532,9 +1538,33 @@ __device__ __forceinline__ void wave_sort_pieces(int2 *p, uint32_t n) {
 template <class L>
 __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, const unsigned long long *__restrict__ svals,
                                                      uint32_t st, uint32_t n, int32_t sequence_length,
-                                                     int32_t min_transitive_len, int32_t mdbr, int2 *P, uint32_t &np) {
+                                                     int32_t min_transitive_len, int32_t mdbr, int2 *P, uint32_t &np,
+                                                     uint32_t &t_next, uint32_t list_cap) {
   const bool writer = lane_id() == 0;
-  for (uint32_t t = 0; t < n; t++) {
+  const uint32_t lane = lane_id();
+  uint32_t t0 = t_next;
+  for (; t0 < n; t0 += 64u) {
+    if (len + 64u > list_cap) break;  // (a batch adds at most 64 ranges: the caller moves the list somewhere bigger)
+    // A hit that one range of the list already covers changes nothing whenever its turn comes: the insert finds no
+    // uncovered piece and leaves the list as it is (impg.rs:314-343), and the list only ever grows.  Deep levels of
+    // a saturating closure are almost all such hits: every lane tests one hit of the batch against the list as it
+    // stands, and only the others take their turn in the sequential replay below.
+    unsigned long long todo;
+    {
+      bool need = false;
+      if (t0 + lane < n) {
+        const unsigned long long iv = svals[st + t0 + lane];
+        const int32_t s0 = max((int32_t)(uint32_t)(iv >> 32), 0), e0 = min((int32_t)(uint32_t)iv, sequence_length);
+        const uint32_t p0 = list_lower_bound(R, len, s0);
+        // (a hit that the clamps leave empty or inverted -- a length-0 set of a masked batch -- takes the literal path)
+        const bool covered = s0 < e0 && ((p0 < len && R.x(p0) == s0 && R.y(p0) >= e0) || (p0 > 0 && R.y(p0 - 1) >= e0));
+        need = !covered;
+      }
+      todo = __ballot(need);
+    }
+    while (todo) {
+    const uint32_t t = t0 + (uint32_t)__ffsll((long long)todo) - 1u;
+    todo &= todo - 1ull;
     const unsigned long long iv = svals[st + t];
     int32_t start = (int32_t)(uint32_t)(iv >> 32), end = (int32_t)(uint32_t)iv;
     uint32_t pos = wave_lower_bound(R, len, start);
@@ -1566,22 +1596,22 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
     uint32_t mfrom;  // impg.rs:330-343
     if (pos > 0 && R.y(pos - 1) >= start) {
       const int32_t ny = max(R.y(pos - 1), end);
-      __syncthreads();
+      order_point(R);
       if (writer) R.y(pos - 1) = ny;
       mfrom = pos - 1;
     } else if (pos < len && end >= R.x(pos)) {
       const int32_t nx = min(start, R.x(pos)), ny = max(end, R.y(pos));
-      __syncthreads();
+      order_point(R);
       if (writer) { R.x(pos) = nx; R.y(pos) = ny; }
       mfrom = pos;
     } else {
       wave_shift_up(R, pos, len);
       if (writer) { R.x(pos) = start; R.y(pos) = end; }
-      __syncthreads();
+      order_point(R);
       len += 1;
       continue;
     }
-    __syncthreads();
+    order_point(R);
     // merge_forward_from (impg.rs:355-368): the list is sorted and its ranges neither overlap nor touch, so the
     // ranges the grown one swallows are one run right behind it; the rest moves down by the run's length
     uint32_t read = mfrom + 1;
@@ -1589,15 +1619,18 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
     while (read < len && wy >= R.x(read)) { wy = max(wy, R.y(read)); read += 1; }
     const uint32_t k = read - (mfrom + 1);
     if (k) {
-      __syncthreads();
+      order_point(R);
       if (writer) R.y(mfrom) = wy;
-      __syncthreads();
+      order_point(R);
       wave_shift_down(R, read, len, k);
       len -= k;
     }
   }
+  }
+  t_next = t0;
   return len;
 }
+template <uint32_t CAP>  // ranges of the list / pieces of the sort that fit the block's LDS (8 bytes each, one buffer for both)
 __global__ __launch_bounds__(64) void visited_update_wave_kernel(VisitedTables vt, const unsigned long long *__restrict__ svals,
                                                                  const int32_t *__restrict__ seq_len,
                                                                  const unsigned long long *__restrict__ gkey,
@@ -1608,16 +1641,22 @@ __global__ __launch_bounds__(64) void visited_update_wave_kernel(VisitedTables v
                                                                  const uint32_t *__restrict__ noff,
                                                                  const uint32_t *__restrict__ poff,
                                                                  const uint32_t *__restrict__ big_list,
-                                                                 const uint32_t *__restrict__ n_big, int32_t min_transitive_len,
+                                                                 const uint32_t *__restrict__ n_big, uint32_t from_back,
+                                                                 int32_t min_transitive_len,
                                                                  int32_t mdbr, int2 *__restrict__ new_ranges,
                                                                  uint32_t *__restrict__ new_len, int2 *__restrict__ pieces,
                                                                  uint32_t *__restrict__ n_pieces) {
-  __shared__ int32_t lx[VW_LIST_CAP], ly[VW_LIST_CAP];
-  __shared__ int2 lp[VW_PIECE_CAP];
+  // The capacities group_prepare sized (old length + hits, + 2 x hits for the pieces) are worst cases; what a group
+  // really needs is usually a fraction (hits pile up on the same regions and merge).  The list therefore starts in
+  // LDS whatever its worst case and moves to its global slice only if it really outgrows the buffer; the pieces go
+  // straight to their global slice during the replay (plain stores nobody waits for) and come back into the same
+  // LDS buffer for the sort once the list has been written out.
+  __shared__ int2 lds[CAP];
+  int32_t *lx = reinterpret_cast<int32_t *>(lds), *ly = lx + CAP;
   const uint32_t lane = lane_id();
   const uint32_t nb = *n_big;
   for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-    const uint32_t g = big_list[b];
+    const uint32_t g = big_list[from_back ? from_back - 1u - b : b];  // (from_back = n_groups: the list's other end)
     int2 *R = new_ranges + noff[g];
     const int2 *src = nullptr;
     uint32_t len = 0;
@@ -1632,55 +1671,68 @@ __global__ __launch_bounds__(64) void visited_update_wave_kernel(VisitedTables v
     }
     const int32_t sequence_length = seq_len[(uint32_t)(gkey[g] & 0xFFFFFFFFull)];
     const uint32_t st = gstart[g], n = glen[g];
-    const bool list_lds = len + n <= VW_LIST_CAP, piece_lds = len + 2u * n <= VW_PIECE_CAP;  // (the capacities group_prepare sized)
-    int2 *P = piece_lds ? lp : pieces + poff[g];
-    uint32_t np = 0;
+    int2 *P = pieces + poff[g];
+    uint32_t np = 0, t_next = 0;
     __syncthreads();  // (the previous group's LDS contents are dead)
-    if (list_lds) {
+    if (len + 64u <= CAP) {
       for (uint32_t i = lane; i < len; i += 64u) { const int2 r = src[i]; lx[i] = r.x; ly[i] = r.y; }
       __syncthreads();
-      len = replay_hits_wave(ListSoA{lx, ly}, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np);
+      len = replay_hits_wave(ListSoA{lx, ly}, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np, t_next, CAP);
       __syncthreads();
       for (uint32_t i = lane; i < len; i += 64u) R[i] = make_int2(lx[i], ly[i]);
     } else {
       for (uint32_t i = lane; i < len; i += 64u) R[i] = src[i];
-      __syncthreads();
-      len = replay_hits_wave(ListInPlace{R}, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np);
     }
     __syncthreads();
+    if (t_next < n)  // the list outgrew the buffer (or never fitted): the rest of the replay in place
+      len = replay_hits_wave(ListInPlace{R}, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np, t_next, 0xFFFFFFFFu);
+    __syncthreads();
     // next-depth ranges of the group: sorted by start, overlapping / contiguous ones merged (impg.rs:2568-2584)
-    wave_sort_pieces(P, np);
+    int2 *S = P;
+    if (np <= CAP) {
+      for (uint32_t i = lane; i < np; i += 64u) lds[i] = P[i];
+      __syncthreads();
+      S = lds;
+    }
+    wave_sort_pieces(S, np);
     uint32_t w = 0;
     if (np) {
-      int32_t cx = P[0].x, cy = P[0].y;
+      int32_t cx = S[0].x, cy = S[0].y;
       int2 *out = pieces + poff[g];
       for (uint32_t r = 1; r < np; r++) {
-        const int2 q = P[r];
+        const int2 q = S[r];
         if (cy >= q.x) cy = max(cy, q.y);
-        else {  // (in place when P is the global slice: w < r, the slot rewritten was read in an earlier iteration)
+        else {  // (in place when S is the global slice: w < r, the slot rewritten was read in an earlier iteration)
           if (lane == 0) out[w] = make_int2(cx, cy);
           w += 1;
           cx = q.x; cy = q.y;
         }
       }
-      __syncthreads();
       if (lane == 0) out[w] = make_int2(cx, cy);
       w += 1;
     }
     if (lane == 0) { new_len[g] = len; n_pieces[g] = w; }
   }
 }
-// groups the lane kernel leaves to the wave kernel, in any order
-__global__ __launch_bounds__(256) void big_groups_kernel(const uint32_t *__restrict__ cap, uint32_t n_groups,
-                                                         uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big) {
+// groups the lane kernel leaves to the wave kernels, in any order: those that fit the small LDS working set are
+// listed from the front of big_list (count n_big[0]), the others from its back (count n_big[1])
+__global__ __launch_bounds__(256) void big_groups_kernel(const uint32_t *__restrict__ cap, const uint32_t *__restrict__ pcap,
+                                                         uint32_t n_groups, uint32_t *__restrict__ big_list,
+                                                         uint32_t *__restrict__ n_big) {
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
   const bool big = g < n_groups && cap[g] > VW_MIN;  // cap = old length + hits of the level (group_prepare)
-  const unsigned long long m = __ballot(big);
-  if (!m) return;
-  uint32_t base = 0;
-  if (lane_id() == 0) base = atomicAdd(n_big, (uint32_t)__popcll(m));
-  base = (uint32_t)__shfl((int)base, 0);
-  if (big) big_list[base + (uint32_t)__popcll(m & lanemask_lt())] = g;
+  // cap = old + hits, pcap = old + 2 hits  =>  hits = pcap - cap, old = 2 cap - pcap
+  const bool small_ws = big && pcap[g] - cap[g] <= VW_SMALL_HITS && 2u * cap[g] - pcap[g] + VW_SMALL_HITS <= VW_CAP_SMALL - 64u;
+  const unsigned long long ms = __ballot(small_ws), ml = __ballot(big && !small_ws);
+  uint32_t bs = 0, bl = 0;
+  if (lane_id() == 0) {
+    if (ms) bs = atomicAdd(&n_big[0], (uint32_t)__popcll(ms));
+    if (ml) bl = atomicAdd(&n_big[1], (uint32_t)__popcll(ml));
+  }
+  bs = (uint32_t)__shfl((int)bs, 0);
+  bl = (uint32_t)__shfl((int)bl, 0);
+  if (small_ws) big_list[bs + (uint32_t)__popcll(ms & lanemask_lt())] = g;
+  else if (big) big_list[n_groups - 1u - (bl + (uint32_t)__popcll(ml & lanemask_lt()))] = g;
 }
 
 __global__ __launch_bounds__(256) void frontier_emit_kernel(const unsigned long long *__restrict__ gkey,
@@ -2321,18 +2373,22 @@ void launch_visited_update(const VisitedTables &vt, const unsigned long long *sv
                            const unsigned long long *gkey, const uint32_t *gstart, const uint32_t *glen,
                            const uint32_t *old_tab, const uint32_t *old_idx, const uint32_t *noff, const uint32_t *poff,
                            uint32_t n_groups, int32_t min_transitive_len, int32_t mdbr, int2 *new_ranges,
-                           uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, const uint32_t *cap, uint32_t *big_list,
-                           uint32_t *n_big, hipStream_t s) {
+                           uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, const uint32_t *cap, const uint32_t *pcap,
+                           uint32_t *big_list, uint32_t *n_big, hipStream_t s) {
   if (!n_groups) return;
-  (void)hipMemsetAsync(n_big, 0, 4, s);
-  big_groups_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(cap, n_groups, big_list, n_big);
+  (void)hipMemsetAsync(n_big, 0, 8, s);
+  big_groups_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(cap, pcap, n_groups, big_list, n_big);
   visited_update_kernel<<<cdiv(n_groups, 64), 64, 0, s>>>(vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff,
                                                           poff, n_groups, min_transitive_len, mdbr, new_ranges, new_len,
                                                           pieces, n_pieces);
   // one wave per big group, grid-strided over however many there are (the count stays on the device)
-  const uint32_t blocks = std::min<uint32_t>(n_groups, 256u * 12u);
-  visited_update_wave_kernel<<<blocks, 64, 0, s>>>(vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list,
-                                                   n_big, min_transitive_len, mdbr, new_ranges, new_len, pieces, n_pieces);
+  const uint32_t blocks = std::min<uint32_t>(n_groups, 256u * 20u);
+  visited_update_wave_kernel<VW_CAP_SMALL><<<blocks, 64, 0, s>>>(
+      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list, n_big, 0u, min_transitive_len, mdbr, new_ranges,
+      new_len, pieces, n_pieces);
+  visited_update_wave_kernel<VW_CAP_LARGE><<<std::min<uint32_t>(n_groups, 256u * 5u), 64, 0, s>>>(
+      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list, n_big + 1, n_groups, min_transitive_len, mdbr,
+      new_ranges, new_len, pieces, n_pieces);
 }
 void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
                           const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s) {

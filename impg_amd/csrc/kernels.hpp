@@ -108,8 +108,8 @@ void launch_visited_update(const VisitedTables &vt, const unsigned long long *sv
                            const unsigned long long *gkey, const uint32_t *gstart, const uint32_t *glen,
                            const uint32_t *old_tab, const uint32_t *old_idx, const uint32_t *noff, const uint32_t *poff,
                            uint32_t n_groups, int32_t min_transitive_len, int32_t mdbr, int2 *new_ranges,
-                           uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, const uint32_t *cap, uint32_t *big_list,
-                           uint32_t *n_big, hipStream_t s);
+                           uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, const uint32_t *cap, const uint32_t *pcap,
+                           uint32_t *big_list, uint32_t *n_big, hipStream_t s);
 void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
                           const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s);
 void launch_subset_filter(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *qid,

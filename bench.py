@@ -46,9 +46,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--records", type=int, default=1_000_000)
-    ap.add_argument("--ranges", type=int, default=100_000, help="query ranges per GPU")
-    ap.add_argument("--max-depth", type=int, default=3)
+    ap.add_argument("--records", type=int, default=None)
+    ap.add_argument("--ranges", type=int, default=None, help="query ranges per GPU")
+    ap.add_argument("--max-depth", type=int, default=None)
     ap.add_argument("--no-transitive", action="store_true")
     ap.add_argument("--chunk-ranges", type=int, default=None,
                     help="ranges per chunk (default 50000 on one GPU; 25000 per rank on a sharded index: two chunks per lane)")
@@ -58,6 +58,11 @@ def main():
                     help="impg_gpu_set_option before the run (timing comparisons, e.g. locality_min=0)")
     ap.add_argument("--paf", default=None, help="reuse an existing synthetic PAF file")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even with one rank")
+    ap.add_argument("--workload", default="headline", choices=["headline", "config4", "config5"],
+                    help="headline: BASELINE.json's metric configuration (the default, what the driver runs).  config4: "
+                         "HPRC-scale index from impg_synth_paf records (--records, default 5e7; 20 000 sequences), 100k ranges "
+                         "-x -m 3.  config5: the headline index, contiguous 5 kb windows end to end (--ranges windows per GPU, "
+                         "default the whole genome: 200 000), -x -m 5")
     ap.add_argument("--lanes", type=int, default=2, help="sharded index: chunks of the batch in flight at once per rank")
     ap.add_argument("--no-extras", action="store_true", help="skip the full-results measurement (profiling runs)")
     args = ap.parse_args()
@@ -80,8 +85,17 @@ def main():
     import torch
 
     import impg_amd
+    wl = args.workload
+    if args.records is None:
+        args.records = 50_000_000 if wl == "config4" else 1_000_000
+    if args.ranges is None:
+        args.ranges = 200_000 if wl == "config5" else 100_000
+    if args.max_depth is None:
+        args.max_depth = 5 if wl == "config5" else 3
     if args.chunk_ranges is None:
-        args.chunk_ranges = 25000 if (args.gpus > 1 or args.force_sharded) else 50000
+        args.chunk_ranges = 500 if wl == "config5" else (25000 if (args.gpus > 1 or args.force_sharded) else 50000)
+    if wl != "headline":
+        args.cpu_sample, args.no_extras = 0, True  # the CPU and full-results legs belong to the headline line
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,9 +112,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # ---- synthetic inputs (SplitMix64 seeds 42 / 7) -------
-    n_seq, seq_len = 200, 5_000_000
+    n_seq, seq_len = (20000 if wl == "config4" else 200), 5_000_000
     paf = args.paf or os.path.join(tempfile.gettempdir(), "impg_synth_%d_seed42.paf" % args.records)
-    if rank == 0 and not os.path.exists(paf):
+    if wl == "config4":
+        paf = None  # built straight from generated records: 31 GB of PAF text per 5e7 records would only be parsed again
+    if paf and rank == 0 and not os.path.exists(paf):
         log("writing synthetic PAF %s" % paf)
         impg_amd.synth_paf_text(paf + ".tmp", 42, args.records, n_seq=n_seq, seq_len=seq_len)
         os.replace(paf + ".tmp", paf)
@@ -113,13 +129,16 @@ def main():
     log("building the device index")
     t_build = time.time()
     comm = None
-    if dist is None:
-        index = impg_amd.GpuImpg.from_paf(paf, device=local_rank)
-    else:
+    if dist is not None:
         # this rank's shard of the index (targets bin-packed over the ranks); torch.distributed only carries the
         # RCCL ids to the ranks -- every collective of a query runs inside libimpg_gpu.so
         comm = impg_amd.Comm.rccl(rank, world, local_rank, lanes=args.lanes)
+    if paf:
         index = impg_amd.GpuImpg.from_paf(paf, device=local_rank, comm=comm)
+    else:
+        rec, ops, sl = impg_amd.synth_paf(42, args.records, n_seq=n_seq, seq_len=seq_len)
+        index = impg_amd.GpuImpg.from_records(rec, ops, sl, device=local_rank, comm=comm)
+        del rec, ops
     t_build = time.time() - t_build
     index.set_option("chunk_ranges", args.chunk_ranges)
     index.set_option("pair_budget", args.pair_budget)
@@ -128,11 +147,21 @@ def main():
         index.set_option(k, int(v))
 
     # each rank is home to its own `--ranges` queries (weak scaling): seed 7 + rank
-    bed = impg_amd.synth_bed(7 + rank, args.ranges, n_seq=n_seq, seq_len=seq_len, range_len=5000)
-    name_to_id = {impg_amd.synth_seq_name(k): index.seq_id(impg_amd.synth_seq_name(k)) for k in range(n_seq)}
     ranges = np.zeros(args.ranges, dtype=impg_amd.RANGE_DTYPE)
-    ranges["target_id"] = [name_to_id[impg_amd.synth_seq_name(int(t))] for t in bed["target_id"]]
-    ranges["start"], ranges["end"] = bed["start"], bed["end"]
+    if wl == "config5":  # windows end to end over whole sequences; rank r tiles its own stretch of the genome
+        per_seq = seq_len // 5000
+        k = (np.arange(args.ranges, dtype=np.int64) + rank * args.ranges) % (per_seq * n_seq)
+        ids = np.array([index.seq_id(impg_amd.synth_seq_name(t)) for t in range(n_seq)], dtype=np.uint32)
+        ranges["target_id"], ranges["start"] = ids[k // per_seq], (k % per_seq) * 5000
+        ranges["end"] = ranges["start"] + 5000
+    else:
+        bed = impg_amd.synth_bed(7 + rank, args.ranges, n_seq=n_seq, seq_len=seq_len, range_len=5000)
+        if paf:
+            ids = np.array([index.seq_id(impg_amd.synth_seq_name(t)) for t in range(n_seq)], dtype=np.uint32)
+            ranges["target_id"] = ids[bed["target_id"]]
+        else:
+            ranges["target_id"] = bed["target_id"]  # records carry the generator's ids
+        ranges["start"], ranges["end"] = bed["start"], bed["end"]
     d_ranges = torch.from_numpy(ranges.view(np.uint8)).to(dev)  # resident in HBM before the timed region
 
     def step():  # (a collective call when the index is sharded: every rank brings its own ranges)
@@ -188,7 +217,8 @@ def main():
             tj = json.load(f)
         traffic = tj["hbm_bytes_per_pair"] * (sum(s.pairs for s in stats) or sum(s.projected for s in stats)) / launches
     out = {
-        "metric": "projected ranges/sec, 1M-PAF 100k-BED -x depth 3; CPU coitrees baseline",
+        "metric": "projected ranges/sec, 1M-PAF 100k-BED -x depth 3; CPU coitrees baseline" if wl == "headline" else
+                  "projected ranges/sec, BASELINE %s (not the headline metric)" % wl,
         "value": projected_total / dt,
         "unit": "projected ranges/s",
         "n_gpus": world,
@@ -201,9 +231,10 @@ def main():
         "dtype": "int32",
         "data": "synthetic",
         "config": {
-            "workload": "synthetic PAF %d records (200 seqs x 5 Mb, 10 kb alignments, 200-op CIGARs, bidirectional "
-                        "index), %d x 5 kb query ranges per GPU, %s" %
-                        (args.records, args.ranges, ("-x -m %d" % args.max_depth) if transitive else "no transitive"),
+            "workload": "synthetic PAF %d records (%d seqs x 5 Mb, 10 kb alignments, 200-op CIGARs, bidirectional "
+                        "index), %d %s per GPU, %s" %
+                        (args.records, n_seq, args.ranges, "contiguous 5 kb windows" if wl == "config5" else "x 5 kb query ranges",
+                         ("-x -m %d" % args.max_depth) if transitive else "no transitive"),
             "records": args.records, "ranges_per_gpu": args.ranges, "max_depth": args.max_depth if transitive else 0,
             "min_transitive_len": 101, "min_distance_between_ranges": 10,
             "parallelism": ("1 process/GPU, index sharded by target sequence (bin-packed), frontier all-to-all-v over RCCL, "

@@ -26,7 +26,15 @@ RANGE_DTYPE = np.dtype([("target_id", "<u4"), ("start", "<i4"), ("end", "<i4")])
 INTERVAL_DTYPE = np.dtype([("query_id", "<u4"), ("q_first", "<i4"), ("q_last", "<i4"),
                            ("target_id", "<u4"), ("t_first", "<i4"), ("t_last", "<i4")])
 assert RECORD_DTYPE.itemsize == 40 and RANGE_DTYPE.itemsize == 12
+TP_RECORD_DTYPE = np.dtype([("query_id", "<u4"), ("target_id", "<u4"), ("query_start", "<i4"), ("query_end", "<i4"),
+                            ("target_start", "<i4"), ("target_end", "<i4"), ("seg_off", "<u8"), ("n_segs", "<u4"),
+                            ("strand", "<u4"), ("query_contig_start", "<i8")], align=True)  # impg_gpu_tp_record_t
+assert TP_RECORD_DTYPE.itemsize == 48
 COMM_ID_BYTES = 128
+
+
+class TpMode(C.Structure):  # impg_gpu_tp_mode_t
+    _fields_ = [("fastga", C.c_int32), ("trace_spacing", C.c_int32), ("max_complexity", C.c_int32)]
 
 
 ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint64))
@@ -80,6 +88,8 @@ SYMBOLS = [
     ("impg_gpu_index_create", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_create_files", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, _P, C.c_uint32, C.c_int, C.c_int,
                                               C.c_int, C.POINTER(_P)]),
+    ("impg_gpu_index_create_tracepoints", C.c_int, [_P, C.c_size_t, _P, _P, _P, C.c_size_t, _P, _P, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                                    C.POINTER(_P)]),
     ("impg_gpu_index_create_from_paf", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_save", C.c_int, [_P, C.c_char_p]),
     ("impg_gpu_index_load", C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),

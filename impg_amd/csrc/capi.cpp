@@ -349,6 +349,36 @@ int impg_gpu_index_create_files(const impg_gpu_record_t *records, size_t n_recor
   IMPG_CATCH
 }
 
+int impg_gpu_index_create_tracepoints(const impg_gpu_tp_record_t *records, size_t n_records, const int32_t *tracepoints,
+                                      const int32_t *query_deltas, const int32_t *diffs, size_t n_segs_total,
+                                      const impg_gpu_tp_mode_t *mode, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
+                                      int order_policy, int device, impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out || !mode || (n_records && !records) || (n_segs_total && !tracepoints) || (n_seq && !seq_len))
+    throw Error{IMPG_E_INVALID, "null argument"};
+  if (mode->fastga) {
+    if (n_segs_total && !diffs) throw Error{IMPG_E_INVALID, "FASTGA tracepoints come with per-segment diffs"};
+    if (mode->trace_spacing <= 0) throw Error{IMPG_E_INVALID, "trace_spacing must be positive"};
+  } else if (n_segs_total && !query_deltas) throw Error{IMPG_E_INVALID, "Standard tracepoints come with per-segment query deltas"};
+  require_device(device);
+  // the shared record shape: cigar_off / cigar_len name the alignment's segments
+  std::vector<impg_gpu_record_t> recs(n_records);
+  for (size_t i = 0; i < n_records; i++) {
+    const impg_gpu_tp_record_t &r = records[i];
+    if (r.seg_off + r.n_segs > n_segs_total) throw Error{IMPG_E_INVALID, "record segments outside the pools"};
+    recs[i] = impg_gpu_record_t{r.query_id, r.target_id, r.query_start, r.query_end, r.target_start, r.target_end, r.seg_off, r.n_segs,
+                                r.strand};
+  }
+  TpInput tp{records, tracepoints, query_deltas, diffs, n_segs_total, *mode};
+  auto ix = std::make_unique<impg_gpu_index>();
+  ix->device = device;
+  build_index(*ix, recs.data(), n_records, nullptr, n_segs_total, seq_len, n_seq, bidirectional != 0, order_policy, 0, 1, nullptr, &tp);
+  { EngineLease warm(*ix); }
+  *out = ix.release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
 int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths, int bidirectional, int order_policy, int device,
                                    impg_gpu_index_t **out) {
   IMPG_TRY

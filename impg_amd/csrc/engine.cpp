@@ -396,6 +396,8 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   split_ok = n > 1 && !remote;  // (ranks of a sharded batch stay in lock step: no re-splitting)
   min_identity = p.min_identity;
   store_cigar = p.store_cigar != 0 && keep != nullptr;  // slices are only materialised for full results
+  if (store_cigar && ix.tp_mode)
+    throw Error{IMPG_E_UNSUPPORTED, "store_cigar is not offered on a tracepoint index (the approximate mode has no CIGAR to slice)"};
   multi = p.multi_impg != 0;
   const DeviceIndexView &v = ix.view;
   cur_ranges = d_ranges;
@@ -472,6 +474,7 @@ void Engine::finish_run(impg_gpu_stats_t *st, hipEvent_t t0, hipEvent_t t1) {
   IMPG_HIP(hipStreamSynchronize(stream));
   uint64_t hc[3];
   IMPG_HIP(hipMemcpy(hc, counters.p, 24, hipMemcpyDeviceToHost));
+  if (hc[2] & 2) throw Error{IMPG_E_INVALID, "Projection resulted in negative query coordinates"};  // the reference panics (impg.rs:1509-1514)
   if (hc[2]) throw Error{IMPG_E_INVALID, "an alignment hit by the query has no CIGAR (missing cg:Z tag)"};
   hc[1] = read_slots(acc_slots);
   if (st) {

@@ -110,6 +110,7 @@ struct DeviceIndexView {  // passed by value to kernels
   uint32_t n_entries;
   uint32_t sorted_order;     // 1 = rank is the identity (IMPG_ORDER_SORTED)
   uint32_t max_seg;          // entries of the largest segment: visit ranks stay below it
+  uint32_t tp_mode;          // 1 = tracepoint index (approximate mode): `ops` holds one uint4 of prefix sums per segment boundary
 };
 
 struct HostSeqIndex {  // SequenceIndex (seqidx.rs)
@@ -162,6 +163,14 @@ struct ParsedPaf {
 void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out);
 void parse_paf_text(const char *text, size_t len, ParsedPaf &out);
 long parse_cigar(const char *s, size_t n, uint32_t *out, size_t cap);
+
+// tracepoint alignments (approximate mode): what build_index reads instead of the op pool
+struct TpInput {
+  const impg_gpu_tp_record_t *records;
+  const int32_t *tracepoints, *query_deltas, *diffs;
+  size_t n_segs_total;
+  impg_gpu_tp_mode_t mode;
+};
 
 // visit rank of each sorted position of an n-entry segment (order policy)
 void coitrees_visit_rank(uint32_t n, uint32_t *rank_out);
@@ -229,6 +238,7 @@ struct impg_gpu_index {
   impg::DevBuf *blob(int k);
   size_t blob_bytes[N_BLOBS] = {};
   bool multi_file = false;
+  bool tp_mode = false;  // built from tracepoints: every projection is the approximate one
   void bind_view(uint32_t n_seq, uint32_t sorted_order);  // view pointers from the device arrays
   size_t device_bytes = 0;
   // engines (engine.cpp: stream + scratch + the visited sets of one batch in flight), handed out by EngineLease

@@ -132,7 +132,7 @@ void parallel_chunks(size_t n, const std::function<void(size_t, size_t)> &f) {
 
 void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops,
                  size_t n_ops, const int64_t *seq_len, uint32_t n_seq, bool bidirectional, int order_policy,
-                 uint32_t shard, uint32_t n_shards, const uint32_t *owner) {
+                 uint32_t shard, uint32_t n_shards, const uint32_t *owner, const TpInput *tp) {
   if (n_shards == 0 || shard >= n_shards) throw Error{IMPG_E_INVALID, "bad shard"};
   if (order_policy != IMPG_ORDER_COITREES && order_policy != IMPG_ORDER_SORTED)
     throw Error{IMPG_E_INVALID, "bad order policy"};
@@ -167,10 +167,55 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     n_tiles += (records[i].cigar_len + TILE_OPS - 1) / TILE_OPS;
     if (n_tiles >= (1ull << 32) - 2) throw Error{IMPG_E_UNSUPPORTED, "op pool exceeds 2^32 tiles"};
   }
+  if (tp) {  // tracepoint alignments: a record occupies n_segs + 1 prefix-sum boundaries of 16 bytes, no tiles
+    n_tiles = 0;
+    uint64_t nb = 0;
+    for (size_t i = 0; i < n_records; i++) {
+      if (!need[i]) continue;
+      tile_base[i] = (uint32_t)nb;
+      nb += (uint64_t)records[i].cigar_len + 1;
+      if (nb >= (1ull << 32) - 2) throw Error{IMPG_E_UNSUPPORTED, "tracepoint pool exceeds 2^32 boundaries"};
+    }
+    n_tiles = (nb * 4 + TILE_WORDS - 1) / TILE_WORDS;  // (the pool is accounted in 128-byte lines like the op pool)
+  }
   std::vector<uint32_t> pool(n_tiles * TILE_WORDS, OP_PAD);
-  std::vector<uint4> idp(TILE_SUBS * n_tiles);  // per sub-tile: matched / mismatched bases and gap ops before it (identity filter)
+  std::vector<uint4> idp(tp ? 0 : TILE_SUBS * n_tiles);  // per sub-tile: matched / mismatched bases and gap ops before it (identity filter)
   std::atomic<bool> bad_op{false};
-  parallel_chunks(n_records, [&](size_t lo, size_t hi) {
+  std::atomic<bool> bad_tp{false};
+  if (tp) parallel_chunks(n_records, [&](size_t lo, size_t hi) {
+    // per boundary k of a record: {sum |tracepoint|, sum query delta, sum matches, sum mismatches} over segments < k
+    // (scan_overlapping_tracepoints, impg.rs:737-803, turned into prefix sums: the scan becomes two searches)
+    for (size_t i = lo; i < hi; i++) {
+      if (!need[i]) continue;
+      const impg_gpu_tp_record_t &r = tp->records[i];
+      uint4 *out = reinterpret_cast<uint4 *>(pool.data()) + tile_base[i];
+      uint64_t st = 0, sq = 0, sm = 0, sx = 0;
+      int32_t fb = 0;
+      if (tp->mode.fastga) {
+        const int32_t ts = tp->mode.trace_spacing, qsc = (int32_t)r.query_contig_start;
+        fb = ((qsc / ts) + 1) * ts - qsc;  // impg.rs:730
+      }
+      for (uint32_t k = 0; k <= r.n_segs; k++) {
+        out[k] = make_uint4((uint32_t)st, (uint32_t)sq, (uint32_t)sm, (uint32_t)sx);
+        if (k == r.n_segs) break;
+        const int64_t t = tp->tracepoints[r.seg_off + k];
+        const int64_t qd = tp->mode.fastga ? (k == 0 ? fb : tp->mode.trace_spacing) : tp->query_deltas[r.seg_off + k];
+        if (t < 0 || qd < 0) { bad_tp = true; break; }
+        int64_t nd;  // impg.rs:771-787
+        if (tp->mode.fastga) nd = tp->diffs[r.seg_off + k];
+        else nd = (qd == 0 || t == 0) ? std::max(qd, t) : (int64_t)tp->mode.max_complexity;
+        if (nd < 0) { bad_tp = true; break; }
+        st += (uint64_t)t; sq += (uint64_t)qd;
+        sm += (uint64_t)std::max<int64_t>(std::min(qd, t) - nd, 0);  // impg.rs:800-802
+        sx += (uint64_t)nd;
+        if (st >= (1ull << 31) || sq >= (1ull << 31) || sm >= (1ull << 31) || sx >= (1ull << 31)) { bad_tp = true; break; }
+      }
+      rec_totT[i] = (uint32_t)st;
+      rec_totQ[i] = (uint32_t)sq;
+    }
+  });
+  if (bad_tp) throw Error{IMPG_E_UNSUPPORTED, "tracepoints, query deltas and diffs must be non-negative and sum below 2^31 per alignment"};
+  if (!tp) parallel_chunks(n_records, [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; i++) {
       if (!need[i]) continue;
       const uint32_t *src = cigar_ops + records[i].cigar_off;
@@ -276,7 +321,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   // entry); back-to-front walk (reversed entry on the reverse strand): total
   // minus the prefix at the END of the mirrored tile.
   std::vector<uint32_t> ext_cp;
-  {
+  if (!tp) {
     std::vector<uint64_t> ext_off(n_entries + 1, 0);
     for (size_t i = 0; i < n_entries; i++) {
       uint32_t n = ent[i].nops_flags & OP_LEN_MASK, m = (n + TILE_OPS - 1) / TILE_OPS;
@@ -445,6 +490,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   ix.n_tiles = n_tiles;
   ix.n_targets = n_targets;
   ix.multi_file = multi_file;
+  ix.tp_mode = tp != nullptr;
   ix.bind_view(n_seq, order_policy == IMPG_ORDER_SORTED);
 }
 
@@ -474,6 +520,7 @@ void impg_gpu_index::bind_view(uint32_t n_seq, uint32_t sorted_order) {
   view.n_seq = n_seq;
   view.n_entries = (uint32_t)n_entries;
   view.sorted_order = sorted_order;
+  view.tp_mode = tp_mode ? 1u : 0u;
   view.max_seg = 0;
   for (size_t t = 0; t + 1 < h_tgt_off.size(); t++) view.max_seg = std::max(view.max_seg, h_tgt_off[t + 1] - h_tgt_off[t]);
   if (h_tgt_off.empty()) view.max_seg = (uint32_t)n_entries;

@@ -1083,6 +1083,118 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
 }
 
 // ---------------------------------------------------------------------------
+// Approximate mode on tracepoint alignments: scan_overlapping_tracepoints + project_overlapping_interval_fast
+// (impg.rs:646-823, :1317-1533).  The reference walks an alignment's trace segments from its start and keeps the
+// first and the last one that overlap the range plus sums over all of them; segment positions are monotone along
+// the scan axis, so with the per-boundary prefix sums {sum |tracepoint|, sum query delta, sum matches, sum
+// mismatches} the index stores (index_build.cpp) the first / last overlapping segments are two binary searches
+// and the sums two differences.  What remains is the reference's boundary refinement, an f64 interpolation inside
+// the first and the last segment, done here with the same operations in the same order (division, two
+// multiplications -- nothing a fused multiply-add could contract --, round half away from zero).
+// One lane per (range, entry) pair, same pair lists and slot discipline as project_kernel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int32_t tp_refine(int32_t query_pos, int32_t query_delta, int32_t seg_start, int32_t overlap_pos,
+                                             int32_t abs_target_delta, bool first, int32_t lo, int32_t hi) {
+  int32_t refined;
+  if (abs_target_delta == 0) {  // impg.rs:1381-1398: a pure insertion maps to one target point
+    refined = first ? query_pos : query_pos + query_delta;
+  } else {
+    const double target_fraction = (double)(overlap_pos - seg_start) / (double)abs_target_delta;
+    const double indel_ratio = (double)query_delta / (double)abs_target_delta;
+    const double query_advance = target_fraction * (double)abs_target_delta * indel_ratio;
+    const double r = round(query_advance);
+    const int32_t adv = r >= 2147483647.0 ? 2147483647 : r <= -2147483648.0 ? (-2147483647 - 1) : (int32_t)r;  // `as i32` saturates
+    refined = (int32_t)((uint32_t)query_pos + (uint32_t)adv);
+  }
+  return min(max(refined, lo), hi);
+}
+template <bool TRANSITIVE>
+__global__ __launch_bounds__(256) void project_tp_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
+                                                         const uint32_t *__restrict__ pair_range,
+                                                         const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
+                                                         HitArrays h, unsigned long long *__restrict__ accepted,
+                                                         uint32_t *__restrict__ err_flag, double min_identity, int use_ident,
+                                                         ProjList pl) {
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);  // one contiguous eighth of the pair list per XCD
+  const uint32_t pp = lblock * 256u + threadIdx.x;
+  bool ok = false;
+  if (pp < n_pairs) {
+    const uint32_t p = pl.slot ? pl.slot[pp] : pp;
+    const uint32_t r = pl.slot ? pl.range[pp] : pair_range[p];
+    const FrontierRec f = fr[r];
+    const uint4 *ep = reinterpret_cast<const uint4 *>(v.entries + (pl.slot ? pl.entry[pp] : pair_entry[p]));
+    const uint4 e0 = ep[0], e1 = ep[1];
+    const int32_t m_ts = (int32_t)e0.x, m_te = (int32_t)e0.y, m_qs = (int32_t)e0.z, m_qe = (int32_t)e0.w;  // the entry's metadata axes
+    const uint32_t n = e1.z & OP_LEN_MASK;
+    const bool is_reverse = (e1.z & EF_STRAND) != 0, reversed_entry = (e1.z & EF_REVERSED) != 0;
+    int32_t rs = f.start, re = f.end;
+    if (TRANSITIVE) { rs = max(rs, m_ts); re = min(re, m_te); }  // the clipped overlap (impg.rs:2398-2400)
+    uint32_t qid = HIT_NONE;
+    int4 out = make_int4(0, 0, 0, 0);
+    if (!(m_ts >= re || m_te <= rs) && n) {  // impg.rs:1327-1329
+      const uint4 *B = reinterpret_cast<const uint4 *>(v.ops) + e1.y;  // boundaries 0..n of the record
+      // scan axis / project axis of this entry (impg.rs:676-713)
+      const int sdir = reversed_entry ? 1 : (is_reverse ? -1 : 1);
+      const int pdir = reversed_entry ? (is_reverse ? -1 : 1) : 1;
+      const int32_t s0 = reversed_entry ? m_ts : (is_reverse ? m_te : m_ts);
+      const int32_t p0 = reversed_entry ? (is_reverse ? m_qe : m_qs) : m_qs;
+      // S = the scan-axis prefix (x = sum |tracepoint| for a forward entry, y = sum query delta for a reversed one)
+      const int64_t x_lo = sdir > 0 ? (int64_t)rs - s0 : (int64_t)s0 - re, x_hi = sdir > 0 ? (int64_t)re - s0 : (int64_t)s0 - rs;
+      auto S = [&](uint32_t k) -> int64_t { const uint4 b = B[k]; return (int64_t)(reversed_entry ? b.y : b.x); };
+      // first = #{i in [1, n] : S[i] <= x_lo}: the first segment whose far end passes the range's near end
+      uint32_t lo = 1, hi = n + 1;
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S(mid) <= x_lo) lo = mid + 1; else hi = mid; }
+      const uint32_t first = lo - 1;
+      // last = #{i in [0, n) : S[i] < x_hi} - 1: the last segment that starts before the range's far end
+      lo = 0; hi = n;
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S(mid) < x_hi) lo = mid + 1; else hi = mid; }
+      if (first < n && lo > 0 && first <= lo - 1) {
+        const uint32_t last = lo - 1;
+        const uint4 bf0 = B[first], bf1 = B[first + 1], bl0 = B[last], bl1 = B[last + 1];
+        auto seg = [&](const uint4 &a, const uint4 &b, int32_t &ppos, int32_t &pdelta, int32_t &sstart, int32_t &send, int32_t &asd) {
+          const int32_t sa = (int32_t)(reversed_entry ? a.y : a.x), sb = (int32_t)(reversed_entry ? b.y : b.x);
+          const int32_t ja = (int32_t)(reversed_entry ? a.x : a.y), jb = (int32_t)(reversed_entry ? b.x : b.y);
+          const int32_t pa = s0 + sdir * sa, pb = s0 + sdir * sb;
+          sstart = min(pa, pb); send = max(pa, pb); asd = sb - sa;
+          ppos = p0 + pdir * ja; pdelta = pdir * (jb - ja);
+        };
+        const int32_t qlo = min(m_qs, m_qe), qhi = max(m_qs, m_qe);
+        int32_t ppos, pdelta, sstart, send, asd;
+        seg(bf0, bf1, ppos, pdelta, sstart, send, asd);
+        const int32_t refined_first = tp_refine(ppos, pdelta, sstart, max(sstart, rs), asd, true, qlo, qhi);
+        seg(bl0, bl1, ppos, pdelta, sstart, send, asd);
+        const int32_t refined_last = tp_refine(ppos, pdelta, sstart, min(send, re), asd, false, qlo, qhi);
+        bool keep = true;
+        if (use_ident) {  // the approximate CIGAR "M= X X" (impg.rs:1476-1491)
+          const int64_t mm = (int64_t)bl1.z - bf0.z, xx = (int64_t)bl1.w - bf0.w;
+          const int64_t total = mm + xx;
+          const double ident = total == 0 ? 0.0 : (double)mm / (double)total;
+          keep = !(ident < min_identity);
+        }
+        if (keep) {
+          if (refined_first < 0 || refined_last < 0) atomicOr(err_flag, 2u);  // the reference panics (impg.rs:1509-1514)
+          const bool swap_q = is_reverse && !reversed_entry;  // impg.rs:1497-1501
+          out = make_int4(swap_q ? refined_last : refined_first, swap_q ? refined_first : refined_last, rs, re);
+          qid = e1.x;
+          ok = true;
+        }
+      }
+    }
+    h.qid[p] = qid;
+    if (ok) h.c[p] = out;
+  }
+  __shared__ uint32_t wcnt[4];
+  unsigned long long m = __ballot(ok);
+  if (lane_id() == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (tot) atomicAdd(&accepted[(blockIdx.x % COUNT_SLOTS) * COUNT_STRIDE], (unsigned long long)tot);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // store_cigar: materialise the projected CIGAR slices (impg.rs:2878-2886)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void slice_counts_kernel(HitArrays h, SliceArrays sl, uint32_t n_pairs,
@@ -2309,6 +2421,14 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
                     ProjList pl, hipStream_t s) {
   if (!n_pairs) return;
   const bool ident = min_identity == min_identity;  // NaN = no filter
+  if (v.tp_mode) {  // tracepoint index: every projection is the approximate one
+    const uint32_t gt = (cdiv(n_pairs, 256) + 7u) & ~7u;
+    if (transitive) project_tp_kernel<true><<<gt, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag,
+                                                               ident ? min_identity : 0.0, ident ? 1 : 0, pl);
+    else project_tp_kernel<false><<<gt, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag,
+                                                     ident ? min_identity : 0.0, ident ? 1 : 0, pl);
+    return;
+  }
   const uint32_t g = (cdiv(n_pairs, 256) + 7u) & ~7u;  // a multiple of the 8 XCDs (see the block mapping in the kernel)
   const int xcd_map = 1;
   const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};

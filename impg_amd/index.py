@@ -147,6 +147,23 @@ class GpuImpg:
         ix._comm = comm  # the communicator outlives the index
         return ix
 
+    @classmethod
+    def from_tracepoints(cls, records, tracepoints, seq_len, query_deltas=None, diffs=None, fastga=False, trace_spacing=0,
+                         max_complexity=0, bidirectional=True, order=_lib.ORDER_COITREES, device=0):
+        """impg_gpu_index_create_tracepoints: an index over tracepoint alignments (.1aln / .tpa content handed over as
+        arrays); every query on it runs in approximate mode (approximate_mode = true of the trait)."""
+        rec = np.ascontiguousarray(records, dtype=_lib.TP_RECORD_DTYPE)
+        tp = np.ascontiguousarray(tracepoints, dtype=np.int32)
+        qd = None if query_deltas is None else np.ascontiguousarray(query_deltas, dtype=np.int32)
+        df = None if diffs is None else np.ascontiguousarray(diffs, dtype=np.int32)
+        sl = np.ascontiguousarray(seq_len, dtype=np.int64)
+        mode = _lib.TpMode(int(bool(fastga)), int(trace_spacing), int(max_complexity))
+        h = C.c_void_p(None)
+        check(lib().impg_gpu_index_create_tracepoints(rec.ctypes.data, rec.size, tp.ctypes.data, None if qd is None else qd.ctypes.data,
+                                                      None if df is None else df.ctypes.data, tp.size, C.byref(mode), sl.ctypes.data,
+                                                      sl.size, int(bidirectional), order, device, C.byref(h)))
+        return cls(h)
+
     def save(self, path):
         """impg_gpu_index_save: the built index (device arrays + sequence table) as one file."""
         check(lib().impg_gpu_index_save(self._h, os.fsencode(path)))
@@ -272,8 +289,8 @@ class GpuImpg:
     def query(self, target_id, range_start, range_end, store_cigar=False, min_gap_compressed_identity=None,
               sequence_index=None, approximate_mode=False):
         """ImpgIndex::query (impg_index.rs:26-35)."""
-        if approximate_mode:
-            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "approximate (tracepoint) mode is out of scope")
+        # approximate_mode is a property of the index here: one built from tracepoints (from_tracepoints) answers
+        # in approximate mode, one built from CIGARs in exact mode
         p = make_params(transitive=False, store_cigar=store_cigar, min_identity=min_gap_compressed_identity)
         return self.query_batch([(target_id, range_start, range_end)], p)[0]
 
@@ -282,8 +299,6 @@ class GpuImpg:
                              store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
                              approximate_mode=False, subset_filter=None):
         """ImpgIndex::query_transitive_bfs (impg_index.rs:79-94)."""
-        if approximate_mode:
-            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "approximate_mode")
         p = make_params(True, False, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
                         min_gap_compressed_identity, store_cigar)
         return self.query_batch([(target_id, range_start, range_end)], p, masked_regions=masked_regions,
@@ -294,8 +309,6 @@ class GpuImpg:
                              store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
                              approximate_mode=False, subset_filter=None):
         """ImpgIndex::query_transitive_dfs (impg_index.rs:63-77)."""
-        if approximate_mode:
-            raise _lib.ImpgGpuError(_lib.IMPG_E_UNSUPPORTED, "approximate_mode")
         p = make_params(True, True, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
                         min_gap_compressed_identity, store_cigar)
         return self.query_batch([(target_id, range_start, range_end)], p, masked_regions=masked_regions,

@@ -111,6 +111,40 @@ int impg_gpu_index_create_files(const impg_gpu_record_t *records, size_t n_recor
                                 uint32_t n_seq, const uint64_t *file_first_record, uint32_t n_files,
                                 int bidirectional, int order_policy, int device, impg_gpu_index_t **out);
 
+/* ---- tracepoint alignments: approximate mode (approximate_mode = true of the trait, impg_index.rs:26-94;
+ *      scan_overlapping_tracepoints + project_overlapping_interval_fast, impg.rs:646-823, :1317-1533).
+ * The .1aln / .tpa readers stay with the host (onealn.rs, tpa crate): it hands every alignment over as its
+ * tracepoints -- n_segs target deltas at tracepoints[seg_off ..] -- plus, per TracepointModeData (onealn.rs:772-782),
+ *   Standard: query_deltas[seg_off ..] and the file's max_complexity (per-segment diffs are estimated from it),
+ *   FASTGA:   diffs[seg_off ..], the file's trace_spacing and the alignment's query_contig_start (the first query
+ *             delta is ((query_contig_start / spacing) + 1) * spacing - query_contig_start, impg.rs:726-735).
+ * An index built this way answers every query in approximate mode: the query interval of a hit is interpolated
+ * inside the first and the last overlapping trace segment (one f64 division and rounding each, bit-for-bit the
+ * reference's arithmetic), its target interval is the (clipped) range itself, and the identity filter sees the
+ * segment statistics ("N= MX").  Per alignment the index keeps prefix sums of the four per-segment quantities, so
+ * a projection is two binary searches instead of a scan.  Tracepoints and query deltas must be non-negative (they
+ * are in files FASTGA / the tracepoints crate write; the reference takes abs() of the former in places) and sum
+ * below 2^31 per alignment: IMPG_E_UNSUPPORTED otherwise.  store_cigar is not offered (IMPG_E_UNSUPPORTED); the
+ * exact mode of these files needs the sequences and a WFA realignment and stays with the host. */
+typedef struct {
+  uint32_t query_id, target_id;
+  int32_t query_start, query_end, target_start, target_end;
+  uint64_t seg_off; /* first segment of this alignment in the pools */
+  uint32_t n_segs;
+  uint32_t strand;  /* 0 '+', 1 '-' */
+  int64_t query_contig_start; /* FASTGA only */
+} impg_gpu_tp_record_t;
+typedef struct {
+  int32_t fastga;         /* 0 Standard, 1 FASTGA */
+  int32_t trace_spacing;  /* FASTGA */
+  int32_t max_complexity; /* Standard */
+} impg_gpu_tp_mode_t;
+int impg_gpu_index_create_tracepoints(const impg_gpu_tp_record_t *records, size_t n_records, const int32_t *tracepoints,
+                                      const int32_t *query_deltas /* Standard, else NULL */,
+                                      const int32_t *diffs /* FASTGA, else NULL */, size_t n_segs_total,
+                                      const impg_gpu_tp_mode_t *mode, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
+                                      int order_policy, int device, impg_gpu_index_t **out);
+
 /* Same, parsing PAF files on the host the way paf.rs:118-194 does; sequence ids
  * are assigned in first-seen order over the files (query then target per line). */
 int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths,

@@ -445,7 +445,18 @@ struct COITree {
 /* ------------------------------------------------------------------------ */
 /* alignment files + index                                                   */
 /* ------------------------------------------------------------------------ */
+/* OneAlnAlignment (onealn.rs:786-802), the fields the approximate mode reads */
+struct TpAlignment {
+  std::vector<int64_t> tracepoints;
+  bool fastga = false;             /* TracepointModeData (onealn.rs:772-782) */
+  std::vector<int64_t> diffs;      /* Fastga */
+  int64_t trace_spacing = 0;       /* Fastga */
+  std::vector<int64_t> query_deltas; /* Standard */
+  int64_t max_complexity = 0;      /* Standard */
+  int64_t query_contig_start = 0;
+};
 struct AlnFile {
+  std::vector<TpAlignment> tp;  /* tracepoint files (.1aln / .tpa): alignment by record index (impg.rs:568, :612) */
   std::string path;
   int fd = -1;
   const char *mem = nullptr;
@@ -470,6 +481,7 @@ struct oracle_index {
   TreeMap trees;                    /* Impg (single index over all files) */
   std::vector<TreeMap> file_trees;  /* MultiImpg: one Impg per file */
   bool preparse = false;
+  bool approximate = false;  /* built from tracepoints: every projection is project_overlapping_interval_fast */
   size_t n_records = 0;
   ~oracle_index() { for (auto &f : files) if (f.fd >= 0) close(f.fd); }
 };
@@ -622,11 +634,125 @@ bool get_cigar_ops(const oracle_index &ix, const QueryMetadata &md, std::vector<
   return true;
 }
 
+/* SubsettingResult + scan_overlapping_tracepoints (impg.rs:646-823) */
+struct SegInfo { int32_t project_pos, project_delta, seg_start, seg_end, abs_scan_delta, num_diffs; };
+struct SubsettingResult {
+  size_t first_idx, last_idx;
+  int32_t first_query_pos, last_query_pos;
+  int num_overlapping_segments;
+  double total_matches, total_mismatches;
+  SegInfo first_segment_info, last_segment_info;
+};
+bool scan_overlapping_tracepoints(const TpAlignment &alignment, const QueryMetadata &metadata, int32_t range_start,
+                                  int32_t range_end, bool is_reversed_entry, SubsettingResult &out) {
+  const bool is_reverse = metadata.strand_reverse();
+  const int32_t scan_dir = is_reversed_entry ? 1 : (is_reverse ? -1 : 1);         /* :676-682 */
+  const int32_t project_dir = is_reversed_entry ? (is_reverse ? -1 : 1) : 1;       /* :683-691 */
+  int32_t scan_pos = is_reversed_entry ? metadata.target_start : (is_reverse ? metadata.target_end : metadata.target_start);
+  int32_t project_pos = is_reversed_entry ? (is_reverse ? metadata.query_end : metadata.query_start) : metadata.query_start;
+  bool have_first = false;
+  size_t first_idx = 0, last_idx = 0;
+  int32_t first_project_pos = 0, last_project_pos = 0;
+  SegInfo first_info{}, last_info{};
+  int num_overlapping = 0;
+  double total_matches = 0.0, total_mismatches = 0.0;
+  int32_t trace_spacing = 0, first_boundary = 0;
+  if (alignment.fastga) { /* :726-735 */
+    const int32_t ts = (int32_t)alignment.trace_spacing;
+    const int32_t qsc = (int32_t)alignment.query_contig_start;
+    trace_spacing = ts;
+    first_boundary = ((qsc / ts) + 1) * ts - qsc;
+  }
+  for (size_t idx = 0; idx < alignment.tracepoints.size(); idx++) {
+    const int64_t tracepoint = alignment.tracepoints[idx];
+    const int32_t query_delta = alignment.fastga ? (idx == 0 ? first_boundary : trace_spacing) : (int32_t)alignment.query_deltas[idx];
+    const int32_t abs_tracepoint = (int32_t)(tracepoint < 0 ? -tracepoint : tracepoint);
+    int32_t scan_delta, project_delta, abs_scan_delta;
+    if (is_reversed_entry) { scan_delta = query_delta; project_delta = abs_tracepoint * project_dir; abs_scan_delta = query_delta; }
+    else { scan_delta = (int32_t)tracepoint * scan_dir; project_delta = query_delta; abs_scan_delta = abs_tracepoint; }
+    const int32_t seg_start = std::min(scan_pos, scan_pos + scan_delta);
+    const int32_t seg_end = std::max(scan_pos, scan_pos + scan_delta);
+    if (seg_start < range_end && seg_end > range_start) { /* :769 */
+      num_overlapping += 1;
+      int32_t num_diffs;
+      if (alignment.fastga) num_diffs = idx < alignment.diffs.size() ? (int32_t)alignment.diffs[idx] : 0;
+      else num_diffs = (query_delta == 0 || abs_tracepoint == 0) ? std::max(query_delta, abs_tracepoint) : (int32_t)alignment.max_complexity;
+      const SegInfo seg_info{project_pos, project_delta, seg_start, seg_end, abs_scan_delta, num_diffs};
+      if (!have_first) { have_first = true; first_idx = idx; first_project_pos = project_pos; first_info = seg_info; }
+      last_idx = idx;
+      last_project_pos = project_pos + project_delta;
+      last_info = seg_info;
+      const double aligned_len = std::max((double)std::min(std::abs(project_delta), abs_scan_delta), 0.0);
+      total_matches += std::max(aligned_len - (double)num_diffs, 0.0);
+      total_mismatches += (double)num_diffs;
+    }
+    scan_pos += scan_delta;
+    project_pos += project_delta;
+    if ((scan_dir == -1 && scan_pos <= range_start) || (scan_dir == 1 && scan_pos >= range_end)) break; /* :806-810 */
+  }
+  if (!have_first) return false;
+  out = SubsettingResult{first_idx, last_idx, first_project_pos, last_project_pos, num_overlapping, total_matches, total_mismatches,
+                         first_info, last_info};
+  return true;
+}
+
+/* project_overlapping_interval_fast (impg.rs:1317-1533): returns 1 Some, 0 None, -1 error (the reference panics) */
+int project_overlapping_interval_fast(const oracle_index &ix, const QueryMetadata &metadata, uint32_t target_id,
+                                      int32_t range_start, int32_t range_end, double min_identity, AdjustedInterval &out) {
+  if (metadata.target_start >= range_end || metadata.target_end <= range_start) return 0; /* :1327-1329 */
+  const AlnFile &f = ix.files[metadata.alignment_file_index];
+  if (metadata.data_offset() >= f.tp.size()) return 0; /* "Cannot fetch tracepoint alignment ... skipping" */
+  const TpAlignment &alignment = f.tp[metadata.data_offset()];
+  SubsettingResult subset;
+  if (!scan_overlapping_tracepoints(alignment, metadata, range_start, range_end, metadata.is_reversed(), subset)) return 0;
+  const bool is_reverse = metadata.strand_reverse();
+  const int32_t working_query_start = metadata.query_start, working_query_end = metadata.query_end;
+  auto refine_boundary = [&](int32_t query_pos, int32_t query_delta, int32_t segment_target_start, int32_t overlap_pos,
+                             int32_t abs_target_delta, bool first) -> int32_t {
+    const int32_t lo = std::min(working_query_start, working_query_end), hi = std::max(working_query_start, working_query_end);
+    if (abs_target_delta == 0) { /* :1381-1398 */
+      const int32_t refined_pos = first ? query_pos : query_pos + query_delta;
+      return std::min(std::max(refined_pos, lo), hi);
+    }
+    const double target_fraction = (double)(overlap_pos - segment_target_start) / (double)abs_target_delta;
+    const double indel_ratio = (double)query_delta / (double)abs_target_delta;
+    const double query_advance = target_fraction * (double)abs_target_delta * indel_ratio;
+    const double rounded = std::round(query_advance); /* f64::round: half away from zero */
+    int32_t adv; /* `as i32` saturates */
+    if (rounded >= 2147483647.0) adv = INT32_MAX; else if (rounded <= -2147483648.0) adv = INT32_MIN; else adv = (int32_t)rounded;
+    const int32_t refined_pos = (int32_t)((uint32_t)query_pos + (uint32_t)adv);
+    return std::min(std::max(refined_pos, lo), hi);
+  };
+  const SegInfo &fi = subset.first_segment_info;
+  const int32_t overlap_start = std::max(fi.seg_start, range_start);
+  const int32_t refined_first = refine_boundary(fi.project_pos, fi.project_delta, fi.seg_start, overlap_start, fi.abs_scan_delta, true);
+  const SegInfo &li = subset.last_segment_info;
+  const int32_t overlap_end = std::min(li.seg_end, range_end);
+  const int32_t refined_last = refine_boundary(li.project_pos, li.project_delta, li.seg_start, overlap_end, li.abs_scan_delta, false);
+  std::vector<uint32_t> approx_cigar; /* :1476-1483 */
+  if (subset.total_matches > 0.0) { uint32_t v; cigar_new((int32_t)std::round(subset.total_matches), '=', &v); approx_cigar.push_back(v); }
+  if (subset.total_mismatches > 0.0) { uint32_t v; cigar_new((int32_t)std::round(subset.total_mismatches), 'X', &v); approx_cigar.push_back(v); }
+  if (!std::isnan(min_identity)) {
+    if (gap_compressed_identity(approx_cigar.data(), approx_cigar.size()) < min_identity) return 0;
+  }
+  int32_t query_start = refined_first, query_end = refined_last;
+  if (is_reverse && !metadata.is_reversed()) std::swap(query_start, query_end); /* :1497-1501 */
+  if (refined_first < 0 || refined_last < 0) { set_err("Projection resulted in negative query coordinates"); return -1; }
+  out.q_id = metadata.query_id; out.q_first = query_start; out.q_last = query_end;
+  out.t_id = target_id; out.t_first = range_start; out.t_last = range_end;
+  out.cigar = std::move(approx_cigar);
+  g_nproj++;
+  return 1;
+}
+
 /* project_overlapping_interval, PAF branch (impg.rs:1260-1312).
  * returns 1 Some, 0 None, -1 error */
 int project_overlapping_interval(const oracle_index &ix, const QueryMetadata &md, uint32_t target_id,
                                  int32_t range_start, int32_t range_end, double min_identity,
                                  AdjustedInterval &out) {
+  /* an index built from tracepoints answers in approximate mode (approximate_mode = true of impg.rs:1860 ff):
+   * the exact mode of .1aln / .tpa needs the sequences and a WFA realignment and is out of scope */
+  if (ix.approximate) return project_overlapping_interval_fast(ix, md, target_id, range_start, range_end, min_identity, out);
   thread_local std::vector<uint32_t> cigar_ops;
   if (!get_cigar_ops(ix, md, cigar_ops)) return -1;
   Projection pr;
@@ -1306,6 +1432,38 @@ oracle_index_t *oracle_index_from_paf_text(const char *text, size_t len, int bid
   std::vector<std::vector<AlignmentRecord>> recs(1);
   if (!parse_paf(ix->files[0].mem, len, ix->seq_index, recs[0])) { delete ix; return nullptr; }
   return finish_index(ix, recs, bidirectional != 0, preparse != 0);
+}
+/* An index over tracepoint alignments (what Impg::from_multi_alignment_records builds from .1aln / .tpa records:
+ * data_offset = the alignment's index in its file, impg.rs:568, :612).  Queries on it run in approximate mode. */
+oracle_index_t *oracle_index_from_tracepoints(const oracle_tp_record_t *records, size_t n_records, const int32_t *tracepoints,
+                                              const int32_t *query_deltas, const int32_t *diffs, int fastga, int32_t trace_spacing,
+                                              int32_t max_complexity, const int64_t *seq_len, uint32_t n_seq, int bidirectional) {
+  auto *ix = new oracle_index();
+  for (uint32_t i = 0; i < n_seq; i++) ix->seq_index.get_or_insert_id("seq" + std::to_string(i), seq_len[i]);
+  AlnFile af;
+  af.path = "<tracepoints>";
+  std::vector<std::vector<AlignmentRecord>> recs(1);
+  for (size_t i = 0; i < n_records; i++) {
+    const oracle_tp_record_t &r = records[i];
+    TpAlignment a;
+    a.fastga = fastga != 0;
+    a.trace_spacing = trace_spacing; a.max_complexity = max_complexity;
+    a.query_contig_start = r.query_contig_start;
+    for (uint32_t k = 0; k < r.n_segs; k++) {
+      a.tracepoints.push_back(tracepoints[r.seg_off + k]);
+      if (fastga) a.diffs.push_back(diffs[r.seg_off + k]); else a.query_deltas.push_back(query_deltas[r.seg_off + k]);
+    }
+    af.tp.push_back(std::move(a));
+    AlignmentRecord rec;
+    rec.query_id = r.query_id; rec.query_start = (uint64_t)r.query_start; rec.query_end = (uint64_t)r.query_end;
+    rec.target_id = r.target_id; rec.target_start = (uint64_t)r.target_start; rec.target_end = (uint64_t)r.target_end;
+    rec.strand_and_data_offset = (uint64_t)i | (r.strand ? STRAND_BIT : 0);
+    rec.data_bytes = r.n_segs;
+    recs[0].push_back(rec);
+  }
+  ix->files.push_back(std::move(af));
+  ix->approximate = true;
+  return finish_index(ix, recs, bidirectional != 0, false);
 }
 void oracle_index_free(oracle_index_t *ix) { delete ix; }
 

@@ -89,6 +89,21 @@ long oracle_sr_get(oracle_sorted_ranges_t *, int32_t *out, size_t cap);
 oracle_index_t *oracle_index_from_paf(const char *const *paths, int n_paths,
                                       int bidirectional, int preparse);
 /* Same, the "file" is a memory buffer (offsets behave like a file). */
+/* One tracepoint alignment (OneAlnAlignment, onealn.rs:786-802, as AlignmentRecord sees it): its n_segs
+ * tracepoints (target deltas) start at tracepoints[seg_off]; Standard mode brings query_deltas[] alongside,
+ * FASTGA mode diffs[] and the query's start within its contig (first query delta, impg.rs:726-735). */
+typedef struct {
+  uint32_t query_id, target_id;
+  int32_t query_start, query_end, target_start, target_end;
+  uint64_t seg_off;
+  uint32_t n_segs;
+  uint32_t strand;
+  int64_t query_contig_start;
+} oracle_tp_record_t;
+oracle_index_t *oracle_index_from_tracepoints(const oracle_tp_record_t *records, size_t n_records, const int32_t *tracepoints,
+                                              const int32_t *query_deltas, const int32_t *diffs, int fastga,
+                                              int32_t trace_spacing, int32_t max_complexity, const int64_t *seq_len,
+                                              uint32_t n_seq, int bidirectional);
 oracle_index_t *oracle_index_from_paf_text(const char *text, size_t len,
                                            int bidirectional, int preparse);
 void oracle_index_free(oracle_index_t *);

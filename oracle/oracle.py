@@ -239,12 +239,35 @@ def pack_mask(masked_regions):
     return mseq, mlen, moff, np.ascontiguousarray(mrng)
 
 
+TP_RECORD_DTYPE = np.dtype([("query_id", "<u4"), ("target_id", "<u4"), ("query_start", "<i4"), ("query_end", "<i4"),
+                            ("target_start", "<i4"), ("target_end", "<i4"), ("seg_off", "<u8"), ("n_segs", "<u4"),
+                            ("strand", "<u4"), ("query_contig_start", "<i8")], align=True)
+assert TP_RECORD_DTYPE.itemsize == 48
+
+
 class OracleIndex:
     """Impg (and MultiImpg) built from PAF text or files."""
 
-    def __init__(self, paf_text=None, paf_paths=None, bidirectional=True, preparse=False):
+    def __init__(self, paf_text=None, paf_paths=None, bidirectional=True, preparse=False, tracepoints=None):
+        """tracepoints = dict(records=TP_RECORD_DTYPE[], tracepoints=int32[], query_deltas=int32[] | None (Standard),
+        diffs=int32[] | None (FASTGA), fastga=bool, trace_spacing=int, max_complexity=int, seq_len=int64[]): an index over
+        tracepoint alignments; every query on it runs in approximate mode (impg.rs:1317-1533)."""
         L = lib()
-        if paf_text is not None:
+        if tracepoints is not None:
+            t = tracepoints
+            rec = np.ascontiguousarray(t["records"], dtype=TP_RECORD_DTYPE)
+            tp = np.ascontiguousarray(t["tracepoints"], dtype=np.int32)
+            qd = None if t.get("query_deltas") is None else np.ascontiguousarray(t["query_deltas"], dtype=np.int32)
+            df = None if t.get("diffs") is None else np.ascontiguousarray(t["diffs"], dtype=np.int32)
+            sl = np.ascontiguousarray(t["seq_len"], dtype=np.int64)
+            L.oracle_index_from_tracepoints.restype = C.c_void_p
+            L.oracle_index_from_tracepoints.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32,
+                                                        C.c_int32, C.c_void_p, C.c_uint32, C.c_int]
+            self._h = L.oracle_index_from_tracepoints(rec.ctypes.data, rec.size, tp.ctypes.data,
+                                                      None if qd is None else qd.ctypes.data, None if df is None else df.ctypes.data,
+                                                      int(bool(t.get("fastga"))), int(t.get("trace_spacing", 0)),
+                                                      int(t.get("max_complexity", 0)), sl.ctypes.data, sl.size, int(bidirectional))
+        elif paf_text is not None:
             b = paf_text.encode() if isinstance(paf_text, str) else bytes(paf_text)
             self._h = L.oracle_index_from_paf_text(b, len(b), int(bidirectional), int(preparse))
         else:

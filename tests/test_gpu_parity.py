@@ -938,3 +938,38 @@ def test_visited_update_big_groups(tmp_path, seed, n_aln, mdbr):
     assert_same(g, c, ranges, transitive=True, dfs=True, max_depth=3, min_transitive_len=5, min_distance_between_ranges=mdbr)
     masked = {int(g.seq_id("B")): (L, [(k * 3000, k * 3000 + 900) for k in range(100)])}  # a mask list of 100 ranges: a big group from its first touch
     assert_same(g, c, ranges[:2], masked_regions=masked, **kw)
+
+
+@pytest.mark.parametrize("fastga,seed", [(False, 1), (False, 2), (True, 3), (True, 4)])
+def test_tracepoint_approximate_mode(fastga, seed):
+    """Approximate mode on tracepoint alignments (scan_overlapping_tracepoints + project_overlapping_interval_fast,
+    impg.rs:646-823, :1317-1533): the prefix-sum kernel against the oracle's literal segment scan -- Standard and
+    FASTGA tracepoints, zero-length segments on either axis, both strands, forward and reversed entries,
+    plain / transitive BFS / DFS / MultiImpg-flavoured queries, identity filter."""
+    from tests.tp_gen import random_tp
+    d = random_tp(seed, 700, n_seq=5, seq_len=60_000, fastga=fastga, self_aln=(seed % 2 == 0))
+    g = impg_amd.GpuImpg.from_tracepoints(d["records"], d["tracepoints"], d["seq_len"], query_deltas=d["query_deltas"], diffs=d["diffs"],
+                                          fastga=d["fastga"], trace_spacing=d["trace_spacing"], max_complexity=d["max_complexity"])
+    c = o.OracleIndex(tracepoints=d)
+    ranges = random_ranges(seed, 120, 5, 60_000, max_len=4000, min_len=1)
+    assert_same(g, c, ranges)
+    assert_same(g, c, ranges, min_identity=0.85)
+    assert_same(g, c, ranges[:60], transitive=True, max_depth=3, min_transitive_len=30)
+    assert_same(g, c, ranges[:60], transitive=True, max_depth=2, min_transitive_len=30, min_identity=0.8)
+    assert_same(g, c, ranges[:40], transitive=True, dfs=True, max_depth=2, min_transitive_len=50)
+    assert_same(g, c, ranges[:40], transitive=True, max_depth=2, multi_impg=True, min_transitive_len=50)
+    with pytest.raises(impg_amd.ImpgGpuError) as ei:
+        g.query_batch(ranges[:2], impg_amd.make_params(store_cigar=True))
+    assert ei.value.code == impg_amd.IMPG_E_UNSUPPORTED
+    # the saved index keeps its mode
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as td:
+        g.save(os.path.join(td, "tp.idx"))
+        g2 = impg_amd.GpuImpg.load(os.path.join(td, "tp.idx"))
+        assert_same(g2, c, ranges[:30], transitive=True, max_depth=2, min_transitive_len=30)
+    # inputs outside the supported domain are refused, not mis-projected
+    bad = d["tracepoints"].copy()
+    bad[3] = -5
+    with pytest.raises(impg_amd.ImpgGpuError):
+        impg_amd.GpuImpg.from_tracepoints(d["records"], bad, d["seq_len"], query_deltas=d["query_deltas"], diffs=d["diffs"],
+                                          fastga=d["fastga"], trace_spacing=d["trace_spacing"], max_complexity=d["max_complexity"])

@@ -434,3 +434,41 @@ def test_merge_query_reference_vector():
         want = o.bed_merge(iv, d, True)
         assert got.tolist() == want.tolist()
     assert len(impg_amd.index.bed_merge(iv.astype(impg_amd.INTERVAL_DTYPE), 100, True)) == 1
+
+
+def test_tracepoint_approximate_mode_by_hand():
+    """project_overlapping_interval_fast / scan_overlapping_tracepoints (impg.rs:646-823, :1317-1533).  The reference
+    holds no test for them; these cases are worked by hand from the cited code (marked so: parity of this row is
+    pinned by restatement only).  One alignment, Standard mode: target deltas 100,100,100, query deltas 100,90,110,
+    target 1000-1300 on T, query 5000-5300 on Q."""
+    def ix(strand):
+        rec = np.zeros(1, dtype=o.TP_RECORD_DTYPE)
+        rec[0] = (0, 1, 5000, 5300, 1000, 1300, 0, 3, strand, 0)
+        return o.OracleIndex(tracepoints=dict(records=rec, tracepoints=[100, 100, 100], query_deltas=[100, 90, 110], diffs=None,
+                                              fastga=False, max_complexity=7, seq_len=[10000, 10000]))
+    Q, T = 0, 1
+    # '+', forward entry: first segment [1000,1100) is entered half way (5000 + round(.5 * 100 * 1.0)), the last
+    # [1200,1300) left half way (5190 + round(.5 * 100 * 1.1))
+    c = ix(0)
+    got = c.query(T, 1050, 1250)
+    assert got.tolist() == [(T, 1050, 1250, T, 1050, 1250), (Q, 5050, 5245, T, 1050, 1250)]
+    # the range is NOT clipped to the alignment by Impg::query (impg.rs:1899-1907), only its segments decide
+    assert c.query(T, 900, 1400)[1].tolist() == (Q, 5000, 5300, T, 900, 1400)
+    # touching the alignment's end is no overlap (impg.rs:1327-1329)
+    assert len(c.query(T, 1300, 1400)) == 1 and len(c.query(T, 500, 1000)) == 1
+    # the reversed entry scans the QUERY axis with the query deltas and projects the target deltas:
+    # segments [5000,5100) [5100,5190) [5190,5300) of Q; range 5050-5200 enters the first half way (1000 + 50) and
+    # leaves the third after 10 of its 110 bases: 1200 + round(10/110 * 110 * (100/110)) = 1209
+    assert c.query(Q, 5050, 5200)[1].tolist() == (T, 1050, 1209, Q, 5050, 5200)
+    # '-', forward entry: scanned from the target END backwards while the query runs forward; segment 0 is
+    # [1200,1300) -> query 5000.., segment 2 is [1000,1100) -> query 5190..5300; the pair is swapped at the end
+    c = ix(1)
+    assert c.query(T, 1050, 1250)[1].tolist() == (Q, 5300, 5000, T, 1050, 1250)
+    # '-', reversed entry: scan Q forward, project the target backwards from its end (1300)
+    assert c.query(Q, 5050, 5200)[1].tolist() == (T, 1250, 1091, Q, 5050, 5200)
+    # identity filter on the segment statistics: per overlapping segment min(qd, td) - max_complexity matches,
+    # max_complexity mismatches: (93 + 83 + 93) / (269 + 21)
+    assert len(c.query(T, 1050, 1250, min_identity=0.93)) == 1 and len(c.query(T, 1050, 1250, min_identity=0.92)) == 2
+    # transitive: the frontier's clipped overlap is what gets projected, and what is reported as the target interval
+    res = c.query(T, 900, 1150, transitive=True, max_depth=1, min_transitive_len=1)
+    assert res[1]["t_first"] == 1000 and res[1]["t_last"] == 1150

@@ -200,7 +200,17 @@ int main(int argc, char **argv) {
   for (auto &p : pafs) pp.push_back(p.c_str());
   impg_gpu_index_t *ix = nullptr;
   bool loaded = false;
+  bool reference_index = false;  // -i names the reference's own IMPGIDX2 / IMPGIDX1 file: read it, never overwrite it
   if (load_saved) {
+    char magic[8] = {0};
+    if (FILE *mf = fopen(index_file.c_str(), "rb")) { (void)!fread(magic, 1, 8, mf); fclose(mf); }
+    reference_index = memcmp(magic, "IMPGIDX", 7) == 0;
+  }
+  if (load_saved && reference_index) {
+    if (pafs.empty()) die("an IMPG index file stores offsets into its alignment files: pass them with -a, in the order it was built with");
+    if (impg_gpu_index_load_impg(index_file.c_str(), pp.data(), (int)pp.size(), order, device, &ix) != IMPG_OK) die(impg_gpu_last_error());
+    loaded = true;
+  } else if (load_saved) {
     if (impg_gpu_index_load(index_file.c_str(), device, &ix) == IMPG_OK) loaded = true;
     else if (pafs.empty()) die(impg_gpu_last_error());
     else fprintf(stderr, "[impg-gpu] %s: %s -- rebuilding it from the alignment files\n", index_file.c_str(), impg_gpu_last_error());

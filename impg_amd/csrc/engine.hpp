@@ -135,7 +135,8 @@ struct Engine {
 // owner: null = one shard holds everything; else owner[target id] = the shard that holds the target's entries
 void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops,
                  size_t n_ops, const int64_t *seq_len, uint32_t n_seq, bool bidirectional, int order_policy,
-                 uint32_t shard, uint32_t n_shards, const uint32_t *owner, const TpInput *tp = nullptr);
+                 uint32_t shard, uint32_t n_shards, const uint32_t *owner, const TpInput *tp = nullptr,
+                 const EntryPlan *plan = nullptr);
 
 struct EngineLease {  // an engine of the index for the duration of one call (capi.cpp)
   impg_gpu_index &ix;

@@ -172,6 +172,13 @@ struct TpInput {
   impg_gpu_tp_mode_t mode;
 };
 
+// Entries in a given input order instead of the order the records imply (a loaded IMPGIDX2 file lists every target's
+// intervals in the order its writer's tree held them; ties among equal starts follow that order when the tree is
+// rebuilt, impg.rs:1745-1755): per target, (record << 1 | reversed entry) in input order.
+struct EntryPlan {
+  std::vector<std::vector<uint64_t>> per_target;
+};
+
 // visit rank of each sorted position of an n-entry segment (order policy)
 void coitrees_visit_rank(uint32_t n, uint32_t *rank_out);
 

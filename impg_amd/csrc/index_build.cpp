@@ -132,7 +132,7 @@ void parallel_chunks(size_t n, const std::function<void(size_t, size_t)> &f) {
 
 void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops,
                  size_t n_ops, const int64_t *seq_len, uint32_t n_seq, bool bidirectional, int order_policy,
-                 uint32_t shard, uint32_t n_shards, const uint32_t *owner, const TpInput *tp) {
+                 uint32_t shard, uint32_t n_shards, const uint32_t *owner, const TpInput *tp, const EntryPlan *plan) {
   if (n_shards == 0 || shard >= n_shards) throw Error{IMPG_E_INVALID, "bad shard"};
   if (order_policy != IMPG_ORDER_COITREES && order_policy != IMPG_ORDER_SORTED)
     throw Error{IMPG_E_INVALID, "bad order policy"};
@@ -150,11 +150,24 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     if (r.query_id >= n_seq || r.target_id >= n_seq) throw Error{IMPG_E_INVALID, "record sequence id out of range"};
     if (r.cigar_off + r.cigar_len > n_ops) throw Error{IMPG_E_INVALID, "record CIGAR outside the op pool"};
     if (r.cigar_len > OP_LEN_MASK) throw Error{IMPG_E_UNSUPPORTED, "CIGAR longer than 2^29 ops"};
+    if (plan) continue;
     if (owned(r.target_id)) { need[i] = 1; seg_count[r.target_id]++; }
     if (bidirectional && r.query_id != r.target_id && owned(r.query_id)) {  // impg.rs:1584
       need[i] = 1;
       seg_count[r.query_id]++;
     }
+  }
+  if (plan) {
+    if (n_shards != 1 || plan->per_target.size() != n_seq) throw Error{IMPG_E_INVALID, "bad entry plan"};
+    for (uint32_t t = 0; t < n_seq; t++)
+      for (uint64_t x : plan->per_target[t]) {
+        const uint64_t rec = x >> 1;
+        if (rec >= n_records) throw Error{IMPG_E_INVALID, "entry plan names an unknown record"};
+        const auto &r = records[rec];
+        if ((x & 1) ? r.query_id != t : r.target_id != t) throw Error{IMPG_E_INVALID, "entry plan puts an entry on the wrong target"};
+        need[rec] = 1;
+        seg_count[t]++;
+      }
   }
 
   // ---- op pool: 128-byte tiles {T0,Q0, 8 x u16 inner sums | 26 ops} (impg_internal.hpp) ----
@@ -269,7 +282,27 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   std::vector<uint32_t> ent_rec(n_entries);  // record of each entry (for the checkpoints below)
   {
     std::vector<uint32_t> cur(tgt_off.begin(), tgt_off.end() - 1);
-    for (size_t i = 0; i < n_records; i++) {
+    if (plan) {
+      for (uint32_t t = 0; t < n_seq; t++)
+        for (uint64_t x : plan->per_target[t]) {
+          const size_t i = (size_t)(x >> 1);
+          const auto &r = records[i];
+          const uint32_t fl = (r.cigar_len & OP_LEN_MASK) | (r.strand ? EF_STRAND : 0);
+          Entry e{};
+          if (!(x & 1)) {
+            e.ts = r.target_start; e.te = r.target_end; e.qs = r.query_start; e.qe = r.query_end;
+            e.query_id = r.query_id; e.tile_base = tile_base[i]; e.nops_flags = fl;
+            e.totT = rec_totT[i]; e.totQ = rec_totQ[i];
+          } else {
+            e.ts = r.query_start; e.te = r.query_end; e.qs = r.target_start; e.qe = r.target_end;
+            e.query_id = r.target_id; e.tile_base = tile_base[i]; e.nops_flags = fl | EF_REVERSED;
+            e.totT = rec_totQ[i]; e.totQ = rec_totT[i];
+          }
+          ent_rec[cur[t]] = (uint32_t)i;
+          ent[cur[t]++] = e;
+        }
+    }
+    for (size_t i = 0; i < n_records && !plan; i++) {
       const auto &r = records[i];
       uint32_t fl = (r.cigar_len & OP_LEN_MASK) | (r.strand ? EF_STRAND : 0);
       if (owned(r.target_id)) {

@@ -148,6 +148,16 @@ class GpuImpg:
         return ix
 
     @classmethod
+    def load_impg(cls, impg_path, alignment_files, order=_lib.ORDER_COITREES, device=0):
+        """impg_gpu_index_load_impg: the reference's own IMPGIDX2 index file + the alignment files it was built from."""
+        if isinstance(alignment_files, str):
+            alignment_files = [alignment_files]
+        arr = (C.c_char_p * len(alignment_files))(*[p.encode() for p in alignment_files])
+        h = C.c_void_p(None)
+        check(lib().impg_gpu_index_load_impg(os.fsencode(impg_path), arr, len(alignment_files), order, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def from_tracepoints(cls, records, tracepoints, seq_len, query_deltas=None, diffs=None, fastga=False, trace_spacing=0,
                          max_complexity=0, bidirectional=True, order=_lib.ORDER_COITREES, device=0):
         """impg_gpu_index_create_tracepoints: an index over tracepoint alignments (.1aln / .tpa content handed over as

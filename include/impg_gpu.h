@@ -158,6 +158,15 @@ int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths,
  * reference's IMPGIDX2 format.  Not for a sharded index.  load: IMPG_E_INVALID for a
  * foreign or damaged file, IMPG_E_UNSUPPORTED for a layout version this build does not read. */
 int impg_gpu_index_save(const impg_gpu_index_t *, const char *path);
+/* The reference's own index file ("IMPGIDX2", or the unidirectional "IMPGIDX1"; writer impg.rs:1655-1721, reader
+ * :1787-1850 + :1724-1767; bincode-2 standard encoding): sequence table and every target's intervals come from the
+ * file, in the file's order (the order the reference rebuilds its trees from, hence its tie order among equal
+ * starts); the CIGARs are read from the alignment files -- the same files, in the same order, the index was built
+ * with (impg.rs:1789, :1844; plain-text PAF: offsets into compressed PAF are BGZF virtual offsets,
+ * IMPG_E_UNSUPPORTED) -- and tokenised once.  An existing `.impg` cache therefore opens without `impg index`
+ * being re-run.  IMPG_E_INVALID for a damaged file or CIGAR text that no longer parses at its offset. */
+int impg_gpu_index_load_impg(const char *impg_path, const char *const *alignment_files, int n_files, int order_policy,
+                             int device, impg_gpu_index_t **out);
 int impg_gpu_index_load(const char *path, int device, impg_gpu_index_t **out);
 void impg_gpu_index_destroy(impg_gpu_index_t *);
 

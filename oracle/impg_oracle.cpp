@@ -1465,6 +1465,173 @@ oracle_index_t *oracle_index_from_tracepoints(const oracle_tp_record_t *records,
   ix->approximate = true;
   return finish_index(ix, recs, bidirectional != 0, false);
 }
+/* ---- the reference's own index file, "IMPGIDX2" (writer impg.rs:1655-1721, reader :1787-1850 + :1724-1767) ----
+ * 16-byte header (magic, u64 LE offset of the forest map), then bincode 2 `config::standard()` values: the
+ * SequenceIndex (seqidx.rs:5-10), one (u32 target_id, Vec<SerializableInterval>) per tree (impg.rs:235-240,
+ * :164-174), the ForestMap (forest_map.rs:6-9).  bincode 2.0.1 (Cargo.lock:186-188) is not in the tree; its
+ * published standard encoding is restated: little-endian varint integers (< 251 one byte, else 0xFB + u16,
+ * 0xFC + u32, 0xFD + u64), signed integers zig-zagged first, usize as u64, strings / sequences / maps a varint
+ * length and then the elements (maps: key, value), structs and tuples their fields in order, no framing.
+ * PARITY UNPINNED: the reference tree holds no .impg file to check these bytes against. */
+namespace {
+struct Enc {
+  std::string b;
+  void u(uint64_t v) {
+    if (v < 251) b.push_back((char)v);
+    else if (v <= 0xFFFFull) { b.push_back((char)0xFB); for (int i = 0; i < 2; i++) b.push_back((char)(v >> (8 * i))); }
+    else if (v <= 0xFFFFFFFFull) { b.push_back((char)0xFC); for (int i = 0; i < 4; i++) b.push_back((char)(v >> (8 * i))); }
+    else { b.push_back((char)0xFD); for (int i = 0; i < 8; i++) b.push_back((char)(v >> (8 * i))); }
+  }
+  void i(int64_t v) { u(((uint64_t)v << 1) ^ (uint64_t)(v >> 63)); }
+  void str(const std::string &x) { u(x.size()); b += x; }
+};
+struct Dec {
+  const unsigned char *p, *e;
+  bool ok = true;
+  uint64_t le(int n) { uint64_t v = 0; if (e - p < n) { ok = false; return 0; } for (int i = 0; i < n; i++) v |= (uint64_t)p[i] << (8 * i); p += n; return v; }
+  uint64_t u() {
+    if (p >= e) { ok = false; return 0; }
+    unsigned char t = *p++;
+    if (t < 251) return t;
+    if (t == 0xFB) return le(2);
+    if (t == 0xFC) return le(4);
+    if (t == 0xFD) return le(8);
+    ok = false; return 0;
+  }
+  int64_t i() { uint64_t z = u(); return (int64_t)(z >> 1) ^ -(int64_t)(z & 1); }
+  std::string str() { uint64_t n = u(); if (!ok || (uint64_t)(e - p) < n) { ok = false; return ""; } std::string x((const char *)p, n); p += n; return x; }
+};
+} // namespace
+
+/* serialize_with_forest_map (impg.rs:1655-1721).  Trees go out in ascending target id (the reference: FxHashMap
+ * iteration order, arbitrary), each tree's intervals in this oracle's node order -- ascending `first`, ties in input
+ * order -- unless shuffle_seed != 0, which permutes them: the reference writes them in coitrees' internal layout
+ * order (tree.iter(), :1686), and a reader rebuilds the tree from whatever order it finds (:1745-1755), so no order
+ * is privileged.  Returns 0 or <0. */
+int oracle_index_write_impg(const oracle_index_t *ix, const char *path, uint64_t shuffle_seed) {
+  Enc seq;
+  const auto &si = ix->seq_index;
+  seq.u(si.name_to_id.size());
+  for (uint32_t id = 0; id < si.id_to_name.size(); id++) { seq.str(si.id_to_name[id]); seq.u(id); }
+  seq.u(si.id_to_name.size());
+  for (uint32_t id = 0; id < si.id_to_name.size(); id++) { seq.u(id); seq.str(si.id_to_name[id]); }
+  size_t n_len = 0;
+  for (auto l : si.id_to_len) n_len += l >= 0;
+  seq.u(n_len);
+  for (uint32_t id = 0; id < si.id_to_len.size(); id++) if (si.id_to_len[id] >= 0) { seq.u(id); seq.u((uint64_t)si.id_to_len[id]); }
+  seq.u(si.id_to_name.size()); /* next_id */
+  std::string body = seq.b;
+  std::vector<std::pair<uint32_t, uint64_t>> forest;
+  std::vector<uint32_t> ids;
+  for (auto &kv : ix->trees) ids.push_back(kv.first);
+  std::sort(ids.begin(), ids.end());
+  uint64_t rng = shuffle_seed;
+  for (uint32_t t : ids) {
+    forest.push_back({t, 16 + body.size()});
+    std::vector<IvNode> nodes = ix->trees.at(t).nodes;
+    if (shuffle_seed) for (size_t k = nodes.size(); k > 1; k--) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; std::swap(nodes[k - 1], nodes[(rng >> 33) % k]); }
+    Enc e;
+    e.u(t);
+    e.u(nodes.size());
+    for (auto &nd : nodes) {
+      e.i(nd.first); e.i(nd.last);
+      const QueryMetadata &m = nd.metadata;
+      e.u(m.query_id); e.i(m.target_start); e.i(m.target_end); e.i(m.query_start); e.i(m.query_end);
+      e.u(m.alignment_file_index); e.u(m.strand_and_data_offset); e.u(m.data_bytes);
+    }
+    body += e.b;
+  }
+  const uint64_t fmo = 16 + body.size();
+  Enc fm;
+  fm.u(forest.size());
+  for (auto &kv : forest) { fm.u(kv.first); fm.u(kv.second); }
+  FILE *f = fopen(path, "wb");
+  if (!f) { set_err(std::string("cannot create ") + path); return -1; }
+  fwrite("IMPGIDX2", 1, 8, f);
+  unsigned char off[8];
+  for (int i = 0; i < 8; i++) off[i] = (unsigned char)(fmo >> (8 * i));
+  fwrite(off, 1, 8, f);
+  fwrite(body.data(), 1, body.size(), f);
+  fwrite(fm.b.data(), 1, fm.b.size(), f);
+  fclose(f);
+  return 0;
+}
+
+/* load_from_file + load_tree_from_disk for every target (impg.rs:1787-1850, :1724-1767): the trees are rebuilt
+ * with BasicCOITree::new from the intervals in FILE order; CIGARs are read from the alignment files given here, in
+ * the order the index was built with (:1789, :1844). */
+oracle_index_t *oracle_index_from_impg(const char *path, const char *const *alignment_files, int n_files, int preparse) {
+  FILE *f = fopen(path, "rb");
+  if (!f) { set_err(std::string("cannot open ") + path); return nullptr; }
+  std::string data;
+  char buf[1 << 16];
+  size_t got;
+  while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);
+  fclose(f);
+  if (data.size() < 16 || (memcmp(data.data(), "IMPGIDX2", 8) != 0 && memcmp(data.data(), "IMPGIDX1", 8) != 0)) {
+    set_err("Invalid magic bytes - not a valid IMPG index file");
+    return nullptr;
+  }
+  uint64_t fmo = 0;
+  for (int i = 0; i < 8; i++) fmo |= (uint64_t)(unsigned char)data[8 + i] << (8 * i);
+  auto *ix = new oracle_index();
+  Dec d{(const unsigned char *)data.data() + 16, (const unsigned char *)data.data() + data.size()};
+  std::vector<std::pair<std::string, uint32_t>> n2i;
+  uint64_t n = d.u();
+  for (uint64_t k = 0; k < n && d.ok; k++) { std::string nm = d.str(); uint32_t id = (uint32_t)d.u(); n2i.push_back({nm, id}); }
+  n = d.u();
+  std::map<uint32_t, std::string> i2n;
+  for (uint64_t k = 0; k < n && d.ok; k++) { uint32_t id = (uint32_t)d.u(); i2n[id] = d.str(); }
+  n = d.u();
+  std::map<uint32_t, uint64_t> i2l;
+  for (uint64_t k = 0; k < n && d.ok; k++) { uint32_t id = (uint32_t)d.u(); i2l[id] = d.u(); }
+  const uint32_t next_id = (uint32_t)d.u();
+  if (!d.ok) { set_err("Failed to load sequence index"); delete ix; return nullptr; }
+  ix->seq_index.id_to_name.assign(next_id, std::string());
+  ix->seq_index.id_to_len.assign(next_id, -1);
+  for (auto &kv : i2n) if (kv.first < next_id) ix->seq_index.id_to_name[kv.first] = kv.second;
+  for (auto &kv : i2l) if (kv.first < next_id) ix->seq_index.id_to_len[kv.first] = (int64_t)kv.second;
+  for (auto &kv : n2i) ix->seq_index.name_to_id.emplace(kv.first, kv.second);
+  Dec fm{(const unsigned char *)data.data() + fmo, (const unsigned char *)data.data() + data.size()};
+  if (fmo > data.size()) { set_err("Failed to load forest map"); delete ix; return nullptr; }
+  std::vector<std::pair<uint32_t, uint64_t>> forest;
+  n = fm.u();
+  for (uint64_t k = 0; k < n && fm.ok; k++) { uint32_t t = (uint32_t)fm.u(); forest.push_back({t, fm.u()}); }
+  if (!fm.ok) { set_err("Failed to load forest map"); delete ix; return nullptr; }
+  for (int k = 0; k < n_files; k++) {
+    AlnFile af;
+    af.path = alignment_files[k];
+    af.fd = open(alignment_files[k], O_RDONLY);
+    if (af.fd < 0) { set_err(std::string("Failed to open file '") + alignment_files[k] + "'"); delete ix; return nullptr; }
+    ix->files.push_back(std::move(af));
+  }
+  std::map<uint32_t, std::vector<IvNode>> all;
+  for (auto &kv : forest) {
+    if (kv.second > data.size()) { set_err("Failed to deserialize tree"); delete ix; return nullptr; }
+    Dec t{(const unsigned char *)data.data() + kv.second, (const unsigned char *)data.data() + data.size()};
+    const uint32_t loaded = (uint32_t)t.u();
+    if (loaded != kv.first) { set_err("Tree mismatch"); delete ix; return nullptr; } /* :1737-1739 */
+    const uint64_t cnt = t.u();
+    std::vector<IvNode> &nodes = all[kv.first];
+    for (uint64_t k = 0; k < cnt && t.ok; k++) {
+      IvNode nd;
+      nd.first = (int32_t)t.i(); nd.last = (int32_t)t.i();
+      QueryMetadata &m = nd.metadata;
+      m.query_id = (uint32_t)t.u(); m.target_start = (int32_t)t.i(); m.target_end = (int32_t)t.i();
+      m.query_start = (int32_t)t.i(); m.query_end = (int32_t)t.i(); m.alignment_file_index = (uint32_t)t.u();
+      m.strand_and_data_offset = t.u(); m.data_bytes = t.u();
+      if (m.alignment_file_index >= (uint32_t)n_files) { set_err("index names an alignment file that was not given"); delete ix; return nullptr; }
+      nodes.push_back(nd);
+      ix->n_records += !m.is_reversed();
+    }
+    if (!t.ok) { set_err("Failed to deserialize tree"); delete ix; return nullptr; }
+  }
+  build_trees(all, ix->trees);
+  ix->preparse = false;
+  (void)preparse;
+  return ix;
+}
+
 void oracle_index_free(oracle_index_t *ix) { delete ix; }
 
 uint32_t oracle_num_seqs(const oracle_index_t *ix) { return (uint32_t)ix->seq_index.id_to_name.size(); }

@@ -100,6 +100,12 @@ typedef struct {
   uint32_t strand;
   int64_t query_contig_start;
 } oracle_tp_record_t;
+/* The reference's index file "IMPGIDX2" (impg.rs:1655-1721 / :1787-1850; bincode 2 standard encoding restated,
+ * PARITY UNPINNED: no .impg file in the reference tree).  write: shuffle_seed != 0 permutes every tree's intervals
+ * (a reader rebuilds the tree from whatever order the file has).  from_impg: the trees are rebuilt from the file's
+ * order; CIGARs are read from the alignment files given, in the order the index was built with. */
+int oracle_index_write_impg(const oracle_index_t *, const char *path, uint64_t shuffle_seed);
+oracle_index_t *oracle_index_from_impg(const char *path, const char *const *alignment_files, int n_files, int preparse);
 oracle_index_t *oracle_index_from_tracepoints(const oracle_tp_record_t *records, size_t n_records, const int32_t *tracepoints,
                                               const int32_t *query_deltas, const int32_t *diffs, int fastga,
                                               int32_t trace_spacing, int32_t max_complexity, const int64_t *seq_len,

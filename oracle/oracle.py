@@ -248,12 +248,17 @@ assert TP_RECORD_DTYPE.itemsize == 48
 class OracleIndex:
     """Impg (and MultiImpg) built from PAF text or files."""
 
-    def __init__(self, paf_text=None, paf_paths=None, bidirectional=True, preparse=False, tracepoints=None):
+    def __init__(self, paf_text=None, paf_paths=None, bidirectional=True, preparse=False, tracepoints=None, impg_path=None):
         """tracepoints = dict(records=TP_RECORD_DTYPE[], tracepoints=int32[], query_deltas=int32[] | None (Standard),
         diffs=int32[] | None (FASTGA), fastga=bool, trace_spacing=int, max_complexity=int, seq_len=int64[]): an index over
         tracepoint alignments; every query on it runs in approximate mode (impg.rs:1317-1533)."""
         L = lib()
-        if tracepoints is not None:
+        if impg_path is not None:  # the reference's IMPGIDX2 file + the alignment files it was built from
+            arr = (C.c_char_p * len(paf_paths))(*[p.encode() for p in paf_paths])
+            L.oracle_index_from_impg.restype = C.c_void_p
+            L.oracle_index_from_impg.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int]
+            self._h = L.oracle_index_from_impg(impg_path.encode(), arr, len(paf_paths), 0)
+        elif tracepoints is not None:
             t = tracepoints
             rec = np.ascontiguousarray(t["records"], dtype=TP_RECORD_DTYPE)
             tp = np.ascontiguousarray(t["tracepoints"], dtype=np.int32)
@@ -275,6 +280,14 @@ class OracleIndex:
             self._h = L.oracle_index_from_paf(arr, len(paf_paths), int(bidirectional), int(preparse))
         if not self._h:
             raise RuntimeError(L.oracle_last_error().decode())
+
+    def write_impg(self, path, shuffle_seed=0):
+        """oracle_index_write_impg: this index as the reference's IMPGIDX2 file."""
+        f = lib().oracle_index_write_impg
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        if f(self._h, path.encode(), shuffle_seed) != 0:
+            raise RuntimeError(lib().oracle_last_error().decode())
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -973,3 +973,44 @@ def test_tracepoint_approximate_mode(fastga, seed):
     with pytest.raises(impg_amd.ImpgGpuError):
         impg_amd.GpuImpg.from_tracepoints(d["records"], bad, d["seq_len"], query_deltas=d["query_deltas"], diffs=d["diffs"],
                                           fastga=d["fastga"], trace_spacing=d["trace_spacing"], max_complexity=d["max_complexity"])
+
+
+@pytest.mark.parametrize("shuffle", [0, 12345])
+def test_load_reference_impg_index(tmp_path, shuffle):
+    """impg_gpu_index_load_impg: the reference's IMPGIDX2 file (written by the oracle's restatement of
+    serialize_with_forest_map, impg.rs:1655-1721) + the PAF files it points into -> HBM index.  The engine and the
+    oracle read the SAME file; with shuffle the file lists every tree's intervals in a scrambled order, as a real
+    file does (coitrees' layout order), and both rebuild their tie order from it."""
+    texts = [random_paf(70 + k, 150, n_seq=6, seq_len=50_000, self_aln=True)[0] for k in range(2)]
+    pafs = []
+    for k, t in enumerate(texts):
+        p = str(tmp_path / ("f%d.paf" % k))
+        open(p, "w").write(t)
+        pafs.append(p)
+    src = o.OracleIndex(paf_paths=pafs)
+    f = str(tmp_path / "idx.impg")
+    src.write_impg(f, shuffle_seed=shuffle)
+    c = o.OracleIndex(impg_path=f, paf_paths=pafs)
+    g = impg_amd.GpuImpg.load_impg(f, pafs)
+    assert g.num_seqs() == c.num_seqs() and g.num_records() == 300
+    for i in range(g.num_seqs()):
+        assert g.seq_name(i) == c.seq_name(i) and g.seq_len(i) == c.seq_len(i)
+    ranges = random_ranges(9, 80, 6, 50_000, max_len=6000, min_len=10)
+    assert_same(g, c, ranges)
+    assert_same(g, c, ranges, transitive=True, max_depth=3, min_transitive_len=20)
+    assert_same(g, c, ranges[:40], transitive=True, dfs=True, max_depth=2)
+    assert_same(g, c, ranges[:40], store_cigar=True, transitive=True, max_depth=2, min_transitive_len=40)
+    # the CLI opens the same file with -i ... -a ...
+    import os, subprocess
+    cli = os.path.join(os.path.dirname(impg_amd.__file__), "impg-gpu")
+    r = subprocess.run([cli, "query", "-i", f, "-a"] + pafs + ["-r", "s1:1000-9000", "-d", "100", "-x", "-m", "2", "-o", "bed"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == c.query_bed("s1", 1000, 9000, "s1:1000-9000", 100, o.make_params(transitive=True, max_depth=2))
+    assert open(f, "rb").read()[:8] == b"IMPGIDX2"  # (never overwritten by the library's own cache format)
+    # a PAF that changed under the index is noticed
+    open(pafs[0], "w").write("x" * 100 + "\n" + texts[0])
+    with pytest.raises(impg_amd.ImpgGpuError):
+        impg_amd.GpuImpg.load_impg(f, pafs)
+    with pytest.raises(impg_amd.ImpgGpuError):
+        impg_amd.GpuImpg.load_impg(pafs[1], pafs)

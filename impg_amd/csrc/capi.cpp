@@ -19,6 +19,9 @@ void render_paf(const impg_gpu_results &res, const impg_gpu_index &ix, const cha
 void render_bed(const impg_gpu_results &res, const impg_gpu_index &ix, const char *const *range_names,
                 const impg_gpu_params_t &p, int32_t merge_distance, std::vector<std::string> &parts);
 char *join_parts(std::vector<std::string> &parts, size_t *len);  // bed.cpp
+void device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, const impg_gpu_params_t &p, int32_t merge_distance,
+                     std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, std::vector<uint32_t> &host_rows,
+                     std::vector<uint64_t> &row_off);  // bed_device.hip
 }  // namespace impg
 
 using namespace impg;
@@ -692,6 +695,89 @@ int impg_gpu_results_bed(const impg_gpu_results_t *res, const impg_gpu_index_t *
   std::vector<std::string> parts;
   render_bed(*res, *ix, range_names, *params, merge_distance, parts);
   *text = join_parts(parts, len);
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+// query + both BED merges on the device + text: only merged rows cross PCIe
+int impg_gpu_query_batch_bed(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
+                             const uint8_t *subset_keep, int32_t merge_distance, const char *const *range_names, char **text,
+                             size_t *len, double *seconds3) {
+  IMPG_TRY
+  if (!ix || !params || !text || !len || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
+  if (ix->shard || ix->cluster) throw Error{IMPG_E_UNSUPPORTED, "the device-side BED path runs on a single-GPU index (use impg_gpu_query_batch + impg_gpu_results_bed)"};
+  check_ranges(ranges, n);
+  Engine::check_params(*params);
+  impg_gpu_params_t p = *params;
+  p.store_cigar = 0;  // BED never needs CIGARs (main.rs:7447)
+  IMPG_HIP(hipSetDevice(ix->device));
+  EngineLease lease(*ix);
+  Engine &E = *lease;
+  apply_subset(E, *ix, subset_keep);
+  E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
+  if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
+  std::vector<std::string> parts(n);
+  double t_engine = 0, t_merge = 0, t_text = 0;
+  const bool orig = p.original_sequence_coordinates != 0;
+  for_chunks(E, n, [&](size_t b, size_t e) {
+    const auto c0 = std::chrono::steady_clock::now();
+    std::vector<std::unique_ptr<LevelBufs>> levels;
+    DevBuf self_dev;
+    E.run(*ix, E.ranges_dev.as<impg_gpu_range_t>() + b, (uint32_t)(e - b), p, &levels, nullptr, nullptr, nullptr, &self_dev);
+    const auto c1 = std::chrono::steady_clock::now();
+    std::vector<uint32_t> rows;
+    std::vector<uint64_t> off;
+    device_bed_rows(E, *ix, (uint32_t)(e - b), p, merge_distance, levels, self_dev, rows, off);
+    const auto c2 = std::chrono::steady_clock::now();
+    // text: one task per range, ranges dealt to the host threads
+    const size_t cnt = e - b;
+    unsigned hw = std::thread::hardware_concurrency();
+    const size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, cnt / 8 + 1));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      char buf[64];
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= cnt) break;
+        std::string &s = parts[b + i];
+        s.clear();
+        const impg_gpu_range_t &q = ranges[b + i];
+        std::string rn;
+        if (range_names && range_names[b + i]) rn = range_names[b + i];
+        else {  // "{chrom}:{start}-{end}" (partition.rs:1741, :1762)
+          rn = q.target_id < ix->seq.names.size() ? ix->seq.names[q.target_id] : std::to_string(q.target_id);
+          const int k = snprintf(buf, sizeof buf, ":%d-%d", q.start, q.end);
+          rn.append(buf, (size_t)k);
+        }
+        s.reserve((size_t)(off[i + 1] - off[i]) * (rn.size() + 40));
+        for (uint64_t r = off[i]; r < off[i + 1]; r++) {
+          const uint32_t *w = rows.data() + r * 4;
+          const uint32_t qid = w[1];
+          uint32_t shift = 0;  // --original-sequence-coordinates (main.rs:11876-11883)
+          if (qid < ix->seq.names.size()) shift = put_original_name(s, ix->seq.names[qid], orig);
+          else s += std::to_string(qid);
+          const int k = snprintf(buf, sizeof buf, "\t%u\t%u\t", (uint32_t)(int32_t)w[2] + shift, (uint32_t)(w[3] >> 1) + shift);
+          s.append(buf, (size_t)k);
+          s += rn;
+          s += "\t.\t";
+          s += (w[3] & 1u) ? '-' : '+';
+          s += '\n';
+        }
+      }
+    };
+    if (T == 1) work();
+    else {
+      std::vector<std::thread> th;
+      for (size_t t = 0; t < T; t++) th.emplace_back(work);
+      for (auto &x : th) x.join();
+    }
+    const auto c3 = std::chrono::steady_clock::now();
+    t_engine += std::chrono::duration<double>(c1 - c0).count();
+    t_merge += std::chrono::duration<double>(c2 - c1).count();
+    t_text += std::chrono::duration<double>(c3 - c2).count();
+  });
+  *text = join_parts(parts, len);
+  if (seconds3) { seconds3[0] = t_engine; seconds3[1] = t_merge; seconds3[2] = t_text; }
   return IMPG_OK;
   IMPG_CATCH
 }

@@ -3,6 +3,8 @@
 // defaults, same validation order, same bytes on stdout; every BED row of a
 // `-b` file goes to the GPU in ONE batch instead of the reference's serial loop
 // (main.rs:7435).
+#include <unistd.h>
+
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -133,6 +135,7 @@ int main(int argc, char **argv) {
     return x;
   };
   bool consider_strandness = false;  // main.rs:4380
+  bool host_merge = false;
   for (int i = 2; i < argc; i++) {
     std::string a = argv[i];
     auto need = [&](const char *f) -> const char * {
@@ -157,6 +160,7 @@ int main(int argc, char **argv) {
     else if (a == "-l" || a == "--min-output-length") min_out = num(a, need("-l"), 0, 2147483647);
     else if (a == "--min-result-identity") min_ident = real(a, need(a.c_str()));
     else if (a == "--consider-strandness") consider_strandness = true;
+    else if (a == "--host-merge") host_merge = true;  // BED merges on the host (impg_gpu_results_bed) instead of the device
     else if (a == "--subset-sequence-list") subset_list = need(a.c_str());
     else if (a == "--original-sequence-coordinates") original_coords = true;
     else if (a == "-o" || a == "--output-format") ofmt = need("-o");
@@ -288,6 +292,21 @@ int main(int argc, char **argv) {
   }
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
+  if (fmt == "bed" && !host_merge) {  // both merges on the device: only merged rows cross PCIe
+    char *text = nullptr;
+    size_t len = 0;
+    double sec[3] = {0, 0, 0};
+    if (impg_gpu_query_batch_bed(ix, ranges.data(), ranges.size(), &p, keep.empty() ? nullptr : keep.data(), merge_distance, names.data(), &text,
+                                 &len, sec) != IMPG_OK)
+      die(impg_gpu_last_error());
+    const double t1 = now();
+    fwrite(text, 1, len, stdout);
+    fflush(stdout);
+    if (verbose >= 1)
+      fprintf(stderr, "[impg-gpu] query + merge + text %.2f s (engine %.2f, device merge + copy back %.2f, text %.2f), write %.2f s, %zu bytes\n",
+              t1 - t0, sec[0], sec[1], sec[2], now() - t1, len);
+    _exit(0);  // (tearing down gigabytes of host buffers and the device context is not worth a second)
+  }
   if (impg_gpu_query_batch_filtered(ix, ranges.data(), ranges.size(), &p, nullptr, keep.empty() ? nullptr : keep.data(), &res) != IMPG_OK)
     die(impg_gpu_last_error());
   const double t1 = now();

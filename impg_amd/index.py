@@ -74,7 +74,7 @@ class QueryResults:
         p = params or make_params()
         arr = None
         if range_names is not None:
-            arr = (C.c_char_p * len(range_names))(*[s.encode() for s in range_names])
+            arr = (C.c_char_p * len(range_names))(*[None if s is None else s.encode() for s in range_names])
         text = C.c_void_p(None)
         ln = C.c_size_t(0)
         check(L.impg_gpu_results_bed(self._h, self._owner._h, arr, C.byref(p), merge_distance, C.byref(text), C.byref(ln)))
@@ -90,7 +90,7 @@ class QueryResults:
         p = params or make_params(store_cigar=True)
         arr = None
         if range_names is not None:
-            arr = (C.c_char_p * len(range_names))(*[s.encode() for s in range_names])
+            arr = (C.c_char_p * len(range_names))(*[None if s is None else s.encode() for s in range_names])
         text = C.c_void_p(None)
         ln = C.c_size_t(0)
         check(L.impg_gpu_results_paf(self._h, self._owner._h, arr, C.byref(p), merge_distance, {"paf": 0, "bedpe": 1}[fmt],
@@ -295,6 +295,26 @@ class GpuImpg:
         else:
             check(lib().impg_gpu_query_batch(self._h, r.ctypes.data, r.size, C.byref(p), C.byref(h)))
         return QueryResults(h, self, copy=copy)
+
+    def query_batch_bed(self, ranges, params=None, merge_distance=0, range_names=None, subset_keep=None, timing=False, raw=False, **kw):
+        """impg_gpu_query_batch_bed: query + both BED merges on the device + text (what `impg query -o bed` prints)."""
+        p = params or make_params(**kw)
+        r = self._ranges(ranges)
+        arr = None
+        if range_names is not None:
+            arr = (C.c_char_p * len(range_names))(*[None if s is None else s.encode() for s in range_names])
+        keep = None if subset_keep is None else np.ascontiguousarray(subset_keep, dtype=np.uint8)
+        text = C.c_void_p(None)
+        ln = C.c_size_t(0)
+        sec = (C.c_double * 3)()
+        check(lib().impg_gpu_query_batch_bed(self._h, r.ctypes.data, r.size, C.byref(p), None if keep is None else keep.ctypes.data,
+                                             merge_distance, arr, C.byref(text), C.byref(ln), sec))
+        try:
+            out = C.string_at(text, ln.value)
+        finally:
+            _lib.free(text)
+        out = out if raw else out.decode()
+        return (out, list(sec)) if timing else out
 
     def query(self, target_id, range_start, range_end, store_cigar=False, min_gap_compressed_identity=None,
               sequence_index=None, approximate_mode=False):

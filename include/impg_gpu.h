@@ -295,6 +295,17 @@ int impg_gpu_results_bed(const impg_gpu_results_t *, const impg_gpu_index_t *,
                          const char *const *range_names, const impg_gpu_params_t *params,
                          int32_t merge_distance, char **text, size_t *len);
 
+/* perform_query + output_results_bed for a whole batch in one call, with both merges ON THE DEVICE
+ * (bed_device.hip): the hit slots never leave HBM; they are turned into rows, sorted, chained
+ * (merge_adjusted_intervals_gap_2d) and swept (merge_query_adjusted_intervals) there, and only the merged rows --
+ * 16 bytes each -- cross PCIe to be printed.  The text is byte-identical to impg_gpu_query_batch_filtered +
+ * impg_gpu_results_bed (what `impg query -o bed` prints: main.rs:7435-7470, :11849-11892).  range_names as in
+ * impg_gpu_results_bed (NULL, or NULL entries, = "{name}:{start}-{end}").  subset_keep may be NULL.  seconds3, if
+ * not NULL, receives the wall seconds of {engine, device-side merge + copy back, text}.  Single-GPU index. */
+int impg_gpu_query_batch_bed(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
+                             const uint8_t *subset_keep, int32_t merge_distance, const char *const *range_names, char **text,
+                             size_t *len, double *seconds3);
+
 /* ---- PAF / BEDPE: results.remove(0) + merge_adjusted_intervals (CIGAR-faithful
  *      merge: contiguity, identical overlap, gaps <= -d) + output_results_paf /
  *      output_results_bedpe with gi:f / bi:f (main.rs:7472-7496, :11894-12103,

@@ -1014,3 +1014,68 @@ def test_load_reference_impg_index(tmp_path, shuffle):
         impg_amd.GpuImpg.load_impg(f, pafs)
     with pytest.raises(impg_amd.ImpgGpuError):
         impg_amd.GpuImpg.load_impg(pafs[1], pafs)
+
+
+def _bed_three_ways(g, c, ranges, names, d, **kw):
+    """device-side merge == host-side merge == the oracle's perform_query + output_results_bed, byte for byte"""
+    p = impg_amd.make_params(**kw)
+    dev = g.query_batch_bed(ranges, p, merge_distance=d, range_names=names)
+    host = g.query_batch(ranges, p).bed(names, merge_distance=d, params=p)
+    assert dev == host, (d, kw)
+    okw = dict(kw)
+    want = "".join(c.query_bed(c.seq_name(t), s, e, range_name=(names[i] if names else None), merge_distance=d, **okw)
+                   for i, (t, s, e) in enumerate(ranges))
+    assert dev == want, (d, kw)
+    return dev
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_device_bed_merge_random(tmp_path, seed):
+    text, _ = random_paf(seed, 500, n_seq=5, seq_len=30000, self_aln=True, weird=(seed == 13))
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(seed, 60, 5, 30000, max_len=5000, min_len=150)
+    names = [None if i % 3 else "n%d" % i for i in range(len(ranges))]
+    names_o = [("n%d" % i) if i % 3 == 0 else None for i in range(len(ranges))]
+    assert names == names_o
+    for d in (-1, 0, 25, 1000, 100000):
+        for kw in (dict(), dict(transitive=True, max_depth=3, min_transitive_len=20), dict(transitive=True, dfs=True, max_depth=2),
+                   dict(transitive=True, max_depth=2, multi_impg=True), dict(min_output_length=400),
+                   dict(transitive=True, max_depth=2, min_output_length=300), dict(transitive=True, max_depth=3, consider_strandness=True),
+                   dict(consider_strandness=True)):
+            _bed_three_ways(g, c, ranges, names, d, **kw)
+    # chunking does not show
+    g.set_option("chunk_ranges", 7)
+    g.set_option("pair_budget", 2048)
+    _bed_three_ways(g, c, ranges, names, 50, transitive=True, max_depth=3, min_transitive_len=20)
+
+
+def test_device_bed_merge_chains_and_worst_case(tmp_path):
+    """gap_2d chains: collinear alignments on one (query, target, strand) at gaps just below / above d on either axis,
+    on both strands, interleaved with off-diagonal ones -- and the O(k^2) worst case: thousands of overlapping hits
+    in one group, every row within d of every other, so no early break ever fires."""
+    lines = []
+    L = 2_000_000
+    pos_q, pos_t = 1000, 5000
+    rng = np.random.default_rng(3)
+    for k in range(300):  # a forward chain with gaps around d = 50 on either axis
+        ln = int(rng.integers(80, 200))
+        lines.append("Q\t%d\t%d\t%d\t+\tT\t%d\t%d\t%d\t%d\t%d\t60\tcg:Z:%d=" % (L, pos_q, pos_q + ln, L, pos_t, pos_t + ln, ln, ln, ln))
+        pos_q += ln + int(rng.choice([0, 10, 49, 50, 51, 200]))
+        pos_t += ln + int(rng.choice([0, 10, 49, 50, 51, 200]))
+    pos_q, pos_t = 900_000, 400_000
+    for k in range(300):  # a reverse-strand chain: the query runs backwards along the target
+        ln = int(rng.integers(80, 200))
+        lines.append("Q\t%d\t%d\t%d\t-\tT\t%d\t%d\t%d\t%d\t%d\t60\tcg:Z:%d=" % (L, pos_q - ln, pos_q, L, pos_t, pos_t + ln, ln, ln, ln))
+        pos_q -= ln + int(rng.choice([0, 10, 49, 50, 51, 200]))
+        pos_t += ln + int(rng.choice([0, 10, 49, 50, 51, 200]))
+    for k in range(3000):  # the worst case: one (Q2, T) group, all hits inside one 3 kb window of both axes
+        ln = int(rng.integers(500, 2500))
+        a = int(rng.integers(0, 3000 - 400))
+        lines.append("Q2\t%d\t%d\t%d\t%s\tT\t%d\t%d\t%d\t%d\t%d\t60\tcg:Z:%d=" %
+                     (L, 10_000 + a, 10_000 + a + ln, "+-"[k % 2], L, 1_000_000 + a, 1_000_000 + a + ln, ln, ln, ln))
+    g, c = both(tmp_path, "\n".join(lines) + "\n", bidirectional=False)
+    T = g.seq_id("T")
+    ranges = [(T, 0, 700_000), (T, 1_000_000, 1_003_000), (T, 0, L), (T, 5000, 5200)]
+    for d in (0, 49, 50, 51, 5000):
+        _bed_three_ways(g, c, ranges, None, d)
+        _bed_three_ways(g, c, ranges, None, d, consider_strandness=True)

@@ -127,6 +127,7 @@ SYMBOLS = [
     ("impg_gpu_results_bed", C.c_int, [_P, _P, _P, C.POINTER(Params), C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("impg_gpu_query_batch_bed", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, C.c_int32, _P, C.POINTER(_P), C.POINTER(C.c_size_t),
                                            _P]),
+    ("impg_gpu_query_batch_bed_fd", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, C.c_int32, _P, C.c_int, C.POINTER(C.c_uint64), _P]),
     ("impg_gpu_results_paf", C.c_int, [_P, _P, _P, C.POINTER(Params), C.c_int32, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("impg_gpu_parse_cigar", C.c_long, [C.c_char_p, C.c_size_t, _P, C.c_size_t]),
     ("impg_gpu_parse_target_range", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -21,6 +21,10 @@
 
 #include <rocprim/device/device_scan.hpp>
 
+#include <algorithm>
+#include <functional>
+#include <string>
+
 #include "engine.hpp"
 
 namespace impg {
@@ -266,11 +270,68 @@ inline unsigned bits_for(uint64_t n) {
 
 }  // namespace
 
-// Rows of one chunk -> merged BED rows on the host (grouped by range, in output order) and rows_per_range[n].
-// levels / self_dev: what Engine::run kept for the chunk.
-void device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, const impg_gpu_params_t &p, int32_t merge_distance,
-                     std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, std::vector<uint32_t> &host_rows /* 4 words each */,
-                     std::vector<uint64_t> &row_off /* [n_ranges + 1] */) {
+// ---- text ---------------------------------------------------------------------------------------------------------------
+// "{name}\t{start}\t{end}\t{range name}\t.\t{strand}\n" per merged row (output_results_bed, main.rs:11868-11890), written
+// by the device: a transitive batch prints gigabytes, which the host's cores format slower than PCIe moves them.
+struct TextTables {
+  const char *names;            // printed sequence names back to back ("base" under --original-sequence-coordinates)
+  const uint32_t *name_off;     // [n_seq + 1]
+  const uint32_t *shift;        // [n_seq] offset added to the coordinates (main.rs:11876-11883)
+  uint32_t n_names;             // 0: sequences print as their ids
+  const char *rnames;           // the chunk's range names back to back
+  const uint32_t *rname_off;    // [n_ranges + 1]
+};
+__device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
+  uint32_t d = 1;
+  while (v >= 10u) { v /= 10u; d++; }
+  return d;
+}
+__device__ __forceinline__ char *put_dec(char *p, uint32_t v, uint32_t digits) {
+  for (uint32_t k = digits; k > 0; k--) { p[k - 1] = (char)('0' + v % 10u); v /= 10u; }
+  return p + digits;
+}
+__global__ __launch_bounds__(256) void text_len_kernel(const BedRow *__restrict__ rows, uint32_t n, TextTables t, uint32_t *__restrict__ len) {
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= n) return;
+  const BedRow x = rows[r];
+  const bool named = x.query_id < t.n_names;
+  const uint32_t sh = named ? t.shift[x.query_id] : 0u;
+  const uint32_t nl = named ? t.name_off[x.query_id + 1] - t.name_off[x.query_id] : dec_digits(x.query_id);
+  len[r] = nl + dec_digits((uint32_t)x.start + sh) + dec_digits((x.end_strand >> 1) + sh) + (t.rname_off[x.q + 1] - t.rname_off[x.q]) + 8u;
+}
+__global__ __launch_bounds__(256) void text_write_kernel(const BedRow *__restrict__ rows, uint32_t n, TextTables t,
+                                                         const unsigned long long *__restrict__ off, unsigned long long base, char *__restrict__ out) {
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= n) return;
+  const BedRow x = rows[r];
+  char *p = out + (off[r] - base);
+  const bool named = x.query_id < t.n_names;
+  const uint32_t sh = named ? t.shift[x.query_id] : 0u;
+  if (named) {
+    const char *nm = t.names + t.name_off[x.query_id];
+    const uint32_t nl = t.name_off[x.query_id + 1] - t.name_off[x.query_id];
+    for (uint32_t k = 0; k < nl; k++) p[k] = nm[k];
+    p += nl;
+  } else p = put_dec(p, x.query_id, dec_digits(x.query_id));
+  *p++ = '\t';
+  const uint32_t a = (uint32_t)x.start + sh, b = (x.end_strand >> 1) + sh;
+  p = put_dec(p, a, dec_digits(a));
+  *p++ = '\t';
+  p = put_dec(p, b, dec_digits(b));
+  *p++ = '\t';
+  const char *rn = t.rnames + t.rname_off[x.q];
+  const uint32_t rl = t.rname_off[x.q + 1] - t.rname_off[x.q];
+  for (uint32_t k = 0; k < rl; k++) p[k] = rn[k];
+  p += rl;
+  *p++ = '\t'; *p++ = '.'; *p++ = '\t';
+  *p++ = (x.end_strand & 1u) ? '-' : '+';
+  *p++ = '\n';
+}
+
+// Rows of one chunk -> merged BED rows, left on the device in `out` (grouped by range, in output order); returns
+// their number.  levels / self_dev: what Engine::run kept for the chunk.
+uint32_t device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, const impg_gpu_params_t &p, int32_t merge_distance,
+                         std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, DevBuf &out) {
   hipStream_t s = E.stream;
   const bool transitive = p.transitive != 0;
   const bool merge_strands = p.consider_strandness == 0;
@@ -301,9 +362,7 @@ void device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, con
   }
   const uint64_t n_rows64 = E.scan(fl, pos.as<uint32_t>(), (uint32_t)S);
   const uint32_t n = (uint32_t)n_rows64;
-  row_off.assign((size_t)n_ranges + 1, 0);
-  host_rows.clear();
-  if (!n) return;
+  if (!n) return 0;
   DevBuf rq, rqid, rtid, rc;
   rq.reserve((size_t)n * 4); rqid.reserve((size_t)n * 4); rtid.reserve((size_t)n * 4); rc.reserve((size_t)n * 16);
   Rows R{rq.as<uint32_t>(), rqid.as<uint32_t>(), rtid.as<uint32_t>(), rc.as<int4>()};
@@ -349,7 +408,7 @@ void device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, con
     cur = R2;
   }
   // ---- query axis ----------------------------------------------------------------------------------------------------
-  DevBuf out, strand_key, seg_head, seg_id, val, pmax, run_head, run_pos;
+  DevBuf strand_key, seg_head, seg_id, val, pmax, run_head, run_pos;
   uint32_t n_runs = m;
   out.reserve((size_t)m * sizeof(BedRow) + 256);
   // (main.rs:12479: the sweep runs when a range has more than one row and (d >= 0 or strands merge); a range with one
@@ -420,12 +479,90 @@ void device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, con
                                                    nullptr, m, 0, out.as<BedRow>(), strand_key.as<uint32_t>());
     axis_strand_kernel<<<cdiv(n_runs, 256), 256, 0, s>>>(out.as<BedRow>(), strand_key.as<uint32_t>(), n_runs);
   }
-  host_rows.resize((size_t)n_runs * 4);
-  IMPG_HIP(hipMemcpyAsync(host_rows.data(), out.p, (size_t)n_runs * sizeof(BedRow), hipMemcpyDeviceToHost, s));
+  IMPG_HIP(hipStreamSynchronize(s));  // (the scratch buffers of this function die here)
+  return n_runs;
+}
+
+// The merged rows of a chunk as text, streamed to `sink(ptr, bytes)` in pieces of at most PIECE bytes through two
+// pinned buffers: while the host consumes one piece the device formats and copies the next.
+void device_bed_text(Engine &E, const impg_gpu_index &ix, const DevBuf &rows, uint32_t n_rows, uint32_t n_ranges,
+                     const std::vector<std::string> &rnames, bool original_coords,
+                     const std::function<void(const char *, size_t)> &sink) {
+  if (!n_rows) return;
+  hipStream_t s = E.stream;
+  // ---- tables -------------------------------------------------------------------------------------------------------
+  std::string nb;
+  std::vector<uint32_t> noff(1, 0), nshift;
+  for (const std::string &nm : ix.seq.names) {
+    nshift.push_back(put_original_name(nb, nm, original_coords));
+    noff.push_back((uint32_t)nb.size());
+  }
+  std::string rb;
+  std::vector<uint32_t> roff(1, 0);
+  for (uint32_t q = 0; q < n_ranges; q++) { rb += rnames[q]; roff.push_back((uint32_t)rb.size()); }
+  DevBuf d_nb, d_noff, d_shift, d_rb, d_roff, len, off, stmp;
+  auto up = [&](DevBuf &d, const void *src, size_t bytes) {
+    d.reserve(std::max<size_t>(bytes, 256));
+    if (bytes) IMPG_HIP(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, s));
+  };
+  up(d_nb, nb.data(), nb.size()); up(d_noff, noff.data(), noff.size() * 4); up(d_shift, nshift.data(), nshift.size() * 4);
+  up(d_rb, rb.data(), rb.size()); up(d_roff, roff.data(), roff.size() * 4);
+  TextTables t{d_nb.as<char>(), d_noff.as<uint32_t>(), d_shift.as<uint32_t>(), (uint32_t)ix.seq.names.size(), d_rb.as<char>(), d_roff.as<uint32_t>()};
+  // ---- lengths -> 64-bit offsets (a transitive batch prints more than 4 GB) ----------------------------------------------
+  len.reserve((size_t)n_rows * 4);
+  off.reserve((size_t)(n_rows + 1) * 8);
+  text_len_kernel<<<cdiv(n_rows, 256), 256, 0, s>>>(rows.as<BedRow>(), n_rows, t, len.as<uint32_t>());
+  size_t sb = 0;
+  IMPG_HIP(rocprim::exclusive_scan(nullptr, sb, len.as<uint32_t>(), off.as<unsigned long long>(), 0ull, n_rows, rocprim::plus<unsigned long long>(), s));
+  stmp.reserve(std::max<size_t>(sb, 256));
+  IMPG_HIP(rocprim::exclusive_scan(stmp.p, sb, len.as<uint32_t>(), off.as<unsigned long long>(), 0ull, n_rows, rocprim::plus<unsigned long long>(), s));
+  // piece boundaries: whole rows, at most PIECE bytes each; found on the host from a sampled copy of the offsets
+  constexpr size_t PIECE = 256ull << 20;
+  std::vector<unsigned long long> h_off(n_rows);
+  IMPG_HIP(hipMemcpyAsync(h_off.data(), off.p, (size_t)n_rows * 8, hipMemcpyDeviceToHost, s));
+  uint32_t last_len = 0;
+  IMPG_HIP(hipMemcpyAsync(&last_len, len.as<uint32_t>() + (n_rows - 1), 4, hipMemcpyDeviceToHost, s));
   IMPG_HIP(hipStreamSynchronize(s));
-  // rows are grouped by range (the sort's high key): offsets by one pass
-  for (uint32_t r = 0; r < n_runs; r++) row_off[(size_t)host_rows[(size_t)r * 4] + 1]++;
-  for (uint32_t q = 0; q < n_ranges; q++) row_off[q + 1] += row_off[q];
+  const unsigned long long total = h_off[n_rows - 1] + last_len;
+  DevBuf piece[2];
+  char *pin[2] = {nullptr, nullptr};
+  struct Unpin { char **p; ~Unpin() { for (int k = 0; k < 2; k++) if (p[k]) (void)hipHostFree(p[k]); } } unpin{pin};
+  const size_t cap = (size_t)std::min<unsigned long long>(total, PIECE) + 4096;
+  for (int k = 0; k < 2; k++) { piece[k].reserve(cap); IMPG_HIP(hipHostMalloc((void **)&pin[k], cap, hipHostMallocDefault)); }
+  hipEvent_t done[2];
+  for (int k = 0; k < 2; k++) IMPG_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+  struct EvFree { hipEvent_t *e; ~EvFree() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); } } evfree{done};
+  struct Pending { size_t bytes; bool live; } pend[2] = {{0, false}, {0, false}};
+  uint32_t r0 = 0;
+  int slot = 0;
+  while (r0 < n_rows || pend[0].live || pend[1].live) {
+    if (r0 < n_rows) {
+      // rows [r0, r1): as many whole rows as fit one piece
+      const unsigned long long base = h_off[r0];
+      uint32_t r1 = (uint32_t)(std::upper_bound(h_off.begin() + r0 + 1, h_off.end(), base + PIECE) - h_off.begin());
+      if (r1 == n_rows) { if (total - base > PIECE && n_rows - 1 > r0) r1 = n_rows - 1; }
+      else r1 = std::max(r1 - 1, r0 + 1);
+      const unsigned long long end = r1 < n_rows ? h_off[r1] : total;
+      if (end - base > cap) throw Error{IMPG_E_UNSUPPORTED, "a single BED row longer than the text buffer"};
+      text_write_kernel<<<cdiv(r1 - r0, 256), 256, 0, s>>>(rows.as<BedRow>() + r0, r1 - r0, t, off.as<unsigned long long>() + r0, base, piece[slot].as<char>());
+      IMPG_HIP(hipMemcpyAsync(pin[slot], piece[slot].p, (size_t)(end - base), hipMemcpyDeviceToHost, s));
+      IMPG_HIP(hipEventRecord(done[slot], s));
+      pend[slot] = {(size_t)(end - base), true};
+      r0 = r1;
+    }
+    // consume the OTHER slot's piece while this one is in flight (or drain at the end)
+    const int other = slot ^ 1;
+    if (pend[other].live) {
+      IMPG_HIP(hipEventSynchronize(done[other]));
+      sink(pin[other], pend[other].bytes);
+      pend[other].live = false;
+    } else if (r0 >= n_rows && pend[slot].live) {
+      IMPG_HIP(hipEventSynchronize(done[slot]));
+      sink(pin[slot], pend[slot].bytes);
+      pend[slot].live = false;
+    }
+    slot ^= 1;
+  }
 }
 
 }  // namespace impg

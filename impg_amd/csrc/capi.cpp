@@ -1,6 +1,9 @@
 // extern "C" entry points of libimpg_gpu.so (include/impg_gpu.h).  Nothing
 // unwinds across this file: every body is wrapped and mapped to a status code.
+#include <unistd.h>
+
 #include <atomic>
+#include <cerrno>
 #include <functional>
 #include <thread>
 #include <chrono>
@@ -19,9 +22,11 @@ void render_paf(const impg_gpu_results &res, const impg_gpu_index &ix, const cha
 void render_bed(const impg_gpu_results &res, const impg_gpu_index &ix, const char *const *range_names,
                 const impg_gpu_params_t &p, int32_t merge_distance, std::vector<std::string> &parts);
 char *join_parts(std::vector<std::string> &parts, size_t *len);  // bed.cpp
-void device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, const impg_gpu_params_t &p, int32_t merge_distance,
-                     std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, std::vector<uint32_t> &host_rows,
-                     std::vector<uint64_t> &row_off);  // bed_device.hip
+uint32_t device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, const impg_gpu_params_t &p, int32_t merge_distance,
+                         std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, DevBuf &out);  // bed_device.hip
+void device_bed_text(Engine &E, const impg_gpu_index &ix, const DevBuf &rows, uint32_t n_rows, uint32_t n_ranges,
+                     const std::vector<std::string> &rnames, bool original_coords,
+                     const std::function<void(const char *, size_t)> &sink);
 }  // namespace impg
 
 using namespace impg;
@@ -699,12 +704,12 @@ int impg_gpu_results_bed(const impg_gpu_results_t *res, const impg_gpu_index_t *
   IMPG_CATCH
 }
 
-// query + both BED merges on the device + text: only merged rows cross PCIe
-int impg_gpu_query_batch_bed(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
-                             const uint8_t *subset_keep, int32_t merge_distance, const char *const *range_names, char **text,
-                             size_t *len, double *seconds3) {
-  IMPG_TRY
-  if (!ix || !params || !text || !len || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
+// query + both BED merges + the text on the device: only text crosses PCIe, in pinned pieces
+namespace {
+void bed_batch(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params, const uint8_t *subset_keep,
+               int32_t merge_distance, const char *const *range_names, const std::function<void(const char *, size_t)> &sink,
+               double *seconds3) {
+  if (!ix || !params || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
   if (ix->shard || ix->cluster) throw Error{IMPG_E_UNSUPPORTED, "the device-side BED path runs on a single-GPU index (use impg_gpu_query_batch + impg_gpu_results_bed)"};
   check_ranges(ranges, n);
   Engine::check_params(*params);
@@ -716,68 +721,82 @@ int impg_gpu_query_batch_bed(impg_gpu_index_t *ix, const impg_gpu_range_t *range
   apply_subset(E, *ix, subset_keep);
   E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
   if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
-  std::vector<std::string> parts(n);
   double t_engine = 0, t_merge = 0, t_text = 0;
-  const bool orig = p.original_sequence_coordinates != 0;
   for_chunks(E, n, [&](size_t b, size_t e) {
     const auto c0 = std::chrono::steady_clock::now();
     std::vector<std::unique_ptr<LevelBufs>> levels;
-    DevBuf self_dev;
+    DevBuf self_dev, rows;
     E.run(*ix, E.ranges_dev.as<impg_gpu_range_t>() + b, (uint32_t)(e - b), p, &levels, nullptr, nullptr, nullptr, &self_dev);
     const auto c1 = std::chrono::steady_clock::now();
-    std::vector<uint32_t> rows;
-    std::vector<uint64_t> off;
-    device_bed_rows(E, *ix, (uint32_t)(e - b), p, merge_distance, levels, self_dev, rows, off);
+    const uint32_t n_rows = device_bed_rows(E, *ix, (uint32_t)(e - b), p, merge_distance, levels, self_dev, rows);
     const auto c2 = std::chrono::steady_clock::now();
-    // text: one task per range, ranges dealt to the host threads
-    const size_t cnt = e - b;
-    unsigned hw = std::thread::hardware_concurrency();
-    const size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, cnt / 8 + 1));
-    std::atomic<size_t> next{0};
-    auto work = [&]() {
-      char buf[64];
-      for (;;) {
-        const size_t i = next.fetch_add(1);
-        if (i >= cnt) break;
-        std::string &s = parts[b + i];
-        s.clear();
-        const impg_gpu_range_t &q = ranges[b + i];
-        std::string rn;
-        if (range_names && range_names[b + i]) rn = range_names[b + i];
-        else {  // "{chrom}:{start}-{end}" (partition.rs:1741, :1762)
-          rn = q.target_id < ix->seq.names.size() ? ix->seq.names[q.target_id] : std::to_string(q.target_id);
-          const int k = snprintf(buf, sizeof buf, ":%d-%d", q.start, q.end);
-          rn.append(buf, (size_t)k);
-        }
-        s.reserve((size_t)(off[i + 1] - off[i]) * (rn.size() + 40));
-        for (uint64_t r = off[i]; r < off[i + 1]; r++) {
-          const uint32_t *w = rows.data() + r * 4;
-          const uint32_t qid = w[1];
-          uint32_t shift = 0;  // --original-sequence-coordinates (main.rs:11876-11883)
-          if (qid < ix->seq.names.size()) shift = put_original_name(s, ix->seq.names[qid], orig);
-          else s += std::to_string(qid);
-          const int k = snprintf(buf, sizeof buf, "\t%u\t%u\t", (uint32_t)(int32_t)w[2] + shift, (uint32_t)(w[3] >> 1) + shift);
-          s.append(buf, (size_t)k);
-          s += rn;
-          s += "\t.\t";
-          s += (w[3] & 1u) ? '-' : '+';
-          s += '\n';
-        }
+    std::vector<std::string> rn(e - b);
+    char buf[64];
+    for (size_t i = b; i < e; i++) {
+      if (range_names && range_names[i]) rn[i - b] = range_names[i];
+      else {  // "{chrom}:{start}-{end}" (partition.rs:1741, :1762)
+        const impg_gpu_range_t &q = ranges[i];
+        rn[i - b] = q.target_id < ix->seq.names.size() ? ix->seq.names[q.target_id] : std::to_string(q.target_id);
+        const int k = snprintf(buf, sizeof buf, ":%d-%d", q.start, q.end);
+        rn[i - b].append(buf, (size_t)k);
       }
-    };
-    if (T == 1) work();
-    else {
-      std::vector<std::thread> th;
-      for (size_t t = 0; t < T; t++) th.emplace_back(work);
-      for (auto &x : th) x.join();
     }
+    device_bed_text(E, *ix, rows, n_rows, (uint32_t)(e - b), rn, p.original_sequence_coordinates != 0, sink);
     const auto c3 = std::chrono::steady_clock::now();
     t_engine += std::chrono::duration<double>(c1 - c0).count();
     t_merge += std::chrono::duration<double>(c2 - c1).count();
     t_text += std::chrono::duration<double>(c3 - c2).count();
   });
-  *text = join_parts(parts, len);
   if (seconds3) { seconds3[0] = t_engine; seconds3[1] = t_merge; seconds3[2] = t_text; }
+}
+}  // namespace
+
+int impg_gpu_query_batch_bed(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
+                             const uint8_t *subset_keep, int32_t merge_distance, const char *const *range_names, char **text,
+                             size_t *len, double *seconds3) {
+  IMPG_TRY
+  if (!text || !len) throw Error{IMPG_E_INVALID, "null argument"};
+  // the text arrives in pieces; it is collected into one malloc'ed buffer that grows geometrically
+  char *buf = nullptr;
+  size_t used = 0, cap = 0;
+  struct Guard { char *&b; bool keep = false; ~Guard() { if (!keep) free(b); } } guard{buf};
+  bed_batch(ix, ranges, n, params, subset_keep, merge_distance, range_names, [&](const char *p, size_t k) {
+    if (used + k + 1 > cap) {
+      const size_t nc = std::max(cap * 2, used + k + 1 + (1u << 20));
+      char *nb = (char *)realloc(buf, nc);
+      if (!nb) throw Error{IMPG_E_OOM, "host out of memory"};
+      buf = nb; cap = nc;
+    }
+    memcpy(buf + used, p, k);
+    used += k;
+  }, seconds3);
+  if (!buf) { buf = (char *)malloc(1); if (!buf) throw Error{IMPG_E_OOM, "host out of memory"}; }
+  buf[used] = 0;
+  guard.keep = true;
+  *text = buf;
+  *len = used;
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_query_batch_bed_fd(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
+                                const uint8_t *subset_keep, int32_t merge_distance, const char *const *range_names, int fd,
+                                uint64_t *bytes_written, double *seconds3) {
+  IMPG_TRY
+  uint64_t total = 0;
+  bed_batch(ix, ranges, n, params, subset_keep, merge_distance, range_names, [&](const char *p, size_t k) {
+    size_t done = 0;
+    while (done < k) {
+      const ssize_t w = write(fd, p + done, k - done);
+      if (w < 0) {
+        if (errno == EINTR) continue;
+        throw Error{IMPG_E_IO, std::string("write failed: ") + strerror(errno)};
+      }
+      done += (size_t)w;
+    }
+    total += k;
+  }, seconds3);
+  if (bytes_written) *bytes_written = total;
   return IMPG_OK;
   IMPG_CATCH
 }

@@ -293,18 +293,16 @@ int main(int argc, char **argv) {
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   if (fmt == "bed" && !host_merge) {  // both merges on the device: only merged rows cross PCIe
-    char *text = nullptr;
-    size_t len = 0;
+    uint64_t len = 0;
     double sec[3] = {0, 0, 0};
-    if (impg_gpu_query_batch_bed(ix, ranges.data(), ranges.size(), &p, keep.empty() ? nullptr : keep.data(), merge_distance, names.data(), &text,
-                                 &len, sec) != IMPG_OK)
+    fflush(stdout);
+    if (impg_gpu_query_batch_bed_fd(ix, ranges.data(), ranges.size(), &p, keep.empty() ? nullptr : keep.data(), merge_distance, names.data(),
+                                    fileno(stdout), &len, sec) != IMPG_OK)
       die(impg_gpu_last_error());
     const double t1 = now();
-    fwrite(text, 1, len, stdout);
-    fflush(stdout);
     if (verbose >= 1)
-      fprintf(stderr, "[impg-gpu] query + merge + text %.2f s (engine %.2f, device merge + copy back %.2f, text %.2f), write %.2f s, %zu bytes\n",
-              t1 - t0, sec[0], sec[1], sec[2], now() - t1, len);
+      fprintf(stderr, "[impg-gpu] query + merge + text + write %.2f s (engine %.2f, device merge %.2f, device text + copy + write %.2f), %llu bytes\n",
+              t1 - t0, sec[0], sec[1], sec[2], (unsigned long long)len);
     _exit(0);  // (tearing down gigabytes of host buffers and the device context is not worth a second)
   }
   if (impg_gpu_query_batch_filtered(ix, ranges.data(), ranges.size(), &p, nullptr, keep.empty() ? nullptr : keep.data(), &res) != IMPG_OK)

@@ -298,13 +298,19 @@ int impg_gpu_results_bed(const impg_gpu_results_t *, const impg_gpu_index_t *,
 /* perform_query + output_results_bed for a whole batch in one call, with both merges ON THE DEVICE
  * (bed_device.hip): the hit slots never leave HBM; they are turned into rows, sorted, chained
  * (merge_adjusted_intervals_gap_2d) and swept (merge_query_adjusted_intervals) there, and only the merged rows --
- * 16 bytes each -- cross PCIe to be printed.  The text is byte-identical to impg_gpu_query_batch_filtered +
+ * 16 bytes each -- are formatted there as well; the text crosses PCIe in pinned pieces while the next piece is being
+ * formatted.  The text is byte-identical to impg_gpu_query_batch_filtered +
  * impg_gpu_results_bed (what `impg query -o bed` prints: main.rs:7435-7470, :11849-11892).  range_names as in
  * impg_gpu_results_bed (NULL, or NULL entries, = "{name}:{start}-{end}").  subset_keep may be NULL.  seconds3, if
  * not NULL, receives the wall seconds of {engine, device-side merge + copy back, text}.  Single-GPU index. */
 int impg_gpu_query_batch_bed(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
                              const uint8_t *subset_keep, int32_t merge_distance, const char *const *range_names, char **text,
                              size_t *len, double *seconds3);
+/* The same, the text written to a file descriptor piece by piece instead of collected (what the CLI does: gigabytes
+ * of BED never exist as one host buffer). */
+int impg_gpu_query_batch_bed_fd(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
+                                const uint8_t *subset_keep, int32_t merge_distance, const char *const *range_names, int fd,
+                                uint64_t *bytes_written, double *seconds3);
 
 /* ---- PAF / BEDPE: results.remove(0) + merge_adjusted_intervals (CIGAR-faithful
  *      merge: contiguity, identical overlap, gaps <= -d) + output_results_paf /

@@ -21,14 +21,14 @@ saved = os.path.join(tmp, "headline.impghbm")
 t = time.perf_counter(); subprocess.run([cli, "index", "-a", paf, "-i", saved], check=True); t_index = time.perf_counter() - t
 out = os.path.join(tmp, "out.bed")
 for label, src in (("from the PAF", ["-a", paf]), ("from the saved index", ["-i", saved])):
-    for flags in (["-d", "1000"], ["-d", "1000", "-x", "-m", "3"]):
+    for flags in (["-d", "1000"], ["-d", "1000", "-x", "-m", "3"], ["-d", "1000", "-x", "-m", "3", "--host-merge"]):
         t = time.perf_counter()
         with open(out, "wb") as fo:
             r = subprocess.run([cli, "query", "-v", "1"] + src + ["-b", bedf, "-o", "bed"] + flags, stdout=fo, stderr=subprocess.PIPE)
         dt = time.perf_counter() - t
         assert r.returncode == 0, r.stderr.decode()[-500:]
         print("%-22s %-18s %6.2f s wall, %7.1f MB of BED, %d rows" % (label, " ".join(flags), dt, os.path.getsize(out) / 1e6,
-                                                                      sum(1 for _ in open(out, "rb"))))
+                                                                      0))
         print("   " + r.stderr.decode().strip().splitlines()[-1])
 print("impg-gpu index: %.2f s" % t_index)
 os.remove(saved); os.remove(out)

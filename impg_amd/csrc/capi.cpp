@@ -394,7 +394,10 @@ int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths, int bi
   require_device(device);
   ParsedPaf pp;
   std::vector<std::string> ps(paths, paths + n_paths);
+  const auto t0 = std::chrono::steady_clock::now();
   parse_paf_files(ps, pp);
+  if (getenv("IMPG_BUILD_TIMING"))
+    fprintf(stderr, "[build] %-28s %.3f s\n", "parse PAF", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   std::vector<int64_t> lens = pp.seq.lens;
   *out = make_index(pp.records.data(), pp.records.size(), pp.ops.data(), pp.ops.size(), lens.data(), (uint32_t)lens.size(),
                     bidirectional, order_policy, device, 0, 1, &pp.seq, &pp.file_first, nullptr).release();
@@ -581,12 +584,21 @@ int impg_gpu_query_batch_filtered(impg_gpu_index_t *ix, const impg_gpu_range_t *
   apply_mask(E, *ix, mask, *params);
   apply_subset(E, *ix, subset_keep);
   auto res = std::make_unique<impg_gpu_results>();
+  if (n && n <= Engine::SMALL_RANGES && !params->transitive) {  // the per-call shape: one chain of launches, one sync
+    const auto c0 = std::chrono::steady_clock::now();
+    if (E.run_small(*ix, ranges, (uint32_t)n, *params, *res)) {
+      res->run_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+      *out = res.release();
+      return IMPG_OK;
+    }
+  }
   E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
   if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
   res->offsets.assign(1, 0);
   for_chunks(E, n, [&](size_t b, size_t e) {
     std::vector<std::unique_ptr<LevelBufs>> levels;
     DevBuf self_dev;
+    self_dev.pool = &E.level_pool;
     const auto c0 = std::chrono::steady_clock::now();
     E.run(*ix, E.ranges_dev.as<impg_gpu_range_t>() + b, (uint32_t)(e - b), *params, &levels, nullptr, nullptr, nullptr, &self_dev);
     const auto c1 = std::chrono::steady_clock::now();
@@ -726,6 +738,7 @@ void bed_batch(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, c
     const auto c0 = std::chrono::steady_clock::now();
     std::vector<std::unique_ptr<LevelBufs>> levels;
     DevBuf self_dev, rows;
+    self_dev.pool = &E.level_pool;
     E.run(*ix, E.ranges_dev.as<impg_gpu_range_t>() + b, (uint32_t)(e - b), p, &levels, nullptr, nullptr, nullptr, &self_dev);
     const auto c1 = std::chrono::steady_clock::now();
     const uint32_t n_rows = device_bed_rows(E, *ix, (uint32_t)(e - b), p, merge_distance, levels, self_dev, rows);

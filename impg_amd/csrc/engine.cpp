@@ -33,7 +33,88 @@ Engine::Engine(int device) {
   IMPG_HIP(hipHostMalloc((void **)&h_counters, 64, hipHostMallocDefault));
   IMPG_HIP(hipHostMalloc((void **)&h_slots, COUNT_BYTES, hipHostMallocDefault));
 }
+bool Engine::run_small(const impg_gpu_index &ix, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p,
+                       impg_gpu_results &res) {
+  // (MultiImpg's plain query sorts its hits by five keys, multi_impg.rs:556-592: the general path does that)
+  if (n == 0 || n > SMALL_RANGES || p.transitive || p.store_cigar || p.multi_impg || masked || subset_on || remote) return false;
+  // every candidate pair of a range is an entry of its target: the sum of those segments bounds the pairs, on the host
+  uint64_t bound = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t t = h_ranges[i].target_id;
+    if (t + 1 < ix.h_tgt_off.size()) bound += ix.h_tgt_off[t + 1] - ix.h_tgt_off[t];
+  }
+  if (bound > SMALL_PAIRS) return false;
+  const uint32_t B = (uint32_t)std::max<uint64_t>(bound, 1);
+  IMPG_HIP(hipSetDevice(ix.device));
+  const size_t need_out = SMALL_HEADER_BYTES + (size_t)SMALL_PAIRS * (sizeof(impg_gpu_interval_t) + 4);
+  if (!small_in) IMPG_HIP(hipHostMalloc((void **)&small_in, SMALL_RANGES * sizeof(impg_gpu_range_t), hipHostMallocDefault));
+  if (!small_out) {
+    IMPG_HIP(hipHostMalloc((void **)&small_out, need_out, hipHostMallocMapped));
+    IMPG_HIP(hipHostGetDevicePointer(&small_out_dev, small_out, 0));
+    small_out_cap = need_out;
+  }
+  const DeviceIndexView &v = ix.view;
+  min_identity = p.min_identity;
+  store_cigar = false;
+  multi = false;
+  memcpy(small_in, h_ranges, (size_t)n * sizeof(impg_gpu_range_t));
+  ranges_dev.reserve(std::max<size_t>((size_t)SMALL_RANGES * sizeof(impg_gpu_range_t), 256));
+  frontier_a.reserve(std::max<size_t>((size_t)SMALL_RANGES * sizeof(FrontierRec), 256));
+  cnt.reserve(SMALL_RANGES * 4); win.reserve(SMALL_RANGES * 16); pair_off.reserve(SMALL_RANGES * 4);
+  wide_n.reserve(256); wide_list.reserve(SMALL_RANGES * 4);
+  LevelBufs &L = level_scratch;
+  const size_t pb = std::max<size_t>((size_t)B * 4, 256);
+  L.pair_range.reserve(pb); pair_entry.reserve(pb); L.qid.reserve(pb); L.coords.reserve(4 * pb);
+  IMPG_HIP(hipMemcpyAsync(ranges_dev.p, small_in, (size_t)n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, stream));
+  IMPG_HIP(hipMemsetAsync(counters.p, 0, 64, stream));
+  IMPG_HIP(hipMemsetAsync(acc_slots.p, 0, COUNT_BYTES, stream));
+  const FrontierRec *fr = frontier_a.as<FrontierRec>();
+  launch_ranges_to_frontier(ranges_dev.as<impg_gpu_range_t>(), n, frontier_a.as<FrontierRec>(), stream);
+  launch_lookup_count(v, fr, n, false, nullptr, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
+  uint32_t *d_total = reinterpret_cast<uint32_t *>(counters.as<uint64_t>() + 3);
+  launch_small_scan(cnt.as<uint32_t>(), n, pair_off.as<uint32_t>(), d_total, stream);
+  launch_lookup_emit(v, fr, n, false, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(),
+                     nullptr, nullptr, ProjList{nullptr, nullptr, nullptr}, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
+  HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
+  launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), B, false, h, acc_slots.as<unsigned long long>(),
+                 (uint32_t *)(counters.as<uint64_t>() + 2), min_identity, nullptr, ProjList{nullptr, nullptr, nullptr}, stream, d_total);
+  char *od = static_cast<char *>(small_out_dev);
+  impg_gpu_interval_t *d_rows = reinterpret_cast<impg_gpu_interval_t *>(od + SMALL_HEADER_BYTES);
+  uint32_t *d_rr = reinterpret_cast<uint32_t *>(od + SMALL_HEADER_BYTES + (size_t)SMALL_PAIRS * sizeof(impg_gpu_interval_t));
+  launch_small_pack(fr, L.pair_range.as<uint32_t>(), d_total, B, h, (const uint32_t *)(counters.as<uint64_t>() + 2),
+                    acc_slots.as<unsigned long long>(), od, d_rows, d_rr, stream);
+  IMPG_HIP(hipStreamSynchronize(stream));
+  struct Hdr { uint32_t n_pairs, err, p0, p1; unsigned long long accepted; };
+  const Hdr *hd = reinterpret_cast<const Hdr *>(small_out);
+  if (hd->err & 2) throw Error{IMPG_E_INVALID, "Projection resulted in negative query coordinates"};
+  if (hd->err) throw Error{IMPG_E_INVALID, "an alignment hit by the query has no CIGAR (missing cg:Z tag)"};
+  const uint32_t P = hd->n_pairs;
+  const impg_gpu_interval_t *rows = reinterpret_cast<const impg_gpu_interval_t *>(small_out + SMALL_HEADER_BYTES);
+  const uint32_t *rr = reinterpret_cast<const uint32_t *>(small_out + SMALL_HEADER_BYTES + (size_t)SMALL_PAIRS * sizeof(impg_gpu_interval_t));
+  // slots are in range order, visit order inside a range: one pass builds the per-range lists, self interval first
+  res.ranges.assign(h_ranges, h_ranges + n);
+  res.offsets.assign((size_t)n + 1, 0);
+  res.intervals.clear();
+  res.intervals.reserve((size_t)P + n);
+  uint32_t pcur = 0;
+  for (uint32_t q = 0; q < n; q++) {
+    const impg_gpu_range_t &r = h_ranges[q];
+    res.intervals.push_back({r.target_id, r.start, r.end, r.target_id, r.start, r.end});  // impg.rs:1864-1880
+    while (pcur < P && rr[pcur] == q) {
+      if (rows[pcur].query_id != HIT_NONE) res.intervals.push_back(rows[pcur]);
+      pcur++;
+    }
+    res.offsets[q + 1] = res.intervals.size();
+  }
+  res.has_cigar = false;
+  res.projected = hd->accepted;
+  last_projected = hd->accepted;
+  return true;
+}
+
 Engine::~Engine() {
+  if (small_in) (void)hipHostFree(small_in);
+  if (small_out) (void)hipHostFree(small_out);
   for (auto e : ev_pool) (void)hipEventDestroy(e);
   if (h_counters) (void)hipHostFree(h_counters);
   if (h_slots) (void)hipHostFree(h_slots);
@@ -437,7 +518,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     std::unique_ptr<LevelBufs> own;
     LevelBufs *L = &level_scratch;
     if (keep) {
-      own = std::make_unique<LevelBufs>();
+      own = std::make_unique<LevelBufs>(&level_pool);
       L = own.get();
     }
     const bool want_stats = d_count || d_cksum;
@@ -552,6 +633,7 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
     k.reserve(std::max<size_t>(m * 8, 256)); s.reserve(std::max<size_t>(m * 4, 256));
     e.reserve(std::max<size_t>(m * 4, 256)); d.reserve(std::max<size_t>(m * 4, 256));
   };
+  for (DevBuf *b : {&dk_a, &ds_a, &de_a, &dd_a, &dk_b, &ds_b, &de_b, &dd_b}) b->pool = &level_pool;  // (swapped with per-round buffers below)
   res4(dk_a, ds_a, de_a, dd_a, n_stack);
   d_popdepth.reserve(std::max<size_t>((size_t)n * 4, 256));
   launch_frontier_to_stack(frontier_a.as<FrontierRec>(), n_stack, nullptr, false, dk_a.as<unsigned long long>(),
@@ -575,7 +657,7 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
     // remaining stack goes to the *_b buffers; the new pieces are appended behind it
     std::unique_ptr<LevelBufs> own;
     LevelBufs *L = &level_scratch;
-    if (keep) { own = std::make_unique<LevelBufs>(); L = own.get(); }
+    if (keep) { own = std::make_unique<LevelBufs>(&level_pool); L = own.get(); }
     if (alive) {
       res4(dk_b, ds_b, de_b, dd_b, (size_t)n_keep + 1);
       launch_dfs_pop_scatter(dk_a.as<unsigned long long>(), ds_a.as<int32_t>(), de_a.as<int32_t>(), dd_a.as<uint32_t>(), n_stack,
@@ -612,6 +694,7 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
     // *_b buffers may have been sized for n_keep only: grow while keeping the kept part
     {
       DevBuf nk, ns, ne, nd;
+      nk.pool = ns.pool = ne.pool = nd.pool = &level_pool;  // (new buffers every round: recycled, not hipMalloc'ed)
       res4(nk, ns, ne, nd, m);
       if (n_keep) {
         IMPG_HIP(hipMemcpyAsync(nk.p, dk_b.p, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, stream));

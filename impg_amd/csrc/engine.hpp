@@ -13,6 +13,12 @@ struct LevelBufs {  // one BFS level: its frontier and its hit slots
   DevBuf sl_a, sl_n, sl_off, sl_rem, slice_pos, slice_pool;
   uint64_t slice_total = 0;
   uint32_t n_frontier = 0, n_pairs = 0;
+  LevelBufs() = default;
+  // the levels a full-results call keeps are new objects at every level of every call: their blocks are recycled
+  // through the engine's pool (hipMalloc / hipFree are 0.1-1 ms each and hipFree synchronises the device)
+  explicit LevelBufs(BufPool *pool) {
+    for (DevBuf *b : {&frontier, &pair_range, &qid, &coords, &sl_a, &sl_n, &sl_off, &sl_rem, &slice_pos, &slice_pool}) b->pool = pool;
+  }
 };
 struct VisitedStore {  // device storage of one VisitedTable
   DevBuf keys, off, len, ranges;
@@ -58,6 +64,7 @@ struct Engine {
       stat_cksum, stage_off;
   LevelBufs level_scratch;
   BufPool table_pool;  // declared before `tables`: the tables hand their blocks back when they die
+  BufPool level_pool;  // blocks of the levels kept for a full-results call, and of the DFS driver's per-round buffers
   std::vector<std::unique_ptr<VisitedStore>> tables;
   uint64_t last_projected = 0;
   uint64_t pair_budget = 1ull << 28;  // candidate pairs per level kept in HBM at once
@@ -130,6 +137,15 @@ struct Engine {
   void run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
            std::vector<std::unique_ptr<LevelBufs>> *keep, unsigned long long *d_count, unsigned long long *d_cksum,
            impg_gpu_stats_t *st, DevBuf *self_out);
+  // Impg::query of a small batch (the trait's per-call shape) as one chain of launches and one synchronisation;
+  // false = not applicable (too many candidate pairs): the caller takes the general path
+  static constexpr uint32_t SMALL_RANGES = 64, SMALL_PAIRS = 1u << 18;
+  bool run_small(const impg_gpu_index &ix, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p,
+                 impg_gpu_results &res);
+  char *small_in = nullptr;    // pinned: the ranges on their way in
+  char *small_out = nullptr;   // pinned + mapped: header, rows, the rows' ranges (written by the device)
+  void *small_out_dev = nullptr;
+  size_t small_out_cap = 0;
 };
 
 // owner: null = one shard holds everything; else owner[target id] = the shard that holds the target's entries

@@ -154,20 +154,6 @@ void parse_chunk(const char *text, size_t begin, size_t end, ChunkOut &o) {
   }
 }
 
-void merge_chunk(ChunkOut &c, ParsedPaf &out) {
-  std::vector<uint32_t> remap(c.names.size());
-  for (size_t i = 0; i < c.names.size(); i++) remap[i] = out.seq.get_or_insert(c.names[i], c.lens[i]);
-  uint64_t shift = out.ops.size();
-  out.ops.insert(out.ops.end(), c.ops.begin(), c.ops.end());
-  out.records.reserve(out.records.size() + c.records.size());
-  for (auto r : c.records) {
-    r.query_id = remap[r.query_id];
-    r.target_id = remap[r.target_id];
-    r.cigar_off += shift;
-    out.records.push_back(r);
-  }
-}
-
 }  // namespace
 
 void parse_paf_text(const char *text, size_t len, ParsedPaf &out) {
@@ -188,7 +174,36 @@ void parse_paf_text(const char *text, size_t len, ParsedPaf &out) {
   for (auto &x : th) x.join();
   for (size_t t = 0; t < T; t++)
     if (!chunks[t].err.empty()) throw Error{IMPG_E_INVALID, "Failed to parse PAF: " + chunks[t].err};
-  for (size_t t = 0; t < T; t++) merge_chunk(chunks[t], out);
+  // Merge: sequence ids in first-seen order over the chunks (serial: a few hundred names), then every chunk's
+  // records and ops copied to their final place in parallel (the ops are most of the input's bytes: appended one
+  // chunk after the other they cost as much as the parse itself).
+  std::vector<std::vector<uint32_t>> remap(T);
+  std::vector<size_t> rec_at(T + 1, out.records.size()), ops_at(T + 1, out.ops.size());
+  for (size_t t = 0; t < T; t++) {
+    remap[t].resize(chunks[t].names.size());
+    for (size_t i = 0; i < chunks[t].names.size(); i++) remap[t][i] = out.seq.get_or_insert(chunks[t].names[i], chunks[t].lens[i]);
+    rec_at[t + 1] = rec_at[t] + chunks[t].records.size();
+    ops_at[t + 1] = ops_at[t] + chunks[t].ops.size();
+  }
+  out.records.resize(rec_at[T]);
+  out.ops.resize(ops_at[T]);
+  th.clear();
+  for (size_t t = 0; t < T; t++)
+    th.emplace_back([&, t]() {
+      ChunkOut &c = chunks[t];
+      if (!c.ops.empty()) memcpy(out.ops.data() + ops_at[t], c.ops.data(), c.ops.size() * 4);
+      impg_gpu_record_t *dst = out.records.data() + rec_at[t];
+      for (size_t i = 0; i < c.records.size(); i++) {
+        impg_gpu_record_t r = c.records[i];
+        r.query_id = remap[t][r.query_id];
+        r.target_id = remap[t][r.target_id];
+        r.cigar_off += ops_at[t];
+        dst[i] = r;
+      }
+      std::vector<uint32_t>().swap(c.ops);
+      std::vector<impg_gpu_record_t>().swap(c.records);
+    });
+  for (auto &x : th) x.join();
 }
 
 void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out) {

@@ -8,6 +8,10 @@
 //     checkpoint per tile, shared by the forward and the reversed entry.
 #include <algorithm>
 #include <atomic>
+#include <memory>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <thread>
 
@@ -112,6 +116,25 @@ void coitrees_visit_rank(uint32_t n, uint32_t *rank) {
 
 namespace {
 
+// a large host array whose elements are all written by the parallel builders: not worth a serial value-initialisation
+// pass first (1.5 GB of fills for the headline index)
+template <class T> struct RawVec {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  explicit RawVec(size_t n_) : p(n_ ? new T[n_] : nullptr), n(n_) {}
+  T *data() { return p.get(); }
+  const T *data() const { return p.get(); }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T &operator[](size_t i) { return p[i]; }
+};
+template <class T> void upload(impg_gpu_index &ix, int k, const RawVec<T> &v, size_t &acc) {
+  DevBuf &b = *ix.blob(k);
+  b.reserve(std::max<size_t>(v.size() * sizeof(T) + 64, 256));
+  if (!v.empty()) IMPG_HIP(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  ix.blob_bytes[k] = v.size() * sizeof(T);
+  acc += v.size() * sizeof(T);
+}
 template <class T> void upload(impg_gpu_index &ix, int k, const std::vector<T> &v, size_t &acc) {
   DevBuf &b = *ix.blob(k);
   b.reserve(std::max<size_t>(v.size() * sizeof(T) + 64, 256));  // + slack: kernels read whole 16-byte vectors
@@ -133,6 +156,15 @@ void parallel_chunks(size_t n, const std::function<void(size_t, size_t)> &f) {
 void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops,
                  size_t n_ops, const int64_t *seq_len, uint32_t n_seq, bool bidirectional, int order_policy,
                  uint32_t shard, uint32_t n_shards, const uint32_t *owner, const TpInput *tp, const EntryPlan *plan) {
+  const bool timing = getenv("IMPG_BUILD_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_prev = tnow();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const double t = tnow();
+    fprintf(stderr, "[build] %-28s %.3f s\n", what, t - t_prev);
+    t_prev = t;
+  };
   if (n_shards == 0 || shard >= n_shards) throw Error{IMPG_E_INVALID, "bad shard"};
   if (order_policy != IMPG_ORDER_COITREES && order_policy != IMPG_ORDER_SORTED)
     throw Error{IMPG_E_INVALID, "bad order policy"};
@@ -191,8 +223,13 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     }
     n_tiles = (nb * 4 + TILE_WORDS - 1) / TILE_WORDS;  // (the pool is accounted in 128-byte lines like the op pool)
   }
-  std::vector<uint32_t> pool(n_tiles * TILE_WORDS, OP_PAD);
-  std::vector<uint4> idp(tp ? 0 : TILE_SUBS * n_tiles);  // per sub-tile: matched / mismatched bases and gap ops before it (identity filter)
+  RawVec<uint32_t> pool(n_tiles * TILE_WORDS);  // (every line is filled by the builder that owns it)
+  RawVec<uint4> idp(tp ? 0 : TILE_SUBS * n_tiles);  // per sub-tile: matched / mismatched bases and gap ops before it (identity filter)
+  if (tp && n_tiles) {  // the tail of the last 128-byte line behind the last boundary
+    uint64_t nb_words = 0;
+    for (size_t i = 0; i < n_records; i++) if (need[i]) nb_words += ((uint64_t)records[i].cigar_len + 1) * 4;
+    for (uint64_t w = nb_words; w < n_tiles * TILE_WORDS; w++) pool[w] = OP_PAD;
+  }
   std::atomic<bool> bad_op{false};
   std::atomic<bool> bad_tp{false};
   if (tp) parallel_chunks(n_records, [&](size_t lo, size_t hi) {
@@ -237,6 +274,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
       for (uint32_t k0 = 0; k0 < n; k0 += TILE_OPS) {
         const size_t tile = (size_t)tile_base[i] + k0 / TILE_OPS;
         uint32_t *line = pool.data() + tile * TILE_WORDS;
+        for (uint32_t w = 0; w < TILE_WORDS; w++) line[w] = OP_PAD;
         const uint32_t t0 = st, q0 = sq;
         uint32_t dt[TILE_SUBS + 1], dq[TILE_SUBS + 1];  // sums before sub-tile s (s = 4: after the tile)
         uint32_t sub = 0;
@@ -272,6 +310,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   });
   if (bad_op) throw Error{IMPG_E_INVALID, "Invalid CIGAR operation"};
 
+  lap("validate + tiles");
   // ---- entries, grouped by key in input order (impg.rs:1559-1623) --------------
   std::vector<uint32_t> tgt_off(n_seq + 1, 0);
   for (uint32_t s = 0; s < n_seq; s++) tgt_off[s + 1] = tgt_off[s] + seg_count[s];
@@ -323,6 +362,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
       }
     }
   }
+  lap("entries");
   // per segment: stable sort by start (coitrees sorts by `first` only)
   {
     std::vector<uint32_t> perm(n_entries);
@@ -349,6 +389,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     ent.swap(e2);
     ent_rec.swap(r2);
   }
+  lap("per-target sort + permute");
   // effective-order target checkpoints of every entry: prefix at the start of
   // effective tile k.  Forward walk: the tile's own T0 (or Q0 for a reversed
   // entry); back-to-front walk (reversed entry on the reverse strand): total
@@ -386,6 +427,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
       }
     });
   }
+  lap("checkpoints");
   // SoA columns, running max of end, visit rank, search levels
   std::vector<int32_t> starts(n_entries), ends(n_entries), ends_t(n_entries), pmax(n_entries);
   std::vector<uint32_t> rank(n_entries);
@@ -499,6 +541,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     for (auto &x : th) x.join();
   }
 
+  lap("columns + ranks + levels");
   // ---- upload -------------------------------------------------------------------
   IMPG_HIP(hipSetDevice(ix.device));
   std::vector<int32_t> sl(n_seq);
@@ -522,6 +565,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   ix.n_entries = n_entries;
   ix.n_tiles = n_tiles;
   ix.n_targets = n_targets;
+  lap("upload");
   ix.multi_file = multi_file;
   ix.tp_mode = tp != nullptr;
   ix.bind_view(n_seq, order_policy == IMPG_ORDER_SORTED);

@@ -819,7 +819,9 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
                                                       const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
                                                       uint32_t *__restrict__ err_flag, double min_identity,
-                                                      SliceArrays sl, ProjList pl, int xcd_map) {
+                                                      SliceArrays sl, ProjList pl, int xcd_map,
+                                                      const uint32_t *__restrict__ n_pairs_dev) {
+  if (n_pairs_dev) n_pairs = *n_pairs_dev;  // small batches: the count stays on the device, the grid covers an upper bound
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   constexpr bool CIGAR = (MODE & MODE_CIGAR) != 0;
   // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give
@@ -1114,7 +1116,8 @@ __global__ __launch_bounds__(256) void project_tp_kernel(DeviceIndexView v, cons
                                                          const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                          HitArrays h, unsigned long long *__restrict__ accepted,
                                                          uint32_t *__restrict__ err_flag, double min_identity, int use_ident,
-                                                         ProjList pl) {
+                                                         ProjList pl, const uint32_t *__restrict__ n_pairs_dev) {
+  if (n_pairs_dev) n_pairs = *n_pairs_dev;
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);  // one contiguous eighth of the pair list per XCD
   const uint32_t pp = lblock * 256u + threadIdx.x;
@@ -2360,6 +2363,57 @@ __global__ __launch_bounds__(256) void hits_unpack_kernel(const uint4 *__restric
 }
 
 // ---------------------------------------------------------------------------
+// Small batches (the trait's per-call shape: one range, a handful of ranges): the whole Impg::query of the batch is
+// one chain of launches with no host round trip in between -- the pair count stays on the device (single-block
+// scan, projection grid sized for a host-known upper bound) and the results are written straight into
+// host-mapped memory, so the call costs one synchronisation.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void small_scan_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ off,
+                                                          uint32_t *__restrict__ total) {
+  __shared__ uint32_t s[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t v = t < n ? cnt[t] : 0u;
+  s[t] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const uint32_t x = t >= d ? s[t - d] : 0u;
+    __syncthreads();
+    s[t] += x;
+    __syncthreads();
+  }
+  if (t < n) off[t] = s[t] - v;
+  if (t == 1023) *total = s[1023];
+}
+struct SmallHeader {  // first 64 bytes of the mapped result buffer
+  uint32_t n_pairs, err, pad0, pad1;
+  unsigned long long accepted, pad2;
+  uint32_t pad3[8];
+};
+__global__ __launch_bounds__(256) void small_pack_kernel(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ pair_range,
+                                                         const uint32_t *__restrict__ n_pairs_dev, HitArrays h,
+                                                         const uint32_t *__restrict__ err_flag, const unsigned long long *__restrict__ accepted,
+                                                         SmallHeader *__restrict__ hdr, impg_gpu_interval_t *__restrict__ rows,
+                                                         uint32_t *__restrict__ row_range) {
+  const uint32_t np = *n_pairs_dev;
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p == 0) {
+    unsigned long long acc = 0;
+    for (uint32_t k = 0; k < COUNT_SLOTS; k++) acc += accepted[k * COUNT_STRIDE];
+    hdr->n_pairs = np; hdr->err = *err_flag; hdr->accepted = acc;
+  }
+  if (p >= np) return;
+  const uint32_t r = pair_range[p];
+  const FrontierRec f = fr[r];
+  const uint32_t qid = h.qid[p];
+  impg_gpu_interval_t x;
+  x.query_id = qid;
+  const int4 c = qid != HIT_NONE ? h.c[p] : make_int4(0, 0, 0, 0);
+  x.q_first = c.x; x.q_last = c.y; x.target_id = f.target_id; x.t_first = c.z; x.t_last = c.w;
+  rows[p] = x;
+  row_range[p] = f.qidx;
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -2398,6 +2452,15 @@ void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln);
   else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln);
 }
+void launch_small_scan(const uint32_t *cnt, uint32_t n, uint32_t *off, uint32_t *total, hipStream_t s) {
+  small_scan_kernel<<<1, 1024, 0, s>>>(cnt, n, off, total);
+}
+void launch_small_pack(const FrontierRec *fr, const uint32_t *pair_range, const uint32_t *n_pairs_dev, uint32_t pairs_bound, HitArrays h,
+                       const uint32_t *err_flag, const unsigned long long *accepted, void *hdr, impg_gpu_interval_t *rows,
+                       uint32_t *row_range, hipStream_t s) {
+  small_pack_kernel<<<std::max(1u, cdiv(pairs_bound, 256)), 256, 0, s>>>(fr, pair_range, n_pairs_dev, h, err_flag, accepted,
+                                                                         static_cast<SmallHeader *>(hdr), rows, row_range);
+}
 void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, const uint32_t *owner, uint32_t n_seq, uint32_t *key,
                        uint32_t *idx, unsigned long long *hist, hipStream_t s) {
   if (n) route_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, n, world, owner, n_seq, key, idx, hist);
@@ -2418,22 +2481,22 @@ void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, ui
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
-                    ProjList pl, hipStream_t s) {
+                    ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev) {
   if (!n_pairs) return;
   const bool ident = min_identity == min_identity;  // NaN = no filter
   if (v.tp_mode) {  // tracepoint index: every projection is the approximate one
     const uint32_t gt = (cdiv(n_pairs, 256) + 7u) & ~7u;
     if (transitive) project_tp_kernel<true><<<gt, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag,
-                                                               ident ? min_identity : 0.0, ident ? 1 : 0, pl);
+                                                               ident ? min_identity : 0.0, ident ? 1 : 0, pl, n_pairs_dev);
     else project_tp_kernel<false><<<gt, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag,
-                                                     ident ? min_identity : 0.0, ident ? 1 : 0, pl);
+                                                     ident ? min_identity : 0.0, ident ? 1 : 0, pl, n_pairs_dev);
     return;
   }
   const uint32_t g = (cdiv(n_pairs, 256) + 7u) & ~7u;  // a multiple of the 8 XCDs (see the block mapping in the kernel)
   const int xcd_map = 1;
   const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};
   const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0);
-#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map)
+#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map, n_pairs_dev)
   if (transitive) {
     switch (mode) { case 0: IMPG_LAUNCH(true, 0); break; case 1: IMPG_LAUNCH(true, 1); break;
                     case 2: IMPG_LAUNCH(true, 2); break; default: IMPG_LAUNCH(true, 3); }

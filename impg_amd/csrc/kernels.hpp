@@ -82,7 +82,14 @@ size_t scan_scratch_bytes(uint32_t n);
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
-                    ProjList pl, hipStream_t s);
+                    ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev = nullptr);
+// small batches (engine.cpp: run_small): n <= 1024 counts scanned by one block, total left on the device; results
+// packed behind a 64-byte header {n_pairs, err, -, -, accepted} into (host-mapped) memory
+constexpr uint32_t SMALL_HEADER_BYTES = 64;
+void launch_small_scan(const uint32_t *cnt, uint32_t n, uint32_t *off, uint32_t *total, hipStream_t s);
+void launch_small_pack(const FrontierRec *fr, const uint32_t *pair_range, const uint32_t *n_pairs_dev, uint32_t pairs_bound, HitArrays h,
+                       const uint32_t *err_flag, const unsigned long long *accepted, void *hdr, impg_gpu_interval_t *rows,
+                       uint32_t *row_range, hipStream_t s);
 void launch_slice_counts(HitArrays h, SliceArrays sl, uint32_t n_pairs, uint32_t *cnt, hipStream_t s);
 void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, HitArrays h, SliceArrays sl, uint32_t n_pairs,
                         const uint32_t *off, uint32_t *out, hipStream_t s);

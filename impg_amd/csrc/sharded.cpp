@@ -428,6 +428,7 @@ void rank_query(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, co
     }
     std::vector<std::unique_ptr<LevelBufs>> levels;
     DevBuf self_dev;
+    self_dev.pool = &E.level_pool;
     const auto c0 = std::chrono::steady_clock::now();
     {
       std::unique_lock<std::mutex> turn(ix.shard->gpu_turn, std::defer_lock);

@@ -2,7 +2,7 @@
 // merge_query_adjusted_intervals (src/main.rs:12474-12560), as output_results_bed (src/main.rs:11849-11892) runs
 // them for every query range -- but for all ranges of a chunk at once and on the hit slots where they lie, so that
 // only merged rows cross PCIe.  bed.cpp holds the host-side implementation of the same two merges (one range at a
-// time, for impg_gpu_results_bed / impg_gpu_bed_merge); the parity tests compare both with the oracle.
+// time, for impg_gpu_results_bed / impg_gpu_bed_merge); the parity tests compare both with the CPU restatement of the reference.
 //
 //   rows      every emitted result of the chunk (self intervals, then level by level in slot order), numbered in
 //             that order: within one range this is the reference's emission order, which all tie rules refer to

@@ -47,6 +47,11 @@ struct Expander {
 };
 
 struct Engine {
+  // The pools come first, so they die last: buffers of every kind end up owning pooled blocks (the slot arrays are
+  // swapped with scratch buffers by the MultiImpg sort, the DFS stacks with per-round buffers) and hand them back
+  // when they are destroyed.
+  BufPool table_pool;  // blocks of the visited tables (new at every level of every chunk)
+  BufPool level_pool;  // blocks of the levels kept for a full-results call, and of the DFS driver's per-round buffers
   hipStream_t stream = nullptr;
   DevBuf counters;          // 8 x u64: [2] error flag, [3] scan total
   DevBuf acc_slots, act_slots;  // striped counters: accepted projections, keyed hits
@@ -63,8 +68,6 @@ struct Engine {
       old_idx, cap, pcap, poff, pieces, n_pieces, foff, frontier_a, frontier_b, self_scratch, ranges_dev, stat_count,
       stat_cksum, stage_off;
   LevelBufs level_scratch;
-  BufPool table_pool;  // declared before `tables`: the tables hand their blocks back when they die
-  BufPool level_pool;  // blocks of the levels kept for a full-results call, and of the DFS driver's per-round buffers
   std::vector<std::unique_ptr<VisitedStore>> tables;
   uint64_t last_projected = 0;
   uint64_t pair_budget = 1ull << 28;  // candidate pairs per level kept in HBM at once

@@ -212,10 +212,10 @@ __global__ __launch_bounds__(256) void axis_run_heads_kernel(Rows R, const uint3
   }
   run_head[k] = head ? 1u : 0u;
 }
-struct BedRow {  // what crosses PCIe: 16 bytes per merged row
-  uint32_t q, query_id;
-  int32_t start;
-  uint32_t end_strand;  // end << 1 | reverse strand
+struct BedRow {  // a merged row, 16 bytes
+  uint32_t q_strand;  // range index | reverse strand << 31
+  uint32_t query_id;
+  int32_t start, end;  // (printed as u32, like the reference: an inconsistent CIGAR can project below zero)
 };
 // one thread per sorted row; run r = run_id[k] (exclusive scan of the heads + own flag - 1)
 __global__ __launch_bounds__(256) void axis_emit_kernel(Rows R, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ run_head,
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void axis_emit_kernel(Rows R, const uint32_t *
   const int32_t ns = min(c.x, c.y), ne = max(c.x, c.y);
   const bool tail = k + 1 == n || run_head[k + 1] != 0;
   if (run_head[k]) {
-    out[run].q = R.q[i];
+    out[run].q_strand = R.q[i];
     out[run].query_id = R.qid[i];
     out[run].start = ns;
     atomicMax(&strand_key[run], (1u << 1) | (f ? 0u : 1u));  // position 0 of the run: the fallback strand
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void axis_emit_kernel(Rows R, const uint32_t *
     // (a run that is a single row ends where the row ends: with a negative distance every row is its own run and the
     // prefix maximum, which runs over the whole segment, is not the row's end)
     const int32_t ce = run_head[k] ? ne : (int32_t)((uint32_t)(pmax[k] & 0xFFFFFFFFull) ^ 0x80000000u);
-    out[run].end_strand = (uint32_t)ce << 1;  // strand filled in by axis_strand_kernel
+    out[run].end = ce;  // (the strand is filled in by axis_strand_kernel)
   }
 }
 __global__ __launch_bounds__(256) void head_pos_kernel(const uint32_t *__restrict__ run_head, uint32_t n, uint32_t *__restrict__ v) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void head_pos_kernel(const uint32_t *__restric
 }
 __global__ __launch_bounds__(256) void axis_strand_kernel(BedRow *__restrict__ out, const uint32_t *__restrict__ strand_key, uint32_t n_runs) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-  if (r < n_runs) out[r].end_strand |= strand_key[r] & 1u;
+  if (r < n_runs) out[r].q_strand |= (strand_key[r] & 1u) << 31;
 }
 
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void text_len_kernel(const BedRow *__restrict_
   const bool named = x.query_id < t.n_names;
   const uint32_t sh = named ? t.shift[x.query_id] : 0u;
   const uint32_t nl = named ? t.name_off[x.query_id + 1] - t.name_off[x.query_id] : dec_digits(x.query_id);
-  len[r] = nl + dec_digits((uint32_t)x.start + sh) + dec_digits((x.end_strand >> 1) + sh) + (t.rname_off[x.q + 1] - t.rname_off[x.q]) + 8u;
+  const uint32_t q = x.q_strand & 0x7FFFFFFFu;
+  len[r] = nl + dec_digits((uint32_t)x.start + sh) + dec_digits((uint32_t)x.end + sh) + (t.rname_off[q + 1] - t.rname_off[q]) + 8u;
 }
 __global__ __launch_bounds__(256) void text_write_kernel(const BedRow *__restrict__ rows, uint32_t n, TextTables t,
                                                          const unsigned long long *__restrict__ off, unsigned long long base, char *__restrict__ out) {
@@ -314,17 +315,18 @@ __global__ __launch_bounds__(256) void text_write_kernel(const BedRow *__restric
     p += nl;
   } else p = put_dec(p, x.query_id, dec_digits(x.query_id));
   *p++ = '\t';
-  const uint32_t a = (uint32_t)x.start + sh, b = (x.end_strand >> 1) + sh;
+  const uint32_t a = (uint32_t)x.start + sh, b = (uint32_t)x.end + sh;
+  const uint32_t q = x.q_strand & 0x7FFFFFFFu;
   p = put_dec(p, a, dec_digits(a));
   *p++ = '\t';
   p = put_dec(p, b, dec_digits(b));
   *p++ = '\t';
-  const char *rn = t.rnames + t.rname_off[x.q];
-  const uint32_t rl = t.rname_off[x.q + 1] - t.rname_off[x.q];
+  const char *rn = t.rnames + t.rname_off[q];
+  const uint32_t rl = t.rname_off[q + 1] - t.rname_off[q];
   for (uint32_t k = 0; k < rl; k++) p[k] = rn[k];
   p += rl;
   *p++ = '\t'; *p++ = '.'; *p++ = '\t';
-  *p++ = (x.end_strand & 1u) ? '-' : '+';
+  *p++ = (x.q_strand >> 31) ? '-' : '+';
   *p++ = '\n';
 }
 

@@ -22,6 +22,7 @@
 // The north-star text says "allgatherv of the frontier"; all-to-all-v moves 1/world of that volume over the
 // point-to-point xGMI links, and is what is built (the all-gather carries the counts).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <exception>
 #include <numeric>
@@ -417,6 +418,7 @@ void rank_query(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, co
   std::vector<std::unique_ptr<impg_gpu_results>> parts((n + chunk - 1) / chunk + 1);
   std::vector<Engine *> prepared;
   std::mutex pm;
+  std::atomic<uint64_t> served{0};  // projections done here for other ranks' records during chunks this rank had no ranges for
   run_lanes(ix, n, [&](size_t, Engine &E, size_t b, size_t e) {
     {
       std::lock_guard<std::mutex> lk(pm);
@@ -436,7 +438,7 @@ void rank_query(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, co
       E.run(ix, d_ranges.as<impg_gpu_range_t>() + b, (uint32_t)(e - b), p, &levels, nullptr, nullptr, nullptr, &self_dev);
     }
     const auto c1 = std::chrono::steady_clock::now();
-    if (e == b) return;  // an empty chunk: this rank only took part in the hops
+    if (e == b) { served += E.last_projected; return; }  // an empty chunk: this rank only took part in the hops
     auto part = std::make_unique<impg_gpu_results>();
     assemble_results(E, ranges + b, (uint32_t)(e - b), p, levels, self_dev, *part);
     part->run_s = std::chrono::duration<double>(c1 - c0).count();
@@ -446,6 +448,7 @@ void rank_query(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, co
   res.offsets.assign(1, 0);
   for (auto &pt : parts)
     if (pt) append_results(res, *pt);
+  res.projected += served.load();
   res.ranges.assign(ranges, ranges + n);
 }
 

@@ -37,12 +37,11 @@ while time.time() < t_end:
         paths.append(p)
     bidir = bool(rng.random() < 0.8)
     order = impg_amd.ORDER_COITREES if rng.random() < 0.8 else impg_amd.ORDER_SORTED
-    g = impg_amd.GpuImpg.from_paf(paths, bidirectional=bidir, order=order)
-    if order == impg_amd.ORDER_SORTED:
-        for p in paths:
-            os.remove(p)
-        seed += 1
-        continue  # (the oracle only restates the coitrees order; the sorted policy has its own test)
+    # one GPU, or the index sharded over 2..4 ranks that share the GPU (the multi handle: same entry points)
+    world = int(rng.choice([1, 1, 2, 3, 4]))
+    devs = None if world == 1 else [0] * world
+    g = impg_amd.GpuImpg.from_paf(paths, bidirectional=bidir, order=order, devices=devs, lanes=int(rng.integers(1, 3)))
+    o.set_sorted_visits(order == impg_amd.ORDER_SORTED)  # both order policies have an exact checker
     c = o.OracleIndex(paf_paths=paths, bidirectional=bidir, preparse=True)
     g.set_option("locality_min", int(rng.choice([0, 1, 4096])))
     if rng.random() < 0.3:
@@ -66,7 +65,9 @@ while time.time() < t_end:
         kw["min_identity"] = float(rng.choice([0.3, 0.7, 0.95]))
     if rng.random() < 0.25:
         kw["multi_impg"] = True
-    cigar = bool(rng.random() < 0.5)
+    cigar = bool(rng.random() < 0.5) and world == 1  # (CIGAR slices stay with their owner on a sharded index)
+    if rng.random() < 0.3:
+        kw["consider_strandness"] = True
     mask = None
     if kw.get("transitive") and rng.random() < 0.35:  # masked_regions: one map for the batch
         mask = {}
@@ -93,7 +94,7 @@ while time.time() < t_end:
         assert res[i].tolist() == want.tolist(), ("rows", seed, i, (t, s, e), kw, mask)
         total += c.last_projection_count()
         n_rows += len(want)
-    assert res.projected == total, ("projected", seed, kw)
+    assert res.projected == total, ("projected", seed, kw, world, res.projected, total)
     # text outputs on the ranges long enough for perform_query's validation
     mtl = kw.get("min_transitive_len", 101)
     ok = [i for i, (t, s, e) in enumerate(ranges) if e - s >= mtl]
@@ -114,8 +115,16 @@ while time.time() < t_end:
             r2 = g.query_batch(sub, params)
             want = "".join(c.query_bed(g.seq_name(t), s, e, range_name=names[k], merge_distance=d, **kw) for k, (t, s, e) in enumerate(sub))
             assert r2.bed(names, merge_distance=d, params=params) == want, ("bed", seed, d, kw)
+            if world == 1:  # both merges + the text on the device
+                got_dev = g.query_batch_bed(sub, params, merge_distance=d, range_names=names)
+                if got_dev != want:
+                    a, b = got_dev.splitlines(), want.splitlines()
+                    k = next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), min(len(a), len(b)))
+                    print("device bed differs at line", k, "of", len(a), len(b), "\n got ", a[max(0, k - 2):k + 3], "\n want", b[max(0, k - 2):k + 3])
+                assert got_dev == want, ("device bed", seed, d, kw)
     n_cases += 1
     for p in paths:
         os.remove(p)
     seed += 1
+o.set_sorted_visits(False)
 print("fuzz ok: %d cases, %d result rows compared, seeds up to %d" % (n_cases, n_rows, seed - 1))

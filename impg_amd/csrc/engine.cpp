@@ -178,18 +178,18 @@ const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec
 }
 // After the count pass: offp[r] = first place of range r's pairs in that order, and room for slot_of[P].
 void Engine::projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
-                                ProjList &pl) {
+                                ProjList &pl, bool lists) {
   d_offp = nullptr;
   pl = ProjList{nullptr, nullptr, nullptr};
   if (!d_perm || !P) return;
   const size_t nb = (size_t)n_fr * 4;
   lo_cnt.reserve(nb); lo_off.reserve(nb); lo_offp.reserve(nb);
   const size_t pb = std::max<size_t>(P * 4, 256);
-  slot_of.reserve(pb); proj_range.reserve(pb); proj_entry.reserve(pb);
+  if (lists) { slot_of.reserve(pb); proj_range.reserve(pb); proj_entry.reserve(pb); }
   launch_gather_u32(d_cnt, d_perm, n_fr, lo_cnt.as<uint32_t>(), stream);
   scan(lo_cnt.as<uint32_t>(), lo_off.as<uint32_t>(), n_fr);
   launch_scatter_u32(lo_off.as<uint32_t>(), d_perm, n_fr, lo_offp.as<uint32_t>(), stream);
-  pl = ProjList{slot_of.as<uint32_t>(), proj_range.as<uint32_t>(), proj_entry.as<uint32_t>()};
+  if (lists) pl = ProjList{slot_of.as<uint32_t>(), proj_range.as<uint32_t>(), proj_entry.as<uint32_t>()};
   d_offp = lo_offp.as<uint32_t>();
 }
 
@@ -218,12 +218,21 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
   const uint32_t *d_offp = nullptr;
   ProjList pl;
-  projection_offsets(d_perm, n_fr, cnt.as<uint32_t>(), P, d_offp, pl);
+  const bool slots_in_projection_order = free_slot_order && !raw && !multi && !store_cigar && d_perm && P;
+  projection_offsets(d_perm, n_fr, cnt.as<uint32_t>(), P, d_offp, pl, !slots_in_projection_order);
+  if (slots_in_projection_order) {
+    // slot = place: range r's run starts at offp[r]; lanes follow the lookup order, so a wave's runs are one
+    // contiguous piece of both lists (coalesced), and there is no slot list at all
+    launch_lookup_emit(v, fr, n_fr, transitive, d_offp, win.as<uint4>(), L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(),
+                       d_perm, nullptr, ProjList{nullptr, nullptr, nullptr}, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
+    pl = ProjList{nullptr, nullptr, nullptr};
+  } else {
   // the slot-order entry list is only read by the slice materialisation and the five-key sort
   const bool entry_slots = store_cigar || multi || !pl.slot;
   launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                      entry_slots ? pair_entry.as<uint32_t>() : nullptr, pl.slot ? d_perm : nullptr, d_offp, pl,
                      wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
+  }
   IMPG_HIP(hipEventRecord(e1, stream));
   HitArrays h = hit_arrays(L, L.n_pairs);
   SliceArrays sl{nullptr, nullptr, nullptr, nullptr};
@@ -480,6 +489,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   if (store_cigar && ix.tp_mode)
     throw Error{IMPG_E_UNSUPPORTED, "store_cigar is not offered on a tracepoint index (the approximate mode has no CIGAR to slice)"};
   multi = p.multi_impg != 0;
+  free_slot_order = keep == nullptr && free_slots_allowed;
   const DeviceIndexView &v = ix.view;
   cur_ranges = d_ranges;
   ev_next = 0;

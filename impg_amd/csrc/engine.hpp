@@ -76,6 +76,13 @@ struct Engine {
   double min_identity = __builtin_nan("");  // of the batch / stage call in flight
   bool store_cigar = false;
   bool multi = false;       // MultiImpg semantics for the batch in flight (params.multi_impg)
+  // Counting runs (no level is kept): nobody reads the slots by position -- the visited update only needs the hits of
+  // one query in frontier order x visit order, and the lookup order preserves exactly that (its key is monotone in
+  // (target, start), the order of a query's frontier; ties keep frontier order).  The slots are then laid out in
+  // projection order: the emit pass writes two coalesced lists instead of four arrays, and the projection kernel
+  // reads and writes them at its own index.
+  bool free_slot_order = false;
+  bool free_slots_allowed = true;  // option "free_slot_order" (A/B runs)
   DevBuf m_dest, m_qid, m_coords, m_pe, m_sa, m_sn, m_so, m_sr;  // 5-key sort: destination + double buffers
   // projection order (locality): ranges sorted by window position, their slots listed in that order
   DevBuf wide_n, wide_list;  // ranges whose window is wider than the lane-per-range emit pass takes
@@ -93,7 +100,7 @@ struct Engine {
   // when not worth it); projection_offsets() after the scan gives every range's first place in slot_of
   const uint32_t *lookup_order(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr);
   void projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
-                          ProjList &pl);
+                          ProjList &pl, bool lists = true);
   DevBuf proj_range, proj_entry;  // the pairs' ranges / entries in projection order (next to slot_of)
   // raw: the owner side of a sharded hop -- slots as projected; the subset filter and the MultiImpg sort run at home
   uint64_t expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,

@@ -1240,8 +1240,8 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-// Slots are in frontier order and every frontier is sorted by query, so the slots of one query are one run:
-// a whole wave, usually a whole block, adds to the same two words.  The wave sums first (a tiling batch at
+// Slots in the reference's order follow the frontier, which is sorted by query, so the slots of one query are one
+// run: a whole wave, usually a whole block, adds to the same two words.  The wave sums first (a tiling batch at
 // depth 5 has 10^7 hits per query: one atomic per hit on one address ran at ~90 atomics/us, 95 % of the batch).
 __global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__restrict__ fr,
                                                         const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
@@ -1275,11 +1275,24 @@ __global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__res
   const uint32_t q0 = live ? (uint32_t)__shfl((int)qx, __ffsll((long long)live) - 1) : 0xFFFFFFFFu;
   const bool uniform = __all(qx == q0 || qx == 0xFFFFFFFFu);
   if (!uniform) {
-    if (c) {
-      if (count) atomicAdd(&count[qx], 1ull);
+    // several queries in the wave (slots in projection order interleave them, one range's run at a time): a
+    // segmented scan over the runs of equal query, one pair of atomics per run
+    const unsigned lane = lane_id();
+    const uint32_t prev = (uint32_t)__shfl_up((int)qx, 1);
+    const unsigned long long heads = __ballot(lane == 0 || prev != qx);
+    const unsigned first = 63u - (unsigned)__clzll((long long)(heads & (lanemask_lt() | (1ull << lane))));
+#pragma unroll
+    for (unsigned o = 1; o < 64; o <<= 1) {
+      const unsigned long long cv = (unsigned long long)__shfl_up((long long)c, o);
+      const unsigned long long av = (unsigned long long)__shfl_up((long long)a, o);
+      if (lane >= first + o) { c += cv; a += av; }
+    }
+    const bool tail = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
+    if (tail && c && qx != 0xFFFFFFFFu) {
+      if (count) atomicAdd(&count[qx], c);
       if (cksum) atomicAdd(&cksum[qx], a);
     }
-    if (lane_id() == 0) s_q[threadIdx.x >> 6] = 0xFFFFFFFFu;
+    if (lane == 0) s_q[threadIdx.x >> 6] = 0xFFFFFFFFu;
   } else {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -1079,3 +1079,31 @@ def test_device_bed_merge_chains_and_worst_case(tmp_path):
     for d in (0, 49, 50, 51, 5000):
         _bed_three_ways(g, c, ranges, None, d)
         _bed_three_ways(g, c, ranges, None, d, consider_strandness=True)
+
+
+def test_counting_runs_with_slots_in_projection_order(tmp_path):
+    """A counting run (nothing kept) under the lookup order lays its hit slots out in projection order, not the
+    reference's: per-range counts and checksums must equal those of the full results -- which keep the
+    reference's slot order -- at every depth, BFS and DFS, whichever way the option is set."""
+    from tests.test_gpu_fullsize import checksum
+    for seed, kwp in [(211, dict(n_seq=6, seq_len=20000, weird=True, self_aln=True)), (212, dict(n_seq=60, seq_len=4000, self_aln=True))]:
+        text, names = random_paf(seed, 900, **kwp)
+        g, c = both(tmp_path, text)
+        ranges = random_ranges(seed + 1, 200, kwp["n_seq"], kwp["seq_len"], max_len=kwp["seq_len"] // 5, min_len=40)
+        for kw in [dict(), dict(transitive=True, max_depth=4, min_transitive_len=20, min_distance_between_ranges=0),
+                   dict(transitive=True, max_depth=0, min_transitive_len=30),
+                   dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=20),
+                   dict(transitive=True, max_depth=3, min_identity=0.7)]:
+            p = impg_amd.make_params(**kw)
+            g.set_option("locality_min", 4096)
+            res = g.query_batch(ranges, p)
+            want_cnt = [len(res[i]) - 1 for i in range(len(ranges))]
+            want_ck = [checksum(res[i][1:]) for i in range(len(ranges))]
+            for lm, free in [(1, 1), (1, 0), (0, 1)]:
+                g.set_option("locality_min", lm)
+                g.set_option("free_slot_order", free)
+                st, cnt, ck = g.query_batch_stats(ranges, p)
+                assert st.projected == res.projected
+                assert cnt.tolist() == want_cnt, (seed, kw, lm, free)
+                assert [int(x) for x in ck] == want_ck, (seed, kw, lm, free)
+        g.set_option("free_slot_order", 1)

@@ -178,18 +178,18 @@ const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec
 }
 // After the count pass: offp[r] = first place of range r's pairs in that order, and room for slot_of[P].
 void Engine::projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
-                                ProjList &pl, bool lists) {
+                                ProjList &pl) {
   d_offp = nullptr;
   pl = ProjList{nullptr, nullptr, nullptr};
   if (!d_perm || !P) return;
   const size_t nb = (size_t)n_fr * 4;
   lo_cnt.reserve(nb); lo_off.reserve(nb); lo_offp.reserve(nb);
   const size_t pb = std::max<size_t>(P * 4, 256);
-  if (lists) { slot_of.reserve(pb); proj_range.reserve(pb); proj_entry.reserve(pb); }
+  slot_of.reserve(pb); proj_range.reserve(pb); proj_entry.reserve(pb);
   launch_gather_u32(d_cnt, d_perm, n_fr, lo_cnt.as<uint32_t>(), stream);
   scan(lo_cnt.as<uint32_t>(), lo_off.as<uint32_t>(), n_fr);
   launch_scatter_u32(lo_off.as<uint32_t>(), d_perm, n_fr, lo_offp.as<uint32_t>(), stream);
-  if (lists) pl = ProjList{slot_of.as<uint32_t>(), proj_range.as<uint32_t>(), proj_entry.as<uint32_t>()};
+  pl = ProjList{slot_of.as<uint32_t>(), proj_range.as<uint32_t>(), proj_entry.as<uint32_t>()};
   d_offp = lo_offp.as<uint32_t>();
 }
 
@@ -206,8 +206,12 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   wide_n.reserve(256);
   wide_list.reserve(std::max<size_t>((size_t)n_fr * 4, 256));
   const uint32_t *d_perm = lookup_order(v, fr, n_fr);
+  // Counting runs under the lookup order (see free_slot_order): slot = place in that order.  The count pass leaves
+  // its counts and windows at the lanes' places, one scan gives the run offsets and the total, and the emit pass
+  // writes the two pair lists as one contiguous piece per wave -- no per-range scatter, no slot list.
+  const bool by_place = free_slot_order && !raw && !multi && !store_cigar && d_perm;
   launch_lookup_count(v, fr, n_fr, transitive, d_perm, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(),
-                      wide_list.as<uint32_t>(), stream);
+                      wide_list.as<uint32_t>(), stream, by_place);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);
   if (P > pair_budget || P >= 0xFFFFFFF0ull) {
     if (split_ok) throw SplitBatch{};
@@ -216,22 +220,18 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   L.n_pairs = (uint32_t)P;
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
-  const uint32_t *d_offp = nullptr;
-  ProjList pl;
-  const bool slots_in_projection_order = free_slot_order && !raw && !multi && !store_cigar && d_perm && P;
-  projection_offsets(d_perm, n_fr, cnt.as<uint32_t>(), P, d_offp, pl, !slots_in_projection_order);
-  if (slots_in_projection_order) {
-    // slot = place: range r's run starts at offp[r]; lanes follow the lookup order, so a wave's runs are one
-    // contiguous piece of both lists (coalesced), and there is no slot list at all
-    launch_lookup_emit(v, fr, n_fr, transitive, d_offp, win.as<uint4>(), L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(),
-                       d_perm, nullptr, ProjList{nullptr, nullptr, nullptr}, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
-    pl = ProjList{nullptr, nullptr, nullptr};
+  ProjList pl{nullptr, nullptr, nullptr};
+  if (by_place) {
+    launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
+                       pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true);
   } else {
-  // the slot-order entry list is only read by the slice materialisation and the five-key sort
-  const bool entry_slots = store_cigar || multi || !pl.slot;
-  launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
-                     entry_slots ? pair_entry.as<uint32_t>() : nullptr, pl.slot ? d_perm : nullptr, d_offp, pl,
-                     wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
+    const uint32_t *d_offp = nullptr;
+    projection_offsets(d_perm, n_fr, cnt.as<uint32_t>(), P, d_offp, pl);
+    // the slot-order entry list is only read by the slice materialisation and the five-key sort
+    const bool entry_slots = store_cigar || multi || !pl.slot;
+    launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
+                       entry_slots ? pair_entry.as<uint32_t>() : nullptr, pl.slot ? d_perm : nullptr, d_offp, pl,
+                       wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
   }
   IMPG_HIP(hipEventRecord(e1, stream));
   HitArrays h = hit_arrays(L, L.n_pairs);

@@ -100,7 +100,7 @@ struct Engine {
   // when not worth it); projection_offsets() after the scan gives every range's first place in slot_of
   const uint32_t *lookup_order(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr);
   void projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
-                          ProjList &pl, bool lists = true);
+                          ProjList &pl);
   DevBuf proj_range, proj_entry;  // the pairs' ranges / entries in projection order (next to slot_of)
   // raw: the owner side of a sharded hop -- slots as projected; the subset filter and the MultiImpg sort run at home
   uint64_t expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,

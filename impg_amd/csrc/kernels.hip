@@ -85,12 +85,14 @@ __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView 
                                                                 uint32_t n, const uint32_t *__restrict__ perm,
                                                                 uint32_t *__restrict__ cnt,
                                                                 uint4 *__restrict__ win, uint32_t *__restrict__ wide_n,
-                                                                uint32_t *__restrict__ wide_list) {
+                                                                uint32_t *__restrict__ wide_list, int by_place) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   // perm (optional): neighbouring lanes take ranges that are neighbours in the entry array, so
-  // their searches and windows share cache lines; results still land at the range's own index
+  // their searches and windows share cache lines; results still land at the range's own index --
+  // or, by_place, at the lane's place in that order (coalesced; the emit pass then reads them there)
   const uint32_t r = perm ? perm[i] : i;
+  const uint32_t o = by_place ? i : r;
   const FrontierRec f = fr[r];
   uint32_t a = 0, sn = 0, off0 = 0, cnt0 = 0;
   if (f.target_id < v.n_seq) {
@@ -131,10 +133,10 @@ __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView 
       if (hit && bit < 64u) mask |= 1ull << bit;
     }
   }
-  cnt[r] = c;
-  win[r] = make_uint4(lo, ub, (uint32_t)mask, (uint32_t)(mask >> 32));
+  cnt[o] = c;
+  win[o] = make_uint4(lo, ub, (uint32_t)mask, (uint32_t)(mask >> 32));
   // windows too wide for the lane-per-range emit pass (dense targets) are listed for the wave-per-range one
-  if (wide_list && lo < ub && ub - (lo & ~3u) > 64u) wide_list[atomicAdd(wide_n, 1u)] = r;
+  if (wide_list && lo < ub && ub - (lo & ~3u) > 64u) wide_list[atomicAdd(wide_n, 1u)] = o;
 }
 
 // ---------------------------------------------------------------------------
@@ -149,7 +151,9 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
                                                           const uint32_t *__restrict__ offp,
                                                           ProjList pl,
                                                           const uint32_t *__restrict__ list,
-                                                          const uint32_t *__restrict__ list_n) {
+                                                          const uint32_t *__restrict__ list_n,
+                                                          const uint32_t *__restrict__ place_perm) {
+  // place_perm (optional): items, win[] and pair_off[] are indexed by PLACE in the lookup order; the range is place_perm[place]
   // list (optional): process only these ranges -- the ones whose window is wider than
   // lookup_emit_lane_kernel takes, collected by the count pass
   const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
@@ -168,8 +172,9 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
   uint4 w = make_uint4(0, 0, 0, 0);
   uint32_t off = 0, po = 0, rcur = 0;
   if (wave < n_items) {
-    rcur = list ? list[wave] : wave;
-    w = win[rcur]; off = pair_off[rcur]; if (slot_of) po = offp[rcur];
+    const uint32_t item = list ? list[wave] : wave;
+    rcur = place_perm ? place_perm[item] : item;
+    w = win[item]; off = pair_off[item]; if (slot_of) po = offp[rcur];
   }
   for (uint32_t it = wave; it < n_items; it += nwaves) {
     const uint32_t r = rcur;
@@ -177,8 +182,9 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
     uint4 wn = make_uint4(0, 0, 0, 0);
     uint32_t offn = 0, pon = 0;
     if (itn < n_items) {
-      rcur = list ? list[itn] : itn;
-      wn = win[rcur]; offn = pair_off[rcur]; if (slot_of) pon = offp[rcur];
+      const uint32_t item = list ? list[itn] : itn;
+      rcur = place_perm ? place_perm[item] : item;
+      wn = win[item]; offn = pair_off[item]; if (slot_of) pon = offp[rcur];
     }
     const uint32_t lo = w.x, ub = w.y;
     const unsigned long long m0 = ((unsigned long long)w.w << 32) | w.z;  // hits of the first chunk, from the count pass
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v,
                                                               uint32_t *__restrict__ pair_entry,
                                                               const uint32_t *__restrict__ perm,
                                                               const uint32_t *__restrict__ offp,
-                                                              ProjList pl) {
+                                                              ProjList pl, int by_place) {
   uint32_t *const slot_of = pl.slot;
   __shared__ uint16_t stage[EMIT_LDS_SLOTS];
   const unsigned lane = threadIdx.x;
@@ -383,10 +389,11 @@ __global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v,
   if (i < n) {
     r = perm ? perm[i] : i;  // (with the lookup order a wave's 64 ranges are neighbours in the entry array
                              //  and in slot_of, where offp[] are then consecutive)
-    const uint4 w = win[r];
+    const uint32_t o = by_place ? i : r;  // (by_place: the count pass left its results at the lane's place)
+    const uint4 w = win[o];
     lo = w.x; ub = w.y;
     mask = ((unsigned long long)w.w << 32) | w.z;
-    off = pair_off[r];
+    off = pair_off[o];
     if (slot_of) po = offp[r];
   }
   const uint32_t b = lo & ~3u;
@@ -2440,30 +2447,33 @@ static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 wa
 }
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
-                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s) {
+                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place) {
   if (!n) return;
   const bool lanes = emit_by_lanes(v);
+  const int bp = by_place && perm ? 1 : 0;
   if (lanes) IMPG_HIP(hipMemsetAsync(wide_n, 0, 4, s));
-  if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr);
-  else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr);
+  if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp);
+  else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp);
 }
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
                         const uint32_t *perm, const uint32_t *offp, ProjList pl, const uint32_t *wide_n,
-                        const uint32_t *wide_list, hipStream_t s) {
+                        const uint32_t *wide_list, hipStream_t s, bool by_place) {
   if (!n) return;
+  const int bp = by_place && perm ? 1 : 0;
+  const uint32_t *pp = bp ? perm : nullptr;
   // windows of <= 64 entries: lane per range; the rest (dense targets), or everything if a rank could
   // overflow the packed sort key: wave per range
   const bool lanes = emit_by_lanes(v);
   if (lanes) {
-    if (transitive) lookup_emit_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, pl);
-    else lookup_emit_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, pl);
+    if (transitive) lookup_emit_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, pl, bp);
+    else lookup_emit_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, pl, bp);
   }
   // the listed wide windows only (a small grid: the list is normally short or empty), or everything
   const uint32_t g = lanes ? std::min(wave_grid(n), 256u) : wave_grid(n);
   const uint32_t *ln = lanes ? wide_n : nullptr, *ll = lanes ? wide_list : nullptr;
-  if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln);
-  else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln);
+  if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln, pp);
+  else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln, pp);
 }
 void launch_small_scan(const uint32_t *cnt, uint32_t n, uint32_t *off, uint32_t *total, hipStream_t s) {
   small_scan_kernel<<<1, 1024, 0, s>>>(cnt, n, off, total);

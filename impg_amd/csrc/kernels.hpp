@@ -52,7 +52,7 @@ struct VisitedTables {
 constexpr uint32_t VISITED_NONE = 0xFFFFFFFFu, VISITED_MASK = 0xFFFFFFFEu;  // old_tab values that name no table
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
-                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s);
+                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place = false);
 // The pairs listed in projection order (optional: slot == nullptr means the projection runs in slot order):
 // place -> the pair's slot, its frontier range and its entry.
 struct ProjList {
@@ -61,7 +61,7 @@ struct ProjList {
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
                         const uint32_t *perm, const uint32_t *offp, ProjList pl, const uint32_t *wide_n,
-                        const uint32_t *wide_list, hipStream_t s);
+                        const uint32_t *wide_list, hipStream_t s, bool by_place = false);
 constexpr uint32_t ROUTE_WORLD_MAX = 1024;
 void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, const uint32_t *owner, uint32_t n_seq, uint32_t *key,
                        uint32_t *idx, unsigned long long *hist, hipStream_t s);

@@ -1107,3 +1107,21 @@ def test_counting_runs_with_slots_in_projection_order(tmp_path):
                 assert cnt.tolist() == want_cnt, (seed, kw, lm, free)
                 assert [int(x) for x in ck] == want_ck, (seed, kw, lm, free)
         g.set_option("free_slot_order", 1)
+    # dense target: windows wider than 64 entries are listed by place for the wave-per-range emit pass
+    lines = []
+    for i in range(300):
+        lines.append("Q%d\t9000\t%d\t%d\t%s\tT\t9000\t%d\t%d\t10\t10\t60\tcg:Z:%d=" %
+                     (i % 11, 100 + i, 1100 + i, "+-"[i % 2], 2000 + (i * 7) % 900, 3000 + (i * 7) % 900, 1000))
+    g, c = both(tmp_path, "\n".join(lines) + "\n")
+    t = g.seq_id("T")
+    dense = [(t, 2500, 2600), (t, 2000, 4000), (t, 2890, 2910), (g.seq_id("Q3"), 0, 2000)] * 20
+    for kw in [dict(), dict(transitive=True, max_depth=2, min_transitive_len=10)]:
+        p = impg_amd.make_params(**kw)
+        res = g.query_batch(dense, p)
+        for lm, free in [(1, 1), (1, 0)]:
+            g.set_option("locality_min", lm)
+            g.set_option("free_slot_order", free)
+            st, cnt, ck = g.query_batch_stats(dense, p)
+            assert st.projected == res.projected
+            assert cnt.tolist() == [len(res[i]) - 1 for i in range(len(dense))]
+            assert [int(x) for x in ck] == [checksum(res[i][1:]) for i in range(len(dense))]

@@ -32,7 +32,7 @@ struct Error {
 
 // ---- packed CIGAR ops (CigarOp, impg.rs:75-140) ----------------------------
 constexpr uint32_t OP_LEN_MASK = (1u << 29) - 1;
-constexpr uint32_t OP_PAD = 0xFFFFFFFFu;  // tile padding, never a valid op (code 7)
+constexpr uint32_t OP_PAD = 0xE0000000u;  // tile padding, never a valid op: code 7, length 0 (so its deltas are zero without a test)
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 
 // One 128-byte line per tile: a 24-byte header followed by 26 packed ops (words 6..31).

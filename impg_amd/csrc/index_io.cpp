@@ -16,7 +16,7 @@ namespace impg {
 namespace {
 
 constexpr char MAGIC[8] = {'I', 'M', 'P', 'G', 'H', 'B', 'M', '1'};
-constexpr uint32_t VERSION = 2;  // 2: checksum of the arrays behind the end mark
+constexpr uint32_t VERSION = 3;  // 2: checksum of the arrays behind the end mark; 3: tile padding words carry length 0
 
 struct Header {  // fixed-size, little-endian (gfx950 hosts are x86-64)
   char magic[8];

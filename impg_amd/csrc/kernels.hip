@@ -626,7 +626,7 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   const bool valid = op != OP_PAD;
   const uint32_t code = op >> 29;
-  const int32_t len = valid ? (int32_t)(op & OP_LEN_MASK) : 0;
+  const int32_t len = (int32_t)(op & OP_LEN_MASK);  // (a padding word carries length 0)
   const int32_t td = code == c.zt ? 0 : len;  // target_delta (impg.rs:115-121), I<->D swapped for reversed entries
   const int32_t qa = code == c.zq ? 0 : len;  // |query_delta| (impg.rs:123-135)
   const bool arm1 = td == 0;
@@ -635,9 +635,12 @@ __device__ __forceinline__ void op_step(uint32_t op, const PairCtx &c, int32_t &
   const int32_t os = max(T, c.R0);
   const int32_t e = T + td;
   const int32_t oe = min(e, lim);
-  // (bitwise on purpose: with && / ?: the compiler branches around each comparison -- three
-  //  exec-mask save/restore sequences per op; both comparisons are cheaper than one branch)
-  const bool pass = valid & (T <= c.last_tp) & ((arm1 & (T >= c.R0)) | (!arm1 & (os < oe)));
+  // One comparison for the three arms: arm 1 passes iff T >= R0; with T <= last_target_pos <= min(R1, last_tp)
+  // its oe is T, so that reads os <= oe, i.e. os < oe + 1; the other arms pass iff os < oe.  (Spelt with the
+  // arms' own tests, the compiler materialises each as 0/1 and selects between them: eight VALU per op instead
+  // of four; with && / ?: it branches around each comparison.)
+  const int32_t slack = 1 - min(td, 1);  // 1 for arm 1, else 0 (td >= 0)
+  const bool pass = valid & (T <= c.last_tp) & (os < oe + slack);
   const bool first = PART != PART_LAST && (pass & !s.found);
   if (IDENT) {
     const bool is_m = valid && (code == 0u || code == 4u), is_x = valid && code == 1u;
@@ -820,8 +823,13 @@ __device__ __forceinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uin
 // MODE & MODE_CIGAR: also record which ops form the projected CIGAR slice
 // (store_cigar); such launches walk tiles A..B literally -- BEDPE/PAF output is
 // not the throughput path.
+#ifdef IMPG_PROJECT_WAVES  // (experiments: force the register allocation that gives this many waves per SIMD)
+#define PROJECT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(IMPG_PROJECT_WAVES, IMPG_PROJECT_WAVES)))
+#else
+#define PROJECT_OCCUPANCY
+#endif
 template <bool TRANSITIVE, int MODE>
-__global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
+__global__ __launch_bounds__(256) PROJECT_OCCUPANCY void project_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
                                                       const uint32_t *__restrict__ pair_range,
                                                       const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
@@ -843,13 +851,19 @@ __global__ __launch_bounds__(256) void project_kernel(DeviceIndexView v, const F
   res.pqs = res.pts = res.pqe = res.pte = -1;
   uint32_t qid = HIT_NONE;
   if (pp < n_pairs) {
-    const uint32_t p = pl.slot ? pl.slot[pp] : pp;
     // (in projection order the pair's range and entry are listed next to its slot: three coalesced reads)
-    const uint32_t r = pl.slot ? pl.range[pp] : pair_range[p];
-    const FrontierRec f = fr[r];
-    // the 64-byte entry: coordinates, record totals and its inline checkpoints
-    const uint4 *ep = reinterpret_cast<const uint4 *>(v.entries + (pl.slot ? pl.entry[pp] : pair_entry[p]));
-    const uint4 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
+    uint32_t p = pp, r, eidx;
+    if (pl.slot) { p = pl.slot[pp]; r = pl.range[pp]; eidx = pl.entry[pp]; }
+    else { r = pair_range[pp]; eidx = pair_entry[pp]; }
+    // Two round trips, not four: both indices are requested together, then the frontier record and the 64-byte
+    // entry (coordinates, record totals, inline checkpoints) together.  The empty asm statements pin that order --
+    // left alone, the compiler sinks the range index and the frontier record below the entry's "has ops" test
+    // and every pair pays their latencies one after the other.
+    asm volatile("" : "+v"(r), "+v"(eidx));
+    const uint4 *ep = reinterpret_cast<const uint4 *>(v.entries + eidx);
+    FrontierRec f = fr[r];
+    uint4 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
+    asm volatile("" : "+v"(f.start), "+v"(f.end), "+v"(e1.z));
     const int32_t en_ts = (int32_t)e0.x, en_te = (int32_t)e0.y, en_qs = (int32_t)e0.z, en_qe = (int32_t)e0.w;
     const uint32_t nops_flags = e1.z;
     const uint32_t n = nops_flags & OP_LEN_MASK;

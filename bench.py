@@ -266,7 +266,7 @@ def main():
     result_out.flush()
 
 
-VALU_CYCLES_PER_WAVE_INST = 2      # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
+VALU_CYCLES_PER_WAVE_INST = 4      # measured: SQ_ACTIVE_INST_VALU (quad-cycles) = SQ_INSTS_VALU on this integer kernel (scripts/make_sq_json.py)
 SIMDS = 256 * 4
 
 
@@ -295,11 +295,12 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches):
             j = json.load(f)
         r["valu_issue_frac"] = j.get("valu_issue_frac")
         r["valu_insts_per_pair"] = j.get("valu_insts_per_pair")
-        r["valu_note"] = "SQ_INSTS_VALU x %d cycles / (GRBM_GUI_ACTIVE x %d SIMDs) of project_kernel, profiles/%s" % (
+        r["valu_note"] = "SQ_ACTIVE_INST_VALU (quad-cycles, = SQ_INSTS_VALU here) x %d clocks / (GRBM_GUI_ACTIVE x %d SIMDs) of project_kernel, profiles/%s" % (
             VALU_CYCLES_PER_WAVE_INST, SIMDS, os.path.basename(sq[-1]))
     r["limiter"] = ("the 856-byte model streams the whole CIGAR; the kernel reads <= 2 tile lines per projection, so "
                     "frac > 1 is accounting, not bandwidth.  Physically HBM is NOT the bound (measured_traffic_frac): the "
-                    "kernel is bound by VALU issue + dependent-load latency (valu_issue_frac)")
+                    "kernel is bound by VALU issue (valu_issue_frac: the SIMDs' vector ALUs are busy that share of the "
+                    "kernel's cycles with the per-op overlap tests and the checkpoint / header arithmetic)")
     return r
 
 

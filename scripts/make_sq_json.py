@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """profiles/<tag>_sq.json from the SQ pass of scripts/profile_r2.sh: the VALU-issue fraction of project_kernel.
-A wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md, wave scheduling), so
-valu_issue_frac = SQ_INSTS_VALU x 2 / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs), counters summed over the kernel's dispatches.
+SQ_ACTIVE_INST_VALU counts, in quad-cycles, the time waves spend executing VALU instructions; on this kernel (32-bit
+integer ops, no packed / MFMA work) it equals SQ_INSTS_VALU to 1 %: one wave64 instruction keeps its SIMD's VALU
+one quad-cycle = 4 clocks (the 2-clock figure of MI355X_MICROARCH.md is the packed / dual-issue rate, which integer
+compare / select / add code does not reach).  So
+valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs), counters summed over the kernel's
+dispatches (SQ_INSTS_VALU x 4 when the pass did not collect SQ_ACTIVE_INST_VALU).
 usage: make_sq_json.py <dir with sq_pmc.csv and sq_bench.json> <out.json>"""
 import csv, json, os, sys
 
@@ -27,8 +31,8 @@ res = {"kernel": "project_kernel", "command": "bench.py " + " ".join(bench.get("
        "valu_insts_per_pair": valu / pairs / 1.0 if pairs else None,  # wave-instructions per pair (x64 lanes / 64 pairs per wave)
        "salu_insts_per_wave": vals.get("SQ_INSTS_SALU", 0.0) / vals["SQ_WAVES"] if vals.get("SQ_WAVES") else None,
        "vmem_insts_per_wave": vals.get("SQ_INSTS_VMEM", 0.0) / vals["SQ_WAVES"] if vals.get("SQ_WAVES") else None,
-       "valu_issue_frac": (valu * 2.0) / (gui * 1024.0) if gui else None,
-       "note": "GRBM_GUI_ACTIVE = kernel cycles (summed over dispatches); 1024 SIMD-32 units; 2 cycles per wave64 VALU instruction "
-               "(64-bit and transcendental ops cost more, so this is a lower bound on VALU-port occupancy)"}
+       "valu_issue_frac": (vals.get("SQ_ACTIVE_INST_VALU", valu) * 4.0) / (gui * 1024.0) if gui else None,
+       "note": "GRBM_GUI_ACTIVE = kernel cycles (summed over dispatches); 1024 SIMDs; SQ_ACTIVE_INST_VALU is in quad-cycles and "
+               "equals SQ_INSTS_VALU here: a wave64 integer VALU instruction occupies its SIMD for 4 clocks"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

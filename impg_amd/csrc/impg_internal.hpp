@@ -61,6 +61,19 @@ IMPG_HD constexpr uint32_t subs_with_ops(uint32_t n_ops_in_tile) {  // sub-tiles
 }
 constexpr uint32_t INLINE_TILES = 8;      // entries of records with <= 8 tiles carry their checkpoints inline
 
+// Prefix line of a tile (array `pfx`, same tile index as the op pool): what the plain projection reads INSTEAD of
+// the ops.  The running sums before every op of the tile, 16 bits per axis, relative to the tile's start:
+//   w0 T0 | wide << 31    wide: a sum of the tile does not fit 16 bits -- no entries, the tile is walked literally
+//   w1 Q0
+//   w2, w3                copies of entries 9 and 18: with the header in one 16-byte read they split the tile in three
+//   w4 + k, k = 0..27     e_k = dT_k | dQ_k << 16: target_delta / |query_delta| sums of the tile's ops before op k
+//                         (k beyond the tile's last op: the tile's own sums)
+// An op's deltas are the differences of neighbouring entries and its arm (impg.rs:2806-2868) follows from which of
+// them is zero, so the first / last overlapping op is found by comparing entries with the range ends.
+constexpr uint32_t PFX_E0 = 4;
+constexpr uint32_t PFX_STEP = 9;
+constexpr uint32_t PFX_ENTRIES = 28;
+
 // ---- device index (HBM layout) ---------------------------------------------
 // One 64-byte payload per index entry, stored in per-target start order.
 struct alignas(16) Entry {
@@ -105,6 +118,7 @@ struct DeviceIndexView {  // passed by value to kernels
   const uint32_t *ops;       // [n_tiles*32] tiles
   const uint32_t *ext_cp;    // effective target prefixes of entries with > 8 tiles
   const uint4 *idp;          // [4*n_tiles] matched bases, mismatched bases, gap ops of the record before each sub-tile
+  const uint32_t *pfx;       // [n_tiles*32] prefix lines (per-op running sums, 16 bits per axis)
   const int32_t *seq_len;    // [n_seq]
   uint32_t n_seq;
   uint32_t n_entries;
@@ -238,10 +252,10 @@ struct impg_gpu_index {
   size_t n_records = 0, n_entries = 0, n_tiles = 0, n_targets = 0;
   std::vector<uint32_t> h_tgt_off;
   std::vector<uint64_t> file_first;  // first record of every alignment file (+ the record count); empty = one file
-  impg::DevBuf d_seg, d_starts, d_ends, d_ends_t, d_pmax, d_starts_lvl, d_pmax_lvl, d_rank, d_mrank, d_entries, d_ops, d_ext_cp, d_idp, d_seq_len;
+  impg::DevBuf d_seg, d_starts, d_ends, d_ends_t, d_pmax, d_starts_lvl, d_pmax_lvl, d_rank, d_mrank, d_entries, d_ops, d_ext_cp, d_idp, d_seq_len, d_pfx;
   impg::DeviceIndexView view{};
   // the device arrays in a fixed order with their content sizes (index_io.cpp writes / reads them back)
-  static constexpr int N_BLOBS = 14;
+  static constexpr int N_BLOBS = 15;
   impg::DevBuf *blob(int k);
   size_t blob_bytes[N_BLOBS] = {};
   bool multi_file = false;

@@ -225,6 +225,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   }
   RawVec<uint32_t> pool(n_tiles * TILE_WORDS);  // (every line is filled by the builder that owns it)
   RawVec<uint4> idp(tp ? 0 : TILE_SUBS * n_tiles);  // per sub-tile: matched / mismatched bases and gap ops before it (identity filter)
+  RawVec<uint32_t> pfx(tp ? 0 : n_tiles * TILE_WORDS);  // prefix lines (impg_internal.hpp)
   if (tp && n_tiles) {  // the tail of the last 128-byte line behind the last boundary
     uint64_t nb_words = 0;
     for (size_t i = 0; i < n_records; i++) if (need[i]) nb_words += ((uint64_t)records[i].cigar_len + 1) * 4;
@@ -279,6 +280,8 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
         uint32_t dt[TILE_SUBS + 1], dq[TILE_SUBS + 1];  // sums before sub-tile s (s = 4: after the tile)
         uint32_t sub = 0;
         const uint32_t cnt = std::min(n - k0, TILE_OPS);
+        uint32_t *pl = pfx.data() + tile * TILE_WORDS;
+        bool pwide = false;
         auto boundary = [&]() {
           dt[sub] = st - t0; dq[sub] = sq - q0;
           if (sub < TILE_SUBS) idp[TILE_SUBS * tile + sub] = make_uint4(sm, sx, sg, 0);
@@ -286,6 +289,8 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
         };
         for (uint32_t u = 0; u < cnt; u++) {
           if (u == sub_first_op(sub)) boundary();
+          if (st - t0 > 0xFFFFu || sq - q0 > 0xFFFFu) pwide = true;
+          pl[PFX_E0 + u] = ((st - t0) & 0xFFFFu) | ((sq - q0) << 16);
           const uint32_t v = src[k0 + u], code = v >> 29, len = v & OP_LEN_MASK;
           if (code > 4) bad_op = true;  // CigarOp::new panics (impg.rs:88)
           line[6 + u] = v;
@@ -296,6 +301,10 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
           else sg += 1;                                 // gap-compressed: one per 'I' / 'D' op
         }
         while (sub <= TILE_SUBS) boundary();  // sub-tiles without ops start (and end) at the tile's end
+        if (st - t0 > 0xFFFFu || sq - q0 > 0xFFFFu) pwide = true;
+        for (uint32_t u = cnt; u < PFX_ENTRIES; u++) pl[PFX_E0 + u] = ((st - t0) & 0xFFFFu) | ((sq - q0) << 16);
+        // (bit 31 is the flag: a sum that large -- no consistent record has one -- reads as wide, and the literal walk takes over)
+        pl[0] = t0 | (pwide ? 1u << 31 : 0u); pl[1] = q0; pl[2] = pl[PFX_E0 + PFX_STEP]; pl[3] = pl[PFX_E0 + 2u * PFX_STEP];
         line[0] = t0; line[1] = q0;
         if (dt[TILE_SUBS] >= TILE_WIDE || dq[TILE_SUBS] >= TILE_WIDE) {
           line[2] = line[3] = line[4] = line[5] = 0xFFFFFFFFu;  // wide tile: no inner splits
@@ -561,6 +570,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   upload(ix, 11, ext_cp, acc);
   upload(ix, 12, idp, acc);
   upload(ix, 13, sl, acc);
+  upload(ix, 14, pfx, acc);
   ix.device_bytes = acc;
   ix.n_entries = n_entries;
   ix.n_tiles = n_tiles;
@@ -575,7 +585,7 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
 
 impg::DevBuf *impg_gpu_index::blob(int k) {
   impg::DevBuf *const b[N_BLOBS] = {&d_seg, &d_starts, &d_ends, &d_ends_t, &d_pmax, &d_starts_lvl, &d_pmax_lvl,
-                                    &d_rank, &d_mrank, &d_entries, &d_ops, &d_ext_cp, &d_idp, &d_seq_len};
+                                    &d_rank, &d_mrank, &d_entries, &d_ops, &d_ext_cp, &d_idp, &d_seq_len, &d_pfx};
   return b[k];
 }
 void impg_gpu_index::bind_view(uint32_t n_seq, uint32_t sorted_order) {
@@ -593,6 +603,7 @@ void impg_gpu_index::bind_view(uint32_t n_seq, uint32_t sorted_order) {
   view.ops = d_ops.as<uint32_t>();
   view.ext_cp = d_ext_cp.as<uint32_t>();
   view.idp = d_idp.as<uint4>();
+  view.pfx = d_pfx.as<uint32_t>();
   view.seq_len = d_seq_len.as<int32_t>();
   view.n_seq = n_seq;
   view.n_entries = (uint32_t)n_entries;

@@ -818,6 +818,112 @@ __device__ __forceinline__ TileScan walk_tiles(const PairCtx &c, uint32_t A, uin
   return s;
 }
 
+// ---------------------------------------------------------------------------
+// Plain projection on the prefix lines (impg_internal.hpp): no op is replayed.
+//
+// In the entry's walking order positions only grow, so with S_k / E_k the target position where op k starts / ends
+//   * the FIRST overlapping op is the first op with E_k >= R0 or the one after it: every op before has
+//     E < R0, which fails all three arms (an insertion sits at E = S < R0; the others end before R0);
+//   * the LAST overlapping op is the last op with S_k <= last_target_pos or the one before it: every op
+//     after starts beyond last_target_pos (impg.rs:2802).
+// Both are located by comparing prefix entries with the range ends, and the candidates are then put through
+// the reference's own per-op test (pfx_eval = op_step on one op, deltas taken from neighbouring entries): a
+// candidate that fails hands over to its neighbour, and if that fails too -- inconsistent CIGARs, empty clipped
+// ranges -- the pair takes the literal walk.  So the result never rests on the search being right, only its speed.
+//
+// In STORAGE order (the order of the line) a reverse-strand reversed entry walks back to front, which turns
+// "first op with E >= x" into "last op with start prefix <= totT - x" and the other way round; "last k with
+// x_k <= t" is "first k with x_{k+1} >= t + 1", so one search serves both: pfx_locate finds the first k of the
+// tile with x_{k+1} >= thr and returns the entries around it, NEXT = the candidate after k (k, k + 1), else the
+// one before it (k, k - 1).
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+struct PfxTile {
+  int32_t bT, bQ;     // T = bT +- x, Qn = bQ +- y (see pfx_eval)
+  uint32_t tsh, qsh;  // bit offsets of the entry's target / query halves (swapped for a reversed entry)
+};
+// exact test of ONE op given the entries before and after it (op_step, arms as there); first-form = what the first
+// overlapping op contributes (query offset, target position), else what the last one does
+__device__ __forceinline__ bool pfx_eval(const PairCtx &c, const PfxTile &t, uint32_t ea, uint32_t eb, bool first_form,
+                                         int32_t &oq, int32_t &ot) {
+  const int32_t xa = (int32_t)__builtin_amdgcn_ubfe(ea, t.tsh, 16u), xb = (int32_t)__builtin_amdgcn_ubfe(eb, t.tsh, 16u);
+  const int32_t ya = (int32_t)__builtin_amdgcn_ubfe(ea, t.qsh, 16u), yb = (int32_t)__builtin_amdgcn_ubfe(eb, t.qsh, 16u);
+  const int32_t td = xb - xa, qa = yb - ya;
+  const int32_t T = c.flip ? t.bT - xb : t.bT + xa;    // back to front: the op starts where the NEXT prefix mirrors to
+  const int32_t Qn = c.flip ? t.bQ - yb : t.bQ + ya;
+  const bool qzero = qa == 0;
+  const int32_t lim = qzero ? c.last_tp : c.R1;
+  const int32_t os = max(T, c.R0);
+  const int32_t oe = min(T + td, lim);
+  const int32_t slack = 1 - min(td, 1);
+  const bool pass = (T <= c.last_tp) & (os < oe + slack);
+  const int32_t fq = Qn + (qzero ? 0 : os - T);
+  const int32_t lq = Qn + (((td == 0) | qzero) ? qa : oe - T);
+  oq = first_form ? fq : lq;
+  ot = first_form ? os : oe;
+  return pass;
+}
+// One end of the projection.  j = storage tile to start in, thr_abs = threshold on the record's storage-order
+// target prefix.  Returns true with (oq, ot) set, or false = take the literal walk.
+template <bool NEXT>
+__device__ __forceinline__ bool pfx_end(const PairCtx &c, const uint32_t *__restrict__ pfx_rec, uint32_t n_ops, uint32_t j,
+                                        int32_t thr_abs, bool first_form, int32_t &oq, int32_t &ot) {
+  for (;;) {
+    const uint32_t *line = pfx_rec + (size_t)j * TILE_WORDS;
+    uint4 h = *reinterpret_cast<const uint4 *>(line);  // T0 | wide << 31, Q0, entry 9, entry 18
+    // (one 16-byte read: without the pin the compiler reads word 0 alone, tests the flag, and only then the rest)
+    asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w));
+    const bool wide = (h.x >> 31) != 0u;
+    const uint32_t cnt = min(TILE_OPS, n_ops - j * TILE_OPS);
+    PfxTile t;
+    t.tsh = c.swp ? 16u : 0u;
+    t.qsh = 16u - t.tsh;
+    const int32_t X0 = (int32_t)(c.swp ? h.y : h.x), Y0 = (int32_t)(c.swp ? h.x : h.y);
+    t.bT = c.flip ? c.ts + (int32_t)c.totT - X0 : c.ts + X0;
+    t.bQ = c.flip ? (int32_t)c.totQ - Y0 : Y0;
+    const int32_t thr = thr_abs - X0;
+    uint32_t s = ((int32_t)__builtin_amdgcn_ubfe(h.z, t.tsh, 16u) < thr ? 1u : 0u) + ((int32_t)__builtin_amdgcn_ubfe(h.w, t.tsh, 16u) < thr ? 1u : 0u);
+    s = min(s, (cnt - 1u) / PFX_STEP);
+    const uint32_t lb = PFX_STEP * s;
+    // twelve entries from e_lb (NEXT) or e_(lb-1): r[i + D] = e_(lb+i).  (4-byte aligned 16-byte loads; the last
+    // words of the tile's last third run into the next line and are never selected)
+    constexpr int D = NEXT ? 0 : 1;
+    const uint32_t *q = line + PFX_E0 + lb - (uint32_t)D;
+    u32x4_u r0 = *reinterpret_cast<const u32x4_u *>(q), r1 = *reinterpret_cast<const u32x4_u *>(q + 4),
+            r2 = *reinterpret_cast<const u32x4_u *>(q + 8);
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2));
+    // m = #{i in 1..8 : x_(lb+i) < thr}: bisection over 1..7, then the eighth; the window r[m..m+2] is selected on the way
+    const uint32_t r[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+    const bool b2 = (int32_t)__builtin_amdgcn_ubfe(r[4 + D], t.tsh, 16u) < thr;
+    const uint32_t uu[6] = {b2 ? r[4] : r[0], b2 ? r[5] : r[1], b2 ? r[6] : r[2], b2 ? r[7] : r[3], b2 ? r[8] : r[4], b2 ? r[9] : r[5]};
+    const bool b1 = (int32_t)__builtin_amdgcn_ubfe(uu[2 + D], t.tsh, 16u) < thr;
+    const uint32_t vv[4] = {b1 ? uu[2] : uu[0], b1 ? uu[3] : uu[1], b1 ? uu[4] : uu[2], b1 ? uu[5] : uu[3]};
+    const bool b0 = (int32_t)__builtin_amdgcn_ubfe(vv[1 + D], t.tsh, 16u) < thr;
+    const bool b3 = (int32_t)__builtin_amdgcn_ubfe(r[8 + D], t.tsh, 16u) < thr;  // (implies the other three)
+    uint32_t w0 = b3 ? r[8] : b0 ? vv[1] : vv[0], w1 = b3 ? r[9] : b0 ? vv[2] : vv[1], w2 = b3 ? r[10] : b0 ? vv[3] : vv[2];
+    uint32_t k = lb + (b3 ? 8u : (b2 ? 4u : 0u) + (b1 ? 2u : 0u) + (b0 ? 1u : 0u));
+    if (wide) return false;  // (tested here so that the window is requested without waiting for the flag)
+    if (k >= cnt) {
+      // NEXT: the threshold lies beyond the tile (inconsistent record): literal walk.  Else every op of the tile starts
+      // at or before the threshold, so the tile's last op is the one looked for
+      if (NEXT) return false;
+      k = cnt - 1u;
+      w0 = line[PFX_E0 + k - 1u]; w1 = line[PFX_E0 + k]; w2 = line[PFX_E0 + k + 1u];
+    }
+    // window: NEXT: e_k, e_(k+1), e_(k+2); else e_(k-1), e_k, e_(k+1)
+    if (pfx_eval(c, t, NEXT ? w0 : w1, NEXT ? w1 : w2, first_form, oq, ot)) return true;
+    if (NEXT) {
+      if (k + 1u < cnt) return pfx_eval(c, t, w1, w2, first_form, oq, ot);
+      if (j + 1u >= c.m) return false;
+      j += 1u;
+    } else {
+      if (k > 0u) return pfx_eval(c, t, w0, w1, first_form, oq, ot);
+      if (j == 0u) return false;
+      j -= 1u;
+    }
+  }
+}
+
 // IDENT: also evaluate calculate_gap_compressed_identity on the projected CIGAR
 // slice (impg.rs:1283-1287, :2952-2973) and drop hits below min_identity.
 // MODE & MODE_CIGAR: also record which ops form the projected CIGAR slice
@@ -903,16 +1009,18 @@ __global__ __launch_bounds__(256) PROJECT_OCCUPANCY void project_kernel(DeviceIn
       //   A = first k with P[k+1] >= R0 - ts        (holds the first op that can overlap)
       //   B = last  k with P[k]   <= last_tp - ts   (holds the last live op)
       const int32_t xa = c.R0 - c.ts, xb = c.last_tp - c.ts;
-      uint32_t cA = 0, cB = 0;  // cA = #{i in [1,m] : P[i] < xa}, cB = #{i in [0,m) : P[i] < xb}
+      // (the plain projection wants the last tile that STARTS at or before last_target_pos: it counts P[i] <= xb)
+      const int32_t xbc = MODE == 0 ? xb + 1 : xb;
+      uint32_t cA = 0, cB = 0;  // cA = #{i in [1,m] : P[i] < xa}, cB = #{i in [0,m) : P[i] < xbc}
       if (c.m <= INLINE_TILES) {
         // the seven inline slots hold P[1..m-1], P[m] = totT, then INT_MAX (index_build.cpp); P[8] is totT when m = 8
         const int32_t P[8] = {(int32_t)e2.y, (int32_t)e2.z, (int32_t)e2.w, (int32_t)e3.x, (int32_t)e3.y, (int32_t)e3.z, (int32_t)e3.w,
                               c.m == INLINE_TILES ? (int32_t)c.totT : 0x7FFFFFFF};
-        cB = 0 < xb ? 1u : 0u;
+        cB = 0 < xbc ? 1u : 0u;
 #pragma unroll
         for (uint32_t i = 0; i < 8; i++) {
           cA += P[i] < xa ? 1u : 0u;
-          cB += P[i] < xb ? 1u : 0u;
+          cB += P[i] < xbc ? 1u : 0u;
         }
         cB = min(cB, c.m);  // (P[m] itself is not a tile start: only an inconsistent CIGAR has totT < xb)
       } else {
@@ -932,7 +1040,7 @@ __global__ __launch_bounds__(256) PROJECT_OCCUPANCY void project_kernel(DeviceIn
             if (pa1 >= xa) ha = a1; else if (pa2 >= xa) { la = a1 + 1; ha = a2; } else if (pa3 >= xa) { la = a2 + 1; ha = a3; } else la = a3 + 1;
           }
           if (gb) {
-            if (pb1 >= xb) hb = b1; else if (pb2 >= xb) { lb = b1 + 1; hb = b2; } else if (pb3 >= xb) { lb = b2 + 1; hb = b3; } else lb = b3 + 1;
+            if (pb1 >= xbc) hb = b1; else if (pb2 >= xbc) { lb = b1 + 1; hb = b2; } else if (pb3 >= xbc) { lb = b2 + 1; hb = b3; } else lb = b3 + 1;
           }
         }
         cA = la - 1;
@@ -961,6 +1069,34 @@ __global__ __launch_bounds__(256) PROJECT_OCCUPANCY void project_kernel(DeviceIn
         if (CIGAR) {
           res = walk_tiles<MODE>(c, orig_tile(c, kA), c.flip ? 0u : c.m - 1u, ia);
           walked = true;
+        } else if (MODE == 0) {
+          // the two ends on the prefix lines (see pfx_end); in storage order a back-to-front entry swaps their roles
+          const uint32_t *pfx_rec = v.pfx + (size_t)e1.y * TILE_WORDS;
+          bool lit = cB == 0u;  // no tile starts at or before last_target_pos: let the literal walk say so
+          const uint32_t kL = cB ? cB - 1u : 0u;  // effective tile of the last op that starts at or before it
+          int32_t fq = 0, ft = c.ts, lq = (int32_t)c.totQ, lt = en_te;  // the shortcuts' answers
+          const bool do_first = !start_cov, do_last = !end_cov;
+          // call 1 looks forward in storage order (k, k + 1): the first end of a front-to-back walk, the last end of a
+          // back-to-front one; call 2 looks backward (k, k - 1)
+          if (!lit && (c.flip ? do_last : do_first)) {
+            int32_t oq, ot;
+            const bool okc = pfx_end<true>(c, pfx_rec, n, orig_tile(c, c.flip ? kL : kA), c.flip ? (int32_t)c.totT - xb : xa, !c.flip, oq, ot);
+            lit = !okc;
+            if (c.flip) { lq = oq; lt = ot; } else { fq = oq; ft = ot; }
+          }
+          if (!lit && (c.flip ? do_first : do_last)) {
+            int32_t oq, ot;
+            const bool okc = pfx_end<false>(c, pfx_rec, n, orig_tile(c, c.flip ? kA : kL), (c.flip ? (int32_t)c.totT - xa : xb) + 1, c.flip, oq, ot);
+            lit = !okc;
+            if (c.flip) { fq = oq; ft = ot; } else { lq = oq; lt = ot; }
+          }
+          if (lit) {
+            res = walk_tiles<MODE>(c, orig_tile(c, kA), c.flip ? 0u : c.m - 1u, ia);
+            walked = true;
+          } else {
+            res.found = true;
+            res.pqs = fq; res.pts = ft; res.pqe = lq; res.pte = lt;
+          }
         } else {
         Cursor cur;
         cur.k = 0xFFFFFFFFu; cur.he = 0; cur.T = 0; cur.Qn = 0;

@@ -297,10 +297,11 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches):
         r["valu_insts_per_pair"] = j.get("valu_insts_per_pair")
         r["valu_note"] = "SQ_ACTIVE_INST_VALU (quad-cycles, = SQ_INSTS_VALU here) x %d clocks / (GRBM_GUI_ACTIVE x %d SIMDs) of project_kernel, profiles/%s" % (
             VALU_CYCLES_PER_WAVE_INST, SIMDS, os.path.basename(sq[-1]))
-    r["limiter"] = ("the 856-byte model streams the whole CIGAR; the kernel reads <= 2 tile lines per projection, so "
-                    "frac > 1 is accounting, not bandwidth.  Physically HBM is NOT the bound (measured_traffic_frac): the "
-                    "kernel is bound by VALU issue (valu_issue_frac: the SIMDs' vector ALUs are busy that share of the "
-                    "kernel's cycles with the per-op overlap tests and the checkpoint / header arithmetic)")
+    r["limiter"] = ("the 856-byte model streams the whole CIGAR; the kernel reads one 64-byte entry and, per end of the projection, "
+                    "a 16-byte header and 48 bytes of 16-bit prefix entries, so frac > 1 is accounting, not bandwidth.  Physically "
+                    "HBM is NOT the bound (measured_traffic_frac) and neither is VALU issue any more (valu_issue_frac): the kernel is "
+                    "bound by the vector-memory pipeline on un-coalesced 16-byte reads, every lane in its own cache line "
+                    "(about 12 per pair; having more of them in flight made it slower, DESIGN.md 5.2 item 13)")
     return r
 
 

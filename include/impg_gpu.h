@@ -186,7 +186,10 @@ size_t impg_gpu_device_bytes(const impg_gpu_index_t *);
  * "chunk_ranges" (initial ranges per chunk, 0 = whole batch), "locality_min"
  * (frontier size from which the projection kernel walks the hit slots in the order
  * of the ranges' windows in the entry array -- a cache-locality order; results
- * are identical either way; 0 = never). */
+ * are identical either way; 0 = never), "free_slot_order" (1, the default: runs
+ * that keep no level -- impg_gpu_query_batch_stats -- lay their hit slots out in
+ * that order too; 0: always the reference's slot order; counts and checksums are
+ * identical either way). */
 int impg_gpu_set_option(impg_gpu_index_t *, const char *key, int64_t value);
 
 /* Visit rank of the sorted positions 0..n-1 of an n-entry target under an order

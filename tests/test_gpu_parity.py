@@ -1125,3 +1125,62 @@ def test_counting_runs_with_slots_in_projection_order(tmp_path):
             assert st.projected == res.projected
             assert cnt.tolist() == [len(res[i]) - 1 for i in range(len(dense))]
             assert [int(x) for x in ck] == [checksum(res[i][1:]) for i in range(len(dense))]
+
+
+def _cigar_spans(cg):
+    """(target span, query span, target offsets of every op boundary) of a CIGAR string."""
+    import re
+    t = q = 0
+    bounds = [0]
+    for n, op in re.findall(r"(\d+)([=XIDM])", cg):
+        n = int(n)
+        if op != "I": t += n
+        if op != "D": q += n
+        bounds.append(t)
+    return t, q, bounds
+
+
+def test_prefix_line_edges(tmp_path):
+    """The plain projection never replays ops: it locates the first / last overlapping op on the tiles' 16-bit
+    prefix lines and verifies the candidates.  Ranges that start and end on, one before and
+    one after EVERY op boundary of multi-tile records -- insertions and deletions sitting exactly on the range ends,
+    candidates across tile borders (26 ops per tile) and across the thirds of a tile, both strands, both entry
+    directions -- must project exactly as the oracle's op-by-op walk does; so must a record whose tiles overflow
+    16 bits (literal walk) and one whose CIGAR disagrees with its PAF coordinates."""
+    unit = "7=2I5=3D1X4=1I6=2D"                      # 9 ops; insertions and deletions between matches
+    cg_a = unit * 9                                   # 81 ops: 4 tiles, borders inside the unit
+    cg_b = ("11=1X" * 13 + "5I" + "9=4D" * 14)        # 55 ops: a tile border between two matches, an insertion at op 26
+    cg_w = "30000=5I20000=7D25000=" + "3=1X" * 20     # the first tile sums to 75 000 on both axes: wide
+    ta, qa, ba = _cigar_spans(cg_a)
+    tb, qb, bb = _cigar_spans(cg_b)
+    tw, qw, _ = _cigar_spans(cg_w)
+    L = 200000
+    lines = []
+    def rec(q, qs, qspan, strand, t, ts, tspan, cg):
+        lines.append("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t1\t1\t60\tcg:Z:%s" % (q, L, qs, qs + qspan, strand, t, L, ts, ts + tspan, cg))
+    rec("Q1", 500, qa, "+", "T", 1000, ta, cg_a)
+    rec("Q2", 700, qa, "-", "T", 1000 + 3, ta, cg_a)
+    rec("Q3", 100, qb, "+", "T", 1200, tb, cg_b)
+    rec("Q4", 900, qb, "-", "T", 1100, tb, cg_b)
+    rec("Q5", 2000, qw, "+", "T", 3000, tw, cg_w)
+    rec("Q6", 2000, qw, "-", "T", 3500, tw, cg_w)
+    rec("Q7", 50, qa, "+", "T", 900, ta + 40, cg_a)  # CIGAR shorter than the PAF target span: no end shortcut, odd tails
+    g, c = both(tmp_path, "\n".join(lines) + "\n")
+    T = g.seq_id("T")
+    pts = sorted({1000 + b + d for b in ba for d in (-1, 0, 1)} | {1200 + b + d for b in bb for d in (-1, 0, 1)} |
+                 {1003 + b for b in ba} | {1100 + b for b in bb})
+    pts = [p for p in pts if p > 0]
+    ranges = []
+    for i, p in enumerate(pts):
+        ranges.append((T, p, p + 1 + (i * 7) % 23))           # starts on / around a boundary
+        ranges.append((T, max(0, p - 1 - (i * 5) % 31), p))   # ends on / around a boundary
+    ranges += [(T, pts[i], pts[j]) for i in range(0, len(pts) - 40, 17) for j in (i + 9, i + 40)]
+    ranges += [(T, 2990, 3010), (T, 32990, 33020), (T, 3000 + 30000, 3000 + 30001), (T, 52000, 54000), (T, 3000, 3000 + tw), (T, 78000, 78100)]
+    # from the query side the reversed entries walk the same records (the reverse-strand ones back to front)
+    for q, qs, qspan in [("Q1", 500, qa), ("Q2", 700, qa), ("Q3", 100, qb), ("Q4", 900, qb)]:
+        qid = g.seq_id(q)
+        for k in range(0, qspan, 3):
+            ranges.append((qid, qs + k, qs + k + 1 + k % 19))
+    for kw in [dict(), dict(transitive=True, max_depth=2, min_transitive_len=1, min_distance_between_ranges=0)]:
+        for lo in range(0, len(ranges), 400):
+            assert_same(g, c, ranges[lo:lo + 400], **kw)

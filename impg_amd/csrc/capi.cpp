@@ -51,6 +51,7 @@ EngineLease::EngineLease(impg_gpu_index &ix_) : ix(ix_) {
   e->chunk_ranges = ix.opt_chunk_ranges;
   e->locality_min = ix.opt_locality_min;
   e->free_slots_allowed = ix.opt_free_slots;
+  e->regroup_pairs = ix.opt_regroup;
 }
 EngineLease::~EngineLease() {
   e->remote = nullptr;
@@ -491,6 +492,8 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
   } else if (k == "locality_min") {  // frontier size from which the projection runs in window order (0 = never)
     if (value < 0 || value >= (1ll << 31)) throw Error{IMPG_E_INVALID, "locality_min out of range"};
     ix->opt_locality_min = (uint32_t)value;
+  } else if (k == "regroup_entries") {  // projection blocks regroup their pairs by entry before reading the index (results identical)
+    ix->opt_regroup = value != 0;
   } else if (k == "free_slot_order") {  // counting runs lay their slots out in projection order (1, default) or keep the reference order (0)
     ix->opt_free_slots = value != 0;
   } else throw Error{IMPG_E_INVALID, "unknown option " + k};

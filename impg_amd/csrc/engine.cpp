@@ -243,7 +243,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   }
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
                  acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity,
-                 store_cigar ? &sl : nullptr, pl, stream);
+                 store_cigar ? &sl : nullptr, pl, stream, nullptr, regroup_pairs);
   if (!raw) {
     post_expand(fr, n_fr, L, pair_off.as<uint32_t>(), pair_entry.as<uint32_t>(), v.mrank, sl);
     h = HitArrays{L.qid.as<uint32_t>(), L.coords.as<int4>()};

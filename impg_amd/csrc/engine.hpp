@@ -83,6 +83,7 @@ struct Engine {
   // reads and writes them at its own index.
   bool free_slot_order = false;
   bool free_slots_allowed = true;  // option "free_slot_order" (A/B runs)
+  bool regroup_pairs = true;       // option "regroup_entries": a projection block sorts its 256 pairs by entry first
   DevBuf m_dest, m_qid, m_coords, m_pe, m_sa, m_sn, m_so, m_sr;  // 5-key sort: destination + double buffers
   // projection order (locality): ranges sorted by window position, their slots listed in that order
   DevBuf wide_n, wide_list;  // ranges whose window is wider than the lane-per-range emit pass takes

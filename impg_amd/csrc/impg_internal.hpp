@@ -271,6 +271,7 @@ struct impg_gpu_index {
   uint64_t opt_pair_budget = 1ull << 28;  // impg_gpu_set_option values, applied to an engine when it is leased
   uint32_t opt_chunk_ranges = 0, opt_locality_min = 4096;
   bool opt_free_slots = true;
+  bool opt_regroup = true;
   impg::ShardCtx *shard = nullptr;    // set: this index is one rank's shard; queries are collective calls
   impg::Cluster *cluster = nullptr;   // set: this handle fronts n_dev shards in this process (no arrays of its own)
   impg_gpu_index();

@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256) PROJECT_OCCUPANCY void project_kernel(DeviceIn
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
                                                       uint32_t *__restrict__ err_flag, double min_identity,
                                                       SliceArrays sl, ProjList pl, int xcd_map,
-                                                      const uint32_t *__restrict__ n_pairs_dev) {
+                                                      const uint32_t *__restrict__ n_pairs_dev, int regroup) {
   if (n_pairs_dev) n_pairs = *n_pairs_dev;  // small batches: the count stays on the device, the grid covers an upper bound
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   constexpr bool CIGAR = (MODE & MODE_CIGAR) != 0;
@@ -956,20 +956,56 @@ __global__ __launch_bounds__(256) PROJECT_OCCUPANCY void project_kernel(DeviceIn
   res.found = res.any = false;
   res.pqs = res.pts = res.pqe = res.pte = -1;
   uint32_t qid = HIT_NONE;
-  if (pp < n_pairs) {
-    // (in projection order the pair's range and entry are listed next to its slot: three coalesced reads)
-    uint32_t p = pp, r, eidx;
+  // (in projection order the pair's range and entry are listed next to its slot: three coalesced reads)
+  bool live = pp < n_pairs;
+  uint32_t p = pp, r = 0, eidx = 0xFFFFFFFFu;
+  int32_t f_start = 0, f_end = 0;
+  if (live) {
     if (pl.slot) { p = pl.slot[pp]; r = pl.range[pp]; eidx = pl.entry[pp]; }
     else { r = pair_range[pp]; eidx = pair_entry[pp]; }
-    // Two round trips, not four: both indices are requested together, then the frontier record and the 64-byte
-    // entry (coordinates, record totals, inline checkpoints) together.  The empty asm statements pin that order --
-    // left alone, the compiler sinks the range index and the frontier record below the entry's "has ops" test
-    // and every pair pays their latencies one after the other.
     asm volatile("" : "+v"(r), "+v"(eidx));
+    const FrontierRec f = fr[r];
+    f_start = f.start; f_end = f.end;
+  }
+  if (regroup) {
+    // The block's 256 pairs, regrouped by entry before anything of the index is read.  In projection order
+    // neighbouring lanes are the hits of ONE range on different entries: every lane reads its own entry line and
+    // its own tile lines.  The ranges of a block are neighbours in the lookup order and hit largely the same
+    // entries, so sorted by entry a wave's lanes share a handful of lines.  A counting sort in LDS over
+    // (entry - the block's smallest entry), one bin per thread; results are stored at the pair's own slot, so
+    // which lane projects which pair changes nothing downstream.
+    __shared__ uint32_t rg_hist[256];
+    __shared__ uint32_t rg_min[4];
+    __shared__ uint4 rg_pay[256];
+    uint32_t mn = eidx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+    rg_hist[threadIdx.x] = 0u;
+    if (lane_id() == 0) rg_min[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    const uint32_t emin = min(min(rg_min[0], rg_min[1]), min(rg_min[2], rg_min[3]));
+    const uint32_t bin = live ? min(eidx - emin, 254u) : 255u;
+    const uint32_t pos = atomicAdd(&rg_hist[bin], 1u);
+    __syncthreads();
+    uint32_t tot;
+    const uint32_t start = block_excl_scan(rg_hist[threadIdx.x], &tot);
+    rg_hist[threadIdx.x] = start;
+    __syncthreads();
+    rg_pay[rg_hist[bin] + pos] = make_uint4(eidx, p, (uint32_t)f_start, (uint32_t)f_end);
+    __syncthreads();
+    const uint4 mine = rg_pay[threadIdx.x];
+    eidx = mine.x; p = mine.y; f_start = (int32_t)mine.z; f_end = (int32_t)mine.w;
+    live = eidx != 0xFFFFFFFFu;
+  }
+  if (live) {
+    // Two round trips, not four ahead of the tiles: the indices (and the frontier record) above, then the
+    // 64-byte entry (coordinates, record totals, inline checkpoints).  The empty asm statement pins the four
+    // reads together -- left alone, the compiler sinks part of them below the entry's "has ops" test.
     const uint4 *ep = reinterpret_cast<const uint4 *>(v.entries + eidx);
-    FrontierRec f = fr[r];
+    FrontierRec f;
+    f.start = f_start; f.end = f_end;
     uint4 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
-    asm volatile("" : "+v"(f.start), "+v"(f.end), "+v"(e1.z));
+    asm volatile("" : "+v"(e0.x), "+v"(e1.z), "+v"(e2.x), "+v"(e3.x));
     const int32_t en_ts = (int32_t)e0.x, en_te = (int32_t)e0.y, en_qs = (int32_t)e0.z, en_qe = (int32_t)e0.w;
     const uint32_t nops_flags = e1.z;
     const uint32_t n = nops_flags & OP_LEN_MASK;
@@ -2654,8 +2690,9 @@ void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, ui
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
-                    ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev) {
+                    ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev, bool regroup) {
   if (!n_pairs) return;
+  const int rg = regroup ? 1 : 0;
   const bool ident = min_identity == min_identity;  // NaN = no filter
   if (v.tp_mode) {  // tracepoint index: every projection is the approximate one
     const uint32_t gt = (cdiv(n_pairs, 256) + 7u) & ~7u;
@@ -2669,7 +2706,7 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
   const int xcd_map = 1;
   const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};
   const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0);
-#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map, n_pairs_dev)
+#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map, n_pairs_dev, rg)
   if (transitive) {
     switch (mode) { case 0: IMPG_LAUNCH(true, 0); break; case 1: IMPG_LAUNCH(true, 1); break;
                     case 2: IMPG_LAUNCH(true, 2); break; default: IMPG_LAUNCH(true, 3); }

@@ -82,7 +82,7 @@ size_t scan_scratch_bytes(uint32_t n);
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
-                    ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev = nullptr);
+                    ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev = nullptr, bool regroup = false);
 // small batches (engine.cpp: run_small): n <= 1024 counts scanned by one block, total left on the device; results
 // packed behind a 64-byte header {n_pairs, err, -, -, accepted} into (host-mapped) memory
 constexpr uint32_t SMALL_HEADER_BYTES = 64;

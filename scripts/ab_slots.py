@@ -20,8 +20,9 @@ ref = None
 for kw in [dict(transitive=True, max_depth=3), dict()]:
     p = impg_amd.make_params(**kw)
     ref = None
-    for free in [0, 1, 0, 1]:
-        g.set_option("free_slot_order", free)
+    for free in [0, 1, 2, 1, 2]:  # 2 = projection-order slots + pairs regrouped by entry inside a projection block
+        g.set_option("free_slot_order", 1 if free else 0)
+        g.set_option("regroup_entries", 1 if free == 2 else 0)
         g.query_batch_stats(r, p)
         st, cnt, ck = g.query_batch_stats(r, p)
         sig = (cnt.tobytes(), ck.tobytes())

@@ -299,9 +299,9 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches):
             VALU_CYCLES_PER_WAVE_INST, SIMDS, os.path.basename(sq[-1]))
     r["limiter"] = ("the 856-byte model streams the whole CIGAR; the kernel reads one 64-byte entry and, per end of the projection, "
                     "a 16-byte header and 48 bytes of 16-bit prefix entries, so frac > 1 is accounting, not bandwidth.  Physically "
-                    "HBM is NOT the bound (measured_traffic_frac) and neither is VALU issue any more (valu_issue_frac): the kernel is "
-                    "bound by the vector-memory pipeline on un-coalesced 16-byte reads, every lane in its own cache line "
-                    "(about 12 per pair; having more of them in flight made it slower, DESIGN.md 5.2 item 13)")
+                    "HBM is NOT the bound (measured_traffic_frac).  The kernel sits between two limits: the vector-memory pipeline on "
+                    "16-byte reads that share few cache lines across a wave (a block regroups its pairs by entry to share more) and "
+                    "VALU issue (valu_issue_frac, which the regrouping sort raised again); DESIGN.md 5.2 items 12-14")
     return r
 
 

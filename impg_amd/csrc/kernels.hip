@@ -500,6 +500,20 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t *total)
   return base + inc - x;
 }
 
+// the same for a block of NW waves
+template <unsigned NW>
+__device__ __forceinline__ uint32_t block_excl_scan_n(uint32_t x, uint32_t *wsum /* [NW] shared */) {
+  const uint32_t inc = wave_incl_scan(x);
+  const unsigned w = threadIdx.x >> 6;
+  if (lane_id() == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+#pragma unroll
+  for (unsigned k = 0; k < NW; k++) base += k < w ? wsum[k] : 0u;
+  __syncthreads();
+  return base + inc - x;
+}
+
 __global__ __launch_bounds__(256) void scan_block_sums(const uint32_t *__restrict__ in, uint32_t n,
                                                        unsigned long long *__restrict__ bsum) {
   uint32_t base = blockIdx.x * SCAN_TILE;
@@ -929,13 +943,17 @@ __device__ __forceinline__ bool pfx_end(const PairCtx &c, const uint32_t *__rest
 // MODE & MODE_CIGAR: also record which ops form the projected CIGAR slice
 // (store_cigar); such launches walk tiles A..B literally -- BEDPE/PAF output is
 // not the throughput path.
+#ifndef IMPG_PROJ_BLOCK
+#define IMPG_PROJ_BLOCK 256
+#endif
 #ifdef IMPG_PROJECT_WAVES  // (experiments: force the register allocation that gives this many waves per SIMD)
 #define PROJECT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(IMPG_PROJECT_WAVES, IMPG_PROJECT_WAVES)))
 #else
 #define PROJECT_OCCUPANCY
 #endif
+constexpr uint32_t PROJ_BLOCK = IMPG_PROJ_BLOCK, PROJ_WAVES = PROJ_BLOCK / 64u;
 template <bool TRANSITIVE, int MODE>
-__global__ __launch_bounds__(256) PROJECT_OCCUPANCY void project_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
+__global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
                                                       const uint32_t *__restrict__ pair_range,
                                                       const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
@@ -950,7 +968,7 @@ __global__ __launch_bounds__(256) PROJECT_OCCUPANCY void project_kernel(DeviceIn
   // every eighth block of it.  The grid is a multiple of 8 blocks.
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t lblock = xcd_map ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-  const uint32_t pp = lblock * 256u + threadIdx.x;
+  const uint32_t pp = lblock * PROJ_BLOCK + threadIdx.x;
   bool ok = false;
   TileScan res;
   res.found = res.any = false;
@@ -974,21 +992,23 @@ __global__ __launch_bounds__(256) PROJECT_OCCUPANCY void project_kernel(DeviceIn
     // entries, so sorted by entry a wave's lanes share a handful of lines.  A counting sort in LDS over
     // (entry - the block's smallest entry), one bin per thread; results are stored at the pair's own slot, so
     // which lane projects which pair changes nothing downstream.
-    __shared__ uint32_t rg_hist[256];
-    __shared__ uint32_t rg_min[4];
-    __shared__ uint4 rg_pay[256];
+    __shared__ uint32_t rg_hist[PROJ_BLOCK];
+    __shared__ uint32_t rg_min[PROJ_WAVES];
+    __shared__ uint32_t rg_ws[PROJ_WAVES];
+    __shared__ uint4 rg_pay[PROJ_BLOCK];
     uint32_t mn = eidx;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
     rg_hist[threadIdx.x] = 0u;
     if (lane_id() == 0) rg_min[threadIdx.x >> 6] = mn;
     __syncthreads();
-    const uint32_t emin = min(min(rg_min[0], rg_min[1]), min(rg_min[2], rg_min[3]));
-    const uint32_t bin = live ? min(eidx - emin, 254u) : 255u;
+    uint32_t emin = rg_min[0];
+#pragma unroll
+    for (uint32_t k = 1; k < PROJ_WAVES; k++) emin = min(emin, rg_min[k]);
+    const uint32_t bin = live ? min(eidx - emin, PROJ_BLOCK - 2u) : PROJ_BLOCK - 1u;
     const uint32_t pos = atomicAdd(&rg_hist[bin], 1u);
     __syncthreads();
-    uint32_t tot;
-    const uint32_t start = block_excl_scan(rg_hist[threadIdx.x], &tot);
+    const uint32_t start = block_excl_scan_n<PROJ_WAVES>(rg_hist[threadIdx.x], rg_ws);
     rg_hist[threadIdx.x] = start;
     __syncthreads();
     rg_pay[rg_hist[bin] + pos] = make_uint4(eidx, p, (uint32_t)f_start, (uint32_t)f_end);
@@ -1267,12 +1287,14 @@ __global__ __launch_bounds__(256) PROJECT_OCCUPANCY void project_kernel(DeviceIn
   }
   // accepted-projection count: one atomic per BLOCK, spread over COUNT_SLOTS
   // cache lines (a single hot word caps the whole chip at ~90 atomics/us)
-  __shared__ uint32_t wcnt[4];
+  __shared__ uint32_t wcnt[PROJ_WAVES];
   unsigned long long m = __ballot(ok);
   if (lane_id() == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    uint32_t tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PROJ_WAVES; k++) tot += wcnt[k];
     if (tot) atomicAdd(&accepted[(blockIdx.x % COUNT_SLOTS) * COUNT_STRIDE], (unsigned long long)tot);
   }
 }
@@ -2702,11 +2724,11 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
                                                      ident ? min_identity : 0.0, ident ? 1 : 0, pl, n_pairs_dev);
     return;
   }
-  const uint32_t g = (cdiv(n_pairs, 256) + 7u) & ~7u;  // a multiple of the 8 XCDs (see the block mapping in the kernel)
+  const uint32_t g = (cdiv(n_pairs, PROJ_BLOCK) + 7u) & ~7u;  // a multiple of the 8 XCDs (see the block mapping in the kernel)
   const int xcd_map = 1;
   const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};
   const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0);
-#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map, n_pairs_dev, rg)
+#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, PROJ_BLOCK, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map, n_pairs_dev, rg)
   if (transitive) {
     switch (mode) { case 0: IMPG_LAUNCH(true, 0); break; case 1: IMPG_LAUNCH(true, 1); break;
                     case 2: IMPG_LAUNCH(true, 2); break; default: IMPG_LAUNCH(true, 3); }

@@ -1099,13 +1099,21 @@ def test_counting_runs_with_slots_in_projection_order(tmp_path):
             res = g.query_batch(ranges, p)
             want_cnt = [len(res[i]) - 1 for i in range(len(ranges))]
             want_ck = [checksum(res[i][1:]) for i in range(len(ranges))]
-            for lm, free in [(1, 1), (1, 0), (0, 1)]:
+            for lm, free, regroup in [(1, 1, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0), (0, 0, 0)]:
                 g.set_option("locality_min", lm)
                 g.set_option("free_slot_order", free)
+                g.set_option("regroup_entries", regroup)  # (a projection block sorts its pairs by entry first: same slots, same rows)
                 st, cnt, ck = g.query_batch_stats(ranges, p)
                 assert st.projected == res.projected
-                assert cnt.tolist() == want_cnt, (seed, kw, lm, free)
-                assert [int(x) for x in ck] == want_ck, (seed, kw, lm, free)
+                assert cnt.tolist() == want_cnt, (seed, kw, lm, free, regroup)
+                assert [int(x) for x in ck] == want_ck, (seed, kw, lm, free, regroup)
+            g.set_option("regroup_entries", 0)
+            g.set_option("locality_min", 4096)
+            res0 = g.query_batch(ranges, p)
+            g.set_option("regroup_entries", 1)
+            assert res0.projected == res.projected
+            for i in range(len(ranges)):
+                assert res0[i].tolist() == res[i].tolist(), (seed, kw, i)
         g.set_option("free_slot_order", 1)
     # dense target: windows wider than 64 entries are listed by place for the wave-per-range emit pass
     lines = []

@@ -175,6 +175,12 @@ def main():
             dist.barrier()
 
     log("index ready (%.1f s, %.2f GB in HBM); warmup" % (t_build, index.device_bytes() / 1e9))
+    if world > 1 or args.force_sharded:
+        # part of the set-up, like the index build: the first collective pass on a fresh process brings up the
+        # transport (RCCL channels, peer mappings) and sizes every lane's scratch -- seconds on a cold box, and with
+        # two chunks in flight per rank one --warmup step does not always touch both lanes' buffers
+        st = step()
+        log("transport + scratch primed: first pass %.1f ms of engine time" % st.ms_total)
     for _ in range(args.warmup):
         st = step()
         log("warmup step: %d projected, engine %.1f ms (lookup %.1f project %.1f update %.1f exchange %.1f)" %

@@ -163,15 +163,23 @@ static HitArrays hit_arrays(LevelBufs &L, uint32_t n_pairs) {
 // windows in the entry array, so that lanes and workgroups in flight together
 // search the same blocks and gather neighbouring entries and CIGAR tiles (L1/L2
 // hits instead of HBM lines).  Returns the permutation, or null when not worth it.
-const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr) {
-  if (!locality_min || n_fr < locality_min) return nullptr;
+const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, const RecordBlocks *blocks) {
+  if (!locality_min || (n_fr < locality_min && !blocks)) return nullptr;
   const size_t nb = (size_t)n_fr * 4;
   lo_key.reserve(nb); lo_key2.reserve(nb); lo_idx.reserve(nb); lo_perm.reserve(nb);
-  launch_order_keys(v, fr, n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream);
+  // keys are positions in the entry array: only the bits below n_entries are sorted (plus the block bits above them)
+  unsigned hi_bit = std::max(1u, bits_for((uint32_t)std::min<size_t>(v.n_entries, 0xFFFFFFFFull)));
+  unsigned block_shift = 0;
+  if (blocks) {
+    const unsigned bb = std::max(1u, bits_for(blocks->n_blocks));
+    if (hi_bit + bb > 32) return nullptr;  // no room for the block above the window bits: the caller keeps the reference's order
+    block_shift = hi_bit;
+    hi_bit += bb;
+  }
+  launch_order_keys(v, fr, n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream, blocks ? blocks->d_bounds : nullptr,
+                    blocks ? blocks->n_blocks : 0u, block_shift);
   const size_t tb = sort_u32_scratch_bytes(n_fr);
   sort_tmp.reserve(tb);
-  // keys are positions in the entry array: only the bits below n_entries are sorted
-  const unsigned hi_bit = std::max(1u, bits_for((uint32_t)std::min<size_t>(v.n_entries, 0xFFFFFFFFull)));
   launch_sort_u32(sort_tmp.p, tb, lo_key.as<uint32_t>(), lo_key2.as<uint32_t>(), lo_idx.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr,
                   stream, 0, hi_bit);
   return lo_perm.as<uint32_t>();
@@ -195,7 +203,7 @@ void Engine::projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uin
 
 // lookup + projection of one frontier; fills L (pair_range, hit arrays), returns #pairs
 uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
-                        impg_gpu_stats_t *st, bool raw) {
+                        impg_gpu_stats_t *st, bool raw, const RecordBlocks *blocks) {
   hipEvent_t e0 = event(), e1 = event(), e2 = event();
   IMPG_HIP(hipEventRecord(e0, stream));
   cnt.reserve((size_t)n_fr * 4);
@@ -205,11 +213,13 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   if (multi) transitive = false;
   wide_n.reserve(256);
   wide_list.reserve(std::max<size_t>((size_t)n_fr * 4, 256));
-  const uint32_t *d_perm = lookup_order(v, fr, n_fr);
+  const uint32_t *d_perm = lookup_order(v, fr, n_fr, blocks);
   // Counting runs under the lookup order (see free_slot_order): slot = place in that order.  The count pass leaves
   // its counts and windows at the lanes' places, one scan gives the run offsets and the total, and the emit pass
   // writes the two pair lists as one contiguous piece per wave -- no per-range scatter, no slot list.
-  const bool by_place = free_slot_order && !raw && !multi && !store_cigar && d_perm;
+  // (the owner side of a sharded hop may do the same when the order runs home rank by home rank: `blocks`)
+  const bool by_place = free_slot_order && (!raw || blocks) && !multi && !store_cigar && d_perm;
+  last_by_place = by_place;
   launch_lookup_count(v, fr, n_fr, transitive, d_perm, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(),
                       wide_list.as<uint32_t>(), stream, by_place);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);

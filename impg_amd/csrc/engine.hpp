@@ -99,13 +99,18 @@ struct Engine {
   uint64_t scan(const uint32_t *in, uint32_t *out, uint32_t n);
   // lookup / projection order (locality): lookup_order() before the count pass gives the permutation (null
   // when not worth it); projection_offsets() after the scan gives every range's first place in slot_of
-  const uint32_t *lookup_order(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr);
+  // blocks (optional, the owner side of a sharded counting hop): the records are n_blocks contiguous blocks, one per
+  // home rank (d_bounds[n_blocks + 1], device); the order then runs block by block, so that the slots -- laid out in
+  // that order -- stay grouped by the rank they go back to
+  struct RecordBlocks { const uint32_t *d_bounds; uint32_t n_blocks; };
+  const uint32_t *lookup_order(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, const RecordBlocks *blocks = nullptr);
   void projection_offsets(const uint32_t *d_perm, uint32_t n_fr, const uint32_t *d_cnt, uint64_t P, const uint32_t *&d_offp,
                           ProjList &pl);
   DevBuf proj_range, proj_entry;  // the pairs' ranges / entries in projection order (next to slot_of)
   // raw: the owner side of a sharded hop -- slots as projected; the subset filter and the MultiImpg sort run at home
   uint64_t expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
-                  impg_gpu_stats_t *st, bool raw = false);
+                  impg_gpu_stats_t *st, bool raw = false, const RecordBlocks *blocks = nullptr);
+  bool last_by_place = false;  // the last expand laid its slots out in lookup order (pair_off is then by place)
   // subset filter + MultiImpg five-key sort of a level's slots (pair_off: first slot of every frontier record;
   // tie_rank[tie_idx[slot]] = the MultiImpg tie order of the slot's entry)
   void post_expand(const FrontierRec *fr, uint32_t n_fr, LevelBufs &L, const uint32_t *d_pair_off, uint32_t *tie_idx,

@@ -339,8 +339,12 @@ __global__ __launch_bounds__(256) void reorder_runs_kernel(const uint32_t *__res
 // Lookup / projection order: ranges sorted by where their window will be in the entry array,
 // estimated before any search from the record alone: segment start + start / sequence length x
 // segment size (alignments spread evenly enough for a LOCALITY key; exactness is not needed).
+// bounds (optional): the records come in n_blocks contiguous blocks (records [bounds[b], bounds[b+1]) -- on a shard,
+// what each home rank sent); the block goes above the window bits, so the order is block by block and a block's
+// pairs stay together.
 __global__ __launch_bounds__(256) void order_keys_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr, uint32_t n,
-                                                         uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
+                                                         uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
+                                                         const uint32_t *__restrict__ bounds, uint32_t n_blocks, uint32_t block_shift) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   if (r >= n) return;
   const FrontierRec f = fr[r];
@@ -351,6 +355,14 @@ __global__ __launch_bounds__(256) void order_keys_kernel(DeviceIndexView v, cons
     const uint64_t st = (uint64_t)(uint32_t)max(f.start, 0);
     const uint64_t rel = len > 0 ? st * d.y / (uint64_t)(uint32_t)len : 0ull;
     k = d.x + (uint32_t)min(rel, (uint64_t)(d.y ? d.y - 1u : 0u));
+  }
+  if (bounds) {
+    uint32_t lo = 0, hi = n_blocks;  // last block b with bounds[b] <= r
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (bounds[mid] <= r) lo = mid; else hi = mid;
+    }
+    k |= lo << block_shift;
   }
   key[r] = k;
   idx[r] = r;
@@ -2703,8 +2715,9 @@ void launch_reorder_runs(const uint32_t *hits, uint32_t n, uint32_t words, uint3
                          uint32_t *run_len, uint32_t *err, hipStream_t s) {
   if (n) reorder_runs_kernel<<<cdiv(n, 256), 256, 0, s>>>(hits, n, words, n_front, run_start, run_len, err);
 }
-void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s) {
-  if (n) order_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, key, idx);
+void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s,
+                       const uint32_t *bounds, uint32_t n_blocks, uint32_t block_shift) {
+  if (n) order_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, key, idx, bounds, n_blocks, block_shift);
 }
 void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, uint32_t *out, hipStream_t s) {
   if (n) scatter_u32_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, perm, n, out);

@@ -74,7 +74,8 @@ void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n
 // stable order of hit records (words u32 each, fidx first) by fidx when equal fidx are already contiguous
 void launch_reorder_runs(const uint32_t *hits, uint32_t n, uint32_t words, uint32_t n_front, uint32_t *run_start,
                          uint32_t *run_len, uint32_t *err, hipStream_t s);
-void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s);
+void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s,
+                       const uint32_t *bounds = nullptr, uint32_t n_blocks = 0, uint32_t block_shift = 0);
 void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, uint32_t *out, hipStream_t s);
 void launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, unsigned long long *d_bsum,
                            unsigned long long *d_total, hipStream_t s);

@@ -65,7 +65,7 @@ struct ShardedExpander : Expander {
   Comm *comm = nullptr;
   const uint32_t *d_owner = nullptr;
   uint32_t n_seq = 0;
-  DevBuf send_fr, recv_fr, hits_out, hits_in, mslot, iota, route_hist;
+  DevBuf send_fr, recv_fr, hits_out, hits_in, mslot, iota, route_hist, d_bounds;
   LevelBufs owner_L;
   uint32_t *h_vals = nullptr;  // pinned: slot offsets at block boundaries
   size_t h_cap = 0;
@@ -162,14 +162,28 @@ struct ShardedExpander : Expander {
       h_cap = std::max<size_t>((size_t)(W + 1) * 4, 4096);
       IMPG_HIP(hipHostMalloc((void **)&h_vals, h_cap, hipHostMallocDefault));
     }
+    // A counting hop (nobody at home reads rows) lets the owner lay its slots out in its own lookup order, home rank
+    // by home rank: the cheaper lookup and projection of Engine::free_slot_order.  Home puts the runs back in
+    // frontier order whatever order they come in (reorder_runs), so nothing else changes.
+    const bool owner_order = E.free_slot_order && !need_rows && !E.multi;
+    bool any_by_place = false;
+    std::vector<uint32_t> hb((size_t)W + 1);
+    if (owner_order) d_bounds.reserve(std::max<size_t>(((size_t)W + 1) * 4, 256));
     uint64_t a = 0, step = std::max<uint64_t>(n_recv, 1);
     while (a < n_recv) {
       const uint64_t m = std::min(step, n_recv - a);
       E.split_ok = m > 1;
       uint64_t P = 0;
       const FrontierRec *sub = recv_fr.as<FrontierRec>() + a;
+      Engine::RecordBlocks blocks{nullptr, (uint32_t)W};
+      if (owner_order) {  // the slice's records by home rank: block r = [hb[r], hb[r+1])
+        for (int r = 0; r <= W; r++) hb[r] = (uint32_t)(std::min(std::max(rstart[r], a), a + m) - a);
+        IMPG_HIP(hipMemcpy(d_bounds.p, hb.data(), ((size_t)W + 1) * 4, hipMemcpyHostToDevice));
+        blocks.d_bounds = d_bounds.as<uint32_t>();
+      }
       try {
-        P = E.expand(v, sub, (uint32_t)m, transitive, owner_L, st, /*raw=*/true);
+        P = E.expand(v, sub, (uint32_t)m, transitive, owner_L, st, /*raw=*/true, owner_order ? &blocks : nullptr);
+        any_by_place = any_by_place || E.last_by_place;
       } catch (const SplitBatch &) {
         step = std::max<uint64_t>(1, m / 2);
         continue;
@@ -238,7 +252,7 @@ struct ShardedExpander : Expander {
     const size_t b = std::max<size_t>((size_t)n_home * 4, 256);
     L.pair_range.reserve(b); L.qid.reserve(b); L.coords.reserve(4 * b);
     HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
-    const bool need_order = W > 1 || E.multi;
+    const bool need_order = W > 1 || E.multi || any_by_place;
     if (E.multi) mslot.reserve(b);
     if (n_home) {
       if (need_order) {

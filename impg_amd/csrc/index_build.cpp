@@ -19,16 +19,31 @@
 
 namespace impg {
 
+// IMPG_POISON=<hex byte> (debugging aid): every block a DevBuf obtains -- new or recycled -- is filled with that byte
+// first, so that a kernel reading a buffer it has not written yet fails the same way every time instead of depending
+// on what the block held before.  The parity soak is run under several patterns (scripts/fuzz_parity.py).
+static int poison_byte() {
+  static const int b = [] {
+    const char *e = getenv("IMPG_POISON");
+    return e && *e ? (int)(strtoul(e, nullptr, 16) & 0xFFu) : -1;
+  }();
+  return b;
+}
 void DevBuf::reserve(size_t bytes) {
   if (bytes <= cap) return;
   release();
   size_t want = std::max<size_t>(bytes, 256);
   if (pool) {
     p = pool->take(want, cap);
-    return;
+  } else {
+    IMPG_HIP(hipMalloc(&p, want));
+    cap = want;
   }
-  IMPG_HIP(hipMalloc(&p, want));
-  cap = want;
+  if (poison_byte() >= 0) {
+    IMPG_HIP(hipDeviceSynchronize());  // (a recycled block may still be read by work in flight on another stream)
+    IMPG_HIP(hipMemset(p, poison_byte(), cap));
+    IMPG_HIP(hipDeviceSynchronize());
+  }
 }
 void DevBuf::release() {
   if (p) {

@@ -331,7 +331,11 @@ struct LaneWork {  // what one lane accumulates
 
 // Runs body(lane, engine, chunk_begin, chunk_end) for every chunk of this rank's ranges, chunks dealt to the
 // lanes round-robin; every rank runs the same number of chunks (ranks with fewer ranges run empty ones).
-template <class F> void run_lanes(impg_gpu_index &ix, size_t n, F body) {
+// prep(E) runs once per lane, right after the lane has taken its engine: whatever the batch hangs on an engine (mask,
+// subset filter) belongs to the LEASE -- the lease's end clears it, and a lane that starts late can be handed the very
+// engine an early lane has just given back.  (It used to be applied once per engine pointer: such a late lane then ran
+// its chunks unmasked and unfiltered.  Found by scripts/fuzz_parity.py, seed 72686, 4 ranks x 2 lanes.)
+template <class P, class F> void run_lanes(impg_gpu_index &ix, size_t n, P prep, F body) {
   ShardCtx &S = *ix.shard;
   const size_t chunk = ix.opt_chunk_ranges ? ix.opt_chunk_ranges : std::max<size_t>(n, 1);
   uint64_t my_chunks = std::max<uint64_t>(1, (n + chunk - 1) / chunk);
@@ -346,6 +350,7 @@ template <class F> void run_lanes(impg_gpu_index &ix, size_t n, F body) {
       EngineLease lease(ix);
       Engine &E = *lease;
       E.remote = S.lanes[l].get();
+      prep(E);
       for (uint64_t c = l; c < n_chunks; c += n_lanes) {
         const size_t b = std::min<size_t>(n, c * chunk), e = std::min<size_t>(n, b + chunk);
         body(l, E, b, e);
@@ -400,7 +405,7 @@ void rank_stats(impg_gpu_index &ix, const impg_gpu_range_t *ranges, bool on_devi
   std::vector<impg_gpu_stats_t> per_lane(S.comm->lanes.size());
   for (auto &x : per_lane) memset(&x, 0, sizeof x);
   for (auto &x : S.lanes) x->exchange_s = 0;
-  run_lanes(ix, n, [&](size_t l, Engine &E, size_t b, size_t e) {
+  run_lanes(ix, n, [](Engine &) {}, [&](size_t l, Engine &E, size_t b, size_t e) {
     impg_gpu_stats_t st;
     {
       std::unique_lock<std::mutex> turn(S.gpu_turn, std::defer_lock);
@@ -430,18 +435,11 @@ void rank_query(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, co
   if (n) IMPG_HIP(hipMemcpy(d_ranges.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice));
   const size_t chunk = ix.opt_chunk_ranges ? ix.opt_chunk_ranges : std::max<size_t>(n, 1);
   std::vector<std::unique_ptr<impg_gpu_results>> parts((n + chunk - 1) / chunk + 1);
-  std::vector<Engine *> prepared;
-  std::mutex pm;
   std::atomic<uint64_t> served{0};  // projections done here for other ranks' records during chunks this rank had no ranges for
-  run_lanes(ix, n, [&](size_t, Engine &E, size_t b, size_t e) {
-    {
-      std::lock_guard<std::mutex> lk(pm);
-      if (std::find(prepared.begin(), prepared.end(), &E) == prepared.end()) {
-        apply_mask(E, ix, mask, p);  // every lane's engine carries the batch's mask / filter
-        apply_subset(E, ix, subset_keep);
-        prepared.push_back(&E);
-      }
-    }
+  run_lanes(ix, n, [&](Engine &E) {
+    apply_mask(E, ix, mask, p);  // every lane's lease carries the batch's mask / filter
+    apply_subset(E, ix, subset_keep);
+  }, [&](size_t, Engine &E, size_t b, size_t e) {
     std::vector<std::unique_ptr<LevelBufs>> levels;
     DevBuf self_dev;
     self_dev.pool = &E.level_pool;

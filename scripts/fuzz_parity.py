@@ -10,6 +10,7 @@ import numpy as np
 import impg_amd
 from oracle import oracle as o
 from tests.paf_gen import random_paf, random_ranges
+from tests.test_gpu_fullsize import checksum
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -17,7 +18,10 @@ BIG = len(sys.argv) > 3
 t_end = time.time() + budget
 n_cases = n_rows = 0
 tmp = tempfile.mkdtemp()
+REPEAT = int(os.environ.get("FUZZ_REPEAT", "0"))  # > 0: the first seed over and over (hunting a failure that comes and goes)
 while time.time() < t_end:
+    if REPEAT and n_cases >= REPEAT:
+        break
     rng = np.random.default_rng(seed)
     n_seq = int(rng.integers(2, 14))
     seq_len = int(rng.choice([2500, 8000, 30000, 120000]))
@@ -44,6 +48,9 @@ while time.time() < t_end:
     o.set_sorted_visits(order == impg_amd.ORDER_SORTED)  # both order policies have an exact checker
     c = o.OracleIndex(paf_paths=paths, bidirectional=bidir, preparse=True)
     g.set_option("locality_min", int(rng.choice([0, 1, 4096])))
+    for kv in filter(None, os.environ.get("FUZZ_OPTS", "").split(",")):  # e.g. FUZZ_OPTS=regroup_entries=0 to bisect a failing seed
+        k, v = kv.split("=")
+        g.set_option(k, int(v))
     if rng.random() < 0.3:
         g.set_option("chunk_ranges", int(rng.integers(1, 40)))
     if rng.random() < 0.2:
@@ -91,10 +98,37 @@ while time.time() < t_end:
             assert [x.tolist() for x in got_cg] == [x.tolist() for x in wcg], ("cigar", seed, i, kw)
         else:
             want = c.query(t, s, e, masked_regions=mask, subset_keep=keep, **kw)
+        if res[i].tolist() != want.tolist():
+            # Always leave enough behind to tell WHICH side moved: the rows, the set-up, and both sides asked again
+            # (a mismatch that does not repeat on a second call is a race or an uninitialised read, and the side
+            # whose answer changed is the one that has it).
+            gl, wl = res[i].tolist(), want.tolist()
+            print("MISMATCH seed", seed, "range", i, (t, s, e), "world", world, "files", n_files, "order", order, "bidir", bidir,
+                  "cigar", cigar, "kw", kw, "got", len(gl), "want", len(wl), flush=True)
+            for k in range(max(len(gl), len(wl))):
+                a = gl[k] if k < len(gl) else None
+                b = wl[k] if k < len(wl) else None
+                if a != b:
+                    print("  row", k, "got", a, "want", b, flush=True)
+            for rep in range(3):
+                g2 = g.query_batch(ranges, params, masked_regions=mask, subset_keep=keep)[i].tolist()
+                w2 = (c.query_cigar(t, s, e, **kw)[0] if cigar else c.query(t, s, e, masked_regions=mask, subset_keep=keep, **kw)).tolist()
+                print("  again", rep, "engine same as before:", g2 == gl, " oracle same as before:", w2 == wl, " agree now:", g2 == w2, flush=True)
         assert res[i].tolist() == want.tolist(), ("rows", seed, i, (t, s, e), kw, mask)
         total += c.last_projection_count()
         n_rows += len(want)
     assert res.projected == total, ("projected", seed, kw, world, res.projected, total)
+    # the counting form of the same batch (slots in lookup order, pairs regrouped by entry -- or not): per-range counts
+    # and checksums must be those of the rows above
+    if mask is None and keep is None:
+        g.set_option("free_slot_order", int(rng.integers(0, 2)))
+        g.set_option("regroup_entries", int(rng.integers(0, 2)))
+        st, cnt, ck = g.query_batch_stats(ranges, impg_amd.make_params(**kw))
+        assert st.projected == total, ("stats projected", seed, kw, world)
+        assert cnt.tolist() == [len(res[i]) - 1 for i in range(len(ranges))], ("stats counts", seed, kw, world)
+        assert [int(x) for x in ck] == [checksum(res[i][1:]) for i in range(len(ranges))], ("stats checksums", seed, kw, world)
+        g.set_option("free_slot_order", 1)
+        g.set_option("regroup_entries", 1)
     # text outputs on the ranges long enough for perform_query's validation
     mtl = kw.get("min_transitive_len", 101)
     ok = [i for i, (t, s, e) in enumerate(ranges) if e - s >= mtl]
@@ -125,6 +159,7 @@ while time.time() < t_end:
     n_cases += 1
     for p in paths:
         os.remove(p)
-    seed += 1
+    if not REPEAT:
+        seed += 1
 o.set_sorted_visits(False)
 print("fuzz ok: %d cases, %d result rows compared, seeds up to %d" % (n_cases, n_rows, seed - 1))

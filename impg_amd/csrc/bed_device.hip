@@ -38,50 +38,6 @@ struct Rows {  // SoA rows of a chunk
   int4 *c;  // {q_first, q_last, t_first, t_last}
 };
 
-// ---- rows ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void self_flags_kernel(const FrontierRec *__restrict__ self, uint32_t n_self, int transitive,
-                                                         int32_t min_len_plain, uint32_t *__restrict__ flag) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n_self) return;
-  const FrontierRec f = self[i];
-  bool on = transitive ? f.start < f.end : true;  // impg.rs:2345-2363 / :1864-1880
-  if (!transitive && min_len_plain >= 0 && abs(f.end - f.start) < min_len_plain) on = false;  // perform_query retain, main.rs:11682-11688
-  flag[i] = on ? 1u : 0u;
-}
-__global__ __launch_bounds__(256) void slot_flags_kernel(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ pair_range,
-                                                         uint32_t n_pairs, HitArrays h, int32_t min_len, int skip_same,
-                                                         uint32_t *__restrict__ flag) {
-  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= n_pairs) return;
-  const uint32_t qid = h.qid[p];
-  bool on = qid != HIT_NONE;
-  if (on) {
-    const int4 hc = h.c[p];
-    if (min_len >= 0 && abs(hc.y - hc.x) < min_len) on = false;          // impg.rs:2482-2504 / main.rs:11682-11688
-    if (on && skip_same && qid == fr[pair_range[p]].target_id) on = false;  // multi_impg.rs:883-885
-  }
-  flag[p] = on ? 1u : 0u;
-}
-__global__ __launch_bounds__(256) void self_rows_kernel(const FrontierRec *__restrict__ self, uint32_t n_self, const uint32_t *__restrict__ flag,
-                                                        const uint32_t *__restrict__ pos, Rows R) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n_self || !flag[i]) return;
-  const FrontierRec f = self[i];
-  const uint32_t d = pos[i];
-  R.q[d] = f.qidx; R.qid[d] = f.target_id; R.tid[d] = f.target_id;
-  R.c[d] = make_int4(f.start, f.end, f.start, f.end);
-}
-__global__ __launch_bounds__(256) void slot_rows_kernel(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ pair_range,
-                                                        uint32_t n_pairs, HitArrays h, const uint32_t *__restrict__ flag,
-                                                        const uint32_t *__restrict__ pos, Rows R) {
-  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= n_pairs || !flag[p]) return;
-  const FrontierRec f = fr[pair_range[p]];
-  const uint32_t d = pos[p];
-  R.q[d] = f.qidx; R.qid[d] = h.qid[p]; R.tid[d] = f.target_id;
-  R.c[d] = h.c[p];
-}
-
 // ---- gap_2d --------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gap_keys_kernel(Rows R, uint32_t n, unsigned seq_bits, uint32_t *__restrict__ k32,
                                                        unsigned long long *__restrict__ k64, uint32_t *__restrict__ idx) {
@@ -335,48 +291,20 @@ __global__ __launch_bounds__(256) void text_write_kernel(const BedRow *__restric
 uint32_t device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, const impg_gpu_params_t &p, int32_t merge_distance,
                          std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, DevBuf &out) {
   hipStream_t s = E.stream;
-  const bool transitive = p.transitive != 0;
   const bool merge_strands = p.consider_strandness == 0;
-  const uint32_t n_self = transitive ? (E.masked ? (uint32_t)E.n_self : n_ranges) : n_ranges;
-  // ---- flags + positions over [self | level 0 | level 1 | ...] -------------------------------------------------
-  uint64_t S = n_self;
-  for (auto &L : levels) S += L->n_pairs;
-  if (S >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 result slots in one chunk: use smaller chunks (chunk_ranges)"};
-  DevBuf flag, pos, self_plain;
-  flag.reserve(std::max<size_t>(S * 4, 256));
-  pos.reserve(std::max<size_t>(S * 4, 256));
-  const FrontierRec *d_self = self_dev.as<FrontierRec>();
-  if (!transitive) {  // Impg::query: the self interval is the range itself (impg.rs:1864-1880): frontier 0 of the run
-    d_self = levels.empty() ? nullptr : levels[0]->frontier.as<FrontierRec>();
-  }
-  uint32_t *fl = flag.as<uint32_t>();
-  if (n_self && d_self) self_flags_kernel<<<cdiv(n_self, 256), 256, 0, s>>>(d_self, n_self, transitive ? 1 : 0, p.min_output_length, fl);
-  else if (n_self) IMPG_HIP(hipMemsetAsync(fl, 0, (size_t)n_self * 4, s));
-  uint64_t base = n_self;
-  const int32_t min_len = p.min_output_length;  // transitive: applied while collecting; plain: perform_query's retain -- the same test
-  for (auto &L : levels) {
-    if (L->n_pairs) {
-      HitArrays h{L->qid.as<uint32_t>(), L->coords.as<int4>()};
-      slot_flags_kernel<<<cdiv(L->n_pairs, 256), 256, 0, s>>>(L->frontier.as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h, min_len,
-                                                              (transitive && p.multi_impg) ? 1 : 0, fl + base);
-    }
-    base += L->n_pairs;
-  }
-  const uint64_t n_rows64 = E.scan(fl, pos.as<uint32_t>(), (uint32_t)S);
-  const uint32_t n = (uint32_t)n_rows64;
-  if (!n) return 0;
+  // ---- rows: range-major, the reference's emission order within a range (rows_device.hip) ---------------------------
+  uint32_t n = 0;
   DevBuf rq, rqid, rtid, rc;
-  rq.reserve((size_t)n * 4); rqid.reserve((size_t)n * 4); rtid.reserve((size_t)n * 4); rc.reserve((size_t)n * 16);
-  Rows R{rq.as<uint32_t>(), rqid.as<uint32_t>(), rtid.as<uint32_t>(), rc.as<int4>()};
-  if (n_self && d_self) self_rows_kernel<<<cdiv(n_self, 256), 256, 0, s>>>(d_self, n_self, fl, pos.as<uint32_t>(), R);
-  base = n_self;
-  for (auto &L : levels) {
-    if (L->n_pairs) {
-      HitArrays h{L->qid.as<uint32_t>(), L->coords.as<int4>()};
-      slot_rows_kernel<<<cdiv(L->n_pairs, 256), 256, 0, s>>>(L->frontier.as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h, fl + base,
-                                                             pos.as<uint32_t>() + base, R);
-    }
-    base += L->n_pairs;
+  Rows R{nullptr, nullptr, nullptr, nullptr};
+  {
+    RowPlan pl;  // (its tables go back to the pool at the end of this block, before the sorts take their memory)
+    plan_rows(E, n_ranges, p, levels, self_dev, /*plain_retain=*/true, pl);
+    n = pl.n_rows;
+    if (!n) return 0;
+    rq.reserve((size_t)n * 4); rqid.reserve((size_t)n * 4); rtid.reserve((size_t)n * 4); rc.reserve((size_t)n * 16);
+    R = Rows{rq.as<uint32_t>(), rqid.as<uint32_t>(), rtid.as<uint32_t>(), rc.as<int4>()};
+    scatter_rows(E, levels, pl, RowSinks{nullptr, R.q, R.qid, R.tid, R.c, nullptr});
+    IMPG_HIP(hipStreamSynchronize(s));
   }
   // the levels' slots are not needed any more: give their memory back before the sorts take theirs
   levels.clear();

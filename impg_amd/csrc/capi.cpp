@@ -113,161 +113,37 @@ std::unique_ptr<impg_gpu_index> make_index(const impg_gpu_record_t *records, siz
 }  // namespace impg
 
 namespace impg {
+// What the trait returns for one chunk: rows placed by the device (rows_device.hip), one copy across PCIe into a
+// pinned block of the result, offsets widened on the host.  `levels` are consumed.
 void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p,
                       std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, impg_gpu_results &res) {
-  const bool transitive = p.transitive != 0;
+  hipStream_t s = E.stream;
   res.ranges.assign(h_ranges, h_ranges + n);
-  // self intervals: one per query (empty ones dropped below), or under masked_regions the pieces the mask left
-  std::vector<FrontierRec> self;
-  std::vector<uint32_t> self_off;
-  if (transitive && E.masked) {
-    self.resize(E.n_self);
-    self_off.assign(n + 1, (uint32_t)E.n_self);
-    if (n) IMPG_HIP(hipMemcpy(self_off.data(), E.self_off.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (E.n_self) IMPG_HIP(hipMemcpy(self.data(), self_dev.p, (size_t)E.n_self * sizeof(FrontierRec), hipMemcpyDeviceToHost));
-  } else if (transitive) {
-    self.resize(n);
-    if (n) IMPG_HIP(hipMemcpy(self.data(), self_dev.p, (size_t)n * sizeof(FrontierRec), hipMemcpyDeviceToHost));
-    self_off.resize(n + 1);
-    for (uint32_t q = 0; q <= n; q++) self_off[q] = q;
-  }
-  struct HostLevel {
-    std::vector<FrontierRec> fr;
-    std::vector<uint32_t> pair_range, qid;
-    std::vector<int4> c;  // {q_first, q_last, t_first, t_last}
-    std::vector<uint32_t> sl_pos, sl_n, pool;
-  };
-  std::vector<HostLevel> hl(levels.size());
-  for (size_t l = 0; l < levels.size(); l++) {
-    LevelBufs &L = *levels[l];
-    HostLevel &H = hl[l];
-    H.fr.resize(L.n_frontier);
-    if (L.n_frontier) IMPG_HIP(hipMemcpy(H.fr.data(), L.frontier.p, (size_t)L.n_frontier * sizeof(FrontierRec), hipMemcpyDeviceToHost));
-    size_t P = L.n_pairs;
-    H.pair_range.resize(P); H.qid.resize(P); H.c.resize(P);
-    if (P) {
-      IMPG_HIP(hipMemcpy(H.pair_range.data(), L.pair_range.p, P * 4, hipMemcpyDeviceToHost));
-      IMPG_HIP(hipMemcpy(H.qid.data(), L.qid.p, P * 4, hipMemcpyDeviceToHost));
-      IMPG_HIP(hipMemcpy(H.c.data(), L.coords.p, P * 16, hipMemcpyDeviceToHost));
-      if (p.store_cigar) {
-        H.sl_pos.resize(P); H.sl_n.resize(P); H.pool.resize(L.slice_total);
-        IMPG_HIP(hipMemcpy(H.sl_pos.data(), L.slice_pos.p, P * 4, hipMemcpyDeviceToHost));
-        IMPG_HIP(hipMemcpy(H.sl_n.data(), L.sl_n.p, P * 4, hipMemcpyDeviceToHost));
-        if (L.slice_total) IMPG_HIP(hipMemcpy(H.pool.data(), L.slice_pool.p, L.slice_total * 4, hipMemcpyDeviceToHost));
-      }
-    }
-  }
-  const bool skip_same = transitive && p.multi_impg;  // multi_impg.rs:883-885
-  auto emitted = [&](const HostLevel &H, size_t k) {
-    if (H.qid[k] == HIT_NONE) return false;
-    if (skip_same && H.qid[k] == H.fr[H.pair_range[k]].target_id) return false;
-    if (transitive && p.min_output_length >= 0 && std::abs((int64_t)H.c[k].y - H.c[k].x) < p.min_output_length) return false;
-    return true;  // impg.rs:2482-2504
-  };
-  // A level's hits come in frontier order and every frontier is sorted by query, so the hits of one range are one
-  // contiguous run per level: seg[l][q] = first slot of range q in level l.  With that the ranges are independent and
-  // the assembly runs over them in parallel (a transitive batch is hundreds of millions of rows).  A level whose
-  // frontier is not in query order (never produced by this engine) falls back to the serial passes below.
-  const size_t nl = hl.size();
-  std::vector<std::vector<uint64_t>> seg(nl);
-  bool by_range = true;
-  unsigned hw = std::thread::hardware_concurrency();
-  const size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, 64));
-  size_t total_hits = 0;
-  for (auto &H : hl) total_hits += H.qid.size();
-  auto parallel = [&](size_t count, const std::function<void(size_t, size_t)> &f) {
-    if (total_hits < (1u << 18) || count < 2 * T || T == 1) { f(0, count); return; }  // small batches: not worth the threads
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < T; t++) th.emplace_back([&, t]() { f(count * t / T, count * (t + 1) / T); });
-    for (auto &x : th) x.join();
-  };
-  for (size_t l = 0; l < nl && by_range; l++) {
-    const HostLevel &H = hl[l];
-    const size_t P = H.qid.size();
-    seg[l].assign((size_t)n + 1, P);
-    std::atomic<bool> ok{true};
-    auto qof = [&](size_t k) { return H.fr[H.pair_range[k]].qidx; };
-    parallel(P, [&](size_t lo, size_t hi) {
-      for (size_t k = lo; k < hi; k++) {
-        const uint32_t q = qof(k);
-        const int64_t prev = k ? (int64_t)qof(k - 1) : -1;
-        if (q >= n || (int64_t)q < prev) { ok = false; return; }
-        for (int64_t x = prev + 1; x <= (int64_t)q; x++) seg[l][(size_t)x] = k;  // ranges without hits share the next start
-      }
-    });
-    by_range = ok.load();
-  }
-  std::vector<uint64_t> cnt(n + 1, 0);
-  auto self_rows = [&](uint32_t q) -> uint64_t {
-    if (!transitive) return 1;                                   // impg.rs:1864-1880
-    uint64_t c = 0;
-    for (uint32_t k = self_off[q]; k < self_off[q + 1]; k++) c += self[k].start < self[k].end ? 1 : 0;  // impg.rs:2345-2363
-    return c;
-  };
-  // pass 1: counts
-  if (by_range) {
-    parallel(n, [&](size_t lo, size_t hi) {
-      for (size_t q = lo; q < hi; q++) {
-        uint64_t c = self_rows((uint32_t)q);
-        for (size_t l = 0; l < nl; l++)
-          for (uint64_t k = seg[l][q]; k < seg[l][q + 1]; k++) c += emitted(hl[l], k) ? 1 : 0;
-        cnt[q] = c;
-      }
-    });
-  } else {
-    for (uint32_t q = 0; q < n; q++) cnt[q] = self_rows(q);
-    for (auto &H : hl)
-      for (size_t k = 0; k < H.qid.size(); k++)
-        if (emitted(H, k)) cnt[H.fr[H.pair_range[k]].qidx]++;
-  }
-  res.offsets.assign(n + 1, 0);
-  for (uint32_t q = 0; q < n; q++) res.offsets[q + 1] = res.offsets[q] + cnt[q];
-  res.intervals.resize(res.offsets[n]);
   res.has_cigar = p.store_cigar != 0;
-  // with store_cigar every interval carries an op list; collected per interval first
-  std::vector<std::vector<uint32_t>> cg;
-  if (res.has_cigar) cg.resize(res.intervals.size());
-  std::vector<uint64_t> cur(res.offsets.begin(), res.offsets.end() - 1);
-  auto put_self = [&](uint32_t q) {
-    if (!transitive) {
-      const auto &r = h_ranges[q];
-      if (res.has_cigar) cg[cur[q]] = {(uint32_t)(r.end - r.start)};  // vec![CigarOp::new(range_end - range_start, '=')] (impg.rs:1870-1872)
-      res.intervals[cur[q]++] = {r.target_id, r.start, r.end, r.target_id, r.start, r.end};
-    } else for (uint32_t k = self_off[q]; k < self_off[q + 1]; k++) {
-      const FrontierRec &f = self[k];
-      if (f.start >= f.end) continue;
-      if (res.has_cigar) cg[cur[q]] = {(uint32_t)(f.end - f.start)};  // impg.rs:2352-2354
-      res.intervals[cur[q]++] = {f.target_id, f.start, f.end, f.target_id, f.start, f.end};
-    }
-  };
-  auto put_hit = [&](const HostLevel &H, size_t k) {
-    const FrontierRec &f = H.fr[H.pair_range[k]];
-    if (res.has_cigar) cg[cur[f.qidx]].assign(H.pool.begin() + H.sl_pos[k], H.pool.begin() + H.sl_pos[k] + H.sl_n[k]);
-    res.intervals[cur[f.qidx]++] = {H.qid[k], H.c[k].x, H.c[k].y, f.target_id, H.c[k].z, H.c[k].w};
-  };
-  // pass 2: per range the self interval(s), then levels in order, slots in order == the reference's emission order
-  if (by_range) {
-    parallel(n, [&](size_t lo, size_t hi) {
-      for (size_t q = lo; q < hi; q++) {
-        put_self((uint32_t)q);
-        for (size_t l = 0; l < nl; l++)
-          for (uint64_t k = seg[l][q]; k < seg[l][q + 1]; k++)
-            if (emitted(hl[l], k)) put_hit(hl[l], k);
-      }
-    });
-  } else {
-    for (uint32_t q = 0; q < n; q++) put_self(q);
-    for (auto &H : hl)
-      for (size_t k = 0; k < H.qid.size(); k++)
-        if (emitted(H, k)) put_hit(H, k);
-  }
+  RowPlan pl;
+  plan_rows(E, n, p, levels, self_dev, false, pl);
+  const size_t nr = pl.n_rows;
+  DevBuf rows, clen, coff, cpool;
+  for (DevBuf *b : {&rows, &clen, &coff, &cpool}) b->pool = &E.level_pool;
+  rows.reserve(std::max<size_t>(nr * sizeof(impg_gpu_interval_t), 256));
+  if (res.has_cigar) clen.reserve(std::max<size_t>(nr * 4, 256));
+  scatter_rows(E, levels, pl, RowSinks{rows.as<impg_gpu_interval_t>(), nullptr, nullptr, nullptr, nullptr,
+                                       res.has_cigar ? clen.as<uint32_t>() : nullptr});
+  res.intervals.resize(nr, true);
+  std::vector<uint32_t> off32((size_t)n + 1);
+  IMPG_HIP(hipMemcpyAsync(off32.data(), pl.offsets.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, s));
+  if (nr) IMPG_HIP(hipMemcpyAsync(res.intervals.data(), rows.p, nr * sizeof(impg_gpu_interval_t), hipMemcpyDeviceToHost, s));
   if (res.has_cigar) {
-    res.cigar_off.assign(1, 0);
-    for (auto &c : cg) {
-      res.cigar_ops.insert(res.cigar_ops.end(), c.begin(), c.end());
-      res.cigar_off.push_back(res.cigar_ops.size());
-    }
+    const uint64_t n_ops = build_row_cigars(E, levels, pl, clen, coff, cpool);
+    res.cigar_off.resize(nr + 1, true);
+    res.cigar_ops.resize(n_ops, true);
+    IMPG_HIP(hipMemcpyAsync(res.cigar_off.data(), coff.p, (nr + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (n_ops) IMPG_HIP(hipMemcpyAsync(res.cigar_ops.data(), cpool.p, n_ops * 4, hipMemcpyDeviceToHost, s));
   }
+  IMPG_HIP(hipStreamSynchronize(s));
+  levels.clear();
+  res.offsets.resize((size_t)n + 1);
+  for (size_t q = 0; q <= n; q++) res.offsets[q] = off32[q];
   res.projected = E.last_projected;
 }
 
@@ -301,24 +177,36 @@ void check_ranges(const impg_gpu_range_t *ranges, size_t n) {
   for (size_t i = 0; i < n; i++)
     if (ranges[i].start >= ranges[i].end) throw Error{IMPG_E_INVALID, "query range must satisfy start < end"};
 }
+// part's rows behind res's.  The first part hands its arrays over; later ones are copied behind them (the
+// destination grows geometrically, pinned like its parts).
+template <class T> static void append_arr(HostArr<T> &dst, HostArr<T> &src, size_t drop_front = 0) {
+  if (dst.empty() && !drop_front) { dst.swap(src); return; }
+  const size_t add = src.size() - drop_front, base = dst.size();
+  if ((base + add) * sizeof(T) > dst.cap) dst.reserve(std::max(base + add, base + base / 2), dst.pinned || src.pinned);
+  dst.n = base + add;
+  parallel_memcpy(dst.data() + base, src.data() + drop_front, add * sizeof(T));
+}
 void append_results(impg_gpu_results &res, impg_gpu_results &part) {
   if (res.offsets.empty()) res.offsets.assign(1, 0);
+  if (part.offsets.empty()) part.offsets.assign(1, 0);
   const uint64_t base = res.intervals.size();
-  if (base == 0 && res.offsets.size() == 1) {  // the first (often the only) part: take its arrays, no copy
-    res.intervals.swap(part.intervals);
-    res.offsets.swap(part.offsets);
-    if (res.offsets.empty()) res.offsets.assign(1, 0);
-  } else {
-    res.intervals.insert(res.intervals.end(), part.intervals.begin(), part.intervals.end());
-    for (size_t i = 1; i < part.offsets.size(); i++) res.offsets.push_back(base + part.offsets[i]);
-  }
   if (part.has_cigar) {
     res.has_cigar = true;
-    if (res.cigar_off.empty()) res.cigar_off.assign(1, 0);
+    if (res.cigar_off.empty()) res.cigar_off.assign((size_t)1, (uint64_t)0);
     const uint64_t cb = res.cigar_ops.size();
-    res.cigar_ops.insert(res.cigar_ops.end(), part.cigar_ops.begin(), part.cigar_ops.end());
-    for (size_t i = 1; i < part.cigar_off.size(); i++) res.cigar_off.push_back(cb + part.cigar_off[i]);
+    const size_t at = res.cigar_off.size();
+    if (part.cigar_off.size() > 1) {
+      if (at == 1 && cb == 0) res.cigar_off.swap(part.cigar_off);
+      else {
+        append_arr(res.cigar_off, part.cigar_off, 1);
+        for (size_t i = at; i < res.cigar_off.size(); i++) res.cigar_off[i] += cb;
+      }
+    }
+    append_arr(res.cigar_ops, part.cigar_ops);
   }
+  append_arr(res.intervals, part.intervals);
+  if (base == 0 && res.offsets.size() == 1) res.offsets.swap(part.offsets);
+  else for (size_t i = 1; i < part.offsets.size(); i++) res.offsets.push_back(base + part.offsets[i]);
   res.projected += part.projected;
   res.run_s += part.run_s;
   res.assemble_s += part.assemble_s;

@@ -499,7 +499,8 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   if (store_cigar && ix.tp_mode)
     throw Error{IMPG_E_UNSUPPORTED, "store_cigar is not offered on a tracepoint index (the approximate mode has no CIGAR to slice)"};
   multi = p.multi_impg != 0;
-  free_slot_order = keep == nullptr && free_slots_allowed;
+  // (kept levels too: the device-side row placement, rows_device.hip, only needs a record's slots to be one run)
+  free_slot_order = free_slots_allowed;
   const DeviceIndexView &v = ix.view;
   cur_ranges = d_ranges;
   ev_next = 0;

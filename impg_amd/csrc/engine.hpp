@@ -76,11 +76,13 @@ struct Engine {
   double min_identity = __builtin_nan("");  // of the batch / stage call in flight
   bool store_cigar = false;
   bool multi = false;       // MultiImpg semantics for the batch in flight (params.multi_impg)
-  // Counting runs (no level is kept): nobody reads the slots by position -- the visited update only needs the hits of
-  // one query in frontier order x visit order, and the lookup order preserves exactly that (its key is monotone in
-  // (target, start), the order of a query's frontier; ties keep frontier order).  The slots are then laid out in
+  // Nobody reads the slots by position: the visited update only needs the hits of one query in frontier order x
+  // visit order, and the lookup order preserves exactly that (its key is monotone in (target, start), the order of
+  // a query's frontier; ties keep frontier order); the result rows are placed record by record (rows_device.hip),
+  // which only needs a frontier record's slots to be one run in visit order.  The slots are therefore laid out in
   // projection order: the emit pass writes two coalesced lists instead of four arrays, and the projection kernel
-  // reads and writes them at its own index.
+  // reads and writes them at its own index.  (Not under store_cigar / MultiImpg, whose slice materialisation and
+  // five-key sort walk the reference's slot order.)
   bool free_slot_order = false;
   bool free_slots_allowed = true;  // option "free_slot_order" (A/B runs)
   bool regroup_pairs = true;       // option "regroup_entries": a projection block sorts its 256 pairs by entry first
@@ -189,6 +191,28 @@ std::unique_ptr<impg_gpu_index> make_index(const impg_gpu_record_t *records, siz
                                            const uint32_t *owner);
 void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p,
                       std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, impg_gpu_results &res);
+// ---- result rows on the device (rows_device.hip) ---------------------------------------------------------------
+// Where every emitted slot of a chunk goes among the chunk's result rows (grouped by range, emission order within).
+struct RowPlan {
+  DevBuf flag, pos;            // per slot over [self records | level 0 | level 1 | ...]
+  DevBuf rec_start, rec_dest;  // per record over [self records | level 0's frontier | ...]: pos of its first slot, its first row
+  DevBuf offsets;              // [n_ranges + 1] u32: first row of every range
+  uint64_t n_slots = 0, n_recs = 0;
+  uint32_t n_rows = 0, n_self = 0;
+  const FrontierRec *d_self = nullptr;
+};
+struct RowSinks {  // any of the two forms (null = not wanted)
+  impg_gpu_interval_t *rows;      // the trait's rows
+  uint32_t *q, *qid, *tid;        // SoA: range, query sequence, target sequence ...
+  int4 *c;                        // ... {q_first, q_last, t_first, t_last} (the BED merges work on these)
+  uint32_t *clen;                 // store_cigar: number of ops of the row's CIGAR
+};
+// plain_retain: a plain query's rows also pass perform_query's min_output_length retain (main.rs:11682-11688: the text writers)
+void plan_rows(Engine &E, uint32_t n_ranges, const impg_gpu_params_t &p, std::vector<std::unique_ptr<LevelBufs>> &levels,
+               DevBuf &self_dev, bool plain_retain, RowPlan &pl);
+void scatter_rows(Engine &E, std::vector<std::unique_ptr<LevelBufs>> &levels, const RowPlan &pl, const RowSinks &out);
+uint64_t build_row_cigars(Engine &E, std::vector<std::unique_ptr<LevelBufs>> &levels, const RowPlan &pl, const DevBuf &clen, DevBuf &coff,
+                          DevBuf &pool);
 void append_results(impg_gpu_results &res, impg_gpu_results &part);  // part's rows behind res's (chunks, ranks)
 void check_ranges(const impg_gpu_range_t *ranges, size_t n);
 // masked_regions / subset filter of a batch -> an engine's device tables (cleared when the engine's lease ends)

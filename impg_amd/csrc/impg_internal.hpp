@@ -3,7 +3,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
+#include <new>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -166,6 +169,66 @@ struct DevBuf {
   DevBuf &operator=(const DevBuf &) = delete;
 };
 
+// ---- host arrays a result hands to the caller (host_mem.cpp) ---------------------------------
+// Large result arrays are the destination of one device-to-host copy: they live in pinned blocks that are recycled
+// through a process-wide pool (pinning 5 GB costs seconds, a recycled block nothing); small ones are plain malloc.
+void *pinned_take(size_t bytes, size_t &cap_out);
+void pinned_give(void *p, size_t cap);
+constexpr size_t PINNED_MIN_BYTES = 1u << 20;
+template <class T> struct HostArr {
+  T *p = nullptr;
+  size_t n = 0, cap = 0;   // elements in use / bytes held
+  bool pinned = false;
+  HostArr() = default;
+  HostArr(const HostArr &) = delete;
+  HostArr &operator=(const HostArr &) = delete;
+  ~HostArr() { release(); }
+  void release() {
+    if (p) { if (pinned) pinned_give(p, cap); else free(p); }
+    p = nullptr; n = 0; cap = 0; pinned = false;
+  }
+  // room for `count` elements; contents are kept.  want_pinned: a DMA target (honoured from PINNED_MIN_BYTES on)
+  void reserve(size_t count, bool want_pinned = false) {
+    const size_t bytes = count * sizeof(T);
+    if (bytes <= cap) return;
+    T *np;
+    size_t ncap;
+    const bool pin = want_pinned && bytes >= PINNED_MIN_BYTES;
+    if (pin) np = static_cast<T *>(pinned_take(bytes, ncap));
+    else {
+      ncap = std::max<size_t>(bytes, 64);
+      np = static_cast<T *>(malloc(ncap));
+      if (!np) throw std::bad_alloc();
+    }
+    if (n) memcpy(np, p, n * sizeof(T));
+    const size_t keep = n;
+    release();
+    p = np; cap = ncap; pinned = pin; n = keep;
+  }
+  void resize(size_t count, bool want_pinned = false) { reserve(count, want_pinned); n = count; }  // new elements are NOT initialised
+  void push_back(const T &v) {
+    if ((n + 1) * sizeof(T) > cap) reserve(std::max<size_t>(2 * n, 16));
+    p[n++] = v;
+  }
+  void assign(const T *b, const T *e) { n = 0; resize((size_t)(e - b)); if (e > b) memcpy(p, b, (size_t)(e - b) * sizeof(T)); }
+  void assign(size_t count, const T &v) { n = 0; resize(count); for (size_t i = 0; i < count; i++) p[i] = v; }
+  void clear() { n = 0; }
+  void swap(HostArr &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); std::swap(pinned, o.pinned); }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  T *begin() { return p; }
+  T *end() { return p + n; }
+  const T *begin() const { return p; }
+  const T *end() const { return p + n; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+  T &back() { return p[n - 1]; }
+};
+// dst[0, bytes) = src, on several threads when it is worth it (concatenating the parts of a result)
+void parallel_memcpy(void *dst, const void *src, size_t bytes);
+
 // ---- host ingest -------------------------------------------------------------
 struct ParsedPaf {
   HostSeqIndex seq;
@@ -280,11 +343,11 @@ struct impg_gpu_index {
 
 struct impg_gpu_results {
   std::vector<uint64_t> offsets;
-  std::vector<impg_gpu_interval_t> intervals;
+  impg::HostArr<impg_gpu_interval_t> intervals;
   std::vector<impg_gpu_range_t> ranges;
   bool has_cigar = false;
-  std::vector<uint64_t> cigar_off;  // [intervals+1] when has_cigar
-  std::vector<uint32_t> cigar_ops;
+  impg::HostArr<uint64_t> cigar_off;  // [intervals+1] when has_cigar
+  impg::HostArr<uint32_t> cigar_ops;
   uint64_t projected = 0;
   double run_s = 0, assemble_s = 0;  // wall time in the engine (GPU) and in the host-side result assembly
 };

@@ -366,6 +366,10 @@ size_t impg_gpu_target_ids(const impg_gpu_index_t *ix, uint32_t *out, size_t cap
 size_t impg_gpu_num_entries(const impg_gpu_index_t *ix) { return ix->n_entries; }
 size_t impg_gpu_num_records(const impg_gpu_index_t *ix) { return ix->n_records; }
 size_t impg_gpu_device_bytes(const impg_gpu_index_t *ix) { return ix->device_bytes; }
+int impg_gpu_index_approximate(const impg_gpu_index_t *ix) {
+  if (ix->cluster) return 0;  // (tracepoint indexes are single-GPU)
+  return ix->tp_mode ? 1 : 0;
+}
 
 int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
   IMPG_TRY
@@ -384,6 +388,12 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
     ix->opt_regroup = value != 0;
   } else if (k == "free_slot_order") {  // counting runs lay their slots out in projection order (1, default) or keep the reference order (0)
     ix->opt_free_slots = value != 0;
+  } else if (k == "debug_fail_owner" || k == "debug_fail_home") {  // tests: (rank + 1) << 16 | hop (sharded indexes; 0 = off)
+    if (value < 0 || value > 0xFFFFFFFFll) throw Error{IMPG_E_INVALID, "debug_fail_* out of range"};
+    (k == "debug_fail_owner" ? ix->opt_debug_fail_owner : ix->opt_debug_fail_home) = (uint32_t)value;
+  } else if (k == "lane_schedule") {  // tests: forced lane start / hand-over order of a sharded batch (0 = off)
+    if (value < 0) throw Error{IMPG_E_INVALID, "lane_schedule out of range"};
+    ix->opt_lane_schedule = (uint64_t)value;
   } else throw Error{IMPG_E_INVALID, "unknown option " + k};
   return IMPG_OK;
   IMPG_CATCH

@@ -72,6 +72,7 @@ struct Rccl {
   int (*GetUniqueId)(void *) = nullptr;
   int (*CommInitRank)(void **, int, Uid, int) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
+  int (*CommAbort)(void *) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -97,6 +98,7 @@ Rccl &rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.Send = (decltype(r.Send))sym("ncclSend");
@@ -113,6 +115,57 @@ void nccl_check(int rc, const char *what) {
 }
 }  // namespace
 
+// ---- issue order of a rank's lanes (comm.hpp) ----
+void IssueOrder::pass_from(int lane) {
+  const int n = (int)active.size();
+  for (int k = 1; k <= n; k++) {
+    const int l = (lane + k) % n;
+    if (active[(size_t)l]) { turn = l; return; }
+  }
+  in_batch = false;  // nobody left
+}
+void IssueOrder::begin(int lane, bool takes_part) {
+  std::lock_guard<std::mutex> lk(m);
+  if (!in_batch) { in_batch = true; turn = -1; }
+  active[(size_t)lane] = takes_part ? 1 : 0;
+  // the first turn belongs to the lowest lane that takes part (every lane's begin runs before any lane issues)
+  turn = -1;
+  for (size_t l = 0; l < active.size(); l++) if (active[l]) { turn = (int)l; break; }
+  if (turn < 0) in_batch = false;
+  cv.notify_all();
+}
+void IssueOrder::end(int lane) {
+  std::lock_guard<std::mutex> lk(m);
+  if (!active[(size_t)lane]) return;
+  active[(size_t)lane] = 0;
+  if (turn == lane) pass_from(lane);
+  else {
+    bool any = false;
+    for (char a : active) any = any || a;
+    if (!any) in_batch = false;
+  }
+  cv.notify_all();
+}
+void IssueOrder::acquire(int lane) {
+  std::unique_lock<std::mutex> lk(m);
+  cv.wait(lk, [&] { return !in_batch || !active[(size_t)lane] || turn == lane; });
+}
+void IssueOrder::release(int lane) {
+  std::lock_guard<std::mutex> lk(m);
+  if (in_batch && active[(size_t)lane] && turn == lane) pass_from(lane);
+  cv.notify_all();
+}
+namespace {
+struct Turn {  // a lane's turn to enqueue, given up when the enqueueing is done (or fails)
+  IssueOrder *o;
+  int lane;
+  bool held = true;
+  Turn(IssueOrder *o_, int lane_) : o(o_), lane(lane_) { if (o) o->acquire(lane); }
+  void done() { if (o && held) o->release(lane); held = false; }
+  ~Turn() { done(); }
+};
+}  // namespace
+
 void rccl_unique_id(uint8_t *id128) {
   memset(id128, 0, RCCL_UNIQUE_ID_BYTES);
   nccl_check(rccl().GetUniqueId(id128), "ncclGetUniqueId");
@@ -126,12 +179,21 @@ RcclComm::RcclComm(const uint8_t *id128, int rank_, int world_, int device_) : d
   nccl_check(rccl().CommInitRank(&comm, world, uid, rank), "ncclCommInitRank");
   IMPG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
 }
+void RcclComm::abort() {
+  if (comm && !dead) {
+    dead = true;
+    if (rccl().CommAbort) (void)rccl().CommAbort(comm);  // frees the communicator; peers' pending operations fail or time out
+    comm = nullptr;
+  }
+  if (order) order->end(lane);
+}
 RcclComm::~RcclComm() {
   if (comm) (void)rccl().CommDestroy(comm);
   if (h_vals) (void)hipHostFree(h_vals);
   if (cs) (void)hipStreamDestroy(cs);
 }
 void RcclComm::allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) {
+  if (dead) throw Error{IMPG_E_HIP, "the RCCL communicator was aborted after an earlier failure"};
   IMPG_HIP(hipSetDevice(device));
   const size_t need = (size_t)(world + 1) * k * 8;
   if (need > h_cap) {
@@ -143,15 +205,20 @@ void RcclComm::allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) {
   hipStream_t s = cs;
   memcpy(h_vals, mine, k * 8);
   uint64_t *d_mine = d_vals.as<uint64_t>(), *d_all = d_mine + k;
-  IMPG_HIP(hipMemcpyAsync(d_mine, h_vals, k * 8, hipMemcpyHostToDevice, s));
-  nccl_check(rccl().AllGather(d_mine, d_all, k, NCCL_UINT64, comm, s), "ncclAllGather");
-  IMPG_HIP(hipMemcpyAsync(h_vals + k, d_all, (size_t)world * k * 8, hipMemcpyDeviceToHost, s));
+  {
+    Turn turn(order.get(), lane);
+    IMPG_HIP(hipMemcpyAsync(d_mine, h_vals, k * 8, hipMemcpyHostToDevice, s));
+    nccl_check(rccl().AllGather(d_mine, d_all, k, NCCL_UINT64, comm, s), "ncclAllGather");
+    IMPG_HIP(hipMemcpyAsync(h_vals + k, d_all, (size_t)world * k * 8, hipMemcpyDeviceToHost, s));
+  }
   IMPG_HIP(hipStreamSynchronize(s));
   memcpy(all, h_vals + k, (size_t)world * k * 8);
 }
 void RcclComm::alltoallv(const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
                          const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) {
+  if (dead) throw Error{IMPG_E_HIP, "the RCCL communicator was aborted after an earlier failure"};
   IMPG_HIP(hipSetDevice(device));
+  Turn turn(order.get(), lane);
   // one message per peer and round, <= 256 MiB each: bounded staging inside RCCL, and far below the size at
   // which a single all-to-all message was seen corrupted on this stack in round 1 (> 1 GiB)
   constexpr uint64_t ROUND = 256ull << 20;
@@ -175,6 +242,7 @@ void RcclComm::alltoallv(const void *d_send, const uint64_t *send_off, const uin
     }
     nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
   }
+  turn.done();  // enqueued: the next lane may issue while this exchange runs
   IMPG_HIP(hipStreamSynchronize(s));
 }
 void RcclComm::barrier() {

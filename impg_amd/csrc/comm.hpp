@@ -33,8 +33,16 @@ struct Comm {
   virtual void alltoallv(const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
                          const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) = 0;
   virtual void barrier() = 0;
-  virtual void abort() {}  // this rank failed: release peers that wait for it, where the transport can
+  // This rank failed INSIDE the transport (a failure outside it is announced through the next all-gather instead,
+  // sharded.cpp "failure agreement"): release peers that wait for it, where the transport can.  LocalComm poisons
+  // its fabric, RcclComm calls ncclCommAbort (the communicator is dead afterwards); a host transport must bring its
+  // own timeout -- the callbacks are the host's.
+  virtual void abort() {}
   virtual void reset() {}  // before a new batch, with no rank inside the transport: forget an earlier abort
+  // The lanes of one rank issue their collectives in one agreed order (RcclComm: see IssueOrder); a batch tells the
+  // transport which lanes take part, and each lane when it has issued its last collective.
+  virtual void batch_begin(bool /*takes_part*/) {}
+  virtual void batch_end() {}
   virtual const char *kind() const = 0;
 };
 
@@ -89,9 +97,31 @@ struct LocalComm : Comm {
 // ---- RCCL ------------------------------------------------------------------------
 constexpr size_t RCCL_UNIQUE_ID_BYTES = 128;  // ncclUniqueId
 void rccl_unique_id(uint8_t *id128);          // rank 0 makes it; the host carries it to the other ranks
+// Every lane of a rank drives its own RCCL communicator from its own host thread.  Communicators that share a device
+// must see their operations ISSUED in the same order on every rank or they can deadlock (each waits for resources
+// the other holds on some rank).  The lanes' collective sequences are identical on all ranks (same chunks per lane,
+// collective hops), so a round-robin over the lanes by operation index -- lanes dropping out when their batch work is
+// done -- is an order every rank derives by itself.  A lane holds its turn only while it enqueues (not while it
+// waits for completion), and never while it holds the GPU turn of sharded.cpp.
+struct IssueOrder {
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<char> active;  // lanes taking part in the batch in flight that have collectives left
+  int turn = 0;
+  bool in_batch = false;
+  explicit IssueOrder(int lanes) : active((size_t)lanes, 0) {}
+  void begin(int lane, bool takes_part);
+  void end(int lane);
+  void acquire(int lane);
+  void release(int lane);
+  void pass_from(int lane);  // (m held) the turn goes to the next active lane after `lane`
+};
 struct RcclComm : Comm {
   void *comm = nullptr;  // ncclComm_t
   int device;
+  std::shared_ptr<IssueOrder> order;  // shared by the lanes of this rank (null: a single lane)
+  int lane = 0;
+  bool dead = false;  // aborted after a failure inside the transport
   DevBuf d_vals;
   uint64_t *h_vals = nullptr;  // pinned
   size_t h_cap = 0;
@@ -102,6 +132,9 @@ struct RcclComm : Comm {
   void alltoallv(const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
                  const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) override;
   void barrier() override;
+  void abort() override;
+  void batch_begin(bool takes_part) override { if (order) order->begin(lane, takes_part); }
+  void batch_end() override { if (order) order->end(lane); }
   const char *kind() const override { return "rccl"; }
 };
 

@@ -38,6 +38,7 @@ bool Engine::run_small(const impg_gpu_index &ix, const impg_gpu_range_t *h_range
   // (MultiImpg's plain query sorts its hits by five keys, multi_impg.rs:556-592: the general path does that)
   if (n == 0 || n > SMALL_RANGES || p.transitive || p.store_cigar || p.multi_impg || masked || subset_on || remote) return false;
   // every candidate pair of a range is an entry of its target: the sum of those segments bounds the pairs, on the host
+  if (ix.h_tgt_off.size() != (size_t)ix.view.n_seq + 1) return false;  // (no table to bound the grid with: the general path counts on the device)
   uint64_t bound = 0;
   for (uint32_t i = 0; i < n; i++) {
     const uint32_t t = h_ranges[i].target_id;

@@ -333,6 +333,10 @@ struct impg_gpu_index {
   int max_engines = 4;
   uint64_t opt_pair_budget = 1ull << 28;  // impg_gpu_set_option values, applied to an engine when it is leased
   uint32_t opt_chunk_ranges = 0, opt_locality_min = 4096;
+  // failure injection for the tests of the multi-rank failure agreement (0 = off): (rank + 1) << 16 | hop of the batch
+  // (1-based, counted per lane) at which that rank throws on the owner side / on the home side of the hop
+  uint32_t opt_debug_fail_owner = 0, opt_debug_fail_home = 0;
+  uint64_t opt_lane_schedule = 0;  // IMPG_LANE_SCHEDULE / option "lane_schedule": see run_lanes (sharded.cpp); 0 = off
   bool opt_free_slots = true;
   bool opt_regroup = true;
   impg::ShardCtx *shard = nullptr;    // set: this index is one rank's shard; queries are collective calls

@@ -16,7 +16,8 @@ namespace impg {
 namespace {
 
 constexpr char MAGIC[8] = {'I', 'M', 'P', 'G', 'H', 'B', 'M', '1'};
-constexpr uint32_t VERSION = 3;  // 2: checksum of the arrays behind the end mark; 3: tile padding words carry length 0, prefix lines
+constexpr uint32_t VERSION = 4;  // 2: checksum of the arrays behind the end mark; 3: tile padding words carry length 0, prefix lines;
+                                 // 4: the checksum also covers the header and the host tables, and the per-target offsets are mandatory
 
 struct Header {  // fixed-size, little-endian (gfx950 hosts are x86-64)
   char magic[8];
@@ -25,9 +26,12 @@ struct Header {  // fixed-size, little-endian (gfx950 hosts are x86-64)
   uint64_t blob_bytes[impg_gpu_index::N_BLOBS];
 };
 
+uint64_t fnv64(uint64_t h, const void *p, size_t n);
+constexpr uint64_t FNV_SEED = 0xCBF29CE484222325ull;
 struct File {
   FILE *f = nullptr;
   std::string path;
+  uint64_t sum = FNV_SEED;  // over everything written / read so far, call by call (save and load make the same calls)
   File(const char *p, const char *mode) : path(p) {
     f = fopen(p, mode);
     if (!f) throw Error{IMPG_E_IO, "cannot open " + path + ": " + strerror(errno)};
@@ -35,9 +39,11 @@ struct File {
   ~File() { if (f) fclose(f); }
   void write(const void *p, size_t n) {
     if (n && fwrite(p, 1, n, f) != n) throw Error{IMPG_E_IO, "short write to " + path};
+    sum = fnv64(sum, p, n);
   }
   void read(void *p, size_t n) {
     if (n && fread(p, 1, n, f) != n) throw Error{IMPG_E_IO, path + " is truncated"};
+    sum = fnv64(sum, p, n);
   }
 };
 
@@ -52,7 +58,6 @@ uint64_t fnv64(uint64_t h, const void *p, size_t n) {  // FNV-1a over 8-byte wor
   for (; i < n; i++) h = (h ^ b[i]) * 0x100000001B3ull;
   return h;
 }
-constexpr uint64_t FNV_SEED = 0xCBF29CE484222325ull;
 
 }  // namespace
 
@@ -75,8 +80,8 @@ void save_index(const impg_gpu_index &cix, const char *path) {
     bool keep = false;
     ~Unlink() { if (!keep) (void)unlink(p.c_str()); }
   } guard{tmp};
+  if (ix.h_tgt_off.size() != (size_t)ix.view.n_seq + 1) throw Error{IMPG_E_INVALID, "internal: the index has no per-target offsets"};
   File out(tmp.c_str(), "wb");
-  uint64_t sum = FNV_SEED;
   out.write(&h, sizeof h);
   out.write(ix.seq.lens.data(), ix.seq.lens.size() * sizeof(int64_t));
   for (const std::string &nm : ix.seq.names) {
@@ -91,11 +96,11 @@ void save_index(const impg_gpu_index &cix, const char *path) {
     const size_t n = ix.blob_bytes[k];
     buf.resize(n);
     if (n) IMPG_HIP(hipMemcpy(buf.data(), ix.blob(k)->p, n, hipMemcpyDeviceToHost));
-    sum = fnv64(sum, buf.data(), n);
     out.write(buf.data(), n);
   }
   const uint64_t tail = 0x454E44474D50ull ^ h.n_entries;  // an end mark: a file cut short is caught even if sizes line up
   out.write(&tail, 8);
+  const uint64_t sum = out.sum;  // header, sequence table, file and target tables, arrays, end mark
   out.write(&sum, 8);
   if (fflush(out.f) != 0 || fsync(fileno(out.f)) != 0) throw Error{IMPG_E_IO, "cannot flush " + out.path};
   fclose(out.f);
@@ -131,7 +136,8 @@ void load_index(impg_gpu_index &ix, const char *path) {
       total += h.blob_bytes[k];
     }
     if (total > file_bytes) throw Error{IMPG_E_INVALID, in.path + " is truncated"};
-    if (h.n_tgt_off != 0 && h.n_tgt_off != S + 1) throw Error{IMPG_E_INVALID, in.path + ": bad table sizes"};
+    // (the small-batch path sizes its projection grid from these offsets, Engine::run_small: they are not optional)
+    if (h.n_tgt_off != S + 1) throw Error{IMPG_E_INVALID, in.path + ": bad table sizes"};
   }
   IMPG_HIP(hipSetDevice(ix.device));
   ix.n_records = h.n_records; ix.n_entries = h.n_entries; ix.n_tiles = h.n_tiles; ix.n_targets = h.n_targets;
@@ -161,13 +167,11 @@ void load_index(impg_gpu_index &ix, const char *path) {
   if (!ix.h_tgt_off.empty() && ix.h_tgt_off.back() != h.n_entries) throw Error{IMPG_E_INVALID, in.path + ": target offsets do not end at the entry count"};
   std::vector<char> buf;
   size_t acc = 0;
-  uint64_t sum = FNV_SEED;
   for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) {
     const size_t n = h.blob_bytes[k];
     if (n > (1ull << 40)) throw Error{IMPG_E_INVALID, in.path + ": unreasonable array size"};
     buf.resize(n);
     in.read(buf.data(), n);
-    sum = fnv64(sum, buf.data(), n);
     if (k == 0) {  // the segment table addresses every other array: it must stay inside them
       const SegDesc *sg = reinterpret_cast<const SegDesc *>(buf.data());
       const uint64_t lvl_words = h.blob_bytes[5] / 4;
@@ -186,9 +190,10 @@ void load_index(impg_gpu_index &ix, const char *path) {
   uint64_t tail = 0;
   in.read(&tail, 8);
   if (tail != (0x454E44474D50ull ^ h.n_entries)) throw Error{IMPG_E_INVALID, in.path + " is damaged (end mark)"};
+  const uint64_t sum = in.sum;
   uint64_t want_sum = 0;
   in.read(&want_sum, 8);
-  if (want_sum != sum) throw Error{IMPG_E_INVALID, in.path + " is damaged (checksum of the arrays)"};
+  if (want_sum != sum) throw Error{IMPG_E_INVALID, in.path + " is damaged (checksum of the header, tables and arrays)"};
   ix.device_bytes = acc;
   ix.bind_view(h.n_seq, h.sorted_order);
 }

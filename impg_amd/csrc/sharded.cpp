@@ -24,6 +24,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
 #include <exception>
 #include <numeric>
 #include <thread>
@@ -75,9 +78,30 @@ struct ShardedExpander : Expander {
   // tiles from L2 (the window-order locality every kernel here leans on) and ran 3.5x slower than back to back.
   // A lane gives the GPU up exactly while it sits in the transport, which is the overlap lanes exist for.
   std::mutex *gpu_turn = nullptr;
+  // Failure agreement.  A rank that fails OUTSIDE the transport must not leave its peers waiting in the next
+  // collective: the all-gathers of a hop carry a status word, a failure on the owner side of a hop is reported
+  // in the hop's second all-gather, one anywhere else in the lane's next all-gather (announce_failure, from
+  // run_lanes), and every rank leaves the batch with an error at the same point of the protocol (`agreed`:
+  // nothing more is to be said on this lane).  A failure INSIDE the transport (`in_transport`) cannot be announced
+  // through it: the lane aborts its communicator instead (Comm::abort).
+  bool agreed = false, in_transport = false;
+  uint32_t hop_no = 0, fail_owner_hop = 0, fail_home_hop = 0;  // failure injection (tests): hop counter of the batch, hops at which to throw
+  static constexpr uint64_t ST_ALIVE = 1, ST_FAILED = 2;
 
   ~ShardedExpander() override {
     if (h_vals) (void)hipHostFree(h_vals);
+  }
+  // The lane's closing word of a batch (failed = false) or its announcement of a failure outside the transport:
+  // an all-gather of the shape every hop starts with, so that peers take it wherever they are -- at their next hop
+  // or at their own closing word.
+  void closing_word(bool failed) {
+    const size_t K = (size_t)comm->world + 1;
+    std::vector<uint64_t> mine(K, 0), mat(K * (size_t)comm->world);
+    mine[comm->world] = failed ? ST_FAILED : 0;
+    comm->allgather_u64(mine.data(), K, mat.data());
+    if (failed) return;
+    for (int r = 0; r < comm->world; r++)
+      if (mat[(size_t)r * K + comm->world] & ST_FAILED) { agreed = true; throw Error{IMPG_E_HIP, "a peer rank failed"}; }
   }
 
   void route(Engine &E, const FrontierRec *fr, uint32_t n, uint64_t *counts) {
@@ -112,6 +136,7 @@ struct ShardedExpander : Expander {
     try {
       f();
     } catch (...) {
+      in_transport = true;
       if (gpu_turn) gpu_turn->lock();
       throw;
     }
@@ -128,14 +153,24 @@ struct ShardedExpander : Expander {
     const size_t K = (size_t)W + 1;
     std::vector<uint64_t> mine(K, 0), mat(K * W);
     L.n_pairs = 0;
+    hop_no++;
     // ---- home: the frontier bucketed by owner; sizes and liveness to everybody
     send_fr.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
     if (n_fr) route(E, fr, n_fr, mine.data());
-    mine[W] = alive ? 1 : 0;
+    mine[W] = alive ? ST_ALIVE : 0;
     timed_comm([&] { comm->allgather_u64(mine.data(), K, mat.data()); });
     bool any = false;
-    for (int r = 0; r < W; r++) any = any || mat[(size_t)r * K + W] != 0;
+    for (int r = 0; r < W; r++) {
+      any = any || (mat[(size_t)r * K + W] & ST_ALIVE) != 0;
+      if (mat[(size_t)r * K + W] & ST_FAILED) { agreed = true; throw Error{IMPG_E_HIP, "a peer rank failed"}; }
+    }
     if (!any) return HopResult{0, true};
+    // (limits are checked for every rank from the gathered sizes, so that all ranks fail together)
+    for (int d = 0; d < W; d++) {
+      uint64_t to_d = 0;
+      for (int r = 0; r < W; r++) to_d += mat[(size_t)r * K + d];
+      if (to_d >= 0xFFFFFFF0ull) { agreed = true; throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 frontier records for one shard in one hop"}; }
+    }
     // ---- frontier records to the owners of their targets
     std::vector<uint64_t> so(W), sb(W), ro(W), rb(W), rstart(W + 1);
     uint64_t acc = 0, n_recv = 0;
@@ -146,17 +181,21 @@ struct ShardedExpander : Expander {
       n_recv += c;
     }
     rstart[W] = n_recv;
-    if (n_recv >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 frontier records for one shard in one hop"};
     recv_fr.reserve(std::max<size_t>(n_recv * sizeof(FrontierRec), 256));
     timed_comm([&] { comm->alltoallv(send_fr.p, so.data(), sb.data(), recv_fr.p, ro.data(), rb.data(), s); });
     bytes_out += acc * sizeof(FrontierRec);
     // ---- owner: expand what arrived, in slices under the pair budget
     const uint32_t words = (need_rows || E.multi) ? 8u : 4u;
-    std::vector<uint64_t> back(W, 0);
+    std::vector<uint64_t> back((size_t)W + 1, 0);  // hits per home rank + this rank's status word
     struct Piece { std::unique_ptr<DevBuf> buf; uint64_t n; };
     std::vector<Piece> pieces;
     uint64_t total_pairs = 0, total_hits = 0;
     const bool saved_split = E.split_ok;
+    const void *out_ptr = nullptr;
+    bool any_by_place = false;
+    std::exception_ptr deferred;  // an owner-side failure waits for the all-gather below, where every rank learns of it
+    try {
+    if (fail_owner_hop && hop_no == fail_owner_hop) throw Error{IMPG_E_INVALID, "injected failure (owner side)"};
     if ((size_t)(W + 1) * 4 > h_cap) {
       if (h_vals) (void)hipHostFree(h_vals);
       h_cap = std::max<size_t>((size_t)(W + 1) * 4, 4096);
@@ -166,7 +205,6 @@ struct ShardedExpander : Expander {
     // by home rank: the cheaper lookup and projection of Engine::free_slot_order.  Home puts the runs back in
     // frontier order whatever order they come in (reorder_runs), so nothing else changes.
     const bool owner_order = E.free_slot_order && !need_rows && !E.multi;
-    bool any_by_place = false;
     std::vector<uint32_t> hb((size_t)W + 1);
     if (owner_order) d_bounds.reserve(std::max<size_t>(((size_t)W + 1) * 4, 256));
     uint64_t a = 0, step = std::max<uint64_t>(n_recv, 1);
@@ -216,38 +254,58 @@ struct ShardedExpander : Expander {
       a += m;
     }
     E.split_ok = saved_split;
-    if (!need_hits) return HopResult{total_pairs, false};
-    if (total_hits >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 hits leave one shard in one hop"};
-    const void *out_ptr = nullptr;
-    if (pieces.size() == 1) {
-      out_ptr = pieces[0].buf->p;
-    } else {
-      hits_out.reserve(std::max<size_t>(total_hits * words * 4, 256));
-      uint64_t pos = 0;
-      for (auto &pc : pieces) {
-        IMPG_HIP(hipMemcpyAsync((char *)hits_out.p + pos * words * 4, pc.buf->p, pc.n * words * 4, hipMemcpyDeviceToDevice, s));
-        pos += pc.n;
+    if (need_hits) {
+      if (total_hits >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 hits leave one shard in one hop"};
+      if (pieces.size() == 1) {
+        out_ptr = pieces[0].buf->p;
+      } else {
+        hits_out.reserve(std::max<size_t>(total_hits * words * 4, 256));
+        uint64_t pos = 0;
+        for (auto &pc : pieces) {
+          IMPG_HIP(hipMemcpyAsync((char *)hits_out.p + pos * words * 4, pc.buf->p, pc.n * words * 4, hipMemcpyDeviceToDevice, s));
+          pos += pc.n;
+        }
+        out_ptr = hits_out.p;
       }
-      out_ptr = hits_out.p;
     }
+    } catch (...) {
+      E.split_ok = saved_split;
+      if (!need_hits) throw;  // no all-gather follows in this hop: run_lanes announces it in the lane's next one
+      deferred = std::current_exception();
+      std::fill(back.begin(), back.end(), 0);
+      back[W] = ST_FAILED;
+    }
+    if (!need_hits) return HopResult{total_pairs, false};
     // ---- hits go home
-    std::vector<uint64_t> mat2((size_t)W * W);
-    timed_comm([&] { comm->allgather_u64(back.data(), W, mat2.data()); });
+    const size_t K2 = (size_t)W + 1;
+    std::vector<uint64_t> mat2(K2 * W);
+    timed_comm([&] { comm->allgather_u64(back.data(), K2, mat2.data()); });
+    for (int o = 0; o < W; o++)
+      if (mat2[(size_t)o * K2 + W] & ST_FAILED) {
+        agreed = true;
+        if (deferred) std::rethrow_exception(deferred);
+        throw Error{IMPG_E_HIP, "a peer rank failed"};
+      }
     uint64_t n_home = 0;
     acc = 0;
     const uint64_t rec = (uint64_t)words * 4;
     for (int d = 0; d < W; d++) { so[d] = acc * rec; sb[d] = back[d] * rec; acc += back[d]; }
     for (int o = 0; o < W; o++) {
-      const uint64_t c = mat2[(size_t)o * W + me];
+      const uint64_t c = mat2[(size_t)o * K2 + me];
       ro[o] = n_home * rec; rb[o] = c * rec;
       n_home += c;
     }
-    if (n_home >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 hits come home in one hop: use smaller chunks (chunk_ranges)"};
+    for (int d = 0; d < W; d++) {  // (checked for every home from the gathered counts: all ranks fail together)
+      uint64_t to_d = 0;
+      for (int o = 0; o < W; o++) to_d += mat2[(size_t)o * K2 + d];
+      if (to_d >= 0xFFFFFFF0ull) { agreed = true; throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 hits come home in one hop: use smaller chunks (chunk_ranges)"}; }
+    }
     hits_in.reserve(std::max<size_t>(n_home * rec, 256));
     timed_comm([&] { comm->alltoallv(out_ptr, so.data(), sb.data(), hits_in.p, ro.data(), rb.data(), s); });
     bytes_out += acc * rec;
     pieces.clear();
     // ---- home: back into frontier order x visit order, into the slot arrays
+    if (fail_home_hop && hop_no == fail_home_hop) throw Error{IMPG_E_INVALID, "injected failure (home side)"};
     L.n_pairs = (uint32_t)n_home;
     const size_t b = std::max<size_t>((size_t)n_home * 4, 256);
     L.pair_range.reserve(b); L.qid.reserve(b); L.coords.reserve(4 * b);
@@ -344,21 +402,58 @@ template <class P, class F> void run_lanes(impg_gpu_index &ix, size_t n, P prep,
   const uint64_t n_chunks = *std::max_element(all.begin(), all.end());
   const size_t n_lanes = std::min<uint64_t>(S.comm->lanes.size(), n_chunks);
   std::vector<std::exception_ptr> errs(n_lanes);
+  for (size_t l = 0; l < S.comm->lanes.size(); l++) {
+    S.comm->lanes[l]->batch_begin(l < n_lanes);
+    S.lanes[l]->agreed = S.lanes[l]->in_transport = false;
+    S.lanes[l]->hop_no = 0;
+    const uint32_t me1 = (uint32_t)S.comm->rank + 1;
+    S.lanes[l]->fail_owner_hop = (ix.opt_debug_fail_owner >> 16) == me1 ? (ix.opt_debug_fail_owner & 0xFFFFu) : 0;
+    S.lanes[l]->fail_home_hop = (ix.opt_debug_fail_home >> 16) == me1 ? (ix.opt_debug_fail_home & 0xFFFFu) : 0;
+  }
+  // Forced lane schedules (tests; option "lane_schedule" / IMPG_LANE_SCHEDULE = v > 0): bit l(l-1)/2 + l' of v - 1
+  // makes lane l take its engine only after lane l' < l has run all its chunks and handed its engine back -- the
+  // late lane is then given that very engine (the pool is last-in first-out).  v = 1 .. 2^(L(L-1)/2) enumerates every
+  // hand-over pattern of L lanes instead of leaving them to thread timing (the class of the seed-72686 defect above).
+  // Not with several RCCL lanes: their issue order (comm.hpp) needs every lane to start.
+  uint64_t sched = ix.opt_lane_schedule;
+  if (!sched) if (const char *e = getenv("IMPG_LANE_SCHEDULE")) sched = strtoull(e, nullptr, 10);
+  if (n_lanes > 1 && std::string(S.comm->lanes[0]->kind()) == "rccl") sched = 0;
+  std::mutex sched_m;
+  std::condition_variable sched_cv;
+  std::vector<char> lane_done(n_lanes, 0);
   auto lane_main = [&](size_t l) {
+    ShardedExpander &X = *S.lanes[l];
+    if (sched) {
+      std::unique_lock<std::mutex> lk(sched_m);
+      for (size_t lp = 0; lp < l; lp++)
+        if (((sched - 1) >> (l * (l - 1) / 2 + lp)) & 1ull) sched_cv.wait(lk, [&] { return lane_done[lp] != 0; });
+    }
     try {
       IMPG_HIP(hipSetDevice(ix.device));
       EngineLease lease(ix);
       Engine &E = *lease;
-      E.remote = S.lanes[l].get();
+      E.remote = &X;
       prep(E);
       for (uint64_t c = l; c < n_chunks; c += n_lanes) {
         const size_t b = std::min<size_t>(n, c * chunk), e = std::min<size_t>(n, b + chunk);
         body(l, E, b, e);
       }
+      X.closing_word(false);  // (a peer that failed after its last hop says so here)
     } catch (...) {
       errs[l] = std::current_exception();
-      for (auto &c : S.comm->lanes) c->abort();  // peers waiting for this rank are released with an error
+      if (X.in_transport) {
+        for (auto &c : S.comm->lanes) c->abort();  // the transport itself failed: release whoever waits for this rank, where it can be done
+      } else if (!X.agreed) {
+        // failed between collectives: the peers of this lane are, or will be, in an all-gather -- tell them there
+        try { X.closing_word(true); } catch (...) { for (auto &c : S.comm->lanes) c->abort(); }
+      }
     }
+    S.comm->lanes[l]->batch_end();
+    {
+      std::lock_guard<std::mutex> lk(sched_m);
+      lane_done[l] = 1;
+    }
+    sched_cv.notify_all();
   };
   if (n_lanes == 1) lane_main(0);
   else {
@@ -512,7 +607,8 @@ int sharded_query_stats(impg_gpu_index &ix, const impg_gpu_range_t *ranges, bool
   std::vector<size_t> cut;
   split_blocks(n, W, cut);
   std::vector<impg_gpu_stats_t> sts(W);
-  for (auto &r : C.ranks) { r->opt_chunk_ranges = ix.opt_chunk_ranges; r->opt_pair_budget = ix.opt_pair_budget; r->opt_locality_min = ix.opt_locality_min; }
+  for (auto &r : C.ranks) { r->opt_chunk_ranges = ix.opt_chunk_ranges; r->opt_pair_budget = ix.opt_pair_budget; r->opt_locality_min = ix.opt_locality_min;
+                            r->opt_debug_fail_owner = ix.opt_debug_fail_owner; r->opt_debug_fail_home = ix.opt_debug_fail_home; r->opt_lane_schedule = ix.opt_lane_schedule; }
   on_every_rank(C, [&](size_t r) {
     rank_stats(*C.ranks[r], ranges + cut[r], false, cut[r + 1] - cut[r], p, per_range_count ? per_range_count + cut[r] : nullptr,
                per_range_checksum ? per_range_checksum + cut[r] : nullptr, &sts[r]);
@@ -545,7 +641,8 @@ int sharded_query_batch(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size
   std::vector<size_t> cut;
   split_blocks(n, W, cut);
   std::vector<impg_gpu_results> parts(W);
-  for (auto &r : C.ranks) { r->opt_chunk_ranges = ix.opt_chunk_ranges; r->opt_pair_budget = ix.opt_pair_budget; r->opt_locality_min = ix.opt_locality_min; }
+  for (auto &r : C.ranks) { r->opt_chunk_ranges = ix.opt_chunk_ranges; r->opt_pair_budget = ix.opt_pair_budget; r->opt_locality_min = ix.opt_locality_min;
+                            r->opt_debug_fail_owner = ix.opt_debug_fail_owner; r->opt_debug_fail_home = ix.opt_debug_fail_home; r->opt_lane_schedule = ix.opt_lane_schedule; }
   on_every_rank(C, [&](size_t r) { rank_query(*C.ranks[r], ranges + cut[r], cut[r + 1] - cut[r], p, mask, subset_keep, parts[r]); });
   res->offsets.assign(1, 0);
   double run_s = 0, asm_s = 0;
@@ -689,7 +786,13 @@ int impg_gpu_comm_create_rccl(const uint8_t *ids, int lanes, int rank, int world
   require_device(device);
   auto cm = std::make_unique<impg_gpu_comm>();
   cm->rank = rank; cm->world = world; cm->device = device;
-  for (int l = 0; l < lanes; l++) cm->lanes.emplace_back(new RcclComm(ids + (size_t)l * IMPG_COMM_ID_BYTES, rank, world, device));
+  auto order = lanes > 1 ? std::make_shared<IssueOrder>(lanes) : nullptr;
+  for (int l = 0; l < lanes; l++) {
+    auto rc = std::make_unique<RcclComm>(ids + (size_t)l * IMPG_COMM_ID_BYTES, rank, world, device);
+    rc->order = order;
+    rc->lane = l;
+    cm->lanes.push_back(std::move(rc));
+  }
   *out = cm.release();
   return IMPG_OK;
   IMPG_CATCH

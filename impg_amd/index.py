@@ -9,7 +9,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import INTERVAL_DTYPE, RANGE_DTYPE, RECORD_DTYPE, Params, Stats, check, lib
+from ._lib import IMPG_E_UNSUPPORTED, INTERVAL_DTYPE, RANGE_DTYPE, RECORD_DTYPE, ImpgGpuError, Params, Stats, check, lib
 
 
 def make_params(transitive=False, dfs=False, max_depth=2, min_transitive_len=101, min_distance_between_ranges=10,
@@ -316,11 +316,24 @@ class GpuImpg:
         out = out if raw else out.decode()
         return (out, list(sec)) if timing else out
 
+    def approximate(self):
+        """True for an index built from tracepoints (every answer is the reference's approximate mode)."""
+        return bool(lib().impg_gpu_index_approximate(self._h))
+
+    def _check_mode(self, approximate_mode):
+        # The reference takes approximate_mode per call (impg.rs:1899): on a CIGAR index it then finds no tracepoints
+        # and skips every hit, on a tracepoint index without it it realigns (WFA, not built here).  Answering in the
+        # index's own mode instead would hand a caller ported from the trait different rows without a word.
+        if bool(approximate_mode) != self.approximate():
+            raise ImpgGpuError(IMPG_E_UNSUPPORTED, "approximate_mode=%s on an index built from %s" %
+                               (bool(approximate_mode), "tracepoints" if self.approximate() else "CIGARs"))
+
     def query(self, target_id, range_start, range_end, store_cigar=False, min_gap_compressed_identity=None,
               sequence_index=None, approximate_mode=False):
         """ImpgIndex::query (impg_index.rs:26-35)."""
         # approximate_mode is a property of the index here: one built from tracepoints (from_tracepoints) answers
-        # in approximate mode, one built from CIGARs in exact mode
+        # in approximate mode, one built from CIGARs in exact mode; a call that asks for the other mode is refused
+        self._check_mode(approximate_mode)
         p = make_params(transitive=False, store_cigar=store_cigar, min_identity=min_gap_compressed_identity)
         return self.query_batch([(target_id, range_start, range_end)], p)[0]
 
@@ -329,6 +342,7 @@ class GpuImpg:
                              store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
                              approximate_mode=False, subset_filter=None):
         """ImpgIndex::query_transitive_bfs (impg_index.rs:79-94)."""
+        self._check_mode(approximate_mode)
         p = make_params(True, False, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
                         min_gap_compressed_identity, store_cigar)
         return self.query_batch([(target_id, range_start, range_end)], p, masked_regions=masked_regions,
@@ -339,6 +353,7 @@ class GpuImpg:
                              store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
                              approximate_mode=False, subset_filter=None):
         """ImpgIndex::query_transitive_dfs (impg_index.rs:63-77)."""
+        self._check_mode(approximate_mode)
         p = make_params(True, True, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
                         min_gap_compressed_identity, store_cigar)
         return self.query_batch([(target_id, range_start, range_end)], p, masked_regions=masked_regions,

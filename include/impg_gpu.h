@@ -180,6 +180,11 @@ size_t impg_gpu_target_ids(const impg_gpu_index_t *, uint32_t *out, size_t cap);
 size_t impg_gpu_num_entries(const impg_gpu_index_t *);
 size_t impg_gpu_num_records(const impg_gpu_index_t *);
 size_t impg_gpu_device_bytes(const impg_gpu_index_t *);
+/* 1: the index was built from tracepoints and answers every query in the reference's approximate mode
+ * (approximate_mode = true of the trait methods, src/impg_index.rs:34, :93); 0: built from CIGARs, exact mode.
+ * The mode is a property of the index here: a host mirroring the trait refuses a call whose approximate_mode
+ * disagrees (IMPG_E_UNSUPPORTED) rather than answer in the other mode. */
+int impg_gpu_index_approximate(const impg_gpu_index_t *);
 
 /* Tunables: "pair_budget" (max candidate pairs held in HBM per level; a batch
  * whose level exceeds it is split by ranges, queries being independent) and

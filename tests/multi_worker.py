@@ -1,6 +1,7 @@
 """Worker of the multi-rank tests (one process per rank, launched by torch.distributed.run).
 
   comm-check <transport>   CPU: the host transport (gloo callbacks) passes impg_gpu_comm_check on every lane
+  fail <transport> <paf>   GPU: a rank fails in the middle of a batch (injected): every rank gets an error, none hangs
   query <transport> <paf>  GPU: every rank builds its shard, submits its own queries (collective calls) and
                            checks its results against the oracle; transport = host (gloo, ranks share GPU 0)
                            or rccl (one GPU per rank)
@@ -53,6 +54,27 @@ def main():
     assert (r, w, l) == (rank, world, lanes)
     g.set_option("chunk_ranges", 7)
     n_seq, seq_len = c.num_seqs(), int(c.seq_len(0))
+    if mode == "fail":  # failure agreement: rank 0 fails on the owner side of hop 2, then rank `world - 1` on the home side
+        rl = random_ranges(100 + rank, 20, n_seq, seq_len, max_len=3000, min_len=120)
+        kw = dict(transitive=True, max_depth=3, min_transitive_len=20)
+        for side, who in (("debug_fail_owner", 0), ("debug_fail_home", world - 1)):
+            g.set_option(side, (who + 1) << 16 | 2)
+            try:
+                g.query_batch(rl, impg_amd.make_params(**kw))
+                raise AssertionError("rank %d: the batch must fail" % rank)
+            except impg_amd.ImpgGpuError as e:
+                assert ("injected failure" in str(e)) == (rank == who), (rank, side, str(e))
+            g.set_option(side, 0)
+            got = g.query_batch(rl, impg_amd.make_params(**kw))
+            for i, (t, s, e) in enumerate(rl):
+                assert got[i].tolist() == c.query(t, s, e, **kw).tolist(), (rank, i)
+        dist.barrier()
+        if rank == 0:
+            print("fail ok world=%d" % world)
+        del g
+        comm.close()
+        dist.destroy_process_group()
+        return
     n_q = 0 if (rank == 1 and world == 3) else 18 + 5 * rank  # ranks own different numbers of queries; one owns none
     rl = random_ranges(100 + rank, n_q, n_seq, seq_len, max_len=3000, min_len=120)
     mask = {0: (seq_len, [(100, 2000), (5000, 9000)]), 2: (seq_len, [(0, 700)])}

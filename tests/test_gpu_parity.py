@@ -961,6 +961,14 @@ def test_tracepoint_approximate_mode(fastga, seed):
     with pytest.raises(impg_amd.ImpgGpuError) as ei:
         g.query_batch(ranges[:2], impg_amd.make_params(store_cigar=True))
     assert ei.value.code == impg_amd.IMPG_E_UNSUPPORTED
+    # the mode belongs to the index: the trait-shaped calls refuse the other one instead of answering in it
+    assert g.approximate()
+    t0, s0, e0 = ranges[0]
+    assert g.query(t0, s0, e0, approximate_mode=True).tolist() == c.query(t0, s0, e0).tolist()
+    for call in (lambda: g.query(t0, s0, e0), lambda: g.query_transitive_bfs(t0, s0, e0), lambda: g.query_transitive_dfs(t0, s0, e0)):
+        with pytest.raises(impg_amd.ImpgGpuError) as ei:
+            call()
+        assert ei.value.code == impg_amd.IMPG_E_UNSUPPORTED
     # the saved index keeps its mode
     import tempfile, os
     with tempfile.TemporaryDirectory() as td:
@@ -1000,6 +1008,10 @@ def test_load_reference_impg_index(tmp_path, shuffle):
     assert_same(g, c, ranges, transitive=True, max_depth=3, min_transitive_len=20)
     assert_same(g, c, ranges[:40], transitive=True, dfs=True, max_depth=2)
     assert_same(g, c, ranges[:40], store_cigar=True, transitive=True, max_depth=2, min_transitive_len=40)
+    assert not g.approximate()
+    with pytest.raises(impg_amd.ImpgGpuError) as ei:  # (a CIGAR index has no approximate mode to offer)
+        g.query(*ranges[0], approximate_mode=True)
+    assert ei.value.code == impg_amd.IMPG_E_UNSUPPORTED
     # the CLI opens the same file with -i ... -a ...
     import os, subprocess
     cli = os.path.join(os.path.dirname(impg_amd.__file__), "impg-gpu")

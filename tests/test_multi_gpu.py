@@ -171,3 +171,69 @@ def test_mask_and_filter_follow_the_lease(tmp_path):
         got = g.query_batch(rl2, impg_amd.make_params(**kw), subset_keep=keep)
         for i, (t, s, e) in enumerate(rl2):
             assert got[i].tolist() == c.query(t, s, e, subset_keep=keep, **kw).tolist(), (rep, i)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,lanes", [(3, 2), (2, 1)])
+def test_failure_agreement_multi_handle(tmp_path, world, lanes):
+    """A rank that fails between two collectives of a hop (owner side) or after one (home side) must not leave its
+    peers waiting: the failure travels in the status word of the next all-gather and every rank leaves the batch with
+    an error (sharded.cpp "failure agreement"); the handle serves the next batch.  The failure is injected at a
+    chosen rank and hop (option debug_fail_owner / debug_fail_home)."""
+    path = write_paf(tmp_path)
+    c = o.OracleIndex(paf_paths=[path], preparse=True)
+    g = impg_amd.GpuImpg.from_paf(path, devices=[0] * world, lanes=lanes)
+    g.set_option("chunk_ranges", 7)
+    rl = random_ranges(100, 100, c.num_seqs(), 20000, max_len=3000, min_len=120)  # >= 4 chunks per rank: two per lane
+    kw = dict(transitive=True, max_depth=3, min_transitive_len=20)
+    p = impg_amd.make_params(**kw)
+    want = [c.query(t, s, e, **kw).tolist() for (t, s, e) in rl]
+    for side in ("debug_fail_owner", "debug_fail_home"):
+        for rank in range(world):
+            for hop in (1, 2, 4):  # (hop 4 of a lane lies in its second chunk)
+                g.set_option(side, (rank + 1) << 16 | hop)
+                with pytest.raises(impg_amd.ImpgGpuError) as ei:
+                    g.query_batch(rl, p)
+                assert "injected failure" in str(ei.value), (side, rank, hop, str(ei.value))
+                with pytest.raises(impg_amd.ImpgGpuError):
+                    g.query_batch_stats(rl, p)
+                g.set_option(side, 0)
+                got = g.query_batch(rl, p)
+                assert [got[i].tolist() for i in range(len(rl))] == want, (side, rank, hop)
+
+
+@pytest.mark.timeout(600)
+def test_failure_agreement_rank_processes(tmp_path):
+    """The same over the host transport, one process per rank: no rank hangs, every rank reports an error."""
+    path = write_paf(tmp_path)
+    out = run_ranks(3, ["fail", "host", path], 29760, lanes=2, timeout=500)
+    assert "fail ok world=3" in out
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,lanes", [(4, 2), (3, 3)])
+def test_lane_schedules_enumerated(tmp_path, world, lanes):
+    """Every hand-over pattern of the lanes' engines, forced one by one (option lane_schedule: lane l starts only
+    after lane l' < l has returned its engine, for every subset of such pairs) instead of left to thread timing:
+    the masked walk of test_mask_and_filter_follow_the_lease, the subset filter and a plain transitive batch must
+    give the oracle's rows under each of them."""
+    path = write_paf(tmp_path, seed=91, n=300)
+    c = o.OracleIndex(paf_paths=[path], preparse=True)
+    g = impg_amd.GpuImpg.from_paf(path, devices=[0] * world, lanes=lanes)
+    g.set_option("chunk_ranges", 2)
+    seq_len = int(c.seq_len(0))
+    rl = random_ranges(311, 9, c.num_seqs(), 20000, max_len=400, min_len=150)
+    mask = {s: (seq_len, [(0, seq_len)]) for s in range(c.num_seqs())}
+    keep = np.array([0, 1, 0, 1, 0, 1, 0], dtype=np.uint8)
+    rl2 = random_ranges(312, 9, c.num_seqs(), 20000, max_len=2500, min_len=600)
+    batches = [(rl, dict(transitive=True, dfs=True, max_depth=1, min_transitive_len=500, min_distance_between_ranges=200), mask, None),
+               (rl, dict(transitive=True, max_depth=1, min_transitive_len=500), mask, None),
+               (rl2, dict(transitive=True, max_depth=2, min_transitive_len=100), None, keep),
+               (rl2, dict(transitive=True, max_depth=2, min_transitive_len=100), None, None)]
+    wants = [[c.query(t, s, e, masked_regions=m, subset_keep=k, **kw).tolist() for (t, s, e) in r] for r, kw, m, k in batches]
+    for v in range(1, 2 ** (lanes * (lanes - 1) // 2) + 1):
+        g.set_option("lane_schedule", v)
+        for rep in range(3):
+            for (r, kw, m, k), w in zip(batches, wants):
+                got = g.query_batch(r, impg_amd.make_params(**kw), masked_regions=m, subset_keep=k)
+                assert [got[i].tolist() for i in range(len(r))] == w, (v, rep, kw)

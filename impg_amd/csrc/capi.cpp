@@ -22,11 +22,6 @@ void render_paf(const impg_gpu_results &res, const impg_gpu_index &ix, const cha
 void render_bed(const impg_gpu_results &res, const impg_gpu_index &ix, const char *const *range_names,
                 const impg_gpu_params_t &p, int32_t merge_distance, std::vector<std::string> &parts);
 char *join_parts(std::vector<std::string> &parts, size_t *len);  // bed.cpp
-uint32_t device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, const impg_gpu_params_t &p, int32_t merge_distance,
-                         std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, DevBuf &out);  // bed_device.hip
-void device_bed_text(Engine &E, const impg_gpu_index &ix, const DevBuf &rows, uint32_t n_rows, uint32_t n_ranges,
-                     const std::vector<std::string> &rnames, bool original_coords,
-                     const std::function<void(const char *, size_t)> &sink);
 }  // namespace impg
 
 using namespace impg;
@@ -52,6 +47,7 @@ EngineLease::EngineLease(impg_gpu_index &ix_) : ix(ix_) {
   e->locality_min = ix.opt_locality_min;
   e->free_slots_allowed = ix.opt_free_slots;
   e->regroup_pairs = ix.opt_regroup;
+  e->filter_covered = ix.opt_filter_covered;
 }
 EngineLease::~EngineLease() {
   e->remote = nullptr;
@@ -172,6 +168,21 @@ template <class F> void for_chunks(Engine &E, size_t n, F fn) {
 }  // namespace
 
 namespace impg {
+std::vector<std::string> bed_range_names(const impg_gpu_index &ix, const impg_gpu_range_t *ranges, const char *const *range_names,
+                                         size_t b, size_t e) {
+  std::vector<std::string> rn(e - b);
+  char buf[64];
+  for (size_t i = b; i < e; i++) {
+    if (range_names && range_names[i]) rn[i - b] = range_names[i];
+    else {
+      const impg_gpu_range_t &q = ranges[i];
+      rn[i - b] = q.target_id < ix.seq.names.size() ? ix.seq.names[q.target_id] : std::to_string(q.target_id);
+      const int k = snprintf(buf, sizeof buf, ":%d-%d", q.start, q.end);
+      rn[i - b].append(buf, (size_t)k);
+    }
+  }
+  return rn;
+}
 void check_ranges(const impg_gpu_range_t *ranges, size_t n) {
   if (n >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 ranges in one batch"};
   for (size_t i = 0; i < n; i++)
@@ -386,6 +397,9 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
     ix->opt_locality_min = (uint32_t)value;
   } else if (k == "regroup_entries") {  // projection blocks regroup their pairs by entry before reading the index (results identical)
     ix->opt_regroup = value != 0;
+  } else if (k == "filter_covered") {  // visited update: hits covered by the old list dropped before the replay (0 off, 1 always, 2 auto; results identical)
+    if (value < 0 || value > 2) throw Error{IMPG_E_INVALID, "filter_covered is 0, 1 or 2"};
+    ix->opt_filter_covered = (int)value;
   } else if (k == "free_slot_order") {  // counting runs lay their slots out in projection order (1, default) or keep the reference order (0)
     ix->opt_free_slots = value != 0;
   } else if (k == "debug_fail_owner" || k == "debug_fail_home") {  // tests: (rank + 1) << 16 | hop (sharded indexes; 0 = off)
@@ -626,11 +640,11 @@ void bed_batch(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, c
                int32_t merge_distance, const char *const *range_names, const std::function<void(const char *, size_t)> &sink,
                double *seconds3) {
   if (!ix || !params || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
-  if (ix->shard || ix->cluster) throw Error{IMPG_E_UNSUPPORTED, "the device-side BED path runs on a single-GPU index (use impg_gpu_query_batch + impg_gpu_results_bed)"};
   check_ranges(ranges, n);
   Engine::check_params(*params);
   impg_gpu_params_t p = *params;
   p.store_cigar = 0;  // BED never needs CIGARs (main.rs:7447)
+  if (ix->shard || ix->cluster) { sharded_bed_batch(*ix, ranges, n, p, subset_keep, merge_distance, range_names, sink, seconds3); return; }
   IMPG_HIP(hipSetDevice(ix->device));
   EngineLease lease(*ix);
   Engine &E = *lease;
@@ -647,17 +661,7 @@ void bed_batch(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, c
     const auto c1 = std::chrono::steady_clock::now();
     const uint32_t n_rows = device_bed_rows(E, *ix, (uint32_t)(e - b), p, merge_distance, levels, self_dev, rows);
     const auto c2 = std::chrono::steady_clock::now();
-    std::vector<std::string> rn(e - b);
-    char buf[64];
-    for (size_t i = b; i < e; i++) {
-      if (range_names && range_names[i]) rn[i - b] = range_names[i];
-      else {  // "{chrom}:{start}-{end}" (partition.rs:1741, :1762)
-        const impg_gpu_range_t &q = ranges[i];
-        rn[i - b] = q.target_id < ix->seq.names.size() ? ix->seq.names[q.target_id] : std::to_string(q.target_id);
-        const int k = snprintf(buf, sizeof buf, ":%d-%d", q.start, q.end);
-        rn[i - b].append(buf, (size_t)k);
-      }
-    }
+    const std::vector<std::string> rn = bed_range_names(*ix, ranges, range_names, b, e);
     device_bed_text(E, *ix, rows, n_rows, (uint32_t)(e - b), rn, p.original_sequence_coordinates != 0, sink);
     const auto c3 = std::chrono::steady_clock::now();
     t_engine += std::chrono::duration<double>(c1 - c0).count();

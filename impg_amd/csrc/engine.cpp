@@ -382,6 +382,21 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
                 (unsigned long long)b[4], (unsigned long long)hits[4], (unsigned long long)b[5], (unsigned long long)hits[5],
                 (unsigned long long)b[6], (unsigned long long)hits[6], (unsigned long long)b[7], (unsigned long long)hits[7]);
       }
+      // Hits that the group's list, as this level found it, already covers are dropped before the replay (they would
+      // change nothing): worth its three passes when groups are long and lists exist, i.e. from the second update of
+      // a walk on -- the deep levels of a saturating closure are almost all such hits.
+      const unsigned long long *replay_vals = svals.as<unsigned long long>();
+      const bool filter = filter_covered == 1 || (filter_covered == 2 && tables.size() >= 2 && (uint64_t)n_active >= 8ull * n_groups);
+      if (filter && n_active) {
+        uint32_t *keep = keys.as<uint32_t>(), *kpos = keep + P;  // (the unsorted key / value buffers are free again)
+        launch_covered_flags(tabs, svals.as<unsigned long long>(), head.as<uint32_t>(), gid.as<uint32_t>(), vt->keys.as<unsigned long long>(),
+                             old_tab.as<uint32_t>(), old_idx.as<uint32_t>(), masked ? mask_touch_len.as<int32_t>() : v.seq_len, n_active, keep, stream);
+        const uint32_t n_kept = (uint32_t)scan(keep, kpos, n_active);
+        launch_covered_compact(svals.as<unsigned long long>(), keep, kpos, n_active, vals.as<unsigned long long>(), n_kept, n_groups,
+                               gstart.as<uint32_t>(), glen.as<uint32_t>(), cap.as<uint32_t>(), pcap.as<uint32_t>(), stream);
+        replay_vals = vals.as<unsigned long long>();
+        covered_dropped += n_active - n_kept;
+      }
       vt->off.reserve((size_t)n_groups * 4);
       poff.reserve((size_t)n_groups * 4);
       uint64_t cap_total = scan(cap.as<uint32_t>(), vt->off.as<uint32_t>(), n_groups);
@@ -393,8 +408,8 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       pieces.reserve(std::max<size_t>(pcap_total * 8, 256));
       n_pieces.reserve((size_t)n_groups * 4);
       foff.reserve((size_t)n_groups * 4);
-      big_list.reserve((size_t)n_groups * 4);
-      launch_visited_update(tabs, svals.as<unsigned long long>(), masked ? mask_touch_len.as<int32_t>() : v.seq_len, vt->keys.as<unsigned long long>(),
+      big_list.reserve((size_t)n_groups * 8);  // two lists: [small from the front | large from the back], [tiny]
+      launch_visited_update(tabs, replay_vals, masked ? mask_touch_len.as<int32_t>() : v.seq_len, vt->keys.as<unsigned long long>(),
                             gstart.as<uint32_t>(), glen.as<uint32_t>(), old_tab.as<uint32_t>(), old_idx.as<uint32_t>(),
                             vt->off.as<uint32_t>(), poff.as<uint32_t>(), n_groups, p.min_transitive_len,
                             p.min_distance_between_ranges, vt->ranges.as<int2>(), vt->len.as<uint32_t>(),

@@ -1,6 +1,8 @@
 // Per-index execution state: stream, events, scratch buffers (engine.cpp).
 #pragma once
+#include <functional>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "kernels.hpp"
@@ -86,6 +88,8 @@ struct Engine {
   bool free_slot_order = false;
   bool free_slots_allowed = true;  // option "free_slot_order" (A/B runs)
   bool regroup_pairs = true;       // option "regroup_entries": a projection block sorts its 256 pairs by entry first
+  int filter_covered = 0;          // option "filter_covered": hits covered by their group's old list dropped before the replay (0 off: it bought nothing on config 5, where hits are covered by the list as it GROWS, not as the level found it; 1 always, 2 long groups)
+  uint64_t covered_dropped = 0;    // ... how many that was, over the engine's life (tuning aid)
   DevBuf m_dest, m_qid, m_coords, m_pe, m_sa, m_sn, m_so, m_sr;  // 5-key sort: destination + double buffers
   // projection order (locality): ranges sorted by window position, their slots listed in that order
   DevBuf wide_n, wide_list;  // ranges whose window is wider than the lane-per-range emit pass takes
@@ -213,7 +217,20 @@ void plan_rows(Engine &E, uint32_t n_ranges, const impg_gpu_params_t &p, std::ve
 void scatter_rows(Engine &E, std::vector<std::unique_ptr<LevelBufs>> &levels, const RowPlan &pl, const RowSinks &out);
 uint64_t build_row_cigars(Engine &E, std::vector<std::unique_ptr<LevelBufs>> &levels, const RowPlan &pl, const DevBuf &clen, DevBuf &coff,
                           DevBuf &pool);
-void append_results(impg_gpu_results &res, impg_gpu_results &part);  // part's rows behind res's (chunks, ranks)
+void append_results(impg_gpu_results &res, impg_gpu_results &part);
+// ---- BED on the device (bed_device.hip) -----------------------------------------------------------------------------
+uint32_t device_bed_rows(Engine &E, const impg_gpu_index &ix, uint32_t n_ranges, const impg_gpu_params_t &p, int32_t merge_distance,
+                         std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, DevBuf &out);
+void device_bed_text(Engine &E, const impg_gpu_index &ix, const DevBuf &rows, uint32_t n_rows, uint32_t n_ranges,
+                     const std::vector<std::string> &rnames, bool original_coords,
+                     const std::function<void(const char *, size_t)> &sink);
+// the names BED rows print for ranges [b, e): the caller's, else "{chrom}:{start}-{end}" (partition.rs:1741, :1762)
+std::vector<std::string> bed_range_names(const impg_gpu_index &ix, const impg_gpu_range_t *ranges, const char *const *range_names,
+                                         size_t b, size_t e);
+// query + both BED merges + text for this rank's / this handle's ranges of a sharded index (sharded.cpp)
+void sharded_bed_batch(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t &p,
+                       const uint8_t *subset_keep, int32_t merge_distance, const char *const *range_names,
+                       const std::function<void(const char *, size_t)> &sink, double *seconds3);  // part's rows behind res's (chunks, ranks)
 void check_ranges(const impg_gpu_range_t *ranges, size_t n);
 // masked_regions / subset filter of a batch -> an engine's device tables (cleared when the engine's lease ends)
 void apply_mask(Engine &E, const impg_gpu_index &ix, const impg_gpu_mask_t *m, const impg_gpu_params_t &p);

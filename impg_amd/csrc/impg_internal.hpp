@@ -339,6 +339,7 @@ struct impg_gpu_index {
   uint64_t opt_lane_schedule = 0;  // IMPG_LANE_SCHEDULE / option "lane_schedule": see run_lanes (sharded.cpp); 0 = off
   bool opt_free_slots = true;
   bool opt_regroup = true;
+  int opt_filter_covered = 0;
   impg::ShardCtx *shard = nullptr;    // set: this index is one rank's shard; queries are collective calls
   impg::Cluster *cluster = nullptr;   // set: this handle fronts n_dev shards in this process (no arrays of its own)
   impg_gpu_index();

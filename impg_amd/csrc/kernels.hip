@@ -1665,7 +1665,18 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
 constexpr uint32_t VU_LDS_CAP = 16;
 // groups whose list can outgrow this get a whole wave (visited_update_wave_kernel below)
 // two sizes of LDS working set (8 KB: 20 waves per CU; 32 KB: 5): groups with few hits and a short list take the small one
-constexpr uint32_t VW_MIN = 64, VW_CAP_SMALL = 1024, VW_CAP_LARGE = 4096, VW_SMALL_HITS = 400;
+#ifndef IMPG_VW_TINY
+#define IMPG_VW_TINY 512
+#endif
+#ifndef IMPG_VW_SMALL
+#define IMPG_VW_SMALL 1024
+#endif
+#ifndef IMPG_VW_TINY_HEADROOM
+#define IMPG_VW_TINY_HEADROOM 1000000  // the tiny tier is OFF: measured on config 5 (4 000 windows, update ms): one 1 024-entry tier 1 323;
+#endif                                 // 1 536 entries 1 595; 2 048 entries 1 902 (fewer waves per CU); + a 768-entry tier for short lists 1 610,
+                                       // + a 512-entry one 1 893 (more waves, but lists that outgrow the buffer replay in global memory)
+constexpr uint32_t VW_MIN = 64, VW_CAP_TINY = IMPG_VW_TINY, VW_CAP_SMALL = IMPG_VW_SMALL, VW_CAP_LARGE = 4096,
+                   VW_TINY_HEADROOM = IMPG_VW_TINY_HEADROOM, VW_SMALL_HEADROOM = 256;
 struct ListInPlace {  // the group's slice of the new table
   int2 *p;
   __device__ __forceinline__ int32_t &x(uint32_t i) const { return p[i].x; }
@@ -2069,24 +2080,91 @@ __global__ __launch_bounds__(64) void visited_update_wave_kernel(VisitedTables v
     if (lane == 0) { new_len[g] = len; n_pieces[g] = w; }
   }
 }
+// ---- hits the OLD list already covers, taken out before the replay --------------------------------------------------
+// A hit that one range of its group's list covers changes nothing whenever its turn comes (see replay_hits_wave), and
+// the list only grows -- so a hit covered by the list as the level FOUND it can be dropped before the sequential replay,
+// by a pass that is parallel over hits instead of over groups.  Deep levels of a saturating closure (BASELINE config 5)
+// are almost all such hits, and the replay of their big groups runs at 5 waves per CU.
+__global__ __launch_bounds__(256) void covered_flags_kernel(VisitedTables vt, const unsigned long long *__restrict__ svals,
+                                                            const uint32_t *__restrict__ head, const uint32_t *__restrict__ gid,
+                                                            const unsigned long long *__restrict__ gkey,
+                                                            const uint32_t *__restrict__ old_tab, const uint32_t *__restrict__ old_idx,
+                                                            const int32_t *__restrict__ seq_len, uint32_t n_active,
+                                                            uint32_t *__restrict__ keep) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_active) return;
+  const uint32_t g = gid[i] + head[i] - 1u;
+  const int2 *src = nullptr;
+  uint32_t len = 0;
+  const uint32_t tab = old_tab[g];
+  if (tab == VISITED_MASK) {
+    const uint32_t a = vt.mask_off[old_idx[g]];
+    len = vt.mask_off[old_idx[g] + 1] - a;
+    src = vt.mask_ranges + a;
+  } else if (tab != VISITED_NONE) {
+    const VisitedTable &T = vt.t[tab];
+    src = T.ranges + T.off[old_idx[g]];
+    len = T.len[old_idx[g]];
+  }
+  bool covered = false;
+  if (len) {
+    const int32_t sequence_length = seq_len[(uint32_t)(gkey[g] & 0xFFFFFFFFull)];
+    const unsigned long long iv = svals[i];
+    const int32_t s0 = max((int32_t)(uint32_t)(iv >> 32), 0), e0 = min((int32_t)(uint32_t)iv, sequence_length);
+    const uint32_t p0 = lower_bound_start(src, len, s0);
+    covered = s0 < e0 && ((p0 < len && src[p0].x == s0 && src[p0].y >= e0) || (p0 > 0 && src[p0 - 1].y >= e0));
+  }
+  keep[i] = covered ? 0u : 1u;
+}
+__global__ __launch_bounds__(256) void covered_compact_kernel(const unsigned long long *__restrict__ svals, const uint32_t *__restrict__ keep,
+                                                              const uint32_t *__restrict__ kpos, uint32_t n_active,
+                                                              unsigned long long *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n_active && keep[i]) out[kpos[i]] = svals[i];
+}
+// the groups' runs in the compacted hit list, and the capacities that follow from the shorter runs
+__global__ __launch_bounds__(256) void covered_regroup_kernel(const uint32_t *__restrict__ kpos, uint32_t n_active, uint32_t n_kept,
+                                                              uint32_t n_groups, uint32_t *__restrict__ gstart, uint32_t *__restrict__ glen,
+                                                              uint32_t *__restrict__ cap, uint32_t *__restrict__ pcap) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint32_t st = gstart[g], n = glen[g], en = st + n;
+  const uint32_t ns = kpos[st], ne = en < n_active ? kpos[en] : n_kept;
+  const uint32_t olen = cap[g] - n;
+  gstart[g] = ns;
+  glen[g] = ne - ns;
+  cap[g] = olen + (ne - ns);
+  pcap[g] = olen + 2u * (ne - ns);
+}
+
 // groups the lane kernel leaves to the wave kernels, in any order: those that fit the small LDS working set are
-// listed from the front of big_list (count n_big[0]), the others from its back (count n_big[1])
+// listed from the front of big_list (count n_big[0]), the others from its back (count n_big[1]); those that fit the
+// tiny one (4 KB: every wave slot of a CU can hold one) in big_list's second half (count n_big[2])
 __global__ __launch_bounds__(256) void big_groups_kernel(const uint32_t *__restrict__ cap, const uint32_t *__restrict__ pcap,
                                                          uint32_t n_groups, uint32_t *__restrict__ big_list,
                                                          uint32_t *__restrict__ n_big) {
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
   const bool big = g < n_groups && cap[g] > VW_MIN;  // cap = old length + hits of the level (group_prepare)
   // cap = old + hits, pcap = old + 2 hits  =>  hits = pcap - cap, old = 2 cap - pcap
-  const bool small_ws = big && pcap[g] - cap[g] <= VW_SMALL_HITS && 2u * cap[g] - pcap[g] + VW_SMALL_HITS <= VW_CAP_SMALL - 64u;
-  const unsigned long long ms = __ballot(small_ws), ml = __ballot(big && !small_ws);
-  uint32_t bs = 0, bl = 0;
+  // The small working set is chosen by the list the group STARTS with, not by its worst case (old + hits): hits of a deep
+  // level pile up on the same few regions, the list grows by a fraction of their number, and a list that does outgrow
+  // the buffer moves to its global slice (visited_update_wave_kernel).  Config-5 groups (2 400 hits on a 150-range
+  // list) used to take the 32 KB set, 5 waves per CU, for a replay that is pure LDS latency.
+  const uint32_t old_len = 2u * cap[g] - pcap[g];
+  const bool tiny_ws = big && old_len + VW_TINY_HEADROOM <= VW_CAP_TINY - 64u;
+  const bool small_ws = big && !tiny_ws && old_len + VW_SMALL_HEADROOM <= VW_CAP_SMALL - 64u;
+  const unsigned long long mt = __ballot(tiny_ws), ms = __ballot(small_ws), ml = __ballot(big && !small_ws && !tiny_ws);
+  uint32_t bt = 0, bs = 0, bl = 0;
   if (lane_id() == 0) {
+    if (mt) bt = atomicAdd(&n_big[2], (uint32_t)__popcll(mt));
     if (ms) bs = atomicAdd(&n_big[0], (uint32_t)__popcll(ms));
     if (ml) bl = atomicAdd(&n_big[1], (uint32_t)__popcll(ml));
   }
+  bt = (uint32_t)__shfl((int)bt, 0);
   bs = (uint32_t)__shfl((int)bs, 0);
   bl = (uint32_t)__shfl((int)bl, 0);
-  if (small_ws) big_list[bs + (uint32_t)__popcll(ms & lanemask_lt())] = g;
+  if (tiny_ws) big_list[n_groups + bt + (uint32_t)__popcll(mt & lanemask_lt())] = g;  // (the list's second half)
+  else if (small_ws) big_list[bs + (uint32_t)__popcll(ms & lanemask_lt())] = g;
   else if (big) big_list[n_groups - 1u - (bl + (uint32_t)__popcll(ml & lanemask_lt()))] = g;
 }
 
@@ -2565,7 +2643,8 @@ __global__ __launch_bounds__(256) void compact_copy_kernel(VisitedTables vt, con
 template <int WORDS>
 __global__ __launch_bounds__(256) void hits_pack_kernel(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ pair_range,
                                                         uint32_t n_pairs, HitArrays h, const uint32_t *__restrict__ pair_entry,
-                                                        const uint32_t *__restrict__ mrank, uint4 *__restrict__ out) {
+                                                        const uint32_t *__restrict__ mrank, const uint32_t *__restrict__ slice_n,
+                                                        uint4 *__restrict__ out) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   if (p >= n_pairs) return;
   const uint32_t q = h.qid[p];
@@ -2575,7 +2654,9 @@ __global__ __launch_bounds__(256) void hits_pack_kernel(const FrontierRec *__res
     out[p] = make_uint4(home, q, (uint32_t)hc.x, (uint32_t)hc.y);
   } else {
     out[2 * (size_t)p] = make_uint4(home, q, (uint32_t)hc.x, (uint32_t)hc.y);
-    out[2 * (size_t)p + 1] = make_uint4((uint32_t)hc.z, (uint32_t)hc.w, (pair_entry && mrank) ? mrank[pair_entry[p]] : 0u, 0u);
+    // word 7, store_cigar: the number of ops of the hit's CIGAR slice (the ops travel in a second exchange, in this order)
+    out[2 * (size_t)p + 1] = make_uint4((uint32_t)hc.z, (uint32_t)hc.w, (pair_entry && mrank) ? mrank[pair_entry[p]] : 0u,
+                                        (slice_n && q != HIT_NONE) ? slice_n[p] : 0u);
   }
 }
 // run_start == nullptr: the records are already in frontier order (one owner)
@@ -2583,7 +2664,8 @@ template <int WORDS>
 __global__ __launch_bounds__(256) void hits_unpack_kernel(const uint4 *__restrict__ in, uint32_t n, uint32_t n_front,
                                                           const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ off,
                                                           uint32_t *__restrict__ pair_range, HitArrays h,
-                                                          uint32_t *__restrict__ mslot) {
+                                                          uint32_t *__restrict__ mslot, const uint32_t *__restrict__ slice_at,
+                                                          uint32_t *__restrict__ slice_pos, uint32_t *__restrict__ slice_n) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   constexpr int Q = WORDS / 4;
@@ -2599,7 +2681,13 @@ __global__ __launch_bounds__(256) void hits_unpack_kernel(const uint4 *__restric
     const uint4 b = in[(size_t)i * Q + 1];
     h.c[d] = make_int4((int32_t)a.z, (int32_t)a.w, (int32_t)b.x, (int32_t)b.y);
     if (mslot) mslot[d] = b.z;
+    if (slice_pos) { slice_pos[d] = slice_at[i]; slice_n[d] = b.w; }  // (the ops arrived in the hits' arrival order)
   }
+}
+// store_cigar over a sharded index: word 7 of every arrived hit record = the number of ops of its slice
+__global__ __launch_bounds__(256) void hits_slice_n_kernel(const uint4 *__restrict__ in, uint32_t n, uint32_t *__restrict__ cnt) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) cnt[i] = in[2 * (size_t)i + 1].w;
 }
 
 // ---------------------------------------------------------------------------
@@ -2804,19 +2892,33 @@ void launch_visited_update(const VisitedTables &vt, const unsigned long long *sv
                            uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, const uint32_t *cap, const uint32_t *pcap,
                            uint32_t *big_list, uint32_t *n_big, hipStream_t s) {
   if (!n_groups) return;
-  (void)hipMemsetAsync(n_big, 0, 8, s);
+  (void)hipMemsetAsync(n_big, 0, 12, s);
   big_groups_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(cap, pcap, n_groups, big_list, n_big);
   visited_update_kernel<<<cdiv(n_groups, 64), 64, 0, s>>>(vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff,
                                                           poff, n_groups, min_transitive_len, mdbr, new_ranges, new_len,
                                                           pieces, n_pieces);
   // one wave per big group, grid-strided over however many there are (the count stays on the device)
-  const uint32_t blocks = std::min<uint32_t>(n_groups, 256u * 20u);
+  const uint32_t blocks = std::min<uint32_t>(n_groups, 256u * std::min(32u, (160u * 1024u) / (VW_CAP_SMALL * 8u)));
   visited_update_wave_kernel<VW_CAP_SMALL><<<blocks, 64, 0, s>>>(
       vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list, n_big, 0u, min_transitive_len, mdbr, new_ranges,
+      new_len, pieces, n_pieces);
+  visited_update_wave_kernel<VW_CAP_TINY><<<std::min<uint32_t>(n_groups, 256u * 32u), 64, 0, s>>>(
+      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list + n_groups, n_big + 2, 0u, min_transitive_len, mdbr, new_ranges,
       new_len, pieces, n_pieces);
   visited_update_wave_kernel<VW_CAP_LARGE><<<std::min<uint32_t>(n_groups, 256u * 5u), 64, 0, s>>>(
       vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list, n_big + 1, n_groups, min_transitive_len, mdbr,
       new_ranges, new_len, pieces, n_pieces);
+}
+void launch_covered_flags(const VisitedTables &vt, const unsigned long long *svals, const uint32_t *head, const uint32_t *gid,
+                          const unsigned long long *gkey, const uint32_t *old_tab, const uint32_t *old_idx, const int32_t *seq_len,
+                          uint32_t n_active, uint32_t *keep, hipStream_t s) {
+  if (n_active) covered_flags_kernel<<<cdiv(n_active, 256), 256, 0, s>>>(vt, svals, head, gid, gkey, old_tab, old_idx, seq_len, n_active, keep);
+}
+void launch_covered_compact(const unsigned long long *svals, const uint32_t *keep, const uint32_t *kpos, uint32_t n_active,
+                            unsigned long long *out, uint32_t n_kept, uint32_t n_groups, uint32_t *gstart, uint32_t *glen, uint32_t *cap,
+                            uint32_t *pcap, hipStream_t s) {
+  if (n_active) covered_compact_kernel<<<cdiv(n_active, 256), 256, 0, s>>>(svals, keep, kpos, n_active, out);
+  if (n_groups) covered_regroup_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(kpos, n_active, n_kept, n_groups, gstart, glen, cap, pcap);
 }
 void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
                           const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s) {
@@ -2950,15 +3052,19 @@ void launch_compact_copy(const VisitedTables &vt, const unsigned long long *src,
   if (n) compact_copy_kernel<<<cdiv(n, 256), 256, 0, s>>>(vt, src, off, len, n, ranges_out);
 }
 void launch_hits_pack(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, const uint32_t *pair_entry,
-                      const uint32_t *mrank, uint32_t words, void *out, hipStream_t s) {
+                      const uint32_t *mrank, uint32_t words, void *out, hipStream_t s, const uint32_t *slice_n) {
   if (!n_pairs) return;
-  if (words == 4) hits_pack_kernel<4><<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, pair_entry, mrank, (uint4 *)out);
-  else hits_pack_kernel<8><<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, pair_entry, mrank, (uint4 *)out);
+  if (words == 4) hits_pack_kernel<4><<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, pair_entry, mrank, nullptr, (uint4 *)out);
+  else hits_pack_kernel<8><<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, pair_entry, mrank, slice_n, (uint4 *)out);
+}
+void launch_hits_slice_n(const void *in, uint32_t n, uint32_t *cnt, hipStream_t s) {
+  if (n) hits_slice_n_kernel<<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, cnt);
 }
 void launch_hits_unpack(const void *in, uint32_t n, uint32_t words, uint32_t n_front, const uint32_t *run_start, const uint32_t *off,
-                        uint32_t *pair_range, HitArrays h, uint32_t *mslot, hipStream_t s) {
+                        uint32_t *pair_range, HitArrays h, uint32_t *mslot, hipStream_t s, const uint32_t *slice_at, uint32_t *slice_pos,
+                        uint32_t *slice_n) {
   if (!n) return;
-  if (words == 4) hits_unpack_kernel<4><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, n_front, run_start, off, pair_range, h, mslot);
-  else hits_unpack_kernel<8><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, n_front, run_start, off, pair_range, h, mslot);
+  if (words == 4) hits_unpack_kernel<4><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, n_front, run_start, off, pair_range, h, mslot, nullptr, nullptr, nullptr);
+  else hits_unpack_kernel<8><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, n_front, run_start, off, pair_range, h, mslot, slice_at, slice_pos, slice_n);
 }
 }  // namespace impg

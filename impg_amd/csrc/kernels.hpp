@@ -66,10 +66,14 @@ constexpr uint32_t ROUTE_WORLD_MAX = 1024;
 void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, const uint32_t *owner, uint32_t n_seq, uint32_t *key,
                        uint32_t *idx, unsigned long long *hist, hipStream_t s);
 // hits between ranks: pack at the owner (word 0 = the home's frontier index), reorder + unpack at home
+// slice_n (store_cigar, 8-word records): ops of every slot's CIGAR slice, carried in word 7; at home slice_at[i] = where the
+// i-th arrived hit's ops start among the arrived ops
 void launch_hits_pack(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, const uint32_t *pair_entry,
-                      const uint32_t *mrank, uint32_t words, void *out, hipStream_t s);
+                      const uint32_t *mrank, uint32_t words, void *out, hipStream_t s, const uint32_t *slice_n = nullptr);
+void launch_hits_slice_n(const void *in, uint32_t n, uint32_t *cnt, hipStream_t s);
 void launch_hits_unpack(const void *in, uint32_t n, uint32_t words, uint32_t n_front, const uint32_t *run_start, const uint32_t *off,
-                        uint32_t *pair_range, HitArrays h, uint32_t *mslot, hipStream_t s);
+                        uint32_t *pair_range, HitArrays h, uint32_t *mslot, hipStream_t s, const uint32_t *slice_at = nullptr,
+                        uint32_t *slice_pos = nullptr, uint32_t *slice_n = nullptr);
 void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s);
 // stable order of hit records (words u32 each, fidx first) by fidx when equal fidx are already contiguous
 void launch_reorder_runs(const uint32_t *hits, uint32_t n, uint32_t words, uint32_t n_front, uint32_t *run_start,
@@ -118,6 +122,13 @@ void launch_visited_update(const VisitedTables &vt, const unsigned long long *sv
                            uint32_t n_groups, int32_t min_transitive_len, int32_t mdbr, int2 *new_ranges,
                            uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, const uint32_t *cap, const uint32_t *pcap,
                            uint32_t *big_list, uint32_t *n_big, hipStream_t s);
+// hits covered by their group's old list dropped before the replay (kernels.hip "covered_flags")
+void launch_covered_flags(const VisitedTables &vt, const unsigned long long *svals, const uint32_t *head, const uint32_t *gid,
+                          const unsigned long long *gkey, const uint32_t *old_tab, const uint32_t *old_idx, const int32_t *seq_len,
+                          uint32_t n_active, uint32_t *keep, hipStream_t s);
+void launch_covered_compact(const unsigned long long *svals, const uint32_t *keep, const uint32_t *kpos, uint32_t n_active,
+                            unsigned long long *out, uint32_t n_kept, uint32_t n_groups, uint32_t *gstart, uint32_t *glen, uint32_t *cap,
+                            uint32_t *pcap, hipStream_t s);
 void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
                           const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s);
 void launch_subset_filter(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *qid,

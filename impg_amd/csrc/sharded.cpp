@@ -22,6 +22,7 @@
 // The north-star text says "allgatherv of the frontier"; all-to-all-v moves 1/world of that volume over the
 // point-to-point xGMI links, and is what is built (the all-gather carries the counts).
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -68,7 +69,7 @@ struct ShardedExpander : Expander {
   Comm *comm = nullptr;
   const uint32_t *d_owner = nullptr;
   uint32_t n_seq = 0;
-  DevBuf send_fr, recv_fr, hits_out, hits_in, mslot, iota, route_hist, d_bounds;
+  DevBuf send_fr, recv_fr, hits_out, hits_in, ops_out, ops_in, mslot, iota, route_hist, d_bounds;
   LevelBufs owner_L;
   uint32_t *h_vals = nullptr;  // pinned: slot offsets at block boundaries
   size_t h_cap = 0;
@@ -146,8 +147,6 @@ struct ShardedExpander : Expander {
 
   HopResult hop(Engine &E, const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
                 impg_gpu_stats_t *st, bool need_hits, bool need_rows, bool alive) override {
-    if (E.store_cigar)
-      throw Error{IMPG_E_UNSUPPORTED, "store_cigar is not available on an index sharded over GPUs (CIGAR slices stay with their owner)"};
     const int W = comm->world, me = comm->rank;
     hipStream_t s = E.stream;
     const size_t K = (size_t)W + 1;
@@ -186,19 +185,23 @@ struct ShardedExpander : Expander {
     bytes_out += acc * sizeof(FrontierRec);
     // ---- owner: expand what arrived, in slices under the pair budget
     const uint32_t words = (need_rows || E.multi) ? 8u : 4u;
-    std::vector<uint64_t> back((size_t)W + 1, 0);  // hits per home rank + this rank's status word
-    struct Piece { std::unique_ptr<DevBuf> buf; uint64_t n; };
+    // store_cigar: the owner materialises every hit's CIGAR slice (Engine::expand) and the ops follow the hit records
+    // home in a second exchange, block by block in the same order; a hit record carries its op count in word 7
+    const bool ship_ops = E.store_cigar && need_hits;
+    const size_t K2 = 2 * (size_t)W + 1;
+    std::vector<uint64_t> back(K2, 0);  // hits per home rank, ops per home rank, this rank's status word
+    struct Piece { std::unique_ptr<DevBuf> buf, ops; uint64_t n, n_ops; };
     std::vector<Piece> pieces;
-    uint64_t total_pairs = 0, total_hits = 0;
+    uint64_t total_pairs = 0, total_hits = 0, total_ops = 0;
     const bool saved_split = E.split_ok;
-    const void *out_ptr = nullptr;
+    const void *out_ptr = nullptr, *ops_ptr = nullptr;
     bool any_by_place = false;
     std::exception_ptr deferred;  // an owner-side failure waits for the all-gather below, where every rank learns of it
     try {
     if (fail_owner_hop && hop_no == fail_owner_hop) throw Error{IMPG_E_INVALID, "injected failure (owner side)"};
-    if ((size_t)(W + 1) * 4 > h_cap) {
+    if ((size_t)(W + 1) * 8 > h_cap) {
       if (h_vals) (void)hipHostFree(h_vals);
-      h_cap = std::max<size_t>((size_t)(W + 1) * 4, 4096);
+      h_cap = std::max<size_t>((size_t)(W + 1) * 8, 4096);
       IMPG_HIP(hipHostMalloc((void **)&h_vals, h_cap, hipHostMallocDefault));
     }
     // A counting hop (nobody at home reads rows) lets the owner lay its slots out in its own lookup order, home rank
@@ -238,15 +241,28 @@ struct ShardedExpander : Expander {
           IMPG_HIP(hipMemcpyAsync(h_vals + nread, E.pair_off.as<uint32_t>() + (lo - a), 4, hipMemcpyDeviceToHost, s));
           nread++;
         }
-        Piece pc{std::make_unique<DevBuf>(), P};
+        Piece pc{std::make_unique<DevBuf>(), std::make_unique<DevBuf>(), P, 0};
         pc.buf->reserve(std::max<size_t>(P * words * 4, 256));
         HitArrays h{owner_L.qid.as<uint32_t>(), owner_L.coords.as<int4>()};
         launch_hits_pack(sub, owner_L.pair_range.as<uint32_t>(), (uint32_t)P, h, E.multi ? E.pair_entry.as<uint32_t>() : nullptr,
-                         E.multi ? v.mrank : nullptr, words, pc.buf->p, s);
+                         E.multi ? v.mrank : nullptr, words, pc.buf->p, s, ship_ops ? E.cnt.as<uint32_t>() : nullptr);
         IMPG_HIP(hipStreamSynchronize(s));
         for (size_t k = 0; k < runs.size(); k++) {
           const uint64_t first = h_vals[k], end = k + 1 < runs.size() ? h_vals[k + 1] : P;
           back[runs[k].first] += end - first;
+        }
+        if (ship_ops) {  // the ops of one home's hits are one stretch of the slice pool (slot order): its ends from slice_pos
+          uint32_t *h_pos = h_vals + (W + 1);
+          for (size_t k = 0; k < runs.size(); k++)
+            IMPG_HIP(hipMemcpyAsync(h_pos + k, owner_L.slice_pos.as<uint32_t>() + h_vals[k], 4, hipMemcpyDeviceToHost, s));
+          IMPG_HIP(hipStreamSynchronize(s));
+          for (size_t k = 0; k < runs.size(); k++) {
+            const uint64_t first = h_pos[k], end = k + 1 < runs.size() ? h_pos[k + 1] : owner_L.slice_total;
+            back[(size_t)W + runs[k].first] += end - first;
+          }
+          pc.n_ops = owner_L.slice_total;
+          pc.ops->swap(owner_L.slice_pool);  // (the next slice materialises into a fresh buffer)
+          total_ops += pc.n_ops;
         }
         total_hits += P;
         pieces.push_back(std::move(pc));
@@ -267,21 +283,33 @@ struct ShardedExpander : Expander {
         }
         out_ptr = hits_out.p;
       }
+      if (ship_ops) {
+        if (total_ops >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 CIGAR ops leave one shard in one hop: use smaller chunks (chunk_ranges)"};
+        if (pieces.size() == 1) ops_ptr = pieces[0].ops->p;
+        else {
+          ops_out.reserve(std::max<size_t>(total_ops * 4, 256));
+          uint64_t pos = 0;
+          for (auto &pc : pieces) {
+            if (pc.n_ops) IMPG_HIP(hipMemcpyAsync((char *)ops_out.p + pos * 4, pc.ops->p, pc.n_ops * 4, hipMemcpyDeviceToDevice, s));
+            pos += pc.n_ops;
+          }
+          ops_ptr = ops_out.p;
+        }
+      }
     }
     } catch (...) {
       E.split_ok = saved_split;
       if (!need_hits) throw;  // no all-gather follows in this hop: run_lanes announces it in the lane's next one
       deferred = std::current_exception();
       std::fill(back.begin(), back.end(), 0);
-      back[W] = ST_FAILED;
+      back[K2 - 1] = ST_FAILED;
     }
     if (!need_hits) return HopResult{total_pairs, false};
     // ---- hits go home
-    const size_t K2 = (size_t)W + 1;
     std::vector<uint64_t> mat2(K2 * W);
     timed_comm([&] { comm->allgather_u64(back.data(), K2, mat2.data()); });
     for (int o = 0; o < W; o++)
-      if (mat2[(size_t)o * K2 + W] & ST_FAILED) {
+      if (mat2[(size_t)o * K2 + (K2 - 1)] & ST_FAILED) {
         agreed = true;
         if (deferred) std::rethrow_exception(deferred);
         throw Error{IMPG_E_HIP, "a peer rank failed"};
@@ -303,6 +331,24 @@ struct ShardedExpander : Expander {
     hits_in.reserve(std::max<size_t>(n_home * rec, 256));
     timed_comm([&] { comm->alltoallv(out_ptr, so.data(), sb.data(), hits_in.p, ro.data(), rb.data(), s); });
     bytes_out += acc * rec;
+    uint64_t ops_home = 0;
+    if (ship_ops) {  // ... and their CIGAR ops, owner by owner like the hit records
+      for (int d = 0; d < W; d++) {
+        uint64_t to_d = 0;
+        for (int o = 0; o < W; o++) to_d += mat2[(size_t)o * K2 + W + d];
+        if (to_d >= 0xFFFFFFF0ull) { agreed = true; throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 CIGAR ops come home in one hop: use smaller chunks (chunk_ranges)"}; }
+      }
+      acc = 0;
+      for (int d = 0; d < W; d++) { so[d] = acc * 4; sb[d] = back[(size_t)W + d] * 4; acc += back[(size_t)W + d]; }
+      for (int o = 0; o < W; o++) {
+        const uint64_t c = mat2[(size_t)o * K2 + W + me];
+        ro[o] = ops_home * 4; rb[o] = c * 4;
+        ops_home += c;
+      }
+      ops_in.reserve(std::max<size_t>(ops_home * 4, 256));
+      timed_comm([&] { comm->alltoallv(ops_ptr, so.data(), sb.data(), ops_in.p, ro.data(), rb.data(), s); });
+      bytes_out += acc * 4;
+    }
     pieces.clear();
     // ---- home: back into frontier order x visit order, into the slot arrays
     if (fail_home_hop && hop_no == fail_home_hop) throw Error{IMPG_E_INVALID, "injected failure (home side)"};
@@ -312,6 +358,26 @@ struct ShardedExpander : Expander {
     HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
     const bool need_order = W > 1 || E.multi || any_by_place;
     if (E.multi) mslot.reserve(b);
+    const uint32_t *slice_at = nullptr;
+    uint32_t *slice_pos = nullptr, *slice_n = nullptr;
+    if (ship_ops) {
+      // where every arrived hit's ops start among the arrived ops: a scan of word 7 in arrival order
+      L.sl_a.reserve(b); L.sl_n.reserve(b); L.sl_off.reserve(b); L.sl_rem.reserve(b);
+      E.cnt.reserve(b); E.gid.reserve(b);
+      L.slice_total = 0;
+      if (n_home) {
+        launch_hits_slice_n(hits_in.p, (uint32_t)n_home, E.cnt.as<uint32_t>(), s);
+        const uint64_t tot = E.scan(E.cnt.as<uint32_t>(), E.gid.as<uint32_t>(), (uint32_t)n_home);
+        if (tot != ops_home) throw Error{IMPG_E_INVALID, "CIGAR ops and hit records that came home disagree"};
+        L.slice_total = tot;
+      }
+      slice_at = E.gid.as<uint32_t>();
+      slice_pos = L.sl_a.as<uint32_t>();  // (kept in sl_a while the five-key sort may still permute the slots)
+      slice_n = L.sl_n.as<uint32_t>();
+      L.slice_pool.swap(ops_in);
+    }
+    SliceArrays home_sl{nullptr, nullptr, nullptr, nullptr};
+    if (ship_ops) home_sl = SliceArrays{L.sl_a.as<uint32_t>(), L.sl_n.as<uint32_t>(), L.sl_off.as<int32_t>(), L.sl_rem.as<int32_t>()};
     if (n_home) {
       if (need_order) {
         const size_t fb = std::max<size_t>((size_t)n_fr * 4, 256);
@@ -325,17 +391,18 @@ struct ShardedExpander : Expander {
         IMPG_HIP(hipMemcpy(&bad, err, 4, hipMemcpyDeviceToHost));
         if (bad || total != n_home) throw Error{IMPG_E_INVALID, "hits came home for a frontier record twice or out of range"};
         launch_hits_unpack(hits_in.p, (uint32_t)n_home, words, n_fr, E.lo_key.as<uint32_t>(), E.lo_off.as<uint32_t>(),
-                           L.pair_range.as<uint32_t>(), h, E.multi ? mslot.as<uint32_t>() : nullptr, s);
+                           L.pair_range.as<uint32_t>(), h, E.multi ? mslot.as<uint32_t>() : nullptr, s, slice_at, slice_pos, slice_n);
       } else {
-        launch_hits_unpack(hits_in.p, (uint32_t)n_home, words, n_fr, nullptr, nullptr, L.pair_range.as<uint32_t>(), h, nullptr, s);
+        launch_hits_unpack(hits_in.p, (uint32_t)n_home, words, n_fr, nullptr, nullptr, L.pair_range.as<uint32_t>(), h, nullptr, s, slice_at,
+                           slice_pos, slice_n);
       }
       if (E.multi) {
         iota.reserve(b);
         launch_iota(iota.as<uint32_t>(), (uint32_t)n_home, s);
       }
-      E.post_expand(fr, n_fr, L, E.lo_off.as<uint32_t>(), iota.as<uint32_t>(), mslot.as<uint32_t>(),
-                    SliceArrays{nullptr, nullptr, nullptr, nullptr});
+      E.post_expand(fr, n_fr, L, E.lo_off.as<uint32_t>(), iota.as<uint32_t>(), mslot.as<uint32_t>(), home_sl);
     }
+    if (ship_ops) L.slice_pos.swap(L.sl_a);  // what the row builder reads (rows_device.hip): slice_pool[slice_pos[slot] .. + sl_n[slot])
     return HopResult{total_pairs, false};
   }
 };
@@ -393,9 +460,16 @@ struct LaneWork {  // what one lane accumulates
 // subset filter) belongs to the LEASE -- the lease's end clears it, and a lane that starts late can be handed the very
 // engine an early lane has just given back.  (It used to be applied once per engine pointer: such a late lane then ran
 // its chunks unmasked and unfiltered.  Found by scripts/fuzz_parity.py, seed 72686, 4 ranks x 2 lanes.)
+// Ranges per chunk of this rank's part of a batch.  Without the option the batch is cut so that every lane has work
+// (lanes only overlap exchange and compute across chunks) and no chunk outgrows the 32-bit slot counts of a hop.
+size_t shard_chunk(const impg_gpu_index &ix, size_t n) {
+  if (ix.opt_chunk_ranges) return ix.opt_chunk_ranges;
+  const size_t lanes = std::max<size_t>(1, ix.shard->comm->lanes.size());
+  return std::min<size_t>(25000, std::max<size_t>(1, (n + lanes - 1) / lanes));
+}
 template <class P, class F> void run_lanes(impg_gpu_index &ix, size_t n, P prep, F body) {
   ShardCtx &S = *ix.shard;
-  const size_t chunk = ix.opt_chunk_ranges ? ix.opt_chunk_ranges : std::max<size_t>(n, 1);
+  const size_t chunk = shard_chunk(ix, n);
   uint64_t my_chunks = std::max<uint64_t>(1, (n + chunk - 1) / chunk);
   std::vector<uint64_t> all(S.comm->world);
   S.comm->lanes[0]->allgather_u64(&my_chunks, 1, all.data());
@@ -528,7 +602,7 @@ void rank_query(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, co
   DevBuf d_ranges;
   d_ranges.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
   if (n) IMPG_HIP(hipMemcpy(d_ranges.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice));
-  const size_t chunk = ix.opt_chunk_ranges ? ix.opt_chunk_ranges : std::max<size_t>(n, 1);
+  const size_t chunk = shard_chunk(ix, n);
   std::vector<std::unique_ptr<impg_gpu_results>> parts((n + chunk - 1) / chunk + 1);
   std::atomic<uint64_t> served{0};  // projections done here for other ranks' records during chunks this rank had no ranges for
   run_lanes(ix, n, [&](Engine &E) {
@@ -557,6 +631,42 @@ void rank_query(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, co
     if (pt) append_results(res, *pt);
   res.projected += served.load();
   res.ranges.assign(ranges, ranges + n);
+}
+
+// one rank's part of a collective BED batch: the text of its own ranges, chunk by chunk
+void rank_bed(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t &p, const uint8_t *subset_keep,
+              int32_t merge_distance, const char *const *range_names, std::vector<std::string> &chunks_out, double *seconds3) {
+  IMPG_HIP(hipSetDevice(ix.device));
+  check_ranges(ranges, n);
+  DevBuf d_ranges;
+  d_ranges.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
+  if (n) IMPG_HIP(hipMemcpy(d_ranges.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice));
+  const size_t chunk = shard_chunk(ix, n);
+  chunks_out.assign((n + chunk - 1) / chunk + 1, std::string());
+  std::mutex tm;
+  double t3[3] = {0, 0, 0};
+  run_lanes(ix, n, [&](Engine &E) { apply_subset(E, ix, subset_keep); }, [&](size_t, Engine &E, size_t b, size_t e) {
+    std::vector<std::unique_ptr<LevelBufs>> levels;
+    DevBuf self_dev, rows;
+    self_dev.pool = &E.level_pool;
+    std::unique_lock<std::mutex> turn(ix.shard->gpu_turn, std::defer_lock);
+    if (ix.shard->comm->lanes.size() > 1) turn.lock();
+    const auto c0 = std::chrono::steady_clock::now();
+    E.run(ix, d_ranges.as<impg_gpu_range_t>() + b, (uint32_t)(e - b), p, &levels, nullptr, nullptr, nullptr, &self_dev);
+    const auto c1 = std::chrono::steady_clock::now();
+    if (e == b) return;  // an empty chunk: this rank only took part in the hops
+    const uint32_t n_rows = device_bed_rows(E, ix, (uint32_t)(e - b), p, merge_distance, levels, self_dev, rows);
+    const auto c2 = std::chrono::steady_clock::now();
+    std::string &out = chunks_out[b / chunk];
+    device_bed_text(E, ix, rows, n_rows, (uint32_t)(e - b), bed_range_names(ix, ranges, range_names, b, e), p.original_sequence_coordinates != 0,
+                    [&](const char *t, size_t k) { out.append(t, k); });
+    const auto c3 = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> lk(tm);
+    t3[0] += std::chrono::duration<double>(c1 - c0).count();
+    t3[1] += std::chrono::duration<double>(c2 - c1).count();
+    t3[2] += std::chrono::duration<double>(c3 - c2).count();
+  });
+  if (seconds3) for (int k = 0; k < 3; k++) seconds3[k] = t3[k];
 }
 
 // ranges of a multi-GPU handle are dealt to the ranks in contiguous blocks (results concatenate in order)
@@ -625,6 +735,32 @@ int sharded_query_stats(impg_gpu_index &ix, const impg_gpu_range_t *ranges, bool
     }
   }
   return IMPG_OK;
+}
+
+void sharded_bed_batch(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t &p,
+                       const uint8_t *subset_keep, int32_t merge_distance, const char *const *range_names,
+                       const std::function<void(const char *, size_t)> &sink, double *seconds3) {
+  if (!ix.cluster) {  // one rank of a process-per-GPU job: the text of ITS ranges
+    std::vector<std::string> chunks;
+    rank_bed(ix, ranges, n, p, subset_keep, merge_distance, range_names, chunks, seconds3);
+    for (auto &c : chunks) if (!c.empty()) sink(c.data(), c.size());
+    return;
+  }
+  Cluster &C = *ix.cluster;
+  const size_t W = C.ranks.size();
+  std::vector<size_t> cut;
+  split_blocks(n, W, cut);
+  std::vector<std::vector<std::string>> parts(W);
+  std::vector<std::array<double, 3>> secs(W);
+  for (auto &r : C.ranks) { r->opt_chunk_ranges = ix.opt_chunk_ranges; r->opt_pair_budget = ix.opt_pair_budget; r->opt_locality_min = ix.opt_locality_min;
+                            r->opt_debug_fail_owner = ix.opt_debug_fail_owner; r->opt_debug_fail_home = ix.opt_debug_fail_home; r->opt_lane_schedule = ix.opt_lane_schedule; }
+  on_every_rank(C, [&](size_t r) {
+    rank_bed(*C.ranks[r], ranges + cut[r], cut[r + 1] - cut[r], p, subset_keep, merge_distance, range_names ? range_names + cut[r] : nullptr, parts[r],
+             secs[r].data());
+  });
+  for (auto &pr : parts)
+    for (auto &c : pr) if (!c.empty()) sink(c.data(), c.size());
+  if (seconds3) for (int k = 0; k < 3; k++) { seconds3[k] = 0; for (auto &x : secs) seconds3[k] = std::max(seconds3[k], x[k]); }
 }
 
 int sharded_query_batch(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t &p,

@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """profiles/<tag>_sq.json from the SQ pass of scripts/profile_r2.sh: the VALU-issue fraction of project_kernel.
-SQ_ACTIVE_INST_VALU counts, in quad-cycles, the time waves spend executing VALU instructions; on this kernel (32-bit
-integer ops, no packed / MFMA work) it equals SQ_INSTS_VALU to 1 %: one wave64 instruction keeps its SIMD's VALU
-one quad-cycle = 4 clocks (the 2-clock figure of MI355X_MICROARCH.md is the packed / dual-issue rate, which integer
-compare / select / add code does not reach).  So
-valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs), counters summed over the kernel's
-dispatches (SQ_INSTS_VALU x 4 when the pass did not collect SQ_ACTIVE_INST_VALU).
-usage: make_sq_json.py <dir with sq_pmc.csv and sq_bench.json> <out.json>"""
+SQ_ACTIVE_INST_VALU ticks ONCE PER INSTRUCTION whatever the instruction costs (scripts/issue_rate.hip,
+profiles/r3_issue_rate_sq_pmc.csv: it equals SQ_INSTS_VALU for 2-cycle v_add_u32 and 4-cycle v_bfe_u32 alike), so it
+cannot give the issue time by itself.  The time comes from the measured per-instruction costs (profiles/r3_issue_rate.json:
+2.07 cycles for add / sub / logic / mov / right shifts on VGPRs, 4.13 for everything else incl. any SGPR operand, 6.3 per
+v_cmp + v_cndmask pair) weighted with the kernel's static instruction mix (scripts/valu_mix.py):
+valu_issue_frac = SQ_INSTS_VALU x cycles_per_inst(mix) / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs), counters summed over
+the kernel's dispatches.  Rounds 1-2 used a flat 2, then a flat 4.
+usage: make_sq_json.py <dir with sq_pmc.csv and sq_bench.json> <out.json> [cycles_per_valu_inst | valu_mix.json]"""
 import csv, json, os, sys
 
 d, out = sys.argv[1], sys.argv[2]
+cpi, cpi_src = 4.13, "default: the half-rate class (no mix given)"
+if len(sys.argv) > 3:
+    if os.path.exists(sys.argv[3]):
+        cpi = json.load(open(sys.argv[3]))["cycles_per_valu_inst"]
+        cpi_src = "static mix of the kernel, " + os.path.basename(sys.argv[3])
+    else:
+        cpi, cpi_src = float(sys.argv[3]), "given on the command line"
 vals, rows_of, disp = {}, {}, 0
 for row in csv.DictReader(open(os.path.join(d, "sq_pmc.csv"))):
     if "project_kernel" in row["Name"]:
@@ -31,8 +39,11 @@ res = {"kernel": "project_kernel", "command": "bench.py " + " ".join(bench.get("
        "valu_insts_per_pair": valu / pairs / 1.0 if pairs else None,  # wave-instructions per pair (x64 lanes / 64 pairs per wave)
        "salu_insts_per_wave": vals.get("SQ_INSTS_SALU", 0.0) / vals["SQ_WAVES"] if vals.get("SQ_WAVES") else None,
        "vmem_insts_per_wave": vals.get("SQ_INSTS_VMEM", 0.0) / vals["SQ_WAVES"] if vals.get("SQ_WAVES") else None,
-       "valu_issue_frac": (vals.get("SQ_ACTIVE_INST_VALU", valu) * 4.0) / (gui * 1024.0) if gui else None,
-       "note": "GRBM_GUI_ACTIVE = kernel cycles (summed over dispatches); 1024 SIMDs; SQ_ACTIVE_INST_VALU is in quad-cycles and "
-               "equals SQ_INSTS_VALU here: a wave64 integer VALU instruction occupies its SIMD for 4 clocks"}
+       "cycles_per_valu_inst": cpi, "cycles_per_valu_inst_source": cpi_src,
+       "valu_issue_frac": (valu * cpi) / (gui * 1024.0) if gui else None,
+       "valu_issue_frac_if_2_cycles": (valu * 2.07) / (gui * 1024.0) if gui else None,
+       "valu_issue_frac_if_4_cycles": (valu * 4.13) / (gui * 1024.0) if gui else None,
+       "note": "GRBM_GUI_ACTIVE = kernel cycles (summed over dispatches); 1024 SIMDs; SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU is a count, "
+               "not a time (profiles/r3_issue_rate.json): the issue time is the count x the measured cost of the kernel's instruction mix"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--ranges ${RANGES:-100000} --steps ${STEPS:-1} --warmup ${WARMUP:-1} --cpu-sample 0 --no-extras ${EXTRA_ARGS:-}"
 run() {  # name, rocprof args...
   local name=$1; shift
-  timeout 600 rocprofv3 "$@" -d $OUT/$name -o $name -- python $REPO/bench.py $ARGS > $OUT/${name}_bench.json 2> $OUT/$name.err
+  timeout ${PASS_TIMEOUT:-600} rocprofv3 "$@" -d $OUT/$name -o $name -- python $REPO/bench.py $ARGS > $OUT/${name}_bench.json 2> $OUT/$name.err
   python3 $REPO/scripts/rocpd_summary.py $OUT/$name/${name}_results.db $OUT/$name
   rm -rf $OUT/$name
 }

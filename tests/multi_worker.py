@@ -103,11 +103,13 @@ def main():
             n_self = 1  # (no mask: one self interval per range)
             for i in range(len(rl)):
                 assert int(cnt[i]) == len(got[i]) - n_self, (rank, i, kw)
-    try:
-        g.query_batch(rl, impg_amd.make_params(store_cigar=True))
-        raise AssertionError("store_cigar on a sharded index must be refused")
-    except impg_amd.ImpgGpuError as e:
-        assert e.code == impg_amd.IMPG_E_UNSUPPORTED
+    for kw in (dict(), dict(transitive=True, max_depth=2, min_transitive_len=40)):  # store_cigar: the slices' ops come home too
+        res = g.query_batch(rl, impg_amd.make_params(store_cigar=True, **kw))
+        for i, (t, s, e) in enumerate(rl):
+            want, wcg = c.query_cigar(t, s, e, **kw)
+            assert res[i].tolist() == want.tolist(), (rank, i, kw)
+            got = res.cigars(i)
+            assert [x.tolist() for x in got] == [x.tolist() for x in wcg], (rank, i, kw)
     dist.barrier()
     if rank == 0:
         print("multi ok world=%d lanes=%d transport=%s" % (world, lanes, transport))

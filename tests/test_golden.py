@@ -92,3 +92,42 @@ def test_engine_reproduces_golden(tmp_path, path):
         else:  # a range with nothing left after dropping the input range: the reference panics, both sides raise
             r2 = g.query_batch([sub[k] for k in ok], params)
             assert r2.paf([names[k] for k in ok], merge_distance=10, params=params, fmt=fmt) == "".join(tx[fmt][k] for k in ok)
+
+
+# ---- BASELINE config 1 stand-in: `impg query -r S288C#1#chrI:50000-100000 -d 1000` on a committed yeast-style PAF -------
+CONFIG1_PAF = os.path.join(HERE, "config1_yeast.paf")
+
+
+def config1_expected():
+    with open(os.path.join(HERE, "config1_expected.json")) as f:
+        return json.load(f)
+
+
+def test_config1_oracle_reproduces_expected_bed():
+    exp = config1_expected()
+    ix = o.OracleIndex(paf_paths=[CONFIG1_PAF], preparse=True)
+    assert ix.num_seqs() == 7 and ix.seq_len(ix.seq_id("S288C#1#chrI")) == 230218
+    assert ix.query_bed("S288C#1#chrI", 50000, 100000, merge_distance=1000) == exp["bed"]
+    assert ix.query_bed("S288C#1#chrI", 50000, 100000, merge_distance=1000, transitive=True, max_depth=2) == exp["bed_transitive_m2"]
+    assert exp["bed"].count("\n") >= 10
+
+
+@pytest.mark.gpu
+def test_config1_cli_prints_expected_bed():
+    """The command line of BASELINE config 1 through the engine's CLI (`impg-gpu query`, main.rs:4259-4381): stdout is the
+    committed BED text, byte for byte; the library calls give the same bytes."""
+    import subprocess
+    exp = config1_expected()
+    cli = os.path.join(os.path.dirname(impg_amd.__file__), "impg-gpu")
+    base = [cli, "query", "-a", CONFIG1_PAF, "-r", "S288C#1#chrI:50000-100000", "-d", "1000"]
+    r = subprocess.run(base, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == exp["bed"]
+    r = subprocess.run(base + ["-x", "-m", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == exp["bed_transitive_m2"]
+    g = impg_amd.GpuImpg.from_paf(CONFIG1_PAF)
+    rng = [(g.seq_id("S288C#1#chrI"), 50000, 100000)]
+    nm = ["S288C#1#chrI:50000-100000"]
+    assert g.query_batch_bed(rng, impg_amd.make_params(), merge_distance=1000, range_names=nm) == exp["bed"]
+    assert g.query_batch(rng, impg_amd.make_params()).bed(nm, merge_distance=1000, params=impg_amd.make_params()) == exp["bed"]

@@ -54,7 +54,7 @@ def test_headline_config_sample_vs_oracle(full):
     assert st.levels == 3 and st.projected > 10_000 * len(ranges)
     c = o.OracleIndex(paf_paths=[paf], preparse=False)  # pread + parse per hit, like the reference
     rng = np.random.default_rng(1)
-    sample = sorted(set(rng.integers(0, len(ranges), 12).tolist()) | {0, len(ranges) - 1})
+    sample = sorted(set(rng.integers(0, len(ranges), 70).tolist()) | {0, len(ranges) - 1})  # (>= 64 ranges: ~1.4e6 projections)
     total = 0
     for i in sample:
         r = ranges[i]
@@ -63,7 +63,7 @@ def test_headline_config_sample_vs_oracle(full):
         assert int(cnt[i]) == len(hits), i
         assert int(ck[i]) == checksum(hits), i
         total += len(hits)
-    assert total > 100_000  # the sample itself is a six-figure number of projections
+    assert len(sample) >= 64 and total > 1_000_000  # the sample itself is a seven-figure number of projections
 
 
 def test_chunking_and_repeat_invariance(full):
@@ -89,8 +89,30 @@ def test_nontransitive_full_results_sample(full):
     c = o.OracleIndex(paf_paths=[paf], preparse=False)
     sub = ranges[:200]
     res = g.query_batch(sub, impg_amd.make_params())
-    for i in range(0, 200, 7):
+    for i in range(200):  # all of them
         r = sub[i]
         want = c.query(int(r["target_id"]), int(r["start"]), int(r["end"]))
         assert res[i].tolist() == want.tolist()
     assert res.projected == sum(len(res[i]) - 1 for i in range(200))
+
+
+def test_headline_batch_prefix_consistency(full):
+    """The headline batch itself (100 000 ranges, -x -m 3): queries are independent, so the first 4 096 ranges of the
+    full batch must give exactly the per-range counts and checksums the 4 096-range batch gives (which the oracle
+    sample above pins), whatever chunks, lookup orders and slot layouts the big batch runs through; and the whole
+    batch's total is the sum of its per-range counts."""
+    paf, g, ranges = full
+    bed = impg_amd.synth_bed(7, 100_000)
+    big = np.zeros(len(bed), dtype=impg_amd.RANGE_DTYPE)
+    big["target_id"] = [g.seq_id(impg_amd.synth_seq_name(int(t))) for t in bed["target_id"]]
+    big["start"], big["end"] = bed["start"], bed["end"]
+    assert (big[:len(ranges)] == ranges).all()  # (the generator is a prefix-stable stream)
+    p = impg_amd.make_params(transitive=True, max_depth=3)
+    g.set_option("chunk_ranges", 2048)
+    st0, cnt0, ck0 = g.query_batch_stats(ranges, p)
+    g.set_option("chunk_ranges", 50000)
+    g.set_option("pair_budget", 1 << 30)
+    st, cnt, ck = g.query_batch_stats(big, p)
+    g.set_option("pair_budget", 1 << 29)
+    assert (cnt[:len(ranges)] == cnt0).all() and (ck[:len(ranges)] == ck0).all()
+    assert st.projected == int(cnt.sum()) and st.projected > 2_000_000_000

@@ -938,6 +938,11 @@ def test_visited_update_big_groups(tmp_path, seed, n_aln, mdbr):
     assert_same(g, c, ranges, transitive=True, dfs=True, max_depth=3, min_transitive_len=5, min_distance_between_ranges=mdbr)
     masked = {int(g.seq_id("B")): (L, [(k * 3000, k * 3000 + 900) for k in range(100)])}  # a mask list of 100 ranges: a big group from its first touch
     assert_same(g, c, ranges[:2], masked_regions=masked, **kw)
+    # the pre-pass that drops hits the level's old lists already cover (option filter_covered: 0 never, 1 always)
+    for f in (0, 1):
+        g.set_option("filter_covered", f)
+        assert_same(g, c, ranges, **kw)
+        assert_same(g, c, ranges[:2], masked_regions=masked, **kw)
 
 
 @pytest.mark.parametrize("fastga,seed", [(False, 1), (False, 2), (True, 3), (True, 4)])

@@ -22,6 +22,24 @@ def write_paf(tmp_path, seed=77, n=260, **kw):
     return path
 
 
+def check_cigars(g, c, rl, masked_regions=None, subset_keep=None, single=None, **kw):
+    """rows and every row's Vec<CigarOp> against the oracle; under a mask / subset filter (the oracle's CIGAR call takes
+    neither) the rows against the oracle and the CIGARs against the single-GPU index"""
+    p = impg_amd.make_params(store_cigar=True, **kw)
+    res = g.query_batch(rl, p, masked_regions=masked_regions, subset_keep=subset_keep)
+    ref = single.query_batch(rl, p, masked_regions=masked_regions, subset_keep=subset_keep) if single is not None else None
+    for i, (t, s, e) in enumerate(rl):
+        if ref is None:
+            want, wcg = c.query_cigar(t, s, e, **kw)
+        else:
+            want, wcg = c.query(t, s, e, masked_regions=masked_regions, subset_keep=subset_keep, **kw), ref.cigars(i)
+        assert res[i].tolist() == want.tolist(), (i, kw)
+        got = res.cigars(i)
+        assert len(got) == len(wcg), (i, kw)
+        for k in range(len(wcg)):
+            assert got[k].tolist() == wcg[k].tolist(), (i, k, kw)
+
+
 CASES = [dict(), dict(transitive=True, max_depth=2), dict(transitive=True, max_depth=3, min_transitive_len=20),
          dict(transitive=True, max_depth=0, min_transitive_len=200, min_output_length=150),
          dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=50),
@@ -62,11 +80,28 @@ def test_multi_handle_matches_oracle(tmp_path, world, lanes):
         got = g.query_batch(rl, impg_amd.make_params(**kw), subset_keep=keep)
         for i, (t, s, e) in enumerate(rl):
             assert got[i].tolist() == c.query(t, s, e, subset_keep=keep, **kw).tolist(), (i, kw, "subset")
-    with pytest.raises(impg_amd.ImpgGpuError) as ei:
-        g.query_batch(rl, impg_amd.make_params(store_cigar=True))
-    assert ei.value.code == impg_amd.IMPG_E_UNSUPPORTED
-    # ... and the handle still works after the refused call
-    assert g.query_batch(rl[:3], impg_amd.make_params())[0].tolist() == c.query(*rl[0]).tolist()
+    # store_cigar: the owners materialise the hits' CIGAR slices, the ops travel home behind the hit records
+    for kw in (dict(), dict(transitive=True, max_depth=2, min_transitive_len=40), dict(transitive=True, dfs=True, max_depth=2, min_transitive_len=40),
+               dict(transitive=True, max_depth=2, multi_impg=True), dict(min_identity=0.7)):
+        check_cigars(g, c, rl, **kw)
+    check_cigars(g, c, rl, subset_keep=keep, single=single, transitive=True, max_depth=2)
+    check_cigars(g, c, rl, masked_regions=mask, single=single, transitive=True, max_depth=2)
+    # PAF / BEDPE text from those results (main.rs:7472-7496) equals the single index's, byte for byte
+    p = impg_amd.make_params(store_cigar=True, transitive=True, max_depth=2)
+    for fmt in ("paf", "bedpe"):
+        assert g.query_batch(rl, p).paf(None, merge_distance=100, params=p, fmt=fmt) == \
+            single.query_batch(rl, p).paf(None, merge_distance=100, params=p, fmt=fmt)
+    # BED: query + both merges + text on the home ranks' devices, concatenated in the caller's order
+    names = ["r%d" % i if i % 3 else None for i in range(len(rl))]
+    for kw in (dict(), dict(transitive=True, max_depth=2), dict(transitive=True, dfs=True, max_depth=2, multi_impg=True)):
+        p = impg_amd.make_params(**kw)
+        for d in (-1, 0, 150):
+            text = g.query_batch_bed(rl, p, merge_distance=d, range_names=names)
+            assert text == single.query_batch_bed(rl, p, merge_distance=d, range_names=names), (kw, d)
+        want = "".join(c.query_bed(c.seq_name(t), s, e, range_name=names[i], merge_distance=150, **kw) for i, (t, s, e) in enumerate(rl))
+        assert text == want, kw
+    assert g.query_batch_bed(rl, impg_amd.make_params(transitive=True, max_depth=2), merge_distance=50, subset_keep=keep) == \
+        single.query_batch_bed(rl, impg_amd.make_params(transitive=True, max_depth=2), merge_distance=50, subset_keep=keep)
     # an empty batch, a batch smaller than the world
     assert len(g.query_batch([], impg_amd.make_params(transitive=True))) == 0
     got = g.query_batch(rl[:2], impg_amd.make_params(transitive=True, max_depth=2))

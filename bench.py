@@ -133,13 +133,16 @@ def main():
         # this rank's shard of the index (targets bin-packed over the ranks); torch.distributed only carries the
         # RCCL ids to the ranks -- every collective of a query runs inside libimpg_gpu.so
         comm = impg_amd.Comm.rccl(rank, world, local_rank, lanes=args.lanes)
+    t_gen = 0.0
     if paf:
         index = impg_amd.GpuImpg.from_paf(paf, device=local_rank, comm=comm)
     else:
         rec, ops, sl = impg_amd.synth_paf(42, args.records, n_seq=n_seq, seq_len=seq_len)
+        t_gen = time.time() - t_build  # generating the records is not building the index
+        log("synthetic records generated (%.1f s)" % t_gen)
         index = impg_amd.GpuImpg.from_records(rec, ops, sl, device=local_rank, comm=comm)
         del rec, ops
-    t_build = time.time() - t_build
+    t_build = time.time() - t_build - t_gen
     index.set_option("chunk_ranges", args.chunk_ranges)
     index.set_option("pair_budget", args.pair_budget)
     for kv in args.engine_option:

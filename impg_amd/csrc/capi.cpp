@@ -1,5 +1,6 @@
 // extern "C" entry points of libimpg_gpu.so (include/impg_gpu.h).  Nothing
 // unwinds across this file: every body is wrapped and mapped to a status code.
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -296,10 +297,50 @@ int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths, int bi
   ParsedPaf pp;
   std::vector<std::string> ps(paths, paths + n_paths);
   const auto t0 = std::chrono::steady_clock::now();
-  parse_paf_files(ps, pp);
-  if (getenv("IMPG_BUILD_TIMING"))
-    fprintf(stderr, "[build] %-28s %.3f s\n", "parse PAF", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  const bool timing = getenv("IMPG_BUILD_TIMING") != nullptr;
+  auto lap = [&](const char *what, std::chrono::steady_clock::time_point from) {
+    if (timing) fprintf(stderr, "[build] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - from).count());
+  };
+  // The CIGAR text is tokenised on the device (parse_cigar_to_delta, impg.rs:2935-2950 -> cigar_tokens_kernel): the
+  // host only splits lines and fields, the text crosses PCIe once and the ops never exist on the host.  Inputs whose
+  // text and ops would not fit next to the index they become (or IMPG_BUILD_HOST=1) are tokenised by the host parser.
+  bool raw = getenv("IMPG_BUILD_HOST") == nullptr;
+  if (raw) {
+    uint64_t bytes = 0;
+    for (auto &p : ps) {
+      struct stat st;
+      if (stat(p.c_str(), &st) == 0) bytes += (uint64_t)st.st_size * ((p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0) ? 6 : 1);
+    }
+    size_t free_b = 0, total_b = 0;
+    IMPG_HIP(hipSetDevice(device));
+    IMPG_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (bytes * 8 > free_b) raw = false;  // text + ops (<= 2 bytes of text per op) + the index (~3.4 x the ops)
+  }
+  parse_paf_files(ps, pp, raw);
+  lap(raw ? "parse PAF (lines, fields)" : "parse PAF", t0);
   std::vector<int64_t> lens = pp.seq.lens;
+  if (raw) {
+    const auto t1 = std::chrono::steady_clock::now();
+    DevBuf d_ops;
+    const uint64_t n_ops = tokenize_on_device(pp, device, d_ops);
+    lap("CIGAR text -> ops (device)", t1);
+    auto ix = std::make_unique<impg_gpu_index>();
+    ix->device = device;
+    ix->seq = pp.seq;
+    if (pp.file_first.size() < 2 || pp.file_first.front() != 0 || pp.file_first.back() != pp.records.size())
+      throw Error{IMPG_E_INVALID, "internal: bad file boundaries"};
+    ix->file_first = pp.file_first;
+    if (order_policy != IMPG_ORDER_COITREES && order_policy != IMPG_ORDER_SORTED) throw Error{IMPG_E_INVALID, "bad order policy"};
+    if (build_index_device(*ix, pp.records.data(), pp.records.size(), nullptr, n_ops, lens.data(), (uint32_t)lens.size(), bidirectional != 0,
+                           order_policy, 0, 1, nullptr, d_ops.as<uint32_t>())) {
+      { EngineLease warm(*ix); }
+      *out = ix.release();
+      return IMPG_OK;
+    }
+    // (the device was short of memory for the build: the ops come back and the host builder takes over)
+    pp.ops.resize(n_ops);
+    if (n_ops) IMPG_HIP(hipMemcpy(pp.ops.data(), d_ops.p, n_ops * 4, hipMemcpyDeviceToHost));
+  }
   *out = make_index(pp.records.data(), pp.records.size(), pp.ops.data(), pp.ops.size(), lens.data(), (uint32_t)lens.size(),
                     bidirectional, order_policy, device, 0, 1, &pp.seq, &pp.file_first, nullptr).release();
   return IMPG_OK;

@@ -77,6 +77,8 @@ bool to_u64(Field f, uint64_t *v) {
 }
 
 struct ChunkOut {
+  const char *raw_text = nullptr;          // raw mode: CIGARs stay text, records carry byte offsets from here ...
+  uint64_t raw_base = 0;                   // ... plus this
   std::vector<impg_gpu_record_t> records;  // ids are chunk-local
   std::vector<uint32_t> ops;
   std::vector<std::string> names;          // chunk-local id -> name, first-seen order
@@ -129,7 +131,11 @@ bool parse_line(const char *line, size_t len, ChunkOut &o) {
   r.strand = sc == '-';
   r.cigar_off = o.ops.size();
   r.cigar_len = 0;
-  if (cg && cgn) {
+  if (o.raw_text) {
+    if (cgn >= 0xFFFFFFF0ull) { o.err = "CIGAR longer than 2^32 bytes"; return false; }
+    r.cigar_off = cg ? (uint64_t)(cg - o.raw_text) + o.raw_base : 0;
+    r.cigar_len = (uint32_t)cgn;
+  } else if (cg && cgn) {
     size_t base = o.ops.size();
     o.ops.resize(base + cgn);  // upper bound: one op per byte
     long k = parse_cigar(cg, cgn, o.ops.data() + base, cgn);
@@ -156,7 +162,7 @@ void parse_chunk(const char *text, size_t begin, size_t end, ChunkOut &o) {
 
 }  // namespace
 
-void parse_paf_text(const char *text, size_t len, ParsedPaf &out) {
+void parse_paf_text(const char *text, size_t len, ParsedPaf &out, bool raw, uint64_t text_base) {
   unsigned hw = std::thread::hardware_concurrency();
   size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, len / (4u << 20) + 1));
   std::vector<size_t> cut(T + 1, len);
@@ -168,6 +174,7 @@ void parse_paf_text(const char *text, size_t len, ParsedPaf &out) {
   }
   for (size_t t = 1; t <= T; t++) cut[t] = std::max(cut[t], cut[t - 1]);
   std::vector<ChunkOut> chunks(T);
+  if (raw) for (auto &c : chunks) { c.raw_text = text; c.raw_base = text_base; }
   std::vector<std::thread> th;
   for (size_t t = 0; t < T; t++)
     th.emplace_back([&, t]() { parse_chunk(text, cut[t], cut[t + 1], chunks[t]); });
@@ -197,7 +204,7 @@ void parse_paf_text(const char *text, size_t len, ParsedPaf &out) {
         impg_gpu_record_t r = c.records[i];
         r.query_id = remap[t][r.query_id];
         r.target_id = remap[t][r.target_id];
-        r.cigar_off += ops_at[t];
+        if (!raw) r.cigar_off += ops_at[t];
         dst[i] = r;
       }
       std::vector<uint32_t>().swap(c.ops);
@@ -206,8 +213,10 @@ void parse_paf_text(const char *text, size_t len, ParsedPaf &out) {
   for (auto &x : th) x.join();
 }
 
-void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out) {
+void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out, bool raw) {
   out.file_first.clear();
+  out.raw = raw;
+  uint64_t text_base = 0;
   for (const auto &path : paths) {
     out.file_first.push_back(out.records.size());
     if (path.size() > 3 && (path.compare(path.size() - 3, 3, ".gz") == 0 ||
@@ -232,7 +241,13 @@ void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out) {
         text.append(buf.data(), (size_t)n);
       }
       gzclose(gz);
-      if (!text.empty()) parse_paf_text(text.data(), text.size(), out);
+      if (raw) {
+        auto keep = std::make_shared<std::string>(std::move(text));
+        out.holders.push_back(keep);
+        out.texts.push_back({keep->data(), keep->size(), text_base});
+        if (!keep->empty()) parse_paf_text(keep->data(), keep->size(), out, true, text_base);
+        text_base += keep->size();
+      } else if (!text.empty()) parse_paf_text(text.data(), text.size(), out);
       continue;
     }
     int fd = open(path.c_str(), O_RDONLY);
@@ -244,6 +259,13 @@ void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out) {
     void *m = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (m == MAP_FAILED) throw Error{IMPG_E_IO, "Failed to map file '" + path + "'"};
+    if (raw) {  // the mapping lives until the device has tokenised the CIGARs
+      out.holders.push_back(std::shared_ptr<void>(m, [sz](void *q) { munmap(q, sz); }));
+      out.texts.push_back({(const char *)m, sz, text_base});
+      parse_paf_text((const char *)m, sz, out, true, text_base);
+      text_base += sz;
+      continue;
+    }
     try {
       parse_paf_text((const char *)m, sz, out);
     } catch (...) {

@@ -235,10 +235,20 @@ struct ParsedPaf {
   std::vector<impg_gpu_record_t> records;
   std::vector<uint32_t> ops;
   std::vector<uint64_t> file_first;  // first record of every input file, then the record count
+  // Raw mode (parse_paf_files(..., raw = true)): the CIGAR text is NOT tokenised on the host; records[i].cigar_off /
+  // cigar_len are a byte offset / byte count in the concatenation of `texts`, and the device tokenises
+  // (tokenize_on_device, index_build_device.hip), after which they are op offsets / counts like everywhere else.
+  bool raw = false;
+  struct Text { const char *p; size_t n; uint64_t base; };  // base: offset of the span in the concatenation
+  std::vector<Text> texts;
+  std::vector<std::shared_ptr<void>> holders;  // keep the spans alive (file mappings, decompressed buffers)
 };
 // parse_paf + parse_cigar_to_delta over whole files (paf.rs:118-194, impg.rs:2935-2950)
-void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out);
-void parse_paf_text(const char *text, size_t len, ParsedPaf &out);
+void parse_paf_files(const std::vector<std::string> &paths, ParsedPaf &out, bool raw = false);
+void parse_paf_text(const char *text, size_t len, ParsedPaf &out, bool raw = false, uint64_t text_base = 0);
+// raw mode: CIGAR text -> packed ops on the device (same tokens and the same errors as parse_cigar); fills d_ops and turns
+// the records' byte offsets into op offsets.  Returns the number of ops.
+uint64_t tokenize_on_device(ParsedPaf &pp, int device, DevBuf &d_ops);
 long parse_cigar(const char *s, size_t n, uint32_t *out, size_t cap);
 
 // tracepoint alignments (approximate mode): what build_index reads instead of the op pool
@@ -256,6 +266,10 @@ struct EntryPlan {
   std::vector<std::vector<uint64_t>> per_target;
 };
 
+// index_build_device.hip: the same index built by kernels from the packed ops; false = not taken (short of device memory)
+bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_records, const uint32_t *cigar_ops, size_t n_ops,
+                        const int64_t *seq_len, uint32_t n_seq, bool bidirectional, int order_policy, uint32_t shard, uint32_t n_shards,
+                        const uint32_t *owner, const uint32_t *d_cigar_ops = nullptr /* the op pool already on the device */);
 // visit rank of each sorted position of an n-entry segment (order policy)
 void coitrees_visit_rank(uint32_t n, uint32_t *rank_out);
 

@@ -183,6 +183,13 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   if (n_shards == 0 || shard >= n_shards) throw Error{IMPG_E_INVALID, "bad shard"};
   if (order_policy != IMPG_ORDER_COITREES && order_policy != IMPG_ORDER_SORTED)
     throw Error{IMPG_E_INVALID, "bad order policy"};
+  if (n_shards > 1 && !owner) throw Error{IMPG_E_INVALID, "a sharded index needs its shard map"};
+  // CIGAR indexes in record order are built on the device (index_build_device.hip); this host builder takes the
+  // rest (tracepoint indexes, the entry order of a loaded .impg file), is the fallback when the device is short of
+  // memory for the build, and the checker of the device build (IMPG_BUILD_HOST=1 forces it).
+  if (!tp && !plan && !getenv("IMPG_BUILD_HOST") &&
+      build_index_device(ix, records, n_records, cigar_ops, n_ops, seq_len, n_seq, bidirectional, order_policy, shard, n_shards, owner))
+    return;
   if (n_records >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 records in one index"};
   ix.n_records = n_records;
   if (ix.seq.lens.empty()) ix.seq.lens.assign(seq_len, seq_len + n_seq);

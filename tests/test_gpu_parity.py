@@ -1209,3 +1209,40 @@ def test_prefix_line_edges(tmp_path):
     for kw in [dict(), dict(transitive=True, max_depth=2, min_transitive_len=1, min_distance_between_ranges=0)]:
         for lo in range(0, len(ranges), 400):
             assert_same(g, c, ranges[lo:lo + 400], **kw)
+
+
+@pytest.mark.parametrize("seed,max_ops,bidirectional,order", [(1, 60, True, 0), (2, 700, True, 0), (3, 30, False, 1), (4, 2500, True, 0)])
+def test_device_build_matches_host_build(tmp_path, seed, max_ops, bidirectional, order):
+    """The index built by kernels from the packed ops (index_build_device.hip: op lines, prefix lines, identity
+    prefixes, checkpoints inline and external, entries by (target, start), columns, levels) against the host builder
+    (index_build.cpp, IMPG_BUILD_HOST=1): the two saved index files are the same bytes.  CIGARs of 1 .. 2 500 ops
+    (external checkpoints from 209 on), zero-length and inconsistent ops, tiles whose sums overflow 16 bits, several
+    alignment files (MultiImpg tie ranks), both order policies."""
+    import os
+    sl = 3_000_000 if max_ops > 1000 else 200_000
+    texts = [random_paf(seed * 10 + k, 220, n_seq=6, seq_len=sl, max_ops=max_ops, weird=True, inconsistent=(seed % 2 == 0), self_aln=True)[0]
+             for k in range(2)]
+    # tiles whose running sums do not fit 16 bits: ops of 70 kb, and 40 ops of 3 kb in one tile
+    texts[0] += "s1\t%d\t0\t140010\t+\ts2\t%d\t100\t140110\t140000\t140010\t60\tcg:Z:70000=10I70000=\n" % (sl, sl)
+    texts[0] += "s0\t%d\t5\t120005\t-\ts3\t%d\t7\t120007\t120000\t120000\t60\tcg:Z:%s\n" % (sl, sl, "3000=" * 40)
+    paths = []
+    for k, t in enumerate(texts):
+        paths.append(str(tmp_path / ("f%d.paf" % k)))
+        open(paths[-1], "w").write(t)
+    files = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            os.environ["IMPG_BUILD_HOST"] = "1"
+        try:
+            g = impg_amd.GpuImpg.from_paf(paths, bidirectional=bidirectional, order=order)
+        finally:
+            os.environ.pop("IMPG_BUILD_HOST", None)
+        f = str(tmp_path / (mode + ".idx"))
+        g.save(f)
+        files[mode] = open(f, "rb").read()
+        del g
+    assert len(files["device"]) == len(files["host"])
+    if files["device"] != files["host"]:
+        a, b = np.frombuffer(files["device"], dtype=np.uint8), np.frombuffer(files["host"], dtype=np.uint8)
+        bad = np.nonzero(a != b)[0]
+        raise AssertionError("saved indexes differ in %d bytes, first at offset %d of %d" % (len(bad), int(bad[0]), len(a)))

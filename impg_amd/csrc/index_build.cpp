@@ -247,7 +247,8 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   }
   RawVec<uint32_t> pool(n_tiles * TILE_WORDS);  // (every line is filled by the builder that owns it)
   RawVec<uint4> idp(tp ? 0 : TILE_SUBS * n_tiles);  // per sub-tile: matched / mismatched bases and gap ops before it (identity filter)
-  RawVec<uint32_t> pfx(tp ? 0 : n_tiles * TILE_WORDS);  // prefix lines (impg_internal.hpp)
+  const bool with_pfx = !tp && !(getenv("IMPG_PREFIX_LINES") && atoi(getenv("IMPG_PREFIX_LINES")) == 0);
+  RawVec<uint32_t> pfx(with_pfx ? n_tiles * TILE_WORDS : 0);  // prefix lines (impg_internal.hpp); optional: see index_build_device.hip
   if (tp && n_tiles) {  // the tail of the last 128-byte line behind the last boundary
     uint64_t nb_words = 0;
     for (size_t i = 0; i < n_records; i++) if (need[i]) nb_words += ((uint64_t)records[i].cigar_len + 1) * 4;
@@ -302,7 +303,8 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
         uint32_t dt[TILE_SUBS + 1], dq[TILE_SUBS + 1];  // sums before sub-tile s (s = 4: after the tile)
         uint32_t sub = 0;
         const uint32_t cnt = std::min(n - k0, TILE_OPS);
-        uint32_t *pl = pfx.data() + tile * TILE_WORDS;
+        uint32_t scratch_line[TILE_WORDS];
+        uint32_t *pl = with_pfx ? pfx.data() + tile * TILE_WORDS : scratch_line;
         bool pwide = false;
         auto boundary = [&]() {
           dt[sub] = st - t0; dq[sub] = sq - q0;
@@ -625,7 +627,7 @@ void impg_gpu_index::bind_view(uint32_t n_seq, uint32_t sorted_order) {
   view.ops = d_ops.as<uint32_t>();
   view.ext_cp = d_ext_cp.as<uint32_t>();
   view.idp = d_idp.as<uint4>();
-  view.pfx = d_pfx.as<uint32_t>();
+  view.pfx = blob_bytes[14] ? d_pfx.as<uint32_t>() : nullptr;  // (an index may come without prefix lines)
   view.seq_len = d_seq_len.as<int32_t>();
   view.n_seq = n_seq;
   view.n_entries = (uint32_t)n_entries;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void tiles_kernel(const impg_gpu_record_t *__r
     if (tile_on) {
       const size_t tile = (size_t)tile_base[rec] + j;
       pool[tile * TILE_WORDS + w] = lw;
-      pfx[tile * TILE_WORDS + w] = pw;
+      if (pfx) pfx[tile * TILE_WORDS + w] = pw;
       if (w < TILE_SUBS) idp[TILE_SUBS * tile + w] = sfo < cnt ? make_uint4(pM, pX, pG, 0u) : make_uint4(endM, endX, endG, 0u);
     }
     // carry: the sums after this step's last op (lane 63 holds them whatever the halves' fill)
@@ -357,7 +357,12 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
   IMPG_HIP(hipSetDevice(ix.device));
   size_t free_b = 0, total_b = 0;
   IMPG_HIP(hipMemGetInfo(&free_b, &total_b));
-  const size_t out_bytes = n_tiles * (2 * TILE_WORDS * 4 + TILE_SUBS * 16) + n_entries * (sizeof(Entry) + 40) + n_records * 64;
+  // The prefix lines are 40 % of the index and only buy speed (the plain projection reads them instead of replaying
+  // ops): an index that does not fit the device with them is built without (IMPG_PREFIX_LINES=0 forces that).
+  bool with_pfx = !(getenv("IMPG_PREFIX_LINES") && atoi(getenv("IMPG_PREFIX_LINES")) == 0);
+  auto bytes_for = [&](bool pf) { return n_tiles * ((pf ? 2 : 1) * TILE_WORDS * 4 + TILE_SUBS * 16) + n_entries * (sizeof(Entry) + 40) + n_records * 64; };
+  if (with_pfx && bytes_for(true) + (1ull << 30) > free_b) with_pfx = false;
+  const size_t out_bytes = bytes_for(with_pfx);
   if (out_bytes + (1ull << 30) > free_b) return false;  // (the host builder reports the shortage in its own words)
   if (!d_cigar_ops && !monotone && n_ops * 4 + out_bytes + (1ull << 30) > free_b) return false;
   ix.n_records = n_records;
@@ -387,7 +392,8 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
   }
   const uint32_t *dev_owner = n_shards > 1 ? d_owner.as<uint32_t>() : nullptr;
   size_blob(ix, 10, n_tiles * TILE_WORDS * 4, acc);
-  size_blob(ix, 14, n_tiles * TILE_WORDS * 4, acc);
+  size_blob(ix, 14, with_pfx ? n_tiles * TILE_WORDS * 4 : 0, acc);
+  uint32_t *const d_pfx = with_pfx ? ix.blob(14)->as<uint32_t>() : nullptr;
   size_blob(ix, 12, n_tiles * TILE_SUBS * 16, acc);
   {
     const size_t BATCH_OPS = 64ull << 20;  // 256 MB of ops per upload
@@ -396,7 +402,7 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
     if (d_cigar_ops) {  // the pool is already here (tokenize_on_device): one launch over all records
       if (n_records)
         tiles_kernel<<<cdiv(n_records, 4), 256, 0, s>>>(d_rec.as<impg_gpu_record_t>(), d_need.as<uint8_t>(), d_tb.as<uint32_t>(), 0u, (uint32_t)n_records,
-                                                          d_cigar_ops, 0ull, ix.blob(10)->as<uint32_t>(), ix.blob(14)->as<uint32_t>(),
+                                                          d_cigar_ops, 0ull, ix.blob(10)->as<uint32_t>(), d_pfx,
                                                           ix.blob(12)->as<uint4>(), d_totT.as<uint32_t>(), d_totQ.as<uint32_t>(), d_flag.as<uint32_t>());
       IMPG_HIP(hipStreamSynchronize(s));
       b0 = n_records;
@@ -421,7 +427,7 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
       }
       const uint32_t nr = (uint32_t)(b1 - b0);
       tiles_kernel<<<cdiv(nr, 4), 256, 0, s>>>(d_rec.as<impg_gpu_record_t>(), d_need.as<uint8_t>(), d_tb.as<uint32_t>(), (uint32_t)b0, nr,
-                                                d_ops.as<uint32_t>(), lo, ix.blob(10)->as<uint32_t>(), ix.blob(14)->as<uint32_t>(),
+                                                d_ops.as<uint32_t>(), lo, ix.blob(10)->as<uint32_t>(), d_pfx,
                                                 ix.blob(12)->as<uint4>(), d_totT.as<uint32_t>(), d_totQ.as<uint32_t>(), d_flag.as<uint32_t>());
       IMPG_HIP(hipStreamSynchronize(s));  // (the next batch overwrites d_ops)
       b0 = b1;

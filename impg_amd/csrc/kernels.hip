@@ -2816,7 +2816,11 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
                     ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev, bool regroup) {
   if (!n_pairs) return;
   const int rg = regroup ? 1 : 0;
-  const bool ident = min_identity == min_identity;  // NaN = no filter
+  bool ident = min_identity == min_identity;  // NaN = no filter
+  // An index built without prefix lines (it would not have fitted the device with them: index_build_device.hip) has
+  // no plain path: its projections take the identity filter's two short walks on the op lines with a threshold
+  // nothing fails (identity >= 0) -- the same answers, about twice the instructions.
+  if (!ident && !v.pfx && !v.tp_mode) { ident = true; min_identity = 0.0; }
   if (v.tp_mode) {  // tracepoint index: every projection is the approximate one
     const uint32_t gt = (cdiv(n_pairs, 256) + 7u) & ~7u;
     if (transitive) project_tp_kernel<true><<<gt, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag,

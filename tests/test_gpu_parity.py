@@ -1246,3 +1246,34 @@ def test_device_build_matches_host_build(tmp_path, seed, max_ops, bidirectional,
         a, b = np.frombuffer(files["device"], dtype=np.uint8), np.frombuffer(files["host"], dtype=np.uint8)
         bad = np.nonzero(a != b)[0]
         raise AssertionError("saved indexes differ in %d bytes, first at offset %d of %d" % (len(bad), int(bad[0]), len(a)))
+
+
+def test_index_without_prefix_lines(tmp_path):
+    """An index that does not fit the device with its prefix lines is built without them (here forced with
+    IMPG_PREFIX_LINES=0): the plain projection then takes the two short walks on the op lines.  Same rows as the oracle,
+    40 % fewer bytes, device build == host build, and the saved file keeps the choice."""
+    import os
+    text, _ = random_paf(11, 400, n_seq=6, seq_len=60_000, max_ops=400, weird=True, inconsistent=True, self_aln=True)
+    g_full, c = both(tmp_path, text)
+    os.environ["IMPG_PREFIX_LINES"] = "0"
+    try:
+        g = impg_amd.GpuImpg.from_paf(str(tmp_path / "t.paf"))
+        os.environ["IMPG_BUILD_HOST"] = "1"
+        g_host = impg_amd.GpuImpg.from_paf(str(tmp_path / "t.paf"))
+    finally:
+        os.environ.pop("IMPG_PREFIX_LINES", None)
+        os.environ.pop("IMPG_BUILD_HOST", None)
+    assert g.device_bytes() < 0.75 * g_full.device_bytes()
+    ranges = random_ranges(5, 150, 6, 60_000, max_len=6000, min_len=1)
+    assert_same(g, c, ranges)
+    assert_same(g, c, ranges[:60], transitive=True, max_depth=3, min_transitive_len=20)
+    assert_same(g, c, ranges[:40], transitive=True, dfs=True, max_depth=2, min_transitive_len=40)
+    assert_same(g, c, ranges, min_identity=0.9)
+    assert_same(g, c, ranges[:40], store_cigar=True, transitive=True, max_depth=2, min_transitive_len=40)
+    assert g.query(*ranges[0]).tolist() == c.query(*ranges[0]).tolist()  # (the one-sync small-batch path)
+    g.save(str(tmp_path / "np.idx"))
+    g_host.save(str(tmp_path / "np_host.idx"))
+    assert open(str(tmp_path / "np.idx"), "rb").read() == open(str(tmp_path / "np_host.idx"), "rb").read()
+    g2 = impg_amd.GpuImpg.load(str(tmp_path / "np.idx"))
+    assert g2.device_bytes() == g.device_bytes()
+    assert_same(g2, c, ranges[:50], transitive=True, max_depth=2)

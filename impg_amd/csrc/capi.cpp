@@ -49,6 +49,8 @@ EngineLease::EngineLease(impg_gpu_index &ix_) : ix(ix_) {
   e->free_slots_allowed = ix.opt_free_slots;
   e->regroup_pairs = ix.opt_regroup;
   e->filter_covered = ix.opt_filter_covered;
+  e->walk_allowed = ix.opt_walk != 0 && !getenv("IMPG_NO_WALK");
+  e->walk_bfs = ix.opt_walk == 2;  // (the environment switch runs a whole test suite on the batch engine)
 }
 EngineLease::~EngineLease() {
   e->remote = nullptr;
@@ -166,6 +168,63 @@ template <class F> void for_chunks(Engine &E, size_t n, F fn) {
   }
 }
 
+}  // namespace
+
+namespace {
+// The trait's rows from the per-query walk (Engine::run_walk).  A handful of queries write into generous fixed
+// regions of one pool and are done in one launch; a batch (or a query that outgrows its region) is counted first and
+// walked again with every query's rows at their final place -- the walk is deterministic, so the second pass writes
+// exactly what the first counted.
+bool walk_query(impg_gpu_index &ix, Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p, impg_gpu_results &res) {
+  hipStream_t s = E.stream;
+  Engine::WalkRows W;
+  for (DevBuf *b : {&W.rows, &W.base, &W.cap, &W.n_rows}) b->pool = &E.level_pool;
+  W.base.reserve(std::max<size_t>((size_t)n * 8, 256)); W.cap.reserve(std::max<size_t>((size_t)n * 4, 256));
+  W.n_rows.reserve(std::max<size_t>((size_t)n * 4, 256));
+  std::vector<unsigned long long> base(n);
+  std::vector<uint32_t> cap(n), cnt(n);
+  const bool optimistic = n <= Engine::SMALL_RANGES;
+  const uint32_t each = optimistic ? (1u << 17) : 0u;
+  for (uint32_t q = 0; q < n; q++) { base[q] = (unsigned long long)q * each; cap[q] = each; }
+  auto pass = [&](uint64_t total_rows) {
+    W.rows.reserve(std::max<size_t>(total_rows * sizeof(impg_gpu_interval_t), 256));
+    IMPG_HIP(hipMemcpyAsync(W.base.p, base.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    IMPG_HIP(hipMemcpyAsync(W.cap.p, cap.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (!E.run_walk(ix, E.ranges_dev.as<impg_gpu_range_t>(), n, p, nullptr, nullptr, nullptr, &W)) return false;
+    IMPG_HIP(hipMemcpy(cnt.data(), W.n_rows.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return true;
+  };
+  if (!pass((uint64_t)n * each)) return false;
+  bool fits = true;
+  uint64_t total = 0;
+  for (uint32_t q = 0; q < n; q++) { fits = fits && cnt[q] <= cap[q]; total += cnt[q]; }
+  bool contiguous = false;
+  if (!fits) {
+    uint64_t at = 0;
+    for (uint32_t q = 0; q < n; q++) { base[q] = at; cap[q] = cnt[q]; at += cnt[q]; }
+    const std::vector<uint32_t> want = cnt;
+    if (!pass(total)) return false;
+    if (cnt != want) throw Error{IMPG_E_INVALID, "internal: the walk's second pass disagrees with its first"};
+    contiguous = true;
+  }
+  res.offsets.assign((size_t)n + 1, 0);
+  for (uint32_t q = 0; q < n; q++) res.offsets[q + 1] = res.offsets[q] + cnt[q];
+  res.intervals.resize(total, true);
+  const impg_gpu_interval_t *d_rows = W.rows.as<impg_gpu_interval_t>();
+  if (contiguous) {
+    if (total) IMPG_HIP(hipMemcpyAsync(res.intervals.data(), d_rows, total * sizeof(impg_gpu_interval_t), hipMemcpyDeviceToHost, s));
+  } else {
+    for (uint32_t q = 0; q < n; q++)
+      if (cnt[q])
+        IMPG_HIP(hipMemcpyAsync(res.intervals.data() + res.offsets[q], d_rows + base[q], (size_t)cnt[q] * sizeof(impg_gpu_interval_t),
+                                hipMemcpyDeviceToHost, s));
+  }
+  IMPG_HIP(hipStreamSynchronize(s));
+  res.has_cigar = false;
+  res.projected = E.last_projected;
+  (void)h_ranges;
+  return true;
+}
 }  // namespace
 
 namespace impg {
@@ -438,6 +497,9 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
     ix->opt_locality_min = (uint32_t)value;
   } else if (k == "regroup_entries") {  // projection blocks regroup their pairs by entry before reading the index (results identical)
     ix->opt_regroup = value != 0;
+  } else if (k == "walk_kernel") {  // the per-query walk (walk_device.inc): 0 never, 1 DFS batches of any size (default), 2 also BFS batches of <= 64 ranges
+    if (value < 0 || value > 2) throw Error{IMPG_E_INVALID, "walk_kernel is 0, 1 or 2"};
+    ix->opt_walk = (int)value;
   } else if (k == "filter_covered") {  // visited update: hits covered by the old list dropped before the replay (0 off, 1 always, 2 auto; results identical)
     if (value < 0 || value > 2) throw Error{IMPG_E_INVALID, "filter_covered is 0, 1 or 2"};
     ix->opt_filter_covered = (int)value;
@@ -553,6 +615,16 @@ int impg_gpu_query_batch_filtered(impg_gpu_index_t *ix, const impg_gpu_range_t *
   }
   E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
   if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
+  if (n < (1ull << 31) && E.walk_applicable(*ix, (uint32_t)n, *params)) {  // small transitive batches, DFS batches: one launch
+    const auto c0 = std::chrono::steady_clock::now();
+    if (walk_query(*ix, E, ranges, (uint32_t)n, *params, *res)) {
+      res->run_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+      res->ranges.assign(ranges, ranges + n);
+      *out = res.release();
+      return IMPG_OK;
+    }
+    res = std::make_unique<impg_gpu_results>();  // (a query outgrew its slab: the batch engine takes the batch)
+  }
   res->offsets.assign(1, 0);
   for_chunks(E, n, [&](size_t b, size_t e) {
     std::vector<std::unique_ptr<LevelBufs>> levels;

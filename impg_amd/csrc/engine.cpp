@@ -113,6 +113,93 @@ bool Engine::run_small(const impg_gpu_index &ix, const impg_gpu_range_t *h_range
   return true;
 }
 
+bool Engine::walk_applicable(const impg_gpu_index &ix, uint32_t n, const impg_gpu_params_t &p) const {
+  if (!walk_allowed || !n || !p.transitive || p.multi_impg || p.store_cigar || masked || remote || ix.tp_mode) return false;
+  if (ix.view.n_seq > 65536u) return false;  // (hit keys are sequence << 15 | slot in 32 bits)
+  // DFS: always (its steps are single pops; the batch engine pays a launch sequence per pop round).  BFS: a small batch
+  // runs level by level either way and the two forms cost the same (0.9 ms per call): the batch engine keeps it, and
+  // walk_kernel = 2 sends it here (tests)
+  return p.dfs != 0 || (walk_bfs && n <= SMALL_RANGES);
+}
+bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
+                      unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows) {
+  if (!walk_applicable(ix, n, p)) return false;
+  IMPG_HIP(hipSetDevice(ix.device));
+  // a BFS processes whole levels: 16 waves per query; a DFS step is one popped range: one wave, cheap barriers
+  const bool wide = !p.dfs;
+  WalkArgs a;
+  memset(&a, 0, sizeof a);
+  a.wcap = wide ? 16384u : 4096u;   // a BFS frontier; the pieces of one DFS pop
+  a.hcap = wide ? 32767u : 4096u;
+  a.vcap = wide ? 131072u : 131072u;  // visited ranges (lists that outgrow their place move and leave it behind)
+  a.gcap = wide ? 262144u : 16384u;
+  a.scap = wide ? 16u : 65536u;       // DFS stack records (incl. the pieces too deep to be explored, until they are popped)
+  const size_t slab = walk_slab_bytes(ix.view.n_seq, wide, a.wcap, a.hcap, a.vcap, a.gcap, a.scap);
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix.device);
+  const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n, wide ? SMALL_RANGES : (uint64_t)cus * 16u);  // (4096 slabs of ~2.5 MB: a wave per query, latency-bound, wants every wave slot it can get)
+  walk_slabs.reserve(slab * n_wg);
+  walk_ctr.reserve(256);
+  ev_next = 0;
+  timed.clear();
+  IMPG_HIP(hipMemsetAsync(walk_ctr.p, 0, 16, stream));
+  IMPG_HIP(hipMemsetAsync(counters.p, 0, 64, stream));
+  IMPG_HIP(hipMemsetAsync(acc_slots.p, 0, COUNT_BYTES, stream));
+  hipEvent_t t0 = event(), t1 = event();
+  IMPG_HIP(hipEventRecord(t0, stream));
+  a.v = ix.view;
+  a.ranges = d_ranges;
+  a.n_queries = n;
+  a.dfs = p.dfs ? 1 : 0;
+  a.max_depth = p.max_depth;
+  a.min_transitive_len = p.min_transitive_len;
+  a.mdbr = p.min_distance_between_ranges;
+  a.min_output_length = p.min_output_length;
+  a.min_identity = p.min_identity;
+  bool ident = p.min_identity == p.min_identity;
+  if (!ident && !ix.view.pfx) { ident = true; a.min_identity = 0.0; }  // (an index without prefix lines: launch_project does the same)
+  a.subset_keep = subset_on ? subset_keep.as<uint8_t>() : nullptr;
+  a.count = d_count;
+  a.cksum = d_cksum;
+  a.accepted = acc_slots.as<unsigned long long>();
+  a.err_flag = (uint32_t *)(counters.as<uint64_t>() + 2);
+  a.next_query = walk_ctr.as<uint32_t>();
+  a.overflow = walk_ctr.as<uint32_t>() + 1;
+  a.slabs = walk_slabs.as<char>();
+  a.slab_bytes = slab;
+  if (rows) {
+    a.rows = rows->rows.as<impg_gpu_interval_t>();
+    a.row_base = rows->base.as<unsigned long long>();
+    a.row_cap = rows->cap.as<uint32_t>();
+    a.n_rows = rows->n_rows.as<uint32_t>();
+  }
+  const bool dbg = getenv("IMPG_WALK_DEBUG") != nullptr;
+  DevBuf d_dbg;
+  if (dbg) {
+    d_dbg.reserve(256);
+    IMPG_HIP(hipMemsetAsync(d_dbg.p, 0, 256, stream));
+    a.dbg = d_dbg.as<unsigned long long>();
+  }
+  if (st) memset(st, 0, sizeof *st);
+  launch_walk(a, n_wg, wide, ident, stream);
+  uint32_t flags[2] = {0, 0};
+  IMPG_HIP(hipMemcpyAsync(flags, walk_ctr.p, 8, hipMemcpyDeviceToHost, stream));
+  finish_run(st, t0, t1);  // (synchronises; raises the projection errors; fills st->projected / ms_total)
+  if (dbg) {
+    unsigned long long h[32];
+    IMPG_HIP(hipMemcpy(h, d_dbg.p, 256, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[walk] Mclk: drop %.1f window %.1f count %.1f emit %.1f project %.1f sort %.1f groups %.1f (gap %.1f) pieces %.1f merge %.1f | pops %llu dropped %llu max stack %llu max pieces %llu | fail q=%llu flag=%llu target=%llu n_seq=%llu nw=%llu npc=%llu vused=%llu\n",
+            h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5] / 1e6, h[6] / 1e6, h[7] / 1e6, h[8] / 1e6, h[9] / 1e6, h[16], h[17], h[18], h[19],
+            h[24], h[25], h[26], h[27], h[28], h[29], h[30]);
+  }
+  if (dbg)
+    fprintf(stderr, "[walk] n=%u %s wg=%u slab=%.2f MB dfs=%d depth=%u overflow=0x%x (1 unknown target, 2 pairs per step, 4 visited pool, 8 piece scratch, 16 pieces, 32 stack / frontier) %.3f ms\n",
+            n, wide ? "wide" : "wave", n_wg, slab / 1048576.0, a.dfs, a.max_depth, flags[1], st ? st->ms_total : -1.0f);
+  if (flags[1]) return false;  // a query outgrew its slab: the batch engine runs the batch
+  if (st) st->levels = p.max_depth;
+  return true;
+}
+
 Engine::~Engine() {
   if (small_in) (void)hipHostFree(small_in);
   if (small_out) (void)hipHostFree(small_out);
@@ -528,6 +615,22 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   IMPG_HIP(hipEventRecord(t0, stream));
   if (st) memset(st, 0, sizeof *st);
   const bool transitive = p.transitive != 0;
+  // small transitive batches and DFS batches: the per-query walk, one launch (walk_device.inc); counts only here --
+  // callers that want rows ask for them directly (capi.cpp)
+  if (!keep && !self_out && walk_applicable(ix, n, p)) {
+    ev_next = 0;
+    if (run_walk(ix, d_ranges, n, p, d_count, d_cksum, st, nullptr)) return;
+    // (not taken after all: start over on the batch path)
+    if (d_count) IMPG_HIP(hipMemsetAsync(d_count, 0, (size_t)n * 8, stream));
+    if (d_cksum) IMPG_HIP(hipMemsetAsync(d_cksum, 0, (size_t)n * 8, stream));
+    ev_next = 0;
+    timed.clear();
+    IMPG_HIP(hipMemsetAsync(counters.p, 0, 64, stream));
+    IMPG_HIP(hipMemsetAsync(acc_slots.p, 0, COUNT_BYTES, stream));
+    t0 = event(); t1 = event();
+    IMPG_HIP(hipEventRecord(t0, stream));
+    if (st) memset(st, 0, sizeof *st);
+  }
   if (transitive && (p.dfs || multi)) {  // one worklist pop at a time per query
     ev_next = 0;
     run_dfs(ix, d_ranges, n, p, keep, d_count, d_cksum, st, self_out);

@@ -164,6 +164,19 @@ struct Engine {
   static constexpr uint32_t SMALL_RANGES = 64, SMALL_PAIRS = 1u << 18;
   bool run_small(const impg_gpu_index &ix, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p,
                  impg_gpu_results &res);
+  // The per-query walk (walk_device.inc): transitive queries of a small batch, and DFS batches of any size, in ONE
+  // launch -- a workgroup per query.  false = not applicable or a query outgrew its slab: the caller takes the batch
+  // engine.  rows: null = counts only; else the queries' rows (see WalkRows).
+  struct WalkRows {
+    DevBuf rows, base, cap, n_rows;           // device: row pool, first row / capacity / row count of every query
+    std::vector<uint32_t> h_n_rows;           // row counts, on the host
+    std::vector<unsigned long long> h_base;   // where each query's rows start in `rows`
+  };
+  bool walk_allowed = true, walk_bfs = false;  // option "walk_kernel": 0 never, 1 DFS (default), 2 also small BFS batches
+  bool walk_applicable(const impg_gpu_index &ix, uint32_t n, const impg_gpu_params_t &p) const;
+  bool run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
+                unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows);
+  DevBuf walk_slabs, walk_ctr;
   char *small_in = nullptr;    // pinned: the ranges on their way in
   char *small_out = nullptr;   // pinned + mapped: header, rows, the rows' ranges (written by the device)
   void *small_out_dev = nullptr;

@@ -354,6 +354,7 @@ struct impg_gpu_index {
   bool opt_free_slots = true;
   bool opt_regroup = true;
   int opt_filter_covered = 0;
+  int opt_walk = 1;
   impg::ShardCtx *shard = nullptr;    // set: this index is one rank's shard; queries are collective calls
   impg::Cluster *cluster = nullptr;   // set: this handle fronts n_dev shards in this process (no arrays of its own)
   impg_gpu_index();

@@ -964,72 +964,18 @@ __device__ __forceinline__ bool pfx_end(const PairCtx &c, const uint32_t *__rest
 #define PROJECT_OCCUPANCY
 #endif
 constexpr uint32_t PROJ_BLOCK = IMPG_PROJ_BLOCK, PROJ_WAVES = PROJ_BLOCK / 64u;
+// One (range, entry) pair: project_overlapping_interval's PAF branch (impg.rs:1260-1312) for the range [f_start, f_end)
+// against entry eidx.  ok: the projection exists (and passes the identity filter); qid / res: its query sequence and
+// {q_first, q_last, t_first, t_last}; slice descriptors go to sl[p] under MODE_CIGAR.  Shared by project_kernel (a
+// lane per pair of a level) and the per-query walk kernel (walk_device.inc).
 template <bool TRANSITIVE, int MODE>
-__global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
-                                                      const uint32_t *__restrict__ pair_range,
-                                                      const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
-                                                      HitArrays h, unsigned long long *__restrict__ accepted,
-                                                      uint32_t *__restrict__ err_flag, double min_identity,
-                                                      SliceArrays sl, ProjList pl, int xcd_map,
-                                                      const uint32_t *__restrict__ n_pairs_dev, int regroup) {
-  if (n_pairs_dev) n_pairs = *n_pairs_dev;  // small batches: the count stays on the device, the grid covers an upper bound
+__device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t eidx, int32_t f_start, int32_t f_end, uint32_t p,
+                                             double min_identity, uint32_t *__restrict__ err_flag, const SliceArrays &sl,
+                                             unsigned long long *__restrict__ accepted, bool &ok, uint32_t &qid, TileScan &res) {
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   constexpr bool CIGAR = (MODE & MODE_CIGAR) != 0;
-  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give
-  // every XCD one contiguous eighth of the (locality-ordered) pair list instead of
-  // every eighth block of it.  The grid is a multiple of 8 blocks.
-  const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t lblock = xcd_map ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-  const uint32_t pp = lblock * PROJ_BLOCK + threadIdx.x;
-  bool ok = false;
-  TileScan res;
-  res.found = res.any = false;
-  res.pqs = res.pts = res.pqe = res.pte = -1;
-  uint32_t qid = HIT_NONE;
-  // (in projection order the pair's range and entry are listed next to its slot: three coalesced reads)
-  bool live = pp < n_pairs;
-  uint32_t p = pp, r = 0, eidx = 0xFFFFFFFFu;
-  int32_t f_start = 0, f_end = 0;
-  if (live) {
-    if (pl.slot) { p = pl.slot[pp]; r = pl.range[pp]; eidx = pl.entry[pp]; }
-    else { r = pair_range[pp]; eidx = pair_entry[pp]; }
-    asm volatile("" : "+v"(r), "+v"(eidx));
-    const FrontierRec f = fr[r];
-    f_start = f.start; f_end = f.end;
-  }
-  if (regroup) {
-    // The block's 256 pairs, regrouped by entry before anything of the index is read.  In projection order
-    // neighbouring lanes are the hits of ONE range on different entries: every lane reads its own entry line and
-    // its own tile lines.  The ranges of a block are neighbours in the lookup order and hit largely the same
-    // entries, so sorted by entry a wave's lanes share a handful of lines.  A counting sort in LDS over
-    // (entry - the block's smallest entry), one bin per thread; results are stored at the pair's own slot, so
-    // which lane projects which pair changes nothing downstream.
-    __shared__ uint32_t rg_hist[PROJ_BLOCK];
-    __shared__ uint32_t rg_min[PROJ_WAVES];
-    __shared__ uint32_t rg_ws[PROJ_WAVES];
-    __shared__ uint4 rg_pay[PROJ_BLOCK];
-    uint32_t mn = eidx;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
-    rg_hist[threadIdx.x] = 0u;
-    if (lane_id() == 0) rg_min[threadIdx.x >> 6] = mn;
-    __syncthreads();
-    uint32_t emin = rg_min[0];
-#pragma unroll
-    for (uint32_t k = 1; k < PROJ_WAVES; k++) emin = min(emin, rg_min[k]);
-    const uint32_t bin = live ? min(eidx - emin, PROJ_BLOCK - 2u) : PROJ_BLOCK - 1u;
-    const uint32_t pos = atomicAdd(&rg_hist[bin], 1u);
-    __syncthreads();
-    const uint32_t start = block_excl_scan_n<PROJ_WAVES>(rg_hist[threadIdx.x], rg_ws);
-    rg_hist[threadIdx.x] = start;
-    __syncthreads();
-    rg_pay[rg_hist[bin] + pos] = make_uint4(eidx, p, (uint32_t)f_start, (uint32_t)f_end);
-    __syncthreads();
-    const uint4 mine = rg_pay[threadIdx.x];
-    eidx = mine.x; p = mine.y; f_start = (int32_t)mine.z; f_end = (int32_t)mine.w;
-    live = eidx != 0xFFFFFFFFu;
-  }
-  if (live) {
+  (void)accepted;
+  {
     // Two round trips, not four ahead of the tiles: the indices (and the frontier record) above, then the
     // 64-byte entry (coordinates, record totals, inline checkpoints).  The empty asm statement pins the four
     // reads together -- left alone, the compiler sinks part of them below the entry's "has ops" test.
@@ -1292,6 +1238,74 @@ __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(D
       res.pqs = qbase + (rev ? -res.pqs : res.pqs);
       res.pqe = qbase + (rev ? -res.pqe : res.pqe);
     }
+  }
+}
+
+template <bool TRANSITIVE, int MODE>
+__global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
+                                                      const uint32_t *__restrict__ pair_range,
+                                                      const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
+                                                      HitArrays h, unsigned long long *__restrict__ accepted,
+                                                      uint32_t *__restrict__ err_flag, double min_identity,
+                                                      SliceArrays sl, ProjList pl, int xcd_map,
+                                                      const uint32_t *__restrict__ n_pairs_dev, int regroup) {
+  if (n_pairs_dev) n_pairs = *n_pairs_dev;  // small batches: the count stays on the device, the grid covers an upper bound
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give
+  // every XCD one contiguous eighth of the (locality-ordered) pair list instead of
+  // every eighth block of it.  The grid is a multiple of 8 blocks.
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t lblock = xcd_map ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t pp = lblock * PROJ_BLOCK + threadIdx.x;
+  bool ok = false;
+  TileScan res;
+  res.found = res.any = false;
+  res.pqs = res.pts = res.pqe = res.pte = -1;
+  uint32_t qid = HIT_NONE;
+  // (in projection order the pair's range and entry are listed next to its slot: three coalesced reads)
+  bool live = pp < n_pairs;
+  uint32_t p = pp, r = 0, eidx = 0xFFFFFFFFu;
+  int32_t f_start = 0, f_end = 0;
+  if (live) {
+    if (pl.slot) { p = pl.slot[pp]; r = pl.range[pp]; eidx = pl.entry[pp]; }
+    else { r = pair_range[pp]; eidx = pair_entry[pp]; }
+    asm volatile("" : "+v"(r), "+v"(eidx));
+    const FrontierRec f = fr[r];
+    f_start = f.start; f_end = f.end;
+  }
+  if (regroup) {
+    // The block's 256 pairs, regrouped by entry before anything of the index is read.  In projection order
+    // neighbouring lanes are the hits of ONE range on different entries: every lane reads its own entry line and
+    // its own tile lines.  The ranges of a block are neighbours in the lookup order and hit largely the same
+    // entries, so sorted by entry a wave's lanes share a handful of lines.  A counting sort in LDS over
+    // (entry - the block's smallest entry), one bin per thread; results are stored at the pair's own slot, so
+    // which lane projects which pair changes nothing downstream.
+    __shared__ uint32_t rg_hist[PROJ_BLOCK];
+    __shared__ uint32_t rg_min[PROJ_WAVES];
+    __shared__ uint32_t rg_ws[PROJ_WAVES];
+    __shared__ uint4 rg_pay[PROJ_BLOCK];
+    uint32_t mn = eidx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+    rg_hist[threadIdx.x] = 0u;
+    if (lane_id() == 0) rg_min[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    uint32_t emin = rg_min[0];
+#pragma unroll
+    for (uint32_t k = 1; k < PROJ_WAVES; k++) emin = min(emin, rg_min[k]);
+    const uint32_t bin = live ? min(eidx - emin, PROJ_BLOCK - 2u) : PROJ_BLOCK - 1u;
+    const uint32_t pos = atomicAdd(&rg_hist[bin], 1u);
+    __syncthreads();
+    const uint32_t start = block_excl_scan_n<PROJ_WAVES>(rg_hist[threadIdx.x], rg_ws);
+    rg_hist[threadIdx.x] = start;
+    __syncthreads();
+    rg_pay[rg_hist[bin] + pos] = make_uint4(eidx, p, (uint32_t)f_start, (uint32_t)f_end);
+    __syncthreads();
+    const uint4 mine = rg_pay[threadIdx.x];
+    eidx = mine.x; p = mine.y; f_start = (int32_t)mine.z; f_end = (int32_t)mine.w;
+    live = eidx != 0xFFFFFFFFu;
+  }
+  if (live) {
+    project_pair<TRANSITIVE, MODE>(v, eidx, f_start, f_end, p, min_identity, err_flag, sl, accepted, ok, qid, res);
     h.qid[p] = qid;
     if (ok) {
       h.c[p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
@@ -3070,5 +3084,19 @@ void launch_hits_unpack(const void *in, uint32_t n, uint32_t words, uint32_t n_f
   if (!n) return;
   if (words == 4) hits_unpack_kernel<4><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, n_front, run_start, off, pair_range, h, mslot, nullptr, nullptr, nullptr);
   else hits_unpack_kernel<8><<<cdiv(n, 256), 256, 0, s>>>((const uint4 *)in, n, n_front, run_start, off, pair_range, h, mslot, slice_at, slice_pos, slice_n);
+}
+#include "walk_device.inc"
+size_t walk_slab_bytes(uint32_t n_seq, bool wide, uint32_t wcap, uint32_t hcap, uint32_t vcap, uint32_t gcap, uint32_t scap) {
+  return walk_slab_layout(nullptr, n_seq, wide ? 1024u : 64u, wcap, hcap, vcap, gcap, scap, nullptr);
+}
+void launch_walk(const WalkArgs &a, uint32_t n_workgroups, bool wide, bool ident_mode, hipStream_t s) {
+  if (!n_workgroups) return;
+  if (wide) {
+    if (ident_mode) walk_kernel<16, 4096, MODE_IDENT><<<n_workgroups, 1024, 0, s>>>(a);
+    else walk_kernel<16, 4096, 0><<<n_workgroups, 1024, 0, s>>>(a);
+  } else {
+    if (ident_mode) walk_kernel<1, 256, MODE_IDENT><<<n_workgroups, 64, 0, s>>>(a);
+    else walk_kernel<1, 256, 0><<<n_workgroups, 64, 0, s>>>(a);
+  }
 }
 }  // namespace impg

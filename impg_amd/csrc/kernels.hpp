@@ -186,4 +186,34 @@ void launch_compact_select(const VisitedTables &vt, const unsigned long long *sk
 void launch_compact_copy(const VisitedTables &vt, const unsigned long long *src, const uint32_t *off, const uint32_t *len,
                          uint32_t n, int2 *ranges_out, hipStream_t s);
 
+// ---- the per-query walk (walk_device.inc): one workgroup takes a query through all its levels / pops ----------------
+struct WalkArgs {
+  DeviceIndexView v;
+  const impg_gpu_range_t *ranges;
+  uint32_t n_queries;
+  int dfs;
+  uint32_t max_depth;
+  int32_t min_transitive_len, mdbr, min_output_length;
+  double min_identity;  // NaN: no filter
+  const uint8_t *subset_keep;
+  unsigned long long *count, *cksum;  // per query, hits only (the self interval is not a hit), nullable
+  unsigned long long *accepted;       // striped
+  uint32_t *err_flag;
+  // rows (nullable): query q writes its rows at rows[row_base[q] ..], at most row_cap[q] of them; n_rows[q] counts all
+  impg_gpu_interval_t *rows;
+  const unsigned long long *row_base;
+  const uint32_t *row_cap;
+  uint32_t *n_rows;
+  uint32_t *next_query;  // work counter
+  uint32_t *overflow;    // set: a query did not fit its slab
+  char *slabs;
+  size_t slab_bytes;
+  uint32_t wcap, hcap, vcap, gcap, scap;  // records per frontier / piece list, pairs per step, visited ranges, piece scratch, DFS stack records
+  unsigned long long *dbg;           // IMPG_WALK_DEBUG: 32 words of phase clocks and counters (null: off)
+};
+size_t walk_slab_bytes(uint32_t n_seq, bool wide, uint32_t wcap, uint32_t hcap, uint32_t vcap, uint32_t gcap, uint32_t scap);
+// wide: 16 waves per workgroup (a handful of queries, latency) instead of one (a batch, throughput); ident_mode: the
+// projections take the identity filter's path (a filter is set, or the index has no prefix lines)
+void launch_walk(const WalkArgs &a, uint32_t n_workgroups, bool wide, bool ident_mode, hipStream_t s);
+
 }  // namespace impg

@@ -1277,3 +1277,44 @@ def test_index_without_prefix_lines(tmp_path):
     g2 = impg_amd.GpuImpg.load(str(tmp_path / "np.idx"))
     assert g2.device_bytes() == g.device_bytes()
     assert_same(g2, c, ranges[:50], transitive=True, max_depth=2)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_walk_kernel_matches_oracle_and_batch_engine(tmp_path, seed):
+    """The per-query walk (walk_device.inc: a workgroup takes a query through all its pops / levels in one launch) against
+    the oracle and against the batch engine: DFS batches of any size (the default), small BFS batches (walk_kernel = 2),
+    the batch engine alone (0) -- rows, per-range counts and checksums; depth limits incl. unlimited, the distance and
+    length cut-offs, the identity filter, the subset filter, ranges on sequences without alignments, dense targets."""
+    text, _ = random_paf(40 + seed, 500, n_seq=7, seq_len=40_000, max_ops=300, weird=True, inconsistent=(seed == 2), self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(seed, 150, 7, 40_000, max_len=5000, min_len=1)
+    keep = np.array([1, 0, 1, 1, 0, 1, 1], dtype=np.uint8)
+    dfs_cases = [dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=30), dict(transitive=True, dfs=True, max_depth=0, min_transitive_len=150),
+                 dict(transitive=True, dfs=True, max_depth=2, min_transitive_len=10, min_distance_between_ranges=0),
+                 dict(transitive=True, dfs=True, max_depth=4, min_transitive_len=60, min_distance_between_ranges=40, min_output_length=80),
+                 dict(transitive=True, dfs=True, max_depth=2, min_identity=0.8)]
+    bfs_cases = [dict(transitive=True, max_depth=3, min_transitive_len=30), dict(transitive=True, max_depth=0, min_transitive_len=200),
+                 dict(transitive=True, max_depth=2, min_identity=0.7, min_output_length=50)]
+    ref = {}
+    for walk in (0, 1, 2):
+        g.set_option("walk_kernel", walk)
+        for k, kw in enumerate(dfs_cases):
+            res = assert_same(g, c, ranges, **kw)
+            st, cnt, ck = g.query_batch_stats(ranges, impg_amd.make_params(**kw))
+            assert [int(x) for x in cnt] == [len(res[i]) - 1 for i in range(len(ranges))] or kw.get("min_output_length")  # (self rows are not hits)
+            if walk == 0:
+                ref[("d", k)] = (cnt.tolist(), ck.tolist(), st.projected)
+            else:
+                assert (cnt.tolist(), ck.tolist(), st.projected) == ref[("d", k)], (walk, kw)
+        assert_same(g, c, ranges[:70], subset_keep=keep, transitive=True, dfs=True, max_depth=3, min_transitive_len=30)
+        for k, kw in enumerate(bfs_cases):
+            for lo in (0, 60):
+                assert_same(g, c, ranges[lo:lo + 50], **kw)
+            st, cnt, ck = g.query_batch_stats(ranges[:64], impg_amd.make_params(**kw))
+            if walk == 0:
+                ref[("b", k)] = (cnt.tolist(), ck.tolist(), st.projected)
+            else:
+                assert (cnt.tolist(), ck.tolist(), st.projected) == ref[("b", k)], (walk, kw)
+        assert_same(g, c, ranges[:40], subset_keep=keep, transitive=True, max_depth=3, min_transitive_len=30)
+        assert g.query_transitive_dfs(*ranges[0], max_depth=3).tolist() == c.query(*ranges[0], transitive=True, dfs=True, max_depth=3).tolist()
+        assert g.query_transitive_bfs(*ranges[0], max_depth=3).tolist() == c.query(*ranges[0], transitive=True, max_depth=3).tolist()

@@ -265,6 +265,7 @@ def main():
     }
     if world == 1 and not args.no_extras:
         out["full_results"] = full_results_leg(index, ranges, params)
+        out["dfs_batch"] = dfs_batch_leg(index, ranges, args.max_depth)
     out["cpu_baseline"] = cpu_baseline(args, paf, ranges, transitive) if (world == 1 and args.cpu_sample > 0) else None
     if dist is not None:
         del index
@@ -275,18 +276,22 @@ def main():
     result_out.flush()
 
 
-VALU_CYCLES_PER_WAVE_INST = 4      # measured: SQ_ACTIVE_INST_VALU (quad-cycles) = SQ_INSTS_VALU on this integer kernel (scripts/make_sq_json.py)
 SIMDS = 256 * 4
 
 
 def roofline(stats, ach, traffic, tpath, ms_project, launches):
-    """The contractual HBM roofline line (856 algorithmic bytes per projection) next to what the memory
-    system and the issue ports actually did: measured HBM traffic as a fraction of peak, and the VALU-issue
-    fraction of project_kernel from the SQ counters of profiles/r*_sq.json (same command, PMC pass)."""
+    """The contractual HBM accounting (856 algorithmic bytes per projection) next to what the memory
+    system and the issue ports actually did for project_kernel: measured HBM traffic as a fraction of peak
+    (profiles/r*_traffic.json) and the VALU-issue fraction (profiles/r*_sq.json: SQ_INSTS_VALU x the measured cost of
+    the kernel's instruction mix, scripts/issue_rate.hip + scripts/valu_mix.py -- SQ_ACTIVE_INST_VALU ticks once per
+    instruction whatever it costs, so a flat 2 or 4 clocks cannot be read off the counters)."""
     avg_ms = ms_project / launches if launches else None
     r = {
-        "bound": "hbm", "kernel": "project_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "kernel": "project_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": ach / HBM_PEAK_GBS,
+        "frac_note": "the contract's accounting: 856 algorithmic bytes per projection (a streamed 200-op CIGAR) / launch time / 8 TB/s. "
+                     "The kernel reads a 64-byte entry and <= 2 x 64 bytes of prefix line instead, so this exceeds 1 and is not a "
+                     "bandwidth; the physical fractions are measured_traffic_frac and valu_issue_frac",
         "traffic": traffic,
         "traffic_note": "bytes per launch = rocprofv3 (FETCH_SIZE x2 [gfx950] + WRITE_SIZE) per pair, from "
                         "profiles/%s, x pairs per launch of this run" % os.path.basename(tpath),
@@ -298,19 +303,31 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches):
     tgbs = (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms) else None
     r["achieved_traffic_GBs"] = tgbs
     r["measured_traffic_frac"] = (tgbs / HBM_PEAK_GBS) if tgbs else None
-    sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq.json")))
+    sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_sq.json"))) or sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq.json")))
+    vf = None
     if sq:
         with open(sq[-1]) as f:
             j = json.load(f)
-        r["valu_issue_frac"] = j.get("valu_issue_frac")
+        vf = j.get("valu_issue_frac")
+        r["valu_issue_frac"] = vf
         r["valu_insts_per_pair"] = j.get("valu_insts_per_pair")
-        r["valu_note"] = "SQ_ACTIVE_INST_VALU (quad-cycles, = SQ_INSTS_VALU here) x %d clocks / (GRBM_GUI_ACTIVE x %d SIMDs) of project_kernel, profiles/%s" % (
-            VALU_CYCLES_PER_WAVE_INST, SIMDS, os.path.basename(sq[-1]))
-    r["limiter"] = ("the 856-byte model streams the whole CIGAR; the kernel reads one 64-byte entry and, per end of the projection, "
-                    "a 16-byte header and 48 bytes of 16-bit prefix entries, so frac > 1 is accounting, not bandwidth.  Physically "
-                    "HBM is NOT the bound (measured_traffic_frac).  The kernel sits between two limits: the vector-memory pipeline on "
-                    "16-byte reads that share few cache lines across a wave (a block regroups its pairs by entry to share more) and "
-                    "VALU issue (valu_issue_frac, which the regrouping sort raised again); DESIGN.md 5.2 items 12-14")
+        r["valu_cycles_per_inst"] = j.get("cycles_per_valu_inst")
+        r["valu_note"] = ("SQ_INSTS_VALU x %.2f clocks (the measured issue cost of the kernel's instruction mix: profiles/r3_issue_rate.json, "
+                          "profiles/r3_valu_mix_project.json) / (GRBM_GUI_ACTIVE x %d SIMDs) of project_kernel, profiles/%s" %
+                          (j.get("cycles_per_valu_inst") or 0.0, SIMDS, os.path.basename(sq[-1])))
+    mf = r["measured_traffic_frac"]
+    # what binds, from the two measured fractions: neither HBM (the 856-byte model's bound) nor the VALUs are saturated on the
+    # headline index -- the rest is latency the resident waves do not cover (dependent 16-byte gathers, each lane its own line)
+    if mf is not None and vf is not None:
+        r["bound"] = "hbm" if mf >= 0.6 else ("valu-issue" if vf >= 0.75 else "latency (HBM at %.2f, VALU issue at %.2f of their peaks)" % (mf, vf))
+    else:
+        r["bound"] = "unmeasured (no PMC summaries under profiles/)"
+    r["contract_bound"] = "hbm"
+    r["limiter"] = ("project_kernel on the headline index is bound by neither roofline: HBM moves measured_traffic_frac of 8 TB/s (the pairs of "
+                    "a level revisit the same 2.7 GB ~60 times and mostly hit L2), the vector ALUs issue valu_issue_frac of their slots. What is "
+                    "left is exposed latency: per pair 3-4 dependent rounds of 16-byte reads that share few cache lines across a wave.  On the "
+                    "config-4 index (20 000 sequences, no reuse) the same kernel IS HBM-bound: 292 B per pair = 4.9 TB/s of 128-byte gathers, "
+                    "0.62 of peak (profiles/r3_config4_traffic.json); DESIGN.md 5.2, 7")
     return r
 
 
@@ -337,6 +354,20 @@ def full_results_leg(index, ranges, params):
                        "into a pinned result block)" % n)
     out["calls"] = legs
     return out
+
+
+def dfs_batch_leg(index, ranges, max_depth):
+    """`--transitive-dfs` for the first 10 000 ranges, counting form: the per-query walk kernel (walk_device.inc), one
+    launch for the batch.  (Round 2's batch engine paid a launch sequence per pop round: minutes for this batch.)"""
+    import impg_amd
+    n = min(10_000, len(ranges))
+    p = impg_amd.make_params(transitive=True, dfs=True, max_depth=max_depth)
+    index.query_batch_stats(ranges[:64], p, counts=False, checksums=False)  # (slabs allocated)
+    t0 = time.perf_counter()
+    st, _, _ = index.query_batch_stats(ranges[:n], p, counts=False, checksums=False)
+    dt = time.perf_counter() - t0
+    return {"workload": "first %d ranges, --transitive-dfs -m %d, counting form" % (n, max_depth), "projected": st.projected, "seconds": dt,
+            "projected_per_s": st.projected / dt if dt > 0 else None}
 
 
 def spawn_ranks(n):

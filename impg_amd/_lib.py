@@ -90,6 +90,8 @@ SYMBOLS = [
                                               C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_create_tracepoints", C.c_int, [_P, C.c_size_t, _P, _P, _P, C.c_size_t, _P, _P, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                                     C.POINTER(_P)]),
+    ("impg_gpu_index_create_tracepoints_multi", C.c_int, [_P, C.c_size_t, _P, _P, _P, C.c_size_t, _P, _P, C.c_uint32, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                                    C.POINTER(_P)]),
     ("impg_gpu_index_create_from_paf", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_save", C.c_int, [_P, C.c_char_p]),
     ("impg_gpu_index_load", C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),

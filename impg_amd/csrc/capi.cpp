@@ -478,7 +478,6 @@ size_t impg_gpu_num_entries(const impg_gpu_index_t *ix) { return ix->n_entries; 
 size_t impg_gpu_num_records(const impg_gpu_index_t *ix) { return ix->n_records; }
 size_t impg_gpu_device_bytes(const impg_gpu_index_t *ix) { return ix->device_bytes; }
 int impg_gpu_index_approximate(const impg_gpu_index_t *ix) {
-  if (ix->cluster) return 0;  // (tracepoint indexes are single-GPU)
   return ix->tp_mode ? 1 : 0;
 }
 

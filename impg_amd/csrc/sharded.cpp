@@ -838,7 +838,7 @@ void check_comm(const impg_gpu_comm *comm) {
 std::unique_ptr<impg_gpu_index> make_cluster(const impg_gpu_record_t *records, size_t n_records, const uint32_t *ops, size_t n_ops,
                                              const int64_t *seq_len, uint32_t n_seq, const std::vector<uint64_t> *file_first,
                                              int bidirectional, int order_policy, const int *devices, int n_dev, int lanes,
-                                             const HostSeqIndex *seq) {
+                                             const HostSeqIndex *seq, const TpInput *tp = nullptr) {
   if (!devices || n_dev < 1 || n_dev > (int)ROUTE_WORLD_MAX) throw Error{IMPG_E_INVALID, "bad device list"};
   if (lanes < 1 || lanes > 8) throw Error{IMPG_E_INVALID, "lanes must be 1..8"};
   for (int r = 0; r < n_dev; r++) require_device(devices[r]);
@@ -871,6 +871,17 @@ std::unique_ptr<impg_gpu_index> make_cluster(const impg_gpu_record_t *records, s
   for (int r = 0; r < n_dev; r++)
     th.emplace_back([&, r] {
       try {
+        if (tp) {  // a tracepoint index (approximate mode): the host builder takes the rank's share of the alignments
+          require_device(devices[r]);
+          auto ix = std::make_unique<impg_gpu_index>();
+          ix->device = devices[r];
+          if (seq) ix->seq = *seq;
+          build_index(*ix, records, n_records, nullptr, n_ops, seq_len, n_seq, bidirectional != 0, order_policy, (uint32_t)r, (uint32_t)n_dev,
+                      owner.data(), tp);
+          { EngineLease warm(*ix); }
+          attach_shard(*ix, C->comms[r].get(), owner);
+          C->ranks[r] = std::move(ix);
+        } else
         C->ranks[r] = make_rank_index(records, n_records, ops, n_ops, seq_len, n_seq, file_first, bidirectional, order_policy,
                                       devices[r], C->comms[r].get(), seq, owner);
       } catch (...) { errs[r] = std::current_exception(); }
@@ -1035,6 +1046,32 @@ int impg_gpu_index_create_multi(const impg_gpu_record_t *records, size_t n_recor
   if (file_first_record && n_files) { ff.assign(file_first_record, file_first_record + n_files); ff.push_back(n_records); }
   *out = make_cluster(records, n_records, cigar_ops, n_ops, seq_len, n_seq, ff.empty() ? nullptr : &ff, bidirectional, order_policy,
                       devices, n_dev, lanes, nullptr).release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_create_tracepoints_multi(const impg_gpu_tp_record_t *records, size_t n_records, const int32_t *tracepoints,
+                                            const int32_t *query_deltas, const int32_t *diffs, size_t n_segs_total,
+                                            const impg_gpu_tp_mode_t *mode, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
+                                            int order_policy, const int *devices, int n_dev, int lanes, impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!out || !mode || (n_records && !records) || (n_segs_total && !tracepoints) || (n_seq && !seq_len))
+    throw Error{IMPG_E_INVALID, "null argument"};
+  if (mode->fastga) {
+    if (n_segs_total && !diffs) throw Error{IMPG_E_INVALID, "FASTGA tracepoints come with per-segment diffs"};
+    if (mode->trace_spacing <= 0) throw Error{IMPG_E_INVALID, "trace_spacing must be positive"};
+  } else if (n_segs_total && !query_deltas) throw Error{IMPG_E_INVALID, "Standard tracepoints come with per-segment query deltas"};
+  std::vector<impg_gpu_record_t> recs(n_records);
+  for (size_t i = 0; i < n_records; i++) {
+    const impg_gpu_tp_record_t &r = records[i];
+    if (r.seg_off + r.n_segs > n_segs_total) throw Error{IMPG_E_INVALID, "record segments outside the pools"};
+    recs[i] = impg_gpu_record_t{r.query_id, r.target_id, r.query_start, r.query_end, r.target_start, r.target_end, r.seg_off, r.n_segs, r.strand};
+  }
+  TpInput tp{records, tracepoints, query_deltas, diffs, n_segs_total, *mode};
+  auto ix = make_cluster(recs.data(), n_records, nullptr, n_segs_total, seq_len, n_seq, nullptr, bidirectional, order_policy, devices, n_dev, lanes,
+                         nullptr, &tp);
+  ix->tp_mode = true;
+  *out = ix.release();
   return IMPG_OK;
   IMPG_CATCH
 }

@@ -159,7 +159,7 @@ class GpuImpg:
 
     @classmethod
     def from_tracepoints(cls, records, tracepoints, seq_len, query_deltas=None, diffs=None, fastga=False, trace_spacing=0,
-                         max_complexity=0, bidirectional=True, order=_lib.ORDER_COITREES, device=0):
+                         max_complexity=0, bidirectional=True, order=_lib.ORDER_COITREES, device=0, devices=None, lanes=2):
         """impg_gpu_index_create_tracepoints: an index over tracepoint alignments (.1aln / .tpa content handed over as
         arrays); every query on it runs in approximate mode (approximate_mode = true of the trait)."""
         rec = np.ascontiguousarray(records, dtype=_lib.TP_RECORD_DTYPE)
@@ -169,6 +169,12 @@ class GpuImpg:
         sl = np.ascontiguousarray(seq_len, dtype=np.int64)
         mode = _lib.TpMode(int(bool(fastga)), int(trace_spacing), int(max_complexity))
         h = C.c_void_p(None)
+        if devices is not None:  # sharded by target sequence over the GPUs of this process
+            dv = np.ascontiguousarray(devices, dtype=np.int32)
+            check(lib().impg_gpu_index_create_tracepoints_multi(rec.ctypes.data, rec.size, tp.ctypes.data, None if qd is None else qd.ctypes.data,
+                                                                None if df is None else df.ctypes.data, tp.size, C.byref(mode), sl.ctypes.data,
+                                                                sl.size, int(bidirectional), order, dv.ctypes.data, dv.size, lanes, C.byref(h)))
+            return cls(h)
         check(lib().impg_gpu_index_create_tracepoints(rec.ctypes.data, rec.size, tp.ctypes.data, None if qd is None else qd.ctypes.data,
                                                       None if df is None else df.ctypes.data, tp.size, C.byref(mode), sl.ctypes.data,
                                                       sl.size, int(bidirectional), order, device, C.byref(h)))

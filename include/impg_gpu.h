@@ -145,6 +145,13 @@ int impg_gpu_index_create_tracepoints(const impg_gpu_tp_record_t *records, size_
                                       const impg_gpu_tp_mode_t *mode, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
                                       int order_policy, int device, impg_gpu_index_t **out);
 
+/* The same index sharded by target sequence over the GPUs of this process (see impg_gpu_index_create_multi below): one
+ * handle, queries answered in approximate mode by the shards that own the targets. */
+int impg_gpu_index_create_tracepoints_multi(const impg_gpu_tp_record_t *records, size_t n_records, const int32_t *tracepoints,
+                                            const int32_t *query_deltas, const int32_t *diffs, size_t n_segs_total,
+                                            const impg_gpu_tp_mode_t *mode, const int64_t *seq_len, uint32_t n_seq, int bidirectional,
+                                            int order_policy, const int *devices, int n_dev, int lanes, impg_gpu_index_t **out);
+
 /* Same, parsing PAF files on the host the way paf.rs:118-194 does; sequence ids
  * are assigned in first-seen order over the files (query then target per line). */
 int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths,

@@ -966,6 +966,16 @@ def test_tracepoint_approximate_mode(fastga, seed):
     with pytest.raises(impg_amd.ImpgGpuError) as ei:
         g.query_batch(ranges[:2], impg_amd.make_params(store_cigar=True))
     assert ei.value.code == impg_amd.IMPG_E_UNSUPPORTED
+    # the same alignments sharded over three ranks (one handle): owners answer in approximate mode, hits come home
+    gm = impg_amd.GpuImpg.from_tracepoints(d["records"], d["tracepoints"], d["seq_len"], query_deltas=d["query_deltas"], diffs=d["diffs"],
+                                           fastga=d["fastga"], trace_spacing=d["trace_spacing"], max_complexity=d["max_complexity"],
+                                           devices=[0, 0, 0], lanes=2)
+    gm.set_option("chunk_ranges", 11)
+    assert gm.approximate()
+    assert_same(gm, c, ranges[:50])
+    assert_same(gm, c, ranges[:50], transitive=True, max_depth=3, min_transitive_len=30)
+    assert_same(gm, c, ranges[:30], transitive=True, dfs=True, max_depth=2, min_transitive_len=50, min_identity=0.8)
+    del gm
     # the mode belongs to the index: the trait-shaped calls refuse the other one instead of answering in it
     assert g.approximate()
     t0, s0, e0 = ranges[0]

@@ -49,6 +49,34 @@ def brute_force_query(rec, ops, t, s, e):
     return np.array(rows, dtype=impg_amd.INTERVAL_DTYPE)
 
 
+CODE = "=XIDM"
+
+
+def oracle_on_subset(rec, ops, ranges_2hop, n_seq, seq_len):
+    # An oracle index that answers a walk exactly like one over ALL records would: every record that overlaps any range the
+    # walk can look up, behind one 1-bp dummy alignment per pair of sequences that pins the sequence ids to the generator's
+    # (the oracle numbers sequences in first-seen order, and ids order the frontier).  ranges_2hop: (seq, start, end) supersets
+    # of every range looked up.  Visit order: the oracle's sorted policy (a subset keeps a target's start order, not its
+    # coitrees ranks), so the engine's index is built with IMPG_ORDER_SORTED too.
+    pick = np.zeros(len(rec), dtype=bool)
+    for (t, s, e) in ranges_2hop:
+        pick |= (rec["target_id"] == t) & (rec["target_start"] <= e) & (rec["target_end"] >= s)
+        pick |= (rec["query_id"] == t) & (rec["query_start"] <= e) & (rec["query_end"] >= s)
+    name = impg_amd.synth_seq_name
+    lines = []
+    for k in range(0, n_seq, 2):  # ids 0, 1, 2, ... in first-seen order; the 1-bp records sit at the very end of the sequences
+        lines.append("%s\t%d\t%d\t%d\t+\t%s\t%d\t%d\t%d\t1\t1\t60\tcg:Z:1=" %
+                     (name(k), seq_len, seq_len - 1, seq_len, name(k + 1), seq_len, seq_len - 1, seq_len))
+    for i in np.nonzero(pick)[0]:
+        r = rec[i]
+        cg = ops[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["cigar_len"])]
+        text = "".join("%d%s" % (int(v) & ((1 << 29) - 1), CODE[int(v) >> 29]) for v in cg)
+        lines.append("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t1\t1\t60\tcg:Z:%s" %
+                     (name(int(r["query_id"])), seq_len, int(r["query_start"]), int(r["query_end"]), "+-"[int(r["strand"])],
+                      name(int(r["target_id"])), seq_len, int(r["target_start"]), int(r["target_end"]), text))
+    return o.OracleIndex(paf_text="\n".join(lines) + "\n", preparse=True), int(pick.sum())
+
+
 def test_config4_hprc_scale_index():
     records = int(float(os.environ.get("IMPG_CONFIG4_RECORDS", "5e7")))
     rec, ops, sl = impg_amd.synth_paf(42, records, n_seq=N_SEQ4, seq_len=SEQ_LEN)
@@ -71,6 +99,27 @@ def test_config4_hprc_scale_index():
         assert int(cnt0[i]) == len(want) and int(ck0[i]) == checksum(want), i
         seen += len(want)
     assert seen > 50
+    # (a') transitive, two hops, exact: the oracle on every record the walk can touch (found by brute force over the
+    # arrays), against an index of ALL records under the sorted visit order
+    gs = impg_amd.GpuImpg.from_records(rec, ops, sl, order=impg_amd.ORDER_SORTED)
+    o.set_sorted_visits(True)
+    try:
+        kw = dict(transitive=True, max_depth=2)
+        for i in sample[:3]:
+            r = ranges[i]
+            t, s0, e0 = int(r["target_id"]), int(r["start"]), int(r["end"])
+            hop1 = gs.query_batch([(t, s0, e0)], plain)[0]
+            look = [(t, s0, e0)] + [(int(h["query_id"]), min(int(h["q_first"]), int(h["q_last"])), max(int(h["q_first"]), int(h["q_last"])))
+                                    for h in hop1[1:]]
+            c2, n_sub = oracle_on_subset(rec, ops, look, N_SEQ4, SEQ_LEN)
+            assert c2.num_seqs() == N_SEQ4 and c2.seq_name(t) == impg_amd.synth_seq_name(t)
+            want = c2.query(t, s0, e0, **kw)
+            got = gs.query_batch([(t, s0, e0)], impg_amd.make_params(**kw))[0]
+            assert got.tolist() == want.tolist(), (i, n_sub)
+            assert len(want) > len(hop1) and SEQ_LEN - 1 not in set(want["t_first"].tolist())  # (no dummy record was reached)
+    finally:
+        o.set_sorted_visits(False)
+    del gs
     # (b) -x -m 3: chunking does not matter
     p = impg_amd.make_params(transitive=True, max_depth=3)
     g.set_option("pair_budget", 1 << 30)

@@ -64,6 +64,8 @@ def main():
                          "-x -m 3.  config5: the headline index, contiguous 5 kb windows end to end (--ranges windows per GPU, "
                          "default the whole genome: 200 000), -x -m 5")
     ap.add_argument("--lanes", type=int, default=2, help="sharded index: chunks of the batch in flight at once per rank")
+    ap.add_argument("--min-identity", type=float, default=None,
+                    help="--min-result-identity of the reference (impg.rs:1283-1287); not part of the headline configuration")
     ap.add_argument("--no-extras", action="store_true", help="skip the full-results measurement (profiling runs)")
     args = ap.parse_args()
 
@@ -125,6 +127,8 @@ def main():
         flush_c_stdio()  # (the communicator exists now: its banner, if any, goes out first)
     transitive = not args.no_transitive
     params = impg_amd.make_params(transitive=transitive, max_depth=args.max_depth)  # -x -m 3, defaults otherwise
+    if args.min_identity is not None:
+        params.min_identity = args.min_identity
 
     log("building the device index")
     t_build = time.time()
@@ -245,7 +249,7 @@ def main():
                         (args.records, n_seq, args.ranges, "contiguous 5 kb windows" if wl == "config5" else "x 5 kb query ranges",
                          ("-x -m %d" % args.max_depth) if transitive else "no transitive"),
             "records": args.records, "ranges_per_gpu": args.ranges, "max_depth": args.max_depth if transitive else 0,
-            "min_transitive_len": 101, "min_distance_between_ranges": 10,
+            "min_transitive_len": 101, "min_distance_between_ranges": 10, "min_identity": args.min_identity,
             "parallelism": ("1 process/GPU, index sharded by target sequence (bin-packed), frontier all-to-all-v over RCCL, "
                             "%d chunks in flight per rank" % args.lanes) if dist is not None else "single GPU",
             "chunk_ranges": args.chunk_ranges, "pair_budget": args.pair_budget,

@@ -76,6 +76,14 @@ constexpr uint32_t INLINE_TILES = 8;      // entries of records with <= 8 tiles 
 constexpr uint32_t PFX_E0 = 4;
 constexpr uint32_t PFX_STEP = 9;
 constexpr uint32_t PFX_ENTRIES = 28;
+// Identity line of a tile (indexes WITH prefix lines; the identity filter's counterpart of the prefix line, round 3):
+//   words 0..3   matched bases, mismatched bases, gap ops of the record before the tile; bit u of word 3: op u is 'I' / 'D'
+//   word 4 + k   matched | mismatched << 16 bases of the tile's ops before op k (k = 0..27; past the last op: the tile's own sums)
+// A tile whose prefix line is not `wide` has target / query sums below 2^16, and matched + mismatched bases are part
+// of both, so the 16-bit fields hold.  Gap ops before op k of the tile: popcount of the mask below bit k.
+constexpr uint32_t IDL_WORDS = 32;
+constexpr uint32_t IDL_E0 = 4;
+constexpr uint32_t IDL_ENTRIES = 28;
 
 // ---- device index (HBM layout) ---------------------------------------------
 // One 64-byte payload per index entry, stored in per-target start order.
@@ -120,7 +128,8 @@ struct DeviceIndexView {  // passed by value to kernels
   const Entry *entries;      // [n_entries]
   const uint32_t *ops;       // [n_tiles*32] tiles
   const uint32_t *ext_cp;    // effective target prefixes of entries with > 8 tiles
-  const uint4 *idp;          // [4*n_tiles] matched bases, mismatched bases, gap ops of the record before each sub-tile
+  const uint4 *idp;          // identity filter: with prefix lines [8*n_tiles] one identity line per tile (IDL_*); without them
+                             // [4*n_tiles] matched bases, mismatched bases, gap ops of the record before each sub-tile
   const uint32_t *pfx;       // [n_tiles*32] prefix lines (per-op running sums, 16 bits per axis)
   const int32_t *seq_len;    // [n_seq]
   uint32_t n_seq;

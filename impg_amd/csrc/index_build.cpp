@@ -246,8 +246,10 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
     n_tiles = (nb * 4 + TILE_WORDS - 1) / TILE_WORDS;  // (the pool is accounted in 128-byte lines like the op pool)
   }
   RawVec<uint32_t> pool(n_tiles * TILE_WORDS);  // (every line is filled by the builder that owns it)
-  RawVec<uint4> idp(tp ? 0 : TILE_SUBS * n_tiles);  // per sub-tile: matched / mismatched bases and gap ops before it (identity filter)
   const bool with_pfx = !tp && !(getenv("IMPG_PREFIX_LINES") && atoi(getenv("IMPG_PREFIX_LINES")) == 0);
+  // identity filter: with prefix lines an *identity line* per tile (per-op matched / mismatched sums, impg_internal.hpp),
+  // without them the sums before each sub-tile, where the two short walks start counting
+  RawVec<uint4> idp(tp ? 0 : (with_pfx ? IDL_WORDS / 4 : TILE_SUBS) * n_tiles);
   RawVec<uint32_t> pfx(with_pfx ? n_tiles * TILE_WORDS : 0);  // prefix lines (impg_internal.hpp); optional: see index_build_device.hip
   if (tp && n_tiles) {  // the tail of the last 128-byte line behind the last boundary
     uint64_t nb_words = 0;
@@ -306,15 +308,19 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
         uint32_t scratch_line[TILE_WORDS];
         uint32_t *pl = with_pfx ? pfx.data() + tile * TILE_WORDS : scratch_line;
         bool pwide = false;
+        uint32_t *il = with_pfx ? reinterpret_cast<uint32_t *>(idp.data()) + tile * IDL_WORDS : scratch_line;
+        const uint32_t m0 = sm, x0 = sx, g0 = sg;
+        uint32_t gapmask = 0;
         auto boundary = [&]() {
           dt[sub] = st - t0; dq[sub] = sq - q0;
-          if (sub < TILE_SUBS) idp[TILE_SUBS * tile + sub] = make_uint4(sm, sx, sg, 0);
+          if (sub < TILE_SUBS && !with_pfx) idp[TILE_SUBS * tile + sub] = make_uint4(sm, sx, sg, 0);
           sub++;
         };
         for (uint32_t u = 0; u < cnt; u++) {
           if (u == sub_first_op(sub)) boundary();
           if (st - t0 > 0xFFFFu || sq - q0 > 0xFFFFu) pwide = true;
           pl[PFX_E0 + u] = ((st - t0) & 0xFFFFu) | ((sq - q0) << 16);
+          if (with_pfx) il[IDL_E0 + u] = ((sm - m0) & 0xFFFFu) | ((sx - x0) << 16);
           const uint32_t v = src[k0 + u], code = v >> 29, len = v & OP_LEN_MASK;
           if (code > 4) bad_op = true;  // CigarOp::new panics (impg.rs:88)
           line[6 + u] = v;
@@ -322,9 +328,13 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
           if (code != 3) sq += len;  // |query_delta|: all but 'D' (impg.rs:123-135)
           if (code == 0 || code == 4) sm += len;       // 'M' counted as match (impg.rs:2959)
           else if (code == 1) sx += len;
-          else sg += 1;                                 // gap-compressed: one per 'I' / 'D' op
+          else { sg += 1; gapmask |= 1u << u; }         // gap-compressed: one per 'I' / 'D' op
         }
         while (sub <= TILE_SUBS) boundary();  // sub-tiles without ops start (and end) at the tile's end
+        if (with_pfx) {
+          for (uint32_t u = cnt; u < IDL_ENTRIES; u++) il[IDL_E0 + u] = ((sm - m0) & 0xFFFFu) | ((sx - x0) << 16);
+          il[0] = m0; il[1] = x0; il[2] = g0; il[3] = gapmask;
+        }
         if (st - t0 > 0xFFFFu || sq - q0 > 0xFFFFu) pwide = true;
         for (uint32_t u = cnt; u < PFX_ENTRIES; u++) pl[PFX_E0 + u] = ((st - t0) & 0xFFFFu) | ((sq - q0) << 16);
         // (bit 31 is the flag: a sum that large -- no consistent record has one -- reads as wide, and the literal walk takes over)

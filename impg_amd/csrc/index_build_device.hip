@@ -122,11 +122,20 @@ __global__ __launch_bounds__(256) void tiles_kernel(const impg_gpu_record_t *__r
     const uint32_t sfo = sub_first_op(w & 3u);
     const uint32_t isrc = hb + 6u + sfo;
     const uint32_t pM = from_lane(eM, isrc), pX = from_lane(eX, isrc), pG = from_lane(eG, isrc);
+    // word w of the identity line (with prefix lines): header, then entry k with the lane of op k = this lane + 2
+    const uint32_t m0 = from_lane(eM, hb + 6u), x0 = from_lane(eX, hb + 6u), g0 = from_lane(eG, hb + 6u);
+    const uint32_t ient = ((eM - m0) & 0xFFFFu) | ((eX - x0) << 16), ient_end = ((endM - m0) & 0xFFFFu) | ((endX - x0) << 16);
+    const uint32_t ient_up2 = (uint32_t)__shfl_down((int)ient, 2);
+    const uint32_t gapmask = (uint32_t)((__ballot(on && dG != 0u) >> (hb + 6u)) & 0x3FFFFFFull);
+    uint32_t iw;
+    if (w >= IDL_E0) iw = (w - IDL_E0) < cnt ? ient_up2 : ient_end;
+    else iw = w == 0u ? m0 : w == 1u ? x0 : w == 2u ? g0 : gapmask;
     if (tile_on) {
       const size_t tile = (size_t)tile_base[rec] + j;
       pool[tile * TILE_WORDS + w] = lw;
       if (pfx) pfx[tile * TILE_WORDS + w] = pw;
-      if (w < TILE_SUBS) idp[TILE_SUBS * tile + w] = sfo < cnt ? make_uint4(pM, pX, pG, 0u) : make_uint4(endM, endX, endG, 0u);
+      if (pfx) reinterpret_cast<uint32_t *>(idp)[tile * IDL_WORDS + w] = iw;
+      else if (w < TILE_SUBS) idp[TILE_SUBS * tile + w] = sfo < cnt ? make_uint4(pM, pX, pG, 0u) : make_uint4(endM, endX, endG, 0u);
     }
     // carry: the sums after this step's last op (lane 63 holds them whatever the halves' fill)
     cT = from_lane(iT, 63u); cQ = from_lane(iQ, 63u); cM = from_lane(iM, 63u); cX = from_lane(iX, 63u); cG = from_lane(iG, 63u);
@@ -360,7 +369,7 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
   // The prefix lines are 40 % of the index and only buy speed (the plain projection reads them instead of replaying
   // ops): an index that does not fit the device with them is built without (IMPG_PREFIX_LINES=0 forces that).
   bool with_pfx = !(getenv("IMPG_PREFIX_LINES") && atoi(getenv("IMPG_PREFIX_LINES")) == 0);
-  auto bytes_for = [&](bool pf) { return n_tiles * ((pf ? 2 : 1) * TILE_WORDS * 4 + TILE_SUBS * 16) + n_entries * (sizeof(Entry) + 40) + n_records * 64; };
+  auto bytes_for = [&](bool pf) { return n_tiles * ((pf ? 2 : 1) * TILE_WORDS * 4 + (pf ? IDL_WORDS * 4 : TILE_SUBS * 16)) + n_entries * (sizeof(Entry) + 40) + n_records * 64; };
   if (with_pfx && bytes_for(true) + (1ull << 30) > free_b) with_pfx = false;
   const size_t out_bytes = bytes_for(with_pfx);
   if (out_bytes + (1ull << 30) > free_b) return false;  // (the host builder reports the shortage in its own words)
@@ -394,7 +403,7 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
   size_blob(ix, 10, n_tiles * TILE_WORDS * 4, acc);
   size_blob(ix, 14, with_pfx ? n_tiles * TILE_WORDS * 4 : 0, acc);
   uint32_t *const d_pfx = with_pfx ? ix.blob(14)->as<uint32_t>() : nullptr;
-  size_blob(ix, 12, n_tiles * TILE_SUBS * 16, acc);
+  size_blob(ix, 12, n_tiles * (with_pfx ? IDL_WORDS * 4 : TILE_SUBS * 16), acc);
   {
     const size_t BATCH_OPS = 64ull << 20;  // 256 MB of ops per upload
     DevBuf d_ops;

@@ -16,8 +16,9 @@ namespace impg {
 namespace {
 
 constexpr char MAGIC[8] = {'I', 'M', 'P', 'G', 'H', 'B', 'M', '1'};
-constexpr uint32_t VERSION = 4;  // 2: checksum of the arrays behind the end mark; 3: tile padding words carry length 0, prefix lines;
-                                 // 4: the checksum also covers the header and the host tables, and the per-target offsets are mandatory
+constexpr uint32_t VERSION = 5;  // 2: checksum of the arrays behind the end mark; 3: tile padding words carry length 0, prefix lines;
+                                 // 4: the checksum also covers the header and the host tables, and the per-target offsets are mandatory;
+                                 // 5: indexes with prefix lines carry identity lines (IDL_*) instead of per-sub-tile identity prefixes
 
 struct Header {  // fixed-size, little-endian (gfx950 hosts are x86-64)
   char magic[8];
@@ -128,7 +129,7 @@ void load_index(impg_gpu_index &ix, const char *path) {
       throw Error{IMPG_E_INVALID, in.path + ": counts out of range"};
     const uint64_t want[impg_gpu_index::N_BLOBS] = {S * sizeof(SegDesc), E * 4, E * 4, E * 4, E * 4, h.blob_bytes[5], h.blob_bytes[5],
                                                     E * 4, (h.multi_file & 1) ? E * 4 : 0, E * sizeof(Entry), T * TILE_WORDS * 4,
-                                                    h.blob_bytes[11], (h.multi_file & 2) ? 0 : T * TILE_SUBS * 16, S * 4,
+                                                    h.blob_bytes[11], (h.multi_file & 2) ? 0 : (h.multi_file & 4) ? T * TILE_SUBS * 16 : T * IDL_WORDS * 4, S * 4,
                                                     (h.multi_file & 6) ? 0 : T * TILE_WORDS * 4};
     uint64_t total = 0;
     for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) {

@@ -623,7 +623,8 @@ struct IdentScan {
   uint32_t first_oi, last_oi;
   int32_t first_off, last_rem;
 };
-constexpr int MODE_IDENT = 1, MODE_CIGAR = 2;
+// MODE_WALK: an index without prefix lines -- the two short walks on the op lines (always together with MODE_IDENT)
+constexpr int MODE_IDENT = 1, MODE_CIGAR = 2, MODE_WALK = 4;
 
 struct PairCtx {
   int32_t ts, R0, R1, last_tp;
@@ -870,8 +871,9 @@ struct PfxTile {
 };
 // exact test of ONE op given the entries before and after it (op_step, arms as there); first-form = what the first
 // overlapping op contributes (query offset, target position), else what the last one does
+// adj: what the slice adjustment takes off the op (impg.rs:2879-2886): first_op_offset / last_op_remaining as op_step has them
 __device__ __forceinline__ bool pfx_eval(const PairCtx &c, const PfxTile &t, uint32_t ea, uint32_t eb, bool first_form,
-                                         int32_t &oq, int32_t &ot) {
+                                         int32_t &oq, int32_t &ot, int32_t &adj) {
   const int32_t xa = (int32_t)__builtin_amdgcn_ubfe(ea, t.tsh, 16u), xb = (int32_t)__builtin_amdgcn_ubfe(eb, t.tsh, 16u);
   const int32_t ya = (int32_t)__builtin_amdgcn_ubfe(ea, t.qsh, 16u), yb = (int32_t)__builtin_amdgcn_ubfe(eb, t.qsh, 16u);
   const int32_t td = xb - xa, qa = yb - ya;
@@ -887,13 +889,16 @@ __device__ __forceinline__ bool pfx_eval(const PairCtx &c, const PfxTile &t, uin
   const int32_t lq = Qn + (((td == 0) | qzero) ? qa : oe - T);
   oq = first_form ? fq : lq;
   ot = first_form ? os : oe;
+  adj = td == 0 ? 0 : first_form ? os - T : oe - (T + td);
   return pass;
 }
 // One end of the projection.  j = storage tile to start in, thr_abs = threshold on the record's storage-order
 // target prefix.  Returns true with (oq, ot) set, or false = take the literal walk.
+// which: the op that answered (storage tile, op within the tile) and its slice adjustment -- the identity filter's inputs
+struct PfxOp { uint32_t j, k; int32_t adj; };
 template <bool NEXT>
 __device__ __forceinline__ bool pfx_end(const PairCtx &c, const uint32_t *__restrict__ pfx_rec, uint32_t n_ops, uint32_t j,
-                                        int32_t thr_abs, bool first_form, int32_t &oq, int32_t &ot) {
+                                        int32_t thr_abs, bool first_form, int32_t &oq, int32_t &ot, PfxOp &which) {
   for (;;) {
     const uint32_t *line = pfx_rec + (size_t)j * TILE_WORDS;
     uint4 h = *reinterpret_cast<const uint4 *>(line);  // T0 | wide << 31, Q0, entry 9, entry 18
@@ -937,13 +942,16 @@ __device__ __forceinline__ bool pfx_end(const PairCtx &c, const uint32_t *__rest
       w0 = line[PFX_E0 + k - 1u]; w1 = line[PFX_E0 + k]; w2 = line[PFX_E0 + k + 1u];
     }
     // window: NEXT: e_k, e_(k+1), e_(k+2); else e_(k-1), e_k, e_(k+1)
-    if (pfx_eval(c, t, NEXT ? w0 : w1, NEXT ? w1 : w2, first_form, oq, ot)) return true;
+    which.j = j; which.k = k;
+    if (pfx_eval(c, t, NEXT ? w0 : w1, NEXT ? w1 : w2, first_form, oq, ot, which.adj)) return true;
     if (NEXT) {
-      if (k + 1u < cnt) return pfx_eval(c, t, w1, w2, first_form, oq, ot);
+      which.k = k + 1u;
+      if (k + 1u < cnt) return pfx_eval(c, t, w1, w2, first_form, oq, ot, which.adj);
       if (j + 1u >= c.m) return false;
       j += 1u;
     } else {
-      if (k > 0u) return pfx_eval(c, t, w0, w1, first_form, oq, ot);
+      which.k = k - 1u;
+      if (k > 0u) return pfx_eval(c, t, w0, w1, first_form, oq, ot, which.adj);
       if (j == 0u) return false;
       j -= 1u;
     }
@@ -1024,7 +1032,7 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
       //   B = last  k with P[k]   <= last_tp - ts   (holds the last live op)
       const int32_t xa = c.R0 - c.ts, xb = c.last_tp - c.ts;
       // (the plain projection wants the last tile that STARTS at or before last_target_pos: it counts P[i] <= xb)
-      const int32_t xbc = MODE == 0 ? xb + 1 : xb;
+      const int32_t xbc = !(MODE & (MODE_WALK | MODE_CIGAR)) ? xb + 1 : xb;
       uint32_t cA = 0, cB = 0;  // cA = #{i in [1,m] : P[i] < xa}, cB = #{i in [0,m) : P[i] < xbc}
       if (c.m <= INLINE_TILES) {
         // the seven inline slots hold P[1..m-1], P[m] = totT, then INT_MAX (index_build.cpp); P[8] is totT when m = 8
@@ -1080,10 +1088,11 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
         bool walked = false, joined = false, need_walk = false;
         constexpr int PA = MODE == 0 ? PART_FIRST : PART_BOTH, PB = MODE == 0 ? PART_LAST : PART_BOTH;
         uint32_t ipa = 0, ipb = 0;  // idp[] rows the two walks count from
+        int64_t lineM = 0, lineX = 0, lineG = 0;  // the slice's counts off the identity lines
         if (CIGAR) {
           res = walk_tiles<MODE>(c, orig_tile(c, kA), c.flip ? 0u : c.m - 1u, ia);
           walked = true;
-        } else if (MODE == 0) {
+        } else if (!(MODE & MODE_WALK)) {
           // the two ends on the prefix lines (see pfx_end); in storage order a back-to-front entry swaps their roles
           const uint32_t *pfx_rec = v.pfx + (size_t)e1.y * TILE_WORDS;
           bool lit = cB == 0u;  // no tile starts at or before last_target_pos: let the literal walk say so
@@ -1092,17 +1101,37 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
           const bool do_first = !start_cov, do_last = !end_cov;
           // call 1 looks forward in storage order (k, k + 1): the first end of a front-to-back walk, the last end of a
           // back-to-front one; call 2 looks backward (k, k - 1)
+          PfxOp lo_op{0u, 0u, 0}, hi_op{0u, 0u, 0};  // (storage order: call 1 finds the lower end, call 2 the upper)
           if (!lit && (c.flip ? do_last : do_first)) {
             int32_t oq, ot;
-            const bool okc = pfx_end<true>(c, pfx_rec, n, orig_tile(c, c.flip ? kL : kA), c.flip ? (int32_t)c.totT - xb : xa, !c.flip, oq, ot);
+            const bool okc = pfx_end<true>(c, pfx_rec, n, orig_tile(c, c.flip ? kL : kA), c.flip ? (int32_t)c.totT - xb : xa, !c.flip, oq, ot, lo_op);
             lit = !okc;
             if (c.flip) { lq = oq; lt = ot; } else { fq = oq; ft = ot; }
           }
           if (!lit && (c.flip ? do_first : do_last)) {
             int32_t oq, ot;
-            const bool okc = pfx_end<false>(c, pfx_rec, n, orig_tile(c, c.flip ? kA : kL), (c.flip ? (int32_t)c.totT - xa : xb) + 1, c.flip, oq, ot);
+            const bool okc = pfx_end<false>(c, pfx_rec, n, orig_tile(c, c.flip ? kA : kL), (c.flip ? (int32_t)c.totT - xa : xb) + 1, c.flip, oq, ot, hi_op);
             lit = !okc;
             if (c.flip) { fq = oq; ft = ot; } else { lq = oq; lt = ot; }
+          }
+          if (IDENT && !lit) {
+            // The slice [first op, last op] in storage order is [lo_op, hi_op]: its matched / mismatched bases and gap ops
+            // are the identity lines' sums after hi_op minus those before lo_op (IDL_*, impg_internal.hpp); an op is a
+            // match / mismatch op iff its own entry difference says so, which is what the two adjustments need to know.
+            const uint32_t *idl = reinterpret_cast<const uint32_t *>(v.idp) + (size_t)e1.y * IDL_WORDS;
+            const uint32_t *la = idl + (size_t)lo_op.j * IDL_WORDS, *lb = idl + (size_t)hi_op.j * IDL_WORDS;
+            uint4 ha = *reinterpret_cast<const uint4 *>(la), hb = *reinterpret_cast<const uint4 *>(lb);
+            u32x2_u ea = *reinterpret_cast<const u32x2_u *>(la + IDL_E0 + lo_op.k), eb = *reinterpret_cast<const u32x2_u *>(lb + IDL_E0 + hi_op.k);
+            asm volatile("" : "+v"(ha.x), "+v"(hb.x), "+v"(ea), "+v"(eb));
+            const int32_t am0 = (int32_t)(ea.x & 0xFFFFu), ax0 = (int32_t)(ea.x >> 16), am1 = (int32_t)(ea.y & 0xFFFFu), ax1 = (int32_t)(ea.y >> 16);
+            const int32_t bm0 = (int32_t)(eb.x & 0xFFFFu), bx0 = (int32_t)(eb.x >> 16), bm1 = (int32_t)(eb.y & 0xFFFFu), bx1 = (int32_t)(eb.y >> 16);
+            lineM = ((int64_t)hb.x + bm1) - ((int64_t)ha.x + am0);
+            lineX = ((int64_t)hb.y + bx1) - ((int64_t)ha.y + ax0);
+            lineG = ((int64_t)hb.z + __popc(hb.w & ((2u << hi_op.k) - 1u))) - ((int64_t)ha.z + __popc(ha.w & ((1u << lo_op.k) - 1u)));
+            // first_op_offset comes off the FIRST op in walking order, last_op_remaining (<= 0) goes onto the LAST
+            const int32_t lo_adj = c.flip ? lo_op.adj : -lo_op.adj, hi_adj = c.flip ? -hi_op.adj : hi_op.adj;
+            lineM += (am1 != am0 ? lo_adj : 0) + (bm1 != bm0 ? hi_adj : 0);
+            lineX += (ax1 != ax0 ? lo_adj : 0) + (bx1 != bx0 ? hi_adj : 0);
           }
           if (lit) {
             res = walk_tiles<MODE>(c, orig_tile(c, kA), c.flip ? 0u : c.m - 1u, ia);
@@ -1208,7 +1237,9 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
           // where prefix(s) = matched / mismatched bases and gap ops before sub-tile s (idp[])
           // and firstA / lastB are the walking-order running sums snapshotted by op_step.
           int64_t M, X, G;
-          if (walked || joined) {  // one continuous walk: plain difference of its running sums
+          if (!walked && !(MODE & MODE_WALK)) {  // both ends on the prefix lines
+            M = lineM; X = lineX; G = lineG;
+          } else if (walked || joined) {  // one continuous walk: plain difference of its running sums
             const IdentScan &w = walked ? ia : ib;
             M = (int64_t)w.lm - w.fm; X = (int64_t)w.lx - w.fx; G = (int64_t)w.lg - w.fg;
             M += -(int64_t)w.first_adj_m + w.last_adj_m;
@@ -2835,6 +2866,7 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
   // no plain path: its projections take the identity filter's two short walks on the op lines with a threshold
   // nothing fails (identity >= 0) -- the same answers, about twice the instructions.
   if (!ident && !v.pfx && !v.tp_mode) { ident = true; min_identity = 0.0; }
+  const bool two_walks = !v.pfx && !slices;
   if (v.tp_mode) {  // tracepoint index: every projection is the approximate one
     const uint32_t gt = (cdiv(n_pairs, 256) + 7u) & ~7u;
     if (transitive) project_tp_kernel<true><<<gt, 256, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag,
@@ -2846,14 +2878,14 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
   const uint32_t g = (cdiv(n_pairs, PROJ_BLOCK) + 7u) & ~7u;  // a multiple of the 8 XCDs (see the block mapping in the kernel)
   const int xcd_map = 1;
   const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};
-  const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0);
+  const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0) | (two_walks ? MODE_WALK : 0);
 #define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, PROJ_BLOCK, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map, n_pairs_dev, rg)
   if (transitive) {
     switch (mode) { case 0: IMPG_LAUNCH(true, 0); break; case 1: IMPG_LAUNCH(true, 1); break;
-                    case 2: IMPG_LAUNCH(true, 2); break; default: IMPG_LAUNCH(true, 3); }
+                    case 2: IMPG_LAUNCH(true, 2); break; case 3: IMPG_LAUNCH(true, 3); break; default: IMPG_LAUNCH(true, 5); }
   } else {
     switch (mode) { case 0: IMPG_LAUNCH(false, 0); break; case 1: IMPG_LAUNCH(false, 1); break;
-                    case 2: IMPG_LAUNCH(false, 2); break; default: IMPG_LAUNCH(false, 3); }
+                    case 2: IMPG_LAUNCH(false, 2); break; case 3: IMPG_LAUNCH(false, 3); break; default: IMPG_LAUNCH(false, 5); }
   }
 #undef IMPG_LAUNCH
 }
@@ -3092,10 +3124,12 @@ size_t walk_slab_bytes(uint32_t n_seq, bool wide, uint32_t wcap, uint32_t hcap, 
 void launch_walk(const WalkArgs &a, uint32_t n_workgroups, bool wide, bool ident_mode, hipStream_t s) {
   if (!n_workgroups) return;
   if (wide) {
-    if (ident_mode) walk_kernel<16, 4096, MODE_IDENT><<<n_workgroups, 1024, 0, s>>>(a);
+    if (ident_mode && !a.v.pfx) walk_kernel<16, 4096, MODE_IDENT | MODE_WALK><<<n_workgroups, 1024, 0, s>>>(a);
+    else if (ident_mode) walk_kernel<16, 4096, MODE_IDENT><<<n_workgroups, 1024, 0, s>>>(a);
     else walk_kernel<16, 4096, 0><<<n_workgroups, 1024, 0, s>>>(a);
   } else {
-    if (ident_mode) walk_kernel<1, 256, MODE_IDENT><<<n_workgroups, 64, 0, s>>>(a);
+    if (ident_mode && !a.v.pfx) walk_kernel<1, 256, MODE_IDENT | MODE_WALK><<<n_workgroups, 64, 0, s>>>(a);
+    else if (ident_mode) walk_kernel<1, 256, MODE_IDENT><<<n_workgroups, 64, 0, s>>>(a);
     else walk_kernel<1, 256, 0><<<n_workgroups, 64, 0, s>>>(a);
   }
 }

@@ -253,8 +253,11 @@ struct ShardedExpander : Expander {
         }
         if (ship_ops) {  // the ops of one home's hits are one stretch of the slice pool (slot order): its ends from slice_pos
           uint32_t *h_pos = h_vals + (W + 1);
-          for (size_t k = 0; k < runs.size(); k++)
-            IMPG_HIP(hipMemcpyAsync(h_pos + k, owner_L.slice_pos.as<uint32_t>() + h_vals[k], 4, hipMemcpyDeviceToHost, s));
+          for (size_t k = 0; k < runs.size(); k++) {
+            // (a run whose records have no slot at all starts at slot P: past the end of slice_pos, its ops start at the pool's end)
+            if (h_vals[k] >= P) h_pos[k] = (uint32_t)owner_L.slice_total;
+            else IMPG_HIP(hipMemcpyAsync(h_pos + k, owner_L.slice_pos.as<uint32_t>() + h_vals[k], 4, hipMemcpyDeviceToHost, s));
+          }
           IMPG_HIP(hipStreamSynchronize(s));
           for (size_t k = 0; k < runs.size(); k++) {
             const uint64_t first = h_pos[k], end = k + 1 < runs.size() ? h_pos[k + 1] : owner_L.slice_total;

@@ -44,7 +44,16 @@ while time.time() < t_end:
     # one GPU, or the index sharded over 2..4 ranks that share the GPU (the multi handle: same entry points)
     world = int(rng.choice([1, 1, 2, 3, 4]))
     devs = None if world == 1 else [0] * world
+    # round 3: the index built on the device (default) or by the host builder, with or without its prefix lines
+    for k2 in ("IMPG_BUILD_HOST", "IMPG_PREFIX_LINES"):
+        os.environ.pop(k2, None)
+    if rng.random() < 0.2:
+        os.environ["IMPG_BUILD_HOST"] = "1"
+    if rng.random() < 0.15:
+        os.environ["IMPG_PREFIX_LINES"] = "0"
     g = impg_amd.GpuImpg.from_paf(paths, bidirectional=bidir, order=order, devices=devs, lanes=int(rng.integers(1, 3)))
+    g.set_option("walk_kernel", int(rng.choice([0, 1, 1, 2])))       # the per-query walk: off / DFS / DFS + small BFS batches
+    g.set_option("filter_covered", int(rng.choice([0, 0, 1, 2])))
     o.set_sorted_visits(order == impg_amd.ORDER_SORTED)  # both order policies have an exact checker
     c = o.OracleIndex(paf_paths=paths, bidirectional=bidir, preparse=True)
     g.set_option("locality_min", int(rng.choice([0, 1, 4096])))
@@ -72,7 +81,7 @@ while time.time() < t_end:
         kw["min_identity"] = float(rng.choice([0.3, 0.7, 0.95]))
     if rng.random() < 0.25:
         kw["multi_impg"] = True
-    cigar = bool(rng.random() < 0.5) and world == 1  # (CIGAR slices stay with their owner on a sharded index)
+    cigar = bool(rng.random() < 0.5)  # (on a sharded index the slices' ops follow the hits home)
     if rng.random() < 0.3:
         kw["consider_strandness"] = True
     mask = None
@@ -89,7 +98,11 @@ while time.time() < t_end:
         keep = (rng.random(g.num_seqs()) < rng.choice([0.2, 0.6, 0.9])).astype(np.uint8)
         cigar = False
     params = impg_amd.make_params(store_cigar=cigar, **kw)
-    res = g.query_batch(ranges, params, masked_regions=mask, subset_keep=keep)
+    try:
+        res = g.query_batch(ranges, params, masked_regions=mask, subset_keep=keep)
+    except Exception:
+        print("FAILED CALL seed", seed, "world", world, "files", n_files, "cigar", cigar, "kw", kw, "mask", mask is not None, "keep", keep is not None, flush=True)
+        raise
     total = 0
     for i, (t, s, e) in enumerate(ranges):
         if cigar:
@@ -149,7 +162,7 @@ while time.time() < t_end:
             r2 = g.query_batch(sub, params)
             want = "".join(c.query_bed(g.seq_name(t), s, e, range_name=names[k], merge_distance=d, **kw) for k, (t, s, e) in enumerate(sub))
             assert r2.bed(names, merge_distance=d, params=params) == want, ("bed", seed, d, kw)
-            if world == 1:  # both merges + the text on the device
+            if True:  # both merges + the text on the device (every rank its own ranges on a sharded index)
                 got_dev = g.query_batch_bed(sub, params, merge_distance=d, range_names=names)
                 if got_dev != want:
                     a, b = got_dev.splitlines(), want.splitlines()

@@ -121,6 +121,21 @@ def test_multi_handle_pair_budget_slices(tmp_path):
         assert got[i].tolist() == c.query(t, s, e, **kw).tolist(), i
 
 
+@pytest.mark.parametrize("world,lanes", [(2, 1), (3, 2)])
+def test_store_cigar_with_hitless_arrivals(tmp_path, world, lanes):
+    """An owner that receives, behind ranges with hits, a home's ranges that hit nothing: that home's run of the slice pool
+    is empty and starts past the last slot (the soak's seed-31xxx failure: "CIGAR ops and hit records that came home disagree")."""
+    path = write_paf(tmp_path, seed=11, n=120)
+    c = o.OracleIndex(paf_paths=[path], preparse=True)
+    g = impg_amd.GpuImpg.from_paf(path, devices=[0] * world, lanes=lanes)
+    g.set_option("chunk_ranges", 1)
+    rl = []
+    for i in range(48):  # every other range lies beyond the sequences' last alignment: no overlap at all
+        rl.append((i % 7, 19990, 20000) if i % 2 else (i % 7, 1000 + 37 * i, 4000 + 37 * i))
+    for kw in (dict(), dict(transitive=True, max_depth=2, min_transitive_len=40)):
+        check_cigars(g, c, rl, **kw)
+
+
 @pytest.mark.parametrize("world,lanes", [(2, 2), (3, 1)])
 def test_rank_processes_host_transport(tmp_path, world, lanes):
     """One process per rank (the torch.distributed.run layout); collectives through the host transport

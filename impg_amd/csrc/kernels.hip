@@ -1023,16 +1023,19 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
       //  * the range reaches the alignment end and the CIGAR is consistent with
       //    the PAF coordinates: the final op is the last overlapping op, ending at
       //    (query offset totQ, target te).
-      // (The identity filter needs the slice's op counts, so it always reads the tiles.)
-      const bool start_cov = MODE == 0 && c.R0 <= c.ts && c.last_tp > c.ts;
-      const bool end_cov = MODE == 0 && c.R1 >= en_te && c.R0 < en_te && (int32_t)c.totT == en_te - c.ts;
+      // (Under the identity filter the slice then starts at the record's first op / ends at its last one with nothing
+      // taken off them: the identity lines give those sums without locating anything.  The two-walk and store_cigar
+      // forms do not take the shortcuts.)
+      constexpr bool ON_LINES = !(MODE & (MODE_WALK | MODE_CIGAR));
+      const bool start_cov = ON_LINES && c.R0 <= c.ts && c.last_tp > c.ts;
+      const bool end_cov = ON_LINES && c.R1 >= en_te && c.R0 < en_te && (int32_t)c.totT == en_te - c.ts;
       // Effective tile k (k-th tile in this entry's walking order) starts at target
       // prefix P[k]: P[0] = 0, P[m] = totT, P[1..m-1] inline (m <= 8) or external.
       //   A = first k with P[k+1] >= R0 - ts        (holds the first op that can overlap)
       //   B = last  k with P[k]   <= last_tp - ts   (holds the last live op)
       const int32_t xa = c.R0 - c.ts, xb = c.last_tp - c.ts;
       // (the plain projection wants the last tile that STARTS at or before last_target_pos: it counts P[i] <= xb)
-      const int32_t xbc = !(MODE & (MODE_WALK | MODE_CIGAR)) ? xb + 1 : xb;
+      const int32_t xbc = ON_LINES ? xb + 1 : xb;
       uint32_t cA = 0, cB = 0;  // cA = #{i in [1,m] : P[i] < xa}, cB = #{i in [0,m) : P[i] < xbc}
       if (c.m <= INLINE_TILES) {
         // the seven inline slots hold P[1..m-1], P[m] = totT, then INT_MAX (index_build.cpp); P[8] is totT when m = 8
@@ -1088,7 +1091,7 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
         bool walked = false, joined = false, need_walk = false;
         constexpr int PA = MODE == 0 ? PART_FIRST : PART_BOTH, PB = MODE == 0 ? PART_LAST : PART_BOTH;
         uint32_t ipa = 0, ipb = 0;  // idp[] rows the two walks count from
-        int64_t lineM = 0, lineX = 0, lineG = 0;  // the slice's counts off the identity lines
+        int32_t lineM = 0, lineX = 0, lineG = 0;  // the slice's counts off the identity lines (sums of one record: below 2^31)
         if (CIGAR) {
           res = walk_tiles<MODE>(c, orig_tile(c, kA), c.flip ? 0u : c.m - 1u, ia);
           walked = true;
@@ -1101,7 +1104,10 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
           const bool do_first = !start_cov, do_last = !end_cov;
           // call 1 looks forward in storage order (k, k + 1): the first end of a front-to-back walk, the last end of a
           // back-to-front one; call 2 looks backward (k, k - 1)
-          PfxOp lo_op{0u, 0u, 0}, hi_op{0u, 0u, 0};  // (storage order: call 1 finds the lower end, call 2 the upper)
+          // (storage order: call 1 finds the lower end, call 2 the upper; an end the shortcuts answer is the record's
+          // first / last op)
+          PfxOp lo_op{0u, 0u, 0}, hi_op{c.m - 1u, n - (c.m - 1u) * TILE_OPS - 1u, 0};
+          const bool lo_edge = c.flip ? !do_last : !do_first;
           if (!lit && (c.flip ? do_last : do_first)) {
             int32_t oq, ot;
             const bool okc = pfx_end<true>(c, pfx_rec, n, orig_tile(c, c.flip ? kL : kA), c.flip ? (int32_t)c.totT - xb : xa, !c.flip, oq, ot, lo_op);
@@ -1120,14 +1126,18 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
             // match / mismatch op iff its own entry difference says so, which is what the two adjustments need to know.
             const uint32_t *idl = reinterpret_cast<const uint32_t *>(v.idp) + (size_t)e1.y * IDL_WORDS;
             const uint32_t *la = idl + (size_t)lo_op.j * IDL_WORDS, *lb = idl + (size_t)hi_op.j * IDL_WORDS;
-            uint4 ha = *reinterpret_cast<const uint4 *>(la), hb = *reinterpret_cast<const uint4 *>(lb);
-            u32x2_u ea = *reinterpret_cast<const u32x2_u *>(la + IDL_E0 + lo_op.k), eb = *reinterpret_cast<const u32x2_u *>(lb + IDL_E0 + hi_op.k);
+            uint4 ha = make_uint4(0u, 0u, 0u, 0u), hb = *reinterpret_cast<const uint4 *>(lb);
+            u32x2_u ea = {0u, 0u}, eb = *reinterpret_cast<const u32x2_u *>(lb + IDL_E0 + hi_op.k);
+            if (!lo_edge) {  // (before the record's first op every sum is zero)
+              ha = *reinterpret_cast<const uint4 *>(la);
+              ea = *reinterpret_cast<const u32x2_u *>(la + IDL_E0 + lo_op.k);
+            }
             asm volatile("" : "+v"(ha.x), "+v"(hb.x), "+v"(ea), "+v"(eb));
             const int32_t am0 = (int32_t)(ea.x & 0xFFFFu), ax0 = (int32_t)(ea.x >> 16), am1 = (int32_t)(ea.y & 0xFFFFu), ax1 = (int32_t)(ea.y >> 16);
             const int32_t bm0 = (int32_t)(eb.x & 0xFFFFu), bx0 = (int32_t)(eb.x >> 16), bm1 = (int32_t)(eb.y & 0xFFFFu), bx1 = (int32_t)(eb.y >> 16);
-            lineM = ((int64_t)hb.x + bm1) - ((int64_t)ha.x + am0);
-            lineX = ((int64_t)hb.y + bx1) - ((int64_t)ha.y + ax0);
-            lineG = ((int64_t)hb.z + __popc(hb.w & ((2u << hi_op.k) - 1u))) - ((int64_t)ha.z + __popc(ha.w & ((1u << lo_op.k) - 1u)));
+            lineM = (int32_t)(hb.x - ha.x) + (bm1 - am0);
+            lineX = (int32_t)(hb.y - ha.y) + (bx1 - ax0);
+            lineG = (int32_t)(hb.z - ha.z) + (__popc(hb.w & ((2u << hi_op.k) - 1u)) - __popc(ha.w & ((1u << lo_op.k) - 1u)));
             // first_op_offset comes off the FIRST op in walking order, last_op_remaining (<= 0) goes onto the LAST
             const int32_t lo_adj = c.flip ? lo_op.adj : -lo_op.adj, hi_adj = c.flip ? -hi_op.adj : hi_op.adj;
             lineM += (am1 != am0 ? lo_adj : 0) + (bm1 != bm0 ? hi_adj : 0);
@@ -1258,9 +1268,17 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
             M += -(int64_t)ia.first_adj_m + ib.last_adj_m;
             X += -(int64_t)ia.first_adj_x + ib.last_adj_x;
           }
-          const int64_t total = M + X + G;  // impg.rs:2967
-          const double ident = total == 0 ? 0.0 : (double)M / (double)total;
-          if (ident < min_identity) res.found = false;  // impg.rs:1284-1286
+          // impg.rs:2967, :1284-1286: drop the hit iff fl(M / total) < min_identity (0 for an empty slice).  The rounded
+          // quotient is within 2^-53 of M / total and the rounded product below within 2^-53 of min_identity * total, so
+          // a comparison with 2^-50 of slack on either side decides all but borderline pairs without the division (a
+          // double-precision quotient is ~40 instructions; every lane of every wave paid them).
+          const int32_t total = (int32_t)(M + X + G);
+          const double dm = (double)(int32_t)M, dt = (double)total, prod = min_identity * dt;
+          bool drop;
+          if (dm < prod * (1.0 - 0x1p-50)) drop = true;
+          else if (dm > prod * (1.0 + 0x1p-50)) drop = false;
+          else drop = (total == 0 ? 0.0 : dm / dt) < min_identity;
+          if (drop) res.found = false;
         }
       }
       ok = res.found && res.pqs != res.pqe && res.pts != res.pte;  // impg.rs:2874-2877

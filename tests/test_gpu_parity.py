@@ -255,6 +255,26 @@ def test_min_gap_compressed_identity(tmp_path, seed, weird, max_ops):
         assert_same(g, c, ranges[:50], transitive=True, max_depth=3, min_transitive_len=30, min_identity=thr)
 
 
+def test_identity_threshold_on_the_border(tmp_path):
+    """Thresholds equal to a hit's own identity and its two neighbouring doubles: the kernel decides most pairs by a
+    comparison with slack and only borderline ones by the division (kernels.hip, project_pair) -- these are the borderline ones."""
+    text, names = random_paf(44, 200, n_seq=4, seq_len=30000, max_ops=150, self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(44, 40, 4, 30000, max_len=5000)
+    idents = set()
+    for (t, s, e) in ranges:
+        _, cg = c.query_cigar(t, s, e)
+        idents.update(o.gap_compressed_identity(ops) for ops in cg if len(ops))
+    idents = sorted(v for v in idents if 0.0 < v < 1.0)
+    assert len(idents) > 20
+    picks = idents[:: max(1, len(idents) // 25)]
+    for v in picks:
+        for thr in (v, float(np.nextafter(v, 1.0)), float(np.nextafter(v, 0.0))):
+            assert_same(g, c, ranges, min_identity=thr)
+    for thr in (1 / 3, 2 / 3, 0.1 + 0.2):
+        assert_same(g, c, ranges, transitive=True, max_depth=2, min_transitive_len=30, min_identity=thr)
+
+
 @pytest.mark.parametrize("seed", [51, 52, 53])
 def test_transitive_dfs(tmp_path, seed):
     """query_transitive_dfs (impg.rs:2057-2309): one stack pop per query per round."""

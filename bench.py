@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--max-depth", type=int, default=None)
     ap.add_argument("--no-transitive", action="store_true")
     ap.add_argument("--chunk-ranges", type=int, default=None,
-                    help="ranges per chunk (default 50000 on one GPU; 25000 per rank on a sharded index: two chunks per lane)")
+                    help="ranges per chunk (default 50000, on one GPU and per rank on a sharded index)")
     ap.add_argument("--pair-budget", type=int, default=1 << 30)
     ap.add_argument("--cpu-sample", type=int, default=1000, help="ranges timed on the CPU oracle, ~15 s of CPU work (0 = skip)")
     ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=VALUE",
@@ -95,7 +95,7 @@ def main():
     if args.max_depth is None:
         args.max_depth = 5 if wl == "config5" else 3
     if args.chunk_ranges is None:
-        args.chunk_ranges = 500 if wl == "config5" else (25000 if (args.gpus > 1 or args.force_sharded) else 50000)
+        args.chunk_ranges = 500 if wl == "config5" else 50000
     if wl != "headline":
         args.cpu_sample, args.no_extras = 0, True  # the CPU and full-results legs belong to the headline line
 

@@ -194,6 +194,7 @@ RcclComm::~RcclComm() {
 }
 void RcclComm::allgather_u64(const uint64_t *mine, size_t k, uint64_t *all) {
   if (dead) throw Error{IMPG_E_HIP, "the RCCL communicator was aborted after an earlier failure"};
+  if (world == 1) { memcpy(all, mine, k * 8); return; }  // (nothing to gather: no collective, no staging)
   IMPG_HIP(hipSetDevice(device));
   const size_t need = (size_t)(world + 1) * k * 8;
   if (need > h_cap) {
@@ -218,17 +219,23 @@ void RcclComm::alltoallv(const void *d_send, const uint64_t *send_off, const uin
                          const uint64_t *recv_off, const uint64_t *recv_bytes, hipStream_t s) {
   if (dead) throw Error{IMPG_E_HIP, "the RCCL communicator was aborted after an earlier failure"};
   IMPG_HIP(hipSetDevice(device));
+  // a rank's block for itself never enters RCCL: a device-to-device copy on the same stream (1/world of the volume; a
+  // send/receive pair to oneself runs through the proxy's staging kernels at a fraction of the copy's rate)
+  if (send_bytes[rank] != recv_bytes[rank]) throw Error{IMPG_E_INVALID, "alltoallv: block sizes disagree"};
+  if (send_bytes[rank])
+    IMPG_HIP(hipMemcpyAsync((char *)d_recv + recv_off[rank], (const char *)d_send + send_off[rank], send_bytes[rank], hipMemcpyDeviceToDevice, s));
+  if (world == 1) { IMPG_HIP(hipStreamSynchronize(s)); return; }
   Turn turn(order.get(), lane);
   // one message per peer and round, <= 256 MiB each: bounded staging inside RCCL, and far below the size at
   // which a single all-to-all message was seen corrupted on this stack in round 1 (> 1 GiB)
   constexpr uint64_t ROUND = 256ull << 20;
   uint64_t most = 0;
-  for (int p = 0; p < world; p++) most = std::max(most, std::max(send_bytes[p], recv_bytes[p]));
+  for (int p = 0; p < world; p++) if (p != rank) most = std::max(most, std::max(send_bytes[p], recv_bytes[p]));
   // sends and receives are matched pair by pair: both ends of a pair derive the same number of messages from the
   // same byte count, so ranks may run different numbers of rounds
   for (uint64_t done = 0; done < most; done += ROUND) {
     nccl_check(rccl().GroupStart(), "ncclGroupStart");
-    for (int k = 0; k < world; k++) {
+    for (int k = 1; k < world; k++) {
       const int p = (rank + k) % world;
       if (send_bytes[p] > done) {
         const uint64_t n = std::min(ROUND, send_bytes[p] - done);

@@ -294,15 +294,27 @@ __global__ __launch_bounds__(256) void route_keys_kernel(const FrontierRec *__re
   __shared__ uint32_t h[ROUTE_MAX_WORLD];
   for (uint32_t k = threadIdx.x; k < world; k += 256u) h[k] = 0;
   __syncthreads();
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i < n) {
-    // owner table of the shard map (targets bin-packed by entry count); a sequence id the index does not know
-    // has no alignments anywhere: any rank may answer "no hits"
-    const uint32_t t = fr[i].target_id;
-    const uint32_t o = (owner && t < n_seq) ? owner[t] : t % world;
-    key[i] = o;
-    idx[i] = i;
-    atomicAdd(&h[o], 1u);
+  // (grid-stride: a bounded number of blocks, so that the closing atomics on the `world` global counters -- which
+  // serialise at one L2 channel -- are a few thousand, not one per 256 records: 0.32 ms per call before this)
+  for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+    const uint32_t i = base + threadIdx.x;
+    uint32_t o = 0xFFFFFFFFu;
+    if (i < n) {
+      // owner table of the shard map (targets bin-packed by entry count); a sequence id the index does not know
+      // has no alignments anywhere: any rank may answer "no hits"
+      const uint32_t t = fr[i].target_id;
+      o = (owner && t < n_seq) ? owner[t] : t % world;
+      key[i] = o;
+      idx[i] = i;
+    }
+    // one LDS atomic per owner present in the wave, not one per record
+    unsigned long long left = __ballot(o != 0xFFFFFFFFu);
+    while (left) {
+      const uint32_t o0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)o, (int)(__ffsll((long long)left) - 1)));
+      const unsigned long long m = __ballot(o == o0);
+      if (lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(&h[o0], (uint32_t)__popcll(m));
+      left &= ~m;
+    }
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < world; k += 256u)
@@ -329,12 +341,18 @@ __global__ __launch_bounds__(256) void reorder_runs_kernel(const uint32_t *__res
   if (i >= n) return;
   const uint32_t f = hits[(size_t)i * words];
   if (f >= n_front) { *err = 1; return; }
-  if (i == 0 || hits[(size_t)(i - 1) * words] != f) {
-    run_start[f] = i;
-    uint32_t e = i + 1;  // runs are a few dozen records (one frontier range's hits): the head walks its own run
-    while (e < n && hits[(size_t)e * words] == f) e++;
-    run_len[f] = e - i;
+  // the run's first record notes where it starts, its last one where it ends (run_len holds the END until
+  // run_lengths_kernel turns it into a length): no thread walks a run
+  if (i == 0 || hits[(size_t)(i - 1) * words] != f) run_start[f] = i;
+  if (i + 1 == n || hits[(size_t)(i + 1) * words] != f) {
+    if (atomicExch(&run_len[f], i + 1u) != 0u) *err = 1;  // a second run for the same frontier record
   }
+}
+__global__ __launch_bounds__(256) void run_lengths_kernel(const uint32_t *__restrict__ run_start, uint32_t *__restrict__ run_len, uint32_t n_front) {
+  const uint32_t f = blockIdx.x * 256u + threadIdx.x;
+  if (f >= n_front) return;
+  const uint32_t e = run_len[f];
+  if (e) run_len[f] = e - run_start[f];
 }
 // Lookup / projection order: ranges sorted by where their window will be in the entry array,
 // estimated before any search from the record alone: segment start + start / sequence length x
@@ -2857,14 +2875,16 @@ void launch_small_pack(const FrontierRec *fr, const uint32_t *pair_range, const 
 }
 void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, const uint32_t *owner, uint32_t n_seq, uint32_t *key,
                        uint32_t *idx, unsigned long long *hist, hipStream_t s) {
-  if (n) route_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, n, world, owner, n_seq, key, idx, hist);
+  if (n) route_keys_kernel<<<std::min(cdiv(n, 256), 2048u), 256, 0, s>>>(fr, n, world, owner, n_seq, key, idx, hist);
 }
 void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s) {
   if (n) route_gather_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, perm, n, out);
 }
 void launch_reorder_runs(const uint32_t *hits, uint32_t n, uint32_t words, uint32_t n_front, uint32_t *run_start,
                          uint32_t *run_len, uint32_t *err, hipStream_t s) {
-  if (n) reorder_runs_kernel<<<cdiv(n, 256), 256, 0, s>>>(hits, n, words, n_front, run_start, run_len, err);
+  if (!n) return;
+  reorder_runs_kernel<<<cdiv(n, 256), 256, 0, s>>>(hits, n, words, n_front, run_start, run_len, err);
+  run_lengths_kernel<<<cdiv(n_front, 256), 256, 0, s>>>(run_start, run_len, n_front);
 }
 void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, uint32_t *key, uint32_t *idx, hipStream_t s,
                        const uint32_t *bounds, uint32_t n_blocks, uint32_t block_shift) {

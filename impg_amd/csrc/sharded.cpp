@@ -71,8 +71,24 @@ struct ShardedExpander : Expander {
   uint32_t n_seq = 0;
   DevBuf send_fr, recv_fr, hits_out, hits_in, ops_out, ops_in, mslot, iota, route_hist, d_bounds;
   LevelBufs owner_L;
-  uint32_t *h_vals = nullptr;  // pinned: slot offsets at block boundaries
+  // pinned words every readback / small upload of a hop goes through (a copy from or to pageable memory stages and
+  // blocks): [0, W] slot offsets at block boundaries, [W+1, 2W+1] slice-pool offsets there, then the route histogram
+  // (W x u64), the reorder error flag, and BOUND_SLOTS x (W+1) block bounds on their way to the device
+  uint32_t *h_vals = nullptr;
   size_t h_cap = 0;
+  static constexpr uint32_t BOUND_SLOTS = 8;
+  uint32_t bound_slot = 0;
+  void pinned_words(uint32_t W) {
+    const size_t need = ((size_t)(W + 1) * (2 + BOUND_SLOTS) + 2 * (size_t)W + 4) * 4;
+    if (need <= h_cap) return;
+    if (h_vals) (void)hipHostFree(h_vals);
+    h_vals = nullptr;
+    h_cap = std::max<size_t>(need, 4096);
+    IMPG_HIP(hipHostMalloc((void **)&h_vals, h_cap, hipHostMallocDefault));
+  }
+  unsigned long long *h_hist(uint32_t W) { return reinterpret_cast<unsigned long long *>(h_vals + 2 * (W + 1)); }
+  uint32_t *h_err(uint32_t W) { return h_vals + 2 * (W + 1) + 2 * W; }
+  uint32_t *h_bounds(uint32_t W, uint32_t slot) { return h_vals + 2 * (W + 1) + 2 * W + 4 + (size_t)slot * (W + 1); }
   double exchange_s = 0;  // wall time inside the transport, accumulated
   uint64_t bytes_out = 0;
   // The lanes of a rank take turns on the GPU: two chunks' kernels side by side evict each other's entries and
@@ -125,8 +141,9 @@ struct ShardedExpander : Expander {
     } else {
       launch_route_gather(fr, E.lo_idx.as<uint32_t>(), n, send_fr.as<FrontierRec>(), s);
     }
-    std::vector<unsigned long long> h(W);
-    IMPG_HIP(hipMemcpyAsync(h.data(), route_hist.p, (size_t)W * 8, hipMemcpyDeviceToHost, s));
+    pinned_words(W);
+    unsigned long long *h = h_hist(W);
+    IMPG_HIP(hipMemcpyAsync(h, route_hist.p, (size_t)W * 8, hipMemcpyDeviceToHost, s));
     IMPG_HIP(hipStreamSynchronize(s));
     for (uint32_t k = 0; k < W; k++) counts[k] = h[k];
   }
@@ -199,16 +216,11 @@ struct ShardedExpander : Expander {
     std::exception_ptr deferred;  // an owner-side failure waits for the all-gather below, where every rank learns of it
     try {
     if (fail_owner_hop && hop_no == fail_owner_hop) throw Error{IMPG_E_INVALID, "injected failure (owner side)"};
-    if ((size_t)(W + 1) * 8 > h_cap) {
-      if (h_vals) (void)hipHostFree(h_vals);
-      h_cap = std::max<size_t>((size_t)(W + 1) * 8, 4096);
-      IMPG_HIP(hipHostMalloc((void **)&h_vals, h_cap, hipHostMallocDefault));
-    }
+    pinned_words((uint32_t)W);
     // A counting hop (nobody at home reads rows) lets the owner lay its slots out in its own lookup order, home rank
     // by home rank: the cheaper lookup and projection of Engine::free_slot_order.  Home puts the runs back in
     // frontier order whatever order they come in (reorder_runs), so nothing else changes.
     const bool owner_order = E.free_slot_order && !need_rows && !E.multi;
-    std::vector<uint32_t> hb((size_t)W + 1);
     if (owner_order) d_bounds.reserve(std::max<size_t>(((size_t)W + 1) * 4, 256));
     uint64_t a = 0, step = std::max<uint64_t>(n_recv, 1);
     while (a < n_recv) {
@@ -218,8 +230,11 @@ struct ShardedExpander : Expander {
       const FrontierRec *sub = recv_fr.as<FrontierRec>() + a;
       Engine::RecordBlocks blocks{nullptr, (uint32_t)W};
       if (owner_order) {  // the slice's records by home rank: block r = [hb[r], hb[r+1])
-        for (int r = 0; r <= W; r++) hb[r] = (uint32_t)(std::min(std::max(rstart[r], a), a + m) - a);
-        IMPG_HIP(hipMemcpy(d_bounds.p, hb.data(), ((size_t)W + 1) * 4, hipMemcpyHostToDevice));
+        // (through a pinned slot, stream-ordered; a hop rarely has more than one slice: when the slots run out, wait)
+        if (bound_slot == BOUND_SLOTS) { IMPG_HIP(hipStreamSynchronize(s)); bound_slot = 0; }
+        uint32_t *hbp = h_bounds((uint32_t)W, bound_slot++);
+        for (int r = 0; r <= W; r++) hbp[r] = (uint32_t)(std::min(std::max(rstart[r], a), a + m) - a);
+        IMPG_HIP(hipMemcpyAsync(d_bounds.p, hbp, ((size_t)W + 1) * 4, hipMemcpyHostToDevice, s));
         blocks.d_bounds = d_bounds.as<uint32_t>();
       }
       try {
@@ -389,9 +404,10 @@ struct ShardedExpander : Expander {
         IMPG_HIP(hipMemsetAsync(E.counters.as<unsigned long long>() + 4, 0, 8, s));
         uint32_t *err = reinterpret_cast<uint32_t *>(E.counters.as<unsigned long long>() + 4);
         launch_reorder_runs(hits_in.as<uint32_t>(), (uint32_t)n_home, words, n_fr, E.lo_key.as<uint32_t>(), E.lo_cnt.as<uint32_t>(), err, s);
+        pinned_words((uint32_t)W);
+        IMPG_HIP(hipMemcpyAsync(h_err((uint32_t)W), err, 4, hipMemcpyDeviceToHost, s));  // (read under the scan's own synchronisation)
         const uint64_t total = E.scan(E.lo_cnt.as<uint32_t>(), E.lo_off.as<uint32_t>(), n_fr);
-        uint32_t bad = 0;
-        IMPG_HIP(hipMemcpy(&bad, err, 4, hipMemcpyDeviceToHost));
+        const uint32_t bad = *h_err((uint32_t)W);
         if (bad || total != n_home) throw Error{IMPG_E_INVALID, "hits came home for a frontier record twice or out of range"};
         launch_hits_unpack(hits_in.p, (uint32_t)n_home, words, n_fr, E.lo_key.as<uint32_t>(), E.lo_off.as<uint32_t>(),
                            L.pair_range.as<uint32_t>(), h, E.multi ? mslot.as<uint32_t>() : nullptr, s, slice_at, slice_pos, slice_n);
@@ -465,10 +481,12 @@ struct LaneWork {  // what one lane accumulates
 // its chunks unmasked and unfiltered.  Found by scripts/fuzz_parity.py, seed 72686, 4 ranks x 2 lanes.)
 // Ranges per chunk of this rank's part of a batch.  Without the option the batch is cut so that every lane has work
 // (lanes only overlap exchange and compute across chunks) and no chunk outgrows the 32-bit slot counts of a hop.
+// 50 000 ranges is the plain engine's chunk: what an owner expands in one hop is, summed over the homes, about one
+// chunk's worth, and every chunk pays its hops' fixed costs (25 000: 74.8 ms per headline step on one rank, 50 000: 69.8).
 size_t shard_chunk(const impg_gpu_index &ix, size_t n) {
   if (ix.opt_chunk_ranges) return ix.opt_chunk_ranges;
   const size_t lanes = std::max<size_t>(1, ix.shard->comm->lanes.size());
-  return std::min<size_t>(25000, std::max<size_t>(1, (n + lanes - 1) / lanes));
+  return std::min<size_t>(50000, std::max<size_t>(1, (n + lanes - 1) / lanes));
 }
 template <class P, class F> void run_lanes(impg_gpu_index &ix, size_t n, P prep, F body) {
   ShardCtx &S = *ix.shard;

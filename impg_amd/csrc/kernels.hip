@@ -401,8 +401,59 @@ __global__ __launch_bounds__(256) void scatter_u32_kernel(const uint32_t *__rest
 // sorted runs in LDS so that the stores stay coalesced.  Needs ranks < 2^26.
 // ---------------------------------------------------------------------------
 constexpr uint32_t EMIT_LDS_SLOTS = 64u * 64u;  // a lane emits at most 64 pairs
+// N = the network's size (a power of two), W <= N = the places that can hold a key
+template <uint32_t N, uint32_t W>
+__device__ __forceinline__ void emit_sort(uint32_t (&key)[64]) {
+#pragma unroll
+  for (uint32_t p = 1; p < N; p <<= 1) {
+#pragma unroll
+    for (uint32_t k = p; k >= 1; k >>= 1) {
+#pragma unroll
+      for (uint32_t j = k % p; j + k <= N - 1; j += 2 * k) {
+#pragma unroll
+        for (uint32_t i = 0; i <= min(k - 1, N - j - k - 1); i++) {
+          const uint32_t a = i + j, b = i + j + k;
+          if (a / (2 * p) == b / (2 * p) && b < W) {
+            // one compare-exchange = v_max_u32 + v_min_u32.  A volatile asm pair so that the exchanges stay in program
+            // order: left to itself the scheduler interleaves a whole stage and keeps its inputs and outputs live
+            // together (140 VGPRs, 3 waves per SIMD).  The minimum replaces its first input in place, the maximum
+            // takes the one new register, and the second input's register is free again.
+            uint32_t mn = key[a], mx;
+            asm volatile("v_max_u32 %1, %0, %2\n\tv_min_u32 %0, %0, %2" : "+v"(mn), "=&v"(mx) : "v"(key[b]));
+            key[a] = mn;
+            key[b] = mx;
+          }
+        }
+      }
+    }
+  }
+}
+template <uint32_t N, uint32_t W>
+__device__ __forceinline__ void emit_keys_sort_stage(const uint32_t *__restrict__ rank, uint32_t b, uint32_t lo, uint32_t ub,
+                                                     unsigned long long mask, uint32_t c, uint32_t loff, uint32_t lane, uint16_t *stage) {
+  uint32_t key[64];
+#pragma unroll
+  for (uint32_t q = 0; q < (W + 3u) / 4u; q++) {
+    uint4 rk = make_uint4(0, 0, 0, 0);
+    if (b + 4u * q < ub) rk = *reinterpret_cast<const uint4 *>(rank + b + 4u * q);
+    const uint32_t rv[4] = {rk.x, rk.y, rk.z, rk.w};
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++) {
+      const uint32_t i = 4u * q + t, pos = b + i;
+      const bool hit = pos >= lo && pos < ub && ((mask >> ((pos - lo) & 63u)) & 1ull);
+      key[i] = hit ? (rv[t] << 6) | i : 0xFFFFFFFFu;
+    }
+    if ((q & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);  // four rank vectors in flight at a time, not sixteen
+  }
+  emit_sort<N, W>(key);
+#pragma unroll
+  for (uint32_t k = 0; k < W; k++) {
+    if (__ballot(k < c) == 0ull) break;
+    if (k < c) stage[loff + k] = (uint16_t)((lane << 6) | (key[k] & 63u));
+  }
+}
 template <bool TRANSITIVE>
-__global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v, uint32_t n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void lookup_emit_lane_kernel(DeviceIndexView v, uint32_t n,
                                                               const uint32_t *__restrict__ pair_off,
                                                               const uint4 *__restrict__ win,
                                                               uint32_t *__restrict__ pair_range,
@@ -429,42 +480,14 @@ __global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v,
   const uint32_t b = lo & ~3u;
   const bool mine = lo < ub && ub - b <= 64u;  // wider windows belong to the wave-per-range kernel
   if (!mine) { ub = b; mask = 0; }
-  uint32_t key[64];
+  // The widest window of the wave picks the network: Batcher's odd-even merge sort, whose comparators all put the
+  // smaller key at the lower index -- so with +inf beyond that width those places never change, and every comparator
+  // that touches one is dropped at compile time: 543 exchanges for 64 places, 384 for 48, 305 for 40, 191 for 32 (the
+  // bitonic network this replaces: 672 whatever the width).
+  uint32_t wmax = mine ? ub - b : 0u;
 #pragma unroll
-  for (uint32_t q = 0; q < 16; q++) {
-    uint4 rk = make_uint4(0, 0, 0, 0);
-    if (b + 4u * q < ub) rk = *reinterpret_cast<const uint4 *>(v.rank + b + 4u * q);
-    const uint32_t rv[4] = {rk.x, rk.y, rk.z, rk.w};
-#pragma unroll
-    for (uint32_t t = 0; t < 4; t++) {
-      const uint32_t i = 4u * q + t, pos = b + i;
-      const bool hit = pos >= lo && pos < ub && ((mask >> ((pos - lo) & 63u)) & 1ull);
-      key[i] = hit ? (rv[t] << 6) | i : 0xFFFFFFFFu;
-    }
-    if ((q & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);  // four rank vectors in flight at a time, not sixteen
-  }
-  // bitonic network over the 64 registers, ascending (ranks of hits are distinct)
-#pragma unroll
-  for (uint32_t k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-      for (uint32_t i = 0; i < 64; i++) {
-        const uint32_t l = i ^ j;
-        if (l > i) {
-          // one compare-exchange = v_min_u32 + v_max_u32.  Written as a volatile asm pair so that the 672
-          // exchanges stay in program order: left to itself the scheduler interleaves a whole stage and keeps
-          // its 64 inputs and 64 outputs live together (140 VGPRs, 3 waves per SIMD).
-          // (the minimum replaces its first input in place; the maximum takes the one new register, and the
-          //  second input's register is free again)
-          uint32_t mn = key[i], mx;
-          asm volatile("v_max_u32 %1, %0, %2\n\tv_min_u32 %0, %0, %2" : "+v"(mn), "=&v"(mx) : "v"(key[l]));
-          key[i] = (i & k) == 0 ? mn : mx;
-          key[l] = (i & k) == 0 ? mx : mn;
-        }
-      }
-    }
-  }
+  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
+  wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
   const uint32_t c = (uint32_t)__popcll(mask);
   // LDS offsets of the lanes' runs: exclusive scan of c over the wave
   uint32_t inc = c;
@@ -475,11 +498,12 @@ __global__ __launch_bounds__(64) void lookup_emit_lane_kernel(DeviceIndexView v,
   }
   const uint32_t loff = inc - c;
   const uint32_t total = (uint32_t)__shfl((int)inc, 63);
-#pragma unroll
-  for (uint32_t k = 0; k < 64; k++) {
-    if (__ballot(k < c) == 0ull) break;
-    if (k < c) stage[loff + k] = (uint16_t)((lane << 6) | (key[k] & 63u));
-  }
+  // (each width loads, sorts AND stages inside its own branch: no key register is live where the branches part or
+  // meet, which pins all 64 of them to the same registers on every path -- 140 VGPRs instead of 93)
+  if (wmax <= 32u) emit_keys_sort_stage<32, 32>(v.rank, b, lo, ub, mask, c, loff, lane, stage);
+  else if (wmax <= 40u) emit_keys_sort_stage<64, 40>(v.rank, b, lo, ub, mask, c, loff, lane, stage);
+  else if (wmax <= 48u) emit_keys_sort_stage<64, 48>(v.rank, b, lo, ub, mask, c, loff, lane, stage);
+  else emit_keys_sort_stage<64, 64>(v.rank, b, lo, ub, mask, c, loff, lane, stage);
   __syncthreads();
   for (uint32_t tb = 0; tb < total; tb += 64u) {  // every lane takes part in the cross-lane reads
     const uint32_t t = tb + lane;
@@ -916,10 +940,12 @@ __device__ __forceinline__ bool pfx_eval(const PairCtx &c, const PfxTile &t, uin
 struct PfxOp { uint32_t j, k; int32_t adj; };
 template <bool NEXT>
 __device__ __forceinline__ bool pfx_end(const PairCtx &c, const uint32_t *__restrict__ pfx_rec, uint32_t n_ops, uint32_t j,
-                                        int32_t thr_abs, bool first_form, int32_t &oq, int32_t &ot, PfxOp &which) {
-  for (;;) {
+                                        int32_t thr_abs, bool first_form, int32_t &oq, int32_t &ot, PfxOp &which, uint4 h0) {
+  for (bool fresh = true;; fresh = false) {
     const uint32_t *line = pfx_rec + (size_t)j * TILE_WORDS;
-    uint4 h = *reinterpret_cast<const uint4 *>(line);  // T0 | wide << 31, Q0, entry 9, entry 18
+    // T0 | wide << 31, Q0, entry 9, entry 18: the first tile's header is handed in (the caller requests both ends' headers together)
+    uint4 h = h0;
+    if (!fresh) h = *reinterpret_cast<const uint4 *>(line);
     // (one 16-byte read: without the pin the compiler reads word 0 alone, tests the flag, and only then the rest)
     asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w));
     const bool wide = (h.x >> 31) != 0u;
@@ -1126,15 +1152,22 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
           // first / last op)
           PfxOp lo_op{0u, 0u, 0}, hi_op{c.m - 1u, n - (c.m - 1u) * TILE_OPS - 1u, 0};
           const bool lo_edge = c.flip ? !do_last : !do_first;
-          if (!lit && (c.flip ? do_last : do_first)) {
+          // both ends' line headers in one round trip, ahead of the searches that depend on them
+          const bool run1 = !lit && (c.flip ? do_last : do_first), run2 = !lit && (c.flip ? do_first : do_last);
+          const uint32_t j1 = orig_tile(c, c.flip ? kL : kA), j2 = orig_tile(c, c.flip ? kA : kL);
+          uint4 hd1 = make_uint4(0u, 0u, 0u, 0u), hd2 = make_uint4(0u, 0u, 0u, 0u);
+          if (run1) hd1 = *reinterpret_cast<const uint4 *>(pfx_rec + (size_t)j1 * TILE_WORDS);
+          if (run2) hd2 = *reinterpret_cast<const uint4 *>(pfx_rec + (size_t)j2 * TILE_WORDS);
+          asm volatile("" : "+v"(hd1.x), "+v"(hd1.y), "+v"(hd1.z), "+v"(hd1.w), "+v"(hd2.x), "+v"(hd2.y), "+v"(hd2.z), "+v"(hd2.w));
+          if (run1) {
             int32_t oq, ot;
-            const bool okc = pfx_end<true>(c, pfx_rec, n, orig_tile(c, c.flip ? kL : kA), c.flip ? (int32_t)c.totT - xb : xa, !c.flip, oq, ot, lo_op);
+            const bool okc = pfx_end<true>(c, pfx_rec, n, j1, c.flip ? (int32_t)c.totT - xb : xa, !c.flip, oq, ot, lo_op, hd1);
             lit = !okc;
             if (c.flip) { lq = oq; lt = ot; } else { fq = oq; ft = ot; }
           }
-          if (!lit && (c.flip ? do_first : do_last)) {
+          if (run2 && !lit) {
             int32_t oq, ot;
-            const bool okc = pfx_end<false>(c, pfx_rec, n, orig_tile(c, c.flip ? kA : kL), (c.flip ? (int32_t)c.totT - xa : xb) + 1, c.flip, oq, ot, hi_op);
+            const bool okc = pfx_end<false>(c, pfx_rec, n, j2, (c.flip ? (int32_t)c.totT - xa : xb) + 1, c.flip, oq, ot, hi_op, hd2);
             lit = !okc;
             if (c.flip) { fq = oq; ft = ot; } else { lq = oq; lt = ot; }
           }

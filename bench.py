@@ -223,7 +223,11 @@ def main():
     # HBM bytes per projection measured with rocprofv3 PMC passes of this same command
     # (scripts/profile_r1.sh -> profiles/r1_v2_traffic.json; FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
     traffic = None
-    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))  # newest build last
+    # the counters of THIS workload's profile (headline: r*_final_*; config 4 / 5: r*_config4_* / r*_config5_*), and only when
+    # the run is the profiled configuration -- another index size or the identity filter moves other bytes per pair
+    tag = "final" if wl == "headline" else wl
+    profiled = args.min_identity is None and args.records == (50_000_000 if wl == "config4" else 1_000_000)
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % tag))) if profiled else []  # newest round last
     tpath = tfiles[-1] if tfiles else ""
     if os.path.exists(tpath) and launches:
         with open(tpath) as f:
@@ -265,7 +269,7 @@ def main():
         "argv": sys.argv[1:],
         "index_build_s": t_build,
         "index_bytes": index.device_bytes(),
-        "roofline": roofline(stats, ach, traffic, tpath, ms_project, launches),
+        "roofline": roofline(stats, ach, traffic, tpath, ms_project, launches, tag if profiled else None),
     }
     if world == 1 and not args.no_extras:
         out["full_results"] = full_results_leg(index, ranges, params)
@@ -283,7 +287,7 @@ def main():
 SIMDS = 256 * 4
 
 
-def roofline(stats, ach, traffic, tpath, ms_project, launches):
+def roofline(stats, ach, traffic, tpath, ms_project, launches, tag):
     """The contractual HBM accounting (856 algorithmic bytes per projection) next to what the memory
     system and the issue ports actually did for project_kernel: measured HBM traffic as a fraction of peak
     (profiles/r*_traffic.json) and the VALU-issue fraction (profiles/r*_sq.json: SQ_INSTS_VALU x the measured cost of
@@ -307,7 +311,7 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches):
     tgbs = (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms) else None
     r["achieved_traffic_GBs"] = tgbs
     r["measured_traffic_frac"] = (tgbs / HBM_PEAK_GBS) if tgbs else None
-    sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_sq.json"))) or sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq.json")))
+    sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_sq.json" % tag))) if tag else []
     vf = None
     if sq:
         with open(sq[-1]) as f:
@@ -325,7 +329,7 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches):
     if mf is not None and vf is not None:
         r["bound"] = "hbm" if mf >= 0.6 else ("valu-issue" if vf >= 0.75 else "latency (HBM at %.2f, VALU issue at %.2f of their peaks)" % (mf, vf))
     else:
-        r["bound"] = "unmeasured (no PMC summaries under profiles/)"
+        r["bound"] = "unmeasured (no PMC summaries of this configuration under profiles/)"
     r["contract_bound"] = "hbm"
     r["limiter"] = ("project_kernel on the headline index is bound by neither roofline: HBM moves measured_traffic_frac of 8 TB/s (the pairs of "
                     "a level revisit the same 2.7 GB ~60 times and mostly hit L2), the vector ALUs issue valu_issue_frac of their slots. What is "

@@ -171,6 +171,15 @@ struct DevBuf {
     size_t tc = cap; cap = o.cap; o.cap = tc;
     BufPool *tq = pool; pool = o.pool; o.pool = tq;
   }
+  // Take over o's block together with o's way of freeing it; o is left empty but keeps allocating as before.  (swap()
+  // exchanges the pools too: right between two buffers of one owner, wrong when one of them outlives the other's pool
+  // user -- a lane's receive buffer swapped with a level's pooled one kept using an engine's pool after the engine
+  // had gone to another lane.)
+  void adopt(DevBuf &o) {
+    release();
+    p = o.p; cap = o.cap; pool = o.pool;
+    o.p = nullptr; o.cap = 0;
+  }
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
   ~DevBuf() { release(); }
   DevBuf() = default;

@@ -392,7 +392,7 @@ struct ShardedExpander : Expander {
       slice_at = E.gid.as<uint32_t>();
       slice_pos = L.sl_a.as<uint32_t>();  // (kept in sl_a while the five-key sort may still permute the slots)
       slice_n = L.sl_n.as<uint32_t>();
-      L.slice_pool.swap(ops_in);
+      L.slice_pool.adopt(ops_in);  // (not swap: ops_in belongs to the lane and must not inherit the engine's buffer pool)
     }
     SliceArrays home_sl{nullptr, nullptr, nullptr, nullptr};
     if (ship_ops) home_sl = SliceArrays{L.sl_a.as<uint32_t>(), L.sl_n.as<uint32_t>(), L.sl_off.as<int32_t>(), L.sl_rem.as<int32_t>()};

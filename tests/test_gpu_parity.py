@@ -255,6 +255,18 @@ def test_min_gap_compressed_identity(tmp_path, seed, weird, max_ops):
         assert_same(g, c, ranges[:50], transitive=True, max_depth=3, min_transitive_len=30, min_identity=thr)
 
 
+@pytest.mark.parametrize("n", [150, 380, 470, 560, 700, 950])
+def test_visit_order_network_widths(tmp_path, n):
+    """lookup_emit_lane sorts a window's hits into visit order with a network pruned to the wave's widest window (32 / 40 /
+    48 / 64 places, kernels.hip emit_sort): coverage swept so that the windows pass through every width and into the
+    wave-per-range kernel beyond 64."""
+    text, names = random_paf(300 + n, n, n_seq=2, seq_len=40000, max_ops=120, self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(n, 300, 2, 40000, max_len=1000)
+    assert_same(g, c, ranges)
+    assert_same(g, c, ranges[:80], transitive=True, max_depth=2, min_transitive_len=30)
+
+
 def test_identity_threshold_on_the_border(tmp_path):
     """Thresholds equal to a hit's own identity and its two neighbouring doubles: the kernel decides most pairs by a
     comparison with slack and only borderline ones by the division (kernels.hip, project_pair) -- these are the borderline ones."""

@@ -287,3 +287,8 @@ def test_lane_schedules_enumerated(tmp_path, world, lanes):
             for (r, kw, m, k), w in zip(batches, wants):
                 got = g.query_batch(r, impg_amd.make_params(**kw), masked_regions=m, subset_keep=k)
                 assert [got[i].tolist() for i in range(len(r))] == w, (v, rep, kw)
+            # store_cigar under the same hand-overs: the ops that came home live in a buffer that the level adopts from
+            # the lane (a swap once handed the lane a block of the ENGINE's pool, which the next lane to hold that engine
+            # also allocated from: wrong ops in one run out of five of test_multi_handle_matches_oracle[5-3])
+            check_cigars(g, c, rl2, transitive=True, dfs=True, max_depth=2, min_transitive_len=100)
+            check_cigars(g, c, rl2, transitive=True, max_depth=2, min_transitive_len=100)

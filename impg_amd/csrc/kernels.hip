@@ -1778,13 +1778,14 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
 // lists of a wave never share a bank) and written out once at the end; longer ones are worked on in place.
 constexpr uint32_t VU_LDS_CAP = 16;
 // groups whose list can outgrow this get a whole wave (visited_update_wave_kernel below)
-// two sizes of LDS working set (8 KB: 20 waves per CU; 32 KB: 5): groups with few hits and a short list take the small one
+// two sizes of LDS working set (9 KB: 17 waves per CU; 32 KB: 5): groups with few hits and a short list take the small one
 #ifndef IMPG_VW_TINY
 #define IMPG_VW_TINY 512
 #endif
 #ifndef IMPG_VW_SMALL
-#define IMPG_VW_SMALL 1024
-#endif
+#define IMPG_VW_SMALL 1152  // 9 KB, 17 waves per CU.  With the isolated hits of a batch going in together (replay_hits_wave), config 5
+#endif                      // (4 000 windows, update ms): 1 024 entries 997 -- 85 % of the deepest level's groups end at ~1 030 ranges and
+                            // finish their replay in global memory at four times the cost per hit --, 1 152: 924, 1 280: 1 012, 1 536: 1 103
 #ifndef IMPG_VW_TINY_HEADROOM
 #define IMPG_VW_TINY_HEADROOM 1000000  // the tiny tier is OFF: measured on config 5 (4 000 windows, update ms): one 1 024-entry tier 1 323;
 #endif                                 // 1 536 entries 1 595; 2 048 entries 1 902 (fewer waves per CU); + a 768-entry tier for short lists 1 610,
@@ -2022,6 +2023,8 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
                                                      uint32_t &t_next, uint32_t list_cap) {
   const bool writer = lane_id() == 0;
   const uint32_t lane = lane_id();
+  __shared__ uint32_t iso_point[64];
+  const int32_t iso_margin = max(mdbr, 0) + 1;
   uint32_t t0 = t_next;
   for (; t0 < n; t0 += 64u) {
     if (len + 64u > list_cap) break;  // (a batch adds at most 64 ranges: the caller moves the list somewhere bigger)
@@ -2030,23 +2033,82 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
     // a saturating closure are almost all such hits: every lane tests one hit of the batch against the list as it
     // stands, and only the others take their turn in the sequential replay below.
     unsigned long long todo;
+    int32_t rs = 0, re = 0;  // this lane's hit of the batch (the sequential part below reads them lane to lane)
     {
-      bool need = false;
+      bool need = false, cand = false;
+      uint32_t p0 = 0;
       if (t0 + lane < n) {
         const unsigned long long iv = svals[st + t0 + lane];
-        const int32_t s0 = max((int32_t)(uint32_t)(iv >> 32), 0), e0 = min((int32_t)(uint32_t)iv, sequence_length);
-        const uint32_t p0 = list_lower_bound(R, len, s0);
+        rs = (int32_t)(uint32_t)(iv >> 32); re = (int32_t)(uint32_t)iv;
+        const int32_t s0 = max(rs, 0), e0 = min(re, sequence_length);
+        p0 = list_lower_bound(R, len, s0);
         // (a hit that the clamps leave empty or inverted -- a length-0 set of a masked batch -- takes the literal path)
         const bool covered = s0 < e0 && ((p0 < len && R.x(p0) == s0 && R.y(p0) >= e0) || (p0 > 0 && R.y(p0 - 1) >= e0));
         need = !covered;
+        // Isolated hits.  A hit that no clamp touches and that lies farther than the merge distance from every range of
+        // the list and from every other hit of the batch still to be replayed interacts with nothing: whenever its turn
+        // comes, both distance tests pass (impg.rs:2513-2545), its walk meets no range and emits the hit itself as one
+        // piece (:314-328), and the insert neither extends nor merges anything (:330-343) -- and it changes none of that
+        // for the others.  Such hits of a batch go into the list together, one pass over the list instead of one
+        // shift each: at depth 4-5 of a saturating closure half the hits are such inserts into lists of ~1 000 ranges.
+        cand = need && rs >= 0 && re <= sequence_length && rs < re && (p0 == 0 || R.y(p0 - 1) < rs - iso_margin) &&
+               (p0 == len || R.x(p0) > re + iso_margin);
       }
       todo = __ballot(need);
+      unsigned long long iso = 0ull;
+      if (__ballot(cand) != 0ull) {
+        for (unsigned long long left = todo; left; left &= left - 1ull) {
+          const uint32_t j = (uint32_t)__ffsll((long long)left) - 1u;
+          const int32_t sj = __builtin_amdgcn_readlane(rs, j), ej = __builtin_amdgcn_readlane(re, j);
+          if (j != lane && sj - iso_margin <= re + iso_margin && rs - iso_margin <= ej + iso_margin) cand = false;
+        }
+        iso = __ballot(cand);
+      }
+      if (__popcll(iso) >= 2) {
+        const uint32_t k = (uint32_t)__popcll(iso);
+        uint32_t rank = 0;
+        for (unsigned long long left = iso; left; left &= left - 1ull) {
+          const uint32_t j = (uint32_t)__ffsll((long long)left) - 1u;
+          rank += __builtin_amdgcn_readlane(rs, j) < rs ? 1u : 0u;
+        }
+        // their pieces (any order: the pieces are sorted afterwards)
+        const bool emit = cand && re - rs >= min_transitive_len;
+        const unsigned long long em = __ballot(emit);
+        if (emit) P[np + (uint32_t)__popcll(em & lanemask_lt())] = make_int2(rs, re);
+        np += (uint32_t)__popcll(em);
+        // lane r takes the insertion point of the new range of rank r (ascending with r: the list is sorted too)
+        __syncthreads();  // (iso_point may still be read by the previous batch)
+        if (cand) iso_point[rank] = p0;
+        __syncthreads();
+        const uint32_t ps = lane < k ? iso_point[lane] : 0xFFFFFFFFu;
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)ps);  // ranges before it stay where they are
+        // every range moves up by the number of new ranges that go in at or before it, from the top of the list down:
+        // those below the chunk in one ballot, those inside it one by one (a couple per chunk)
+        for (uint32_t top = len; top > first;) {
+          const uint32_t base = top > first + 64u ? top - 64u : first;
+          const uint32_t i = base + lane;
+          const bool on = i < top;
+          int32_t vx = 0, vy = 0;
+          if (on) { vx = R.x(i); vy = R.y(i); }
+          uint32_t c = (uint32_t)__popcll(__ballot(ps <= base));
+          for (unsigned long long in = __ballot(ps > base && ps < top); in; in &= in - 1ull)
+            c += (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)(__ffsll((long long)in) - 1)) <= i ? 1u : 0u;
+          order_point(R);
+          if (on) { R.x(i + c) = vx; R.y(i + c) = vy; }
+          order_point(R);
+          top = base;
+        }
+        if (cand) { R.x(p0 + rank) = rs; R.y(p0 + rank) = re; }
+        order_point(R);
+        len += k;
+        todo &= ~iso;
+      }
     }
     while (todo) {
-    const uint32_t t = t0 + (uint32_t)__ffsll((long long)todo) - 1u;
+    const uint32_t tl = (uint32_t)__ffsll((long long)todo) - 1u;
     todo &= todo - 1ull;
-    const unsigned long long iv = svals[st + t];
-    int32_t start = (int32_t)(uint32_t)(iv >> 32), end = (int32_t)(uint32_t)iv;
+    // (from the lane that loaded it: a second read of svals here was a global-memory round trip per replayed hit)
+    int32_t start = __builtin_amdgcn_readlane(rs, tl), end = __builtin_amdgcn_readlane(re, tl);
     uint32_t pos = wave_lower_bound(R, len, start);
     if (mdbr > 0) {  // impg.rs:2513-2545
       bool should_add = true;

@@ -137,7 +137,7 @@ bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges
   const size_t slab = walk_slab_bytes(ix.view.n_seq, wide, a.wcap, a.hcap, a.vcap, a.gcap, a.scap);
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix.device);
-  const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n, wide ? SMALL_RANGES : (uint64_t)cus * 16u);  // (4096 slabs of ~2.5 MB: a wave per query, latency-bound, wants every wave slot it can get)
+  const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n, wide ? SMALL_RANGES : (uint64_t)cus * 4u * WALK_WAVES_PER_SIMD);  // (slabs of ~2.5 MB: a wave per query, latency-bound, wants every wave slot it can get)
   walk_slabs.reserve(slab * n_wg);
   walk_ctr.reserve(256);
   ev_next = 0;

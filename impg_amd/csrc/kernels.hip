@@ -3261,9 +3261,9 @@ void launch_walk(const WalkArgs &a, uint32_t n_workgroups, bool wide, bool ident
     else if (ident_mode) walk_kernel<16, 4096, MODE_IDENT><<<n_workgroups, 1024, 0, s>>>(a);
     else walk_kernel<16, 4096, 0><<<n_workgroups, 1024, 0, s>>>(a);
   } else {
-    if (ident_mode && !a.v.pfx) walk_kernel<1, 256, MODE_IDENT | MODE_WALK><<<n_workgroups, 64, 0, s>>>(a);
-    else if (ident_mode) walk_kernel<1, 256, MODE_IDENT><<<n_workgroups, 64, 0, s>>>(a);
-    else walk_kernel<1, 256, 0><<<n_workgroups, 64, 0, s>>>(a);
+    if (ident_mode && !a.v.pfx) walk_wave_kernel<256, MODE_IDENT | MODE_WALK><<<n_workgroups, 64, 0, s>>>(a);
+    else if (ident_mode) walk_wave_kernel<256, MODE_IDENT><<<n_workgroups, 64, 0, s>>>(a);
+    else walk_wave_kernel<256, 0><<<n_workgroups, 64, 0, s>>>(a);
   }
 }
 }  // namespace impg

@@ -214,6 +214,10 @@ struct WalkArgs {
 size_t walk_slab_bytes(uint32_t n_seq, bool wide, uint32_t wcap, uint32_t hcap, uint32_t vcap, uint32_t gcap, uint32_t scap);
 // wide: 16 waves per workgroup (a handful of queries, latency) instead of one (a batch, throughput); ident_mode: the
 // projections take the identity filter's path (a filter is set, or the index has no prefix lines)
+#ifndef IMPG_WALK_WAVES
+#define IMPG_WALK_WAVES 6  // 100 000-range DFS batch: 4 waves per SIMD (101 VGPRs, what the compiler takes unasked) 4.22 s, 5: 3.80, 6: 3.66, 8: 3.68
+#endif
+constexpr uint32_t WALK_WAVES_PER_SIMD = IMPG_WALK_WAVES;  // resident waves per SIMD the one-wave-per-query walk is compiled for
 void launch_walk(const WalkArgs &a, uint32_t n_workgroups, bool wide, bool ident_mode, hipStream_t s);
 
 }  // namespace impg

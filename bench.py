@@ -370,12 +370,16 @@ def dfs_batch_leg(index, ranges, max_depth):
     import impg_amd
     n = min(10_000, len(ranges))
     p = impg_amd.make_params(transitive=True, dfs=True, max_depth=max_depth)
-    index.query_batch_stats(ranges[:64], p, counts=False, checksums=False)  # (slabs allocated)
-    t0 = time.perf_counter()
-    st, _, _ = index.query_batch_stats(ranges[:n], p, counts=False, checksums=False)
-    dt = time.perf_counter() - t0
+    # two calls: the first allocates the per-wave slabs of the walk (15 GB for a batch that fills the device's wave slots),
+    # the second is a process that has served a DFS batch before
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        st, _, _ = index.query_batch_stats(ranges[:n], p, counts=False, checksums=False)
+        times.append(time.perf_counter() - t0)
+    dt = times[-1]
     return {"workload": "first %d ranges, --transitive-dfs -m %d, counting form" % (n, max_depth), "projected": st.projected, "seconds": dt,
-            "projected_per_s": st.projected / dt if dt > 0 else None}
+            "first_call_seconds": times[0], "projected_per_s": st.projected / dt if dt > 0 else None}
 
 
 def spawn_ranks(n):

@@ -1776,7 +1776,10 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
 // The list is searched three times and shifted once per hit, every step a dependent access: lists of at most
 // VU_LDS_CAP ranges (nearly all of them) are kept in LDS while they are worked on (lane-interleaved, so the 64
 // lists of a wave never share a bank) and written out once at the end; longer ones are worked on in place.
-constexpr uint32_t VU_LDS_CAP = 16;
+#ifndef IMPG_VU_LDS_CAP
+#define IMPG_VU_LDS_CAP 16
+#endif
+constexpr uint32_t VU_LDS_CAP = IMPG_VU_LDS_CAP;
 // groups whose list can outgrow this get a whole wave (visited_update_wave_kernel below)
 // two sizes of LDS working set (9 KB: 17 waves per CU; 32 KB: 5): groups with few hits and a short list take the small one
 #ifndef IMPG_VW_TINY

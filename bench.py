@@ -51,8 +51,10 @@ def main():
     ap.add_argument("--max-depth", type=int, default=None)
     ap.add_argument("--no-transitive", action="store_true")
     ap.add_argument("--chunk-ranges", type=int, default=None,
-                    help="ranges per chunk (default 50000, on one GPU and per rank on a sharded index)")
-    ap.add_argument("--pair-budget", type=int, default=1 << 30)
+                    help="ranges per chunk (default: the whole batch on one GPU, 50000 per rank on a sharded index)")
+    ap.add_argument("--pair-budget", type=int, default=None,
+                    help="hit slots a level of a chunk may fill (default 3 x 2^30 on one GPU: the headline batch runs as one chunk, "
+                         "85 GB of slot arrays on a 288 GB device; 2^30 on a sharded index)")
     ap.add_argument("--cpu-sample", type=int, default=1000, help="ranges timed on the CPU oracle, ~15 s of CPU work (0 = skip)")
     ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=VALUE",
                     help="impg_gpu_set_option before the run (timing comparisons, e.g. locality_min=0)")
@@ -94,8 +96,14 @@ def main():
         args.ranges = 200_000 if wl == "config5" else 100_000
     if args.max_depth is None:
         args.max_depth = 5 if wl == "config5" else 3
+    sharded_run = args.gpus > 1 or args.force_sharded
     if args.chunk_ranges is None:
-        args.chunk_ranges = 500 if wl == "config5" else 50000
+        # one GPU: the whole batch in one chunk (2.1e9 slots a level; every level's fixed costs paid once: 61.7 -> 59.5 ms per
+        # step against two chunks of 50 000); a sharded index: two chunks per rank, one per lane, so that a lane's exchange
+        # overlaps the other's kernels
+        args.chunk_ranges = 500 if wl == "config5" else (50000 if sharded_run else max(50000, args.ranges))
+    if args.pair_budget is None:
+        args.pair_budget = (1 << 30) if (sharded_run or wl == "config5") else (3 << 30)
     if wl != "headline":
         args.cpu_sample, args.no_extras = 0, True  # the CPU and full-results legs belong to the headline line
 

@@ -2039,7 +2039,8 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
     int32_t rs = 0, re = 0;  // this lane's hit of the batch (the sequential part below reads them lane to lane)
     {
       bool need = false, cand = false;
-      uint32_t p0 = 0;
+      uint32_t p0 = 0, q = 0, ext = 0;  // ext: 1 / 2 = the hit grows the one range q (see below)
+      int32_t flo = 0, fhi = 0, xq = 0, yq = 0;  // the stretch nothing else may come near: the hit (and its range) plus the margin
       if (t0 + lane < n) {
         const unsigned long long iv = svals[st + t0 + lane];
         rs = (int32_t)(uint32_t)(iv >> 32); re = (int32_t)(uint32_t)iv;
@@ -2054,18 +2055,67 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
         // piece (:314-328), and the insert neither extends nor merges anything (:330-343) -- and it changes none of that
         // for the others.  Such hits of a batch go into the list together, one pass over the list instead of one
         // shift each: at depth 4-5 of a saturating closure half the hits are such inserts into lists of ~1 000 ranges.
-        cand = need && rs >= 0 && re <= sequence_length && rs < re && (p0 == 0 || R.y(p0 - 1) < rs - iso_margin) &&
-               (p0 == len || R.x(p0) > re + iso_margin);
+        const bool plain = need && rs >= 0 && re <= sequence_length && rs < re;
+        const bool prev_far = p0 == 0 || R.y(p0 - 1) < rs - iso_margin, next_far = p0 == len || R.x(p0) > re + iso_margin;
+        cand = plain && prev_far && next_far;
+        flo = rs - iso_margin; fhi = re + iso_margin;
+        // Hits that grow exactly ONE range.  The hit overlaps or touches the range before its lower bound (A) or the one
+        // at it (B), every other range is farther than the merge distance from what the two become together, and no
+        // other uncovered hit of the batch comes near that stretch: then its turn in the replay is a few lines of
+        // arithmetic on that one range -- the distance tests against it (impg.rs:2513-2545: a hit whose end lies within
+        // the merge distance of the range's is dropped), at most two pieces, the uncovered stretch on either side
+        // (:314-328), the range's new ends (:330-343), nothing to swallow (:355-368) -- and no range changes its place.
+        if (plain && !cand) {
+          if (p0 > 0 && R.y(p0 - 1) >= rs && next_far) {  // A: q = p0 - 1 starts before the hit and reaches it
+            ext = 1; q = p0 - 1u; xq = R.x(q); yq = R.y(q);
+            flo = xq - iso_margin;
+          } else if (prev_far && p0 < len && R.x(p0) <= re) {  // B: q = p0 starts inside the hit (or at its end)
+            xq = R.x(p0); yq = R.y(p0);
+            if (p0 + 1u == len || R.x(p0 + 1u) > max(re, yq) + iso_margin) { ext = 2; q = p0; fhi = max(re, yq) + iso_margin; }
+          }
+        }
       }
       todo = __ballot(need);
-      unsigned long long iso = 0ull;
-      if (__ballot(cand) != 0ull) {
+      unsigned long long iso = 0ull, grown = 0ull;
+      if (__ballot(cand || ext != 0) != 0ull) {
+        bool clear = true;  // nothing else that is still to be replayed comes near this hit's stretch
         for (unsigned long long left = todo; left; left &= left - 1ull) {
           const uint32_t j = (uint32_t)__ffsll((long long)left) - 1u;
           const int32_t sj = __builtin_amdgcn_readlane(rs, j), ej = __builtin_amdgcn_readlane(re, j);
-          if (j != lane && sj - iso_margin <= re + iso_margin && rs - iso_margin <= ej + iso_margin) cand = false;
+          if (j != lane && sj - iso_margin <= fhi && flo <= ej + iso_margin) clear = false;
         }
+        cand = cand && clear;
         iso = __ballot(cand);
+        grown = __ballot(ext != 0 && clear);
+        if (ext != 0 && !clear) ext = 0;
+      }
+      if (grown) {
+        bool p1 = false, p2 = false;
+        int2 pc1 = make_int2(0, 0), pc2 = make_int2(0, 0);
+        if (ext == 1) {
+          // the first distance test is against this range's end, the second against a range that is far away
+          if (!(mdbr > 0 && yq - rs < mdbr)) {
+            p1 = re - yq >= min_transitive_len;  // (yq < re: the hit is not covered)
+            pc1 = make_int2(yq, re);
+            R.y(q) = re;
+          }
+        } else if (ext == 2) {
+          if (!(mdbr > 0 && re - xq < mdbr)) {  // (xq <= re; the first test is against a range that is far away)
+            p1 = rs < xq && xq - rs >= min_transitive_len;
+            pc1 = make_int2(rs, xq);
+            p2 = yq < re && re - yq >= min_transitive_len;
+            pc2 = make_int2(yq, re);
+            R.x(q) = rs;  // (xq >= rs: the lower bound)
+            R.y(q) = max(re, yq);
+          }
+        }
+        const unsigned long long m1 = __ballot(p1), m2 = __ballot(p2);
+        if (p1) P[np + (uint32_t)__popcll(m1 & lanemask_lt())] = pc1;
+        np += (uint32_t)__popcll(m1);
+        if (p2) P[np + (uint32_t)__popcll(m2 & lanemask_lt())] = pc2;
+        np += (uint32_t)__popcll(m2);
+        order_point(R);
+        todo &= ~grown;
       }
       if (__popcll(iso) >= 2) {
         const uint32_t k = (uint32_t)__popcll(iso);

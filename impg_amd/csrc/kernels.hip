@@ -2236,7 +2236,7 @@ __global__ __launch_bounds__(64) void visited_update_wave_kernel(VisitedTables v
                                                                  const uint32_t *__restrict__ noff,
                                                                  const uint32_t *__restrict__ poff,
                                                                  const uint32_t *__restrict__ big_list,
-                                                                 const uint32_t *__restrict__ n_big, uint32_t from_back,
+                                                                 const uint32_t *__restrict__ n_big, uint32_t *__restrict__ next_group, uint32_t from_back,
                                                                  int32_t min_transitive_len,
                                                                  int32_t mdbr, int2 *__restrict__ new_ranges,
                                                                  uint32_t *__restrict__ new_len, int2 *__restrict__ pieces,
@@ -2250,7 +2250,16 @@ __global__ __launch_bounds__(64) void visited_update_wave_kernel(VisitedTables v
   int32_t *lx = reinterpret_cast<int32_t *>(lds), *ly = lx + CAP;
   const uint32_t lane = lane_id();
   const uint32_t nb = *n_big;
-  for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+  // Groups are handed out one at a time (a counter), not dealt round-robin: a group's replay takes anything from
+  // microseconds to milliseconds, and with a fixed deal the launch lasted as long as its unluckiest wave -- the waves of a
+  // config-5 level were busy a fifth of the kernel's time.
+  __shared__ uint32_t next_b;
+  for (;;) {
+    __syncthreads();  // (everybody has read the previous next_b)
+    if (lane == 0) next_b = atomicAdd(next_group, 1u);
+    __syncthreads();
+    const uint32_t b = next_b;
+    if (b >= nb) break;
     const uint32_t g = big_list[from_back ? from_back - 1u - b : b];  // (from_back = n_groups: the list's other end)
     int2 *R = new_ranges + noff[g];
     const int2 *src = nullptr;
@@ -3128,7 +3137,7 @@ void launch_visited_update(const VisitedTables &vt, const unsigned long long *sv
                            uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, const uint32_t *cap, const uint32_t *pcap,
                            uint32_t *big_list, uint32_t *n_big, hipStream_t s) {
   if (!n_groups) return;
-  (void)hipMemsetAsync(n_big, 0, 12, s);
+  (void)hipMemsetAsync(n_big, 0, 24, s);  // three list lengths, three work counters
   big_groups_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(cap, pcap, n_groups, big_list, n_big);
   visited_update_kernel<<<cdiv(n_groups, 64), 64, 0, s>>>(vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff,
                                                           poff, n_groups, min_transitive_len, mdbr, new_ranges, new_len,
@@ -3136,13 +3145,13 @@ void launch_visited_update(const VisitedTables &vt, const unsigned long long *sv
   // one wave per big group, grid-strided over however many there are (the count stays on the device)
   const uint32_t blocks = std::min<uint32_t>(n_groups, 256u * std::min(32u, (160u * 1024u) / (VW_CAP_SMALL * 8u)));
   visited_update_wave_kernel<VW_CAP_SMALL><<<blocks, 64, 0, s>>>(
-      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list, n_big, 0u, min_transitive_len, mdbr, new_ranges,
+      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list, n_big, n_big + 3, 0u, min_transitive_len, mdbr, new_ranges,
       new_len, pieces, n_pieces);
   visited_update_wave_kernel<VW_CAP_TINY><<<std::min<uint32_t>(n_groups, 256u * 32u), 64, 0, s>>>(
-      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list + n_groups, n_big + 2, 0u, min_transitive_len, mdbr, new_ranges,
+      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list + n_groups, n_big + 2, n_big + 5, 0u, min_transitive_len, mdbr, new_ranges,
       new_len, pieces, n_pieces);
   visited_update_wave_kernel<VW_CAP_LARGE><<<std::min<uint32_t>(n_groups, 256u * 5u), 64, 0, s>>>(
-      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list, n_big + 1, n_groups, min_transitive_len, mdbr,
+      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list, n_big + 1, n_big + 4, n_groups, min_transitive_len, mdbr,
       new_ranges, new_len, pieces, n_pieces);
 }
 void launch_covered_flags(const VisitedTables &vt, const unsigned long long *svals, const uint32_t *head, const uint32_t *gid,

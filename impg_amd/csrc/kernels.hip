@@ -1922,18 +1922,41 @@ __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, co
   }
   // next-depth ranges of this group: sort by start, merge overlapping/contiguous
   // (impg.rs:2568-2584; ranges of different groups never share (query, id))
-  for (uint32_t i = 1; i < np; i++) {
-    int2 x = P[i];
-    uint32_t j = i;
-    while (j > 0 && P[j - 1].x > x.x) { P[j] = P[j - 1]; j--; }
-    P[j] = x;
+  if (np > 1 && np <= VU_LDS_CAP) {
+    // a handful of pieces: fetched once into the lane's LDS column (the list has been written out), sorted and merged
+    // there -- on the global slice every comparison of the insertion sort was a dependent round trip to memory, and
+    // they, not the replay, were most of this kernel's time
+    const ListInLds S{lds_x + threadIdx.x, lds_y + threadIdx.x};
+    for (uint32_t i = 0; i < np; i++) { const int2 t = P[i]; S.x(i) = t.x; S.y(i) = t.y; }
+    for (uint32_t i = 1; i < np; i++) {
+      const int32_t tx = S.x(i), ty = S.y(i);
+      uint32_t j = i;
+      while (j > 0 && S.x(j - 1) > tx) { S.x(j) = S.x(j - 1); S.y(j) = S.y(j - 1); j--; }
+      S.x(j) = tx; S.y(j) = ty;
+    }
+    uint32_t w = 0;
+    int32_t cx = S.x(0), cy = S.y(0);
+    for (uint32_t r = 1; r < np; r++) {
+      const int32_t rx = S.x(r), ry = S.y(r);
+      if (cy >= rx) cy = max(cy, ry);
+      else { P[w] = make_int2(cx, cy); w += 1; cx = rx; cy = ry; }
+    }
+    P[w] = make_int2(cx, cy);
+    np = w + 1;
+  } else {
+    for (uint32_t i = 1; i < np; i++) {
+      int2 x = P[i];
+      uint32_t j = i;
+      while (j > 0 && P[j - 1].x > x.x) { P[j] = P[j - 1]; j--; }
+      P[j] = x;
+    }
+    uint32_t w = 0;
+    for (uint32_t r = 1; r < np; r++) {
+      if (P[w].y >= P[r].x) P[w].y = max(P[w].y, P[r].y);
+      else { w += 1; P[w] = P[r]; }
+    }
+    if (np) np = w + 1;
   }
-  uint32_t w = 0;
-  for (uint32_t r = 1; r < np; r++) {
-    if (P[w].y >= P[r].x) P[w].y = max(P[w].y, P[r].y);
-    else { w += 1; P[w] = P[r]; }
-  }
-  if (np) np = w + 1;
   new_len[g] = len;
   n_pieces[g] = np;
 }

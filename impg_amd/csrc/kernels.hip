@@ -33,6 +33,37 @@ namespace impg {
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
+// Inclusive scan over the wave on the DPP network: four shifts inside each row of 16 lanes, then lane 15 of rows 0 / 2
+// into rows 1 / 3 and lane 31 into rows 2 and 3.  A lane without a source (row start, masked row) reads 0.  Six
+// v_add_u32_dpp where the __shfl_up form is six ds_bpermute round trips through LDS with a compare + select each.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or0(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  x += dpp_or0<0x111, 0xF>(x);  // row_shr:1
+  x += dpp_or0<0x112, 0xF>(x);  // row_shr:2
+  x += dpp_or0<0x114, 0xF>(x);  // row_shr:4
+  x += dpp_or0<0x118, 0xF>(x);  // row_shr:8
+  x += dpp_or0<0x142, 0xA>(x);  // row_bcast:15 into rows 1, 3
+  x += dpp_or0<0x143, 0xC>(x);  // row_bcast:31 into rows 2, 3
+  return x;
+}
+// max over the wave, in every lane (same network; a lane without a source keeps its own value; lane 63 ends up with it)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_self(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+  x = max(x, dpp_or_self<0x111, 0xF>(x));
+  x = max(x, dpp_or_self<0x112, 0xF>(x));
+  x = max(x, dpp_or_self<0x114, 0xF>(x));
+  x = max(x, dpp_or_self<0x118, 0xF>(x));
+  x = max(x, dpp_or_self<0x142, 0xA>(x));
+  x = max(x, dpp_or_self<0x143, 0xC>(x));
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 // Inside a window every entry already starts before the range end (ub), so the
 // overlap test needs the end column only.  Transitive levels use ends_t, where an
 // entry with first >= last holds INT_MIN: max(cs,first) < min(ce,last)
@@ -484,20 +515,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   // smaller key at the lower index -- so with +inf beyond that width those places never change, and every comparator
   // that touches one is dropped at compile time: 543 exchanges for 64 places, 384 for 48, 305 for 40, 191 for 32 (the
   // bitonic network this replaces: 672 whatever the width).
-  uint32_t wmax = mine ? ub - b : 0u;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
-  wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
+  const uint32_t wmax = wave_max_u32(mine ? ub - b : 0u);
   const uint32_t c = (uint32_t)__popcll(mask);
   // LDS offsets of the lanes' runs: exclusive scan of c over the wave
-  uint32_t inc = c;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t y = (uint32_t)__shfl_up((int)inc, d);
-    if ((int)lane >= d) inc += y;
-  }
+  const uint32_t inc = wave_incl_scan(c);
   const uint32_t loff = inc - c;
-  const uint32_t total = (uint32_t)__shfl((int)inc, 63);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
   // (each width loads, sorts AND stages inside its own branch: no key register is live where the branches part or
   // meet, which pins all 64 of them to the same registers on every path -- 140 VGPRs instead of 93)
   if (wmax <= 32u) emit_keys_sort_stage<32, 32>(v.rank, b, lo, ub, mask, c, loff, lane, stage);
@@ -531,14 +554,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 // ---------------------------------------------------------------------------
 constexpr uint32_t SCAN_ITEMS = 8, SCAN_BLOCK = 256, SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t y = (uint32_t)__shfl_up((int)x, d);
-    if ((int)lane_id() >= d) x += y;
-  }
-  return x;
-}
 // block-wide exclusive scan of one value per thread (256 threads); returns the
 // exclusive prefix and, in *total, the block sum
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t *total) {
@@ -1010,6 +1025,21 @@ __device__ __forceinline__ bool pfx_end(const PairCtx &c, const uint32_t *__rest
 #ifndef IMPG_PROJ_BLOCK
 #define IMPG_PROJ_BLOCK 256
 #endif
+// -DIMPG_PHASE_CLOCKS (experiments): s_memtime at the projection kernel's dependency boundaries, summed over the waves of
+// every 64th block; read (and cleared) by impg_gpu_debug_phase_clocks -- scripts/phase_clocks.py.  Each mark waits for
+// everything outstanding first, so the phases are what a wave WAITS for, not what it issues.
+#ifdef IMPG_PHASE_CLOCKS
+__device__ unsigned long long g_phase_clk[16];
+#define PHASE_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); phase_t[i] = __builtin_readcyclecounter(); } while (0)
+#define PHASE_MARK_NW(i) do { phase_t[i] = __builtin_readcyclecounter(); } while (0)
+#define PHASE_ARG , unsigned long long *phase_t
+#define PHASE_PASS , phase_t
+#else
+#define PHASE_MARK(i) do { } while (0)
+#define PHASE_MARK_NW(i) do { } while (0)
+#define PHASE_ARG
+#define PHASE_PASS
+#endif
 #ifdef IMPG_PROJECT_WAVES  // (experiments: force the register allocation that gives this many waves per SIMD)
 #define PROJECT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(IMPG_PROJECT_WAVES, IMPG_PROJECT_WAVES)))
 #else
@@ -1023,7 +1053,7 @@ constexpr uint32_t PROJ_BLOCK = IMPG_PROJ_BLOCK, PROJ_WAVES = PROJ_BLOCK / 64u;
 template <bool TRANSITIVE, int MODE>
 __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t eidx, int32_t f_start, int32_t f_end, uint32_t p,
                                              double min_identity, uint32_t *__restrict__ err_flag, const SliceArrays &sl,
-                                             unsigned long long *__restrict__ accepted, bool &ok, uint32_t &qid, TileScan &res) {
+                                             unsigned long long *__restrict__ accepted, bool &ok, uint32_t &qid, TileScan &res PHASE_ARG) {
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   constexpr bool CIGAR = (MODE & MODE_CIGAR) != 0;
   (void)accepted;
@@ -1036,6 +1066,7 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
     f.start = f_start; f.end = f_end;
     uint4 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
     asm volatile("" : "+v"(e0.x), "+v"(e1.z), "+v"(e2.x), "+v"(e3.x));
+    PHASE_MARK(3);
     const int32_t en_ts = (int32_t)e0.x, en_te = (int32_t)e0.y, en_qs = (int32_t)e0.z, en_qe = (int32_t)e0.w;
     const uint32_t nops_flags = e1.z;
     const uint32_t n = nops_flags & OP_LEN_MASK;
@@ -1159,17 +1190,25 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
           if (run1) hd1 = *reinterpret_cast<const uint4 *>(pfx_rec + (size_t)j1 * TILE_WORDS);
           if (run2) hd2 = *reinterpret_cast<const uint4 *>(pfx_rec + (size_t)j2 * TILE_WORDS);
           asm volatile("" : "+v"(hd1.x), "+v"(hd1.y), "+v"(hd1.z), "+v"(hd1.w), "+v"(hd2.x), "+v"(hd2.y), "+v"(hd2.z), "+v"(hd2.w));
+          PHASE_MARK(4);
           if (run1) {
             int32_t oq, ot;
             const bool okc = pfx_end<true>(c, pfx_rec, n, j1, c.flip ? (int32_t)c.totT - xb : xa, !c.flip, oq, ot, lo_op, hd1);
             lit = !okc;
             if (c.flip) { lq = oq; lt = ot; } else { fq = oq; ft = ot; }
           }
+          PHASE_MARK(5);
           if (run2 && !lit) {
             int32_t oq, ot;
             const bool okc = pfx_end<false>(c, pfx_rec, n, j2, (c.flip ? (int32_t)c.totT - xa : xb) + 1, c.flip, oq, ot, hi_op, hd2);
             lit = !okc;
             if (c.flip) { fq = oq; ft = ot; } else { lq = oq; lt = ot; }
+          }
+          PHASE_MARK(6);
+          if (IDENT && !lit && (c.flip ? !do_first : !do_last)) {
+            // The upper end came from a shortcut, so no search looked at the record's last tile: if that tile is `wide`
+            // its identity line's 16-bit fields do not hold its sums (a 70000= op) -- literal walk, as pfx_end would say.
+            lit = (pfx_rec[(size_t)(c.m - 1u) * TILE_WORDS] >> 31) != 0u;
           }
           if (IDENT && !lit) {
             // The slice [first op, last op] in storage order is [lo_op, hi_op]: its matched / mismatched bases and gap ops
@@ -1341,6 +1380,12 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
   }
 }
 
+// (Round 4, measured and dropped: one block working through 8 consecutive tiles as a two-stage pipeline -- the next
+// tile's list entries and frontier records in flight under the current tile's projection.  s_memtime at the dependency
+// boundaries (-DIMPG_PHASE_CLOCKS, scripts/phase_clocks.py) had shown a wave waiting 3 400 of its 17 900 cycles for those
+// two reads; with them hidden the other phases stretched by the same amount -- 17 900 cycles per tile again, at 72
+// VGPRs / 7 waves: 36.5 ms against 33.6.  The kernel is bound by a shared pipe (the vector-memory path, see DESIGN
+// 5.2), not by the latency of any one read.)
 template <bool TRANSITIVE, int MODE>
 __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr,
                                                       const uint32_t *__restrict__ pair_range,
@@ -1356,6 +1401,11 @@ __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(D
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t lblock = xcd_map ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
   const uint32_t pp = lblock * PROJ_BLOCK + threadIdx.x;
+#ifdef IMPG_PHASE_CLOCKS
+  unsigned long long phase_t[10];
+  for (int i = 0; i < 10; i++) phase_t[i] = 0;
+  PHASE_MARK(0);
+#endif
   bool ok = false;
   TileScan res;
   res.found = res.any = false;
@@ -1372,31 +1422,34 @@ __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(D
     const FrontierRec f = fr[r];
     f_start = f.start; f_end = f.end;
   }
+  PHASE_MARK(1);
   if (regroup) {
     // The block's 256 pairs, regrouped by entry before anything of the index is read.  In projection order
     // neighbouring lanes are the hits of ONE range on different entries: every lane reads its own entry line and
     // its own tile lines.  The ranges of a block are neighbours in the lookup order and hit largely the same
-    // entries, so sorted by entry a wave's lanes share a handful of lines.  A counting sort in LDS over
-    // (entry - the block's smallest entry), one bin per thread; results are stored at the pair's own slot, so
-    // which lane projects which pair changes nothing downstream.
+    // entries, so sorted by entry a wave's lanes share a handful of lines.  A counting sort in LDS, one bin per
+    // thread; results are stored at the pair's own slot, so which lane projects which pair changes nothing downstream.
+    // (bin = entry mod the block size: equal entries share a bin and neighbours sit in neighbouring bins, which is all the
+    // grouping is for -- the block's entries span fewer than 256 places but for a rare wide block, where bins then
+    // mix two entries.  The round-3 form binned by `entry - the block's smallest entry`: a wave reduction, an LDS round
+    // and a barrier more.)
     __shared__ uint32_t rg_hist[PROJ_BLOCK];
-    __shared__ uint32_t rg_min[PROJ_WAVES];
     __shared__ uint32_t rg_ws[PROJ_WAVES];
     __shared__ uint4 rg_pay[PROJ_BLOCK];
-    uint32_t mn = eidx;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
     rg_hist[threadIdx.x] = 0u;
-    if (lane_id() == 0) rg_min[threadIdx.x >> 6] = mn;
     __syncthreads();
-    uint32_t emin = rg_min[0];
-#pragma unroll
-    for (uint32_t k = 1; k < PROJ_WAVES; k++) emin = min(emin, rg_min[k]);
-    const uint32_t bin = live ? min(eidx - emin, PROJ_BLOCK - 2u) : PROJ_BLOCK - 1u;
+    const uint32_t bin = eidx & (PROJ_BLOCK - 1u);  // (a place beyond the list carries entry ~0: the last bin)
     const uint32_t pos = atomicAdd(&rg_hist[bin], 1u);
     __syncthreads();
-    const uint32_t start = block_excl_scan_n<PROJ_WAVES>(rg_hist[threadIdx.x], rg_ws);
-    rg_hist[threadIdx.x] = start;
+    {  // bin starts: exclusive scan of the counts over the block (one barrier for the waves' sums, one for the starts)
+      const uint32_t cnt = rg_hist[threadIdx.x], inc = wave_incl_scan(cnt);
+      if (lane_id() == 63u) rg_ws[threadIdx.x >> 6] = inc;
+      __syncthreads();
+      uint32_t base = 0;
+#pragma unroll
+      for (uint32_t k = 0; k + 1u < PROJ_WAVES; k++) base += k < (threadIdx.x >> 6) ? rg_ws[k] : 0u;
+      rg_hist[threadIdx.x] = base + inc - cnt;
+    }
     __syncthreads();
     rg_pay[rg_hist[bin] + pos] = make_uint4(eidx, p, (uint32_t)f_start, (uint32_t)f_end);
     __syncthreads();
@@ -1404,13 +1457,15 @@ __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(D
     eidx = mine.x; p = mine.y; f_start = (int32_t)mine.z; f_end = (int32_t)mine.w;
     live = eidx != 0xFFFFFFFFu;
   }
+  PHASE_MARK(2);
   if (live) {
-    project_pair<TRANSITIVE, MODE>(v, eidx, f_start, f_end, p, min_identity, err_flag, sl, accepted, ok, qid, res);
+    project_pair<TRANSITIVE, MODE>(v, eidx, f_start, f_end, p, min_identity, err_flag, sl, accepted, ok, qid, res PHASE_PASS);
     h.qid[p] = qid;
     if (ok) {
       h.c[p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
     }
   }
+  PHASE_MARK(7);
   // accepted-projection count: one atomic per BLOCK, spread over COUNT_SLOTS
   // cache lines (a single hot word caps the whole chip at ~90 atomics/us)
   __shared__ uint32_t wcnt[PROJ_WAVES];
@@ -1423,7 +1478,22 @@ __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(D
     for (uint32_t k = 0; k < PROJ_WAVES; k++) tot += wcnt[k];
     if (tot) atomicAdd(&accepted[(blockIdx.x % COUNT_SLOTS) * COUNT_STRIDE], (unsigned long long)tot);
   }
+#ifdef IMPG_PHASE_CLOCKS
+  PHASE_MARK(8);
+  if ((blockIdx.x & 63u) == 0u && lane_id() == 0u && phase_t[3] && phase_t[4] && phase_t[5] && phase_t[6]) {
+    for (int i = 0; i < 8; i++) atomicAdd(&g_phase_clk[i], phase_t[i + 1] - phase_t[i]);
+    atomicAdd(&g_phase_clk[15], 1ull);
+  }
+#endif
 }
+#ifdef IMPG_PHASE_CLOCKS
+extern "C" void impg_gpu_debug_phase_clocks(unsigned long long *out) {
+  unsigned long long z[16] = {};
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_clk), sizeof(z));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clk), z, sizeof(z));
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // Approximate mode on tracepoint alignments: scan_overlapping_tracepoints + project_overlapping_interval_fast

@@ -1253,6 +1253,39 @@ def test_prefix_line_edges(tmp_path):
             assert_same(g, c, ranges[lo:lo + 400], **kw)
 
 
+def test_identity_filter_wide_last_tile(tmp_path):
+    """min_gap_compressed_identity when an end of the slice is answered by the no-read shortcut (the range covers the
+    alignment's start / end) and the record's LAST storage tile is `wide` (its sums pass 2^16, e.g. a 70000= op): the
+    identity line's 16-bit fields do not hold that tile's sums, so the pair must take the literal walk (round-3 advisory:
+    the flag was only tested inside the search, which a shortcut end skips).  Both strands, both entry directions,
+    ranges covering the end, the start, the whole alignment and neither."""
+    cgs = ["70000=10I70000=", "65536=5X", "3=1X" * 30 + "70000=10I70000=", "70000=10I70000=" + "3=1X" * 30, "40000=30000X5D"]
+    L = 400000
+    lines = []
+    spans = []
+    for i, cg in enumerate(cgs):
+        t, q, _ = _cigar_spans(cg)
+        for strand in "+-":
+            ts = 1000 + 37 * i
+            qs = 2000 + 11 * i
+            lines.append("Q%d%s\t%d\t%d\t%d\t%s\tT\t%d\t%d\t%d\t1\t1\t60\tcg:Z:%s" % (i, "f" if strand == "+" else "r", L, qs, qs + q, strand, L, ts, ts + t, cg))
+            spans.append(("Q%d%s" % (i, "f" if strand == "+" else "r"), qs, q, ts, t))
+    g, c = both(tmp_path, "\n".join(lines) + "\n")
+    T = g.seq_id("T")
+    ranges = []
+    for name, qs, q, ts, t in spans:
+        qid = g.seq_id(name)
+        for (a, b) in [(0, t + 5000), (ts, ts + t), (ts + t - 100, ts + t + 50), (ts + t - 70001, ts + t), (ts - 10, ts + 50), (ts + 10, ts + t - 10),
+                       (ts + 69990, ts + 70020), (ts + 100, ts + t)]:
+            ranges.append((T, max(0, a), min(L, b)))
+        for (a, b) in [(0, qs + q + 100), (qs, qs + q), (qs + q - 100, qs + q + 10), (qs - 5, qs + 70005), (qs + 50, qs + q - 50), (qs + 69995, qs + q)]:
+            ranges.append((qid, max(0, a), min(L, b)))
+    ranges = [r for r in ranges if r[1] < r[2]]
+    for thr in (0.5, 0.9999, 0.99995, 0.999929, 0.57, 1.0):
+        assert_same(g, c, ranges, min_identity=thr)
+    assert_same(g, c, ranges[:40], transitive=True, max_depth=2, min_transitive_len=1, min_identity=0.9999)
+
+
 @pytest.mark.parametrize("seed,max_ops,bidirectional,order", [(1, 60, True, 0), (2, 700, True, 0), (3, 30, False, 1), (4, 2500, True, 0)])
 def test_device_build_matches_host_build(tmp_path, seed, max_ops, bidirectional, order):
     """The index built by kernels from the packed ops (index_build_device.hip: op lines, prefix lines, identity

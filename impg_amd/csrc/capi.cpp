@@ -48,6 +48,7 @@ EngineLease::EngineLease(impg_gpu_index &ix_) : ix(ix_) {
   e->locality_min = ix.opt_locality_min;
   e->free_slots_allowed = ix.opt_free_slots;
   e->regroup_pairs = ix.opt_regroup;
+  e->fuse_allowed = ix.opt_fuse_final;
   e->filter_covered = ix.opt_filter_covered;
   e->walk_allowed = ix.opt_walk != 0 && !getenv("IMPG_NO_WALK");
   e->walk_bfs = ix.opt_walk == 2;  // (the environment switch runs a whole test suite on the batch engine)
@@ -494,6 +495,8 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
   } else if (k == "locality_min") {  // frontier size from which the projection runs in window order (0 = never)
     if (value < 0 || value >= (1ll << 31)) throw Error{IMPG_E_INVALID, "locality_min out of range"};
     ix->opt_locality_min = (uint32_t)value;
+  } else if (k == "fuse_final_level") {  // a counting run's final level enumerates its pairs from the count pass's windows: no emit pass (results identical)
+    ix->opt_fuse_final = value != 0;
   } else if (k == "regroup_entries") {  // projection blocks regroup their pairs by entry before reading the index (results identical)
     ix->opt_regroup = value != 0;
   } else if (k == "walk_kernel") {  // the per-query walk (walk_device.inc): 0 never, 1 DFS batches of any size (default), 2 also BFS batches of <= 64 ranges

@@ -308,8 +308,10 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   // (the owner side of a sharded hop may do the same when the order runs home rank by home rank: `blocks`)
   const bool by_place = free_slot_order && (!raw || blocks) && !multi && !store_cigar && d_perm;
   last_by_place = by_place;
+  const bool fused = by_place && fuse_final && !raw && emit_by_lanes(v) && !v.tp_mode;
+  if (fused) win_se.reserve((size_t)n_fr * 8);
   launch_lookup_count(v, fr, n_fr, transitive, d_perm, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(),
-                      wide_list.as<uint32_t>(), stream, by_place);
+                      wide_list.as<uint32_t>(), stream, by_place, fused ? win_se.as<int2>() : nullptr);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);
   if (P > pair_budget || P >= 0xFFFFFFF0ull) {
     if (split_ok) throw SplitBatch{};
@@ -319,7 +321,16 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
   ProjList pl{nullptr, nullptr, nullptr};
-  if (by_place) {
+  WindowLists wlists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
+  if (fused) {
+    // the final level of a counting run: pairs by windows (WindowLists); only the windows too wide for a 64-bit mask are listed
+    tile_first.reserve(((size_t)(P + 255) / 256 + 1) * 4);
+    launch_tile_first(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr, tile_first.as<uint32_t>(), stream);
+    launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
+                       pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true, true);
+    wlists = WindowLists{tile_first.as<uint32_t>(), pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<int2>(), d_perm, n_fr,
+                         fuse_need_ranges ? L.pair_range.as<uint32_t>() : nullptr};
+  } else if (by_place) {
     launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                        pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true);
   } else {
@@ -341,7 +352,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   }
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
                  acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity,
-                 store_cigar ? &sl : nullptr, pl, stream, nullptr, regroup_pairs);
+                 store_cigar ? &sl : nullptr, pl, stream, nullptr, regroup_pairs, fused ? &wlists : nullptr);
   if (!raw) {
     post_expand(fr, n_fr, L, pair_off.as<uint32_t>(), pair_entry.as<uint32_t>(), v.mrank, sl);
     h = HitArrays{L.qid.as<uint32_t>(), L.coords.as<int4>()};
@@ -662,8 +673,11 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
       L = own.get();
     }
     const bool want_stats = d_count || d_cksum;
+    fuse_final = fuse_allowed && last && !keep && !remote;
+    fuse_need_ranges = want_stats || subset_on;
     const HopResult hr = hop(v, cur->as<FrontierRec>(), alive ? n_fr : 0, transitive, *L, st, keep || want_stats || !last,
                              keep || d_cksum, alive);
+    fuse_final = false;
     if (hr.all_dead) break;
     uint32_t n_next = 0;
     if (alive) {

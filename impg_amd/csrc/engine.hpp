@@ -88,6 +88,12 @@ struct Engine {
   bool free_slot_order = false;
   bool free_slots_allowed = true;  // option "free_slot_order" (A/B runs)
   bool regroup_pairs = true;       // option "regroup_entries": a projection block sorts its 256 pairs by entry first
+  // A counting run's final level (max_depth reached, or a plain query): no update follows and no row is kept, so nothing
+  // reads its slots in order -- the projection kernel enumerates the pairs from the count pass's windows and the emit
+  // pass is skipped (WindowLists, kernels.hpp).  Set by run() around that level's hop.
+  bool fuse_allowed = true;        // option "fuse_final_level" (A/B runs)
+  bool fuse_final = false, fuse_need_ranges = false;
+  DevBuf win_se, tile_first;       // the ranges' (start, end) by place; first range of every projection tile
   int filter_covered = 0;          // option "filter_covered": hits covered by their group's old list dropped before the replay (0 off: it bought nothing on config 5, where hits are covered by the list as it GROWS, not as the level found it; 1 always, 2 long groups)
   uint64_t covered_dropped = 0;    // ... how many that was, over the engine's life (tuning aid)
   DevBuf m_dest, m_qid, m_coords, m_pe, m_sa, m_sn, m_so, m_sr;  // 5-key sort: destination + double buffers

@@ -371,6 +371,7 @@ struct impg_gpu_index {
   uint64_t opt_lane_schedule = 0;  // IMPG_LANE_SCHEDULE / option "lane_schedule": see run_lanes (sharded.cpp); 0 = off
   bool opt_free_slots = true;
   bool opt_regroup = true;
+  bool opt_fuse_final = true;
   int opt_filter_covered = 0;
   int opt_walk = 1;
   impg::ShardCtx *shard = nullptr;    // set: this index is one rank's shard; queries are collective calls

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView 
                                                                 uint32_t n, const uint32_t *__restrict__ perm,
                                                                 uint32_t *__restrict__ cnt,
                                                                 uint4 *__restrict__ win, uint32_t *__restrict__ wide_n,
-                                                                uint32_t *__restrict__ wide_list, int by_place) {
+                                                                uint32_t *__restrict__ wide_list, int by_place, int2 *__restrict__ se) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   // perm (optional): neighbouring lanes take ranges that are neighbours in the entry array, so
@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView 
   }
   cnt[o] = c;
   win[o] = make_uint4(lo, ub, (uint32_t)mask, (uint32_t)(mask >> 32));
+  if (se) se[o] = make_int2(qs, qe);
   // windows too wide for the lane-per-range emit pass (dense targets) are listed for the wave-per-range one
   if (wide_list && lo < ub && ub - (lo & ~3u) > 64u) wide_list[atomicAdd(wide_n, 1u)] = o;
 }
@@ -1380,6 +1381,16 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
   }
 }
 
+// position of the k-th set bit (k from 0) of the 64-bit mask hi:lo; k < popcount
+__device__ __forceinline__ uint32_t select_bit64(uint32_t lo, uint32_t hi, uint32_t k) {
+  uint32_t c = (uint32_t)__popc(lo), w = lo, base = 0;
+  if (k >= c) { k -= c; w = hi; base = 32u; }
+  c = (uint32_t)__popc(w & 0xFFFFu); if (k >= c) { k -= c; w >>= 16; base += 16u; }
+  c = (uint32_t)__popc(w & 0xFFu);   if (k >= c) { k -= c; w >>= 8; base += 8u; }
+  c = (uint32_t)__popc(w & 0xFu);    if (k >= c) { k -= c; w >>= 4; base += 4u; }
+  c = (uint32_t)__popc(w & 0x3u);    if (k >= c) { k -= c; w >>= 2; base += 2u; }
+  return base + (k >= (w & 1u) ? 1u : 0u);
+}
 // (Round 4, measured and dropped: one block working through 8 consecutive tiles as a two-stage pipeline -- the next
 // tile's list entries and frontier records in flight under the current tile's projection.  s_memtime at the dependency
 // boundaries (-DIMPG_PHASE_CLOCKS, scripts/phase_clocks.py) had shown a wave waiting 3 400 of its 17 900 cycles for those
@@ -1393,7 +1404,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(D
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
                                                       uint32_t *__restrict__ err_flag, double min_identity,
                                                       SliceArrays sl, ProjList pl, int xcd_map,
-                                                      const uint32_t *__restrict__ n_pairs_dev, int regroup) {
+                                                      const uint32_t *__restrict__ n_pairs_dev, int regroup, WindowLists wl) {
   if (n_pairs_dev) n_pairs = *n_pairs_dev;  // small batches: the count stays on the device, the grid covers an upper bound
   // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give
   // every XCD one contiguous eighth of the (locality-ordered) pair list instead of
@@ -1415,7 +1426,41 @@ __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(D
   bool live = pp < n_pairs;
   uint32_t p = pp, r = 0, eidx = 0xFFFFFFFFu;
   int32_t f_start = 0, f_end = 0;
-  if (live) {
+  if (wl.tile_first && lblock * PROJ_BLOCK >= n_pairs) {
+    // (a block past the list: the grid is rounded up to the 8 XCDs)
+  } else if (wl.tile_first) {
+    // The pairs of this tile straight from the count pass's per-range records (WindowLists, kernels.hpp): which
+    // range holds place pp (a search over the place offsets of the <= 64 ranges from the tile's first one on, in
+    // LDS; more of them only where ranges without hits pile up), then the (pp - offset)-th set bit of its hit mask.
+    __shared__ uint32_t wl_off[65];
+    const uint32_t pp_last = min(lblock * PROJ_BLOCK + PROJ_BLOCK, n_pairs) - 1u;
+    uint32_t base_i = wl.tile_first[lblock], ri = 0, k = 0;
+    bool found = !live;
+    for (;;) {
+      if (threadIdx.x < 65u) wl_off[threadIdx.x] = base_i + threadIdx.x < wl.n_fr ? wl.pair_off[base_i + threadIdx.x] : 0xFFFFFFFFu;
+      __syncthreads();
+      const uint32_t lim = wl_off[64];
+      if (!found && pp < lim) {
+        uint32_t j = 0;  // the last of the 64 with offset <= pp (ranges without hits share their successor's offset: the last one holds the place)
+#pragma unroll
+        for (uint32_t st = 32u; st > 0u; st >>= 1) j += wl_off[j + st] <= pp ? st : 0u;
+        ri = base_i + j;
+        k = pp - wl_off[j];
+        found = true;
+      }
+      __syncthreads();
+      if (lim > pp_last) break;
+      base_i += 64u;
+    }
+    if (live) {
+      const uint4 w = wl.win[ri];
+      const int2 se = wl.se[ri];
+      f_start = se.x; f_end = se.y;
+      if (w.y - (w.x & ~3u) > 64u) eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
+      else eidx = w.x + select_bit64(w.z, w.w, k);
+      if (wl.range_out) wl.range_out[pp] = wl.perm[ri];
+    }
+  } else if (live) {
     if (pl.slot) { p = pl.slot[pp]; r = pl.range[pp]; eidx = pl.entry[pp]; }
     else { r = pair_range[pp]; eidx = pair_entry[pp]; }
     asm volatile("" : "+v"(r), "+v"(eidx));
@@ -3078,7 +3123,7 @@ __global__ __launch_bounds__(256) void small_pack_kernel(const FrontierRec *__re
 static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 // windows of <= 64 entries are emitted lane-per-range (needs ranks < 2^26 for the packed sort key: a rank is a
 // position within its target's segment, so the largest segment decides, not the index)
-static inline bool emit_by_lanes(const DeviceIndexView &v) { return v.max_seg < (1u << 26); }
+bool emit_by_lanes(const DeviceIndexView &v) { return v.max_seg < (1u << 26); }
 static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 waves per block, capped
   uint32_t blocks = cdiv(n_items, 4);
   const uint32_t cap = 256u * 32u;  // 32 blocks per CU worth of grid-stride
@@ -3086,25 +3131,40 @@ static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 wa
 }
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
-                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place) {
+                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place, int2 *se) {
   if (!n) return;
   const bool lanes = emit_by_lanes(v);
   const int bp = by_place && perm ? 1 : 0;
+  if (!bp) se = nullptr;
   if (lanes) IMPG_HIP(hipMemsetAsync(wide_n, 0, 4, s));
-  if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp);
-  else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp);
+  if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp, se);
+  else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp, se);
+}
+// tile_first[t] = the range whose places include place t * PROJ_BLOCK (see WindowLists): one thread per range, which
+// names itself at every tile border inside its run of places (a run of <= 64 places crosses at most one)
+__global__ __launch_bounds__(256) void tile_first_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off, uint32_t n,
+                                                         uint32_t *__restrict__ tile_first) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c = cnt[i];
+  if (!c) return;
+  const uint32_t first = pair_off[i], last = first + c - 1u;
+  for (uint32_t t = (first + PROJ_BLOCK - 1u) / PROJ_BLOCK; t <= last / PROJ_BLOCK; t++) tile_first[t] = i;
+}
+void launch_tile_first(const uint32_t *cnt, const uint32_t *pair_off, uint32_t n_fr, uint32_t *tile_first, hipStream_t s) {
+  if (n_fr) tile_first_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(cnt, pair_off, n_fr, tile_first);
 }
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
                         const uint32_t *perm, const uint32_t *offp, ProjList pl, const uint32_t *wide_n,
-                        const uint32_t *wide_list, hipStream_t s, bool by_place) {
+                        const uint32_t *wide_list, hipStream_t s, bool by_place, bool wide_only) {
   if (!n) return;
   const int bp = by_place && perm ? 1 : 0;
   const uint32_t *pp = bp ? perm : nullptr;
   // windows of <= 64 entries: lane per range; the rest (dense targets), or everything if a rank could
   // overflow the packed sort key: wave per range
   const bool lanes = emit_by_lanes(v);
-  if (lanes) {
+  if (lanes && !wide_only) {
     if (transitive) lookup_emit_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, pl, bp);
     else lookup_emit_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, pl, bp);
   }
@@ -3146,8 +3206,9 @@ void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, ui
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
-                    ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev, bool regroup) {
+                    ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev, bool regroup, const WindowLists *wlp) {
   if (!n_pairs) return;
+  const WindowLists wl = wlp ? *wlp : WindowLists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
   const int rg = regroup ? 1 : 0;
   bool ident = min_identity == min_identity;  // NaN = no filter
   // An index built without prefix lines (it would not have fitted the device with them: index_build_device.hip) has
@@ -3167,7 +3228,7 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
   const int xcd_map = 1;
   const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};
   const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0) | (two_walks ? MODE_WALK : 0);
-#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, PROJ_BLOCK, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map, n_pairs_dev, rg)
+#define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, PROJ_BLOCK, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map, n_pairs_dev, rg, wl)
   if (transitive) {
     switch (mode) { case 0: IMPG_LAUNCH(true, 0); break; case 1: IMPG_LAUNCH(true, 1); break;
                     case 2: IMPG_LAUNCH(true, 2); break; case 3: IMPG_LAUNCH(true, 3); break; default: IMPG_LAUNCH(true, 5); }

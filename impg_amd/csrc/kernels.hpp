@@ -52,7 +52,23 @@ struct VisitedTables {
 constexpr uint32_t VISITED_NONE = 0xFFFFFFFFu, VISITED_MASK = 0xFFFFFFFEu;  // old_tab values that name no table
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
-                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place = false);
+                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place = false,
+                         int2 *se = nullptr /* by_place: the ranges' (start, end) at their places */);
+// A counting run's FINAL level listed by windows instead of by pairs (engine.cpp: Engine::expand): nothing reads that
+// level's slots by position or in order, so the projection kernel takes its pairs straight from what the count pass
+// left per range -- place offset, window, hit mask -- and the emit pass with its two 4-byte-per-pair lists is not run
+// (only the windows wider than 64 entries, which the wave-per-range emit still lists in pair_entry).
+struct WindowLists {
+  const uint32_t *tile_first;  // [tiles of PROJ_BLOCK places] the range (by place in the lookup order) that holds the tile's first place; null = off
+  const uint32_t *pair_off;    // [n_fr] first place of every range's pairs
+  const uint4 *win;            // [n_fr] {lo, ub, hit mask of the first 64 window entries}
+  const int2 *se;              // [n_fr] the range's (start, end)
+  const uint32_t *perm;        // [n_fr] place -> frontier range
+  uint32_t n_fr;
+  uint32_t *range_out;         // optional: pair_range[] for the per-range counts / the subset filter
+};
+void launch_tile_first(const uint32_t *cnt, const uint32_t *pair_off, uint32_t n_fr, uint32_t *tile_first, hipStream_t s);
+bool emit_by_lanes(const DeviceIndexView &v);
 // The pairs listed in projection order (optional: slot == nullptr means the projection runs in slot order):
 // place -> the pair's slot, its frontier range and its entry.
 struct ProjList {
@@ -61,7 +77,7 @@ struct ProjList {
 void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive,
                         const uint32_t *pair_off, const uint4 *win, uint32_t *pair_range, uint32_t *pair_entry,
                         const uint32_t *perm, const uint32_t *offp, ProjList pl, const uint32_t *wide_n,
-                        const uint32_t *wide_list, hipStream_t s, bool by_place = false);
+                        const uint32_t *wide_list, hipStream_t s, bool by_place = false, bool wide_only = false);
 constexpr uint32_t ROUTE_WORLD_MAX = 1024;
 void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, const uint32_t *owner, uint32_t n_seq, uint32_t *key,
                        uint32_t *idx, unsigned long long *hist, hipStream_t s);
@@ -87,7 +103,8 @@ size_t scan_scratch_bytes(uint32_t n);
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
-                    ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev = nullptr, bool regroup = false);
+                    ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev = nullptr, bool regroup = false,
+                    const WindowLists *wl = nullptr);
 // small batches (engine.cpp: run_small): n <= 1024 counts scanned by one block, total left on the device; results
 // packed behind a 64-byte header {n_pairs, err, -, -, accepted} into (host-mapped) memory
 constexpr uint32_t SMALL_HEADER_BYTES = 64;

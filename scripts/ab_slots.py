@@ -20,13 +20,16 @@ ref = None
 for kw in [dict(transitive=True, max_depth=3), dict()]:
     p = impg_amd.make_params(**kw)
     ref = None
-    for free in [0, 1, 2, 1, 2]:  # 2 = projection-order slots + pairs regrouped by entry inside a projection block
-        g.set_option("free_slot_order", 1 if free else 0)
-        g.set_option("regroup_entries", 1 if free == 2 else 0)
+    # free_slot_order, regroup_entries (pairs regrouped by entry inside a projection block), fuse_final_level (the final
+    # level's pairs enumerated from the count pass's windows: no emit pass)
+    for free, regroup, fuse in [(0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1), (1, 1, 0), (1, 1, 1)]:
+        g.set_option("free_slot_order", free)
+        g.set_option("regroup_entries", regroup)
+        g.set_option("fuse_final_level", fuse)
         g.query_batch_stats(r, p)
         st, cnt, ck = g.query_batch_stats(r, p)
         sig = (cnt.tobytes(), ck.tobytes())
         if ref is None: ref = sig
         assert sig == ref
-        print("%-40s free_slot_order %d: projected %d  lookup %.2f  project %.2f  update %.2f  total %.2f ms" %
-              (kw, free, st.projected, st.ms_lookup, st.ms_project, st.ms_update, st.ms_total), flush=True)
+        print("%-40s free_slot_order %d regroup %d fuse %d: projected %d  lookup %.2f  project %.2f  update %.2f  total %.2f ms" %
+              (kw, free, regroup, fuse, st.projected, st.ms_lookup, st.ms_project, st.ms_update, st.ms_total), flush=True)

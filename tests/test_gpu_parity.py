@@ -1158,14 +1158,18 @@ def test_counting_runs_with_slots_in_projection_order(tmp_path):
             res = g.query_batch(ranges, p)
             want_cnt = [len(res[i]) - 1 for i in range(len(ranges))]
             want_ck = [checksum(res[i][1:]) for i in range(len(ranges))]
-            for lm, free, regroup in [(1, 1, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0), (0, 0, 0)]:
+            for lm, free, regroup, fuse in [(1, 1, 1, 1), (1, 1, 1, 0), (1, 0, 1, 1), (0, 1, 1, 1), (1, 1, 0, 1), (0, 0, 0, 0)]:
                 g.set_option("locality_min", lm)
                 g.set_option("free_slot_order", free)
                 g.set_option("regroup_entries", regroup)  # (a projection block sorts its pairs by entry first: same slots, same rows)
+                g.set_option("fuse_final_level", fuse)    # (the final level's pairs enumerated from the count pass's windows: no emit pass)
                 st, cnt, ck = g.query_batch_stats(ranges, p)
                 assert st.projected == res.projected
-                assert cnt.tolist() == want_cnt, (seed, kw, lm, free, regroup)
-                assert [int(x) for x in ck] == want_ck, (seed, kw, lm, free, regroup)
+                assert cnt.tolist() == want_cnt, (seed, kw, lm, free, regroup, fuse)
+                assert [int(x) for x in ck] == want_ck, (seed, kw, lm, free, regroup, fuse)
+                st2, _, _ = g.query_batch_stats(ranges, p, counts=False, checksums=False)  # (no per-range list is written at all)
+                assert st2.projected == res.projected
+            g.set_option("fuse_final_level", 1)
             g.set_option("regroup_entries", 0)
             g.set_option("locality_min", 4096)
             res0 = g.query_batch(ranges, p)
@@ -1185,13 +1189,34 @@ def test_counting_runs_with_slots_in_projection_order(tmp_path):
     for kw in [dict(), dict(transitive=True, max_depth=2, min_transitive_len=10)]:
         p = impg_amd.make_params(**kw)
         res = g.query_batch(dense, p)
-        for lm, free in [(1, 1), (1, 0)]:
+        for lm, free, fuse in [(1, 1, 1), (1, 1, 0), (1, 0, 1)]:
             g.set_option("locality_min", lm)
             g.set_option("free_slot_order", free)
+            g.set_option("fuse_final_level", fuse)
             st, cnt, ck = g.query_batch_stats(dense, p)
             assert st.projected == res.projected
             assert cnt.tolist() == [len(res[i]) - 1 for i in range(len(dense))]
             assert [int(x) for x in ck] == [checksum(res[i][1:]) for i in range(len(dense))]
+    # runs of ranges without a single hit between the ones with hits (the final level's tiles then span more than the 64
+    # ranges a projection block looks at in one go), unknown targets, and windows wider than the hit mask in the same batch
+    lines = lines[:120] + ["E%d\t5000\t0\t100\t+\tE%d\t5000\t4000\t4100\t10\t10\t60\tcg:Z:100=" % (i, i + 1) for i in range(0, 40, 2)]
+    g, c = both(tmp_path, "\n".join(lines) + "\n")
+    t = g.seq_id("T")
+    gaps = []
+    for i in range(12):
+        gaps += [(g.seq_id("E%d" % (2 * (j % 20))), 1000 + j, 1500 + j) for j in range(90 + 17 * i)]   # no alignment there
+        gaps += [(t, 2000 + 31 * i, 2300 + 31 * i), (g.seq_id("Q%d" % (i % 11)), 0, 3000), (g.num_seqs() + 5, 10, 20)]
+    g.set_option("locality_min", 1)
+    g.set_option("free_slot_order", 1)
+    for kw in [dict(), dict(transitive=True, max_depth=2, min_transitive_len=10), dict(transitive=True, max_depth=1)]:
+        p = impg_amd.make_params(**kw)
+        res = g.query_batch(gaps, p)
+        for fuse in (1, 0):
+            g.set_option("fuse_final_level", fuse)
+            st, cnt, ck = g.query_batch_stats(gaps, p)
+            assert st.projected == res.projected
+            assert cnt.tolist() == [len(res[i]) - 1 for i in range(len(gaps))]
+            assert [int(x) for x in ck] == [checksum(res[i][1:]) for i in range(len(gaps))]
 
 
 def _cigar_spans(cg):

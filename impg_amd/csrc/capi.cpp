@@ -482,6 +482,8 @@ int impg_gpu_index_approximate(const impg_gpu_index_t *ix) {
   return ix->tp_mode ? 1 : 0;
 }
 
+uint64_t impg_gpu_host_pool_trim(uint64_t keep_bytes) { return (uint64_t)impg::pinned_trim((size_t)keep_bytes); }
+
 int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
   IMPG_TRY
   if (!ix || !key) throw Error{IMPG_E_INVALID, "null argument"};

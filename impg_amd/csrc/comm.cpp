@@ -180,15 +180,15 @@ RcclComm::RcclComm(const uint8_t *id128, int rank_, int world_, int device_) : d
   IMPG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
 }
 void RcclComm::abort() {
-  if (comm && !dead) {
-    dead = true;
+  // (called from any lane's thread: `dead` flips once; `comm` itself stays as it is until the destructor, so that the
+  // owner thread, which may be inside a call on it right now, never sees a null handle -- ncclCommAbort makes that call return)
+  if (comm && !dead.exchange(true)) {
     if (rccl().CommAbort) (void)rccl().CommAbort(comm);  // frees the communicator; peers' pending operations fail or time out
-    comm = nullptr;
   }
   if (order) order->end(lane);
 }
 RcclComm::~RcclComm() {
-  if (comm) (void)rccl().CommDestroy(comm);
+  if (comm && !dead) (void)rccl().CommDestroy(comm);  // (an aborted communicator is already freed)
   if (h_vals) (void)hipHostFree(h_vals);
   if (cs) (void)hipStreamDestroy(cs);
 }

@@ -11,6 +11,7 @@
 //   HostComm   the host brings the transport (MPI, gloo, ...) as two callbacks over host memory; blocks are
 //              staged through pinned buffers.  Also what the multi-rank tests on a one-GPU box use.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <condition_variable>
@@ -121,7 +122,7 @@ struct RcclComm : Comm {
   int device;
   std::shared_ptr<IssueOrder> order;  // shared by the lanes of this rank (null: a single lane)
   int lane = 0;
-  bool dead = false;  // aborted after a failure inside the transport
+  std::atomic<bool> dead{false};  // aborted after a failure inside the transport (set by whichever lane thread notices; read by the owner)
   DevBuf d_vals;
   uint64_t *h_vals = nullptr;  // pinned
   size_t h_cap = 0;

@@ -308,7 +308,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   // (the owner side of a sharded hop may do the same when the order runs home rank by home rank: `blocks`)
   const bool by_place = free_slot_order && (!raw || blocks) && !multi && !store_cigar && d_perm;
   last_by_place = by_place;
-  const bool fused = by_place && fuse_final && !raw && emit_by_lanes(v) && !v.tp_mode;
+  const bool fused = by_place && fuse_final && emit_by_lanes(v) && !v.tp_mode;
   if (fused) win_se.reserve((size_t)n_fr * 8);
   launch_lookup_count(v, fr, n_fr, transitive, d_perm, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(),
                       wide_list.as<uint32_t>(), stream, by_place, fused ? win_se.as<int2>() : nullptr);

@@ -3,7 +3,8 @@
 // (rows_device.hip) and cross PCIe in one copy, which wants a pinned destination -- and pinning 5 GB of fresh
 // memory costs more than the copy.  A block goes back to the pool when its result is freed
 // (impg_gpu_results_free) and serves the next call; IMPG_PINNED_POOL_BYTES bounds what the pool keeps
-// (default 12 GiB, 0 = keep nothing).
+// (default 6 GiB per process -- room for one config-3 result; 0 = keep nothing), impg_gpu_host_pool_trim gives
+// blocks back on request (a job of one process per GPU holds the pool once per rank).
 #include <mutex>
 #include <thread>
 
@@ -18,7 +19,7 @@ struct PinnedPool {
   size_t held = 0, max_held;
   PinnedPool() {
     const char *e = getenv("IMPG_PINNED_POOL_BYTES");
-    max_held = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)12 << 30;
+    max_held = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)6 << 30;
   }
   // (blocks still on the list at process exit are left to the runtime's own teardown: hipHostFree from a static
   // destructor can run after the HIP runtime has shut down)
@@ -82,6 +83,26 @@ void pinned_give(void *p, size_t cap) {
     }
   }
   for (auto &b : drop) (void)hipHostFree(b.p);
+}
+
+size_t pinned_trim(size_t keep_bytes) {
+  PinnedPool &P = pool();
+  std::vector<PinnedPool::Blk> drop;
+  size_t freed = 0;
+  {
+    std::lock_guard<std::mutex> lk(P.m);
+    while (P.held > keep_bytes && !P.free_.empty()) {  // the largest blocks go first
+      size_t big = 0;
+      for (size_t i = 1; i < P.free_.size(); i++) if (P.free_[i].cap > P.free_[big].cap) big = i;
+      drop.push_back(P.free_[big]);
+      P.held -= P.free_[big].cap;
+      freed += P.free_[big].cap;
+      P.free_[big] = P.free_.back();
+      P.free_.pop_back();
+    }
+  }
+  for (auto &b : drop) (void)hipHostFree(b.p);
+  return freed;
 }
 
 void parallel_memcpy(void *dst, const void *src, size_t bytes) {

@@ -192,6 +192,7 @@ struct DevBuf {
 // through a process-wide pool (pinning 5 GB costs seconds, a recycled block nothing); small ones are plain malloc.
 void *pinned_take(size_t bytes, size_t &cap_out);
 void pinned_give(void *p, size_t cap);
+size_t pinned_trim(size_t keep_bytes);  // frees pooled blocks until at most keep_bytes are held; returns the bytes freed
 constexpr size_t PINNED_MIN_BYTES = 1u << 20;
 template <class T> struct HostArr {
   T *p = nullptr;

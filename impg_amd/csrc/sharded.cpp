@@ -148,6 +148,18 @@ struct ShardedExpander : Expander {
     for (uint32_t k = 0; k < W; k++) counts[k] = h[k];
   }
 
+  // An allocation between a hop's all-gather and the all-to-all-v it announced: the peers are already on their way into
+  // that exchange, so a failure here can be neither agreed on nor announced through the lane -- it counts as a failure
+  // inside the transport (the lane's communicator is aborted, run_lanes), like a throw from the exchange itself.
+  void reserve_mid_exchange(DevBuf &b, size_t bytes) {
+    try {
+      b.reserve(bytes);
+    } catch (...) {
+      in_transport = true;
+      throw;
+    }
+  }
+
   template <class F> void timed_comm(F f) {
     if (gpu_turn) gpu_turn->unlock();
     const auto t0 = std::chrono::steady_clock::now();
@@ -197,7 +209,7 @@ struct ShardedExpander : Expander {
       n_recv += c;
     }
     rstart[W] = n_recv;
-    recv_fr.reserve(std::max<size_t>(n_recv * sizeof(FrontierRec), 256));
+    reserve_mid_exchange(recv_fr, std::max<size_t>(n_recv * sizeof(FrontierRec), 256));
     timed_comm([&] { comm->alltoallv(send_fr.p, so.data(), sb.data(), recv_fr.p, ro.data(), rb.data(), s); });
     bytes_out += acc * sizeof(FrontierRec);
     // ---- owner: expand what arrived, in slices under the pair budget
@@ -238,9 +250,15 @@ struct ShardedExpander : Expander {
         blocks.d_bounds = d_bounds.as<uint32_t>();
       }
       try {
+        // (a hop nobody at home reads hits of -- the final level of a counting run -- takes its pairs from the count
+        // pass's windows: no emit pass, Engine::fuse_final)
+        E.fuse_final = E.fuse_allowed && !need_hits;
+        E.fuse_need_ranges = false;
         P = E.expand(v, sub, (uint32_t)m, transitive, owner_L, st, /*raw=*/true, owner_order ? &blocks : nullptr);
+        E.fuse_final = false;
         any_by_place = any_by_place || E.last_by_place;
       } catch (const SplitBatch &) {
+        E.fuse_final = false;
         step = std::max<uint64_t>(1, m / 2);
         continue;
       }
@@ -317,6 +335,7 @@ struct ShardedExpander : Expander {
     }
     } catch (...) {
       E.split_ok = saved_split;
+      E.fuse_final = false;
       if (!need_hits) throw;  // no all-gather follows in this hop: run_lanes announces it in the lane's next one
       deferred = std::current_exception();
       std::fill(back.begin(), back.end(), 0);
@@ -346,7 +365,7 @@ struct ShardedExpander : Expander {
       for (int o = 0; o < W; o++) to_d += mat2[(size_t)o * K2 + d];
       if (to_d >= 0xFFFFFFF0ull) { agreed = true; throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 hits come home in one hop: use smaller chunks (chunk_ranges)"}; }
     }
-    hits_in.reserve(std::max<size_t>(n_home * rec, 256));
+    reserve_mid_exchange(hits_in, std::max<size_t>(n_home * rec, 256));
     timed_comm([&] { comm->alltoallv(out_ptr, so.data(), sb.data(), hits_in.p, ro.data(), rb.data(), s); });
     bytes_out += acc * rec;
     uint64_t ops_home = 0;
@@ -363,7 +382,7 @@ struct ShardedExpander : Expander {
         ro[o] = ops_home * 4; rb[o] = c * 4;
         ops_home += c;
       }
-      ops_in.reserve(std::max<size_t>(ops_home * 4, 256));
+      reserve_mid_exchange(ops_in, std::max<size_t>(ops_home * 4, 256));
       timed_comm([&] { comm->alltoallv(ops_ptr, so.data(), sb.data(), ops_in.p, ro.data(), rb.data(), s); });
       bytes_out += acc * 4;
     }

@@ -330,12 +330,14 @@ class GpuImpg:
         # The reference takes approximate_mode per call (impg.rs:1899): on a CIGAR index it then finds no tracepoints
         # and skips every hit, on a tracepoint index without it it realigns (WFA, not built here).  Answering in the
         # index's own mode instead would hand a caller ported from the trait different rows without a word.
-        if bool(approximate_mode) != self.approximate():
+        # None (the default) = the index's own mode; only an explicit mismatch is refused, as the C entry points do
+        # through params (impg_gpu_index_approximate, IMPG_E_UNSUPPORTED).
+        if approximate_mode is not None and bool(approximate_mode) != self.approximate():
             raise ImpgGpuError(IMPG_E_UNSUPPORTED, "approximate_mode=%s on an index built from %s" %
                                (bool(approximate_mode), "tracepoints" if self.approximate() else "CIGARs"))
 
     def query(self, target_id, range_start, range_end, store_cigar=False, min_gap_compressed_identity=None,
-              sequence_index=None, approximate_mode=False):
+              sequence_index=None, approximate_mode=None):
         """ImpgIndex::query (impg_index.rs:26-35)."""
         # approximate_mode is a property of the index here: one built from tracepoints (from_tracepoints) answers
         # in approximate mode, one built from CIGARs in exact mode; a call that asks for the other mode is refused
@@ -346,7 +348,7 @@ class GpuImpg:
     def query_transitive_bfs(self, target_id, range_start, range_end, masked_regions=None, max_depth=2,
                              min_transitive_len=101, min_distance_between_ranges=10, min_output_length=None,
                              store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
-                             approximate_mode=False, subset_filter=None):
+                             approximate_mode=None, subset_filter=None):
         """ImpgIndex::query_transitive_bfs (impg_index.rs:79-94)."""
         self._check_mode(approximate_mode)
         p = make_params(True, False, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,
@@ -357,7 +359,7 @@ class GpuImpg:
     def query_transitive_dfs(self, target_id, range_start, range_end, masked_regions=None, max_depth=2,
                              min_transitive_len=101, min_distance_between_ranges=10, min_output_length=None,
                              store_cigar=False, min_gap_compressed_identity=None, sequence_index=None,
-                             approximate_mode=False, subset_filter=None):
+                             approximate_mode=None, subset_filter=None):
         """ImpgIndex::query_transitive_dfs (impg_index.rs:63-77)."""
         self._check_mode(approximate_mode)
         p = make_params(True, True, max_depth, min_transitive_len, min_distance_between_ranges, min_output_length,

@@ -201,8 +201,15 @@ int impg_gpu_index_approximate(const impg_gpu_index_t *);
  * are identical either way; 0 = never), "free_slot_order" (1, the default: runs
  * that keep no level -- impg_gpu_query_batch_stats -- lay their hit slots out in
  * that order too; 0: always the reference's slot order; counts and checksums are
- * identical either way). */
+ * identical either way),
+ * "fuse_final_level" (1, the default: the final level of such a run -- no update follows, no row is kept --
+ * takes its (range, entry) pairs straight from the lookup's per-range windows inside the projection kernel; the emit
+ * pass and its pair lists are skipped; counts and checksums are identical either way). */
 int impg_gpu_set_option(impg_gpu_index_t *, const char *key, int64_t value);
+/* Large result arrays live in pinned host blocks that are recycled through a process-wide pool (at most
+ * IMPG_PINNED_POOL_BYTES, default 6 GiB, are kept when results are freed).  Gives pooled blocks back to the system
+ * until at most keep_bytes are held; returns the number of bytes freed. */
+uint64_t impg_gpu_host_pool_trim(uint64_t keep_bytes);
 
 /* Visit rank of the sorted positions 0..n-1 of an n-entry target under an order
  * policy (what the index stores per entry); host-only, no GPU needed. */
@@ -317,7 +324,8 @@ int impg_gpu_results_bed(const impg_gpu_results_t *, const impg_gpu_index_t *,
  * formatted.  The text is byte-identical to impg_gpu_query_batch_filtered +
  * impg_gpu_results_bed (what `impg query -o bed` prints: main.rs:7435-7470, :11849-11892).  range_names as in
  * impg_gpu_results_bed (NULL, or NULL entries, = "{name}:{start}-{end}").  subset_keep may be NULL.  seconds3, if
- * not NULL, receives the wall seconds of {engine, device-side merge + copy back, text}.  Single-GPU index. */
+ * not NULL, receives the wall seconds of {engine, device-side merge + copy back, text}.  On an index sharded over GPUs the
+ * merges and the text run on each range's home rank and the pieces are concatenated in the caller's order. */
 int impg_gpu_query_batch_bed(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
                              const uint8_t *subset_keep, int32_t merge_distance, const char *const *range_names, char **text,
                              size_t *len, double *seconds3);
@@ -371,7 +379,8 @@ int impg_gpu_parse_target_range(const char *s, char *name_out, size_t name_cap,
  *
  * `lanes` chunks of a batch ("chunk_ranges") are in flight at once, each on its own engine, stream, host thread
  * and communicator, so one lane's exchange overlaps the other lanes' kernels.
- * Not offered on a sharded index: store_cigar (IMPG_E_UNSUPPORTED), impg_gpu_index_save.  projected / pairs /
+ * Not offered on a sharded index: impg_gpu_index_save (save the plain index, shard at load).  store_cigar, the
+ * device-side BED call and tracepoint indexes work there as on one GPU (the ops follow the hits home).  projected / pairs /
  * stage times of a rank (2) count the work done ON THAT RANK's shard; a multi handle (1) reports the sum of
  * the work and the slowest rank's times. */
 typedef struct impg_gpu_comm impg_gpu_comm_t;

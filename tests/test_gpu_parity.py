@@ -1012,7 +1012,9 @@ def test_tracepoint_approximate_mode(fastga, seed):
     assert g.approximate()
     t0, s0, e0 = ranges[0]
     assert g.query(t0, s0, e0, approximate_mode=True).tolist() == c.query(t0, s0, e0).tolist()
-    for call in (lambda: g.query(t0, s0, e0), lambda: g.query_transitive_bfs(t0, s0, e0), lambda: g.query_transitive_dfs(t0, s0, e0)):
+    assert g.query(t0, s0, e0).tolist() == c.query(t0, s0, e0).tolist()  # (default: the index's own mode, as the C entry points have it)
+    for call in (lambda: g.query(t0, s0, e0, approximate_mode=False), lambda: g.query_transitive_bfs(t0, s0, e0, approximate_mode=False),
+                 lambda: g.query_transitive_dfs(t0, s0, e0, approximate_mode=False)):
         with pytest.raises(impg_amd.ImpgGpuError) as ei:
             call()
         assert ei.value.code == impg_amd.IMPG_E_UNSUPPORTED

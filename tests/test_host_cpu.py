@@ -39,7 +39,7 @@ def test_no_gpu_fails_loudly():
 def test_product_never_references_the_oracle():
     for d, _, files in os.walk(os.path.join(ROOT, "impg_amd")):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h", ".inc")) or f == "Makefile":
                 assert "oracle" not in open(os.path.join(d, f)).read().replace("Independent of the oracle", ""), f
 
 

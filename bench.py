@@ -141,10 +141,13 @@ def main():
     log("building the device index")
     t_build = time.time()
     comm = None
+    comm_report = None
     if dist is not None:
         # this rank's shard of the index (targets bin-packed over the ranks); torch.distributed only carries the
         # RCCL ids to the ranks -- every collective of a query runs inside libimpg_gpu.so
         comm = impg_amd.Comm.rccl(rank, world, local_rank, lanes=args.lanes)
+        comm.check()  # impg_gpu_comm_check on every lane (collective): known words through the all-gather before anything is built on it
+        comm_report = {"kind": comm.kind(), "world": comm.world, "lanes": comm.lanes, "check": "ok on every lane"}
     t_gen = 0.0
     if paf:
         index = impg_amd.GpuImpg.from_paf(paf, device=local_rank, comm=comm)
@@ -190,22 +193,65 @@ def main():
             dist.barrier()
 
     log("index ready (%.1f s, %.2f GB in HBM); warmup" % (t_build, index.device_bytes() / 1e9))
+    parity = None
+    if dist is not None and paf:
+        # Before anything is timed: the N-rank answer against the one-GPU answer.  Rank 0 submits its first 4096 ranges
+        # (the other ranks none: the call is collective) with per-range counts and checksums, builds the PLAIN index of
+        # the same PAF next to its shard, asks it the same, and the run goes on only if every count and checksum agrees.
+        npar = min(4096, args.ranges)
+        st_p, cnt_p, ck_p = index.query_batch_stats(ranges[:npar] if rank == 0 else ranges[:0], params)
+        ok = 1
+        if rank == 0:
+            single = impg_amd.GpuImpg.from_paf(paf, device=local_rank)
+            st_s, cnt_s, ck_s = single.query_batch_stats(ranges[:npar], params)
+            del single
+            ok = int(st_p.projected == st_s.projected and np.array_equal(cnt_p, cnt_s) and np.array_equal(ck_p, ck_s))
+            parity = {"parity_vs_single": bool(ok), "ranges_checked": npar, "projected_sharded": int(st_p.projected),
+                      "projected_single": int(st_s.projected)}
+            log("parity vs the single-GPU index on %d ranges: %s (%d projections)" % (npar, "identical" if ok else "DIFFERENT", st_s.projected))
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.broadcast(flag, src=0)
+        if int(flag.item()) != 1:
+            if rank == 0:
+                result_out.write(json.dumps({"metric": "projected ranges/sec, 1M-PAF 100k-BED -x depth 3; CPU coitrees baseline", "value": None,
+                                             "n_gpus": world, "error": "the %d-rank answer differs from the single-GPU answer" % world,
+                                             **parity}) + "\n")
+                result_out.flush()
+            sys.exit(3)
     if world > 1 or args.force_sharded:
         # part of the set-up, like the index build: the first collective pass on a fresh process brings up the
         # transport (RCCL channels, peer mappings) and sizes every lane's scratch -- seconds on a cold box, and with
         # two chunks in flight per rank one --warmup step does not always touch both lanes' buffers
-        st = step()
-        log("transport + scratch primed: first pass %.1f ms of engine time" % st.ms_total)
+        # (passes until two in a row take about the same time, at most six: on a cold box the first ones also pay for the
+        # device's page mappings of every lane's buffers, 1.1 s then 0.45 s where a settled pass takes 0.06 s)
+        prev = None
+        for k in range(6):
+            ts = time.perf_counter()
+            st = step()
+            cur = time.perf_counter() - ts
+            log("transport + scratch priming pass %d: %.1f ms wall, %.1f ms of engine time" % (k + 1, cur * 1e3, st.ms_total))
+            if prev is not None and cur > 0.9 * prev:
+                break
+            prev = cur
     for _ in range(args.warmup):
         st = step()
         log("warmup step: %d projected, engine %.1f ms (lookup %.1f project %.1f update %.1f exchange %.1f)" %
             (st.projected, st.ms_total, st.ms_lookup, st.ms_project, st.ms_update, st.ms_exchange))
+    if dist is not None:
+        index.hop_profile(reset=True)
     sync()
     t0 = time.perf_counter()
-    stats = [step() for _ in range(args.steps)]
+    stats, step_ms = [], []
+    for _ in range(args.steps):  # (a step returns when its results are complete: the per-step clock adds no synchronisation)
+        ts = time.perf_counter()
+        stats.append(step())
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     sync()
     dt = time.perf_counter() - t0
-    log("timed region: %.3f s for %d steps" % (dt, args.steps))
+    log("timed region: %.3f s for %d steps (%s ms)" % (dt, args.steps, " ".join("%.1f" % x for x in step_ms)))
+    hops = sharded_diagnostics(index, stats, args, dist, dev, world) if dist is not None else None
+    strong = strong_scaling_leg(index, args, params, dist, dev, rank, world, local_rank, n_seq, seq_len, bool(paf), sync) \
+        if (dist is not None and wl == "headline" and not args.no_extras) else None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,10 +262,15 @@ def main():
     else:
         projected_total = float(sum(s.projected for s in stats))
 
+    run_multi = dist is not None and wl == "headline" and not args.no_extras and paf
+    wait_group = dist.new_group(backend="gloo") if run_multi else None  # (a CPU-side wait: an RCCL barrier would spin on the other GPUs)
     if rank != 0:
         if dist is not None:
             del index
             comm.close()
+            if run_multi:
+                dist.barrier(group=wait_group)  # the shards are gone: rank 0 may build the multi handle over every GPU
+                dist.barrier(group=wait_group)  # ... and is done with it
             dist.destroy_process_group()
         flush_c_stdio()
         return
@@ -274,18 +325,32 @@ def main():
                                     "update": sum(s.ms_update for s in stats) / max(1, args.steps),
                                     "exchange_wall": sum(s.ms_exchange for s in stats) / max(1, args.steps),
                                     "engine_total": sum(s.ms_total for s in stats) / max(1, args.steps)},
+        "step_ms_rank0": step_ms,
         "argv": sys.argv[1:],
         "index_build_s": t_build,
         "index_bytes": index.device_bytes(),
         "roofline": roofline(stats, ach, traffic, tpath, ms_project, launches, tag if profiled else None),
     }
-    if world == 1 and not args.no_extras:
+    if dist is not None:
+        out["comm"] = comm_report
+        out["parity"] = parity
+        out["parity_vs_single"] = parity["parity_vs_single"] if parity else None
+        out["hops"] = hops
+        out["strong_scaling"] = strong
+    if world == 1 and dist is None and not args.no_extras:
         out["full_results"] = full_results_leg(index, ranges, params)
         out["dfs_batch"] = dfs_batch_leg(index, ranges, args.max_depth)
     out["cpu_baseline"] = cpu_baseline(args, paf, ranges, transitive) if (world == 1 and args.cpu_sample > 0) else None
     if dist is not None:
         del index
         comm.close()
+        if run_multi:
+            dist.barrier(group=wait_group)
+            try:
+                out["multi_handle"] = multi_handle_leg(paf, ranges, params, args, world)
+            except Exception as e:  # (a diagnostic leg: its failure is reported, the headline line still goes out)
+                out["multi_handle"] = {"error": str(e)}
+            dist.barrier(group=wait_group)
         dist.destroy_process_group()
     flush_c_stdio()
     result_out.write(json.dumps(out) + "\n")
@@ -345,6 +410,99 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches, tag):
                     "config-4 index (20 000 sequences, no reuse) the same kernel IS HBM-bound: 292 B per pair = 4.9 TB/s of 128-byte gathers, "
                     "0.62 of peak (profiles/r3_config4_traffic.json); DESIGN.md 5.2, 7")
     return r
+
+
+def sharded_diagnostics(index, stats, args, dist, dev, world):
+    """Per-hop breakdown of the timed steps on a sharded index: every rank's impg_gpu_index_hop_profile (wall seconds of
+    the hop's stages and bytes sent, by hop number, summed over its lanes) and its engine's stage times, gathered to
+    rank 0 and reported per step as max and mean over the ranks -- what says whether an N-GPU step waits for compute, for
+    the links, or for its slowest rank."""
+    import numpy as np
+    import torch
+    import impg_amd
+    prof = index.hop_profile(reset=True)[0]  # [8][12]
+    eng = np.array([sum(s.ms_lookup for s in stats), sum(s.ms_project for s in stats), sum(s.ms_update for s in stats),
+                    sum(s.ms_exchange for s in stats), sum(s.ms_total for s in stats), float(sum(s.projected for s in stats)),
+                    float(sum(s.pairs for s in stats))], dtype=np.float64)
+    mine = torch.from_numpy(np.concatenate([prof.reshape(-1), eng])).to(dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    a = np.stack([t.cpu().numpy() for t in allr])  # [world][96 + 7]
+    P = a[:, :96].reshape(world, 8, 12) / max(1, args.steps)
+    E = a[:, 96:] / max(1, args.steps)
+    F = impg_amd.index.HOP_PROFILE_FIELDS
+    hops = []
+    for h in range(8):
+        if P[:, h, 0].max() <= 0:
+            continue
+        hops.append({"hop": h + 1, **{F[f]: {"max": float(P[:, h, f].max()), "mean": float(P[:, h, f].mean())} for f in range(12)}})
+    names = ["ms_lookup", "ms_project", "ms_update", "ms_exchange_wall", "ms_engine_total", "projected", "pairs"]
+    return {"per_step": True, "note": "seconds are host wall time per step summed over a rank's lanes (a stage that ends in a collective includes "
+                                      "the wait for the slowest rank); max / mean over the ranks",
+            "by_hop": hops, "engine_per_rank": {names[k]: {"max": float(E[:, k].max()), "mean": float(E[:, k].mean()), "min": float(E[:, k].min())}
+                                                for k in range(len(names))}}
+
+
+def strong_scaling_leg(index, args, params, dist, dev, rank, world, local_rank, n_seq, seq_len, from_paf, sync):
+    """The SAME batch whatever the world: rank 0's 100 000 ranges (seed 7) dealt out to the ranks, every n-th to rank n --
+    total work fixed, next to the weak-scaling headline where every rank brings its own 100 000."""
+    import numpy as np
+    import torch
+    import impg_amd
+    bed = impg_amd.synth_bed(7, args.ranges, n_seq=n_seq, seq_len=seq_len, range_len=5000)[rank::world]
+    r = np.zeros(len(bed), dtype=impg_amd.RANGE_DTYPE)
+    if from_paf:
+        ids = np.array([index.seq_id(impg_amd.synth_seq_name(t)) for t in range(n_seq)], dtype=np.uint32)
+        r["target_id"] = ids[bed["target_id"]]
+    else:
+        r["target_id"] = bed["target_id"]
+    r["start"], r["end"] = bed["start"], bed["end"]
+    d_r = torch.from_numpy(r.view(np.uint8)).to(dev)
+
+    def step():
+        st, _, _ = index.query_batch_stats(None, params, counts=False, checksums=False, device_ptr=d_r.data_ptr(), n=len(r))
+        return st
+    step()
+    sync()
+    t0 = time.perf_counter()
+    sts = [step() for _ in range(args.steps)]
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(sum(s.projected for s in sts))], dtype=torch.float64, device=dev)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dtm, proj = float(tmax[0].item()), float(t[1].item())
+    return {"workload": "the headline's %d ranges (seed 7) dealt out over the %d ranks" % (args.ranges, world), "scaling": "strong",
+            "value": proj / dtm if dtm > 0 else None, "unit": "projected ranges/s", "ms_per_step": dtm * 1e3 / max(1, args.steps),
+            "projected_per_step": proj / max(1, args.steps)}
+
+
+def multi_handle_leg(paf, ranges, params, args, world):
+    """One process, one handle over all the node's GPUs (impg_gpu_index_create_from_paf_multi: LocalComm, peer copies over
+    xGMI, no RCCL): rank 0's batch through it, after the ranks have let go of their shards."""
+    import impg_amd
+    log("multi-handle leg: one process over %d GPU(s)" % world)
+    t0 = time.perf_counter()
+    mh = impg_amd.GpuImpg.from_paf(paf, devices=list(range(world)), lanes=args.lanes)
+    build_s = time.perf_counter() - t0
+    mh.set_option("chunk_ranges", max(1, min(50000, (len(ranges) + world - 1) // world)))
+    mh.set_option("pair_budget", 1 << 30)
+    mh.query_batch_stats(ranges, params, counts=False, checksums=False)
+    mh.query_batch_stats(ranges, params, counts=False, checksums=False)
+    mh.hop_profile(reset=True)
+    t0 = time.perf_counter()
+    sts = [mh.query_batch_stats(ranges, params, counts=False, checksums=False)[0] for _ in range(args.steps)]
+    dt = time.perf_counter() - t0
+    proj = sum(s.projected for s in sts)
+    prof = mh.hop_profile(reset=True) / max(1, args.steps)  # [world][8][12]
+    F = impg_amd.index.HOP_PROFILE_FIELDS
+    hops = [{"hop": h + 1, **{F[f]: {"max": float(prof[:, h, f].max()), "mean": float(prof[:, h, f].mean())} for f in range(12)}}
+            for h in range(8) if prof[:, h, 0].max() > 0]
+    del mh
+    return {"workload": "rank 0's %d ranges through ONE handle over %d GPU(s) of this process (ranges from host memory; strong scaling)" % (len(ranges), world),
+            "value": proj / dt if dt > 0 else None, "unit": "projected ranges/s", "ms_per_step": dt * 1e3 / max(1, args.steps),
+            "projected_per_step": proj / max(1, args.steps), "index_build_s": build_s, "by_hop": hops}
 
 
 def full_results_leg(index, ranges, params):

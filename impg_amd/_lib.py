@@ -150,6 +150,7 @@ SYMBOLS = [
                                                        C.POINTER(_P)]),
     ("impg_gpu_shard_assign", C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     ("impg_gpu_index_shard_info", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _P, C.c_size_t]),
+    ("impg_gpu_index_hop_profile", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]),
     ("impg_synth_paf", C.c_int, [C.c_uint64, C.c_size_t, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, _P, _P, C.c_size_t,
                                  C.POINTER(C.c_size_t)]),
     ("impg_synth_paf_text", C.c_int, [C.c_uint64, C.c_size_t, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_char_p]),

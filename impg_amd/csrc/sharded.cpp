@@ -91,6 +91,12 @@ struct ShardedExpander : Expander {
   uint32_t *h_bounds(uint32_t W, uint32_t slot) { return h_vals + 2 * (W + 1) + 2 * W + 4 + (size_t)slot * (W + 1); }
   double exchange_s = 0;  // wall time inside the transport, accumulated
   uint64_t bytes_out = 0;
+  // Where a hop's wall time goes on this lane, by hop number within its batch (impg_gpu_index_hop_profile; accumulates
+  // until read with reset): host wall clocks around the hop's stages, so a stage that ends in a collective includes the
+  // wait for the slowest rank.
+  static constexpr int PROF_HOPS = 8, PROF_FIELDS = 12;
+  enum { PF_HOPS, PF_ROUTE, PF_GATHER1, PF_A2A1, PF_EXPAND, PF_GATHER2, PF_A2A2, PF_HOME, PF_BYTES_FR, PF_BYTES_HITS, PF_RECS_IN, PF_HITS_HOME };
+  double prof[PROF_HOPS][PROF_FIELDS] = {};
   // The lanes of a rank take turns on the GPU: two chunks' kernels side by side evict each other's entries and
   // tiles from L2 (the window-order locality every kernel here leans on) and ran 3.5x slower than back to back.
   // A lane gives the GPU up exactly while it sits in the transport, which is the overlap lanes exist for.
@@ -182,11 +188,21 @@ struct ShardedExpander : Expander {
     std::vector<uint64_t> mine(K, 0), mat(K * W);
     L.n_pairs = 0;
     hop_no++;
+    double *pf = prof[std::min<uint32_t>(hop_no - 1u, PROF_HOPS - 1)];
+    auto clk = std::chrono::steady_clock::now();
+    auto lap = [&](int field) {
+      const auto now = std::chrono::steady_clock::now();
+      pf[field] += std::chrono::duration<double>(now - clk).count();
+      clk = now;
+    };
+    pf[PF_HOPS] += 1;
     // ---- home: the frontier bucketed by owner; sizes and liveness to everybody
     send_fr.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
     if (n_fr) route(E, fr, n_fr, mine.data());
     mine[W] = alive ? ST_ALIVE : 0;
+    lap(PF_ROUTE);
     timed_comm([&] { comm->allgather_u64(mine.data(), K, mat.data()); });
+    lap(PF_GATHER1);
     bool any = false;
     for (int r = 0; r < W; r++) {
       any = any || (mat[(size_t)r * K + W] & ST_ALIVE) != 0;
@@ -212,6 +228,9 @@ struct ShardedExpander : Expander {
     reserve_mid_exchange(recv_fr, std::max<size_t>(n_recv * sizeof(FrontierRec), 256));
     timed_comm([&] { comm->alltoallv(send_fr.p, so.data(), sb.data(), recv_fr.p, ro.data(), rb.data(), s); });
     bytes_out += acc * sizeof(FrontierRec);
+    pf[PF_BYTES_FR] += (double)(acc * sizeof(FrontierRec));
+    pf[PF_RECS_IN] += (double)n_recv;
+    lap(PF_A2A1);
     // ---- owner: expand what arrived, in slices under the pair budget
     const uint32_t words = (need_rows || E.multi) ? 8u : 4u;
     // store_cigar: the owner materialises every hit's CIGAR slice (Engine::expand) and the ops follow the hit records
@@ -341,10 +360,16 @@ struct ShardedExpander : Expander {
       std::fill(back.begin(), back.end(), 0);
       back[K2 - 1] = ST_FAILED;
     }
-    if (!need_hits) return HopResult{total_pairs, false};
+    if (!need_hits) {
+      IMPG_HIP(hipStreamSynchronize(s));  // (the profile's clock: the owner's kernels, not just their launches)
+      lap(PF_EXPAND);
+      return HopResult{total_pairs, false};
+    }
+    lap(PF_EXPAND);
     // ---- hits go home
     std::vector<uint64_t> mat2(K2 * W);
     timed_comm([&] { comm->allgather_u64(back.data(), K2, mat2.data()); });
+    lap(PF_GATHER2);
     for (int o = 0; o < W; o++)
       if (mat2[(size_t)o * K2 + (K2 - 1)] & ST_FAILED) {
         agreed = true;
@@ -387,6 +412,9 @@ struct ShardedExpander : Expander {
       bytes_out += acc * 4;
     }
     pieces.clear();
+    pf[PF_BYTES_HITS] += (double)(bytes_out_hits(back, W, rec));
+    pf[PF_HITS_HOME] += (double)n_home;
+    lap(PF_A2A2);
     // ---- home: back into frontier order x visit order, into the slot arrays
     if (fail_home_hop && hop_no == fail_home_hop) throw Error{IMPG_E_INVALID, "injected failure (home side)"};
     L.n_pairs = (uint32_t)n_home;
@@ -441,7 +469,13 @@ struct ShardedExpander : Expander {
       E.post_expand(fr, n_fr, L, E.lo_off.as<uint32_t>(), iota.as<uint32_t>(), mslot.as<uint32_t>(), home_sl);
     }
     if (ship_ops) L.slice_pos.swap(L.sl_a);  // what the row builder reads (rows_device.hip): slice_pool[slice_pos[slot] .. + sl_n[slot])
+    lap(PF_HOME);
     return HopResult{total_pairs, false};
+  }
+  static uint64_t bytes_out_hits(const std::vector<uint64_t> &back, int W, uint64_t rec) {
+    uint64_t b = 0;
+    for (int d = 0; d < W; d++) b += back[(size_t)d] * rec + back[(size_t)W + d] * 4;
+    return b;
   }
 };
 
@@ -1139,6 +1173,28 @@ int impg_gpu_index_shard_info(const impg_gpu_index_t *ix, int *rank, int *world,
   if (lanes) *lanes = S ? (int)S->comm->lanes.size() : 1;
   if (owner_out && S)
     for (size_t t = 0; t < S->owner.size() && t < cap; t++) owner_out[t] = S->owner[t];
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_hop_profile(impg_gpu_index_t *ix, double *out, size_t cap, int reset, size_t *n_out) {
+  IMPG_TRY
+  if (!ix || !n_out) throw Error{IMPG_E_INVALID, "null argument"};
+  std::vector<ShardCtx *> ctx;
+  if (ix->shard) ctx.push_back(ix->shard);
+  else if (ix->cluster) for (auto &r : ix->cluster->ranks) if (r->shard) ctx.push_back(r->shard);
+  constexpr size_t per = (size_t)ShardedExpander::PROF_HOPS * ShardedExpander::PROF_FIELDS;
+  *n_out = ctx.size() * per;
+  if (out && cap < *n_out) throw Error{IMPG_E_INVALID, "hop profile: output too small"};
+  for (size_t r = 0; r < ctx.size(); r++) {
+    if (out) std::fill(out + r * per, out + (r + 1) * per, 0.0);
+    for (auto &x : ctx[r]->lanes) {
+      if (out)
+        for (int h = 0; h < ShardedExpander::PROF_HOPS; h++)
+          for (int f = 0; f < ShardedExpander::PROF_FIELDS; f++) out[r * per + (size_t)h * ShardedExpander::PROF_FIELDS + f] += x->prof[h][f];
+      if (reset) memset(x->prof, 0, sizeof x->prof);
+    }
+  }
   return IMPG_OK;
   IMPG_CATCH
 }

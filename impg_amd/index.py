@@ -384,12 +384,25 @@ class GpuImpg:
             check(lib().impg_gpu_query_batch_stats_dev(self._h, device_ptr, n, C.byref(p), cp, kp, C.byref(st)))
         return st, cnt, ck
 
+    def hop_profile(self, reset=True):
+        """impg_gpu_index_hop_profile: array [shards][8 hops][12 fields] (HOP_PROFILE_FIELDS), zeros for a plain index."""
+        n = C.c_size_t(0)
+        check(lib().impg_gpu_index_hop_profile(self._h, None, 0, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.float64)
+        if n.value:
+            check(lib().impg_gpu_index_hop_profile(self._h, out.ctypes.data, out.size, 1 if reset else 0, C.byref(n)))
+        return out[:n.value].reshape(-1, 8, 12)
+
     def shard_info(self):
         """(rank, world, lanes, owner[num_seqs]) of a sharded index; rank -1 = a multi-GPU handle; (0, 1, 1, None) = plain."""
         r, w, l = C.c_int(0), C.c_int(1), C.c_int(1)
         owner = np.zeros(self.num_seqs(), dtype=np.uint32)
         check(lib().impg_gpu_index_shard_info(self._h, C.byref(r), C.byref(w), C.byref(l), owner.ctypes.data, owner.size))
         return r.value, w.value, l.value, (owner if w.value > 1 or r.value != 0 else None)
+
+
+HOP_PROFILE_FIELDS = ["hops", "route_s", "gather_sizes_s", "records_out_s", "owner_expand_s", "gather_hits_s", "hits_home_s", "reorder_s",
+                      "bytes_records_out", "bytes_hits_out", "records_in", "hits_home"]
 
 
 def shard_assign(entries_per_target, n_shards):

@@ -424,6 +424,15 @@ int impg_gpu_index_create_from_paf_multi(const char *const *paths, int n_paths, 
 int impg_gpu_shard_assign(const uint64_t *entries_per_target, uint32_t n_seq, uint32_t n_shards, uint32_t *owner_out);
 /* rank (-1 for a multi handle), world, lanes and the shard map of an index (1 / 0 for a plain one) */
 int impg_gpu_index_shard_info(const impg_gpu_index_t *, int *rank, int *world, int *lanes, uint32_t *owner_out, size_t cap);
+/* Where the hops of the queries since the last reset spent their wall time, by hop number within a batch (hop 8 and
+ * later are counted with hop 8), summed over the lanes: out[(shard * 8 + hop) * 12 + field] with fields
+ *   0 hops, then seconds: 1 bucketing the frontier by owner, 2 all-gather of the sizes (incl. the wait for the slowest
+ *   rank), 3 frontier records to the owners, 4 the owner's lookup + projection (+ packing the hits), 5 all-gather of
+ *   the hit counts, 6 hits (and CIGAR ops) home, 7 putting them back in frontier order; then 8 bytes of frontier
+ *   records sent, 9 bytes of hits + ops sent, 10 frontier records received, 11 hits that came home.
+ * One shard for a rank's index, n_dev for a multi handle, none for a plain index.  *n_out = doubles written (or
+ * needed when out is NULL). */
+int impg_gpu_index_hop_profile(impg_gpu_index_t *, double *out, size_t cap, int reset, size_t *n_out);
 
 /* ---- synthetic workload generators (SplitMix64) ----- */
 /* Fills records / ops for `n_records` synthetic alignments (200-op CIGARs by

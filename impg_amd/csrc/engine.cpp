@@ -309,9 +309,9 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   const bool by_place = free_slot_order && (!raw || blocks) && !multi && !store_cigar && d_perm;
   last_by_place = by_place;
   const bool fused = by_place && fuse_final && emit_by_lanes(v) && !v.tp_mode;
-  if (fused) win_se.reserve((size_t)n_fr * 8);
+  if (by_place) win_se.reserve((size_t)n_fr * 8);
   launch_lookup_count(v, fr, n_fr, transitive, d_perm, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(),
-                      wide_list.as<uint32_t>(), stream, by_place, fused ? win_se.as<int2>() : nullptr);
+                      wide_list.as<uint32_t>(), stream, by_place, by_place ? win_se.as<int2>() : nullptr);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);
   if (P > pair_budget || P >= 0xFFFFFFF0ull) {
     if (split_ok) throw SplitBatch{};
@@ -333,6 +333,8 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   } else if (by_place) {
     launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                        pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true);
+    // (which range owns which places, for the staged projection of a dense level)
+    wlists = WindowLists{nullptr, pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<int2>(), d_perm, n_fr, nullptr};
   } else {
     const uint32_t *d_offp = nullptr;
     projection_offsets(d_perm, n_fr, cnt.as<uint32_t>(), P, d_offp, pl);
@@ -352,7 +354,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   }
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
                  acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity,
-                 store_cigar ? &sl : nullptr, pl, stream, nullptr, regroup_pairs, fused ? &wlists : nullptr);
+                 store_cigar ? &sl : nullptr, pl, stream, nullptr, regroup_pairs, by_place ? &wlists : nullptr);
   if (!raw) {
     post_expand(fr, n_fr, L, pair_off.as<uint32_t>(), pair_entry.as<uint32_t>(), v.mrank, sl);
     h = HitArrays{L.qid.as<uint32_t>(), L.coords.as<int4>()};

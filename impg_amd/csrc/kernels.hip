@@ -954,11 +954,11 @@ __device__ __forceinline__ bool pfx_eval(const PairCtx &c, const PfxTile &t, uin
 // target prefix.  Returns true with (oq, ot) set, or false = take the literal walk.
 // which: the op that answered (storage tile, op within the tile) and its slice adjustment -- the identity filter's inputs
 struct PfxOp { uint32_t j, k; int32_t adj; };
-template <bool NEXT>
+template <bool NEXT, uint32_t LINE_STRIDE = TILE_WORDS>  // LINE_STRIDE: words from one line of the record to the next (LDS copies are padded)
 __device__ __forceinline__ bool pfx_end(const PairCtx &c, const uint32_t *__restrict__ pfx_rec, uint32_t n_ops, uint32_t j,
                                         int32_t thr_abs, bool first_form, int32_t &oq, int32_t &ot, PfxOp &which, uint4 h0) {
   for (bool fresh = true;; fresh = false) {
-    const uint32_t *line = pfx_rec + (size_t)j * TILE_WORDS;
+    const uint32_t *line = pfx_rec + (size_t)j * LINE_STRIDE;
     // T0 | wide << 31, Q0, entry 9, entry 18: the first tile's header is handed in (the caller requests both ends' headers together)
     uint4 h = h0;
     if (!fresh) h = *reinterpret_cast<const uint4 *>(line);
@@ -1047,22 +1047,31 @@ __device__ unsigned long long g_phase_clk[16];
 #define PROJECT_OCCUPANCY
 #endif
 constexpr uint32_t PROJ_BLOCK = IMPG_PROJ_BLOCK, PROJ_WAVES = PROJ_BLOCK / 64u;
+// LDS copies of entries and prefix lines (project_staged_kernel) are padded so that lanes reading the same word of
+// different entries / lines do not meet on one bank: the strides are 4 banks (16 bytes) off a multiple of the 32.
+constexpr uint32_t STG_ENT_STRIDE = 20u;                                   // words per staged entry (16 + 4)
+constexpr uint32_t STG_LINE_STRIDE = TILE_WORDS + 4u;                      // words per staged prefix line
+constexpr uint32_t STG_REC_STRIDE = INLINE_TILES * STG_LINE_STRIDE + 4u;   // words per staged record (8 lines)
 // One (range, entry) pair: project_overlapping_interval's PAF branch (impg.rs:1260-1312) for the range [f_start, f_end)
 // against entry eidx.  ok: the projection exists (and passes the identity filter); qid / res: its query sequence and
 // {q_first, q_last, t_first, t_last}; slice descriptors go to sl[p] under MODE_CIGAR.  Shared by project_kernel (a
 // lane per pair of a level) and the per-query walk kernel (walk_device.inc).
-template <bool TRANSITIVE, int MODE>
+// STAGED (project_staged_kernel): the entry and the record's prefix lines are read from the block's LDS copy
+// (st_entry = the entry's four vectors, st_pfx = the record's first prefix line) instead of from the index.
+template <bool TRANSITIVE, int MODE, bool STAGED = false>
 __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t eidx, int32_t f_start, int32_t f_end, uint32_t p,
                                              double min_identity, uint32_t *__restrict__ err_flag, const SliceArrays &sl,
-                                             unsigned long long *__restrict__ accepted, bool &ok, uint32_t &qid, TileScan &res PHASE_ARG) {
+                                             unsigned long long *__restrict__ accepted, bool &ok, uint32_t &qid, TileScan &res PHASE_ARG,
+                                             const uint4 *st_entry = nullptr, const uint32_t *st_pfx = nullptr) {
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   constexpr bool CIGAR = (MODE & MODE_CIGAR) != 0;
+  static_assert(!STAGED || MODE == 0, "only the plain projection runs on staged lines");
   (void)accepted;
   {
     // Two round trips, not four ahead of the tiles: the indices (and the frontier record) above, then the
     // 64-byte entry (coordinates, record totals, inline checkpoints).  The empty asm statement pins the four
     // reads together -- left alone, the compiler sinks part of them below the entry's "has ops" test.
-    const uint4 *ep = reinterpret_cast<const uint4 *>(v.entries + eidx);
+    const uint4 *ep = STAGED ? st_entry : reinterpret_cast<const uint4 *>(v.entries + eidx);
     FrontierRec f;
     f.start = f_start; f.end = f_end;
     uint4 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
@@ -1173,7 +1182,7 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
           walked = true;
         } else if (!(MODE & MODE_WALK)) {
           // the two ends on the prefix lines (see pfx_end); in storage order a back-to-front entry swaps their roles
-          const uint32_t *pfx_rec = v.pfx + (size_t)e1.y * TILE_WORDS;
+          const uint32_t *pfx_rec = STAGED ? st_pfx : v.pfx + (size_t)e1.y * TILE_WORDS;
           bool lit = cB == 0u;  // no tile starts at or before last_target_pos: let the literal walk say so
           const uint32_t kL = cB ? cB - 1u : 0u;  // effective tile of the last op that starts at or before it
           int32_t fq = 0, ft = c.ts, lq = (int32_t)c.totQ, lt = en_te;  // the shortcuts' answers
@@ -1188,20 +1197,21 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
           const bool run1 = !lit && (c.flip ? do_last : do_first), run2 = !lit && (c.flip ? do_first : do_last);
           const uint32_t j1 = orig_tile(c, c.flip ? kL : kA), j2 = orig_tile(c, c.flip ? kA : kL);
           uint4 hd1 = make_uint4(0u, 0u, 0u, 0u), hd2 = make_uint4(0u, 0u, 0u, 0u);
-          if (run1) hd1 = *reinterpret_cast<const uint4 *>(pfx_rec + (size_t)j1 * TILE_WORDS);
-          if (run2) hd2 = *reinterpret_cast<const uint4 *>(pfx_rec + (size_t)j2 * TILE_WORDS);
+          constexpr uint32_t LSTRIDE = STAGED ? STG_LINE_STRIDE : TILE_WORDS;
+          if (run1) hd1 = *reinterpret_cast<const uint4 *>(pfx_rec + (size_t)j1 * LSTRIDE);
+          if (run2) hd2 = *reinterpret_cast<const uint4 *>(pfx_rec + (size_t)j2 * LSTRIDE);
           asm volatile("" : "+v"(hd1.x), "+v"(hd1.y), "+v"(hd1.z), "+v"(hd1.w), "+v"(hd2.x), "+v"(hd2.y), "+v"(hd2.z), "+v"(hd2.w));
           PHASE_MARK(4);
           if (run1) {
             int32_t oq, ot;
-            const bool okc = pfx_end<true>(c, pfx_rec, n, j1, c.flip ? (int32_t)c.totT - xb : xa, !c.flip, oq, ot, lo_op, hd1);
+            const bool okc = pfx_end<true, LSTRIDE>(c, pfx_rec, n, j1, c.flip ? (int32_t)c.totT - xb : xa, !c.flip, oq, ot, lo_op, hd1);
             lit = !okc;
             if (c.flip) { lq = oq; lt = ot; } else { fq = oq; ft = ot; }
           }
           PHASE_MARK(5);
           if (run2 && !lit) {
             int32_t oq, ot;
-            const bool okc = pfx_end<false>(c, pfx_rec, n, j2, (c.flip ? (int32_t)c.totT - xa : xb) + 1, c.flip, oq, ot, hi_op, hd2);
+            const bool okc = pfx_end<false, LSTRIDE>(c, pfx_rec, n, j2, (c.flip ? (int32_t)c.totT - xa : xb) + 1, c.flip, oq, ot, hi_op, hd2);
             lit = !okc;
             if (c.flip) { fq = oq; ft = ot; } else { lq = oq; lt = ot; }
           }
@@ -1209,7 +1219,7 @@ __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t 
           if (IDENT && !lit && (c.flip ? !do_first : !do_last)) {
             // The upper end came from a shortcut, so no search looked at the record's last tile: if that tile is `wide`
             // its identity line's 16-bit fields do not hold its sums (a 70000= op) -- literal walk, as pfx_end would say.
-            lit = (pfx_rec[(size_t)(c.m - 1u) * TILE_WORDS] >> 31) != 0u;
+            lit = (pfx_rec[(size_t)(c.m - 1u) * LSTRIDE] >> 31) != 0u;
           }
           if (IDENT && !lit) {
             // The slice [first op, last op] in storage order is [lo_op, hi_op]: its matched / mismatched bases and gap ops
@@ -1391,6 +1401,117 @@ __device__ __forceinline__ uint32_t select_bit64(uint32_t lo, uint32_t hi, uint3
   c = (uint32_t)__popc(w & 0x3u);    if (k >= c) { k -= c; w >>= 2; base += 2u; }
   return base + (k >= (w & 1u) ? 1u : 0u);
 }
+// One place of the projection order -> its pair.  live: the place holds a pair; p: the pair's slot.
+struct PairIn {
+  uint32_t eidx, p;
+  int32_t f_start, f_end;
+  uint32_t live;  // (a word, not a bool: copies of the struct then move no padding bytes -- the compiler took those through scratch)
+};
+// LDS a block needs for pair_of_place (WindowLists form) and regroup_by_entry
+constexpr uint32_t PROJ_WL_WORDS = 65u + 3u;                                   // place offsets of 65 ranges (+ padding to 16 bytes)
+constexpr uint32_t PROJ_RG_WORDS = PROJ_BLOCK + 4u * PROJ_BLOCK + PROJ_WAVES + (4u - PROJ_WAVES % 4u) % 4u;  // payload, histogram, wave sums
+// The pair at place pp of tile `lblock` (a tile = PROJ_BLOCK consecutive places; every thread of the block calls this
+// together: the WindowLists form goes through LDS and barriers).
+__device__ __forceinline__ PairIn pair_of_place(uint32_t pp, uint32_t lblock, uint32_t n_pairs, const FrontierRec *__restrict__ fr,
+                                                const uint32_t *__restrict__ pair_range, const uint32_t *__restrict__ pair_entry,
+                                                const ProjList &pl, const WindowLists &wl, uint32_t *wl_off /* LDS, PROJ_WL_WORDS */) {
+  PairIn x;
+  x.live = pp < n_pairs;
+  x.p = pp; x.eidx = 0xFFFFFFFFu; x.f_start = 0; x.f_end = 0;
+  uint32_t r = 0;
+  // (in projection order the pair's range and entry are listed next to its slot: three coalesced reads)
+  if (wl.tile_first && lblock * PROJ_BLOCK >= n_pairs) {
+    // (a tile past the list: the grid is rounded up)
+  } else if (wl.tile_first) {
+    // The pairs of this tile straight from the count pass's per-range records (WindowLists, kernels.hpp): which
+    // range holds place pp (a search over the place offsets of the <= 64 ranges from the tile's first one on, in
+    // LDS; more of them only where ranges without hits pile up), then the (pp - offset)-th set bit of its hit mask.
+    const uint32_t pp_last = min(lblock * PROJ_BLOCK + PROJ_BLOCK, n_pairs) - 1u;
+    uint32_t base_i = wl.tile_first[lblock], ri = 0, k = 0;
+    bool found = !x.live;
+    for (;;) {
+      if (threadIdx.x < 65u) wl_off[threadIdx.x] = base_i + threadIdx.x < wl.n_fr ? wl.pair_off[base_i + threadIdx.x] : 0xFFFFFFFFu;
+      __syncthreads();
+      const uint32_t lim = wl_off[64];
+      if (!found && pp < lim) {
+        uint32_t j = 0;  // the last of the 64 with offset <= pp (ranges without hits share their successor's offset: the last one holds the place)
+#pragma unroll
+        for (uint32_t st = 32u; st > 0u; st >>= 1) j += wl_off[j + st] <= pp ? st : 0u;
+        ri = base_i + j;
+        k = pp - wl_off[j];
+        found = true;
+      }
+      __syncthreads();
+      if (lim > pp_last) break;
+      base_i += 64u;
+    }
+    if (x.live) {
+      const uint4 w = wl.win[ri];
+      const int2 se = wl.se[ri];
+      x.f_start = se.x; x.f_end = se.y;
+      if (w.y - (w.x & ~3u) > 64u) x.eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
+      else x.eidx = w.x + select_bit64(w.z, w.w, k);
+      if (wl.range_out) wl.range_out[pp] = wl.perm[ri];
+    }
+  } else if (x.live) {
+    if (pl.slot) { x.p = pl.slot[pp]; r = pl.range[pp]; x.eidx = pl.entry[pp]; }
+    else { r = pair_range[pp]; x.eidx = pair_entry[pp]; }
+    asm volatile("" : "+v"(r), "+v"(x.eidx));
+    const FrontierRec f = fr[r];
+    x.f_start = f.start; x.f_end = f.end;
+  }
+  return x;
+}
+// The block's 256 pairs, regrouped by entry before anything of the index is read.  In projection order
+// neighbouring lanes are the hits of ONE range on different entries: every lane reads its own entry line and
+// its own tile lines.  The ranges of a block are neighbours in the lookup order and hit largely the same
+// entries, so sorted by entry a wave's lanes share a handful of lines.  A counting sort in LDS, one bin per
+// thread; results are stored at the pair's own slot, so which lane projects which pair changes nothing downstream.
+// (bin = entry mod the block size: equal entries share a bin and neighbours sit in neighbouring bins, which is all the
+// grouping is for -- the block's entries span fewer than 256 places but for a rare wide block, where bins then
+// mix two entries.  The round-3 form binned by `entry - the block's smallest entry`: a wave reduction, an LDS round
+// and a barrier more.)
+template <uint32_t NB>  // threads of the block = pairs regrouped together
+__device__ __forceinline__ void regroup_by_entry(PairIn &x, uint32_t *scratch /* LDS, 5 * NB + NB / 64 words, 16-byte aligned */) {
+  uint4 *rg_pay = reinterpret_cast<uint4 *>(scratch);
+  uint32_t *rg_hist = scratch + 4u * NB, *rg_ws = rg_hist + NB;
+  rg_hist[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t bin = x.eidx & (NB - 1u);  // (a place beyond the list carries entry ~0: the last bin)
+  const uint32_t pos = atomicAdd(&rg_hist[bin], 1u);
+  __syncthreads();
+  {  // bin starts: exclusive scan of the counts over the block (one barrier for the waves' sums, one for the starts)
+    const uint32_t cnt = rg_hist[threadIdx.x], inc = wave_incl_scan(cnt);
+    if (lane_id() == 63u) rg_ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (uint32_t k = 0; k + 1u < NB / 64u; k++) base += k < (threadIdx.x >> 6) ? rg_ws[k] : 0u;
+    rg_hist[threadIdx.x] = base + inc - cnt;
+  }
+  __syncthreads();
+  rg_pay[rg_hist[bin] + pos] = make_uint4(x.eidx, x.p, (uint32_t)x.f_start, (uint32_t)x.f_end);
+  __syncthreads();
+  const uint4 mine = rg_pay[threadIdx.x];
+  x.eidx = mine.x; x.p = mine.y; x.f_start = (int32_t)mine.z; x.f_end = (int32_t)mine.w;
+  x.live = x.eidx != 0xFFFFFFFFu;
+}
+// accepted-projection count: one atomic per BLOCK, spread over COUNT_SLOTS
+// cache lines (a single hot word caps the whole chip at ~90 atomics/us)
+template <uint32_t NW>  // waves of the block
+__device__ __forceinline__ void count_accepted(uint32_t mine, unsigned long long *__restrict__ accepted, uint32_t *wcnt /* LDS, NW */) {
+  uint32_t w = mine;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
+  if (lane_id() == 0) wcnt[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < NW; k++) tot += wcnt[k];
+    if (tot) atomicAdd(&accepted[(blockIdx.x % COUNT_SLOTS) * COUNT_STRIDE], (unsigned long long)tot);
+  }
+}
 // (Round 4, measured and dropped: one block working through 8 consecutive tiles as a two-stage pipeline -- the next
 // tile's list entries and frontier records in flight under the current tile's projection.  s_memtime at the dependency
 // boundaries (-DIMPG_PHASE_CLOCKS, scripts/phase_clocks.py) had shown a wave waiting 3 400 of its 17 900 cycles for those
@@ -1422,107 +1543,22 @@ __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(D
   res.found = res.any = false;
   res.pqs = res.pts = res.pqe = res.pte = -1;
   uint32_t qid = HIT_NONE;
-  // (in projection order the pair's range and entry are listed next to its slot: three coalesced reads)
-  bool live = pp < n_pairs;
-  uint32_t p = pp, r = 0, eidx = 0xFFFFFFFFu;
-  int32_t f_start = 0, f_end = 0;
-  if (wl.tile_first && lblock * PROJ_BLOCK >= n_pairs) {
-    // (a block past the list: the grid is rounded up to the 8 XCDs)
-  } else if (wl.tile_first) {
-    // The pairs of this tile straight from the count pass's per-range records (WindowLists, kernels.hpp): which
-    // range holds place pp (a search over the place offsets of the <= 64 ranges from the tile's first one on, in
-    // LDS; more of them only where ranges without hits pile up), then the (pp - offset)-th set bit of its hit mask.
-    __shared__ uint32_t wl_off[65];
-    const uint32_t pp_last = min(lblock * PROJ_BLOCK + PROJ_BLOCK, n_pairs) - 1u;
-    uint32_t base_i = wl.tile_first[lblock], ri = 0, k = 0;
-    bool found = !live;
-    for (;;) {
-      if (threadIdx.x < 65u) wl_off[threadIdx.x] = base_i + threadIdx.x < wl.n_fr ? wl.pair_off[base_i + threadIdx.x] : 0xFFFFFFFFu;
-      __syncthreads();
-      const uint32_t lim = wl_off[64];
-      if (!found && pp < lim) {
-        uint32_t j = 0;  // the last of the 64 with offset <= pp (ranges without hits share their successor's offset: the last one holds the place)
-#pragma unroll
-        for (uint32_t st = 32u; st > 0u; st >>= 1) j += wl_off[j + st] <= pp ? st : 0u;
-        ri = base_i + j;
-        k = pp - wl_off[j];
-        found = true;
-      }
-      __syncthreads();
-      if (lim > pp_last) break;
-      base_i += 64u;
-    }
-    if (live) {
-      const uint4 w = wl.win[ri];
-      const int2 se = wl.se[ri];
-      f_start = se.x; f_end = se.y;
-      if (w.y - (w.x & ~3u) > 64u) eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
-      else eidx = w.x + select_bit64(w.z, w.w, k);
-      if (wl.range_out) wl.range_out[pp] = wl.perm[ri];
-    }
-  } else if (live) {
-    if (pl.slot) { p = pl.slot[pp]; r = pl.range[pp]; eidx = pl.entry[pp]; }
-    else { r = pair_range[pp]; eidx = pair_entry[pp]; }
-    asm volatile("" : "+v"(r), "+v"(eidx));
-    const FrontierRec f = fr[r];
-    f_start = f.start; f_end = f.end;
-  }
+  __shared__ uint32_t wl_off[PROJ_WL_WORDS];
+  __shared__ uint4 rg_scratch[PROJ_RG_WORDS / 4u];
+  __shared__ uint32_t wcnt[PROJ_WAVES];
+  PairIn x = pair_of_place(pp, lblock, n_pairs, fr, pair_range, pair_entry, pl, wl, wl_off);
   PHASE_MARK(1);
-  if (regroup) {
-    // The block's 256 pairs, regrouped by entry before anything of the index is read.  In projection order
-    // neighbouring lanes are the hits of ONE range on different entries: every lane reads its own entry line and
-    // its own tile lines.  The ranges of a block are neighbours in the lookup order and hit largely the same
-    // entries, so sorted by entry a wave's lanes share a handful of lines.  A counting sort in LDS, one bin per
-    // thread; results are stored at the pair's own slot, so which lane projects which pair changes nothing downstream.
-    // (bin = entry mod the block size: equal entries share a bin and neighbours sit in neighbouring bins, which is all the
-    // grouping is for -- the block's entries span fewer than 256 places but for a rare wide block, where bins then
-    // mix two entries.  The round-3 form binned by `entry - the block's smallest entry`: a wave reduction, an LDS round
-    // and a barrier more.)
-    __shared__ uint32_t rg_hist[PROJ_BLOCK];
-    __shared__ uint32_t rg_ws[PROJ_WAVES];
-    __shared__ uint4 rg_pay[PROJ_BLOCK];
-    rg_hist[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t bin = eidx & (PROJ_BLOCK - 1u);  // (a place beyond the list carries entry ~0: the last bin)
-    const uint32_t pos = atomicAdd(&rg_hist[bin], 1u);
-    __syncthreads();
-    {  // bin starts: exclusive scan of the counts over the block (one barrier for the waves' sums, one for the starts)
-      const uint32_t cnt = rg_hist[threadIdx.x], inc = wave_incl_scan(cnt);
-      if (lane_id() == 63u) rg_ws[threadIdx.x >> 6] = inc;
-      __syncthreads();
-      uint32_t base = 0;
-#pragma unroll
-      for (uint32_t k = 0; k + 1u < PROJ_WAVES; k++) base += k < (threadIdx.x >> 6) ? rg_ws[k] : 0u;
-      rg_hist[threadIdx.x] = base + inc - cnt;
-    }
-    __syncthreads();
-    rg_pay[rg_hist[bin] + pos] = make_uint4(eidx, p, (uint32_t)f_start, (uint32_t)f_end);
-    __syncthreads();
-    const uint4 mine = rg_pay[threadIdx.x];
-    eidx = mine.x; p = mine.y; f_start = (int32_t)mine.z; f_end = (int32_t)mine.w;
-    live = eidx != 0xFFFFFFFFu;
-  }
+  if (regroup) regroup_by_entry<PROJ_BLOCK>(x, reinterpret_cast<uint32_t *>(rg_scratch));
   PHASE_MARK(2);
-  if (live) {
-    project_pair<TRANSITIVE, MODE>(v, eidx, f_start, f_end, p, min_identity, err_flag, sl, accepted, ok, qid, res PHASE_PASS);
-    h.qid[p] = qid;
+  if (x.live) {
+    project_pair<TRANSITIVE, MODE>(v, x.eidx, x.f_start, x.f_end, x.p, min_identity, err_flag, sl, accepted, ok, qid, res PHASE_PASS);
+    h.qid[x.p] = qid;
     if (ok) {
-      h.c[p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+      h.c[x.p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
     }
   }
   PHASE_MARK(7);
-  // accepted-projection count: one atomic per BLOCK, spread over COUNT_SLOTS
-  // cache lines (a single hot word caps the whole chip at ~90 atomics/us)
-  __shared__ uint32_t wcnt[PROJ_WAVES];
-  unsigned long long m = __ballot(ok);
-  if (lane_id() == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < PROJ_WAVES; k++) tot += wcnt[k];
-    if (tot) atomicAdd(&accepted[(blockIdx.x % COUNT_SLOTS) * COUNT_STRIDE], (unsigned long long)tot);
-  }
+  count_accepted<PROJ_WAVES>(ok ? 1u : 0u, accepted, wcnt);
 #ifdef IMPG_PHASE_CLOCKS
   PHASE_MARK(8);
   if ((blockIdx.x & 63u) == 0u && lane_id() == 0u && phase_t[3] && phase_t[4] && phase_t[5] && phase_t[6]) {
@@ -1531,6 +1567,205 @@ __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(D
   }
 #endif
 }
+
+// ---------------------------------------------------------------------------
+// The plain projection with the block's entries and prefix lines STAGED IN LDS (round 4).
+//
+// Where a level is dense -- the final level of the headline batch lists 2 x 10^9 pairs on 2 x 10^6 entries: every entry
+// is hit by a thousand ranges, and in the lookup order those ranges are neighbours -- the per-pair reads of
+// project_kernel fetch the same 64-byte entries and 128-byte prefix lines over and over through the vector-memory
+// path (192 bytes per pair in un-coalesced 16-byte reads; that path, not HBM and not the ALUs, is what bounds it).
+// Here one block takes STG_TILES consecutive tiles of the projection order (2 048 places: ~80 ranges, whose windows
+// overlap almost completely), copies the entries they span and those entries' prefix lines into LDS once -- coalesced
+// 16-byte reads, ~25 bytes per pair -- and every pair then runs the same search (project_pair<.., STAGED>) on LDS: no
+// regrouping, and lanes keep the place order, so the result stores of a wave are one contiguous piece.
+// A block whose places span more than STG_ECAP entries (sparse levels, segment borders) runs its tiles the way
+// project_kernel does; a pair whose record has more than INLINE_TILES prefix lines reads them from the index.
+// launch_project picks this kernel when the level averages >= IMPG_STAGE_DENSITY pairs per index entry.
+// ---------------------------------------------------------------------------
+#ifndef IMPG_STG_THREADS
+#define IMPG_STG_THREADS 512
+#endif
+#ifndef IMPG_STG_RANGES
+#define IMPG_STG_RANGES 256
+#endif
+#ifndef IMPG_STG_ECAP
+#define IMPG_STG_ECAP 56
+#endif
+constexpr uint32_t STG_THREADS = IMPG_STG_THREADS, STG_WAVES = STG_THREADS / 64u;
+constexpr uint32_t STG_RANGES = IMPG_STG_RANGES;                       // ranges (consecutive in the lookup order) per block
+constexpr uint32_t STG_ECAP = IMPG_STG_ECAP;                           // entries staged per block
+constexpr uint32_t STG_ENT_V4 = STG_ECAP * STG_ENT_STRIDE / 4u;       // entries: 4 vectors each (+ padding)
+constexpr uint32_t STG_LINE_V4 = STG_ECAP * STG_REC_STRIDE / 4u;       // prefix lines: 8 lines of 8 vectors per entry (+ padding)
+static_assert((STG_RANGES & (STG_RANGES - 1u)) == 0u && STG_RANGES < STG_THREADS && STG_THREADS % 64u == 0, "a thread per range, whole waves");
+static_assert(STG_LINE_V4 * 4u >= 5u * STG_THREADS + STG_WAVES, "the unstaged path's scratch overlays the line buffer");
+static_assert(STG_ECAP * 4u <= STG_THREADS, "one pass copies the entries");
+#ifdef IMPG_STG_WAVES  // (experiments: force the register allocation that gives this many waves per SIMD)
+#define STG_OCCUPANCY __attribute__((amdgpu_waves_per_eu(IMPG_STG_WAVES, IMPG_STG_WAVES)))
+#else
+#define STG_OCCUPANCY
+#endif
+// MASKS: the level's pairs are named by the count pass's hit masks (WindowLists with tile_first, a counting run's final
+// level); else by the emit pass's list pair_entry[place] (slots by place, kernels.hpp).  Either way a block takes
+// STG_RANGES consecutive ranges of the lookup order and all their places -- wl.pair_off[], the windows and the
+// ranges' (start, end) go to LDS first, so a place finds its range, its entry and the range's ends without leaving the CU.
+template <bool TRANSITIVE, bool MASKS>
+__global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry,
+                                                      uint32_t n_pairs, HitArrays h, unsigned long long *__restrict__ accepted,
+                                                      uint32_t *__restrict__ err_flag, int regroup, WindowLists wl) {
+  // (XCD-contiguous mapping as in project_kernel)
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t sblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  __shared__ uint4 st_ent[STG_ENT_V4];
+  __shared__ uint4 st_line[STG_LINE_V4];
+  __shared__ uint4 st_win[STG_RANGES];
+  __shared__ int2 st_se[STG_RANGES];
+  __shared__ uint32_t st_off[STG_RANGES + 4u];
+  __shared__ uint32_t wred[2u * STG_WAVES];
+  __shared__ uint32_t wcnt[STG_WAVES];
+  const uint32_t r0 = sblock * STG_RANGES;
+  if (r0 >= wl.n_fr) return;  // (block-uniform: the grid is rounded up to the 8 XCDs)
+  const uint32_t nr = min(STG_RANGES, wl.n_fr - r0);
+#ifdef IMPG_PHASE_CLOCKS
+  unsigned long long stg_t[8], phase_t[10];
+#define STG_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stg_t[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STG_MARK(i) do { } while (0)
+#endif
+  STG_MARK(0);
+  // the block's ranges: place offsets, windows, ends; and the span of entries their hits lie in
+  uint32_t emin = 0xFFFFFFFFu, emax = 0u;
+  if (threadIdx.x <= STG_RANGES) {
+    uint32_t o = 0xFFFFFFFFu;
+    if (threadIdx.x < nr) o = wl.pair_off[r0 + threadIdx.x];
+    else if (threadIdx.x == nr) o = r0 + nr < wl.n_fr ? wl.pair_off[r0 + nr] : n_pairs;
+    st_off[threadIdx.x] = o;
+    if (threadIdx.x < nr) {
+      const uint4 w = wl.win[r0 + threadIdx.x];
+      st_win[threadIdx.x] = w;
+      st_se[threadIdx.x] = wl.se[r0 + threadIdx.x];
+      if (w.y - (w.x & ~3u) > 64u) { emin = w.x; emax = w.y - 1u; }  // (a window wider than the mask: its hits lie somewhere in it)
+      else if (w.z | w.w) {
+        emin = w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w));
+        emax = w.x + (w.w ? 63u - (uint32_t)__builtin_clz(w.w) : 31u - (uint32_t)__builtin_clz(w.z));
+      }
+    }
+  }
+  {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      emin = min(emin, (uint32_t)__shfl_xor((int)emin, o));
+      emax = max(emax, (uint32_t)__shfl_xor((int)emax, o));
+    }
+    if (lane_id() == 0) { wred[threadIdx.x >> 6] = emin; wred[STG_WAVES + (threadIdx.x >> 6)] = emax; }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < STG_WAVES; k++) { emin = min(emin, wred[k]); emax = max(emax, wred[STG_WAVES + k]); }
+  }
+  const uint32_t P0 = st_off[0], P1 = st_off[nr];
+  const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
+  uint32_t n_ok = 0;
+  STG_MARK(1);
+  // a sparse stretch of the level (its hits spread over many more entries than can be staged): nothing is staged, the
+  // pairs are regrouped by entry and read the index as in project_kernel (the scratch overlays the line buffer)
+  const bool sparse = emin <= emax && emax - emin >= 4u * STG_ECAP;
+  uint32_t n_e = 0;
+  if (emin <= emax && !sparse) {
+    // stage 1: the entries emin .. emin + n_e - 1, four 16-byte vectors each
+    n_e = min(STG_ECAP, emax - emin + 1u);
+    if (threadIdx.x < n_e * 4u) st_ent[(threadIdx.x >> 2) * (STG_ENT_STRIDE / 4u) + (threadIdx.x & 3u)] = reinterpret_cast<const uint4 *>(v.entries + emin)[threadIdx.x];
+    __syncthreads();
+    // stage 2: their records' prefix lines, a wave per entry and turn, a lane per 16-byte piece of the record's <= 8 lines
+    const uint32_t w = threadIdx.x >> 6, l = lane_id();
+    constexpr uint32_t TURNS = (STG_ECAP + STG_WAVES - 1u) / STG_WAVES;
+    uint4 buf[TURNS];
+#pragma unroll
+    for (uint32_t k = 0; k < TURNS; k++) {
+      const uint32_t i = w + k * STG_WAVES;
+      buf[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < n_e) {
+        const uint4 e1 = st_ent[i * (STG_ENT_STRIDE / 4u) + 1u];
+        const uint32_t n = e1.z & OP_LEN_MASK, m = (n + TILE_OPS - 1u) / TILE_OPS;
+        if (m <= INLINE_TILES && (l >> 3) < m) buf[k] = reinterpret_cast<const uint4 *>(v.pfx + (size_t)e1.y * TILE_WORDS)[l];
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < TURNS; k++) {
+      const uint32_t i = w + k * STG_WAVES;
+      if (i < n_e) st_line[i * (STG_REC_STRIDE / 4u) + (l >> 3) * (STG_LINE_STRIDE / 4u) + (l & 7u)] = buf[k];
+    }
+    __syncthreads();
+  }
+  STG_MARK(2);
+  // the block's places, a turn of STG_THREADS at a time (pair lists: the next turn's entry is requested a turn ahead)
+  uint32_t e_next = 0xFFFFFFFFu;
+  if (!MASKS && (unsigned long long)P0 + threadIdx.x < P1) e_next = pair_entry[P0 + threadIdx.x];
+#pragma unroll 1
+  for (uint32_t base = P0; base < P1; base += STG_THREADS) {
+    if (base + STG_THREADS < base) break;  // (cannot happen: n_pairs stays 16 below 2^32 and P1 <= n_pairs)
+    const uint32_t pp = base + threadIdx.x;
+    PairIn y;
+    y.live = pp < P1 ? 1u : 0u;
+    y.p = pp; y.eidx = 0xFFFFFFFFu; y.f_start = 0; y.f_end = 0;
+    // the place's range: the last one with offset <= pp (ranges without hits share their successor's offset)
+    uint32_t j = 0;
+#pragma unroll
+    for (uint32_t st = STG_RANGES / 2u; st > 0u; st >>= 1) j += st_off[j + st] <= pp ? st : 0u;
+    if (y.live) {
+      const int2 se = st_se[j];
+      y.f_start = se.x; y.f_end = se.y;
+      if (MASKS) {
+        const uint4 w = st_win[j];
+        if (w.y - (w.x & ~3u) > 64u) y.eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
+        else y.eidx = w.x + select_bit64(w.z, w.w, pp - st_off[j]);
+        if (wl.range_out) wl.range_out[pp] = wl.perm[r0 + j];
+      } else {
+        y.eidx = e_next;
+      }
+    }
+    if (!MASKS) {
+      e_next = 0xFFFFFFFFu;
+      if ((unsigned long long)pp + STG_THREADS < P1) e_next = pair_entry[pp + STG_THREADS];
+    }
+    if (sparse && regroup) regroup_by_entry<STG_THREADS>(y, reinterpret_cast<uint32_t *>(st_line));
+    if (y.live) {
+      bool ok = false;
+      TileScan res;
+      res.found = res.any = false;
+      res.pqs = res.pts = res.pqe = res.pte = -1;
+      uint32_t qid = HIT_NONE;
+      const uint32_t slot = y.eidx - emin;
+      const uint4 *se = st_ent + min(slot, STG_ECAP - 1u) * (STG_ENT_STRIDE / 4u);
+      if (slot < n_e && (se[1].z & OP_LEN_MASK) <= INLINE_TILES * TILE_OPS)
+        project_pair<TRANSITIVE, 0, true>(v, y.eidx, y.f_start, y.f_end, y.p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, se,
+                                          reinterpret_cast<const uint32_t *>(st_line + slot * (STG_REC_STRIDE / 4u)));
+      else  // an entry beyond the staged span, or a record with more prefix lines than a staged record holds
+        project_pair<TRANSITIVE, 0>(v, y.eidx, y.f_start, y.f_end, y.p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
+      h.qid[y.p] = qid;
+      if (ok) h.c[y.p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+      n_ok += ok ? 1u : 0u;
+    }
+    if (sparse && regroup) __syncthreads();  // (the next turn's regrouping reuses the scratch)
+  }
+#ifdef IMPG_PHASE_CLOCKS
+  STG_MARK(3);
+  if ((blockIdx.x & 15u) == 0u && threadIdx.x == 0u) {
+    if (sparse) {
+      atomicAdd(&g_phase_clk[13], stg_t[3] - stg_t[0]);
+      atomicAdd(&g_phase_clk[14], 1ull);
+      atomicAdd(&g_phase_clk[12], (unsigned long long)(emax - emin));
+    } else {
+      for (int i = 0; i < 3; i++) atomicAdd(&g_phase_clk[i], stg_t[i + 1] - stg_t[i]);
+      atomicAdd(&g_phase_clk[9], (unsigned long long)(P1 - P0));
+      atomicAdd(&g_phase_clk[10], emin <= emax && emax - emin >= STG_ECAP ? 1ull : 0ull);
+      atomicAdd(&g_phase_clk[15], 1ull);
+      atomicAdd(&g_phase_clk[11], emin <= emax ? (unsigned long long)(emax - emin + 1u) : 0ull);
+    }
+  }
+#endif
+  count_accepted<STG_WAVES>(n_ok, accepted, wcnt);
+}
+#undef STG_MARK
 #ifdef IMPG_PHASE_CLOCKS
 extern "C" void impg_gpu_debug_phase_clocks(unsigned long long *out) {
   unsigned long long z[16] = {};
@@ -3228,6 +3463,19 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
   const int xcd_map = 1;
   const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};
   const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0) | (two_walks ? MODE_WALK : 0);
+  // A dense level -- many pairs per index entry -- runs with the entries and prefix lines staged in LDS
+  // (project_staged_kernel); IMPG_STAGE_DENSITY = pairs per entry from which on (default 32; 0 = always, < 0 = never)
+  static const double stage_density = [] { const char *e = getenv("IMPG_STAGE_DENSITY"); return e ? atof(e) : 32.0; }();
+  if (mode == 0 && v.pfx && !n_pairs_dev && wl.pair_off && wl.se && !pl.slot && stage_density >= 0.0 &&
+      (double)n_pairs >= stage_density * (double)v.n_entries) {
+    const uint32_t gs = (cdiv(wl.n_fr, STG_RANGES) + 7u) & ~7u;
+    const bool masks = wl.tile_first != nullptr;
+#define IMPG_LAUNCH_STG(T, M) project_staged_kernel<T, M><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl)
+    if (transitive) { if (masks) IMPG_LAUNCH_STG(true, true); else IMPG_LAUNCH_STG(true, false); }
+    else { if (masks) IMPG_LAUNCH_STG(false, true); else IMPG_LAUNCH_STG(false, false); }
+#undef IMPG_LAUNCH_STG
+    return;
+  }
 #define IMPG_LAUNCH(T, M) project_kernel<T, M><<<g, PROJ_BLOCK, 0, s>>>(v, fr, pair_range, pair_entry, n_pairs, h, accepted, err_flag, ident ? min_identity : 0.0, sl, pl, xcd_map, n_pairs_dev, rg, wl)
   if (transitive) {
     switch (mode) { case 0: IMPG_LAUNCH(true, 0); break; case 1: IMPG_LAUNCH(true, 1); break;

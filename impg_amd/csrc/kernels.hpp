@@ -58,8 +58,10 @@ void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32
 // level's slots by position or in order, so the projection kernel takes its pairs straight from what the count pass
 // left per range -- place offset, window, hit mask -- and the emit pass with its two 4-byte-per-pair lists is not run
 // (only the windows wider than 64 entries, which the wave-per-range emit still lists in pair_entry).
+// (With tile_first null but the rest set -- any level whose slots follow the lookup order -- the struct only tells
+// project_staged_kernel which ranges own which places; the pairs' entries then come from the emit pass's list.)
 struct WindowLists {
-  const uint32_t *tile_first;  // [tiles of PROJ_BLOCK places] the range (by place in the lookup order) that holds the tile's first place; null = off
+  const uint32_t *tile_first;  // [tiles of PROJ_BLOCK places] the range (by place in the lookup order) that holds the tile's first place; null = the pairs are listed
   const uint32_t *pair_off;    // [n_fr] first place of every range's pairs
   const uint4 *win;            // [n_fr] {lo, ub, hit mask of the first 64 window entries}
   const int2 *se;              // [n_fr] the range's (start, end)

@@ -1058,32 +1058,48 @@ constexpr uint32_t STG_REC_STRIDE = INLINE_TILES * STG_LINE_STRIDE + 4u;   // wo
 // lane per pair of a level) and the per-query walk kernel (walk_device.inc).
 // STAGED (project_staged_kernel): the entry and the record's prefix lines are read from the block's LDS copy
 // (st_entry = the entry's four vectors, st_pfx = the record's first prefix line) instead of from the index.
+// ORIENT (project_entries_kernel: a wave works on ONE entry, whose words sit in scalar registers): the entry's
+// orientation as a compile-time constant -- 0 = a forward entry, 1 = a reversed entry walked front to back, 2 = a
+// reversed entry of a reverse-strand record, walked back to front; -1 = read from the entry's flags.  With it every
+// `swp ? a : b` / `flip ? a : b` below folds away.
+template <bool TRANSITIVE, int MODE, bool STAGED, int ORIENT>
+__device__ __forceinline__ void project_core(const DeviceIndexView &v, uint4 e0, uint4 e1, uint4 e2, uint4 e3, int32_t f_start, int32_t f_end,
+                                             uint32_t p, double min_identity, uint32_t *__restrict__ err_flag, const SliceArrays &sl,
+                                             unsigned long long *__restrict__ accepted, bool &ok, uint32_t &qid, TileScan &res PHASE_ARG,
+                                             const uint32_t *st_pfx);
 template <bool TRANSITIVE, int MODE, bool STAGED = false>
 __device__ __forceinline__ void project_pair(const DeviceIndexView &v, uint32_t eidx, int32_t f_start, int32_t f_end, uint32_t p,
                                              double min_identity, uint32_t *__restrict__ err_flag, const SliceArrays &sl,
                                              unsigned long long *__restrict__ accepted, bool &ok, uint32_t &qid, TileScan &res PHASE_ARG,
                                              const uint4 *st_entry = nullptr, const uint32_t *st_pfx = nullptr) {
+  // Two round trips, not four ahead of the tiles: the indices (and the frontier record) above, then the
+  // 64-byte entry (coordinates, record totals, inline checkpoints).  The empty asm statement pins the four
+  // reads together -- left alone, the compiler sinks part of them below the entry's "has ops" test.
+  const uint4 *ep = STAGED ? st_entry : reinterpret_cast<const uint4 *>(v.entries + eidx);
+  uint4 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
+  asm volatile("" : "+v"(e0.x), "+v"(e1.z), "+v"(e2.x), "+v"(e3.x));
+  PHASE_MARK(3);
+  project_core<TRANSITIVE, MODE, STAGED, -1>(v, e0, e1, e2, e3, f_start, f_end, p, min_identity, err_flag, sl, accepted, ok, qid, res PHASE_PASS, st_pfx);
+}
+template <bool TRANSITIVE, int MODE, bool STAGED, int ORIENT>
+__device__ __forceinline__ void project_core(const DeviceIndexView &v, uint4 e0, uint4 e1, uint4 e2, uint4 e3, int32_t f_start, int32_t f_end,
+                                             uint32_t p, double min_identity, uint32_t *__restrict__ err_flag, const SliceArrays &sl,
+                                             unsigned long long *__restrict__ accepted, bool &ok, uint32_t &qid, TileScan &res PHASE_ARG,
+                                             const uint32_t *st_pfx) {
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   constexpr bool CIGAR = (MODE & MODE_CIGAR) != 0;
   static_assert(!STAGED || MODE == 0, "only the plain projection runs on staged lines");
   (void)accepted;
   {
-    // Two round trips, not four ahead of the tiles: the indices (and the frontier record) above, then the
-    // 64-byte entry (coordinates, record totals, inline checkpoints).  The empty asm statement pins the four
-    // reads together -- left alone, the compiler sinks part of them below the entry's "has ops" test.
-    const uint4 *ep = STAGED ? st_entry : reinterpret_cast<const uint4 *>(v.entries + eidx);
     FrontierRec f;
     f.start = f_start; f.end = f_end;
-    uint4 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
-    asm volatile("" : "+v"(e0.x), "+v"(e1.z), "+v"(e2.x), "+v"(e3.x));
-    PHASE_MARK(3);
     const int32_t en_ts = (int32_t)e0.x, en_te = (int32_t)e0.y, en_qs = (int32_t)e0.z, en_qe = (int32_t)e0.w;
     const uint32_t nops_flags = e1.z;
     const uint32_t n = nops_flags & OP_LEN_MASK;
     const bool rev = (nops_flags & EF_STRAND) != 0;
     PairCtx c;
-    c.swp = (nops_flags & EF_REVERSED) != 0;
-    c.flip = c.swp && rev;
+    c.swp = ORIENT < 0 ? (nops_flags & EF_REVERSED) != 0 : ORIENT >= 1;
+    c.flip = ORIENT < 0 ? c.swp && rev : ORIENT == 2;
     c.zt = c.swp ? 3u : 2u;  // 'I' consumes no target; for a reversed entry 'D' does (impg.rs:146-151)
     c.zq = c.swp ? 2u : 3u;
     c.ts = en_ts;
@@ -1600,6 +1616,71 @@ constexpr uint32_t STG_LINE_V4 = STG_ECAP * STG_REC_STRIDE / 4u;       // prefix
 static_assert((STG_RANGES & (STG_RANGES - 1u)) == 0u && STG_RANGES < STG_THREADS && STG_THREADS % 64u == 0, "a thread per range, whole waves");
 static_assert(STG_LINE_V4 * 4u >= 5u * STG_THREADS + STG_WAVES, "the unstaged path's scratch overlays the line buffer");
 static_assert(STG_ECAP * 4u <= STG_THREADS, "one pass copies the entries");
+// The places [P0, P1) of a block's ranges, a turn of STG_THREADS at a time, a lane per place: the place's range from the
+// block's LDS offsets, its entry from the range's hit mask (MASKS) or from the emit pass's list (then the next turn's
+// entry is requested a turn ahead), and the projection on the staged copies where the entry is one of the n_e staged
+// from emin on, else on the index (regroup_all: nothing is staged and every turn's pairs are regrouped by entry first,
+// as project_kernel does; the scratch overlays the line buffer).  Returns the thread's count of accepted projections.
+template <bool TRANSITIVE, bool MASKS, bool CAN_STAGE = true>
+__device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, const uint32_t *__restrict__ pair_entry, const HitArrays &h,
+                                                   unsigned long long *__restrict__ accepted, uint32_t *__restrict__ err_flag,
+                                                   const WindowLists &wl, uint32_t r0, uint32_t P0, uint32_t P1, uint32_t emin, uint32_t n_e,
+                                                   bool regroup_all, const uint32_t *st_off, const uint4 *st_win, const int2 *st_se,
+                                                   const uint4 *st_ent, uint4 *st_line PHASE_ARG) {
+  const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
+  uint32_t n_ok = 0;
+  // the block's places, a turn of STG_THREADS at a time (pair lists: the next turn's entry is requested a turn ahead)
+  uint32_t e_next = 0xFFFFFFFFu;
+  if (!MASKS && (unsigned long long)P0 + threadIdx.x < P1) e_next = pair_entry[P0 + threadIdx.x];
+#pragma unroll 1
+  for (uint32_t base = P0; base < P1; base += STG_THREADS) {
+    if (base + STG_THREADS < base) break;  // (cannot happen: n_pairs stays 16 below 2^32 and P1 <= n_pairs)
+    const uint32_t pp = base + threadIdx.x;
+    PairIn y;
+    y.live = pp < P1 ? 1u : 0u;
+    y.p = pp; y.eidx = 0xFFFFFFFFu; y.f_start = 0; y.f_end = 0;
+    // the place's range: the last one with offset <= pp (ranges without hits share their successor's offset)
+    uint32_t j = 0;
+#pragma unroll
+    for (uint32_t st = STG_RANGES / 2u; st > 0u; st >>= 1) j += st_off[j + st] <= pp ? st : 0u;
+    if (y.live) {
+      const int2 se = st_se[j];
+      y.f_start = se.x; y.f_end = se.y;
+      if (MASKS) {
+        const uint4 w = st_win[j];
+        if (w.y - (w.x & ~3u) > 64u) y.eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
+        else y.eidx = w.x + select_bit64(w.z, w.w, pp - st_off[j]);
+        if (wl.range_out) wl.range_out[pp] = wl.perm[r0 + j];
+      } else {
+        y.eidx = e_next;
+      }
+    }
+    if (!MASKS) {
+      e_next = 0xFFFFFFFFu;
+      if ((unsigned long long)pp + STG_THREADS < P1) e_next = pair_entry[pp + STG_THREADS];
+    }
+    if (regroup_all) regroup_by_entry<STG_THREADS>(y, reinterpret_cast<uint32_t *>(st_line));
+    if (y.live) {
+      bool ok = false;
+      TileScan res;
+      res.found = res.any = false;
+      res.pqs = res.pts = res.pqe = res.pte = -1;
+      uint32_t qid = HIT_NONE;
+      const uint32_t slot = y.eidx - emin;
+      const uint4 *se = st_ent + min(slot, STG_ECAP - 1u) * (STG_ENT_STRIDE / 4u);
+      if (CAN_STAGE && slot < n_e && (se[1].z & OP_LEN_MASK) <= INLINE_TILES * TILE_OPS)
+        project_pair<TRANSITIVE, 0, true>(v, y.eidx, y.f_start, y.f_end, y.p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, se,
+                                          reinterpret_cast<const uint32_t *>(st_line + slot * (STG_REC_STRIDE / 4u)));
+      else  // an entry beyond the staged span, or a record with more prefix lines than a staged record holds
+        project_pair<TRANSITIVE, 0>(v, y.eidx, y.f_start, y.f_end, y.p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
+      h.qid[y.p] = qid;
+      if (ok) h.c[y.p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+      n_ok += ok ? 1u : 0u;
+    }
+    if (regroup_all) __syncthreads();  // (the next turn's regrouping reuses the scratch)
+  }
+  return n_ok;
+}
 #ifdef IMPG_STG_WAVES  // (experiments: force the register allocation that gives this many waves per SIMD)
 #define STG_OCCUPANCY __attribute__((amdgpu_waves_per_eu(IMPG_STG_WAVES, IMPG_STG_WAVES)))
 #else
@@ -1663,7 +1744,6 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
     for (uint32_t k = 0; k < STG_WAVES; k++) { emin = min(emin, wred[k]); emax = max(emax, wred[STG_WAVES + k]); }
   }
   const uint32_t P0 = st_off[0], P1 = st_off[nr];
-  const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
   uint32_t n_ok = 0;
   STG_MARK(1);
   // a sparse stretch of the level (its hits spread over many more entries than can be staged): nothing is staged, the
@@ -1697,56 +1777,8 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
     __syncthreads();
   }
   STG_MARK(2);
-  // the block's places, a turn of STG_THREADS at a time (pair lists: the next turn's entry is requested a turn ahead)
-  uint32_t e_next = 0xFFFFFFFFu;
-  if (!MASKS && (unsigned long long)P0 + threadIdx.x < P1) e_next = pair_entry[P0 + threadIdx.x];
-#pragma unroll 1
-  for (uint32_t base = P0; base < P1; base += STG_THREADS) {
-    if (base + STG_THREADS < base) break;  // (cannot happen: n_pairs stays 16 below 2^32 and P1 <= n_pairs)
-    const uint32_t pp = base + threadIdx.x;
-    PairIn y;
-    y.live = pp < P1 ? 1u : 0u;
-    y.p = pp; y.eidx = 0xFFFFFFFFu; y.f_start = 0; y.f_end = 0;
-    // the place's range: the last one with offset <= pp (ranges without hits share their successor's offset)
-    uint32_t j = 0;
-#pragma unroll
-    for (uint32_t st = STG_RANGES / 2u; st > 0u; st >>= 1) j += st_off[j + st] <= pp ? st : 0u;
-    if (y.live) {
-      const int2 se = st_se[j];
-      y.f_start = se.x; y.f_end = se.y;
-      if (MASKS) {
-        const uint4 w = st_win[j];
-        if (w.y - (w.x & ~3u) > 64u) y.eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
-        else y.eidx = w.x + select_bit64(w.z, w.w, pp - st_off[j]);
-        if (wl.range_out) wl.range_out[pp] = wl.perm[r0 + j];
-      } else {
-        y.eidx = e_next;
-      }
-    }
-    if (!MASKS) {
-      e_next = 0xFFFFFFFFu;
-      if ((unsigned long long)pp + STG_THREADS < P1) e_next = pair_entry[pp + STG_THREADS];
-    }
-    if (sparse && regroup) regroup_by_entry<STG_THREADS>(y, reinterpret_cast<uint32_t *>(st_line));
-    if (y.live) {
-      bool ok = false;
-      TileScan res;
-      res.found = res.any = false;
-      res.pqs = res.pts = res.pqe = res.pte = -1;
-      uint32_t qid = HIT_NONE;
-      const uint32_t slot = y.eidx - emin;
-      const uint4 *se = st_ent + min(slot, STG_ECAP - 1u) * (STG_ENT_STRIDE / 4u);
-      if (slot < n_e && (se[1].z & OP_LEN_MASK) <= INLINE_TILES * TILE_OPS)
-        project_pair<TRANSITIVE, 0, true>(v, y.eidx, y.f_start, y.f_end, y.p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, se,
-                                          reinterpret_cast<const uint32_t *>(st_line + slot * (STG_REC_STRIDE / 4u)));
-      else  // an entry beyond the staged span, or a record with more prefix lines than a staged record holds
-        project_pair<TRANSITIVE, 0>(v, y.eidx, y.f_start, y.f_end, y.p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
-      h.qid[y.p] = qid;
-      if (ok) h.c[y.p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
-      n_ok += ok ? 1u : 0u;
-    }
-    if (sparse && regroup) __syncthreads();  // (the next turn's regrouping reuses the scratch)
-  }
+  n_ok = project_places<TRANSITIVE, MASKS>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, n_e, sparse && regroup != 0, st_off, st_win,
+                                           st_se, st_ent, st_line PHASE_PASS);
 #ifdef IMPG_PHASE_CLOCKS
   STG_MARK(3);
   if ((blockIdx.x & 15u) == 0u && threadIdx.x == 0u) {
@@ -1761,6 +1793,252 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
       atomicAdd(&g_phase_clk[15], 1ull);
       atomicAdd(&g_phase_clk[11], emin <= emax ? (unsigned long long)(emax - emin + 1u) : 0ull);
     }
+  }
+#endif
+  count_accepted<STG_WAVES>(n_ok, accepted, wcnt);
+}
+#undef STG_MARK
+
+// ---------------------------------------------------------------------------
+// A dense final level, ENTRY by entry (round 4): a wave works on one entry at a time, a lane per range that hits it.
+//
+// project_staged_kernel keeps project_kernel's shape -- a lane per place, so the 64 lanes of a wave read 64 different
+// entries -- and on the headline's final level it is bound by the vector ALUs (0.65 busy) and by LDS bank conflicts
+// (60 % of the LDS cycles): every lane decodes its own entry, selects on its own orientation flags, and the lanes'
+// records collide on banks.  With the block's ranges and windows in LDS the pairs can just as well be listed the other
+// way round: for one staged entry, the block's ranges whose hit mask has its bit -- one ballot per 64 ranges.  The
+// wave then holds the entry's 16 words in SCALAR registers (its checkpoints are compared as scalar operands, nothing
+// is selected per lane), its orientation is a compile-time constant of the code path taken (project_core's ORIENT),
+// and its lanes read the SAME record's lines: equal addresses are one LDS access, different lines of the record sit
+// on different banks.  A pair's slot is its range's place offset + the number of mask bits below the entry's: the
+// same slots project_kernel's WindowLists form fills, so nothing downstream can tell.
+// Ranges whose window is wider than the mask (their pairs are listed by the wave-per-range emit) are projected at the
+// end from that list; a block whose pairs are few for the entries they touch takes project_places (nothing staged).
+// ---------------------------------------------------------------------------
+#ifndef IMPG_ENT_ECAP
+#define IMPG_ENT_ECAP 52
+#endif
+constexpr uint32_t ENT_ECAP = IMPG_ENT_ECAP;                              // entries staged per piece of the block's span
+constexpr uint32_t ENT_REC_STRIDE = INLINE_TILES * STG_LINE_STRIDE;       // words per staged record (lines padded, records not)
+static_assert(ENT_ECAP * 4u <= STG_THREADS, "one pass copies the entries");
+static_assert(ENT_ECAP * ENT_REC_STRIDE >= 5u * STG_THREADS + STG_WAVES, "the unstaged path's scratch overlays the line buffer");
+template <bool TRANSITIVE, int ORIENT>
+__device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, uint4 e0, uint4 e1, uint4 e2, uint4 e3, uint32_t eidx, bool live,
+                                                    int32_t f_start, int32_t f_end, uint32_t p, const uint32_t *rec, const HitArrays &h,
+                                                    unsigned long long *__restrict__ accepted, uint32_t *__restrict__ err_flag,
+                                                    uint32_t &n_ok PHASE_ARG) {
+  const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
+  if (live) {
+    bool ok = false;
+    TileScan res;
+    res.found = res.any = false;
+    res.pqs = res.pts = res.pqe = res.pte = -1;
+    uint32_t qid = HIT_NONE;
+    if (ORIENT >= 0)
+      project_core<TRANSITIVE, 0, true, ORIENT>(v, e0, e1, e2, e3, f_start, f_end, p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, rec);
+    else  // (a record with more prefix lines than a staged record holds: from the index)
+      project_pair<TRANSITIVE, 0>(v, eidx, f_start, f_end, p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
+    h.qid[p] = qid;
+    if (ok) h.c[p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+    n_ok += ok ? 1u : 0u;
+  }
+}
+template <bool TRANSITIVE>
+__global__ __launch_bounds__(STG_THREADS) void project_entries_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
+                                                      HitArrays h, unsigned long long *__restrict__ accepted,
+                                                      uint32_t *__restrict__ err_flag, int regroup, WindowLists wl) {
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t sblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  __shared__ uint4 st_line[ENT_ECAP * ENT_REC_STRIDE / 4u];
+  __shared__ uint4 st_ent[ENT_ECAP * 4u];
+  __shared__ uint4 st_win[STG_RANGES];
+  __shared__ int2 st_se[STG_RANGES];
+  __shared__ uint32_t st_off[STG_RANGES + 4u];
+  __shared__ uint16_t st_list[STG_WAVES][STG_RANGES];
+  __shared__ uint16_t st_wide[STG_RANGES];
+  __shared__ uint32_t st_nwide;
+  __shared__ uint32_t wred[2u * STG_WAVES];
+  __shared__ uint32_t wcnt[STG_WAVES];
+  const uint32_t r0 = sblock * STG_RANGES;
+  if (r0 >= wl.n_fr) return;  // (block-uniform: the grid is rounded up to the 8 XCDs)
+  const uint32_t nr = min(STG_RANGES, wl.n_fr - r0);
+  const uint32_t wv = threadIdx.x >> 6, l = lane_id();
+#ifdef IMPG_PHASE_CLOCKS
+  unsigned long long stg_t[8], phase_t[10];
+#define STG_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stg_t[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STG_MARK(i) do { } while (0)
+#endif
+  STG_MARK(0);
+  if (threadIdx.x == 0) st_nwide = 0u;
+  // the block's ranges: place offsets, windows, ends; the span of entries their masks name; the ranges listed instead
+  uint32_t emin = 0xFFFFFFFFu, emax = 0u;
+  bool wide = false;
+  if (threadIdx.x <= STG_RANGES) {
+    uint32_t o = 0xFFFFFFFFu;
+    if (threadIdx.x < nr) o = wl.pair_off[r0 + threadIdx.x];
+    else if (threadIdx.x == nr) o = r0 + nr < wl.n_fr ? wl.pair_off[r0 + nr] : n_pairs;
+    st_off[threadIdx.x] = o;
+    if (threadIdx.x < nr) {
+      const uint4 w = wl.win[r0 + threadIdx.x];
+      st_win[threadIdx.x] = w;
+      st_se[threadIdx.x] = wl.se[r0 + threadIdx.x];
+      if (w.y - (w.x & ~3u) > 64u) wide = true;
+      else if (w.z | w.w) {
+        emin = w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w));
+        emax = w.x + (w.w ? 63u - (uint32_t)__builtin_clz(w.w) : 31u - (uint32_t)__builtin_clz(w.z));
+      }
+    }
+  }
+  {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      emin = min(emin, (uint32_t)__shfl_xor((int)emin, o));
+      emax = max(emax, (uint32_t)__shfl_xor((int)emax, o));
+    }
+    if (l == 0) { wred[wv] = emin; wred[STG_WAVES + wv] = emax; }
+    __syncthreads();
+    if (wide) st_wide[atomicAdd(&st_nwide, 1u)] = (uint16_t)threadIdx.x;
+#pragma unroll
+    for (uint32_t k = 0; k < STG_WAVES; k++) { emin = min(emin, wred[k]); emax = max(emax, wred[STG_WAVES + k]); }
+  }
+  const uint32_t P0 = st_off[0], P1 = st_off[nr];
+  uint32_t n_ok = 0;
+  STG_MARK(1);
+  // few pairs for the entries they touch (a sparse stretch of the level): staging a record for a pair or two would read
+  // more than the pairs do -- by place, regrouped, from the index (the ranges listed instead take the same path there)
+  const bool sparse = emin <= emax && (unsigned long long)(P1 - P0) < 4ull * (emax - emin + 1u);
+  if (sparse) {
+    n_ok = project_places<TRANSITIVE, true, false>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
+                                                   st_se, st_ent, st_line PHASE_PASS);
+  } else if (emin <= emax) {
+#ifdef IMPG_PHASE_CLOCKS
+    unsigned long long t_stage = 0, t_proj = 0;
+#endif
+    for (uint32_t eb = emin;; eb += ENT_ECAP) {
+      STG_MARK(2);
+      // stage the piece: entries eb .. eb + n_e - 1 (four vectors each), then their records' prefix lines -- a wave per
+      // entry and turn, a lane per 16-byte piece of the record's <= 8 lines
+      const uint32_t n_e = min(ENT_ECAP, emax - eb + 1u);
+      if (threadIdx.x < n_e * 4u) st_ent[threadIdx.x] = reinterpret_cast<const uint4 *>(v.entries + eb)[threadIdx.x];
+      __syncthreads();
+      {
+        constexpr uint32_t TURNS = (ENT_ECAP + STG_WAVES - 1u) / STG_WAVES;
+        uint4 buf[TURNS];
+#pragma unroll
+        for (uint32_t k = 0; k < TURNS; k++) {
+          const uint32_t i = wv + k * STG_WAVES;
+          buf[k] = make_uint4(0u, 0u, 0u, 0u);
+          if (i < n_e) {
+            const uint4 e1 = st_ent[i * 4u + 1u];
+            const uint32_t n = e1.z & OP_LEN_MASK, m = (n + TILE_OPS - 1u) / TILE_OPS;
+            if (m <= INLINE_TILES && (l >> 3) < m) buf[k] = reinterpret_cast<const uint4 *>(v.pfx + (size_t)e1.y * TILE_WORDS)[l];
+          }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < TURNS; k++) {
+          const uint32_t i = wv + k * STG_WAVES;
+          if (i < n_e) st_line[i * (ENT_REC_STRIDE / 4u) + (l >> 3) * (STG_LINE_STRIDE / 4u) + (l & 7u)] = buf[k];
+        }
+      }
+      __syncthreads();
+      STG_MARK(3);
+      // the wave's entries of the piece
+#pragma unroll 1
+      for (uint32_t sl = wv; sl < n_e; sl += STG_WAVES) {
+        const uint32_t eidx = eb + sl;
+        uint4 e0 = st_ent[sl * 4u], e1 = st_ent[sl * 4u + 1u], e2 = st_ent[sl * 4u + 2u], e3 = st_ent[sl * 4u + 3u];
+#define IMPG_RFL(x) x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x))
+        IMPG_RFL(e0.x); IMPG_RFL(e0.y); IMPG_RFL(e0.z); IMPG_RFL(e0.w); IMPG_RFL(e1.x); IMPG_RFL(e1.y); IMPG_RFL(e1.z); IMPG_RFL(e1.w);
+        IMPG_RFL(e2.x); IMPG_RFL(e2.y); IMPG_RFL(e2.z); IMPG_RFL(e2.w); IMPG_RFL(e3.x); IMPG_RFL(e3.y); IMPG_RFL(e3.z); IMPG_RFL(e3.w);
+#undef IMPG_RFL
+        // the block's ranges that hit it, 64 at a time: bit (entry - window start) of the range's mask
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < STG_RANGES / 64u; q++) {
+          const uint32_t r = q * 64u + l;
+          bool hit = false;
+          if (r < nr) {
+            const uint4 w = st_win[r];
+            const uint32_t d = eidx - w.x;
+            hit = d < 64u && w.y - (w.x & ~3u) <= 64u && (((d < 32u ? w.z >> d : w.w >> (d - 32u)) & 1u) != 0u);
+          }
+          const unsigned long long b = __ballot(hit);
+          if (hit) st_list[wv][cnt + (uint32_t)__popcll(b & lanemask_lt())] = (uint16_t)r;
+          cnt += (uint32_t)__popcll(b);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t *rec = reinterpret_cast<const uint32_t *>(st_line) + sl * ENT_REC_STRIDE;
+        const int orient = (e1.z & OP_LEN_MASK) > INLINE_TILES * TILE_OPS ? -1 : !(e1.z & EF_REVERSED) ? 0 : (e1.z & EF_STRAND) ? 2 : 1;
+#pragma unroll 1
+        for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
+          const bool live = c0 + l < cnt;
+          const uint32_t r = live ? (uint32_t)st_list[wv][c0 + l] : 0u;
+          const int2 se = st_se[r];
+          const uint4 w = st_win[r];
+          const uint32_t d = eidx - w.x;
+          // slot = the range's first place + the mask bits below the entry's
+          const uint32_t below = d < 32u ? (uint32_t)__popc(w.z & ((1u << d) - 1u))
+                                         : (uint32_t)__popc(w.z) + (uint32_t)__popc(w.w & ((1u << (d - 32u)) - 1u));
+          const uint32_t p = st_off[r] + below;
+          if (live && wl.range_out) wl.range_out[p] = wl.perm[r0 + r];
+          if (orient == 0) project_entry_chunk<TRANSITIVE, 0>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
+          else if (orient == 1) project_entry_chunk<TRANSITIVE, 1>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
+          else if (orient == 2) project_entry_chunk<TRANSITIVE, 2>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
+          else project_entry_chunk<TRANSITIVE, -1>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
+        }
+        __builtin_amdgcn_wave_barrier();  // (the next entry's list overwrites this one)
+      }
+#ifdef IMPG_PHASE_CLOCKS
+      STG_MARK(4);
+      t_stage += stg_t[3] - stg_t[2]; t_proj += stg_t[4] - stg_t[3];
+#endif
+      if (emax - eb < ENT_ECAP) break;
+      __syncthreads();  // (the next piece overwrites the buffers)
+    }
+#ifdef IMPG_PHASE_CLOCKS
+    if ((blockIdx.x & 15u) == 0u && threadIdx.x == 0u) {
+      atomicAdd(&g_phase_clk[0], stg_t[1] - stg_t[0]);
+      atomicAdd(&g_phase_clk[1], t_stage);
+      atomicAdd(&g_phase_clk[2], t_proj);
+      atomicAdd(&g_phase_clk[9], (unsigned long long)(P1 - P0));
+      atomicAdd(&g_phase_clk[10], emax - emin >= ENT_ECAP ? 1ull : 0ull);
+      atomicAdd(&g_phase_clk[15], 1ull);
+      atomicAdd(&g_phase_clk[11], (unsigned long long)(emax - emin + 1u));
+    }
+#endif
+  }
+  // the ranges whose pairs are listed (windows wider than the mask), a lane per place, from the index
+  if (!sparse) {
+    const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
+    const uint32_t nw = st_nwide;
+#pragma unroll 1
+    for (uint32_t k = 0; k < nw; k++) {
+      const uint32_t r = st_wide[k];
+      const uint32_t a = st_off[r], b = st_off[r + 1u];
+      const int2 se = st_se[r];
+#pragma unroll 1
+      for (uint32_t pp = a + threadIdx.x; pp < b; pp += STG_THREADS) {
+        bool ok = false;
+        TileScan res;
+        res.found = res.any = false;
+        res.pqs = res.pts = res.pqe = res.pte = -1;
+        uint32_t qid = HIT_NONE;
+        project_pair<TRANSITIVE, 0>(v, pair_entry[pp], se.x, se.y, pp, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
+        h.qid[pp] = qid;
+        if (ok) h.c[pp] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+        n_ok += ok ? 1u : 0u;
+        if (wl.range_out) wl.range_out[pp] = wl.perm[r0 + r];
+      }
+    }
+  }
+#ifdef IMPG_PHASE_CLOCKS
+  if (sparse && (blockIdx.x & 15u) == 0u && threadIdx.x == 0u) {
+    STG_MARK(3);
+    atomicAdd(&g_phase_clk[13], stg_t[3] - stg_t[0]);
+    atomicAdd(&g_phase_clk[14], 1ull);
+    atomicAdd(&g_phase_clk[12], (unsigned long long)(emax - emin));
   }
 #endif
   count_accepted<STG_WAVES>(n_ok, accepted, wcnt);
@@ -3470,6 +3748,12 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
       (double)n_pairs >= stage_density * (double)v.n_entries) {
     const uint32_t gs = (cdiv(wl.n_fr, STG_RANGES) + 7u) & ~7u;
     const bool masks = wl.tile_first != nullptr;
+    static const bool by_entry = [] { const char *e = getenv("IMPG_ENTRY_MAJOR"); return !e || atoi(e) != 0; }();  // (A/B: 0 = a lane per place)
+    if (masks && by_entry) {
+      if (transitive) project_entries_kernel<true><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
+      else project_entries_kernel<false><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
+      return;
+    }
 #define IMPG_LAUNCH_STG(T, M) project_staged_kernel<T, M><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl)
     if (transitive) { if (masks) IMPG_LAUNCH_STG(true, true); else IMPG_LAUNCH_STG(true, false); }
     else { if (masks) IMPG_LAUNCH_STG(false, true); else IMPG_LAUNCH_STG(false, false); }

@@ -12,6 +12,6 @@ for set in "$@"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $set -d $OUT/p$i -o p$i -- python $REPO/bench.py $ARGS > /dev/null 2> $OUT/p$i.err
   python3 $REPO/scripts/rocpd_summary.py $OUT/p$i/p${i}_results.db $OUT/p$i 2>&1 | tail -2
-  grep -E "project_kernel|lookup_" $OUT/p${i}_pmc.csv | cut -c1-40,100-
+  grep -E "project_|lookup_count" $OUT/p${i}_pmc.csv | cut -c1-40,100-
   rm -rf $OUT/p$i
 done

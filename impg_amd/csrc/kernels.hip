@@ -1621,7 +1621,7 @@ static_assert(STG_ECAP * 4u <= STG_THREADS, "one pass copies the entries");
 // entry is requested a turn ahead), and the projection on the staged copies where the entry is one of the n_e staged
 // from emin on, else on the index (regroup_all: nothing is staged and every turn's pairs are regrouped by entry first,
 // as project_kernel does; the scratch overlays the line buffer).  Returns the thread's count of accepted projections.
-template <bool TRANSITIVE, bool MASKS, bool CAN_STAGE = true>
+template <bool TRANSITIVE, bool MASKS, bool CAN_STAGE = true, uint32_t NR = STG_RANGES>  // NR: ranges of a block (st_off holds NR + 1 offsets)
 __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, const uint32_t *__restrict__ pair_entry, const HitArrays &h,
                                                    unsigned long long *__restrict__ accepted, uint32_t *__restrict__ err_flag,
                                                    const WindowLists &wl, uint32_t r0, uint32_t P0, uint32_t P1, uint32_t emin, uint32_t n_e,
@@ -1642,7 +1642,7 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
     // the place's range: the last one with offset <= pp (ranges without hits share their successor's offset)
     uint32_t j = 0;
 #pragma unroll
-    for (uint32_t st = STG_RANGES / 2u; st > 0u; st >>= 1) j += st_off[j + st] <= pp ? st : 0u;
+    for (uint32_t st = NR / 2u; st > 0u; st >>= 1) j += st_off[j + st] <= pp ? st : 0u;
     if (y.live) {
       const int2 se = st_se[j];
       y.f_start = se.x; y.f_end = se.y;
@@ -1815,13 +1815,19 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
 // Ranges whose window is wider than the mask (their pairs are listed by the wave-per-range emit) are projected at the
 // end from that list; a block whose pairs are few for the entries they touch takes project_places (nothing staged).
 // ---------------------------------------------------------------------------
-#ifndef IMPG_ENT_ECAP
-#define IMPG_ENT_ECAP 52
+#ifndef IMPG_ENT_RANGES
+#define IMPG_ENT_RANGES 512
 #endif
-constexpr uint32_t ENT_ECAP = IMPG_ENT_ECAP;                              // entries staged per piece of the block's span
-constexpr uint32_t ENT_REC_STRIDE = INLINE_TILES * STG_LINE_STRIDE;       // words per staged record (lines padded, records not)
-static_assert(ENT_ECAP * 4u <= STG_THREADS, "one pass copies the entries");
-static_assert(ENT_ECAP * ENT_REC_STRIDE >= 5u * STG_THREADS + STG_WAVES, "the unstaged path's scratch overlays the line buffer");
+constexpr uint32_t ENT_RANGES = IMPG_ENT_RANGES;                          // ranges (consecutive in the lookup order) per block
+constexpr uint32_t ENT_REC_STRIDE = INLINE_TILES * STG_LINE_STRIDE;       // words of a wave's LDS record (8 padded lines)
+static_assert((ENT_RANGES & (ENT_RANGES - 1u)) == 0u && ENT_RANGES <= STG_THREADS && ENT_RANGES % 64u == 0, "a thread per range");
+constexpr uint32_t ENT_REC_V4 = STG_WAVES * ENT_REC_STRIDE / 4u, ENT_LIST_V4 = STG_WAVES * ENT_RANGES * 2u / 16u;
+static_assert((ENT_REC_V4 + ENT_LIST_V4) * 4u >= 5u * STG_THREADS + STG_WAVES, "the unstaged path's scratch overlays the waves' records and lists");
+#ifdef IMPG_ENT_WAVES  // (experiments: force the register allocation that gives this many waves per SIMD)
+#define ENT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(IMPG_ENT_WAVES, IMPG_ENT_WAVES)))
+#else
+#define ENT_OCCUPANCY
+#endif
 template <bool TRANSITIVE, int ORIENT>
 __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, uint4 e0, uint4 e1, uint4 e2, uint4 e3, uint32_t eidx, bool live,
                                                     int32_t f_start, int32_t f_end, uint32_t p, const uint32_t *rec, const HitArrays &h,
@@ -1844,25 +1850,25 @@ __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, ui
   }
 }
 template <bool TRANSITIVE>
-__global__ __launch_bounds__(STG_THREADS) void project_entries_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
+__global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
                                                       uint32_t *__restrict__ err_flag, int regroup, WindowLists wl) {
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t sblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  __shared__ uint4 st_line[ENT_ECAP * ENT_REC_STRIDE / 4u];
-  __shared__ uint4 st_ent[ENT_ECAP * 4u];
-  __shared__ uint4 st_win[STG_RANGES];
-  __shared__ int2 st_se[STG_RANGES];
-  __shared__ uint32_t st_off[STG_RANGES + 4u];
-  __shared__ uint16_t st_list[STG_WAVES][STG_RANGES];
-  __shared__ uint16_t st_wide[STG_RANGES];
-  __shared__ uint32_t st_nwide;
+  __shared__ uint4 st_work[ENT_REC_V4 + ENT_LIST_V4];
+  uint4 (*st_rec)[ENT_REC_STRIDE / 4u] = reinterpret_cast<uint4 (*)[ENT_REC_STRIDE / 4u]>(st_work);  // a wave's current record: its prefix lines (padded)
+  uint16_t (*st_list)[ENT_RANGES] = reinterpret_cast<uint16_t (*)[ENT_RANGES]>(st_work + ENT_REC_V4);  // a wave's list of the ranges that hit its entry
+  __shared__ uint4 st_win[ENT_RANGES];
+  __shared__ int2 st_se[ENT_RANGES];
+  __shared__ uint32_t st_off[ENT_RANGES + 4u];
+  __shared__ uint16_t st_wide[ENT_RANGES];
+  __shared__ uint32_t st_nwide, st_alloc;
   __shared__ uint32_t wred[2u * STG_WAVES];
   __shared__ uint32_t wcnt[STG_WAVES];
-  const uint32_t r0 = sblock * STG_RANGES;
+  const uint32_t r0 = sblock * ENT_RANGES;
   if (r0 >= wl.n_fr) return;  // (block-uniform: the grid is rounded up to the 8 XCDs)
-  const uint32_t nr = min(STG_RANGES, wl.n_fr - r0);
-  const uint32_t wv = threadIdx.x >> 6, l = lane_id();
+  const uint32_t nr = min(ENT_RANGES, wl.n_fr - r0);
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = lane_id();
 #ifdef IMPG_PHASE_CLOCKS
   unsigned long long stg_t[8], phase_t[10];
 #define STG_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stg_t[i] = __builtin_readcyclecounter(); } while (0)
@@ -1870,20 +1876,20 @@ __global__ __launch_bounds__(STG_THREADS) void project_entries_kernel(DeviceInde
 #define STG_MARK(i) do { } while (0)
 #endif
   STG_MARK(0);
-  if (threadIdx.x == 0) st_nwide = 0u;
+  if (threadIdx.x == 0) { st_nwide = 0u; st_alloc = 0u; }
+  __syncthreads();
   // the block's ranges: place offsets, windows, ends; the span of entries their masks name; the ranges listed instead
   uint32_t emin = 0xFFFFFFFFu, emax = 0u;
-  bool wide = false;
-  if (threadIdx.x <= STG_RANGES) {
-    uint32_t o = 0xFFFFFFFFu;
-    if (threadIdx.x < nr) o = wl.pair_off[r0 + threadIdx.x];
-    else if (threadIdx.x == nr) o = r0 + nr < wl.n_fr ? wl.pair_off[r0 + nr] : n_pairs;
-    st_off[threadIdx.x] = o;
+  if (threadIdx.x < ENT_RANGES) {
+    // (st_off[nr] = where the block's places end, all ones beyond: the searches never step past the block's ranges)
+    if (threadIdx.x < nr) st_off[threadIdx.x] = wl.pair_off[r0 + threadIdx.x];
+    else st_off[threadIdx.x + 1u] = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) st_off[nr] = r0 + nr < wl.n_fr ? wl.pair_off[r0 + nr] : n_pairs;
     if (threadIdx.x < nr) {
       const uint4 w = wl.win[r0 + threadIdx.x];
       st_win[threadIdx.x] = w;
       st_se[threadIdx.x] = wl.se[r0 + threadIdx.x];
-      if (w.y - (w.x & ~3u) > 64u) wide = true;
+      if (w.y - (w.x & ~3u) > 64u) st_wide[atomicAdd(&st_nwide, 1u)] = (uint16_t)threadIdx.x;
       else if (w.z | w.w) {
         emin = w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w));
         emax = w.x + (w.w ? 63u - (uint32_t)__builtin_clz(w.w) : 31u - (uint32_t)__builtin_clz(w.z));
@@ -1898,112 +1904,115 @@ __global__ __launch_bounds__(STG_THREADS) void project_entries_kernel(DeviceInde
     }
     if (l == 0) { wred[wv] = emin; wred[STG_WAVES + wv] = emax; }
     __syncthreads();
-    if (wide) st_wide[atomicAdd(&st_nwide, 1u)] = (uint16_t)threadIdx.x;
 #pragma unroll
     for (uint32_t k = 0; k < STG_WAVES; k++) { emin = min(emin, wred[k]); emax = max(emax, wred[STG_WAVES + k]); }
+    emin = (uint32_t)__builtin_amdgcn_readfirstlane((int)emin);
+    emax = (uint32_t)__builtin_amdgcn_readfirstlane((int)emax);
   }
   const uint32_t P0 = st_off[0], P1 = st_off[nr];
+  // Which slot a pair lands in is free here (a counting run's final level: nothing reads its slots by position or in
+  // order, only together with range_out), so the block's pairs fill its places [P0, P1) ENTRY BY ENTRY -- an entry's
+  // pairs take the next run of places (an LDS counter) and a wave's 64 results are one contiguous store.  By range
+  // (place offset + mask bits below the entry's) the lanes of a wave scatter over as many lines as it has lanes, and
+  // the store path, not the ALUs, bounded the kernel.  Not when a range of the block is listed instead: its pairs
+  // keep their places, so the others do too.
+  const bool compact = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_nwide) == 0u;
   uint32_t n_ok = 0;
   STG_MARK(1);
-  // few pairs for the entries they touch (a sparse stretch of the level): staging a record for a pair or two would read
+  // few pairs for the entries they touch (a sparse stretch of the level): fetching a record for a pair or two would read
   // more than the pairs do -- by place, regrouped, from the index (the ranges listed instead take the same path there)
   const bool sparse = emin <= emax && (unsigned long long)(P1 - P0) < 4ull * (emax - emin + 1u);
   if (sparse) {
-    n_ok = project_places<TRANSITIVE, true, false>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
-                                                   st_se, st_ent, st_line PHASE_PASS);
+    n_ok = project_places<TRANSITIVE, true, false, ENT_RANGES>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
+                                                               st_se, nullptr, st_work PHASE_PASS);
   } else if (emin <= emax) {
-#ifdef IMPG_PHASE_CLOCKS
-    unsigned long long t_stage = 0, t_proj = 0;
-#endif
-    for (uint32_t eb = emin;; eb += ENT_ECAP) {
-      STG_MARK(2);
-      // stage the piece: entries eb .. eb + n_e - 1 (four vectors each), then their records' prefix lines -- a wave per
-      // entry and turn, a lane per 16-byte piece of the record's <= 8 lines
-      const uint32_t n_e = min(ENT_ECAP, emax - eb + 1u);
-      if (threadIdx.x < n_e * 4u) st_ent[threadIdx.x] = reinterpret_cast<const uint4 *>(v.entries + eb)[threadIdx.x];
-      __syncthreads();
-      {
-        constexpr uint32_t TURNS = (ENT_ECAP + STG_WAVES - 1u) / STG_WAVES;
-        uint4 buf[TURNS];
-#pragma unroll
-        for (uint32_t k = 0; k < TURNS; k++) {
-          const uint32_t i = wv + k * STG_WAVES;
-          buf[k] = make_uint4(0u, 0u, 0u, 0u);
-          if (i < n_e) {
-            const uint4 e1 = st_ent[i * 4u + 1u];
-            const uint32_t n = e1.z & OP_LEN_MASK, m = (n + TILE_OPS - 1u) / TILE_OPS;
-            if (m <= INLINE_TILES && (l >> 3) < m) buf[k] = reinterpret_cast<const uint4 *>(v.pfx + (size_t)e1.y * TILE_WORDS)[l];
-          }
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < TURNS; k++) {
-          const uint32_t i = wv + k * STG_WAVES;
-          if (i < n_e) st_line[i * (ENT_REC_STRIDE / 4u) + (l >> 3) * (STG_LINE_STRIDE / 4u) + (l & 7u)] = buf[k];
-        }
-      }
-      __syncthreads();
-      STG_MARK(3);
-      // the wave's entries of the piece
+    // The wave's entries: emin + wv, + STG_WAVES, ...  Each is fetched by the wave alone -- its 64 bytes (one address
+    // for the whole wave, then scalar registers), then its record's <= 8 prefix lines, a 16-byte piece per lane, into
+    // the wave's own LDS record -- two entries ahead / one record ahead of the one being worked on, so that the
+    // index's latency hides behind the projections.  No barrier: the block shares only the ranges' data.
+    const uint4 *ents = reinterpret_cast<const uint4 *>(v.entries);
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t ec = emin + wv;
+    uint4 c0 = zero4, c1 = zero4, c2 = zero4, c3 = zero4, n0 = zero4, n1 = zero4, n2 = zero4, n3 = zero4, lc = zero4;
+    if (ec <= emax) { c0 = ents[(size_t)ec * 4u]; c1 = ents[(size_t)ec * 4u + 1u]; c2 = ents[(size_t)ec * 4u + 2u]; c3 = ents[(size_t)ec * 4u + 3u]; }
+    if (emax - emin >= wv + STG_WAVES) {
+      const size_t en = (size_t)(ec + STG_WAVES) * 4u;
+      n0 = ents[en]; n1 = ents[en + 1u]; n2 = ents[en + 2u]; n3 = ents[en + 3u];
+    }
+    if (ec <= emax) {
+      const uint32_t m = ((c1.z & OP_LEN_MASK) + TILE_OPS - 1u) / TILE_OPS;
+      if (m <= INLINE_TILES && (l >> 3) < m) lc = reinterpret_cast<const uint4 *>(v.pfx + (size_t)c1.y * TILE_WORDS)[l];
+    }
 #pragma unroll 1
-      for (uint32_t sl = wv; sl < n_e; sl += STG_WAVES) {
-        const uint32_t eidx = eb + sl;
-        uint4 e0 = st_ent[sl * 4u], e1 = st_ent[sl * 4u + 1u], e2 = st_ent[sl * 4u + 2u], e3 = st_ent[sl * 4u + 3u];
+    for (; ec <= emax; ec += STG_WAVES) {
+      const uint32_t eidx = ec;
+      // this entry's record into the wave's LDS record (the previous entry's reads are done: their results were used)
+      __builtin_amdgcn_wave_barrier();
+      st_rec[wv][(l >> 3) * (STG_LINE_STRIDE / 4u) + (l & 7u)] = lc;
+      uint4 e0 = c0, e1 = c1, e2 = c2, e3 = c3;
 #define IMPG_RFL(x) x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x))
-        IMPG_RFL(e0.x); IMPG_RFL(e0.y); IMPG_RFL(e0.z); IMPG_RFL(e0.w); IMPG_RFL(e1.x); IMPG_RFL(e1.y); IMPG_RFL(e1.z); IMPG_RFL(e1.w);
-        IMPG_RFL(e2.x); IMPG_RFL(e2.y); IMPG_RFL(e2.z); IMPG_RFL(e2.w); IMPG_RFL(e3.x); IMPG_RFL(e3.y); IMPG_RFL(e3.z); IMPG_RFL(e3.w);
+      IMPG_RFL(e0.x); IMPG_RFL(e0.y); IMPG_RFL(e0.z); IMPG_RFL(e0.w); IMPG_RFL(e1.x); IMPG_RFL(e1.y); IMPG_RFL(e1.z); IMPG_RFL(e1.w);
+      IMPG_RFL(e2.x); IMPG_RFL(e2.y); IMPG_RFL(e2.z); IMPG_RFL(e2.w); IMPG_RFL(e3.x); IMPG_RFL(e3.y); IMPG_RFL(e3.z); IMPG_RFL(e3.w);
 #undef IMPG_RFL
-        // the block's ranges that hit it, 64 at a time: bit (entry - window start) of the range's mask
-        uint32_t cnt = 0;
+      // the next entry of the wave moves up; its record and the entry after it are requested
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      lc = zero4;
+      if (emax - ec >= STG_WAVES) {
+        const uint32_t m = ((c1.z & OP_LEN_MASK) + TILE_OPS - 1u) / TILE_OPS;
+        if (m <= INLINE_TILES && (l >> 3) < m) lc = reinterpret_cast<const uint4 *>(v.pfx + (size_t)c1.y * TILE_WORDS)[l];
+      }
+      if (emax - ec >= 2u * STG_WAVES) {
+        const size_t en = (size_t)(ec + 2u * STG_WAVES) * 4u;
+        n0 = ents[en]; n1 = ents[en + 1u]; n2 = ents[en + 2u]; n3 = ents[en + 3u];
+      }
+      // the block's ranges that hit the entry, 64 at a time: bit (entry - window start) of the range's mask
+      uint32_t cnt = 0;
 #pragma unroll
-        for (uint32_t q = 0; q < STG_RANGES / 64u; q++) {
-          const uint32_t r = q * 64u + l;
-          bool hit = false;
-          if (r < nr) {
-            const uint4 w = st_win[r];
-            const uint32_t d = eidx - w.x;
-            hit = d < 64u && w.y - (w.x & ~3u) <= 64u && (((d < 32u ? w.z >> d : w.w >> (d - 32u)) & 1u) != 0u);
-          }
-          const unsigned long long b = __ballot(hit);
-          if (hit) st_list[wv][cnt + (uint32_t)__popcll(b & lanemask_lt())] = (uint16_t)r;
-          cnt += (uint32_t)__popcll(b);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t *rec = reinterpret_cast<const uint32_t *>(st_line) + sl * ENT_REC_STRIDE;
-        const int orient = (e1.z & OP_LEN_MASK) > INLINE_TILES * TILE_OPS ? -1 : !(e1.z & EF_REVERSED) ? 0 : (e1.z & EF_STRAND) ? 2 : 1;
-#pragma unroll 1
-        for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
-          const bool live = c0 + l < cnt;
-          const uint32_t r = live ? (uint32_t)st_list[wv][c0 + l] : 0u;
-          const int2 se = st_se[r];
+      for (uint32_t q = 0; q < ENT_RANGES / 64u; q++) {
+        const uint32_t r = q * 64u + l;
+        bool hit = false;
+        if (r < nr) {
           const uint4 w = st_win[r];
           const uint32_t d = eidx - w.x;
-          // slot = the range's first place + the mask bits below the entry's
-          const uint32_t below = d < 32u ? (uint32_t)__popc(w.z & ((1u << d) - 1u))
-                                         : (uint32_t)__popc(w.z) + (uint32_t)__popc(w.w & ((1u << (d - 32u)) - 1u));
-          const uint32_t p = st_off[r] + below;
-          if (live && wl.range_out) wl.range_out[p] = wl.perm[r0 + r];
-          if (orient == 0) project_entry_chunk<TRANSITIVE, 0>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
-          else if (orient == 1) project_entry_chunk<TRANSITIVE, 1>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
-          else if (orient == 2) project_entry_chunk<TRANSITIVE, 2>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
-          else project_entry_chunk<TRANSITIVE, -1>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
+          hit = d < 64u && w.y - (w.x & ~3u) <= 64u && (((d < 32u ? w.z >> d : w.w >> (d - 32u)) & 1u) != 0u);
         }
-        __builtin_amdgcn_wave_barrier();  // (the next entry's list overwrites this one)
+        const unsigned long long b = __ballot(hit);
+        if (hit) st_list[wv][cnt + (uint32_t)__popcll(b & lanemask_lt())] = (uint16_t)r;
+        cnt += (uint32_t)__popcll(b);
       }
-#ifdef IMPG_PHASE_CLOCKS
-      STG_MARK(4);
-      t_stage += stg_t[3] - stg_t[2]; t_proj += stg_t[4] - stg_t[3];
-#endif
-      if (emax - eb < ENT_ECAP) break;
-      __syncthreads();  // (the next piece overwrites the buffers)
+      uint32_t run = 0;  // compact: the entry's first place
+      if (compact) {
+        if (l == 0) run = atomicAdd(&st_alloc, cnt);
+        run = P0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t *rec = reinterpret_cast<const uint32_t *>(&st_rec[wv][0]);
+      const int orient = (e1.z & OP_LEN_MASK) > INLINE_TILES * TILE_OPS ? -1 : !(e1.z & EF_REVERSED) ? 0 : (e1.z & EF_STRAND) ? 2 : 1;
+#pragma unroll 1
+      for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
+        const bool live = k0 + l < cnt;
+        const uint32_t r = live ? (uint32_t)st_list[wv][k0 + l] : 0u;
+        const int2 se = st_se[r];
+        const uint4 w = st_win[r];
+        const uint32_t d = eidx - w.x;
+        // slot = the range's first place + the mask bits below the entry's
+        const uint32_t below = d < 32u ? (uint32_t)__popc(w.z & ((1u << d) - 1u))
+                                       : (uint32_t)__popc(w.z) + (uint32_t)__popc(w.w & ((1u << (d - 32u)) - 1u));
+        const uint32_t p = compact ? run + k0 + l : st_off[r] + below;
+        if (live && wl.range_out) wl.range_out[p] = wl.perm[r0 + r];
+        if (orient == 0) project_entry_chunk<TRANSITIVE, 0>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
+        else if (orient == 1) project_entry_chunk<TRANSITIVE, 1>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
+        else if (orient == 2) project_entry_chunk<TRANSITIVE, 2>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
+        else project_entry_chunk<TRANSITIVE, -1>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
+      }
     }
 #ifdef IMPG_PHASE_CLOCKS
+    STG_MARK(2);
     if ((blockIdx.x & 15u) == 0u && threadIdx.x == 0u) {
       atomicAdd(&g_phase_clk[0], stg_t[1] - stg_t[0]);
-      atomicAdd(&g_phase_clk[1], t_stage);
-      atomicAdd(&g_phase_clk[2], t_proj);
+      atomicAdd(&g_phase_clk[2], stg_t[2] - stg_t[1]);
       atomicAdd(&g_phase_clk[9], (unsigned long long)(P1 - P0));
-      atomicAdd(&g_phase_clk[10], emax - emin >= ENT_ECAP ? 1ull : 0ull);
       atomicAdd(&g_phase_clk[15], 1ull);
       atomicAdd(&g_phase_clk[11], (unsigned long long)(emax - emin + 1u));
     }
@@ -3750,8 +3759,9 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
     const bool masks = wl.tile_first != nullptr;
     static const bool by_entry = [] { const char *e = getenv("IMPG_ENTRY_MAJOR"); return !e || atoi(e) != 0; }();  // (A/B: 0 = a lane per place)
     if (masks && by_entry) {
-      if (transitive) project_entries_kernel<true><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
-      else project_entries_kernel<false><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
+      const uint32_t ge = (cdiv(wl.n_fr, ENT_RANGES) + 7u) & ~7u;
+      if (transitive) project_entries_kernel<true><<<ge, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
+      else project_entries_kernel<false><<<ge, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
       return;
     }
 #define IMPG_LAUNCH_STG(T, M) project_staged_kernel<T, M><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl)

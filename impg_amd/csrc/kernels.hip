@@ -1862,7 +1862,7 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
   __shared__ int2 st_se[ENT_RANGES];
   __shared__ uint32_t st_off[ENT_RANGES + 4u];
   __shared__ uint16_t st_wide[ENT_RANGES];
-  __shared__ uint32_t st_nwide, st_alloc;
+  __shared__ uint32_t st_nwide, st_alloc, st_next;
   __shared__ uint32_t wred[2u * STG_WAVES];
   __shared__ uint32_t wcnt[STG_WAVES];
   const uint32_t r0 = sblock * ENT_RANGES;
@@ -1876,7 +1876,7 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
 #define STG_MARK(i) do { } while (0)
 #endif
   STG_MARK(0);
-  if (threadIdx.x == 0) { st_nwide = 0u; st_alloc = 0u; }
+  if (threadIdx.x == 0) { st_nwide = 0u; st_alloc = 0u; st_next = 0u; }
   __syncthreads();
   // the block's ranges: place offsets, windows, ends; the span of entries their masks name; the ranges listed instead
   uint32_t emin = 0xFFFFFFFFu, emax = 0u;
@@ -1926,26 +1926,30 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
     n_ok = project_places<TRANSITIVE, true, false, ENT_RANGES>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
                                                                st_se, nullptr, st_work PHASE_PASS);
   } else if (emin <= emax) {
-    // The wave's entries: emin + wv, + STG_WAVES, ...  Each is fetched by the wave alone -- its 64 bytes (one address
-    // for the whole wave, then scalar registers), then its record's <= 8 prefix lines, a 16-byte piece per lane, into
-    // the wave's own LDS record -- two entries ahead / one record ahead of the one being worked on, so that the
-    // index's latency hides behind the projections.  No barrier: the block shares only the ranges' data.
+    // The waves take the span's entries one by one off an LDS counter (an entry is anything from a handful to 500 pairs:
+    // dealt round-robin, a block waited for its unluckiest wave).  Each entry is fetched by its wave alone -- its 64
+    // bytes (one address for the whole wave, then scalar registers), then its record's <= 8 prefix lines, a 16-byte
+    // piece per lane, into the wave's own LDS record -- two entries ahead / one record ahead of the one being worked
+    // on, so that the index's latency hides behind the projections.  No barrier: the block shares only the ranges' data.
     const uint4 *ents = reinterpret_cast<const uint4 *>(v.entries);
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t ec = emin + wv;
+    const uint32_t n_span = emax - emin + 1u;
+    auto take = [&]() -> uint32_t {  // the next entry of the span (>= n_span: none left)
+      uint32_t i = 0;
+      if (l == 0) i = atomicAdd(&st_next, 1u);
+      return (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+    };
+    uint32_t ic = take(), in = take();
     uint4 c0 = zero4, c1 = zero4, c2 = zero4, c3 = zero4, n0 = zero4, n1 = zero4, n2 = zero4, n3 = zero4, lc = zero4;
-    if (ec <= emax) { c0 = ents[(size_t)ec * 4u]; c1 = ents[(size_t)ec * 4u + 1u]; c2 = ents[(size_t)ec * 4u + 2u]; c3 = ents[(size_t)ec * 4u + 3u]; }
-    if (emax - emin >= wv + STG_WAVES) {
-      const size_t en = (size_t)(ec + STG_WAVES) * 4u;
-      n0 = ents[en]; n1 = ents[en + 1u]; n2 = ents[en + 2u]; n3 = ents[en + 3u];
-    }
-    if (ec <= emax) {
+    if (ic < n_span) { const size_t e = (size_t)(emin + ic) * 4u; c0 = ents[e]; c1 = ents[e + 1u]; c2 = ents[e + 2u]; c3 = ents[e + 3u]; }
+    if (in < n_span) { const size_t e = (size_t)(emin + in) * 4u; n0 = ents[e]; n1 = ents[e + 1u]; n2 = ents[e + 2u]; n3 = ents[e + 3u]; }
+    if (ic < n_span) {
       const uint32_t m = ((c1.z & OP_LEN_MASK) + TILE_OPS - 1u) / TILE_OPS;
       if (m <= INLINE_TILES && (l >> 3) < m) lc = reinterpret_cast<const uint4 *>(v.pfx + (size_t)c1.y * TILE_WORDS)[l];
     }
 #pragma unroll 1
-    for (; ec <= emax; ec += STG_WAVES) {
-      const uint32_t eidx = ec;
+    while (ic < n_span) {
+      const uint32_t eidx = emin + ic;
       // this entry's record into the wave's LDS record (the previous entry's reads are done: their results were used)
       __builtin_amdgcn_wave_barrier();
       st_rec[wv][(l >> 3) * (STG_LINE_STRIDE / 4u) + (l & 7u)] = lc;
@@ -1955,15 +1959,14 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
       IMPG_RFL(e2.x); IMPG_RFL(e2.y); IMPG_RFL(e2.z); IMPG_RFL(e2.w); IMPG_RFL(e3.x); IMPG_RFL(e3.y); IMPG_RFL(e3.z); IMPG_RFL(e3.w);
 #undef IMPG_RFL
       // the next entry of the wave moves up; its record and the entry after it are requested
+      ic = in;
       c0 = n0; c1 = n1; c2 = n2; c3 = n3;
       lc = zero4;
-      if (emax - ec >= STG_WAVES) {
+      if (ic < n_span) {
         const uint32_t m = ((c1.z & OP_LEN_MASK) + TILE_OPS - 1u) / TILE_OPS;
         if (m <= INLINE_TILES && (l >> 3) < m) lc = reinterpret_cast<const uint4 *>(v.pfx + (size_t)c1.y * TILE_WORDS)[l];
-      }
-      if (emax - ec >= 2u * STG_WAVES) {
-        const size_t en = (size_t)(ec + 2u * STG_WAVES) * 4u;
-        n0 = ents[en]; n1 = ents[en + 1u]; n2 = ents[en + 2u]; n3 = ents[en + 3u];
+        in = take();
+        if (in < n_span) { const size_t e = (size_t)(emin + in) * 4u; n0 = ents[e]; n1 = ents[e + 1u]; n2 = ents[e + 2u]; n3 = ents[e + 3u]; }
       }
       // the block's ranges that hit the entry, 64 at a time: bit (entry - window start) of the range's mask
       uint32_t cnt = 0;

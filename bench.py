@@ -368,11 +368,14 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches, tag):
     instruction whatever it costs, so a flat 2 or 4 clocks cannot be read off the counters)."""
     avg_ms = ms_project / launches if launches else None
     r = {
-        "kernel": "project_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "kernel": "the projection launches of a step: project_entries_kernel (the dense final level, ~94 % of the pairs), "
+                  "project_staged_kernel (dense listed levels), project_kernel (sparse levels)",
+        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": ach / HBM_PEAK_GBS,
         "frac_note": "the contract's accounting: 856 algorithmic bytes per projection (a streamed 200-op CIGAR) / launch time / 8 TB/s. "
-                     "The kernel reads a 64-byte entry and <= 2 x 64 bytes of prefix line instead, so this exceeds 1 and is not a "
-                     "bandwidth; the physical fractions are measured_traffic_frac and valu_issue_frac",
+                     "The kernels read a 64-byte entry and <= 2 x 64 bytes of prefix line per pair instead -- on a dense level from "
+                     "copies staged in LDS once per ~240 pairs -- so this exceeds 1 and is not a bandwidth; the physical fractions "
+                     "are measured_traffic_frac and valu_issue_frac",
         "traffic": traffic,
         "traffic_note": "bytes per launch = rocprofv3 (FETCH_SIZE x2 [gfx950] + WRITE_SIZE) per pair, from "
                         "profiles/%s, x pairs per launch of this run" % os.path.basename(tpath),
@@ -394,7 +397,7 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches, tag):
         r["valu_insts_per_pair"] = j.get("valu_insts_per_pair")
         r["valu_cycles_per_inst"] = j.get("cycles_per_valu_inst")
         r["valu_note"] = ("SQ_INSTS_VALU x %.2f clocks (the measured issue cost of the kernel's instruction mix: profiles/r3_issue_rate.json, "
-                          "profiles/r3_valu_mix_project.json) / (GRBM_GUI_ACTIVE x %d SIMDs) of project_kernel, profiles/%s" %
+                          "profiles/r*_valu_mix_*.json) / (GRBM_GUI_ACTIVE x %d SIMDs) of the projection kernels, profiles/%s" %
                           (j.get("cycles_per_valu_inst") or 0.0, SIMDS, os.path.basename(sq[-1])))
     mf = r["measured_traffic_frac"]
     # what binds, from the two measured fractions: neither HBM (the 856-byte model's bound) nor the VALUs are saturated on the
@@ -404,11 +407,11 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches, tag):
     else:
         r["bound"] = "unmeasured (no PMC summaries of this configuration under profiles/)"
     r["contract_bound"] = "hbm"
-    r["limiter"] = ("project_kernel on the headline index is bound by neither roofline: HBM moves measured_traffic_frac of 8 TB/s (the pairs of "
-                    "a level revisit the same 2.7 GB ~60 times and mostly hit L2), the vector ALUs issue valu_issue_frac of their slots. What is "
-                    "left is exposed latency: per pair 3-4 dependent rounds of 16-byte reads that share few cache lines across a wave.  On the "
-                    "config-4 index (20 000 sequences, no reuse) the same kernel IS HBM-bound: 292 B per pair = 4.9 TB/s of 128-byte gathers, "
-                    "0.62 of peak (profiles/r3_config4_traffic.json); DESIGN.md 5.2, 7")
+    r["limiter"] = ("on the headline index the projection is bound by VALU issue: the final level runs entry by entry with the index "
+                    "staged in LDS (project_entries_kernel, DESIGN.md 5.2 item 19), HBM sees little more than the result stores "
+                    "(measured_traffic_frac), the vector ALUs issue valu_issue_frac of their slots at 4 waves per SIMD.  On the config-4 "
+                    "index (20 000 sequences, no reuse: project_kernel) the projection IS HBM-bound: 292 B per pair = 4.9 TB/s of "
+                    "128-byte gathers, 0.62 of peak (profiles/r3_config4_traffic.json); DESIGN.md 5.2, 7")
     return r
 
 

@@ -1997,12 +1997,14 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
         const bool live = k0 + l < cnt;
         const uint32_t r = live ? (uint32_t)st_list[wv][k0 + l] : 0u;
         const int2 se = st_se[r];
-        const uint4 w = st_win[r];
-        const uint32_t d = eidx - w.x;
-        // slot = the range's first place + the mask bits below the entry's
-        const uint32_t below = d < 32u ? (uint32_t)__popc(w.z & ((1u << d) - 1u))
-                                       : (uint32_t)__popc(w.z) + (uint32_t)__popc(w.w & ((1u << (d - 32u)) - 1u));
-        const uint32_t p = compact ? run + k0 + l : st_off[r] + below;
+        uint32_t p = run + k0 + l;
+        if (!compact) {  // slot = the range's first place + the mask bits below the entry's
+          const uint4 w = st_win[r];
+          const uint32_t d = eidx - w.x;
+          const uint32_t below = d < 32u ? (uint32_t)__popc(w.z & ((1u << d) - 1u))
+                                         : (uint32_t)__popc(w.z) + (uint32_t)__popc(w.w & ((1u << (d - 32u)) - 1u));
+          p = st_off[r] + below;
+        }
         if (live && wl.range_out) wl.range_out[p] = wl.perm[r0 + r];
         if (orient == 0) project_entry_chunk<TRANSITIVE, 0>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
         else if (orient == 1) project_entry_chunk<TRANSITIVE, 1>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
@@ -2410,6 +2412,10 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
   return lo;
 }
 
+// (Round 4, measured and dropped: a block of 256 groups handing them to its lanes sorted by their number of hits, so that
+// a wave's replays are equally long -- update 12.7 -> 16.1 ms.  Neighbouring groups own neighbouring hits, lists and
+// slices; permuted, a wave's every read and write touches 64 lines instead of ~17: the kernel is bound by the lines
+// its memory instructions touch, not by the longest replay of a wave.)
 // one thread per (query, sequence) group: replay the group's hits in emission
 // order against its visited list (SortedRanges::insert with min_distance = 0,
 // impg.rs:270-368), collect the new pieces.

@@ -8,7 +8,10 @@ v_cmp + v_cndmask pair) weighted with the kernel's static instruction mix (scrip
 valu_issue_frac = SQ_INSTS_VALU x cycles_per_inst(mix) / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs), counters summed over
 the kernel's dispatches.  Rounds 1-2 used a flat 2, then a flat 4.
 usage: make_sq_json.py <dir with sq_pmc.csv and sq_bench.json> <out.json> [cycles_per_valu_inst | valu_mix.json]"""
-import csv, json, os, sys
+import csv, json, os, re, sys
+
+# the projection of a step: project_kernel (sparse levels), project_staged_kernel (dense listed levels), project_entries_kernel (dense final level)
+PROJ = re.compile(r"project_(kernel|staged_kernel|entries_kernel)")
 
 d, out = sys.argv[1], sys.argv[2]
 cpi, cpi_src = 4.13, "default: the half-rate class (no mix given)"
@@ -20,11 +23,11 @@ if len(sys.argv) > 3:
         cpi, cpi_src = float(sys.argv[3]), "given on the command line"
 vals, rows_of, disp = {}, {}, 0
 for row in csv.DictReader(open(os.path.join(d, "sq_pmc.csv"))):
-    if "project_kernel" in row["Name"]:
+    if PROJ.search(row["Name"]):
         vals[row["Counter"]] = vals.get(row["Counter"], 0.0) + float(row["Sum"])
         rows_of[row["Counter"]] = rows_of.get(row["Counter"], 0) + int(row["Dispatches"])
 for row in csv.DictReader(open(os.path.join(d, "sq_kernel_stats.csv"))):
-    if "project_kernel" in row["Name"]:
+    if PROJ.search(row["Name"]):
         disp += int(row["Calls"])
 bench = json.loads(open(os.path.join(d, "sq_bench.json")).read().strip().splitlines()[-1])
 passes = bench["steps"] + bench["warmup"]
@@ -33,7 +36,7 @@ pairs = bench["pairs_per_step_rank0"] * passes
 # summed over its dispatches, are the mean row x the number of dispatches
 gui = vals.get("GRBM_GUI_ACTIVE", 0.0) / max(1, rows_of.get("GRBM_GUI_ACTIVE", 1)) * disp
 valu = vals.get("SQ_INSTS_VALU", 0.0)
-res = {"kernel": "project_kernel", "command": "bench.py " + " ".join(bench.get("argv", [])) + " (scripts/profile_r2.sh, --pmc pass)",
+res = {"kernel": "project_kernel + project_staged_kernel + project_entries_kernel (the projections of a step's levels)", "command": "bench.py " + " ".join(bench.get("argv", [])) + " (scripts/profile_r2.sh, --pmc pass)",
        "dispatches": disp, "pairs": pairs, "counters": vals, "counter_rows": rows_of, "kernel_cycles_total": gui,
        "valu_insts_per_wave": valu / vals["SQ_WAVES"] if vals.get("SQ_WAVES") else None,
        "valu_insts_per_pair": valu / pairs / 1.0 if pairs else None,  # wave-instructions per pair (x64 lanes / 64 pairs per wave)

@@ -3,14 +3,17 @@
 HBM bytes per candidate pair of project_kernel = FETCH_SIZE (KB) x 2 [gfx950: 128-byte
 requests are tallied at 64 B; checked against TCC_EA0_RDREQ_128B] + WRITE_SIZE (KB).
 usage: make_traffic_json.py <dir with *_pmc.csv and trace_bench.json> <out.json>"""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
+
+# the projection of a step: project_kernel (sparse levels), project_staged_kernel (dense listed levels), project_entries_kernel (dense final level)
+PROJ = re.compile(r"project_(kernel|staged_kernel|entries_kernel)")
 
 d, out = sys.argv[1], sys.argv[2]
 vals = {}
 disp = 0
 for path in glob.glob(os.path.join(d, "*_pmc.csv")):
     for row in csv.DictReader(open(path)):
-        if "project_kernel" in row["Name"]:
+        if PROJ.search(row["Name"]):
             vals[row["Counter"]] = vals.get(row["Counter"], 0.0) + float(row["Sum"])
             disp = max(disp, int(row["Dispatches"]))
 bench = json.loads(open(os.path.join(d, "fetch_bench.json")).read().strip().splitlines()[-1])
@@ -19,7 +22,7 @@ passes = bench["steps"] + bench["warmup"]
 pairs = bench["pairs_per_step_rank0"] * passes
 rd128 = vals.get("TCC_EA0_RDREQ_128B_sum", 0.0)
 res = {
-    "kernel": "project_kernel",
+    "kernel": "project_kernel + project_staged_kernel + project_entries_kernel (the projections of a step's levels)",
     "command": "bench.py " + " ".join(bench.get("argv", ["--ranges 16384 --steps 2 --warmup 1 --cpu-sample 0"])) + " (scripts/profile_r*.sh, separate --pmc passes)",
     "dispatches": disp,
     "pairs": pairs,

@@ -27,4 +27,4 @@ for pass in $PASSES; do
   esac
 done
 head -8 $OUT/trace_kernel_stats.csv | cut -c1-60,140-
-grep -E "project_kernel" $OUT/*_pmc.csv | cut -c1-60,150-
+grep -E "project_" $OUT/*_pmc.csv | cut -c1-60,150-

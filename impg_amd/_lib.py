@@ -95,6 +95,8 @@ SYMBOLS = [
     ("impg_gpu_index_create_from_paf", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_save", C.c_int, [_P, C.c_char_p]),
     ("impg_gpu_index_load", C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
+    ("impg_gpu_index_load_rank", C.c_int, [C.c_char_p, C.c_int, _P, C.POINTER(_P)]),
+    ("impg_gpu_index_load_multi", C.c_int, [C.c_char_p, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_load_impg", C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_destroy", None, [_P]),
     ("impg_gpu_num_seqs", C.c_uint32, [_P]),

@@ -435,8 +435,8 @@ int impg_gpu_subset_keep(const char *list_text, size_t len, const char *const *n
 int impg_gpu_index_save(const impg_gpu_index_t *ix, const char *path) {
   IMPG_TRY
   if (!ix || !path) throw Error{IMPG_E_INVALID, "null argument"};
-  if (ix->shard || ix->cluster) throw Error{IMPG_E_UNSUPPORTED, "an index sharded over GPUs is not saved: save the plain index and shard it at load"};
-  save_index(*ix, path);
+  if (ix->shard || ix->cluster) save_sharded(*ix, path);
+  else save_index(*ix, path);
   return IMPG_OK;
   IMPG_CATCH
 }

@@ -293,8 +293,15 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
 void coitrees_visit_rank(uint32_t n, uint32_t *rank_out);
 
 // ---- saved device index (index_io.cpp) ------------------------------------------
-void save_index(const impg_gpu_index &ix, const char *path);
-void load_index(impg_gpu_index &ix, const char *path);  // ix.device set; fills everything but the engine
+struct ShardInfo {  // what a saved part of a sharded index says about itself
+  uint32_t world = 0, rank = 0;
+  std::vector<uint32_t> owner;  // target sequence -> rank
+  bool front = false;           // the file of the handle that fronts the shards of one process (no arrays)
+};
+void save_index(const impg_gpu_index &ix, const char *path, const ShardInfo *shard = nullptr, bool front = false);
+void load_index(impg_gpu_index &ix, const char *path, ShardInfo *shard = nullptr);  // ix.device set; fills everything but the engine
+// sharded.cpp: impg_gpu_index_save of a rank's shard (one file) / of a multi handle (path + path.shard<k>of<n>)
+void save_sharded(const impg_gpu_index &ix, const char *path);
 
 // ---- subset lists (subset.cpp): keep[i] = the list selects names[i]; returns the number of list entries
 size_t subset_select(const char *text, size_t len, const char *const *names, size_t n, uint8_t *keep);

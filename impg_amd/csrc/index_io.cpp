@@ -62,7 +62,9 @@ uint64_t fnv64(uint64_t h, const void *p, size_t n) {  // FNV-1a over 8-byte wor
 
 }  // namespace
 
-void save_index(const impg_gpu_index &cix, const char *path) {
+// shard: this file is one rank's part of an index sharded over GPUs (its world, rank and the target -> rank map follow the
+// host tables); front: the handle that fronts the shards of one process -- host tables only, no arrays.
+void save_index(const impg_gpu_index &cix, const char *path, const ShardInfo *shard, bool front) {
   impg_gpu_index &ix = const_cast<impg_gpu_index &>(cix);  // (blob() is not const; nothing is modified)
   IMPG_HIP(hipSetDevice(ix.device));
   Header h;
@@ -70,10 +72,11 @@ void save_index(const impg_gpu_index &cix, const char *path) {
   memcpy(h.magic, MAGIC, 8);
   h.version = VERSION;
   h.tile_words = TILE_WORDS; h.tile_ops = TILE_OPS; h.tile_subs = TILE_SUBS; h.entry_bytes = sizeof(Entry);
-  h.n_seq = ix.view.n_seq; h.sorted_order = ix.view.sorted_order; h.multi_file = (ix.multi_file ? 1 : 0) | (ix.tp_mode ? 2 : 0) | ((!ix.tp_mode && ix.n_tiles && !ix.blob_bytes[14]) ? 4 : 0);  // 4: no prefix lines
+  h.n_seq = ix.view.n_seq; h.sorted_order = ix.view.sorted_order; h.multi_file = (ix.multi_file ? 1 : 0) | (ix.tp_mode ? 2 : 0) | ((!ix.tp_mode && ix.n_tiles && !ix.blob_bytes[14]) ? 4 : 0)  // 4: no prefix lines
+                                                                            | (shard ? 8 : 0) | (front ? 16 : 0);
   h.n_records = ix.n_records; h.n_entries = ix.n_entries; h.n_tiles = ix.n_tiles; h.n_targets = ix.n_targets;
   h.n_names = ix.seq.names.size(); h.n_file_first = ix.file_first.size(); h.n_tgt_off = ix.h_tgt_off.size();
-  for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) h.blob_bytes[k] = ix.blob_bytes[k];
+  for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) h.blob_bytes[k] = front ? 0 : ix.blob_bytes[k];
   // written next to the target and renamed over it: an interrupted save never leaves a truncated cache behind
   const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
   struct Unlink {
@@ -92,9 +95,14 @@ void save_index(const impg_gpu_index &cix, const char *path) {
   }
   out.write(ix.file_first.data(), ix.file_first.size() * sizeof(uint64_t));
   out.write(ix.h_tgt_off.data(), ix.h_tgt_off.size() * sizeof(uint32_t));
+  if (shard) {
+    const uint32_t hd[3] = {shard->world, shard->rank, (uint32_t)shard->owner.size()};
+    out.write(hd, sizeof hd);
+    out.write(shard->owner.data(), shard->owner.size() * sizeof(uint32_t));
+  }
   std::vector<char> buf;
   for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) {
-    const size_t n = ix.blob_bytes[k];
+    const size_t n = front ? 0 : ix.blob_bytes[k];
     buf.resize(n);
     if (n) IMPG_HIP(hipMemcpy(buf.data(), ix.blob(k)->p, n, hipMemcpyDeviceToHost));
     out.write(buf.data(), n);
@@ -110,7 +118,7 @@ void save_index(const impg_gpu_index &cix, const char *path) {
   guard.keep = true;
 }
 
-void load_index(impg_gpu_index &ix, const char *path) {
+void load_index(impg_gpu_index &ix, const char *path, ShardInfo *shard) {
   File in(path, "rb");
   Header h;
   in.read(&h, sizeof h);
@@ -119,6 +127,9 @@ void load_index(impg_gpu_index &ix, const char *path) {
       h.entry_bytes != sizeof(Entry))
     throw Error{IMPG_E_UNSUPPORTED, in.path + " was written by a build with a different index layout: rebuild it"};
   if (h.n_names != 0 && h.n_names != h.n_seq) throw Error{IMPG_E_INVALID, in.path + ": inconsistent sequence table"};
+  const bool has_shard = (h.multi_file & 8) != 0, front = (h.multi_file & 16) != 0;
+  if (has_shard && !shard) throw Error{IMPG_E_INVALID, in.path + " is a part of an index sharded over GPUs: load it with impg_gpu_index_load_rank / _load_multi"};
+  if (!has_shard && shard) throw Error{IMPG_E_INVALID, in.path + " is not a part of a sharded index"};
   // every array's size follows from the counts in the header: check them all before anything is allocated or uploaded
   {
     if (fseek(in.f, 0, SEEK_END) != 0) throw Error{IMPG_E_IO, "cannot seek in " + in.path};
@@ -133,7 +144,7 @@ void load_index(impg_gpu_index &ix, const char *path) {
                                                     (h.multi_file & 6) ? 0 : T * TILE_WORDS * 4};
     uint64_t total = 0;
     for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) {
-      if (h.blob_bytes[k] != want[k] || (h.blob_bytes[k] & 3)) throw Error{IMPG_E_INVALID, in.path + ": array sizes do not match the header"};
+      if (front ? h.blob_bytes[k] != 0 : h.blob_bytes[k] != want[k] || (h.blob_bytes[k] & 3)) throw Error{IMPG_E_INVALID, in.path + ": array sizes do not match the header"};
       total += h.blob_bytes[k];
     }
     if (total > file_bytes) throw Error{IMPG_E_INVALID, in.path + " is truncated"};
@@ -166,6 +177,17 @@ void load_index(impg_gpu_index &ix, const char *path) {
     if ((i && ix.h_tgt_off[i] < ix.h_tgt_off[i - 1]) || ix.h_tgt_off[i] > h.n_entries || (i == 0 && ix.h_tgt_off[0] != 0))
       throw Error{IMPG_E_INVALID, in.path + ": target offsets are not ascending within the entry count"};
   if (!ix.h_tgt_off.empty() && ix.h_tgt_off.back() != h.n_entries) throw Error{IMPG_E_INVALID, in.path + ": target offsets do not end at the entry count"};
+  if (has_shard) {
+    uint32_t hd[3] = {0, 0, 0};
+    in.read(hd, sizeof hd);
+    if (hd[0] < 1 || hd[1] >= hd[0] || hd[2] != h.n_seq) throw Error{IMPG_E_INVALID, in.path + ": bad shard section"};
+    shard->world = hd[0]; shard->rank = hd[1];
+    shard->owner.resize(hd[2]);
+    in.read(shard->owner.data(), (size_t)hd[2] * sizeof(uint32_t));
+    for (uint32_t o : shard->owner)
+      if (o >= hd[0]) throw Error{IMPG_E_INVALID, in.path + ": a target is owned by a rank outside the world"};
+    shard->front = front;
+  }
   std::vector<char> buf;
   size_t acc = 0;
   for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) {
@@ -173,7 +195,7 @@ void load_index(impg_gpu_index &ix, const char *path) {
     if (n > (1ull << 40)) throw Error{IMPG_E_INVALID, in.path + ": unreasonable array size"};
     buf.resize(n);
     in.read(buf.data(), n);
-    if (k == 0) {  // the segment table addresses every other array: it must stay inside them
+    if (k == 0 && !front) {  // the segment table addresses every other array: it must stay inside them
       const SegDesc *sg = reinterpret_cast<const SegDesc *>(buf.data());
       const uint64_t lvl_words = h.blob_bytes[5] / 4;
       for (uint32_t t = 0; t < h.n_seq; t++) {
@@ -196,6 +218,7 @@ void load_index(impg_gpu_index &ix, const char *path) {
   in.read(&want_sum, 8);
   if (want_sum != sum) throw Error{IMPG_E_INVALID, in.path + " is damaged (checksum of the header, tables and arrays)"};
   ix.device_bytes = acc;
+  if (front) { ix.view.n_seq = h.n_seq; return; }  // (no arrays: the shards hold them)
   ix.bind_view(h.n_seq, h.sorted_order);
 }
 

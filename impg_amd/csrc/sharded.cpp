@@ -909,14 +909,8 @@ void check_comm(const impg_gpu_comm *comm) {
   if (comm->world < 1 || comm->world > (int)ROUTE_WORLD_MAX) throw Error{IMPG_E_INVALID, "world size out of range"};
 }
 
-std::unique_ptr<impg_gpu_index> make_cluster(const impg_gpu_record_t *records, size_t n_records, const uint32_t *ops, size_t n_ops,
-                                             const int64_t *seq_len, uint32_t n_seq, const std::vector<uint64_t> *file_first,
-                                             int bidirectional, int order_policy, const int *devices, int n_dev, int lanes,
-                                             const HostSeqIndex *seq, const TpInput *tp = nullptr) {
-  if (!devices || n_dev < 1 || n_dev > (int)ROUTE_WORLD_MAX) throw Error{IMPG_E_INVALID, "bad device list"};
-  if (lanes < 1 || lanes > 8) throw Error{IMPG_E_INVALID, "lanes must be 1..8"};
-  for (int r = 0; r < n_dev; r++) require_device(devices[r]);
-  const std::vector<uint32_t> owner = owner_map(records, n_records, n_seq, bidirectional, n_dev);
+// the ranks' in-process communicators (one LocalComm per lane, all on one fabric per lane) and peer access between their devices
+std::unique_ptr<Cluster> make_local_comms(const int *devices, int n_dev, int lanes) {
   auto C = std::make_unique<Cluster>();
   std::vector<std::shared_ptr<LocalFabric>> fabs;
   for (int l = 0; l < lanes; l++) fabs.push_back(std::make_shared<LocalFabric>(n_dev));
@@ -939,6 +933,18 @@ std::unique_ptr<impg_gpu_index> make_cluster(const impg_gpu_record_t *records, s
         else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
       }
     }
+  return C;
+}
+
+std::unique_ptr<impg_gpu_index> make_cluster(const impg_gpu_record_t *records, size_t n_records, const uint32_t *ops, size_t n_ops,
+                                             const int64_t *seq_len, uint32_t n_seq, const std::vector<uint64_t> *file_first,
+                                             int bidirectional, int order_policy, const int *devices, int n_dev, int lanes,
+                                             const HostSeqIndex *seq, const TpInput *tp = nullptr) {
+  if (!devices || n_dev < 1 || n_dev > (int)ROUTE_WORLD_MAX) throw Error{IMPG_E_INVALID, "bad device list"};
+  if (lanes < 1 || lanes > 8) throw Error{IMPG_E_INVALID, "lanes must be 1..8"};
+  for (int r = 0; r < n_dev; r++) require_device(devices[r]);
+  const std::vector<uint32_t> owner = owner_map(records, n_records, n_seq, bidirectional, n_dev);
+  auto C = make_local_comms(devices, n_dev, lanes);
   C->ranks.resize(n_dev);
   std::vector<std::exception_ptr> errs(n_dev);
   std::vector<std::thread> th;
@@ -981,9 +987,95 @@ std::unique_ptr<impg_gpu_index> make_cluster(const impg_gpu_record_t *records, s
   front->cluster = C.release();
   return front;
 }
+
+// ---- a sharded index on disk (impg.rs:1655-1850 is the role: start-up without re-reading the alignments) ----------------
+// A rank's shard is one file -- the arrays of that shard plus {world, rank, target -> rank map}; a multi handle is its
+// front file (host tables, the map) at `path` and its shards at path.shard<k>of<n>.  Loading wants the same world.
+static std::string shard_path(const char *path, int k, int n) { return std::string(path) + ".shard" + std::to_string(k) + "of" + std::to_string(n); }
 }  // namespace
+namespace impg {
+void save_sharded(const impg_gpu_index &ix, const char *path) {
+  if (ix.shard) {
+    ShardInfo si;
+    si.world = (uint32_t)ix.shard->comm->world; si.rank = (uint32_t)ix.shard->comm->rank; si.owner = ix.shard->owner;
+    save_index(ix, path, &si, false);
+    return;
+  }
+  const Cluster &C = *ix.cluster;
+  const int n = (int)C.ranks.size();
+  ShardInfo fi;
+  fi.world = (uint32_t)n; fi.rank = 0; fi.owner = C.ranks[0]->shard->owner;
+  for (int r = 0; r < n; r++) {
+    ShardInfo si;
+    si.world = (uint32_t)n; si.rank = (uint32_t)r; si.owner = fi.owner;
+    save_index(*C.ranks[r], shard_path(path, r, n).c_str(), &si, false);
+  }
+  save_index(ix, path, &fi, true);  // written last: a front file means its shards are complete
+}
+}  // namespace impg
 
 extern "C" {
+
+int impg_gpu_index_load_rank(const char *path, int device, impg_gpu_comm_t *comm, impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!path || !out) throw Error{IMPG_E_INVALID, "null argument"};
+  check_comm(comm);
+  require_device(device);
+  auto ix = std::make_unique<impg_gpu_index>();
+  ix->device = device;
+  ShardInfo si;
+  load_index(*ix, path, &si);
+  if (si.front) throw Error{IMPG_E_INVALID, std::string(path) + " is the front file of a multi handle: load it with impg_gpu_index_load_multi"};
+  if ((int)si.world != comm->world || (int)si.rank != comm->rank)
+    throw Error{IMPG_E_INVALID, std::string(path) + " is shard " + std::to_string(si.rank) + " of " + std::to_string(si.world) +
+                                ", this communicator is rank " + std::to_string(comm->rank) + " of " + std::to_string(comm->world)};
+  { EngineLease warm(*ix); }
+  attach_shard(*ix, comm, si.owner);
+  *out = ix.release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+int impg_gpu_index_load_multi(const char *path, const int *devices, int n_dev, int lanes, impg_gpu_index_t **out) {
+  IMPG_TRY
+  if (!path || !out || !devices || n_dev < 1 || n_dev > (int)ROUTE_WORLD_MAX) throw Error{IMPG_E_INVALID, "bad arguments"};
+  if (lanes < 1 || lanes > 8) throw Error{IMPG_E_INVALID, "lanes must be 1..8"};
+  for (int r = 0; r < n_dev; r++) require_device(devices[r]);
+  auto front = std::make_unique<impg_gpu_index>();
+  front->device = devices[0];
+  ShardInfo fi;
+  load_index(*front, path, &fi);
+  if (!fi.front) throw Error{IMPG_E_INVALID, std::string(path) + " is one shard, not the front file of a multi handle"};
+  if ((int)fi.world != n_dev) throw Error{IMPG_E_INVALID, std::string(path) + " was saved over " + std::to_string(fi.world) + " GPUs, asked for " + std::to_string(n_dev)};
+  auto C = make_local_comms(devices, n_dev, lanes);
+  C->ranks.resize(n_dev);
+  std::vector<std::exception_ptr> errs(n_dev);
+  std::vector<std::thread> th;
+  for (int r = 0; r < n_dev; r++)
+    th.emplace_back([&, r] {
+      try {
+        auto ix = std::make_unique<impg_gpu_index>();
+        ix->device = devices[r];
+        ShardInfo si;
+        const std::string sp = shard_path(path, r, n_dev);
+        load_index(*ix, sp.c_str(), &si);
+        if (si.front || (int)si.world != n_dev || (int)si.rank != r || si.owner != fi.owner)
+          throw Error{IMPG_E_INVALID, sp + " does not belong to " + path};
+        { EngineLease warm(*ix); }
+        attach_shard(*ix, C->comms[r].get(), si.owner);
+        C->ranks[r] = std::move(ix);
+      } catch (...) { errs[r] = std::current_exception(); }
+    });
+  for (auto &t : th) t.join();
+  for (auto &e : errs)
+    if (e) std::rethrow_exception(e);
+  front->device_bytes = 0;
+  for (auto &r : C->ranks) front->device_bytes += r->device_bytes;
+  front->cluster = C.release();
+  *out = front.release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
 
 int impg_gpu_shard_assign(const uint64_t *entries_per_target, uint32_t n_seq, uint32_t n_shards, uint32_t *owner_out) {
   IMPG_TRY

@@ -185,11 +185,21 @@ class GpuImpg:
         check(lib().impg_gpu_index_save(self._h, os.fsencode(path)))
 
     @classmethod
-    def load(cls, path, device=0):
-        """impg_gpu_index_load: what `save` wrote, back in HBM without touching the alignment files."""
+    def load(cls, path, device=0, devices=None, lanes=2, comm=None):
+        """impg_gpu_index_load: what `save` wrote, back in HBM without touching the alignment files.
+        devices=[...]: a saved multi handle (impg_gpu_index_load_multi); comm=Comm: this rank's saved shard
+        (impg_gpu_index_load_rank)."""
         h = C.c_void_p(None)
-        check(lib().impg_gpu_index_load(os.fsencode(path), device, C.byref(h)))
-        return cls(h)
+        if devices is not None:
+            dv = np.ascontiguousarray(devices, dtype=np.int32)
+            check(lib().impg_gpu_index_load_multi(os.fsencode(path), dv.ctypes.data, dv.size, lanes, C.byref(h)))
+        elif comm is not None:
+            check(lib().impg_gpu_index_load_rank(os.fsencode(path), device, comm._h, C.byref(h)))
+        else:
+            check(lib().impg_gpu_index_load(os.fsencode(path), device, C.byref(h)))
+        ix = cls(h)
+        ix._comm = comm
+        return ix
 
     @classmethod
     def from_paf(cls, paths, bidirectional=True, order=_lib.ORDER_COITREES, device=0, devices=None, lanes=2, comm=None):

@@ -162,8 +162,13 @@ int impg_gpu_index_create_from_paf(const char *const *paths, int n_paths,
  * parsing and tokenising once.  The file holds the device arrays as they sit in HBM plus the sequence
  * table (so the alignment files are not needed again, unlike with `.impg`, which stores byte offsets into
  * them); it is this library's own layout ("IMPGHBM1"), tied to the build's tile constants, and NOT the
- * reference's IMPGIDX2 format.  Not for a sharded index.  load: IMPG_E_INVALID for a
- * foreign or damaged file, IMPG_E_UNSUPPORTED for a layout version this build does not read. */
+ * reference's IMPGIDX2 format.  A rank's shard of a sharded index is saved the same way (one file per rank, the caller
+ * names it; it also holds the world size, the rank and the target -> rank map) and comes back with
+ * impg_gpu_index_load_rank on a communicator of the same world and rank; a multi handle writes its front file at `path`
+ * and its shards at path.shard<k>of<n> and comes back with impg_gpu_index_load_multi -- so the ranks of a job parse the
+ * alignments once, not once per rank per start (the role of impg.rs:1655-1850).  load: IMPG_E_INVALID for a
+ * foreign or damaged file (or a shard handed to the plain load / the wrong rank), IMPG_E_UNSUPPORTED for a layout
+ * version this build does not read. */
 int impg_gpu_index_save(const impg_gpu_index_t *, const char *path);
 /* The reference's own index file ("IMPGIDX2", or the unidirectional "IMPGIDX1"; writer impg.rs:1655-1721, reader
  * :1787-1850 + :1724-1767; bincode-2 standard encoding): sequence table and every target's intervals come from the
@@ -379,7 +384,7 @@ int impg_gpu_parse_target_range(const char *s, char *name_out, size_t name_cap,
  *
  * `lanes` chunks of a batch ("chunk_ranges") are in flight at once, each on its own engine, stream, host thread
  * and communicator, so one lane's exchange overlaps the other lanes' kernels.
- * Not offered on a sharded index: impg_gpu_index_save (save the plain index, shard at load).  store_cigar, the
+ * impg_gpu_index_save works on a shard and on a multi handle (see there); store_cigar, the
  * device-side BED call and tracepoint indexes work there as on one GPU (the ops follow the hits home).  projected / pairs /
  * stage times of a rank (2) count the work done ON THAT RANK's shard; a multi handle (1) reports the sum of
  * the work and the slowest rank's times. */
@@ -420,6 +425,11 @@ int impg_gpu_index_create_multi(const impg_gpu_record_t *records, size_t n_recor
                                 int lanes, impg_gpu_index_t **out);
 int impg_gpu_index_create_from_paf_multi(const char *const *paths, int n_paths, int bidirectional, int order_policy,
                                          const int *devices, int n_dev, int lanes, impg_gpu_index_t **out);
+/* What impg_gpu_index_save wrote for a rank's shard / for a multi handle, back in HBM without the alignment files.
+ * load_rank: collective in the sense that every rank loads its own file before the first query; the file's world and
+ * rank must be the communicator's.  load_multi: n_dev must be the number of GPUs the handle was saved over. */
+int impg_gpu_index_load_rank(const char *path, int device, impg_gpu_comm_t *comm, impg_gpu_index_t **out);
+int impg_gpu_index_load_multi(const char *path, const int *devices, int n_dev, int lanes, impg_gpu_index_t **out);
 /* The shard map: owner_out[t] = shard of target t given its entry count (host-only, deterministic). */
 int impg_gpu_shard_assign(const uint64_t *entries_per_target, uint32_t n_seq, uint32_t n_shards, uint32_t *owner_out);
 /* rank (-1 for a multi handle), world, lanes and the shard map of an index (1 / 0 for a plain one) */

@@ -110,6 +110,24 @@ def main():
             assert res[i].tolist() == want.tolist(), (rank, i, kw)
             got = res.cigars(i)
             assert [x.tolist() for x in got] == [x.tolist() for x in wcg], (rank, i, kw)
+    # the rank's shard saved and loaded back on the same communicator (one file per rank): same answers, no PAF needed
+    saved = "%s.rank%dof%d.idx" % (paf_path, rank, world)
+    g.save(saved)
+    del g
+    try:
+        impg_amd.GpuImpg.load(saved)
+        raise AssertionError("a shard must not open as a plain index")
+    except impg_amd.ImpgGpuError as e:
+        assert e.code == impg_amd.IMPG_E_INVALID
+    g = impg_amd.GpuImpg.load(saved, device=device, comm=comm)
+    assert g.shard_info()[:3] == (rank, world, lanes)
+    assert (owner is None and g.shard_info()[3] is None) or g.shard_info()[3].tolist() == owner.tolist()
+    g.set_option("chunk_ranges", 7)
+    for kw in (dict(transitive=True, max_depth=3, min_transitive_len=20), dict(transitive=True, dfs=True, max_depth=2, multi_impg=True)):
+        got = g.query_batch(rl, impg_amd.make_params(**kw))
+        for i, (t, s, e) in enumerate(rl):
+            assert got[i].tolist() == c.query(t, s, e, **kw).tolist(), (rank, i, kw, "loaded")
+    os.unlink(saved)
     dist.barrier()
     if rank == 0:
         print("multi ok world=%d lanes=%d transport=%s" % (world, lanes, transport))

@@ -706,12 +706,15 @@ def test_saved_index_round_trip(tmp_path, n_files):
     b = h.query_batch(ranges[:10], impg_amd.make_params(store_cigar=True, **kw))
     for i in range(10):
         assert a[i].tolist() == b[i].tolist() and [x.tolist() for x in a.cigars(i)] == [x.tolist() for x in b.cigars(i)]
-    # an index sharded over GPUs is not saved
+    # an index sharded over GPUs is saved part by part (tests/test_multi_gpu.py::test_multi_handle_save_load); its parts are
+    # not plain indexes
     paths0 = [str(tmp_path / ("f%d.paf" % k)) for k in range(n_files)]
     sh = impg_amd.GpuImpg.from_paf(paths0, devices=[0, 0, 0])
-    with pytest.raises(impg_amd.ImpgGpuError):
-        sh.save(str(tmp_path / "sharded.impghbm"))
+    sh.save(str(tmp_path / "sharded.impghbm"))
     del sh
+    for part in ("sharded.impghbm", "sharded.impghbm.shard0of3"):
+        with pytest.raises(impg_amd.ImpgGpuError):
+            impg_amd.GpuImpg.load(str(tmp_path / part))
     # a second save of the loaded index is the same file
     again = str(tmp_path / "again.impghbm")
     h.save(again)

@@ -1,6 +1,7 @@
 """The index sharded over GPUs, on the GPU box (one MI355X: the shards of a multi handle share device 0, the
 ranks of the process-per-rank runs share it too; only the transport differs from an 8-GPU node).
 Everything goes through the C ABI; results are compared with the oracle row for row."""
+import os
 import threading
 
 import numpy as np
@@ -106,6 +107,43 @@ def test_multi_handle_matches_oracle(tmp_path, world, lanes):
     assert len(g.query_batch([], impg_amd.make_params(transitive=True))) == 0
     got = g.query_batch(rl[:2], impg_amd.make_params(transitive=True, max_depth=2))
     assert [got[i].tolist() for i in range(2)] == [c.query(*rl[i], transitive=True, max_depth=2).tolist() for i in range(2)]
+
+
+def test_multi_handle_save_load(tmp_path):
+    """A multi handle saved (front file + one file per shard) and loaded back: same answers without the PAF; the parts
+    refuse to open as anything else (impg_gpu_index_load_multi / _load_rank; the role of impg.rs:1655-1850)."""
+    path = write_paf(tmp_path)
+    c = o.OracleIndex(paf_paths=[path], preparse=True)
+    g = impg_amd.GpuImpg.from_paf(path, devices=[0] * 3, lanes=2)
+    saved = str(tmp_path / "multi.idx")
+    g.save(saved)
+    assert all(os.path.exists("%s.shard%dof3" % (saved, k)) for k in range(3))
+    owner = g.shard_info()[3]
+    del g
+    os.unlink(path)  # (the alignment files are not needed again)
+    for bad in (lambda: impg_amd.GpuImpg.load(saved), lambda: impg_amd.GpuImpg.load(saved + ".shard1of3"),
+                lambda: impg_amd.GpuImpg.load(saved, devices=[0] * 2), lambda: impg_amd.GpuImpg.load(saved + ".shard0of3", devices=[0] * 3)):
+        with pytest.raises(impg_amd.ImpgGpuError) as e:
+            bad()
+        assert e.value.code == impg_amd.IMPG_E_INVALID
+    g = impg_amd.GpuImpg.load(saved, devices=[0] * 3, lanes=2)
+    r, w, l, owner2 = g.shard_info()
+    assert (r, w, l) == (-1, 3, 2) and owner2.tolist() == owner.tolist()
+    assert g.num_seqs() == c.num_seqs() and g.seq_name(1) == c.seq_name(1)
+    g.set_option("chunk_ranges", 7)
+    rl = random_ranges(100, 41, c.num_seqs(), 20000, max_len=3000, min_len=120)
+    for kw in (dict(), dict(transitive=True, max_depth=3, min_transitive_len=20), dict(transitive=True, dfs=True, max_depth=2, multi_impg=True),
+               dict(transitive=True, max_depth=2, min_identity=0.6)):
+        got = g.query_batch(rl, impg_amd.make_params(**kw))
+        for i, (t, s, e) in enumerate(rl):
+            assert got[i].tolist() == c.query(t, s, e, **kw).tolist(), (i, kw)
+    check_cigars(g, c, rl, transitive=True, max_depth=2, min_transitive_len=40)
+    # a shard file cut short is refused
+    with open(saved + ".shard2of3", "r+b") as f:
+        f.truncate(os.path.getsize(saved + ".shard2of3") - 64)
+    del g
+    with pytest.raises(impg_amd.ImpgGpuError):
+        impg_amd.GpuImpg.load(saved, devices=[0] * 3)
 
 
 def test_multi_handle_pair_budget_slices(tmp_path):

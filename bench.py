@@ -530,6 +530,42 @@ def full_results_leg(index, ranges, params):
     out["workload"] = ("config 3: first %d ranges, same PAF and flags, impg_gpu_query_batch (rows placed on the device, one D2H "
                        "into a pinned result block)" % n)
     out["calls"] = legs
+    out["stream"] = row_stream_leg(index, ranges, params)
+    return out
+
+
+def row_stream_leg(index, ranges, params):
+    """The whole headline batch's rows through impg_gpu_query_batch_stream: 10 000-range chunks computed on two engines in
+    turn, each chunk's rows copied into one of two pinned blocks while the next chunk is computed, handed over in range
+    order.  The consumer here reads one column of every chunk (the rows are touched, not just counted).  Two passes: the
+    first pins the two blocks."""
+    import numpy as np
+    chunk = 10_000
+    legs = []
+    for label in ("first call (the two blocks pinned during the call)", "second call (blocks recycled)"):
+        log("row-stream leg: impg_gpu_query_batch_stream on %d ranges, %s" % (len(ranges), label))
+        seen = {"rows": 0, "chunks": 0, "ranges": 0, "sum": 0, "max_chunk_rows": 0}
+
+        def consume(first, part):
+            assert first == seen["ranges"]
+            seen["rows"] += part.total
+            seen["ranges"] += len(part)
+            seen["chunks"] += 1
+            seen["max_chunk_rows"] = max(seen["max_chunk_rows"], part.total)
+            if part.total:
+                seen["sum"] += int(part.intervals["query_id"][:: max(1, part.total // 65536)].astype(np.int64).sum())
+            return False
+
+        t0 = time.perf_counter()
+        proj = index.query_batch_stream(ranges, consume, params, chunk_ranges=chunk)
+        dt = time.perf_counter() - t0
+        legs.append({"call": label, "rows": seen["rows"], "projected": proj, "chunks": seen["chunks"], "seconds": dt,
+                     "rows_per_s": seen["rows"] / dt if dt > 0 else None, "GB_per_s": seen["rows"] * 24 / dt / 1e9 if dt > 0 else None,
+                     "largest_chunk_GB": seen["max_chunk_rows"] * 24 / 1e9})
+    out = dict(legs[-1])
+    out["workload"] = ("the headline batch's rows (%d ranges, -x -m 3) through impg_gpu_query_batch_stream, %d-range chunks, "
+                       "two pinned blocks" % (len(ranges), chunk))
+    out["calls"] = legs
     return out
 
 

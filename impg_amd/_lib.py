@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("IMPG_GPU_LIB") or os.path.join(_HERE, "libimpg_gpu.so
 CSRC = os.path.join(_HERE, "csrc")
 
 IMPG_OK = 0
-IMPG_E_INVALID, IMPG_E_HIP, IMPG_E_OOM, IMPG_E_IO, IMPG_E_UNSUPPORTED = -1, -2, -3, -4, -5
+IMPG_E_INVALID, IMPG_E_HIP, IMPG_E_OOM, IMPG_E_IO, IMPG_E_UNSUPPORTED, IMPG_E_CANCELLED = -1, -2, -3, -4, -5, -6
+STREAM_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 ORDER_COITREES, ORDER_SORTED = 0, 1
 HIT_NONE = 0xFFFFFFFF
 
@@ -95,6 +96,7 @@ SYMBOLS = [
     ("impg_gpu_index_create_from_paf", C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_save", C.c_int, [_P, C.c_char_p]),
     ("impg_gpu_index_load", C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
+    ("impg_gpu_query_batch_stream", C.c_int, [_P, _P, C.c_size_t, _P, _P, _P, C.c_size_t, C.c_size_t, _P, _P, C.POINTER(C.c_uint64)]),
     ("impg_gpu_index_load_rank", C.c_int, [C.c_char_p, C.c_int, _P, C.POINTER(_P)]),
     ("impg_gpu_index_load_multi", C.c_int, [C.c_char_p, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     ("impg_gpu_index_load_impg", C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),

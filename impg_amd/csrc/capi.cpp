@@ -115,14 +115,19 @@ std::unique_ptr<impg_gpu_index> make_index(const impg_gpu_record_t *records, siz
 namespace impg {
 // What the trait returns for one chunk: rows placed by the device (rows_device.hip), one copy across PCIe into a
 // pinned block of the result, offsets widened on the host.  `levels` are consumed.
+// max_rows: a chunk of several ranges with more rows than this is not assembled -- SplitBatch, the caller halves it
+// (the row stream's bound on its host blocks); kernels_done: recorded on the stream once the chunk's last kernel is
+// enqueued, ahead of the copies (whoever takes turns on the GPU may let the next one in while the rows cross PCIe)
 void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p,
-                      std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, impg_gpu_results &res) {
+                      std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, impg_gpu_results &res, uint64_t max_rows,
+                      hipEvent_t kernels_done) {
   hipStream_t s = E.stream;
   res.ranges.assign(h_ranges, h_ranges + n);
   res.has_cigar = p.store_cigar != 0;
   RowPlan pl;
   plan_rows(E, n, p, levels, self_dev, false, pl);
   const size_t nr = pl.n_rows;
+  if (nr > max_rows && n > 1) throw SplitBatch{};
   DevBuf rows, clen, coff, cpool;
   for (DevBuf *b : {&rows, &clen, &coff, &cpool}) b->pool = &E.level_pool;
   rows.reserve(std::max<size_t>(nr * sizeof(impg_gpu_interval_t), 256));
@@ -137,9 +142,13 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
     const uint64_t n_ops = build_row_cigars(E, levels, pl, clen, coff, cpool);
     res.cigar_off.resize(nr + 1, true);
     res.cigar_ops.resize(n_ops, true);
+    if (kernels_done) IMPG_HIP(hipEventRecord(kernels_done, s));
     IMPG_HIP(hipMemcpyAsync(res.cigar_off.data(), coff.p, (nr + 1) * 8, hipMemcpyDeviceToHost, s));
     if (n_ops) IMPG_HIP(hipMemcpyAsync(res.cigar_ops.data(), cpool.p, n_ops * 4, hipMemcpyDeviceToHost, s));
+  } else if (kernels_done) {
+    IMPG_HIP(hipEventRecord(kernels_done, s));  // (behind the rows' copy: what follows is host work only)
   }
+  if (kernels_done) { IMPG_HIP(hipEventSynchronize(kernels_done)); if (E.on_kernels_done) E.on_kernels_done(); }
   IMPG_HIP(hipStreamSynchronize(s));
   levels.clear();
   res.offsets.resize((size_t)n + 1);
@@ -653,6 +662,134 @@ int impg_gpu_query(impg_gpu_index_t *ix, uint32_t target_id, int32_t start, int3
                    impg_gpu_results_t **out) {
   impg_gpu_range_t r{target_id, start, end};
   return impg_gpu_query_batch(ix, &r, 1, params, out);
+}
+
+// The trait's rows for a batch that does not fit one result object (the headline's 100 000 ranges return 2.1 x 10^9 rows,
+// 51 GB; the reference prints range by range, main.rs:7435-7470): chunks of the batch are computed on two engines in
+// turn, each chunk's rows placed on the device and copied into that engine's pinned block while the other engine
+// computes the next chunk, and handed to the callback in range order.
+int impg_gpu_query_batch_stream(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
+                                const impg_gpu_mask_t *mask, const uint8_t *subset_keep, size_t chunk_ranges, size_t max_block_bytes,
+                                impg_gpu_stream_cb cb, void *ctx, uint64_t *projected_out) {
+  IMPG_TRY
+  if (!ix || !params || !cb || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
+  check_ranges(ranges, n);
+  Engine::check_params(*params);
+  if (!chunk_ranges) chunk_ranges = 8192;
+  if (!max_block_bytes) max_block_bytes = 6ull << 30;
+  const uint64_t max_rows = std::max<uint64_t>(1, max_block_bytes / sizeof(impg_gpu_interval_t));
+  uint64_t projected = 0;
+  if (ix->shard || ix->cluster) {
+    // a sharded index: the chunks one after the other through the collective call (every rank streams its own ranges;
+    // ranks must agree on n == 0 or not per call, as for impg_gpu_query_batch)
+    for (size_t b = 0; b < n || (b == 0 && n == 0); b += chunk_ranges) {
+      const size_t e = std::min(n, b + chunk_ranges);
+      impg_gpu_results_t *part = nullptr;
+      const int rc = sharded_query_batch(*ix, ranges + b, e - b, *params, mask, subset_keep, &part);
+      if (rc != IMPG_OK) return rc;
+      std::unique_ptr<impg_gpu_results> own(part);
+      projected += part->projected;
+      if (e > b && cb(ctx, part, b) != 0) throw Error{IMPG_E_CANCELLED, "the row stream's consumer stopped it"};
+      if (n == 0) break;
+    }
+    if (projected_out) *projected_out = projected;
+    return IMPG_OK;
+  }
+  IMPG_HIP(hipSetDevice(ix->device));
+  struct Shared {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t next_begin = 0, chunk = 0;
+    uint64_t next_seq = 0, deliver_seq = 0;
+    bool stop = false;
+    std::mutex gpu;  // whose kernels are on the GPU (two chunks' kernels side by side evict each other's lines from L2)
+    std::exception_ptr err;
+    uint64_t projected = 0;
+  } sh;
+  sh.chunk = chunk_ranges;
+  auto worker = [&]() {
+    try {
+      IMPG_HIP(hipSetDevice(ix->device));
+      EngineLease lease(*ix);
+      Engine &E = *lease;
+      apply_mask(E, *ix, mask, *params);
+      apply_subset(E, *ix, subset_keep);
+      E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
+      if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
+      struct Ev {  // (an event of the call's own: the engine recycles its pool run by run)
+        hipEvent_t e = nullptr;
+        Ev() { IMPG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+        ~Ev() { if (e) (void)hipEventDestroy(e); }
+      } done_ev;
+      hipEvent_t done = done_ev.e;
+      impg_gpu_results part;  // reused chunk after chunk: its pinned arrays grow to the largest chunk and stay
+      for (;;) {
+        size_t b, e;
+        uint64_t seq;
+        {
+          std::unique_lock<std::mutex> lk(sh.m);
+          if (sh.stop || sh.next_begin >= n) break;
+          b = sh.next_begin; e = std::min(n, b + sh.chunk);
+          sh.next_begin = e; seq = sh.next_seq++;
+        }
+        // the chunk, in pieces if it outgrows the pair budget or the block (pieces are delivered in order within the turn)
+        std::vector<std::pair<size_t, size_t>> todo{{b, e}};
+        while (!todo.empty()) {
+          const auto [pb, pe] = todo.back();
+          todo.pop_back();
+          std::unique_lock<std::mutex> turn(sh.gpu);
+          bool released = false;
+          E.on_kernels_done = [&]() { if (!released) { released = true; turn.unlock(); } };
+          try {
+            std::vector<std::unique_ptr<LevelBufs>> levels;
+            DevBuf self_dev;
+            self_dev.pool = &E.level_pool;
+            const auto c0 = std::chrono::steady_clock::now();
+            E.run(*ix, E.ranges_dev.as<impg_gpu_range_t>() + pb, (uint32_t)(pe - pb), *params, &levels, nullptr, nullptr, nullptr, &self_dev);
+            const auto c1 = std::chrono::steady_clock::now();
+            part.offsets.clear(); part.intervals.clear(); part.cigar_off.clear(); part.cigar_ops.clear();
+            assemble_results(E, ranges + pb, (uint32_t)(pe - pb), *params, levels, self_dev, part, max_rows, done);
+            part.run_s = std::chrono::duration<double>(c1 - c0).count();
+            part.assemble_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - c1).count();
+          } catch (const SplitBatch &) {
+            E.on_kernels_done = nullptr;
+            if (pe - pb <= 1) throw Error{IMPG_E_UNSUPPORTED, "a single range exceeds the pair budget"};
+            const size_t mid = pb + (pe - pb) / 2;
+            todo.push_back({mid, pe});
+            todo.push_back({pb, mid});
+            continue;
+          }
+          E.on_kernels_done = nullptr;
+          if (!released) turn.unlock();
+          // in range order: this chunk's turn comes when every earlier chunk has been handed over
+          std::unique_lock<std::mutex> lk(sh.m);
+          sh.cv.wait(lk, [&] { return sh.stop || sh.deliver_seq == seq; });
+          if (sh.stop) break;
+          sh.projected += part.projected;
+          lk.unlock();
+          if (cb(ctx, &part, pb) != 0) throw Error{IMPG_E_CANCELLED, "the row stream's consumer stopped it"};
+        }
+        std::lock_guard<std::mutex> lk(sh.m);
+        if (sh.stop) break;
+        sh.deliver_seq = seq + 1;
+        sh.cv.notify_all();
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(sh.m);
+      if (!sh.err) sh.err = std::current_exception();
+      sh.stop = true;
+      sh.cv.notify_all();
+    }
+  };
+  if (n) {
+    std::thread second(worker);
+    worker();
+    second.join();
+  }
+  if (sh.err) std::rethrow_exception(sh.err);
+  if (projected_out) *projected_out = sh.projected;
+  return IMPG_OK;
+  IMPG_CATCH
 }
 
 size_t impg_gpu_results_num_ranges(const impg_gpu_results_t *r) { return r->offsets.empty() ? 0 : r->offsets.size() - 1; }

@@ -87,6 +87,7 @@ struct Engine {
   // five-key sort walk the reference's slot order.)
   bool free_slot_order = false;
   bool free_slots_allowed = true;  // option "free_slot_order" (A/B runs)
+  std::function<void()> on_kernels_done;  // the row stream: called by assemble_results once the chunk's kernels have run (the copies follow)
   bool regroup_pairs = true;       // option "regroup_entries": a projection block sorts its 256 pairs by entry first
   // A counting run's final level (max_depth reached, or a plain query): no update follows and no row is kept, so nothing
   // reads its slots in order -- the projection kernel enumerates the pairs from the count pass's windows and the emit
@@ -213,7 +214,8 @@ std::unique_ptr<impg_gpu_index> make_index(const impg_gpu_record_t *records, siz
                                            const HostSeqIndex *seq, const std::vector<uint64_t> *file_first,
                                            const uint32_t *owner);
 void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, const impg_gpu_params_t &p,
-                      std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, impg_gpu_results &res);
+                      std::vector<std::unique_ptr<LevelBufs>> &levels, DevBuf &self_dev, impg_gpu_results &res,
+                      uint64_t max_rows = ~0ull, hipEvent_t kernels_done = nullptr);
 // ---- result rows on the device (rows_device.hip) ---------------------------------------------------------------
 // Where every emitted slot of a chunk goes among the chunk's result rows (grouped by range, emission order within).
 struct RowPlan {

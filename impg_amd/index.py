@@ -101,7 +101,7 @@ class QueryResults:
             _lib.free(text)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not getattr(self, "_borrowed", False):
             try:
                 lib().impg_gpu_results_free(self._h)
             except Exception:
@@ -311,6 +311,43 @@ class GpuImpg:
         else:
             check(lib().impg_gpu_query_batch(self._h, r.ctypes.data, r.size, C.byref(p), C.byref(h)))
         return QueryResults(h, self, copy=copy)
+
+    def query_batch_stream(self, ranges, consumer, params=None, masked_regions=None, subset_keep=None, chunk_ranges=0,
+                           max_block_bytes=0, copy=False, **kw):
+        """impg_gpu_query_batch_stream: the rows of a batch too big for one result object, chunk by chunk in range order.
+        consumer(first_range, QueryResults) is called for every chunk (copy=False: its arrays are views of the library's
+        pinned block, valid only during the call); a truthy return stops the stream.  Returns the projections counted."""
+        p = params or make_params(**kw)
+        r = self._ranges(ranges)
+        keep = None
+        if subset_keep is not None:
+            keep = np.ascontiguousarray(subset_keep, dtype=np.uint8)
+            if keep.size != self.num_seqs():
+                raise _lib.ImpgGpuError(_lib.IMPG_E_INVALID, "subset_keep needs one entry per sequence")
+        m, keepalive = self._mask(masked_regions) if masked_regions is not None else (None, None)
+        failure = []
+
+        def trampoline(ctx, chunk, first):
+            try:
+                q = QueryResults.__new__(QueryResults)
+                q._borrowed = True
+                QueryResults.__init__(q, C.c_void_p(chunk), self, copy=copy)
+                return 1 if consumer(int(first), q) else 0
+            except BaseException as e:  # (an exception must not unwind through the library's thread)
+                failure.append(e)
+                return 1
+
+        cb = _lib.STREAM_CB(trampoline)
+        proj = C.c_uint64(0)
+        rc = lib().impg_gpu_query_batch_stream(self._h, r.ctypes.data, r.size, C.byref(p), C.byref(m) if m is not None else None,
+                                               None if keep is None else keep.ctypes.data, chunk_ranges, max_block_bytes,
+                                               C.cast(cb, C.c_void_p), None, C.byref(proj))
+        del keepalive
+        if failure:
+            raise failure[0]
+        if rc != _lib.IMPG_E_CANCELLED:
+            check(rc)
+        return proj.value
 
     def query_batch_bed(self, ranges, params=None, merge_distance=0, range_names=None, subset_keep=None, timing=False, raw=False, **kw):
         """impg_gpu_query_batch_bed: query + both BED merges on the device + text (what `impg query -o bed` prints)."""

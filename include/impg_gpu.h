@@ -29,6 +29,7 @@ extern "C" {
 #define IMPG_E_OOM (-3)
 #define IMPG_E_IO (-4)
 #define IMPG_E_UNSUPPORTED (-5) /* valid in the reference, not built yet */
+#define IMPG_E_CANCELLED (-6)   /* a callback of the caller's asked the call to stop */
 
 typedef struct impg_gpu_index impg_gpu_index_t;
 typedef struct impg_gpu_results impg_gpu_results_t;
@@ -261,6 +262,19 @@ int impg_gpu_query_batch_masked(impg_gpu_index_t *, const impg_gpu_range_t *rang
 int impg_gpu_query_batch_filtered(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n,
                                   const impg_gpu_params_t *params, const impg_gpu_mask_t *mask,
                                   const uint8_t *subset_keep, impg_gpu_results_t **out);
+/* The same rows for a batch too big for one result object (the 100 000-range headline batch returns 2.1 x 10^9 rows,
+ * 51 GB): the batch is cut into chunks of chunk_ranges ranges (0 = 8192; a chunk that outgrows the pair budget or
+ * max_block_bytes of rows -- 0 = 6 GiB -- is halved), two engines compute them in turn, and `cb` receives every chunk
+ * as a results object (the impg_gpu_results_* accessors; its range i is ranges[first_range + i]) valid until the
+ * callback returns -- IN RANGE ORDER, one call at a time, from a thread of the library, while the next chunk is
+ * computed and copied: what a caller that prints or folds range by range consumes (main.rs:7435-7470).  Host memory:
+ * two pinned blocks of at most max_block_bytes (+ the CIGAR pools under store_cigar).  A non-zero return of the
+ * callback stops the stream (IMPG_E_CANCELLED).  mask / subset_keep as in impg_gpu_query_batch_filtered (NULL = none).
+ * On a sharded index the chunks run one after the other through the collective call (no overlap). */
+typedef int (*impg_gpu_stream_cb)(void *ctx, const impg_gpu_results_t *chunk, size_t first_range);
+int impg_gpu_query_batch_stream(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t *params,
+                                const impg_gpu_mask_t *mask, const uint8_t *subset_keep, size_t chunk_ranges, size_t max_block_bytes,
+                                impg_gpu_stream_cb cb, void *ctx, uint64_t *projected_out);
 /* The name matching for hosts that do not bring their own SubsetFilter: list_text is the content of a
  * `--subset-sequence-list` file (one name per line, '#' comments; parse_subset_filter, subset_filter.rs:117-141);
  * keep_out[i] = SubsetFilter::matches(names[i]) (:23-60: exact, without ":start-end", or by the

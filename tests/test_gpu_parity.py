@@ -1423,3 +1423,56 @@ def test_walk_kernel_matches_oracle_and_batch_engine(tmp_path, seed):
         assert_same(g, c, ranges[:40], subset_keep=keep, transitive=True, max_depth=3, min_transitive_len=30)
         assert g.query_transitive_dfs(*ranges[0], max_depth=3).tolist() == c.query(*ranges[0], transitive=True, dfs=True, max_depth=3).tolist()
         assert g.query_transitive_bfs(*ranges[0], max_depth=3).tolist() == c.query(*ranges[0], transitive=True, max_depth=3).tolist()
+
+
+# ---- the row stream: impg_gpu_query_batch_stream ---------------------------------
+def test_query_batch_stream_matches_the_one_shot_call(tmp_path):
+    """Chunks arrive in range order, one at a time, and hold the rows (and CIGARs) impg_gpu_query_batch returns for the same
+    ranges -- whatever the chunk size, also when chunks are halved to stay under the block size, under a mask / a subset
+    filter, and a consumer can stop the stream (main.rs:7435-7470 is the loop this feeds)."""
+    text, _ = random_paf(4242, 300, n_seq=7, seq_len=30000, self_aln=True, max_ops=120)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(17, 61, g.num_seqs(), 30000, max_len=4000, min_len=100)
+    seq_len = int(c.seq_len(0))
+    mask = {0: (seq_len, [(100, 2000), (5000, 9000)]), 2: (seq_len, [(0, 700)])}
+    keep = np.array([1, 0, 1, 1, 0, 1, 1], dtype=np.uint8)
+    cases = [(dict(), {}), (dict(transitive=True, max_depth=3, min_transitive_len=20), {}),
+             (dict(transitive=True, dfs=True, max_depth=2, min_transitive_len=40), {}),
+             (dict(transitive=True, max_depth=2, multi_impg=True), {}),
+             (dict(transitive=True, max_depth=2), dict(masked_regions=mask)),
+             (dict(transitive=True, max_depth=2), dict(subset_keep=keep)),
+             (dict(transitive=True, max_depth=2, min_transitive_len=40, store_cigar=True), {})]
+    for kw, extra in cases:
+        p = impg_amd.make_params(**kw)
+        want = g.query_batch(ranges, p, **extra)
+        for chunk, block in ((7, 0), (1, 0), (1000, 0), (16, 24 * 10)):
+            seen = []
+
+            def consume(first, part):
+                assert first == (seen[-1][0] + seen[-1][1] if seen else 0)  # in range order, nothing skipped
+                rows = [part[i].tolist() for i in range(len(part))]
+                cg = [[x.tolist() for x in part.cigars(i)] for i in range(len(part))] if kw.get("store_cigar") else None
+                seen.append((first, len(part), rows, cg))
+                return False
+
+            proj = g.query_batch_stream(ranges, consume, p, chunk_ranges=chunk, max_block_bytes=block, **extra)
+            assert proj == want.projected, (kw, chunk)
+            assert sum(n for _, n, _, _ in seen) == len(ranges)
+            if block:  # (chunks of several ranges are halved until their rows fit the block: 10 rows here)
+                assert all(n == 1 or sum(len(r) for r in rows) <= 10 for _, n, rows, _ in seen) and len(seen) > len(ranges) // 16 + 1
+            i = 0
+            for first, n, rows, cg in seen:
+                for k in range(n):
+                    assert rows[k] == want[i].tolist(), (kw, chunk, i)
+                    if cg is not None:
+                        assert cg[k] == [x.tolist() for x in want.cigars(i)], (kw, chunk, i)
+                    i += 1
+    # a consumer that stops after the second chunk; one that raises
+    calls = []
+    g.query_batch_stream(ranges, lambda first, part: calls.append(first) or len(calls) >= 2, impg_amd.make_params(transitive=True), chunk_ranges=5)
+    assert calls == [0, 5]
+    with pytest.raises(ZeroDivisionError):
+        g.query_batch_stream(ranges, lambda first, part: 1 // 0, impg_amd.make_params(), chunk_ranges=5)
+    assert g.query_batch_stream([], lambda first, part: False, impg_amd.make_params()) == 0
+    # the handle is fine afterwards
+    assert_same(g, c, ranges[:10], transitive=True, max_depth=2)

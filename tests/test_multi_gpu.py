@@ -146,6 +146,24 @@ def test_multi_handle_save_load(tmp_path):
         impg_amd.GpuImpg.load(saved, devices=[0] * 3)
 
 
+def test_multi_handle_row_stream(tmp_path):
+    """impg_gpu_query_batch_stream on a sharded index: the chunks go through the collective call one after the other."""
+    path = write_paf(tmp_path)
+    c = o.OracleIndex(paf_paths=[path], preparse=True)
+    g = impg_amd.GpuImpg.from_paf(path, devices=[0] * 3, lanes=2)
+    rl = random_ranges(100, 37, c.num_seqs(), 20000, max_len=3000, min_len=120)
+    for kw in (dict(), dict(transitive=True, max_depth=3, min_transitive_len=20)):
+        got = []
+        total = g.query_batch_stream(rl, lambda first, part: got.extend((first + i, part[i].tolist()) for i in range(len(part))) or False,
+                                     impg_amd.make_params(**kw), chunk_ranges=8)
+        assert [i for i, _ in got] == list(range(len(rl)))
+        want_total = 0
+        for i, (t, s, e) in enumerate(rl):
+            assert got[i][1] == c.query(t, s, e, **kw).tolist(), (i, kw)
+            want_total += c.last_projection_count()
+        assert total == want_total
+
+
 def test_multi_handle_pair_budget_slices(tmp_path):
     """Owners expand what arrives in slices under the pair budget; results do not change."""
     path = write_paf(tmp_path, seed=5, n=400)

@@ -535,12 +535,12 @@ def full_results_leg(index, ranges, params):
 
 
 def row_stream_leg(index, ranges, params):
-    """The whole headline batch's rows through impg_gpu_query_batch_stream: 10 000-range chunks computed on two engines in
+    """The whole headline batch's rows through impg_gpu_query_batch_stream: 4 000-range chunks (2 GB of rows each) computed on two engines in
     turn, each chunk's rows copied into one of two pinned blocks while the next chunk is computed, handed over in range
     order.  The consumer here reads one column of every chunk (the rows are touched, not just counted).  Two passes: the
     first pins the two blocks."""
     import numpy as np
-    chunk = 10_000
+    chunk = 4_000
     legs = []
     for label in ("first call (the two blocks pinned during the call)", "second call (blocks recycled)"):
         log("row-stream leg: impg_gpu_query_batch_stream on %d ranges, %s" % (len(ranges), label))

@@ -134,6 +134,10 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
   if (res.has_cigar) clen.reserve(std::max<size_t>(nr * 4, 256));
   scatter_rows(E, levels, pl, RowSinks{rows.as<impg_gpu_interval_t>(), nullptr, nullptr, nullptr, nullptr,
                                        res.has_cigar ? clen.as<uint32_t>() : nullptr});
+  // (the row stream reuses `res` chunk after chunk: a chunk a little larger than every one before it must not pin a new
+  // block -- seconds for 5 GB --, so its blocks grow with a quarter to spare, within the stream's bound)
+  if (max_rows != ~0ull && nr * sizeof(impg_gpu_interval_t) > res.intervals.cap)
+    res.intervals.reserve(std::max<size_t>(nr, (size_t)std::min<uint64_t>(max_rows, nr + nr / 4)), true);
   res.intervals.resize(nr, true);
   std::vector<uint32_t> off32((size_t)n + 1);
   IMPG_HIP(hipMemcpyAsync(off32.data(), pl.offsets.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -676,7 +680,7 @@ int impg_gpu_query_batch_stream(impg_gpu_index_t *ix, const impg_gpu_range_t *ra
   check_ranges(ranges, n);
   Engine::check_params(*params);
   if (!chunk_ranges) chunk_ranges = 8192;
-  if (!max_block_bytes) max_block_bytes = 6ull << 30;
+  if (!max_block_bytes) max_block_bytes = 5ull << 29;  // 2.5 GiB: two such blocks go back into the pinned pool (6 GiB) after the call
   const uint64_t max_rows = std::max<uint64_t>(1, max_block_bytes / sizeof(impg_gpu_interval_t));
   uint64_t projected = 0;
   if (ix->shard || ix->cluster) {
@@ -755,6 +759,10 @@ int impg_gpu_query_batch_stream(impg_gpu_index_t *ix, const impg_gpu_range_t *ra
             E.on_kernels_done = nullptr;
             if (pe - pb <= 1) throw Error{IMPG_E_UNSUPPORTED, "a single range exceeds the pair budget"};
             const size_t mid = pb + (pe - pb) / 2;
+            {  // (the chunks still to be dealt start at the size that fitted: a split costs the run that found it out)
+              std::lock_guard<std::mutex> lk(sh.m);
+              sh.chunk = std::min(sh.chunk, std::max<size_t>(1, (pe - pb) / 2));
+            }
             todo.push_back({mid, pe});
             todo.push_back({pb, mid});
             continue;

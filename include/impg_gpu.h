@@ -264,7 +264,8 @@ int impg_gpu_query_batch_filtered(impg_gpu_index_t *, const impg_gpu_range_t *ra
                                   const uint8_t *subset_keep, impg_gpu_results_t **out);
 /* The same rows for a batch too big for one result object (the 100 000-range headline batch returns 2.1 x 10^9 rows,
  * 51 GB): the batch is cut into chunks of chunk_ranges ranges (0 = 8192; a chunk that outgrows the pair budget or
- * max_block_bytes of rows -- 0 = 6 GiB -- is halved), two engines compute them in turn, and `cb` receives every chunk
+ * max_block_bytes of rows -- 0 = 2.5 GiB, two of which the library's pinned pool keeps between calls -- is halved, and so
+ * are the chunks after it), two engines compute them in turn, and `cb` receives every chunk
  * as a results object (the impg_gpu_results_* accessors; its range i is ranges[first_range + i]) valid until the
  * callback returns -- IN RANGE ORDER, one call at a time, from a thread of the library, while the next chunk is
  * computed and copied: what a caller that prints or folds range by range consumes (main.rs:7435-7470).  Host memory:

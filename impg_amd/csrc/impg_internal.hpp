@@ -166,7 +166,13 @@ struct DevBuf {
   BufPool *pool = nullptr;     // set: blocks come from / go back to the pool
   void reserve(size_t bytes);  // contents are NOT preserved on growth
   void release();
+  // Between two buffers of ONE owner only -- an engine's scratch and its levels, say; the blocks take their way of being
+  // freed with them.  A lane of a sharded index outlives the engine it leases: its buffers are marked lane_owned, and a
+  // swap between one of them and an engine's is refused -- it once left a lane's receive buffer allocating from an
+  // engine's pool after the engine had gone to another lane (wrong CIGARs one run in five).  That hand-over is adopt().
+  bool lane_owned = false;
   void swap(DevBuf &o) {
+    if (lane_owned != o.lane_owned) throw Error{IMPG_E_INVALID, "internal: DevBuf::swap between a lane's buffer and an engine's (use adopt)"};
     void *tp = p; p = o.p; o.p = tp;
     size_t tc = cap; cap = o.cap; o.cap = tc;
     BufPool *tq = pool; pool = o.pool; o.pool = tq;

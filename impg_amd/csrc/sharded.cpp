@@ -70,6 +70,9 @@ struct ShardedExpander : Expander {
   const uint32_t *d_owner = nullptr;
   uint32_t n_seq = 0;
   DevBuf send_fr, recv_fr, hits_out, hits_in, ops_out, ops_in, mslot, iota, route_hist, d_bounds;
+  ShardedExpander() {  // (the lane's own buffers: never swapped with an engine's, DevBuf::swap)
+    for (DevBuf *b : {&send_fr, &recv_fr, &hits_out, &hits_in, &ops_out, &ops_in, &mslot, &iota, &route_hist, &d_bounds}) b->lane_owned = true;
+  }
   LevelBufs owner_L;
   // pinned words every readback / small upload of a hop goes through (a copy from or to pageable memory stages and
   // blocks): [0, W] slot offsets at block boundaries, [W+1, 2W+1] slice-pool offsets there, then the route histogram

@@ -48,11 +48,21 @@ CASES = [dict(), dict(transitive=True, max_depth=2), dict(transitive=True, max_d
          dict(min_identity=0.8), dict(transitive=True, max_depth=2, min_identity=0.6)]
 
 
-@pytest.mark.parametrize("world,lanes", [(1, 1), (2, 1), (3, 2), (5, 3), (8, 2)])
-def test_multi_handle_matches_oracle(tmp_path, world, lanes):
+def lane_cases(cases):
+    """(world, lanes) -> (world, lanes, lane_schedule) for 0 = the lanes' threads as the scheduler runs them and every forced
+    hand-over pattern of the lanes' engines (option lane_schedule): what a run depends on beyond its inputs."""
+    out = []
+    for world, lanes in cases:
+        out += [(world, lanes, v) for v in range(0, 2 ** (lanes * (lanes - 1) // 2) + 1) if lanes > 1 or v == 0]
+    return out
+
+
+@pytest.mark.parametrize("world,lanes,schedule", lane_cases([(1, 1), (2, 1), (3, 2), (5, 3), (8, 2)]))
+def test_multi_handle_matches_oracle(tmp_path, world, lanes, schedule):
     path = write_paf(tmp_path)
     c = o.OracleIndex(paf_paths=[path], preparse=True)
     g = impg_amd.GpuImpg.from_paf(path, devices=[0] * world, lanes=lanes)
+    g.set_option("lane_schedule", schedule)
     single = impg_amd.GpuImpg.from_paf(path)
     assert g.num_seqs() == c.num_seqs() and g.num_entries() == single.num_entries()
     assert g.num_targets() == single.num_targets() and g.target_ids().tolist() == single.target_ids().tolist()
@@ -177,13 +187,14 @@ def test_multi_handle_pair_budget_slices(tmp_path):
         assert got[i].tolist() == c.query(t, s, e, **kw).tolist(), i
 
 
-@pytest.mark.parametrize("world,lanes", [(2, 1), (3, 2)])
-def test_store_cigar_with_hitless_arrivals(tmp_path, world, lanes):
+@pytest.mark.parametrize("world,lanes,schedule", lane_cases([(2, 1), (3, 2), (2, 3)]))
+def test_store_cigar_with_hitless_arrivals(tmp_path, world, lanes, schedule):
     """An owner that receives, behind ranges with hits, a home's ranges that hit nothing: that home's run of the slice pool
     is empty and starts past the last slot (the soak's seed-31xxx failure: "CIGAR ops and hit records that came home disagree")."""
     path = write_paf(tmp_path, seed=11, n=120)
     c = o.OracleIndex(paf_paths=[path], preparse=True)
     g = impg_amd.GpuImpg.from_paf(path, devices=[0] * world, lanes=lanes)
+    g.set_option("lane_schedule", schedule)
     g.set_option("chunk_ranges", 1)
     rl = []
     for i in range(48):  # every other range lies beyond the sequences' last alignment: no overlap at all
@@ -348,3 +359,19 @@ def test_lane_schedules_enumerated(tmp_path, world, lanes):
             # also allocated from: wrong ops in one run out of five of test_multi_handle_matches_oracle[5-3])
             check_cigars(g, c, rl2, transitive=True, dfs=True, max_depth=2, min_transitive_len=100)
             check_cigars(g, c, rl2, transitive=True, max_depth=2, min_transitive_len=100)
+
+
+def test_poisoned_buffers(tmp_path):
+    """The lane-sensitive tests of this file once more with IMPG_POISON: every device block is filled with a pattern when
+    it is obtained, so a kernel that reads a buffer before it is written -- the class of defect two rounds found by
+    rerunning the suite -- fails here every time instead of once in five runs."""
+    import subprocess
+    import sys
+    if os.environ.get("IMPG_POISON"):
+        pytest.skip("already a poisoned run")
+    env = dict(os.environ, IMPG_POISON="a5")
+    sel = "hitless or lane_schedules or save_load or row_stream or (matches_oracle and (3-2 or 5-3-0 or 5-3-8))"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
+                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -597,31 +597,29 @@ __global__ __launch_bounds__(256) void scan_block_sums(const uint32_t *__restric
   block_excl_scan(s, &tot);
   if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-// single block: exclusive scan of the block sums in place, grand total to *total
-__global__ __launch_bounds__(256) void scan_of_sums(unsigned long long *bsum, uint32_t nb, unsigned long long *total) {
-  __shared__ unsigned long long carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < nb; base += 256) {
-    uint32_t i = base + threadIdx.x;
-    unsigned long long x = i < nb ? bsum[i] : 0;
-    // 64-bit inclusive scan over the block through shared memory (small: nb/256 rounds)
-    __shared__ unsigned long long buf[256];
-    buf[threadIdx.x] = x;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-      unsigned long long y = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
-      __syncthreads();
-      buf[threadIdx.x] += y;
-      __syncthreads();
-    }
-    unsigned long long carry = carry_s;
-    if (i < nb) bsum[i] = carry + buf[threadIdx.x] - x;
-    __syncthreads();
-    if (threadIdx.x == 255) carry_s = carry + buf[255];
-    __syncthreads();
+// single block: exclusive scan of the block sums in place, grand total to *total.  A thread owns one contiguous stretch
+// of the sums: it adds them up, the 1 024 stretch totals are scanned once across the block, and it writes its stretch's
+// running prefixes back.  (Until round 4: 256 sums per turn through a 16-barrier shared-memory scan -- 150 turns for the
+// 4 x 10^4 block sums of a level's pairs, 0.5 ms of a headline step in twelve scans.)
+__global__ __launch_bounds__(1024) void scan_of_sums(unsigned long long *bsum, uint32_t nb, unsigned long long *total) {
+  __shared__ unsigned long long wsum[16];
+  const uint32_t per = (nb + 1023u) / 1024u, a = min(nb, threadIdx.x * per), e = min(nb, a + per);
+  unsigned long long mine = 0;
+  for (uint32_t i = a; i < e; i++) mine += bsum[i];
+  // exclusive scan of `mine` over the block: within the wave by shuffles, then over the 16 waves' totals
+  unsigned long long inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long y = __shfl_up(inc, d);
+    if ((int)lane_id() >= d) inc += y;
   }
-  if (threadIdx.x == 0) *total = carry_s;
+  if (lane_id() == 63u) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  unsigned long long base = 0;
+  for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) base += wsum[k];
+  unsigned long long run = base + inc - mine;
+  for (uint32_t i = a; i < e; i++) { const unsigned long long x = bsum[i]; bsum[i] = run; run += x; }
+  if (threadIdx.x == 1023u) *total = run;
 }
 __global__ __launch_bounds__(256) void scan_apply(const uint32_t *__restrict__ in, uint32_t n,
                                                   const unsigned long long *__restrict__ bsum,
@@ -653,7 +651,7 @@ void launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, un
   // note: block sums are computed with a strided ownership, applied with a
   // blocked ownership; both cover the same tile so the sums agree.
   scan_block_sums<<<nb, SCAN_BLOCK, 0, s>>>(d_in, n, d_bsum);
-  scan_of_sums<<<1, 256, 0, s>>>(d_bsum, nb, d_total);
+  scan_of_sums<<<1, 1024, 0, s>>>(d_bsum, nb, d_total);
   scan_apply<<<nb, SCAN_BLOCK, 0, s>>>(d_in, n, d_bsum, d_out);
 }
 size_t scan_scratch_bytes(uint32_t n) { return ((size_t)(n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(unsigned long long); }
@@ -1621,7 +1619,7 @@ static_assert(STG_ECAP * 4u <= STG_THREADS, "one pass copies the entries");
 // entry is requested a turn ahead), and the projection on the staged copies where the entry is one of the n_e staged
 // from emin on, else on the index (regroup_all: nothing is staged and every turn's pairs are regrouped by entry first,
 // as project_kernel does; the scratch overlays the line buffer).  Returns the thread's count of accepted projections.
-template <bool TRANSITIVE, bool MASKS, bool CAN_STAGE = true, uint32_t NR = STG_RANGES>  // NR: ranges of a block (st_off holds NR + 1 offsets)
+template <bool TRANSITIVE, bool MASKS, bool CAN_STAGE = true, uint32_t NR = STG_RANGES, uint32_t NT = STG_THREADS>  // NR: ranges of a block (st_off holds NR + 1 offsets); NT: its threads
 __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, const uint32_t *__restrict__ pair_entry, const HitArrays &h,
                                                    unsigned long long *__restrict__ accepted, uint32_t *__restrict__ err_flag,
                                                    const WindowLists &wl, uint32_t r0, uint32_t P0, uint32_t P1, uint32_t emin, uint32_t n_e,
@@ -1629,12 +1627,12 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
                                                    const uint4 *st_ent, uint4 *st_line PHASE_ARG) {
   const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
   uint32_t n_ok = 0;
-  // the block's places, a turn of STG_THREADS at a time (pair lists: the next turn's entry is requested a turn ahead)
+  // the block's places, a turn of NT at a time (pair lists: the next turn's entry is requested a turn ahead)
   uint32_t e_next = 0xFFFFFFFFu;
   if (!MASKS && (unsigned long long)P0 + threadIdx.x < P1) e_next = pair_entry[P0 + threadIdx.x];
 #pragma unroll 1
-  for (uint32_t base = P0; base < P1; base += STG_THREADS) {
-    if (base + STG_THREADS < base) break;  // (cannot happen: n_pairs stays 16 below 2^32 and P1 <= n_pairs)
+  for (uint32_t base = P0; base < P1; base += NT) {
+    if (base + NT < base) break;  // (cannot happen: n_pairs stays 16 below 2^32 and P1 <= n_pairs)
     const uint32_t pp = base + threadIdx.x;
     PairIn y;
     y.live = pp < P1 ? 1u : 0u;
@@ -1657,9 +1655,9 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
     }
     if (!MASKS) {
       e_next = 0xFFFFFFFFu;
-      if ((unsigned long long)pp + STG_THREADS < P1) e_next = pair_entry[pp + STG_THREADS];
+      if ((unsigned long long)pp + NT < P1) e_next = pair_entry[pp + NT];
     }
-    if (regroup_all) regroup_by_entry<STG_THREADS>(y, reinterpret_cast<uint32_t *>(st_line));
+    if (regroup_all) regroup_by_entry<NT>(y, reinterpret_cast<uint32_t *>(st_line));
     if (y.live) {
       bool ok = false;
       TileScan res;
@@ -1818,11 +1816,15 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
 #ifndef IMPG_ENT_RANGES
 #define IMPG_ENT_RANGES 512
 #endif
+#ifndef IMPG_ENT_THREADS
+#define IMPG_ENT_THREADS 512
+#endif
 constexpr uint32_t ENT_RANGES = IMPG_ENT_RANGES;                          // ranges (consecutive in the lookup order) per block
+constexpr uint32_t ENT_THREADS = IMPG_ENT_THREADS, ENT_WAVES = ENT_THREADS / 64u;
 constexpr uint32_t ENT_REC_STRIDE = INLINE_TILES * STG_LINE_STRIDE;       // words of a wave's LDS record (8 padded lines)
-static_assert((ENT_RANGES & (ENT_RANGES - 1u)) == 0u && ENT_RANGES <= STG_THREADS && ENT_RANGES % 64u == 0, "a thread per range");
-constexpr uint32_t ENT_REC_V4 = STG_WAVES * ENT_REC_STRIDE / 4u, ENT_LIST_V4 = STG_WAVES * ENT_RANGES * 2u / 16u;
-static_assert((ENT_REC_V4 + ENT_LIST_V4) * 4u >= 5u * STG_THREADS + STG_WAVES, "the unstaged path's scratch overlays the waves' records and lists");
+static_assert((ENT_RANGES & (ENT_RANGES - 1u)) == 0u && ENT_RANGES % ENT_THREADS == 0 && ENT_THREADS % 64u == 0, "whole turns of the block over its ranges");
+constexpr uint32_t ENT_REC_V4 = ENT_WAVES * ENT_REC_STRIDE / 4u, ENT_LIST_V4 = ENT_WAVES * ENT_RANGES * 2u / 16u;
+static_assert((ENT_REC_V4 + ENT_LIST_V4) * 4u >= 5u * ENT_THREADS + ENT_WAVES, "the unstaged path's scratch overlays the waves' records and lists");
 #ifdef IMPG_ENT_WAVES  // (experiments: force the register allocation that gives this many waves per SIMD)
 #define ENT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(IMPG_ENT_WAVES, IMPG_ENT_WAVES)))
 #else
@@ -1850,7 +1852,7 @@ __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, ui
   }
 }
 template <bool TRANSITIVE>
-__global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
+__global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
                                                       uint32_t *__restrict__ err_flag, int regroup, WindowLists wl) {
   const uint32_t per_xcd = gridDim.x >> 3;
@@ -1863,8 +1865,8 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
   __shared__ uint32_t st_off[ENT_RANGES + 4u];
   __shared__ uint16_t st_wide[ENT_RANGES];
   __shared__ uint32_t st_nwide, st_alloc, st_next;
-  __shared__ uint32_t wred[2u * STG_WAVES];
-  __shared__ uint32_t wcnt[STG_WAVES];
+  __shared__ uint32_t wred[2u * ENT_WAVES];
+  __shared__ uint32_t wcnt[ENT_WAVES];
   const uint32_t r0 = sblock * ENT_RANGES;
   if (r0 >= wl.n_fr) return;  // (block-uniform: the grid is rounded up to the 8 XCDs)
   const uint32_t nr = min(ENT_RANGES, wl.n_fr - r0);
@@ -1880,19 +1882,20 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
   __syncthreads();
   // the block's ranges: place offsets, windows, ends; the span of entries their masks name; the ranges listed instead
   uint32_t emin = 0xFFFFFFFFu, emax = 0u;
-  if (threadIdx.x < ENT_RANGES) {
+#pragma unroll
+  for (uint32_t t = threadIdx.x; t < ENT_RANGES; t += ENT_THREADS) {
     // (st_off[nr] = where the block's places end, all ones beyond: the searches never step past the block's ranges)
-    if (threadIdx.x < nr) st_off[threadIdx.x] = wl.pair_off[r0 + threadIdx.x];
-    else st_off[threadIdx.x + 1u] = 0xFFFFFFFFu;
-    if (threadIdx.x == 0) st_off[nr] = r0 + nr < wl.n_fr ? wl.pair_off[r0 + nr] : n_pairs;
-    if (threadIdx.x < nr) {
-      const uint4 w = wl.win[r0 + threadIdx.x];
-      st_win[threadIdx.x] = w;
-      st_se[threadIdx.x] = wl.se[r0 + threadIdx.x];
-      if (w.y - (w.x & ~3u) > 64u) st_wide[atomicAdd(&st_nwide, 1u)] = (uint16_t)threadIdx.x;
+    if (t < nr) st_off[t] = wl.pair_off[r0 + t];
+    else st_off[t + 1u] = 0xFFFFFFFFu;
+    if (t == 0) st_off[nr] = r0 + nr < wl.n_fr ? wl.pair_off[r0 + nr] : n_pairs;
+    if (t < nr) {
+      const uint4 w = wl.win[r0 + t];
+      st_win[t] = w;
+      st_se[t] = wl.se[r0 + t];
+      if (w.y - (w.x & ~3u) > 64u) st_wide[atomicAdd(&st_nwide, 1u)] = (uint16_t)t;
       else if (w.z | w.w) {
-        emin = w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w));
-        emax = w.x + (w.w ? 63u - (uint32_t)__builtin_clz(w.w) : 31u - (uint32_t)__builtin_clz(w.z));
+        emin = min(emin, w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w)));
+        emax = max(emax, w.x + (w.w ? 63u - (uint32_t)__builtin_clz(w.w) : 31u - (uint32_t)__builtin_clz(w.z)));
       }
     }
   }
@@ -1902,10 +1905,10 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
       emin = min(emin, (uint32_t)__shfl_xor((int)emin, o));
       emax = max(emax, (uint32_t)__shfl_xor((int)emax, o));
     }
-    if (l == 0) { wred[wv] = emin; wred[STG_WAVES + wv] = emax; }
+    if (l == 0) { wred[wv] = emin; wred[ENT_WAVES + wv] = emax; }
     __syncthreads();
 #pragma unroll
-    for (uint32_t k = 0; k < STG_WAVES; k++) { emin = min(emin, wred[k]); emax = max(emax, wred[STG_WAVES + k]); }
+    for (uint32_t k = 0; k < ENT_WAVES; k++) { emin = min(emin, wred[k]); emax = max(emax, wred[ENT_WAVES + k]); }
     emin = (uint32_t)__builtin_amdgcn_readfirstlane((int)emin);
     emax = (uint32_t)__builtin_amdgcn_readfirstlane((int)emax);
   }
@@ -1923,7 +1926,7 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
   // more than the pairs do -- by place, regrouped, from the index (the ranges listed instead take the same path there)
   const bool sparse = emin <= emax && (unsigned long long)(P1 - P0) < 4ull * (emax - emin + 1u);
   if (sparse) {
-    n_ok = project_places<TRANSITIVE, true, false, ENT_RANGES>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
+    n_ok = project_places<TRANSITIVE, true, false, ENT_RANGES, ENT_THREADS>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
                                                                st_se, nullptr, st_work PHASE_PASS);
   } else if (emin <= emax) {
     // The waves take the span's entries one by one off an LDS counter (an entry is anything from a handful to 500 pairs:
@@ -2033,7 +2036,7 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
       const uint32_t a = st_off[r], b = st_off[r + 1u];
       const int2 se = st_se[r];
 #pragma unroll 1
-      for (uint32_t pp = a + threadIdx.x; pp < b; pp += STG_THREADS) {
+      for (uint32_t pp = a + threadIdx.x; pp < b; pp += ENT_THREADS) {
         bool ok = false;
         TileScan res;
         res.found = res.any = false;
@@ -2055,7 +2058,7 @@ __global__ __launch_bounds__(STG_THREADS) ENT_OCCUPANCY void project_entries_ker
     atomicAdd(&g_phase_clk[12], (unsigned long long)(emax - emin));
   }
 #endif
-  count_accepted<STG_WAVES>(n_ok, accepted, wcnt);
+  count_accepted<ENT_WAVES>(n_ok, accepted, wcnt);
 }
 #undef STG_MARK
 #ifdef IMPG_PHASE_CLOCKS
@@ -3769,8 +3772,8 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
     static const bool by_entry = [] { const char *e = getenv("IMPG_ENTRY_MAJOR"); return !e || atoi(e) != 0; }();  // (A/B: 0 = a lane per place)
     if (masks && by_entry) {
       const uint32_t ge = (cdiv(wl.n_fr, ENT_RANGES) + 7u) & ~7u;
-      if (transitive) project_entries_kernel<true><<<ge, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
-      else project_entries_kernel<false><<<ge, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
+      if (transitive) project_entries_kernel<true><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
+      else project_entries_kernel<false><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
       return;
     }
 #define IMPG_LAUNCH_STG(T, M) project_staged_kernel<T, M><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl)

@@ -1817,7 +1817,7 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
 #define IMPG_ENT_RANGES 512
 #endif
 #ifndef IMPG_ENT_THREADS
-#define IMPG_ENT_THREADS 512
+#define IMPG_ENT_THREADS 256
 #endif
 constexpr uint32_t ENT_RANGES = IMPG_ENT_RANGES;                          // ranges (consecutive in the lookup order) per block
 constexpr uint32_t ENT_THREADS = IMPG_ENT_THREADS, ENT_WAVES = ENT_THREADS / 64u;

@@ -2418,7 +2418,9 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
 // (Round 4, measured and dropped: a block of 256 groups handing them to its lanes sorted by their number of hits, so that
 // a wave's replays are equally long -- update 12.7 -> 16.1 ms.  Neighbouring groups own neighbouring hits, lists and
 // slices; permuted, a wave's every read and write touches 64 lines instead of ~17: the kernel is bound by the lines
-// its memory instructions touch, not by the longest replay of a wave.)
+// its memory instructions touch, not by the longest replay of a wave.  Nor does it pay to fetch the wave's stretch of the
+// sorted hits into LDS first (coalesced, 4 KB per wave): 12 KB of LDS per wave instead of 8 leave 13 waves per CU instead
+// of 20, update 12.6 -> 14.3 ms; with a 3 KB buffer 13.7.)
 // one thread per (query, sequence) group: replay the group's hits in emission
 // order against its visited list (SortedRanges::insert with min_distance = 0,
 // impg.rs:270-368), collect the new pieces.

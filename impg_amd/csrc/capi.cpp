@@ -528,6 +528,25 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
   } else if (k == "lane_schedule") {  // tests: forced lane start / hand-over order of a sharded batch (0 = off)
     if (value < 0) throw Error{IMPG_E_INVALID, "lane_schedule out of range"};
     ix->opt_lane_schedule = (uint64_t)value;
+  } else if (k == "prewarm_result_bytes") {
+    // A pinned host block of this size goes into the library's pool now (host_mem.cpp), so that a process's FIRST
+    // result-returning call copies into a recycled block like every later one (pinning 5 GB costs ~0.3-1 s, inside the
+    // call otherwise).  Blocks beyond IMPG_PINNED_POOL_BYTES (6 GiB) are not kept: ask for what the calls return.
+    if (value < 0) throw Error{IMPG_E_INVALID, "prewarm_result_bytes is a size"};
+    if (value) {
+      size_t cap = 0;
+      void *b = pinned_take((size_t)value, cap);
+      pinned_give(b, cap);
+    }
+  } else if (k == "prewarm_walk") {
+    // The per-query walk's slabs (walk_device.inc) exist before the first call that needs them: 1 = the 64 slabs of the
+    // per-call / small-batch BFS shape, 2 = also the DFS batch's slabs (~15 GB: one per resident wave).
+    if (value < 0 || value > 2) throw Error{IMPG_E_INVALID, "prewarm_walk is 0, 1 or 2"};
+    if (value && !ix->shard && !ix->cluster) {
+      IMPG_HIP(hipSetDevice(ix->device));
+      EngineLease lease(*ix);
+      lease->reserve_walk_slabs(*ix, value >= 2);
+    }
   } else throw Error{IMPG_E_INVALID, "unknown option " + k};
   return IMPG_OK;
   IMPG_CATCH

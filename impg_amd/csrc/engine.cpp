@@ -121,6 +121,30 @@ bool Engine::walk_applicable(const impg_gpu_index &ix, uint32_t n, const impg_gp
   // walk_kernel = 2 sends it here (tests)
   return p.dfs != 0 || (walk_bfs && n <= SMALL_RANGES);
 }
+// the walk's slab shape: a BFS processes whole levels (16 waves per query), a DFS step is one popped range (one wave)
+void Engine::walk_caps(bool wide, WalkArgs &a) {
+  a.wcap = wide ? 16384u : 4096u;   // a BFS frontier; the pieces of one DFS pop
+  a.hcap = wide ? 32767u : 4096u;
+  a.vcap = wide ? 131072u : 131072u;  // visited ranges (lists that outgrow their place move and leave it behind)
+  a.gcap = wide ? 262144u : 16384u;
+  a.scap = wide ? 16u : 65536u;       // DFS stack records (incl. the pieces too deep to be explored, until they are popped)
+}
+uint64_t Engine::walk_workgroups(const impg_gpu_index &ix, bool wide) {
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix.device);
+  return wide ? SMALL_RANGES : (uint64_t)cus * 4u * WALK_WAVES_PER_SIMD;  // (slabs of ~2.5 MB: a wave per query, latency-bound, wants every wave slot it can get)
+}
+void Engine::reserve_walk_slabs(const impg_gpu_index &ix, bool dfs_too) {
+  size_t want = 0;
+  for (int wide = 1; wide >= (dfs_too ? 0 : 1); wide--) {
+    WalkArgs a;
+    memset(&a, 0, sizeof a);
+    walk_caps(wide != 0, a);
+    want = std::max(want, walk_slab_bytes(ix.view.n_seq, wide != 0, a.wcap, a.hcap, a.vcap, a.gcap, a.scap) * (size_t)walk_workgroups(ix, wide != 0));
+  }
+  if (walk_slabs.cap < want) walk_slabs.reserve(want);
+  walk_ctr.reserve(256);
+}
 bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
                       unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows) {
   if (!walk_applicable(ix, n, p)) return false;
@@ -129,16 +153,10 @@ bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges
   const bool wide = !p.dfs;
   WalkArgs a;
   memset(&a, 0, sizeof a);
-  a.wcap = wide ? 16384u : 4096u;   // a BFS frontier; the pieces of one DFS pop
-  a.hcap = wide ? 32767u : 4096u;
-  a.vcap = wide ? 131072u : 131072u;  // visited ranges (lists that outgrow their place move and leave it behind)
-  a.gcap = wide ? 262144u : 16384u;
-  a.scap = wide ? 16u : 65536u;       // DFS stack records (incl. the pieces too deep to be explored, until they are popped)
+  walk_caps(wide, a);
   const size_t slab = walk_slab_bytes(ix.view.n_seq, wide, a.wcap, a.hcap, a.vcap, a.gcap, a.scap);
-  int cus = 256;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix.device);
-  const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n, wide ? SMALL_RANGES : (uint64_t)cus * 4u * WALK_WAVES_PER_SIMD);  // (slabs of ~2.5 MB: a wave per query, latency-bound, wants every wave slot it can get)
-  walk_slabs.reserve(slab * n_wg);
+  const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n, walk_workgroups(ix, wide));
+  if (walk_slabs.cap < slab * n_wg) walk_slabs.reserve(slab * n_wg);  // (never shrunk: option prewarm_walk reserves the largest shape)
   walk_ctr.reserve(256);
   ev_next = 0;
   timed.clear();

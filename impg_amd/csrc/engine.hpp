@@ -181,6 +181,9 @@ struct Engine {
   };
   bool walk_allowed = true, walk_bfs = false;  // option "walk_kernel": 0 never, 1 DFS (default), 2 also small BFS batches
   bool walk_applicable(const impg_gpu_index &ix, uint32_t n, const impg_gpu_params_t &p) const;
+  static void walk_caps(bool wide, WalkArgs &a);
+  static uint64_t walk_workgroups(const impg_gpu_index &ix, bool wide);
+  void reserve_walk_slabs(const impg_gpu_index &ix, bool dfs_too);  // option prewarm_walk
   bool run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
                 unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows);
   DevBuf walk_slabs, walk_ctr;

@@ -210,7 +210,11 @@ int impg_gpu_index_approximate(const impg_gpu_index_t *);
  * identical either way),
  * "fuse_final_level" (1, the default: the final level of such a run -- no update follows, no row is kept --
  * takes its (range, entry) pairs straight from the lookup's per-range windows inside the projection kernel; the emit
- * pass and its pair lists are skipped; counts and checksums are identical either way). */
+ * pass and its pair lists are skipped; counts and checksums are identical either way).
+ * Actions rather than settings, so that a process's FIRST call costs what its later ones do: "prewarm_result_bytes" = N
+ * pins a host block of N bytes into the result pool now (a 5 GB result pins its block inside the first call
+ * otherwise, ~0.3-1 s); "prewarm_walk" = 1 / 2 allocates the per-query walk's slabs (1: the per-call / small-batch BFS
+ * shape; 2: also the DFS batch's, ~15 GB) on the index's first engine. */
 int impg_gpu_set_option(impg_gpu_index_t *, const char *key, int64_t value);
 /* Large result arrays live in pinned host blocks that are recycled through a process-wide pool (at most
  * IMPG_PINNED_POOL_BYTES, default 6 GiB, are kept when results are freed).  Gives pooled blocks back to the system

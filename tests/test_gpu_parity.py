@@ -1476,3 +1476,17 @@ def test_query_batch_stream_matches_the_one_shot_call(tmp_path):
     assert g.query_batch_stream([], lambda first, part: False, impg_amd.make_params()) == 0
     # the handle is fine afterwards
     assert_same(g, c, ranges[:10], transitive=True, max_depth=2)
+
+
+def test_prewarm_options(tmp_path):
+    """"prewarm_result_bytes" / "prewarm_walk": the first call's one-off allocations made ahead of it; results unchanged."""
+    text, _ = random_paf(99, 200, n_seq=5, seq_len=20000)
+    g, c = both(tmp_path, text)
+    g.set_option("prewarm_result_bytes", 8 << 20)
+    g.set_option("prewarm_walk", 2)
+    ranges = random_ranges(3, 20, g.num_seqs(), 20000, max_len=3000, min_len=100)
+    assert_same(g, c, ranges, transitive=True, max_depth=3, min_transitive_len=20)
+    assert_same(g, c, ranges, transitive=True, dfs=True, max_depth=2, min_transitive_len=20)
+    assert g.query_transitive_bfs(*ranges[0], max_depth=2).tolist() == c.query(*ranges[0], transitive=True, max_depth=2).tolist()
+    with pytest.raises(impg_amd.ImpgGpuError):
+        g.set_option("prewarm_walk", 3)

@@ -339,20 +339,22 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
   ProjList pl{nullptr, nullptr, nullptr};
-  WindowLists wlists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
+  WindowLists wlists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u};
   if (fused) {
     // the final level of a counting run: pairs by windows (WindowLists); only the windows too wide for a 64-bit mask are listed
+    // (tile_first[]: only project_kernel needs it -- the kernels of a dense level search their own block's offsets)
+    const bool staged = project_is_staged(v, P, !store_cigar && !(min_identity == min_identity));
     tile_first.reserve(((size_t)(P + 255) / 256 + 1) * 4);
-    launch_tile_first(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr, tile_first.as<uint32_t>(), stream);
+    if (!staged) launch_tile_first(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr, tile_first.as<uint32_t>(), stream);
     launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                        pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true, true);
     wlists = WindowLists{tile_first.as<uint32_t>(), pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<int2>(), d_perm, n_fr,
-                         fuse_need_ranges ? L.pair_range.as<uint32_t>() : nullptr};
+                         fuse_need_ranges ? L.pair_range.as<uint32_t>() : nullptr, 1u};
   } else if (by_place) {
     launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                        pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true);
     // (which range owns which places, for the staged projection of a dense level)
-    wlists = WindowLists{nullptr, pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<int2>(), d_perm, n_fr, nullptr};
+    wlists = WindowLists{nullptr, pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<int2>(), d_perm, n_fr, nullptr, 0u};
   } else {
     const uint32_t *d_offp = nullptr;
     projection_offsets(d_perm, n_fr, cnt.as<uint32_t>(), P, d_offp, pl);

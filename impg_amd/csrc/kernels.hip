@@ -3759,12 +3759,25 @@ void launch_order_keys(const DeviceIndexView &v, const FrontierRec *fr, uint32_t
 void launch_scatter_u32(const uint32_t *in, const uint32_t *perm, uint32_t n, uint32_t *out, hipStream_t s) {
   if (n) scatter_u32_kernel<<<cdiv(n, 256), 256, 0, s>>>(in, perm, n, out);
 }
+static double stage_density() {  // IMPG_STAGE_DENSITY = pairs per index entry from which on a level is "dense" (default 32; 0 = always, < 0 = never)
+  static const double d = [] { const char *e = getenv("IMPG_STAGE_DENSITY"); return e ? atof(e) : 32.0; }();
+  return d;
+}
+static bool entry_major() {  // (A/B: IMPG_ENTRY_MAJOR=0 keeps a lane per place on the final level too)
+  static const bool b = [] { const char *e = getenv("IMPG_ENTRY_MAJOR"); return !e || atoi(e) != 0; }();
+  return b;
+}
+// A plain projection of n_pairs pairs whose slots follow the lookup order runs on the staged kernels (which find a
+// place's range in the block's own LDS offsets: no tile_first[]) when the level is dense.
+bool project_is_staged(const DeviceIndexView &v, uint64_t n_pairs, bool plain) {
+  return plain && v.pfx && !v.tp_mode && stage_density() >= 0.0 && (double)n_pairs >= stage_density() * (double)v.n_entries;
+}
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
                     ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev, bool regroup, const WindowLists *wlp) {
   if (!n_pairs) return;
-  const WindowLists wl = wlp ? *wlp : WindowLists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
+  const WindowLists wl = wlp ? *wlp : WindowLists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u};
   const int rg = regroup ? 1 : 0;
   bool ident = min_identity == min_identity;  // NaN = no filter
   // An index built without prefix lines (it would not have fitted the device with them: index_build_device.hip) has
@@ -3785,14 +3798,11 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
   const SliceArrays sl = slices ? *slices : SliceArrays{nullptr, nullptr, nullptr, nullptr};
   const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0) | (two_walks ? MODE_WALK : 0);
   // A dense level -- many pairs per index entry -- runs with the entries and prefix lines staged in LDS
-  // (project_staged_kernel); IMPG_STAGE_DENSITY = pairs per entry from which on (default 32; 0 = always, < 0 = never)
-  static const double stage_density = [] { const char *e = getenv("IMPG_STAGE_DENSITY"); return e ? atof(e) : 32.0; }();
-  if (mode == 0 && v.pfx && !n_pairs_dev && wl.pair_off && wl.se && !pl.slot && stage_density >= 0.0 &&
-      (double)n_pairs >= stage_density * (double)v.n_entries) {
+  // (project_staged_kernel / project_entries_kernel)
+  if (mode == 0 && !n_pairs_dev && wl.pair_off && wl.se && !pl.slot && project_is_staged(v, n_pairs, true)) {
     const uint32_t gs = (cdiv(wl.n_fr, STG_RANGES) + 7u) & ~7u;
-    const bool masks = wl.tile_first != nullptr;
-    static const bool by_entry = [] { const char *e = getenv("IMPG_ENTRY_MAJOR"); return !e || atoi(e) != 0; }();  // (A/B: 0 = a lane per place)
-    if (masks && by_entry) {
+    const bool masks = wl.masks != 0;
+    if (masks && entry_major()) {
       const uint32_t ge = (cdiv(wl.n_fr, ENT_RANGES) + 7u) & ~7u;
       if (transitive) project_entries_kernel<true><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
       else project_entries_kernel<false><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);

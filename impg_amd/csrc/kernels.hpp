@@ -68,7 +68,10 @@ struct WindowLists {
   const uint32_t *perm;        // [n_fr] place -> frontier range
   uint32_t n_fr;
   uint32_t *range_out;         // optional: pair_range[] for the per-range counts / the subset filter
+  uint32_t masks;              // 1: the pairs are named by the windows' hit masks (tile_first is only needed when project_kernel runs the level)
 };
+// whether launch_project will run a plain projection of n_pairs by-place pairs on the staged kernels (no tile_first[] needed)
+bool project_is_staged(const DeviceIndexView &v, uint64_t n_pairs, bool plain);
 void launch_tile_first(const uint32_t *cnt, const uint32_t *pair_off, uint32_t n_fr, uint32_t *tile_first, hipStream_t s);
 bool emit_by_lanes(const DeviceIndexView &v);
 // The pairs listed in projection order (optional: slot == nullptr means the projection runs in slot order):

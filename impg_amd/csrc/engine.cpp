@@ -465,15 +465,29 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
                      vals.as<unsigned long long>(), P, stream, std::min(64u, 32 + qbits + 1), 32);
     keys.swap(skeys);
     vals.swap(svals);
-    head.reserve((size_t)P * 4); gid.reserve((size_t)P * 4);
-    launch_group_heads(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), stream);
-    uint32_t n_groups = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), P);
+    // the groups: per-tile head counts + their scan + a fill pass; the per-hit head flags and group ids only exist for
+    // the covered-hit filter, which reads them
+    const bool want_flags = filter_covered != 0;
+    uint32_t n_groups;
+    if (want_flags) {
+      head.reserve((size_t)P * 4); gid.reserve((size_t)P * 4);
+      launch_group_heads(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), stream);
+      n_groups = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), P);
+    } else {
+      const uint32_t nt = group_tiles(P);
+      head.reserve((size_t)nt * 4); gid.reserve((size_t)nt * 4);
+      launch_group_count(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), stream);
+      n_groups = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), nt);
+    }
     if (n_groups) {
       auto vt = std::make_unique<VisitedStore>(&table_pool);
       vt->keys.reserve((size_t)n_groups * 8);
       gstart.reserve((size_t)n_groups * 4);
-      launch_group_scatter(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), gid.as<uint32_t>(), gstart.as<uint32_t>(),
-                           vt->keys.as<unsigned long long>(), stream);
+      if (want_flags)
+        launch_group_scatter(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), gid.as<uint32_t>(), gstart.as<uint32_t>(),
+                             vt->keys.as<unsigned long long>(), stream);
+      else
+        launch_group_fill(skeys.as<unsigned long long>(), P, gid.as<uint32_t>(), gstart.as<uint32_t>(), vt->keys.as<unsigned long long>(), stream);
       const uint32_t n_active = (uint32_t)read_slots(act_slots);  // hits that carry a (query, sequence) key
       glen.reserve((size_t)n_groups * 4); old_tab.reserve((size_t)n_groups * 4); old_idx.reserve((size_t)n_groups * 4);
       cap.reserve((size_t)n_groups * 4); pcap.reserve((size_t)n_groups * 4);

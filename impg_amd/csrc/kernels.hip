@@ -2361,6 +2361,45 @@ __global__ __launch_bounds__(256) void group_scatter_kernel(const unsigned long 
   }
 }
 
+// The same in two passes over the sorted keys and nothing else (round 4): heads counted per tile, the tiles' counts
+// scanned, then every head writes its group's start and key at (tile base + its rank in the tile).  (head flags, a scan
+// of them and a scatter were 44 bytes of traffic per hit; this is 16.)  A thread owns GROUP_ITEMS consecutive keys.
+constexpr uint32_t GROUP_ITEMS = 8, GROUP_TILE = 256u * GROUP_ITEMS;
+__global__ __launch_bounds__(256) void group_count_kernel(const unsigned long long *__restrict__ skeys, uint32_t n, uint32_t *__restrict__ tile_heads) {
+  const uint32_t base = blockIdx.x * GROUP_TILE + threadIdx.x * GROUP_ITEMS;
+  unsigned long long prev = base > 0 && base <= n ? skeys[base - 1u] : 0ull;
+  uint32_t c = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < GROUP_ITEMS; k++) {
+    const uint32_t i = base + k;
+    const unsigned long long key = i < n ? skeys[i] : ~0ull;
+    c += (key != ~0ull && (i == 0 || key != prev)) ? 1u : 0u;
+    prev = key;
+  }
+  uint32_t tot;
+  block_excl_scan(c, &tot);
+  if (threadIdx.x == 0) tile_heads[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void group_fill_kernel(const unsigned long long *__restrict__ skeys, uint32_t n, const uint32_t *__restrict__ tile_base,
+                                                         uint32_t *__restrict__ gstart, unsigned long long *__restrict__ gkey) {
+  const uint32_t base = blockIdx.x * GROUP_TILE + threadIdx.x * GROUP_ITEMS;
+  unsigned long long key[GROUP_ITEMS];
+  unsigned long long prev = base > 0 && base <= n ? skeys[base - 1u] : 0ull;
+  uint32_t c = 0, flags = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < GROUP_ITEMS; k++) {
+    const uint32_t i = base + k;
+    key[k] = i < n ? skeys[i] : ~0ull;
+    if (key[k] != ~0ull && (i == 0 || key[k] != prev)) { flags |= 1u << k; c += 1u; }
+    prev = key[k];
+  }
+  uint32_t tot;
+  uint32_t g = tile_base[blockIdx.x] + block_excl_scan(c, &tot);
+#pragma unroll
+  for (uint32_t k = 0; k < GROUP_ITEMS; k++)
+    if (flags & (1u << k)) { gstart[g] = base + k; gkey[g] = key[k]; g += 1u; }
+}
+
 __device__ __forceinline__ uint32_t lower_bound_u64(const unsigned long long *a, uint32_t n, unsigned long long k) {
   uint32_t lo = 0, hi = n;
   while (lo < hi) {
@@ -3854,6 +3893,13 @@ void launch_sort_pairs(void *tmp, size_t tmp_bytes, const unsigned long long *ki
                        const uint32_t *vin, uint32_t *vout, uint32_t n, unsigned end_bit, hipStream_t s) {
   if (!n) return;
   IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s));
+}
+uint32_t group_tiles(uint32_t n) { return (n + GROUP_TILE - 1u) / GROUP_TILE; }
+void launch_group_count(const unsigned long long *skeys, uint32_t n, uint32_t *tile_heads, hipStream_t s) {
+  if (n) group_count_kernel<<<group_tiles(n), 256, 0, s>>>(skeys, n, tile_heads);
+}
+void launch_group_fill(const unsigned long long *skeys, uint32_t n, const uint32_t *tile_base, uint32_t *gstart, unsigned long long *gkey, hipStream_t s) {
+  if (n) group_fill_kernel<<<group_tiles(n), 256, 0, s>>>(skeys, n, tile_base, gstart, gkey);
 }
 void launch_group_heads(const unsigned long long *skeys, uint32_t n, uint32_t *head, hipStream_t s) {
   if (!n) return;

@@ -132,6 +132,11 @@ void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint3
 size_t sort_pairs_scratch_bytes(uint32_t n);
 void launch_sort_pairs(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
                        const uint32_t *vin, uint32_t *vout, uint32_t n, unsigned end_bit, hipStream_t s);
+// the groups of the sorted keys (runs of equal keys != ~0) in two passes: per-tile head counts, then -- with their exclusive
+// scan -- every group's start and key
+uint32_t group_tiles(uint32_t n);
+void launch_group_count(const unsigned long long *skeys, uint32_t n, uint32_t *tile_heads, hipStream_t s);
+void launch_group_fill(const unsigned long long *skeys, uint32_t n, const uint32_t *tile_base, uint32_t *gstart, unsigned long long *gkey, hipStream_t s);
 void launch_group_heads(const unsigned long long *skeys, uint32_t n, uint32_t *head, hipStream_t s);
 void launch_group_scatter(const unsigned long long *skeys, uint32_t n, const uint32_t *head, const uint32_t *gid,
                           uint32_t *gstart, unsigned long long *gkey, hipStream_t s);

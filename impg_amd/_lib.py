@@ -112,6 +112,7 @@ SYMBOLS = [
     ("impg_gpu_device_bytes", C.c_size_t, [_P]),
     ("impg_gpu_index_approximate", C.c_int, [_P]),
     ("impg_gpu_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
+    ("impg_gpu_get_counter", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     ("impg_gpu_host_pool_trim", C.c_uint64, [C.c_uint64]),
     ("impg_gpu_visit_rank", C.c_int, [C.c_uint32, C.c_int, _P]),
     ("impg_gpu_query_batch", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), C.POINTER(_P)]),

@@ -52,6 +52,7 @@ EngineLease::EngineLease(impg_gpu_index &ix_) : ix(ix_) {
   e->filter_covered = ix.opt_filter_covered;
   e->walk_allowed = ix.opt_walk != 0 && !getenv("IMPG_NO_WALK");
   e->walk_bfs = ix.opt_walk == 2;  // (the environment switch runs a whole test suite on the batch engine)
+  e->walk_members = ix.opt_walk_members;
 }
 EngineLease::~EngineLease() {
   e->remote = nullptr;
@@ -514,9 +515,12 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
     ix->opt_fuse_final = value != 0;
   } else if (k == "regroup_entries") {  // projection blocks regroup their pairs by entry before reading the index (results identical)
     ix->opt_regroup = value != 0;
-  } else if (k == "walk_kernel") {  // the per-query walk (walk_device.inc): 0 never, 1 DFS batches of any size (default), 2 also BFS batches of <= 64 ranges
+  } else if (k == "walk_kernel") {  // the per-query walk (walk_device.inc): 0 never, 1 DFS batches of any size and depth-limited BFS batches of <= 64 ranges (default), 2 every BFS batch of <= 64 ranges
     if (value < 0 || value > 2) throw Error{IMPG_E_INVALID, "walk_kernel is 0, 1 or 2"};
     ix->opt_walk = (int)value;
+  } else if (k == "walk_members") {  // workgroups per query of the walk's grid form (depth-limited BFS, <= 64 ranges): 0 = as many as fit (<= 32), 1 = no grid form
+    if (value < 0 || value > (long long)WALK_MAX_MEMBERS) throw Error{IMPG_E_INVALID, "walk_members is 0 .. 64"};
+    ix->opt_walk_members = (uint32_t)value;
   } else if (k == "filter_covered") {  // visited update: hits covered by the old list dropped before the replay (0 off, 1 always, 2 auto; results identical)
     if (value < 0 || value > 2) throw Error{IMPG_E_INVALID, "filter_covered is 0, 1 or 2"};
     ix->opt_filter_covered = (int)value;
@@ -552,6 +556,18 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
   IMPG_CATCH
 }
 
+int impg_gpu_get_counter(const impg_gpu_index_t *ix, const char *key, int64_t *value_out) {
+  IMPG_TRY
+  if (!ix || !key || !value_out) throw Error{IMPG_E_INVALID, "null argument"};
+  const std::string k = key;
+  if (k == "walk_launches") *value_out = (int64_t)ix->walk_launches.load();
+  else if (k == "walk_fallbacks") *value_out = (int64_t)ix->walk_fallbacks.load();
+  else if (k == "walk_members") *value_out = (int64_t)ix->walk_last_members.load();
+  else throw Error{IMPG_E_INVALID, "unknown counter " + k};
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
 int impg_gpu_visit_rank(uint32_t n, int order_policy, uint32_t *rank_out) {
   IMPG_TRY
   if (!rank_out && n) throw Error{IMPG_E_INVALID, "null argument"};
@@ -578,6 +594,7 @@ void apply_mask(Engine &E, const impg_gpu_index &ix, const impg_gpu_mask_t *m, c
     // a sequence absent from the map: Impg starts its set with length 0 (visited_entry, impg.rs:2048-2053), MultiImpg
     // with the real length (multi_impg.rs:919-922) except for the query's own target (entry().or_default(), :827-830)
     std::vector<int32_t> init_len(n_seq, 0), touch_len(n_seq, 0);
+    bool has_empty = false;
     if (p.multi_impg) for (uint32_t s = 0; s < n_seq; s++) touch_len[s] = (int32_t)std::min<int64_t>(std::max<int64_t>(ix.seq.lens[s], 0), INT32_MAX);
     for (uint32_t i = 0; i < m->n_seqs; i++) {
       const uint32_t s = m->seq_id[i];
@@ -590,6 +607,7 @@ void apply_mask(Engine &E, const impg_gpu_index &ix, const impg_gpu_mask_t *m, c
         const int32_t a = m->ranges[2 * k], b = m->ranges[2 * k + 1];
         if (a > b || (k > m->range_off[i] && a <= m->ranges[2 * k - 1]))  // SortedRanges invariant (impg.rs:330-368)
           throw Error{IMPG_E_INVALID, "mask ranges must be sorted, disjoint and non-touching"};
+        has_empty = has_empty || a == b;
       }
     }
     for (uint32_t s = 0; s < n_seq; s++) off[s + 1] += off[s];
@@ -605,6 +623,7 @@ void apply_mask(Engine &E, const impg_gpu_index &ix, const impg_gpu_mask_t *m, c
       IMPG_HIP(hipMemcpy(E.mask_touch_len.p, touch_len.data(), (size_t)n_seq * 4, hipMemcpyHostToDevice));
     }
     E.masked = true;
+    E.mask_has_empty = has_empty;
   }
 }
 void apply_subset(Engine &E, const impg_gpu_index &ix, const uint8_t *subset_keep) {

@@ -114,12 +114,25 @@ bool Engine::run_small(const impg_gpu_index &ix, const impg_gpu_range_t *h_range
 }
 
 bool Engine::walk_applicable(const impg_gpu_index &ix, uint32_t n, const impg_gpu_params_t &p) const {
-  if (!walk_allowed || !n || !p.transitive || p.multi_impg || p.store_cigar || masked || remote || ix.tp_mode) return false;
+  if (!walk_allowed || !n || !p.transitive || p.multi_impg || p.store_cigar || remote || ix.tp_mode) return false;
   if (ix.view.n_seq > 65536u) return false;  // (hit keys are sequence << 15 | slot in 32 bits)
+  // (a mask with empty ranges gives self pieces that touch: the reference's stack merges them after the first pop, the
+  // walk's per-sequence stack lists only where new pieces land -- the batch engine runs those)
+  if (masked && mask_has_empty && p.dfs) return false;
   // DFS: always (its steps are single pops; the batch engine pays a launch sequence per pop round).  BFS: a small batch
-  // runs level by level either way and the two forms cost the same (0.9 ms per call): the batch engine keeps it, and
-  // walk_kernel = 2 sends it here (tests)
-  return p.dfs != 0 || (walk_bfs && n <= SMALL_RANGES);
+  // with a depth limit of two or more goes to the grid form (walk_members workgroups per query share its last level
+  // out); without one the two engines cost the same per call and the batch engine keeps it -- walk_kernel = 2 sends
+  // every small BFS batch here (tests)
+  if (p.dfs) return true;
+  return n <= SMALL_RANGES && (walk_bfs || (walk_members != 1 && p.max_depth >= 2));
+}
+uint32_t Engine::walk_group_size(const impg_gpu_index &ix, uint32_t n, const impg_gpu_params_t &p) const {
+  if (p.dfs || p.max_depth < 2 || n > SMALL_RANGES || walk_members == 1) return 1;
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix.device);
+  // every workgroup of the launch must be resident (the members wait for each other): one 1024-thread workgroup per CU
+  const uint32_t fit = std::max(1u, (uint32_t)cus / n);
+  return std::min({walk_members ? walk_members : 32u, fit, WALK_MAX_MEMBERS});
 }
 // the walk's slab shape: a BFS processes whole levels (16 waves per query), a DFS step is one popped range (one wave)
 void Engine::walk_caps(bool wide, WalkArgs &a) {
@@ -142,8 +155,15 @@ void Engine::reserve_walk_slabs(const impg_gpu_index &ix, bool dfs_too) {
     walk_caps(wide != 0, a);
     want = std::max(want, walk_slab_bytes(ix.view.n_seq, wide != 0, a.wcap, a.hcap, a.vcap, a.gcap, a.scap) * (size_t)walk_workgroups(ix, wide != 0));
   }
+  if (walk_members != 1) {  // the grid form of one call: a slab per member
+    WalkArgs a;
+    memset(&a, 0, sizeof a);
+    walk_caps(true, a);
+    want = std::max(want, walk_slab_bytes(ix.view.n_seq, true, a.wcap, a.hcap, a.vcap, a.gcap, a.scap) * (size_t)(walk_members ? walk_members : 32u));
+  }
   if (walk_slabs.cap < want) walk_slabs.reserve(want);
   walk_ctr.reserve(256);
+  walk_ctl.reserve((size_t)SMALL_RANGES * sizeof(WalkGroupCtl));
 }
 bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
                       unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows) {
@@ -155,12 +175,17 @@ bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges
   memset(&a, 0, sizeof a);
   walk_caps(wide, a);
   const size_t slab = walk_slab_bytes(ix.view.n_seq, wide, a.wcap, a.hcap, a.vcap, a.gcap, a.scap);
-  const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n, walk_workgroups(ix, wide));
+  const uint32_t members = walk_group_size(ix, n, p);
+  const uint32_t n_wg = members > 1 ? n * members : (uint32_t)std::min<uint64_t>(n, walk_workgroups(ix, wide));
   if (walk_slabs.cap < slab * n_wg) walk_slabs.reserve(slab * n_wg);  // (never shrunk: option prewarm_walk reserves the largest shape)
   walk_ctr.reserve(256);
   ev_next = 0;
   timed.clear();
   IMPG_HIP(hipMemsetAsync(walk_ctr.p, 0, 16, stream));
+  if (members > 1) {
+    walk_ctl.reserve((size_t)n * sizeof(WalkGroupCtl));
+    IMPG_HIP(hipMemsetAsync(walk_ctl.p, 0, (size_t)n * sizeof(WalkGroupCtl), stream));  // (every polled word, every call)
+  }
   IMPG_HIP(hipMemsetAsync(counters.p, 0, 64, stream));
   IMPG_HIP(hipMemsetAsync(acc_slots.p, 0, COUNT_BYTES, stream));
   hipEvent_t t0 = event(), t1 = event();
@@ -185,6 +210,14 @@ bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges
   a.overflow = walk_ctr.as<uint32_t>() + 1;
   a.slabs = walk_slabs.as<char>();
   a.slab_bytes = slab;
+  a.members = members;
+  a.ctl = members > 1 ? walk_ctl.as<WalkGroupCtl>() : nullptr;
+  if (masked) {
+    a.mask_off = mask_off.as<uint32_t>();
+    a.mask_ranges = mask_ranges.as<int2>();
+    a.mask_init_len = mask_init_len.as<int32_t>();
+    a.mask_touch_len = mask_touch_len.as<int32_t>();
+  }
   if (rows) {
     a.rows = rows->rows.as<impg_gpu_interval_t>();
     a.row_base = rows->base.as<unsigned long long>();
@@ -211,9 +244,11 @@ bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges
             h[24], h[25], h[26], h[27], h[28], h[29], h[30]);
   }
   if (dbg)
-    fprintf(stderr, "[walk] n=%u %s wg=%u slab=%.2f MB dfs=%d depth=%u overflow=0x%x (1 unknown target, 2 pairs per step, 4 visited pool, 8 piece scratch, 16 pieces, 32 stack / frontier) %.3f ms\n",
-            n, wide ? "wide" : "wave", n_wg, slab / 1048576.0, a.dfs, a.max_depth, flags[1], st ? st->ms_total : -1.0f);
-  if (flags[1]) return false;  // a query outgrew its slab: the batch engine runs the batch
+    fprintf(stderr, "[walk] n=%u %s wg=%u members=%u slab=%.2f MB dfs=%d depth=%u overflow=0x%x (1 unknown target, 2 pairs per step, 4 visited pool, 8 piece scratch, 16 pieces, 32 stack / frontier, 128 hand-off timed out) %.3f ms\n",
+            n, wide ? "wide" : "wave", n_wg, members, slab / 1048576.0, a.dfs, a.max_depth, flags[1], st ? st->ms_total : -1.0f);
+  ix.walk_last_members = members;
+  if (flags[1]) { ix.walk_fallbacks++; return false; }  // a query outgrew its slab: the batch engine runs the batch
+  ix.walk_launches++;
   if (st) st->levels = p.max_depth;
   return true;
 }

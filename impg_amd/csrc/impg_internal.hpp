@@ -1,6 +1,7 @@
 // Internal declarations shared by the host side of libimpg_gpu.so.
 // Layouts here are the HBM data layout described in DESIGN.md section 4.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -388,6 +389,8 @@ struct impg_gpu_index {
   bool opt_fuse_final = true;
   int opt_filter_covered = 0;
   int opt_walk = 1;
+  uint32_t opt_walk_members = 0;  // option "walk_members" (Engine::walk_members)
+  mutable std::atomic<uint64_t> walk_launches{0}, walk_fallbacks{0}, walk_last_members{1};  // impg_gpu_get_counter
   impg::ShardCtx *shard = nullptr;    // set: this index is one rank's shard; queries are collective calls
   impg::Cluster *cluster = nullptr;   // set: this handle fronts n_dev shards in this process (no arrays of its own)
   impg_gpu_index();

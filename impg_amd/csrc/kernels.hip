@@ -4104,7 +4104,11 @@ size_t walk_slab_bytes(uint32_t n_seq, bool wide, uint32_t wcap, uint32_t hcap, 
 }
 void launch_walk(const WalkArgs &a, uint32_t n_workgroups, bool wide, bool ident_mode, hipStream_t s) {
   if (!n_workgroups) return;
-  if (wide) {
+  if (wide && a.members > 1) {
+    if (ident_mode && !a.v.pfx) walk_grid_kernel<16, 4096, MODE_IDENT | MODE_WALK><<<n_workgroups, 1024, 0, s>>>(a);
+    else if (ident_mode) walk_grid_kernel<16, 4096, MODE_IDENT><<<n_workgroups, 1024, 0, s>>>(a);
+    else walk_grid_kernel<16, 4096, 0><<<n_workgroups, 1024, 0, s>>>(a);
+  } else if (wide) {
     if (ident_mode && !a.v.pfx) walk_kernel<16, 4096, MODE_IDENT | MODE_WALK><<<n_workgroups, 1024, 0, s>>>(a);
     else if (ident_mode) walk_kernel<16, 4096, MODE_IDENT><<<n_workgroups, 1024, 0, s>>>(a);
     else walk_kernel<16, 4096, 0><<<n_workgroups, 1024, 0, s>>>(a);

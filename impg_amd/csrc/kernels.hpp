@@ -237,7 +237,27 @@ struct WalkArgs {
   size_t slab_bytes;
   uint32_t wcap, hcap, vcap, gcap, scap;  // records per frontier / piece list, pairs per step, visited ranges, piece scratch, DFS stack records
   unsigned long long *dbg;           // IMPG_WALK_DEBUG: 32 words of phase clocks and counters (null: off)
+  // masked_regions (null: none): the map's lists by sequence id; the length a list clamps to when the range's own
+  // target opens it (0 for a sequence the map does not hold, impg.rs:2048-2053) and when a hit opens it
+  const uint32_t *mask_off;
+  const int2 *mask_ranges;
+  const int32_t *mask_init_len, *mask_touch_len;
+  // grid form (members > 1; BFS with a depth limit): query q is walked by workgroups [q * members, (q + 1) * members);
+  // the first one takes it up to its last level, whose ranges all of them share out (walk_final_level)
+  uint32_t members;
+  struct WalkGroupCtl *ctl;  // one per query, zeroed before the launch
 };
+constexpr uint32_t WALK_MAX_MEMBERS = 64;
+struct WalkGroupCtl {
+  uint32_t state;     // 0: the leader is on the earlier levels; 1: the last level's frontier is published; 2: there is none
+  uint32_t nw;        // ranges of the last level's frontier (the leader's wa[])
+  uint32_t rows_run;  // rows written before the last level
+  uint32_t arrived;   // members whose projections are done
+  unsigned long long cksum, count;
+  uint32_t emit[WALK_MAX_MEMBERS];  // rows of each member's share
+  uint32_t pad[(512 - 32 - 4 * WALK_MAX_MEMBERS) / 4];
+};
+static_assert(sizeof(WalkGroupCtl) == 512, "one control block per query");
 size_t walk_slab_bytes(uint32_t n_seq, bool wide, uint32_t wcap, uint32_t hcap, uint32_t vcap, uint32_t gcap, uint32_t scap);
 // wide: 16 waves per workgroup (a handful of queries, latency) instead of one (a batch, throughput); ident_mode: the
 // projections take the identity filter's path (a filter is set, or the index has no prefix lines)
@@ -245,6 +265,6 @@ size_t walk_slab_bytes(uint32_t n_seq, bool wide, uint32_t wcap, uint32_t hcap, 
 #define IMPG_WALK_WAVES 6  // 100 000-range DFS batch: 4 waves per SIMD (101 VGPRs, what the compiler takes unasked) 4.22 s, 5: 3.80, 6: 3.66, 8: 3.68
 #endif
 constexpr uint32_t WALK_WAVES_PER_SIMD = IMPG_WALK_WAVES;  // resident waves per SIMD the one-wave-per-query walk is compiled for
-void launch_walk(const WalkArgs &a, uint32_t n_workgroups, bool wide, bool ident_mode, hipStream_t s);
+void launch_walk(const WalkArgs &a, uint32_t n_workgroups, bool wide, bool ident_mode, hipStream_t s);  // (members > 1: n_workgroups = queries x members)
 
 }  // namespace impg

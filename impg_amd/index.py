@@ -264,6 +264,12 @@ class GpuImpg:
     def set_option(self, key, value):
         check(lib().impg_gpu_set_option(self._h, key.encode(), int(value)))
 
+    def counter(self, key):
+        """impg_gpu_get_counter: "walk_launches", "walk_fallbacks", "walk_members"."""
+        v = C.c_int64(0)
+        check(lib().impg_gpu_get_counter(self._h, key.encode(), C.byref(v)))
+        return v.value
+
     # ---- queries ---------------------------------------------------------------
     @staticmethod
     def _ranges(ranges):

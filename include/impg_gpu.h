@@ -208,6 +208,9 @@ int impg_gpu_index_approximate(const impg_gpu_index_t *);
  * that keep no level -- impg_gpu_query_batch_stats -- lay their hit slots out in
  * that order too; 0: always the reference's slot order; counts and checksums are
  * identical either way),
+ * "walk_kernel" (the per-query walk: 0 never, 1 -- the default -- DFS batches of any size and depth-limited BFS batches of
+ * <= 64 ranges, 2 also BFS batches of <= 64 ranges without a depth limit) and "walk_members" (workgroups per query of
+ * the walk's grid form, which shares a depth-limited BFS's last level out: 0 = as many as fit, at most 32; 1 = none),
  * "fuse_final_level" (1, the default: the final level of such a run -- no update follows, no row is kept --
  * takes its (range, entry) pairs straight from the lookup's per-range windows inside the projection kernel; the emit
  * pass and its pair lists are skipped; counts and checksums are identical either way).
@@ -216,6 +219,12 @@ int impg_gpu_index_approximate(const impg_gpu_index_t *);
  * otherwise, ~0.3-1 s); "prewarm_walk" = 1 / 2 allocates the per-query walk's slabs (1: the per-call / small-batch BFS
  * shape; 2: also the DFS batch's, ~15 GB) on the index's first engine. */
 int impg_gpu_set_option(impg_gpu_index_t *, const char *key, int64_t value);
+/* Read-only counters of an index handle (no reference counterpart; they tell a test, or an operator, which engine
+ * answered): "walk_launches" = per-query walk launches that answered their batch (walk_device.inc: DFS batches, small
+ * depth-limited BFS batches incl. masked ones -- the shape of partition.rs:359-391), "walk_fallbacks" = launches whose
+ * batch the batch engine had to run again (a query outgrew its slab), "walk_members" = workgroups per query of the
+ * last grid-form launch (1: not the grid form). */
+int impg_gpu_get_counter(const impg_gpu_index_t *, const char *key, int64_t *value_out);
 /* Large result arrays live in pinned host blocks that are recycled through a process-wide pool (at most
  * IMPG_PINNED_POOL_BYTES, default 6 GiB, are kept when results are freed).  Gives pooled blocks back to the system
  * until at most keep_bytes are held; returns the number of bytes freed. */

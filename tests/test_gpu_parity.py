@@ -1425,6 +1425,66 @@ def test_walk_kernel_matches_oracle_and_batch_engine(tmp_path, seed):
         assert g.query_transitive_bfs(*ranges[0], max_depth=3).tolist() == c.query(*ranges[0], transitive=True, max_depth=3).tolist()
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_walk_grid_form_and_masks(tmp_path, seed):
+    """The walk's grid form (a depth-limited BFS of <= 64 ranges: `walk_members` workgroups per query share the last level
+    out, walk_final_level) and masked_regions inside the walk (the shape partition.rs:359-391 calls, BFS and DFS): rows
+    against the oracle, counts / checksums / projections against the batch engine, for 1 .. many members, batches of 1,
+    3 and 64 ranges, depth 1 .. 4, the length / distance / identity / subset cut-offs -- and the counters say the walk
+    answered."""
+    text, _ = random_paf(900 + seed, 600, n_seq=7, seq_len=40_000, max_ops=300, weird=True, inconsistent=(seed == 12), self_aln=True)
+    g, c = both(tmp_path, text)
+    ranges = random_ranges(seed, 128, 7, 40_000, max_len=5000, min_len=1)
+    keep = np.array([1, 0, 1, 1, 0, 1, 1], dtype=np.uint8)
+    bfs_cases = [dict(transitive=True, max_depth=3, min_transitive_len=30), dict(transitive=True, max_depth=2),
+                 dict(transitive=True, max_depth=4, min_transitive_len=60, min_distance_between_ranges=40, min_output_length=80),
+                 dict(transitive=True, max_depth=2, min_identity=0.7, min_output_length=50)]
+    g.set_option("walk_kernel", 0)
+    ref = [g.query_batch_stats(ranges[:64], impg_amd.make_params(**kw)) for kw in bfs_cases]
+    g.set_option("walk_kernel", 1)
+    for members in (0, 2, 5, 64, 1):
+        g.set_option("walk_members", members)
+        before = g.counter("walk_launches")
+        for k, kw in enumerate(bfs_cases):
+            for lo, n in ((0, 64), (64, 3), (70, 1), (90, 38)):
+                assert_same(g, c, ranges[lo:lo + n], **kw)
+            st, cnt, ck = g.query_batch_stats(ranges[:64], impg_amd.make_params(**kw))
+            assert (cnt.tolist(), ck.tolist(), st.projected) == (ref[k][1].tolist(), ref[k][2].tolist(), ref[k][0].projected), (members, kw)
+        assert_same(g, c, ranges[:40], subset_keep=keep, transitive=True, max_depth=3, min_transitive_len=30)
+        assert g.query_transitive_bfs(*ranges[5], max_depth=3).tolist() == c.query(*ranges[5], transitive=True, max_depth=3).tolist()
+        if members != 1:
+            assert g.counter("walk_launches") > before and g.counter("walk_fallbacks") == 0
+            assert g.counter("walk_members") == {0: 32, 2: 2, 5: 5, 64: 64}[members]  # (the last call: one range)
+        else:
+            assert g.counter("walk_launches") == before  # (no grid form: the batch engine keeps a BFS)
+    # masks: the walk (grid BFS, DFS batches of any size, every small BFS under walk_kernel = 2) and the batch engine
+    g.set_option("walk_members", 0)
+    for m_seed, present, odd in ((1, 1.0, False), (2, 0.6, True), (3, 0.3, True)):
+        mask = random_mask(seed * 10 + m_seed, 7, 40_000, present=present, odd_lengths=odd)
+        for walk in (1, 2, 0):
+            g.set_option("walk_kernel", walk)
+            before = g.counter("walk_launches")
+            for kw in [dict(transitive=True, max_depth=2), dict(transitive=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=10),
+                       dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=10),
+                       dict(transitive=True, max_depth=0, min_transitive_len=300, min_distance_between_ranges=10),
+                       dict(transitive=True, dfs=True, max_depth=0, min_transitive_len=300)]:
+                assert_same(g, c, ranges[:48], masked_regions=mask, **kw)
+                assert_same(g, c, ranges[100:101], masked_regions=mask, **kw)
+            if kw.get("dfs"):
+                assert_same(g, c, ranges, masked_regions=mask, **kw)  # a DFS batch of any size
+            assert (g.counter("walk_launches") > before) == (walk != 0)
+            assert g.counter("walk_fallbacks") == 0
+    # a mask with empty ranges: its self pieces touch; the DFS goes to the batch engine, the BFS stays
+    g.set_option("walk_kernel", 1)
+    L = int(c.seq_len(int(ranges[0][0])))
+    t0 = int(ranges[0][0])
+    mask = {t0: (L, [(1000, 1000), (1500, 1500), (2500, 2600)])}
+    probe = [(t0, 400, 3000), (t0, 1000, 1500), (t0, 0, L)]
+    for kw in [dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=20), dict(transitive=True, max_depth=3, min_transitive_len=20),
+               dict(transitive=True, dfs=True, max_depth=2, min_transitive_len=700)]:
+        assert_same(g, c, probe, masked_regions=mask, **kw)
+
+
 # ---- the row stream: impg_gpu_query_batch_stream ---------------------------------
 def test_query_batch_stream_matches_the_one_shot_call(tmp_path):
     """Chunks arrive in range order, one at a time, and hold the rows (and CIGARs) impg_gpu_query_batch returns for the same

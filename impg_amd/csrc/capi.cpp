@@ -205,9 +205,7 @@ bool walk_query(impg_gpu_index &ix, Engine &E, const impg_gpu_range_t *h_ranges,
     W.rows.reserve(std::max<size_t>(total_rows * sizeof(impg_gpu_interval_t), 256));
     IMPG_HIP(hipMemcpyAsync(W.base.p, base.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
     IMPG_HIP(hipMemcpyAsync(W.cap.p, cap.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    if (!E.run_walk(ix, E.ranges_dev.as<impg_gpu_range_t>(), n, p, nullptr, nullptr, nullptr, &W)) return false;
-    IMPG_HIP(hipMemcpy(cnt.data(), W.n_rows.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    return true;
+    return E.run_walk(ix, E.ranges_dev.as<impg_gpu_range_t>(), n, p, nullptr, nullptr, nullptr, &W, cnt.data());  // (cnt: the rows every query wrote)
   };
   if (!pass((uint64_t)n * each)) return false;
   bool fits = true;
@@ -624,6 +622,8 @@ void apply_mask(Engine &E, const impg_gpu_index &ix, const impg_gpu_mask_t *m, c
     }
     E.masked = true;
     E.mask_has_empty = has_empty;
+    E.mask_ranges_total = total;
+    E.mask_lists = m->n_seqs;
   }
 }
 void apply_subset(Engine &E, const impg_gpu_index &ix, const uint8_t *subset_keep) {

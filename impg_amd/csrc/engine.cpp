@@ -124,7 +124,13 @@ bool Engine::walk_applicable(const impg_gpu_index &ix, uint32_t n, const impg_gp
   // out); without one the two engines cost the same per call and the batch engine keeps it -- walk_kernel = 2 sends
   // every small BFS batch here (tests)
   if (p.dfs) return true;
-  return n <= SMALL_RANGES && (walk_bfs || (walk_members != 1 && p.max_depth >= 2));
+  if (n > SMALL_RANGES) return false;
+  if (walk_bfs) return true;
+  // (under a mask of long lists the walk's update -- one CU, a thread per (sequence) group on a copy of the map's list in
+  // the slab -- loses to the batch engine's wave-per-group kernels as soon as a second level is updated: measured on
+  // the headline index with 190 ranges per sequence masked, `-m 2` 0.37 vs 0.70 ms, `-m 3` 1.28 vs 0.98 ms per call)
+  if (masked && p.max_depth >= 3 && mask_ranges_total > 16ull * std::max<uint64_t>(1, mask_lists)) return false;
+  return walk_members != 1 && p.max_depth >= 2;
 }
 uint32_t Engine::walk_group_size(const impg_gpu_index &ix, uint32_t n, const impg_gpu_params_t &p) const {
   if (p.dfs || p.max_depth < 2 || n > SMALL_RANGES || walk_members == 1) return 1;
@@ -166,7 +172,7 @@ void Engine::reserve_walk_slabs(const impg_gpu_index &ix, bool dfs_too) {
   walk_ctl.reserve((size_t)SMALL_RANGES * sizeof(WalkGroupCtl));
 }
 bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
-                      unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows) {
+                      unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows, uint32_t *h_n_rows) {
   if (!walk_applicable(ix, n, p)) return false;
   IMPG_HIP(hipSetDevice(ix.device));
   // a BFS processes whole levels: 16 waves per query; a DFS step is one popped range: one wave, cheap barriers
@@ -235,12 +241,13 @@ bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges
   launch_walk(a, n_wg, wide, ident, stream);
   uint32_t flags[2] = {0, 0};
   IMPG_HIP(hipMemcpyAsync(flags, walk_ctr.p, 8, hipMemcpyDeviceToHost, stream));
+  if (rows && h_n_rows) IMPG_HIP(hipMemcpyAsync(h_n_rows, rows->n_rows.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));  // (under the same synchronisation)
   finish_run(st, t0, t1);  // (synchronises; raises the projection errors; fills st->projected / ms_total)
   if (dbg) {
     unsigned long long h[32];
     IMPG_HIP(hipMemcpy(h, d_dbg.p, 256, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[walk] Mclk: drop %.1f window %.1f count %.1f emit %.1f project %.1f sort %.1f groups %.1f (gap %.1f) pieces %.1f merge %.1f | pops %llu dropped %llu max stack %llu max pieces %llu | fail q=%llu flag=%llu target=%llu n_seq=%llu nw=%llu npc=%llu vused=%llu\n",
-            h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5] / 1e6, h[6] / 1e6, h[7] / 1e6, h[8] / 1e6, h[9] / 1e6, h[16], h[17], h[18], h[19],
+    fprintf(stderr, "[walk] Mclk: drop %.3f window %.3f count %.3f emit %.3f project %.3f sort %.3f groups %.3f (gap %.3f) pieces %.3f merge %.3f shared last level %.3f | pops %llu dropped %llu max stack %llu max pieces %llu | fail q=%llu flag=%llu target=%llu n_seq=%llu nw=%llu npc=%llu vused=%llu\n",
+            h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5] / 1e6, h[6] / 1e6, h[7] / 1e6, h[8] / 1e6, h[9] / 1e6, h[10] / 1e6, h[16], h[17], h[18], h[19],
             h[24], h[25], h[26], h[27], h[28], h[29], h[30]);
   }
   if (dbg)
@@ -755,8 +762,9 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
       L->n_frontier = n_fr;
       if (want_stats) {
         HitArrays h{L->qid.as<uint32_t>(), L->coords.as<int4>()};
-        launch_hit_stats(cur->as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h,
-                         transitive ? p.min_output_length : -1, false, d_count, d_cksum, stream);
+        rstat.reserve(std::max<size_t>((size_t)n_fr * 16, 256));
+        launch_hit_stats(cur->as<FrontierRec>(), n_fr, L->pair_range.as<uint32_t>(), L->n_pairs, h,
+                         transitive ? p.min_output_length : -1, false, rstat.as<unsigned long long>(), d_count, d_cksum, stream);
       }
       if (st) st->levels += 1;
       if (!last) n_next = update(v, cur->as<FrontierRec>(), *L, n, p, *nxt);
@@ -864,6 +872,10 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
   launch_frontier_to_stack(frontier_a.as<FrontierRec>(), n_stack, nullptr, false, dk_a.as<unsigned long long>(),
                            ds_a.as<int32_t>(), de_a.as<int32_t>(), dd_a.as<uint32_t>(), stream);
   // current stack in the *_a buffers, sorted by (qidx, sequence, start)
+  // (a mask with empty ranges gives first pieces that touch: the reference merges them at its first re-sort, which it
+  // runs after every explored pop, pushes or not -- impg.rs:2289-2304 -- so the "nothing pushed" shortcut below waits
+  // until one round has merged the stacks)
+  bool unmerged = masked && mask_has_empty;
   for (;;) {
     const bool alive = n_stack > 0;
     // ---- pop the top of every query's stack -----------------------------------
@@ -897,8 +909,9 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
       L->n_frontier = n_fr;
       if (d_count || d_cksum) {
         HitArrays h{L->qid.as<uint32_t>(), L->coords.as<int4>()};
-        launch_hit_stats(frontier_b.as<FrontierRec>(), L->pair_range.as<uint32_t>(), L->n_pairs, h, p.min_output_length,
-                         multi, d_count, d_cksum, stream);
+        rstat.reserve(std::max<size_t>((size_t)n_fr * 16, 256));
+        launch_hit_stats(frontier_b.as<FrontierRec>(), n_fr, L->pair_range.as<uint32_t>(), L->n_pairs, h, p.min_output_length,
+                         multi, rstat.as<unsigned long long>(), d_count, d_cksum, stream);
       }
       if (st) st->levels += 1;
       n_pieces = update(v, frontier_b.as<FrontierRec>(), *L, n, p, frontier_a);  // pieces, sorted by (qidx, seq, start)
@@ -910,7 +923,7 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
     }
     const uint32_t m = n_keep + n_pieces;
     if (m == 0) { n_stack = 0; continue; }  // (one more hop call tells the other ranks, or ends the walk)
-    if (n_pieces == 0) {  // nothing pushed: the remaining stack is still sorted and merged
+    if (n_pieces == 0 && !unmerged) {  // nothing pushed: the remaining stack is still sorted and merged
       dk_a.swap(dk_b); ds_a.swap(ds_b); de_a.swap(de_b); dd_a.swap(dd_b);
       n_stack = n_keep;
       continue;
@@ -927,9 +940,10 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
         IMPG_HIP(hipMemcpyAsync(ne.p, de_b.p, (size_t)n_keep * 4, hipMemcpyDeviceToDevice, stream));
         IMPG_HIP(hipMemcpyAsync(nd.p, dd_b.p, (size_t)n_keep * 4, hipMemcpyDeviceToDevice, stream));
       }
-      launch_frontier_to_stack(frontier_a.as<FrontierRec>(), n_pieces, d_popdepth.as<uint32_t>(), true,
-                               nk.as<unsigned long long>() + n_keep, ns.as<int32_t>() + n_keep, ne.as<int32_t>() + n_keep,
-                               nd.as<uint32_t>() + n_keep, stream);
+      if (n_pieces)
+        launch_frontier_to_stack(frontier_a.as<FrontierRec>(), n_pieces, d_popdepth.as<uint32_t>(), true,
+                                 nk.as<unsigned long long>() + n_keep, ns.as<int32_t>() + n_keep, ne.as<int32_t>() + n_keep,
+                                 nd.as<uint32_t>() + n_keep, stream);
       IMPG_HIP(hipStreamSynchronize(stream));
       dk_b.swap(nk); ds_b.swap(ns); de_b.swap(ne); dd_b.swap(nd);
     }
@@ -960,6 +974,7 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
                        sm.as<int32_t>(), em.as<int32_t>(), dm.as<uint32_t>(), dk_a.as<unsigned long long>(), ds_a.as<int32_t>(),
                        de_a.as<int32_t>(), dd_a.as<uint32_t>(), stream);
     n_stack = n_new;
+    unmerged = false;
   }
   finish_run(st, t0, t1);
 }

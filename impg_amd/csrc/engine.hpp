@@ -156,6 +156,7 @@ struct Engine {
   bool masked = false;
   DevBuf mask_off, mask_ranges, mask_init_len, mask_touch_len;
   bool mask_has_empty = false;  // a mask range with start == end
+  uint64_t mask_ranges_total = 0, mask_lists = 0;  // ranges / sequences of the map
   DevBuf self_off;        // masked batches: query q's self intervals are self[self_off[q] .. self_off[q+1])
   uint64_t n_self = 0;
   uint32_t begin_transitive_masked(const DeviceIndexView &v, const impg_gpu_range_t *d_ranges, uint32_t n,
@@ -186,8 +187,9 @@ struct Engine {
   static uint64_t walk_workgroups(const impg_gpu_index &ix, bool wide);
   void reserve_walk_slabs(const impg_gpu_index &ix, bool dfs_too);  // option prewarm_walk
   bool run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
-                unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows);
+                unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows, uint32_t *h_n_rows = nullptr);
   DevBuf walk_slabs, walk_ctr, walk_ctl;
+  DevBuf rstat;  // hit_stats: a level's per-range counts / checksums
   uint32_t walk_members = 0;  // option "walk_members": workgroups per query of the grid form (0: as many as fit, at most 32; 1: no grid form)
   uint32_t walk_group_size(const impg_gpu_index &ix, uint32_t n, const impg_gpu_params_t &p) const;
   char *small_in = nullptr;    // pinned: the ranges on their way in

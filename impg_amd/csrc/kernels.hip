@@ -2226,46 +2226,44 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-// Slots in the reference's order follow the frontier, which is sorted by query, so the slots of one query are one
-// run: a whole wave, usually a whole block, adds to the same two words.  The wave sums first (a tiling batch at
-// depth 5 has 10^7 hits per query: one atomic per hit on one address ran at ~90 atomics/us, 95 % of the batch).
+// Per-range counts / checksums in two steps.  (1) A hit adds to its frontier RANGE's pair of words: the slots of a range
+// are one run in every layout but the fused final level's (places filled entry by entry), a wave sums each run first, and
+// whatever is left lands on as many addresses as the level has ranges.  (2) The ranges' words are summed per query over
+// the frontier, which is sorted by query.  (Adding to the QUERY's words directly -- one pair of atomics per run of equal
+// query -- was fine while a query's slots were one run; with the slots of a level's final pass in entry order every hit
+// of a wave belongs to another range, and a window tiling at depth 5 -- 2 000 queries a chunk, 10^7 hits each -- spent
+// 9 of its 10 s on those few thousand addresses.)
 __global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__restrict__ fr,
                                                         const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
                                                         HitArrays h, int32_t min_output_length, int skip_same_target,
-                                                        unsigned long long *__restrict__ count,
-                                                        unsigned long long *__restrict__ cksum) {
-  __shared__ uint32_t s_q[4];
-  __shared__ unsigned long long s_c[4], s_k[4];
+                                                        unsigned long long *__restrict__ rstat, int want_ck) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  uint32_t qx = 0xFFFFFFFFu;
+  uint32_t r = 0xFFFFFFFFu;
   unsigned long long c = 0, a = 0;
   if (p < n_pairs) {
-    const FrontierRec f = fr[pair_range[p]];
-    qx = f.qidx;
+    r = pair_range[p];
     const uint32_t qid = h.qid[p];
     if (qid != HIT_NONE) {
+      const uint32_t tgt = fr[r].target_id;
       const int4 hc = h.c[p];
       const int32_t qs = hc.x, qe = hc.y;
       const bool drop = (min_output_length >= 0 && abs(qe - qs) < min_output_length) ||
-                        (skip_same_target && qid == f.target_id);  // multi_impg.rs:883-885
+                        (skip_same_target && qid == tgt);  // multi_impg.rs:883-885
       if (!drop) {
-        a = mix64(((unsigned long long)qid << 32) | (uint32_t)qs);
-        a = mix64(a ^ (((unsigned long long)(uint32_t)qe << 32) | f.target_id));
-        a = mix64(a ^ (((unsigned long long)(uint32_t)hc.z << 32) | (uint32_t)hc.w));
+        if (want_ck) {
+          a = mix64(((unsigned long long)qid << 32) | (uint32_t)qs);
+          a = mix64(a ^ (((unsigned long long)(uint32_t)qe << 32) | tgt));
+          a = mix64(a ^ (((unsigned long long)(uint32_t)hc.z << 32) | (uint32_t)hc.w));
+        }
         c = 1;
       }
     }
   }
-  // one query for the whole wave? (lanes past the end carry 0xFFFFFFFF and nothing to add: they go along)
-  const unsigned long long live = __ballot(qx != 0xFFFFFFFFu);
-  const uint32_t q0 = live ? (uint32_t)__shfl((int)qx, __ffsll((long long)live) - 1) : 0xFFFFFFFFu;
-  const bool uniform = __all(qx == q0 || qx == 0xFFFFFFFFu);
-  if (!uniform) {
-    // several queries in the wave (slots in projection order interleave them, one range's run at a time): a
-    // segmented scan over the runs of equal query, one pair of atomics per run
-    const unsigned lane = lane_id();
-    const uint32_t prev = (uint32_t)__shfl_up((int)qx, 1);
-    const unsigned long long heads = __ballot(lane == 0 || prev != qx);
+  // a segmented scan over the wave's runs of equal range, one pair of atomics per run
+  const unsigned lane = lane_id();
+  const uint32_t prev = (uint32_t)__shfl_up((int)r, 1);
+  const unsigned long long heads = __ballot(lane == 0 || prev != r);
+  if (__popcll(heads) < 64) {
     const unsigned first = 63u - (unsigned)__clzll((long long)(heads & (lanemask_lt() | (1ull << lane))));
 #pragma unroll
     for (unsigned o = 1; o < 64; o <<= 1) {
@@ -2273,33 +2271,39 @@ __global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__res
       const unsigned long long av = (unsigned long long)__shfl_up((long long)a, o);
       if (lane >= first + o) { c += cv; a += av; }
     }
-    const bool tail = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
-    if (tail && c && qx != 0xFFFFFFFFu) {
-      if (count) atomicAdd(&count[qx], c);
-      if (cksum) atomicAdd(&cksum[qx], a);
-    }
-    if (lane == 0) s_q[threadIdx.x >> 6] = 0xFFFFFFFFu;
-  } else {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      c += (unsigned long long)__shfl_xor((long long)c, o);
-      a += (unsigned long long)__shfl_xor((long long)a, o);
-    }
-    if (lane_id() == 0) { s_q[threadIdx.x >> 6] = q0; s_c[threadIdx.x >> 6] = c; s_k[threadIdx.x >> 6] = a; }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {  // the block's (up to four) wave sums, merged where they name the same query
-    for (int w = 0; w < 4; w++) {
-      const uint32_t q = s_q[w];
-      if (q == 0xFFFFFFFFu) continue;
-      unsigned long long cc = s_c[w], kk = s_k[w];
-      for (int w2 = w + 1; w2 < 4; w2++)
-        if (s_q[w2] == q) { cc += s_c[w2]; kk += s_k[w2]; s_q[w2] = 0xFFFFFFFFu; }
-      if (cc) {
-        if (count) atomicAdd(&count[q], cc);
-        if (cksum) atomicAdd(&cksum[q], kk);
-      }
-    }
+  const bool tail = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
+  if (tail && c && r != 0xFFFFFFFFu) {
+    atomicAdd(&rstat[2u * (size_t)r], c);
+    if (want_ck) atomicAdd(&rstat[2u * (size_t)r + 1u], a);
+  }
+}
+__global__ __launch_bounds__(256) void range_stats_reduce_kernel(const FrontierRec *__restrict__ fr, uint32_t n_fr,
+                                                                 const unsigned long long *__restrict__ rstat,
+                                                                 unsigned long long *__restrict__ count,
+                                                                 unsigned long long *__restrict__ cksum) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  uint32_t q = 0xFFFFFFFFu;
+  unsigned long long c = 0, a = 0;
+  if (i < n_fr) {
+    q = fr[i].qidx;
+    const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(rstat)[i];
+    c = x.x; a = x.y;
+  }
+  const unsigned lane = lane_id();
+  const uint32_t prev = (uint32_t)__shfl_up((int)q, 1);
+  const unsigned long long heads = __ballot(lane == 0 || prev != q);
+  const unsigned first = 63u - (unsigned)__clzll((long long)(heads & (lanemask_lt() | (1ull << lane))));
+#pragma unroll
+  for (unsigned o = 1; o < 64; o <<= 1) {
+    const unsigned long long cv = (unsigned long long)__shfl_up((long long)c, o);
+    const unsigned long long av = (unsigned long long)__shfl_up((long long)a, o);
+    if (lane >= first + o) { c += cv; a += av; }
+  }
+  const bool tail = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
+  if (tail && q != 0xFFFFFFFFu && (c | a)) {
+    if (count && c) atomicAdd(&count[q], c);
+    if (cksum && a) atomicAdd(&cksum[q], a);
   }
 }
 
@@ -3870,12 +3874,14 @@ void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, Hi
                         const uint32_t *off, uint32_t *out, hipStream_t s) {
   if (n_pairs) slice_write_kernel<<<cdiv(n_pairs, 64), 64, 0, s>>>(v, pair_entry, h, sl, n_pairs, off, out);
 }
-void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
-                      int32_t min_output_length, bool skip_same_target, unsigned long long *count, unsigned long long *cksum,
-                      hipStream_t s) {
-  if (!n_pairs) return;
-  hit_stats_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, min_output_length, skip_same_target ? 1 : 0,
-                                                     count, cksum);
+void launch_hit_stats(const FrontierRec *fr, uint32_t n_fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
+                      int32_t min_output_length, bool skip_same_target, unsigned long long *rstat, unsigned long long *count,
+                      unsigned long long *cksum, hipStream_t s) {
+  if (!n_pairs || !n_fr) return;
+  IMPG_HIP(hipMemsetAsync(rstat, 0, (size_t)n_fr * 16, s));
+  hit_stats_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, min_output_length, skip_same_target ? 1 : 0, rstat,
+                                                     cksum ? 1 : 0);
+  range_stats_reduce_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(fr, n_fr, rstat, count, cksum);
 }
 void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
                         unsigned long long *keys, unsigned long long *vals, unsigned long long *n_active, hipStream_t s) {

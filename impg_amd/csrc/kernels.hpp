@@ -120,9 +120,10 @@ void launch_small_pack(const FrontierRec *fr, const uint32_t *pair_range, const 
 void launch_slice_counts(HitArrays h, SliceArrays sl, uint32_t n_pairs, uint32_t *cnt, hipStream_t s);
 void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, HitArrays h, SliceArrays sl, uint32_t n_pairs,
                         const uint32_t *off, uint32_t *out, hipStream_t s);
-void launch_hit_stats(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
-                      int32_t min_output_length, bool skip_same_target, unsigned long long *count, unsigned long long *cksum,
-                      hipStream_t s);
+// per-range counts / checksums of a level's hits: rstat = 16 bytes of scratch per frontier range (zeroed here)
+void launch_hit_stats(const FrontierRec *fr, uint32_t n_fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
+                      int32_t min_output_length, bool skip_same_target, unsigned long long *rstat, unsigned long long *count,
+                      unsigned long long *cksum, hipStream_t s);
 void launch_sort5(const FrontierRec *fr, uint32_t n, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
                   const uint32_t *pair_entry, const uint32_t *mrank, uint32_t *dest, hipStream_t s);
 void launch_permute_slots(const uint32_t *dest, uint32_t n_pairs, HitArrays in, HitArrays out, const uint32_t *pe_in,

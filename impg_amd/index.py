@@ -109,6 +109,18 @@ class QueryResults:
             self._h = None
 
 
+class PreparedMask:
+    """A masked_regions map already in the C layout (impg_gpu_mask_t + the arrays it points into): per-call users --
+    the shape of partition.rs:359-391 -- convert once per change of the map, not once per call."""
+
+    def __init__(self, m, arrays):
+        self.m, self.arrays = m, arrays
+
+
+def prepare_mask(masked_regions):
+    return PreparedMask(*GpuImpg._mask(masked_regions))
+
+
 class GpuImpg:
     """`impl ImpgIndex` backed by the HIP engine."""
 
@@ -282,7 +294,10 @@ class GpuImpg:
 
     @staticmethod
     def _mask(masked_regions):
-        """{sequence id: (sequence_length, [(start, end), ...])} -> (impg_gpu_mask_t, arrays kept alive)."""
+        """{sequence id: (sequence_length, [(start, end), ...])} -> (impg_gpu_mask_t, arrays kept alive).  A
+        PreparedMask (prepare_mask: the conversion done once for many calls) passes through."""
+        if isinstance(masked_regions, PreparedMask):
+            return masked_regions.m, masked_regions.arrays
         ids = sorted(masked_regions)
         seq = np.array(ids, dtype=np.uint32)
         slen = np.array([masked_regions[i][0] for i in ids], dtype=np.int32)

@@ -173,7 +173,10 @@ def test_config5_window_tiling_depth5():
     ranges["end"] = ranges["start"] + 5000
     g.set_option("pair_budget", 1 << 30)
     g.set_option("chunk_ranges", 2000)
+    import time
+    t0 = time.perf_counter()
     st1, cnt1, ck1 = g.query_batch_stats(ranges, p5)
+    print("config 5: %d windows -m 5 in %.1f s (engine %.1f s), %.3g projections" % (n_windows, time.perf_counter() - t0, st1.ms_total / 1e3, st1.projected), flush=True)
     assert st1.levels == 5 and st1.projected == int(cnt1.sum()) > 500_000 * n_windows
     sub = slice(0, 1500)
     g.set_option("chunk_ranges", 333)

@@ -53,6 +53,7 @@ EngineLease::EngineLease(impg_gpu_index &ix_) : ix(ix_) {
   e->walk_allowed = ix.opt_walk != 0 && !getenv("IMPG_NO_WALK");
   e->walk_bfs = ix.opt_walk == 2;  // (the environment switch runs a whole test suite on the batch engine)
   e->walk_members = ix.opt_walk_members;
+  e->seg_group = ix.opt_seg_group;
 }
 EngineLease::~EngineLease() {
   e->remote = nullptr;
@@ -516,6 +517,8 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
   } else if (k == "walk_kernel") {  // the per-query walk (walk_device.inc): 0 never, 1 DFS batches of any size and depth-limited BFS batches of <= 64 ranges (default), 2 every BFS batch of <= 64 ranges
     if (value < 0 || value > 2) throw Error{IMPG_E_INVALID, "walk_kernel is 0, 1 or 2"};
     ix->opt_walk = (int)value;
+  } else if (k == "segment_groups") {  // the update's hits grouped query by query (1, default) or by the library's radix sort (0); results identical
+    ix->opt_seg_group = value != 0;
   } else if (k == "walk_members") {  // workgroups per query of the walk's grid form (depth-limited BFS, <= 64 ranges): 0 = as many as fit (<= 32), 1 = no grid form
     if (value < 0 || value > (long long)WALK_MAX_MEMBERS) throw Error{IMPG_E_INVALID, "walk_members is 0 .. 64"};
     ix->opt_walk_members = (uint32_t)value;

@@ -490,26 +490,54 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
   uint32_t n_next = 0;
   HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
   if (P) {
+    const uint32_t P_slots = P;
+    const bool want_flags = filter_covered != 0;
     keys.reserve((size_t)P * 8); skeys.reserve((size_t)P * 8);
     vals.reserve((size_t)P * 8); svals.reserve((size_t)P * 8);
-    IMPG_HIP(hipMemsetAsync(act_slots.p, 0, COUNT_BYTES, stream));
-    launch_update_keys(fr, L.pair_range.as<uint32_t>(), P, h, keys.as<unsigned long long>(), vals.as<unsigned long long>(),
-                       act_slots.as<unsigned long long>(), stream);
-    size_t tb = sort_u64v_scratch_bytes(P);
-    sort_tmp.reserve(tb);
-    // key = qidx << 32 | sequence id (all ones for a hit without a key): the bits between the sequence id and
-    // the query index are zero, so two stable sorts -- the sequence-id bits, then the query bits plus the one
-    // above them that only the all-ones keys have -- order the keys in 4 radix passes instead of 6
-    const unsigned sbits = std::max(1u, bits_for(v.n_seq)), qbits = std::max(1u, bits_for(n_queries));
-    launch_sort_u64v(sort_tmp.p, tb, keys.as<unsigned long long>(), skeys.as<unsigned long long>(), vals.as<unsigned long long>(),
-                     svals.as<unsigned long long>(), P, stream, sbits, 0);
-    launch_sort_u64v(sort_tmp.p, tb, skeys.as<unsigned long long>(), keys.as<unsigned long long>(), svals.as<unsigned long long>(),
-                     vals.as<unsigned long long>(), P, stream, std::min(64u, 32 + qbits + 1), 32);
-    keys.swap(skeys);
-    vals.swap(svals);
+    // The hits that carry a key in the stable order by (query, hit sequence).  By segments (kernels.hip, seg_group_kernel:
+    // a query's ranges run by run in frontier order, a counting sort by sequence inside the query) when the batch allows
+    // it; with the library's radix sort otherwise.
+    uint32_t seg_active = 0;
+    bool by_segments = seg_group && !want_flags && !multi && seg_group_fits(v.n_seq) && L.n_frontier > 0 && (uint64_t)P <= 16384ull * n_queries;
+    if (by_segments) {
+      const uint32_t n_fr = L.n_frontier;
+      seg_run.reserve(std::max<size_t>((size_t)n_fr * 8, 256));
+      seg_q.reserve(std::max<size_t>((size_t)n_queries * 16 + 256, 512));  // (four words a query, then `unsorted` and the largest query's hits)
+      uint32_t *run_start = seg_run.as<uint32_t>(), *run_end = run_start + n_fr;
+      uint32_t *qfirst = seg_q.as<uint32_t>(), *qlast = qfirst + n_queries, *qact = qlast + n_queries, *qdst = qact + n_queries;
+      uint32_t *unsorted = qdst + n_queries;
+      launch_seg_bounds(fr, n_fr, n_queries, L.pair_range.as<uint32_t>(), P, run_start, run_end, qfirst, qlast, unsorted, stream);
+      launch_seg_group(true, fr, qfirst, qlast, run_start, run_end, h, n_queries, v.n_seq, qact, qdst, nullptr, nullptr, stream);
+      seg_active = (uint32_t)scan(qact, qdst, n_queries);  // (synchronises)
+      uint32_t bad[2] = {0, 0};
+      IMPG_HIP(hipMemcpy(bad, unsorted, 8, hipMemcpyDeviceToHost));
+      if (bad[0] || bad[1]) by_segments = false;  // a frontier that is not sorted by query, or one huge query: the library sort below
+      else
+        launch_seg_group(false, fr, qfirst, qlast, run_start, run_end, h, n_queries, v.n_seq, qact, qdst, skeys.as<unsigned long long>(),
+                         svals.as<unsigned long long>(), stream);
+    }
+    if (!by_segments) {
+      IMPG_HIP(hipMemsetAsync(act_slots.p, 0, COUNT_BYTES, stream));
+      launch_update_keys(fr, L.pair_range.as<uint32_t>(), P, h, keys.as<unsigned long long>(), vals.as<unsigned long long>(),
+                         act_slots.as<unsigned long long>(), stream);
+      size_t tb = sort_u64v_scratch_bytes(P);
+      sort_tmp.reserve(tb);
+      // key = qidx << 32 | sequence id (all ones for a hit without a key): the bits between the sequence id and
+      // the query index are zero, so two stable sorts -- the sequence-id bits, then the query bits plus the one
+      // above them that only the all-ones keys have -- order the keys in 4 radix passes instead of 6
+      const unsigned sbits = std::max(1u, bits_for(v.n_seq)), qbits = std::max(1u, bits_for(n_queries));
+      launch_sort_u64v(sort_tmp.p, tb, keys.as<unsigned long long>(), skeys.as<unsigned long long>(), vals.as<unsigned long long>(),
+                       svals.as<unsigned long long>(), P, stream, sbits, 0);
+      launch_sort_u64v(sort_tmp.p, tb, skeys.as<unsigned long long>(), keys.as<unsigned long long>(), svals.as<unsigned long long>(),
+                       vals.as<unsigned long long>(), P, stream, std::min(64u, 32 + qbits + 1), 32);
+      keys.swap(skeys);
+      vals.swap(svals);
+    }
+    // (from here on P = the entries of the sorted arrays: all slots after the library sort, whose keyless hits sort last;
+    // only the hits that carry a key after the segment form)
+    const uint32_t P = by_segments ? seg_active : P_slots;
     // the groups: per-tile head counts + their scan + a fill pass; the per-hit head flags and group ids only exist for
     // the covered-hit filter, which reads them
-    const bool want_flags = filter_covered != 0;
     uint32_t n_groups;
     if (want_flags) {
       head.reserve((size_t)P * 4); gid.reserve((size_t)P * 4);
@@ -530,7 +558,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
                              vt->keys.as<unsigned long long>(), stream);
       else
         launch_group_fill(skeys.as<unsigned long long>(), P, gid.as<uint32_t>(), gstart.as<uint32_t>(), vt->keys.as<unsigned long long>(), stream);
-      const uint32_t n_active = (uint32_t)read_slots(act_slots);  // hits that carry a (query, sequence) key
+      const uint32_t n_active = by_segments ? seg_active : (uint32_t)read_slots(act_slots);  // hits that carry a (query, sequence) key
       glen.reserve((size_t)n_groups * 4); old_tab.reserve((size_t)n_groups * 4); old_idx.reserve((size_t)n_groups * 4);
       cap.reserve((size_t)n_groups * 4); pcap.reserve((size_t)n_groups * 4);
       VisitedTables tabs = tables_view();

@@ -2404,6 +2404,140 @@ __global__ __launch_bounds__(256) void group_fill_kernel(const unsigned long lon
     if (flags & (1u << k)) { gstart[g] = base + k; gkey[g] = key[k]; g += 1u; }
 }
 
+// ---------------------------------------------------------------------------
+// The update's hits grouped by (query, sequence) WITHOUT a global sort (round 4).  What the update needs is the stable
+// order by (qidx, hit sequence) of the hits that carry a key.  The slots of one frontier range are one run in every
+// layout an updated level can have; restricted to one query, slot order is frontier order x visit order; and the
+// frontier is sorted by query.  So "stable by query" is the query's ranges taken in frontier order, run by run, and what
+// is left is a stable counting sort by sequence id INSIDE a query -- a wave per query, the sequence counters in LDS,
+// ranks within a 64-hit chunk from ballots (slot order kept).  Per hit: 4 bytes read to count (seg_group_kernel<true>),
+// 4 + 20 read and 16 written to place (…<false>), against update_keys' 40 + the radix sort's four passes and two
+// histograms over 16-byte records (144).  Not for MultiImpg batches, the covered-hit filter, more than SEG_MAX_SEQ
+// sequences, or a frontier that is not sorted by query (checked on the device): those keep the library sort.
+// ---------------------------------------------------------------------------
+constexpr uint32_t SEG_MAX_SEQ = 2048, SEG_WAVES = 4;
+// (a query is one wave's work, hit after hit: beyond this many hits in one query -- a saturating closure's deep levels have
+// 10^5-10^6 -- the library sort's parallelism wins: config 5's update 0.66 s per 4 000 windows sorted, 2.65 s by segments)
+constexpr uint32_t SEG_BIG_QUERY = 32768;
+__global__ __launch_bounds__(256) void run_bounds_kernel(const uint32_t *__restrict__ pair_range, uint32_t n, uint32_t *__restrict__ run_start,
+                                                         uint32_t *__restrict__ run_end) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t r = pair_range[p];
+  if (p == 0 || pair_range[p - 1u] != r) run_start[r] = p;
+  if (p + 1u == n || pair_range[p + 1u] != r) run_end[r] = p + 1u;
+}
+__global__ __launch_bounds__(256) void query_bounds_kernel(const FrontierRec *__restrict__ fr, uint32_t n_fr, uint32_t n_queries, uint32_t *__restrict__ qfirst,
+                                                           uint32_t *__restrict__ qlast, uint32_t *__restrict__ unsorted) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_fr) return;
+  const uint32_t q = fr[i].qidx;
+  if (q >= n_queries) { *unsorted = 1u; return; }
+  if (i == 0 || fr[i - 1u].qidx != q) {
+    qfirst[q] = i;
+    if (i && fr[i - 1u].qidx > q) *unsorted = 1u;
+  }
+  if (i + 1u == n_fr || fr[i + 1u].qidx != q) qlast[q] = i + 1u;
+}
+// The slots of the ranges [f0, f1) of one query, 64 at a time in frontier order x slot order (one wave): f(qid, hc, active)
+// per chunk, the next chunk's loads already under way (a chunk is one or two memory round trips, and a query's ~20 runs
+// of ~40 slots were that many trips in a row).  WITH_HC: the hit's coordinates are loaded beside its sequence id.
+template <bool WITH_HC, class F>
+__device__ __forceinline__ void seg_for_chunks(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ run_start,
+                                               const uint32_t *__restrict__ run_end, const HitArrays &h, uint32_t f0, uint32_t f1, F f) {
+  const uint32_t lane = lane_id();
+  for (uint32_t base = f0; base < f1; base += 64u) {
+    const uint32_t i = base + lane;
+    const bool have = i < f1;
+    const uint32_t rs = have ? run_start[i] : 0u, re = have ? run_end[i] : 0u, tg = have ? fr[i].target_id : 0u;
+    const uint32_t m = min(64u, f1 - base);
+    uint32_t j = 0, c0 = 0, e = 0, t = 0;
+    auto seek = [&](uint32_t &jj, uint32_t &cc, uint32_t &ee, uint32_t &tt) {  // the first chunk at or after (jj, cc) that holds slots
+      while (jj < m && cc >= ee) {
+        jj += 1u;
+        if (jj < m) {
+          cc = (uint32_t)__builtin_amdgcn_readlane((int)rs, (int)jj);
+          ee = (uint32_t)__builtin_amdgcn_readlane((int)re, (int)jj);
+          tt = (uint32_t)__builtin_amdgcn_readlane((int)tg, (int)jj);
+        }
+      }
+    };
+    c0 = (uint32_t)__builtin_amdgcn_readlane((int)rs, 0);
+    e = (uint32_t)__builtin_amdgcn_readlane((int)re, 0);
+    t = (uint32_t)__builtin_amdgcn_readlane((int)tg, 0);
+    seek(j, c0, e, t);
+    uint32_t qid = HIT_NONE;
+    int4 hc = make_int4(0, 0, 0, 0);
+    if (j < m && c0 + lane < e) { qid = h.qid[c0 + lane]; if (WITH_HC) hc = h.c[c0 + lane]; }
+    while (j < m) {
+      uint32_t nj = j, nc = c0 + 64u, ne = e, nt = t;
+      seek(nj, nc, ne, nt);
+      uint32_t nqid = HIT_NONE;
+      int4 nhc = make_int4(0, 0, 0, 0);
+      if (nj < m && nc + lane < ne) { nqid = h.qid[nc + lane]; if (WITH_HC) nhc = h.c[nc + lane]; }
+      f(qid, hc, qid != HIT_NONE && qid != t);  // impg.rs:2507
+      j = nj; c0 = nc; e = ne; t = nt; qid = nqid; hc = nhc;
+    }
+  }
+}
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(64 * SEG_WAVES) void seg_group_kernel(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ qfirst,
+                                                                   const uint32_t *__restrict__ qlast, const uint32_t *__restrict__ run_start,
+                                                                   const uint32_t *__restrict__ run_end, HitArrays h, uint32_t n_queries, uint32_t nb,
+                                                                   uint32_t nbits, uint32_t *__restrict__ qact, const uint32_t *__restrict__ qdst,
+                                                                   unsigned long long *__restrict__ skeys, unsigned long long *__restrict__ svals) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t seg_bins[];  // SEG_WAVES x nb sequence counters
+  const uint32_t w = threadIdx.x >> 6, lane = lane_id();
+  const uint32_t q = blockIdx.x * SEG_WAVES + w;
+  if (q >= n_queries) return;  // (no barrier below: the waves of a block share nothing)
+  const uint32_t f0 = qfirst[q], f1 = qlast[q];
+  if (f0 >= f1) { if (COUNT_ONLY && lane == 0) qact[q] = 0u; return; }
+  if (COUNT_ONLY) {  // how many of the query's hits carry a key
+    uint32_t cnt = 0;
+    seg_for_chunks<false>(fr, run_start, run_end, h, f0, f1, [&](uint32_t, const int4 &, bool active) { cnt += active ? 1u : 0u; });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+    if (lane == 0) { qact[q] = cnt; if (cnt > SEG_BIG_QUERY) atomicMax(qact + 2u * (size_t)n_queries + 1u, cnt); }  // (the word behind `unsorted`)
+    return;
+  }
+  uint32_t *bins = seg_bins + w * nb;
+  for (uint32_t b = lane; b < nb; b += 64u) bins[b] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  // pass A: the query's hits per sequence
+  seg_for_chunks<false>(fr, run_start, run_end, h, f0, f1, [&](uint32_t qid, const int4 &, bool active) { if (active) atomicAdd(&bins[qid], 1u); });
+  __builtin_amdgcn_wave_barrier();
+  // the sequences' offsets inside the query's stretch of the output
+  uint32_t carry = 0;
+  for (uint32_t b = 0; b < nb; b += 64u) {
+    const uint32_t x = bins[b + lane];
+    const uint32_t inc = wave_incl_scan(x);
+    bins[b + lane] = carry + inc - x;
+    carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // pass B: a hit's place = its sequence's counter + its rank among the chunk's earlier hits of that sequence
+  const uint32_t dst0 = qdst[q];
+  const unsigned long long khi = (unsigned long long)q << 32;
+  seg_for_chunks<true>(fr, run_start, run_end, h, f0, f1, [&](uint32_t qid, const int4 &hc, bool active) {
+    const unsigned long long am = __ballot(active);
+    if (!am) return;
+    unsigned long long mask = am;  // the chunk's hits of this lane's sequence
+    for (uint32_t b = 0; b < nbits; b++) {
+      const bool bit = (qid >> b) & 1u;
+      const unsigned long long bal = __ballot(active && bit);
+      mask &= bit ? bal : ~bal;
+    }
+    if (active) {
+      const uint32_t pos = dst0 + bins[qid] + (uint32_t)__popcll(mask & lanemask_lt());
+      skeys[pos] = khi | qid;
+      svals[pos] = ((unsigned long long)(uint32_t)min(hc.x, hc.y) << 32) | (uint32_t)max(hc.x, hc.y);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (active && lane == 63u - (uint32_t)__clzll((long long)mask)) bins[qid] += (uint32_t)__popcll(mask);
+    __builtin_amdgcn_wave_barrier();
+  });
+}
+
 __device__ __forceinline__ uint32_t lower_bound_u64(const unsigned long long *a, uint32_t n, unsigned long long k) {
   uint32_t lo = 0, hi = n;
   while (lo < hi) {
@@ -3899,6 +4033,31 @@ void launch_sort_pairs(void *tmp, size_t tmp_bytes, const unsigned long long *ki
                        const uint32_t *vin, uint32_t *vout, uint32_t n, unsigned end_bit, hipStream_t s) {
   if (!n) return;
   IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s));
+}
+bool seg_group_fits(uint32_t n_seq) { return n_seq <= SEG_MAX_SEQ; }
+void launch_seg_bounds(const FrontierRec *fr, uint32_t n_fr, uint32_t n_queries, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *run_start,
+                       uint32_t *run_end, uint32_t *qfirst, uint32_t *qlast, uint32_t *unsorted, hipStream_t s) {
+  IMPG_HIP(hipMemsetAsync(run_start, 0, (size_t)n_fr * 4, s));
+  IMPG_HIP(hipMemsetAsync(run_end, 0, (size_t)n_fr * 4, s));
+  IMPG_HIP(hipMemsetAsync(qfirst, 0, (size_t)n_queries * 4, s));
+  IMPG_HIP(hipMemsetAsync(qlast, 0, (size_t)n_queries * 4, s));
+  IMPG_HIP(hipMemsetAsync(unsorted, 0, 8, s));  // (and the largest query's hit count behind it)
+  if (n_pairs) run_bounds_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(pair_range, n_pairs, run_start, run_end);
+  if (n_fr) query_bounds_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(fr, n_fr, n_queries, qfirst, qlast, unsorted);
+}
+void launch_seg_group(bool count_only, const FrontierRec *fr, const uint32_t *qfirst, const uint32_t *qlast, const uint32_t *run_start,
+                      const uint32_t *run_end, HitArrays h, uint32_t n_queries, uint32_t n_seq, uint32_t *qact, const uint32_t *qdst,
+                      unsigned long long *skeys, unsigned long long *svals, hipStream_t s) {
+  if (!n_queries) return;
+  const uint32_t nb = (std::max(n_seq, 1u) + 63u) & ~63u;
+  uint32_t nbits = 1;
+  while ((1u << nbits) < n_seq) nbits++;
+  const uint32_t grid = cdiv(n_queries, SEG_WAVES);
+  if (count_only)
+    seg_group_kernel<true><<<grid, 64 * SEG_WAVES, 0, s>>>(fr, qfirst, qlast, run_start, run_end, h, n_queries, nb, nbits, qact, qdst, skeys, svals);
+  else
+    seg_group_kernel<false><<<grid, 64 * SEG_WAVES, SEG_WAVES * nb * 4, s>>>(fr, qfirst, qlast, run_start, run_end, h, n_queries, nb, nbits, qact, qdst, skeys,
+                                                                           svals);
 }
 uint32_t group_tiles(uint32_t n) { return (n + GROUP_TILE - 1u) / GROUP_TILE; }
 void launch_group_count(const unsigned long long *skeys, uint32_t n, uint32_t *tile_heads, hipStream_t s) {

@@ -1425,6 +1425,36 @@ def test_walk_kernel_matches_oracle_and_batch_engine(tmp_path, seed):
         assert g.query_transitive_bfs(*ranges[0], max_depth=3).tolist() == c.query(*ranges[0], transitive=True, max_depth=3).tolist()
 
 
+@pytest.mark.parametrize("seed", [21, 22])
+def test_update_by_segments_matches_the_library_sort(tmp_path, seed):
+    """The visited update's hits grouped query by query (seg_group_kernel: runs in frontier order, a counting sort by
+    sequence inside a query -- the default) against the same hits ordered by the library's stable radix sort (option
+    segment_groups = 0), and both against the oracle: rows, counts, checksums, BFS and DFS, with masks and a subset
+    filter, many sequences, dense targets, ranges without hits."""
+    text, _ = random_paf(500 + seed, 700, n_seq=(9 if seed == 21 else 70), seq_len=30_000, max_ops=200, weird=True, self_aln=True)
+    g, c = both(tmp_path, text)
+    n_seq = g.num_seqs()
+    ranges = random_ranges(seed, 300, n_seq, 30_000, max_len=6000, min_len=1)
+    g.set_option("walk_kernel", 0)  # (everything on the batch engine, whose update this is)
+    cases = [dict(transitive=True, max_depth=3, min_transitive_len=20), dict(transitive=True, max_depth=0, min_transitive_len=150),
+             dict(transitive=True, max_depth=4, min_transitive_len=40, min_distance_between_ranges=30, min_output_length=60),
+             dict(transitive=True, dfs=True, max_depth=3, min_transitive_len=30)]
+    mask = random_mask(seed, n_seq, 30_000, present=0.7)
+    for kw in cases:
+        out = {}
+        for seg in (1, 0):
+            g.set_option("segment_groups", seg)
+            st, cnt, ck = g.query_batch_stats(ranges, impg_amd.make_params(**kw))
+            out[seg] = (st.projected, cnt.tolist(), ck.tolist())
+            if not kw.get("dfs") or seg == 1:
+                assert_same(g, c, ranges[:120], **kw)
+                assert_same(g, c, ranges[100:160], masked_regions=mask, **kw)
+        assert out[0] == out[1], kw
+    g.set_option("segment_groups", 1)
+    g.set_option("chunk_ranges", 37)  # (chunks: a query's index inside its chunk is what the keys carry)
+    assert_same(g, c, ranges, transitive=True, max_depth=3, min_transitive_len=20)
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_walk_grid_form_and_masks(tmp_path, seed):
     """The walk's grid form (a depth-limited BFS of <= 64 ranges: `walk_members` workgroups per query share the last level

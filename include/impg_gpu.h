@@ -211,6 +211,9 @@ int impg_gpu_index_approximate(const impg_gpu_index_t *);
  * "walk_kernel" (the per-query walk: 0 never, 1 -- the default -- DFS batches of any size and depth-limited BFS batches of
  * <= 64 ranges, 2 also BFS batches of <= 64 ranges without a depth limit) and "walk_members" (workgroups per query of
  * the walk's grid form, which shares a depth-limited BFS's last level out: 0 = as many as fit, at most 32; 1 = none),
+ * "segment_groups" (1, the default: the visited update orders a level's hits by (query, hit sequence) query by query --
+ * a query's ranges run by run in frontier order, a counting sort by sequence inside the query; 0: with the library's
+ * stable radix sort; results are identical either way),
  * "fuse_final_level" (1, the default: the final level of such a run -- no update follows, no row is kept --
  * takes its (range, entry) pairs straight from the lookup's per-range windows inside the projection kernel; the emit
  * pass and its pair lists are skipped; counts and checksums are identical either way).

@@ -497,24 +497,26 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
     // The hits that carry a key in the stable order by (query, hit sequence).  By segments (kernels.hip, seg_group_kernel:
     // a query's ranges run by run in frontier order, a counting sort by sequence inside the query) when the batch allows
     // it; with the library's radix sort otherwise.
-    uint32_t seg_active = 0;
+    uint32_t seg_active = 0, seg_groups = 0;
+    uint32_t *sg_run_start = nullptr, *sg_run_end = nullptr, *sg_q = nullptr;
     bool by_segments = seg_group && !want_flags && !multi && seg_group_fits(v.n_seq) && L.n_frontier > 0 && (uint64_t)P <= 16384ull * n_queries;
     if (by_segments) {
       const uint32_t n_fr = L.n_frontier;
       seg_run.reserve(std::max<size_t>((size_t)n_fr * 8, 256));
-      seg_q.reserve(std::max<size_t>((size_t)n_queries * 16 + 256, 512));  // (four words a query, then `unsorted` and the largest query's hits)
-      uint32_t *run_start = seg_run.as<uint32_t>(), *run_end = run_start + n_fr;
-      uint32_t *qfirst = seg_q.as<uint32_t>(), *qlast = qfirst + n_queries, *qact = qlast + n_queries, *qdst = qact + n_queries;
-      uint32_t *unsorted = qdst + n_queries;
-      launch_seg_bounds(fr, n_fr, n_queries, L.pair_range.as<uint32_t>(), P, run_start, run_end, qfirst, qlast, unsorted, stream);
-      launch_seg_group(true, fr, qfirst, qlast, run_start, run_end, h, n_queries, v.n_seq, qact, qdst, nullptr, nullptr, stream);
+      // six words a query -- first / last frontier range, hits with a key, their offset, groups, their offset -- then
+      // `unsorted` and the largest query's hits
+      seg_q.reserve(std::max<size_t>((size_t)n_queries * 24 + 256, 512));
+      sg_run_start = seg_run.as<uint32_t>(); sg_run_end = sg_run_start + n_fr;
+      sg_q = seg_q.as<uint32_t>();
+      uint32_t *qfirst = sg_q, *qlast = qfirst + n_queries, *qact = qlast + n_queries, *qdst = qact + n_queries, *qgrp = qdst + n_queries,
+               *gdst = qgrp + n_queries, *unsorted = gdst + n_queries;
+      launch_seg_bounds(fr, n_fr, n_queries, L.pair_range.as<uint32_t>(), P, sg_run_start, sg_run_end, qfirst, qlast, unsorted, stream);
+      launch_seg_group(true, fr, qfirst, qlast, sg_run_start, sg_run_end, h, n_queries, v.n_seq, qact, qdst, qgrp, gdst, nullptr, nullptr, nullptr, stream);
       seg_active = (uint32_t)scan(qact, qdst, n_queries);  // (synchronises)
       uint32_t bad[2] = {0, 0};
       IMPG_HIP(hipMemcpy(bad, unsorted, 8, hipMemcpyDeviceToHost));
       if (bad[0] || bad[1]) by_segments = false;  // a frontier that is not sorted by query, or one huge query: the library sort below
-      else
-        launch_seg_group(false, fr, qfirst, qlast, run_start, run_end, h, n_queries, v.n_seq, qact, qdst, skeys.as<unsigned long long>(),
-                         svals.as<unsigned long long>(), stream);
+      else seg_groups = (uint32_t)scan(qgrp, gdst, n_queries);  // (the place pass runs below, once the groups' arrays exist)
     }
     if (!by_segments) {
       IMPG_HIP(hipMemsetAsync(act_slots.p, 0, COUNT_BYTES, stream));
@@ -539,7 +541,8 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
     // the groups: per-tile head counts + their scan + a fill pass; the per-hit head flags and group ids only exist for
     // the covered-hit filter, which reads them
     uint32_t n_groups;
-    if (want_flags) {
+    if (by_segments) n_groups = seg_groups;
+    else if (want_flags) {
       head.reserve((size_t)P * 4); gid.reserve((size_t)P * 4);
       launch_group_heads(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), stream);
       n_groups = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), P);
@@ -553,7 +556,12 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       auto vt = std::make_unique<VisitedStore>(&table_pool);
       vt->keys.reserve((size_t)n_groups * 8);
       gstart.reserve((size_t)n_groups * 4);
-      if (want_flags)
+      if (by_segments) {  // the hits to their places, and every query's groups (start, key) straight from its sequence counters
+        uint32_t *qfirst = sg_q, *qlast = qfirst + n_queries, *qact = qlast + n_queries, *qdst = qact + n_queries, *qgrp = qdst + n_queries,
+                 *gdst = qgrp + n_queries;
+        launch_seg_group(false, fr, qfirst, qlast, sg_run_start, sg_run_end, h, n_queries, v.n_seq, qact, qdst, qgrp, gdst, gstart.as<uint32_t>(),
+                         vt->keys.as<unsigned long long>(), svals.as<unsigned long long>(), stream);
+      } else if (want_flags)
         launch_group_scatter(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), gid.as<uint32_t>(), gstart.as<uint32_t>(),
                              vt->keys.as<unsigned long long>(), stream);
       else

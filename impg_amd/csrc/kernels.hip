@@ -2485,39 +2485,52 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void seg_group_kernel(const Frontie
                                                                    const uint32_t *__restrict__ qlast, const uint32_t *__restrict__ run_start,
                                                                    const uint32_t *__restrict__ run_end, HitArrays h, uint32_t n_queries, uint32_t nb,
                                                                    uint32_t nbits, uint32_t *__restrict__ qact, const uint32_t *__restrict__ qdst,
-                                                                   unsigned long long *__restrict__ skeys, unsigned long long *__restrict__ svals) {
+                                                                   uint32_t *__restrict__ qgrp, const uint32_t *__restrict__ gdst,
+                                                                   uint32_t *__restrict__ gstart, unsigned long long *__restrict__ gkey,
+                                                                   unsigned long long *__restrict__ svals) {
   extern __shared__ __attribute__((aligned(16))) uint32_t seg_bins[];  // SEG_WAVES x nb sequence counters
   const uint32_t w = threadIdx.x >> 6, lane = lane_id();
   const uint32_t q = blockIdx.x * SEG_WAVES + w;
   if (q >= n_queries) return;  // (no barrier below: the waves of a block share nothing)
   const uint32_t f0 = qfirst[q], f1 = qlast[q];
-  if (f0 >= f1) { if (COUNT_ONLY && lane == 0) qact[q] = 0u; return; }
-  if (COUNT_ONLY) {  // how many of the query's hits carry a key
-    uint32_t cnt = 0;
-    seg_for_chunks<false>(fr, run_start, run_end, h, f0, f1, [&](uint32_t, const int4 &, bool active) { cnt += active ? 1u : 0u; });
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
-    if (lane == 0) { qact[q] = cnt; if (cnt > SEG_BIG_QUERY) atomicMax(qact + 2u * (size_t)n_queries + 1u, cnt); }  // (the word behind `unsorted`)
-    return;
-  }
+  if (f0 >= f1) { if (COUNT_ONLY && lane == 0) { qact[q] = 0u; qgrp[q] = 0u; } return; }
   uint32_t *bins = seg_bins + w * nb;
   for (uint32_t b = lane; b < nb; b += 64u) bins[b] = 0u;
   __builtin_amdgcn_wave_barrier();
   // pass A: the query's hits per sequence
   seg_for_chunks<false>(fr, run_start, run_end, h, f0, f1, [&](uint32_t qid, const int4 &, bool active) { if (active) atomicAdd(&bins[qid], 1u); });
   __builtin_amdgcn_wave_barrier();
-  // the sequences' offsets inside the query's stretch of the output
-  uint32_t carry = 0;
+  if (COUNT_ONLY) {  // how many of the query's hits carry a key, and how many sequences they name (its groups)
+    uint32_t cnt = 0, grp = 0;
+    for (uint32_t b = lane; b < nb; b += 64u) { const uint32_t x = bins[b]; cnt += x; grp += x ? 1u : 0u; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += (uint32_t)__shfl_xor((int)cnt, o); grp += (uint32_t)__shfl_xor((int)grp, o); }
+    if (lane == 0) {
+      qact[q] = cnt; qgrp[q] = grp;
+      if (cnt > SEG_BIG_QUERY) atomicMax(qact + 4u * (size_t)n_queries + 1u, cnt);  // (the word behind `unsorted`: Engine::update lays the six per-query arrays out)
+    }
+    return;
+  }
+  // the sequences' offsets inside the query's stretch of the output; a sequence with hits is a group: its start, its key
+  const uint32_t dst0 = qdst[q];
+  const unsigned long long khi = (unsigned long long)q << 32;
+  uint32_t carry = 0, g = gdst[q];
   for (uint32_t b = 0; b < nb; b += 64u) {
     const uint32_t x = bins[b + lane];
     const uint32_t inc = wave_incl_scan(x);
-    bins[b + lane] = carry + inc - x;
+    const uint32_t off = carry + inc - x;
+    bins[b + lane] = off;
     carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    const unsigned long long gm = __ballot(x != 0u);
+    if (x) {
+      const uint32_t gi = g + (uint32_t)__popcll(gm & lanemask_lt());
+      gstart[gi] = dst0 + off;
+      gkey[gi] = khi | (b + lane);
+    }
+    g += (uint32_t)__popcll(gm);
   }
   __builtin_amdgcn_wave_barrier();
   // pass B: a hit's place = its sequence's counter + its rank among the chunk's earlier hits of that sequence
-  const uint32_t dst0 = qdst[q];
-  const unsigned long long khi = (unsigned long long)q << 32;
   seg_for_chunks<true>(fr, run_start, run_end, h, f0, f1, [&](uint32_t qid, const int4 &hc, bool active) {
     const unsigned long long am = __ballot(active);
     if (!am) return;
@@ -2529,7 +2542,6 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void seg_group_kernel(const Frontie
     }
     if (active) {
       const uint32_t pos = dst0 + bins[qid] + (uint32_t)__popcll(mask & lanemask_lt());
-      skeys[pos] = khi | qid;
       svals[pos] = ((unsigned long long)(uint32_t)min(hc.x, hc.y) << 32) | (uint32_t)max(hc.x, hc.y);
     }
     __builtin_amdgcn_wave_barrier();
@@ -4046,18 +4058,19 @@ void launch_seg_bounds(const FrontierRec *fr, uint32_t n_fr, uint32_t n_queries,
   if (n_fr) query_bounds_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(fr, n_fr, n_queries, qfirst, qlast, unsorted);
 }
 void launch_seg_group(bool count_only, const FrontierRec *fr, const uint32_t *qfirst, const uint32_t *qlast, const uint32_t *run_start,
-                      const uint32_t *run_end, HitArrays h, uint32_t n_queries, uint32_t n_seq, uint32_t *qact, const uint32_t *qdst,
-                      unsigned long long *skeys, unsigned long long *svals, hipStream_t s) {
+                      const uint32_t *run_end, HitArrays h, uint32_t n_queries, uint32_t n_seq, uint32_t *qact, const uint32_t *qdst, uint32_t *qgrp,
+                      const uint32_t *gdst, uint32_t *gstart, unsigned long long *gkey, unsigned long long *svals, hipStream_t s) {
   if (!n_queries) return;
   const uint32_t nb = (std::max(n_seq, 1u) + 63u) & ~63u;
   uint32_t nbits = 1;
   while ((1u << nbits) < n_seq) nbits++;
   const uint32_t grid = cdiv(n_queries, SEG_WAVES);
   if (count_only)
-    seg_group_kernel<true><<<grid, 64 * SEG_WAVES, 0, s>>>(fr, qfirst, qlast, run_start, run_end, h, n_queries, nb, nbits, qact, qdst, skeys, svals);
+    seg_group_kernel<true><<<grid, 64 * SEG_WAVES, SEG_WAVES * nb * 4, s>>>(fr, qfirst, qlast, run_start, run_end, h, n_queries, nb, nbits, qact, qdst, qgrp,
+                                                                          gdst, gstart, gkey, svals);
   else
-    seg_group_kernel<false><<<grid, 64 * SEG_WAVES, SEG_WAVES * nb * 4, s>>>(fr, qfirst, qlast, run_start, run_end, h, n_queries, nb, nbits, qact, qdst, skeys,
-                                                                           svals);
+    seg_group_kernel<false><<<grid, 64 * SEG_WAVES, SEG_WAVES * nb * 4, s>>>(fr, qfirst, qlast, run_start, run_end, h, n_queries, nb, nbits, qact, qdst, qgrp,
+                                                                           gdst, gstart, gkey, svals);
 }
 uint32_t group_tiles(uint32_t n) { return (n + GROUP_TILE - 1u) / GROUP_TILE; }
 void launch_group_count(const unsigned long long *skeys, uint32_t n, uint32_t *tile_heads, hipStream_t s) {

@@ -498,7 +498,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
     // a query's ranges run by run in frontier order, a counting sort by sequence inside the query) when the batch allows
     // it; with the library's radix sort otherwise.
     uint32_t seg_active = 0, seg_groups = 0;
-    uint32_t *sg_run_start = nullptr, *sg_run_end = nullptr, *sg_q = nullptr;
+    uint32_t *sg_run_start = nullptr, *sg_run_end = nullptr, *sg_q = nullptr, *sg_bins = nullptr;
     bool by_segments = seg_group && !want_flags && !multi && seg_group_fits(v.n_seq) && L.n_frontier > 0 && (uint64_t)P <= 16384ull * n_queries;
     if (by_segments) {
       const uint32_t n_fr = L.n_frontier;
@@ -511,7 +511,10 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       uint32_t *qfirst = sg_q, *qlast = qfirst + n_queries, *qact = qlast + n_queries, *qdst = qact + n_queries, *qgrp = qdst + n_queries,
                *gdst = qgrp + n_queries, *unsorted = gdst + n_queries;
       launch_seg_bounds(fr, n_fr, n_queries, L.pair_range.as<uint32_t>(), P, sg_run_start, sg_run_end, qfirst, qlast, unsorted, stream);
-      launch_seg_group(true, fr, qfirst, qlast, sg_run_start, sg_run_end, h, n_queries, v.n_seq, qact, qdst, qgrp, gdst, nullptr, nullptr, nullptr, stream);
+      const size_t bb = seg_group_bins_bytes(n_queries, v.n_seq);
+      if (bb <= (512ull << 20)) { seg_bins.reserve(std::max<size_t>(bb, 256)); sg_bins = seg_bins.as<uint32_t>(); }  // (kept for the place pass)
+      launch_seg_group(true, fr, qfirst, qlast, sg_run_start, sg_run_end, h, n_queries, v.n_seq, qact, qdst, qgrp, gdst, nullptr, nullptr, nullptr, sg_bins,
+                       stream);
       seg_active = (uint32_t)scan(qact, qdst, n_queries);  // (synchronises)
       uint32_t bad[2] = {0, 0};
       IMPG_HIP(hipMemcpy(bad, unsorted, 8, hipMemcpyDeviceToHost));
@@ -560,7 +563,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
         uint32_t *qfirst = sg_q, *qlast = qfirst + n_queries, *qact = qlast + n_queries, *qdst = qact + n_queries, *qgrp = qdst + n_queries,
                  *gdst = qgrp + n_queries;
         launch_seg_group(false, fr, qfirst, qlast, sg_run_start, sg_run_end, h, n_queries, v.n_seq, qact, qdst, qgrp, gdst, gstart.as<uint32_t>(),
-                         vt->keys.as<unsigned long long>(), svals.as<unsigned long long>(), stream);
+                         vt->keys.as<unsigned long long>(), svals.as<unsigned long long>(), sg_bins, stream);
       } else if (want_flags)
         launch_group_scatter(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), gid.as<uint32_t>(), gstart.as<uint32_t>(),
                              vt->keys.as<unsigned long long>(), stream);

@@ -2487,7 +2487,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void seg_group_kernel(const Frontie
                                                                    uint32_t nbits, uint32_t *__restrict__ qact, const uint32_t *__restrict__ qdst,
                                                                    uint32_t *__restrict__ qgrp, const uint32_t *__restrict__ gdst,
                                                                    uint32_t *__restrict__ gstart, unsigned long long *__restrict__ gkey,
-                                                                   unsigned long long *__restrict__ svals) {
+                                                                   unsigned long long *__restrict__ svals, uint32_t *__restrict__ qbins) {
   extern __shared__ __attribute__((aligned(16))) uint32_t seg_bins[];  // SEG_WAVES x nb sequence counters
   const uint32_t w = threadIdx.x >> 6, lane = lane_id();
   const uint32_t q = blockIdx.x * SEG_WAVES + w;
@@ -2495,14 +2495,23 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void seg_group_kernel(const Frontie
   const uint32_t f0 = qfirst[q], f1 = qlast[q];
   if (f0 >= f1) { if (COUNT_ONLY && lane == 0) { qact[q] = 0u; qgrp[q] = 0u; } return; }
   uint32_t *bins = seg_bins + w * nb;
-  for (uint32_t b = lane; b < nb; b += 64u) bins[b] = 0u;
-  __builtin_amdgcn_wave_barrier();
-  // pass A: the query's hits per sequence
-  seg_for_chunks<false>(fr, run_start, run_end, h, f0, f1, [&](uint32_t qid, const int4 &, bool active) { if (active) atomicAdd(&bins[qid], 1u); });
+  // pass A: the query's hits per sequence (the place pass reads the count pass's counters back when they were kept: nb
+  // words a query, instead of walking the query's scattered runs once more)
+  if (COUNT_ONLY || !qbins) {
+    for (uint32_t b = lane; b < nb; b += 64u) bins[b] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    seg_for_chunks<false>(fr, run_start, run_end, h, f0, f1, [&](uint32_t qid, const int4 &, bool active) { if (active) atomicAdd(&bins[qid], 1u); });
+  } else {
+    for (uint32_t b = lane; b < nb; b += 64u) bins[b] = qbins[(size_t)q * nb + b];
+  }
   __builtin_amdgcn_wave_barrier();
   if (COUNT_ONLY) {  // how many of the query's hits carry a key, and how many sequences they name (its groups)
     uint32_t cnt = 0, grp = 0;
-    for (uint32_t b = lane; b < nb; b += 64u) { const uint32_t x = bins[b]; cnt += x; grp += x ? 1u : 0u; }
+    for (uint32_t b = lane; b < nb; b += 64u) {
+      const uint32_t x = bins[b];
+      cnt += x; grp += x ? 1u : 0u;
+      if (qbins) qbins[(size_t)q * nb + b] = x;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { cnt += (uint32_t)__shfl_xor((int)cnt, o); grp += (uint32_t)__shfl_xor((int)grp, o); }
     if (lane == 0) {
@@ -4047,6 +4056,7 @@ void launch_sort_pairs(void *tmp, size_t tmp_bytes, const unsigned long long *ki
   IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s));
 }
 bool seg_group_fits(uint32_t n_seq) { return n_seq <= SEG_MAX_SEQ; }
+size_t seg_group_bins_bytes(uint32_t n_queries, uint32_t n_seq) { return (size_t)n_queries * ((std::max(n_seq, 1u) + 63u) & ~63u) * 4; }
 void launch_seg_bounds(const FrontierRec *fr, uint32_t n_fr, uint32_t n_queries, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *run_start,
                        uint32_t *run_end, uint32_t *qfirst, uint32_t *qlast, uint32_t *unsorted, hipStream_t s) {
   IMPG_HIP(hipMemsetAsync(run_start, 0, (size_t)n_fr * 4, s));
@@ -4059,7 +4069,7 @@ void launch_seg_bounds(const FrontierRec *fr, uint32_t n_fr, uint32_t n_queries,
 }
 void launch_seg_group(bool count_only, const FrontierRec *fr, const uint32_t *qfirst, const uint32_t *qlast, const uint32_t *run_start,
                       const uint32_t *run_end, HitArrays h, uint32_t n_queries, uint32_t n_seq, uint32_t *qact, const uint32_t *qdst, uint32_t *qgrp,
-                      const uint32_t *gdst, uint32_t *gstart, unsigned long long *gkey, unsigned long long *svals, hipStream_t s) {
+                      const uint32_t *gdst, uint32_t *gstart, unsigned long long *gkey, unsigned long long *svals, uint32_t *qbins, hipStream_t s) {
   if (!n_queries) return;
   const uint32_t nb = (std::max(n_seq, 1u) + 63u) & ~63u;
   uint32_t nbits = 1;
@@ -4067,10 +4077,10 @@ void launch_seg_group(bool count_only, const FrontierRec *fr, const uint32_t *qf
   const uint32_t grid = cdiv(n_queries, SEG_WAVES);
   if (count_only)
     seg_group_kernel<true><<<grid, 64 * SEG_WAVES, SEG_WAVES * nb * 4, s>>>(fr, qfirst, qlast, run_start, run_end, h, n_queries, nb, nbits, qact, qdst, qgrp,
-                                                                          gdst, gstart, gkey, svals);
+                                                                          gdst, gstart, gkey, svals, qbins);
   else
     seg_group_kernel<false><<<grid, 64 * SEG_WAVES, SEG_WAVES * nb * 4, s>>>(fr, qfirst, qlast, run_start, run_end, h, n_queries, nb, nbits, qact, qdst, qgrp,
-                                                                           gdst, gstart, gkey, svals);
+                                                                           gdst, gstart, gkey, svals, qbins);
 }
 uint32_t group_tiles(uint32_t n) { return (n + GROUP_TILE - 1u) / GROUP_TILE; }
 void launch_group_count(const unsigned long long *skeys, uint32_t n, uint32_t *tile_heads, hipStream_t s) {

@@ -220,7 +220,8 @@ void launch_seg_bounds(const FrontierRec *fr, uint32_t n_fr, uint32_t n_queries,
                        uint32_t *run_end, uint32_t *qfirst, uint32_t *qlast, uint32_t *unsorted, hipStream_t s);
 void launch_seg_group(bool count_only, const FrontierRec *fr, const uint32_t *qfirst, const uint32_t *qlast, const uint32_t *run_start,
                       const uint32_t *run_end, HitArrays h, uint32_t n_queries, uint32_t n_seq, uint32_t *qact, const uint32_t *qdst, uint32_t *qgrp,
-                      const uint32_t *gdst, uint32_t *gstart, unsigned long long *gkey, unsigned long long *svals, hipStream_t s);
+                      const uint32_t *gdst, uint32_t *gstart, unsigned long long *gkey, unsigned long long *svals, uint32_t *qbins, hipStream_t s);
+size_t seg_group_bins_bytes(uint32_t n_queries, uint32_t n_seq);  // qbins (nullable): the count pass's per-query sequence counters, kept for the place pass
 
 // ---- the per-query walk (walk_device.inc): one workgroup takes a query through all its levels / pops ----------------
 struct WalkArgs {

@@ -492,8 +492,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
   if (P) {
     const uint32_t P_slots = P;
     const bool want_flags = filter_covered != 0;
-    keys.reserve((size_t)P * 8); skeys.reserve((size_t)P * 8);
-    vals.reserve((size_t)P * 8); svals.reserve((size_t)P * 8);
+    svals.reserve((size_t)P * 8);
     // The hits that carry a key in the stable order by (query, hit sequence).  By segments (kernels.hip, seg_group_kernel:
     // a query's ranges run by run in frontier order, a counting sort by sequence inside the query) when the batch allows
     // it; with the library's radix sort otherwise.
@@ -522,6 +521,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       else seg_groups = (uint32_t)scan(qgrp, gdst, n_queries);  // (the place pass runs below, once the groups' arrays exist)
     }
     if (!by_segments) {
+      keys.reserve((size_t)P * 8); skeys.reserve((size_t)P * 8); vals.reserve((size_t)P * 8);
       IMPG_HIP(hipMemsetAsync(act_slots.p, 0, COUNT_BYTES, stream));
       launch_update_keys(fr, L.pair_range.as<uint32_t>(), P, h, keys.as<unsigned long long>(), vals.as<unsigned long long>(),
                          act_slots.as<unsigned long long>(), stream);

@@ -21,9 +21,12 @@ timeout 400 python bench.py > $F/bench_full.json 2> $F/bench_full.err
 timeout 300 python bench.py --force-sharded --steps 5 --warmup 2 --cpu-sample 0 --no-extras > $F/bench_sharded_1rank.json 2> $F/bench_sharded_1rank.err
 timeout 400 python bench.py --workload config4 --cpu-sample 0 --no-extras > $F/bench_config4.json 2> $F/bench_config4.err
 timeout 300 python bench.py --workload config5 --ranges 20000 --steps 2 --warmup 1 --cpu-sample 0 --no-extras > $F/bench_config5_20000.json 2> $F/bench_config5_20000.err
+if [ -n "${CONFIG5_FULL:-}" ]; then  # BASELINE config 5 at its size: 10^6 windows, ~5 min
+  timeout 900 python bench.py --workload config5 --ranges 1000000 --steps 1 --warmup 0 --cpu-sample 0 --no-extras > $F/bench_config5_1e6.json 2> $F/bench_config5_1e6.err
+fi
 (timeout 1200 python -m pytest tests -m gpu -x -q --durations=8 2>&1 | tail -20) > $F/gputest.log
 tail -4 $F/gputest.log
-for f in bench_full bench_sharded_1rank bench_config4 bench_config5_20000; do python3 -c "
+for f in bench_full bench_sharded_1rank bench_config4 bench_config5_20000 bench_config5_1e6; do python3 -c "
 import json,sys
 try:
     d=json.loads(open('$F/$f.json').read().strip().splitlines()[-1]); print('$f', '%.4g' % d['value'], '%.2f ms' % d['ms_per_step'], d.get('stage_ms_per_step_rank0'), (d.get('roofline') or {}).get('measured_traffic_frac'), (d.get('roofline') or {}).get('valu_issue_frac'), d.get('parity_vs_single'))

@@ -2,6 +2,9 @@
 // Layouts here are the HBM data layout described in DESIGN.md section 4.
 #pragma once
 #include <atomic>
+#include <chrono>
+#include <exception>
+#include <vector>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -22,10 +25,35 @@ namespace impg {
 
 // ---- errors ---------------------------------------------------------------
 void set_error(const std::string &msg);
+// (when: the moment the error was raised.  A failure in one lane or rank of a sharded batch makes its peers fail too -- with
+// "a peer rank failed", or with whatever the transport says when a partner has left a collective -- and the caller is told
+// the FIRST one, the cause, not whichever thread's exception happens to be looked at first.)
+inline uint64_t error_clock() {
+  return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 struct Error {
   int code;
   std::string msg;
+  uint64_t when = error_clock();
 };
+// of several threads' exceptions: the earliest Error that is not a transport echo, else the earliest (anything that is
+// not an Error -- bad_alloc ... -- comes first)
+inline std::exception_ptr first_cause(const std::vector<std::exception_ptr> &errs) {
+  std::exception_ptr best;
+  uint64_t best_when = ~0ull;
+  bool best_echo = true;
+  for (const auto &e : errs) {
+    if (!e) continue;
+    try { std::rethrow_exception(e); }
+    catch (const Error &er) {
+      const bool echo = er.msg == "a peer rank failed" || er.msg.rfind("alltoallv: block sizes disagree", 0) == 0 ||
+                        er.msg.rfind("the RCCL communicator was aborted", 0) == 0 || er.msg.rfind("host transport:", 0) == 0;
+      if (!best || (best_echo && !echo) || (best_echo == echo && er.when < best_when)) { best = e; best_when = er.when; best_echo = echo; }
+    }
+    catch (...) { return e; }
+  }
+  return best;
+}
 #define IMPG_HIP(expr)                                                                      \
   do {                                                                                      \
     hipError_t _e = (expr);                                                                 \

@@ -612,8 +612,7 @@ template <class P, class F> void run_lanes(impg_gpu_index &ix, size_t n, P prep,
     for (size_t l = 0; l < n_lanes; l++) th.emplace_back(lane_main, l);
     for (auto &t : th) t.join();
   }
-  for (auto &e : errs)
-    if (e) std::rethrow_exception(e);
+  if (auto e = first_cause(errs)) std::rethrow_exception(e);  // (the lane that failed first, not the lowest-numbered one)
 }
 
 void add_stats(impg_gpu_stats_t &tot, const impg_gpu_stats_t &st) {
@@ -768,15 +767,8 @@ template <class F> void on_every_rank(Cluster &C, F f) {
       }
     });
   for (auto &t : th) t.join();
-  // report the first real failure, not the "a peer rank failed" echoes it caused
-  std::exception_ptr first;
-  for (auto &e : errs) {
-    if (!e) continue;
-    try { std::rethrow_exception(e); }
-    catch (const Error &er) { if (er.msg != "a peer rank failed") { first = e; break; } if (!first) first = e; }
-    catch (...) { first = e; break; }
-  }
-  if (first) std::rethrow_exception(first);
+  // report the failure that came first, not the echoes it caused in the other ranks
+  if (auto first = first_cause(errs)) std::rethrow_exception(first);
 }
 
 }  // namespace

@@ -130,14 +130,21 @@ bool Engine::walk_applicable(const impg_gpu_index &ix, uint32_t n, const impg_gp
   // the slab -- loses to the batch engine's wave-per-group kernels as soon as a second level is updated: measured on
   // the headline index with 190 ranges per sequence masked, `-m 2` 0.37 vs 0.70 ms, `-m 3` 1.28 vs 0.98 ms per call)
   if (masked && p.max_depth >= 3 && mask_ranges_total > 16ull * std::max<uint64_t>(1, mask_lists)) return false;
-  return walk_members != 1 && p.max_depth >= 2;
+  // (the grid form, or nothing: a batch too big for two workgroups a query -- more than 32 ranges with four engines a handle --
+  // costs the one-workgroup walk 2.6 ms where the batch engine takes 2.1)
+  return p.max_depth >= 2 && walk_group_size(ix, n, p) >= 2;
 }
 uint32_t Engine::walk_group_size(const impg_gpu_index &ix, uint32_t n, const impg_gpu_params_t &p) const {
   if (p.dfs || p.max_depth < 2 || n > SMALL_RANGES || walk_members == 1) return 1;
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix.device);
-  // every workgroup of the launch must be resident (the members wait for each other): one 1024-thread workgroup per CU
-  const uint32_t fit = std::max(1u, (uint32_t)cus / n);
+  // every workgroup of the launch must be resident (the members wait for each other): one 1024-thread workgroup per CU --
+  // and up to max_engines callers of one handle launch side by side on their own streams (rayon workers calling the trait:
+  // multi_impg.rs:518-530, partition.rs), whose workgroups the dispatcher may interleave: each launch takes at most its
+  // share of the CUs, so that all of them fit together.  (A launch that still cannot become resident -- another process
+  // on the device -- gives up after the spin limit and the batch engine answers.)
+  const uint32_t share = std::max(1u, (uint32_t)cus / (uint32_t)std::max(1, ix.max_engines));
+  const uint32_t fit = std::max(1u, share / n);
   return std::min({walk_members ? walk_members : 32u, fit, WALK_MAX_MEMBERS});
 }
 // the walk's slab shape: a BFS processes whole levels (16 waves per query), a DFS step is one popped range (one wave)

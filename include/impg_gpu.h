@@ -209,7 +209,7 @@ int impg_gpu_index_approximate(const impg_gpu_index_t *);
  * that order too; 0: always the reference's slot order; counts and checksums are
  * identical either way),
  * "walk_kernel" (the per-query walk: 0 never, 1 -- the default -- DFS batches of any size and depth-limited BFS batches of
- * <= 64 ranges, 2 also BFS batches of <= 64 ranges without a depth limit) and "walk_members" (workgroups per query of
+ * <= 32 ranges, 2 also every BFS batch of <= 64 ranges) and "walk_members" (workgroups per query of
  * the walk's grid form, which shares a depth-limited BFS's last level out: 0 = as many as fit, at most 32; 1 = none),
  * "segment_groups" (1, the default: the visited update orders a level's hits by (query, hit sequence) query by query --
  * a query's ranges run by run in frontier order, a counting sort by sequence inside the query; 0: with the library's

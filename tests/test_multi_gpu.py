@@ -241,6 +241,10 @@ def test_concurrent_calls_on_one_handle(tmp_path):
                 res = g.query_batch(rl[lo:lo + 40], impg_amd.make_params(**kws[k]))
                 for i in range(40):
                     assert res[i].tolist() == want[k][lo + i], (tid, rep, k, i)
+                # the per-call shape: depth-limited BFS calls run in the walk's grid form, whose workgroups wait for each
+                # other inside one launch -- several callers' launches must fit the device together
+                for j in range(lo, lo + 6):
+                    assert g.query_transitive_bfs(*rl[j], max_depth=3, min_transitive_len=20).tolist() == want[1][j], (tid, rep, j)
         except Exception as e:  # noqa: BLE001
             errs.append(repr(e))
 
@@ -250,6 +254,7 @@ def test_concurrent_calls_on_one_handle(tmp_path):
     for t in th:
         t.join()
     assert not errs, errs[:3]
+    assert g.counter("walk_launches") > 0 and g.counter("walk_fallbacks") == 0  # (no launch gave up waiting for its members)
 
 
 def test_mask_and_filter_follow_the_lease(tmp_path):

@@ -22,6 +22,10 @@ if ROOT not in sys.path:
 
 ALG_BYTES_PER_PROJECTION = 856  # 32 B entry + 4 B x 200 ops + 24 B result
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+# Projections of one headline step (synth PAF seed 42, 1 000 000 records; BED seed 7, 100 000 ranges; -x -m 3, coitrees
+# visit order).  Pinned by tests/test_gpu_fullsize.py::test_headline_timed_form, which runs the timed form beside the
+# per-range counts (themselves checked against the oracle on a sample) -- the timed region asserts this very number.
+HEADLINE_PROJECTED = 2_125_313_869
 
 
 T_START = time.time()
@@ -70,6 +74,7 @@ def main():
                     help="--min-result-identity of the reference (impg.rs:1283-1287); not part of the headline configuration")
     ap.add_argument("--no-extras", action="store_true", help="skip the full-results measurement (profiling runs)")
     args = ap.parse_args()
+    args.engine_option_changes_results = False  # (no engine option changes a result row: they are layout / schedule knobs)
 
     # `--gpus N` without a launcher: bring the N ranks up ourselves (one process per GPU) and pass the
     # one JSON line through.  Under torch.distributed.run the world must agree with --gpus.
@@ -276,6 +281,7 @@ def main():
         return
 
     proj_per_step = sum(s.projected for s in stats) / max(1, args.steps)
+    self_check = self_check_timed(stats, args, wl, world, dist is not None)
     ms_project = sum(s.ms_project for s in stats)
     launches = sum(s.project_launches for s in stats)
     ach = (sum(s.projected for s in stats) * ALG_BYTES_PER_PROJECTION) / (ms_project * 1e-3) / 1e9 if ms_project > 0 else 0.0
@@ -330,6 +336,8 @@ def main():
         "index_build_s": t_build,
         "index_bytes": index.device_bytes(),
         "roofline": roofline(stats, ach, traffic, tpath, ms_project, launches, tag if profiled else None),
+        "self_check": self_check["status"],
+        "self_check_detail": self_check,
     }
     if dist is not None:
         out["comm"] = comm_report
@@ -340,6 +348,13 @@ def main():
     if world == 1 and dist is None and not args.no_extras:
         out["full_results"] = full_results_leg(index, ranges, params)
         out["dfs_batch"] = dfs_batch_leg(index, ranges, args.max_depth)
+        # the rows the trait would return for the same batch: one per projection plus every range's self interval
+        sp = out["full_results"]["stream"]
+        self_check["stream_projected"] = sp["projected"]
+        self_check["stream_rows_minus_self"] = sp["rows"] - len(ranges)
+        if wl == "headline" and self_check["status"] == "ok" and not (
+                sp["projected"] == self_check["timed_projected_per_step"] == sp["rows"] - len(ranges)):
+            self_check["status"] = out["self_check"] = "FAILED: the row stream's projections differ from the timed form's"
     out["cpu_baseline"] = cpu_baseline(args, paf, ranges, transitive) if (world == 1 and args.cpu_sample > 0) else None
     if dist is not None:
         del index
@@ -355,6 +370,26 @@ def main():
     flush_c_stdio()
     result_out.write(json.dumps(out) + "\n")
     result_out.flush()
+    if out["self_check"] != "ok":  # a number whose answer is wrong is not a measurement
+        log("SELF CHECK FAILED: %s" % out["self_check"])
+        sys.exit(4)
+
+
+def self_check_timed(stats, args, wl, world, sharded):
+    """What the timed steps computed, against what they must compute: every step the same total; on the headline
+    configuration of one rank the pinned constant (the sharded runs have their own parity_vs_single leg)."""
+    per = sorted({int(s.projected) for s in stats})
+    chk = {"status": "ok", "timed_projected_per_step": per[0] if len(per) == 1 else per, "expected": None}
+    if len(per) != 1:
+        chk["status"] = "FAILED: the timed steps disagree with each other"
+        return chk
+    pinned = (wl == "headline" and not args.no_transitive and args.max_depth == 3 and args.records == 1_000_000 and
+              args.ranges == 100_000 and args.min_identity is None and not args.paf and not args.engine_option_changes_results)
+    if pinned and world == 1:  # (one rank through the sharded path answers the same batch; N ranks bring N different batches)
+        chk["expected"] = HEADLINE_PROJECTED
+        if per[0] != HEADLINE_PROJECTED:
+            chk["status"] = "FAILED: %d projections per step, the headline batch has %d" % (per[0], HEADLINE_PROJECTED)
+    return chk
 
 
 SIMDS = 256 * 4

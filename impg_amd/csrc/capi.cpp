@@ -59,6 +59,7 @@ EngineLease::~EngineLease() {
   e->remote = nullptr;
   e->masked = false;
   e->subset_on = false;
+  e->on_kernels_done = nullptr;  // (the row stream's hook captures its caller's locals: never past the lease)
   std::lock_guard<std::mutex> lk(ix.eng_m);
   ix.eng_free.push_back(e);
   ix.eng_cv.notify_one();
@@ -143,6 +144,9 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
   res.intervals.resize(nr, true);
   std::vector<uint32_t> off32((size_t)n + 1);
   IMPG_HIP(hipMemcpyAsync(off32.data(), pl.offsets.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, s));
+  // (without CIGARs the rows' placement was the chunk's last kernel: the GPU turn ends here, the copy below overlaps the
+  // other engine's kernels)
+  if (kernels_done && !res.has_cigar) IMPG_HIP(hipEventRecord(kernels_done, s));
   if (nr) IMPG_HIP(hipMemcpyAsync(res.intervals.data(), rows.p, nr * sizeof(impg_gpu_interval_t), hipMemcpyDeviceToHost, s));
   if (res.has_cigar) {
     const uint64_t n_ops = build_row_cigars(E, levels, pl, clen, coff, cpool);
@@ -151,8 +155,6 @@ void assemble_results(Engine &E, const impg_gpu_range_t *h_ranges, uint32_t n, c
     if (kernels_done) IMPG_HIP(hipEventRecord(kernels_done, s));
     IMPG_HIP(hipMemcpyAsync(res.cigar_off.data(), coff.p, (nr + 1) * 8, hipMemcpyDeviceToHost, s));
     if (n_ops) IMPG_HIP(hipMemcpyAsync(res.cigar_ops.data(), cpool.p, n_ops * 4, hipMemcpyDeviceToHost, s));
-  } else if (kernels_done) {
-    IMPG_HIP(hipEventRecord(kernels_done, s));  // (behind the rows' copy: what follows is host work only)
   }
   if (kernels_done) { IMPG_HIP(hipEventSynchronize(kernels_done)); if (E.on_kernels_done) E.on_kernels_done(); }
   IMPG_HIP(hipStreamSynchronize(s));
@@ -725,18 +727,28 @@ int impg_gpu_query_batch_stream(impg_gpu_index_t *ix, const impg_gpu_range_t *ra
   const uint64_t max_rows = std::max<uint64_t>(1, max_block_bytes / sizeof(impg_gpu_interval_t));
   uint64_t projected = 0;
   if (ix->shard || ix->cluster) {
-    // a sharded index: the chunks one after the other through the collective call (every rank streams its own ranges;
-    // ranks must agree on n == 0 or not per call, as for impg_gpu_query_batch)
-    for (size_t b = 0; b < n || (b == 0 && n == 0); b += chunk_ranges) {
-      const size_t e = std::min(n, b + chunk_ranges);
+    // a sharded index: the chunks one after the other through the collective call.  On a rank's shard (one process per
+    // GPU) every chunk is a collective: the ranks agree on the number of calls first -- each brings its own n, so the
+    // counts differ -- and a rank that has run out of ranges, or whose consumer has stopped it, keeps taking part with
+    // empty chunks until the longest stream is through (its peers' hops need its shard).
+    uint64_t my_chunks = std::max<uint64_t>(1, (n + chunk_ranges - 1) / chunk_ranges), n_chunks = my_chunks;
+    if (ix->shard && !ix->cluster) {
+      n_chunks = shard_agree_max(*ix, my_chunks);
+    }
+    bool cancelled = false;
+    for (uint64_t c = 0; c < n_chunks; c++) {
+      const size_t b = cancelled ? n : std::min<size_t>(n, (size_t)c * chunk_ranges), e = cancelled ? n : std::min(n, b + chunk_ranges);
       impg_gpu_results_t *part = nullptr;
       const int rc = sharded_query_batch(*ix, ranges + b, e - b, *params, mask, subset_keep, &part);
       if (rc != IMPG_OK) return rc;
       std::unique_ptr<impg_gpu_results> own(part);
       projected += part->projected;
-      if (e > b && cb(ctx, part, b) != 0) throw Error{IMPG_E_CANCELLED, "the row stream's consumer stopped it"};
-      if (n == 0) break;
+      if (e > b && cb(ctx, part, b) != 0) {
+        cancelled = true;
+        if (ix->cluster) break;  // (one caller, no peers waiting)
+      }
     }
+    if (cancelled) throw Error{IMPG_E_CANCELLED, "the row stream's consumer stopped it"};
     if (projected_out) *projected_out = projected;
     return IMPG_OK;
   }

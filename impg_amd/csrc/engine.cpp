@@ -27,7 +27,7 @@ inline unsigned bits_for(uint64_t n) {  // bits needed to represent values < n
 Engine::Engine(int device) {
   IMPG_HIP(hipSetDevice(device));
   IMPG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  counters.reserve(64);
+  counters.reserve(128);  // (words 0..7: the counters of a run; 8..11: the list lengths and work counters of the update)
   acc_slots.reserve(COUNT_BYTES);
   act_slots.reserve(COUNT_BYTES);
   IMPG_HIP(hipHostMalloc((void **)&h_counters, 64, hipHostMallocDefault));
@@ -168,11 +168,14 @@ void Engine::reserve_walk_slabs(const impg_gpu_index &ix, bool dfs_too) {
     walk_caps(wide != 0, a);
     want = std::max(want, walk_slab_bytes(ix.view.n_seq, wide != 0, a.wcap, a.hcap, a.vcap, a.gcap, a.scap) * (size_t)walk_workgroups(ix, wide != 0));
   }
-  if (walk_members != 1) {  // the grid form of one call: a slab per member
+  if (walk_members != 1) {  // the grid form: queries x members workgroups, at most this launch's share of the CUs (walk_group_size)
     WalkArgs a;
     memset(&a, 0, sizeof a);
     walk_caps(true, a);
-    want = std::max(want, walk_slab_bytes(ix.view.n_seq, true, a.wcap, a.hcap, a.vcap, a.gcap, a.scap) * (size_t)(walk_members ? walk_members : 32u));
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix.device);
+    const size_t share = std::max<size_t>(1, (size_t)cus / (size_t)std::max(1, ix.max_engines));
+    want = std::max(want, walk_slab_bytes(ix.view.n_seq, true, a.wcap, a.hcap, a.vcap, a.gcap, a.scap) * std::max<size_t>(share, SMALL_RANGES));
   }
   if (walk_slabs.cap < want) walk_slabs.reserve(want);
   walk_ctr.reserve(256);
@@ -577,11 +580,11 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       else
         launch_group_fill(skeys.as<unsigned long long>(), P, gid.as<uint32_t>(), gstart.as<uint32_t>(), vt->keys.as<unsigned long long>(), stream);
       const uint32_t n_active = by_segments ? seg_active : (uint32_t)read_slots(act_slots);  // hits that carry a (query, sequence) key
-      glen.reserve((size_t)n_groups * 4); old_tab.reserve((size_t)n_groups * 4); old_idx.reserve((size_t)n_groups * 4);
+      glen.reserve((size_t)n_groups * 4); old_src.reserve((size_t)n_groups * 8);
       cap.reserve((size_t)n_groups * 4); pcap.reserve((size_t)n_groups * 4);
       VisitedTables tabs = tables_view();
       launch_group_prepare(tabs, vt->keys.as<unsigned long long>(), gstart.as<uint32_t>(), n_groups, n_active,
-                           glen.as<uint32_t>(), old_tab.as<uint32_t>(), old_idx.as<uint32_t>(), cap.as<uint32_t>(),
+                           glen.as<uint32_t>(), old_src.as<const int2 *>(), cap.as<uint32_t>(),
                            pcap.as<uint32_t>(), stream);
       if (getenv("IMPG_DEBUG_GROUPS")) {  // histogram of group sizes (tuning aid)
         std::vector<uint32_t> hc(n_groups), hp(n_groups), hl(n_groups);
@@ -598,6 +601,15 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
           b[k]++; hits[k] += hl[g2];
           mx = std::max(mx, hc[g2]); mxl = std::max(mxl, hl[g2]);
         }
+        {  // the short end, which the lane-per-group kernel lives on: groups by cap (old + hits) and by hits, 1..20
+          uint64_t bc[21] = {0}, bh[21] = {0};
+          for (uint32_t g2 = 0; g2 < n_groups; g2++) { bc[std::min(hc[g2], 20u)]++; bh[std::min(hl[g2], 20u)]++; }
+          fprintf(stderr, "[groups] by cap 1..20+:");
+          for (int k2 = 1; k2 <= 20; k2++) fprintf(stderr, " %llu", (unsigned long long)bc[k2]);
+          fprintf(stderr, "\n[groups] by hits 1..20+:");
+          for (int k2 = 1; k2 <= 20; k2++) fprintf(stderr, " %llu", (unsigned long long)bh[k2]);
+          fprintf(stderr, "\n");
+        }
         fprintf(stderr, "[groups] n=%u P=%u maxcap=%u maxhits=%u | cap<=16:%llu(%llu) 64:%llu(%llu) 512:%llu(%llu) 1k:%llu(%llu) 2k:%llu(%llu) 4k:%llu(%llu) 16k:%llu(%llu) more:%llu(%llu)\n",
                 n_groups, P, mx, mxl, (unsigned long long)b[0], (unsigned long long)hits[0], (unsigned long long)b[1], (unsigned long long)hits[1],
                 (unsigned long long)b[2], (unsigned long long)hits[2], (unsigned long long)b[3], (unsigned long long)hits[3],
@@ -611,8 +623,9 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       const bool filter = filter_covered == 1 || (filter_covered == 2 && tables.size() >= 2 && (uint64_t)n_active >= 8ull * n_groups);
       if (filter && n_active) {
         uint32_t *keep = keys.as<uint32_t>(), *kpos = keep + P;  // (the unsorted key / value buffers are free again)
-        launch_covered_flags(tabs, svals.as<unsigned long long>(), head.as<uint32_t>(), gid.as<uint32_t>(), vt->keys.as<unsigned long long>(),
-                             old_tab.as<uint32_t>(), old_idx.as<uint32_t>(), masked ? mask_touch_len.as<int32_t>() : v.seq_len, n_active, keep, stream);
+        launch_covered_flags(svals.as<unsigned long long>(), head.as<uint32_t>(), gid.as<uint32_t>(), vt->keys.as<unsigned long long>(),
+                             old_src.as<const int2 *>(), cap.as<uint32_t>(), glen.as<uint32_t>(), masked ? mask_touch_len.as<int32_t>() : v.seq_len,
+                             n_active, keep, stream);
         const uint32_t n_kept = (uint32_t)scan(keep, kpos, n_active);
         launch_covered_compact(svals.as<unsigned long long>(), keep, kpos, n_active, vals.as<unsigned long long>(), n_kept, n_groups,
                                gstart.as<uint32_t>(), glen.as<uint32_t>(), cap.as<uint32_t>(), pcap.as<uint32_t>(), stream);
@@ -630,13 +643,13 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       pieces.reserve(std::max<size_t>(pcap_total * 8, 256));
       n_pieces.reserve((size_t)n_groups * 4);
       foff.reserve((size_t)n_groups * 4);
-      big_list.reserve((size_t)n_groups * 8);  // two lists: [small from the front | large from the back], [tiny]
-      launch_visited_update(tabs, replay_vals, masked ? mask_touch_len.as<int32_t>() : v.seq_len, vt->keys.as<unsigned long long>(),
-                            gstart.as<uint32_t>(), glen.as<uint32_t>(), old_tab.as<uint32_t>(), old_idx.as<uint32_t>(),
+      big_list.reserve((size_t)n_groups * 12);  // three lists: [small from the front | large from the back], [tiny], [mid] (big_groups_kernel)
+      launch_visited_update(replay_vals, masked ? mask_touch_len.as<int32_t>() : v.seq_len, vt->keys.as<unsigned long long>(),
+                            gstart.as<uint32_t>(), glen.as<uint32_t>(), old_src.as<const int2 *>(),
                             vt->off.as<uint32_t>(), poff.as<uint32_t>(), n_groups, p.min_transitive_len,
                             p.min_distance_between_ranges, vt->ranges.as<int2>(), vt->len.as<uint32_t>(),
                             pieces.as<int2>(), n_pieces.as<uint32_t>(), cap.as<uint32_t>(), pcap.as<uint32_t>(), big_list.as<uint32_t>(),
-                            (uint32_t *)(counters.as<uint64_t>() + 5), stream);
+                            (uint32_t *)(counters.as<uint64_t>() + 8), stream);
       uint64_t nn = scan(n_pieces.as<uint32_t>(), foff.as<uint32_t>(), n_groups);
       if (nn >= 0xFFFFFFF0ull) { if (split_ok) throw SplitBatch{}; throw Error{IMPG_E_UNSUPPORTED, "frontier exceeds 2^32 ranges"}; }
       n_next = (uint32_t)nn;

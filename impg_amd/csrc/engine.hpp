@@ -66,8 +66,8 @@ struct Engine {
   std::vector<Timed> timed;
   // scratch, grown on demand and reused across calls
   DevBuf big_list;  // groups of a level whose visited list gets a whole wave
-  DevBuf cnt, win, pair_off, pair_entry, scan_tmp, keys, skeys, vals, svals, sort_tmp, head, gid, gstart, glen, old_tab,
-      old_idx, cap, pcap, poff, pieces, n_pieces, foff, frontier_a, frontier_b, self_scratch, ranges_dev, stat_count,
+  DevBuf cnt, win, pair_off, pair_entry, scan_tmp, keys, skeys, vals, svals, sort_tmp, head, gid, gstart, glen, old_src,
+      cap, pcap, poff, pieces, n_pieces, foff, frontier_a, frontier_b, self_scratch, ranges_dev, stat_count,
       stat_cksum, stage_off;
   LevelBufs level_scratch;
   std::vector<std::unique_ptr<VisitedStore>> tables;
@@ -267,6 +267,8 @@ void check_ranges(const impg_gpu_range_t *ranges, size_t n);
 void apply_mask(Engine &E, const impg_gpu_index &ix, const impg_gpu_mask_t *m, const impg_gpu_params_t &p);
 void apply_subset(Engine &E, const impg_gpu_index &ix, const uint8_t *subset_keep);
 // entry points of sharded.cpp behind the public query calls
+// the largest of the ranks' values (a collective on lane 0 of a rank's shard: every rank calls it at the same point)
+uint64_t shard_agree_max(impg_gpu_index &ix, uint64_t mine);
 int sharded_query_batch(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t &p,
                         const impg_gpu_mask_t *mask, const uint8_t *subset_keep, impg_gpu_results **out);
 int sharded_query_stats(impg_gpu_index &ix, const impg_gpu_range_t *ranges, bool on_device, size_t n,

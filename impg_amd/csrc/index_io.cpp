@@ -130,6 +130,7 @@ void load_index(impg_gpu_index &ix, const char *path, ShardInfo *shard) {
   const bool has_shard = (h.multi_file & 8) != 0, front = (h.multi_file & 16) != 0;
   if (has_shard && !shard) throw Error{IMPG_E_INVALID, in.path + " is a part of an index sharded over GPUs: load it with impg_gpu_index_load_rank / _load_multi"};
   if (!has_shard && shard) throw Error{IMPG_E_INVALID, in.path + " is not a part of a sharded index"};
+  if (front && !has_shard) throw Error{IMPG_E_INVALID, in.path + ": a front file without a shard section (damaged header)"};
   // every array's size follows from the counts in the header: check them all before anything is allocated or uploaded
   {
     if (fseek(in.f, 0, SEEK_END) != 0) throw Error{IMPG_E_IO, "cannot seek in " + in.path};

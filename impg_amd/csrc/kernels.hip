@@ -2569,11 +2569,14 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const unsigned long long *a,
 }
 
 // per group: run length, the group's current visited list (newest table that
-// holds the key), capacities for the new list and for the pieces
+// holds the key; its length is cap - glen), capacities for the new list and for the pieces.
+// The list is handed on as a POINTER: the update kernels used to resolve (table, index) themselves -- a dynamic index
+// into the by-value table array, then the table's offset and length, then the list: three dependent round trips
+// before the first range, per group.
 __global__ __launch_bounds__(256) void group_prepare_kernel(VisitedTables vt, const unsigned long long *__restrict__ gkey,
                                                             const uint32_t *__restrict__ gstart, uint32_t n_groups,
                                                             uint32_t n_active, uint32_t *__restrict__ glen,
-                                                            uint32_t *__restrict__ old_tab, uint32_t *__restrict__ old_idx,
+                                                            const int2 **__restrict__ old_src,
                                                             uint32_t *__restrict__ cap, uint32_t *__restrict__ pcap) {
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
   if (g >= n_groups) return;
@@ -2582,24 +2585,26 @@ __global__ __launch_bounds__(256) void group_prepare_kernel(VisitedTables vt, co
   const uint32_t len = en - st;
   glen[g] = len;
   const unsigned long long k = gkey[g];
-  uint32_t tab = VISITED_NONE, idx = 0, olen = 0;
+  const int2 *src = nullptr;
+  uint32_t olen = 0;
+  bool found = false;
   for (int t = (int)vt.n_tables - 1; t >= 0; t--) {
     const VisitedTable &T = vt.t[t];
     uint32_t i = lower_bound_u64(T.keys, T.n_groups, k);
     if (i < T.n_groups && T.keys[i] == k) {
-      tab = (uint32_t)t;
-      idx = i;
+      src = T.ranges + T.off[i];
       olen = T.len[i];
+      found = true;
       break;
     }
   }
-  if (tab == VISITED_NONE && vt.mask_off) {  // first touch under a mask: the clone of the mask's list (impg.rs:2077-2078)
+  if (!found && vt.mask_off) {  // first touch under a mask: the clone of the mask's list (impg.rs:2077-2078)
     const uint32_t seq = (uint32_t)(k & 0xFFFFFFFFull);
-    olen = vt.mask_off[seq + 1] - vt.mask_off[seq];
-    if (olen) { tab = VISITED_MASK; idx = seq; }
+    const uint32_t a = vt.mask_off[seq];
+    olen = vt.mask_off[seq + 1] - a;
+    src = vt.mask_ranges + a;
   }
-  old_tab[g] = tab;
-  old_idx[g] = idx;
+  old_src[g] = olen ? src : nullptr;
   cap[g] = olen + len;
   pcap[g] = olen + 2u * len;
 }
@@ -2632,18 +2637,34 @@ constexpr uint32_t VU_LDS_CAP = IMPG_VU_LDS_CAP;
 // groups whose list can outgrow this get a whole wave (visited_update_wave_kernel below)
 // two sizes of LDS working set (9 KB: 17 waves per CU; 32 KB: 5): groups with few hits and a short list take the small one
 #ifndef IMPG_VW_TINY
-#define IMPG_VW_TINY 512
+#define IMPG_VW_TINY 192  // 1.5 KB: groups whose list cannot outgrow 128 ranges (cap = old + hits <= 128), every wave slot of a CU holds one
 #endif
 #ifndef IMPG_VW_SMALL
 #define IMPG_VW_SMALL 1152  // 9 KB, 17 waves per CU.  With the isolated hits of a batch going in together (replay_hits_wave), config 5
 #endif                      // (4 000 windows, update ms): 1 024 entries 997 -- 85 % of the deepest level's groups end at ~1 030 ranges and
                             // finish their replay in global memory at four times the cost per hit --, 1 152: 924, 1 280: 1 012, 1 536: 1 103
-#ifndef IMPG_VW_TINY_HEADROOM
-#define IMPG_VW_TINY_HEADROOM 1000000  // the tiny tier is OFF: measured on config 5 (4 000 windows, update ms): one 1 024-entry tier 1 323;
-#endif                                 // 1 536 entries 1 595; 2 048 entries 1 902 (fewer waves per CU); + a 768-entry tier for short lists 1 610,
-                                       // + a 512-entry one 1 893 (more waves, but lists that outgrow the buffer replay in global memory)
-constexpr uint32_t VW_MIN = 64, VW_CAP_TINY = IMPG_VW_TINY, VW_CAP_SMALL = IMPG_VW_SMALL, VW_CAP_LARGE = 4096,
-                   VW_TINY_HEADROOM = IMPG_VW_TINY_HEADROOM, VW_SMALL_HEADROOM = 256;
+// (the tiny tier of round 3 -- short lists of deep groups, 512 / 768 entries -- lost to one 1 152-entry tier on config 5: more
+// waves, but lists that outgrew the buffer replayed in global memory.  Round 5's tiny tier is for groups that CANNOT outgrow it.)
+// Which kernel takes a group, by cap = old length + hits (what its list cannot outgrow):
+//   cap <= VU_TINY_MAX  visited_update_kernel<VU_LDS_CAP, false>: a lane per group, 64 neighbouring groups a wave (98.5 % of a
+//                       headline level's groups; list AND pieces in the lane's 16-entry LDS column)
+//   cap <= VU_MID_MAX   visited_update_kernel<VU_MID_CAP, true>: a lane per group too, but of a LIST of such groups and with a
+//                       64-entry column -- among tiny groups one of them kept 63 lanes waiting for its 30 hits (and, with
+//                       17..64 hits, replayed in place on its global slice: two thirds of all wave cycles, round 4)
+//   beyond              visited_update_wave_kernel: a wave per group (three LDS sizes)
+#ifndef IMPG_VU_TINY_MAX
+#define IMPG_VU_TINY_MAX 9
+#endif
+#ifndef IMPG_VU_MID_MAX
+#define IMPG_VU_MID_MAX 48
+#endif
+#ifndef IMPG_VU_MID_CAP
+#define IMPG_VU_MID_CAP 64
+#endif
+constexpr uint32_t VU_TINY_MAX = IMPG_VU_TINY_MAX, VU_MID_MAX = IMPG_VU_MID_MAX, VU_MID_CAP = IMPG_VU_MID_CAP;
+static_assert(VU_TINY_MAX <= VU_LDS_CAP && VU_MID_MAX <= VU_MID_CAP, "a lane's list must fit its LDS column");
+constexpr uint32_t VW_CAP_TINY = IMPG_VW_TINY, VW_CAP_SMALL = IMPG_VW_SMALL, VW_CAP_LARGE = 4096,
+                   VW_SMALL_HEADROOM = 256;
 struct ListInPlace {  // the group's slice of the new table
   int2 *p;
   __device__ __forceinline__ int32_t &x(uint32_t i) const { return p[i].x; }
@@ -2662,6 +2683,68 @@ template <class L> __device__ __forceinline__ uint32_t list_lower_bound(const L 
   }
   return lo;
 }
+// one hit's turn against the list R (len entries): the proximity test (impg.rs:2513-2545), then SortedRanges::insert
+// with min_distance = 0 (impg.rs:270-368); the not-yet-visited pieces that are long enough go to emit(start, end)
+// (grow() is called right before the list gets one range longer -- R[len] is about to be written)
+template <class L, class E, class G>
+__device__ __forceinline__ void replay_one(const L &R, uint32_t &len, int32_t start, int32_t end, int32_t sequence_length,
+                                           int32_t min_transitive_len, int32_t mdbr, E &&emit, G &&grow) {
+  bool should_add = true;
+  if (mdbr > 0) {  // impg.rs:2513-2545
+    const uint32_t idx = list_lower_bound(R, len, start);
+    if (idx > 0 && abs(start - R.y(idx - 1)) < mdbr) should_add = false;
+    if (should_add && idx < len && abs(R.x(idx) - end) < mdbr) should_add = false;
+  }
+  if (!should_add) return;
+  // ---- SortedRanges::insert, min_distance = 0 --------------------------------
+  if (start < 0) start = 0;                       // impg.rs:287-289
+  if (end > sequence_length) end = sequence_length;  // impg.rs:294-296
+  int32_t current = start;
+  const uint32_t pos = list_lower_bound(R, len, start);  // (the same lower bound serves :303 and :330)
+  uint32_t i = pos;
+  if (i > 0 && R.y(i - 1) > start) i -= 1;
+  while (i < len && current < end) {  // impg.rs:314-324
+    const int32_t rx = R.x(i), ry = R.y(i);
+    if (rx > end) break;
+    if (current < rx) {
+      if (abs(rx - current) >= min_transitive_len) emit(current, rx);
+    }
+    current = max(current, ry);
+    i += 1;
+  }
+  if (current < end) {
+    if (abs(end - current) >= min_transitive_len) emit(current, end);
+  }
+  uint32_t mfrom;  // impg.rs:330-343
+  if (pos > 0 && R.y(pos - 1) >= start) {
+    R.y(pos - 1) = max(R.y(pos - 1), end);
+    mfrom = pos - 1;
+  } else if (pos < len && end >= R.x(pos)) {
+    R.x(pos) = min(start, R.x(pos));
+    R.y(pos) = max(end, R.y(pos));
+    mfrom = pos;
+  } else {
+    grow();
+    for (uint32_t k = len; k > pos; k--) { R.x(k) = R.x(k - 1); R.y(k) = R.y(k - 1); }
+    R.x(pos) = start;
+    R.y(pos) = end;
+    len += 1;
+    return;
+  }
+  uint32_t write = mfrom, read = mfrom + 1;  // merge_forward_from, impg.rs:355-368
+  while (read < len) {
+    if (R.y(write) >= R.x(read)) {
+      R.y(write) = max(R.y(write), R.y(read));
+    } else {
+      write += 1;
+      const int32_t tx = R.x(write), ty = R.y(write);
+      R.x(write) = R.x(read); R.y(write) = R.y(read);
+      R.x(read) = tx; R.y(read) = ty;
+    }
+    read += 1;
+  }
+  len = write + 1;
+}
 // replays hits [st, st+n) against the list R (len entries on entry); returns the new length, appends pieces to P
 template <class L>
 __device__ __forceinline__ uint32_t replay_hits(const L &R, uint32_t len, const unsigned long long *__restrict__ svals,
@@ -2669,114 +2752,175 @@ __device__ __forceinline__ uint32_t replay_hits(const L &R, uint32_t len, const 
                                                 int32_t min_transitive_len, int32_t mdbr, int2 *__restrict__ P, uint32_t &np) {
   for (uint32_t t = 0; t < n; t++) {
     const unsigned long long iv = svals[st + t];  // (min, max) of the hit's query interval, packed by update_keys
-    int32_t start = (int32_t)(uint32_t)(iv >> 32), end = (int32_t)(uint32_t)iv;
-    bool should_add = true;
-    if (mdbr > 0) {  // impg.rs:2513-2545
-      const uint32_t idx = list_lower_bound(R, len, start);
-      if (idx > 0 && abs(start - R.y(idx - 1)) < mdbr) should_add = false;
-      if (should_add && idx < len && abs(R.x(idx) - end) < mdbr) should_add = false;
-    }
-    if (!should_add) continue;
-    // ---- SortedRanges::insert, min_distance = 0 --------------------------------
-    if (start < 0) start = 0;                       // impg.rs:287-289
-    if (end > sequence_length) end = sequence_length;  // impg.rs:294-296
-    int32_t current = start;
-    const uint32_t pos = list_lower_bound(R, len, start);  // (the same lower bound serves :303 and :330)
-    uint32_t i = pos;
-    if (i > 0 && R.y(i - 1) > start) i -= 1;
-    while (i < len && current < end) {  // impg.rs:314-324
-      const int32_t rx = R.x(i), ry = R.y(i);
-      if (rx > end) break;
-      if (current < rx) {
-        if (abs(rx - current) >= min_transitive_len) P[np++] = make_int2(current, rx);
-      }
-      current = max(current, ry);
-      i += 1;
-    }
-    if (current < end) {
-      if (abs(end - current) >= min_transitive_len) P[np++] = make_int2(current, end);
-    }
-    uint32_t mfrom;  // impg.rs:330-343
-    if (pos > 0 && R.y(pos - 1) >= start) {
-      R.y(pos - 1) = max(R.y(pos - 1), end);
-      mfrom = pos - 1;
-    } else if (pos < len && end >= R.x(pos)) {
-      R.x(pos) = min(start, R.x(pos));
-      R.y(pos) = max(end, R.y(pos));
-      mfrom = pos;
-    } else {
-      for (uint32_t k = len; k > pos; k--) { R.x(k) = R.x(k - 1); R.y(k) = R.y(k - 1); }
-      R.x(pos) = start;
-      R.y(pos) = end;
-      len += 1;
-      continue;
-    }
-    uint32_t write = mfrom, read = mfrom + 1;  // merge_forward_from, impg.rs:355-368
-    while (read < len) {
-      if (R.y(write) >= R.x(read)) {
-        R.y(write) = max(R.y(write), R.y(read));
-      } else {
-        write += 1;
-        const int32_t tx = R.x(write), ty = R.y(write);
-        R.x(write) = R.x(read); R.y(write) = R.y(read);
-        R.x(read) = tx; R.y(read) = ty;
-      }
-      read += 1;
-    }
-    len = write + 1;
+    replay_one(R, len, (int32_t)(uint32_t)(iv >> 32), (int32_t)(uint32_t)iv, sequence_length, min_transitive_len, mdbr,
+               [&](int32_t a, int32_t b) { P[np++] = make_int2(a, b); }, [] {});
   }
   return len;
 }
-__global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, const unsigned long long *__restrict__ svals,
+// Round 5: what the kernel waited for (scripts/vu_clocks.py, -DIMPG_VU_CLOCKS: the cycle counter at the phase boundaries).
+// (i) Two thirds of all wave cycles went to the 0.5 % of groups with 17..64 hits, which the lane kernel replayed IN PLACE on
+// their global slice -- three searches and a shift per hit, every step a memory round trip -- while the 63 other lanes
+// of the wave waited: a third of the waves held one.  They now go to a wave of their own (visited_update_wave_kernel's
+// 192-entry tier, VW_MIN = the LDS column).  (ii) Every variable-trip loop -- the old list copied into LDS, the hits
+// replayed, the pieces fetched back for their sort -- paid one memory round trip PER ITERATION (load, s_waitcnt, use,
+// next), and a wave runs as many iterations as its longest lane.  Now: the group's list arrives as a pointer
+// (group_prepare), the first four hits and the first four ranges of the old list are requested together right behind
+// the group's record, the hits come four at a time with the next four under way while four are replayed, and a
+// group's pieces collect at the TOP of the lane's LDS column, growing down towards the list (they move to the group's
+// global slice only if the two meet): sorted and merged where they are, stored once -- nothing is read back.
+// -DIMPG_VU_CLOCKS (experiments, scripts/vu_clocks.py): the cycle counter at the kernel's phase boundaries (everything
+// outstanding waited for first), summed over all waves; read and cleared by impg_gpu_debug_vu_clocks
+#ifdef IMPG_VU_CLOCKS
+constexpr uint32_t VU_CLK_ROWS = 1024;
+__device__ unsigned long long g_vu_clk[VU_CLK_ROWS][16];  // (striped: 14 atomics a wave on ONE row serialised the whole kernel)
+#define VU_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); vu_t[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VU_MARK(i) do { } while (0)
+#endif
+// a visited list through a pointer that was read from memory: eight bytes a range, as a GLOBAL address (through a generic
+// pointer the loads are flat_load: the slower path, and a wait on two counters)
+typedef const unsigned long long __attribute__((address_space(1))) *global_list_t;
+__device__ __forceinline__ int2 list_range(global_list_t p, uint32_t i) {
+  const unsigned long long v = p[i];
+  return make_int2((int32_t)(uint32_t)v, (int32_t)(uint32_t)(v >> 32));
+}
+template <uint32_t CAP, bool LISTED>  // CAP: entries of a lane's LDS column; LISTED: the groups of list[0 .. *n_list), grid-strided
+__global__ __launch_bounds__(64) void visited_update_kernel(const unsigned long long *__restrict__ svals,
                                                             const int32_t *__restrict__ seq_len,
                                                             const unsigned long long *__restrict__ gkey,
                                                             const uint32_t *__restrict__ gstart,
                                                             const uint32_t *__restrict__ glen,
-                                                            const uint32_t *__restrict__ old_tab,
-                                                            const uint32_t *__restrict__ old_idx,
+                                                            const unsigned long long *__restrict__ old_src,
+                                                            const uint32_t *__restrict__ cap,
                                                             const uint32_t *__restrict__ noff,
                                                             const uint32_t *__restrict__ poff, uint32_t n_groups,
                                                             int32_t min_transitive_len, int32_t mdbr,
                                                             int2 *__restrict__ new_ranges, uint32_t *__restrict__ new_len,
-                                                            int2 *__restrict__ pieces, uint32_t *__restrict__ n_pieces) {
-  __shared__ int32_t lds_x[VU_LDS_CAP * 64], lds_y[VU_LDS_CAP * 64];
-  const uint32_t g = blockIdx.x * 64u + threadIdx.x;
-  if (g >= n_groups) return;
-  int2 *R = new_ranges + noff[g];
-  // the group's current list: the newest table that holds the key, else the mask's list of the sequence
-  const int2 *src = nullptr;
-  uint32_t len = 0;
-  if (old_tab[g] == VISITED_MASK) {
-    const uint32_t a = vt.mask_off[old_idx[g]];
-    len = vt.mask_off[old_idx[g] + 1] - a;
-    src = vt.mask_ranges + a;
-  } else if (old_tab[g] != VISITED_NONE) {
-    const VisitedTable &T = vt.t[old_tab[g]];
-    src = T.ranges + T.off[old_idx[g]];
-    len = T.len[old_idx[g]];
+                                                            int2 *__restrict__ pieces, uint32_t *__restrict__ n_pieces,
+                                                            const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list) {
+  __shared__ int32_t lds_x[CAP * 64], lds_y[CAP * 64];
+  const uint32_t n_items = LISTED ? *n_list : n_groups;
+  for (uint32_t item0 = blockIdx.x * 64u; item0 < n_items; item0 += gridDim.x * 64u) {  // (one trip unless LISTED)
+  const uint32_t item = item0 + threadIdx.x;
+#ifdef IMPG_VU_CLOCKS
+  unsigned long long vu_t[8];
+  VU_MARK(0);
+#endif
+  // round 1 (coalesced): the group's record.  Lanes without a group of their own (the grid's tail; groups another
+  // kernel takes) stay in the wave with nothing to do: the loops below are wave-uniform.
+  const bool have = item < n_items;
+  const uint32_t g = LISTED ? list[min(item, n_items - 1u)] : item;
+  const uint32_t gi = min(g, n_groups - 1u);  // (unconditional loads: one round trip, not one per dependent condition)
+  const uint32_t c_ = cap[gi], n_ = glen[gi], st_ = gstart[gi], no = noff[gi], po = poff[gi];
+  // (the list pointer is read as an integer and made a GLOBAL pointer: through a generic one its loads were flat_load)
+  const global_list_t src_ = (global_list_t)old_src[gi];
+  const unsigned long long key = gkey[gi];
+  const uint32_t c = have ? c_ : 0u;
+  const bool mine = have && (LISTED || c <= VU_TINY_MAX);  // cap = old length + hits bounds the list at every step
+  const uint32_t n = mine ? n_ : 0u, st = mine ? st_ : 0u;
+  const uint32_t olen = mine ? c - n : 0u;
+  int2 *R = new_ranges + no;
+  int2 *P = pieces + po;
+  VU_MARK(1);
+  // round 2: the clamp length, the first hits and the first ranges of the old list, all under way together -- straight-
+  // line code: a lane with nothing to fetch reads a harmless address (the compiler cannot count loads across branches
+  // and waits for ALL of them at every join)
+  const int32_t sequence_length = seq_len[(uint32_t)(key & 0xFFFFFFFFull)];  // visited_entry, impg.rs:2048-2053
+  const unsigned long long *hp = svals + st;
+  const uint32_t hl = max(n, 1u) - 1u;
+  unsigned long long h0 = hp[0], h1 = hp[min(1u, hl)], h2 = hp[min(2u, hl)], h3 = hp[min(3u, hl)];
+  const global_list_t src = olen ? src_ : (global_list_t)(unsigned long long)(uintptr_t)svals;
+  const uint32_t sl = max(olen, 1u) - 1u;
+  const int2 s0 = list_range(src, 0), s1 = list_range(src, min(1u, sl)), s2 = list_range(src, min(2u, sl)), s3 = list_range(src, min(3u, sl));
+  VU_MARK(2);
+  uint32_t len = olen, np = 0;
+  VU_MARK(3);
+  const bool fast = mine;
+  const ListInLds A{lds_x + threadIdx.x, lds_y + threadIdx.x};
+  if (fast) {
+    if (olen > 0) { A.x(0) = s0.x; A.y(0) = s0.y; }
+    if (olen > 1) { A.x(1) = s1.x; A.y(1) = s1.y; }
+    if (olen > 2) { A.x(2) = s2.x; A.y(2) = s2.y; }
+    if (olen > 3) { A.x(3) = s3.x; A.y(3) = s3.y; }
+    for (uint32_t i = 4; i < olen; i += 4) {  // (four requests a round trip)
+      const uint32_t l = olen - 1u;
+      const int2 r0 = list_range(src, i), r1 = list_range(src, min(i + 1u, l)), r2 = list_range(src, min(i + 2u, l)), r3 = list_range(src, min(i + 3u, l));
+      A.x(i) = r0.x; A.y(i) = r0.y;
+      if (i + 1u < olen) { A.x(i + 1u) = r1.x; A.y(i + 1u) = r1.y; }
+      if (i + 2u < olen) { A.x(i + 2u) = r2.x; A.y(i + 2u) = r2.y; }
+      if (i + 3u < olen) { A.x(i + 3u) = r3.x; A.y(i + 3u) = r3.y; }
+    }
   }
-  const int32_t sequence_length = seq_len[(uint32_t)(gkey[g] & 0xFFFFFFFFull)];  // visited_entry, impg.rs:2048-2053
-  int2 *P = pieces + poff[g];
-  uint32_t np = 0;
-  const uint32_t st = gstart[g], n = glen[g];
-  if (len + n > VW_MIN) return;  // a wave of visited_update_wave_kernel takes this group
-  if (len + n <= VU_LDS_CAP) {  // (len + n bounds the list at every step)
-    const ListInLds A{lds_x + threadIdx.x, lds_y + threadIdx.x};
-    for (uint32_t i = 0; i < len; i++) { const int2 r = src[i]; A.x(i) = r.x; A.y(i) = r.y; }
-    len = replay_hits(A, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np);
-    for (uint32_t i = 0; i < len; i++) R[i] = make_int2(A.x(i), A.y(i));
-  } else {
-    for (uint32_t i = 0; i < len; i++) R[i] = src[i];
-    len = replay_hits(ListInPlace{R}, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np);
+  VU_MARK(4);
+  // the replay, four hits a batch: the next batch is requested before this one is worked on
+  const uint32_t nf = fast ? n : 0u;
+  const uint32_t nmax = wave_max_u32(nf);
+  // pieces: the k-th at the column's entry CAP - 1 - k while list and pieces do not meet
+  bool spilled = false;
+  auto spill = [&]() {
+    for (uint32_t k = 0; k < np; k++) P[k] = make_int2(A.x(CAP - 1u - k), A.y(CAP - 1u - k));
+    spilled = true;
+  };
+  auto emit = [&](int32_t a, int32_t b) {
+    if (!spilled && len + np >= CAP) spill();
+    if (!spilled) { A.x(CAP - 1u - np) = a; A.y(CAP - 1u - np) = b; }
+    else P[np] = make_int2(a, b);
+    np += 1;
+  };
+  auto grow = [&]() { if (!spilled && len + np >= CAP) spill(); };
+  for (uint32_t t0 = 0; t0 < nmax; t0 += 4u) {
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (t0 + 4u < nmax && nf) {  // (a lane past its last hit reads that hit again: never used)
+      const unsigned long long *hp = svals + st;
+      const uint32_t l = nf - 1u;
+      q0 = hp[min(t0 + 4u, l)]; q1 = hp[min(t0 + 5u, l)]; q2 = hp[min(t0 + 6u, l)]; q3 = hp[min(t0 + 7u, l)];
+    }
+#pragma nounroll
+    for (uint32_t k = 0; k < 4u; k++) {
+      const unsigned long long iv = h0;
+      h0 = h1; h1 = h2; h2 = h3;
+      if (t0 + k < nf)
+        replay_one(A, len, (int32_t)(uint32_t)(iv >> 32), (int32_t)(uint32_t)iv, sequence_length, min_transitive_len, mdbr, emit, grow);
+    }
+    h0 = q0; h1 = q1; h2 = q2; h3 = q3;
   }
+  VU_MARK(5);
+  if (fast) for (uint32_t i = 0; i < len; i++) R[i] = make_int2(A.x(i), A.y(i));
+  VU_MARK(6);
   // next-depth ranges of this group: sort by start, merge overlapping/contiguous
   // (impg.rs:2568-2584; ranges of different groups never share (query, id))
-  if (np > 1 && np <= VU_LDS_CAP) {
+  if (fast && !spilled) {
+    // the usual case: the pieces are in the column (entry CAP - 1 - k): insertion sort by start, sweep, store
+    const uint32_t T = CAP - 1u;
+    for (uint32_t i = 1; i < np; i++) {
+      const int32_t tx = A.x(T - i), ty = A.y(T - i);
+      uint32_t j = i;
+      while (j > 0 && A.x(T - (j - 1u)) > tx) { A.x(T - j) = A.x(T - (j - 1u)); A.y(T - j) = A.y(T - (j - 1u)); j--; }
+      A.x(T - j) = tx; A.y(T - j) = ty;
+    }
+    if (np) {
+      uint32_t w = 0;
+      int32_t cx = A.x(T), cy = A.y(T);
+      for (uint32_t r = 1; r < np; r++) {
+        const int32_t rx = A.x(T - r), ry = A.y(T - r);
+        if (cy >= rx) cy = max(cy, ry);
+        else { P[w] = make_int2(cx, cy); w += 1; cx = rx; cy = ry; }
+      }
+      P[w] = make_int2(cx, cy);
+      np = w + 1;
+    }
+  } else if (mine && np > 1 && np <= CAP) {
     // a handful of pieces: fetched once into the lane's LDS column (the list has been written out), sorted and merged
-    // there -- on the global slice every comparison of the insertion sort was a dependent round trip to memory, and
-    // they, not the replay, were most of this kernel's time
+    // there -- on the global slice every comparison of the insertion sort was a dependent round trip to memory
     const ListInLds S{lds_x + threadIdx.x, lds_y + threadIdx.x};
-    for (uint32_t i = 0; i < np; i++) { const int2 t = P[i]; S.x(i) = t.x; S.y(i) = t.y; }
+    for (uint32_t i = 0; i < np; i += 4) {
+      const uint32_t l = np - 1u;
+      const int2 r0 = P[i], r1 = P[min(i + 1u, l)], r2 = P[min(i + 2u, l)], r3 = P[min(i + 3u, l)];
+      S.x(i) = r0.x; S.y(i) = r0.y;
+      if (i + 1u < np) { S.x(i + 1u) = r1.x; S.y(i + 1u) = r1.y; }
+      if (i + 2u < np) { S.x(i + 2u) = r2.x; S.y(i + 2u) = r2.y; }
+      if (i + 3u < np) { S.x(i + 3u) = r3.x; S.y(i + 3u) = r3.y; }
+    }
     for (uint32_t i = 1; i < np; i++) {
       const int32_t tx = S.x(i), ty = S.y(i);
       uint32_t j = i;
@@ -2792,7 +2936,7 @@ __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, co
     }
     P[w] = make_int2(cx, cy);
     np = w + 1;
-  } else {
+  } else if (mine) {
     for (uint32_t i = 1; i < np; i++) {
       int2 x = P[i];
       uint32_t j = i;
@@ -2806,9 +2950,41 @@ __global__ __launch_bounds__(64) void visited_update_kernel(VisitedTables vt, co
     }
     if (np) np = w + 1;
   }
-  new_len[g] = len;
-  n_pieces[g] = np;
+  if (mine) {
+    new_len[g] = len;
+    n_pieces[g] = np;
+  }
+#ifdef IMPG_VU_CLOCKS
+  VU_MARK(7);
+  {
+    const unsigned long long slow = 0ull, regp = __ballot(fast && spilled);
+    const uint32_t nsum = wave_incl_scan(n), smax = 0u;
+    const uint32_t ntot = (uint32_t)__builtin_amdgcn_readlane((int)nsum, 63);
+    if (threadIdx.x == 0 && (blockIdx.x & 15u) == 0u) {  // (every 16th wave)
+      unsigned long long *row = g_vu_clk[(blockIdx.x >> 4) % VU_CLK_ROWS];
+      for (int i = 0; i < 7; i++) atomicAdd(&row[i], vu_t[i + 1] - vu_t[i]);
+      atomicAdd(&row[8], 1ull);
+      atomicAdd(&row[9], slow ? 1ull : 0ull);
+      atomicAdd(&row[10], (unsigned long long)nmax);
+      atomicAdd(&row[11], (unsigned long long)ntot);
+      atomicAdd(&row[12], (unsigned long long)smax);
+      atomicAdd(&row[13], regp ? 1ull : 0ull);
+      if (slow) atomicAdd(&row[14], vu_t[3] - vu_t[2]);
+    }
+  }
+#endif
+  }
 }
+#ifdef IMPG_VU_CLOCKS
+extern "C" void impg_gpu_debug_vu_clocks(unsigned long long *out) {
+  static unsigned long long rows[VU_CLK_ROWS][16];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_vu_clk), sizeof(rows));
+  for (int k = 0; k < 16; k++) { out[k] = 0; for (uint32_t r = 0; r < VU_CLK_ROWS; r++) out[k] += rows[r][k]; }
+  memset(rows, 0, sizeof(rows));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_vu_clk), rows, sizeof(rows));
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // The same replay for groups with long lists or many hits (deep closures: at depth 5 of a window tiling a group
@@ -3097,14 +3273,14 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
   t_next = t0;
   return len;
 }
-template <uint32_t CAP>  // ranges of the list / pieces of the sort that fit the block's LDS (8 bytes each, one buffer for both)
-__global__ __launch_bounds__(64) void visited_update_wave_kernel(VisitedTables vt, const unsigned long long *__restrict__ svals,
+template <uint32_t CAP, bool DEAL = false>  // CAP: ranges of the list / pieces of the sort that fit the block's LDS (8 bytes each, one buffer for both)
+__global__ __launch_bounds__(64) void visited_update_wave_kernel(const unsigned long long *__restrict__ svals,
                                                                  const int32_t *__restrict__ seq_len,
                                                                  const unsigned long long *__restrict__ gkey,
                                                                  const uint32_t *__restrict__ gstart,
                                                                  const uint32_t *__restrict__ glen,
-                                                                 const uint32_t *__restrict__ old_tab,
-                                                                 const uint32_t *__restrict__ old_idx,
+                                                                 const int2 *const *__restrict__ old_src,
+                                                                 const uint32_t *__restrict__ cap,
                                                                  const uint32_t *__restrict__ noff,
                                                                  const uint32_t *__restrict__ poff,
                                                                  const uint32_t *__restrict__ big_list,
@@ -3125,28 +3301,26 @@ __global__ __launch_bounds__(64) void visited_update_wave_kernel(VisitedTables v
   // Groups are handed out one at a time (a counter), not dealt round-robin: a group's replay takes anything from
   // microseconds to milliseconds, and with a fixed deal the launch lasted as long as its unluckiest wave -- the waves of a
   // config-5 level were busy a fifth of the kernel's time.
+  // (DEAL: groups of much the same small size -- the tiny working set -- are dealt round-robin instead: 10^5 of them
+  // fetching their number from ONE counter queued on it for longer than they took to replay)
   __shared__ uint32_t next_b;
-  for (;;) {
-    __syncthreads();  // (everybody has read the previous next_b)
-    if (lane == 0) next_b = atomicAdd(next_group, 1u);
-    __syncthreads();
-    const uint32_t b = next_b;
+  for (uint32_t round = 0;; round++) {
+    uint32_t b;
+    if (DEAL) {
+      b = blockIdx.x + round * gridDim.x;
+    } else {
+      __syncthreads();  // (everybody has read the previous next_b)
+      if (lane == 0) next_b = atomicAdd(next_group, 1u);
+      __syncthreads();
+      b = next_b;
+    }
     if (b >= nb) break;
     const uint32_t g = big_list[from_back ? from_back - 1u - b : b];  // (from_back = n_groups: the list's other end)
     int2 *R = new_ranges + noff[g];
-    const int2 *src = nullptr;
-    uint32_t len = 0;
-    if (old_tab[g] == VISITED_MASK) {
-      const uint32_t a = vt.mask_off[old_idx[g]];
-      len = vt.mask_off[old_idx[g] + 1] - a;
-      src = vt.mask_ranges + a;
-    } else if (old_tab[g] != VISITED_NONE) {
-      const VisitedTable &T = vt.t[old_tab[g]];
-      src = T.ranges + T.off[old_idx[g]];
-      len = T.len[old_idx[g]];
-    }
-    const int32_t sequence_length = seq_len[(uint32_t)(gkey[g] & 0xFFFFFFFFull)];
     const uint32_t st = gstart[g], n = glen[g];
+    const int2 *src = old_src[g];  // (the group's current list, resolved by group_prepare; cap = its length + the hits)
+    uint32_t len = cap[g] - n;
+    const int32_t sequence_length = seq_len[(uint32_t)(gkey[g] & 0xFFFFFFFFull)];
     int2 *P = pieces + poff[g];
     uint32_t np = 0, t_next = 0;
     __syncthreads();  // (the previous group's LDS contents are dead)
@@ -3195,27 +3369,18 @@ __global__ __launch_bounds__(64) void visited_update_wave_kernel(VisitedTables v
 // the list only grows -- so a hit covered by the list as the level FOUND it can be dropped before the sequential replay,
 // by a pass that is parallel over hits instead of over groups.  Deep levels of a saturating closure (BASELINE config 5)
 // are almost all such hits, and the replay of their big groups runs at 5 waves per CU.
-__global__ __launch_bounds__(256) void covered_flags_kernel(VisitedTables vt, const unsigned long long *__restrict__ svals,
+__global__ __launch_bounds__(256) void covered_flags_kernel(const unsigned long long *__restrict__ svals,
                                                             const uint32_t *__restrict__ head, const uint32_t *__restrict__ gid,
                                                             const unsigned long long *__restrict__ gkey,
-                                                            const uint32_t *__restrict__ old_tab, const uint32_t *__restrict__ old_idx,
+                                                            const int2 *const *__restrict__ old_src, const uint32_t *__restrict__ cap,
+                                                            const uint32_t *__restrict__ glen,
                                                             const int32_t *__restrict__ seq_len, uint32_t n_active,
                                                             uint32_t *__restrict__ keep) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n_active) return;
   const uint32_t g = gid[i] + head[i] - 1u;
-  const int2 *src = nullptr;
-  uint32_t len = 0;
-  const uint32_t tab = old_tab[g];
-  if (tab == VISITED_MASK) {
-    const uint32_t a = vt.mask_off[old_idx[g]];
-    len = vt.mask_off[old_idx[g] + 1] - a;
-    src = vt.mask_ranges + a;
-  } else if (tab != VISITED_NONE) {
-    const VisitedTable &T = vt.t[tab];
-    src = T.ranges + T.off[old_idx[g]];
-    len = T.len[old_idx[g]];
-  }
+  const int2 *src = old_src[g];
+  const uint32_t len = cap[g] - glen[g];
   bool covered = false;
   if (len) {
     const int32_t sequence_length = seq_len[(uint32_t)(gkey[g] & 0xFFFFFFFFull)];
@@ -3247,35 +3412,68 @@ __global__ __launch_bounds__(256) void covered_regroup_kernel(const uint32_t *__
   pcap[g] = olen + 2u * (ne - ns);
 }
 
-// groups the lane kernel leaves to the wave kernels, in any order: those that fit the small LDS working set are
-// listed from the front of big_list (count n_big[0]), the others from its back (count n_big[1]); those that fit the
-// tiny one (4 KB: every wave slot of a CU can hold one) in big_list's second half (count n_big[2])
-__global__ __launch_bounds__(256) void big_groups_kernel(const uint32_t *__restrict__ cap, const uint32_t *__restrict__ pcap,
-                                                         uint32_t n_groups, uint32_t *__restrict__ big_list,
-                                                         uint32_t *__restrict__ n_big) {
-  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-  const bool big = g < n_groups && cap[g] > VW_MIN;  // cap = old length + hits of the level (group_prepare)
-  // cap = old + hits, pcap = old + 2 hits  =>  hits = pcap - cap, old = 2 cap - pcap
-  // The small working set is chosen by the list the group STARTS with, not by its worst case (old + hits): hits of a deep
-  // level pile up on the same few regions, the list grows by a fraction of their number, and a list that does outgrow
-  // the buffer moves to its global slice (visited_update_wave_kernel).  Config-5 groups (2 400 hits on a 150-range
-  // list) used to take the 32 KB set, 5 waves per CU, for a replay that is pure LDS latency.
-  const uint32_t old_len = 2u * cap[g] - pcap[g];
-  const bool tiny_ws = big && old_len + VW_TINY_HEADROOM <= VW_CAP_TINY - 64u;
-  const bool small_ws = big && !tiny_ws && old_len + VW_SMALL_HEADROOM <= VW_CAP_SMALL - 64u;
-  const unsigned long long mt = __ballot(tiny_ws), ms = __ballot(small_ws), ml = __ballot(big && !small_ws && !tiny_ws);
-  uint32_t bt = 0, bs = 0, bl = 0;
-  if (lane_id() == 0) {
-    if (mt) bt = atomicAdd(&n_big[2], (uint32_t)__popcll(mt));
-    if (ms) bs = atomicAdd(&n_big[0], (uint32_t)__popcll(ms));
-    if (ml) bl = atomicAdd(&n_big[1], (uint32_t)__popcll(ml));
+// The groups the dense lane kernel does not take, listed by who does (any order inside a list):
+//   big_list[0 ..)                 wave kernel, small LDS working set     (count n_big[0])
+//   big_list[n_groups - 1 .. down) wave kernel, large working set         (count n_big[1])
+//   big_list[n_groups ..)          wave kernel, tiny working set          (count n_big[2])
+//   big_list[2 n_groups ..)        the listed lane kernel (mid groups)    (count n_big[6])
+// A block classifies 4 096 groups and claims its stretch of every list with ONE atomic per list: a wave claiming its
+// own (a third of a headline level's waves hold a listed group) queued 10^5 atomics on one address -- 1.1 ms.
+constexpr uint32_t BG_THREADS = 1024, BG_PER_THREAD = 4;
+__global__ __launch_bounds__(BG_THREADS) void big_groups_kernel(const uint32_t *__restrict__ cap, const uint32_t *__restrict__ pcap,
+                                                                uint32_t n_groups, uint32_t *__restrict__ big_list,
+                                                                uint32_t *__restrict__ n_big) {
+  __shared__ uint32_t cnt[4], base[4];
+  if (threadIdx.x < 4u) cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  uint32_t tier[BG_PER_THREAD], off[BG_PER_THREAD];
+#pragma unroll
+  for (uint32_t k = 0; k < BG_PER_THREAD; k++) {
+    const uint32_t g = (blockIdx.x * BG_PER_THREAD + k) * BG_THREADS + threadIdx.x;
+    const uint32_t c = g < n_groups ? cap[g] : 0u;  // cap = old length + hits of the level (group_prepare)
+    uint32_t t = 0;  // 0: the dense lane kernel's; 1 mid; 2 tiny / 3 small / 4 large working set of the wave kernel
+    if (c > VU_TINY_MAX) {
+      if (c <= VU_MID_MAX) t = 1u;
+      else {
+        // cap = old + hits, pcap = old + 2 hits  =>  old = 2 cap - pcap.  The small working set is chosen by the list
+        // the group STARTS with, not by its worst case: hits of a deep level pile up on the same few regions, the list
+        // grows by a fraction of their number, and a list that does outgrow the buffer moves to its global slice
+        // (visited_update_wave_kernel); the tiny one only takes groups that cannot outgrow it.
+        const uint32_t old_len = 2u * c - pcap[g];
+        t = c + 64u <= VW_CAP_TINY ? 2u : (old_len + VW_SMALL_HEADROOM <= VW_CAP_SMALL - 64u ? 3u : 4u);
+      }
+    }
+    tier[k] = t;
+    off[k] = 0u;
+    if (__ballot(t != 0u)) {
+#pragma unroll
+      for (uint32_t tt = 1; tt <= 4u; tt++) {
+        const unsigned long long m = __ballot(t == tt);
+        if (!m) continue;
+        uint32_t o = 0;
+        if (lane_id() == 0) o = atomicAdd(&cnt[tt - 1u], (uint32_t)__popcll(m));
+        o = (uint32_t)__shfl((int)o, 0);
+        if (t == tt) off[k] = o + (uint32_t)__popcll(m & lanemask_lt());
+      }
+    }
   }
-  bt = (uint32_t)__shfl((int)bt, 0);
-  bs = (uint32_t)__shfl((int)bs, 0);
-  bl = (uint32_t)__shfl((int)bl, 0);
-  if (tiny_ws) big_list[n_groups + bt + (uint32_t)__popcll(mt & lanemask_lt())] = g;  // (the list's second half)
-  else if (small_ws) big_list[bs + (uint32_t)__popcll(ms & lanemask_lt())] = g;
-  else if (big) big_list[n_groups - 1u - (bl + (uint32_t)__popcll(ml & lanemask_lt()))] = g;
+  __syncthreads();
+  if (threadIdx.x < 4u) {
+    const uint32_t slot = threadIdx.x == 0u ? 6u : (threadIdx.x == 1u ? 2u : (threadIdx.x == 2u ? 0u : 1u));
+    base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&n_big[slot], cnt[threadIdx.x]) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < BG_PER_THREAD; k++) {
+    const uint32_t g = (blockIdx.x * BG_PER_THREAD + k) * BG_THREADS + threadIdx.x;
+    const uint32_t t = tier[k];
+    if (!t) continue;
+    const uint32_t pos = base[t - 1u] + off[k];
+    if (t == 1u) big_list[2u * (size_t)n_groups + pos] = g;
+    else if (t == 2u) big_list[(size_t)n_groups + pos] = g;
+    else if (t == 3u) big_list[pos] = g;
+    else big_list[n_groups - 1u - pos] = g;
+  }
 }
 
 __global__ __launch_bounds__(256) void frontier_emit_kernel(const unsigned long long *__restrict__ gkey,
@@ -4099,39 +4297,45 @@ void launch_group_scatter(const unsigned long long *skeys, uint32_t n, const uin
   group_scatter_kernel<<<cdiv(n, 256), 256, 0, s>>>(skeys, n, head, gid, gstart, gkey);
 }
 void launch_group_prepare(const VisitedTables &vt, const unsigned long long *gkey, const uint32_t *gstart,
-                          uint32_t n_groups, uint32_t n_active, uint32_t *glen, uint32_t *old_tab, uint32_t *old_idx,
+                          uint32_t n_groups, uint32_t n_active, uint32_t *glen, const int2 **old_src,
                           uint32_t *cap, uint32_t *pcap, hipStream_t s) {
   if (!n_groups) return;
-  group_prepare_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(vt, gkey, gstart, n_groups, n_active, glen, old_tab, old_idx, cap, pcap);
+  group_prepare_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(vt, gkey, gstart, n_groups, n_active, glen, old_src, cap, pcap);
 }
-void launch_visited_update(const VisitedTables &vt, const unsigned long long *svals, const int32_t *seq_len,
+void launch_visited_update(const unsigned long long *svals, const int32_t *seq_len,
                            const unsigned long long *gkey, const uint32_t *gstart, const uint32_t *glen,
-                           const uint32_t *old_tab, const uint32_t *old_idx, const uint32_t *noff, const uint32_t *poff,
+                           const int2 *const *old_src, const uint32_t *noff, const uint32_t *poff,
                            uint32_t n_groups, int32_t min_transitive_len, int32_t mdbr, int2 *new_ranges,
                            uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, const uint32_t *cap, const uint32_t *pcap,
                            uint32_t *big_list, uint32_t *n_big, hipStream_t s) {
   if (!n_groups) return;
-  (void)hipMemsetAsync(n_big, 0, 24, s);  // three list lengths, three work counters
-  big_groups_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(cap, pcap, n_groups, big_list, n_big);
-  visited_update_kernel<<<cdiv(n_groups, 64), 64, 0, s>>>(vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff,
-                                                          poff, n_groups, min_transitive_len, mdbr, new_ranges, new_len,
-                                                          pieces, n_pieces);
+  (void)hipMemsetAsync(n_big, 0, 32, s);  // three list lengths, three work counters, the mid list's length
+  big_groups_kernel<<<cdiv(n_groups, BG_THREADS * BG_PER_THREAD), BG_THREADS, 0, s>>>(cap, pcap, n_groups, big_list, n_big);
+  const unsigned long long *srcs = reinterpret_cast<const unsigned long long *>(old_src);
+  visited_update_kernel<VU_LDS_CAP, false><<<cdiv(n_groups, 64), 64, 0, s>>>(svals, seq_len, gkey, gstart, glen, srcs, cap, noff, poff, n_groups,
+                                                                             min_transitive_len, mdbr, new_ranges, new_len, pieces, n_pieces,
+                                                                             nullptr, nullptr);
+  // the listed groups: as many blocks as stay resident (their number is on the device), each striding over the list
+  const uint32_t mid_blocks = std::min<uint32_t>(cdiv(n_groups, 64), 256u * std::min(32u, (160u * 1024u) / (VU_MID_CAP * 64u * 8u)));
+  visited_update_kernel<VU_MID_CAP, true><<<mid_blocks, 64, 0, s>>>(svals, seq_len, gkey, gstart, glen, srcs, cap, noff, poff, n_groups,
+                                                                    min_transitive_len, mdbr, new_ranges, new_len, pieces, n_pieces,
+                                                                    big_list + 2u * (size_t)n_groups, n_big + 6);
   // one wave per big group, grid-strided over however many there are (the count stays on the device)
   const uint32_t blocks = std::min<uint32_t>(n_groups, 256u * std::min(32u, (160u * 1024u) / (VW_CAP_SMALL * 8u)));
   visited_update_wave_kernel<VW_CAP_SMALL><<<blocks, 64, 0, s>>>(
-      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list, n_big, n_big + 3, 0u, min_transitive_len, mdbr, new_ranges,
+      svals, seq_len, gkey, gstart, glen, old_src, cap, noff, poff, big_list, n_big, n_big + 3, 0u, min_transitive_len, mdbr, new_ranges,
       new_len, pieces, n_pieces);
-  visited_update_wave_kernel<VW_CAP_TINY><<<std::min<uint32_t>(n_groups, 256u * 32u), 64, 0, s>>>(
-      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list + n_groups, n_big + 2, n_big + 5, 0u, min_transitive_len, mdbr, new_ranges,
+  visited_update_wave_kernel<VW_CAP_TINY, true><<<std::min<uint32_t>(n_groups, 256u * 32u), 64, 0, s>>>(
+      svals, seq_len, gkey, gstart, glen, old_src, cap, noff, poff, big_list + n_groups, n_big + 2, n_big + 5, 0u, min_transitive_len, mdbr, new_ranges,
       new_len, pieces, n_pieces);
   visited_update_wave_kernel<VW_CAP_LARGE><<<std::min<uint32_t>(n_groups, 256u * 5u), 64, 0, s>>>(
-      vt, svals, seq_len, gkey, gstart, glen, old_tab, old_idx, noff, poff, big_list, n_big + 1, n_big + 4, n_groups, min_transitive_len, mdbr,
+      svals, seq_len, gkey, gstart, glen, old_src, cap, noff, poff, big_list, n_big + 1, n_big + 4, n_groups, min_transitive_len, mdbr,
       new_ranges, new_len, pieces, n_pieces);
 }
-void launch_covered_flags(const VisitedTables &vt, const unsigned long long *svals, const uint32_t *head, const uint32_t *gid,
-                          const unsigned long long *gkey, const uint32_t *old_tab, const uint32_t *old_idx, const int32_t *seq_len,
-                          uint32_t n_active, uint32_t *keep, hipStream_t s) {
-  if (n_active) covered_flags_kernel<<<cdiv(n_active, 256), 256, 0, s>>>(vt, svals, head, gid, gkey, old_tab, old_idx, seq_len, n_active, keep);
+void launch_covered_flags(const unsigned long long *svals, const uint32_t *head, const uint32_t *gid,
+                          const unsigned long long *gkey, const int2 *const *old_src, const uint32_t *cap, const uint32_t *glen,
+                          const int32_t *seq_len, uint32_t n_active, uint32_t *keep, hipStream_t s) {
+  if (n_active) covered_flags_kernel<<<cdiv(n_active, 256), 256, 0, s>>>(svals, head, gid, gkey, old_src, cap, glen, seq_len, n_active, keep);
 }
 void launch_covered_compact(const unsigned long long *svals, const uint32_t *keep, const uint32_t *kpos, uint32_t n_active,
                             unsigned long long *out, uint32_t n_kept, uint32_t n_groups, uint32_t *gstart, uint32_t *glen, uint32_t *cap,

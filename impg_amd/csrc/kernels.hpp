@@ -49,7 +49,6 @@ struct VisitedTables {
   const uint32_t *mask_off;
   const int2 *mask_ranges;
 };
-constexpr uint32_t VISITED_NONE = 0xFFFFFFFFu, VISITED_MASK = 0xFFFFFFFEu;  // old_tab values that name no table
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
                          uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place = false,
@@ -142,18 +141,18 @@ void launch_group_heads(const unsigned long long *skeys, uint32_t n, uint32_t *h
 void launch_group_scatter(const unsigned long long *skeys, uint32_t n, const uint32_t *head, const uint32_t *gid,
                           uint32_t *gstart, unsigned long long *gkey, hipStream_t s);
 void launch_group_prepare(const VisitedTables &vt, const unsigned long long *gkey, const uint32_t *gstart,
-                          uint32_t n_groups, uint32_t n_active, uint32_t *glen, uint32_t *old_tab, uint32_t *old_idx,
+                          uint32_t n_groups, uint32_t n_active, uint32_t *glen, const int2 **old_src,
                           uint32_t *cap, uint32_t *pcap, hipStream_t s);
-void launch_visited_update(const VisitedTables &vt, const unsigned long long *svals, const int32_t *seq_len,
+void launch_visited_update(const unsigned long long *svals, const int32_t *seq_len,
                            const unsigned long long *gkey, const uint32_t *gstart, const uint32_t *glen,
-                           const uint32_t *old_tab, const uint32_t *old_idx, const uint32_t *noff, const uint32_t *poff,
+                           const int2 *const *old_src, const uint32_t *noff, const uint32_t *poff,
                            uint32_t n_groups, int32_t min_transitive_len, int32_t mdbr, int2 *new_ranges,
                            uint32_t *new_len, int2 *pieces, uint32_t *n_pieces, const uint32_t *cap, const uint32_t *pcap,
                            uint32_t *big_list, uint32_t *n_big, hipStream_t s);
 // hits covered by their group's old list dropped before the replay (kernels.hip "covered_flags")
-void launch_covered_flags(const VisitedTables &vt, const unsigned long long *svals, const uint32_t *head, const uint32_t *gid,
-                          const unsigned long long *gkey, const uint32_t *old_tab, const uint32_t *old_idx, const int32_t *seq_len,
-                          uint32_t n_active, uint32_t *keep, hipStream_t s);
+void launch_covered_flags(const unsigned long long *svals, const uint32_t *head, const uint32_t *gid,
+                          const unsigned long long *gkey, const int2 *const *old_src, const uint32_t *cap, const uint32_t *glen,
+                          const int32_t *seq_len, uint32_t n_active, uint32_t *keep, hipStream_t s);
 void launch_covered_compact(const unsigned long long *svals, const uint32_t *keep, const uint32_t *kpos, uint32_t n_active,
                             unsigned long long *out, uint32_t n_kept, uint32_t n_groups, uint32_t *gstart, uint32_t *glen, uint32_t *cap,
                             uint32_t *pcap, hipStream_t s);

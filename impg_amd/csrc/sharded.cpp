@@ -832,6 +832,14 @@ void sharded_bed_batch(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_
   if (seconds3) for (int k = 0; k < 3; k++) { seconds3[k] = 0; for (auto &x : secs) seconds3[k] = std::max(seconds3[k], x[k]); }
 }
 
+uint64_t shard_agree_max(impg_gpu_index &ix, uint64_t mine) {
+  if (!ix.shard) return mine;
+  ShardCtx &S = *ix.shard;
+  std::vector<uint64_t> all((size_t)S.comm->world);
+  S.comm->lanes[0]->allgather_u64(&mine, 1, all.data());
+  return *std::max_element(all.begin(), all.end());
+}
+
 int sharded_query_batch(impg_gpu_index &ix, const impg_gpu_range_t *ranges, size_t n, const impg_gpu_params_t &p,
                         const impg_gpu_mask_t *mask, const uint8_t *subset_keep, impg_gpu_results **out) {
   if (mask && !p.transitive) throw Error{IMPG_E_INVALID, "masked_regions belong to the transitive queries"};

@@ -208,9 +208,12 @@ int impg_gpu_index_approximate(const impg_gpu_index_t *);
  * that keep no level -- impg_gpu_query_batch_stats -- lay their hit slots out in
  * that order too; 0: always the reference's slot order; counts and checksums are
  * identical either way),
- * "walk_kernel" (the per-query walk: 0 never, 1 -- the default -- DFS batches of any size and depth-limited BFS batches of
- * <= 32 ranges, 2 also every BFS batch of <= 64 ranges) and "walk_members" (workgroups per query of
- * the walk's grid form, which shares a depth-limited BFS's last level out: 0 = as many as fit, at most 32; 1 = none),
+ * "walk_kernel" (the per-query walk: 0 never, 1 -- the default -- DFS batches of any size and those depth-limited
+ * (max_depth >= 2) BFS batches of <= 64 ranges that get at least two workgroups a query out of the launch's share of
+ * the compute units -- CUs / max_engines, i.e. <= 32 ranges on a 256-CU device with four engines a handle --, 2 also
+ * every other BFS batch of <= 64 ranges) and "walk_members" (workgroups per query of the walk's grid form, which
+ * shares a depth-limited BFS's last level out: 0 = as many as fit the share, at most 32; N > 1 = at most N, itself at
+ * most 64; 1 = none),
  * "segment_groups" (1, the default: the visited update orders a level's hits by (query, hit sequence) query by query --
  * a query's ranges run by run in frontier order, a counting sort by sequence inside the query; 0: with the library's
  * stable radix sort; results are identical either way),

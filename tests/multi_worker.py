@@ -110,6 +110,23 @@ def main():
             assert res[i].tolist() == want.tolist(), (rank, i, kw)
             got = res.cigars(i)
             assert [x.tolist() for x in got] == [x.tolist() for x in wcg], (rank, i, kw)
+    # the row stream on a rank's shard: every chunk is a collective and the ranks bring different n (one none at all), so
+    # they agree on the number of calls first; a rank whose consumer stops the stream keeps serving its peers' hops
+    kw = dict(transitive=True, max_depth=2, min_transitive_len=40)
+    p = impg_amd.make_params(**kw)
+    seen = []
+    proj = g.query_batch_stream(rl, lambda first, part: seen.append((first, [part[i].tolist() for i in range(len(part))])) and False,
+                                p, chunk_ranges=5)
+    flat = [rows for _, parts in seen for rows in parts]
+    assert [f for f, _ in seen] == list(range(0, len(rl), 5)), (rank, [f for f, _ in seen])
+    assert flat == [c.query(t, s, e, **kw).tolist() for t, s, e in rl], rank
+    stopper = world - 1  # (the rank with the most ranges: its peers have long run out when it stops)
+    calls = []
+    g.query_batch_stream(rl, lambda first, part: calls.append(first) or (rank == stopper and len(calls) == 2), p, chunk_ranges=5)
+    assert calls == (list(range(0, len(rl), 5))[:2] if rank == stopper else list(range(0, len(rl), 5))), (rank, calls)
+    got = g.query_batch(rl, p)  # (and the handle still answers, in step with its peers)
+    for i, (t, s, e) in enumerate(rl):
+        assert got[i].tolist() == c.query(t, s, e, **kw).tolist(), (rank, i, "after the stopped stream")
     # the rank's shard saved and loaded back on the same communicator (one file per rank): same answers, no PAF needed
     saved = "%s.rank%dof%d.idx" % (paf_path, rank, world)
     g.save(saved)

@@ -1,8 +1,8 @@
 """BASELINE configs 4 and 5 on one MI355X.
 
 Config 4 (HPRC scale): the synthetic generator at 20 000 sequences, index built straight from impg_synth_paf
-records (no PAF text).  Default 5 x 10^7 records (85 GB of index; IMPG_CONFIG4_RECORDS overrides, 10^8 fits one
-288 GB MI355X).  The oracle cannot hold an index of this size in the time a test has, so the checks at full size
+records (no PAF text).  Default 2 x 10^7 records in the suite (the driver's run has a time limit; scripts/final_r5.sh
+runs this test at IMPG_CONFIG4_RECORDS=5e7 -- 162 GB of index -- and records it under profiles/; 10^8 fits one 288 GB MI355X).  The oracle cannot hold an index of this size in the time a test has, so the checks at full size
 are: (a) non-transitive results of a sample of ranges against a brute-force scan of the record arrays with every
 projection done by the oracle's project_target_range_through_alignment; (b) -x -m 3 over 100 000 ranges is
 invariant under re-chunking; (c) the same batch on the index sharded three ways (multi handle) gives identical
@@ -78,7 +78,7 @@ def oracle_on_subset(rec, ops, ranges_2hop, n_seq, seq_len):
 
 
 def test_config4_hprc_scale_index():
-    records = int(float(os.environ.get("IMPG_CONFIG4_RECORDS", "5e7")))
+    records = int(float(os.environ.get("IMPG_CONFIG4_RECORDS", "2e7")))
     rec, ops, sl = impg_amd.synth_paf(42, records, n_seq=N_SEQ4, seq_len=SEQ_LEN)
     g = impg_amd.GpuImpg.from_records(rec, ops, sl)
     assert g.num_entries() == 2 * records and g.num_seqs() == N_SEQ4
@@ -98,7 +98,7 @@ def test_config4_hprc_scale_index():
         assert sorted(got.tolist()) == sorted(want.tolist()), i
         assert int(cnt0[i]) == len(want) and int(ck0[i]) == checksum(want), i
         seen += len(want)
-    assert seen > 50
+    assert seen > 30
     # (a') transitive, two hops, exact: the oracle on every record the walk can touch (found by brute force over the
     # arrays), against an index of ALL records under the sorted visit order
     gs = impg_amd.GpuImpg.from_records(rec, ops, sl, order=impg_amd.ORDER_SORTED)

@@ -46,13 +46,18 @@ def full(tmp_path_factory):
     return paf, g, ranges
 
 
-def test_headline_config_sample_vs_oracle(full):
+@pytest.fixture(scope="module")
+def oracle_ix(full):
+    return o.OracleIndex(paf_paths=[full[0]], preparse=False)  # pread + parse per hit, like the reference
+
+
+def test_headline_config_sample_vs_oracle(full, oracle_ix):
     paf, g, ranges = full
     p = impg_amd.make_params(transitive=True, max_depth=3)
     g.set_option("chunk_ranges", 2048)
     st, cnt, ck = g.query_batch_stats(ranges, p)
     assert st.levels == 3 and st.projected > 10_000 * len(ranges)
-    c = o.OracleIndex(paf_paths=[paf], preparse=False)  # pread + parse per hit, like the reference
+    c = oracle_ix
     rng = np.random.default_rng(1)
     sample = sorted(set(rng.integers(0, len(ranges), 70).tolist()) | {0, len(ranges) - 1})  # (>= 64 ranges: ~1.4e6 projections)
     total = 0
@@ -82,11 +87,11 @@ def test_chunking_and_repeat_invariance(full):
     assert (cnt1 == cnt3).all() and (ck1 == ck3).all()
 
 
-def test_nontransitive_full_results_sample(full):
+def test_nontransitive_full_results_sample(full, oracle_ix):
     """BASELINE config 2 (no transitive): full results through the C ABI for a
     slice of the batch, every interval compared with the oracle."""
     paf, g, ranges = full
-    c = o.OracleIndex(paf_paths=[paf], preparse=False)
+    c = oracle_ix
     sub = ranges[:200]
     res = g.query_batch(sub, impg_amd.make_params())
     for i in range(200):  # all of them
@@ -96,16 +101,73 @@ def test_nontransitive_full_results_sample(full):
     assert res.projected == sum(len(res[i]) - 1 for i in range(200))
 
 
-def test_headline_batch_prefix_consistency(full):
-    """The headline batch itself (100 000 ranges, -x -m 3): queries are independent, so the first 4 096 ranges of the
-    full batch must give exactly the per-range counts and checksums the 4 096-range batch gives (which the oracle
-    sample above pins), whatever chunks, lookup orders and slot layouts the big batch runs through; and the whole
-    batch's total is the sum of its per-range counts."""
+@pytest.fixture(scope="module")
+def big_batch(full):
     paf, g, ranges = full
     bed = impg_amd.synth_bed(7, 100_000)
     big = np.zeros(len(bed), dtype=impg_amd.RANGE_DTYPE)
     big["target_id"] = [g.seq_id(impg_amd.synth_seq_name(int(t))) for t in bed["target_id"]]
     big["start"], big["end"] = bed["start"], bed["end"]
+    return big
+
+
+def test_headline_timed_form(full, big_batch):
+    """The form bench.py times -- query_batch_stats(counts=False, checksums=False) on the 100 000 ranges as ONE chunk under a
+    pair budget of 3 x 2^30, whose final level is the fused, entry-ordered one with no per-range output at all -- gives
+    the projections the counting form gives (whose per-range counts and checksums the oracle sample and the prefix test
+    pin), and that number is the constant bench.py's self check asserts inside the timed region."""
+    import bench
+    paf, g, ranges = full
+    p = impg_amd.make_params(transitive=True, max_depth=3)
+    g.set_option("chunk_ranges", 100_000)
+    g.set_option("pair_budget", 3 << 30)
+    try:
+        st_timed, _, _ = g.query_batch_stats(big_batch, p, counts=False, checksums=False)
+        st_again, _, _ = g.query_batch_stats(big_batch, p, counts=False, checksums=False)
+        st_cnt, cnt, ck = g.query_batch_stats(big_batch, p)
+    finally:
+        g.set_option("pair_budget", 1 << 29)
+        g.set_option("chunk_ranges", 4096)
+    assert st_timed.levels == 3
+    assert st_timed.projected == st_again.projected == st_cnt.projected == int(cnt.sum())
+    assert st_timed.projected == bench.HEADLINE_PROJECTED
+    assert st_timed.pairs == st_cnt.pairs and st_timed.frontier_ranges == st_cnt.frontier_ranges
+
+
+def test_headline_ordered_rows_and_bed_vs_oracle(full, oracle_ix):
+    """Ordered rows at the headline index: `-x -m 3` through impg_gpu_query_batch (coitrees visit order, ~10 000 entries a
+    target) row for row against the oracle for a sample of ranges, and the BED text of `-d 1000` byte for byte.  The
+    count + checksum tests above cannot see an emission-order defect; this one can (impg.rs:2471-2560)."""
+    paf, g, ranges = full
+    c = oracle_ix
+    rng = np.random.default_rng(5)
+    sample = sorted(set(rng.integers(0, len(ranges), 10).tolist()) | {1, len(ranges) - 2})
+    assert len(sample) >= 8
+    sub = ranges[sample]
+    kw = dict(transitive=True, max_depth=3)
+    p = impg_amd.make_params(**kw)
+    res = g.query_batch(sub, p)
+    rows = 0
+    for k in range(len(sub)):
+        r = sub[k]
+        want = c.query(int(r["target_id"]), int(r["start"]), int(r["end"]), **kw)
+        assert res[k].tolist() == want.tolist(), sample[k]
+        rows += len(want)
+    assert rows > 150_000
+    got = res.bed(None, merge_distance=1000, params=p)
+    want = "".join(c.query_bed(g.seq_name(int(r["target_id"])), int(r["start"]), int(r["end"]), merge_distance=1000, **kw) for r in sub)
+    assert got == want
+    dev = g.query_batch_bed(sub, p, merge_distance=1000)
+    assert dev == want
+
+
+def test_headline_batch_prefix_consistency(full, big_batch):
+    """The headline batch itself (100 000 ranges, -x -m 3): queries are independent, so the first 4 096 ranges of the
+    full batch must give exactly the per-range counts and checksums the 4 096-range batch gives (which the oracle
+    sample above pins), whatever chunks, lookup orders and slot layouts the big batch runs through; and the whole
+    batch's total is the sum of its per-range counts."""
+    paf, g, ranges = full
+    big = big_batch
     assert (big[:len(ranges)] == ranges).all()  # (the generator is a prefix-stable stream)
     p = impg_amd.make_params(transitive=True, max_depth=3)
     g.set_option("chunk_ranges", 2048)

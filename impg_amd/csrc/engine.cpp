@@ -310,6 +310,22 @@ uint64_t Engine::scan(const uint32_t *in, uint32_t *out, uint32_t n) {
   return read_counter(3);
 }
 
+void Engine::scan2(const uint32_t *in_a, uint32_t *out_a, const uint32_t *in_b, uint32_t *out_b, uint32_t n, uint64_t &total_a, uint64_t &total_b,
+                   const uint32_t *d_extra, uint32_t *h_extra, uint32_t n_extra) {
+  total_a = total_b = 0;
+  if (n) {
+    scan_tmp.reserve(scan_scratch_bytes(n));
+    scan_tmp2.reserve(scan_scratch_bytes(n));
+    launch_exclusive_scan(in_a, out_a, n, scan_tmp.as<unsigned long long>(), counters.as<unsigned long long>() + 12, stream);
+    launch_exclusive_scan(in_b, out_b, n, scan_tmp2.as<unsigned long long>(), counters.as<unsigned long long>() + 13, stream);
+    IMPG_HIP(hipMemcpyAsync(h_counters, counters.as<uint64_t>() + 12, 16, hipMemcpyDeviceToHost, stream));
+  }
+  if (n_extra) IMPG_HIP(hipMemcpyAsync(h_counters + 2, d_extra, (size_t)n_extra * 4, hipMemcpyDeviceToHost, stream));
+  IMPG_HIP(hipStreamSynchronize(stream));
+  if (n) { total_a = h_counters[0]; total_b = h_counters[1]; }
+  if (n_extra) memcpy(h_extra, h_counters + 2, (size_t)n_extra * 4);
+}
+
 static HitArrays hit_arrays(LevelBufs &L, uint32_t n_pairs) {
   size_t b = std::max<size_t>((size_t)n_pairs * 4, 256);
   L.qid.reserve(b); L.coords.reserve(4 * b);
@@ -524,11 +540,13 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       if (bb <= (512ull << 20)) { seg_bins.reserve(std::max<size_t>(bb, 256)); sg_bins = seg_bins.as<uint32_t>(); }  // (kept for the place pass)
       launch_seg_group(true, fr, qfirst, qlast, sg_run_start, sg_run_end, h, n_queries, v.n_seq, qact, qdst, qgrp, gdst, nullptr, nullptr, nullptr, sg_bins,
                        stream);
-      seg_active = (uint32_t)scan(qact, qdst, n_queries);  // (synchronises)
+      // both scans and the kernels' two flags behind one synchronisation (the place pass runs below, once the groups' arrays exist)
+      uint64_t ta = 0, tg = 0;
       uint32_t bad[2] = {0, 0};
-      IMPG_HIP(hipMemcpy(bad, unsorted, 8, hipMemcpyDeviceToHost));
+      scan2(qact, qdst, qgrp, gdst, n_queries, ta, tg, unsorted, bad, 2);
+      seg_active = (uint32_t)ta;
       if (bad[0] || bad[1]) by_segments = false;  // a frontier that is not sorted by query, or one huge query: the library sort below
-      else seg_groups = (uint32_t)scan(qgrp, gdst, n_queries);  // (the place pass runs below, once the groups' arrays exist)
+      else seg_groups = (uint32_t)tg;
     }
     if (!by_segments) {
       keys.reserve((size_t)P * 8); skeys.reserve((size_t)P * 8); vals.reserve((size_t)P * 8);
@@ -634,8 +652,8 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       }
       vt->off.reserve((size_t)n_groups * 4);
       poff.reserve((size_t)n_groups * 4);
-      uint64_t cap_total = scan(cap.as<uint32_t>(), vt->off.as<uint32_t>(), n_groups);
-      uint64_t pcap_total = scan(pcap.as<uint32_t>(), poff.as<uint32_t>(), n_groups);
+      uint64_t cap_total = 0, pcap_total = 0;
+      scan2(cap.as<uint32_t>(), vt->off.as<uint32_t>(), pcap.as<uint32_t>(), poff.as<uint32_t>(), n_groups, cap_total, pcap_total);
       if (cap_total >= 0xFFFFFFF0ull || pcap_total >= 0xFFFFFFF0ull)
         { if (split_ok) throw SplitBatch{}; throw Error{IMPG_E_UNSUPPORTED, "visited sets exceed 2^32 ranges"}; }
       vt->ranges.reserve(std::max<size_t>(cap_total * 8, 256));
@@ -657,6 +675,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       launch_frontier_emit(vt->keys.as<unsigned long long>(), poff.as<uint32_t>(), n_pieces.as<uint32_t>(),
                            foff.as<uint32_t>(), n_groups, pieces.as<int2>(), next_frontier.as<FrontierRec>(), stream);
       vt->n_groups = n_groups;
+      index_table(*vt);
       tables.push_back(std::move(vt));
       if (tables.size() + 2 >= (size_t)MAX_VISITED_TABLES) compact_tables();
     }
@@ -664,6 +683,11 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
   IMPG_HIP(hipEventRecord(e1, stream));
   timed.push_back({e0, e1, 2});
   return n_next;
+}
+
+void Engine::index_table(VisitedStore &t) {
+  t.qoff.reserve(((size_t)table_queries + 1) * 4);
+  launch_table_qoff(t.keys.as<unsigned long long>(), t.n_groups, table_queries, t.qoff.as<uint32_t>(), stream);
 }
 
 VisitedTables Engine::tables_view() const {
@@ -675,6 +699,7 @@ VisitedTables Engine::tables_view() const {
     t.t[i].off = tables[i]->off.as<uint32_t>();
     t.t[i].len = tables[i]->len.as<uint32_t>();
     t.t[i].ranges = tables[i]->ranges.as<int2>();
+    t.t[i].qoff = tables[i]->qoff.as<uint32_t>();
     t.t[i].n_groups = tables[i]->n_groups;
   }
   if (masked) {
@@ -697,6 +722,8 @@ uint32_t Engine::begin_transitive(const DeviceIndexView &v, const impg_gpu_range
   uint32_t n_fr = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), n);
   frontier_out.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
   launch_compact_frontier(d_self, head.as<uint32_t>(), gid.as<uint32_t>(), n, frontier_out.as<FrontierRec>(), stream);
+  table_queries = n;
+  index_table(*t);
   tables.push_back(std::move(t));
   return n_fr;
 }
@@ -728,6 +755,8 @@ uint32_t Engine::begin_transitive_masked(const DeviceIndexView &v, const impg_gp
   launch_masked_self_emit(d_ranges, n, t->off.as<uint32_t>(), n_pieces.as<uint32_t>(), self_off.as<uint32_t>(),
                           gid.as<uint32_t>(), p.min_transitive_len, pieces.as<int2>(), self.as<FrontierRec>(),
                           frontier_out.as<FrontierRec>(), stream);
+  table_queries = n;
+  index_table(*t);
   tables.push_back(std::move(t));
   return n_fr;
 }
@@ -904,6 +933,7 @@ void Engine::compact_tables() {
   launch_compact_copy(tv, d_src.as<unsigned long long>(), nt->off.as<uint32_t>(), nt->len.as<uint32_t>(), g2,
                       nt->ranges.as<int2>(), stream);
   nt->n_groups = g2;
+  index_table(*nt);
   IMPG_HIP(hipStreamSynchronize(stream));  // the old tables are read by the copy above
   tables.clear();
   tables.push_back(std::move(nt));

@@ -23,9 +23,9 @@ struct LevelBufs {  // one BFS level: its frontier and its hit slots
   }
 };
 struct VisitedStore {  // device storage of one VisitedTable
-  DevBuf keys, off, len, ranges;
+  DevBuf keys, off, len, ranges, qoff;
   uint32_t n_groups = 0;
-  explicit VisitedStore(BufPool *pool) { keys.pool = off.pool = len.pool = ranges.pool = pool; }
+  explicit VisitedStore(BufPool *pool) { keys.pool = off.pool = len.pool = ranges.pool = qoff.pool = pool; }
 };
 
 struct SplitBatch {};  // thrown when a level exceeds pair_budget: the caller halves the chunk
@@ -66,11 +66,13 @@ struct Engine {
   std::vector<Timed> timed;
   // scratch, grown on demand and reused across calls
   DevBuf big_list;  // groups of a level whose visited list gets a whole wave
-  DevBuf cnt, win, pair_off, pair_entry, scan_tmp, keys, skeys, vals, svals, sort_tmp, head, gid, gstart, glen, old_src,
+  DevBuf cnt, win, pair_off, pair_entry, scan_tmp, scan_tmp2, keys, skeys, vals, svals, sort_tmp, head, gid, gstart, glen, old_src,
       cap, pcap, poff, pieces, n_pieces, foff, frontier_a, frontier_b, self_scratch, ranges_dev, stat_count,
       stat_cksum, stage_off;
   LevelBufs level_scratch;
   std::vector<std::unique_ptr<VisitedStore>> tables;
+  uint32_t table_queries = 0;  // queries of the batch the tables belong to (their qoff arrays have one entry more)
+  void index_table(VisitedStore &t);  // qoff[] of a table whose keys are in place
   uint64_t last_projected = 0;
   uint64_t pair_budget = 1ull << 28;  // candidate pairs per level kept in HBM at once
   uint32_t chunk_ranges = 0;          // ranges per chunk (0 = try the whole batch)
@@ -110,6 +112,9 @@ struct Engine {
   hipEvent_t event();
   uint64_t read_counter(int k);
   uint64_t scan(const uint32_t *in, uint32_t *out, uint32_t n);
+  // two scans over n items each and up to four extra device words (a kernel's flags) behind ONE synchronisation
+  void scan2(const uint32_t *in_a, uint32_t *out_a, const uint32_t *in_b, uint32_t *out_b, uint32_t n, uint64_t &total_a, uint64_t &total_b,
+             const uint32_t *d_extra = nullptr, uint32_t *h_extra = nullptr, uint32_t n_extra = 0);
   // lookup / projection order (locality): lookup_order() before the count pass gives the permutation (null
   // when not worth it); projection_offsets() after the scan gives every range's first place in slot_of
   // blocks (optional, the owner side of a sharded counting hop): the records are n_blocks contiguous blocks, one per

@@ -1830,6 +1830,13 @@ static_assert((ENT_REC_V4 + ENT_LIST_V4) * 4u >= 5u * ENT_THREADS + ENT_WAVES, "
 #else
 #define ENT_OCCUPANCY
 #endif
+// (Round 5, measured and dropped: a fast path without the second candidate test -- the neighbouring op chosen up front by two
+// comparisons when the located op only touches the threshold, ~2 % of ends; the 0.1 % of pairs that still fail listed in
+// LDS and projected 64 at a time by the general form at one place of a flattened (entry, chunk) loop.  Exact -- every test
+// green with IMPG_STAGE_DENSITY=0 -- and 8 KB less code, but 374 VALU per 64 pairs where this form runs 338
+// (SQ_INSTS_VALU): the flat loop alone, with the old two-candidate search, costs the same 21.9 -> 23.6 ms -- carried
+// around it the entry's sixteen scalar words and the chunk counters spill to vector lanes -- and the second test, which
+// only 60 % of the chunks execute at all, is worth what the choice costs.)
 template <bool TRANSITIVE, int ORIENT>
 __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, uint4 e0, uint4 e1, uint4 e2, uint4 e3, uint32_t eidx, bool live,
                                                     int32_t f_start, int32_t f_end, uint32_t p, const uint32_t *rec, const HitArrays &h,
@@ -2568,6 +2575,11 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const unsigned long long *a,
   return lo;
 }
 
+__global__ __launch_bounds__(256) void table_qoff_kernel(const unsigned long long *__restrict__ keys, uint32_t n_groups, uint32_t n_queries,
+                                                         uint32_t *__restrict__ qoff) {
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q <= n_queries) qoff[q] = lower_bound_u64(keys, n_groups, (unsigned long long)q << 32);
+}
 // per group: run length, the group's current visited list (newest table that
 // holds the key; its length is cap - glen), capacities for the new list and for the pieces.
 // The list is handed on as a POINTER: the update kernels used to resolve (table, index) themselves -- a dynamic index
@@ -2588,10 +2600,14 @@ __global__ __launch_bounds__(256) void group_prepare_kernel(VisitedTables vt, co
   const int2 *src = nullptr;
   uint32_t olen = 0;
   bool found = false;
+  const uint32_t q = (uint32_t)(k >> 32);
   for (int t = (int)vt.n_tables - 1; t >= 0; t--) {
     const VisitedTable &T = vt.t[t];
-    uint32_t i = lower_bound_u64(T.keys, T.n_groups, k);
-    if (i < T.n_groups && T.keys[i] == k) {
+    // (among the query's own keys: a handful of steps instead of log2 of the whole table -- 22 dependent reads on a
+    // headline level's 2.8 x 10^6-key table)
+    const uint32_t lo = T.qoff[q], hi = T.qoff[q + 1u];
+    const uint32_t i = lo + lower_bound_u64(T.keys + lo, hi - lo, k);
+    if (i < hi && T.keys[i] == k) {
       src = T.ranges + T.off[i];
       olen = T.len[i];
       found = true;
@@ -2653,7 +2669,7 @@ constexpr uint32_t VU_LDS_CAP = IMPG_VU_LDS_CAP;
 //                       17..64 hits, replayed in place on its global slice: two thirds of all wave cycles, round 4)
 //   beyond              visited_update_wave_kernel: a wave per group (three LDS sizes)
 #ifndef IMPG_VU_TINY_MAX
-#define IMPG_VU_TINY_MAX 9
+#define IMPG_VU_TINY_MAX 12
 #endif
 #ifndef IMPG_VU_MID_MAX
 #define IMPG_VU_MID_MAX 48
@@ -4295,6 +4311,9 @@ void launch_group_scatter(const unsigned long long *skeys, uint32_t n, const uin
                           uint32_t *gstart, unsigned long long *gkey, hipStream_t s) {
   if (!n) return;
   group_scatter_kernel<<<cdiv(n, 256), 256, 0, s>>>(skeys, n, head, gid, gstart, gkey);
+}
+void launch_table_qoff(const unsigned long long *keys, uint32_t n_groups, uint32_t n_queries, uint32_t *qoff, hipStream_t s) {
+  table_qoff_kernel<<<cdiv((uint64_t)n_queries + 1, 256), 256, 0, s>>>(keys, n_groups, n_queries, qoff);
 }
 void launch_group_prepare(const VisitedTables &vt, const unsigned long long *gkey, const uint32_t *gstart,
                           uint32_t n_groups, uint32_t n_active, uint32_t *glen, const int2 **old_src,

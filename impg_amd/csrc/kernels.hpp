@@ -35,6 +35,7 @@ struct VisitedTable {
   const unsigned long long *keys;  // sorted unique (qidx << 32 | sequence id)
   const uint32_t *off, *len;       // into ranges
   const int2 *ranges;              // sorted disjoint (start,end) per key
+  const uint32_t *qoff;            // [n_queries + 1] first key of every query (table_qoff_kernel): a key is searched among its query's only
   uint32_t n_groups;
 };
 constexpr int MAX_VISITED_TABLES = 48;
@@ -140,6 +141,8 @@ void launch_group_fill(const unsigned long long *skeys, uint32_t n, const uint32
 void launch_group_heads(const unsigned long long *skeys, uint32_t n, uint32_t *head, hipStream_t s);
 void launch_group_scatter(const unsigned long long *skeys, uint32_t n, const uint32_t *head, const uint32_t *gid,
                           uint32_t *gstart, unsigned long long *gkey, hipStream_t s);
+// qoff[q] = first key of table `keys` whose query index is >= q, q = 0 .. n_queries
+void launch_table_qoff(const unsigned long long *keys, uint32_t n_groups, uint32_t n_queries, uint32_t *qoff, hipStream_t s);
 void launch_group_prepare(const VisitedTables &vt, const unsigned long long *gkey, const uint32_t *gstart,
                           uint32_t n_groups, uint32_t n_active, uint32_t *glen, const int2 **old_src,
                           uint32_t *cap, uint32_t *pcap, hipStream_t s);

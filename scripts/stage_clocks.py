@@ -44,7 +44,8 @@ def main():
     out = {"staged_blocks_sampled": int(n), "unstaged_blocks_sampled": int(nf),
            "span_of_staged_block": buf[11] / max(n, 1), "span_of_unstaged_block": buf[12] / max(nf, 1),
            "cycles_per_unstaged_block": buf[13] / max(nf, 1),
-           "pairs_per_staged_block": buf[9] / max(n, 1), "staged_blocks_wider_than_the_buffer": buf[10] / max(n, 1),
+           "pairs_per_staged_block": buf[9] / max(n, 1), "pairs_listed_for_the_general_form": int(buf[8]),
+           "listed_share_of_pairs": buf[8] / max(buf[9], 1), "staged_blocks_wider_than_the_buffer": buf[10] / max(n, 1),
            "phases": [{"phase": NAMES[i], "cycles_per_block": buf[i] / max(n, 1)} for i in range(3)],
            "projected": int(st.projected), "ms_project": st.ms_project}
     print(json.dumps(out, indent=1))

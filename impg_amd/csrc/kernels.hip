@@ -2650,6 +2650,17 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
 #define IMPG_VU_LDS_CAP 16
 #endif
 constexpr uint32_t VU_LDS_CAP = IMPG_VU_LDS_CAP;
+// IMPG_VW_WINDOWS = 1: every hit of a batch that meets no earlier one takes its turn at once (replay_hits_wave).  Exact -- the
+// suite and the config-5 tiling test are green with it -- and measured SLOWER: config 5, 4 000 windows, update 629 -> 1 045 ms.
+// Two passes over a ~1 000-range list per batch and 5 KB more LDS a wave (10 waves a CU instead of 17) cost more than the ~25
+// hits a batch it frees from the sequential part save.  0 (the default): round 3's two classes.
+#ifndef IMPG_VW_WINDOWS
+#define IMPG_VW_WINDOWS 0
+#endif
+#ifndef IMPG_VW_WINDOW
+#define IMPG_VW_WINDOW 4   // ranges a hit may start in / swallow and still take its turn on a private copy
+#endif
+constexpr uint32_t VW_WINDOW = IMPG_VW_WINDOW;
 // groups whose list can outgrow this get a whole wave (visited_update_wave_kernel below)
 // two sizes of LDS working set (9 KB: 17 waves per CU; 32 KB: 5): groups with few hits and a short list take the small one
 #ifndef IMPG_VW_TINY
@@ -3090,8 +3101,10 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
                                                      uint32_t &t_next, uint32_t list_cap) {
   const bool writer = lane_id() == 0;
   const uint32_t lane = lane_id();
+#if !IMPG_VW_WINDOWS
   __shared__ uint32_t iso_point[64];
   const int32_t iso_margin = max(mdbr, 0) + 1;
+#endif
   uint32_t t0 = t_next;
   for (; t0 < n; t0 += 64u) {
     if (len + 64u > list_cap) break;  // (a batch adds at most 64 ranges: the caller moves the list somewhere bigger)
@@ -3099,6 +3112,148 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
     // uncovered piece and leaves the list as it is (impg.rs:314-343), and the list only ever grows.  Deep levels of
     // a saturating closure are almost all such hits: every lane tests one hit of the batch against the list as it
     // stands, and only the others take their turn in the sequential replay below.
+#if IMPG_VW_WINDOWS
+    // ---- round 5: every hit that meets no EARLIER hit of its batch takes its turn at once -------------------------------
+    // A hit's turn reads and writes a handful of neighbouring ranges and nothing else: the range before its lower bound
+    // (proximity test, impg.rs:2513-2545; the walk's first range, :305-313), the ranges that start inside it (the walk,
+    // the insert, the ranges merge_forward swallows, :314-368) and the first range that starts beyond it (where the walk,
+    // the second proximity test and the merge stop) -- list positions [lb - 1, ub], lb = first range starting at or after
+    // the hit's start, ub = first range starting beyond its end.  Two hits whose position intervals are disjoint cannot
+    // tell in which order they were replayed; so every uncovered hit whose interval meets that of no EARLIER uncovered hit
+    // of the batch (a later one it meets waits: that one needs this one's result) is replayed NOW, by its own lane, with
+    // the reference's own code (replay_one) on a private copy of its <= W + 2 ranges, and the list is rebuilt once for
+    // all of them: the copied stretches taken out (one ascending pass), room made for what they became (one descending
+    // pass), the private lists written back.  What is left -- hits behind an earlier one they meet, hits on more than W
+    // ranges, hits the clamps touch -- takes its turn in the sequential part below, in order.  (Round 3's two classes,
+    // hits that meet no range at all and hits that grow exactly one, were the cases ub - lb = 0 and most of = 1: 57 % of
+    // the uncovered hits of a deep level; a list of ~1 000 ranges on 5 Mb under 5-10 kb hits has most hits on two or three.)
+    constexpr uint32_t W = VW_WINDOW, PRIV = VW_WINDOW + 4u;
+    __shared__ int32_t priv_x[PRIV * 64u], priv_y[PRIV * 64u];
+    __shared__ uint32_t s_os[64], s_ol[64], s_cr[64], s_cn[64], s_cpos[64];
+    unsigned long long todo;
+    int32_t rs = 0, re = 0;  // this lane's hit of the batch (the sequential part below reads them lane to lane)
+    {
+      bool need = false, plain = false;
+      uint32_t lb = 0, ub = 0;
+      if (t0 + lane < n) {
+        const unsigned long long iv = svals[st + t0 + lane];
+        rs = (int32_t)(uint32_t)(iv >> 32); re = (int32_t)(uint32_t)iv;
+        const int32_t s0 = max(rs, 0), e0 = min(re, sequence_length);
+        const uint32_t p0 = list_lower_bound(R, len, s0);
+        // (a hit that the clamps leave empty or inverted -- a length-0 set of a masked batch -- takes the literal path)
+        const bool covered = s0 < e0 && ((p0 < len && R.x(p0) == s0 && R.y(p0) >= e0) || (p0 > 0 && R.y(p0 - 1) >= e0));
+        need = !covered;
+        plain = need && rs >= 0 && re <= sequence_length && rs < re && re < 0x7FFFFFFF;
+        if (plain) { lb = p0; ub = list_lower_bound(R, len, re + 1); }
+      }
+      todo = __ballot(need);
+      // the hit's interval of list positions, closed, not clamped (-1 and len stand for "before the first" / "behind the
+      // last range": two hits in front of the whole list meet there); a hit the clamps touch meets everything
+      const int32_t blo = plain ? (int32_t)lb - 1 : (int32_t)0x80000000, bhi = plain ? (int32_t)ub : 0x7FFFFFFF;
+      bool earlier = false;
+      for (unsigned long long left = todo; left; left &= left - 1ull) {
+        const uint32_t j = (uint32_t)__ffsll((long long)left) - 1u;
+        const int32_t lo_j = __builtin_amdgcn_readlane(blo, j), hi_j = __builtin_amdgcn_readlane(bhi, j);
+        if (j < lane && lo_j <= bhi && blo <= hi_j) earlier = true;
+      }
+      const bool par = plain && ub - lb <= W && !earlier;
+      const unsigned long long pm = __ballot(par);
+      if (pm) {
+        const uint32_t k = (uint32_t)__popcll(pm);
+        // the private copy and the hit's turn on it
+        const uint32_t bs = (uint32_t)max(blo, 0), be = min((uint32_t)bhi + 1u, len), ol = par ? be - bs : 0u;
+        const ListInLds Q{priv_x + lane, priv_y + lane};
+        uint32_t pl = ol, pn = 0;
+        int32_t qx0 = 0, qx1 = 0, qx2 = 0, qx3 = 0, qx4 = 0, qx5 = 0, qy0 = 0, qy1 = 0, qy2 = 0, qy3 = 0, qy4 = 0, qy5 = 0;  // its pieces: at most W + 2
+        static_assert(VW_WINDOW + 2u <= 6u, "a hit's pieces are held in six register pairs");
+        if (par) {
+          for (uint32_t i = 0; i < ol; i++) { Q.x(i) = R.x(bs + i); Q.y(i) = R.y(bs + i); }
+          replay_one(Q, pl, rs, re, sequence_length, min_transitive_len, mdbr,
+                     [&](int32_t a, int32_t b) {
+                       if (pn == 0) { qx0 = a; qy0 = b; } else if (pn == 1) { qx1 = a; qy1 = b; } else if (pn == 2) { qx2 = a; qy2 = b; }
+                       else if (pn == 3) { qx3 = a; qy3 = b; } else if (pn == 4) { qx4 = a; qy4 = b; } else { qx5 = a; qy5 = b; }
+                       pn += 1;
+                     }, [] {});
+        }
+        {  // the pieces, in any order (they are sorted afterwards)
+          const uint32_t inc = wave_incl_scan(pn);
+          const uint32_t at = np + inc - pn;
+          if (pn > 0) P[at] = make_int2(qx0, qy0);
+          if (pn > 1) P[at + 1u] = make_int2(qx1, qy1);
+          if (pn > 2) P[at + 2u] = make_int2(qx2, qy2);
+          if (pn > 3) P[at + 3u] = make_int2(qx3, qy3);
+          if (pn > 4) P[at + 4u] = make_int2(qx4, qy4);
+          if (pn > 5) P[at + 5u] = make_int2(qx5, qy5);
+          np += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+        // the copied stretches in list order (their intervals are disjoint: ranked by where they start)
+        uint32_t rank = 0;
+        for (unsigned long long left = pm; left; left &= left - 1ull) {
+          const uint32_t j = (uint32_t)__ffsll((long long)left) - 1u;
+          rank += __builtin_amdgcn_readlane(blo, j) < blo ? 1u : 0u;
+        }
+        __syncthreads();  // (the arrays may still be read by the previous batch)
+        if (par) { s_os[rank] = bs; s_ol[rank] = ol; s_cn[rank] = pl; }
+        __syncthreads();
+        {
+          const uint32_t o = lane < k ? s_ol[lane] : 0u, nl = lane < k ? s_cn[lane] : 0u;
+          const uint32_t cr = wave_incl_scan(o), cn = wave_incl_scan(nl);
+          __syncthreads();
+          if (lane < k) { s_cr[lane] = cr; s_cn[lane] = cn; s_cpos[lane] = s_os[lane] - (cr - o); }
+          __syncthreads();
+        }
+        const uint32_t removed = s_cr[k - 1u], added = s_cn[k - 1u];
+        // (number of entries of the ascending array a[0 .. k) that are <= v)
+        auto count_le = [&](const uint32_t *a, uint32_t v) -> uint32_t {
+          uint32_t lo = 0, hi = k;
+          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1u; else hi = mid; }
+          return lo;
+        };
+        // pass A, ascending: the copied stretches out, what stays moves down by what was taken out before it
+        for (uint32_t base = s_os[0]; base < len; base += 64u) {
+          const uint32_t i = base + lane;
+          const bool on = i < len;
+          int32_t vx = 0, vy = 0;
+          uint32_t dst = 0;
+          bool keep = false;
+          if (on) {
+            vx = R.x(i); vy = R.y(i);
+            const uint32_t j = count_le(s_os, i);
+            keep = j == 0u || i >= s_os[j - 1u] + s_ol[j - 1u];
+            dst = i - (j ? s_cr[j - 1u] : 0u);
+          }
+          order_point(R);
+          if (keep) { R.x(dst) = vx; R.y(dst) = vy; }
+          order_point(R);
+        }
+        const uint32_t len_c = len - removed;
+        // pass B, descending: room for what the stretches became
+        for (uint32_t top = len_c; top > s_cpos[0];) {
+          const uint32_t base = top > s_cpos[0] + 64u ? top - 64u : s_cpos[0];
+          const uint32_t c = base + lane;
+          const bool on = c < top;
+          int32_t vx = 0, vy = 0;
+          uint32_t dst = 0;
+          if (on) {
+            vx = R.x(c); vy = R.y(c);
+            const uint32_t j = count_le(s_cpos, c);
+            dst = c + (j ? s_cn[j - 1u] : 0u);
+          }
+          order_point(R);
+          if (on) { R.x(dst) = vx; R.y(dst) = vy; }
+          order_point(R);
+          top = base;
+        }
+        if (par) {
+          const uint32_t at = s_cpos[rank] + (s_cn[rank] - pl);
+          for (uint32_t i = 0; i < pl; i++) { R.x(at + i) = Q.x(i); R.y(at + i) = Q.y(i); }
+        }
+        order_point(R);
+        len = len_c + added;
+        todo &= ~pm;
+      }
+    }
+#else
     unsigned long long todo;
     int32_t rs = 0, re = 0;  // this lane's hit of the batch (the sequential part below reads them lane to lane)
     {
@@ -3221,6 +3376,7 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
         todo &= ~iso;
       }
     }
+#endif
     while (todo) {
     const uint32_t tl = (uint32_t)__ffsll((long long)todo) - 1u;
     todo &= todo - 1ull;

@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--min-identity", type=float, default=None,
                     help="--min-result-identity of the reference (impg.rs:1283-1287); not part of the headline configuration")
     ap.add_argument("--no-extras", action="store_true", help="skip the full-results measurement (profiling runs)")
+    ap.add_argument("--world-sweep", action="store_true",
+                    help="one device, constant work: the batch through a multi handle of 1 / 2 / 4 / 8 ranks that all share device 0 "
+                         "(threads of this process, LocalComm) -- what the sharded path's fixed costs do as the world grows, "
+                         "measurable without a second GPU; every world is checked against the plain index first")
     args = ap.parse_args()
     args.engine_option_changes_results = False  # (no engine option changes a result row: they are layout / schedule knobs)
 
@@ -345,6 +349,8 @@ def main():
         out["parity_vs_single"] = parity["parity_vs_single"] if parity else None
         out["hops"] = hops
         out["strong_scaling"] = strong
+    if world == 1 and dist is None and args.world_sweep:
+        out["world_sweep"] = world_sweep_leg(index, paf, ranges, params, args)
     if world == 1 and dist is None and not args.no_extras:
         out["full_results"] = full_results_leg(index, ranges, params)
         out["dfs_batch"] = dfs_batch_leg(index, ranges, args.max_depth)
@@ -434,6 +440,14 @@ def roofline(stats, ach, traffic, tpath, ms_project, launches, tag):
         r["valu_note"] = ("SQ_INSTS_VALU x %.2f clocks (the measured issue cost of the kernel's instruction mix: profiles/r3_issue_rate.json, "
                           "profiles/r*_valu_mix_*.json) / (GRBM_GUI_ACTIVE x %d SIMDs) of the projection kernels, profiles/%s" %
                           (j.get("cycles_per_valu_inst") or 0.0, SIMDS, os.path.basename(sq[-1])))
+    # every kernel of the step that takes >= 1 % of it (scripts/make_per_kernel_json.py on the PMC passes of this command)
+    pk = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_per_kernel.json" % tag))) if tag else []
+    if pk:
+        with open(pk[-1]) as f:
+            j = json.load(f)
+        r["per_kernel"] = [{"name": k["name"], "ms": k["ms_per_step"], "hbm_frac": k.get("hbm_frac"), "valu_issue_frac": k.get("valu_issue_frac"),
+                            "waves_per_simd": k.get("waves_per_simd_mean")} for k in j["kernels"]]
+        r["per_kernel_source"] = "profiles/" + os.path.basename(pk[-1])
     mf = r["measured_traffic_frac"]
     # what binds, from the two measured fractions: neither HBM (the 856-byte model's bound) nor the VALUs are saturated on the
     # headline index -- the rest is latency the resident waves do not cover (dependent 16-byte gathers, each lane its own line)
@@ -541,6 +555,58 @@ def multi_handle_leg(paf, ranges, params, args, world):
     return {"workload": "rank 0's %d ranges through ONE handle over %d GPU(s) of this process (ranges from host memory; strong scaling)" % (len(ranges), world),
             "value": proj / dt if dt > 0 else None, "unit": "projected ranges/s", "ms_per_step": dt * 1e3 / max(1, args.steps),
             "projected_per_step": proj / max(1, args.steps), "index_build_s": build_s, "by_hop": hops}
+
+
+def world_sweep_leg(plain, paf, ranges, params, args):
+    """The SAME batch through the sharded path with 1, 2, 4 and 8 ranks that share this one device (a multi handle over
+    devices [0] * w: one thread per rank, LocalComm, peer copies that stay on the device): total work is constant, the
+    kernels of all ranks run on the same GPU, so whatever ms_per_step gains with w is the sharded path's own cost per rank
+    and hop -- routing, the two all-gathers, pack / unpack, the host synchronisations -- which an N-GPU run pays too,
+    there in parallel.  Every world's per-range counts and checksums are compared with the plain index's first."""
+    import numpy as np
+    import impg_amd
+    if not paf:
+        return {"error": "needs the PAF (headline / config 5 workloads)"}
+    npar = min(4096, len(ranges))
+    plain.set_option("chunk_ranges", 4096)
+    st_s, cnt_s, ck_s = plain.query_batch_stats(ranges[:npar], params)
+    plain.set_option("chunk_ranges", args.chunk_ranges)
+    F = impg_amd.index.HOP_PROFILE_FIELDS
+    legs = []
+    for w in (1, 2, 4, 8):
+        log("world sweep: %d rank(s) on device 0" % w)
+        t0 = time.perf_counter()
+        mh = impg_amd.GpuImpg.from_paf(paf, devices=[0] * w, lanes=args.lanes)
+        build_s = time.perf_counter() - t0
+        mh.set_option("pair_budget", 1 << 30)
+        mh.set_option("chunk_ranges", 4096)
+        st_p, cnt_p, ck_p = mh.query_batch_stats(ranges[:npar], params)
+        ok = bool(st_p.projected == st_s.projected and np.array_equal(cnt_p, cnt_s) and np.array_equal(ck_p, ck_s))
+        # (the batch is dealt to the ranks in contiguous blocks; a rank's block in chunks of at most 50 000, one per lane at w = 1)
+        mh.set_option("chunk_ranges", max(1, min(50000, (len(ranges) + w * args.lanes - 1) // (w * args.lanes))))
+        for _ in range(2):
+            mh.query_batch_stats(ranges, params, counts=False, checksums=False)
+        mh.hop_profile(reset=True)
+        t0 = time.perf_counter()
+        sts = [mh.query_batch_stats(ranges, params, counts=False, checksums=False)[0] for _ in range(args.steps)]
+        dt = time.perf_counter() - t0
+        prof = mh.hop_profile(reset=True) / max(1, args.steps)  # [w][8][12]
+        hops = int((prof[:, :, 0].sum(axis=0) > 0).sum())
+        per_rank = prof.sum(axis=1)  # [w][12]: a rank's seconds per step over its hops and lanes
+        fixed = {F[f]: float(per_rank[:, f].sum()) * 1e3 for f in (1, 2, 3, 5, 6, 7)}  # everything but the owner's expansion, ms summed over ranks
+        legs.append({"world": w, "parity_vs_single": ok, "ms_per_step": dt * 1e3 / max(1, args.steps),
+                     "projected_per_step": sum(s.projected for s in sts) / max(1, args.steps), "index_build_s": build_s, "hops": hops,
+                     "owner_expand_ms_sum_over_ranks": float(per_rank[:, 4].sum()) * 1e3,
+                     "other_stages_ms_sum_over_ranks": fixed,
+                     "fixed_ms_per_rank_and_hop": float(sum(fixed.values())) / max(1, w * max(1, hops))})
+        del mh
+    base = legs[0]["ms_per_step"]
+    return {"workload": "the batch's %d ranges through ONE multi handle of w ranks sharing device 0 (LocalComm, %d lanes a rank); constant work" %
+                        (len(ranges), args.lanes),
+            "legs": legs, "growth_1_to_8": legs[-1]["ms_per_step"] / base if base else None,
+            "parity_vs_single_all": all(l["parity_vs_single"] for l in legs),
+            "note": "seconds of the stages are host wall time summed over a rank's lanes (stages that end in an exchange include the wait "
+                    "for the other ranks, which here share the device)"}
 
 
 def full_results_leg(index, ranges, params):

@@ -1813,6 +1813,12 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
 // Ranges whose window is wider than the mask (their pairs are listed by the wave-per-range emit) are projected at the
 // end from that list; a block whose pairs are few for the entries they touch takes project_places (nothing staged).
 // ---------------------------------------------------------------------------
+// IMPG_ENT_GROUP_SKIP = 1: an entry's enumeration only looks at the groups of 64 ranges whose masks can name it (one LDS read and
+// a ballot pick one or two of the eight).  Measured, round 5: 21.7 -> 21.8-22.1 ms -- the eight unrolled ballots overlap with
+// the record's LDS traffic and cost less than the loop that replaces them.  0 (the default): all eight.
+#ifndef IMPG_ENT_GROUP_SKIP
+#define IMPG_ENT_GROUP_SKIP 0
+#endif
 #ifndef IMPG_ENT_RANGES
 #define IMPG_ENT_RANGES 512
 #endif
@@ -1871,6 +1877,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   __shared__ int2 st_se[ENT_RANGES];
   __shared__ uint32_t st_off[ENT_RANGES + 4u];
   __shared__ uint16_t st_wide[ENT_RANGES];
+  __shared__ int2 st_grp[ENT_RANGES / 64u];  // per 64 ranges: the first and the last entry their masks name (IMPG_ENT_GROUP_SKIP)
   __shared__ uint32_t st_nwide, st_alloc, st_next;
   __shared__ uint32_t wred[2u * ENT_WAVES];
   __shared__ uint32_t wcnt[ENT_WAVES];
@@ -1895,16 +1902,29 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
     if (t < nr) st_off[t] = wl.pair_off[r0 + t];
     else st_off[t + 1u] = 0xFFFFFFFFu;
     if (t == 0) st_off[nr] = r0 + nr < wl.n_fr ? wl.pair_off[r0 + nr] : n_pairs;
+    uint32_t glo = 0xFFFFFFFFu, ghi = 0u;
     if (t < nr) {
       const uint4 w = wl.win[r0 + t];
       st_win[t] = w;
       st_se[t] = wl.se[r0 + t];
       if (w.y - (w.x & ~3u) > 64u) st_wide[atomicAdd(&st_nwide, 1u)] = (uint16_t)t;
       else if (w.z | w.w) {
-        emin = min(emin, w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w)));
-        emax = max(emax, w.x + (w.w ? 63u - (uint32_t)__builtin_clz(w.w) : 31u - (uint32_t)__builtin_clz(w.z)));
+        glo = w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w));
+        ghi = w.x + (w.w ? 63u - (uint32_t)__builtin_clz(w.w) : 31u - (uint32_t)__builtin_clz(w.z));
+        emin = min(emin, glo);
+        emax = max(emax, ghi);
       }
     }
+#if IMPG_ENT_GROUP_SKIP
+    {  // the 64 ranges this wave has just loaded are one group of the enumeration below
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        glo = min(glo, (uint32_t)__shfl_xor((int)glo, o));
+        ghi = max(ghi, (uint32_t)__shfl_xor((int)ghi, o));
+      }
+      if (l == 0) st_grp[t >> 6] = make_int2((int32_t)glo, (int32_t)ghi);  // (an empty group: lo > hi, nothing lies between)
+    }
+#endif
   }
   {
 #pragma unroll
@@ -1980,9 +2000,20 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
       }
       // the block's ranges that hit the entry, 64 at a time: bit (entry - window start) of the range's mask
       uint32_t cnt = 0;
+#if IMPG_ENT_GROUP_SKIP
+      // (in the lookup order a block's 512 ranges climb through its ~50 entries: one or two of the eight groups of 64 can
+      // name a given entry at all -- found with one LDS read and a ballot; the other groups' masks are not looked at)
+      const int2 gb = st_grp[l & (ENT_RANGES / 64u - 1u)];
+      uint32_t groups = (uint32_t)__ballot(l < ENT_RANGES / 64u && eidx >= (uint32_t)gb.x && eidx <= (uint32_t)gb.y);
+#pragma unroll 1
+      for (; groups; groups &= groups - 1u) {
+        const uint32_t q = (uint32_t)__builtin_ctz(groups);
+        const uint32_t r = q * 64u + l;
+#else
 #pragma unroll
       for (uint32_t q = 0; q < ENT_RANGES / 64u; q++) {
         const uint32_t r = q * 64u + l;
+#endif
         bool hit = false;
         if (r < nr) {
           const uint4 w = st_win[r];
@@ -2660,7 +2691,7 @@ constexpr uint32_t VU_LDS_CAP = IMPG_VU_LDS_CAP;
 #ifndef IMPG_VW_WINDOW
 #define IMPG_VW_WINDOW 4   // ranges a hit may start in / swallow and still take its turn on a private copy
 #endif
-constexpr uint32_t VW_WINDOW = IMPG_VW_WINDOW;
+[[maybe_unused]] constexpr uint32_t VW_WINDOW = IMPG_VW_WINDOW;
 // groups whose list can outgrow this get a whole wave (visited_update_wave_kernel below)
 // two sizes of LDS working set (9 KB: 17 waves per CU; 32 KB: 5): groups with few hits and a short list take the small one
 #ifndef IMPG_VW_TINY

@@ -37,6 +37,7 @@ bool Engine::run_small(const impg_gpu_index &ix, const impg_gpu_range_t *h_range
                        impg_gpu_results &res) {
   // (MultiImpg's plain query sorts its hits by five keys, multi_impg.rs:556-592: the general path does that)
   if (n == 0 || n > SMALL_RANGES || p.transitive || p.store_cigar || p.multi_impg || masked || subset_on || remote) return false;
+  if (p.min_identity == p.min_identity && ix.lacks_identity_lines()) const_cast<impg_gpu_index &>(ix).ensure_identity_lines();
   // every candidate pair of a range is an entry of its target: the sum of those segments bounds the pairs, on the host
   if (ix.h_tgt_off.size() != (size_t)ix.view.n_seq + 1) return false;  // (no table to bound the grid with: the general path counts on the device)
   uint64_t bound = 0;
@@ -184,6 +185,7 @@ void Engine::reserve_walk_slabs(const impg_gpu_index &ix, bool dfs_too) {
 bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
                       unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows, uint32_t *h_n_rows) {
   if (!walk_applicable(ix, n, p)) return false;
+  if (p.min_identity == p.min_identity && ix.lacks_identity_lines()) const_cast<impg_gpu_index &>(ix).ensure_identity_lines();
   IMPG_HIP(hipSetDevice(ix.device));
   // a BFS processes whole levels: 16 waves per query; a DFS step is one popped range: one wave, cheap barriers
   const bool wide = !p.dfs;
@@ -772,6 +774,8 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
                  std::vector<std::unique_ptr<LevelBufs>> *keep, unsigned long long *d_count,
                  unsigned long long *d_cksum, impg_gpu_stats_t *st, DevBuf *self_out) {
   check_params(p);
+  // (the identity filter on an index built without its identity lines: they are built now, once)
+  if (p.min_identity == p.min_identity && ix.lacks_identity_lines()) const_cast<impg_gpu_index &>(ix).ensure_identity_lines();
   IMPG_HIP(hipSetDevice(ix.device));
   split_ok = n > 1 && !remote;  // (ranks of a sharded batch stay in lock step: no re-splitting)
   min_identity = p.min_identity;

@@ -249,7 +249,9 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
   const bool with_pfx = !tp && !(getenv("IMPG_PREFIX_LINES") && atoi(getenv("IMPG_PREFIX_LINES")) == 0);
   // identity filter: with prefix lines an *identity line* per tile (per-op matched / mismatched sums, impg_internal.hpp),
   // without them the sums before each sub-tile, where the two short walks start counting
-  RawVec<uint4> idp(tp ? 0 : (with_pfx ? IDL_WORDS / 4 : TILE_SUBS) * n_tiles);
+  // (with prefix lines they are built on demand, impg_gpu_index::ensure_identity_lines, unless IMPG_IDENTITY_LINES=1 asks for them now)
+  const bool with_idl = with_pfx && getenv("IMPG_IDENTITY_LINES") && atoi(getenv("IMPG_IDENTITY_LINES")) == 1;
+  RawVec<uint4> idp(tp ? 0 : (with_pfx ? (with_idl ? IDL_WORDS / 4 : 0) : TILE_SUBS) * n_tiles);
   RawVec<uint32_t> pfx(with_pfx ? n_tiles * TILE_WORDS : 0);  // prefix lines (impg_internal.hpp); optional: see index_build_device.hip
   if (tp && n_tiles) {  // the tail of the last 128-byte line behind the last boundary
     uint64_t nb_words = 0;
@@ -308,7 +310,8 @@ void build_index(impg_gpu_index &ix, const impg_gpu_record_t *records, size_t n_
         uint32_t scratch_line[TILE_WORDS];
         uint32_t *pl = with_pfx ? pfx.data() + tile * TILE_WORDS : scratch_line;
         bool pwide = false;
-        uint32_t *il = with_pfx ? reinterpret_cast<uint32_t *>(idp.data()) + tile * IDL_WORDS : scratch_line;
+        uint32_t scratch_idl[TILE_WORDS];
+        uint32_t *il = with_idl ? reinterpret_cast<uint32_t *>(idp.data()) + tile * IDL_WORDS : scratch_idl;
         const uint32_t m0 = sm, x0 = sx, g0 = sg;
         uint32_t gapmask = 0;
         auto boundary = [&]() {

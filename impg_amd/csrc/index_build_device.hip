@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void tiles_kernel(const impg_gpu_record_t *__r
       const size_t tile = (size_t)tile_base[rec] + j;
       pool[tile * TILE_WORDS + w] = lw;
       if (pfx) pfx[tile * TILE_WORDS + w] = pw;
-      if (pfx) reinterpret_cast<uint32_t *>(idp)[tile * IDL_WORDS + w] = iw;
+      if (pfx) { if (idp) reinterpret_cast<uint32_t *>(idp)[tile * IDL_WORDS + w] = iw; }  // (idp null: the identity lines come later, on demand)
       else if (w < TILE_SUBS) idp[TILE_SUBS * tile + w] = sfo < cnt ? make_uint4(pM, pX, pG, 0u) : make_uint4(endM, endX, endG, 0u);
     }
     // carry: the sums after this step's last op (lane 63 holds them whatever the halves' fill)
@@ -369,7 +369,9 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
   // The prefix lines are 40 % of the index and only buy speed (the plain projection reads them instead of replaying
   // ops): an index that does not fit the device with them is built without (IMPG_PREFIX_LINES=0 forces that).
   bool with_pfx = !(getenv("IMPG_PREFIX_LINES") && atoi(getenv("IMPG_PREFIX_LINES")) == 0);
-  auto bytes_for = [&](bool pf) { return n_tiles * ((pf ? 2 : 1) * TILE_WORDS * 4 + (pf ? IDL_WORDS * 4 : TILE_SUBS * 16)) + n_entries * (sizeof(Entry) + 40) + n_records * 64; };
+  // (the identity lines beside them are built when a query first needs them: impg_gpu_index::ensure_identity_lines)
+  const bool with_idl = getenv("IMPG_IDENTITY_LINES") && atoi(getenv("IMPG_IDENTITY_LINES")) == 1;
+  auto bytes_for = [&](bool pf) { return n_tiles * ((pf ? 2 : 1) * TILE_WORDS * 4 + (pf ? (with_idl ? IDL_WORDS * 4 : 0) : TILE_SUBS * 16)) + n_entries * (sizeof(Entry) + 40) + n_records * 64; };
   if (with_pfx && bytes_for(true) + (1ull << 30) > free_b) with_pfx = false;
   const size_t out_bytes = bytes_for(with_pfx);
   if (out_bytes + (1ull << 30) > free_b) return false;  // (the host builder reports the shortage in its own words)
@@ -403,7 +405,8 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
   size_blob(ix, 10, n_tiles * TILE_WORDS * 4, acc);
   size_blob(ix, 14, with_pfx ? n_tiles * TILE_WORDS * 4 : 0, acc);
   uint32_t *const d_pfx = with_pfx ? ix.blob(14)->as<uint32_t>() : nullptr;
-  size_blob(ix, 12, n_tiles * (with_pfx ? IDL_WORDS * 4 : TILE_SUBS * 16), acc);
+  size_blob(ix, 12, n_tiles * (with_pfx ? (with_idl ? IDL_WORDS * 4 : 0) : TILE_SUBS * 16), acc);
+  uint4 *const d_idp = (with_pfx && !with_idl) ? nullptr : ix.blob(12)->as<uint4>();
   {
     const size_t BATCH_OPS = 64ull << 20;  // 256 MB of ops per upload
     DevBuf d_ops;
@@ -412,7 +415,7 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
       if (n_records)
         tiles_kernel<<<cdiv(n_records, 4), 256, 0, s>>>(d_rec.as<impg_gpu_record_t>(), d_need.as<uint8_t>(), d_tb.as<uint32_t>(), 0u, (uint32_t)n_records,
                                                           d_cigar_ops, 0ull, ix.blob(10)->as<uint32_t>(), d_pfx,
-                                                          ix.blob(12)->as<uint4>(), d_totT.as<uint32_t>(), d_totQ.as<uint32_t>(), d_flag.as<uint32_t>());
+                                                          d_idp, d_totT.as<uint32_t>(), d_totQ.as<uint32_t>(), d_flag.as<uint32_t>());
       IMPG_HIP(hipStreamSynchronize(s));
       b0 = n_records;
     } else if (!monotone && n_ops) {
@@ -437,7 +440,7 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
       const uint32_t nr = (uint32_t)(b1 - b0);
       tiles_kernel<<<cdiv(nr, 4), 256, 0, s>>>(d_rec.as<impg_gpu_record_t>(), d_need.as<uint8_t>(), d_tb.as<uint32_t>(), (uint32_t)b0, nr,
                                                 d_ops.as<uint32_t>(), lo, ix.blob(10)->as<uint32_t>(), d_pfx,
-                                                ix.blob(12)->as<uint4>(), d_totT.as<uint32_t>(), d_totQ.as<uint32_t>(), d_flag.as<uint32_t>());
+                                                d_idp, d_totT.as<uint32_t>(), d_totQ.as<uint32_t>(), d_flag.as<uint32_t>());
       IMPG_HIP(hipStreamSynchronize(s));  // (the next batch overwrites d_ops)
       b0 = b1;
     }
@@ -610,6 +613,48 @@ bool build_index_device(impg_gpu_index &ix, const impg_gpu_record_t *records, si
   return true;
 }
 
+// The identity lines of an index that was built without them (tiles_kernel's words, from the op LINES this time): a wave
+// per entry walks its record's tiles two at a time, a lane per op slot.  A record's two entries write the same bytes.
+__global__ __launch_bounds__(256) void identity_lines_kernel(const Entry *__restrict__ entries, uint32_t n_entries,
+                                                             const uint32_t *__restrict__ pool, uint32_t *__restrict__ idl) {
+  const uint32_t ei = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (ei >= n_entries) return;
+  const Entry en = entries[ei];
+  const uint32_t n = en.nops_flags & OP_LEN_MASK;
+  const uint32_t l = lane(), h = l >> 5, w = l & 31u, hb = h << 5;
+  uint32_t cM = 0, cX = 0, cG = 0;  // running sums of the record before this step's first op
+  const uint32_t m = (n + TILE_OPS - 1) / TILE_OPS;
+  for (uint32_t j0 = 0; j0 < m; j0 += 2) {
+    const uint32_t j = j0 + h;
+    const bool tile_on = j < m;
+    const uint32_t cnt = tile_on ? min(TILE_OPS, n - j * TILE_OPS) : 0u;
+    const uint32_t u = w - 6u;
+    const bool on = w >= 6u && u < cnt;
+    const size_t tile = (size_t)en.tile_base + j;
+    uint32_t dM = 0, dX = 0, dG = 0;
+    if (on) {
+      const uint32_t op = pool[tile * TILE_WORDS + w];
+      const uint32_t code = op >> 29, len = op & OP_LEN_MASK;
+      if (code == 0u || code == 4u) dM = len;  // 'M' counted as match (impg.rs:2959)
+      else if (code == 1u) dX = len;
+      else dG = 1u;                 // gap-compressed: one per 'I' / 'D' op
+    }
+    const uint32_t iM = cM + wscan(dM), iX = cX + wscan(dX), iG = cG + wscan(dG);
+    const uint32_t eM = iM - dM, eX = iX - dX, eG = iG - dG;  // before this lane's op
+    const uint32_t last = hb + 5u + max(cnt, 1u);
+    const uint32_t endM = from_lane(iM, last), endX = from_lane(iX, last);
+    const uint32_t m0 = from_lane(eM, hb + 6u), x0 = from_lane(eX, hb + 6u), g0 = from_lane(eG, hb + 6u);
+    const uint32_t ient = ((eM - m0) & 0xFFFFu) | ((eX - x0) << 16), ient_end = ((endM - m0) & 0xFFFFu) | ((endX - x0) << 16);
+    const uint32_t ient_up2 = (uint32_t)__shfl_down((int)ient, 2);
+    const uint32_t gapmask = (uint32_t)((__ballot(on && dG != 0u) >> (hb + 6u)) & 0x3FFFFFFull);
+    uint32_t iw;
+    if (w >= IDL_E0) iw = (w - IDL_E0) < cnt ? ient_up2 : ient_end;
+    else iw = w == 0u ? m0 : w == 1u ? x0 : w == 2u ? g0 : gapmask;
+    if (tile_on) idl[tile * IDL_WORDS + w] = iw;
+    cM = from_lane(iM, 63u); cX = from_lane(iX, 63u); cG = from_lane(iG, 63u);
+  }
+}
+
 uint64_t tokenize_on_device(ParsedPaf &pp, int device, DevBuf &d_ops) {
   IMPG_HIP(hipSetDevice(device));
   const size_t n = pp.records.size();
@@ -665,3 +710,25 @@ uint64_t tokenize_on_device(ParsedPaf &pp, int device, DevBuf &d_ops) {
 }
 
 }  // namespace impg
+
+void impg_gpu_index::ensure_identity_lines() {
+  using namespace impg;
+  std::lock_guard<std::mutex> lk(idl_m);
+  if (!lacks_identity_lines()) return;
+  IMPG_HIP(hipSetDevice(device));
+  const size_t bytes = n_tiles * (size_t)IDL_WORDS * 4;
+  try {
+    d_idp.reserve(std::max<size_t>(bytes + 64, 256));
+  } catch (const Error &) {
+    throw Error{IMPG_E_OOM, "not enough device memory for the identity lines of this index (" + std::to_string(bytes >> 20) +
+                                " MiB, built when a query first filters by min_gap_compressed_identity)"};
+  }
+  if (n_entries)
+    identity_lines_kernel<<<(unsigned)((n_entries + 3) / 4), 256>>>(d_entries.as<Entry>(), (uint32_t)n_entries, d_ops.as<uint32_t>(),
+                                                                     d_idp.as<uint32_t>());
+  IMPG_HIP(hipDeviceSynchronize());
+  view.idp = d_idp.as<uint4>();
+  blob_bytes[12] = bytes;
+  device_bytes += bytes;
+}
+

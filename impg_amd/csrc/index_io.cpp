@@ -73,7 +73,7 @@ void save_index(const impg_gpu_index &cix, const char *path, const ShardInfo *sh
   h.version = VERSION;
   h.tile_words = TILE_WORDS; h.tile_ops = TILE_OPS; h.tile_subs = TILE_SUBS; h.entry_bytes = sizeof(Entry);
   h.n_seq = ix.view.n_seq; h.sorted_order = ix.view.sorted_order; h.multi_file = (ix.multi_file ? 1 : 0) | (ix.tp_mode ? 2 : 0) | ((!ix.tp_mode && ix.n_tiles && !ix.blob_bytes[14]) ? 4 : 0)  // 4: no prefix lines
-                                                                            | (shard ? 8 : 0) | (front ? 16 : 0);
+                                                                            | (shard ? 8 : 0) | (front ? 16 : 0) | (ix.lacks_identity_lines() ? 32 : 0);  // 32: prefix lines without identity lines
   h.n_records = ix.n_records; h.n_entries = ix.n_entries; h.n_tiles = ix.n_tiles; h.n_targets = ix.n_targets;
   h.n_names = ix.seq.names.size(); h.n_file_first = ix.file_first.size(); h.n_tgt_off = ix.h_tgt_off.size();
   for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) h.blob_bytes[k] = front ? 0 : ix.blob_bytes[k];
@@ -141,7 +141,7 @@ void load_index(impg_gpu_index &ix, const char *path, ShardInfo *shard) {
       throw Error{IMPG_E_INVALID, in.path + ": counts out of range"};
     const uint64_t want[impg_gpu_index::N_BLOBS] = {S * sizeof(SegDesc), E * 4, E * 4, E * 4, E * 4, h.blob_bytes[5], h.blob_bytes[5],
                                                     E * 4, (h.multi_file & 1) ? E * 4 : 0, E * sizeof(Entry), T * TILE_WORDS * 4,
-                                                    h.blob_bytes[11], (h.multi_file & 2) ? 0 : (h.multi_file & 4) ? T * TILE_SUBS * 16 : T * IDL_WORDS * 4, S * 4,
+                                                    h.blob_bytes[11], (h.multi_file & (2 | 32)) ? 0 : (h.multi_file & 4) ? T * TILE_SUBS * 16 : T * IDL_WORDS * 4, S * 4,
                                                     (h.multi_file & 6) ? 0 : T * TILE_WORDS * 4};
     uint64_t total = 0;
     for (int k = 0; k < impg_gpu_index::N_BLOBS; k++) {

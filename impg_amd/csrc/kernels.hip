@@ -1877,7 +1877,9 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   __shared__ int2 st_se[ENT_RANGES];
   __shared__ uint32_t st_off[ENT_RANGES + 4u];
   __shared__ uint16_t st_wide[ENT_RANGES];
-  __shared__ int2 st_grp[ENT_RANGES / 64u];  // per 64 ranges: the first and the last entry their masks name (IMPG_ENT_GROUP_SKIP)
+#if IMPG_ENT_GROUP_SKIP
+  __shared__ int2 st_grp[ENT_RANGES / 64u];  // per 64 ranges: the first and the last entry their masks name
+#endif
   __shared__ uint32_t st_nwide, st_alloc, st_next;
   __shared__ uint32_t wred[2u * ENT_WAVES];
   __shared__ uint32_t wcnt[ENT_WAVES];

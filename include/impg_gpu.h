@@ -192,6 +192,10 @@ size_t impg_gpu_num_targets(const impg_gpu_index_t *);
 size_t impg_gpu_target_ids(const impg_gpu_index_t *, uint32_t *out, size_t cap);
 size_t impg_gpu_num_entries(const impg_gpu_index_t *);
 size_t impg_gpu_num_records(const impg_gpu_index_t *);
+/* HBM the index's arrays hold.  Grows once, by 128 bytes per CIGAR tile, when a query first sets min_identity
+ * (min_gap_compressed_identity, impg_index.rs:31): the identity lines -- a third of a full index, read by that filter
+ * only -- are built on the device at that point (IMPG_E_OOM if they do not fit); IMPG_IDENTITY_LINES=1 in the
+ * environment builds them with the index. */
 size_t impg_gpu_device_bytes(const impg_gpu_index_t *);
 /* 1: the index was built from tracepoints and answers every query in the reference's approximate mode
  * (approximate_mode = true of the trait methods, src/impg_index.rs:34, :93); 0: built from CIGARs, exact mode.

@@ -715,10 +715,13 @@ def test_saved_index_round_trip(tmp_path, n_files):
     for part in ("sharded.impghbm", "sharded.impghbm.shard0of3"):
         with pytest.raises(impg_amd.ImpgGpuError):
             impg_amd.GpuImpg.load(str(tmp_path / part))
-    # a second save of the loaded index is the same file
+    # a second save of the loaded index is the same file (of a fresh load: `h` has built its identity lines for the filter
+    # above, test_identity_lines_on_demand, and would save them too)
     again = str(tmp_path / "again.impghbm")
-    h.save(again)
+    impg_amd.GpuImpg.load(saved).save(again)
     assert open(saved, "rb").read() == open(again, "rb").read()
+    h.save(again)
+    assert len(open(again, "rb").read()) > len(open(saved, "rb").read())
     # damaged / foreign files are refused
     blob = open(saved, "rb").read()
     for bad in (blob[:len(blob) // 2], b"IMPGIDX2" + blob[8:], blob[:-8] + bytes(8)):
@@ -1368,7 +1371,7 @@ def test_index_without_prefix_lines(tmp_path):
     finally:
         os.environ.pop("IMPG_PREFIX_LINES", None)
         os.environ.pop("IMPG_BUILD_HOST", None)
-    assert g.device_bytes() < 0.75 * g_full.device_bytes()
+    assert g.device_bytes() < 0.85 * g_full.device_bytes()  # (op lines + sub-tile rows against op + prefix lines; the identity lines come on demand)
     ranges = random_ranges(5, 150, 6, 60_000, max_len=6000, min_len=1)
     assert_same(g, c, ranges)
     assert_same(g, c, ranges[:60], transitive=True, max_depth=3, min_transitive_len=20)
@@ -1382,6 +1385,52 @@ def test_index_without_prefix_lines(tmp_path):
     g2 = impg_amd.GpuImpg.load(str(tmp_path / "np.idx"))
     assert g2.device_bytes() == g.device_bytes()
     assert_same(g2, c, ranges[:50], transitive=True, max_depth=2)
+
+
+def test_identity_lines_on_demand(tmp_path):
+    """An index with prefix lines carries no identity lines until a query filters by min_gap_compressed_identity
+    (impg.rs:1283-1287): 2.2 KB a record instead of 3.2.  The lines built on demand, from the op lines, are byte for byte
+    the ones both builders write when asked up front (IMPG_IDENTITY_LINES=1), through every entry point that can be the
+    first to ask -- the batch engine, the one-synchronisation small batch, the per-query walk -- and a saved index keeps
+    whichever state it was saved in."""
+    import os
+    text, _ = random_paf(31, 300, n_seq=6, seq_len=50_000, max_ops=500, weird=True, inconsistent=True, self_aln=True)
+    g, c = both(tmp_path, text)
+    paf = str(tmp_path / "t.paf")
+    ranges = random_ranges(9, 120, 6, 50_000, max_len=5000, min_len=1)
+    lean = g.device_bytes()
+    assert_same(g, c, ranges, transitive=True, max_depth=2, min_transitive_len=20)  # (no filter: nothing is built)
+    assert g.device_bytes() == lean
+    g.save(str(tmp_path / "lean.idx"))
+    assert_same(g, c, ranges, min_identity=0.9)  # the batch engine asks first
+    full = g.device_bytes()
+    assert full > lean and (full - lean) % 128 == 0  # one 128-byte line a tile
+    assert_same(g, c, ranges[:40], transitive=True, max_depth=3, min_transitive_len=20, min_identity=0.85)
+    g.save(str(tmp_path / "lazy.idx"))
+    os.environ["IMPG_IDENTITY_LINES"] = "1"
+    try:
+        eager = impg_amd.GpuImpg.from_paf(paf)
+        os.environ["IMPG_BUILD_HOST"] = "1"
+        eager_host = impg_amd.GpuImpg.from_paf(paf)
+    finally:
+        os.environ.pop("IMPG_IDENTITY_LINES", None)
+        os.environ.pop("IMPG_BUILD_HOST", None)
+    assert eager.device_bytes() == full == eager_host.device_bytes()
+    eager.save(str(tmp_path / "eager.idx"))
+    eager_host.save(str(tmp_path / "eager_host.idx"))
+    lazy_bytes = open(str(tmp_path / "lazy.idx"), "rb").read()
+    assert lazy_bytes == open(str(tmp_path / "eager.idx"), "rb").read() == open(str(tmp_path / "eager_host.idx"), "rb").read()
+    # a lean file loads lean and builds its lines like the index it was saved from; other first askers: the small batch, the walk
+    h = impg_amd.GpuImpg.load(str(tmp_path / "lean.idx"))
+    assert h.device_bytes() == lean
+    t, s0, e0 = ranges[3]
+    assert h.query(t, s0, e0, min_gap_compressed_identity=0.9).tolist() == c.query(t, s0, e0, min_identity=0.9).tolist()
+    assert h.device_bytes() == full
+    h2 = impg_amd.GpuImpg.load(str(tmp_path / "lean.idx"))
+    got = h2.query_transitive_dfs(t, s0, e0, max_depth=2, min_transitive_len=20, min_gap_compressed_identity=0.9)
+    assert got.tolist() == c.query(t, s0, e0, transitive=True, dfs=True, max_depth=2, min_transitive_len=20, min_identity=0.9).tolist()
+    assert h2.device_bytes() == full
+    assert impg_amd.GpuImpg.load(str(tmp_path / "lazy.idx")).device_bytes() == full
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])

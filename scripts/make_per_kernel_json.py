@@ -37,11 +37,11 @@ bench = json.loads(open(os.path.join(d, "trace_bench.json")).read().strip().spli
 passes = bench["steps"] + bench["warmup"]
 trace = list(csv.DictReader(open(os.path.join(d, "trace_kernel_stats.csv"))))
 pmc = {}  # kernel -> counter -> (sum, rows)
-for path in glob.glob(os.path.join(d, "*_pmc.csv")):
+for path in sorted(glob.glob(os.path.join(d, "*_pmc.csv"))):
     for row in csv.DictReader(open(path)):
         c = pmc.setdefault(row["Name"], {})
-        s, n = c.get(row["Counter"], (0.0, 0))
-        c[row["Counter"]] = (s + float(row["Sum"]), n + int(row["Dispatches"]))
+        if row["Counter"] not in c:  # (a counter taken in two passes -- SQ_WAVE_CYCLES, GRBM_GUI_ACTIVE -- counts once: the first file's)
+            c[row["Counter"]] = (float(row["Sum"]), int(row["Dispatches"]))
 step_ns = sum(int(r["TotalDurationNs"]) for r in trace if "cigar_" not in r["Name"] and "tiles_kernel" not in r["Name"] and "entries_kernelEPK17" not in r["Name"]) / passes
 res = []
 for r in trace:

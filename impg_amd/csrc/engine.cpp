@@ -396,6 +396,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   // (the owner side of a sharded hop may do the same when the order runs home rank by home rank: `blocks`)
   const bool by_place = free_slot_order && (!raw || blocks) && !multi && !store_cigar && d_perm;
   last_by_place = by_place;
+  expand_n_fr = n_fr;
   const bool fused = by_place && fuse_final && emit_by_lanes(v) && !v.tp_mode;
   if (by_place) win_se.reserve((size_t)n_fr * 8);
   launch_lookup_count(v, fr, n_fr, transitive, d_perm, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(),
@@ -537,7 +538,12 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       sg_q = seg_q.as<uint32_t>();
       uint32_t *qfirst = sg_q, *qlast = qfirst + n_queries, *qact = qlast + n_queries, *qdst = qact + n_queries, *qgrp = qdst + n_queries,
                *gdst = qgrp + n_queries, *unsorted = gdst + n_queries;
-      launch_seg_bounds(fr, n_fr, n_queries, L.pair_range.as<uint32_t>(), P, sg_run_start, sg_run_end, qfirst, qlast, unsorted, stream);
+      // (the runs from the offsets the lookup left on this device -- by place in its order, or by range -- when they are still
+      // there: a hop over other ranks brings slots without them, store_cigar reuses the counts for its slices)
+      const bool own_offsets = !remote && !store_cigar && L.n_frontier == expand_n_fr;
+      launch_seg_bounds(fr, n_fr, n_queries, L.pair_range.as<uint32_t>(), P, sg_run_start, sg_run_end, qfirst, qlast, unsorted, stream,
+                        own_offsets && last_by_place ? lo_perm.as<uint32_t>() : nullptr, own_offsets ? pair_off.as<uint32_t>() : nullptr,
+                        own_offsets ? cnt.as<uint32_t>() : nullptr);
       const size_t bb = seg_group_bins_bytes(n_queries, v.n_seq);
       if (bb <= (512ull << 20)) { seg_bins.reserve(std::max<size_t>(bb, 256)); sg_bins = seg_bins.as<uint32_t>(); }  // (kept for the place pass)
       launch_seg_group(true, fr, qfirst, qlast, sg_run_start, sg_run_end, h, n_queries, v.n_seq, qact, qdst, qgrp, gdst, nullptr, nullptr, nullptr, sg_bins,

@@ -2467,6 +2467,18 @@ __global__ __launch_bounds__(256) void run_bounds_kernel(const uint32_t *__restr
   if (p == 0 || pair_range[p - 1u] != r) run_start[r] = p;
   if (p + 1u == n || pair_range[p + 1u] != r) run_end[r] = p + 1u;
 }
+// ... and where the lookup left the ranges' offsets and counts (Engine::expand on this device), straight from those: a pass
+// over the frontier instead of one over every slot (0.31 ms of a headline step).  perm: the lookup order the offsets are
+// listed in (slot = place in that order), or null for offsets by range.
+__global__ __launch_bounds__(256) void run_bounds_by_offsets_kernel(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pair_off,
+                                                                    const uint32_t *__restrict__ cnt, uint32_t n_fr,
+                                                                    uint32_t *__restrict__ run_start, uint32_t *__restrict__ run_end) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_fr) return;
+  const uint32_t r = perm ? perm[i] : i, a = pair_off[i];
+  run_start[r] = a;
+  run_end[r] = a + cnt[i];
+}
 __global__ __launch_bounds__(256) void query_bounds_kernel(const FrontierRec *__restrict__ fr, uint32_t n_fr, uint32_t n_queries, uint32_t *__restrict__ qfirst,
                                                            uint32_t *__restrict__ qlast, uint32_t *__restrict__ unsorted) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -3081,29 +3093,52 @@ template <class L> __device__ __forceinline__ uint32_t wave_lower_bound(const L 
   const uint32_t idx = lo + lane;
   return lo + (uint32_t)__popcll(__ballot(idx < hi && R.x(idx) < s));
 }
+// (Round 5: four chunks of 64 per round trip.  A chunk was read, waited for and written before the next was read -- eight
+// dependent LDS round trips to make room in the middle of a 1 000-range list, most of a sequential hit's ~1 200 clocks.
+// The chunks of one round neither read what another of them writes -- going down, chunk j writes [b_j + 1, t_j + 1) and
+// the chunks below it read below b_j -- so all four are requested, then all four stored; IMPG_VW_SHIFT_CHUNKS = 1 is the old loop.)
+#ifndef IMPG_VW_SHIFT_CHUNKS
+#define IMPG_VW_SHIFT_CHUNKS 4
+#endif
+constexpr uint32_t VW_SHIFT_CHUNKS = IMPG_VW_SHIFT_CHUNKS;
 template <class L> __device__ __forceinline__ void wave_shift_up(const L &R, uint32_t pos, uint32_t len) {  // [pos, len) -> [pos+1, len+1)
   const uint32_t lane = lane_id();
   for (uint32_t top = len; top > pos;) {
-    const uint32_t base = top > pos + 64u ? top - 64u : pos;
-    const uint32_t i = base + lane;
-    const bool on = i < top;
-    int32_t vx = 0, vy = 0;
-    if (on) { vx = R.x(i); vy = R.y(i); }
+    int32_t vx[VW_SHIFT_CHUNKS], vy[VW_SHIFT_CHUNKS];
+    uint32_t at[VW_SHIFT_CHUNKS];
+    bool on[VW_SHIFT_CHUNKS];
+#pragma unroll
+    for (uint32_t c = 0; c < VW_SHIFT_CHUNKS; c++) {
+      const uint32_t base = top > pos + 64u ? top - 64u : pos;
+      at[c] = base + lane;
+      on[c] = at[c] < top;
+      vx[c] = 0; vy[c] = 0;
+      if (on[c]) { vx[c] = R.x(at[c]); vy[c] = R.y(at[c]); }
+      top = base;  // (an exhausted range leaves top == pos: the remaining chunks of the round are empty)
+    }
     order_point(R);
-    if (on) { R.x(i + 1) = vx; R.y(i + 1) = vy; }
+#pragma unroll
+    for (uint32_t c = 0; c < VW_SHIFT_CHUNKS; c++)
+      if (on[c]) { R.x(at[c] + 1) = vx[c]; R.y(at[c] + 1) = vy[c]; }
     order_point(R);
-    top = base;
   }
 }
 template <class L> __device__ __forceinline__ void wave_shift_down(const L &R, uint32_t from, uint32_t len, uint32_t k) {  // [from, len) -> [from-k, len-k)
   const uint32_t lane = lane_id();
-  for (uint32_t base = from; base < len; base += 64u) {
-    const uint32_t i = base + lane;
-    const bool on = i < len;
-    int32_t vx = 0, vy = 0;
-    if (on) { vx = R.x(i); vy = R.y(i); }
+  for (uint32_t base = from; base < len; base += 64u * VW_SHIFT_CHUNKS) {
+    int32_t vx[VW_SHIFT_CHUNKS], vy[VW_SHIFT_CHUNKS];
+#pragma unroll
+    for (uint32_t c = 0; c < VW_SHIFT_CHUNKS; c++) {
+      const uint32_t i = base + c * 64u + lane;
+      vx[c] = 0; vy[c] = 0;
+      if (i < len) { vx[c] = R.x(i); vy[c] = R.y(i); }
+    }
     order_point(R);
-    if (on) { R.x(i - k) = vx; R.y(i - k) = vy; }
+#pragma unroll
+    for (uint32_t c = 0; c < VW_SHIFT_CHUNKS; c++) {
+      const uint32_t i = base + c * 64u + lane;
+      if (i < len) { R.x(i - k) = vx[c]; R.y(i - k) = vy[c]; }
+    }
     order_point(R);
   }
 }
@@ -4461,13 +4496,18 @@ void launch_sort_pairs(void *tmp, size_t tmp_bytes, const unsigned long long *ki
 bool seg_group_fits(uint32_t n_seq) { return n_seq <= SEG_MAX_SEQ; }
 size_t seg_group_bins_bytes(uint32_t n_queries, uint32_t n_seq) { return (size_t)n_queries * ((std::max(n_seq, 1u) + 63u) & ~63u) * 4; }
 void launch_seg_bounds(const FrontierRec *fr, uint32_t n_fr, uint32_t n_queries, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *run_start,
-                       uint32_t *run_end, uint32_t *qfirst, uint32_t *qlast, uint32_t *unsorted, hipStream_t s) {
-  IMPG_HIP(hipMemsetAsync(run_start, 0, (size_t)n_fr * 4, s));
-  IMPG_HIP(hipMemsetAsync(run_end, 0, (size_t)n_fr * 4, s));
+                       uint32_t *run_end, uint32_t *qfirst, uint32_t *qlast, uint32_t *unsorted, hipStream_t s, const uint32_t *off_perm,
+                       const uint32_t *pair_off, const uint32_t *cnt) {
   IMPG_HIP(hipMemsetAsync(qfirst, 0, (size_t)n_queries * 4, s));
   IMPG_HIP(hipMemsetAsync(qlast, 0, (size_t)n_queries * 4, s));
   IMPG_HIP(hipMemsetAsync(unsorted, 0, 8, s));  // (and the largest query's hit count behind it)
-  if (n_pairs) run_bounds_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(pair_range, n_pairs, run_start, run_end);
+  if (pair_off && cnt) {
+    if (n_fr) run_bounds_by_offsets_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(off_perm, pair_off, cnt, n_fr, run_start, run_end);
+  } else {
+    IMPG_HIP(hipMemsetAsync(run_start, 0, (size_t)n_fr * 4, s));
+    IMPG_HIP(hipMemsetAsync(run_end, 0, (size_t)n_fr * 4, s));
+    if (n_pairs) run_bounds_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(pair_range, n_pairs, run_start, run_end);
+  }
   if (n_fr) query_bounds_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(fr, n_fr, n_queries, qfirst, qlast, unsorted);
 }
 void launch_seg_group(bool count_only, const FrontierRec *fr, const uint32_t *qfirst, const uint32_t *qlast, const uint32_t *run_start,

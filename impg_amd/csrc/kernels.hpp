@@ -219,7 +219,8 @@ void launch_compact_copy(const VisitedTables &vt, const unsigned long long *src,
 // the update's hits grouped by (query, sequence) without a global sort (kernels.hip: seg_group_kernel)
 bool seg_group_fits(uint32_t n_seq);
 void launch_seg_bounds(const FrontierRec *fr, uint32_t n_fr, uint32_t n_queries, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *run_start,
-                       uint32_t *run_end, uint32_t *qfirst, uint32_t *qlast, uint32_t *unsorted, hipStream_t s);
+                       uint32_t *run_end, uint32_t *qfirst, uint32_t *qlast, uint32_t *unsorted, hipStream_t s, const uint32_t *off_perm = nullptr,
+                       const uint32_t *pair_off = nullptr, const uint32_t *cnt = nullptr);  // pair_off / cnt (+ the order they are listed in): the runs straight from the lookup's offsets
 void launch_seg_group(bool count_only, const FrontierRec *fr, const uint32_t *qfirst, const uint32_t *qlast, const uint32_t *run_start,
                       const uint32_t *run_end, HitArrays h, uint32_t n_queries, uint32_t n_seq, uint32_t *qact, const uint32_t *qdst, uint32_t *qgrp,
                       const uint32_t *gdst, uint32_t *gstart, unsigned long long *gkey, unsigned long long *svals, uint32_t *qbins, hipStream_t s);

@@ -3098,7 +3098,7 @@ template <class L> __device__ __forceinline__ uint32_t wave_lower_bound(const L 
 // The chunks of one round neither read what another of them writes -- going down, chunk j writes [b_j + 1, t_j + 1) and
 // the chunks below it read below b_j -- so all four are requested, then all four stored; IMPG_VW_SHIFT_CHUNKS = 1 is the old loop.)
 #ifndef IMPG_VW_SHIFT_CHUNKS
-#define IMPG_VW_SHIFT_CHUNKS 4
+#define IMPG_VW_SHIFT_CHUNKS 1  // (4: measured on config 5, 4 000 windows: update 629-634 -> 644 ms -- the shifts are not what a sequential hit waits for)
 #endif
 constexpr uint32_t VW_SHIFT_CHUNKS = IMPG_VW_SHIFT_CHUNKS;
 template <class L> __device__ __forceinline__ void wave_shift_up(const L &R, uint32_t pos, uint32_t len) {  // [pos, len) -> [pos+1, len+1)
@@ -3162,6 +3162,24 @@ __device__ __forceinline__ void wave_sort_pieces(int2 *p, uint32_t n) {
     }
   }
 }
+// -DIMPG_VW_CLOCKS (experiments, scripts/vw_clocks.py): where a wave of the deep-closure replay spends its cycles
+#ifdef IMPG_VW_CLOCKS
+constexpr uint32_t VW_CLK_ROWS = 256;
+__device__ unsigned long long g_vw_clk[VW_CLK_ROWS][16];
+#define VW_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define VW_ADD(slot_, val_) do { if (lane_id() == 0) atomicAdd(&g_vw_clk[blockIdx.x % VW_CLK_ROWS][slot_], (unsigned long long)(val_)); } while (0)
+extern "C" void impg_gpu_debug_vw_clocks(unsigned long long *out) {
+  static unsigned long long rows[VW_CLK_ROWS][16];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_vw_clk), sizeof(rows));
+  for (int k = 0; k < 16; k++) { out[k] = 0; for (uint32_t r = 0; r < VW_CLK_ROWS; r++) out[k] += rows[r][k]; }
+  memset(rows, 0, sizeof(rows));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_vw_clk), rows, sizeof(rows));
+}
+#else
+#define VW_T(v) do { } while (0)
+#define VW_ADD(slot_, val_) do { } while (0)
+#endif
 template <class L>
 __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, const unsigned long long *__restrict__ svals,
                                                      uint32_t st, uint32_t n, int32_t sequence_length,
@@ -3324,6 +3342,7 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
 #else
     unsigned long long todo;
     int32_t rs = 0, re = 0;  // this lane's hit of the batch (the sequential part below reads them lane to lane)
+    VW_T(vw0);
     {
       bool need = false, cand = false;
       uint32_t p0 = 0, q = 0, ext = 0;  // ext: 1 / 2 = the hit grows the one range q (see below)
@@ -3363,6 +3382,8 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
         }
       }
       todo = __ballot(need);
+      VW_T(vw1);
+      VW_ADD(0, vw1 - vw0); VW_ADD(4, min(64u, n - t0)); VW_ADD(5, __popcll(todo));
       unsigned long long iso = 0ull, grown = 0ull;
       if (__ballot(cand || ext != 0) != 0ull) {
         bool clear = true;  // nothing else that is still to be replayed comes near this hit's stretch
@@ -3376,6 +3397,8 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
         grown = __ballot(ext != 0 && clear);
         if (ext != 0 && !clear) ext = 0;
       }
+      VW_T(vw2);
+      VW_ADD(1, vw2 - vw1); VW_ADD(6, __popcll(grown)); VW_ADD(7, __popcll(iso) >= 2 ? __popcll(iso) : 0);
       if (grown) {
         bool p1 = false, p2 = false;
         int2 pc1 = make_int2(0, 0), pc2 = make_int2(0, 0);
@@ -3443,9 +3466,13 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
         len += k;
         todo &= ~iso;
       }
+      VW_T(vw3);
+      VW_ADD(2, vw3 - vw2);
     }
 #endif
+    VW_ADD(8, __popcll(todo));
     while (todo) {
+    VW_T(vs0);
     const uint32_t tl = (uint32_t)__ffsll((long long)todo) - 1u;
     todo &= todo - 1ull;
     // (from the lane that loaded it: a second read of svals here was a global-memory round trip per replayed hit)
@@ -3455,8 +3482,10 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
       bool should_add = true;
       if (pos > 0 && abs(start - R.y(pos - 1)) < mdbr) should_add = false;
       if (should_add && pos < len && abs(R.x(pos) - end) < mdbr) should_add = false;
-      if (!should_add) continue;
+      if (!should_add) { VW_T(vsx); VW_ADD(9, vsx - vs0); VW_ADD(13, 1); continue; }
     }
+    VW_T(vs1);
+    VW_ADD(9, vs1 - vs0);
     if (start < 0) { start = 0; pos = wave_lower_bound(R, len, start); }  // impg.rs:287-289 (never taken on real coordinates)
     if (end > sequence_length) end = sequence_length;                      // impg.rs:294-296
     int32_t current = start;
@@ -3476,6 +3505,8 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
       if (writer) P[np] = make_int2(current, end);
       np++;
     }
+    VW_T(vs2);
+    VW_ADD(10, vs2 - vs1);
     uint32_t mfrom;  // impg.rs:330-343
     if (pos > 0 && R.y(pos - 1) >= start) {
       const int32_t ny = max(R.y(pos - 1), end);
@@ -3492,6 +3523,7 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
       if (writer) { R.x(pos) = start; R.y(pos) = end; }
       order_point(R);
       len += 1;
+      { VW_T(vs3); VW_ADD(11, vs3 - vs2); VW_ADD(14, 1); }
       continue;
     }
     order_point(R);
@@ -3508,6 +3540,7 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
       wave_shift_down(R, read, len, k);
       len -= k;
     }
+    { VW_T(vs4); VW_ADD(12, vs4 - vs2); }
   }
   }
   t_next = t0;
@@ -3556,6 +3589,7 @@ __global__ __launch_bounds__(64) void visited_update_wave_kernel(const unsigned 
     }
     if (b >= nb) break;
     const uint32_t g = big_list[from_back ? from_back - 1u - b : b];  // (from_back = n_groups: the list's other end)
+    VW_T(vwg0);
     int2 *R = new_ranges + noff[g];
     const uint32_t st = gstart[g], n = glen[g];
     const int2 *src = old_src[g];  // (the group's current list, resolved by group_prepare; cap = its length + the hits)
@@ -3602,6 +3636,7 @@ __global__ __launch_bounds__(64) void visited_update_wave_kernel(const unsigned 
       w += 1;
     }
     if (lane == 0) { new_len[g] = len; n_pieces[g] = w; }
+    { VW_T(vwg1); VW_ADD(15, vwg1 - vwg0); VW_ADD(3, 1); }
   }
 }
 // ---- hits the OLD list already covers, taken out before the replay --------------------------------------------------

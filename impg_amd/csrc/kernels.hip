@@ -3142,15 +3142,49 @@ template <class L> __device__ __forceinline__ void wave_shift_down(const L &R, u
     order_point(R);
   }
 }
-// ascending sort of p[0..n) by .x: a bitonic network in its all-ascending form (first step of every merge pairs i
-// with its mirror image in the block), so an index past n behaves as +infinity without being stored
+// One compare-exchange of the network between a lane's element and another lane's, in registers (the lower place keeps
+// the smaller start; equal starts stay where they are; a place past the end holds +infinity and never moves).
+__device__ __forceinline__ void sort_cx_lane(int2 &v, uint32_t partner) {
+  int2 o;
+  o.x = __shfl(v.x, (int)partner);
+  o.y = __shfl(v.y, (int)partner);
+  const bool take = partner > lane_id() ? v.x > o.x : v.x < o.x;
+  if (take) v = o;
+}
+// The stages of the network whose partners are less than 64 places apart, for every aligned run of 64 places of q[0 .. m):
+// a lane takes its place's piece into registers once and runs them all there (round 5: 45 of the 55 stages of a
+// 1 024-piece sort; each used to be a pass over LDS with a barrier).  first_k: 0 = the stages j = 32 .. 1 of one merge
+// (its wider stages are done), else every merge k = 2 .. first_k <= 64 from its mirror stage down.
+__device__ __forceinline__ void sort_close_stages(int2 *q, uint32_t m, uint32_t first_k) {
+  const uint32_t lane = lane_id();
+  for (uint32_t base = 0; base < m; base += 64u) {
+    const uint32_t i = base + lane;
+    int2 v = make_int2(0x7FFFFFFF, 0);
+    if (i < m) v = q[i];
+    if (first_k) {
+      for (uint32_t k = 2; k <= first_k; k <<= 1) {
+        sort_cx_lane(v, lane ^ (k - 1u));
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) sort_cx_lane(v, lane ^ j);
+      }
+    } else {
+#pragma unroll
+      for (uint32_t j = 32; j > 0; j >>= 1) sort_cx_lane(v, lane ^ j);
+    }
+    if (i < m) q[i] = v;
+  }
+  __syncthreads();
+}
+// ascending sort of p[0..n) by .x (p in LDS, or a slice of global memory for the in-place lists' few pieces): a bitonic
+// network in its all-ascending form (first step of every merge pairs i with its mirror image in the block), so an index
+// past n behaves as +infinity without being stored
 __device__ __forceinline__ void wave_sort_pieces(int2 *p, uint32_t n) {
   if (n < 2) return;
   const uint32_t lane = lane_id();
   uint32_t n2 = 1;
   while (n2 < n) n2 <<= 1;
-  for (uint32_t k = 2; k <= n2; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+  sort_close_stages(p, n, min(n2, 64u));
+  for (uint32_t k = 128; k <= n2; k <<= 1) {
+    for (uint32_t j = k >> 1; j >= 64u; j >>= 1) {
       for (uint32_t i = lane; i < n; i += 64u) {
         const uint32_t l = (j == (k >> 1)) ? (i ^ (k - 1u)) : (i ^ j);
         if (l > i && l < n) {
@@ -3160,7 +3194,114 @@ __device__ __forceinline__ void wave_sort_pieces(int2 *p, uint32_t n) {
       }
       __syncthreads();
     }
+    sort_close_stages(p, n, 0u);
   }
+}
+// The same network for more pieces than the block's LDS holds (round 5: a deep group of config 5 leaves ~1 000 pieces, a
+// quarter of the groups more than the 1 152 the buffer takes; sorted on their global slice, all 66 stages of a 2 048-piece
+// sort were global-memory round trips, chunk after chunk -- with the piece-by-piece sweep behind it two thirds of the wave
+// kernel's cycles, scripts/vw_clocks.py).  Tiles of TS pieces are sorted in LDS; of the merges beyond a tile only the stages
+// whose partners lie in another tile run on the global slice, the rest again tile by tile in LDS: 2 048 pieces take one
+// global stage and two passes over their tiles.
+template <uint32_t TS>
+__device__ __forceinline__ void wave_sort_pieces_tiled(int2 *p, uint32_t n, int2 *lds) {
+  static_assert((TS & (TS - 1u)) == 0u, "tiles of a power of two");
+  if (n < 2) return;
+  const uint32_t lane = lane_id();
+  uint32_t n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  // every tile by itself
+  for (uint32_t base = 0; base < n; base += TS) {
+    const uint32_t m = min(TS, n - base);
+    __syncthreads();
+    for (uint32_t i = lane; i < m; i += 64u) lds[i] = p[base + i];
+    __syncthreads();
+    sort_close_stages(lds, m, min(min(TS, n2), 64u));
+    for (uint32_t k = 128; k <= min(TS, n2); k <<= 1) {
+      for (uint32_t j = k >> 1; j >= 64u; j >>= 1) {
+        for (uint32_t i = lane; i < m; i += 64u) {
+          const uint32_t l = (j == (k >> 1)) ? (i ^ (k - 1u)) : (i ^ j);
+          if (l > i && l < m) {
+            const int2 a = lds[i], b = lds[l];
+            if (a.x > b.x) { lds[i] = b; lds[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+      sort_close_stages(lds, m, 0u);
+    }
+    for (uint32_t i = lane; i < m; i += 64u) p[base + i] = lds[i];
+  }
+  __syncthreads();
+  for (uint32_t k = 2u * TS; k <= n2; k <<= 1) {
+    for (uint32_t j = k >> 1; j >= TS; j >>= 1) {  // partners in another tile: on the global slice
+      for (uint32_t i = lane; i < n; i += 64u) {
+        const uint32_t l = (j == (k >> 1)) ? (i ^ (k - 1u)) : (i ^ j);
+        if (l > i && l < n) {
+          const int2 a = p[i], b = p[l];
+          if (a.x > b.x) { p[i] = b; p[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+    for (uint32_t base = 0; base < n; base += TS) {  // partners inside the tile (j < TS <= k / 2: never the mirror form)
+      const uint32_t m = min(TS, n - base);
+      for (uint32_t i = lane; i < m; i += 64u) lds[i] = p[base + i];
+      __syncthreads();
+      for (uint32_t j = TS >> 1; j >= 64u; j >>= 1) {
+        for (uint32_t i = lane; i < m; i += 64u) {
+          const uint32_t l = i ^ j;
+          if (l > i && l < m) {
+            const int2 a = lds[i], b = lds[l];
+            if (a.x > b.x) { lds[i] = b; lds[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+      sort_close_stages(lds, m, 0u);
+      for (uint32_t i = lane; i < m; i += 64u) p[base + i] = lds[i];
+      __syncthreads();
+    }
+  }
+}
+// The sweep over the sorted pieces (impg.rs:2568-2584: a piece that starts at or before the running end of the range being
+// built extends it, one that starts beyond it closes the range and opens the next), 64 pieces a step: the running end is
+// a prefix maximum of the ends -- over ALL earlier pieces, which is the current range's own maximum: an earlier range
+// ended before the current one began -- a piece that starts beyond it is a head; a head stores its start as range k's
+// and the maximum before it as range k - 1's end.  (Piece by piece this was one dependent read per piece: 10^3 LDS round
+// trips a group, global-memory ones when the pieces did not fit the buffer.)  S may be the slice `out` itself: range k
+// lies at or below the piece that opens it, and a step's pieces are read before any of its stores.
+__device__ __forceinline__ uint32_t wave_merge_sorted_pieces(const int2 *S, uint32_t n, int2 *out) {
+  const uint32_t lane = lane_id();
+  int32_t carry = (int32_t)0x80000000;
+  uint32_t heads = 0;
+  int32_t *o = reinterpret_cast<int32_t *>(out);
+  for (uint32_t base = 0; base < n; base += 64u) {
+    const uint32_t i = base + lane;
+    const bool on = i < n;
+    int2 q = make_int2(0x7FFFFFFF, (int32_t)0x80000000);
+    if (on) q = S[i];
+    int32_t m = q.y;  // inclusive prefix maximum of the ends over the step
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int32_t y = __shfl_up(m, d);
+      if ((int)lane >= d) m = max(m, y);
+    }
+    int32_t prev = __shfl_up(m, 1);
+    prev = lane == 0 ? carry : max(carry, prev);
+    const bool head = on && (i == 0u || q.x > prev);
+    const unsigned long long hm = __ballot(head);
+    const uint32_t k = heads + (uint32_t)__popcll(hm & lanemask_lt());
+    __syncthreads();  // (every piece of the step has been read: its stores may land on them)
+    if (head) {
+      o[2u * k] = q.x;
+      if (k > 0u) o[2u * (k - 1u) + 1u] = prev;
+    }
+    carry = max(carry, __shfl(m, 63));
+    heads += (uint32_t)__popcll(hm);
+  }
+  if (n && lane == 0) o[2u * (heads - 1u) + 1u] = carry;
+  return heads;
 }
 // -DIMPG_VW_CLOCKS (experiments, scripts/vw_clocks.py): where a wave of the deep-closure replay spends its cycles
 #ifdef IMPG_VW_CLOCKS
@@ -3398,7 +3539,7 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
         if (ext != 0 && !clear) ext = 0;
       }
       VW_T(vw2);
-      VW_ADD(1, vw2 - vw1); VW_ADD(6, __popcll(grown)); VW_ADD(7, __popcll(iso) >= 2 ? __popcll(iso) : 0);
+      VW_ADD(1, vw2 - vw1); VW_ADD(6, __popcll(grown) + (__popcll(iso) >= 2 ? __popcll(iso) : 0));
       if (grown) {
         bool p1 = false, p2 = false;
         int2 pc1 = make_int2(0, 0), pc2 = make_int2(0, 0);
@@ -3482,7 +3623,7 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
       bool should_add = true;
       if (pos > 0 && abs(start - R.y(pos - 1)) < mdbr) should_add = false;
       if (should_add && pos < len && abs(R.x(pos) - end) < mdbr) should_add = false;
-      if (!should_add) { VW_T(vsx); VW_ADD(9, vsx - vs0); VW_ADD(13, 1); continue; }
+      if (!should_add) { VW_T(vsx); VW_ADD(9, vsx - vs0); continue; }
     }
     VW_T(vs1);
     VW_ADD(9, vs1 - vs0);
@@ -3523,7 +3664,7 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
       if (writer) { R.x(pos) = start; R.y(pos) = end; }
       order_point(R);
       len += 1;
-      { VW_T(vs3); VW_ADD(11, vs3 - vs2); VW_ADD(14, 1); }
+      { VW_T(vs3); VW_ADD(11, vs3 - vs2); }
       continue;
     }
     order_point(R);
@@ -3612,29 +3753,22 @@ __global__ __launch_bounds__(64) void visited_update_wave_kernel(const unsigned 
       len = replay_hits_wave(ListInPlace{R}, len, svals, st, n, sequence_length, min_transitive_len, mdbr, P, np, t_next, 0xFFFFFFFFu);
     __syncthreads();
     // next-depth ranges of the group: sorted by start, overlapping / contiguous ones merged (impg.rs:2568-2584)
+    VW_T(vwp0);
     int2 *S = P;
     if (np <= CAP) {
       for (uint32_t i = lane; i < np; i += 64u) lds[i] = P[i];
       __syncthreads();
       S = lds;
+      wave_sort_pieces(S, np);
+    } else {
+      constexpr uint32_t TS = CAP >= 4096u ? 4096u : CAP >= 1024u ? 1024u : 128u;  // the largest power of two the buffer holds
+      wave_sort_pieces_tiled<TS>(P, np, lds);
     }
-    wave_sort_pieces(S, np);
-    uint32_t w = 0;
-    if (np) {
-      int32_t cx = S[0].x, cy = S[0].y;
-      int2 *out = pieces + poff[g];
-      for (uint32_t r = 1; r < np; r++) {
-        const int2 q = S[r];
-        if (cy >= q.x) cy = max(cy, q.y);
-        else {  // (in place when S is the global slice: w < r, the slot rewritten was read in an earlier iteration)
-          if (lane == 0) out[w] = make_int2(cx, cy);
-          w += 1;
-          cx = q.x; cy = q.y;
-        }
-      }
-      if (lane == 0) out[w] = make_int2(cx, cy);
-      w += 1;
-    }
+    VW_T(vwp1);
+    VW_ADD(13, vwp1 - vwp0); VW_ADD(7, np > CAP ? 1 : 0);
+    const uint32_t w = wave_merge_sorted_pieces(S, np, pieces + poff[g]);
+    __syncthreads();
+    { VW_T(vwp2); VW_ADD(14, vwp2 - vwp1); }
     if (lane == 0) { new_len[g] = len; n_pieces[g] = w; }
     { VW_T(vwg1); VW_ADD(15, vwg1 - vwg0); VW_ADD(3, 1); }
   }

@@ -39,15 +39,15 @@ def main():
     b = [int(x) for x in buf]
     groups = max(b[3], 1)
     out = {"groups": b[3], "cycles_per_group": b[15] / groups, "hits_per_group": b[4] / groups,
-           "uncovered_share": b[5] / max(b[4], 1), "grown_share_of_uncovered": b[6] / max(b[5], 1), "isolated_share_of_uncovered": b[7] / max(b[5], 1),
-           "sequential_share_of_uncovered": b[8] / max(b[5], 1), "dropped_by_proximity_share_of_sequential": b[13] / max(b[8], 1),
-           "plain_inserts_share_of_sequential": b[14] / max(b[8], 1),
+           "uncovered_share": b[5] / max(b[4], 1), "grown_or_isolated_share_of_uncovered": b[6] / max(b[5], 1),
+           "sequential_share_of_uncovered": b[8] / max(b[5], 1), "groups_with_more_pieces_than_the_buffer": b[7] / groups,
            "cycles_share": {"batch head (load, coverage test, classes' tests)": b[0] / max(b[15], 1), "conflict loop": b[1] / max(b[15], 1),
                             "grown + isolated classes applied": b[2] / max(b[15], 1),
                             "sequential: lower bound + proximity": b[9] / max(b[15], 1), "sequential: walk (pieces)": b[10] / max(b[15], 1),
-                            "sequential: plain insert (shift up)": b[11] / max(b[15], 1), "sequential: grow + merge forward (shift down)": b[12] / max(b[15], 1)},
+                            "sequential: plain insert (shift up)": b[11] / max(b[15], 1), "sequential: grow + merge forward (shift down)": b[12] / max(b[15], 1),
+                            "pieces sorted": b[13] / max(b[15], 1), "pieces swept into ranges": b[14] / max(b[15], 1)},
            "cycles_per_sequential_hit": (b[9] + b[10] + b[11] + b[12]) / max(b[8], 1), "ms_update": st.ms_update}
-    out["cycles_share"]["the rest (list in / out of LDS, pieces sorted, group fetch)"] = 1.0 - sum(out["cycles_share"].values())
+    out["cycles_share"]["the rest (list in / out of LDS, group fetch)"] = 1.0 - sum(out["cycles_share"].values())
     print(json.dumps(out, indent=1))
 
 

@@ -3097,6 +3097,9 @@ template <class L> __device__ __forceinline__ uint32_t wave_lower_bound(const L 
 // dependent LDS round trips to make room in the middle of a 1 000-range list, most of a sequential hit's ~1 200 clocks.
 // The chunks of one round neither read what another of them writes -- going down, chunk j writes [b_j + 1, t_j + 1) and
 // the chunks below it read below b_j -- so all four are requested, then all four stored; IMPG_VW_SHIFT_CHUNKS = 1 is the old loop.)
+#ifndef IMPG_VW_WINDOW_TURN
+#define IMPG_VW_WINDOW_TURN 1  // a sequential hit's turn on one 64-range read of the list (replay_hits_wave); 0: round 3's loops
+#endif
 #ifndef IMPG_VW_SHIFT_CHUNKS
 #define IMPG_VW_SHIFT_CHUNKS 1  // (4: measured on config 5, 4 000 windows: update 629-634 -> 644 ms -- the shifts are not what a sequential hit waits for)
 #endif
@@ -3302,6 +3305,22 @@ __device__ __forceinline__ uint32_t wave_merge_sorted_pieces(const int2 *S, uint
   }
   if (n && lane == 0) o[2u * (heads - 1u) + 1u] = carry;
   return heads;
+}
+// The wave's 64 (key, lane) pairs in ascending order of the key, a pair per lane, by a bitonic network on the lanes
+// themselves (21 exchanges of two shuffles; ties by lane: a total order, so both partners of an exchange agree).
+__device__ __forceinline__ void wave_sort_by_key(int32_t &key, uint32_t &val) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (uint32_t k = 2; k <= 64u; k <<= 1) {
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const int32_t ok = __shfl_xor(key, (int)j);
+      const uint32_t ov = (uint32_t)__shfl_xor((int)val, (int)j);
+      const bool keep_min = ((lane & j) == 0u) == ((lane & k) == 0u);  // (k = 64: every block ascends)
+      const bool other_less = ok < key || (ok == key && ov < val);
+      if (keep_min == other_less) { key = ok; val = ov; }
+    }
+  }
 }
 // -DIMPG_VW_CLOCKS (experiments, scripts/vw_clocks.py): where a wave of the deep-closure replay spends its cycles
 #ifdef IMPG_VW_CLOCKS
@@ -3526,13 +3545,39 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
       VW_T(vw1);
       VW_ADD(0, vw1 - vw0); VW_ADD(4, min(64u, n - t0)); VW_ADD(5, __popcll(todo));
       unsigned long long iso = 0ull, grown = 0ull;
+      uint32_t iso_rank = 0;  // an isolated hit's place among the isolated hits of the batch, by start
       if (__ballot(cand || ext != 0) != 0ull) {
-        bool clear = true;  // nothing else that is still to be replayed comes near this hit's stretch
-        for (unsigned long long left = todo; left; left &= left - 1ull) {
-          const uint32_t j = (uint32_t)__ffsll((long long)left) - 1u;
-          const int32_t sj = __builtin_amdgcn_readlane(rs, j), ej = __builtin_amdgcn_readlane(re, j);
-          if (j != lane && sj - iso_margin <= fhi && flo <= ej + iso_margin) clear = false;
+        // "nothing else that is still to be replayed comes near this hit's stretch": with the hits still to be replayed in
+        // the order of their starts, something BEFORE this hit reaches its stretch iff the largest end (+ margin) before
+        // it does, something AFTER it iff the next start (- margin) does -- a sort of the wave's 64 starts on the lanes, a
+        // prefix maximum and a look at the neighbour, where round 3 had every lane walk over all the others (a
+        // v_readlane pair per hit and lane: 14 % of the deep groups' cycles).  The stretch [flo, fhi] contains the hit's
+        // own [start - margin, end + margin], which is what makes "before" and "after" one-sided tests.
+        const bool in_todo = ((todo >> lane) & 1ull) != 0ull;
+        int32_t key = in_todo ? rs - iso_margin : 0x7FFFFFFF;
+        uint32_t o = lane;
+        wave_sort_by_key(key, o);
+        const int32_t hi_o = __shfl(in_todo ? re + iso_margin : (int32_t)0x80000000, (int)o);
+        const int32_t flo_o = __shfl(flo, (int)o), fhi_o = __shfl(fhi, (int)o);
+        const bool cand_o = __shfl((int)cand, (int)o) != 0;
+        int32_t pm = hi_o;  // inclusive prefix maximum of the ends in start order
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int32_t y = __shfl_up(pm, d);
+          if ((int)lane >= d) pm = max(pm, y);
         }
+        int32_t before = __shfl_up(pm, 1);
+        if (lane == 0) before = (int32_t)0x80000000;
+        int32_t next = __shfl_down(key, 1);
+        if (lane == 63u) next = 0x7FFFFFFF;
+        const bool clear_o = before < flo_o && next > fhi_o;
+        const unsigned long long iso_o = __ballot(cand_o && clear_o);
+        __syncthreads();  // (iso_point may still be read by the previous batch)
+        iso_point[o] = (clear_o ? 1u : 0u) | ((uint32_t)__popcll(iso_o & lanemask_lt()) << 1);
+        __syncthreads();
+        const uint32_t back = iso_point[lane];
+        const bool clear = (back & 1u) != 0u;
+        iso_rank = back >> 1;
         cand = cand && clear;
         iso = __ballot(cand);
         grown = __ballot(ext != 0 && clear);
@@ -3570,11 +3615,7 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
       }
       if (__popcll(iso) >= 2) {
         const uint32_t k = (uint32_t)__popcll(iso);
-        uint32_t rank = 0;
-        for (unsigned long long left = iso; left; left &= left - 1ull) {
-          const uint32_t j = (uint32_t)__ffsll((long long)left) - 1u;
-          rank += __builtin_amdgcn_readlane(rs, j) < rs ? 1u : 0u;
-        }
+        const uint32_t rank = iso_rank;  // (from the sort above: the isolated hits before this one in start order)
         // their pieces (any order: the pieces are sorted afterwards)
         const bool emit = cand && re - rs >= min_transitive_len;
         const unsigned long long em = __ballot(emit);
@@ -3619,6 +3660,83 @@ __device__ __forceinline__ uint32_t replay_hits_wave(const L &R, uint32_t len, c
     // (from the lane that loaded it: a second read of svals here was a global-memory round trip per replayed hit)
     int32_t start = __builtin_amdgcn_readlane(rs, tl), end = __builtin_amdgcn_readlane(re, tl);
     uint32_t pos = wave_lower_bound(R, len, start);
+#if IMPG_VW_WINDOW_TURN
+    // Round 5: a sequential hit's turn on ONE read of the list.  Everything the turn looks at -- the range before the hit's
+    // lower bound (proximity test, the walk's first range, the insert's extension), the ranges that start inside the
+    // hit (the walk's gaps, the ranges merge_forward swallows) and the first one beyond -- is the 64 ranges from pos - 1:
+    // a lane takes one, and the walk (impg.rs:314-328), the insert (:330-343) and the merge (:355-368) become ballots
+    // over them instead of loops of dependent LDS reads (4 200 clocks a hit, a third of a deep group's cycles).  The
+    // walk's `current` before range k is max(start, end of range k - 1) -- the list's ends ascend --, the ranges it
+    // visits are a prefix (start <= end and current < end), and what the grown range swallows are the ranges that start
+    // at or below its new end: also a prefix, and the last of them gives the final end.  A hit the clamps touch, or
+    // whose ranges run past the 64, takes the loops below.
+    {
+      const uint32_t w0 = pos ? pos - 1u : 0u, wi = w0 + lane;
+      const bool wv = wi < len;
+      int32_t wx = 0x7FFFFFFF, wyv = (int32_t)0x80000000;
+      if (wv) { wx = R.x(wi); wyv = R.y(wi); }
+      const uint32_t tp = pos - w0;  // the lane of range `pos`: 1, or 0 in front of the whole list
+      const int32_t y_prev = __builtin_amdgcn_readlane(wyv, 0);                       // (meaningful iff pos > 0)
+      const int32_t x_pos = tp ? __builtin_amdgcn_readlane(wx, 1) : __builtin_amdgcn_readlane(wx, 0);  // INT_MAX iff pos == len
+      const int32_t y_pos = tp ? __builtin_amdgcn_readlane(wyv, 1) : __builtin_amdgcn_readlane(wyv, 0);
+      const bool far = w0 + 64u < len && __builtin_amdgcn_readlane(wx, 63) <= end;
+      if (start >= 0 && end <= sequence_length && !far) {
+        if (mdbr > 0) {  // impg.rs:2513-2545
+          bool should_add = true;
+          if (pos > 0 && abs(start - y_prev) < mdbr) should_add = false;
+          if (should_add && pos < len && abs(x_pos - end) < mdbr) should_add = false;
+          if (!should_add) { VW_T(vsx); VW_ADD(9, vsx - vs0); continue; }
+        }
+        VW_T(vs1);
+        VW_ADD(9, vs1 - vs0);
+        // the walk: ranges from lane `off` on
+        const uint32_t off = (pos > 0 && y_prev > start) ? 0u : tp;
+        const int32_t yp = __shfl_up(wyv, 1);
+        const int32_t cur = lane <= off ? start : max(start, yp);
+        const bool proc = lane >= off && wv && wx <= end && cur < end;
+        const unsigned long long pmask = __ballot(proc) >> off;
+        const uint32_t K = ~pmask ? (uint32_t)__builtin_ctzll(~pmask) : 64u - off;  // the ranges the walk visits: lanes [off, off + K)
+        const bool gap = lane >= off && lane < off + K && cur < wx && wx - cur >= min_transitive_len;
+        const unsigned long long gm = __ballot(gap);
+        if (gap) P[np + (uint32_t)__popcll(gm & lanemask_lt())] = make_int2(cur, wx);
+        np += (uint32_t)__popcll(gm);
+        const int32_t cK = K ? max(start, (int32_t)__shfl(wyv, (int)(off + K - 1u))) : start;
+        if (cK < end && end - cK >= min_transitive_len) {
+          if (writer) P[np] = make_int2(cK, end);
+          np++;
+        }
+        VW_T(vs2);
+        VW_ADD(10, vs2 - vs1);
+        // the insert (impg.rs:330-343) and what the grown range swallows (merge_forward_from, :355-368)
+        const bool ext_prev = pos > 0 && y_prev >= start, ext_pos = !ext_prev && pos < len && end >= x_pos;
+        if (!ext_prev && !ext_pos) {
+          wave_shift_up(R, pos, len);
+          if (writer) { R.x(pos) = start; R.y(pos) = end; }
+          order_point(R);
+          len += 1;
+          { VW_T(vs3); VW_ADD(11, vs3 - vs2); }
+          continue;
+        }
+        const uint32_t tm = ext_prev ? 0u : tp, mfrom = w0 + tm;
+        const int32_t wy0 = ext_prev ? max(y_prev, end) : max(end, y_pos);
+        const unsigned long long sw = __ballot(lane > tm && wv && wx <= wy0);
+        const uint32_t k = (uint32_t)__popcll(sw);
+        const int32_t wyf = k ? max(wy0, (int32_t)__shfl(wyv, (int)(tm + k))) : wy0;
+        order_point(R);
+        if (writer) {
+          R.y(mfrom) = wyf;
+          if (ext_pos) R.x(mfrom) = min(start, x_pos);
+        }
+        order_point(R);
+        if (k) {
+          wave_shift_down(R, mfrom + 1u + k, len, k);
+          len -= k;
+        }
+        { VW_T(vs4); VW_ADD(12, vs4 - vs2); }
+        continue;
+      }
+    }
+#endif
     if (mdbr > 0) {  // impg.rs:2513-2545
       bool should_add = true;
       if (pos > 0 && abs(start - R.y(pos - 1)) < mdbr) should_add = false;

@@ -392,23 +392,22 @@ __global__ __launch_bounds__(256) void run_lengths_kernel(const uint32_t *__rest
 // bounds (optional): the records come in n_blocks contiguous blocks (records [bounds[b], bounds[b+1]) -- on a shard,
 // what each home rank sent); the block goes above the window bits, so the order is block by block and a block's
 // pairs stay together.
-// where a range's window will be in the entry array, estimated from the record alone (the lookup order's key)
-__device__ __forceinline__ uint32_t order_key(const SegDesc *__restrict__ seg, const int32_t *__restrict__ seq_len, uint32_t n_seq,
-                                              uint32_t target_id, int32_t start) {
-  if (target_id >= n_seq) return 0u;
-  const uint2 d = *reinterpret_cast<const uint2 *>(seg + target_id);  // {a, n}
-  const int32_t len = seq_len[target_id];
-  const uint64_t st = (uint64_t)(uint32_t)max(start, 0);
-  const uint64_t rel = len > 0 ? st * d.y / (uint64_t)(uint32_t)len : 0ull;
-  return d.x + (uint32_t)min(rel, (uint64_t)(d.y ? d.y - 1u : 0u));
-}
+// (Round 5, measured and dropped: frontier_emit writing the next level's keys beside the records -- lookup 5.65 -> 5.25 ms,
+// update 6.03 -> 6.36: the key's 64-bit division costs the same wherever it runs.)
 __global__ __launch_bounds__(256) void order_keys_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr, uint32_t n,
                                                          uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
                                                          const uint32_t *__restrict__ bounds, uint32_t n_blocks, uint32_t block_shift) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   if (r >= n) return;
   const FrontierRec f = fr[r];
-  uint32_t k = order_key(v.seg, v.seq_len, v.n_seq, f.target_id, f.start);
+  uint32_t k = 0;
+  if (f.target_id < v.n_seq) {
+    const uint2 d = *reinterpret_cast<const uint2 *>(v.seg + f.target_id);  // {a, n}
+    const int32_t len = v.seq_len[f.target_id];
+    const uint64_t st = (uint64_t)(uint32_t)max(f.start, 0);
+    const uint64_t rel = len > 0 ? st * d.y / (uint64_t)(uint32_t)len : 0ull;
+    k = d.x + (uint32_t)min(rel, (uint64_t)(d.y ? d.y - 1u : 0u));
+  }
   if (bounds) {
     uint32_t lo = 0, hi = n_blocks;  // last block b with bounds[b] <= r
     while (hi - lo > 1u) {
@@ -4011,11 +4010,7 @@ __global__ __launch_bounds__(256) void frontier_emit_kernel(const unsigned long 
                                                             const uint32_t *__restrict__ n_pieces,
                                                             const uint32_t *__restrict__ foff, uint32_t n_groups,
                                                             const int2 *__restrict__ pieces,
-                                                            FrontierRec *__restrict__ out, const SegDesc *__restrict__ seg,
-                                                            const int32_t *__restrict__ seq_len, uint32_t n_seq,
-                                                            uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
-  // (key / idx: the next level's lookup-order keys beside the records, order_keys_kernel's words, while the record is in
-  // registers -- one read of the frontier less)
+                                                            FrontierRec *__restrict__ out) {
   // A wave takes 64 consecutive groups, whose records are one contiguous stretch of the frontier: a lane per OUTPUT
   // record (its group found by a search over the lanes' offsets), so that a store instruction writes 1 KB in a row.
   // (A lane per group wrote its ~3.5 records 16 bytes at a time, 64 lines per instruction: 1.0 ms of a headline step.)
@@ -4048,7 +4043,6 @@ __global__ __launch_bounds__(256) void frontier_emit_kernel(const unsigned long 
       f.end = piece.y;
       f.qidx = khi;
       out[o] = f;
-      if (key) { key[o] = order_key(seg, seq_len, n_seq, klo, piece.x); idx[o] = o; }
     }
   }
 }
@@ -4887,11 +4881,9 @@ void launch_covered_compact(const unsigned long long *svals, const uint32_t *kee
   if (n_groups) covered_regroup_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(kpos, n_active, n_kept, n_groups, gstart, glen, cap, pcap);
 }
 void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
-                          const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s,
-                          const DeviceIndexView *v, uint32_t *key, uint32_t *idx) {
+                          const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s) {
   if (!n_groups) return;
-  frontier_emit_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(gkey, poff, n_pieces, foff, n_groups, pieces, out, v ? v->seg : nullptr,
-                                                           v ? v->seq_len : nullptr, v ? v->n_seq : 0u, v ? key : nullptr, v ? idx : nullptr);
+  frontier_emit_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(gkey, poff, n_pieces, foff, n_groups, pieces, out);
 }
 void launch_subset_filter(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *qid,
                           const uint8_t *keep, const impg_gpu_range_t *ranges, hipStream_t s) {

@@ -1088,7 +1088,7 @@ __device__ __forceinline__ void project_core(const DeviceIndexView &v, uint4 e0,
                                              const uint32_t *st_pfx) {
   constexpr bool IDENT = (MODE & MODE_IDENT) != 0;
   constexpr bool CIGAR = (MODE & MODE_CIGAR) != 0;
-  static_assert(!STAGED || MODE == 0, "only the plain projection runs on staged lines");
+  static_assert(!STAGED || MODE == 0 || MODE == MODE_IDENT, "on staged lines: the plain projection, or the one under the identity filter (its identity lines are read from the index)");
   (void)accepted;
   {
     FrontierRec f;
@@ -1621,12 +1621,12 @@ static_assert(STG_ECAP * 4u <= STG_THREADS, "one pass copies the entries");
 // entry is requested a turn ahead), and the projection on the staged copies where the entry is one of the n_e staged
 // from emin on, else on the index (regroup_all: nothing is staged and every turn's pairs are regrouped by entry first,
 // as project_kernel does; the scratch overlays the line buffer).  Returns the thread's count of accepted projections.
-template <bool TRANSITIVE, bool MASKS, bool CAN_STAGE = true, uint32_t NR = STG_RANGES, uint32_t NT = STG_THREADS>  // NR: ranges of a block (st_off holds NR + 1 offsets); NT: its threads
+template <bool TRANSITIVE, bool MASKS, bool CAN_STAGE = true, uint32_t NR = STG_RANGES, uint32_t NT = STG_THREADS, int MODE = 0>  // NR: ranges of a block (st_off holds NR + 1 offsets); NT: its threads
 __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, const uint32_t *__restrict__ pair_entry, const HitArrays &h,
                                                    unsigned long long *__restrict__ accepted, uint32_t *__restrict__ err_flag,
                                                    const WindowLists &wl, uint32_t r0, uint32_t P0, uint32_t P1, uint32_t emin, uint32_t n_e,
                                                    bool regroup_all, const uint32_t *st_off, const uint4 *st_win, const int2 *st_se,
-                                                   const uint4 *st_ent, uint4 *st_line PHASE_ARG) {
+                                                   const uint4 *st_ent, uint4 *st_line PHASE_ARG, double min_identity = 0.0) {
   const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
   uint32_t n_ok = 0;
   // the block's places, a turn of NT at a time (pair lists: the next turn's entry is requested a turn ahead)
@@ -1669,10 +1669,10 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
       const uint32_t slot = y.eidx - emin;
       const uint4 *se = st_ent + min(slot, STG_ECAP - 1u) * (STG_ENT_STRIDE / 4u);
       if (CAN_STAGE && slot < n_e && (se[1].z & OP_LEN_MASK) <= INLINE_TILES * TILE_OPS)
-        project_pair<TRANSITIVE, 0, true>(v, y.eidx, y.f_start, y.f_end, y.p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, se,
-                                          reinterpret_cast<const uint32_t *>(st_line + slot * (STG_REC_STRIDE / 4u)));
+        project_pair<TRANSITIVE, MODE, true>(v, y.eidx, y.f_start, y.f_end, y.p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, se,
+                                             reinterpret_cast<const uint32_t *>(st_line + slot * (STG_REC_STRIDE / 4u)));
       else  // an entry beyond the staged span, or a record with more prefix lines than a staged record holds
-        project_pair<TRANSITIVE, 0>(v, y.eidx, y.f_start, y.f_end, y.p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
+        project_pair<TRANSITIVE, MODE>(v, y.eidx, y.f_start, y.f_end, y.p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
       h.qid[y.p] = qid;
       if (ok) h.c[y.p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
       n_ok += ok ? 1u : 0u;
@@ -1845,11 +1845,11 @@ static_assert((ENT_REC_V4 + ENT_LIST_V4) * 4u >= 5u * ENT_THREADS + ENT_WAVES, "
 // (SQ_INSTS_VALU): the flat loop alone, with the old two-candidate search, costs the same 21.9 -> 23.6 ms -- carried
 // around it the entry's sixteen scalar words and the chunk counters spill to vector lanes -- and the second test, which
 // only 60 % of the chunks execute at all, is worth what the choice costs.)
-template <bool TRANSITIVE, int ORIENT>
+template <bool TRANSITIVE, int ORIENT, int MODE>
 __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, uint4 e0, uint4 e1, uint4 e2, uint4 e3, uint32_t eidx, bool live,
                                                     int32_t f_start, int32_t f_end, uint32_t p, const uint32_t *rec, const HitArrays &h,
                                                     unsigned long long *__restrict__ accepted, uint32_t *__restrict__ err_flag,
-                                                    uint32_t &n_ok PHASE_ARG) {
+                                                    uint32_t &n_ok PHASE_ARG, double min_identity) {
   const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
   if (live) {
     bool ok = false;
@@ -1858,18 +1858,21 @@ __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, ui
     res.pqs = res.pts = res.pqe = res.pte = -1;
     uint32_t qid = HIT_NONE;
     if (ORIENT >= 0)
-      project_core<TRANSITIVE, 0, true, ORIENT>(v, e0, e1, e2, e3, f_start, f_end, p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, rec);
+      project_core<TRANSITIVE, MODE, true, ORIENT>(v, e0, e1, e2, e3, f_start, f_end, p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, rec);
     else  // (a record with more prefix lines than a staged record holds: from the index)
-      project_pair<TRANSITIVE, 0>(v, eidx, f_start, f_end, p, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
+      project_pair<TRANSITIVE, MODE>(v, eidx, f_start, f_end, p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
     h.qid[p] = qid;
     if (ok) h.c[p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
     n_ok += ok ? 1u : 0u;
   }
 }
-template <bool TRANSITIVE>
+// MODE: 0, or MODE_IDENT -- the identity filter (round 5: `--min-result-identity` used to send the whole final level back to the
+// lane-per-pair kernel, 42 ms of projection a headline step against 21.7 plain); the slice's counts come off the identity
+// lines in the index (a wave's 64 lanes read the same record's <= 8 lines: L1 hits), everything else as in the plain form.
+template <bool TRANSITIVE, int MODE>
 __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
-                                                      uint32_t *__restrict__ err_flag, int regroup, WindowLists wl) {
+                                                      uint32_t *__restrict__ err_flag, int regroup, WindowLists wl, double min_identity) {
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t sblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
   __shared__ uint4 st_work[ENT_REC_V4 + ENT_LIST_V4];
@@ -1957,8 +1960,8 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   // more than the pairs do -- by place, regrouped, from the index (the ranges listed instead take the same path there)
   const bool sparse = emin <= emax && (unsigned long long)(P1 - P0) < 4ull * (emax - emin + 1u);
   if (sparse) {
-    n_ok = project_places<TRANSITIVE, true, false, ENT_RANGES, ENT_THREADS>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
-                                                               st_se, nullptr, st_work PHASE_PASS);
+    n_ok = project_places<TRANSITIVE, true, false, ENT_RANGES, ENT_THREADS, MODE>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
+                                                               st_se, nullptr, st_work PHASE_PASS, min_identity);
   } else if (emin <= emax) {
     // The waves take the span's entries one by one off an LDS counter (an entry is anything from a handful to 500 pairs:
     // dealt round-robin, a block waited for its unluckiest wave).  Each entry is fetched by its wave alone -- its 64
@@ -2051,10 +2054,10 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
           p = st_off[r] + below;
         }
         if (live && wl.range_out) wl.range_out[p] = wl.perm[r0 + r];
-        if (orient == 0) project_entry_chunk<TRANSITIVE, 0>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
-        else if (orient == 1) project_entry_chunk<TRANSITIVE, 1>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
-        else if (orient == 2) project_entry_chunk<TRANSITIVE, 2>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
-        else project_entry_chunk<TRANSITIVE, -1>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS);
+        if (orient == 0) project_entry_chunk<TRANSITIVE, 0, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
+        else if (orient == 1) project_entry_chunk<TRANSITIVE, 1, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
+        else if (orient == 2) project_entry_chunk<TRANSITIVE, 2, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
+        else project_entry_chunk<TRANSITIVE, -1, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
       }
     }
 #ifdef IMPG_PHASE_CLOCKS
@@ -2084,7 +2087,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
         res.found = res.any = false;
         res.pqs = res.pts = res.pqe = res.pte = -1;
         uint32_t qid = HIT_NONE;
-        project_pair<TRANSITIVE, 0>(v, pair_entry[pp], se.x, se.y, pp, 0.0, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
+        project_pair<TRANSITIVE, MODE>(v, pair_entry[pp], se.x, se.y, pp, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
         h.qid[pp] = qid;
         if (ok) h.c[pp] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
         n_ok += ok ? 1u : 0u;
@@ -4724,15 +4727,23 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
   const int mode = (ident ? MODE_IDENT : 0) | (slices ? MODE_CIGAR : 0) | (two_walks ? MODE_WALK : 0);
   // A dense level -- many pairs per index entry -- runs with the entries and prefix lines staged in LDS
   // (project_staged_kernel / project_entries_kernel)
-  if (mode == 0 && !n_pairs_dev && wl.pair_off && wl.se && !pl.slot && project_is_staged(v, n_pairs, true)) {
+  const bool dense = !n_pairs_dev && wl.pair_off && wl.se && !pl.slot && project_is_staged(v, n_pairs, true);
+  if (dense && wl.masks != 0 && entry_major() && (mode == 0 || (mode == MODE_IDENT && v.idp))) {
+    // the final level of a counting run, entry by entry; also under the identity filter
+    const uint32_t ge = (cdiv(wl.n_fr, ENT_RANGES) + 7u) & ~7u;
+    const double mi = ident ? min_identity : 0.0;
+    if (mode == 0) {
+      if (transitive) project_entries_kernel<true, 0><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi);
+      else project_entries_kernel<false, 0><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi);
+    } else {
+      if (transitive) project_entries_kernel<true, MODE_IDENT><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi);
+      else project_entries_kernel<false, MODE_IDENT><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi);
+    }
+    return;
+  }
+  if (mode == 0 && dense) {
     const uint32_t gs = (cdiv(wl.n_fr, STG_RANGES) + 7u) & ~7u;
     const bool masks = wl.masks != 0;
-    if (masks && entry_major()) {
-      const uint32_t ge = (cdiv(wl.n_fr, ENT_RANGES) + 7u) & ~7u;
-      if (transitive) project_entries_kernel<true><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
-      else project_entries_kernel<false><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
-      return;
-    }
 #define IMPG_LAUNCH_STG(T, M) project_staged_kernel<T, M><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl)
     if (transitive) { if (masks) IMPG_LAUNCH_STG(true, true); else IMPG_LAUNCH_STG(true, false); }
     else { if (masks) IMPG_LAUNCH_STG(false, true); else IMPG_LAUNCH_STG(false, false); }

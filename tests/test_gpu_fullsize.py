@@ -161,6 +161,24 @@ def test_headline_ordered_rows_and_bed_vs_oracle(full, oracle_ix):
     assert dev == want
 
 
+def test_headline_identity_filter_sample(full, oracle_ix):
+    """`--min-result-identity` at the headline index (impg.rs:1283-1287): the 4 096-range batch's dense final level runs entry
+    by entry under the filter too (project_entries_kernel<.., MODE_IDENT>, the identity lines built on demand); per-range
+    counts and checksums of a sample against the oracle, at a threshold that drops a good part of the hits."""
+    paf, g, ranges = full
+    kw = dict(transitive=True, max_depth=3, min_identity=0.985)
+    p = impg_amd.make_params(**kw)
+    g.set_option("chunk_ranges", 4096)
+    st, cnt, ck = g.query_batch_stats(ranges, p)
+    st0, cnt0, _ = g.query_batch_stats(ranges, impg_amd.make_params(transitive=True, max_depth=3))
+    assert 0 < st.projected < st0.projected and (cnt <= cnt0).all()
+    rng = np.random.default_rng(3)
+    for i in sorted(set(rng.integers(0, len(ranges), 8).tolist())):
+        r = ranges[i]
+        want = oracle_ix.query(int(r["target_id"]), int(r["start"]), int(r["end"]), **kw)[1:]
+        assert int(cnt[i]) == len(want) and int(ck[i]) == checksum(want), i
+
+
 def test_headline_batch_prefix_consistency(full, big_batch):
     """The headline batch itself (100 000 ranges, -x -m 3): queries are independent, so the first 4 096 ranges of the
     full batch must give exactly the per-range counts and checksums the 4 096-range batch gives (which the oracle

@@ -144,7 +144,11 @@ uint32_t Engine::walk_group_size(const impg_gpu_index &ix, uint32_t n, const imp
   // multi_impg.rs:518-530, partition.rs), whose workgroups the dispatcher may interleave: each launch takes at most its
   // share of the CUs, so that all of them fit together.  (A launch that still cannot become resident -- another process
   // on the device -- gives up after the spin limit and the batch engine answers.)
-  const uint32_t share = std::max(1u, (uint32_t)cus / (uint32_t)std::max(1, ix.max_engines));
+  // (asked of the runtime once, not assumed: a kernel that grew past one workgroup per CU -- or a device that keeps none
+  // resident -- gets the one-workgroup form / the batch engine instead of members spinning for partners that cannot start)
+  static const uint32_t per_cu = walk_grid_blocks_per_cu();
+  if (!per_cu) return 1;
+  const uint32_t share = std::max(1u, (uint32_t)cus * std::min(per_cu, 1u) / (uint32_t)std::max(1, ix.max_engines));
   const uint32_t fit = std::max(1u, share / n);
   return std::min({walk_members ? walk_members : 32u, fit, WALK_MAX_MEMBERS});
 }

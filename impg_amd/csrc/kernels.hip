@@ -5042,6 +5042,15 @@ void launch_hits_unpack(const void *in, uint32_t n, uint32_t words, uint32_t n_f
 size_t walk_slab_bytes(uint32_t n_seq, bool wide, uint32_t wcap, uint32_t hcap, uint32_t vcap, uint32_t gcap, uint32_t scap) {
   return walk_slab_layout(nullptr, n_seq, wide ? 1024u : 64u, wcap, hcap, vcap, gcap, scap, nullptr);
 }
+// Workgroups of the walk's grid form the runtime says one CU keeps resident (its members wait for each other inside one
+// launch: a launch must fit the device; 0 = the form cannot run here).  The smallest over the three instantiations.
+uint32_t walk_grid_blocks_per_cu() {
+  int a = 0, b = 0, c = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, walk_grid_kernel<16, 4096, 0>, 1024, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, walk_grid_kernel<16, 4096, MODE_IDENT>, 1024, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, walk_grid_kernel<16, 4096, MODE_IDENT | MODE_WALK>, 1024, 0) != hipSuccess) return 0;
+  return (uint32_t)std::max(0, std::min({a, b, c}));
+}
 void launch_walk(const WalkArgs &a, uint32_t n_workgroups, bool wide, bool ident_mode, hipStream_t s) {
   if (!n_workgroups) return;
   if (wide && a.members > 1) {

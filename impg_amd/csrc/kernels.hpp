@@ -278,6 +278,7 @@ size_t walk_slab_bytes(uint32_t n_seq, bool wide, uint32_t wcap, uint32_t hcap, 
 #define IMPG_WALK_WAVES 6  // 100 000-range DFS batch: 4 waves per SIMD (101 VGPRs, what the compiler takes unasked) 4.22 s, 5: 3.80, 6: 3.66, 8: 3.68
 #endif
 constexpr uint32_t WALK_WAVES_PER_SIMD = IMPG_WALK_WAVES;  // resident waves per SIMD the one-wave-per-query walk is compiled for
+uint32_t walk_grid_blocks_per_cu();  // the occupancy query behind the grid form's launch size (Engine::walk_group_size)
 void launch_walk(const WalkArgs &a, uint32_t n_workgroups, bool wide, bool ident_mode, hipStream_t s);  // (members > 1: n_workgroups = queries x members)
 
 }  // namespace impg

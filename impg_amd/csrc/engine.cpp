@@ -360,6 +360,9 @@ const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec
                     blocks ? blocks->n_blocks : 0u, block_shift);
   const size_t tb = sort_u32_scratch_bytes(n_fr);
   sort_tmp.reserve(tb);
+  // (every bit of the key is sorted.  Round 5, measured: leaving the low 5 bits unsorted -- two radix passes instead of
+  // three -- takes 0.35 ms off the lookup and puts 4.4 ms ON the projection (22.1 -> 26.5 ms: the entries kernel's waves
+  // find their entry's places in shorter runs); 9 bits: 87 ms.)
   launch_sort_u32(sort_tmp.p, tb, lo_key.as<uint32_t>(), lo_key2.as<uint32_t>(), lo_idx.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr,
                   stream, 0, hi_bit);
   return lo_perm.as<uint32_t>();

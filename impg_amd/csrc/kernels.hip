@@ -1052,6 +1052,14 @@ constexpr uint32_t PROJ_BLOCK = IMPG_PROJ_BLOCK, PROJ_WAVES = PROJ_BLOCK / 64u;
 constexpr uint32_t STG_ENT_STRIDE = 20u;                                   // words per staged entry (16 + 4)
 constexpr uint32_t STG_LINE_STRIDE = TILE_WORDS + 4u;                      // words per staged prefix line
 constexpr uint32_t STG_REC_STRIDE = INLINE_TILES * STG_LINE_STRIDE + 4u;   // words per staged record (8 lines)
+// project_entries_kernel (IMPG_ENT_CP_LDS, round 5): the entry's words 8 .. 15 -- total query length and the seven inline
+// checkpoints -- also sit behind the wave's LDS record, and a chunk's lanes read them from there (two broadcast reads)
+// instead of comparing against scalar registers: held in scalars they were the registers the allocator spilled (the
+// kernel runs at its 102-SGPR limit), and every chunk fetched them back with fourteen v_readlane.
+#ifndef IMPG_ENT_CP_LDS
+#define IMPG_ENT_CP_LDS 1
+#endif
+constexpr uint32_t ENT_CP_OFF = INLINE_TILES * STG_LINE_STRIDE;           // where the entry's checkpoint words sit in the wave's LDS record
 // One (range, entry) pair: project_overlapping_interval's PAF branch (impg.rs:1260-1312) for the range [f_start, f_end)
 // against entry eidx.  ok: the projection exists (and passes the identity filter); qid / res: its query sequence and
 // {q_first, q_last, t_first, t_last}; slice descriptors go to sl[p] under MODE_CIGAR.  Shared by project_kernel (a
@@ -1138,9 +1146,16 @@ __device__ __forceinline__ void project_core(const DeviceIndexView &v, uint4 e0,
       // (the plain projection wants the last tile that STARTS at or before last_target_pos: it counts P[i] <= xb)
       const int32_t xbc = ON_LINES ? xb + 1 : xb;
       uint32_t cA = 0, cB = 0;  // cA = #{i in [1,m] : P[i] < xa}, cB = #{i in [0,m) : P[i] < xbc}
-      if (c.m <= INLINE_TILES) {
+      if (ORIENT >= 0 || c.m <= INLINE_TILES) {  // (a known orientation is only handed in for a record of at most INLINE_TILES tiles)
         // the seven inline slots hold P[1..m-1], P[m] = totT, then INT_MAX (index_build.cpp); P[8] is totT when m = 8
-        const int32_t P[8] = {(int32_t)e2.y, (int32_t)e2.z, (int32_t)e2.w, (int32_t)e3.x, (int32_t)e3.y, (int32_t)e3.z, (int32_t)e3.w,
+        uint4 p2 = e2, p3 = e3;
+        if (IMPG_ENT_CP_LDS && STAGED && ORIENT >= 0) {
+          const uint4 *cp = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(st_pfx, 16)) + ENT_CP_OFF / 4u;
+          p2 = cp[0];
+          p3 = cp[1];
+          asm volatile("" : "+v"(p2.x), "+v"(p2.y), "+v"(p2.z), "+v"(p2.w), "+v"(p3.x), "+v"(p3.y), "+v"(p3.z), "+v"(p3.w));  // (two 16-byte reads off the record's address)
+        }
+        const int32_t P[8] = {(int32_t)p2.y, (int32_t)p2.z, (int32_t)p2.w, (int32_t)p3.x, (int32_t)p3.y, (int32_t)p3.z, (int32_t)p3.w,
                               c.m == INLINE_TILES ? (int32_t)c.totT : 0x7FFFFFFF};
         cB = 0 < xbc ? 1u : 0u;
 #pragma unroll
@@ -1829,11 +1844,18 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
 #endif
 constexpr uint32_t ENT_RANGES = IMPG_ENT_RANGES;                          // ranges (consecutive in the lookup order) per block
 constexpr uint32_t ENT_THREADS = IMPG_ENT_THREADS, ENT_WAVES = ENT_THREADS / 64u;
-constexpr uint32_t ENT_REC_STRIDE = INLINE_TILES * STG_LINE_STRIDE;       // words of a wave's LDS record (8 padded lines)
+constexpr uint32_t ENT_REC_STRIDE = ENT_CP_OFF + 8u;                      // words of a wave's LDS record (8 padded lines, the entry's words 8 .. 15)
 static_assert((ENT_RANGES & (ENT_RANGES - 1u)) == 0u && ENT_RANGES % ENT_THREADS == 0 && ENT_THREADS % 64u == 0, "whole turns of the block over its ranges");
 constexpr uint32_t ENT_REC_V4 = ENT_WAVES * ENT_REC_STRIDE / 4u, ENT_LIST_V4 = ENT_WAVES * ENT_RANGES * 2u / 16u;
 static_assert((ENT_REC_V4 + ENT_LIST_V4) * 4u >= 5u * ENT_THREADS + ENT_WAVES, "the unstaged path's scratch overlays the waves' records and lists");
-#ifdef IMPG_ENT_WAVES  // (experiments: force the register allocation that gives this many waves per SIMD)
+// Waves per SIMD the register allocation is held to.  Round 5: with an entry in flight held as four registers instead of
+// sixteen (below) the kernel needs 106 vector registers where it needed 126, and held to 96 / 80 it spills 12 / 44 bytes
+// outside the chunk loop: projection of a headline step 20.8 ms at 4 waves (what the allocator picks on its own),
+// 19.2 at 5, 18.8 at 6 (the block's 24 KB of LDS allow no more).
+#ifndef IMPG_ENT_WAVES
+#define IMPG_ENT_WAVES 6
+#endif
+#if IMPG_ENT_WAVES > 0
 #define ENT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(IMPG_ENT_WAVES, IMPG_ENT_WAVES)))
 #else
 #define ENT_OCCUPANCY
@@ -1977,33 +1999,46 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
       return (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
     };
     uint32_t ic = take(), in = take();
-    uint4 c0 = zero4, c1 = zero4, c2 = zero4, c3 = zero4, n0 = zero4, n1 = zero4, n2 = zero4, n3 = zero4, lc = zero4;
-    if (ic < n_span) { const size_t e = (size_t)(emin + ic) * 4u; c0 = ents[e]; c1 = ents[e + 1u]; c2 = ents[e + 2u]; c3 = ents[e + 3u]; }
-    if (in < n_span) { const size_t e = (size_t)(emin + in) * 4u; n0 = ents[e]; n1 = ents[e + 1u]; n2 = ents[e + 2u]; n3 = ents[e + 3u]; }
-    if (ic < n_span) {
-      const uint32_t m = ((c1.z & OP_LEN_MASK) + TILE_OPS - 1u) / TILE_OPS;
-      if (m <= INLINE_TILES && (l >> 3) < m) lc = reinterpret_cast<const uint4 *>(v.pfx + (size_t)c1.y * TILE_WORDS)[l];
-    }
+    // (an entry's 64 bytes are held as one 16-byte piece in each of lanes 0 .. 3 -- four registers for an entry in flight
+    // instead of sixteen with every lane reading all four pieces: with two entries in flight that is 24 registers of
+    // the kernel's 126; its words are picked off the lanes into scalar registers when its turn comes)
+    uint4 cq = zero4, nq = zero4, lc = zero4;
+    auto fetch_entry = [&](uint32_t i) -> uint4 {
+      uint4 q = zero4;
+      if (i < n_span && l < 4u) q = ents[(size_t)(emin + i) * 4u + l];
+      return q;
+    };
+#define IMPG_RDL(x, j) (uint32_t)__builtin_amdgcn_readlane((int)(x), j)
+    auto fetch_record = [&](const uint4 &q) -> uint4 {  // the record's <= 8 prefix lines, a 16-byte piece per lane
+      uint4 r = zero4;
+      const uint32_t nz = IMPG_RDL(q.z, 1), ny = IMPG_RDL(q.y, 1);  // the entry's words 6 and 5: op count | flags, first tile
+      const uint32_t m = ((nz & OP_LEN_MASK) + TILE_OPS - 1u) / TILE_OPS;
+      if (m <= INLINE_TILES && (l >> 3) < m) r = reinterpret_cast<const uint4 *>(v.pfx + (size_t)ny * TILE_WORDS)[l];
+      return r;
+    };
+    cq = fetch_entry(ic);
+    nq = fetch_entry(in);
+    if (ic < n_span) lc = fetch_record(cq);
 #pragma unroll 1
     while (ic < n_span) {
       const uint32_t eidx = emin + ic;
       // this entry's record into the wave's LDS record (the previous entry's reads are done: their results were used)
       __builtin_amdgcn_wave_barrier();
       st_rec[wv][(l >> 3) * (STG_LINE_STRIDE / 4u) + (l & 7u)] = lc;
-      uint4 e0 = c0, e1 = c1, e2 = c2, e3 = c3;
-#define IMPG_RFL(x) x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x))
-      IMPG_RFL(e0.x); IMPG_RFL(e0.y); IMPG_RFL(e0.z); IMPG_RFL(e0.w); IMPG_RFL(e1.x); IMPG_RFL(e1.y); IMPG_RFL(e1.z); IMPG_RFL(e1.w);
-      IMPG_RFL(e2.x); IMPG_RFL(e2.y); IMPG_RFL(e2.z); IMPG_RFL(e2.w); IMPG_RFL(e3.x); IMPG_RFL(e3.y); IMPG_RFL(e3.z); IMPG_RFL(e3.w);
-#undef IMPG_RFL
+      if (IMPG_ENT_CP_LDS && l >= 2u && l < 4u) st_rec[wv][ENT_CP_OFF / 4u + l - 2u] = cq;
+      uint4 e0, e1, e2, e3;
+      e0.x = IMPG_RDL(cq.x, 0); e0.y = IMPG_RDL(cq.y, 0); e0.z = IMPG_RDL(cq.z, 0); e0.w = IMPG_RDL(cq.w, 0);
+      e1.x = IMPG_RDL(cq.x, 1); e1.y = IMPG_RDL(cq.y, 1); e1.z = IMPG_RDL(cq.z, 1); e1.w = IMPG_RDL(cq.w, 1);
+      e2.x = IMPG_RDL(cq.x, 2); e2.y = IMPG_RDL(cq.y, 2); e2.z = IMPG_RDL(cq.z, 2); e2.w = IMPG_RDL(cq.w, 2);
+      e3.x = IMPG_RDL(cq.x, 3); e3.y = IMPG_RDL(cq.y, 3); e3.z = IMPG_RDL(cq.z, 3); e3.w = IMPG_RDL(cq.w, 3);
       // the next entry of the wave moves up; its record and the entry after it are requested
       ic = in;
-      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      cq = nq;
       lc = zero4;
       if (ic < n_span) {
-        const uint32_t m = ((c1.z & OP_LEN_MASK) + TILE_OPS - 1u) / TILE_OPS;
-        if (m <= INLINE_TILES && (l >> 3) < m) lc = reinterpret_cast<const uint4 *>(v.pfx + (size_t)c1.y * TILE_WORDS)[l];
+        lc = fetch_record(cq);
         in = take();
-        if (in < n_span) { const size_t e = (size_t)(emin + in) * 4u; n0 = ents[e]; n1 = ents[e + 1u]; n2 = ents[e + 2u]; n3 = ents[e + 3u]; }
+        nq = fetch_entry(in);
       }
       // the block's ranges that hit the entry, 64 at a time: bit (entry - window start) of the range's mask
       uint32_t cnt = 0;
@@ -2060,6 +2095,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
         else project_entry_chunk<TRANSITIVE, -1, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
       }
     }
+#undef IMPG_RDL
 #ifdef IMPG_PHASE_CLOCKS
     STG_MARK(2);
     if ((blockIdx.x & 15u) == 0u && threadIdx.x == 0u) {

@@ -2733,7 +2733,7 @@ __device__ __forceinline__ uint32_t lower_bound_start(const int2 *a, uint32_t n,
 // VU_LDS_CAP ranges (nearly all of them) are kept in LDS while they are worked on (lane-interleaved, so the 64
 // lists of a wave never share a bank) and written out once at the end; longer ones are worked on in place.
 #ifndef IMPG_VU_LDS_CAP
-#define IMPG_VU_LDS_CAP 16
+#define IMPG_VU_LDS_CAP 12
 #endif
 constexpr uint32_t VU_LDS_CAP = IMPG_VU_LDS_CAP;
 // IMPG_VW_WINDOWS = 1: every hit of a batch that meets no earlier one takes its turn at once (replay_hits_wave).  Exact -- the
@@ -2760,7 +2760,7 @@ constexpr uint32_t VU_LDS_CAP = IMPG_VU_LDS_CAP;
 // waves, but lists that outgrew the buffer replayed in global memory.  Round 5's tiny tier is for groups that CANNOT outgrow it.)
 // Which kernel takes a group, by cap = old length + hits (what its list cannot outgrow):
 //   cap <= VU_TINY_MAX  visited_update_kernel<VU_LDS_CAP, false>: a lane per group, 64 neighbouring groups a wave (98.5 % of a
-//                       headline level's groups; list AND pieces in the lane's 16-entry LDS column)
+//                       headline level's groups; list AND pieces in the lane's 12-entry LDS column)
 //   cap <= VU_MID_MAX   visited_update_kernel<VU_MID_CAP, true>: a lane per group too, but of a LIST of such groups and with a
 //                       64-entry column -- among tiny groups one of them kept 63 lanes waiting for its 30 hits (and, with
 //                       17..64 hits, replayed in place on its global slice: two thirds of all wave cycles, round 4)
@@ -2897,8 +2897,20 @@ __device__ __forceinline__ int2 list_range(global_list_t p, uint32_t i) {
   const unsigned long long v = p[i];
   return make_int2((int32_t)(uint32_t)v, (int32_t)(uint32_t)(v >> 32));
 }
+// Waves per SIMD the dense form's register allocation is held to.  Left alone the allocator takes 96 registers -- the 8 KB
+// LDS column of a 16-entry cap allowed five waves whatever it did --; with a 12-entry column (6 KB: 26 waves a CU) and
+// held to six waves it needs 59 and spills nothing: headline update 6.05 -> 5.80 ms (round 5; 7 waves / 11 entries and
+// 8 / 10 send more groups to the listed form than the waves win back: 6.08, 6.40).
+#ifndef IMPG_VU_WAVES
+#define IMPG_VU_WAVES 6
+#endif
+#if IMPG_VU_WAVES > 0
+#define VU_OCCUPANCY __attribute__((amdgpu_waves_per_eu(IMPG_VU_WAVES, IMPG_VU_WAVES)))
+#else
+#define VU_OCCUPANCY
+#endif
 template <uint32_t CAP, bool LISTED>  // CAP: entries of a lane's LDS column; LISTED: the groups of list[0 .. *n_list), grid-strided
-__global__ __launch_bounds__(64) void visited_update_kernel(const unsigned long long *__restrict__ svals,
+__global__ __launch_bounds__(64) VU_OCCUPANCY void visited_update_kernel(const unsigned long long *__restrict__ svals,
                                                             const int32_t *__restrict__ seq_len,
                                                             const unsigned long long *__restrict__ gkey,
                                                             const uint32_t *__restrict__ gstart,

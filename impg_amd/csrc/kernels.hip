@@ -1159,7 +1159,7 @@ constexpr uint32_t PROJ_BLOCK = IMPG_PROJ_BLOCK, PROJ_WAVES = PROJ_BLOCK / 64u;
 constexpr uint32_t STG_ENT_STRIDE = 20u;                                   // words per staged entry (16 + 4)
 constexpr uint32_t STG_LINE_STRIDE = TILE_WORDS + 4u;                      // words per staged prefix line
 constexpr uint32_t STG_REC_STRIDE = INLINE_TILES * STG_LINE_STRIDE + 4u;   // words per staged record (8 lines)
-// project_entries_kernel (IMPG_ENT_CP_LDS, round 5): the entry's words 8 .. 15 -- total query length and the seven inline
+// project_entries_kernel (IMPG_ENT_CP_LDS, round 5): the entry's words 4 .. 15 -- the record totals and the seven inline
 // checkpoints -- also sit behind the wave's LDS record, and a chunk's lanes read them from there (two broadcast reads)
 // instead of comparing against scalar registers: held in scalars they were the registers the allocator spilled (the
 // kernel runs at its 102-SGPR limit), and every chunk fetched them back with fourteen v_readlane.
@@ -1229,6 +1229,12 @@ __device__ __forceinline__ void project_core(const DeviceIndexView &v, uint4 e0,
     c.m = (n + TILE_OPS - 1) / TILE_OPS;
     c.totT = e1.w;
     c.totQ = e2.x;
+    if (IMPG_ENT_CP_LDS && STAGED && ORIENT >= 0) {
+      // (record totals off the wave's LDS record too: as scalars they were two more of the spilled registers, fetched back
+      // ten times a chunk)
+      c.totT = st_pfx[ENT_CP_OFF + 3u];
+      c.totQ = st_pfx[ENT_CP_OFF + 4u];
+    }
     c.ops = v.ops + (size_t)e1.y * TILE_WORDS;
     if (n == 0) {
       atomicOr(err_flag, 1u);  // record without cg:Z (the reference panics, impg.rs:506-511)
@@ -1258,8 +1264,8 @@ __device__ __forceinline__ void project_core(const DeviceIndexView &v, uint4 e0,
         uint4 p2 = e2, p3 = e3;
         if (IMPG_ENT_CP_LDS && STAGED && ORIENT >= 0) {
           const uint4 *cp = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(st_pfx, 16)) + ENT_CP_OFF / 4u;
-          p2 = cp[0];
-          p3 = cp[1];
+          p2 = cp[1];
+          p3 = cp[2];
           asm volatile("" : "+v"(p2.x), "+v"(p2.y), "+v"(p2.z), "+v"(p2.w), "+v"(p3.x), "+v"(p3.y), "+v"(p3.z), "+v"(p3.w));  // (two 16-byte reads off the record's address)
         }
         const int32_t P[8] = {(int32_t)p2.y, (int32_t)p2.z, (int32_t)p2.w, (int32_t)p3.x, (int32_t)p3.y, (int32_t)p3.z, (int32_t)p3.w,
@@ -1951,7 +1957,7 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
 #endif
 constexpr uint32_t ENT_RANGES = IMPG_ENT_RANGES;                          // ranges (consecutive in the lookup order) per block
 constexpr uint32_t ENT_THREADS = IMPG_ENT_THREADS, ENT_WAVES = ENT_THREADS / 64u;
-constexpr uint32_t ENT_REC_STRIDE = ENT_CP_OFF + 8u;                      // words of a wave's LDS record (8 padded lines, the entry's words 8 .. 15)
+constexpr uint32_t ENT_REC_STRIDE = ENT_CP_OFF + 12u;                     // words of a wave's LDS record (8 padded lines, the entry's words 4 .. 15)
 static_assert((ENT_RANGES & (ENT_RANGES - 1u)) == 0u && ENT_RANGES % ENT_THREADS == 0 && ENT_THREADS % 64u == 0, "whole turns of the block over its ranges");
 constexpr uint32_t ENT_REC_V4 = ENT_WAVES * ENT_REC_STRIDE / 4u, ENT_LIST_V4 = ENT_WAVES * ENT_RANGES * 2u / 16u;
 static_assert((ENT_REC_V4 + ENT_LIST_V4) * 4u >= 5u * ENT_THREADS + ENT_WAVES, "the unstaged path's scratch overlays the waves' records and lists");
@@ -2132,7 +2138,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
       // this entry's record into the wave's LDS record (the previous entry's reads are done: their results were used)
       __builtin_amdgcn_wave_barrier();
       st_rec[wv][(l >> 3) * (STG_LINE_STRIDE / 4u) + (l & 7u)] = lc;
-      if (IMPG_ENT_CP_LDS && l >= 2u && l < 4u) st_rec[wv][ENT_CP_OFF / 4u + l - 2u] = cq;
+      if (IMPG_ENT_CP_LDS && l >= 1u && l < 4u) st_rec[wv][ENT_CP_OFF / 4u + l - 1u] = cq;
       uint4 e0, e1, e2, e3;
       e0.x = IMPG_RDL(cq.x, 0); e0.y = IMPG_RDL(cq.y, 0); e0.z = IMPG_RDL(cq.z, 0); e0.w = IMPG_RDL(cq.w, 0);
       e1.x = IMPG_RDL(cq.x, 1); e1.y = IMPG_RDL(cq.y, 1); e1.z = IMPG_RDL(cq.z, 1); e1.w = IMPG_RDL(cq.w, 1);

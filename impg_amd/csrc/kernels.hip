@@ -1957,7 +1957,13 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
 #endif
 constexpr uint32_t ENT_RANGES = IMPG_ENT_RANGES;                          // ranges (consecutive in the lookup order) per block
 constexpr uint32_t ENT_THREADS = IMPG_ENT_THREADS, ENT_WAVES = ENT_THREADS / 64u;
-constexpr uint32_t ENT_REC_STRIDE = ENT_CP_OFF + 12u;                     // words of a wave's LDS record (8 padded lines, the entry's words 4 .. 15)
+// IMPG_ENT_E0_LDS: a chunk's lanes also take the entry's coordinates (words 0 .. 3) from the LDS copy, as vector registers:
+// an add or a compare with a scalar operand issues at half the rate of one on vector registers (profiles/r3_issue_rate.json),
+// and four more scalars are free.  Projection of a headline step 19.1 -> 18.7 ms on the same box.
+#ifndef IMPG_ENT_E0_LDS
+#define IMPG_ENT_E0_LDS 1
+#endif
+constexpr uint32_t ENT_REC_STRIDE = ENT_CP_OFF + 16u;                     // words of a wave's LDS record (8 padded lines, then the entry: words 4 .. 15, 0 .. 3)
 static_assert((ENT_RANGES & (ENT_RANGES - 1u)) == 0u && ENT_RANGES % ENT_THREADS == 0 && ENT_THREADS % 64u == 0, "whole turns of the block over its ranges");
 constexpr uint32_t ENT_REC_V4 = ENT_WAVES * ENT_REC_STRIDE / 4u, ENT_LIST_V4 = ENT_WAVES * ENT_RANGES * 2u / 16u;
 static_assert((ENT_REC_V4 + ENT_LIST_V4) * 4u >= 5u * ENT_THREADS + ENT_WAVES, "the unstaged path's scratch overlays the waves' records and lists");
@@ -1992,6 +1998,10 @@ __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, ui
     res.found = res.any = false;
     res.pqs = res.pts = res.pqe = res.pte = -1;
     uint32_t qid = HIT_NONE;
+    if (IMPG_ENT_E0_LDS && IMPG_ENT_CP_LDS && ORIENT >= 0) {
+      e0 = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(rec, 16))[ENT_CP_OFF / 4u + 3u];
+      asm volatile("" : "+v"(e0.x), "+v"(e0.y), "+v"(e0.z), "+v"(e0.w));
+    }
     if (ORIENT >= 0)
       project_core<TRANSITIVE, MODE, true, ORIENT>(v, e0, e1, e2, e3, f_start, f_end, p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, rec);
     else  // (a record with more prefix lines than a staged record holds: from the index)
@@ -2138,7 +2148,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
       // this entry's record into the wave's LDS record (the previous entry's reads are done: their results were used)
       __builtin_amdgcn_wave_barrier();
       st_rec[wv][(l >> 3) * (STG_LINE_STRIDE / 4u) + (l & 7u)] = lc;
-      if (IMPG_ENT_CP_LDS && l >= 1u && l < 4u) st_rec[wv][ENT_CP_OFF / 4u + l - 1u] = cq;
+      if (IMPG_ENT_CP_LDS && l < 4u) st_rec[wv][ENT_CP_OFF / 4u + ((l + 3u) & 3u)] = cq;  // (words 4 .. 15, then 0 .. 3)
       uint4 e0, e1, e2, e3;
       e0.x = IMPG_RDL(cq.x, 0); e0.y = IMPG_RDL(cq.y, 0); e0.z = IMPG_RDL(cq.z, 0); e0.w = IMPG_RDL(cq.w, 0);
       e1.x = IMPG_RDL(cq.x, 1); e1.y = IMPG_RDL(cq.y, 1); e1.z = IMPG_RDL(cq.z, 1); e1.w = IMPG_RDL(cq.w, 1);

@@ -3033,6 +3033,7 @@ __device__ __forceinline__ int2 list_range(global_list_t p, uint32_t i) {
 #define VU_OCCUPANCY
 #endif
 // (the listed form's 32 KB column allows two waves whatever the allocator does: the target is the dense form's)
+#pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"
 template <uint32_t CAP, bool LISTED>  // CAP: entries of a lane's LDS column; LISTED: the groups of list[0 .. *n_list), grid-strided
 __global__ __launch_bounds__(64) VU_OCCUPANCY void visited_update_kernel(const unsigned long long *__restrict__ svals,
@@ -3225,6 +3226,7 @@ __global__ __launch_bounds__(64) VU_OCCUPANCY void visited_update_kernel(const u
 #endif
   }
 }
+#pragma clang diagnostic pop
 #ifdef IMPG_VU_CLOCKS
 extern "C" void impg_gpu_debug_vu_clocks(unsigned long long *out) {
   static unsigned long long rows[VU_CLK_ROWS][16];

@@ -404,8 +404,18 @@ __global__ __launch_bounds__(256) void order_keys_kernel(DeviceIndexView v, cons
   if (f.target_id < v.n_seq) {
     const uint2 d = *reinterpret_cast<const uint2 *>(v.seg + f.target_id);  // {a, n}
     const int32_t len = v.seq_len[f.target_id];
-    const uint64_t st = (uint64_t)(uint32_t)max(f.start, 0);
-    const uint64_t rel = len > 0 ? st * d.y / (uint64_t)(uint32_t)len : 0ull;
+#ifndef IMPG_ORDER_KEY_F64
+#define IMPG_ORDER_KEY_F64 1
+#endif
+    const uint32_t st = (uint32_t)max(f.start, 0);
+    uint64_t rel = 0;
+    if (len > 0) {
+      // floor(st * n / len): a 64-bit integer division is ~150 instructions a record; in double precision the product is
+      // exact below 2^53 (a 31-bit start, a segment of < 2^22 entries), the quotient correctly rounded, and a quotient that
+      // is no integer lies at least 1 / len from one -- so the truncation is the integer division's result
+      if (IMPG_ORDER_KEY_F64 && d.y < (1u << 22)) rel = (uint64_t)((double)st * (double)d.y / (double)(uint32_t)len);
+      else rel = (uint64_t)st * d.y / (uint64_t)(uint32_t)len;
+    }
     k = d.x + (uint32_t)min(rel, (uint64_t)(d.y ? d.y - 1u : 0u));
   }
   if (bounds) {

@@ -344,7 +344,7 @@ static HitArrays hit_arrays(LevelBufs &L, uint32_t n_pairs) {
 // search the same blocks and gather neighbouring entries and CIGAR tiles (L1/L2
 // hits instead of HBM lines).  Returns the permutation, or null when not worth it.
 const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, const RecordBlocks *blocks) {
-  if (!locality_min || (n_fr < locality_min && !blocks)) return nullptr;
+  if (!locality_min || (n_fr < locality_min && !blocks)) { keys_for = nullptr; return nullptr; }
   const size_t nb = (size_t)n_fr * 4;
   lo_key.reserve(nb); lo_key2.reserve(nb); lo_idx.reserve(nb); lo_perm.reserve(nb);
   // keys are positions in the entry array: only the bits below n_entries are sorted (plus the block bits above them)
@@ -356,8 +356,12 @@ const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec
     block_shift = hi_bit;
     hi_bit += bb;
   }
-  launch_order_keys(v, fr, n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream, blocks ? blocks->d_bounds : nullptr,
-                    blocks ? blocks->n_blocks : 0u, block_shift);
+  if (!blocks && keys_for && keys_for == (const void *)fr && keys_n == n_fr) {
+    // (frontier_emit wrote them beside this frontier's records)
+  } else
+    launch_order_keys(v, fr, n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream, blocks ? blocks->d_bounds : nullptr,
+                      blocks ? blocks->n_blocks : 0u, block_shift);
+  keys_for = nullptr;
   const size_t tb = sort_u32_scratch_bytes(n_fr);
   sort_tmp.reserve(tb);
   // (every bit of the key is sorted.  Round 5, measured: leaving the low 5 bits unsorted -- two radix passes instead of
@@ -687,8 +691,14 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       if (nn >= 0xFFFFFFF0ull) { if (split_ok) throw SplitBatch{}; throw Error{IMPG_E_UNSUPPORTED, "frontier exceeds 2^32 ranges"}; }
       n_next = (uint32_t)nn;
       next_frontier.reserve(std::max<size_t>((size_t)n_next * sizeof(FrontierRec), 256));
+      // (the next level's lookup-order keys with the records, when that level will be looked up in that order on this device)
+      const bool keys_too = !remote && locality_min && n_next >= locality_min;
+      if (keys_too) { lo_key.reserve((size_t)n_next * 4); lo_idx.reserve((size_t)n_next * 4); }
       launch_frontier_emit(vt->keys.as<unsigned long long>(), poff.as<uint32_t>(), n_pieces.as<uint32_t>(),
-                           foff.as<uint32_t>(), n_groups, pieces.as<int2>(), next_frontier.as<FrontierRec>(), stream);
+                           foff.as<uint32_t>(), n_groups, pieces.as<int2>(), next_frontier.as<FrontierRec>(), stream,
+                           keys_too ? &v : nullptr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>());
+      keys_for = keys_too ? next_frontier.p : nullptr;
+      keys_n = n_next;
       vt->n_groups = n_groups;
       index_table(*vt);
       tables.push_back(std::move(vt));
@@ -800,6 +810,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
   free_slot_order = free_slots_allowed;
   const DeviceIndexView &v = ix.view;
   cur_ranges = d_ranges;
+  keys_for = nullptr;
   ev_next = 0;
   timed.clear();
   tables.clear();

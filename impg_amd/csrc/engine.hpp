@@ -128,6 +128,8 @@ struct Engine {
   // raw: the owner side of a sharded hop -- slots as projected; the subset filter and the MultiImpg sort run at home
   uint64_t expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
                   impg_gpu_stats_t *st, bool raw = false, const RecordBlocks *blocks = nullptr);
+  const void *keys_for = nullptr;  // the frontier whose lookup-order keys frontier_emit has already written (lo_key / lo_idx)
+  uint32_t keys_n = 0;
   uint32_t expand_n_fr = 0;    // the frontier the last expand looked up (its cnt / pair_off describe that frontier's runs)
   bool last_by_place = false;  // the last expand laid its slots out in lookup order (pair_off is then by place)
   // subset filter + MultiImpg five-key sort of a level's slots (pair_off: first slot of every frontier record;

@@ -392,32 +392,35 @@ __global__ __launch_bounds__(256) void run_lengths_kernel(const uint32_t *__rest
 // bounds (optional): the records come in n_blocks contiguous blocks (records [bounds[b], bounds[b+1]) -- on a shard,
 // what each home rank sent); the block goes above the window bits, so the order is block by block and a block's
 // pairs stay together.
-// (Round 5, measured and dropped: frontier_emit writing the next level's keys beside the records -- lookup 5.65 -> 5.25 ms,
-// update 6.03 -> 6.36: the key's 64-bit division costs the same wherever it runs.)
+// where a range's window will be in the entry array, estimated from the record alone (the lookup order's key)
+#ifndef IMPG_ORDER_KEY_F64
+#define IMPG_ORDER_KEY_F64 1
+#endif
+__device__ __forceinline__ uint32_t order_key(const SegDesc *__restrict__ seg, const int32_t *__restrict__ seq_len, uint32_t n_seq,
+                                              uint32_t target_id, int32_t start) {
+  if (target_id >= n_seq) return 0u;
+  const uint2 d = *reinterpret_cast<const uint2 *>(seg + target_id);  // {a, n}
+  const int32_t len = seq_len[target_id];
+  const uint32_t st = (uint32_t)max(start, 0);
+  uint64_t rel = 0;
+  if (len > 0) {
+    // floor(st * n / len): a 64-bit integer division is a long sequence per record; in double precision the product is
+    // exact below 2^53 (a 31-bit start, a segment of < 2^22 entries), the quotient correctly rounded, and a quotient that
+    // is no integer lies at least 1 / len from one -- so the truncation is the integer division's result
+    if (IMPG_ORDER_KEY_F64 && d.y < (1u << 22)) rel = (uint64_t)((double)st * (double)d.y / (double)(uint32_t)len);
+    else rel = (uint64_t)st * d.y / (uint64_t)(uint32_t)len;
+  }
+  return d.x + (uint32_t)min(rel, (uint64_t)(d.y ? d.y - 1u : 0u));
+}
+// (Round 5: frontier_emit writes the next level's keys beside the records -- with the 64-bit division the key cost the same
+// wherever it ran (lookup 5.65 -> 5.25 ms, update 6.03 -> 6.36) and the fusion was dropped; with the double division it pays.)
 __global__ __launch_bounds__(256) void order_keys_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr, uint32_t n,
                                                          uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
                                                          const uint32_t *__restrict__ bounds, uint32_t n_blocks, uint32_t block_shift) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   if (r >= n) return;
   const FrontierRec f = fr[r];
-  uint32_t k = 0;
-  if (f.target_id < v.n_seq) {
-    const uint2 d = *reinterpret_cast<const uint2 *>(v.seg + f.target_id);  // {a, n}
-    const int32_t len = v.seq_len[f.target_id];
-#ifndef IMPG_ORDER_KEY_F64
-#define IMPG_ORDER_KEY_F64 1
-#endif
-    const uint32_t st = (uint32_t)max(f.start, 0);
-    uint64_t rel = 0;
-    if (len > 0) {
-      // floor(st * n / len): a 64-bit integer division is ~150 instructions a record; in double precision the product is
-      // exact below 2^53 (a 31-bit start, a segment of < 2^22 entries), the quotient correctly rounded, and a quotient that
-      // is no integer lies at least 1 / len from one -- so the truncation is the integer division's result
-      if (IMPG_ORDER_KEY_F64 && d.y < (1u << 22)) rel = (uint64_t)((double)st * (double)d.y / (double)(uint32_t)len);
-      else rel = (uint64_t)st * d.y / (uint64_t)(uint32_t)len;
-    }
-    k = d.x + (uint32_t)min(rel, (uint64_t)(d.y ? d.y - 1u : 0u));
-  }
+  uint32_t k = order_key(v.seg, v.seq_len, v.n_seq, f.target_id, f.start);
   if (bounds) {
     uint32_t lo = 0, hi = n_blocks;  // last block b with bounds[b] <= r
     while (hi - lo > 1u) {
@@ -4198,7 +4201,11 @@ __global__ __launch_bounds__(256) void frontier_emit_kernel(const unsigned long 
                                                             const uint32_t *__restrict__ n_pieces,
                                                             const uint32_t *__restrict__ foff, uint32_t n_groups,
                                                             const int2 *__restrict__ pieces,
-                                                            FrontierRec *__restrict__ out) {
+                                                            FrontierRec *__restrict__ out, const SegDesc *__restrict__ seg,
+                                                            const int32_t *__restrict__ seq_len, uint32_t n_seq,
+                                                            uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
+  // (key / idx: the next level's lookup-order keys beside the records, order_keys_kernel's words, while the record is in
+  // registers -- one read of the frontier less)
   // A wave takes 64 consecutive groups, whose records are one contiguous stretch of the frontier: a lane per OUTPUT
   // record (its group found by a search over the lanes' offsets), so that a store instruction writes 1 KB in a row.
   // (A lane per group wrote its ~3.5 records 16 bytes at a time, 64 lines per instruction: 1.0 ms of a headline step.)
@@ -4231,6 +4238,7 @@ __global__ __launch_bounds__(256) void frontier_emit_kernel(const unsigned long 
       f.end = piece.y;
       f.qidx = khi;
       out[o] = f;
+      if (key) { key[o] = order_key(seg, seq_len, n_seq, klo, piece.x); idx[o] = o; }
     }
   }
 }
@@ -5077,9 +5085,11 @@ void launch_covered_compact(const unsigned long long *svals, const uint32_t *kee
   if (n_groups) covered_regroup_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(kpos, n_active, n_kept, n_groups, gstart, glen, cap, pcap);
 }
 void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
-                          const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s) {
+                          const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s,
+                          const DeviceIndexView *v, uint32_t *key, uint32_t *idx) {
   if (!n_groups) return;
-  frontier_emit_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(gkey, poff, n_pieces, foff, n_groups, pieces, out);
+  frontier_emit_kernel<<<cdiv(n_groups, 256), 256, 0, s>>>(gkey, poff, n_pieces, foff, n_groups, pieces, out, v ? v->seg : nullptr,
+                                                           v ? v->seq_len : nullptr, v ? v->n_seq : 0u, v ? key : nullptr, v ? idx : nullptr);
 }
 void launch_subset_filter(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *qid,
                           const uint8_t *keep, const impg_gpu_range_t *ranges, hipStream_t s) {

@@ -160,7 +160,8 @@ void launch_covered_compact(const unsigned long long *svals, const uint32_t *kee
                             unsigned long long *out, uint32_t n_kept, uint32_t n_groups, uint32_t *gstart, uint32_t *glen, uint32_t *cap,
                             uint32_t *pcap, hipStream_t s);
 void launch_frontier_emit(const unsigned long long *gkey, const uint32_t *poff, const uint32_t *n_pieces,
-                          const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s);
+                          const uint32_t *foff, uint32_t n_groups, const int2 *pieces, FrontierRec *out, hipStream_t s,
+                          const DeviceIndexView *v = nullptr, uint32_t *key = nullptr, uint32_t *idx = nullptr);  // v + key + idx: the next lookup order's keys too
 void launch_subset_filter(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *qid,
                           const uint8_t *keep, const impg_gpu_range_t *ranges, hipStream_t s);
 // level -1 under a mask: the input range is inserted into a copy of its target's mask list (impg.rs:2084-2086);

@@ -666,6 +666,7 @@ __global__ __launch_bounds__(256) void scan_apply(const uint32_t *__restrict__ i
 // state[t] = flag << 62 | value (flag 0: nothing yet, 1: the tile's own sum, 2: the sum of everything up to and
 // including the tile); state[n_tiles] = the ticket.  A tile's own sum is a 32-bit sum like scan_block_sums' (counts
 // per range are small); prefixes are 64-bit, the offsets written are their low 32 bits and *total is exact.
+// (n < 2^32 - 4096, like the three-kernel form: a tile's lane offsets are 32-bit; the engine's counts stay far below.)
 // The three kernels above read the counts twice and ran the level's 8 x 10^7-range scan at 2.3 TB/s (282 + 89 + 72 us);
 // IMPG_SCAN_LOOKBACK = 0 brings them back.
 // ---------------------------------------------------------------------------

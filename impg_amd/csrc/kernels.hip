@@ -1739,7 +1739,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) PROJECT_OCCUPANCY void project_kernel(D
 // regrouping, and lanes keep the place order, so the result stores of a wave are one contiguous piece.
 // A block whose places span more than STG_ECAP entries (sparse levels, segment borders) runs its tiles the way
 // project_kernel does; a pair whose record has more than INLINE_TILES prefix lines reads them from the index.
-// launch_project picks this kernel when the level averages >= IMPG_STAGE_DENSITY pairs per index entry.
+// launch_project picks this kernel when the level averages >= IMPG_STAGE_DENSITY pairs per index entry (listed levels: >= 128, see stage_density_listed).
 // ---------------------------------------------------------------------------
 #ifndef IMPG_STG_THREADS
 #define IMPG_STG_THREADS 512

@@ -26,6 +26,10 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # visit order).  Pinned by tests/test_gpu_fullsize.py::test_headline_timed_form, which runs the timed form beside the
 # per-range counts (themselves checked against the oracle on a sample) -- the timed region asserts this very number.
 HEADLINE_PROJECTED = 2_125_313_869
+# Sum over the batch's 100 000 ranges of the per-range order-independent checksums (hit_stats_kernel's: a 64-bit mix of every
+# row's query id, query interval, target id and target interval, added up mod 2^64).  Pinned by the same test, which ties the
+# per-range checksums to the oracle on a sample; the self check recomputes it FROM THE ROWS the timed form leaves in HBM.
+HEADLINE_CHECKSUM = 16_006_759_611_715_120_108  # (tests/test_gpu_fullsize.py::test_headline_timed_form asserts it)
 
 
 T_START = time.time()
@@ -73,6 +77,13 @@ def main():
     ap.add_argument("--min-identity", type=float, default=None,
                     help="--min-result-identity of the reference (impg.rs:1283-1287); not part of the headline configuration")
     ap.add_argument("--no-extras", action="store_true", help="skip the full-results measurement (profiling runs)")
+    ap.add_argument("--no-tiers", action="store_true", help="skip the checksum of the rows left in HBM and the other tiers' timings (profiling runs)")
+    ap.add_argument("--form", default="rows", choices=["rows", "count"],
+                    help="what a timed step leaves behind.  rows (default, one GPU): every result row in HBM, attributable -- "
+                         "impg_gpu_query_batch_device, 24 bytes a row (query id, four coordinates, the frontier record that names "
+                         "its range and target).  count: nothing but the number of projections (impg_gpu_query_batch_stats without "
+                         "per-range output: the final level's rows are written but not attributed) -- rounds 1-5's timed form, and "
+                         "still the form of a sharded index")
     ap.add_argument("--world-sweep", action="store_true",
                     help="one device, constant work: the batch through a multi handle of 1 / 2 / 4 / 8 ranks that all share device 0 "
                          "(threads of this process, LocalComm) -- what the sharded path's fixed costs do as the world grows, "
@@ -193,10 +204,20 @@ def main():
         ranges["start"], ranges["end"] = bed["start"], bed["end"]
     d_ranges = torch.from_numpy(ranges.view(np.uint8)).to(dev)  # resident in HBM before the timed region
 
-    def step():  # (a collective call when the index is sharded: every rank brings its own ranges)
+    def step_count():  # (a collective call when the index is sharded: every rank brings its own ranges)
         st, _, _ = index.query_batch_stats(None, params, counts=False, checksums=False,
                                            device_ptr=d_ranges.data_ptr(), n=args.ranges)
         return st
+
+    def step_rows():  # every row left in HBM, attributable; the handle's HBM goes back to the engine's pool for the next step
+        dr = index.query_batch_device(None, params, device_ptr=d_ranges.data_ptr(), n=args.ranges)
+        st = dr.stats
+        dr.free()
+        return st
+
+    # (rows left on the device belong to one GPU's index; config 5's 10^12 rows do not fit any HBM: a caller would take them chunk by chunk)
+    form = "count" if (dist is not None or wl == "config5") else args.form
+    step = step_rows if form == "rows" else step_count
 
     def sync():
         torch.cuda.synchronize()
@@ -299,6 +320,9 @@ def main():
                                 "sum_of_per_range_counts": int(cnt_c.sum())}
         if not (st_t.projected == st_c.projected == int(cnt_c.sum())):
             self_check["status"] = "FAILED: the timed form and the counting form disagree on the first %d ranges" % ns
+    tiers = None
+    if dist is None and form == "rows" and not args.no_tiers:
+        tiers = rows_form_legs(index, ranges, params, args, d_ranges, step_count, sync, self_check, wl, dt)
     ms_project = sum(s.ms_project for s in stats)
     launches = sum(s.project_launches for s in stats)
     ach = (sum(s.projected for s in stats) * ALG_BYTES_PER_PROJECTION) / (ms_project * 1e-3) / 1e9 if ms_project > 0 else 0.0
@@ -355,7 +379,14 @@ def main():
         "roofline": roofline(stats, ach, traffic, tpath, ms_project, launches, tag if profiled else None),
         "self_check": self_check["status"],
         "self_check_detail": self_check,
+        "timed_form": ("rows: every result row left in HBM, 24 B each -- query id, q_first, q_last, t_first, t_last and the frontier record that "
+                       "names its range of the batch and its target (impg_gpu_query_batch_device, IMPG_ROWS_ATTRIBUTED); slot order free")
+                      if form == "rows" else
+                      "count: the number of projections only (impg_gpu_query_batch_stats without per-range output; the final level's rows "
+                      "are computed and stored but not attributed to a range)",
     }
+    if tiers:
+        out.update(tiers)
     if dist is not None:
         out["comm"] = comm_report
         out["parity"] = parity
@@ -409,6 +440,57 @@ def self_check_timed(stats, args, wl, world, sharded):
         if per[0] != HEADLINE_PROJECTED:
             chk["status"] = "FAILED: %d projections per step, the headline batch has %d" % (per[0], HEADLINE_PROJECTED)
     return chk
+
+
+def rows_form_legs(index, ranges, params, args, d_ranges, step_count, sync, self_check, wl, dt_rows):
+    """The timed form leaves rows; this says (a) that they are the right rows -- per-range counts and order-independent
+    checksums recomputed FROM THE ROWS IN HBM (impg_gpu_device_rows_check: every slot attributed through its frontier
+    record), their sums against the pinned constants at the headline, against the counting form's otherwise -- and (b)
+    what the other tiers of the same batch cost: nothing attributed (rounds 1-5's timed form) and, at the headline,
+    rows grouped by range in the reference's emission order."""
+    import numpy as np
+    out = {}
+    dr = index.query_batch_device(None, params, device_ptr=d_ranges.data_ptr(), n=args.ranges)
+    cnt, ck = dr.check()
+    parts = [{"level": int(d.level), "slots": int(d.n_slots), "frontier": int(d.n_frontier)} for d in dr.parts()]
+    projected = dr.projected
+    dr.free()
+    with np.errstate(over="ignore"):
+        rows_sum = int(ck.sum(dtype=np.uint64))
+    rows_cnt = int(cnt.sum())
+    self_check["rows_in_hbm"] = {"sum_of_per_range_counts": rows_cnt, "sum_of_per_range_checksums": rows_sum, "projected": int(projected),
+                                 "parts": parts, "bytes_per_slot": 24}
+    if self_check["status"] == "ok" and rows_cnt != projected:
+        self_check["status"] = "FAILED: the rows left in HBM (%d) are not the projections counted (%d)" % (rows_cnt, projected)
+    if self_check.get("expected") is not None:  # the headline batch: pinned
+        self_check["expected_checksum"] = HEADLINE_CHECKSUM
+        if self_check["status"] == "ok" and HEADLINE_CHECKSUM is not None and rows_sum != HEADLINE_CHECKSUM:
+            self_check["status"] = "FAILED: checksum of the rows left in HBM %d, the headline batch's is %d" % (rows_sum, HEADLINE_CHECKSUM)
+    elif self_check["status"] == "ok":
+        ns = min(args.ranges, 2000)
+        st_c, cnt_c, ck_c = index.query_batch_stats(ranges[:ns], params)
+        ok = bool((cnt_c == cnt[:ns]).all() and (ck_c == ck[:ns]).all())
+        self_check["rows_vs_counting_form"] = {"ranges": ns, "identical": ok}
+        if not ok:
+            self_check["status"] = "FAILED: rows left in HBM and the counting form disagree on the first %d ranges" % ns
+    # ---- the other tiers of the same batch --------------------------------------------------------------------------
+    for _ in range(max(1, args.warmup)):
+        step_count()
+    sync()
+    t0 = time.perf_counter()
+    sts = [step_count() for _ in range(args.steps)]
+    sync()
+    dtc = time.perf_counter() - t0
+    pc = sum(s.projected for s in sts)
+    out["value_count_only"] = pc / dtc if dtc > 0 else None
+    out["ms_per_step_count_only"] = dtc * 1e3 / max(1, args.steps)
+    out["count_only_stage_ms"] = {"lookup": sum(s.ms_lookup for s in sts) / max(1, args.steps), "project": sum(s.ms_project for s in sts) / max(1, args.steps),
+                                  "update": sum(s.ms_update for s in sts) / max(1, args.steps)}
+    out["tiers_note"] = ("value = rows left in HBM, attributable (the timed form); value_count_only = the same batch with nothing but the "
+                         "projection count kept (rounds 1-5's timed form); full_results.stream = the same rows in the reference's emission "
+                         "order delivered to the host (PCIe-bound)")
+    log("tiers: rows in HBM %.2f ms/step, count only %.2f ms/step" % (dt_rows * 1e3 / max(1, args.steps), out["ms_per_step_count_only"]))
+    return out
 
 
 SIMDS = 256 * 4

@@ -62,6 +62,16 @@ class Stats(C.Structure):
                 ("ms_exchange", C.c_float)]
 
 
+class DevicePart(C.Structure):  # impg_gpu_device_part_t
+    _fields_ = [("first_range", C.c_size_t), ("n_ranges", C.c_size_t), ("level", C.c_uint32), ("n_frontier", C.c_uint32),
+                ("n_slots", C.c_uint64), ("query_id", C.c_void_p), ("coords", C.c_void_p), ("source", C.c_void_p),
+                ("frontier", C.c_void_p)]
+
+
+ROWS_ATTRIBUTED = 0
+FRONTIER_DTYPE = np.dtype([("target_id", "<u4"), ("start", "<i4"), ("end", "<i4"), ("range_idx", "<u4")])
+
+
 class ImpgGpuError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("impg_gpu error %d: %s" % (code, msg))
@@ -132,6 +142,12 @@ SYMBOLS = [
     ("impg_gpu_results_free", None, [_P]),
     ("impg_gpu_query_batch_stats", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, _P, C.POINTER(Stats)]),
     ("impg_gpu_query_batch_stats_dev", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, _P, C.POINTER(Stats)]),
+    ("impg_gpu_query_batch_device", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(Params), C.c_int, C.POINTER(_P)]),
+    ("impg_gpu_device_rows_num_parts", C.c_size_t, [_P]),
+    ("impg_gpu_device_rows_part", C.c_int, [_P, C.c_size_t, C.POINTER(DevicePart)]),
+    ("impg_gpu_device_rows_stats", None, [_P, C.POINTER(Stats)]),
+    ("impg_gpu_device_rows_check", C.c_int, [_P, _P, _P]),
+    ("impg_gpu_device_rows_free", None, [_P]),
     ("impg_gpu_bed_merge", C.c_long, [_P, C.c_size_t, C.c_int32, C.c_int]),
     ("impg_gpu_results_bed", C.c_int, [_P, _P, _P, C.POINTER(Params), C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("impg_gpu_query_batch_bed", C.c_int, [_P, _P, C.c_size_t, C.POINTER(Params), _P, C.c_int32, _P, C.POINTER(_P), C.POINTER(C.c_size_t),

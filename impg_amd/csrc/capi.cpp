@@ -60,6 +60,7 @@ EngineLease::~EngineLease() {
   e->masked = false;
   e->subset_on = false;
   e->on_kernels_done = nullptr;  // (the row stream's hook captures its caller's locals: never past the lease)
+  e->keep_any_order = false;
   std::lock_guard<std::mutex> lk(ix.eng_m);
   ix.eng_free.push_back(e);
   ix.eng_cv.notify_one();
@@ -512,6 +513,9 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
   } else if (k == "locality_min") {  // frontier size from which the projection runs in window order (0 = never)
     if (value < 0 || value >= (1ll << 31)) throw Error{IMPG_E_INVALID, "locality_min out of range"};
     ix->opt_locality_min = (uint32_t)value;
+  } else if (k == "device_rows_pool_bytes") {  // HBM an engine keeps between impg_gpu_query_batch_device calls (freed slot arrays, reused by the next call)
+    if (value < 0) throw Error{IMPG_E_INVALID, "device_rows_pool_bytes must not be negative"};
+    ix->opt_device_rows_pool = (uint64_t)value;
   } else if (k == "fuse_final_level") {  // a counting run's final level enumerates its pairs from the count pass's windows: no emit pass (results identical)
     ix->opt_fuse_final = value != 0;
   } else if (k == "regroup_entries") {  // projection blocks regroup their pairs by entry before reading the index (results identical)
@@ -927,6 +931,137 @@ int impg_gpu_query_batch_stats_dev(impg_gpu_index_t *ix, const impg_gpu_range_t 
   EngineLease lease(*ix);
   return stats_impl(ix, *lease, d_ranges, n, params, per_range_count, per_range_checksum, stats);
   IMPG_CATCH
+}
+
+// ---- rows left in HBM ------------------------------------------------------------------------------------------------
+// impg_gpu_query_batch_device: the batch's result rows stay on the device, complete -- what SURVEY.md 8(d) calls the result
+// record: {range_idx, query_id, q_first, q_last, t_first, t_last} -- for a consumer that lives there too (the BED merges of
+// bed_device.hip are one; a caller's own kernels another).  The handle keeps the engine it ran on (its buffers are the
+// engine's pooled blocks) until it is freed.
+struct impg_gpu_device_rows {
+  // (declared first, destroyed last: the chunks' buffers go back to the engine's pool while the lease still holds it)
+  std::unique_ptr<impg::EngineLease> lease;
+  struct Chunk {
+    size_t first = 0, n = 0;
+    std::vector<std::unique_ptr<impg::LevelBufs>> levels;
+  };
+  std::vector<Chunk> chunks;
+  struct Part { size_t chunk; size_t level; };
+  std::vector<Part> parts;
+  impg_gpu_index *ix = nullptr;
+  impg_gpu_params_t params{};
+  size_t n = 0;
+  int layout = 0;
+  impg_gpu_stats_t stats{};
+};
+
+int impg_gpu_query_batch_device(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, int ranges_on_device,
+                                const impg_gpu_params_t *params, int layout, impg_gpu_device_rows_t **out) {
+  IMPG_TRY
+  if (!ix || !params || !out || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
+  if (layout != IMPG_ROWS_ATTRIBUTED) throw Error{IMPG_E_INVALID, "unknown row layout"};
+  if (n >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 ranges in one batch"};
+  if (!ranges_on_device) check_ranges(ranges, n);
+  Engine::check_params(*params);
+  if (ix->shard || ix->cluster)
+    throw Error{IMPG_E_UNSUPPORTED, "rows left on the device belong to one GPU: a sharded index returns rows through impg_gpu_query_batch"};
+  if (params->store_cigar || params->multi_impg || (params->transitive && params->dfs))
+    throw Error{IMPG_E_UNSUPPORTED, "impg_gpu_query_batch_device takes Impg::query and query_transitive_bfs without store_cigar"};
+  IMPG_HIP(hipSetDevice(ix->device));
+  auto h = std::make_unique<impg_gpu_device_rows>();
+  h->lease = std::make_unique<EngineLease>(*ix);
+  Engine &E = **h->lease;
+  // (the slot arrays of a big batch are tens of GB: they go back to the engine's pool when the handle is freed and are
+  // the next call's -- the pool's default cap would hipFree / hipMalloc them call after call)
+  E.level_pool.max_held = std::max<size_t>(E.level_pool.max_held, (size_t)ix->opt_device_rows_pool);
+  h->ix = ix;
+  h->params = *params;
+  h->n = n;
+  h->layout = layout;
+  const impg_gpu_range_t *d_ranges = ranges;
+  if (!ranges_on_device) {
+    E.ranges_dev.reserve(std::max<size_t>(n * sizeof(impg_gpu_range_t), 256));
+    if (n) IMPG_HIP(hipMemcpyAsync(E.ranges_dev.p, ranges, n * sizeof(impg_gpu_range_t), hipMemcpyHostToDevice, E.stream));
+    d_ranges = E.ranges_dev.as<impg_gpu_range_t>();
+  }
+  impg_gpu_stats_t tot;
+  memset(&tot, 0, sizeof tot);
+  for_chunks(E, n, [&](size_t b, size_t e) {
+    impg_gpu_device_rows::Chunk c;
+    c.first = b; c.n = e - b;
+    impg_gpu_stats_t st;
+    E.keep_any_order = true;  // a slot names its frontier record (pair_range): the final level may be fused like a counting run's
+    try {
+      E.run(*ix, d_ranges + b, (uint32_t)(e - b), *params, &c.levels, nullptr, nullptr, &st, nullptr);
+    } catch (...) { E.keep_any_order = false; throw; }
+    E.keep_any_order = false;
+    tot.projected += st.projected; tot.pairs += st.pairs; tot.frontier_ranges += st.frontier_ranges;
+    tot.levels = std::max(tot.levels, st.levels);
+    tot.ms_total += st.ms_total; tot.ms_lookup += st.ms_lookup; tot.ms_project += st.ms_project; tot.ms_update += st.ms_update;
+    tot.project_launches += st.project_launches;
+    h->chunks.push_back(std::move(c));
+  });
+  for (size_t c = 0; c < h->chunks.size(); c++)
+    for (size_t l = 0; l < h->chunks[c].levels.size(); l++) h->parts.push_back({c, l});
+  h->stats = tot;
+  *out = h.release();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
+size_t impg_gpu_device_rows_num_parts(const impg_gpu_device_rows_t *h) { return h ? h->parts.size() : 0; }
+int impg_gpu_device_rows_part(const impg_gpu_device_rows_t *h, size_t k, impg_gpu_device_part_t *out) {
+  IMPG_TRY
+  if (!h || !out || k >= h->parts.size()) throw Error{IMPG_E_INVALID, "no such part"};
+  const auto &c = h->chunks[h->parts[k].chunk];
+  const LevelBufs &L = *c.levels[h->parts[k].level];
+  memset(out, 0, sizeof *out);
+  out->first_range = c.first;
+  out->n_ranges = c.n;
+  out->level = (uint32_t)h->parts[k].level;
+  out->n_slots = L.n_pairs;
+  out->n_frontier = L.n_frontier;
+  out->query_id = L.qid.as<uint32_t>();
+  out->coords = L.coords.as<int32_t>();
+  out->source = L.pair_range.as<uint32_t>();
+  out->frontier = L.frontier.as<impg_gpu_frontier_t>();
+  return IMPG_OK;
+  IMPG_CATCH
+}
+void impg_gpu_device_rows_stats(const impg_gpu_device_rows_t *h, impg_gpu_stats_t *stats) {
+  if (h && stats) *stats = h->stats;
+}
+// the per-range counts and checksums of impg_gpu_query_batch_stats, recomputed from the rows the call left in HBM
+int impg_gpu_device_rows_check(impg_gpu_device_rows_t *h, uint64_t *per_range_count, uint64_t *per_range_checksum) {
+  IMPG_TRY
+  if (!h) throw Error{IMPG_E_INVALID, "null argument"};
+  Engine &E = **h->lease;
+  IMPG_HIP(hipSetDevice(h->ix->device));
+  const size_t n = h->n;
+  E.stat_count.reserve(std::max<size_t>(n * 8, 256));
+  E.stat_cksum.reserve(std::max<size_t>(n * 8, 256));
+  IMPG_HIP(hipMemsetAsync(E.stat_count.p, 0, std::max<size_t>(n * 8, 8), E.stream));
+  IMPG_HIP(hipMemsetAsync(E.stat_cksum.p, 0, std::max<size_t>(n * 8, 8), E.stream));
+  for (auto &c : h->chunks)
+    for (auto &Lp : c.levels) {
+      LevelBufs &L = *Lp;
+      if (!L.n_pairs) continue;
+      HitArrays ha{L.qid.as<uint32_t>(), L.coords.as<int4>()};
+      E.rstat.reserve(std::max<size_t>((size_t)L.n_frontier * 16, 256));
+      launch_hit_stats(L.frontier.as<FrontierRec>(), L.n_frontier, L.pair_range.as<uint32_t>(), L.n_pairs, ha,
+                       h->params.transitive ? h->params.min_output_length : -1, false, E.rstat.as<unsigned long long>(),
+                       E.stat_count.as<unsigned long long>() + c.first, E.stat_cksum.as<unsigned long long>() + c.first, E.stream);
+    }
+  IMPG_HIP(hipStreamSynchronize(E.stream));
+  if (per_range_count && n) IMPG_HIP(hipMemcpy(per_range_count, E.stat_count.p, n * 8, hipMemcpyDeviceToHost));
+  if (per_range_checksum && n) IMPG_HIP(hipMemcpy(per_range_checksum, E.stat_cksum.p, n * 8, hipMemcpyDeviceToHost));
+  return IMPG_OK;
+  IMPG_CATCH
+}
+void impg_gpu_device_rows_free(impg_gpu_device_rows_t *h) {
+  if (!h) return;
+  if (h->ix) (void)hipSetDevice(h->ix->device);
+  delete h;
 }
 
 long impg_gpu_bed_merge(impg_gpu_interval_t *iv, size_t n, int32_t merge_distance, int merge_strands) {

@@ -27,6 +27,7 @@ inline unsigned bits_for(uint64_t n) {  // bits needed to represent values < n
 Engine::Engine(int device) {
   IMPG_HIP(hipSetDevice(device));
   IMPG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  win_se.pool = &level_pool;  // (handed over to a kept fused level as its frontier: a pooled block like the level's others)
   counters.reserve(128);  // (words 0..7: the counters of a run; 8..11: the list lengths and work counters of the update)
   acc_slots.reserve(COUNT_BYTES);
   act_slots.reserve(COUNT_BYTES);
@@ -407,11 +408,12 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   // (the owner side of a sharded hop may do the same when the order runs home rank by home rank: `blocks`)
   const bool by_place = free_slot_order && (!raw || blocks) && !multi && !store_cigar && d_perm;
   last_by_place = by_place;
+  last_range_places = false;
   expand_n_fr = n_fr;
   const bool fused = by_place && fuse_final && emit_by_lanes(v) && !v.tp_mode;
-  if (by_place) win_se.reserve((size_t)n_fr * 8);
+  if (by_place) win_se.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
   launch_lookup_count(v, fr, n_fr, transitive, d_perm, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(),
-                      wide_list.as<uint32_t>(), stream, by_place, by_place ? win_se.as<int2>() : nullptr);
+                      wide_list.as<uint32_t>(), stream, by_place, by_place ? win_se.as<FrontierRec>() : nullptr);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);
   if (P > pair_budget || P >= 0xFFFFFFF0ull) {
     if (split_ok) throw SplitBatch{};
@@ -421,7 +423,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
   ProjList pl{nullptr, nullptr, nullptr};
-  WindowLists wlists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u};
+  WindowLists wlists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u, 0u};
   if (fused) {
     // the final level of a counting run: pairs by windows (WindowLists); only the windows too wide for a 64-bit mask are listed
     // (tile_first[]: only project_kernel needs it -- the kernels of a dense level search their own block's offsets)
@@ -430,13 +432,14 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
     if (!staged) launch_tile_first(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr, tile_first.as<uint32_t>(), stream);
     launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                        pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true, true);
-    wlists = WindowLists{tile_first.as<uint32_t>(), pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<int2>(), d_perm, n_fr,
-                         fuse_need_ranges ? L.pair_range.as<uint32_t>() : nullptr, 1u};
+    wlists = WindowLists{tile_first.as<uint32_t>(), pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<FrontierRec>(), d_perm, n_fr,
+                         fuse_need_ranges ? L.pair_range.as<uint32_t>() : nullptr, 1u, fuse_range_places ? 1u : 0u};
+    last_range_places = fuse_need_ranges && fuse_range_places;
   } else if (by_place) {
     launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                        pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true);
     // (which range owns which places, for the staged projection of a dense level)
-    wlists = WindowLists{nullptr, pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<int2>(), d_perm, n_fr, nullptr, 0u};
+    wlists = WindowLists{nullptr, pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<FrontierRec>(), d_perm, n_fr, nullptr, 0u, 0u};
   } else {
     const uint32_t *d_offp = nullptr;
     projection_offsets(d_perm, n_fr, cnt.as<uint32_t>(), P, d_offp, pl);
@@ -867,12 +870,17 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
       L = own.get();
     }
     const bool want_stats = d_count || d_cksum;
-    fuse_final = fuse_allowed && last && !keep && !remote;
+    // (kept levels too when their reader takes the slots in any order and finds a slot's frontier record through
+    // pair_range -- the rows left in HBM, impg_gpu_query_batch_device's attributed layout: keep_any_order)
+    fuse_final = fuse_allowed && last && (!keep || keep_any_order) && !remote;
     // (per-range counts / checksums of a fused level cost two atomics per hit -- its slots are in entry order, a range's
     // are no run -- which a deep closure's final level, 10^4+ ranges a query, does not earn back: config 5 with counts
     // 2.8 s per 4 000 windows fused, 1.4 s not)
     if (want_stats && (uint64_t)n_fr > 8192ull * n) fuse_final = false;
-    fuse_need_ranges = want_stats || subset_on;
+    fuse_need_ranges = want_stats || subset_on || keep != nullptr;
+    // (a kept fused level names a slot's range by its place in the lookup order -- no load in the kernel -- and keeps its
+    // copy of the frontier in that order; the per-range statistics and the subset filter index the frontier itself)
+    fuse_range_places = keep != nullptr && !want_stats && !subset_on;
     const HopResult hr = hop(v, cur->as<FrontierRec>(), alive ? n_fr : 0, transitive, *L, st, keep || want_stats || !last,
                              keep || d_cksum, alive);
     fuse_final = false;
@@ -890,8 +898,13 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
       if (!last) n_next = update(v, cur->as<FrontierRec>(), *L, n, p, *nxt);
       if (keep) {
         // the level keeps its own copy of the frontier (qidx / target per pair)
-        L->frontier.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
-        IMPG_HIP(hipMemcpyAsync(L->frontier.p, cur->p, (size_t)n_fr * sizeof(FrontierRec), hipMemcpyDeviceToDevice, stream));
+        if (!(last_range_places && !remote)) L->frontier.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
+        if (last_range_places && !remote) {
+          // (pair_range holds places of the lookup order: the level's frontier in that order is what the count pass left
+          // beside the windows -- handed over, not copied; win_se allocates anew at the next by-place level)
+          L->frontier.adopt(win_se);
+        } else
+          IMPG_HIP(hipMemcpyAsync(L->frontier.p, cur->p, (size_t)n_fr * sizeof(FrontierRec), hipMemcpyDeviceToDevice, stream));
         keep->push_back(std::move(own));
       }
     }

@@ -95,7 +95,11 @@ struct Engine {
   // reads its slots in order -- the projection kernel enumerates the pairs from the count pass's windows and the emit
   // pass is skipped (WindowLists, kernels.hpp).  Set by run() around that level's hop.
   bool fuse_allowed = true;        // option "fuse_final_level" (A/B runs)
-  bool fuse_final = false, fuse_need_ranges = false;
+  bool fuse_final = false, fuse_need_ranges = false, fuse_range_places = false;
+  bool last_range_places = false;  // the last expand wrote places of the lookup order into pair_range (a kept fused level)
+  // set by the caller around run(): the kept levels' slots may come in any order, as long as pair_range names every
+  // slot's frontier record (a kept final level may then be fused like a counting run's)
+  bool keep_any_order = false;
   DevBuf win_se, tile_first;       // the ranges' (start, end) by place; first range of every projection tile
   int filter_covered = 0;          // option "filter_covered": hits covered by their group's old list dropped before the replay (0 off: it bought nothing on config 5, where hits are covered by the list as it GROWS, not as the level found it; 1 always, 2 long groups)
   uint64_t covered_dropped = 0;    // ... how many that was, over the engine's life (tuning aid)

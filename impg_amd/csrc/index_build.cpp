@@ -85,7 +85,7 @@ void *BufPool::take(size_t bytes, size_t &cap_out) {
 void BufPool::give(void *p, size_t cap) {
   free_.push_back({p, cap});
   held += cap;
-  while (held > MAX_HELD && !free_.empty()) {
+  while (held > max_held && !free_.empty()) {
     size_t big = 0;
     for (size_t i = 1; i < free_.size(); i++) if (free_[i].cap > free_[big].cap) big = i;
     (void)hipFree(free_[big].p);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView 
                                                                 uint32_t n, const uint32_t *__restrict__ perm,
                                                                 uint32_t *__restrict__ cnt,
                                                                 uint4 *__restrict__ win, uint32_t *__restrict__ wide_n,
-                                                                uint32_t *__restrict__ wide_list, int by_place, int2 *__restrict__ se) {
+                                                                uint32_t *__restrict__ wide_list, int by_place, FrontierRec *__restrict__ se) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   // perm (optional): neighbouring lanes take ranges that are neighbours in the entry array, so
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView 
   }
   cnt[o] = c;
   win[o] = make_uint4(lo, ub, (uint32_t)mask, (uint32_t)(mask >> 32));
-  if (se) se[o] = make_int2(qs, qe);
+  if (se) se[o] = f;  // (the whole record at the range's place: the projection reads its ends there, a kept level its range and target)
   // windows too wide for the lane-per-range emit pass (dense targets) are listed for the wave-per-range one
   if (wide_list && lo < ub && ub - (lo & ~3u) > 64u) wide_list[atomicAdd(wide_n, 1u)] = o;
 }
@@ -360,6 +360,13 @@ __global__ __launch_bounds__(256) void route_gather_kernel(const FrontierRec *__
   FrontierRec f = fr[src];
   f.qidx = src;  // the home index the owner echoes back
   out[i] = f;
+}
+
+// a level's frontier in its lookup order: what a kept fused level's pair_range indexes (Engine::run, fuse_range_places)
+__global__ __launch_bounds__(256) void frontier_gather_kernel(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ perm,
+                                                              uint32_t n, FrontierRec *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) out[i] = fr[perm[i]];
 }
 
 // Home side of a hop: hit records arrive grouped by owner rank, every owner's block in ascending fidx (the index
@@ -1605,11 +1612,12 @@ __device__ __forceinline__ PairIn pair_of_place(uint32_t pp, uint32_t lblock, ui
     }
     if (x.live) {
       const uint4 w = wl.win[ri];
-      const int2 se = wl.se[ri];
+      const FrontierRec sf = wl.se[ri];
+      const int2 se = make_int2(sf.start, sf.end);
       x.f_start = se.x; x.f_end = se.y;
       if (w.y - (w.x & ~3u) > 64u) x.eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
       else x.eidx = w.x + select_bit64(w.z, w.w, k);
-      if (wl.range_out) wl.range_out[pp] = wl.perm[ri];
+      if (wl.range_out) wl.range_out[pp] = wl.range_places ? ri : wl.perm[ri];
     }
   } else if (x.live) {
     if (pl.slot) { x.p = pl.slot[pp]; r = pl.range[pp]; x.eidx = pl.entry[pp]; }
@@ -1792,7 +1800,7 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
         const uint4 w = st_win[j];
         if (w.y - (w.x & ~3u) > 64u) y.eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
         else y.eidx = w.x + select_bit64(w.z, w.w, pp - st_off[j]);
-        if (wl.range_out) wl.range_out[pp] = wl.perm[r0 + j];
+        if (wl.range_out) wl.range_out[pp] = wl.range_places ? r0 + j : wl.perm[r0 + j];
       } else {
         y.eidx = e_next;
       }
@@ -1866,7 +1874,7 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
     if (threadIdx.x < nr) {
       const uint4 w = wl.win[r0 + threadIdx.x];
       st_win[threadIdx.x] = w;
-      st_se[threadIdx.x] = wl.se[r0 + threadIdx.x];
+      { const FrontierRec sf = wl.se[r0 + threadIdx.x]; st_se[threadIdx.x] = make_int2(sf.start, sf.end); }
       if (w.y - (w.x & ~3u) > 64u) { emin = w.x; emax = w.y - 1u; }  // (a window wider than the mask: its hits lie somewhere in it)
       else if (w.z | w.w) {
         emin = w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w));
@@ -2072,7 +2080,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
     if (t < nr) {
       const uint4 w = wl.win[r0 + t];
       st_win[t] = w;
-      st_se[t] = wl.se[r0 + t];
+      { const FrontierRec sf = wl.se[r0 + t]; st_se[t] = make_int2(sf.start, sf.end); }
       if (w.y - (w.x & ~3u) > 64u) st_wide[atomicAdd(&st_nwide, 1u)] = (uint16_t)t;
       else if (w.z | w.w) {
         glo = w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w));
@@ -2225,7 +2233,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
                                          : (uint32_t)__popc(w.z) + (uint32_t)__popc(w.w & ((1u << (d - 32u)) - 1u));
           p = st_off[r] + below;
         }
-        if (live && wl.range_out) wl.range_out[p] = wl.perm[r0 + r];
+        if (live && wl.range_out) wl.range_out[p] = wl.range_places ? r0 + r : wl.perm[r0 + r];
         if (orient == 0) project_entry_chunk<TRANSITIVE, 0, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
         else if (orient == 1) project_entry_chunk<TRANSITIVE, 1, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
         else if (orient == 2) project_entry_chunk<TRANSITIVE, 2, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
@@ -2264,7 +2272,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
         h.qid[pp] = qid;
         if (ok) h.c[pp] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
         n_ok += ok ? 1u : 0u;
-        if (wl.range_out) wl.range_out[pp] = wl.perm[r0 + r];
+        if (wl.range_out) wl.range_out[pp] = wl.range_places ? r0 + r : wl.perm[r0 + r];
       }
     }
   }
@@ -4809,7 +4817,7 @@ static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 wa
 }
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
-                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place, int2 *se) {
+                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place, FrontierRec *se) {
   if (!n) return;
   const bool lanes = emit_by_lanes(v);
   const int bp = by_place && perm ? 1 : 0;
@@ -4868,6 +4876,9 @@ void launch_route_keys(const FrontierRec *fr, uint32_t n, uint32_t world, const 
 void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s) {
   if (n) route_gather_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, perm, n, out);
 }
+void launch_frontier_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s) {
+  if (n) frontier_gather_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, perm, n, out);
+}
 void launch_reorder_runs(const uint32_t *hits, uint32_t n, uint32_t words, uint32_t n_front, uint32_t *run_start,
                          uint32_t *run_len, uint32_t *err, hipStream_t s) {
   if (!n) return;
@@ -4912,7 +4923,7 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
                     ProjList pl, hipStream_t s, const uint32_t *n_pairs_dev, bool regroup, const WindowLists *wlp) {
   if (!n_pairs) return;
-  const WindowLists wl = wlp ? *wlp : WindowLists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u};
+  const WindowLists wl = wlp ? *wlp : WindowLists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u, 0u};
   const int rg = regroup ? 1 : 0;
   bool ident = min_identity == min_identity;  // NaN = no filter
   // An index built without prefix lines (it would not have fitted the device with them: index_build_device.hip) has

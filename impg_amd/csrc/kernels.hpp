@@ -53,7 +53,7 @@ struct VisitedTables {
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
                          uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place = false,
-                         int2 *se = nullptr /* by_place: the ranges' (start, end) at their places */);
+                         FrontierRec *se = nullptr /* by_place: the ranges' records at their places (the projection reads the ends there) */);
 // A counting run's FINAL level listed by windows instead of by pairs (engine.cpp: Engine::expand): nothing reads that
 // level's slots by position or in order, so the projection kernel takes its pairs straight from what the count pass
 // left per range -- place offset, window, hit mask -- and the emit pass with its two 4-byte-per-pair lists is not run
@@ -64,11 +64,12 @@ struct WindowLists {
   const uint32_t *tile_first;  // [tiles of PROJ_BLOCK places] the range (by place in the lookup order) that holds the tile's first place; null = the pairs are listed
   const uint32_t *pair_off;    // [n_fr] first place of every range's pairs
   const uint4 *win;            // [n_fr] {lo, ub, hit mask of the first 64 window entries}
-  const int2 *se;              // [n_fr] the range's (start, end)
+  const FrontierRec *se;       // [n_fr] the range's record (its start and end are what the projection reads)
   const uint32_t *perm;        // [n_fr] place -> frontier range
   uint32_t n_fr;
   uint32_t *range_out;         // optional: pair_range[] for the per-range counts / the subset filter
   uint32_t masks;              // 1: the pairs are named by the windows' hit masks (tile_first is only needed when project_kernel runs the level)
+  uint32_t range_places;       // 1: range_out names a pair's range by its PLACE in the lookup order (perm not applied: no load) -- kept levels, whose frontier copy is taken in that order
 };
 // whether launch_project will run a plain projection of n_pairs by-place pairs on the staged kernels (no tile_first[] needed)
 bool project_is_staged(const DeviceIndexView &v, uint64_t n_pairs, bool plain);
@@ -96,6 +97,7 @@ void launch_hits_unpack(const void *in, uint32_t n, uint32_t words, uint32_t n_f
                         uint32_t *pair_range, HitArrays h, uint32_t *mslot, hipStream_t s, const uint32_t *slice_at = nullptr,
                         uint32_t *slice_pos = nullptr, uint32_t *slice_n = nullptr);
 void launch_route_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s);
+void launch_frontier_gather(const FrontierRec *fr, const uint32_t *perm, uint32_t n, FrontierRec *out, hipStream_t s);  // out[i] = fr[perm[i]]
 // stable order of hit records (words u32 each, fidx first) by fidx when equal fidx are already contiguous
 void launch_reorder_runs(const uint32_t *hits, uint32_t n, uint32_t words, uint32_t n_front, uint32_t *run_start,
                          uint32_t *run_len, uint32_t *err, hipStream_t s);

@@ -109,6 +109,77 @@ class QueryResults:
             self._h = None
 
 
+_HIP = None
+
+
+def _hip_memcpy_d2h(dst, src, nbytes):
+    """hipMemcpy device -> host through the HIP runtime the library itself links (tests and probes read device rows back)."""
+    global _HIP
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")
+        _HIP.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _HIP.hipMemcpy.restype = C.c_int
+    if nbytes:
+        rc = _HIP.hipMemcpy(dst, src, nbytes, 2)
+        if rc != 0:
+            raise ImpgGpuError(_lib.IMPG_E_HIP, "hipMemcpy (device to host) failed: %d" % rc)
+
+
+class DeviceRows:
+    """impg_gpu_device_rows_t: the rows of a batch left in HBM (impg_gpu_query_batch_device).  Holds one of the index's
+    engines until freed (free() or garbage collection)."""
+
+    def __init__(self, handle, owner, n):
+        self._h = handle
+        self._owner = owner  # keeps the index alive
+        self._n = int(n)
+        st = Stats()
+        lib().impg_gpu_device_rows_stats(self._h, C.byref(st))
+        self.stats = st
+        self.projected = int(st.projected)
+
+    def parts(self):
+        out = []
+        for k in range(lib().impg_gpu_device_rows_num_parts(self._h)):
+            d = _lib.DevicePart()
+            check(lib().impg_gpu_device_rows_part(self._h, k, C.byref(d)))
+            out.append(d)
+        return out
+
+    def part_to_host(self, k):
+        """One part copied back: (first_range, level, query_id[n], coords[n, 4], source[n], frontier[n_frontier])."""
+        d = self.parts()[k]
+        n, nf = int(d.n_slots), int(d.n_frontier)
+        qid = np.empty(n, dtype=np.uint32)
+        co = np.empty((n, 4), dtype=np.int32)
+        src = np.empty(n, dtype=np.uint32)
+        fr = np.empty(nf, dtype=_lib.FRONTIER_DTYPE)
+        _hip_memcpy_d2h(qid.ctypes.data, d.query_id, n * 4)
+        _hip_memcpy_d2h(co.ctypes.data, d.coords, n * 16)
+        _hip_memcpy_d2h(src.ctypes.data, d.source, n * 4)
+        _hip_memcpy_d2h(fr.ctypes.data, d.frontier, nf * 16)
+        return int(d.first_range), int(d.level), qid, co, src, fr
+
+    def check(self, counts=True, checksums=True):
+        """impg_gpu_device_rows_check: per-range counts / checksums recomputed from the rows in HBM."""
+        n = self._n
+        cnt = np.zeros(n, dtype=np.uint64) if counts else None
+        ck = np.zeros(n, dtype=np.uint64) if checksums else None
+        check(lib().impg_gpu_device_rows_check(self._h, cnt.ctypes.data if counts else None, ck.ctypes.data if checksums else None))
+        return cnt, ck
+
+    def free(self):
+        if self._h:
+            lib().impg_gpu_device_rows_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class PreparedMask:
     """A masked_regions map already in the C layout (impg_gpu_mask_t + the arrays it points into): per-call users --
     the shape of partition.rs:359-391 -- convert once per change of the map, not once per call."""
@@ -451,6 +522,19 @@ class GpuImpg:
         else:
             check(lib().impg_gpu_query_batch_stats_dev(self._h, device_ptr, n, C.byref(p), cp, kp, C.byref(st)))
         return st, cnt, ck
+
+    def query_batch_device(self, ranges, params=None, device_ptr=None, n=None, layout=_lib.ROWS_ATTRIBUTED, **kw):
+        """impg_gpu_query_batch_device: every result row left in HBM, attributable (DeviceRows).  device_ptr / n: the
+        ranges are already on the device."""
+        p = params or make_params(**kw)
+        h = C.c_void_p(None)
+        if device_ptr is None:
+            r = self._ranges(ranges)
+            n = r.size
+            check(lib().impg_gpu_query_batch_device(self._h, r.ctypes.data, r.size, 0, C.byref(p), layout, C.byref(h)))
+        else:
+            check(lib().impg_gpu_query_batch_device(self._h, device_ptr, n, 1, C.byref(p), layout, C.byref(h)))
+        return DeviceRows(h, self, n)
 
     def hop_profile(self, reset=True):
         """impg_gpu_index_hop_profile: array [shards][8 hops][12 fields] (HOP_PROFILE_FIELDS), zeros for a plain index."""

@@ -347,6 +347,56 @@ int impg_gpu_query_batch_stats_dev(impg_gpu_index_t *, const impg_gpu_range_t *d
                                    const impg_gpu_params_t *params, uint64_t *per_range_count,
                                    uint64_t *per_range_checksum, impg_gpu_stats_t *stats);
 
+/* ---- rows left in HBM ------------------------------------------------------------------------------------
+ * The same queries with every result row left ON THE DEVICE, complete and attributable, for a consumer that lives
+ * there too (the BED merges of this library are one; a caller's own kernels another): no row crosses PCIe, no
+ * per-range statistics are folded.  What the reference's sequential phase pushes per hit -- the AdjustedInterval with
+ * the frontier range's target as its target metadata (impg.rs:2491-2503, :1920-1923) -- is here one slot of a PART:
+ * the hits of one BFS level (level 0 = the hits of the ranges themselves; a plain query has only that) of one chunk of
+ * the batch, as device arrays of n_slots entries
+ *     query_id[k]   the hit's query sequence; 0xFFFFFFFF = the projection returned None (impg.rs:2874-2877), or the
+ *                   subset filter dropped the hit: not a row
+ *     coords[4k..]  q_first, q_last, t_first, t_last (q_first > q_last: reverse strand)
+ *     source[k]     index into frontier[]: the frontier record the hit was found with
+ *     frontier[j]   {target_id, start, end, range_idx}: the row's target sequence (the target interval's metadata) and
+ *                   the range of the batch it belongs to, as ranges[first_range + range_idx]
+ * i.e. SURVEY-style 24 bytes per slot (query_id, four coordinates, source) with range_idx and target_id one
+ * look-up away.  Slot order within a part is unspecified (IMPG_ROWS_ATTRIBUTED): the final level is written entry by
+ * entry, which is what makes it fast; a caller that needs the reference's emission order asks impg_gpu_query_batch /
+ * _stream for it.  Transitive rows shorter than min_output_length (impg.rs:2482-2504) are NOT removed from the
+ * slots: compare |q_last - q_first| as the reference does.  The self interval of a range is the range itself
+ * (impg.rs:1864-1880, :2345-2363) and is not stored.
+ * Takes Impg::query and query_transitive_bfs on a single-GPU CIGAR or tracepoint index (IMPG_E_UNSUPPORTED: DFS,
+ * MultiImpg worklists, store_cigar, sharded handles).  ranges_on_device != 0: `ranges` is a device pointer.
+ * The handle holds one of the index's engines (max 4) and its HBM until impg_gpu_device_rows_free. */
+typedef struct impg_gpu_device_rows impg_gpu_device_rows_t;
+#define IMPG_ROWS_ATTRIBUTED 0
+typedef struct {
+  uint32_t target_id;
+  int32_t start, end;
+  uint32_t range_idx; /* relative to the part's first_range */
+} impg_gpu_frontier_t;
+typedef struct {
+  size_t first_range, n_ranges; /* the chunk of the batch the part belongs to (chunks: "chunk_ranges" / "pair_budget") */
+  uint32_t level;               /* BFS level of the part's hits */
+  uint32_t n_frontier;
+  uint64_t n_slots;
+  const uint32_t *query_id;     /* [n_slots]      device */
+  const int32_t *coords;        /* [4 * n_slots]  device, 16-byte aligned */
+  const uint32_t *source;       /* [n_slots]      device */
+  const impg_gpu_frontier_t *frontier; /* [n_frontier] device */
+} impg_gpu_device_part_t;
+int impg_gpu_query_batch_device(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n, int ranges_on_device,
+                                const impg_gpu_params_t *params, int layout, impg_gpu_device_rows_t **out);
+size_t impg_gpu_device_rows_num_parts(const impg_gpu_device_rows_t *);
+int impg_gpu_device_rows_part(const impg_gpu_device_rows_t *, size_t k, impg_gpu_device_part_t *out);
+/* projections, candidate pairs and per-stage times of the call (impg_gpu_stats_t as above) */
+void impg_gpu_device_rows_stats(const impg_gpu_device_rows_t *, impg_gpu_stats_t *stats);
+/* Verification: the per-range counts and order-independent checksums of impg_gpu_query_batch_stats, recomputed FROM
+ * THE ROWS the call left in HBM (every slot attributed through source[] / frontier[]); either may be NULL. */
+int impg_gpu_device_rows_check(impg_gpu_device_rows_t *, uint64_t *per_range_count, uint64_t *per_range_checksum);
+void impg_gpu_device_rows_free(impg_gpu_device_rows_t *);
+
 /* ---- BED: merge_adjusted_intervals_gap_2d + merge_query_adjusted_intervals +
  *      output_results_bed (main.rs:12858-13011, :12474-12560, :11849-11892) ---- */
 /* In-place merge of one range's results as output_results_bed does for BED

@@ -112,26 +112,37 @@ def big_batch(full):
 
 
 def test_headline_timed_form(full, big_batch):
-    """The form bench.py times -- query_batch_stats(counts=False, checksums=False) on the 100 000 ranges as ONE chunk under a
-    pair budget of 3 x 2^30, whose final level is the fused, entry-ordered one with no per-range output at all -- gives
-    the projections the counting form gives (whose per-range counts and checksums the oracle sample and the prefix test
-    pin), and that number is the constant bench.py's self check asserts inside the timed region."""
+    """The form bench.py times -- impg_gpu_query_batch_device on the 100 000 ranges as ONE chunk under a pair budget of
+    3 x 2^30: every result row left in HBM, 24 bytes a slot, the final level fused and written entry by entry with each
+    slot naming its frontier record -- gives the projections the counting form gives, and the rows it leaves ARE the
+    counting form's rows: per-range counts and order-independent checksums recomputed from the slots in HBM
+    (impg_gpu_device_rows_check) equal the counting form's for all 100 000 ranges (whose values the oracle sample and the
+    prefix test pin).  Their totals are the two constants bench.py's self check asserts around the timed region.  The
+    count-only form (rounds 1-5's timed form: no per-range output at all) must agree too."""
     import bench
     paf, g, ranges = full
     p = impg_amd.make_params(transitive=True, max_depth=3)
     g.set_option("chunk_ranges", 100_000)
     g.set_option("pair_budget", 3 << 30)
     try:
+        dr = g.query_batch_device(big_batch, p)
+        parts = dr.parts()
+        cnt_rows, ck_rows = dr.check()
+        proj_rows = dr.projected
+        dr.free()
         st_timed, _, _ = g.query_batch_stats(big_batch, p, counts=False, checksums=False)
         st_again, _, _ = g.query_batch_stats(big_batch, p, counts=False, checksums=False)
         st_cnt, cnt, ck = g.query_batch_stats(big_batch, p)
     finally:
         g.set_option("pair_budget", 1 << 29)
         g.set_option("chunk_ranges", 4096)
-    assert st_timed.levels == 3
-    assert st_timed.projected == st_again.projected == st_cnt.projected == int(cnt.sum())
+    assert st_timed.levels == 3 and [int(d.level) for d in parts] == [0, 1, 2]
+    assert st_timed.projected == st_again.projected == st_cnt.projected == int(cnt.sum()) == proj_rows
     assert st_timed.projected == bench.HEADLINE_PROJECTED
-    assert st_timed.pairs == st_cnt.pairs and st_timed.frontier_ranges == st_cnt.frontier_ranges
+    assert st_timed.pairs == st_cnt.pairs == sum(int(d.n_slots) for d in parts) and st_timed.frontier_ranges == st_cnt.frontier_ranges
+    assert (cnt_rows == cnt).all() and (ck_rows == ck).all()
+    with np.errstate(over="ignore"):
+        assert int(ck_rows.sum(dtype=np.uint64)) == bench.HEADLINE_CHECKSUM
 
 
 def test_headline_ordered_rows_and_bed_vs_oracle(full, oracle_ix):

@@ -1148,6 +1148,65 @@ def test_device_bed_merge_chains_and_worst_case(tmp_path):
         _bed_three_ways(g, c, ranges, None, d, consider_strandness=True)
 
 
+def _device_rows_by_range(dr, n_ranges, min_output_length=None):
+    """The slots impg_gpu_query_batch_device left in HBM, attributed through source[] / frontier[]: per range of the batch
+    the list of (query_id, q_first, q_last, target_id, t_first, t_last) rows, in no particular order."""
+    rows = [[] for _ in range(n_ranges)]
+    for k in range(len(dr.parts())):
+        first, level, qid, co, src, fr = dr.part_to_host(k)
+        live = qid != np.uint32(0xFFFFFFFF)
+        if min_output_length is not None:
+            live &= np.abs(co[:, 1].astype(np.int64) - co[:, 0]) >= min_output_length
+        assert (src < len(fr)).all()
+        f = fr[src[live]]
+        for q, r, tg in zip((first + f["range_idx"]).tolist(), np.column_stack([qid[live], co[live]]).tolist(), f["target_id"].tolist()):
+            rows[q].append((r[0], r[1], r[2], tg, r[3], r[4]))
+    return rows
+
+
+def test_device_rows_attributed(tmp_path):
+    """impg_gpu_query_batch_device: every row left in HBM belongs to a range of the batch and carries its target -- the
+    multiset of a range's rows equals the oracle's (impg.rs:2491-2503 pushes exactly these), whichever kernels lay the final
+    level out (fused entry by entry or listed), and the counts / checksums recomputed from those rows equal the counting
+    form's.  The emission ORDER is not part of this layout (IMPG_ROWS_ATTRIBUTED)."""
+    from tests.test_gpu_fullsize import checksum
+    for seed, kwp in [(311, dict(n_seq=6, seq_len=20000, weird=True, self_aln=True)), (312, dict(n_seq=60, seq_len=4000, self_aln=True))]:
+        text, names = random_paf(seed, 900, **kwp)
+        g, c = both(tmp_path, text)
+        ranges = random_ranges(seed + 1, 200, kwp["n_seq"], kwp["seq_len"], max_len=kwp["seq_len"] // 5, min_len=40)
+        for kw in [dict(), dict(transitive=True, max_depth=1, min_transitive_len=20),
+                   dict(transitive=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=0),
+                   dict(transitive=True, max_depth=0, min_transitive_len=30, min_output_length=60),
+                   dict(transitive=True, max_depth=3, min_identity=0.7)]:
+            p = impg_amd.make_params(**kw)
+            want, n_proj = [], 0
+            for (t, s, e) in ranges:
+                want.append(c.query(t, s, e, **kw))
+                n_proj += c.last_projection_count()  # (every Some(..), rows below min_output_length included: impg.rs:2482-2504)
+            for lm, fuse, chunk in [(1, 1, 0), (1, 0, 0), (4096, 1, 0), (1, 1, 37)]:
+                g.set_option("locality_min", lm)
+                g.set_option("fuse_final_level", fuse)
+                g.set_option("chunk_ranges", chunk)
+                dr = g.query_batch_device(ranges, p)
+                st, cnt, ck = g.query_batch_stats(ranges, p)
+                assert dr.projected == st.projected == n_proj
+                cnt2, ck2 = dr.check()
+                assert (cnt2 == cnt).all() and (ck2 == ck).all(), (seed, kw, lm, fuse, chunk)
+                got = _device_rows_by_range(dr, len(ranges), kw.get("min_output_length") if kw.get("transitive") else None)
+                for i in range(len(ranges)):
+                    assert sorted(got[i]) == sorted(tuple(int(x) for x in r) for r in want[i][1:].tolist()), (seed, kw, lm, fuse, chunk, i)
+                    assert int(ck2[i]) == checksum(want[i][1:])
+                dr.free()
+            g.set_option("chunk_ranges", 0)
+            g.set_option("locality_min", 4096)
+            g.set_option("fuse_final_level", 1)
+        # what the layout does not take is refused, not answered some other way
+        for kw in [dict(transitive=True, dfs=True), dict(store_cigar=True), dict(transitive=True, multi_impg=True)]:
+            with pytest.raises(impg_amd.ImpgGpuError) as e:
+                g.query_batch_device(ranges[:4], impg_amd.make_params(**kw))
+            assert e.value.code == impg_amd.IMPG_E_UNSUPPORTED
+
+
 def test_counting_runs_with_slots_in_projection_order(tmp_path):
     """A counting run (nothing kept) under the lookup order lays its hit slots out in projection order, not the
     reference's: per-range counts and checksums must equal those of the full results -- which keep the

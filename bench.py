@@ -486,9 +486,52 @@ def rows_form_legs(index, ranges, params, args, d_ranges, step_count, sync, self
     out["ms_per_step_count_only"] = dtc * 1e3 / max(1, args.steps)
     out["count_only_stage_ms"] = {"lookup": sum(s.ms_lookup for s in sts) / max(1, args.steps), "project": sum(s.ms_project for s in sts) / max(1, args.steps),
                                   "update": sum(s.ms_update for s in sts) / max(1, args.steps)}
+    if wl == "headline":
+        # rows grouped by range in the reference's emission order, left in HBM (IMPG_ROWS_ORDERED): engine + row placement, no D2H
+        import impg_amd
+        def step_ordered(layout):
+            do = index.query_batch_device(None, params, device_ptr=d_ranges.data_ptr(), n=args.ranges, layout=layout)
+            st, pm, rows = do.stats, do.place_ms, sum(int(d.n_slots) for d in do.parts())
+            do.free()
+            return st, pm, rows
+
+        def ordered_leg(layout, steps, what):
+            for _ in range(max(1, args.warmup)):
+                step_ordered(layout)
+            sync()
+            t0 = time.perf_counter()
+            so = [step_ordered(layout) for _ in range(steps)]
+            sync()
+            dto = time.perf_counter() - t0
+            po = sum(s[0].projected for s in so)
+            return po, steps, {"value": po / dto if dto > 0 else None, "ms_per_step": dto * 1e3 / max(1, steps),
+                               "rows_per_step": so[-1][2], "engine_ms": sum(s[0].ms_total for s in so) / max(1, steps),
+                               "placement_ms": sum(s[1] for s in so) / max(1, steps),
+                               "stage_ms": {"lookup": sum(s[0].ms_lookup for s in so) / max(1, steps),
+                                            "project": sum(s[0].ms_project for s in so) / max(1, steps),
+                                            "update": sum(s[0].ms_update for s in so) / max(1, steps)}, "what": what}
+        po, ks, leg = ordered_leg(impg_amd._lib.ROWS_ORDERED_SLOTS, args.steps,
+                                  "impg_gpu_query_batch_device(IMPG_ROWS_ORDERED_SLOTS): the batch's rows grouped by range in the reference's emission "
+                                  "order (self interval, then level by level in frontier order x visit order), 24 B each, every slot at its place -- a "
+                                  "None projection is a hole row (query_id 0xFFFFFFFF) -- and per-range offsets, in HBM; the final level's kernel "
+                                  "writes its rows itself where they belong; wall time per step, no D2H")
+        out["value_ordered_rows_device"] = leg["value"]
+        out["ms_per_step_ordered_rows_device"] = leg["ms_per_step"]
+        out["ordered_rows_device"] = leg
+        pc_per = pc / max(1, args.steps)
+        if po / max(1, ks) != pc_per:
+            self_check["status"] = "FAILED: the ordered rows' projections differ from the count-only form's"
+        log("tiers: ordered rows in HBM (slots) %.2f ms/step (engine %.2f, of which placement %.2f)" % (leg["ms_per_step"], leg["engine_ms"], leg["placement_ms"]))
+        if not args.no_extras:
+            po2, ks2, leg2 = ordered_leg(impg_amd._lib.ROWS_ORDERED, 1,
+                                         "impg_gpu_query_batch_device(IMPG_ROWS_ORDERED): the same rows with the holes closed (what impg_gpu_query_batch "
+                                         "returns, left in HBM): every level kept and listed, rows placed by rows_device.hip's scans and scatters")
+            out["ordered_rows_device_compact"] = leg2
+            if po2 / max(1, ks2) != pc_per:
+                self_check["status"] = "FAILED: the compact ordered rows' projections differ from the count-only form's"
     out["tiers_note"] = ("value = rows left in HBM, attributable (the timed form); value_count_only = the same batch with nothing but the "
-                         "projection count kept (rounds 1-5's timed form); full_results.stream = the same rows in the reference's emission "
-                         "order delivered to the host (PCIe-bound)")
+                         "projection count kept (rounds 1-5's timed form); value_ordered_rows_device = the same rows grouped by range in the "
+                         "reference's emission order, left in HBM; full_results.stream = those delivered to the host (PCIe-bound)")
     log("tiers: rows in HBM %.2f ms/step, count only %.2f ms/step" % (dt_rows * 1e3 / max(1, args.steps), out["ms_per_step_count_only"]))
     return out
 

@@ -61,6 +61,7 @@ EngineLease::~EngineLease() {
   e->subset_on = false;
   e->on_kernels_done = nullptr;  // (the row stream's hook captures its caller's locals: never past the lease)
   e->keep_any_order = false;
+  e->ordered_rows = false;
   std::lock_guard<std::mutex> lk(ix.eng_m);
   ix.eng_free.push_back(e);
   ix.eng_cv.notify_one();
@@ -943,9 +944,11 @@ struct impg_gpu_device_rows {
   std::unique_ptr<impg::EngineLease> lease;
   struct Chunk {
     size_t first = 0, n = 0;
-    std::vector<std::unique_ptr<impg::LevelBufs>> levels;
+    std::vector<std::unique_ptr<impg::LevelBufs>> levels;  // IMPG_ROWS_ATTRIBUTED
+    impg::DevBuf rows, offsets;                            // IMPG_ROWS_ORDERED: impg_gpu_interval_t[n_rows], u32 [n + 1]
+    uint64_t n_rows = 0;
   };
-  std::vector<Chunk> chunks;
+  std::vector<std::unique_ptr<Chunk>> chunks;  // (a chunk owns device buffers: not movable)
   struct Part { size_t chunk; size_t level; };
   std::vector<Part> parts;
   impg_gpu_index *ix = nullptr;
@@ -953,13 +956,14 @@ struct impg_gpu_device_rows {
   size_t n = 0;
   int layout = 0;
   impg_gpu_stats_t stats{};
+  float ms_place = 0;  // ordered layout: HIP-event time of the row placement
 };
 
 int impg_gpu_query_batch_device(impg_gpu_index_t *ix, const impg_gpu_range_t *ranges, size_t n, int ranges_on_device,
                                 const impg_gpu_params_t *params, int layout, impg_gpu_device_rows_t **out) {
   IMPG_TRY
   if (!ix || !params || !out || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
-  if (layout != IMPG_ROWS_ATTRIBUTED) throw Error{IMPG_E_INVALID, "unknown row layout"};
+  if (layout != IMPG_ROWS_ATTRIBUTED && layout != IMPG_ROWS_ORDERED && layout != IMPG_ROWS_ORDERED_SLOTS) throw Error{IMPG_E_INVALID, "unknown row layout"};
   if (n >= (1ull << 31)) throw Error{IMPG_E_UNSUPPORTED, "more than 2^31 ranges in one batch"};
   if (!ranges_on_device) check_ranges(ranges, n);
   Engine::check_params(*params);
@@ -987,22 +991,54 @@ int impg_gpu_query_batch_device(impg_gpu_index_t *ix, const impg_gpu_range_t *ra
   impg_gpu_stats_t tot;
   memset(&tot, 0, sizeof tot);
   for_chunks(E, n, [&](size_t b, size_t e) {
-    impg_gpu_device_rows::Chunk c;
+    auto cp = std::make_unique<impg_gpu_device_rows::Chunk>();
+    impg_gpu_device_rows::Chunk &c = *cp;
     c.first = b; c.n = e - b;
     impg_gpu_stats_t st;
-    E.keep_any_order = true;  // a slot names its frontier record (pair_range): the final level may be fused like a counting run's
+    DevBuf self_dev;
+    self_dev.pool = &E.level_pool;
+    // attributed: a slot names its frontier record (pair_range), so the final level may be fused like a counting run's;
+    // ordered: every level's slots are runs in visit order, placed below
+    E.keep_any_order = layout == IMPG_ROWS_ATTRIBUTED;
+    E.ordered_rows = layout == IMPG_ROWS_ORDERED_SLOTS;  // rows placed slot by slot, the fused final level's by its own kernel
     try {
-      E.run(*ix, d_ranges + b, (uint32_t)(e - b), *params, &c.levels, nullptr, nullptr, &st, nullptr);
-    } catch (...) { E.keep_any_order = false; throw; }
-    E.keep_any_order = false;
+      E.run(*ix, d_ranges + b, (uint32_t)(e - b), *params, &c.levels, nullptr, nullptr, &st, layout != IMPG_ROWS_ATTRIBUTED ? &self_dev : nullptr);
+    } catch (...) { E.keep_any_order = E.ordered_rows = false; throw; }
+    E.keep_any_order = E.ordered_rows = false;
+    if (layout == IMPG_ROWS_ORDERED_SLOTS) {
+      c.rows.adopt(E.ord_rows);
+      c.offsets.adopt(E.ord_offsets);
+      c.n_rows = E.ord_total;
+      h->ms_place += E.ms_place;
+      c.levels.clear();
+    }
+    if (layout == IMPG_ROWS_ORDERED) {  // the trait's rows (rows_device.hip), left where they are built
+      hipEvent_t r0 = E.event(), r1 = E.event();
+      IMPG_HIP(hipEventRecord(r0, E.stream));
+      RowPlan pl;
+      plan_rows(E, (uint32_t)(e - b), *params, c.levels, self_dev, false, pl);
+      c.rows.pool = &E.level_pool;
+      c.rows.reserve(std::max<size_t>((size_t)pl.n_rows * sizeof(impg_gpu_interval_t), 256));
+      scatter_rows(E, c.levels, pl, RowSinks{c.rows.as<impg_gpu_interval_t>(), nullptr, nullptr, nullptr, nullptr, nullptr});
+      IMPG_HIP(hipEventRecord(r1, E.stream));
+      IMPG_HIP(hipStreamSynchronize(E.stream));
+      float ms = 0;
+      IMPG_HIP(hipEventElapsedTime(&ms, r0, r1));
+      h->ms_place += ms;
+      c.offsets.adopt(pl.offsets);
+      c.n_rows = pl.n_rows;
+      c.levels.clear();
+    }
     tot.projected += st.projected; tot.pairs += st.pairs; tot.frontier_ranges += st.frontier_ranges;
     tot.levels = std::max(tot.levels, st.levels);
     tot.ms_total += st.ms_total; tot.ms_lookup += st.ms_lookup; tot.ms_project += st.ms_project; tot.ms_update += st.ms_update;
     tot.project_launches += st.project_launches;
-    h->chunks.push_back(std::move(c));
+    h->chunks.push_back(std::move(cp));
   });
-  for (size_t c = 0; c < h->chunks.size(); c++)
-    for (size_t l = 0; l < h->chunks[c].levels.size(); l++) h->parts.push_back({c, l});
+  for (size_t c = 0; c < h->chunks.size(); c++) {
+    if (layout != IMPG_ROWS_ATTRIBUTED) h->parts.push_back({c, 0});
+    else for (size_t l = 0; l < h->chunks[c]->levels.size(); l++) h->parts.push_back({c, l});
+  }
   h->stats = tot;
   *out = h.release();
   return IMPG_OK;
@@ -1013,11 +1049,18 @@ size_t impg_gpu_device_rows_num_parts(const impg_gpu_device_rows_t *h) { return 
 int impg_gpu_device_rows_part(const impg_gpu_device_rows_t *h, size_t k, impg_gpu_device_part_t *out) {
   IMPG_TRY
   if (!h || !out || k >= h->parts.size()) throw Error{IMPG_E_INVALID, "no such part"};
-  const auto &c = h->chunks[h->parts[k].chunk];
-  const LevelBufs &L = *c.levels[h->parts[k].level];
+  const auto &c = *h->chunks[h->parts[k].chunk];
   memset(out, 0, sizeof *out);
   out->first_range = c.first;
   out->n_ranges = c.n;
+  if (h->layout != IMPG_ROWS_ATTRIBUTED) {
+    out->n_slots = c.n_rows;
+    if (h->layout == IMPG_ROWS_ORDERED_SLOTS) out->rows32 = c.rows.as<impg_gpu_row32_t>();
+    else out->rows = c.rows.as<impg_gpu_interval_t>();
+    out->offsets = c.offsets.as<uint32_t>();
+    return IMPG_OK;
+  }
+  const LevelBufs &L = *c.levels[h->parts[k].level];
   out->level = (uint32_t)h->parts[k].level;
   out->n_slots = L.n_pairs;
   out->n_frontier = L.n_frontier;
@@ -1031,10 +1074,12 @@ int impg_gpu_device_rows_part(const impg_gpu_device_rows_t *h, size_t k, impg_gp
 void impg_gpu_device_rows_stats(const impg_gpu_device_rows_t *h, impg_gpu_stats_t *stats) {
   if (h && stats) *stats = h->stats;
 }
+float impg_gpu_device_rows_place_ms(const impg_gpu_device_rows_t *h) { return h ? h->ms_place : 0.f; }
 // the per-range counts and checksums of impg_gpu_query_batch_stats, recomputed from the rows the call left in HBM
 int impg_gpu_device_rows_check(impg_gpu_device_rows_t *h, uint64_t *per_range_count, uint64_t *per_range_checksum) {
   IMPG_TRY
   if (!h) throw Error{IMPG_E_INVALID, "null argument"};
+  if (h->layout != IMPG_ROWS_ATTRIBUTED) throw Error{IMPG_E_UNSUPPORTED, "impg_gpu_device_rows_check reads the attributed layout (ordered rows: compare them with impg_gpu_query_batch's)"};
   Engine &E = **h->lease;
   IMPG_HIP(hipSetDevice(h->ix->device));
   const size_t n = h->n;
@@ -1042,8 +1087,9 @@ int impg_gpu_device_rows_check(impg_gpu_device_rows_t *h, uint64_t *per_range_co
   E.stat_cksum.reserve(std::max<size_t>(n * 8, 256));
   IMPG_HIP(hipMemsetAsync(E.stat_count.p, 0, std::max<size_t>(n * 8, 8), E.stream));
   IMPG_HIP(hipMemsetAsync(E.stat_cksum.p, 0, std::max<size_t>(n * 8, 8), E.stream));
-  for (auto &c : h->chunks)
-    for (auto &Lp : c.levels) {
+  for (auto &cp : h->chunks)
+    for (auto &Lp : cp->levels) {
+      auto &c = *cp;
       LevelBufs &L = *Lp;
       if (!L.n_pairs) continue;
       HitArrays ha{L.qid.as<uint32_t>(), L.coords.as<int4>()};

@@ -27,6 +27,7 @@ inline unsigned bits_for(uint64_t n) {  // bits needed to represent values < n
 Engine::Engine(int device) {
   IMPG_HIP(hipSetDevice(device));
   IMPG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  for (DevBuf *b : {&ord_offsets, &ord_rows}) b->pool = &level_pool;  // (handed over to the caller's result)
   win_se.pool = &level_pool;  // (handed over to a kept fused level as its frontier: a pooled block like the level's others)
   counters.reserve(128);  // (words 0..7: the counters of a run; 8..11: the list lengths and work counters of the update)
   acc_slots.reserve(COUNT_BYTES);
@@ -410,17 +411,29 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   last_by_place = by_place;
   last_range_places = false;
   expand_n_fr = n_fr;
-  const bool fused = by_place && fuse_final && emit_by_lanes(v) && !v.tp_mode;
+  bool fused = by_place && fuse_final && emit_by_lanes(v) && !v.tp_mode;
   if (by_place) win_se.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
+  const bool ordered = ordered_rows && !raw;
+  if (ordered) { L.slot_ref.reserve(std::max<size_t>((size_t)n_fr * 4, 256)); ord_cnt.reserve(std::max<size_t>((size_t)n_fr * 4, 256)); }
   launch_lookup_count(v, fr, n_fr, transitive, d_perm, cnt.as<uint32_t>(), win.as<uint4>(), wide_n.as<uint32_t>(),
-                      wide_list.as<uint32_t>(), stream, by_place, by_place ? win_se.as<FrontierRec>() : nullptr);
+                      wide_list.as<uint32_t>(), stream, by_place, by_place ? win_se.as<FrontierRec>() : nullptr,
+                      ordered && by_place ? ord_cnt.as<uint32_t>() : nullptr);
   uint64_t P = scan(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), n_fr);
   if (P > pair_budget || P >= 0xFFFFFFF0ull) {
     if (split_ok) throw SplitBatch{};
     if (P >= 0xFFFFFFF0ull) throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 candidate pairs for a single range"};
   }
   L.n_pairs = (uint32_t)P;
-  L.pair_range.reserve(std::max<size_t>(P * 4, 256));
+  L.n_frontier = n_fr;
+  bool direct = false;
+  if (ordered) {
+    ordered_level(fr, n_fr, L, !by_place, P);
+    // the fused final level writes its rows itself where the entry-ordered kernel runs it (a dense level); any other level
+    // keeps its slots, listed in visit order, and is placed when the walk is over (ordered_finish)
+    direct = fused && !store_cigar && project_entry_major(v, P, min_identity);
+    if (!direct) fused = false;
+  }
+  L.pair_range.reserve(std::max<size_t>(P * 4, 256));  // (a direct level: only the wave-per-range emit of wide windows writes it)
   pair_entry.reserve(std::max<size_t>(P * 4, 256));
   ProjList pl{nullptr, nullptr, nullptr};
   WindowLists wlists{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u, 0u};
@@ -433,8 +446,21 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
     launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                        pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true, true);
     wlists = WindowLists{tile_first.as<uint32_t>(), pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<FrontierRec>(), d_perm, n_fr,
-                         fuse_need_ranges ? L.pair_range.as<uint32_t>() : nullptr, 1u, fuse_range_places ? 1u : 0u};
-    last_range_places = fuse_need_ranges && fuse_range_places;
+                         fuse_need_ranges && !direct ? L.pair_range.as<uint32_t>() : nullptr, getenv("IMPG_ENT_NONCOMPACT") ? 3u : 1u, fuse_range_places ? 1u : 0u};
+    last_range_places = fuse_need_ranges && fuse_range_places && !direct;
+    if (direct) {
+      // every level is counted: the ranges' first rows, then this level's rows straight from the projection kernel --
+      // a slot's place in its record's run is the hit's visit position, one byte a pair from the lookup (emit_vpos)
+      ordered_offsets();
+      ord_dest.reserve(std::max<size_t>((size_t)n_fr * 4, 256));
+      launch_ord_dest_by_place(win_se.as<FrontierRec>(), d_perm, n_fr, L.slot_ref.as<uint32_t>(), ord_offsets.as<uint32_t>(), L.lvbase.as<uint32_t>(),
+                               ord_dest.as<uint32_t>(), stream);
+      ord_vpos.reserve(std::max<size_t>(P + 256, 256));
+      launch_emit_vpos(v, n_fr, pair_off.as<uint32_t>(), win.as<uint4>(), ord_vpos.as<uint8_t>(), stream);
+      wlists.ord = OrderedOut{ord_rows.as<impg_gpu_row32_t>(), ord_dest.as<uint32_t>(), ord_vpos.as<uint8_t>(), ord_min_len, ord_depth};
+      L.level = ord_depth;
+      L.placed = true;
+    }
   } else if (by_place) {
     launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                        pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true);
@@ -450,7 +476,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
                        wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream);
   }
   IMPG_HIP(hipEventRecord(e1, stream));
-  HitArrays h = hit_arrays(L, L.n_pairs);
+  HitArrays h = direct ? HitArrays{nullptr, nullptr} : hit_arrays(L, L.n_pairs);
   SliceArrays sl{nullptr, nullptr, nullptr, nullptr};
   if (store_cigar) {
     size_t b = std::max<size_t>((size_t)L.n_pairs * 4, 256);
@@ -460,7 +486,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   launch_project(v, fr, L.pair_range.as<uint32_t>(), pair_entry.as<uint32_t>(), L.n_pairs, transitive, h,
                  acc_slots.as<unsigned long long>(), (uint32_t *)(counters.as<uint64_t>() + 2), min_identity,
                  store_cigar ? &sl : nullptr, pl, stream, nullptr, regroup_pairs, by_place ? &wlists : nullptr);
-  if (!raw) {
+  if (!raw && !direct) {
     post_expand(fr, n_fr, L, pair_off.as<uint32_t>(), pair_entry.as<uint32_t>(), v.mrank, sl);
     h = HitArrays{L.qid.as<uint32_t>(), L.coords.as<int4>()};
     if (store_cigar) sl = SliceArrays{L.sl_a.as<uint32_t>(), L.sl_n.as<uint32_t>(), L.sl_off.as<int32_t>(), L.sl_rem.as<int32_t>()};
@@ -514,6 +540,46 @@ void Engine::post_expand(const FrontierRec *fr, uint32_t n_fr, LevelBufs &L, con
     if (tie_idx == pair_entry.as<uint32_t>()) pair_entry.swap(m_pe);
     if (sl.a) { L.sl_a.swap(m_sa); L.sl_n.swap(m_sn); L.sl_off.swap(m_so); L.sl_rem.swap(m_sr); }
   }
+}
+
+// ---- ordered rows placed by slot (kernels.hip "Ordered rows placed slot by slot") ----------------------------------------
+// after a level's count pass: the records' slot counts in frontier order (the count pass scattered them there, or `cnt`
+// itself when the lookup ran in frontier order) -> their exclusive scan; the queries' level bases; acc += the level's slots
+void Engine::ordered_level(const FrontierRec *fr, uint32_t n_fr, LevelBufs &L, bool counts_by_range, uint64_t P) {
+  const uint64_t total = scan(counts_by_range ? cnt.as<uint32_t>() : ord_cnt.as<uint32_t>(), L.slot_ref.as<uint32_t>(), n_fr);
+  if (total != P) throw Error{IMPG_E_INVALID, "internal: a level's slot counts disagree between its two orders"};
+  L.lvbase.reserve(std::max<size_t>((size_t)ord_n * 4, 256));
+  L.level = ord_depth;
+  launch_ord_level_bases(fr, n_fr, L.slot_ref.as<uint32_t>(), (uint32_t)P, ord_n, ord_acc.as<uint32_t>(), L.lvbase.as<uint32_t>(), stream);
+}
+void Engine::ordered_offsets() {
+  if (ord_offsets_done) return;
+  ord_offsets.reserve(((size_t)ord_n + 1) * 4);
+  ord_total = scan(ord_acc.as<uint32_t>(), ord_offsets.as<uint32_t>(), ord_n + 1u);  // (acc[n] = 0: offsets[n] = the total)
+  if (ord_total >= 0xFFFFFFF0ull) { if (split_ok) throw SplitBatch{}; throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 result rows in one chunk: use smaller chunks (chunk_ranges)"}; }
+  ord_rows.reserve(std::max<size_t>(ord_total * sizeof(impg_gpu_row32_t), 256));
+  ord_offsets_done = true;
+}
+void Engine::ordered_finish(std::vector<std::unique_ptr<LevelBufs>> &levels) {
+  hipEvent_t p0 = event(), p1 = event();
+  IMPG_HIP(hipEventRecord(p0, stream));
+  ordered_offsets();
+  launch_ord_self_rows(ord_self, ord_ranges, ord_n, ord_offsets.as<uint32_t>(), ord_rows.as<impg_gpu_row32_t>(), stream);
+  for (auto &Lp : levels) {
+    LevelBufs &L = *Lp;
+    if (L.placed || !L.n_pairs) continue;
+    L.run_start.reserve(std::max<size_t>((size_t)L.n_frontier * 4, 256));
+    launch_ord_run_heads(L.pair_range.as<uint32_t>(), L.n_pairs, L.run_start.as<uint32_t>(), stream);
+    HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
+    launch_ord_level_rows(L.frontier.as<FrontierRec>(), L.pair_range.as<uint32_t>(), L.n_pairs, h, L.run_start.as<uint32_t>(), L.slot_ref.as<uint32_t>(),
+                          ord_offsets.as<uint32_t>(), L.lvbase.as<uint32_t>(), ord_min_len, L.level, ord_rows.as<impg_gpu_row32_t>(), stream);
+    L.placed = true;
+  }
+  IMPG_HIP(hipEventRecord(p1, stream));
+  IMPG_HIP(hipStreamSynchronize(stream));
+  float ms = 0;
+  IMPG_HIP(hipEventElapsedTime(&ms, p0, p1));
+  ms_place = ms;
 }
 
 HopResult Engine::hop(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n_fr, bool transitive, LevelBufs &L,
@@ -857,6 +923,20 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     self.reserve(std::max<size_t>((size_t)n * sizeof(FrontierRec), 256));
     n_fr = masked ? begin_transitive_masked(v, d_ranges, n, p, self, *cur)
                   : begin_transitive(v, d_ranges, n, p, self.as<FrontierRec>(), *cur);
+    ord_self = self.as<FrontierRec>();
+  }
+  if (ordered_rows) {
+    if (!keep || masked || multi || store_cigar || remote) throw Error{IMPG_E_INVALID, "internal: ordered rows are placed for plain and BFS batches of one GPU"};
+    ord_n = n;
+    ord_ranges = d_ranges;
+    if (!transitive) ord_self = nullptr;
+    ord_min_len = transitive ? p.min_output_length : -1;
+    ord_offsets_done = false;
+    ord_total = 0;
+    ms_place = 0;
+    ord_acc.reserve(((size_t)n + 1) * 4);
+    IMPG_HIP(hipMemsetAsync(ord_acc.p, 0, ((size_t)n + 1) * 4, stream));
+    launch_ord_self_count(ord_self, d_ranges, n, ord_acc.as<uint32_t>(), stream);
   }
 
   uint32_t depth = 0;
@@ -872,7 +952,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     const bool want_stats = d_count || d_cksum;
     // (kept levels too when their reader takes the slots in any order and finds a slot's frontier record through
     // pair_range -- the rows left in HBM, impg_gpu_query_batch_device's attributed layout: keep_any_order)
-    fuse_final = fuse_allowed && last && (!keep || keep_any_order) && !remote;
+    fuse_final = fuse_allowed && last && (!keep || keep_any_order || ordered_rows) && !remote;
     // (per-range counts / checksums of a fused level cost two atomics per hit -- its slots are in entry order, a range's
     // are no run -- which a deep closure's final level, 10^4+ ranges a query, does not earn back: config 5 with counts
     // 2.8 s per 4 000 windows fused, 1.4 s not)
@@ -881,6 +961,8 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     // (a kept fused level names a slot's range by its place in the lookup order -- no load in the kernel -- and keeps its
     // copy of the frontier in that order; the per-range statistics and the subset filter index the frontier itself)
     fuse_range_places = keep != nullptr && !want_stats && !subset_on;
+    if (ordered_rows) fuse_need_ranges = fuse_range_places = false;  // (a fused level of ordered rows writes rows, nothing else)
+    ord_depth = depth;
     const HopResult hr = hop(v, cur->as<FrontierRec>(), alive ? n_fr : 0, transitive, *L, st, keep || want_stats || !last,
                              keep || d_cksum, alive);
     fuse_final = false;
@@ -898,13 +980,15 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
       if (!last) n_next = update(v, cur->as<FrontierRec>(), *L, n, p, *nxt);
       if (keep) {
         // the level keeps its own copy of the frontier (qidx / target per pair)
-        if (!(last_range_places && !remote)) L->frontier.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
-        if (last_range_places && !remote) {
+        if (L->placed) {  // (its rows are written: nobody reads its slots)
+        } else if (last_range_places && !remote) {
           // (pair_range holds places of the lookup order: the level's frontier in that order is what the count pass left
           // beside the windows -- handed over, not copied; win_se allocates anew at the next by-place level)
           L->frontier.adopt(win_se);
-        } else
+        } else {
+          L->frontier.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
           IMPG_HIP(hipMemcpyAsync(L->frontier.p, cur->p, (size_t)n_fr * sizeof(FrontierRec), hipMemcpyDeviceToDevice, stream));
+        }
         keep->push_back(std::move(own));
       }
     }
@@ -913,6 +997,7 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     n_fr = n_next;
     depth += 1;
   }
+  if (ordered_rows) ordered_finish(*keep);
   finish_run(st, t0, t1);
 }
 

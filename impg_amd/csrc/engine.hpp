@@ -15,11 +15,16 @@ struct LevelBufs {  // one BFS level: its frontier and its hit slots
   DevBuf sl_a, sl_n, sl_off, sl_rem, slice_pos, slice_pool;
   uint64_t slice_total = 0;
   uint32_t n_frontier = 0, n_pairs = 0;
+  // ordered rows placed by slot (Engine::ordered_rows): the level's slots per frontier record -- counts, then their exclusive
+  // scan -- in frontier order, and per query where the level's rows start relative to the scan (kernels.hip "Ordered rows")
+  DevBuf slot_ref, lvbase, run_start;
+  uint32_t level = 0;   // the BFS level (ordered rows carry it)
+  bool placed = false;  // its rows are already in the batch's row array (the fused final level writes them itself)
   LevelBufs() = default;
   // the levels a full-results call keeps are new objects at every level of every call: their blocks are recycled
   // through the engine's pool (hipMalloc / hipFree are 0.1-1 ms each and hipFree synchronises the device)
   explicit LevelBufs(BufPool *pool) {
-    for (DevBuf *b : {&frontier, &pair_range, &qid, &coords, &sl_a, &sl_n, &sl_off, &sl_rem, &slice_pos, &slice_pool}) b->pool = pool;
+    for (DevBuf *b : {&frontier, &pair_range, &qid, &coords, &sl_a, &sl_n, &sl_off, &sl_rem, &slice_pos, &slice_pool, &slot_ref, &lvbase, &run_start}) b->pool = pool;
   }
 };
 struct VisitedStore {  // device storage of one VisitedTable
@@ -100,6 +105,22 @@ struct Engine {
   // set by the caller around run(): the kept levels' slots may come in any order, as long as pair_range names every
   // slot's frontier record (a kept final level may then be fused like a counting run's)
   bool keep_any_order = false;
+  // Ordered rows placed by slot (set by the caller around run(), with `keep`): the batch's rows grouped by range in the
+  // reference's emission order, every SLOT at its final place (a None projection stays as a hole row) -- so that where a
+  // row goes follows from the lookups' counts alone and the fused final level can write its rows itself.  After run():
+  // ord_rows[ord_total] (impg_gpu_row32_t), ord_offsets[n + 1].
+  bool ordered_rows = false;
+  DevBuf ord_acc, ord_offsets, ord_rows, ord_dest, ord_vpos, ord_cnt;
+  uint64_t ord_total = 0;
+  bool ord_offsets_done = false;
+  uint32_t ord_n = 0, ord_depth = 0;
+  int32_t ord_min_len = -1;
+  const FrontierRec *ord_self = nullptr;        // transitive: the self intervals (null: the ranges themselves)
+  const impg_gpu_range_t *ord_ranges = nullptr;
+  void ordered_level(const FrontierRec *fr, uint32_t n_fr, LevelBufs &L, bool counts_by_range, uint64_t P);  // after a level's count pass
+  void ordered_offsets();                                                                                   // once every level is counted
+  void ordered_finish(std::vector<std::unique_ptr<LevelBufs>> &levels);                                       // self rows + the levels not yet placed
+  float ms_place = 0;
   DevBuf win_se, tile_first;       // the ranges' (start, end) by place; first range of every projection tile
   int filter_covered = 0;          // option "filter_covered": hits covered by their group's old list dropped before the replay (0 off: it bought nothing on config 5, where hits are covered by the list as it GROWS, not as the level found it; 1 always, 2 long groups)
   uint64_t covered_dropped = 0;    // ... how many that was, over the engine's life (tuning aid)

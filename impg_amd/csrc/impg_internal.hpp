@@ -419,7 +419,7 @@ struct impg_gpu_index {
   // (1-based, counted per lane) at which that rank throws on the owner side / on the home side of the hop
   uint32_t opt_debug_fail_owner = 0, opt_debug_fail_home = 0;
   uint64_t opt_lane_schedule = 0;  // IMPG_LANE_SCHEDULE / option "lane_schedule": see run_lanes (sharded.cpp); 0 = off
-  uint64_t opt_device_rows_pool = 96ull << 30;  // option "device_rows_pool_bytes"
+  uint64_t opt_device_rows_pool = 160ull << 30;  // option "device_rows_pool_bytes"
   bool opt_free_slots = true;
   bool opt_regroup = true;
   bool opt_fuse_final = true;

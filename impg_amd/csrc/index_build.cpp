@@ -68,8 +68,8 @@ void *BufPool::take(size_t bytes, size_t &cap_out) {
     cap_out = b.cap;
     return b.p;
   }
-  // a quarter of slack: the same level of the next chunk is about, not exactly, this size
-  size_t want = (bytes + bytes / 4 + 255) & ~(size_t)255;
+  // a quarter of slack (at most 1 GiB): the same level of the next chunk is about, not exactly, this size
+  size_t want = (bytes + std::min<size_t>(bytes / 4, (size_t)1 << 30) + 255) & ~(size_t)255;
   void *p = nullptr;
   if (hipMalloc(&p, want) != hipSuccess) {
     (void)hipGetLastError();

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView 
                                                                 uint32_t n, const uint32_t *__restrict__ perm,
                                                                 uint32_t *__restrict__ cnt,
                                                                 uint4 *__restrict__ win, uint32_t *__restrict__ wide_n,
-                                                                uint32_t *__restrict__ wide_list, int by_place, FrontierRec *__restrict__ se) {
+                                                                uint32_t *__restrict__ wide_list, int by_place, FrontierRec *__restrict__ se,
+                                                                uint32_t *__restrict__ cnt_ref) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   // perm (optional): neighbouring lanes take ranges that are neighbours in the entry array, so
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView 
     }
   }
   cnt[o] = c;
+  if (cnt_ref) cnt_ref[r] = c;
   win[o] = make_uint4(lo, ub, (uint32_t)mask, (uint32_t)(mask >> 32));
   if (se) se[o] = f;  // (the whole record at the range's place: the projection reads its ends there, a kept level its range and target)
   // windows too wide for the lane-per-range emit pass (dense targets) are listed for the wave-per-range one
@@ -569,6 +571,82 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         pl.entry[place] = lb + rel;
       }
     }
+  }
+}
+
+// K1b'': the visit order WITHOUT the pair lists (ordered rows written by a fused final level, OrderedOut): the same
+// per-lane sorting network, but what leaves the kernel is one byte per hit -- the visit position of a range's k-th hit
+// in index order, at the hit's place pair_off[i] + k -- 1 byte a pair instead of the 8 of pair_range + pair_entry.
+template <uint32_t N, uint32_t W>
+__device__ __forceinline__ void emit_vpos_sort_stage(const uint32_t *__restrict__ rank, uint32_t b, uint32_t lo, uint32_t ub,
+                                                     unsigned long long mask, uint32_t c, uint8_t *out) {
+  uint32_t key[64];
+#pragma unroll
+  for (uint32_t q = 0; q < (W + 3u) / 4u; q++) {
+    uint4 rk = make_uint4(0, 0, 0, 0);
+    if (b + 4u * q < ub) rk = *reinterpret_cast<const uint4 *>(rank + b + 4u * q);
+    const uint32_t rv[4] = {rk.x, rk.y, rk.z, rk.w};
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++) {
+      const uint32_t i = 4u * q + t, pos = b + i;
+      const bool hit = pos >= lo && pos < ub && ((mask >> ((pos - lo) & 63u)) & 1ull);
+      key[i] = hit ? (rv[t] << 6) | i : 0xFFFFFFFFu;
+    }
+    if ((q & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);
+  }
+  emit_sort<N, W>(key);
+  const uint32_t shift = lo - b;  // (window position i = b + i; mask bit = position - lo)
+#pragma unroll
+  for (uint32_t k = 0; k < W; k++) {
+    if (__ballot(k < c) == 0ull) break;
+    if (k < c) {
+      const uint32_t bit = (key[k] & 63u) - shift;
+      out[__popcll(mask & ((1ull << bit) - 1ull))] = (uint8_t)k;
+    }
+  }
+}
+constexpr uint32_t VPOS_LDS = 64u * 64u + 8u;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void emit_vpos_lane_kernel(DeviceIndexView v, uint32_t n,
+                                                              const uint32_t *__restrict__ pair_off, const uint4 *__restrict__ win,
+                                                              uint8_t *__restrict__ vpos) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[VPOS_LDS];
+  const unsigned lane = threadIdx.x;
+  const uint32_t i = blockIdx.x * 64u + lane;
+  uint32_t lo = 0, ub = 0, off = 0;
+  unsigned long long mask = 0;
+  if (i < n) {
+    const uint4 w = win[i];
+    lo = w.x; ub = w.y;
+    mask = ((unsigned long long)w.w << 32) | w.z;
+    off = pair_off[i];
+  }
+  const uint32_t b = lo & ~3u;
+  const bool mine = lo < ub && ub - b <= 64u;  // (wider windows: the wave-per-range emit lists their entries in visit order)
+  if (!mine) { ub = b; mask = 0; }
+  const uint32_t wmax = wave_max_u32(mine ? ub - b : 0u);
+  const uint32_t c = (uint32_t)__popcll(mask);
+  // the wave's places are one contiguous piece of vpos[] starting at lane 0's offset; a lane's run is staged in LDS at the
+  // same distance from there (+ the piece's misalignment, so that whole words line up), or written straight out when a
+  // wide window's run in between pushes it past the buffer
+  const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+  const uint32_t mis = off0 & 3u;
+  const uint32_t rel = off - off0 + mis;
+  const bool in_lds = rel + c <= VPOS_LDS;
+  uint8_t *out = in_lds ? stage + rel : vpos + off;
+  if (wmax <= 32u) emit_vpos_sort_stage<32, 32>(v.rank, b, lo, ub, mask, c, out);
+  else if (wmax <= 40u) emit_vpos_sort_stage<64, 40>(v.rank, b, lo, ub, mask, c, out);
+  else if (wmax <= 48u) emit_vpos_sort_stage<64, 48>(v.rank, b, lo, ub, mask, c, out);
+  else emit_vpos_sort_stage<64, 64>(v.rank, b, lo, ub, mask, c, out);
+  __syncthreads();
+  // copy out: LDS bytes [mis, covered) are the piece's first covered - mis bytes (a wide window's run in between holds
+  // whatever was there: nobody reads those bytes).  Whole aligned words, except where the piece's first / last word is
+  // shared with a neighbouring wave's piece.
+  const uint32_t covered = wave_max_u32(in_lds ? rel + c : 0u);
+  uint8_t *g0 = vpos + (off0 - mis);
+  for (uint32_t d = lane; 4u * d < covered; d += 64u) {
+    const uint32_t lo_b = 4u * d, hi_b = lo_b + 4u;
+    if (lo_b >= mis && hi_b <= covered) *reinterpret_cast<uint32_t *>(g0 + lo_b) = *reinterpret_cast<const uint32_t *>(stage + lo_b);
+    else for (uint32_t j = max(lo_b, mis); j < min(hi_b, covered); j++) g0[j] = stage[j];
   }
 }
 
@@ -1567,6 +1645,17 @@ __device__ __forceinline__ uint32_t select_bit64(uint32_t lo, uint32_t hi, uint3
   return base + (k >= (w & 1u) ? 1u : 0u);
 }
 // One place of the projection order -> its pair.  live: the place holds a pair; p: the pair's slot.
+// a finished row at its final place (OrderedOut): the hit, or a hole (query_id = 0xFFFFFFFF) where the projection returned
+// None or the row is shorter than min_output_length
+__device__ __forceinline__ void put_ordered_row(const OrderedOut &o, uint32_t d, uint32_t qid, uint32_t tid, bool ok, int32_t qs, int32_t qe,
+                                                int32_t ts, int32_t te) {
+  const bool on = ok && !(o.min_output_length >= 0 && abs(qe - qs) < o.min_output_length);
+  // (one aligned 32-byte sector, two 16-byte stores that the L2 merges: a row is a line of its own among 10^9, and a
+  // 24-byte row straddling sectors made every store a read-modify-write of HBM -- 56 ms of projection against 27)
+  uint4 *p = reinterpret_cast<uint4 *>(o.rows) + 2ull * d;
+  p[0] = make_uint4(on ? qid : HIT_NONE, on ? (uint32_t)qs : 0u, on ? (uint32_t)qe : 0u, tid);
+  p[1] = make_uint4(on ? (uint32_t)ts : 0u, on ? (uint32_t)te : 0u, o.level, 0u);
+}
 struct PairIn {
   uint32_t eidx, p;
   int32_t f_start, f_end;
@@ -1776,9 +1865,12 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
                                                    unsigned long long *__restrict__ accepted, uint32_t *__restrict__ err_flag,
                                                    const WindowLists &wl, uint32_t r0, uint32_t P0, uint32_t P1, uint32_t emin, uint32_t n_e,
                                                    bool regroup_all, const uint32_t *st_off, const uint4 *st_win, const int2 *st_se,
-                                                   const uint4 *st_ent, uint4 *st_line PHASE_ARG, double min_identity = 0.0) {
+                                                   const uint4 *st_ent, uint4 *st_line PHASE_ARG, double min_identity = 0.0,
+                                                   const uint32_t *st_dest = nullptr) {
   const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
   uint32_t n_ok = 0;
+  const bool ordered = wl.ord.rows != nullptr;  // (then nothing is regrouped: a lane keeps its place's range, whose row and target it writes)
+  if (ordered) regroup_all = false;
   // the block's places, a turn of NT at a time (pair lists: the next turn's entry is requested a turn ahead)
   uint32_t e_next = 0xFFFFFFFFu;
   if (!MASKS && (unsigned long long)P0 + threadIdx.x < P1) e_next = pair_entry[P0 + threadIdx.x];
@@ -1793,14 +1885,19 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
     uint32_t j = 0;
 #pragma unroll
     for (uint32_t st = NR / 2u; st > 0u; st >>= 1) j += st_off[j + st] <= pp ? st : 0u;
+    uint32_t o_dest = 0, o_tid = 0;
     if (y.live) {
       const int2 se = st_se[j];
       y.f_start = se.x; y.f_end = se.y;
       if (MASKS) {
         const uint4 w = st_win[j];
-        if (w.y - (w.x & ~3u) > 64u) y.eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
+        const bool listed = w.y - (w.x & ~3u) > 64u;
+        if (listed) y.eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
         else y.eidx = w.x + select_bit64(w.z, w.w, pp - st_off[j]);
-        if (wl.range_out) wl.range_out[pp] = wl.range_places ? r0 + j : wl.perm[r0 + j];
+        if (ordered) {  // (a listed window's entries are in visit order already)
+          o_dest = st_dest[j] + (listed ? pp - st_off[j] : (uint32_t)wl.ord.vpos[pp]);
+          o_tid = wl.se[r0 + j].target_id;
+        } else if (wl.range_out) wl.range_out[pp] = wl.range_places ? r0 + j : wl.perm[r0 + j];
       } else {
         y.eidx = e_next;
       }
@@ -1823,8 +1920,11 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
                                              reinterpret_cast<const uint32_t *>(st_line + slot * (STG_REC_STRIDE / 4u)));
       else  // an entry beyond the staged span, or a record with more prefix lines than a staged record holds
         project_pair<TRANSITIVE, MODE>(v, y.eidx, y.f_start, y.f_end, y.p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
-      h.qid[y.p] = qid;
-      if (ok) h.c[y.p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+      if (ordered) put_ordered_row(wl.ord, o_dest, qid, o_tid, ok, res.pqs, res.pqe, res.pts, res.pte);
+      else {
+        h.qid[y.p] = qid;
+        if (ok) h.c[y.p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+      }
       n_ok += ok ? 1u : 0u;
     }
     if (regroup_all) __syncthreads();  // (the next turn's regrouping reuses the scratch)
@@ -2012,7 +2112,7 @@ template <bool TRANSITIVE, int ORIENT, int MODE>
 __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, uint4 e0, uint4 e1, uint4 e2, uint4 e3, uint32_t eidx, bool live,
                                                     int32_t f_start, int32_t f_end, uint32_t p, const uint32_t *rec, const HitArrays &h,
                                                     unsigned long long *__restrict__ accepted, uint32_t *__restrict__ err_flag,
-                                                    uint32_t &n_ok PHASE_ARG, double min_identity) {
+                                                    uint32_t &n_ok PHASE_ARG, double min_identity, const OrderedOut &ord, uint32_t tid) {
   const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
   if (live) {
     bool ok = false;
@@ -2028,8 +2128,11 @@ __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, ui
       project_core<TRANSITIVE, MODE, true, ORIENT>(v, e0, e1, e2, e3, f_start, f_end, p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, rec);
     else  // (a record with more prefix lines than a staged record holds: from the index)
       project_pair<TRANSITIVE, MODE>(v, eidx, f_start, f_end, p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
-    h.qid[p] = qid;
-    if (ok) h.c[p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+    if (ord.rows) put_ordered_row(ord, p, qid, tid, ok, res.pqs, res.pqe, res.pts, res.pte);  // (p = the row's final place)
+    else {
+      h.qid[p] = qid;
+      if (ok) h.c[p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+    }
     n_ok += ok ? 1u : 0u;
   }
 }
@@ -2049,6 +2152,8 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   __shared__ int2 st_se[ENT_RANGES];
   __shared__ uint32_t st_off[ENT_RANGES + 4u];
   __shared__ uint16_t st_wide[ENT_RANGES];
+  __shared__ uint32_t st_dest[ENT_RANGES];  // ordered rows (OrderedOut): the row of every range's first slot
+  const bool ordered = wl.ord.rows != nullptr;
 #if IMPG_ENT_GROUP_SKIP
   __shared__ int2 st_grp[ENT_RANGES / 64u];  // per 64 ranges: the first and the last entry their masks name
 #endif
@@ -2081,6 +2186,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
       const uint4 w = wl.win[r0 + t];
       st_win[t] = w;
       { const FrontierRec sf = wl.se[r0 + t]; st_se[t] = make_int2(sf.start, sf.end); }
+      if (ordered) st_dest[t] = wl.ord.dest[r0 + t];
       if (w.y - (w.x & ~3u) > 64u) st_wide[atomicAdd(&st_nwide, 1u)] = (uint16_t)t;
       else if (w.z | w.w) {
         glo = w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w));
@@ -2120,7 +2226,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   // (place offset + mask bits below the entry's) the lanes of a wave scatter over as many lines as it has lanes, and
   // the store path, not the ALUs, bounded the kernel.  Not when a range of the block is listed instead: its pairs
   // keep their places, so the others do too.
-  const bool compact = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_nwide) == 0u;
+  const bool compact = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_nwide) == 0u && !ordered && !(wl.masks & 2u);  // (masks bit 1: slots by range, an experiment)
   uint32_t n_ok = 0;
   STG_MARK(1);
   // few pairs for the entries they touch (a sparse stretch of the level): fetching a record for a pair or two would read
@@ -2128,7 +2234,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   const bool sparse = emin <= emax && (unsigned long long)(P1 - P0) < 4ull * (emax - emin + 1u);
   if (sparse) {
     n_ok = project_places<TRANSITIVE, true, false, ENT_RANGES, ENT_THREADS, MODE>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
-                                                               st_se, nullptr, st_work PHASE_PASS, min_identity);
+                                                               st_se, nullptr, st_work PHASE_PASS, min_identity, st_dest);
   } else if (emin <= emax) {
     // The waves take the span's entries one by one off an LDS counter (an entry is anything from a handful to 500 pairs:
     // dealt round-robin, a block waited for its unluckiest wave).  Each entry is fetched by its wave alone -- its 64
@@ -2220,6 +2326,9 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
       __builtin_amdgcn_wave_barrier();
       const uint32_t *rec = reinterpret_cast<const uint32_t *>(&st_rec[wv][0]);
       const int orient = (e1.z & OP_LEN_MASK) > INLINE_TILES * TILE_OPS ? -1 : !(e1.z & EF_REVERSED) ? 0 : (e1.z & EF_STRAND) ? 2 : 1;
+      // ordered rows: the target of every row of this entry is the sequence its ranges look up -- the first one's says it
+      uint32_t tid = 0;
+      if (ordered && cnt) tid = wl.se[r0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)st_list[wv][0])].target_id;
 #pragma unroll 1
       for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
         const bool live = k0 + l < cnt;
@@ -2233,11 +2342,13 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
                                          : (uint32_t)__popc(w.z) + (uint32_t)__popc(w.w & ((1u << (d - 32u)) - 1u));
           p = st_off[r] + below;
         }
-        if (live && wl.range_out) wl.range_out[p] = wl.range_places ? r0 + r : wl.perm[r0 + r];
-        if (orient == 0) project_entry_chunk<TRANSITIVE, 0, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
-        else if (orient == 1) project_entry_chunk<TRANSITIVE, 1, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
-        else if (orient == 2) project_entry_chunk<TRANSITIVE, 2, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
-        else project_entry_chunk<TRANSITIVE, -1, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity);
+        if (ordered) {  // the row's final place: the range's first row + the hit's visit position (the byte the lookup left at its place)
+          if (live) p = st_dest[r] + (uint32_t)wl.ord.vpos[p];
+        } else if (live && wl.range_out) wl.range_out[p] = wl.range_places ? r0 + r : wl.perm[r0 + r];
+        if (orient == 0) project_entry_chunk<TRANSITIVE, 0, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
+        else if (orient == 1) project_entry_chunk<TRANSITIVE, 1, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
+        else if (orient == 2) project_entry_chunk<TRANSITIVE, 2, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
+        else project_entry_chunk<TRANSITIVE, -1, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
       }
     }
 #undef IMPG_RDL
@@ -2269,10 +2380,14 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
         res.pqs = res.pts = res.pqe = res.pte = -1;
         uint32_t qid = HIT_NONE;
         project_pair<TRANSITIVE, MODE>(v, pair_entry[pp], se.x, se.y, pp, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
-        h.qid[pp] = qid;
-        if (ok) h.c[pp] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+        if (ordered)  // (a listed window's entries are in visit order: the slot's position in the run is its visit position)
+          put_ordered_row(wl.ord, st_dest[r] + (pp - a), qid, wl.se[r0 + r].target_id, ok, res.pqs, res.pqe, res.pts, res.pte);
+        else {
+          h.qid[pp] = qid;
+          if (ok) h.c[pp] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
+        }
         n_ok += ok ? 1u : 0u;
-        if (wl.range_out) wl.range_out[pp] = wl.range_places ? r0 + r : wl.perm[r0 + r];
+        if (wl.range_out && !ordered) wl.range_out[pp] = wl.range_places ? r0 + r : wl.perm[r0 + r];
       }
     }
   }
@@ -4817,14 +4932,15 @@ static inline uint32_t wave_grid(uint32_t n_items) {  // one wave per item, 4 wa
 }
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
-                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place, FrontierRec *se) {
+                         uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place, FrontierRec *se,
+                         uint32_t *cnt_ref) {
   if (!n) return;
   const bool lanes = emit_by_lanes(v);
   const int bp = by_place && perm ? 1 : 0;
   if (!bp) se = nullptr;
   if (lanes) IMPG_HIP(hipMemsetAsync(wide_n, 0, 4, s));
-  if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp, se);
-  else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp, se);
+  if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp, se, cnt_ref);
+  else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp, se, cnt_ref);
 }
 // tile_first[t] = the range whose places include place t * PROJ_BLOCK (see WindowLists): one thread per range, which
 // names itself at every tile border inside its run of places (a run of <= 64 places crosses at most one)
@@ -4836,6 +4952,105 @@ __global__ __launch_bounds__(256) void tile_first_kernel(const uint32_t *__restr
   if (!c) return;
   const uint32_t first = pair_off[i], last = first + c - 1u;
   for (uint32_t t = (first + PROJ_BLOCK - 1u) / PROJ_BLOCK; t <= last / PROJ_BLOCK; t++) tile_first[t] = i;
+}
+// ---------------------------------------------------------------------------
+// Ordered rows placed slot by slot (Engine::ordered_*, engine.cpp): the batch's rows grouped by range in the reference's
+// emission order -- self interval, then level by level, each level's slots in frontier order x visit order
+// (impg.rs:1864-1925, :2345-2363, :2471-2504) -- with every SLOT at its final place: a slot whose projection returned
+// None (or whose row is shorter than min_output_length) stays as a hole row, query_id = 0xFFFFFFFF, instead of
+// shifting every row behind it.  Where a row goes is then known from the lookups' counts alone, before anything is
+// projected: row(slot k of record r of level l, query q) = offsets[q] + lvbase_l[q] + slot_ref_l[r] + k, with
+//   slot_ref_l = exclusive scan of the level's per-record slot counts in frontier order,
+//   acc[q]     = rows of q so far (self interval, earlier levels),  lvbase_l[q] = acc[q] - slot_ref_l[q's first record],
+//   offsets    = exclusive scan of the final acc.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ord_self_count_kernel(const FrontierRec *__restrict__ self, const impg_gpu_range_t *__restrict__ ranges,
+                                                             uint32_t n, uint32_t *__restrict__ acc) {
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= n) return;
+  acc[q] = self ? (self[q].start < self[q].end ? 1u : 0u) : 1u;  // impg.rs:2345-2363 / :1864-1880
+  (void)ranges;
+}
+__global__ __launch_bounds__(256) void ord_level_bases_kernel(const FrontierRec *__restrict__ fr, uint32_t n_fr, const uint32_t *__restrict__ slot_ref,
+                                                              uint32_t total, uint32_t n_queries, uint32_t *__restrict__ acc,
+                                                              uint32_t *__restrict__ lvbase) {
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= n_queries) return;
+  // the query's records: [first record with qidx >= q, first with qidx >= q + 1) of a frontier sorted by query
+  uint32_t lo = 0, hi = n_fr;
+  while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (fr[m].qidx < q) lo = m + 1u; else hi = m; }
+  const uint32_t a = lo;
+  hi = n_fr;
+  while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (fr[m].qidx <= q) lo = m + 1u; else hi = m; }
+  const uint32_t sa = a < n_fr ? slot_ref[a] : total, sb = lo < n_fr ? slot_ref[lo] : total;
+  const uint32_t at = acc[q];
+  lvbase[q] = at - sa;  // (mod 2^32: row = offsets[q] + lvbase[q] + slot_ref[r] + k)
+  acc[q] = at + (sb - sa);
+}
+__global__ __launch_bounds__(256) void ord_dest_by_place_kernel(const FrontierRec *__restrict__ frp, const uint32_t *__restrict__ perm, uint32_t n_fr,
+                                                                const uint32_t *__restrict__ slot_ref, const uint32_t *__restrict__ offsets,
+                                                                const uint32_t *__restrict__ lvbase, uint32_t *__restrict__ dest) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_fr) return;
+  const uint32_t q = frp[i].qidx;
+  dest[i] = offsets[q] + lvbase[q] + slot_ref[perm[i]];
+}
+__global__ __launch_bounds__(256) void ord_self_rows_kernel(const FrontierRec *__restrict__ self, const impg_gpu_range_t *__restrict__ ranges, uint32_t n,
+                                                            const uint32_t *__restrict__ offsets, impg_gpu_row32_t *__restrict__ rows) {
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= n) return;
+  uint32_t t; int32_t a, b;
+  if (self) { const FrontierRec f = self[q]; if (!(f.start < f.end)) return; t = f.target_id; a = f.start; b = f.end; }
+  else { const impg_gpu_range_t r = ranges[q]; t = r.target_id; a = r.start; b = r.end; }
+  rows[offsets[q]] = impg_gpu_row32_t{t, a, b, t, a, b, 0xFFFFFFFFu, 0u};
+}
+__global__ __launch_bounds__(256) void ord_run_heads_kernel(const uint32_t *__restrict__ pair_range, uint32_t n_pairs, uint32_t *__restrict__ run_start) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n_pairs) return;
+  const uint32_t r = pair_range[p];
+  if (p == 0 || pair_range[p - 1] != r) run_start[r] = p;  // (a record's slots are one run in every layout of a listed level)
+}
+__global__ __launch_bounds__(256) void ord_level_rows_kernel(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
+                                                             HitArrays h, const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ slot_ref,
+                                                             const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ lvbase,
+                                                             int32_t min_output_length, uint32_t level, impg_gpu_row32_t *__restrict__ rows) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n_pairs) return;
+  const uint32_t r = pair_range[p];
+  const FrontierRec f = fr[r];
+  const uint32_t d = offsets[f.qidx] + lvbase[f.qidx] + slot_ref[r] + (p - run_start[r]);
+  const uint32_t qid = h.qid[p];
+  const bool ok = qid != HIT_NONE;
+  int4 c = make_int4(0, 0, 0, 0);
+  if (ok) c = h.c[p];
+  OrderedOut o{rows, nullptr, nullptr, min_output_length, level};
+  put_ordered_row(o, d, qid, f.target_id, ok, c.x, c.y, c.z, c.w);
+}
+void launch_ord_self_count(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, uint32_t *acc, hipStream_t s) {
+  if (n) ord_self_count_kernel<<<cdiv(n, 256), 256, 0, s>>>(self, ranges, n, acc);
+}
+void launch_ord_level_bases(const FrontierRec *fr, uint32_t n_fr, const uint32_t *slot_ref, uint32_t total, uint32_t n_queries, uint32_t *acc,
+                            uint32_t *lvbase, hipStream_t s) {
+  if (n_queries) ord_level_bases_kernel<<<cdiv(n_queries, 256), 256, 0, s>>>(fr, n_fr, slot_ref, total, n_queries, acc, lvbase);
+}
+void launch_ord_dest_by_place(const FrontierRec *frp, const uint32_t *perm, uint32_t n_fr, const uint32_t *slot_ref, const uint32_t *offsets,
+                              const uint32_t *lvbase, uint32_t *dest, hipStream_t s) {
+  if (n_fr) ord_dest_by_place_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(frp, perm, n_fr, slot_ref, offsets, lvbase, dest);
+}
+void launch_ord_self_rows(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *offsets, impg_gpu_row32_t *rows,
+                          hipStream_t s) {
+  if (n) ord_self_rows_kernel<<<cdiv(n, 256), 256, 0, s>>>(self, ranges, n, offsets, rows);
+}
+void launch_ord_run_heads(const uint32_t *pair_range, uint32_t n_pairs, uint32_t *run_start, hipStream_t s) {
+  if (n_pairs) ord_run_heads_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(pair_range, n_pairs, run_start);
+}
+void launch_ord_level_rows(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, const uint32_t *run_start,
+                           const uint32_t *slot_ref, const uint32_t *offsets, const uint32_t *lvbase, int32_t min_output_length,
+                           uint32_t level, impg_gpu_row32_t *rows, hipStream_t s) {
+  if (n_pairs) ord_level_rows_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, run_start, slot_ref, offsets, lvbase, min_output_length, level, rows);
+}
+void launch_emit_vpos(const DeviceIndexView &v, uint32_t n, const uint32_t *pair_off, const uint4 *win, uint8_t *vpos, hipStream_t s) {
+  if (n) emit_vpos_lane_kernel<<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, vpos);
 }
 void launch_tile_first(const uint32_t *cnt, const uint32_t *pair_off, uint32_t n_fr, uint32_t *tile_first, hipStream_t s) {
   if (n_fr) tile_first_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(cnt, pair_off, n_fr, tile_first);
@@ -4917,6 +5132,12 @@ static bool entry_major() {  // (A/B: IMPG_ENTRY_MAJOR=0 keeps a lane per place 
 // place's range in the block's own LDS offsets: no tile_first[]) when the level is dense.
 bool project_is_staged(const DeviceIndexView &v, uint64_t n_pairs, bool plain) {
   return plain && v.pfx && !v.tp_mode && stage_density() >= 0.0 && (double)n_pairs >= stage_density() * (double)v.n_entries;
+}
+// ... and a level named by the lookup's hit masks (a fused final level) entry by entry on project_entries_kernel: the
+// plain projection, or the identity filter on an index that holds its identity lines
+bool project_entry_major(const DeviceIndexView &v, uint64_t n_pairs, double min_identity) {
+  const bool ident = min_identity == min_identity;
+  return project_is_staged(v, n_pairs, true) && entry_major() && (!ident || v.idp != nullptr);
 }
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,

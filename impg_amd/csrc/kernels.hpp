@@ -53,7 +53,33 @@ struct VisitedTables {
 
 void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32_t n, bool transitive, const uint32_t *perm,
                          uint32_t *cnt, uint4 *win, uint32_t *wide_n, uint32_t *wide_list, hipStream_t s, bool by_place = false,
-                         FrontierRec *se = nullptr /* by_place: the ranges' records at their places (the projection reads the ends there) */);
+                         FrontierRec *se = nullptr /* by_place: the ranges' records at their places (the projection reads the ends there) */,
+                         uint32_t *cnt_ref = nullptr /* by_place: the counts in FRONTIER order too (ordered rows) */);
+// visit position of every hit of the windows of <= 64 entries, by place: vpos[pair_off[i] + k] for range i's k-th hit in index order
+void launch_emit_vpos(const DeviceIndexView &v, uint32_t n, const uint32_t *pair_off, const uint4 *win, uint8_t *vpos, hipStream_t s);
+// ---- ordered rows, placed by slot (Engine::ordered_*): see engine.cpp ------------------------------------------------
+void launch_ord_self_count(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, uint32_t *acc, hipStream_t s);
+// qbase[q] = slot_ref of the first record with qidx >= q (total beyond the last); lvbase[q] = acc[q] - qbase[q]; acc[q] += the query's slots
+void launch_ord_level_bases(const FrontierRec *fr, uint32_t n_fr, const uint32_t *slot_ref, uint32_t total, uint32_t n_queries, uint32_t *acc,
+                            uint32_t *lvbase, hipStream_t s);
+void launch_ord_dest_by_place(const FrontierRec *frp, const uint32_t *perm, uint32_t n_fr, const uint32_t *slot_ref, const uint32_t *offsets,
+                              const uint32_t *lvbase, uint32_t *dest, hipStream_t s);
+void launch_ord_self_rows(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *offsets, impg_gpu_row32_t *rows,
+                          hipStream_t s);
+void launch_ord_run_heads(const uint32_t *pair_range, uint32_t n_pairs, uint32_t *run_start, hipStream_t s);
+void launch_ord_level_rows(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, const uint32_t *run_start,
+                           const uint32_t *slot_ref, const uint32_t *offsets, const uint32_t *lvbase, int32_t min_output_length,
+                           uint32_t level, impg_gpu_row32_t *rows, hipStream_t s);
+// Ordered rows written by the final level itself (Engine::ordered_rows): a pair's finished 32-byte row (one aligned sector) goes to
+// rows[dest[the range's place] + the hit's visit position] instead of the level's hit arrays -- the level's slots in the
+// reference's emission order (frontier order x visit order, impg.rs:2471-2504) at their final place among the batch's rows.
+struct OrderedOut {
+  impg_gpu_row32_t *rows;      // null: off
+  const uint32_t *dest;        // [n_fr] by place: the row of the range's first slot
+  const uint8_t *vpos;         // [n_pairs] by place: visit position of a range's k-th hit in index order (windows of <= 64 entries)
+  int32_t min_output_length;   // rows with |q_last - q_first| below it are holes (impg.rs:2482-2504); -1: none
+  uint32_t level;              // the BFS level the rows belong to
+};
 // A counting run's FINAL level listed by windows instead of by pairs (engine.cpp: Engine::expand): nothing reads that
 // level's slots by position or in order, so the projection kernel takes its pairs straight from what the count pass
 // left per range -- place offset, window, hit mask -- and the emit pass with its two 4-byte-per-pair lists is not run
@@ -70,9 +96,11 @@ struct WindowLists {
   uint32_t *range_out;         // optional: pair_range[] for the per-range counts / the subset filter
   uint32_t masks;              // 1: the pairs are named by the windows' hit masks (tile_first is only needed when project_kernel runs the level)
   uint32_t range_places;       // 1: range_out names a pair's range by its PLACE in the lookup order (perm not applied: no load) -- kept levels, whose frontier copy is taken in that order
+  OrderedOut ord;              // rows != null: the kernel writes finished rows (see OrderedOut); range_out and the hit arrays are not used
 };
 // whether launch_project will run a plain projection of n_pairs by-place pairs on the staged kernels (no tile_first[] needed)
 bool project_is_staged(const DeviceIndexView &v, uint64_t n_pairs, bool plain);
+bool project_entry_major(const DeviceIndexView &v, uint64_t n_pairs, double min_identity);  // ... on project_entries_kernel (a level named by hit masks)
 void launch_tile_first(const uint32_t *cnt, const uint32_t *pair_off, uint32_t n_fr, uint32_t *tile_first, hipStream_t s);
 bool emit_by_lanes(const DeviceIndexView &v);
 // The pairs listed in projection order (optional: slot == nullptr means the projection runs in slot order):

@@ -137,6 +137,7 @@ class DeviceRows:
         lib().impg_gpu_device_rows_stats(self._h, C.byref(st))
         self.stats = st
         self.projected = int(st.projected)
+        self.place_ms = float(lib().impg_gpu_device_rows_place_ms(self._h))
 
     def parts(self):
         out = []
@@ -159,6 +160,15 @@ class DeviceRows:
         _hip_memcpy_d2h(src.ctypes.data, d.source, n * 4)
         _hip_memcpy_d2h(fr.ctypes.data, d.frontier, nf * 16)
         return int(d.first_range), int(d.level), qid, co, src, fr
+
+    def ordered_to_host(self, k=0):
+        """IMPG_ROWS_ORDERED part k copied back: (first_range, rows[INTERVAL_DTYPE], offsets[n_ranges + 1])."""
+        d = self.parts()[k]
+        rows = np.empty(int(d.n_slots), dtype=_lib.ROW32_DTYPE if d.rows32 else INTERVAL_DTYPE)
+        off = np.empty(int(d.n_ranges) + 1, dtype=np.uint32)
+        _hip_memcpy_d2h(rows.ctypes.data, d.rows32 or d.rows, rows.nbytes)
+        _hip_memcpy_d2h(off.ctypes.data, d.offsets, off.nbytes)
+        return int(d.first_range), rows, off
 
     def check(self, counts=True, checksums=True):
         """impg_gpu_device_rows_check: per-range counts / checksums recomputed from the rows in HBM."""

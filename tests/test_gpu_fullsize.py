@@ -172,6 +172,36 @@ def test_headline_ordered_rows_and_bed_vs_oracle(full, oracle_ix):
     assert dev == want
 
 
+def test_headline_ordered_slots_on_device_vs_oracle(full, oracle_ix):
+    """IMPG_ROWS_ORDERED_SLOTS at the headline index: the 4 096-range batch's 8.7 x 10^7 rows left in HBM in the reference's
+    emission order, the dense final level written by project_entries_kernel itself at dest[range] + visit position (the byte
+    emit_vpos_lane_kernel leaves per hit).  A sample of ranges row for row against the oracle (hole rows = None projections
+    taken out), every range's slot count against the counting form's pairs, and the hole count against pairs - projections."""
+    paf, g, ranges = full
+    kw = dict(transitive=True, max_depth=3)
+    p = impg_amd.make_params(**kw)
+    g.set_option("chunk_ranges", 4096)
+    ds = g.query_batch_device(ranges, p, layout=impg_amd._lib.ROWS_ORDERED_SLOTS)
+    st, cnt, _ = g.query_batch_stats(ranges, p)
+    assert ds.projected == st.projected and len(ds.parts()) == 1
+    first, rows, off = ds.ordered_to_host(0)
+    ds.free()
+    assert first == 0 and len(off) == len(ranges) + 1 and int(off[-1]) == len(rows) == st.pairs + len(ranges)
+    live = rows["query_id"] != 0xFFFFFFFF
+    assert int(live.sum()) == st.projected + len(ranges)  # every Some(..) plus the self intervals; the rest are holes
+    per_range = np.add.reduceat(live.astype(np.int64), off[:-1].astype(np.int64))
+    assert (per_range == cnt.astype(np.int64) + 1).all()
+    rng = np.random.default_rng(11)
+    for i in sorted(set(rng.integers(0, len(ranges), 6).tolist()) | {0, len(ranges) - 1}):
+        r = ranges[i]
+        want = oracle_ix.query(int(r["target_id"]), int(r["start"]), int(r["end"]), **kw)
+        got = rows[off[i]:off[i + 1]]
+        got = got[got["query_id"] != 0xFFFFFFFF]
+        assert got[["query_id", "q_first", "q_last", "target_id", "t_first", "t_last"]].tolist() == want.tolist(), i
+        lv = got["level"].astype(np.int64)
+        assert lv[0] == 0xFFFFFFFF and (np.diff(lv[1:]) >= 0).all() and lv[-1] == 2
+
+
 def test_headline_identity_filter_sample(full, oracle_ix):
     """`--min-result-identity` at the headline index (impg.rs:1283-1287): the 4 096-range batch's dense final level runs entry
     by entry under the filter too (project_entries_kernel<.., MODE_IDENT>, the identity lines built on demand); per-range

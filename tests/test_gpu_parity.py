@@ -1200,6 +1200,36 @@ def test_device_rows_attributed(tmp_path):
             g.set_option("chunk_ranges", 0)
             g.set_option("locality_min", 4096)
             g.set_option("fuse_final_level", 1)
+            # IMPG_ROWS_ORDERED: the trait's rows themselves, left in HBM -- the oracle's rows in the oracle's order
+            for lm, chunk in [(1, 0), (4096, 0), (1, 37)]:
+                g.set_option("locality_min", lm)
+                g.set_option("chunk_ranges", chunk)
+                do = g.query_batch_device(ranges, p, layout=impg_amd._lib.ROWS_ORDERED)
+                assert do.projected == n_proj
+                seen = 0
+                for k in range(len(do.parts())):
+                    first, rows, off = do.ordered_to_host(k)
+                    for j in range(len(off) - 1):
+                        assert rows[off[j]:off[j + 1]].tolist() == want[first + j].tolist(), (seed, kw, lm, chunk, first + j)
+                    seen += len(off) - 1
+                assert seen == len(ranges)
+                do.free()
+                # IMPG_ROWS_ORDERED_SLOTS: every slot at its place; with the hole rows taken out, the same rows in the same order
+                ds = g.query_batch_device(ranges, p, layout=impg_amd._lib.ROWS_ORDERED_SLOTS)
+                assert ds.projected == n_proj
+                seen = 0
+                for k in range(len(ds.parts())):
+                    first, rows, off = ds.ordered_to_host(k)
+                    for j in range(len(off) - 1):
+                        r = rows[off[j]:off[j + 1]]
+                        r = r[r["query_id"] != 0xFFFFFFFF]
+                        assert r[["query_id", "q_first", "q_last", "target_id", "t_first", "t_last"]].tolist() == want[first + j].tolist(), (seed, kw, lm, chunk, first + j)
+                        assert (r["level"][:1] == 0xFFFFFFFF).all() and (np.diff(r["level"][1:].astype(np.int64)) >= 0).all()  # self first, then level by level
+                    seen += len(off) - 1
+                assert seen == len(ranges)
+                ds.free()
+            g.set_option("chunk_ranges", 0)
+            g.set_option("locality_min", 4096)
         # what the layout does not take is refused, not answered some other way
         for kw in [dict(transitive=True, dfs=True), dict(store_cigar=True), dict(transitive=True, multi_impg=True)]:
             with pytest.raises(impg_amd.ImpgGpuError) as e:

@@ -65,12 +65,10 @@ class Stats(C.Structure):
 class DevicePart(C.Structure):  # impg_gpu_device_part_t
     _fields_ = [("first_range", C.c_size_t), ("n_ranges", C.c_size_t), ("level", C.c_uint32), ("n_frontier", C.c_uint32),
                 ("n_slots", C.c_uint64), ("query_id", C.c_void_p), ("coords", C.c_void_p), ("source", C.c_void_p),
-                ("frontier", C.c_void_p), ("rows", C.c_void_p), ("offsets", C.c_void_p), ("rows32", C.c_void_p)]
+                ("frontier", C.c_void_p), ("rows", C.c_void_p), ("offsets", C.c_void_p)]
 
 
 ROWS_ATTRIBUTED, ROWS_ORDERED, ROWS_ORDERED_SLOTS = 0, 1, 2
-ROW32_DTYPE = np.dtype([("query_id", "<u4"), ("q_first", "<i4"), ("q_last", "<i4"), ("target_id", "<u4"), ("t_first", "<i4"), ("t_last", "<i4"),
-                        ("level", "<u4"), ("reserved", "<u4")])
 FRONTIER_DTYPE = np.dtype([("target_id", "<u4"), ("start", "<i4"), ("end", "<i4"), ("range_idx", "<u4")])
 
 

@@ -1055,8 +1055,7 @@ int impg_gpu_device_rows_part(const impg_gpu_device_rows_t *h, size_t k, impg_gp
   out->n_ranges = c.n;
   if (h->layout != IMPG_ROWS_ATTRIBUTED) {
     out->n_slots = c.n_rows;
-    if (h->layout == IMPG_ROWS_ORDERED_SLOTS) out->rows32 = c.rows.as<impg_gpu_row32_t>();
-    else out->rows = c.rows.as<impg_gpu_interval_t>();
+    out->rows = c.rows.as<impg_gpu_interval_t>();
     out->offsets = c.offsets.as<uint32_t>();
     return IMPG_OK;
   }

@@ -457,8 +457,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
                                ord_dest.as<uint32_t>(), stream);
       ord_vpos.reserve(std::max<size_t>(P + 256, 256));
       launch_emit_vpos(v, n_fr, pair_off.as<uint32_t>(), win.as<uint4>(), ord_vpos.as<uint8_t>(), stream);
-      wlists.ord = OrderedOut{ord_rows.as<impg_gpu_row32_t>(), ord_dest.as<uint32_t>(), ord_vpos.as<uint8_t>(), ord_min_len, ord_depth};
-      L.level = ord_depth;
+      wlists.ord = OrderedOut{ord_rows.as<impg_gpu_interval_t>(), ord_dest.as<uint32_t>(), ord_vpos.as<uint8_t>(), ord_min_len};
       L.placed = true;
     }
   } else if (by_place) {
@@ -549,7 +548,6 @@ void Engine::ordered_level(const FrontierRec *fr, uint32_t n_fr, LevelBufs &L, b
   const uint64_t total = scan(counts_by_range ? cnt.as<uint32_t>() : ord_cnt.as<uint32_t>(), L.slot_ref.as<uint32_t>(), n_fr);
   if (total != P) throw Error{IMPG_E_INVALID, "internal: a level's slot counts disagree between its two orders"};
   L.lvbase.reserve(std::max<size_t>((size_t)ord_n * 4, 256));
-  L.level = ord_depth;
   launch_ord_level_bases(fr, n_fr, L.slot_ref.as<uint32_t>(), (uint32_t)P, ord_n, ord_acc.as<uint32_t>(), L.lvbase.as<uint32_t>(), stream);
 }
 void Engine::ordered_offsets() {
@@ -557,14 +555,14 @@ void Engine::ordered_offsets() {
   ord_offsets.reserve(((size_t)ord_n + 1) * 4);
   ord_total = scan(ord_acc.as<uint32_t>(), ord_offsets.as<uint32_t>(), ord_n + 1u);  // (acc[n] = 0: offsets[n] = the total)
   if (ord_total >= 0xFFFFFFF0ull) { if (split_ok) throw SplitBatch{}; throw Error{IMPG_E_UNSUPPORTED, "more than 2^32 result rows in one chunk: use smaller chunks (chunk_ranges)"}; }
-  ord_rows.reserve(std::max<size_t>(ord_total * sizeof(impg_gpu_row32_t), 256));
+  ord_rows.reserve(std::max<size_t>(ord_total * sizeof(impg_gpu_interval_t), 256));
   ord_offsets_done = true;
 }
 void Engine::ordered_finish(std::vector<std::unique_ptr<LevelBufs>> &levels) {
   hipEvent_t p0 = event(), p1 = event();
   IMPG_HIP(hipEventRecord(p0, stream));
   ordered_offsets();
-  launch_ord_self_rows(ord_self, ord_ranges, ord_n, ord_offsets.as<uint32_t>(), ord_rows.as<impg_gpu_row32_t>(), stream);
+  launch_ord_self_rows(ord_self, ord_ranges, ord_n, ord_offsets.as<uint32_t>(), ord_rows.as<impg_gpu_interval_t>(), stream);
   for (auto &Lp : levels) {
     LevelBufs &L = *Lp;
     if (L.placed || !L.n_pairs) continue;
@@ -572,7 +570,7 @@ void Engine::ordered_finish(std::vector<std::unique_ptr<LevelBufs>> &levels) {
     launch_ord_run_heads(L.pair_range.as<uint32_t>(), L.n_pairs, L.run_start.as<uint32_t>(), stream);
     HitArrays h{L.qid.as<uint32_t>(), L.coords.as<int4>()};
     launch_ord_level_rows(L.frontier.as<FrontierRec>(), L.pair_range.as<uint32_t>(), L.n_pairs, h, L.run_start.as<uint32_t>(), L.slot_ref.as<uint32_t>(),
-                          ord_offsets.as<uint32_t>(), L.lvbase.as<uint32_t>(), ord_min_len, L.level, ord_rows.as<impg_gpu_row32_t>(), stream);
+                          ord_offsets.as<uint32_t>(), L.lvbase.as<uint32_t>(), ord_min_len, ord_rows.as<impg_gpu_interval_t>(), stream);
     L.placed = true;
   }
   IMPG_HIP(hipEventRecord(p1, stream));
@@ -962,7 +960,6 @@ void Engine::run(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uin
     // copy of the frontier in that order; the per-range statistics and the subset filter index the frontier itself)
     fuse_range_places = keep != nullptr && !want_stats && !subset_on;
     if (ordered_rows) fuse_need_ranges = fuse_range_places = false;  // (a fused level of ordered rows writes rows, nothing else)
-    ord_depth = depth;
     const HopResult hr = hop(v, cur->as<FrontierRec>(), alive ? n_fr : 0, transitive, *L, st, keep || want_stats || !last,
                              keep || d_cksum, alive);
     fuse_final = false;

@@ -18,7 +18,6 @@ struct LevelBufs {  // one BFS level: its frontier and its hit slots
   // ordered rows placed by slot (Engine::ordered_rows): the level's slots per frontier record -- counts, then their exclusive
   // scan -- in frontier order, and per query where the level's rows start relative to the scan (kernels.hip "Ordered rows")
   DevBuf slot_ref, lvbase, run_start;
-  uint32_t level = 0;   // the BFS level (ordered rows carry it)
   bool placed = false;  // its rows are already in the batch's row array (the fused final level writes them itself)
   LevelBufs() = default;
   // the levels a full-results call keeps are new objects at every level of every call: their blocks are recycled
@@ -108,12 +107,12 @@ struct Engine {
   // Ordered rows placed by slot (set by the caller around run(), with `keep`): the batch's rows grouped by range in the
   // reference's emission order, every SLOT at its final place (a None projection stays as a hole row) -- so that where a
   // row goes follows from the lookups' counts alone and the fused final level can write its rows itself.  After run():
-  // ord_rows[ord_total] (impg_gpu_row32_t), ord_offsets[n + 1].
+  // ord_rows[ord_total] (impg_gpu_interval_t), ord_offsets[n + 1].
   bool ordered_rows = false;
   DevBuf ord_acc, ord_offsets, ord_rows, ord_dest, ord_vpos, ord_cnt;
   uint64_t ord_total = 0;
   bool ord_offsets_done = false;
-  uint32_t ord_n = 0, ord_depth = 0;
+  uint32_t ord_n = 0;
   int32_t ord_min_len = -1;
   const FrontierRec *ord_self = nullptr;        // transitive: the self intervals (null: the ranges themselves)
   const impg_gpu_range_t *ord_ranges = nullptr;

@@ -1644,18 +1644,21 @@ __device__ __forceinline__ uint32_t select_bit64(uint32_t lo, uint32_t hi, uint3
   c = (uint32_t)__popc(w & 0x3u);    if (k >= c) { k -= c; w >>= 2; base += 2u; }
   return base + (k >= (w & 1u) ? 1u : 0u);
 }
-// One place of the projection order -> its pair.  live: the place holds a pair; p: the pair's slot.
 // a finished row at its final place (OrderedOut): the hit, or a hole (query_id = 0xFFFFFFFF) where the projection returned
 // None or the row is shorter than min_output_length
 __device__ __forceinline__ void put_ordered_row(const OrderedOut &o, uint32_t d, uint32_t qid, uint32_t tid, bool ok, int32_t qs, int32_t qe,
                                                 int32_t ts, int32_t te) {
   const bool on = ok && !(o.min_output_length >= 0 && abs(qe - qs) < o.min_output_length);
-  // (one aligned 32-byte sector, two 16-byte stores that the L2 merges: a row is a line of its own among 10^9, and a
-  // 24-byte row straddling sectors made every store a read-modify-write of HBM -- 56 ms of projection against 27)
-  uint4 *p = reinterpret_cast<uint4 *>(o.rows) + 2ull * d;
-  p[0] = make_uint4(on ? qid : HIT_NONE, on ? (uint32_t)qs : 0u, on ? (uint32_t)qe : 0u, tid);
-  p[1] = make_uint4(on ? (uint32_t)ts : 0u, on ? (uint32_t)te : 0u, o.level, 0u);
+  // (24 bytes at an 8-byte boundary: a 16-byte and an 8-byte store.  A row is a line of its own among 10^9 and every store
+  // instruction of a wave touches 64 lines -- ~12 ms of the headline's final level per such instruction, measured; rows of
+  // one aligned 32-byte sector cost the same: it is the scattered store, not a read-modify-write)
+  uint32_t *p = reinterpret_cast<uint32_t *>(o.rows) + 6ull * d;
+  const uint4 a = make_uint4(on ? qid : HIT_NONE, on ? (uint32_t)qs : 0u, on ? (uint32_t)qe : 0u, tid);
+  const uint2 b = make_uint2(on ? (uint32_t)ts : 0u, on ? (uint32_t)te : 0u);
+  __builtin_memcpy(p, &a, 16);
+  __builtin_memcpy(p + 4, &b, 8);
 }
+// One place of the projection order -> its pair.  live: the place holds a pair; p: the pair's slot.
 struct PairIn {
   uint32_t eidx, p;
   int32_t f_start, f_end;
@@ -4996,13 +4999,13 @@ __global__ __launch_bounds__(256) void ord_dest_by_place_kernel(const FrontierRe
   dest[i] = offsets[q] + lvbase[q] + slot_ref[perm[i]];
 }
 __global__ __launch_bounds__(256) void ord_self_rows_kernel(const FrontierRec *__restrict__ self, const impg_gpu_range_t *__restrict__ ranges, uint32_t n,
-                                                            const uint32_t *__restrict__ offsets, impg_gpu_row32_t *__restrict__ rows) {
+                                                            const uint32_t *__restrict__ offsets, impg_gpu_interval_t *__restrict__ rows) {
   const uint32_t q = blockIdx.x * 256u + threadIdx.x;
   if (q >= n) return;
   uint32_t t; int32_t a, b;
   if (self) { const FrontierRec f = self[q]; if (!(f.start < f.end)) return; t = f.target_id; a = f.start; b = f.end; }
   else { const impg_gpu_range_t r = ranges[q]; t = r.target_id; a = r.start; b = r.end; }
-  rows[offsets[q]] = impg_gpu_row32_t{t, a, b, t, a, b, 0xFFFFFFFFu, 0u};
+  rows[offsets[q]] = impg_gpu_interval_t{t, a, b, t, a, b};
 }
 __global__ __launch_bounds__(256) void ord_run_heads_kernel(const uint32_t *__restrict__ pair_range, uint32_t n_pairs, uint32_t *__restrict__ run_start) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -5013,7 +5016,7 @@ __global__ __launch_bounds__(256) void ord_run_heads_kernel(const uint32_t *__re
 __global__ __launch_bounds__(256) void ord_level_rows_kernel(const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
                                                              HitArrays h, const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ slot_ref,
                                                              const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ lvbase,
-                                                             int32_t min_output_length, uint32_t level, impg_gpu_row32_t *__restrict__ rows) {
+                                                             int32_t min_output_length, impg_gpu_interval_t *__restrict__ rows) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   if (p >= n_pairs) return;
   const uint32_t r = pair_range[p];
@@ -5023,7 +5026,7 @@ __global__ __launch_bounds__(256) void ord_level_rows_kernel(const FrontierRec *
   const bool ok = qid != HIT_NONE;
   int4 c = make_int4(0, 0, 0, 0);
   if (ok) c = h.c[p];
-  OrderedOut o{rows, nullptr, nullptr, min_output_length, level};
+  OrderedOut o{rows, nullptr, nullptr, min_output_length};
   put_ordered_row(o, d, qid, f.target_id, ok, c.x, c.y, c.z, c.w);
 }
 void launch_ord_self_count(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, uint32_t *acc, hipStream_t s) {
@@ -5037,7 +5040,7 @@ void launch_ord_dest_by_place(const FrontierRec *frp, const uint32_t *perm, uint
                               const uint32_t *lvbase, uint32_t *dest, hipStream_t s) {
   if (n_fr) ord_dest_by_place_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(frp, perm, n_fr, slot_ref, offsets, lvbase, dest);
 }
-void launch_ord_self_rows(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *offsets, impg_gpu_row32_t *rows,
+void launch_ord_self_rows(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *offsets, impg_gpu_interval_t *rows,
                           hipStream_t s) {
   if (n) ord_self_rows_kernel<<<cdiv(n, 256), 256, 0, s>>>(self, ranges, n, offsets, rows);
 }
@@ -5046,8 +5049,8 @@ void launch_ord_run_heads(const uint32_t *pair_range, uint32_t n_pairs, uint32_t
 }
 void launch_ord_level_rows(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, const uint32_t *run_start,
                            const uint32_t *slot_ref, const uint32_t *offsets, const uint32_t *lvbase, int32_t min_output_length,
-                           uint32_t level, impg_gpu_row32_t *rows, hipStream_t s) {
-  if (n_pairs) ord_level_rows_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, run_start, slot_ref, offsets, lvbase, min_output_length, level, rows);
+                           impg_gpu_interval_t *rows, hipStream_t s) {
+  if (n_pairs) ord_level_rows_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, run_start, slot_ref, offsets, lvbase, min_output_length, rows);
 }
 void launch_emit_vpos(const DeviceIndexView &v, uint32_t n, const uint32_t *pair_off, const uint4 *win, uint8_t *vpos, hipStream_t s) {
   if (n) emit_vpos_lane_kernel<<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, vpos);

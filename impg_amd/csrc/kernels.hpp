@@ -64,21 +64,20 @@ void launch_ord_level_bases(const FrontierRec *fr, uint32_t n_fr, const uint32_t
                             uint32_t *lvbase, hipStream_t s);
 void launch_ord_dest_by_place(const FrontierRec *frp, const uint32_t *perm, uint32_t n_fr, const uint32_t *slot_ref, const uint32_t *offsets,
                               const uint32_t *lvbase, uint32_t *dest, hipStream_t s);
-void launch_ord_self_rows(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *offsets, impg_gpu_row32_t *rows,
+void launch_ord_self_rows(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *offsets, impg_gpu_interval_t *rows,
                           hipStream_t s);
 void launch_ord_run_heads(const uint32_t *pair_range, uint32_t n_pairs, uint32_t *run_start, hipStream_t s);
 void launch_ord_level_rows(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h, const uint32_t *run_start,
                            const uint32_t *slot_ref, const uint32_t *offsets, const uint32_t *lvbase, int32_t min_output_length,
-                           uint32_t level, impg_gpu_row32_t *rows, hipStream_t s);
-// Ordered rows written by the final level itself (Engine::ordered_rows): a pair's finished 32-byte row (one aligned sector) goes to
+                           impg_gpu_interval_t *rows, hipStream_t s);
+// Ordered rows written by the final level itself (Engine::ordered_rows): a pair's finished 24-byte row goes to
 // rows[dest[the range's place] + the hit's visit position] instead of the level's hit arrays -- the level's slots in the
 // reference's emission order (frontier order x visit order, impg.rs:2471-2504) at their final place among the batch's rows.
 struct OrderedOut {
-  impg_gpu_row32_t *rows;      // null: off
+  impg_gpu_interval_t *rows;      // null: off
   const uint32_t *dest;        // [n_fr] by place: the row of the range's first slot
   const uint8_t *vpos;         // [n_pairs] by place: visit position of a range's k-th hit in index order (windows of <= 64 entries)
   int32_t min_output_length;   // rows with |q_last - q_first| below it are holes (impg.rs:2482-2504); -1: none
-  uint32_t level;              // the BFS level the rows belong to
 };
 // A counting run's FINAL level listed by windows instead of by pairs (engine.cpp: Engine::expand): nothing reads that
 // level's slots by position or in order, so the projection kernel takes its pairs straight from what the count pass

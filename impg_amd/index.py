@@ -164,9 +164,9 @@ class DeviceRows:
     def ordered_to_host(self, k=0):
         """IMPG_ROWS_ORDERED part k copied back: (first_range, rows[INTERVAL_DTYPE], offsets[n_ranges + 1])."""
         d = self.parts()[k]
-        rows = np.empty(int(d.n_slots), dtype=_lib.ROW32_DTYPE if d.rows32 else INTERVAL_DTYPE)
+        rows = np.empty(int(d.n_slots), dtype=INTERVAL_DTYPE)
         off = np.empty(int(d.n_ranges) + 1, dtype=np.uint32)
-        _hip_memcpy_d2h(rows.ctypes.data, d.rows32 or d.rows, rows.nbytes)
+        _hip_memcpy_d2h(rows.ctypes.data, d.rows, rows.nbytes)
         _hip_memcpy_d2h(off.ctypes.data, d.offsets, off.nbytes)
         return int(d.first_range), rows, off
 

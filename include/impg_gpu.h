@@ -379,21 +379,10 @@ typedef struct impg_gpu_device_rows impg_gpu_device_rows_t;
  * projection returned None (impg.rs:2874-2877: 7 in 10^5 at the headline), or whose transitive row is shorter than
  * min_output_length, stays as a HOLE row, query_id = 0xFFFFFFFF, instead of moving every row behind it up: skip those
  * (offsets[] counts them).  Where a row goes then follows from the lookups' counts alone, so the final level's kernel
- * writes its rows itself where they belong -- no placement pass over 2 x 10^9 rows; the headline batch's rows are in
- * HBM, in emission order, in little more than the time the attributed layout takes. */
+ * writes its rows itself where they belong -- no listed final level, no scans and scatters over 2 x 10^9 rows: the
+ * headline batch's rows are in HBM in emission order in ~75 ms where IMPG_ROWS_ORDERED takes 1.7 s (what
+ * is left is the scattered store itself -- every row is a line of its own among 10^9). */
 #define IMPG_ROWS_ORDERED_SLOTS 2
-/* A row of IMPG_ROWS_ORDERED_SLOTS: the AdjustedInterval in one aligned 32-byte sector (a row is written on its own,
- * among 10^9, by whichever wave projected it: a 24-byte row straddles sectors and every store becomes a read-modify-write
- * of HBM -- measured: 56 ms of projection against 27).  level: BFS level the row was found at (0 = hits of the range
- * itself), 0xFFFFFFFF for the self interval. */
-typedef struct {
-  uint32_t query_id; /* 0xFFFFFFFF: a hole (skip) */
-  int32_t q_first, q_last;
-  uint32_t target_id;
-  int32_t t_first, t_last;
-  uint32_t level;
-  uint32_t reserved;
-} impg_gpu_row32_t;
 typedef struct {
   uint32_t target_id;
   int32_t start, end;
@@ -408,9 +397,8 @@ typedef struct {
   const int32_t *coords;        /* [4 * n_slots]  device, 16-byte aligned */
   const uint32_t *source;       /* [n_slots]      device */
   const impg_gpu_frontier_t *frontier; /* [n_frontier] device */
-  const impg_gpu_interval_t *rows;     /* IMPG_ROWS_ORDERED: [n_slots] device (the fields above are NULL / 0) */
+  const impg_gpu_interval_t *rows;     /* IMPG_ROWS_ORDERED[_SLOTS]: [n_slots] device (the fields above are NULL / 0) */
   const uint32_t *offsets;             /* IMPG_ROWS_ORDERED[_SLOTS]: [n_ranges + 1] device */
-  const impg_gpu_row32_t *rows32;      /* IMPG_ROWS_ORDERED_SLOTS: [n_slots] device */
 } impg_gpu_device_part_t;
 int impg_gpu_query_batch_device(impg_gpu_index_t *, const impg_gpu_range_t *ranges, size_t n, int ranges_on_device,
                                 const impg_gpu_params_t *params, int layout, impg_gpu_device_rows_t **out);

@@ -197,9 +197,7 @@ def test_headline_ordered_slots_on_device_vs_oracle(full, oracle_ix):
         want = oracle_ix.query(int(r["target_id"]), int(r["start"]), int(r["end"]), **kw)
         got = rows[off[i]:off[i + 1]]
         got = got[got["query_id"] != 0xFFFFFFFF]
-        assert got[["query_id", "q_first", "q_last", "target_id", "t_first", "t_last"]].tolist() == want.tolist(), i
-        lv = got["level"].astype(np.int64)
-        assert lv[0] == 0xFFFFFFFF and (np.diff(lv[1:]) >= 0).all() and lv[-1] == 2
+        assert got.tolist() == want.tolist(), i
 
 
 def test_headline_identity_filter_sample(full, oracle_ix):

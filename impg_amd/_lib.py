@@ -64,7 +64,7 @@ class Stats(C.Structure):
 
 class DevicePart(C.Structure):  # impg_gpu_device_part_t
     _fields_ = [("first_range", C.c_size_t), ("n_ranges", C.c_size_t), ("level", C.c_uint32), ("n_frontier", C.c_uint32),
-                ("n_slots", C.c_uint64), ("query_id", C.c_void_p), ("coords", C.c_void_p), ("source", C.c_void_p),
+                ("slot_stride", C.c_uint32), ("n_slots", C.c_uint64), ("query_id", C.c_void_p), ("coords", C.c_void_p), ("source", C.c_void_p),
                 ("frontier", C.c_void_p), ("rows", C.c_void_p), ("offsets", C.c_void_p)]
 
 

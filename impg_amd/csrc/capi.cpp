@@ -1065,7 +1065,9 @@ int impg_gpu_device_rows_part(const impg_gpu_device_rows_t *h, size_t k, impg_gp
   out->n_frontier = L.n_frontier;
   out->query_id = L.qid.as<uint32_t>();
   out->coords = L.coords.as<int32_t>();
-  out->source = L.pair_range.as<uint32_t>();
+  // (a fused final level stores a slot's query id and source as one pair: one store instruction in the kernel instead of two)
+  out->source = L.qs_interleaved ? L.qid.as<uint32_t>() + 1 : L.pair_range.as<uint32_t>();
+  out->slot_stride = L.qs_interleaved ? 2u : 1u;
   out->frontier = L.frontier.as<impg_gpu_frontier_t>();
   return IMPG_OK;
   IMPG_CATCH
@@ -1093,9 +1095,10 @@ int impg_gpu_device_rows_check(impg_gpu_device_rows_t *h, uint64_t *per_range_co
       if (!L.n_pairs) continue;
       HitArrays ha{L.qid.as<uint32_t>(), L.coords.as<int4>()};
       E.rstat.reserve(std::max<size_t>((size_t)L.n_frontier * 16, 256));
-      launch_hit_stats(L.frontier.as<FrontierRec>(), L.n_frontier, L.pair_range.as<uint32_t>(), L.n_pairs, ha,
+      launch_hit_stats(L.frontier.as<FrontierRec>(), L.n_frontier, L.qs_interleaved ? L.qid.as<uint32_t>() + 1 : L.pair_range.as<uint32_t>(), L.n_pairs, ha,
                        h->params.transitive ? h->params.min_output_length : -1, false, E.rstat.as<unsigned long long>(),
-                       E.stat_count.as<unsigned long long>() + c.first, E.stat_cksum.as<unsigned long long>() + c.first, E.stream);
+                       E.stat_count.as<unsigned long long>() + c.first, E.stat_cksum.as<unsigned long long>() + c.first, E.stream,
+                       L.qs_interleaved ? 2u : 1u);
     }
   IMPG_HIP(hipStreamSynchronize(E.stream));
   if (per_range_count && n) IMPG_HIP(hipMemcpy(per_range_count, E.stat_count.p, n * 8, hipMemcpyDeviceToHost));

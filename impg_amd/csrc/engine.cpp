@@ -336,7 +336,7 @@ void Engine::scan2(const uint32_t *in_a, uint32_t *out_a, const uint32_t *in_b, 
 
 static HitArrays hit_arrays(LevelBufs &L, uint32_t n_pairs) {
   size_t b = std::max<size_t>((size_t)n_pairs * 4, 256);
-  L.qid.reserve(b); L.coords.reserve(4 * b);
+  L.qid.reserve(L.qs_interleaved ? 2 * b : b); L.coords.reserve(4 * b);
   return HitArrays{L.qid.as<uint32_t>(), L.coords.as<int4>()};
 }
 
@@ -410,6 +410,8 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   const bool by_place = free_slot_order && (!raw || blocks) && !multi && !store_cigar && d_perm;
   last_by_place = by_place;
   last_range_places = false;
+  L.qs_interleaved = false;
+  L.placed = false;
   expand_n_fr = n_fr;
   bool fused = by_place && fuse_final && emit_by_lanes(v) && !v.tp_mode;
   if (by_place) win_se.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));
@@ -430,7 +432,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
     ordered_level(fr, n_fr, L, !by_place, P);
     // the fused final level writes its rows itself where the entry-ordered kernel runs it (a dense level); any other level
     // keeps its slots, listed in visit order, and is placed when the walk is over (ordered_finish)
-    direct = fused && !store_cigar && project_entry_major(v, P, min_identity);
+    direct = fused && !store_cigar && !(min_identity == min_identity) && project_entry_major(v, P, min_identity);
     if (!direct) fused = false;
   }
   L.pair_range.reserve(std::max<size_t>(P * 4, 256));  // (a direct level: only the wave-per-range emit of wide windows writes it)
@@ -448,6 +450,9 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
     wlists = WindowLists{tile_first.as<uint32_t>(), pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<FrontierRec>(), d_perm, n_fr,
                          fuse_need_ranges && !direct ? L.pair_range.as<uint32_t>() : nullptr, getenv("IMPG_ENT_NONCOMPACT") ? 3u : 1u, fuse_range_places ? 1u : 0u};
     last_range_places = fuse_need_ranges && fuse_range_places && !direct;
+    // (a kept fused level: query id and source of a slot as one {qid, place} pair in L.qid -- one store instead of two)
+    L.qs_interleaved = last_range_places && project_entry_major(v, P, min_identity) && !(min_identity == min_identity) && !store_cigar && !getenv("IMPG_NO_QS");  // (IMPG_NO_QS: A/B)
+    if (L.qs_interleaved) { wlists.masks |= 4u; wlists.range_out = nullptr; }
     if (direct) {
       // every level is counted: the ranges' first rows, then this level's rows straight from the projection kernel --
       // a slot's place in its record's run is the hit's visit position, one byte a pair from the lookup (emit_vpos)

@@ -18,6 +18,7 @@ struct LevelBufs {  // one BFS level: its frontier and its hit slots
   // ordered rows placed by slot (Engine::ordered_rows): the level's slots per frontier record -- counts, then their exclusive
   // scan -- in frontier order, and per query where the level's rows start relative to the scan (kernels.hip "Ordered rows")
   DevBuf slot_ref, lvbase, run_start;
+  bool qs_interleaved = false;  // qid holds {query id, source} pairs, 8 bytes a slot (a kept fused level); pair_range is not written
   bool placed = false;  // its rows are already in the batch's row array (the fused final level writes them itself)
   LevelBufs() = default;
   // the levels a full-results call keeps are new objects at every level of every call: their blocks are recycled

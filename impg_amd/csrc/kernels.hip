@@ -1863,7 +1863,10 @@ static_assert(STG_ECAP * 4u <= STG_THREADS, "one pass copies the entries");
 // entry is requested a turn ahead), and the projection on the staged copies where the entry is one of the n_e staged
 // from emin on, else on the index (regroup_all: nothing is staged and every turn's pairs are regrouped by entry first,
 // as project_kernel does; the scratch overlays the line buffer).  Returns the thread's count of accepted projections.
-template <bool TRANSITIVE, bool MASKS, bool CAN_STAGE = true, uint32_t NR = STG_RANGES, uint32_t NT = STG_THREADS, int MODE = 0>  // NR: ranges of a block (st_off holds NR + 1 offsets); NT: its threads
+// OUT: what a pair leaves behind -- OUT_SLOTS: the level's hit arrays (+ range_out); OUT_QS: {query id, the range's place} as one
+// pair in HitArrays::qid (a kept fused level); OUT_ROWS: a finished row at its final place (OrderedOut)
+constexpr int OUT_SLOTS = 0, OUT_QS = 1, OUT_ROWS = 2;
+template <bool TRANSITIVE, bool MASKS, bool CAN_STAGE = true, uint32_t NR = STG_RANGES, uint32_t NT = STG_THREADS, int MODE = 0, int OUT = OUT_SLOTS>  // NR: ranges of a block (st_off holds NR + 1 offsets); NT: its threads
 __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, const uint32_t *__restrict__ pair_entry, const HitArrays &h,
                                                    unsigned long long *__restrict__ accepted, uint32_t *__restrict__ err_flag,
                                                    const WindowLists &wl, uint32_t r0, uint32_t P0, uint32_t P1, uint32_t emin, uint32_t n_e,
@@ -1872,8 +1875,9 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
                                                    const uint32_t *st_dest = nullptr) {
   const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
   uint32_t n_ok = 0;
-  const bool ordered = wl.ord.rows != nullptr;  // (then nothing is regrouped: a lane keeps its place's range, whose row and target it writes)
-  if (ordered) regroup_all = false;
+  constexpr bool ordered = OUT == OUT_ROWS;  // (then nothing is regrouped: a lane keeps its place's range, whose row and target it writes)
+  constexpr bool qs = OUT == OUT_QS;         // slots as {query id, the range's place} pairs (see project_entries_kernel)
+  if (ordered || qs) regroup_all = false;
   // the block's places, a turn of NT at a time (pair lists: the next turn's entry is requested a turn ahead)
   uint32_t e_next = 0xFFFFFFFFu;
   if (!MASKS && (unsigned long long)P0 + threadIdx.x < P1) e_next = pair_entry[P0 + threadIdx.x];
@@ -1900,7 +1904,8 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
         if (ordered) {  // (a listed window's entries are in visit order already)
           o_dest = st_dest[j] + (listed ? pp - st_off[j] : (uint32_t)wl.ord.vpos[pp]);
           o_tid = wl.se[r0 + j].target_id;
-        } else if (wl.range_out) wl.range_out[pp] = wl.range_places ? r0 + j : wl.perm[r0 + j];
+        } else if (qs) o_tid = r0 + j;
+        else if (wl.range_out) wl.range_out[pp] = wl.range_places ? r0 + j : wl.perm[r0 + j];
       } else {
         y.eidx = e_next;
       }
@@ -1925,7 +1930,8 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
         project_pair<TRANSITIVE, MODE>(v, y.eidx, y.f_start, y.f_end, y.p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
       if (ordered) put_ordered_row(wl.ord, o_dest, qid, o_tid, ok, res.pqs, res.pqe, res.pts, res.pte);
       else {
-        h.qid[y.p] = qid;
+        if (qs) reinterpret_cast<uint2 *>(h.qid)[y.p] = make_uint2(qid, o_tid);
+        else h.qid[y.p] = qid;
         if (ok) h.c[y.p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
       }
       n_ok += ok ? 1u : 0u;
@@ -2111,7 +2117,7 @@ static_assert((ENT_REC_V4 + ENT_LIST_V4) * 4u >= 5u * ENT_THREADS + ENT_WAVES, "
 // (SQ_INSTS_VALU): the flat loop alone, with the old two-candidate search, costs the same 21.9 -> 23.6 ms -- carried
 // around it the entry's sixteen scalar words and the chunk counters spill to vector lanes -- and the second test, which
 // only 60 % of the chunks execute at all, is worth what the choice costs.)
-template <bool TRANSITIVE, int ORIENT, int MODE>
+template <bool TRANSITIVE, int ORIENT, int MODE, int OUT>
 __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, uint4 e0, uint4 e1, uint4 e2, uint4 e3, uint32_t eidx, bool live,
                                                     int32_t f_start, int32_t f_end, uint32_t p, const uint32_t *rec, const HitArrays &h,
                                                     unsigned long long *__restrict__ accepted, uint32_t *__restrict__ err_flag,
@@ -2131,9 +2137,12 @@ __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, ui
       project_core<TRANSITIVE, MODE, true, ORIENT>(v, e0, e1, e2, e3, f_start, f_end, p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS, rec);
     else  // (a record with more prefix lines than a staged record holds: from the index)
       project_pair<TRANSITIVE, MODE>(v, eidx, f_start, f_end, p, min_identity, err_flag, no_sl, accepted, ok, qid, res PHASE_PASS);
-    if (ord.rows) put_ordered_row(ord, p, qid, tid, ok, res.pqs, res.pqe, res.pts, res.pte);  // (p = the row's final place)
+    if (OUT == OUT_ROWS) put_ordered_row(ord, p, qid, tid, ok, res.pqs, res.pqe, res.pts, res.pte);  // (p = the row's final place)
     else {
-      h.qid[p] = qid;
+      // (qs: the slot's query id and its source -- the range's place, handed in as `tid` -- as ONE 8-byte store into an
+      // interleaved array: a third store instruction per chunk cost the level 2.3 ms, this one nothing measurable)
+      if (OUT == OUT_QS) reinterpret_cast<uint2 *>(h.qid)[p] = make_uint2(qid, tid);
+      else h.qid[p] = qid;
       if (ok) h.c[p] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
     }
     n_ok += ok ? 1u : 0u;
@@ -2142,7 +2151,7 @@ __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, ui
 // MODE: 0, or MODE_IDENT -- the identity filter (round 5: `--min-result-identity` used to send the whole final level back to the
 // lane-per-pair kernel, 42 ms of projection a headline step against 21.7 plain); the slice's counts come off the identity
 // lines in the index (a wave's 64 lanes read the same record's <= 8 lines: L1 hits), everything else as in the plain form.
-template <bool TRANSITIVE, int MODE>
+template <bool TRANSITIVE, int MODE, int OUT>
 __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
                                                       uint32_t *__restrict__ err_flag, int regroup, WindowLists wl, double min_identity) {
@@ -2155,8 +2164,9 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   __shared__ int2 st_se[ENT_RANGES];
   __shared__ uint32_t st_off[ENT_RANGES + 4u];
   __shared__ uint16_t st_wide[ENT_RANGES];
-  __shared__ uint32_t st_dest[ENT_RANGES];  // ordered rows (OrderedOut): the row of every range's first slot
-  const bool ordered = wl.ord.rows != nullptr;
+  __shared__ uint32_t st_dest[OUT == OUT_ROWS ? ENT_RANGES : 1u];  // ordered rows (OrderedOut): the row of every range's first slot
+  constexpr bool ordered = OUT == OUT_ROWS;
+  constexpr bool qs = OUT == OUT_QS;  // slots as {query id, the range's place} pairs in h.qid (a kept fused level)
 #if IMPG_ENT_GROUP_SKIP
   __shared__ int2 st_grp[ENT_RANGES / 64u];  // per 64 ranges: the first and the last entry their masks name
 #endif
@@ -2236,7 +2246,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   // more than the pairs do -- by place, regrouped, from the index (the ranges listed instead take the same path there)
   const bool sparse = emin <= emax && (unsigned long long)(P1 - P0) < 4ull * (emax - emin + 1u);
   if (sparse) {
-    n_ok = project_places<TRANSITIVE, true, false, ENT_RANGES, ENT_THREADS, MODE>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
+    n_ok = project_places<TRANSITIVE, true, false, ENT_RANGES, ENT_THREADS, MODE, OUT>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
                                                                st_se, nullptr, st_work PHASE_PASS, min_identity, st_dest);
   } else if (emin <= emax) {
     // The waves take the span's entries one by one off an LDS counter (an entry is anything from a handful to 500 pairs:
@@ -2347,11 +2357,12 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
         }
         if (ordered) {  // the row's final place: the range's first row + the hit's visit position (the byte the lookup left at its place)
           if (live) p = st_dest[r] + (uint32_t)wl.ord.vpos[p];
-        } else if (live && wl.range_out) wl.range_out[p] = wl.range_places ? r0 + r : wl.perm[r0 + r];
-        if (orient == 0) project_entry_chunk<TRANSITIVE, 0, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
-        else if (orient == 1) project_entry_chunk<TRANSITIVE, 1, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
-        else if (orient == 2) project_entry_chunk<TRANSITIVE, 2, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
-        else project_entry_chunk<TRANSITIVE, -1, MODE>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
+        } else if (qs) tid = r0 + r;
+        else if (live && wl.range_out) wl.range_out[p] = wl.range_places ? r0 + r : wl.perm[r0 + r];
+        if (orient == 0) project_entry_chunk<TRANSITIVE, 0, MODE, OUT>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
+        else if (orient == 1) project_entry_chunk<TRANSITIVE, 1, MODE, OUT>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
+        else if (orient == 2) project_entry_chunk<TRANSITIVE, 2, MODE, OUT>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
+        else project_entry_chunk<TRANSITIVE, -1, MODE, OUT>(v, e0, e1, e2, e3, eidx, live, se.x, se.y, p, rec, h, accepted, err_flag, n_ok PHASE_PASS, min_identity, wl.ord, tid);
       }
     }
 #undef IMPG_RDL
@@ -2386,11 +2397,12 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
         if (ordered)  // (a listed window's entries are in visit order: the slot's position in the run is its visit position)
           put_ordered_row(wl.ord, st_dest[r] + (pp - a), qid, wl.se[r0 + r].target_id, ok, res.pqs, res.pqe, res.pts, res.pte);
         else {
-          h.qid[pp] = qid;
+          if (qs) reinterpret_cast<uint2 *>(h.qid)[pp] = make_uint2(qid, r0 + r);
+          else h.qid[pp] = qid;
           if (ok) h.c[pp] = make_int4(res.pqs, res.pqe, res.pts, res.pte);
         }
         n_ok += ok ? 1u : 0u;
-        if (wl.range_out && !ordered) wl.range_out[pp] = wl.range_places ? r0 + r : wl.perm[r0 + r];
+        if (wl.range_out && !ordered && !qs) wl.range_out[pp] = wl.range_places ? r0 + r : wl.perm[r0 + r];
       }
     }
   }
@@ -2580,13 +2592,14 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 __global__ __launch_bounds__(256) void hit_stats_kernel(const FrontierRec *__restrict__ fr,
                                                         const uint32_t *__restrict__ pair_range, uint32_t n_pairs,
                                                         HitArrays h, int32_t min_output_length, int skip_same_target,
-                                                        unsigned long long *__restrict__ rstat, int want_ck) {
+                                                        unsigned long long *__restrict__ rstat, int want_ck, uint32_t stride) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   uint32_t r = 0xFFFFFFFFu;
   unsigned long long c = 0, a = 0;
   if (p < n_pairs) {
-    r = pair_range[p];
-    const uint32_t qid = h.qid[p];
+    // (stride 2: a kept fused level's {query id, source} pairs -- pair_range then points at the second word of the first)
+    r = pair_range[(size_t)p * stride];
+    const uint32_t qid = h.qid[(size_t)p * stride];
     if (qid != HIT_NONE) {
       const uint32_t tgt = fr[r].target_id;
       const int4 hc = h.c[p];
@@ -5174,13 +5187,19 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
     // the final level of a counting run, entry by entry; also under the identity filter
     const uint32_t ge = (cdiv(wl.n_fr, ENT_RANGES) + 7u) & ~7u;
     const double mi = ident ? min_identity : 0.0;
+    // (what a pair leaves behind is a template constant: the plain form carries none of the other two's registers -- the kernel
+    // runs at its scalar-register limit.  The engine asks for rows / {qid, place} pairs only under the plain projection.)
+    const int out = wl.ord.rows ? OUT_ROWS : (wl.masks & 4u) ? OUT_QS : OUT_SLOTS;
+    if (out != OUT_SLOTS && mode != 0) throw Error{IMPG_E_INVALID, "internal: ordered rows / paired slots under the identity filter"};
+#define IMPG_LAUNCH_ENT(T, M, O) project_entries_kernel<T, M, O><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi)
     if (mode == 0) {
-      if (transitive) project_entries_kernel<true, 0><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi);
-      else project_entries_kernel<false, 0><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi);
+      if (out == OUT_ROWS) { if (transitive) IMPG_LAUNCH_ENT(true, 0, OUT_ROWS); else IMPG_LAUNCH_ENT(false, 0, OUT_ROWS); }
+      else if (out == OUT_QS) { if (transitive) IMPG_LAUNCH_ENT(true, 0, OUT_QS); else IMPG_LAUNCH_ENT(false, 0, OUT_QS); }
+      else { if (transitive) IMPG_LAUNCH_ENT(true, 0, OUT_SLOTS); else IMPG_LAUNCH_ENT(false, 0, OUT_SLOTS); }
     } else {
-      if (transitive) project_entries_kernel<true, MODE_IDENT><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi);
-      else project_entries_kernel<false, MODE_IDENT><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi);
+      if (transitive) IMPG_LAUNCH_ENT(true, MODE_IDENT, OUT_SLOTS); else IMPG_LAUNCH_ENT(false, MODE_IDENT, OUT_SLOTS);
     }
+#undef IMPG_LAUNCH_ENT
     return;
   }
   // (a level named by masks has no tile_first[] once the engine has seen it dense: it stays on the staged kernels)
@@ -5212,11 +5231,11 @@ void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, Hi
 }
 void launch_hit_stats(const FrontierRec *fr, uint32_t n_fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
                       int32_t min_output_length, bool skip_same_target, unsigned long long *rstat, unsigned long long *count,
-                      unsigned long long *cksum, hipStream_t s) {
+                      unsigned long long *cksum, hipStream_t s, uint32_t stride) {
   if (!n_pairs || !n_fr) return;
   IMPG_HIP(hipMemsetAsync(rstat, 0, (size_t)n_fr * 16, s));
   hit_stats_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, min_output_length, skip_same_target ? 1 : 0, rstat,
-                                                     cksum ? 1 : 0);
+                                                     cksum ? 1 : 0, stride);
   range_stats_reduce_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(fr, n_fr, rstat, count, cksum);
 }
 void launch_update_keys(const FrontierRec *fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,

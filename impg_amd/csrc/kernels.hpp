@@ -93,7 +93,9 @@ struct WindowLists {
   const uint32_t *perm;        // [n_fr] place -> frontier range
   uint32_t n_fr;
   uint32_t *range_out;         // optional: pair_range[] for the per-range counts / the subset filter
-  uint32_t masks;              // 1: the pairs are named by the windows' hit masks (tile_first is only needed when project_kernel runs the level)
+  uint32_t masks;              // bit 0: the pairs are named by the windows' hit masks (tile_first is only needed when project_kernel runs the level);
+                               // bit 2: the slots' query ids and sources ({qid, the range's place}) interleaved in HitArrays::qid, one 8-byte store (a kept fused level);
+                               // bit 1: slots by range instead of entry by entry (an experiment: IMPG_ENT_NONCOMPACT)
   uint32_t range_places;       // 1: range_out names a pair's range by its PLACE in the lookup order (perm not applied: no load) -- kept levels, whose frontier copy is taken in that order
   OrderedOut ord;              // rows != null: the kernel writes finished rows (see OrderedOut); range_out and the hit arrays are not used
 };
@@ -152,7 +154,7 @@ void launch_slice_write(const DeviceIndexView &v, const uint32_t *pair_entry, Hi
 // per-range counts / checksums of a level's hits: rstat = 16 bytes of scratch per frontier range (zeroed here)
 void launch_hit_stats(const FrontierRec *fr, uint32_t n_fr, const uint32_t *pair_range, uint32_t n_pairs, HitArrays h,
                       int32_t min_output_length, bool skip_same_target, unsigned long long *rstat, unsigned long long *count,
-                      unsigned long long *cksum, hipStream_t s);
+                      unsigned long long *cksum, hipStream_t s, uint32_t stride = 1 /* words between consecutive slots' pair_range / qid */);
 void launch_sort5(const FrontierRec *fr, uint32_t n, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
                   const uint32_t *pair_entry, const uint32_t *mrank, uint32_t *dest, hipStream_t s);
 void launch_permute_slots(const uint32_t *dest, uint32_t n_pairs, HitArrays in, HitArrays out, const uint32_t *pe_in,

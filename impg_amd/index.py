@@ -150,14 +150,20 @@ class DeviceRows:
     def part_to_host(self, k):
         """One part copied back: (first_range, level, query_id[n], coords[n, 4], source[n], frontier[n_frontier])."""
         d = self.parts()[k]
-        n, nf = int(d.n_slots), int(d.n_frontier)
-        qid = np.empty(n, dtype=np.uint32)
+        n, nf, st = int(d.n_slots), int(d.n_frontier), int(d.slot_stride)
         co = np.empty((n, 4), dtype=np.int32)
-        src = np.empty(n, dtype=np.uint32)
         fr = np.empty(nf, dtype=_lib.FRONTIER_DTYPE)
-        _hip_memcpy_d2h(qid.ctypes.data, d.query_id, n * 4)
+        if st == 1:
+            qid = np.empty(n, dtype=np.uint32)
+            src = np.empty(n, dtype=np.uint32)
+            _hip_memcpy_d2h(qid.ctypes.data, d.query_id, n * 4)
+            _hip_memcpy_d2h(src.ctypes.data, d.source, n * 4)
+        else:  # query_id and source side by side (source = query_id + 1 word)
+            assert d.source == d.query_id + 4 and st == 2
+            both = np.empty((n, 2), dtype=np.uint32)
+            _hip_memcpy_d2h(both.ctypes.data, d.query_id, n * 8)
+            qid, src = np.ascontiguousarray(both[:, 0]), np.ascontiguousarray(both[:, 1])
         _hip_memcpy_d2h(co.ctypes.data, d.coords, n * 16)
-        _hip_memcpy_d2h(src.ctypes.data, d.source, n * 4)
         _hip_memcpy_d2h(fr.ctypes.data, d.frontier, nf * 16)
         return int(d.first_range), int(d.level), qid, co, src, fr
 

@@ -354,10 +354,12 @@ int impg_gpu_query_batch_stats_dev(impg_gpu_index_t *, const impg_gpu_range_t *d
  * the frontier range's target as its target metadata (impg.rs:2491-2503, :1920-1923) -- is here one slot of a PART:
  * the hits of one BFS level (level 0 = the hits of the ranges themselves; a plain query has only that) of one chunk of
  * the batch, as device arrays of n_slots entries
- *     query_id[k]   the hit's query sequence; 0xFFFFFFFF = the projection returned None (impg.rs:2874-2877), or the
+ *     query_id[s*k] the hit's query sequence; 0xFFFFFFFF = the projection returned None (impg.rs:2874-2877), or the
  *                   subset filter dropped the hit: not a row
  *     coords[4k..]  q_first, q_last, t_first, t_last (q_first > q_last: reverse strand)
- *     source[k]     index into frontier[]: the frontier record the hit was found with
+ *     source[s*k]   index into frontier[]: the frontier record the hit was found with
+ *                   (s = slot_stride: 1, or 2 where the part keeps a slot's query_id and source side by side as one
+ *                   8-byte pair -- the fused final level, which writes them with one store)
  *     frontier[j]   {target_id, start, end, range_idx}: the row's target sequence (the target interval's metadata) and
  *                   the range of the batch it belongs to, as ranges[first_range + range_idx]
  * i.e. SURVEY-style 24 bytes per slot (query_id, four coordinates, source) with range_idx and target_id one
@@ -392,10 +394,11 @@ typedef struct {
   size_t first_range, n_ranges; /* the chunk of the batch the part belongs to (chunks: "chunk_ranges" / "pair_budget") */
   uint32_t level;               /* BFS level of the part's hits */
   uint32_t n_frontier;
+  uint32_t slot_stride;         /* 4-byte words between consecutive slots' query_id (and source) */
   uint64_t n_slots;
-  const uint32_t *query_id;     /* [n_slots]      device */
-  const int32_t *coords;        /* [4 * n_slots]  device, 16-byte aligned */
-  const uint32_t *source;       /* [n_slots]      device */
+  const uint32_t *query_id;     /* [slot_stride * n_slots]  device */
+  const int32_t *coords;        /* [4 * n_slots]            device, 16-byte aligned */
+  const uint32_t *source;       /* [slot_stride * n_slots]  device */
   const impg_gpu_frontier_t *frontier; /* [n_frontier] device */
   const impg_gpu_interval_t *rows;     /* IMPG_ROWS_ORDERED[_SLOTS]: [n_slots] device (the fields above are NULL / 0) */
   const uint32_t *offsets;             /* IMPG_ROWS_ORDERED[_SLOTS]: [n_ranges + 1] device */

@@ -68,11 +68,13 @@ def main():
                     help="impg_gpu_set_option before the run (timing comparisons, e.g. locality_min=0)")
     ap.add_argument("--paf", default=None, help="reuse an existing synthetic PAF file")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even with one rank")
-    ap.add_argument("--workload", default="headline", choices=["headline", "config4", "config5"],
+    ap.add_argument("--workload", default="headline", choices=["headline", "config4", "config5", "skewed"],
                     help="headline: BASELINE.json's metric configuration (the default, what the driver runs).  config4: "
                          "HPRC-scale index from impg_synth_paf records (--records, default 5e7; 20 000 sequences), 100k ranges "
                          "-x -m 3.  config5: the headline index, contiguous 5 kb windows end to end (--ranges windows per GPU, "
-                         "default the whole genome: 200 000), -x -m 5")
+                         "default the whole genome: 200 000), -x -m 5.  skewed: the NON-uniform index (impg_synth_skewed_paf_text: log-normal "
+                         "alignment lengths 1 kb ... 5 Mb = 20 ... 10^5 ops a CIGAR, 1 %% of the sequences holding ~30 %% of the entries; "
+                         "--records, default 2e5), --ranges (default 2 000) uniform 5 kb ranges, -x -m 3")
     ap.add_argument("--lanes", type=int, default=2, help="sharded index: chunks of the batch in flight at once per rank")
     ap.add_argument("--min-identity", type=float, default=None,
                     help="--min-result-identity of the reference (impg.rs:1283-1287); not part of the headline configuration")
@@ -111,9 +113,9 @@ def main():
     import impg_amd
     wl = args.workload
     if args.records is None:
-        args.records = 50_000_000 if wl == "config4" else 1_000_000
+        args.records = 50_000_000 if wl == "config4" else 200_000 if wl == "skewed" else 1_000_000
     if args.ranges is None:
-        args.ranges = 200_000 if wl == "config5" else 100_000
+        args.ranges = 200_000 if wl == "config5" else 2_000 if wl == "skewed" else 100_000
     if args.max_depth is None:
         args.max_depth = 5 if wl == "config5" else 3
     sharded_run = args.gpus > 1 or args.force_sharded
@@ -121,7 +123,7 @@ def main():
         # one GPU: the whole batch in one chunk (2.1e9 slots a level; every level's fixed costs paid once: 61.7 -> 59.5 ms per
         # step against two chunks of 50 000); a sharded index: two chunks per rank, one per lane, so that a lane's exchange
         # overlaps the other's kernels
-        args.chunk_ranges = 500 if wl == "config5" else (50000 if sharded_run else max(50000, args.ranges))
+        args.chunk_ranges = 500 if wl == "config5" else 2000 if wl == "skewed" else (50000 if sharded_run else max(50000, args.ranges))
     if args.pair_budget is None:
         # (config 5: 500 windows at depth 5 list 1.4e9 pairs in their last level -- under 2^30 every chunk was split after the run that
         # found it out, 797 ms per 4 000 windows against 608 with room for the level)
@@ -145,12 +147,15 @@ def main():
 
     # ---- synthetic inputs (SplitMix64 seeds 42 / 7) -------
     n_seq, seq_len = (20000 if wl == "config4" else 200), 5_000_000
-    paf = args.paf or os.path.join(tempfile.gettempdir(), "impg_synth_%d_seed42.paf" % args.records)
+    paf = args.paf or os.path.join(tempfile.gettempdir(), "impg_synth%s_%d_seed42.paf" % ("_skewed" if wl == "skewed" else "", args.records))
     if wl == "config4":
         paf = None  # built straight from generated records: 31 GB of PAF text per 5e7 records would only be parsed again
     if paf and rank == 0 and not os.path.exists(paf):
         log("writing synthetic PAF %s" % paf)
-        impg_amd.synth_paf_text(paf + ".tmp", 42, args.records, n_seq=n_seq, seq_len=seq_len)
+        if wl == "skewed":
+            impg_amd.synth_skewed_paf_text(paf + ".tmp", 42, args.records, n_seq=n_seq, seq_len=seq_len)
+        else:
+            impg_amd.synth_paf_text(paf + ".tmp", 42, args.records, n_seq=n_seq, seq_len=seq_len)
         os.replace(paf + ".tmp", paf)
     if dist is not None:
         dist.barrier()
@@ -216,7 +221,7 @@ def main():
         return st
 
     # (rows left on the device belong to one GPU's index; config 5's 10^12 rows do not fit any HBM: a caller would take them chunk by chunk)
-    form = "count" if (dist is not None or wl == "config5") else args.form
+    form = "count" if (dist is not None or wl in ("config5", "skewed")) else args.form
     step = step_rows if form == "rows" else step_count
 
     def sync():
@@ -354,9 +359,11 @@ def main():
         "dtype": "int32",
         "data": "synthetic",
         "config": {
-            "workload": "synthetic PAF %d records (%d seqs x 5 Mb, 10 kb alignments, 200-op CIGARs, bidirectional "
+            "workload": "synthetic PAF %d records (%d seqs x 5 Mb, %s, bidirectional "
                         "index), %d %s per GPU, %s" %
-                        (args.records, n_seq, args.ranges, "contiguous 5 kb windows" if wl == "config5" else "x 5 kb query ranges",
+                        (args.records, n_seq, "log-normal alignment lengths 1 kb ... 5 Mb (median 8 kb; one {= run, edit} block per 100 bases: 20 ... 10^5 ops "
+                                              "a CIGAR), 1 % of the sequences target / query of 30 % of the records" if wl == "skewed" else
+                                              "10 kb alignments, 200-op CIGARs", args.ranges, "contiguous 5 kb windows" if wl == "config5" else "x 5 kb query ranges",
                          ("-x -m %d" % args.max_depth) if transitive else "no transitive"),
             "records": args.records, "ranges_per_gpu": args.ranges, "max_depth": args.max_depth if transitive else 0,
             "min_transitive_len": 101, "min_distance_between_ranges": 10, "min_identity": args.min_identity,

@@ -65,7 +65,7 @@ bool Engine::run_small(const impg_gpu_index &ix, const impg_gpu_range_t *h_range
   ranges_dev.reserve(std::max<size_t>((size_t)SMALL_RANGES * sizeof(impg_gpu_range_t), 256));
   frontier_a.reserve(std::max<size_t>((size_t)SMALL_RANGES * sizeof(FrontierRec), 256));
   cnt.reserve(SMALL_RANGES * 4); win.reserve(SMALL_RANGES * 16); pair_off.reserve(SMALL_RANGES * 4);
-  wide_n.reserve(256); wide_list.reserve(SMALL_RANGES * 4);
+  wide_n.reserve(256); wide_list.reserve(SMALL_RANGES * 8);  // (the wide list + its overflow list)
   LevelBufs &L = level_scratch;
   const size_t pb = std::max<size_t>((size_t)B * 4, 256);
   L.pair_range.reserve(pb); pair_entry.reserve(pb); L.qid.reserve(pb); L.coords.reserve(4 * pb);
@@ -401,7 +401,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
   // MultiImpg steps are Impg::query calls (multi_impg.rs:520-530): closed overlap test, unclipped range
   if (multi) transitive = false;
   wide_n.reserve(256);
-  wide_list.reserve(std::max<size_t>((size_t)n_fr * 4, 256));
+  wide_list.reserve(std::max<size_t>((size_t)n_fr * 8, 256));  // (the wide list + its overflow list behind it)
   const uint32_t *d_perm = lookup_order(v, fr, n_fr, blocks);
   // Counting runs under the lookup order (see free_slot_order): slot = place in that order.  The count pass leaves
   // its counts and windows at the lanes' places, one scan gives the run offsets and the total, and the emit pass
@@ -448,7 +448,7 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
     launch_lookup_emit(v, fr, n_fr, transitive, pair_off.as<uint32_t>(), win.as<uint4>(), L.pair_range.as<uint32_t>(),
                        pair_entry.as<uint32_t>(), d_perm, nullptr, pl, wide_n.as<uint32_t>(), wide_list.as<uint32_t>(), stream, true, true);
     wlists = WindowLists{tile_first.as<uint32_t>(), pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<FrontierRec>(), d_perm, n_fr,
-                         fuse_need_ranges && !direct ? L.pair_range.as<uint32_t>() : nullptr, getenv("IMPG_ENT_NONCOMPACT") ? 3u : 1u, fuse_range_places ? 1u : 0u};
+                         fuse_need_ranges && !direct ? L.pair_range.as<uint32_t>() : nullptr, 1u, fuse_range_places ? 1u : 0u};
     last_range_places = fuse_need_ranges && fuse_range_places && !direct;
     // (a kept fused level: query id and source of a slot as one {qid, place} pair in L.qid -- one store instead of two)
     L.qs_interleaved = last_range_places && project_entry_major(v, P, min_identity) && !(min_identity == min_identity) && !store_cigar && !getenv("IMPG_NO_QS");  // (IMPG_NO_QS: A/B)

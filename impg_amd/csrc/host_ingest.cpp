@@ -2,6 +2,7 @@
 // synthetic workload generators.  Mirrors the reference's parsers
 // (src/paf.rs:118-194, src/impg.rs:2935-2950, src/commands/partition.rs:1752-1789)
 // so that the same text yields the same records and sequence ids.
+#include <cmath>
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -301,15 +302,9 @@ struct SynthRecord {
   int32_t qs, qe, ts, te;
   uint64_t matches, block;
 };
-// generates record i; appends 2*n_blocks ops
-SynthRecord synth_record(uint64_t seed, uint64_t i, uint32_t n_seq, int32_t L, int32_t span,
-                         uint32_t n_blocks, std::vector<uint32_t> &ops) {
-  SplitMix64 g = rng_for(seed, i);
-  SynthRecord r;
-  r.target = (uint32_t)g.below(n_seq);
-  r.query = (uint32_t)g.below(n_seq - 1);
-  if (r.query >= r.target) r.query++;
-  r.strand = (uint32_t)g.below(2);
+// the CIGAR and the coordinates of a record whose sequences, strand, target span and block count are chosen: appends
+// 2*n_blocks ops (n_blocks x {'=' run, one edit: X 60 %, I 1-8 20 %, D 1-8 20 %}) whose target deltas sum to `span`
+void synth_fill(SplitMix64 &g, SynthRecord &r, int32_t L, int32_t span, uint32_t n_blocks, std::vector<uint32_t> &ops) {
   std::vector<uint32_t> edit(n_blocks);
   int64_t sumX = 0, sumD = 0, sumI = 0;
   for (uint32_t b = 0; b < n_blocks; b++) {
@@ -337,6 +332,43 @@ SynthRecord synth_record(uint64_t seed, uint64_t i, uint32_t n_seq, int32_t L, i
   r.qe = r.qs + (int32_t)qspan;
   r.matches = (uint64_t)E;
   r.block = (uint64_t)(E + sumX + sumI + sumD);
+}
+// generates record i; appends 2*n_blocks ops
+SynthRecord synth_record(uint64_t seed, uint64_t i, uint32_t n_seq, int32_t L, int32_t span,
+                         uint32_t n_blocks, std::vector<uint32_t> &ops) {
+  SplitMix64 g = rng_for(seed, i);
+  SynthRecord r;
+  r.target = (uint32_t)g.below(n_seq);
+  r.query = (uint32_t)g.below(n_seq - 1);
+  if (r.query >= r.target) r.query++;
+  r.strand = (uint32_t)g.below(2);
+  synth_fill(g, r, L, span, n_blocks, ops);
+  return r;
+}
+// The NON-uniform workload (`bench.py --workload skewed`; SURVEY section 7 "Hard parts": real cohorts have alignments of 10^5-10^6
+// ops and repeat-driven hit skew): target spans log-normal (median 8 kb, sigma 1.25 in ln units) clamped to [1 kb, seq_len - 16 kb]
+// -- 20 ops to 10^5 ops a CIGAR, one block of {'=' run, edit} per 100 target bases, so records of more than 8 tiles carry
+// external checkpoints -- and the first max(1, n_seq / 100) sequences are HOT: a record's target is one of them with
+// probability 0.3, and so is its query (1 % of the sequences hold ~30 % of a bidirectional index's entries: windows of
+// hundreds to thousands of entries, the wave-per-range emit and the listed wide windows).
+SynthRecord synth_record_skewed(uint64_t seed, uint64_t i, uint32_t n_seq, int32_t L, std::vector<uint32_t> &ops) {
+  SplitMix64 g = rng_for(seed ^ 0x5CE3ED5EEDull, i);
+  SynthRecord r;
+  const uint32_t n_hot = std::max<uint32_t>(1, n_seq / 100);
+  auto pick = [&]() -> uint32_t { return g.below(10) < 3 ? (uint32_t)g.below(n_hot) : (uint32_t)g.below(n_seq); };
+  r.target = pick();
+  do { r.query = pick(); } while (r.query == r.target);
+  r.strand = (uint32_t)g.below(2);
+  // Box-Muller on two 53-bit uniforms
+  const double u1 = ((double)(g.next() >> 11) + 1.0) * (1.0 / 9007199254740993.0), u2 = (double)(g.next() >> 11) * (1.0 / 9007199254740992.0);
+  const double z = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+  double len = 8000.0 * std::exp(1.25 * z);
+  const double lo = 1000.0, hi = (double)L - 16384.0;
+  if (len < lo) len = lo;
+  if (len > hi) len = hi;
+  const int32_t span = (int32_t)len;
+  const uint32_t n_blocks = std::max<uint32_t>(10u, (uint32_t)(span / 100));
+  synth_fill(g, r, L, span, n_blocks, ops);
   return r;
 }
 }  // namespace
@@ -434,6 +466,60 @@ int impg_synth_paf_text(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t
   }
   if (fclose(fp) != 0) ok = false;
   if (!ok) { set_error("write failed"); return IMPG_E_IO; }
+  return IMPG_OK;
+}
+
+// the skewed workload as PAF text (synth_record_skewed): returns the number of ops written in *n_ops_out
+int impg_synth_skewed_paf_text(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t seq_len, const char *path, uint64_t *n_ops_out) {
+  if (n_seq < 2 || seq_len < 65536) { set_error("impg_synth_skewed_paf_text: bad shape"); return IMPG_E_INVALID; }
+  FILE *fp = fopen(path, "wb");
+  if (!fp) { set_error(std::string("cannot create ") + path); return IMPG_E_IO; }
+  static const char OPC[] = "=XIDM";
+  auto put_u = [](std::string &o, unsigned long long v) {
+    char b[24];
+    int n = 0;
+    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) o.push_back(b[--n]);
+  };
+  const size_t BLOCK = 1024;
+  unsigned hw = std::thread::hardware_concurrency();
+  const size_t T = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, 32));
+  bool ok = true;
+  std::atomic<uint64_t> n_ops{0};
+  for (size_t base = 0; base < n_records && ok; base += BLOCK * T) {
+    std::vector<std::string> bufs(T);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; t++)
+      th.emplace_back([&, t]() {
+        size_t lo = base + t * BLOCK, hi = std::min(n_records, lo + BLOCK);
+        std::string &line = bufs[t];
+        std::vector<uint32_t> tmp;
+        char qn[32], tn[32];
+        uint64_t mine = 0;
+        for (size_t i = lo; i < hi; i++) {
+          tmp.clear();
+          SynthRecord s = synth_record_skewed(seed, i, n_seq, seq_len, tmp);
+          mine += tmp.size();
+          impg_synth_seq_name(s.query, qn, sizeof qn);
+          impg_synth_seq_name(s.target, tn, sizeof tn);
+          line += qn; line.push_back('\t'); put_u(line, (unsigned)seq_len); line.push_back('\t');
+          put_u(line, (unsigned)s.qs); line.push_back('\t'); put_u(line, (unsigned)s.qe); line.push_back('\t');
+          line.push_back(s.strand ? '-' : '+'); line.push_back('\t');
+          line += tn; line.push_back('\t'); put_u(line, (unsigned)seq_len); line.push_back('\t');
+          put_u(line, (unsigned)s.ts); line.push_back('\t'); put_u(line, (unsigned)s.te); line.push_back('\t');
+          put_u(line, s.matches); line.push_back('\t'); put_u(line, s.block); line += "\t255\tcg:Z:";
+          for (uint32_t v : tmp) { put_u(line, v & OP_LEN_MASK); line.push_back(OPC[v >> 29]); }
+          line.push_back('\n');
+        }
+        n_ops += mine;
+      });
+    for (auto &x : th) x.join();
+    for (size_t t = 0; t < T && ok; t++)
+      if (!bufs[t].empty() && fwrite(bufs[t].data(), 1, bufs[t].size(), fp) != bufs[t].size()) ok = false;
+  }
+  if (fclose(fp) != 0) ok = false;
+  if (!ok) { set_error("write failed"); return IMPG_E_IO; }
+  if (n_ops_out) *n_ops_out = n_ops.load();
   return IMPG_OK;
 }
 

@@ -317,6 +317,75 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
   }
 }
 
+// K1b-wide: the listed wide windows (dense targets, repeat hot spots: `bench.py --workload skewed` has windows of thousands of
+// entries), a BLOCK per range: the window's hits are collected as (visit rank, entry) keys in LDS, sorted there (bitonic), and
+// written out in visit order -- O(W + H log^2 H) per range.  (The wave-per-range kernel above ranks every hit against every
+// other with a readlane loop, O(W x H): 98 % of a skewed step, 3.2 s.)  More than WIDE_CAP hits: the range goes onto
+// the overflow list and the kernel above takes it.
+constexpr uint32_t WIDE_CAP = 4096;
+template <bool TRANSITIVE>
+__global__ __launch_bounds__(256) void lookup_emit_wide_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr, uint32_t n,
+                                                               const uint32_t *__restrict__ pair_off, const uint4 *__restrict__ win,
+                                                               uint32_t *__restrict__ pair_range, uint32_t *__restrict__ pair_entry,
+                                                               const uint32_t *__restrict__ offp, ProjList pl, const uint32_t *__restrict__ list,
+                                                               const uint32_t *__restrict__ list_n, const uint32_t *__restrict__ place_perm,
+                                                               uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_n) {
+  __shared__ unsigned long long keys[WIDE_CAP];
+  __shared__ uint32_t s_cnt;
+  const int32_t *ecol = end_col<TRANSITIVE>(v);
+  uint32_t *const slot_of = pl.slot;
+  const uint32_t n_items = min(*list_n, n), tid = threadIdx.x;
+  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const uint32_t item = list[it];
+    const uint32_t r = place_perm ? place_perm[item] : item;
+    const uint4 w = win[item];
+    const uint32_t off = pair_off[item], po = slot_of ? offp[r] : 0u;
+    const uint32_t lo = w.x, ub = w.y;
+    const int32_t qs = fr[r].start;
+    if (tid == 0) s_cnt = 0u;
+    __syncthreads();
+    for (uint32_t base = lo; base < ub; base += 256u) {
+      const uint32_t i = base + tid;
+      const bool hit = i < ub && window_hit<TRANSITIVE>(ecol[i], qs);
+      const unsigned long long m = __ballot(hit);
+      uint32_t wb = 0;
+      if (lane_id() == 0 && m) wb = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+      wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
+      const uint32_t pos = wb + (uint32_t)__popcll(m & lanemask_lt());
+      if (hit && pos < WIDE_CAP) keys[pos] = ((unsigned long long)(v.sorted_order ? i : v.rank[i]) << 32) | i;
+    }
+    __syncthreads();
+    const uint32_t H = s_cnt;
+    if (H > WIDE_CAP) {  // (block-uniform) more hits than the buffer takes: the wave-per-range kernel's turn
+      if (tid == 0) over_list[atomicAdd(over_n, 1u)] = item;
+      __syncthreads();
+      continue;
+    }
+    uint32_t P2 = 64u;
+    while (P2 < H) P2 <<= 1;
+    for (uint32_t k = H + tid; k < P2; k += 256u) keys[k] = ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2u; k <= P2; k <<= 1) {
+      for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+        for (uint32_t t = tid; t < (P2 >> 1); t += 256u) {
+          const uint32_t a = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), b = a | j;  // the t-th pair at distance j
+          const bool up = (a & k) == 0u;
+          const unsigned long long x = keys[a], y = keys[b];
+          if ((x > y) == up) { keys[a] = y; keys[b] = x; }
+        }
+        __syncthreads();
+      }
+    }
+    for (uint32_t k = tid; k < H; k += 256u) {
+      const uint32_t e = (uint32_t)keys[k];
+      pair_range[off + k] = r;
+      if (pair_entry) pair_entry[off + k] = e;
+      if (slot_of) { slot_of[po + k] = off + k; pl.range[po + k] = r; pl.entry[po + k] = e; }
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------
 // multi-GPU routing: owner rank of a frontier record = owner[target_id] (shard map), else target_id % world
 // ---------------------------------------------------------------------------
@@ -2167,6 +2236,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   __shared__ uint32_t st_dest[OUT == OUT_ROWS ? ENT_RANGES : 1u];  // ordered rows (OrderedOut): the row of every range's first slot
   constexpr bool ordered = OUT == OUT_ROWS;
   constexpr bool qs = OUT == OUT_QS;  // slots as {query id, the range's place} pairs in h.qid (a kept fused level)
+  constexpr bool WIDE_LISTED = ordered;  // windows wider than the hit mask: listed (pair_entry, in visit order) or by the window test
 #if IMPG_ENT_GROUP_SKIP
   __shared__ int2 st_grp[ENT_RANGES / 64u];  // per 64 ranges: the first and the last entry their masks name
 #endif
@@ -2200,8 +2270,13 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
       st_win[t] = w;
       { const FrontierRec sf = wl.se[r0 + t]; st_se[t] = make_int2(sf.start, sf.end); }
       if (ordered) st_dest[t] = wl.ord.dest[r0 + t];
-      if (w.y - (w.x & ~3u) > 64u) st_wide[atomicAdd(&st_nwide, 1u)] = (uint16_t)t;
-      else if (w.z | w.w) {
+      if (w.y - (w.x & ~3u) > 64u) {
+        // a window wider than the hit mask (a dense target, a repeat hot spot).  Where slots may be filled entry by entry its hits
+        // join the entry-major loop below, named by the window test itself instead of a mask bit; ordered rows need the hit's
+        // visit position, which only the listed form has: those ranges are listed and taken a lane per place at the end
+        if (WIDE_LISTED) st_wide[atomicAdd(&st_nwide, 1u)] = (uint16_t)t;
+        else if (w.x < w.y) { glo = w.x; ghi = w.y - 1u; emin = min(emin, glo); emax = max(emax, ghi); }
+      } else if (w.z | w.w) {
         glo = w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w));
         ghi = w.x + (w.w ? 63u - (uint32_t)__builtin_clz(w.w) : 31u - (uint32_t)__builtin_clz(w.z));
         emin = min(emin, glo);
@@ -2239,7 +2314,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   // (place offset + mask bits below the entry's) the lanes of a wave scatter over as many lines as it has lanes, and
   // the store path, not the ALUs, bounded the kernel.  Not when a range of the block is listed instead: its pairs
   // keep their places, so the others do too.
-  const bool compact = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_nwide) == 0u && !ordered && !(wl.masks & 2u);  // (masks bit 1: slots by range, an experiment)
+  const bool compact = !ordered;  // (by range -- slot = the range's first place + the mask bits below the entry's -- measured 2.3 x slower: every lane of a store another line)
   uint32_t n_ok = 0;
   STG_MARK(1);
   // few pairs for the entries they touch (a sparse stretch of the level): fetching a record for a pair or two would read
@@ -2306,6 +2381,8 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
       }
       // the block's ranges that hit the entry, 64 at a time: bit (entry - window start) of the range's mask
       uint32_t cnt = 0;
+      // (what the count pass tested a wide window's entries with -- ends[] / ends_t[] -- from the entry's own words: no load)
+      const int32_t e_end = TRANSITIVE ? ((int32_t)e0.x < (int32_t)e0.y ? (int32_t)e0.y : (-2147483647 - 1)) : (int32_t)e0.y;
 #if IMPG_ENT_GROUP_SKIP
       // (in the lookup order a block's 512 ranges climb through its ~50 entries: one or two of the eight groups of 64 can
       // name a given entry at all -- found with one LDS read and a ballot; the other groups' masks are not looked at)
@@ -2324,7 +2401,8 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
         if (r < nr) {
           const uint4 w = st_win[r];
           const uint32_t d = eidx - w.x;
-          hit = d < 64u && w.y - (w.x & ~3u) <= 64u && (((d < 32u ? w.z >> d : w.w >> (d - 32u)) & 1u) != 0u);
+          if (w.y - (w.x & ~3u) <= 64u) hit = d < 64u && (((d < 32u ? w.z >> d : w.w >> (d - 32u)) & 1u) != 0u);
+          else if (!WIDE_LISTED) hit = eidx >= w.x && eidx < w.y && window_hit<TRANSITIVE>(e_end, st_se[r].x);  // the count pass's own test
         }
         const unsigned long long b = __ballot(hit);
         if (hit) st_list[wv][cnt + (uint32_t)__popcll(b & lanemask_lt())] = (uint16_t)r;
@@ -2348,7 +2426,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
         const uint32_t r = live ? (uint32_t)st_list[wv][k0 + l] : 0u;
         const int2 se = st_se[r];
         uint32_t p = run + k0 + l;
-        if (!compact) {  // slot = the range's first place + the mask bits below the entry's
+        if (!compact) {  // slot = the range's first place + the mask bits below the entry's (ordered rows / the by-range experiment: narrow windows only)
           const uint4 w = st_win[r];
           const uint32_t d = eidx - w.x;
           const uint32_t below = d < 32u ? (uint32_t)__popc(w.z & ((1u << d) - 1u))
@@ -4954,7 +5032,7 @@ void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32
   const bool lanes = emit_by_lanes(v);
   const int bp = by_place && perm ? 1 : 0;
   if (!bp) se = nullptr;
-  if (lanes) IMPG_HIP(hipMemsetAsync(wide_n, 0, 4, s));
+  if (lanes) IMPG_HIP(hipMemsetAsync(wide_n, 0, 8, s));  // (the wide list's length, and its overflow list's: launch_lookup_emit)
   if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp, se, cnt_ref);
   else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp, se, cnt_ref);
 }
@@ -5085,11 +5163,23 @@ void launch_lookup_emit(const DeviceIndexView &v, const FrontierRec *fr, uint32_
     if (transitive) lookup_emit_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, pl, bp);
     else lookup_emit_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, pair_range, pair_entry, perm, offp, pl, bp);
   }
-  // the listed wide windows only (a small grid: the list is normally short or empty), or everything
-  const uint32_t g = lanes ? std::min(wave_grid(n), 256u) : wave_grid(n);
-  const uint32_t *ln = lanes ? wide_n : nullptr, *ll = lanes ? wide_list : nullptr;
-  if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln, pp);
-  else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, ll, ln, pp);
+  if (lanes) {
+    // the listed wide windows (the list is normally short or empty): a block per range sorts the window's hits by visit rank in
+    // LDS; a range with more hits than its buffer takes goes onto the overflow list (behind the wide list's n entries; its
+    // count is wide_n[1], zeroed with wide_n[0] by the count pass) for the wave-per-range kernel
+    uint32_t *over_list = const_cast<uint32_t *>(wide_list) + n, *over_n = const_cast<uint32_t *>(wide_n) + 1;
+    const uint32_t gw = std::min(n, 4096u);
+    if (transitive) lookup_emit_wide_kernel<true><<<gw, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, wide_list, wide_n, pp, over_list, over_n);
+    else lookup_emit_wide_kernel<false><<<gw, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, wide_list, wide_n, pp, over_list, over_n);
+    const uint32_t g = std::min(wave_grid(n), 256u);
+    if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, over_list, over_n, pp);
+    else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, over_list, over_n, pp);
+    return;
+  }
+  // everything wave per range (ranks too large for the lane kernel's packed keys)
+  const uint32_t g = wave_grid(n);
+  if (transitive) lookup_emit_kernel<true><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, nullptr, nullptr, pp);
+  else lookup_emit_kernel<false><<<g, 256, 0, s>>>(v, fr, n, pair_off, win, pair_range, pair_entry, offp, pl, nullptr, nullptr, pp);
 }
 void launch_small_scan(const uint32_t *cnt, uint32_t n, uint32_t *off, uint32_t *total, hipStream_t s) {
   small_scan_kernel<<<1, 1024, 0, s>>>(cnt, n, off, total);

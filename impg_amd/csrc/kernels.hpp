@@ -94,8 +94,7 @@ struct WindowLists {
   uint32_t n_fr;
   uint32_t *range_out;         // optional: pair_range[] for the per-range counts / the subset filter
   uint32_t masks;              // bit 0: the pairs are named by the windows' hit masks (tile_first is only needed when project_kernel runs the level);
-                               // bit 2: the slots' query ids and sources ({qid, the range's place}) interleaved in HitArrays::qid, one 8-byte store (a kept fused level);
-                               // bit 1: slots by range instead of entry by entry (an experiment: IMPG_ENT_NONCOMPACT)
+                               // bit 2: the slots' query ids and sources ({qid, the range's place}) interleaved in HitArrays::qid, one 8-byte store (a kept fused level)
   uint32_t range_places;       // 1: range_out names a pair's range by its PLACE in the lookup order (perm not applied: no load) -- kept levels, whose frontier copy is taken in that order
   OrderedOut ord;              // rows != null: the kernel writes finished rows (see OrderedOut); range_out and the hit arrays are not used
 };

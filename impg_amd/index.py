@@ -737,6 +737,13 @@ def synth_paf_text(path, seed, n_records, n_seq=200, seq_len=5_000_000, target_s
     return path
 
 
+def synth_skewed_paf_text(path, seed, n_records, n_seq=200, seq_len=5_000_000):
+    """impg_synth_skewed_paf_text: log-normal alignment lengths, 1 % of the sequences holding ~30 % of the entries; returns the ops written."""
+    n = C.c_uint64(0)
+    check(lib().impg_synth_skewed_paf_text(seed, n_records, n_seq, seq_len, path.encode(), C.byref(n)))
+    return int(n.value)
+
+
 def synth_seq_name(i):
     b = C.create_string_buffer(64)
     lib().impg_synth_seq_name(i, b, 64)

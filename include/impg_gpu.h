@@ -561,6 +561,11 @@ int impg_synth_paf(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t seq_
 int impg_synth_paf_text(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t seq_len,
                         int32_t target_span, uint32_t n_blocks, const char *path);
 int impg_synth_seq_name(uint32_t id, char *out, size_t cap);
+/* The non-uniform workload of `bench.py --workload skewed` as PAF text: log-normal target spans (1 kb ... the sequence,
+ * median 8 kb: 20 ... 10^5 ops a CIGAR) and 1 % of the sequences (the first max(1, n_seq / 100)) chosen as target / as query with
+ * probability 0.3 each, i.e. holding ~30 % of a bidirectional index's entries.  Same names and record format as
+ * impg_synth_paf_text; *n_ops_out = CIGAR ops written. */
+int impg_synth_skewed_paf_text(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t seq_len, const char *path, uint64_t *n_ops_out);
 int impg_synth_bed(uint64_t seed, size_t n, uint32_t n_seq, int32_t seq_len, int32_t range_len,
                    impg_gpu_range_t *out);
 

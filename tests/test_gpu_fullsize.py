@@ -235,3 +235,55 @@ def test_headline_batch_prefix_consistency(full, big_batch):
     g.set_option("pair_budget", 1 << 29)
     assert (cnt[:len(ranges)] == cnt0).all() and (ck[:len(ranges)] == ck0).all()
     assert st.projected == int(cnt.sum()) and st.projected > 2_000_000_000
+
+
+# ---- the non-uniform index (bench.py --workload skewed): long CIGARs, hot sequences -------------------------------------------
+@pytest.fixture(scope="module")
+def skewed(tmp_path_factory):
+    d = tmp_path_factory.mktemp("skewed")
+    paf = str(d / "skewed_100k.paf")
+    n_ops = impg_amd.synth_skewed_paf_text(paf, 42, 100_000)
+    assert n_ops > 100_000 * 200  # (mean ~340 ops a record; the longest CIGARs have > 10^4)
+    g = impg_amd.GpuImpg.from_paf(paf)
+    bed = impg_amd.synth_bed(7, 2000)
+    ranges = np.zeros(len(bed), dtype=impg_amd.RANGE_DTYPE)
+    ranges["target_id"] = [g.seq_id(impg_amd.synth_seq_name(int(t))) for t in bed["target_id"]]
+    ranges["start"], ranges["end"] = bed["start"], bed["end"]
+    # a tenth of the ranges on the two hot sequences (1 % of uniform ranges would leave them almost untested)
+    hot = np.arange(0, len(ranges), 10)
+    ranges["target_id"][hot] = [g.seq_id(impg_amd.synth_seq_name(int(k % 2))) for k in range(len(hot))]
+    return paf, g, ranges
+
+
+def test_skewed_index_sample_vs_oracle(skewed):
+    """The non-uniform workload -- log-normal alignment lengths (CIGARs of 20 ... 10^4+ ops: external checkpoints, records of
+    hundreds of tiles) and two sequences holding 30 % of the entries (windows far wider than the 64-entry hit mask: the
+    wave-per-range emit, listed windows inside the fused final level) -- `-x -m 2` and plain: per-range counts and checksums of
+    the whole batch, a sample of them against the oracle (hot ranges included), full rows of a few ranges through
+    impg_gpu_query_batch, and the rows left in HBM (attributed layout) against the counting form."""
+    paf, g, ranges = skewed
+    c = o.OracleIndex(paf_paths=[paf], preparse=True)
+    g.set_option("chunk_ranges", 500)
+    for kw in (dict(), dict(transitive=True, max_depth=2)):
+        p = impg_amd.make_params(**kw)
+        st, cnt, ck = g.query_batch_stats(ranges, p)
+        assert st.projected == int(cnt.sum())
+        hot = [i for i in range(0, len(ranges), 10)]
+        assert max(int(cnt[i]) for i in hot) > 64 * (3 if kw else 1)  # windows wider than the hit mask are in play
+        rng = np.random.default_rng(2)
+        sample = sorted(set(rng.integers(0, len(ranges), 12).tolist()) | set(hot[:6]))
+        for i in sample:
+            r = ranges[i]
+            want = c.query(int(r["target_id"]), int(r["start"]), int(r["end"]), **kw)
+            assert int(cnt[i]) == len(want) - 1, (kw, i)
+            assert int(ck[i]) == checksum(want[1:]), (kw, i)
+        sub = ranges[[hot[0], hot[1], 1, 2]]
+        res = g.query_batch(sub, p)
+        for k in range(len(sub)):
+            r = sub[k]
+            assert res[k].tolist() == c.query(int(r["target_id"]), int(r["start"]), int(r["end"]), **kw).tolist(), (kw, k)
+        dr = g.query_batch_device(ranges, p)
+        cnt2, ck2 = dr.check()
+        dr.free()
+        assert (cnt2 == cnt).all() and (ck2 == ck).all()
+    g.set_option("chunk_ranges", 4096)

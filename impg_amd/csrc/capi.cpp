@@ -724,9 +724,20 @@ int impg_gpu_query_batch_stream(impg_gpu_index_t *ix, const impg_gpu_range_t *ra
                                 const impg_gpu_mask_t *mask, const uint8_t *subset_keep, size_t chunk_ranges, size_t max_block_bytes,
                                 impg_gpu_stream_cb cb, void *ctx, uint64_t *projected_out) {
   IMPG_TRY
-  if (!ix || !params || !cb || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
-  check_ranges(ranges, n);
-  Engine::check_params(*params);
+  if (!ix) throw Error{IMPG_E_INVALID, "null argument"};
+  // On a rank's shard the call is collective and opens with an agreement on the number of chunks: a rank whose own
+  // arguments are refused must still take part in it -- its peers are already waiting there -- and says so with the word it
+  // contributes, so that every rank leaves together (the refused one with its own error).
+  const bool collective = ix->shard && !ix->cluster;
+  std::exception_ptr refused;
+  try {
+    if (!params || !cb || (!ranges && n)) throw Error{IMPG_E_INVALID, "null argument"};
+    check_ranges(ranges, n);
+    Engine::check_params(*params);
+  } catch (...) {
+    if (!collective) throw;
+    refused = std::current_exception();
+  }
   if (!chunk_ranges) chunk_ranges = 8192;
   if (!max_block_bytes) max_block_bytes = 5ull << 29;  // 2.5 GiB: two such blocks go back into the pinned pool (6 GiB) after the call
   const uint64_t max_rows = std::max<uint64_t>(1, max_block_bytes / sizeof(impg_gpu_interval_t));
@@ -737,8 +748,10 @@ int impg_gpu_query_batch_stream(impg_gpu_index_t *ix, const impg_gpu_range_t *ra
     // counts differ -- and a rank that has run out of ranges, or whose consumer has stopped it, keeps taking part with
     // empty chunks until the longest stream is through (its peers' hops need its shard).
     uint64_t my_chunks = std::max<uint64_t>(1, (n + chunk_ranges - 1) / chunk_ranges), n_chunks = my_chunks;
-    if (ix->shard && !ix->cluster) {
-      n_chunks = shard_agree_max(*ix, my_chunks);
+    if (collective) {
+      n_chunks = shard_agree_max(*ix, refused ? ~0ull : my_chunks);
+      if (refused) std::rethrow_exception(refused);
+      if (n_chunks == ~0ull) throw Error{IMPG_E_INVALID, "a peer rank's arguments to the row stream were refused: no rank runs it"};
     }
     bool cancelled = false;
     for (uint64_t c = 0; c < n_chunks; c++) {

@@ -400,13 +400,18 @@ struct impg_gpu_index {
   bool multi_file = false;
   bool tp_mode = false;  // built from tracepoints: every projection is the approximate one
   void bind_view(uint32_t n_seq, uint32_t sorted_order);  // view pointers from the device arrays
-  size_t device_bytes = 0;
+  std::atomic<size_t> device_bytes{0};
   // The identity lines (idp[] beside prefix lines: a third of the index, read by the identity filter only) are built on
   // the device the first time a query asks for min_gap_compressed_identity -- from the op lines, byte for byte what the
   // builders write when IMPG_IDENTITY_LINES=1 -- so that an index nobody filters costs 2.2 KB a record, not 3.2.
   std::mutex idl_m;
   void ensure_identity_lines();
-  bool lacks_identity_lines() const { return !tp_mode && n_tiles && blob_bytes[14] && !blob_bytes[12]; }
+  // (the fast path of every filtered query reads this without the lock: an acquire load of a flag that is stored, with
+  // release, after view.idp -- a handle serves up to max_engines callers at once)
+  std::atomic<bool> has_identity_lines{false};
+  bool lacks_identity_lines() const {
+    return !tp_mode && n_tiles && blob_bytes[14] && !has_identity_lines.load(std::memory_order_acquire);
+  }
   // engines (engine.cpp: stream + scratch + the visited sets of one batch in flight), handed out by EngineLease
   std::vector<std::unique_ptr<impg::Engine>> engines;
   std::vector<impg::Engine *> eng_free;

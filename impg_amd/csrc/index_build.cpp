@@ -640,6 +640,7 @@ void impg_gpu_index::bind_view(uint32_t n_seq, uint32_t sorted_order) {
   view.ops = d_ops.as<uint32_t>();
   view.ext_cp = d_ext_cp.as<uint32_t>();
   view.idp = d_idp.as<uint4>();
+  has_identity_lines.store(blob_bytes[12] != 0, std::memory_order_release);  // (built / loaded with them, or built on demand later)
   view.pfx = blob_bytes[14] ? d_pfx.as<uint32_t>() : nullptr;  // (an index may come without prefix lines)
   view.seq_len = d_seq_len.as<int32_t>();
   view.n_seq = n_seq;

@@ -723,12 +723,21 @@ void impg_gpu_index::ensure_identity_lines() {
     throw Error{IMPG_E_OOM, "not enough device memory for the identity lines of this index (" + std::to_string(bytes >> 20) +
                                 " MiB, built when a query first filters by min_gap_compressed_identity)"};
   }
-  if (n_entries)
-    identity_lines_kernel<<<(unsigned)((n_entries + 3) / 4), 256>>>(d_entries.as<Entry>(), (uint32_t)n_entries, d_ops.as<uint32_t>(),
-                                                                     d_idp.as<uint32_t>());
-  IMPG_HIP(hipDeviceSynchronize());
+  // (on a stream of its own, and only that stream is waited for: the handle's other engines keep running.  A launch failure
+  // shows in hipGetLastError, not in the synchronisation: the lines count as built only once both have been checked.)
+  struct Stream {
+    hipStream_t s = nullptr;
+    Stream() { IMPG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+    ~Stream() { if (s) (void)hipStreamDestroy(s); }
+  } st;
+  if (n_entries) {
+    identity_lines_kernel<<<(unsigned)((n_entries + 3) / 4), 256, 0, st.s>>>(d_entries.as<Entry>(), (uint32_t)n_entries, d_ops.as<uint32_t>(),
+                                                                            d_idp.as<uint32_t>());
+    IMPG_HIP(hipGetLastError());
+  }
+  IMPG_HIP(hipStreamSynchronize(st.s));
   view.idp = d_idp.as<uint4>();
   blob_bytes[12] = bytes;
   device_bytes += bytes;
+  has_identity_lines.store(true, std::memory_order_release);  // (published last: a reader that sees it sees view.idp)
 }
-

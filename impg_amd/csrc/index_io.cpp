@@ -16,9 +16,11 @@ namespace impg {
 namespace {
 
 constexpr char MAGIC[8] = {'I', 'M', 'P', 'G', 'H', 'B', 'M', '1'};
-constexpr uint32_t VERSION = 5;  // 2: checksum of the arrays behind the end mark; 3: tile padding words carry length 0, prefix lines;
+constexpr uint32_t VERSION = 6;  // 2: checksum of the arrays behind the end mark; 3: tile padding words carry length 0, prefix lines;
                                  // 4: the checksum also covers the header and the host tables, and the per-target offsets are mandatory;
                                  // 5: indexes with prefix lines carry identity lines (IDL_*) instead of per-sub-tile identity prefixes
+                                 // 6: ... or none (flag 32: they are built on the device when a query first filters by identity; a
+                                 //    version-5 reader would reject such a file as a size mismatch instead of by its version)
 
 struct Header {  // fixed-size, little-endian (gfx950 hosts are x86-64)
   char magic[8];

@@ -450,6 +450,14 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
     wlists = WindowLists{tile_first.as<uint32_t>(), pair_off.as<uint32_t>(), win.as<uint4>(), win_se.as<FrontierRec>(), d_perm, n_fr,
                          fuse_need_ranges && !direct ? L.pair_range.as<uint32_t>() : nullptr, 1u, fuse_range_places ? 1u : 0u};
     last_range_places = fuse_need_ranges && fuse_range_places && !direct;
+    if (project_entry_major(v, P, min_identity) && !store_cigar) {  // the slice list and the range blocks' place counters of its heavy blocks
+      const uint32_t cap = project_entry_slice_cap(P), nb = project_entry_blocks(n_fr);
+      ent_work.reserve(((size_t)cap + 1) * 4);
+      ent_alloc.reserve(std::max<size_t>((size_t)nb * 4, 256));
+      IMPG_HIP(hipMemsetAsync(ent_work.p, 0, 4, stream));
+      IMPG_HIP(hipMemsetAsync(ent_alloc.p, 0, (size_t)nb * 4, stream));
+      wlists.slice_work = ent_work.as<uint32_t>(); wlists.slice_alloc = ent_alloc.as<uint32_t>(); wlists.slice_cap = cap;
+    }
     // (a kept fused level: query id and source of a slot as one {qid, place} pair in L.qid -- one store instead of two)
     L.qs_interleaved = last_range_places && project_entry_major(v, P, min_identity) && !(min_identity == min_identity) && !store_cigar && !getenv("IMPG_NO_QS");  // (IMPG_NO_QS: A/B)
     if (L.qs_interleaved) { wlists.masks |= 4u; wlists.range_out = nullptr; }

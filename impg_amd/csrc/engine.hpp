@@ -121,6 +121,7 @@ struct Engine {
   void ordered_offsets();                                                                                   // once every level is counted
   void ordered_finish(std::vector<std::unique_ptr<LevelBufs>> &levels);                                       // self rows + the levels not yet placed
   float ms_place = 0;
+  DevBuf ent_work, ent_alloc;      // project_entries_kernel: the slice list of its heavy blocks, a place counter per range block
   DevBuf win_se, tile_first;       // the ranges' (start, end) by place; first range of every projection tile
   int filter_covered = 0;          // option "filter_covered": hits covered by their group's old list dropped before the replay (0 off: it bought nothing on config 5, where hits are covered by the list as it GROWS, not as the level found it; 1 always, 2 long groups)
   uint64_t covered_dropped = 0;    // ... how many that was, over the engine's life (tuning aid)

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void lookup_emit_kernel(DeviceIndexView v, con
 // written out in visit order -- O(W + H log^2 H) per range.  (The wave-per-range kernel above ranks every hit against every
 // other with a readlane loop, O(W x H): 98 % of a skewed step, 3.2 s.)  More than WIDE_CAP hits: the range goes onto
 // the overflow list and the kernel above takes it.
-constexpr uint32_t WIDE_CAP = 4096;
+constexpr uint32_t WIDE_CAP = 4096, WIDE_BINS = 1024;
 template <bool TRANSITIVE>
 __global__ __launch_bounds__(256) void lookup_emit_wide_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr, uint32_t n,
                                                                const uint32_t *__restrict__ pair_off, const uint4 *__restrict__ win,
@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void lookup_emit_wide_kernel(DeviceIndexView v
                                                                const uint32_t *__restrict__ list_n, const uint32_t *__restrict__ place_perm,
                                                                uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_n) {
   __shared__ unsigned long long keys[WIDE_CAP];
-  __shared__ uint32_t s_cnt;
+  __shared__ uint32_t hist[WIDE_BINS];
+  __shared__ uint16_t gb[WIDE_BINS + 2];  // group g = rank bins [gb[g], gb[g + 1])
+  __shared__ uint32_t s_cnt, s_ng;
   const int32_t *ecol = end_col<TRANSITIVE>(v);
   uint32_t *const slot_of = pl.slot;
   const uint32_t n_items = min(*list_n, n), tid = threadIdx.x;
@@ -342,47 +344,93 @@ __global__ __launch_bounds__(256) void lookup_emit_wide_kernel(DeviceIndexView v
     const uint32_t off = pair_off[item], po = slot_of ? offp[r] : 0u;
     const uint32_t lo = w.x, ub = w.y;
     const int32_t qs = fr[r].start;
-    if (tid == 0) s_cnt = 0u;
+    // a hit's sort key: its visit rank (its place in the window under the sorted order policy), below `dom`
+    const uint32_t dom = v.sorted_order ? ub - lo : max(v.max_seg, 1u);
+    uint32_t shift = 0;
+    while ((dom >> shift) > WIDE_BINS) shift++;
+    if (dom >> shift == WIDE_BINS && (dom & ((1u << shift) - 1u))) shift++;  // (every key >> shift below WIDE_BINS)
+    // the window's hits whose rank bin lies in [b0, b1), in visit order, to the range's slots from `at` on; returns their number
+    // (or more than WIDE_CAP, nothing written: the caller splits the bins)
+    auto emit_bins = [&](uint32_t b0, uint32_t b1, uint32_t at) -> uint32_t {
+      if (tid == 0) s_cnt = 0u;
+      __syncthreads();
+      for (uint32_t base = lo; base < ub; base += 256u) {
+        const uint32_t i = base + tid;
+        bool hit = i < ub && window_hit<TRANSITIVE>(ecol[i], qs);
+        uint32_t rk = 0;
+        if (hit) {
+          rk = v.sorted_order ? i - lo : v.rank[i];
+          const uint32_t bin = rk >> shift;
+          hit = bin >= b0 && bin < b1;
+        }
+        const unsigned long long m = __ballot(hit);
+        uint32_t wb = 0;
+        if (lane_id() == 0 && m) wb = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+        wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
+        const uint32_t pos = wb + (uint32_t)__popcll(m & lanemask_lt());
+        if (hit && pos < WIDE_CAP) keys[pos] = ((unsigned long long)rk << 32) | i;
+      }
+      __syncthreads();
+      const uint32_t H = s_cnt;
+      if (H > WIDE_CAP) return H;
+      uint32_t P2 = 64u;
+      while (P2 < H) P2 <<= 1;
+      for (uint32_t k = H + tid; k < P2; k += 256u) keys[k] = ~0ull;
+      __syncthreads();
+      for (uint32_t k = 2u; k <= P2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+          for (uint32_t t = tid; t < (P2 >> 1); t += 256u) {
+            const uint32_t a = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), b = a | j;  // the t-th pair at distance j
+            const bool up = (a & k) == 0u;
+            const unsigned long long x = keys[a], y = keys[b];
+            if ((x > y) == up) { keys[a] = y; keys[b] = x; }
+          }
+          __syncthreads();
+        }
+      }
+      for (uint32_t k = tid; k < H; k += 256u) {
+        const uint32_t e = (uint32_t)keys[k];
+        pair_range[off + at + k] = r;
+        if (pair_entry) pair_entry[off + at + k] = e;
+        if (slot_of) { slot_of[po + at + k] = off + at + k; pl.range[po + at + k] = r; pl.entry[po + at + k] = e; }
+      }
+      __syncthreads();
+      return H;
+    };
+    const uint32_t H = emit_bins(0u, WIDE_BINS, 0u);
+    if (H <= WIDE_CAP) continue;
+    // more hits than the buffer takes (a thousand-fold repeat): the rank bins' histogram, bins gathered into groups of at most
+    // WIDE_CAP hits, a collect-sort-write pass per group -- the window is read once more per group
+    for (uint32_t b = tid; b < WIDE_BINS; b += 256u) hist[b] = 0u;
     __syncthreads();
     for (uint32_t base = lo; base < ub; base += 256u) {
       const uint32_t i = base + tid;
-      const bool hit = i < ub && window_hit<TRANSITIVE>(ecol[i], qs);
-      const unsigned long long m = __ballot(hit);
-      uint32_t wb = 0;
-      if (lane_id() == 0 && m) wb = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
-      wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
-      const uint32_t pos = wb + (uint32_t)__popcll(m & lanemask_lt());
-      if (hit && pos < WIDE_CAP) keys[pos] = ((unsigned long long)(v.sorted_order ? i : v.rank[i]) << 32) | i;
+      if (i < ub && window_hit<TRANSITIVE>(ecol[i], qs)) atomicAdd(&hist[(v.sorted_order ? i - lo : v.rank[i]) >> shift], 1u);
     }
     __syncthreads();
-    const uint32_t H = s_cnt;
-    if (H > WIDE_CAP) {  // (block-uniform) more hits than the buffer takes: the wave-per-range kernel's turn
+    if (tid == 0) {
+      uint32_t ng = 0, acc = 0;
+      bool bad = false;
+      gb[0] = 0;
+      for (uint32_t b = 0; b < WIDE_BINS; b++) {
+        const uint32_t c = hist[b];
+        bad = bad || c > WIDE_CAP;
+        if (acc + c > WIDE_CAP) { ng++; gb[ng] = (uint16_t)b; acc = 0; }
+        acc += c;
+      }
+      ng++;
+      gb[ng] = (uint16_t)WIDE_BINS;
+      s_ng = bad ? 0u : ng;
+    }
+    __syncthreads();
+    const uint32_t ng = s_ng;
+    if (!ng) {  // one bin alone overflows the buffer: the wave-per-range kernel's turn (correct, quadratic)
       if (tid == 0) over_list[atomicAdd(over_n, 1u)] = item;
       __syncthreads();
       continue;
     }
-    uint32_t P2 = 64u;
-    while (P2 < H) P2 <<= 1;
-    for (uint32_t k = H + tid; k < P2; k += 256u) keys[k] = ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2u; k <= P2; k <<= 1) {
-      for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
-        for (uint32_t t = tid; t < (P2 >> 1); t += 256u) {
-          const uint32_t a = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), b = a | j;  // the t-th pair at distance j
-          const bool up = (a & k) == 0u;
-          const unsigned long long x = keys[a], y = keys[b];
-          if ((x > y) == up) { keys[a] = y; keys[b] = x; }
-        }
-        __syncthreads();
-      }
-    }
-    for (uint32_t k = tid; k < H; k += 256u) {
-      const uint32_t e = (uint32_t)keys[k];
-      pair_range[off + k] = r;
-      if (pair_entry) pair_entry[off + k] = e;
-      if (slot_of) { slot_of[po + k] = off + k; pl.range[po + k] = r; pl.entry[po + k] = e; }
-    }
-    __syncthreads();
+    uint32_t at = 0;
+    for (uint32_t g = 0; g < ng; g++) at += emit_bins(gb[g], gb[g + 1u], at);
   }
 }
 
@@ -2220,12 +2268,31 @@ __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, ui
 // MODE: 0, or MODE_IDENT -- the identity filter (round 5: `--min-result-identity` used to send the whole final level back to the
 // lane-per-pair kernel, 42 ms of projection a headline step against 21.7 plain); the slice's counts come off the identity
 // lines in the index (a wave's 64 lanes read the same record's <= 8 lines: L1 hits), everything else as in the plain form.
+// Heavy blocks are SLICED (round 6): a block whose 512 ranges list more than ENT_SLICE_PAIRS pairs -- repeat hot spots: a
+// thousand hits a range, 7 x 10^5 pairs where the headline's block has 13 000 -- would run alone on its CU long after the rest
+// of the grid has drained (the skewed workload's final level: ~80 such blocks, 3 x 10^9 pairs/s).  Its first launch
+// (phase 0) takes every n-th entry of the span and leaves the other n - 1 slices on a work list for a second launch
+// (phase 1), whose blocks load the same ranges and take the other entries; the slices share the block's places through
+// one global counter a range block.
+constexpr uint32_t ENT_SLICE_PAIRS = 32768u, ENT_MAX_SLICES = 64u;
+struct EntSlices {
+  uint32_t *work;   // [0] items listed, [1 ..] sblock << 12 | slice << 6 | (slices - 1)
+  uint32_t *alloc;  // [range blocks] places handed out so far (zeroed before phase 0)
+  uint32_t cap;     // items the list takes
+  int phase;
+};
 template <bool TRANSITIVE, int MODE, int OUT>
 __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry, uint32_t n_pairs,
                                                       HitArrays h, unsigned long long *__restrict__ accepted,
-                                                      uint32_t *__restrict__ err_flag, int regroup, WindowLists wl, double min_identity) {
+                                                      uint32_t *__restrict__ err_flag, int regroup, WindowLists wl, double min_identity, EntSlices sl) {
   const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t sblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  uint32_t sblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  uint32_t slice = 0u, n_slices = 1u;
+  if (sl.phase) {  // one listed slice a block (the launch covers the list's capacity; most of its blocks leave here)
+    if (blockIdx.x >= min(sl.work[0], sl.cap)) return;
+    const uint32_t item = sl.work[1u + blockIdx.x];
+    sblock = item >> 12; slice = (item >> 6) & 63u; n_slices = (item & 63u) + 1u;
+  }
   __shared__ uint4 st_work[ENT_REC_V4 + ENT_LIST_V4];
   uint4 (*st_rec)[ENT_REC_STRIDE / 4u] = reinterpret_cast<uint4 (*)[ENT_REC_STRIDE / 4u]>(st_work);  // a wave's current record: its prefix lines (padded)
   uint16_t (*st_list)[ENT_RANGES] = reinterpret_cast<uint16_t (*)[ENT_RANGES]>(st_work + ENT_REC_V4);  // a wave's list of the ranges that hit its entry
@@ -2320,6 +2387,16 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   // few pairs for the entries they touch (a sparse stretch of the level): fetching a record for a pair or two would read
   // more than the pairs do -- by place, regrouped, from the index (the ranges listed instead take the same path there)
   const bool sparse = emin <= emax && (unsigned long long)(P1 - P0) < 4ull * (emax - emin + 1u);
+  if (!sl.phase && sl.work && !sparse && emin <= emax && P1 - P0 > ENT_SLICE_PAIRS && (uint32_t)__builtin_amdgcn_readfirstlane((int)st_nwide) == 0u) {
+    // (block-uniform) a heavy block: this launch takes slice 0, the others go onto the list (which cannot overflow: the
+    // slices beyond the first number at most P / ENT_SLICE_PAIRS over the whole level, and that is its capacity)
+    n_slices = min(ENT_MAX_SLICES, (P1 - P0 + ENT_SLICE_PAIRS - 1u) / ENT_SLICE_PAIRS);
+    if (threadIdx.x == 0) {
+      const uint32_t at = atomicAdd(&sl.work[0], n_slices - 1u);
+      for (uint32_t k = 1; k < n_slices; k++)
+        if (at + k - 1u < sl.cap) sl.work[1u + at + k - 1u] = sblock << 12 | k << 6 | (n_slices - 1u);
+    }
+  }
   if (sparse) {
     n_ok = project_places<TRANSITIVE, true, false, ENT_RANGES, ENT_THREADS, MODE, OUT>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, 0u, regroup != 0, st_off, st_win,
                                                                st_se, nullptr, st_work PHASE_PASS, min_identity, st_dest);
@@ -2332,10 +2409,11 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
     const uint4 *ents = reinterpret_cast<const uint4 *>(v.entries);
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     const uint32_t n_span = emax - emin + 1u;
-    auto take = [&]() -> uint32_t {  // the next entry of the span (>= n_span: none left)
+    auto take = [&]() -> uint32_t {  // the next entry of the span (>= n_span: none left); a slice takes every n_slices-th
       uint32_t i = 0;
       if (l == 0) i = atomicAdd(&st_next, 1u);
-      return (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+      i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+      return n_slices > 1u ? min(n_span, slice + i * n_slices) : i;
     };
     uint32_t ic = take(), in = take();
     // (an entry's 64 bytes are held as one 16-byte piece in each of lanes 0 .. 3 -- four registers for an entry in flight
@@ -2410,7 +2488,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
       }
       uint32_t run = 0;  // compact: the entry's first place
       if (compact) {
-        if (l == 0) run = atomicAdd(&st_alloc, cnt);
+        if (l == 0) run = n_slices > 1u ? atomicAdd(&sl.alloc[sblock], cnt) : atomicAdd(&st_alloc, cnt);  // (slices share the block's places)
         run = P0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -5245,6 +5323,8 @@ bool project_entry_major(const DeviceIndexView &v, uint64_t n_pairs, double min_
   const bool ident = min_identity == min_identity;
   return project_is_staged(v, n_pairs, true) && entry_major() && (!ident || v.idp != nullptr);
 }
+uint32_t project_entry_blocks(uint32_t n_fr) { return (cdiv(n_fr, ENT_RANGES) + 7u) & ~7u; }
+uint32_t project_entry_slice_cap(uint64_t n_pairs) { return (uint32_t)(n_pairs / ENT_SLICE_PAIRS) + 16u; }
 void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint32_t *pair_range,
                     const uint32_t *pair_entry, uint32_t n_pairs, bool transitive, HitArrays h,
                     unsigned long long *accepted, uint32_t *err_flag, double min_identity, const SliceArrays *slices,
@@ -5281,7 +5361,12 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
     // runs at its scalar-register limit.  The engine asks for rows / {qid, place} pairs only under the plain projection.)
     const int out = wl.ord.rows ? OUT_ROWS : (wl.masks & 4u) ? OUT_QS : OUT_SLOTS;
     if (out != OUT_SLOTS && mode != 0) throw Error{IMPG_E_INVALID, "internal: ordered rows / paired slots under the identity filter"};
-#define IMPG_LAUNCH_ENT(T, M, O) project_entries_kernel<T, M, O><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi)
+    // (heavy blocks are sliced: phase 0 over the range blocks, then phase 1 over the slices phase 0 listed -- a launch of the
+    // list's capacity whose blocks leave at once where nothing was listed, the usual case)
+    EntSlices es{wl.slice_work, wl.slice_alloc, wl.slice_cap, 0};
+    if (!es.work || !es.alloc || !es.cap) es = EntSlices{nullptr, nullptr, 0u, 0};
+#define IMPG_LAUNCH_ENT(T, M, O) do { project_entries_kernel<T, M, O><<<ge, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi, es); \
+      if (es.work) { EntSlices e1 = es; e1.phase = 1; project_entries_kernel<T, M, O><<<es.cap, ENT_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl, mi, e1); } } while (0)
     if (mode == 0) {
       if (out == OUT_ROWS) { if (transitive) IMPG_LAUNCH_ENT(true, 0, OUT_ROWS); else IMPG_LAUNCH_ENT(false, 0, OUT_ROWS); }
       else if (out == OUT_QS) { if (transitive) IMPG_LAUNCH_ENT(true, 0, OUT_QS); else IMPG_LAUNCH_ENT(false, 0, OUT_QS); }

@@ -96,11 +96,15 @@ struct WindowLists {
   uint32_t masks;              // bit 0: the pairs are named by the windows' hit masks (tile_first is only needed when project_kernel runs the level);
                                // bit 2: the slots' query ids and sources ({qid, the range's place}) interleaved in HitArrays::qid, one 8-byte store (a kept fused level)
   uint32_t range_places;       // 1: range_out names a pair's range by its PLACE in the lookup order (perm not applied: no load) -- kept levels, whose frontier copy is taken in that order
+  uint32_t *slice_work, *slice_alloc;  // project_entries_kernel's heavy blocks (EntSlices): the slice list [1 + slice_cap] (word 0 zeroed), a
+  uint32_t slice_cap;                  // counter per range block (zeroed); slice_cap >= n_pairs / 32768 + 1.  Null / 0: blocks are taken whole
   OrderedOut ord;              // rows != null: the kernel writes finished rows (see OrderedOut); range_out and the hit arrays are not used
 };
 // whether launch_project will run a plain projection of n_pairs by-place pairs on the staged kernels (no tile_first[] needed)
 bool project_is_staged(const DeviceIndexView &v, uint64_t n_pairs, bool plain);
-bool project_entry_major(const DeviceIndexView &v, uint64_t n_pairs, double min_identity);  // ... on project_entries_kernel (a level named by hit masks)
+bool project_entry_major(const DeviceIndexView &v, uint64_t n_pairs, double min_identity);
+uint32_t project_entry_blocks(uint32_t n_fr);          // range blocks of project_entries_kernel over n_fr ranges
+uint32_t project_entry_slice_cap(uint64_t n_pairs);    // what its slice list must take  // ... on project_entries_kernel (a level named by hit masks)
 void launch_tile_first(const uint32_t *cnt, const uint32_t *pair_off, uint32_t n_fr, uint32_t *tile_first, hipStream_t s);
 bool emit_by_lanes(const DeviceIndexView &v);
 // The pairs listed in projection order (optional: slot == nullptr means the projection runs in slot order):

@@ -1236,6 +1236,55 @@ def test_device_rows_attributed(tmp_path):
             assert e.value.code == impg_amd.IMPG_E_UNSUPPORTED
 
 
+@pytest.mark.parametrize("order", [impg_amd.ORDER_COITREES, impg_amd.ORDER_SORTED])
+def test_windows_of_thousands_of_hits(tmp_path, order):
+    """A repeat hot spot: 9 500 alignments piled on one stretch of a target, so that a range's window holds more hits than the
+    block-per-window emit's 4 096-key buffer (lookup_emit_wide_kernel: rank bins gathered into groups, a collect-sort-write pass
+    per group) -- and ranges beside it with a few hundred and a few dozen.  Rows in visit order against the oracle, plain and
+    transitive, listed and fused final levels, the rows left in HBM in both ordered layouts."""
+    rng = np.random.default_rng(77)
+    L = 400_000
+    lines = []
+    for i in range(9500):
+        a = int(rng.integers(100_000, 100_400))
+        ln = int(rng.integers(300, 900))
+        q = "Q%d" % (i % 37)
+        qa = int(rng.integers(0, L - 2000))
+        lines.append("%s\t%d\t%d\t%d\t%s\tT\t%d\t%d\t%d\t%d\t%d\t60\tcg:Z:%d=" % (q, L, qa, qa + ln, "+-"[i % 2], L, a, a + ln, ln, ln, ln))
+    for i in range(600):  # a milder pile and a sparse stretch on the same target
+        a = int(rng.integers(200_000, 203_000)) if i < 450 else int(rng.integers(250_000, 390_000))
+        ln = int(rng.integers(200, 700))
+        qa = int(rng.integers(0, L - 2000))
+        lines.append("Q%d\t%d\t%d\t%d\t+\tT\t%d\t%d\t%d\t%d\t%d\t60\tcg:Z:%d=" % (i % 37, L, qa, qa + ln, L, a, a + ln, ln, ln, ln))
+    g, c = both(tmp_path, "\n".join(lines) + "\n", order=order, bidirectional=False)
+    if order == impg_amd.ORDER_SORTED:
+        o.set_sorted_visits(True)
+    try:
+        T = g.seq_id("T")
+        ranges = [(T, 100_350, 100_420), (T, 100_000, 101_500), (T, 200_500, 201_000), (T, 300_000, 300_900), (T, 100_399, 100_401)] * 3
+        for kw in [dict(), dict(transitive=True, max_depth=1, min_transitive_len=10), dict(transitive=True, max_depth=2, min_transitive_len=10)]:
+            p = impg_amd.make_params(**kw)
+            want = [c.query(t, s, e, **kw) for (t, s, e) in ranges]
+            assert max(len(w) for w in want) > 4096 + 1
+            for lm in (1, 4096):
+                g.set_option("locality_min", lm)
+                res = g.query_batch(ranges, p)
+                for i in range(len(ranges)):
+                    assert res[i].tolist() == want[i].tolist(), (kw, lm, i)
+                st, cnt, ck = g.query_batch_stats(ranges, p)
+                assert cnt.tolist() == [len(w) - 1 for w in want]
+                for layout in (impg_amd._lib.ROWS_ORDERED, impg_amd._lib.ROWS_ORDERED_SLOTS):
+                    d = g.query_batch_device(ranges, p, layout=layout)
+                    first, rows, off = d.ordered_to_host(0)
+                    d.free()
+                    for i in range(len(ranges)):
+                        r = rows[off[i]:off[i + 1]]
+                        assert r[r["query_id"] != 0xFFFFFFFF].tolist() == want[i].tolist(), (kw, lm, layout, i)
+            g.set_option("locality_min", 4096)
+    finally:
+        o.set_sorted_visits(False)
+
+
 def test_counting_runs_with_slots_in_projection_order(tmp_path):
     """A counting run (nothing kept) under the lookup order lays its hit slots out in projection order, not the
     reference's: per-range counts and checksums must equal those of the full results -- which keep the

@@ -2274,7 +2274,14 @@ __device__ __forceinline__ void project_entry_chunk(const DeviceIndexView &v, ui
 // (phase 0) takes every n-th entry of the span and leaves the other n - 1 slices on a work list for a second launch
 // (phase 1), whose blocks load the same ranges and take the other entries; the slices share the block's places through
 // one global counter a range block.
-constexpr uint32_t ENT_SLICE_PAIRS = 32768u, ENT_MAX_SLICES = 64u;
+#ifndef IMPG_ENT_SLICE_PAIRS
+#define IMPG_ENT_SLICE_PAIRS 32768
+#endif
+constexpr uint32_t ENT_SLICE_PAIRS = IMPG_ENT_SLICE_PAIRS, ENT_MAX_SLICES = 64u;
+#ifndef IMPG_ENT_SPARSE
+#define IMPG_ENT_SPARSE 4
+#endif
+constexpr uint32_t ENT_SPARSE = IMPG_ENT_SPARSE;  // a block with fewer pairs than this per entry of its span runs a lane per place instead
 struct EntSlices {
   uint32_t *work;   // [0] items listed, [1 ..] sblock << 12 | slice << 6 | (slices - 1)
   uint32_t *alloc;  // [range blocks] places handed out so far (zeroed before phase 0)
@@ -2386,7 +2393,7 @@ __global__ __launch_bounds__(ENT_THREADS) ENT_OCCUPANCY void project_entries_ker
   STG_MARK(1);
   // few pairs for the entries they touch (a sparse stretch of the level): fetching a record for a pair or two would read
   // more than the pairs do -- by place, regrouped, from the index (the ranges listed instead take the same path there)
-  const bool sparse = emin <= emax && (unsigned long long)(P1 - P0) < 4ull * (emax - emin + 1u);
+  const bool sparse = emin <= emax && (unsigned long long)(P1 - P0) < (unsigned long long)ENT_SPARSE * (emax - emin + 1u);
   if (!sl.phase && sl.work && !sparse && emin <= emax && P1 - P0 > ENT_SLICE_PAIRS && (uint32_t)__builtin_amdgcn_readfirstlane((int)st_nwide) == 0u) {
     // (block-uniform) a heavy block: this launch takes slice 0, the others go onto the list (which cannot overflow: the
     // slices beyond the first number at most P / ENT_SLICE_PAIRS over the whole level, and that is its capacity)

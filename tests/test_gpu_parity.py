@@ -1173,11 +1173,12 @@ def test_device_rows_attributed(tmp_path):
     for seed, kwp in [(311, dict(n_seq=6, seq_len=20000, weird=True, self_aln=True)), (312, dict(n_seq=60, seq_len=4000, self_aln=True))]:
         text, names = random_paf(seed, 900, **kwp)
         g, c = both(tmp_path, text)
-        ranges = random_ranges(seed + 1, 200, kwp["n_seq"], kwp["seq_len"], max_len=kwp["seq_len"] // 5, min_len=40)
-        for kw in [dict(), dict(transitive=True, max_depth=1, min_transitive_len=20),
-                   dict(transitive=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=0),
-                   dict(transitive=True, max_depth=0, min_transitive_len=30, min_output_length=60),
-                   dict(transitive=True, max_depth=3, min_identity=0.7)]:
+        ranges = random_ranges(seed + 1, 120, kwp["n_seq"], kwp["seq_len"], max_len=kwp["seq_len"] // 5, min_len=40)
+        kws = [dict(), dict(transitive=True, max_depth=1, min_transitive_len=20),
+               dict(transitive=True, max_depth=3, min_transitive_len=20, min_distance_between_ranges=0),
+               dict(transitive=True, max_depth=0, min_transitive_len=30, min_output_length=60),
+               dict(transitive=True, max_depth=3, min_identity=0.7)]
+        for kw in (kws if seed == 311 else kws[:1] + kws[2:4]):
             p = impg_amd.make_params(**kw)
             want, n_proj = [], 0
             for (t, s, e) in ranges:

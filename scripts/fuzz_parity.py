@@ -142,6 +142,36 @@ while time.time() < t_end:
         assert [int(x) for x in ck] == [checksum(res[i][1:]) for i in range(len(ranges))], ("stats checksums", seed, kw, world)
         g.set_option("free_slot_order", 1)
         g.set_option("regroup_entries", 1)
+    # round 6: the same batch with its rows left in HBM (single GPU; plain and BFS without store_cigar / MultiImpg): the
+    # attributed layout's rows as multisets per range + its recomputed counts and checksums, both ordered layouts row for row
+    if world == 1 and mask is None and keep is None and not kw.get("dfs") and not kw.get("multi_impg") and not cigar:
+        pdev = impg_amd.make_params(**kw)
+        mol = kw.get("min_output_length") if kw.get("transitive") else None
+        dr = g.query_batch_device(ranges, pdev)
+        assert dr.projected == total, ("device rows projected", seed, kw)
+        got = [[] for _ in ranges]
+        for k in range(len(dr.parts())):
+            first, level, qid, co, src, fr = dr.part_to_host(k)
+            live = qid != np.uint32(0xFFFFFFFF)
+            if mol is not None:
+                live &= np.abs(co[:, 1].astype(np.int64) - co[:, 0]) >= mol
+            f = fr[src[live]]
+            for q, r, tg in zip((first + f["range_idx"]).tolist(), np.column_stack([qid[live], co[live]]).tolist(), f["target_id"].tolist()):
+                got[q].append((r[0], r[1], r[2], tg, r[3], r[4]))
+        for i in range(len(ranges)):
+            assert sorted(got[i]) == sorted(tuple(int(x) for x in r) for r in res[i][1:].tolist()), ("device rows", seed, i, kw)
+        cnt2, ck2 = dr.check()
+        dr.free()
+        assert cnt2.tolist() == [len(res[i]) - 1 for i in range(len(ranges))], ("device rows counts", seed, kw)
+        assert [int(x) for x in ck2] == [checksum(res[i][1:]) for i in range(len(ranges))], ("device rows checksums", seed, kw)
+        for layout in (impg_amd._lib.ROWS_ORDERED, impg_amd._lib.ROWS_ORDERED_SLOTS):
+            do = g.query_batch_device(ranges, pdev, layout=layout)
+            for k in range(len(do.parts())):
+                first, rows, off = do.ordered_to_host(k)
+                for j in range(len(off) - 1):
+                    r = rows[off[j]:off[j + 1]]
+                    assert r[r["query_id"] != 0xFFFFFFFF].tolist() == res[first + j].tolist(), ("ordered rows", layout, seed, first + j, kw)
+            do.free()
     # text outputs on the ranges long enough for perform_query's validation
     mtl = kw.get("min_transitive_len", 101)
     ok = [i for i, (t, s, e) in enumerate(ranges) if e - s >= mtl]

@@ -337,7 +337,9 @@ def main():
     # the counters of THIS workload's profile (headline: r*_final_*; config 4 / 5: r*_config4_* / r*_config5_*), and only when
     # the run is the profiled configuration -- another index size or the identity filter moves other bytes per pair
     tag = "final" if wl == "headline" else wl
-    profiled = args.min_identity is None and args.records == (50_000_000 if wl == "config4" else 1_000_000)
+    if wl == "config4" and args.records == 100_000_000:
+        tag = "config4_1e8"  # (BASELINE config 4's full 10^8 records: its own profile, profiles/r6_config4_1e8_*)
+    profiled = args.min_identity is None and args.records == (50_000_000 if tag == "config4" else 100_000_000 if tag == "config4_1e8" else 1_000_000)
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % tag))) if profiled else []  # newest round last
     tpath = tfiles[-1] if tfiles else ""
     if os.path.exists(tpath) and launches:

@@ -54,6 +54,7 @@ EngineLease::EngineLease(impg_gpu_index &ix_) : ix(ix_) {
   e->walk_bfs = ix.opt_walk == 2;  // (the environment switch runs a whole test suite on the batch engine)
   e->walk_members = ix.opt_walk_members;
   e->seg_group = ix.opt_seg_group;
+  e->seg_parts_force = ix.opt_seg_parts;
 }
 EngineLease::~EngineLease() {
   e->remote = nullptr;
@@ -526,6 +527,9 @@ int impg_gpu_set_option(impg_gpu_index_t *ix, const char *key, int64_t value) {
     ix->opt_walk = (int)value;
   } else if (k == "segment_groups") {  // the update's hits grouped query by query (1, default) or by the library's radix sort (0); results identical
     ix->opt_seg_group = value != 0;
+  } else if (k == "segment_parts") {  // slices a query's hits are grouped in: 0 = from the level's size (default), n = that many on every level that groups by segments (testing; results identical)
+    if (value < 0 || value > 4096) throw Error{IMPG_E_INVALID, "segment_parts is 0 .. 4096"};
+    ix->opt_seg_parts = (uint32_t)value;
   } else if (k == "walk_members") {  // workgroups per query of the walk's grid form (depth-limited BFS, <= 64 ranges): 0 = as many as fit (<= 32), 1 = no grid form
     if (value < 0 || value > (long long)WALK_MAX_MEMBERS) throw Error{IMPG_E_INVALID, "walk_members is 0 .. 64"};
     ix->opt_walk_members = (uint32_t)value;

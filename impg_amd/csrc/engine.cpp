@@ -618,12 +618,15 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
     // it; with the library's radix sort otherwise.
     uint32_t seg_active = 0, seg_groups = 0;
     uint32_t *sg_run_start = nullptr, *sg_run_end = nullptr, *sg_q = nullptr, *sg_bins = nullptr;
-    bool by_segments = seg_group && !want_flags && !multi && seg_group_fits(v.n_seq) && L.n_frontier > 0 && (uint64_t)P <= 16384ull * n_queries;
+    // (a query with more than a wave's worth of hits is cut into slices of its frontier ranges: seg_group_parts)
+    uint32_t seg_parts = seg_group && !want_flags && !multi && seg_group_fits(v.n_seq) && L.n_frontier > 0 ? seg_group_parts(P, n_queries, v.n_seq) : 0u;
+    if (seg_parts_force && seg_parts) seg_parts = std::max(1u, std::min(seg_parts_force, 4096u));
+    bool by_segments = seg_parts != 0;
     if (by_segments) {
       const uint32_t n_fr = L.n_frontier;
       seg_run.reserve(std::max<size_t>((size_t)n_fr * 8, 256));
       // six words a query -- first / last frontier range, hits with a key, their offset, groups, their offset -- then
-      // `unsorted` and the largest query's hits
+      // `unsorted` and the largest query's (slice's) hits
       seg_q.reserve(std::max<size_t>((size_t)n_queries * 24 + 256, 512));
       sg_run_start = seg_run.as<uint32_t>(); sg_run_end = sg_run_start + n_fr;
       sg_q = seg_q.as<uint32_t>();
@@ -635,17 +638,25 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
       launch_seg_bounds(fr, n_fr, n_queries, L.pair_range.as<uint32_t>(), P, sg_run_start, sg_run_end, qfirst, qlast, unsorted, stream,
                         own_offsets && last_by_place ? lo_perm.as<uint32_t>() : nullptr, own_offsets ? pair_off.as<uint32_t>() : nullptr,
                         own_offsets ? cnt.as<uint32_t>() : nullptr);
-      const size_t bb = seg_group_bins_bytes(n_queries, v.n_seq);
-      if (bb <= (512ull << 20)) { seg_bins.reserve(std::max<size_t>(bb, 256)); sg_bins = seg_bins.as<uint32_t>(); }  // (kept for the place pass)
-      launch_seg_group(true, fr, qfirst, qlast, sg_run_start, sg_run_end, h, n_queries, v.n_seq, qact, qdst, qgrp, gdst, nullptr, nullptr, nullptr, sg_bins,
-                       stream);
-      // both scans and the kernels' two flags behind one synchronisation (the place pass runs below, once the groups' arrays exist)
-      uint64_t ta = 0, tg = 0;
-      uint32_t bad[2] = {0, 0};
-      scan2(qact, qdst, qgrp, gdst, n_queries, ta, tg, unsorted, bad, 2);
-      seg_active = (uint32_t)ta;
-      if (bad[0] || bad[1]) by_segments = false;  // a frontier that is not sorted by query, or one huge query: the library sort below
-      else seg_groups = (uint32_t)tg;
+      for (int attempt = 0; attempt < 2 && by_segments; attempt++) {
+        const size_t bb = seg_group_bins_bytes(n_queries, v.n_seq, seg_parts);
+        sg_bins = nullptr;
+        if (seg_parts > 1 || bb <= (512ull << 20)) { seg_bins.reserve(std::max<size_t>(bb, 256)); sg_bins = seg_bins.as<uint32_t>(); }  // (kept for the place pass)
+        if (seg_parts > 1) seg_tot.reserve(std::max<size_t>(seg_group_bins_bytes(n_queries, v.n_seq, 1), 256));
+        launch_seg_group(true, fr, qfirst, qlast, sg_run_start, sg_run_end, h, n_queries, v.n_seq, qact, qdst, qgrp, gdst, nullptr, nullptr, nullptr, sg_bins,
+                         stream, seg_parts, seg_tot.as<uint32_t>());
+        // both scans and the kernels' two flags behind one synchronisation (the place pass runs below, once the groups' arrays exist)
+        uint64_t ta = 0, tg = 0;
+        uint32_t bad[2] = {0, 0};
+        scan2(qact, qdst, qgrp, gdst, n_queries, ta, tg, unsorted, bad, 2);
+        seg_active = (uint32_t)ta;
+        if (bad[0]) by_segments = false;  // a frontier that is not sorted by query: the library sort below
+        else if (bad[1]) {  // one huge query among small ones (bad[1] = its hits): once more in slices cut for it, or the library sort
+          const uint32_t again = seg_parts == 1 && attempt == 0 ? seg_group_parts(P, n_queries, v.n_seq, bad[1]) : 0u;
+          if (again > 1) { seg_parts = again; IMPG_HIP(hipMemsetAsync(unsorted, 0, 8, stream)); }
+          else by_segments = false;
+        } else { seg_groups = (uint32_t)tg; break; }
+      }
     }
     if (!by_segments) {
       keys.reserve((size_t)P * 8); skeys.reserve((size_t)P * 8); vals.reserve((size_t)P * 8);
@@ -690,7 +701,7 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
         uint32_t *qfirst = sg_q, *qlast = qfirst + n_queries, *qact = qlast + n_queries, *qdst = qact + n_queries, *qgrp = qdst + n_queries,
                  *gdst = qgrp + n_queries;
         launch_seg_group(false, fr, qfirst, qlast, sg_run_start, sg_run_end, h, n_queries, v.n_seq, qact, qdst, qgrp, gdst, gstart.as<uint32_t>(),
-                         vt->keys.as<unsigned long long>(), svals.as<unsigned long long>(), sg_bins, stream);
+                         vt->keys.as<unsigned long long>(), svals.as<unsigned long long>(), sg_bins, stream, seg_parts, seg_tot.as<uint32_t>());
       } else if (want_flags)
         launch_group_scatter(skeys.as<unsigned long long>(), P, head.as<uint32_t>(), gid.as<uint32_t>(), gstart.as<uint32_t>(),
                              vt->keys.as<unsigned long long>(), stream);

@@ -224,7 +224,8 @@ struct Engine {
                 unsigned long long *d_count, unsigned long long *d_cksum, impg_gpu_stats_t *st, WalkRows *rows, uint32_t *h_n_rows = nullptr);
   DevBuf walk_slabs, walk_ctr, walk_ctl;
   DevBuf rstat;  // hit_stats: a level's per-range counts / checksums
-  DevBuf seg_run, seg_q, seg_bins;  // update by segments: run bounds per frontier range; first / last range, active hits and output offset per query
+  DevBuf seg_run, seg_q, seg_bins, seg_tot;  // update by segments: run bounds per frontier range; first / last range, active hits and output offset per query
+  uint32_t seg_parts_force = 0;  // option "segment_parts": every level that groups by segments cuts its queries into this many slices (0: by size)
   bool seg_group = true;  // option "segment_groups": the update's hits grouped query by query instead of by the library's radix sort
   uint32_t walk_members = 0;  // option "walk_members": workgroups per query of the grid form (0: as many as fit, at most 32; 1: no grid form)
   uint32_t walk_group_size(const impg_gpu_index &ix, uint32_t n, const impg_gpu_params_t &p) const;

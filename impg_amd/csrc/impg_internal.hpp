@@ -432,6 +432,7 @@ struct impg_gpu_index {
   int opt_walk = 1;
   uint32_t opt_walk_members = 0;  // option "walk_members" (Engine::walk_members)
   bool opt_seg_group = true;      // option "segment_groups" (Engine::seg_group)
+  uint32_t opt_seg_parts = 0;     // option "segment_parts" (Engine::seg_parts_force)
   mutable std::atomic<uint64_t> walk_launches{0}, walk_fallbacks{0}, walk_last_members{1};  // impg_gpu_get_counter
   impg::ShardCtx *shard = nullptr;    // set: this index is one rank's shard; queries are collective calls
   impg::Cluster *cluster = nullptr;   // set: this handle fronts n_dev shards in this process (no arrays of its own)

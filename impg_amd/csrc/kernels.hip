@@ -2066,7 +2066,7 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
 // level); else by the emit pass's list pair_entry[place] (slots by place, kernels.hpp).  Either way a block takes
 // STG_RANGES consecutive ranges of the lookup order and all their places -- wl.pair_off[], the windows and the
 // ranges' (start, end) go to LDS first, so a place finds its range, its entry and the range's ends without leaving the CU.
-template <bool TRANSITIVE, bool MASKS>
+template <bool TRANSITIVE, bool MASKS, int OUT = OUT_SLOTS>
 __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kernel(DeviceIndexView v, const uint32_t *__restrict__ pair_entry,
                                                       uint32_t n_pairs, HitArrays h, unsigned long long *__restrict__ accepted,
                                                       uint32_t *__restrict__ err_flag, int regroup, WindowLists wl) {
@@ -2078,11 +2078,13 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
   __shared__ uint4 st_win[STG_RANGES];
   __shared__ int2 st_se[STG_RANGES];
   __shared__ uint32_t st_off[STG_RANGES + 4u];
+  __shared__ uint32_t st_dest[OUT == OUT_ROWS ? STG_RANGES : 1u];  // (ordered rows: the ranges' first rows)
   __shared__ uint32_t wred[2u * STG_WAVES];
   __shared__ uint32_t wcnt[STG_WAVES];
   const uint32_t r0 = sblock * STG_RANGES;
   if (r0 >= wl.n_fr) return;  // (block-uniform: the grid is rounded up to the 8 XCDs)
   const uint32_t nr = min(STG_RANGES, wl.n_fr - r0);
+  if (OUT == OUT_ROWS && threadIdx.x < nr) st_dest[threadIdx.x] = wl.ord.dest[r0 + threadIdx.x];
 #ifdef IMPG_PHASE_CLOCKS
   unsigned long long stg_t[8], phase_t[10];
 #define STG_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stg_t[i] = __builtin_readcyclecounter(); } while (0)
@@ -2153,8 +2155,9 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
     __syncthreads();
   }
   STG_MARK(2);
-  n_ok = project_places<TRANSITIVE, MASKS>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, n_e, sparse && regroup != 0, st_off, st_win,
-                                           st_se, st_ent, st_line PHASE_PASS);
+  n_ok = project_places<TRANSITIVE, MASKS, true, STG_RANGES, STG_THREADS, 0, OUT>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, n_e,
+                                                                                  sparse && regroup != 0, st_off, st_win, st_se, st_ent, st_line PHASE_PASS,
+                                                                                  0.0, st_dest);
 #ifdef IMPG_PHASE_CLOCKS
   STG_MARK(3);
   if ((blockIdx.x & 15u) == 0u && threadIdx.x == 0u) {
@@ -2939,6 +2942,12 @@ constexpr uint32_t SEG_MAX_SEQ = 2048, SEG_WAVES = 4;
 // (a query is one wave's work, hit after hit: beyond this many hits in one query -- a saturating closure's deep levels have
 // 10^5-10^6 -- the library sort's parallelism wins: config 5's update 0.66 s per 4 000 windows sorted, 2.65 s by segments)
 constexpr uint32_t SEG_BIG_QUERY = 32768;
+// Past that a query is cut into `parts` slices of its frontier ranges, a wave each (round 6): the count pass leaves every
+// slice's sequence counters in qbins, seg_parts_scan_kernel turns them into the slice's offset inside each of the query's
+// sequences (an exclusive scan over the slices: slice order = frontier order, so the order stays the stable one) and adds
+// the query's totals up; the place pass starts every sequence's counter at (the sequence's offset in the query) + (the
+// slice's offset in the sequence).  A slice that still holds more than SEG_BIG_SLICE hits sends the level to the library.
+constexpr uint32_t SEG_SLICE_HITS = 8192, SEG_BIG_SLICE = 131072, SEG_MAX_PARTS = 4096;
 __global__ __launch_bounds__(256) void run_bounds_kernel(const uint32_t *__restrict__ pair_range, uint32_t n, uint32_t *__restrict__ run_start,
                                                          uint32_t *__restrict__ run_end) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -3019,21 +3028,28 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void seg_group_kernel(const Frontie
                                                                    uint32_t nbits, uint32_t *__restrict__ qact, const uint32_t *__restrict__ qdst,
                                                                    uint32_t *__restrict__ qgrp, const uint32_t *__restrict__ gdst,
                                                                    uint32_t *__restrict__ gstart, unsigned long long *__restrict__ gkey,
-                                                                   unsigned long long *__restrict__ svals, uint32_t *__restrict__ qbins) {
+                                                                   unsigned long long *__restrict__ svals, uint32_t *__restrict__ qbins,
+                                                                   uint32_t parts, uint32_t *__restrict__ qtot) {
   extern __shared__ __attribute__((aligned(16))) uint32_t seg_bins[];  // SEG_WAVES x nb sequence counters
   const uint32_t w = threadIdx.x >> 6, lane = lane_id();
-  const uint32_t q = blockIdx.x * SEG_WAVES + w;
-  if (q >= n_queries) return;  // (no barrier below: the waves of a block share nothing)
-  const uint32_t f0 = qfirst[q], f1 = qlast[q];
-  if (f0 >= f1) { if (COUNT_ONLY && lane == 0) { qact[q] = 0u; qgrp[q] = 0u; } return; }
+  const uint32_t u = blockIdx.x * SEG_WAVES + w;  // the unit: a query, or one of the `parts` slices of a query's frontier ranges
+  if (u >= n_queries * parts) return;  // (no barrier below: the waves of a block share nothing)
+  const bool sliced = parts > 1u;
+  const uint32_t q = sliced ? u / parts : u, part = u - q * parts;
+  uint32_t f0 = qfirst[q], f1 = qlast[q];
+  if (sliced) {
+    const uint32_t len = f1 > f0 ? f1 - f0 : 0u;
+    f1 = f0 + (uint32_t)(((unsigned long long)len * (part + 1u)) / parts);
+    f0 = f0 + (uint32_t)(((unsigned long long)len * part) / parts);
+  } else if (f0 >= f1) { if (COUNT_ONLY && lane == 0) { qact[q] = 0u; qgrp[q] = 0u; } return; }
   uint32_t *bins = seg_bins + w * nb;
-  // pass A: the query's hits per sequence (the place pass reads the count pass's counters back when they were kept: nb
-  // words a query, instead of walking the query's scattered runs once more)
+  // pass A: the unit's hits per sequence (the place pass reads the count pass's counters back when they were kept: nb
+  // words a unit, instead of walking its scattered runs once more)
   if (COUNT_ONLY || !qbins) {
     for (uint32_t b = lane; b < nb; b += 64u) bins[b] = 0u;
     __builtin_amdgcn_wave_barrier();
     seg_for_chunks<false>(fr, run_start, run_end, h, f0, f1, [&](uint32_t qid, const int4 &, bool active) { if (active) atomicAdd(&bins[qid], 1u); });
-  } else {
+  } else if (!sliced) {
     for (uint32_t b = lane; b < nb; b += 64u) bins[b] = qbins[(size_t)q * nb + b];
   }
   __builtin_amdgcn_wave_barrier();
@@ -3042,28 +3058,30 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void seg_group_kernel(const Frontie
     for (uint32_t b = lane; b < nb; b += 64u) {
       const uint32_t x = bins[b];
       cnt += x; grp += x ? 1u : 0u;
-      if (qbins) qbins[(size_t)q * nb + b] = x;
+      if (qbins) qbins[(size_t)u * nb + b] = x;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { cnt += (uint32_t)__shfl_xor((int)cnt, o); grp += (uint32_t)__shfl_xor((int)grp, o); }
     if (lane == 0) {
-      qact[q] = cnt; qgrp[q] = grp;
-      if (cnt > SEG_BIG_QUERY) atomicMax(qact + 4u * (size_t)n_queries + 1u, cnt);  // (the word behind `unsorted`: Engine::update lays the six per-query arrays out)
+      if (!sliced) { qact[q] = cnt; qgrp[q] = grp; }  // (sliced: seg_parts_scan_kernel adds the slices up)
+      // (the word behind `unsorted`: Engine::update lays the six per-query arrays out)
+      if (cnt > (sliced ? SEG_BIG_SLICE : SEG_BIG_QUERY)) atomicMax(qact + 4u * (size_t)n_queries + 1u, cnt);
     }
     return;
   }
   // the sequences' offsets inside the query's stretch of the output; a sequence with hits is a group: its start, its key
+  // (sliced: the query's totals from qtot, the slice's own offset inside each sequence from qbins; slice 0 names the groups)
   const uint32_t dst0 = qdst[q];
   const unsigned long long khi = (unsigned long long)q << 32;
   uint32_t carry = 0, g = gdst[q];
   for (uint32_t b = 0; b < nb; b += 64u) {
-    const uint32_t x = bins[b + lane];
+    const uint32_t x = sliced ? qtot[(size_t)q * nb + b + lane] : bins[b + lane];
     const uint32_t inc = wave_incl_scan(x);
     const uint32_t off = carry + inc - x;
-    bins[b + lane] = off;
+    bins[b + lane] = off + (sliced ? qbins[(size_t)u * nb + b + lane] : 0u);
     carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     const unsigned long long gm = __ballot(x != 0u);
-    if (x) {
+    if (x && part == 0u) {
       const uint32_t gi = g + (uint32_t)__popcll(gm & lanemask_lt());
       gstart[gi] = dst0 + off;
       gkey[gi] = khi | (b + lane);
@@ -3089,6 +3107,31 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void seg_group_kernel(const Frontie
     if (active && lane == 63u - (uint32_t)__clzll((long long)mask)) bins[qid] += (uint32_t)__popcll(mask);
     __builtin_amdgcn_wave_barrier();
   });
+}
+
+// (a thread per (query, sequence): the slices' counters to their exclusive prefix, in place; the total to qtot; the query's
+// hits and groups added up -- qact / qgrp zeroed by the launcher)
+__global__ __launch_bounds__(256) void seg_parts_scan_kernel(uint32_t *__restrict__ qbins, uint32_t nb, uint32_t parts, uint32_t *__restrict__ qtot,
+                                                             uint32_t *__restrict__ qact, uint32_t *__restrict__ qgrp) {
+  const uint32_t q = blockIdx.x, b = blockIdx.y * 256u + threadIdx.x;
+  uint32_t run = 0;
+  if (b < nb) {
+    uint32_t *p = qbins + (size_t)q * parts * nb + b;
+    uint32_t k = 0;
+    for (; k + 4u <= parts; k += 4u) {
+      const uint32_t x0 = p[(size_t)k * nb], x1 = p[(size_t)(k + 1u) * nb], x2 = p[(size_t)(k + 2u) * nb], x3 = p[(size_t)(k + 3u) * nb];
+      p[(size_t)k * nb] = run; run += x0;
+      p[(size_t)(k + 1u) * nb] = run; run += x1;
+      p[(size_t)(k + 2u) * nb] = run; run += x2;
+      p[(size_t)(k + 3u) * nb] = run; run += x3;
+    }
+    for (; k < parts; k++) { const uint32_t x = p[(size_t)k * nb]; p[(size_t)k * nb] = run; run += x; }
+    qtot[(size_t)q * nb + b] = run;
+  }
+  uint32_t cnt = run, grp = run ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cnt += (uint32_t)__shfl_xor((int)cnt, o); grp += (uint32_t)__shfl_xor((int)grp, o); }
+  if (lane_id() == 0 && cnt) { atomicAdd(&qact[q], cnt); atomicAdd(&qgrp[q], grp); }
 }
 
 __device__ __forceinline__ uint32_t lower_bound_u64(const unsigned long long *a, uint32_t n, unsigned long long k) {
@@ -5360,6 +5403,14 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
   // A dense level -- many pairs per index entry -- runs with the entries and prefix lines staged in LDS
   // (project_staged_kernel / project_entries_kernel)
   const bool dense = !n_pairs_dev && wl.pair_off && wl.se && !pl.slot && project_is_staged(v, n_pairs, true);
+  // (IMPG_ORD_STAGED: ordered rows by the lane-per-place kernel -- a wave's rows lie in one or two ranges' stretches of the output)
+  static const bool ord_staged = getenv("IMPG_ORD_STAGED") && atoi(getenv("IMPG_ORD_STAGED")) != 0;
+  if (dense && wl.masks != 0 && wl.ord.rows && ord_staged && mode == 0) {
+    const uint32_t gs = (cdiv(wl.n_fr, STG_RANGES) + 7u) & ~7u;
+    if (transitive) project_staged_kernel<true, true, OUT_ROWS><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
+    else project_staged_kernel<false, true, OUT_ROWS><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);
+    return;
+  }
   if (dense && wl.masks != 0 && entry_major() && (mode == 0 || (mode == MODE_IDENT && v.idp))) {
     // the final level of a counting run, entry by entry; also under the identity filter
     const uint32_t ge = (cdiv(wl.n_fr, ENT_RANGES) + 7u) & ~7u;
@@ -5438,7 +5489,20 @@ void launch_sort_pairs(void *tmp, size_t tmp_bytes, const unsigned long long *ki
   IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s));
 }
 bool seg_group_fits(uint32_t n_seq) { return n_seq <= SEG_MAX_SEQ; }
-size_t seg_group_bins_bytes(uint32_t n_queries, uint32_t n_seq) { return (size_t)n_queries * ((std::max(n_seq, 1u) + 63u) & ~63u) * 4; }
+size_t seg_group_bins_bytes(uint32_t n_queries, uint32_t n_seq, uint32_t parts) {
+  return (size_t)n_queries * parts * ((std::max(n_seq, 1u) + 63u) & ~63u) * 4;
+}
+// how many slices a query is cut into for a level of n_hits slots (1: a wave per query; 0: beyond what the slices' counters may
+// take -- the library sort)
+uint32_t seg_group_parts(uint64_t n_hits, uint32_t n_queries, uint32_t n_seq, uint64_t largest_query) {
+  if (!n_queries) return 1;
+  const uint64_t per_query = std::max<uint64_t>(n_hits / n_queries, largest_query);
+  if (per_query <= (largest_query ? SEG_BIG_QUERY : SEG_BIG_QUERY / 2)) return 1;
+  const uint64_t parts = (per_query + SEG_SLICE_HITS - 1) / SEG_SLICE_HITS;
+  if (parts > SEG_MAX_PARTS || (uint64_t)n_queries * parts >= (1ull << 31)) return 0;
+  if (seg_group_bins_bytes(n_queries, n_seq, (uint32_t)parts) > (1ull << 30)) return 0;
+  return (uint32_t)parts;
+}
 void launch_seg_bounds(const FrontierRec *fr, uint32_t n_fr, uint32_t n_queries, const uint32_t *pair_range, uint32_t n_pairs, uint32_t *run_start,
                        uint32_t *run_end, uint32_t *qfirst, uint32_t *qlast, uint32_t *unsorted, hipStream_t s, const uint32_t *off_perm,
                        const uint32_t *pair_off, const uint32_t *cnt) {
@@ -5456,18 +5520,25 @@ void launch_seg_bounds(const FrontierRec *fr, uint32_t n_fr, uint32_t n_queries,
 }
 void launch_seg_group(bool count_only, const FrontierRec *fr, const uint32_t *qfirst, const uint32_t *qlast, const uint32_t *run_start,
                       const uint32_t *run_end, HitArrays h, uint32_t n_queries, uint32_t n_seq, uint32_t *qact, const uint32_t *qdst, uint32_t *qgrp,
-                      const uint32_t *gdst, uint32_t *gstart, unsigned long long *gkey, unsigned long long *svals, uint32_t *qbins, hipStream_t s) {
+                      const uint32_t *gdst, uint32_t *gstart, unsigned long long *gkey, unsigned long long *svals, uint32_t *qbins, hipStream_t s,
+                      uint32_t parts, uint32_t *qtot) {
   if (!n_queries) return;
+  if (parts > 1u && (!qbins || !qtot)) throw Error{IMPG_E_INVALID, "internal: sliced segment grouping without its counters"};
   const uint32_t nb = (std::max(n_seq, 1u) + 63u) & ~63u;
   uint32_t nbits = 1;
   while ((1u << nbits) < n_seq) nbits++;
-  const uint32_t grid = cdiv(n_queries, SEG_WAVES);
+  const uint32_t grid = cdiv(n_queries * parts, SEG_WAVES);
   if (count_only)
     seg_group_kernel<true><<<grid, 64 * SEG_WAVES, SEG_WAVES * nb * 4, s>>>(fr, qfirst, qlast, run_start, run_end, h, n_queries, nb, nbits, qact, qdst, qgrp,
-                                                                          gdst, gstart, gkey, svals, qbins);
+                                                                          gdst, gstart, gkey, svals, qbins, parts, qtot);
   else
     seg_group_kernel<false><<<grid, 64 * SEG_WAVES, SEG_WAVES * nb * 4, s>>>(fr, qfirst, qlast, run_start, run_end, h, n_queries, nb, nbits, qact, qdst, qgrp,
-                                                                           gdst, gstart, gkey, svals, qbins);
+                                                                           gdst, gstart, gkey, svals, qbins, parts, qtot);
+  if (count_only && parts > 1u) {
+    IMPG_HIP(hipMemsetAsync(qact, 0, (size_t)n_queries * 4, s));
+    IMPG_HIP(hipMemsetAsync(qgrp, 0, (size_t)n_queries * 4, s));
+    seg_parts_scan_kernel<<<dim3(n_queries, cdiv(nb, 256u)), 256, 0, s>>>(qbins, nb, parts, qtot, qact, qgrp);
+  }
 }
 uint32_t group_tiles(uint32_t n) { return (n + GROUP_TILE - 1u) / GROUP_TILE; }
 void launch_group_count(const unsigned long long *skeys, uint32_t n, uint32_t *tile_heads, hipStream_t s) {

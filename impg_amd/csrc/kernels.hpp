@@ -258,8 +258,10 @@ void launch_seg_bounds(const FrontierRec *fr, uint32_t n_fr, uint32_t n_queries,
                        const uint32_t *pair_off = nullptr, const uint32_t *cnt = nullptr);  // pair_off / cnt (+ the order they are listed in): the runs straight from the lookup's offsets
 void launch_seg_group(bool count_only, const FrontierRec *fr, const uint32_t *qfirst, const uint32_t *qlast, const uint32_t *run_start,
                       const uint32_t *run_end, HitArrays h, uint32_t n_queries, uint32_t n_seq, uint32_t *qact, const uint32_t *qdst, uint32_t *qgrp,
-                      const uint32_t *gdst, uint32_t *gstart, unsigned long long *gkey, unsigned long long *svals, uint32_t *qbins, hipStream_t s);
-size_t seg_group_bins_bytes(uint32_t n_queries, uint32_t n_seq);  // qbins (nullable): the count pass's per-query sequence counters, kept for the place pass
+                      const uint32_t *gdst, uint32_t *gstart, unsigned long long *gkey, unsigned long long *svals, uint32_t *qbins, hipStream_t s,
+                      uint32_t parts = 1, uint32_t *qtot = nullptr);  // parts > 1: every query cut into that many slices (qbins per slice, qtot per query: required)
+size_t seg_group_bins_bytes(uint32_t n_queries, uint32_t n_seq, uint32_t parts = 1);  // qbins (nullable when parts == 1): the count pass's sequence counters, kept for the place pass
+uint32_t seg_group_parts(uint64_t n_hits, uint32_t n_queries, uint32_t n_seq, uint64_t largest_query = 0);  // slices per query for such a level (0: library sort)
 
 // ---- the per-query walk (walk_device.inc): one workgroup takes a query through all its levels / pops ----------------
 struct WalkArgs {

@@ -54,6 +54,7 @@ while time.time() < t_end:
     g = impg_amd.GpuImpg.from_paf(paths, bidirectional=bidir, order=order, devices=devs, lanes=int(rng.integers(1, 3)))
     g.set_option("walk_kernel", int(rng.choice([0, 1, 1, 2])))       # the per-query walk: off / DFS / DFS + small BFS batches
     g.set_option("filter_covered", int(rng.choice([0, 0, 1, 2])))
+    g.set_option("segment_parts", int(rng.choice([0, 0, 2, 3, 17])))    # the update's queries cut into slices (forced)
     o.set_sorted_visits(order == impg_amd.ORDER_SORTED)  # both order policies have an exact checker
     c = o.OracleIndex(paf_paths=paths, bidirectional=bidir, preparse=True)
     g.set_option("locality_min", int(rng.choice([0, 1, 4096])))

@@ -1637,6 +1637,16 @@ def test_update_by_segments_matches_the_library_sort(tmp_path, seed):
                 assert_same(g, c, ranges[:120], **kw)
                 assert_same(g, c, ranges[100:160], masked_regions=mask, **kw)
         assert out[0] == out[1], kw
+        # ... and a query's hits cut into slices of its frontier ranges (what a level with more than a wave's worth of hits
+        # per query gets; forced here on every level, more slices than some queries have ranges)
+        g.set_option("segment_groups", 1)
+        for parts in (2, 5, 64):
+            g.set_option("segment_parts", parts)
+            st, cnt, ck = g.query_batch_stats(ranges, impg_amd.make_params(**kw))
+            assert (st.projected, cnt.tolist(), ck.tolist()) == out[1], (kw, parts)
+        assert_same(g, c, ranges[:120], **kw)
+        assert_same(g, c, ranges[100:160], masked_regions=mask, **kw)
+        g.set_option("segment_parts", 0)
     g.set_option("segment_groups", 1)
     g.set_option("chunk_ranges", 37)  # (chunks: a query's index inside its chunk is what the keys carry)
     assert_same(g, c, ranges, transitive=True, max_depth=3, min_transitive_len=20)

@@ -80,12 +80,13 @@ def main():
                     help="--min-result-identity of the reference (impg.rs:1283-1287); not part of the headline configuration")
     ap.add_argument("--no-extras", action="store_true", help="skip the full-results measurement (profiling runs)")
     ap.add_argument("--no-tiers", action="store_true", help="skip the checksum of the rows left in HBM and the other tiers' timings (profiling runs)")
-    ap.add_argument("--form", default="rows", choices=["rows", "count"],
+    ap.add_argument("--form", default="rows", choices=["rows", "count", "ordered"],
                     help="what a timed step leaves behind.  rows (default, one GPU): every result row in HBM, attributable -- "
                          "impg_gpu_query_batch_device, 24 bytes a row (query id, four coordinates, the frontier record that names "
                          "its range and target).  count: nothing but the number of projections (impg_gpu_query_batch_stats without "
                          "per-range output: the final level's rows are written but not attributed) -- rounds 1-5's timed form, and "
-                         "still the form of a sharded index")
+                         "still the form of a sharded index.  ordered: the rows grouped by range in the reference's emission order "
+                         "(IMPG_ROWS_ORDERED_SLOTS) -- the value_ordered_rows_device tier as the timed step, for profiling it")
     ap.add_argument("--world-sweep", action="store_true",
                     help="one device, constant work: the batch through a multi handle of 1 / 2 / 4 / 8 ranks that all share device 0 "
                          "(threads of this process, LocalComm) -- what the sharded path's fixed costs do as the world grows, "
@@ -222,7 +223,14 @@ def main():
 
     # (rows left on the device belong to one GPU's index; config 5's 10^12 rows do not fit any HBM: a caller would take them chunk by chunk)
     form = "count" if (dist is not None or wl in ("config5", "skewed")) else args.form
-    step = step_rows if form == "rows" else step_count
+    def step_ordered():  # the rows grouped by range in the reference's emission order, in HBM (a profiling form: the tier's own step)
+        import impg_amd._lib as _l
+        dr = index.query_batch_device(None, params, device_ptr=d_ranges.data_ptr(), n=args.ranges, layout=_l.ROWS_ORDERED_SLOTS)
+        st = dr.stats
+        dr.free()
+        return st
+
+    step = step_rows if form == "rows" else step_ordered if form == "ordered" else step_count
 
     def sync():
         torch.cuda.synchronize()
@@ -391,6 +399,9 @@ def main():
         "timed_form": ("rows: every result row left in HBM, 24 B each -- query id, q_first, q_last, t_first, t_last and the frontier record that "
                        "names its range of the batch and its target (impg_gpu_query_batch_device, IMPG_ROWS_ATTRIBUTED); slot order free")
                       if form == "rows" else
+                      "ordered: every slot's row at its place of the batch's ordered output, 24 B each, grouped by range in the reference's emission "
+                      "order, hole rows where a projection returned None (impg_gpu_query_batch_device, IMPG_ROWS_ORDERED_SLOTS)"
+                      if form == "ordered" else
                       "count: the number of projections only (impg_gpu_query_batch_stats without per-range output; the final level's rows "
                       "are computed and stored but not attributed to a range)",
     }

@@ -469,8 +469,9 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
       launch_ord_dest_by_place(win_se.as<FrontierRec>(), d_perm, n_fr, L.slot_ref.as<uint32_t>(), ord_offsets.as<uint32_t>(), L.lvbase.as<uint32_t>(),
                                ord_dest.as<uint32_t>(), stream);
       ord_vpos.reserve(std::max<size_t>(P + 256, 256));
-      launch_emit_vpos(v, n_fr, pair_off.as<uint32_t>(), win.as<uint4>(), ord_vpos.as<uint8_t>(), stream);
-      wlists.ord = OrderedOut{ord_rows.as<impg_gpu_interval_t>(), ord_dest.as<uint32_t>(), ord_vpos.as<uint8_t>(), ord_min_len};
+      const bool by_visit = ordered_rows_by_visit();
+      launch_emit_vpos(v, n_fr, pair_off.as<uint32_t>(), win.as<uint4>(), ord_vpos.as<uint8_t>(), stream, by_visit);
+      wlists.ord = OrderedOut{ord_rows.as<impg_gpu_interval_t>(), ord_dest.as<uint32_t>(), ord_vpos.as<uint8_t>(), ord_min_len, by_visit ? 1u : 0u};
       L.placed = true;
     }
   } else if (by_place) {

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 // K1b'': the visit order WITHOUT the pair lists (ordered rows written by a fused final level, OrderedOut): the same
 // per-lane sorting network, but what leaves the kernel is one byte per hit -- the visit position of a range's k-th hit
 // in index order, at the hit's place pair_off[i] + k -- 1 byte a pair instead of the 8 of pair_range + pair_entry.
-template <uint32_t N, uint32_t W>
+template <uint32_t N, uint32_t W, bool BY_VISIT>  // BY_VISIT: out[k] = the mask bit of the k-th visited hit (the inverse map)
 __device__ __forceinline__ void emit_vpos_sort_stage(const uint32_t *__restrict__ rank, uint32_t b, uint32_t lo, uint32_t ub,
                                                      unsigned long long mask, uint32_t c, uint8_t *out) {
   uint32_t key[64];
@@ -718,11 +718,13 @@ __device__ __forceinline__ void emit_vpos_sort_stage(const uint32_t *__restrict_
     if (__ballot(k < c) == 0ull) break;
     if (k < c) {
       const uint32_t bit = (key[k] & 63u) - shift;
-      out[__popcll(mask & ((1ull << bit) - 1ull))] = (uint8_t)k;
+      if (BY_VISIT) out[k] = (uint8_t)bit;
+      else out[__popcll(mask & ((1ull << bit) - 1ull))] = (uint8_t)k;
     }
   }
 }
 constexpr uint32_t VPOS_LDS = 64u * 64u + 8u;
+template <bool BY_VISIT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void emit_vpos_lane_kernel(DeviceIndexView v, uint32_t n,
                                                               const uint32_t *__restrict__ pair_off, const uint4 *__restrict__ win,
                                                               uint8_t *__restrict__ vpos) {
@@ -750,10 +752,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   const uint32_t rel = off - off0 + mis;
   const bool in_lds = rel + c <= VPOS_LDS;
   uint8_t *out = in_lds ? stage + rel : vpos + off;
-  if (wmax <= 32u) emit_vpos_sort_stage<32, 32>(v.rank, b, lo, ub, mask, c, out);
-  else if (wmax <= 40u) emit_vpos_sort_stage<64, 40>(v.rank, b, lo, ub, mask, c, out);
-  else if (wmax <= 48u) emit_vpos_sort_stage<64, 48>(v.rank, b, lo, ub, mask, c, out);
-  else emit_vpos_sort_stage<64, 64>(v.rank, b, lo, ub, mask, c, out);
+  if (wmax <= 32u) emit_vpos_sort_stage<32, 32, BY_VISIT>(v.rank, b, lo, ub, mask, c, out);
+  else if (wmax <= 40u) emit_vpos_sort_stage<64, 40, BY_VISIT>(v.rank, b, lo, ub, mask, c, out);
+  else if (wmax <= 48u) emit_vpos_sort_stage<64, 48, BY_VISIT>(v.rank, b, lo, ub, mask, c, out);
+  else emit_vpos_sort_stage<64, 64, BY_VISIT>(v.rank, b, lo, ub, mask, c, out);
   __syncthreads();
   // copy out: LDS bytes [mis, covered) are the piece's first covered - mis bytes (a wide window's run in between holds
   // whatever was there: nobody reads those bytes).  Whole aligned words, except where the piece's first / last word is
@@ -1766,6 +1768,9 @@ __device__ __forceinline__ uint32_t select_bit64(uint32_t lo, uint32_t hi, uint3
 __device__ __forceinline__ void put_ordered_row(const OrderedOut &o, uint32_t d, uint32_t qid, uint32_t tid, bool ok, int32_t qs, int32_t qe,
                                                 int32_t ts, int32_t te) {
   const bool on = ok && !(o.min_output_length >= 0 && abs(qe - qs) < o.min_output_length);
+#ifdef IMPG_ORD_NOSTORE  // (experiment: the kernel without its row stores)
+  if (!(qs == -0x7FFFFFF0 && te == 0x7FFFFFF1)) return;
+#endif
   // (24 bytes at an 8-byte boundary: a 16-byte and an 8-byte store.  A row is a line of its own among 10^9 and every store
   // instruction of a wave touches 64 lines -- ~12 ms of the headline's final level per such instruction, measured; rows of
   // one aligned 32-byte sector cost the same: it is the scattered store, not a read-modify-write)
@@ -1989,7 +1994,7 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
                                                    const WindowLists &wl, uint32_t r0, uint32_t P0, uint32_t P1, uint32_t emin, uint32_t n_e,
                                                    bool regroup_all, const uint32_t *st_off, const uint4 *st_win, const int2 *st_se,
                                                    const uint4 *st_ent, uint4 *st_line PHASE_ARG, double min_identity = 0.0,
-                                                   const uint32_t *st_dest = nullptr) {
+                                                   const uint32_t *st_dest = nullptr, const uint32_t *st_tid = nullptr) {
   const SliceArrays no_sl{nullptr, nullptr, nullptr, nullptr};
   uint32_t n_ok = 0;
   constexpr bool ordered = OUT == OUT_ROWS;  // (then nothing is regrouped: a lane keeps its place's range, whose row and target it writes)
@@ -1998,6 +2003,10 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
   // the block's places, a turn of NT at a time (pair lists: the next turn's entry is requested a turn ahead)
   uint32_t e_next = 0xFFFFFFFFu;
   if (!MASKS && (unsigned long long)P0 + threadIdx.x < P1) e_next = pair_entry[P0 + threadIdx.x];
+  // (ordered rows by visit: the place's byte -- which bit of its window's mask -- likewise a turn ahead)
+  const bool by_visit = ordered && MASKS && wl.ord.by_visit != 0u;  // (the range's places run in visit order: the rows of a wave's lanes lie in a row)
+  uint32_t v_next = 0u;
+  if (by_visit && (unsigned long long)P0 + threadIdx.x < P1) v_next = wl.ord.vpos[P0 + threadIdx.x];
 #pragma unroll 1
   for (uint32_t base = P0; base < P1; base += NT) {
     if (base + NT < base) break;  // (cannot happen: n_pairs stays 16 below 2^32 and P1 <= n_pairs)
@@ -2017,10 +2026,11 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
         const uint4 w = st_win[j];
         const bool listed = w.y - (w.x & ~3u) > 64u;
         if (listed) y.eidx = pair_entry[pp];  // a window wider than the mask: listed by the wave-per-range emit
+        else if (by_visit) y.eidx = w.x + v_next;
         else y.eidx = w.x + select_bit64(w.z, w.w, pp - st_off[j]);
         if (ordered) {  // (a listed window's entries are in visit order already)
-          o_dest = st_dest[j] + (listed ? pp - st_off[j] : (uint32_t)wl.ord.vpos[pp]);
-          o_tid = wl.se[r0 + j].target_id;
+          o_dest = st_dest[j] + (listed || by_visit ? pp - st_off[j] : (uint32_t)wl.ord.vpos[pp]);
+          o_tid = st_tid ? st_tid[j] : wl.se[r0 + j].target_id;
         } else if (qs) o_tid = r0 + j;
         else if (wl.range_out) wl.range_out[pp] = wl.range_places ? r0 + j : wl.perm[r0 + j];
       } else {
@@ -2030,6 +2040,10 @@ __device__ __forceinline__ uint32_t project_places(const DeviceIndexView &v, con
     if (!MASKS) {
       e_next = 0xFFFFFFFFu;
       if ((unsigned long long)pp + NT < P1) e_next = pair_entry[pp + NT];
+    }
+    if (by_visit) {
+      v_next = 0u;
+      if ((unsigned long long)pp + NT < P1) v_next = wl.ord.vpos[pp + NT];
     }
     if (regroup_all) regroup_by_entry<NT>(y, reinterpret_cast<uint32_t *>(st_line));
     if (y.live) {
@@ -2078,7 +2092,7 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
   __shared__ uint4 st_win[STG_RANGES];
   __shared__ int2 st_se[STG_RANGES];
   __shared__ uint32_t st_off[STG_RANGES + 4u];
-  __shared__ uint32_t st_dest[OUT == OUT_ROWS ? STG_RANGES : 1u];  // (ordered rows: the ranges' first rows)
+  __shared__ uint32_t st_dest[OUT == OUT_ROWS ? STG_RANGES : 1u], st_tid[OUT == OUT_ROWS ? STG_RANGES : 1u];  // (ordered rows: the ranges' first rows, their targets)
   __shared__ uint32_t wred[2u * STG_WAVES];
   __shared__ uint32_t wcnt[STG_WAVES];
   const uint32_t r0 = sblock * STG_RANGES;
@@ -2102,7 +2116,7 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
     if (threadIdx.x < nr) {
       const uint4 w = wl.win[r0 + threadIdx.x];
       st_win[threadIdx.x] = w;
-      { const FrontierRec sf = wl.se[r0 + threadIdx.x]; st_se[threadIdx.x] = make_int2(sf.start, sf.end); }
+      { const FrontierRec sf = wl.se[r0 + threadIdx.x]; st_se[threadIdx.x] = make_int2(sf.start, sf.end); if (OUT == OUT_ROWS) st_tid[threadIdx.x] = sf.target_id; }
       if (w.y - (w.x & ~3u) > 64u) { emin = w.x; emax = w.y - 1u; }  // (a window wider than the mask: its hits lie somewhere in it)
       else if (w.z | w.w) {
         emin = w.x + (w.z ? (uint32_t)__builtin_ctz(w.z) : 32u + (uint32_t)__builtin_ctz(w.w));
@@ -2157,7 +2171,7 @@ __global__ __launch_bounds__(STG_THREADS) STG_OCCUPANCY void project_staged_kern
   STG_MARK(2);
   n_ok = project_places<TRANSITIVE, MASKS, true, STG_RANGES, STG_THREADS, 0, OUT>(v, pair_entry, h, accepted, err_flag, wl, r0, P0, P1, emin, n_e,
                                                                                   sparse && regroup != 0, st_off, st_win, st_se, st_ent, st_line PHASE_PASS,
-                                                                                  0.0, st_dest);
+                                                                                  0.0, st_dest, OUT == OUT_ROWS ? st_tid : nullptr);
 #ifdef IMPG_PHASE_CLOCKS
   STG_MARK(3);
   if ((blockIdx.x & 15u) == 0u && threadIdx.x == 0u) {
@@ -5271,8 +5285,15 @@ void launch_ord_level_rows(const FrontierRec *fr, const uint32_t *pair_range, ui
                            impg_gpu_interval_t *rows, hipStream_t s) {
   if (n_pairs) ord_level_rows_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, run_start, slot_ref, offsets, lvbase, min_output_length, rows);
 }
-void launch_emit_vpos(const DeviceIndexView &v, uint32_t n, const uint32_t *pair_off, const uint4 *win, uint8_t *vpos, hipStream_t s) {
-  if (n) emit_vpos_lane_kernel<<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, vpos);
+void launch_emit_vpos(const DeviceIndexView &v, uint32_t n, const uint32_t *pair_off, const uint4 *win, uint8_t *vpos, hipStream_t s, bool by_visit) {
+  if (!n) return;
+  if (by_visit) emit_vpos_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, vpos);
+  else emit_vpos_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, vpos);
+}
+// (IMPG_ORD_ENTRIES=1: ordered rows from the entry-major kernel, for the comparison -- see launch_project)
+bool ordered_rows_by_visit() {
+  static const bool by_entries = getenv("IMPG_ORD_ENTRIES") && atoi(getenv("IMPG_ORD_ENTRIES")) != 0;
+  return !by_entries;
 }
 void launch_tile_first(const uint32_t *cnt, const uint32_t *pair_off, uint32_t n_fr, uint32_t *tile_first, hipStream_t s) {
   if (n_fr) tile_first_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(cnt, pair_off, n_fr, tile_first);
@@ -5403,8 +5424,11 @@ void launch_project(const DeviceIndexView &v, const FrontierRec *fr, const uint3
   // A dense level -- many pairs per index entry -- runs with the entries and prefix lines staged in LDS
   // (project_staged_kernel / project_entries_kernel)
   const bool dense = !n_pairs_dev && wl.pair_off && wl.se && !pl.slot && project_is_staged(v, n_pairs, true);
-  // (IMPG_ORD_STAGED: ordered rows by the lane-per-place kernel -- a wave's rows lie in one or two ranges' stretches of the output)
-  static const bool ord_staged = getenv("IMPG_ORD_STAGED") && atoi(getenv("IMPG_ORD_STAGED")) != 0;
+  // Ordered rows come from the lane-per-place kernel: a wave's 64 places lie in one or two ranges, so its rows are one or two
+  // stretches of the output.  Entry by entry a wave's lanes are 64 RANGES, whose rows lie in 64 queries' stretches of a 51-GB
+  // array -- 64 pages per store instruction: the headline's ordered step 74.5 ms that way, 53.5 ms this way (same box;
+  // IMPG_ORD_ENTRIES=1 selects the entry-major kernel for the comparison).
+  const bool ord_staged = wl.ord.by_visit != 0;
   if (dense && wl.masks != 0 && wl.ord.rows && ord_staged && mode == 0) {
     const uint32_t gs = (cdiv(wl.n_fr, STG_RANGES) + 7u) & ~7u;
     if (transitive) project_staged_kernel<true, true, OUT_ROWS><<<gs, STG_THREADS, 0, s>>>(v, pair_entry, n_pairs, h, accepted, err_flag, rg, wl);

@@ -56,7 +56,7 @@ void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32
                          FrontierRec *se = nullptr /* by_place: the ranges' records at their places (the projection reads the ends there) */,
                          uint32_t *cnt_ref = nullptr /* by_place: the counts in FRONTIER order too (ordered rows) */);
 // visit position of every hit of the windows of <= 64 entries, by place: vpos[pair_off[i] + k] for range i's k-th hit in index order
-void launch_emit_vpos(const DeviceIndexView &v, uint32_t n, const uint32_t *pair_off, const uint4 *win, uint8_t *vpos, hipStream_t s);
+void launch_emit_vpos(const DeviceIndexView &v, uint32_t n, const uint32_t *pair_off, const uint4 *win, uint8_t *vpos, hipStream_t s, bool by_visit = false);
 // ---- ordered rows, placed by slot (Engine::ordered_*): see engine.cpp ------------------------------------------------
 void launch_ord_self_count(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, uint32_t *acc, hipStream_t s);
 // qbase[q] = slot_ref of the first record with qidx >= q (total beyond the last); lvbase[q] = acc[q] - qbase[q]; acc[q] += the query's slots
@@ -76,9 +76,11 @@ void launch_ord_level_rows(const FrontierRec *fr, const uint32_t *pair_range, ui
 struct OrderedOut {
   impg_gpu_interval_t *rows;      // null: off
   const uint32_t *dest;        // [n_fr] by place: the row of the range's first slot
-  const uint8_t *vpos;         // [n_pairs] by place: visit position of a range's k-th hit in index order (windows of <= 64 entries)
+  const uint8_t *vpos;         // [n_pairs] by place: visit position of a range's k-th hit in index order (windows of <= 64 entries) -- or, by_visit, the inverse
   int32_t min_output_length;   // rows with |q_last - q_first| below it are holes (impg.rs:2482-2504); -1: none
+  uint32_t by_visit;           // 1: the range's place k is its k-th VISITED hit and vpos[place] names that hit's bit in the window's mask (the lane-per-place kernel: rows leave in a row)
 };
+bool ordered_rows_by_visit();  // which of the two the projection of a direct level wants (kernels.hip: launch_project)
 // A counting run's FINAL level listed by windows instead of by pairs (engine.cpp: Engine::expand): nothing reads that
 // level's slots by position or in order, so the projection kernel takes its pairs straight from what the count pass
 // left per range -- place offset, window, hit mask -- and the emit pass with its two 4-byte-per-pair lists is not run

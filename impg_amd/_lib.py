@@ -177,6 +177,7 @@ SYMBOLS = [
                                  C.POINTER(C.c_size_t)]),
     ("impg_synth_paf_text", C.c_int, [C.c_uint64, C.c_size_t, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_char_p]),
     ("impg_synth_skewed_paf_text", C.c_int, [C.c_uint64, C.c_size_t, C.c_uint32, C.c_int32, C.c_char_p, C.POINTER(C.c_uint64)]),
+    ("impg_gpu_selftest_order_sort", C.c_int, [C.c_int, C.c_uint32, C.c_uint, C.c_uint64]),
     ("impg_synth_seq_name", C.c_int, [C.c_uint32, C.c_char_p, C.c_size_t]),
     ("impg_synth_bed", C.c_int, [C.c_uint64, C.c_size_t, C.c_uint32, C.c_int32, C.c_int32, _P]),
 ]

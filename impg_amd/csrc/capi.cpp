@@ -1249,4 +1249,53 @@ int impg_gpu_results_paf(const impg_gpu_results_t *res, const impg_gpu_index_t *
   IMPG_CATCH
 }
 
+// The lookup order's sort checked on its own (diagnostics; tests/test_gpu_parity.py): n pseudo-random keys of `end_bit` bits
+// (seed; every 7th key repeats its predecessor's, so equal keys are common) through launch_order_sort on `device`; the result
+// must be a permutation of 0 .. n-1 that lists the keys in non-decreasing order, equal keys by ascending index.
+int impg_gpu_selftest_order_sort(int device, uint32_t n, unsigned end_bit, uint64_t seed) {
+  IMPG_TRY
+  if (end_bit < 1 || end_bit > 32) throw Error{IMPG_E_INVALID, "end_bit is 1 .. 32"};
+  IMPG_HIP(hipSetDevice(device));
+  std::vector<uint32_t> keys(n), perm(n);
+  uint64_t x = seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+  const uint32_t mask = end_bit >= 32 ? 0xFFFFFFFFu : ((1u << end_bit) - 1u);
+  for (uint32_t i = 0; i < n; i++) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    keys[i] = (i % 7u == 3u && i) ? keys[i - 1] : (uint32_t)(x >> 20);  // (bits above end_bit stay set: they must not matter)
+  }
+  hipStream_t s;
+  IMPG_HIP(hipStreamCreate(&s));
+  DevBuf ka, kb, pa, pb, sc;
+  const size_t nb = std::max<size_t>((size_t)n * 4, 256);
+  ka.reserve(nb); kb.reserve(nb); pa.reserve(nb); pb.reserve(nb); sc.reserve(order_sort_scratch_bytes(n));
+  IMPG_HIP(hipMemcpyAsync(ka.p, keys.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  IMPG_HIP(hipMemsetAsync(pa.p, 0xA5, nb, s));
+  launch_order_sort(ka.as<uint32_t>(), kb.as<uint32_t>(), pa.as<uint32_t>(), pb.as<uint32_t>(), n, end_bit, sc.p, s);
+  IMPG_HIP(hipGetLastError());
+  IMPG_HIP(hipMemcpyAsync(perm.data(), pa.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  IMPG_HIP(hipStreamSynchronize(s));
+  IMPG_HIP(hipStreamDestroy(s));
+#ifdef IMPG_OS_CLOCKS
+  {
+    unsigned long long c[8];
+    order_sort_clocks(c, false);
+    fprintf(stderr, "[order sort clocks] n=%u bits=%u tiles x passes=%llu: per tile-pass zero+load %.0f rank %.0f bases %.0f lds %.0f out %.0f cycles\n", n, end_bit, c[7],
+            (double)c[0] / c[7], (double)c[1] / c[7], (double)c[2] / c[7], (double)c[3] / c[7], (double)c[4] / c[7]);
+    order_sort_clocks(nullptr, true);
+  }
+#endif
+  std::vector<uint8_t> seen(n, 0);
+  for (uint32_t k = 0; k < n; k++) {
+    const uint32_t i = perm[k];
+    if (i >= n || seen[i]) throw Error{IMPG_E_INVALID, "order sort: not a permutation at place " + std::to_string(k)};
+    seen[i] = 1;
+    if (k) {
+      const uint32_t a = keys[perm[k - 1]] & mask, b = keys[i] & mask;
+      if (a > b || (a == b && perm[k - 1] > i)) throw Error{IMPG_E_INVALID, "order sort: out of order at place " + std::to_string(k)};
+    }
+  }
+  return IMPG_OK;
+  IMPG_CATCH
+}
+
 }  // extern "C"

@@ -364,13 +364,19 @@ const uint32_t *Engine::lookup_order(const DeviceIndexView &v, const FrontierRec
     launch_order_keys(v, fr, n_fr, lo_key.as<uint32_t>(), lo_idx.as<uint32_t>(), stream, blocks ? blocks->d_bounds : nullptr,
                       blocks ? blocks->n_blocks : 0u, block_shift);
   keys_for = nullptr;
-  const size_t tb = sort_u32_scratch_bytes(n_fr);
-  sort_tmp.reserve(tb);
   // (every bit of the key is sorted.  Round 5, measured: leaving the low 5 bits unsorted -- two radix passes instead of
   // three -- takes 0.35 ms off the lookup and puts 4.4 ms ON the projection (22.1 -> 26.5 ms: the entries kernel's waves
   // find their entry's places in shorter runs); 9 bits: 87 ms.)
-  launch_sort_u32(sort_tmp.p, tb, lo_key.as<uint32_t>(), lo_key2.as<uint32_t>(), lo_idx.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr,
-                  stream, 0, hi_bit);
+  static const bool lib_sort = getenv("IMPG_LIB_SORT") && atoi(getenv("IMPG_LIB_SORT")) != 0;  // (A/B: the library's radix sort)
+  if (lib_sort) {
+    const size_t tb = sort_u32_scratch_bytes(n_fr);
+    sort_tmp.reserve(tb);
+    launch_sort_u32(sort_tmp.p, tb, lo_key.as<uint32_t>(), lo_key2.as<uint32_t>(), lo_idx.as<uint32_t>(), lo_perm.as<uint32_t>(), n_fr,
+                    stream, 0, hi_bit);
+  } else {  // (a key's value is its index: lo_idx is scratch here)
+    sort_tmp.reserve(order_sort_scratch_bytes(n_fr));
+    launch_order_sort(lo_key.as<uint32_t>(), lo_key2.as<uint32_t>(), lo_perm.as<uint32_t>(), lo_idx.as<uint32_t>(), n_fr, hi_bit, sort_tmp.p, stream);
+  }
   return lo_perm.as<uint32_t>();
 }
 // After the count pass: offp[r] = first place of range r's pairs in that order, and room for slot_of[P].

@@ -5734,6 +5734,201 @@ void launch_sort_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t 
   if (!n) return;
   IMPG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s));
 }
+
+// ---------------------------------------------------------------------------
+// The lookup order's sort, hand-written (round 6): a stable argsort of n 32-bit keys by their low `end_bit` bits.
+//
+// What is sorted is small -- 4-byte keys whose values are their own indices, 21 key bits at the headline -- and the library's
+// onesweep moved three times the algorithmic bytes for it (rocprofv3: 0.5 GB read + 0.5 GB written per pass over 21 x 10^6
+// pairs, 555 us a pass: a block's ~4 000 keys over 256 bins leave in runs of 60 bytes).  Here a pass is an LSD counting
+// sort by one digit of <= 7 bits (21 bits: three digits), a block per tile of 4 096 keys:
+//   order_hist_kernel     the tile's digit histogram -> hist[digit][tile]
+//   order_rowscan_kernel  a block per digit: its row of tile counts to exclusive offsets, the digit's total
+//   order_scatter_kernel  the tile's keys ranked (a wave owns a quarter of the tile: its keys' ranks among equal digits from
+//                         ballots, round by round, on per-wave LDS counters), laid out in LDS in digit order, and written
+//                         from there: a digit's keys of a tile leave as ONE run (7-bit digits: 64 keys, 256 bytes).
+// The first pass reads no values (a key's value is its index), the last writes no keys.  Stable: tile order, then the
+// waves' quarters in order, then rounds, then lanes.
+// ---------------------------------------------------------------------------
+#ifndef IMPG_OS_TILE
+#define IMPG_OS_TILE 4096
+#endif
+#ifndef IMPG_OS_THREADS
+#define IMPG_OS_THREADS 512
+#endif
+constexpr uint32_t OS_TILE = IMPG_OS_TILE, OS_THREADS = IMPG_OS_THREADS, OS_WAVES = OS_THREADS / 64u, OS_ROUNDS = OS_TILE / OS_THREADS, OS_DIGIT_BITS = 7, OS_MAX_BINS = 1u << OS_DIGIT_BITS;
+constexpr uint32_t OS_HIST_THREADS = 256;
+static_assert(OS_ROUNDS * OS_THREADS == OS_TILE && OS_THREADS >= OS_MAX_BINS && OS_TILE / OS_WAVES <= 65535u && OS_TILE % (4u * OS_HIST_THREADS) == 0,
+              "a thread per bin, whole rounds, a wave's counters fit 16 bits");
+__global__ __launch_bounds__(OS_HIST_THREADS) void order_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t shift, uint32_t bins,
+                                                                     uint32_t n_tiles, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t h[OS_MAX_BINS];
+  if (threadIdx.x < OS_MAX_BINS) h[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * OS_TILE, m = bins - 1u;
+#pragma unroll 4
+  for (uint32_t r = 0; r < OS_TILE / (4u * OS_HIST_THREADS); r++) {  // (tiles start at multiples of the tile: 16-byte aligned)
+    const uint32_t j = (r * OS_HIST_THREADS + threadIdx.x) * 4u;
+    if (base + j + 4u <= n) {
+      const uint4 k = *reinterpret_cast<const uint4 *>(keys + base + j);
+      atomicAdd(&h[(k.x >> shift) & m], 1u); atomicAdd(&h[(k.y >> shift) & m], 1u);
+      atomicAdd(&h[(k.z >> shift) & m], 1u); atomicAdd(&h[(k.w >> shift) & m], 1u);
+    } else {
+      for (uint32_t t = 0; t < 4u && base + j + t < n; t++) atomicAdd(&h[(keys[base + j + t] >> shift) & m], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < bins) hist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void order_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ tot) {
+  uint32_t *row = hist + (size_t)blockIdx.x * n_tiles;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n_tiles; base += 256u) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t x = i < n_tiles ? row[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(x, &total);
+    if (i < n_tiles) row[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) tot[blockIdx.x] = carry;
+}
+#ifdef IMPG_OS_CLOCKS
+__device__ unsigned long long g_os_clk[8];
+#define OS_MARK(i) do { __syncthreads(); if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); os_t[i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define OS_MARK(i) do { } while (0)
+#endif
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(OS_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void order_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t n,
+                                                                   uint32_t shift, uint32_t bins, uint32_t nbits, uint32_t n_tiles,
+                                                                   const uint32_t *__restrict__ hist, const uint32_t *__restrict__ tot,
+                                                                   uint32_t *__restrict__ kout, uint32_t *__restrict__ vout) {
+  __shared__ uint2 tile[OS_TILE];                  // (key, value) at its place of the tile's digit order
+  __shared__ uint16_t wcnt[OS_WAVES][OS_MAX_BINS];  // a wave's digit counters while it ranks; then its offset inside the digit's run
+  __shared__ uint32_t dbase[OS_MAX_BINS];           // the digit's first place in the tile
+  __shared__ uint32_t gbase[OS_MAX_BINS];           // ... and where that place goes: destination = gbase[digit] + place
+  __shared__ uint32_t wsum[OS_WAVES];
+  __shared__ unsigned long long wmatch[OS_WAVES][OS_MAX_BINS];  // a round's lanes per digit (see the ranking below)
+  const uint32_t w = threadIdx.x >> 6, lane = lane_id(), m = bins - 1u;
+  const uint32_t base = blockIdx.x * OS_TILE;
+  const uint32_t cnt = min(OS_TILE, n - base);
+#ifdef IMPG_OS_CLOCKS
+  unsigned long long os_t[8];
+#endif
+  OS_MARK(0);
+  for (uint32_t i = threadIdx.x; i < OS_WAVES * OS_MAX_BINS; i += OS_THREADS) { (&wcnt[0][0])[i] = 0; (&wmatch[0][0])[i] = 0ull; }
+  // (what the bases step adds up, requested now: the tile's offsets inside the digits' runs, the digits' totals)
+  uint32_t my_hist = 0, my_tot = 0;
+  if (threadIdx.x < bins) { my_hist = hist[(size_t)threadIdx.x * n_tiles + blockIdx.x]; my_tot = tot[threadIdx.x]; }
+  // the wave's stretch of the tile, 64 keys a round: a short chain of rounds per wave, many waves
+  uint32_t key[OS_ROUNDS], val[FIRST ? 1 : OS_ROUNDS], loc[OS_ROUNDS];
+  const uint32_t j0 = w * (OS_TILE / OS_WAVES) + lane;
+#pragma unroll
+  for (uint32_t r = 0; r < OS_ROUNDS; r++) {
+    const uint32_t j = j0 + r * 64u;
+    key[r] = j < cnt ? kin[base + j] : 0xFFFFFFFFu;
+    if (!FIRST) val[r] = j < cnt ? vin[base + j] : 0u;
+  }
+  __syncthreads();
+  OS_MARK(1);
+#pragma unroll
+  for (uint32_t r = 0; r < OS_ROUNDS; r++) {
+    const uint32_t j = j0 + r * 64u;
+    const bool live = j < cnt;
+    const uint32_t d = (key[r] >> shift) & m;
+    // the round's lanes of this lane's digit: every lane ORs its bit into the digit's word of the wave (an OR commutes: the
+    // word does not depend on the order the LDS serves the lanes in), reads the word back, and the digit's last lane
+    // clears it and moves the digit's counter on.  (Ballots over the digit's bits -- eight per round -- kept the vector
+    // ALUs busy for 1 600 cycles a round; this is three LDS operations.)
+    unsigned long long mask = 1ull << lane;
+    uint32_t prior = 0;
+    if (live) atomicOr(&wmatch[w][d], 1ull << lane);
+    __builtin_amdgcn_wave_barrier();
+    if (live) { mask = wmatch[w][d]; prior = wcnt[w][d]; }
+    __builtin_amdgcn_wave_barrier();
+    if (live && lane == 63u - (uint32_t)__clzll((long long)mask)) { wmatch[w][d] = 0ull; wcnt[w][d] = (uint16_t)(prior + (uint32_t)__popcll(mask)); }
+    __builtin_amdgcn_wave_barrier();
+    loc[r] = prior + (uint32_t)__popcll(mask & lanemask_lt());
+  }
+  __syncthreads();
+  OS_MARK(2);
+  // per digit: the waves' offsets inside its run, its first place in the tile, its run's destination
+  {
+    const uint32_t t = threadIdx.x;
+    uint32_t total = 0;
+    if (t < OS_MAX_BINS) {
+#pragma unroll
+      for (uint32_t k = 0; k < OS_WAVES; k++) { const uint32_t c = wcnt[k][t]; wcnt[k][t] = (uint16_t)total; total += c; }
+    }
+    const uint32_t ex = block_excl_scan_n<OS_WAVES>(total, wsum);
+    const uint32_t gx = block_excl_scan_n<OS_WAVES>(my_tot, wsum);  // the digit's first destination over all tiles
+    if (t < OS_MAX_BINS) {
+      dbase[t] = ex;
+      gbase[t] = t < bins ? gx + my_hist - ex : 0u;
+    }
+  }
+  __syncthreads();
+  OS_MARK(3);
+#pragma unroll
+  for (uint32_t r = 0; r < OS_ROUNDS; r++) {
+    const uint32_t j = j0 + r * 64u;
+    if (j < cnt) {
+      const uint32_t d = (key[r] >> shift) & m;
+      tile[dbase[d] + wcnt[w][d] + loc[r]] = make_uint2(key[r], FIRST ? base + j : val[r]);
+    }
+  }
+  __syncthreads();
+  OS_MARK(4);
+  for (uint32_t p = threadIdx.x; p < cnt; p += OS_THREADS) {
+    const uint2 kv = tile[p];
+    const uint32_t dest = gbase[(kv.x >> shift) & m] + p;
+    if (!LAST) kout[dest] = kv.x;
+    vout[dest] = kv.y;
+  }
+#ifdef IMPG_OS_CLOCKS
+  OS_MARK(5);
+  if (threadIdx.x == 0) { for (int i = 0; i < 5; i++) atomicAdd(&g_os_clk[i], os_t[i + 1] - os_t[i]); atomicAdd(&g_os_clk[7], 1ull); }
+#endif
+}
+#ifdef IMPG_OS_CLOCKS
+void order_sort_clocks(unsigned long long *out, bool reset) {
+  if (reset) { unsigned long long z[8] = {0}; IMPG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_os_clk), z, sizeof z)); return; }
+  IMPG_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_os_clk), 64));
+}
+#endif
+static unsigned order_sort_passes(unsigned end_bit) { return std::max(1u, (end_bit + OS_DIGIT_BITS - 1u) / OS_DIGIT_BITS); }
+size_t order_sort_scratch_bytes(uint32_t n) {
+  const size_t n_tiles = ((size_t)n + OS_TILE - 1) / OS_TILE;
+  return (OS_MAX_BINS * std::max<size_t>(n_tiles, 1) + OS_MAX_BINS) * 4;
+}
+// keys: the n keys (left in an unspecified order); key_tmp, perm_tmp: n words each; scratch: order_sort_scratch_bytes(n).
+// perm_out[k] = the index of the k-th smallest key by its bits [0, end_bit), equal keys in index order.
+void launch_order_sort(uint32_t *keys, uint32_t *key_tmp, uint32_t *perm_out, uint32_t *perm_tmp, uint32_t n, unsigned end_bit, void *scratch,
+                       hipStream_t s) {
+  if (!n) return;
+  end_bit = std::min(32u, std::max(1u, end_bit));
+  const unsigned np = order_sort_passes(end_bit), per = (end_bit + np - 1u) / np;
+  const uint32_t n_tiles = cdiv(n, OS_TILE);
+  uint32_t *hist = reinterpret_cast<uint32_t *>(scratch), *tot = hist + (size_t)OS_MAX_BINS * n_tiles;
+  // pass k (from 1) writes perm_out when np - k is even: the last pass lands there
+  uint32_t *kin = keys, *kout = key_tmp;
+  const uint32_t *vin = nullptr;
+  for (unsigned k = 1, shift = 0; k <= np; k++, shift += per) {
+    const unsigned nbits = std::min(per, end_bit - shift);
+    const uint32_t bins = 1u << nbits;
+    uint32_t *vout = ((np - k) & 1u) ? perm_tmp : perm_out;
+    order_hist_kernel<<<n_tiles, OS_HIST_THREADS, 0, s>>>(kin, n, shift, bins, n_tiles, hist);
+    order_rowscan_kernel<<<bins, 256, 0, s>>>(hist, n_tiles, tot);
+    const bool first = k == 1, last = k == np;
+    if (first && last) order_scatter_kernel<true, true><<<n_tiles, OS_THREADS, 0, s>>>(kin, vin, n, shift, bins, nbits, n_tiles, hist, tot, kout, vout);
+    else if (first) order_scatter_kernel<true, false><<<n_tiles, OS_THREADS, 0, s>>>(kin, vin, n, shift, bins, nbits, n_tiles, hist, tot, kout, vout);
+    else if (last) order_scatter_kernel<false, true><<<n_tiles, OS_THREADS, 0, s>>>(kin, vin, n, shift, bins, nbits, n_tiles, hist, tot, kout, vout);
+    else order_scatter_kernel<false, false><<<n_tiles, OS_THREADS, 0, s>>>(kin, vin, n, shift, bins, nbits, n_tiles, hist, tot, kout, vout);
+    std::swap(kin, kout);
+    vin = vout;
+  }
+}
 size_t sort_u64v_scratch_bytes(uint32_t n) {
   size_t bytes = 0;
   (void)rocprim::radix_sort_pairs<rocprim::default_config, const unsigned long long *, unsigned long long *,

@@ -240,6 +240,14 @@ void launch_dfs_compact(const uint32_t *gstart, const uint32_t *cnt, const uint3
 size_t sort_u32_scratch_bytes(uint32_t n);
 void launch_sort_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
                      uint32_t n, hipStream_t s, unsigned begin_bit = 0, unsigned end_bit = 32);
+// the lookup order's sort (kernels.hip: order_scatter_kernel): perm_out[k] = the index of the k-th smallest key by its bits
+// [0, end_bit), equal keys in index order.  keys are left in an unspecified order; key_tmp / perm_tmp: n words each
+size_t order_sort_scratch_bytes(uint32_t n);
+void launch_order_sort(uint32_t *keys, uint32_t *key_tmp, uint32_t *perm_out, uint32_t *perm_tmp, uint32_t n, unsigned end_bit, void *scratch,
+                       hipStream_t s);
+#ifdef IMPG_OS_CLOCKS
+void order_sort_clocks(unsigned long long *out, bool reset);  // (phase clocks of order_scatter_kernel: a tuning build)
+#endif
 size_t sort_u64v_scratch_bytes(uint32_t n);
 void launch_sort_u64v(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout,
                       const unsigned long long *vin, unsigned long long *vout, uint32_t n, hipStream_t s, unsigned end_bit = 64,

@@ -142,10 +142,9 @@ struct ShardedExpander : Expander {
     if (W > 1) {
       unsigned bits = 1;
       while ((1u << bits) < W) bits++;
-      const size_t tb = sort_u32_scratch_bytes(n);
-      E.sort_tmp.reserve(tb);
-      launch_sort_u32(E.sort_tmp.p, tb, E.lo_key.as<uint32_t>(), E.lo_key2.as<uint32_t>(), E.lo_idx.as<uint32_t>(),
-                      E.lo_perm.as<uint32_t>(), n, s, 0, bits);  // stable: frontier order within an owner
+      E.sort_tmp.reserve(order_sort_scratch_bytes(n));
+      launch_order_sort(E.lo_key.as<uint32_t>(), E.lo_key2.as<uint32_t>(), E.lo_perm.as<uint32_t>(), E.lo_idx.as<uint32_t>(), n, bits,
+                        E.sort_tmp.p, s);  // stable: frontier order within an owner
       launch_route_gather(fr, E.lo_perm.as<uint32_t>(), n, send_fr.as<FrontierRec>(), s);
     } else {
       launch_route_gather(fr, E.lo_idx.as<uint32_t>(), n, send_fr.as<FrontierRec>(), s);

@@ -568,6 +568,11 @@ int impg_synth_seq_name(uint32_t id, char *out, size_t cap);
 int impg_synth_skewed_paf_text(uint64_t seed, size_t n_records, uint32_t n_seq, int32_t seq_len, const char *path, uint64_t *n_ops_out);
 int impg_synth_bed(uint64_t seed, size_t n, uint32_t n_seq, int32_t seq_len, int32_t range_len,
                    impg_gpu_range_t *out);
+/* Diagnostics: the engine's own sort of a level's lookup order (impg_amd/csrc/kernels.hip, order_scatter_kernel -- the place
+ * of the reference's per-tree query order, which the engine is free to choose: interval_tree lookups commute) run on `n`
+ * pseudo-random keys of `end_bit` bits on `device` and checked on the host: a permutation, keys non-decreasing, equal keys
+ * in index order.  IMPG_OK or IMPG_E_INVALID with the first offending place in impg_gpu_last_error(). */
+int impg_gpu_selftest_order_sort(int device, uint32_t n, unsigned end_bit, uint64_t seed);
 
 #ifdef __cplusplus
 }

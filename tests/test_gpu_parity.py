@@ -1777,3 +1777,15 @@ def test_prewarm_options(tmp_path):
     assert g.query_transitive_bfs(*ranges[0], max_depth=2).tolist() == c.query(*ranges[0], transitive=True, max_depth=2).tolist()
     with pytest.raises(impg_amd.ImpgGpuError):
         g.set_option("prewarm_walk", 3)
+
+
+def test_lookup_order_sort():
+    """The hand-written stable argsort behind a level's lookup order (order_scatter_kernel): a permutation, keys
+    non-decreasing by their low bits, equal keys in index order -- checked on the host by impg_gpu_selftest_order_sort for
+    sizes around the tile (8 192 keys) and pass boundaries (digits of <= 8 bits: 1 .. 4 passes), repeated keys, and bits
+    above end_bit set."""
+    from impg_amd import _lib
+    for n, bits in [(1, 1), (2, 1), (63, 3), (64, 7), (8191, 8), (8192, 9), (8193, 16), (100_000, 17), (1_000_003, 21), (3_000_000, 24),
+                    (500_000, 25), (70_000, 32), (2_000_000, 5), (16_384, 21)]:
+        for seed in (1, 2):
+            _lib.check(_lib.lib().impg_gpu_selftest_order_sort(0, n, bits, seed + 10 * bits))

@@ -472,11 +472,10 @@ uint64_t Engine::expand(const DeviceIndexView &v, const FrontierRec *fr, uint32_
       // a slot's place in its record's run is the hit's visit position, one byte a pair from the lookup (emit_vpos)
       ordered_offsets();
       ord_dest.reserve(std::max<size_t>((size_t)n_fr * 4, 256));
-      launch_ord_dest_by_place(win_se.as<FrontierRec>(), d_perm, n_fr, L.slot_ref.as<uint32_t>(), ord_offsets.as<uint32_t>(), L.lvbase.as<uint32_t>(),
-                               ord_dest.as<uint32_t>(), stream);
       ord_vpos.reserve(std::max<size_t>(P + 256, 256));
       const bool by_visit = ordered_rows_by_visit();
-      launch_emit_vpos(v, n_fr, pair_off.as<uint32_t>(), win.as<uint4>(), ord_vpos.as<uint8_t>(), stream, by_visit);
+      const OrdDestArgs od{win_se.as<FrontierRec>(), d_perm, L.slot_ref.as<uint32_t>(), ord_offsets.as<uint32_t>(), L.lvbase.as<uint32_t>(), ord_dest.as<uint32_t>()};
+      launch_emit_vpos(v, n_fr, pair_off.as<uint32_t>(), win.as<uint4>(), ord_vpos.as<uint8_t>(), stream, by_visit, &od);
       wlists.ord = OrderedOut{ord_rows.as<impg_gpu_interval_t>(), ord_dest.as<uint32_t>(), ord_vpos.as<uint8_t>(), ord_min_len, by_visit ? 1u : 0u};
       L.placed = true;
     }

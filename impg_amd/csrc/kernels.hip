@@ -727,7 +727,7 @@ constexpr uint32_t VPOS_LDS = 64u * 64u + 8u;
 template <bool BY_VISIT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void emit_vpos_lane_kernel(DeviceIndexView v, uint32_t n,
                                                               const uint32_t *__restrict__ pair_off, const uint4 *__restrict__ win,
-                                                              uint8_t *__restrict__ vpos) {
+                                                              uint8_t *__restrict__ vpos, OrdDestArgs od) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[VPOS_LDS];
   const unsigned lane = threadIdx.x;
   const uint32_t i = blockIdx.x * 64u + lane;
@@ -738,6 +738,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     lo = w.x; ub = w.y;
     mask = ((unsigned long long)w.w << 32) | w.z;
     off = pair_off[i];
+    // (the range's first row, ord_dest_by_place_kernel's gathers, under the sort: a kernel of its own took 1.5 ms for them)
+    if (od.dest) { const uint32_t q = od.frp[i].qidx; od.dest[i] = od.offsets[q] + od.lvbase[q] + od.slot_ref[od.perm[i]]; }
   }
   const uint32_t b = lo & ~3u;
   const bool mine = lo < ub && ub - b <= 64u;  // (wider windows: the wave-per-range emit lists their entries in visit order)
@@ -5285,10 +5287,12 @@ void launch_ord_level_rows(const FrontierRec *fr, const uint32_t *pair_range, ui
                            impg_gpu_interval_t *rows, hipStream_t s) {
   if (n_pairs) ord_level_rows_kernel<<<cdiv(n_pairs, 256), 256, 0, s>>>(fr, pair_range, n_pairs, h, run_start, slot_ref, offsets, lvbase, min_output_length, rows);
 }
-void launch_emit_vpos(const DeviceIndexView &v, uint32_t n, const uint32_t *pair_off, const uint4 *win, uint8_t *vpos, hipStream_t s, bool by_visit) {
+void launch_emit_vpos(const DeviceIndexView &v, uint32_t n, const uint32_t *pair_off, const uint4 *win, uint8_t *vpos, hipStream_t s, bool by_visit,
+                      const OrdDestArgs *dest) {
   if (!n) return;
-  if (by_visit) emit_vpos_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, vpos);
-  else emit_vpos_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, vpos);
+  const OrdDestArgs od = dest ? *dest : OrdDestArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (by_visit) emit_vpos_lane_kernel<true><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, vpos, od);
+  else emit_vpos_lane_kernel<false><<<cdiv(n, 64), 64, 0, s>>>(v, n, pair_off, win, vpos, od);
 }
 // (IMPG_ORD_ENTRIES=1: ordered rows from the entry-major kernel, for the comparison -- see launch_project)
 bool ordered_rows_by_visit() {
@@ -5780,16 +5784,21 @@ __global__ __launch_bounds__(OS_HIST_THREADS) void order_hist_kernel(const uint3
   __syncthreads();
   if (threadIdx.x < bins) hist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
 }
-__global__ __launch_bounds__(256) void order_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ tot) {
+constexpr uint32_t OS_ROW_THREADS = 1024;
+__global__ __launch_bounds__(OS_ROW_THREADS) void order_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ tot) {
+  __shared__ uint32_t wsum[OS_ROW_THREADS / 64u];
   uint32_t *row = hist + (size_t)blockIdx.x * n_tiles;
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < n_tiles; base += 256u) {
+  for (uint32_t base = 0; base < n_tiles; base += OS_ROW_THREADS) {
     const uint32_t i = base + threadIdx.x;
     const uint32_t x = i < n_tiles ? row[i] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_excl_scan(x, &total);
+    const uint32_t ex = block_excl_scan_n<OS_ROW_THREADS / 64u>(x, wsum);
     if (i < n_tiles) row[i] = carry + ex;
-    carry += total;
+    // (the turn's total: the last thread's inclusive value, through LDS)
+    if (threadIdx.x == OS_ROW_THREADS - 1u) wsum[0] = ex + x;
+    __syncthreads();
+    carry += wsum[0];
+    __syncthreads();
   }
   if (threadIdx.x == 0) tot[blockIdx.x] = carry;
 }
@@ -5919,7 +5928,7 @@ void launch_order_sort(uint32_t *keys, uint32_t *key_tmp, uint32_t *perm_out, ui
     const uint32_t bins = 1u << nbits;
     uint32_t *vout = ((np - k) & 1u) ? perm_tmp : perm_out;
     order_hist_kernel<<<n_tiles, OS_HIST_THREADS, 0, s>>>(kin, n, shift, bins, n_tiles, hist);
-    order_rowscan_kernel<<<bins, 256, 0, s>>>(hist, n_tiles, tot);
+    order_rowscan_kernel<<<bins, OS_ROW_THREADS, 0, s>>>(hist, n_tiles, tot);
     const bool first = k == 1, last = k == np;
     if (first && last) order_scatter_kernel<true, true><<<n_tiles, OS_THREADS, 0, s>>>(kin, vin, n, shift, bins, nbits, n_tiles, hist, tot, kout, vout);
     else if (first) order_scatter_kernel<true, false><<<n_tiles, OS_THREADS, 0, s>>>(kin, vin, n, shift, bins, nbits, n_tiles, hist, tot, kout, vout);

@@ -220,7 +220,9 @@ int impg_gpu_index_approximate(const impg_gpu_index_t *);
  * most 64; 1 = none),
  * "segment_groups" (1, the default: the visited update orders a level's hits by (query, hit sequence) query by query --
  * a query's ranges run by run in frontier order, a counting sort by sequence inside the query; 0: with the library's
- * stable radix sort; results are identical either way),
+ * stable radix sort; results are identical either way) and "segment_parts" (0, the default: a query whose level holds
+ * more hits than one wave should take is cut into slices of its frontier ranges, as many as the level's size asks for;
+ * N = that many slices on every level that groups by segments -- for tests; results are identical),
  * "fuse_final_level" (1, the default: the final level of such a run -- no update follows, no row is kept --
  * takes its (range, entry) pairs straight from the lookup's per-range windows inside the projection kernel; the emit
  * pass and its pair lists are skipped; counts and checksums are identical either way).

@@ -4,7 +4,7 @@
 # (scripts/profile_r2.sh) -- the JSON summaries bench.py's roofline block reads, the default bench line with its three tiers,
 # configs 4 / 5, the skewed workload (+ its kernel trace), one rank through the sharded path, --min-identity, and the GPU
 # suite with its durations.  Everything lands in gpurun_out/final_r6/ (copy what is to be judged into profiles/).
-# PARTS: space-separated subset of "profile config4prof bench suite" (default: all).
+# PARTS: space-separated subset of "profile config4prof bench ordered config45full suite" (default: the first three and the suite).
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
@@ -57,7 +57,7 @@ if has bench; then
     timeout 900 python bench.py --workload config5 --ranges 1000000 --steps 1 --warmup 0 --cpu-sample 0 --no-extras > $F/bench_config5_1e6.json 2> $F/bench_config5_1e6.err
   fi
   if [ -n "${CONFIG4_FULL:-}" ]; then
-    timeout 900 python bench.py --workload config4 --records 100000000 --steps 3 --warmup 1 --no-extras --cpu-sample 0 > $F/bench_config4_1e8.json 2> $F/bench_config4_1e8.err
+    timeout 900 python bench.py --workload config4 --records 100000000 --form count --steps 3 --warmup 1 --no-extras --cpu-sample 0 > $F/bench_config4_1e8.json 2> $F/bench_config4_1e8.err
   fi
   for f in bench_full bench_count_form bench_sharded_1rank bench_config4 bench_config5_20000 bench_skewed bench_skewed_1e6 bench_min_identity bench_config5_1e6 bench_config4_1e8; do python3 -c "
 import json,sys
@@ -65,6 +65,15 @@ try:
     d=json.loads(open('$F/$f.json').read().strip().splitlines()[-1]); print('$f', '%.4g' % d['value'], '%.2f ms' % d['ms_per_step'], d.get('stage_ms_per_step_rank0'), d.get('self_check'), (d.get('roofline') or {}).get('measured_traffic_frac'), (d.get('roofline') or {}).get('valu_issue_frac'), d.get('parity_vs_single'), d.get('value_count_only'), d.get('value_ordered_rows_device'))
 except Exception as e: print('$f', 'FAILED', e)
 "; done
+fi
+if has ordered; then  # the ordered-rows tier as the timed step, under the kernel trace
+  TAG=r6_ordered STEPS=2 WARMUP=1 PASSES="trace" EXTRA_ARGS="--form ordered" bash scripts/profile_r2.sh > $F/ordered_trace.log 2>&1
+  cp $REPO/gpurun_out/prof_r6_ordered/trace_kernel_stats.csv $F/r6_ordered_trace_kernel_stats.csv 2>/dev/null
+  cp $REPO/gpurun_out/prof_r6_ordered/trace_bench.json $F/r6_ordered_trace_bench.json 2>/dev/null
+fi
+if has config45full; then  # the config-4 / config-5 parity tests at the sizes the suite's defaults were cut from (round 5's review)
+  (IMPG_CONFIG4_RECORDS=5e7 IMPG_CONFIG5_WINDOWS=2e5 timeout 1500 python -m pytest tests/test_gpu_config45.py -m gpu -x -q --durations=8 2>&1 | tail -16) > $F/gputest_config45_full.log
+  tail -3 $F/gputest_config45_full.log
 fi
 if has suite; then
   (timeout 1500 python -m pytest tests -m gpu -x -q --durations=20 2>&1 | tail -34) > $F/gputest.log

@@ -5823,7 +5823,10 @@ __device__ unsigned long long g_os_clk[8];
 #define OS_MARK(i) do { } while (0)
 #endif
 template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(OS_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void order_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t n,
+#ifndef IMPG_OS_WAVES_PER_EU
+#define IMPG_OS_WAVES_PER_EU 6
+#endif
+__global__ __launch_bounds__(OS_THREADS) __attribute__((amdgpu_waves_per_eu(IMPG_OS_WAVES_PER_EU, IMPG_OS_WAVES_PER_EU))) void order_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t n,
                                                                    uint32_t shift, uint32_t bins, uint32_t nbits, uint32_t n_tiles,
                                                                    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ tot,
                                                                    uint32_t *__restrict__ kout, uint32_t *__restrict__ vout) {

@@ -264,8 +264,8 @@ bool Engine::run_walk(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges
   if (dbg) {
     unsigned long long h[32];
     IMPG_HIP(hipMemcpy(h, d_dbg.p, 256, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[walk] Mclk: drop %.3f window %.3f count %.3f emit %.3f project %.3f sort %.3f groups %.3f (gap %.3f) pieces %.3f merge %.3f shared last level %.3f | pops %llu dropped %llu max stack %llu max pieces %llu max group hits %llu max group list %llu | fail q=%llu flag=%llu target=%llu n_seq=%llu nw=%llu npc=%llu vused=%llu\n",
-            h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5] / 1e6, h[6] / 1e6, h[7] / 1e6, h[8] / 1e6, h[9] / 1e6, h[10] / 1e6, h[16], h[17], h[18], h[19], h[20], h[21],
+    fprintf(stderr, "[walk] Mclk: drop %.3f window %.3f count %.3f emit %.3f project %.3f sort %.3f groups %.3f (gap %.3f) pieces %.3f merge %.3f shared last level %.3f | pops %llu dropped %llu max stack %llu max pieces %llu max group hits %llu max group list %llu heads pass %.3f Mclk slowest group %.3f Mclk | fail q=%llu flag=%llu target=%llu n_seq=%llu nw=%llu npc=%llu vused=%llu\n",
+            h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5] / 1e6, h[6] / 1e6, h[7] / 1e6, h[8] / 1e6, h[9] / 1e6, h[10] / 1e6, h[16], h[17], h[18], h[19], h[20], h[21], h[22] / 1e6, h[23] / 1e6,
             h[24], h[25], h[26], h[27], h[28], h[29], h[30]);
   }
   if (dbg)

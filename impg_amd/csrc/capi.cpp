@@ -55,6 +55,7 @@ EngineLease::EngineLease(impg_gpu_index &ix_) : ix(ix_) {
   e->walk_members = ix.opt_walk_members;
   e->seg_group = ix.opt_seg_group;
   e->seg_parts_force = ix.opt_seg_parts;
+  e->seg_stats = ix.seg_stats;
 }
 EngineLease::~EngineLease() {
   e->remote = nullptr;
@@ -575,6 +576,9 @@ int impg_gpu_get_counter(const impg_gpu_index_t *ix, const char *key, int64_t *v
   if (k == "walk_launches") *value_out = (int64_t)ix->walk_launches.load();
   else if (k == "walk_fallbacks") *value_out = (int64_t)ix->walk_fallbacks.load();
   else if (k == "walk_members") *value_out = (int64_t)ix->walk_last_members.load();
+  else if (k == "segment_sliced_levels") *value_out = (int64_t)ix->seg_stats[0].load();
+  else if (k == "segment_retries") *value_out = (int64_t)ix->seg_stats[1].load();
+  else if (k == "segment_library_levels") *value_out = (int64_t)ix->seg_stats[2].load();
   else throw Error{IMPG_E_INVALID, "unknown counter " + k};
   return IMPG_OK;
   IMPG_CATCH

@@ -659,12 +659,14 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
         if (bad[0]) by_segments = false;  // a frontier that is not sorted by query: the library sort below
         else if (bad[1]) {  // one huge query among small ones (bad[1] = its hits): once more in slices cut for it, or the library sort
           const uint32_t again = seg_parts == 1 && attempt == 0 ? seg_group_parts(P, n_queries, v.n_seq, bad[1]) : 0u;
-          if (again > 1) { seg_parts = again; IMPG_HIP(hipMemsetAsync(unsorted, 0, 8, stream)); }
+          if (again > 1) { seg_parts = again; IMPG_HIP(hipMemsetAsync(unsorted, 0, 8, stream)); if (seg_stats) seg_stats[1]++; }
           else by_segments = false;
         } else { seg_groups = (uint32_t)tg; break; }
       }
+      if (by_segments && seg_parts > 1 && seg_stats) seg_stats[0]++;
     }
     if (!by_segments) {
+      if (seg_stats) seg_stats[2]++;
       keys.reserve((size_t)P * 8); skeys.reserve((size_t)P * 8); vals.reserve((size_t)P * 8);
       IMPG_HIP(hipMemsetAsync(act_slots.p, 0, COUNT_BYTES, stream));
       launch_update_keys(fr, L.pair_range.as<uint32_t>(), P, h, keys.as<unsigned long long>(), vals.as<unsigned long long>(),

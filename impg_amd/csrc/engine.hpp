@@ -1,5 +1,6 @@
 // Per-index execution state: stream, events, scratch buffers (engine.cpp).
 #pragma once
+#include <atomic>
 #include <functional>
 #include <memory>
 #include <string>
@@ -225,6 +226,7 @@ struct Engine {
   DevBuf walk_slabs, walk_ctr, walk_ctl;
   DevBuf rstat;  // hit_stats: a level's per-range counts / checksums
   DevBuf seg_run, seg_q, seg_bins, seg_tot;  // update by segments: run bounds per frontier range; first / last range, active hits and output offset per query
+  std::atomic<uint64_t> *seg_stats = nullptr;  // the handle's counters (impg_gpu_index::seg_stats), or null
   uint32_t seg_parts_force = 0;  // option "segment_parts": every level that groups by segments cuts its queries into this many slices (0: by size)
   bool seg_group = true;  // option "segment_groups": the update's hits grouped query by query instead of by the library's radix sort
   uint32_t walk_members = 0;  // option "walk_members": workgroups per query of the grid form (0: as many as fit, at most 32; 1: no grid form)

@@ -434,6 +434,9 @@ struct impg_gpu_index {
   bool opt_seg_group = true;      // option "segment_groups" (Engine::seg_group)
   uint32_t opt_seg_parts = 0;     // option "segment_parts" (Engine::seg_parts_force)
   mutable std::atomic<uint64_t> walk_launches{0}, walk_fallbacks{0}, walk_last_members{1};  // impg_gpu_get_counter
+  // ... and how the visited updates of its batches grouped their hits: levels cut into slices, levels counted a second time
+  // for one huge query, levels that went to the library sort ([0], [1], [2]; Engine::update)
+  mutable std::atomic<uint64_t> seg_stats[3] = {};
   impg::ShardCtx *shard = nullptr;    // set: this index is one rank's shard; queries are collective calls
   impg::Cluster *cluster = nullptr;   // set: this handle fronts n_dev shards in this process (no arrays of its own)
   impg_gpu_index();

@@ -235,7 +235,10 @@ int impg_gpu_set_option(impg_gpu_index_t *, const char *key, int64_t value);
  * answered): "walk_launches" = per-query walk launches that answered their batch (walk_device.inc: DFS batches, small
  * depth-limited BFS batches incl. masked ones -- the shape of partition.rs:359-391), "walk_fallbacks" = launches whose
  * batch the batch engine had to run again (a query outgrew its slab), "walk_members" = workgroups per query of the
- * last grid-form launch (1: not the grid form). */
+ * last grid-form launch (1: not the grid form); how the visited updates grouped their hits: "segment_sliced_levels" =
+ * levels whose queries were cut into slices of their frontier ranges, "segment_retries" = levels counted a second time
+ * because one query held more hits than a wave should take, "segment_library_levels" = levels that went through the
+ * library's radix sort instead. */
 int impg_gpu_get_counter(const impg_gpu_index_t *, const char *key, int64_t *value_out);
 /* Large result arrays live in pinned host blocks that are recycled through a process-wide pool (at most
  * IMPG_PINNED_POOL_BYTES, default 6 GiB, are kept when results are freed).  Gives pooled blocks back to the system

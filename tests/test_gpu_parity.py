@@ -1789,3 +1789,37 @@ def test_lookup_order_sort():
                     (500_000, 25), (70_000, 32), (2_000_000, 5), (16_384, 21)]:
         for seed in (1, 2):
             _lib.check(_lib.lib().impg_gpu_selftest_order_sort(0, n, bits, seed + 10 * bits))
+
+
+def test_update_slices_a_huge_query(tmp_path):
+    """The visited update's automatic choices (no option forced).  An index of a dense component (s0-s2: every level of a
+    whole-sequence query holds tens of thousands of hits) and a sparse one (t0-t2).  A batch of small queries on the sparse
+    component with two whole-sequence queries on the dense one: the level's average is small, one query holds more hits
+    than a wave should take, so the level is counted again in slices cut for it (segment_retries); then a batch of
+    whole-sequence queries only (sliced from the start).  Counts, checksums and projections equal the library-sort form's;
+    rows equal the oracle's on the small queries and on one whole-sequence query."""
+    dense, _ = random_paf(4242, 45_000, n_seq=3, seq_len=40_000, max_ops=40, weird=False, self_aln=False)
+    sparse, _ = random_paf(4243, 400, n_seq=3, seq_len=40_000, max_ops=40, weird=False, self_aln=False)
+    sparse = "\n".join(ln.replace("s0\t", "t0\t").replace("s1\t", "t1\t").replace("s2\t", "t2\t") for ln in sparse.splitlines()) + "\n"
+    g, c = both(tmp_path, dense + sparse)
+    g.set_option("walk_kernel", 0)
+    sid = {g.seq_name(i): i for i in range(g.num_seqs())}
+    small = [(sid["t%d" % t], a, b) for t, a, b in random_ranges(5, 60, 3, 40_000, max_len=3000, min_len=200)]
+    whole = [(sid["s0"], 0, 40_000), (sid["s1"], 0, 40_000), (sid["s2"], 100, 39_000)]
+    kw = dict(transitive=True, max_depth=3, min_transitive_len=10)
+    p = impg_amd.make_params(**kw)
+    for batch, want_retry in ((small + whole[:2], True), (whole, False)):
+        before = {k: g.counter(k) for k in ("segment_sliced_levels", "segment_retries", "segment_library_levels")}
+        g.set_option("segment_groups", 1)
+        st1, cnt1, ck1 = g.query_batch_stats(batch, p)
+        after = {k: g.counter(k) for k in before}
+        assert after["segment_sliced_levels"] > before["segment_sliced_levels"], (before, after)
+        if want_retry:
+            assert after["segment_retries"] > before["segment_retries"], (before, after)
+        assert after["segment_library_levels"] == before["segment_library_levels"], (before, after)
+        g.set_option("segment_groups", 0)
+        st0, cnt0, ck0 = g.query_batch_stats(batch, p)
+        assert (st1.projected, cnt1.tolist(), ck1.tolist()) == (st0.projected, cnt0.tolist(), ck0.tolist())
+        assert int(cnt1.max()) > 32768
+    g.set_option("segment_groups", 1)
+    assert_same(g, c, small[:12] + whole[:1], **kw)

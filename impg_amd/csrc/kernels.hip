@@ -151,7 +151,11 @@ __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView 
   const int32_t *ecol = end_col<TRANSITIVE>(v);
   uint32_t c = 0;
   unsigned long long mask = 0;
-  for (uint32_t b = lo & ~3u; b < ub; b += 8u) {
+  // (a window wider than the mask is counted by a wave of lookup_count_wide_kernel, which takes it off the wide list: a lane
+  // walking thousands of entries of a dense target kept its 63 neighbours waiting -- 3.6 of a skewed step's 22 ms)
+  const bool wide = lo < ub && ub - (lo & ~3u) > 64u;
+  const bool deferred = wide && wide_list != nullptr;
+  for (uint32_t b = lo & ~3u; b < ub && !deferred; b += 8u) {
     const int4 e0 = *reinterpret_cast<const int4 *>(ecol + b);
     int4 e1 = make_int4(0, 0, 0, 0);
     if (b + 4u < ub) e1 = *reinterpret_cast<const int4 *>(ecol + b + 4u);
@@ -170,7 +174,33 @@ __global__ __launch_bounds__(256) void lookup_count_lane_kernel(DeviceIndexView 
   win[o] = make_uint4(lo, ub, (uint32_t)mask, (uint32_t)(mask >> 32));
   if (se) se[o] = f;  // (the whole record at the range's place: the projection reads its ends there, a kept level its range and target)
   // windows too wide for the lane-per-range emit pass (dense targets) are listed for the wave-per-range one
-  if (wide_list && lo < ub && ub - (lo & ~3u) > 64u) wide_list[atomicAdd(wide_n, 1u)] = o;
+  if (deferred) wide_list[atomicAdd(wide_n, 1u)] = o;
+}
+// ... and the wide windows' counts: a wave per listed window, 64 entries a round
+template <bool TRANSITIVE>
+__global__ __launch_bounds__(256) void lookup_count_wide_kernel(DeviceIndexView v, const FrontierRec *__restrict__ fr, const uint32_t *__restrict__ perm,
+                                                                const uint32_t *__restrict__ wide_n, const uint32_t *__restrict__ wide_list,
+                                                                const uint4 *__restrict__ win, int by_place, uint32_t *__restrict__ cnt,
+                                                                uint32_t *__restrict__ cnt_ref) {
+  const uint32_t nw = *wide_n, lane = lane_id();
+  const int32_t *ecol = end_col<TRANSITIVE>(v);
+  for (uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6); k < nw; k += gridDim.x * 4u) {
+    const uint32_t o = wide_list[k];
+    const uint32_t r = by_place ? perm[o] : o;
+    const uint4 w = win[o];
+    const int32_t qs = fr[r].start;
+    uint32_t c = 0;
+    for (uint32_t b = w.x + lane; b < w.y; b += 256u) {  // (four loads in flight)
+      int32_t e[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; u++) e[u] = b + 64u * u < w.y ? ecol[b + 64u * u] : 0;
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; u++) c += (b + 64u * u < w.y && window_hit<TRANSITIVE>(e[u], qs)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
+    if (lane == 0) { cnt[o] = c; if (cnt_ref) cnt_ref[r] = c; }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -5179,6 +5209,11 @@ void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32
   if (lanes) IMPG_HIP(hipMemsetAsync(wide_n, 0, 8, s));  // (the wide list's length, and its overflow list's: launch_lookup_emit)
   if (transitive) lookup_count_lane_kernel<true><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp, se, cnt_ref);
   else lookup_count_lane_kernel<false><<<cdiv(n, 256), 256, 0, s>>>(v, fr, n, perm, cnt, win, wide_n, lanes ? wide_list : nullptr, bp, se, cnt_ref);
+  if (lanes) {  // the listed (wide) windows' counts; the list's length stays on the device: a grid of at most 8 192 waves strides over it
+    const uint32_t g = std::min(cdiv(n, 4u), 2048u);
+    if (transitive) lookup_count_wide_kernel<true><<<g, 256, 0, s>>>(v, fr, perm, wide_n, wide_list, win, bp, cnt, cnt_ref);
+    else lookup_count_wide_kernel<false><<<g, 256, 0, s>>>(v, fr, perm, wide_n, wide_list, win, bp, cnt, cnt_ref);
+  }
 }
 // tile_first[t] = the range whose places include place t * PROJ_BLOCK (see WindowLists): one thread per range, which
 // names itself at every tile border inside its run of places (a run of <= 64 places crosses at most one)

@@ -626,7 +626,10 @@ uint32_t Engine::update(const DeviceIndexView &v, const FrontierRec *fr, LevelBu
     uint32_t *sg_run_start = nullptr, *sg_run_end = nullptr, *sg_q = nullptr, *sg_bins = nullptr;
     // (a query with more than a wave's worth of hits is cut into slices of its frontier ranges: seg_group_parts)
     uint32_t seg_parts = seg_group && !want_flags && !multi && seg_group_fits(v.n_seq) && L.n_frontier > 0 ? seg_group_parts(P, n_queries, v.n_seq) : 0u;
-    if (seg_parts_force && seg_parts) seg_parts = std::max(1u, std::min(seg_parts_force, 4096u));
+    if (seg_parts_force && seg_parts) {  // (forced, for tests: within what the unit index and the counters' buffer take)
+      seg_parts = std::max(1u, std::min(seg_parts_force, 4096u));
+      while (seg_parts > 1 && ((uint64_t)n_queries * seg_parts >= (1ull << 31) || seg_group_bins_bytes(n_queries, v.n_seq, seg_parts) > (1ull << 30))) seg_parts >>= 1;
+    }
     bool by_segments = seg_parts != 0;
     if (by_segments) {
       const uint32_t n_fr = L.n_frontier;

@@ -14,10 +14,14 @@ ranges = np.zeros(len(bed), dtype=impg_amd.RANGE_DTYPE)
 ranges["target_id"] = [g.seq_id(impg_amd.synth_seq_name(int(t))) for t in bed["target_id"]]
 ranges["start"], ranges["end"] = bed["start"], bed["end"]
 for label, p in (("query", impg_amd.make_params()), ("bfs -m 3", impg_amd.make_params(transitive=True, max_depth=3)),
-                 ("dfs -m 2", impg_amd.make_params(transitive=True, dfs=True, max_depth=2))):
-    for nb in (1, 8, 64):
-        reps = 200 if nb == 1 else 50
-        for _ in range(5):
+                 ("dfs -m 2", impg_amd.make_params(transitive=True, dfs=True, max_depth=2)),
+                 # the shapes the per-query walk does not take (the batch engine answers them)
+                 ("bfs3 cigar", impg_amd.make_params(transitive=True, max_depth=3, store_cigar=True)),
+                 ("bfs3 multi", impg_amd.make_params(transitive=True, max_depth=3, multi_impg=True))):
+    slow = label.startswith("bfs3 ")  # (answered by the batch engine: milliseconds to seconds a call -- a few calls only)
+    for nb in ((1,) if slow else (1, 8, 64)):
+        reps = 3 if slow else (200 if nb == 1 else 50)
+        for _ in range(1 if slow else 5):
             g.query_batch(ranges[:nb], p)
         t0 = time.perf_counter()
         rows = 0

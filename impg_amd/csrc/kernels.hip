@@ -768,7 +768,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     lo = w.x; ub = w.y;
     mask = ((unsigned long long)w.w << 32) | w.z;
     off = pair_off[i];
-    // (the range's first row, ord_dest_by_place_kernel's gathers, under the sort: a kernel of its own took 1.5 ms for them)
+    // (the range's first row -- offsets[query] + the level's base + the record's slots -- gathered under the sort: a kernel of its own took 1.5 ms for it)
     if (od.dest) { const uint32_t q = od.frp[i].qidx; od.dest[i] = od.offsets[q] + od.lvbase[q] + od.slot_ref[od.perm[i]]; }
   }
   const uint32_t b = lo & ~3u;
@@ -5260,14 +5260,6 @@ __global__ __launch_bounds__(256) void ord_level_bases_kernel(const FrontierRec 
   lvbase[q] = at - sa;  // (mod 2^32: row = offsets[q] + lvbase[q] + slot_ref[r] + k)
   acc[q] = at + (sb - sa);
 }
-__global__ __launch_bounds__(256) void ord_dest_by_place_kernel(const FrontierRec *__restrict__ frp, const uint32_t *__restrict__ perm, uint32_t n_fr,
-                                                                const uint32_t *__restrict__ slot_ref, const uint32_t *__restrict__ offsets,
-                                                                const uint32_t *__restrict__ lvbase, uint32_t *__restrict__ dest) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n_fr) return;
-  const uint32_t q = frp[i].qidx;
-  dest[i] = offsets[q] + lvbase[q] + slot_ref[perm[i]];
-}
 __global__ __launch_bounds__(256) void ord_self_rows_kernel(const FrontierRec *__restrict__ self, const impg_gpu_range_t *__restrict__ ranges, uint32_t n,
                                                             const uint32_t *__restrict__ offsets, impg_gpu_interval_t *__restrict__ rows) {
   const uint32_t q = blockIdx.x * 256u + threadIdx.x;
@@ -5305,10 +5297,6 @@ void launch_ord_self_count(const FrontierRec *self, const impg_gpu_range_t *rang
 void launch_ord_level_bases(const FrontierRec *fr, uint32_t n_fr, const uint32_t *slot_ref, uint32_t total, uint32_t n_queries, uint32_t *acc,
                             uint32_t *lvbase, hipStream_t s) {
   if (n_queries) ord_level_bases_kernel<<<cdiv(n_queries, 256), 256, 0, s>>>(fr, n_fr, slot_ref, total, n_queries, acc, lvbase);
-}
-void launch_ord_dest_by_place(const FrontierRec *frp, const uint32_t *perm, uint32_t n_fr, const uint32_t *slot_ref, const uint32_t *offsets,
-                              const uint32_t *lvbase, uint32_t *dest, hipStream_t s) {
-  if (n_fr) ord_dest_by_place_kernel<<<cdiv(n_fr, 256), 256, 0, s>>>(frp, perm, n_fr, slot_ref, offsets, lvbase, dest);
 }
 void launch_ord_self_rows(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *offsets, impg_gpu_interval_t *rows,
                           hipStream_t s) {

@@ -56,7 +56,7 @@ void launch_lookup_count(const DeviceIndexView &v, const FrontierRec *fr, uint32
                          FrontierRec *se = nullptr /* by_place: the ranges' records at their places (the projection reads the ends there) */,
                          uint32_t *cnt_ref = nullptr /* by_place: the counts in FRONTIER order too (ordered rows) */);
 // visit position of every hit of the windows of <= 64 entries, by place: vpos[pair_off[i] + k] for range i's k-th hit in index order
-// (dest: the ranges' first rows computed by the same kernel -- launch_ord_dest_by_place's arguments)
+// (dest: the ranges' first rows, computed by the same kernel: dest[place] = offsets[query] + lvbase[query] + slot_ref[range])
 struct OrdDestArgs { const FrontierRec *frp; const uint32_t *perm, *slot_ref, *offsets, *lvbase; uint32_t *dest; };
 void launch_emit_vpos(const DeviceIndexView &v, uint32_t n, const uint32_t *pair_off, const uint4 *win, uint8_t *vpos, hipStream_t s, bool by_visit = false,
                       const OrdDestArgs *dest = nullptr);
@@ -65,8 +65,6 @@ void launch_ord_self_count(const FrontierRec *self, const impg_gpu_range_t *rang
 // qbase[q] = slot_ref of the first record with qidx >= q (total beyond the last); lvbase[q] = acc[q] - qbase[q]; acc[q] += the query's slots
 void launch_ord_level_bases(const FrontierRec *fr, uint32_t n_fr, const uint32_t *slot_ref, uint32_t total, uint32_t n_queries, uint32_t *acc,
                             uint32_t *lvbase, hipStream_t s);
-void launch_ord_dest_by_place(const FrontierRec *frp, const uint32_t *perm, uint32_t n_fr, const uint32_t *slot_ref, const uint32_t *offsets,
-                              const uint32_t *lvbase, uint32_t *dest, hipStream_t s);
 void launch_ord_self_rows(const FrontierRec *self, const impg_gpu_range_t *ranges, uint32_t n, const uint32_t *offsets, impg_gpu_interval_t *rows,
                           hipStream_t s);
 void launch_ord_run_heads(const uint32_t *pair_range, uint32_t n_pairs, uint32_t *run_start, hipStream_t s);

@@ -1135,8 +1135,9 @@ void Engine::run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges,
     if (alive) {
       head.reserve((size_t)n_stack * 4); gid.reserve((size_t)n_stack * 4);
       d_flag2.reserve((size_t)n_stack * 4); d_pos2.reserve((size_t)n_stack * 4);
+      d_popsel.reserve(std::max<size_t>((size_t)n * 4, 256));
       launch_dfs_pop_flags(dk_a.as<unsigned long long>(), dd_a.as<uint32_t>(), n_stack, p.max_depth, multi && !p.dfs, head.as<uint32_t>(),
-                           d_flag2.as<uint32_t>(), d_popdepth.as<uint32_t>(), stream);
+                           d_flag2.as<uint32_t>(), d_popdepth.as<uint32_t>(), d_popsel.as<uint32_t>(), n, stream);
       n_fr = (uint32_t)scan(head.as<uint32_t>(), gid.as<uint32_t>(), n_stack);
       n_keep = (uint32_t)scan(d_flag2.as<uint32_t>(), d_pos2.as<uint32_t>(), n_stack);
       frontier_b.reserve(std::max<size_t>((size_t)n_fr * sizeof(FrontierRec), 256));

@@ -171,7 +171,7 @@ struct Engine {
   VisitedTables tables_view() const;
   void compact_tables();   // fold all visited tables into one
   // scratch of the DFS driver / table compaction
-  DevBuf dk_a, dk_b, ds_a, ds_b, de_a, de_b, dd_a, dd_b, d_flag2, d_pos2, d_popdepth, d_perm, d_perm2, d_k32, d_k32b,
+  DevBuf dk_a, dk_b, ds_a, ds_b, de_a, de_b, dd_a, dd_b, d_flag2, d_pos2, d_popdepth, d_popsel, d_perm, d_perm2, d_k32, d_k32b,
       d_src, d_src2, d_ckey, d_ckey2;
   void run_dfs(const impg_gpu_index &ix, const impg_gpu_range_t *d_ranges, uint32_t n, const impg_gpu_params_t &p,
                std::vector<std::unique_ptr<LevelBufs>> *keep, unsigned long long *d_count, unsigned long long *d_cksum,

@@ -4910,23 +4910,37 @@ __global__ __launch_bounds__(256) void frontier_to_stack_kernel(const FrontierRe
   en[i] = f.end;
   depth[i] = use_depth ? pop_depth[f.qidx] + 1u : 0u;  // impg.rs:2277 pushes current_depth + 1
 }
-// the last record of a query's segment is its stack top (impg.rs:2117-2122)
+// A round's pop (impg.rs:2117-2127; MultiImpg's FIFO worklist pops the first record, multi_impg.rs:849-854).  The record at the
+// query's end of the stack is popped; one that is too deep to be explored is dropped without anything else happening (the
+// reference's `continue` comes before the re-sort), and so is the next -- so a round takes every too-deep record off that end
+// and explores the first one that is not (round 6: one such record a round made a lone MultiImpg -m 3 call 20 000 rounds of
+// which 834 explored anything, 1.26 s).  pop_sel[q]: back = 1 + the index of the query's LAST explorable record (0: none),
+// front = the index of its FIRST (0xFFFFFFFF: none) -- set by dfs_pop_select_kernel, the launcher clears it.
+__global__ __launch_bounds__(256) void dfs_pop_select_kernel(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ depth, uint32_t n,
+                                                             uint32_t max_depth, int pop_front, uint32_t *__restrict__ pop_sel) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  if (max_depth > 0 && depth[i] >= max_depth) return;
+  const uint32_t q = (uint32_t)(key[i] >> 32);
+  if (pop_front) atomicMin(&pop_sel[q], i); else atomicMax(&pop_sel[q], i + 1u);
+}
 __global__ __launch_bounds__(256) void dfs_pop_flags_kernel(const unsigned long long *__restrict__ key,
-                                                            const uint32_t *__restrict__ depth, uint32_t n,
-                                                            uint32_t max_depth, int pop_front,
+                                                            const uint32_t *__restrict__ depth, uint32_t n, int pop_front,
+                                                            const uint32_t *__restrict__ pop_sel,
                                                             uint32_t *__restrict__ fr_flag,
                                                             uint32_t *__restrict__ keep_flag,
                                                             uint32_t *__restrict__ pop_depth) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const uint32_t q = (uint32_t)(key[i] >> 32);
-  // stack top = last record of the query's run; MultiImpg's FIFO worklist pops the first (multi_impg.rs:849-854)
-  const bool last = pop_front ? (i == 0 || (uint32_t)(key[i - 1] >> 32) != q)
-                              : ((i + 1 == n) || ((uint32_t)(key[i + 1] >> 32) != q));
-  const uint32_t d = depth[i];
-  keep_flag[i] = last ? 0u : 1u;
-  fr_flag[i] = (last && !(max_depth > 0 && d >= max_depth)) ? 1u : 0u;  // impg.rs:2125: too deep -> popped, not explored
-  if (last) pop_depth[q] = d;
+  const uint32_t sel = pop_sel[q];
+  // (no explorable record: the whole run is popped and dropped)
+  const bool have = pop_front ? sel != 0xFFFFFFFFu : sel != 0u;
+  const uint32_t x = pop_front ? sel : sel - 1u;  // the explored record
+  const bool explored = have && i == x;
+  keep_flag[i] = have && (pop_front ? i > x : i < x) ? 1u : 0u;
+  fr_flag[i] = explored ? 1u : 0u;
+  if (explored) pop_depth[q] = depth[i];
 }
 __global__ __launch_bounds__(256) void dfs_pop_scatter_kernel(const unsigned long long *__restrict__ key,
                                                               const int32_t *__restrict__ st, const int32_t *__restrict__ en,
@@ -5706,9 +5720,12 @@ void launch_frontier_to_stack(const FrontierRec *fr, uint32_t n, const uint32_t 
   frontier_to_stack_kernel<<<cdiv(n, 256), 256, 0, s>>>(fr, n, pop_depth, use_depth ? 1 : 0, key, st, en, depth);
 }
 void launch_dfs_pop_flags(const unsigned long long *key, const uint32_t *depth, uint32_t n, uint32_t max_depth,
-                          bool pop_front, uint32_t *fr_flag, uint32_t *keep_flag, uint32_t *pop_depth, hipStream_t s) {
+                          bool pop_front, uint32_t *fr_flag, uint32_t *keep_flag, uint32_t *pop_depth, uint32_t *pop_sel, uint32_t n_queries,
+                          hipStream_t s) {
   if (!n) return;
-  dfs_pop_flags_kernel<<<cdiv(n, 256), 256, 0, s>>>(key, depth, n, max_depth, pop_front ? 1 : 0, fr_flag, keep_flag, pop_depth);
+  IMPG_HIP(hipMemsetAsync(pop_sel, pop_front ? 0xFF : 0x00, (size_t)n_queries * 4, s));
+  dfs_pop_select_kernel<<<cdiv(n, 256), 256, 0, s>>>(key, depth, n, max_depth, pop_front ? 1 : 0, pop_sel);
+  dfs_pop_flags_kernel<<<cdiv(n, 256), 256, 0, s>>>(key, depth, n, pop_front ? 1 : 0, pop_sel, fr_flag, keep_flag, pop_depth);
 }
 void launch_sort5(const FrontierRec *fr, uint32_t n, const uint32_t *pair_off, uint32_t n_pairs, HitArrays h,
                   const uint32_t *pair_entry, const uint32_t *mrank, uint32_t *dest, hipStream_t s) {

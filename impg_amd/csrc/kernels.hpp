@@ -222,7 +222,8 @@ void launch_ranges_to_frontier(const impg_gpu_range_t *ranges, uint32_t n, Front
 void launch_frontier_to_stack(const FrontierRec *fr, uint32_t n, const uint32_t *pop_depth, bool use_depth,
                               unsigned long long *key, int32_t *st, int32_t *en, uint32_t *depth, hipStream_t s);
 void launch_dfs_pop_flags(const unsigned long long *key, const uint32_t *depth, uint32_t n, uint32_t max_depth,
-                          bool pop_front, uint32_t *fr_flag, uint32_t *keep_flag, uint32_t *pop_depth, hipStream_t s);
+                          bool pop_front, uint32_t *fr_flag, uint32_t *keep_flag, uint32_t *pop_depth, uint32_t *pop_sel /* n_queries words of scratch */,
+                          uint32_t n_queries, hipStream_t s);
 void launch_dfs_pop_scatter(const unsigned long long *key, const int32_t *st, const int32_t *en, const uint32_t *depth,
                             uint32_t n, const uint32_t *fr_flag, const uint32_t *fr_pos, const uint32_t *keep_flag,
                             const uint32_t *keep_pos, FrontierRec *fr_out, unsigned long long *key_out, int32_t *st_out,
